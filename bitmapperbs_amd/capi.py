@@ -1,0 +1,113 @@
+"""ctypes binding of the C-ABI in include/bmbs.h (libbmbs_hip.so, built in-tree by
+``__graft_entry__.build()`` / ``make -C bitmapperbs_amd/csrc``).
+
+The library is the product: if it is missing or cannot create a context on a HIP device the calls
+raise -- there is no Python/CPU fallback for any stage.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbmbs_hip.so")
+
+# every symbol include/bmbs.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "bmbs_default_params", "bmbs_create", "bmbs_destroy", "bmbs_last_error", "bmbs_index_attach",
+    "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se", "bmbs_map_se_device",
+    "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
+    "bmbs_counters_last", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
+    "bmbs_index_file_free", "bmbs_index_build",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("e_f", C.c_double), ("mp_max", C.c_int32), ("mp_min", C.c_int32), ("np", C.c_int32),
+                ("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("q_base", C.c_int32),
+                ("seed_len", C.c_int32), ("min_ins", C.c_int32), ("max_ins", C.c_int32),
+                ("sensitive", C.c_int32), ("reserved", C.c_int32)]
+
+
+class IndexView(C.Structure):
+    _fields_ = [("ref_len", C.c_uint64), ("pac", C.c_void_p), ("pac_bytes", C.c_uint64),
+                ("sa_length", C.c_uint64), ("shapline", C.c_uint64), ("nacgt", C.c_uint64 * 5),
+                ("bwt", C.c_void_p), ("bwt_words", C.c_uint64), ("high_occ", C.c_void_p),
+                ("high_occ_words", C.c_uint64), ("hash_hi", C.c_void_p), ("hash_lo", C.c_void_p),
+                ("hash_entries", C.c_uint64), ("sa", C.c_void_p), ("sa_entries", C.c_uint64),
+                ("sa_flag", C.c_void_p), ("sa_flag_words", C.c_uint64), ("n_chrom", C.c_int32),
+                ("chrom_len", C.c_void_p)]
+
+
+# numpy view of bmbs_result (32 bytes)
+RESULT_DTYPE = np.dtype([("pos", "<u8"), ("cigar_off", "<u4"), ("chrom", "<i2"), ("status", "u1"),
+                         ("mapq", "u1"), ("flag", "<u2"), ("nm", "<u2"), ("score", "<i2"),
+                         ("n_cigar", "u1"), ("path", "u1"), ("n_cand", "<u4"), ("reserved", "<u4")])
+assert RESULT_DTYPE.itemsize == 32
+
+ST_UNMAPPED, ST_UNIQUE, ST_AMBIG, ST_OFFEND = 0, 1, 2, 3
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libbmbs_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C bitmapperbs_amd/csrc` (the HIP library is mandatory, there is no CPU path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    L.bmbs_default_params.argtypes = [C.POINTER(Params)]
+    L.bmbs_default_params.restype = None
+    L.bmbs_create.argtypes = [C.c_int, C.POINTER(Params)]
+    L.bmbs_create.restype = vp
+    L.bmbs_destroy.argtypes = [vp]
+    L.bmbs_destroy.restype = None
+    L.bmbs_last_error.argtypes = [vp]
+    L.bmbs_last_error.restype = C.c_char_p
+    L.bmbs_index_attach.argtypes = [vp, C.POINTER(IndexView)]
+    L.bmbs_filter_batch.argtypes = [vp, vp, i32, i32, i64, vp, vp, i64, vp, vp]
+    L.bmbs_align_batch.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i32]
+    L.bmbs_seed_batch.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
+    L.bmbs_map_se.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]
+    L.bmbs_map_se_device.argtypes = [vp, u64, u64, i32, i32, i64, u64, u64, i64]
+    L.bmbs_sync.argtypes = [vp]
+    L.bmbs_stats_get.argtypes = [vp, vp]
+    L.bmbs_stats_reset.argtypes = [vp]
+    L.bmbs_stats_allreduce.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.bmbs_profile_last.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.bmbs_counters_last.argtypes = [vp, vp]
+    L.bmbs_index_file_load.argtypes = [C.c_char_p]
+    L.bmbs_index_file_load.restype = vp
+    L.bmbs_index_file_view.argtypes = [vp, C.POINTER(IndexView)]
+    L.bmbs_index_file_view.restype = None
+    L.bmbs_index_file_chrom_name.argtypes = [vp, C.c_int]
+    L.bmbs_index_file_chrom_name.restype = C.c_char_p
+    L.bmbs_index_file_free.argtypes = [vp]
+    L.bmbs_index_file_free.restype = None
+    L.bmbs_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    for name in ("bmbs_index_attach", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se",
+                 "bmbs_map_se_device", "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce",
+                 "bmbs_profile_last", "bmbs_counters_last", "bmbs_index_build"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().bmbs_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def ptr(a: np.ndarray) -> int:
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data

@@ -1,0 +1,596 @@
+// bitmapperbs_amd/csrc/bmbs_api.hip -- C-ABI (include/bmbs.h) over the gfx950 kernels.
+// Owns the device buffers, the stream, the HIP-event profile and the per-ctx counters.  There is no
+// CPU fallback anywhere in this library: without a HIP device every entry point fails with
+// BMBS_ENODEV.
+#include "../../include/bmbs.h"
+#include "bmbs_kernels.hip"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Prof { const char* name; hipEvent_t a, b; bool used; };
+
+}  // namespace
+
+struct bmbs_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    bmbs_params prm;
+    ScoreParams sp;
+    std::string err;
+    bool attached = false;
+    DevIndex ix;
+    u64 rows = 0;
+    // index buffers
+    DevBuf occ, hash, sa, gen2, chrom_start;
+    // LUTs
+    DevBuf pen_lut, mapq_lut;
+    int mapq_k = -1, mapq_range = 0;
+    // per-read workspace
+    DevBuf verdict, n_seeds, multi, mm_site, exit_site, seeds, n_cand, cand_off, n_votes, best_site,
+        best_end, best_err, sbd, red_status, job_flag, job_off, scan_tmp, totals;
+    // per-candidate / per-job workspace
+    DevBuf cand, votes, slot_read, ferr, fend, job_read, H, E, z, a_start, a_end, a_nm, a_score, a_nops;
+    // host-variant staging
+    DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d;
+    DevBuf stats, counters;
+    std::vector<Prof> prof;
+    int n_prof_used = 0;
+    u64 last_total_cand = 0, last_n_jobs = 0;
+    int last_max_ops = 0;
+    u64 h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+#define HIPCHK(c, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                 \
+            return BMBS_ENODEV;                                                                           \
+        }                                                                                                 \
+    } while (0)
+
+int ensure(bmbs_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return BMBS_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); b.p = nullptr; return BMBS_ENOMEM; }
+    b.cap = want;
+    return BMBS_OK;
+}
+void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+#define ENS(c, buf, bytes) do { int rc_ = ensure((c), (buf), (bytes)); if (rc_) return rc_; } while (0)
+
+inline unsigned nblk(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+void prof_begin(bmbs_ctx* c, const char* name)
+{
+    if ((size_t)c->n_prof_used == c->prof.size()) {
+        Prof p; p.name = name; p.used = false;
+        (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b);
+        c->prof.push_back(p);
+    }
+    Prof& p = c->prof[c->n_prof_used];
+    p.name = name; p.used = true;
+    (void)hipEventRecord(p.a, c->stream);
+}
+void prof_end(bmbs_ctx* c) { (void)hipEventRecord(c->prof[c->n_prof_used].b, c->stream); c->n_prof_used++; }
+
+// exclusive scan u32[n] -> u64[n+1], total left in c->totals[slot]
+int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot)
+{
+    const u64 per = (u64)SCAN_BLOCK * SCAN_ITEMS;
+    const u64 nb = (n + per - 1) / per;
+    ENS(c, c->scan_tmp, (nb + 1) * 8);
+    u64* bs = c->scan_tmp.as<u64>();
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, bs, nb, c->totals.as<u64>() + slot);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out);
+    return BMBS_OK;
+}
+
+// MismatchPenaltyByQuality (ksw.h:148-161), evaluated here in IEEE double exactly as the reference
+int mismatch_penalty(const bmbs_params& P, int Q)
+{
+    double Phred = Q - P.q_base;
+    if (Phred > 40) Phred = 40;
+    Phred = Phred / 40;
+    int r = Phred * (P.mp_max - P.mp_min);
+    return r + P.mp_min;
+}
+
+// MAP_Calculation (Schema.cpp:168-405) in the reference's double arithmetic; tabulated per k
+int map_calculation(const bmbs_params& P, unsigned second_best_diff, unsigned error_threshold, int best_score)
+{
+    int scoreMax = P.gap_open + P.gap_ext;
+    if (scoreMax < P.mp_max) scoreMax = P.mp_max;
+    scoreMax = -scoreMax * error_threshold;
+    int scoreMaxRange = -scoreMax;
+    int score_diff = best_score - scoreMax;
+    if (score_diff < 0) score_diff = 0;
+    int error_diff = second_best_diff;
+    if (second_best_diff > error_threshold) error_diff = error_threshold + 1;
+    double rank, rank_error;
+    if ((unsigned)error_diff > error_threshold) {
+        rank = (double)score_diff / (double)scoreMaxRange;
+        if (rank >= 0.8) return 42;
+        if (rank >= 0.7) return 40;
+        if (rank >= 0.6) return 24;
+        if (rank >= 0.5) return 23;
+        if (rank >= 0.4) return 8;
+        if (rank >= 0.3) return 3;
+        return 0;
+    }
+    rank_error = (double)error_diff / (double)error_threshold;
+    rank = (double)score_diff / (double)scoreMaxRange;
+    const bool z = best_score == 0;
+    if (rank_error >= 0.9) return z ? 39 : 33;
+    if (rank_error >= 0.8) return z ? 38 : 27;
+    if (rank_error >= 0.7) return z ? 37 : 26;
+    if (rank_error >= 0.6) return z ? 36 : 22;
+    if (rank_error >= 0.5) return z ? 35 : rank >= 0.84 ? 25 : rank >= 0.68 ? 16 : 5;
+    if (rank_error >= 0.4) return z ? 34 : rank >= 0.84 ? 21 : rank >= 0.68 ? 14 : 4;
+    if (rank_error >= 0.3) return z ? 32 : rank >= 0.88 ? 18 : rank >= 0.67 ? 15 : 3;
+    if (rank_error >= 0.2) return z ? 31 : rank >= 0.88 ? 17 : rank >= 0.67 ? 11 : 0;
+    if (rank_error >= 0.1) return z ? 30 : rank >= 0.88 ? 12 : rank >= 0.67 ? 7 : 0;
+    if (error_diff == 0) return rank >= 0.67 ? 1 : 0;
+    return rank >= 0.67 ? 6 : 2;
+}
+
+int threshold_k(const bmbs_params& P, int L)
+{
+    u64 k = (u64)(P.e_f * L);            // error_threshold1 = thread_e_f * length (Schema.cpp:24546)
+    if (k >= 31) k = 31;
+    return (int)k;
+}
+
+int prepare_luts(bmbs_ctx* c, int k)
+{
+    if (c->mapq_k == k) return BMBS_OK;
+    int unit = c->prm.gap_open + c->prm.gap_ext;
+    if (unit < c->prm.mp_max) unit = c->prm.mp_max;
+    const int range = unit * k;
+    std::vector<u8> lut((size_t)(k + 2) * (range + 1));
+    for (int ed = 0; ed <= k + 1; ed++)
+        for (int sd = 0; sd <= range; sd++)
+            lut[(size_t)ed * (range + 1) + sd] = (u8)map_calculation(c->prm, (unsigned)ed, (unsigned)k, sd - range);
+    ENS(c, c->mapq_lut, lut.size());
+    HIPCHK(c, hipMemcpyAsync(c->mapq_lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->mapq_k = k; c->mapq_range = range;
+    return BMBS_OK;
+}
+
+int per_read_workspace(bmbs_ctx* c, u64 n)
+{
+    ENS(c, c->verdict, n); ENS(c, c->n_seeds, n); ENS(c, c->multi, n); ENS(c, c->mm_site, n * 2);
+    ENS(c, c->exit_site, n * 8); ENS(c, c->seeds, n * BMBS_MAX_SEEDS * sizeof(SeedRec));
+    ENS(c, c->n_cand, n * 4); ENS(c, c->cand_off, (n + 1) * 8); ENS(c, c->n_votes, n * 4);
+    ENS(c, c->best_site, n * 8); ENS(c, c->best_end, n * 4); ENS(c, c->best_err, n * 4); ENS(c, c->sbd, n * 4);
+    ENS(c, c->red_status, n); ENS(c, c->job_flag, n * 4); ENS(c, c->job_off, (n + 1) * 8);
+    return BMBS_OK;
+}
+
+ReadState read_state(bmbs_ctx* c)
+{
+    ReadState s;
+    s.verdict = c->verdict.as<u8>(); s.n_seeds = c->n_seeds.as<u8>(); s.multi = c->multi.as<u8>();
+    s.mm_site = c->mm_site.as<u16>(); s.exit_site = c->exit_site.as<u64>(); s.seeds = c->seeds.as<SeedRec>();
+    s.n_cand = c->n_cand.as<u32>(); s.cand_off = c->cand_off.as<u64>(); s.n_votes = c->n_votes.as<u32>();
+    s.best_site = c->best_site.as<u64>(); s.best_end = c->best_end.as<int32_t>(); s.best_err = c->best_err.as<u32>();
+    s.sbd = c->sbd.as<u32>(); s.red_status = c->red_status.as<u8>(); s.job_flag = c->job_flag.as<u32>();
+    s.job_off = c->job_off.as<u64>();
+    return s;
+}
+
+int align_scratch(bmbs_ctx* c, u64 n_jobs, int L, int k, AlignScratch& sc)
+{
+    const u64 nj = n_jobs ? n_jobs : 1;
+    const u64 qlen = (u64)L + 2 * k;
+    ENS(c, c->H, (qlen + 2) * nj * 4); ENS(c, c->E, (qlen + 2) * nj * 4);
+    ENS(c, c->z, (u64)(2 * k + 1) * L * nj);
+    ENS(c, c->a_start, nj * 4); ENS(c, c->a_end, nj * 4); ENS(c, c->a_nm, nj * 4); ENS(c, c->a_score, nj * 4); ENS(c, c->a_nops, nj * 4);
+    sc.H = c->H.as<int>(); sc.E = c->E.as<int>(); sc.z = c->z.as<u8>(); sc.n_jobs = nj;
+    return BMBS_OK;
+}
+
+// stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
+int run_seed_stages(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int k, u64* total_cand)
+{
+    ReadState st = read_state(c);
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    prof_begin(c, "k_seed");
+    hipLaunchKernelGGL(k_seed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+                       c->prm.seed_len, st, cnt);
+    prof_end(c);
+    prof_begin(c, "scan_cand");
+    int rc = scan_u32(c, st.n_cand, n, st.cand_off, 0);
+    if (rc) return rc;
+    prof_end(c);
+    u64 tot = 0;
+    HIPCHK(c, hipMemcpyAsync(&tot, c->totals.as<u64>(), 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *total_cand = tot;
+    const u64 t1 = tot ? tot : 1;
+    ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(bmbs_vote)); ENS(c, c->slot_read, t1 * 4);
+    ENS(c, c->ferr, t1 * 4); ENS(c, c->fend, t1 * 4);
+    if (tot) {
+        prof_begin(c, "k_locate");
+        hipLaunchKernelGGL(k_locate, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, (long)n, tot, st, c->cand.as<u64>());
+        prof_end(c);
+    }
+    prof_begin(c, "k_vote");
+    hipLaunchKernelGGL(k_vote, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, k, st, c->cand.as<u64>(),
+                       c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
+    prof_end(c);
+    return BMBS_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" void bmbs_default_params(bmbs_params* p)
+{
+    p->e_f = 0.08; p->mp_max = 6; p->mp_min = 2; p->np = 1; p->gap_open = 5; p->gap_ext = 3; p->q_base = 33;
+    p->seed_len = 30; p->min_ins = 0; p->max_ins = 500; p->sensitive = 0; p->reserved = 0;
+}
+
+extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    bmbs_ctx* c = new bmbs_ctx();
+    c->dev = device_id;
+    if (params) c->prm = *params; else bmbs_default_params(&c->prm);
+    c->sp.mp_max = c->prm.mp_max; c->sp.mp_min = c->prm.mp_min; c->sp.np = c->prm.np;
+    c->sp.gap_open = c->prm.gap_open; c->sp.gap_ext = c->prm.gap_ext; c->sp.q_base = c->prm.q_base;
+    c->sp.seed_len = c->prm.seed_len;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
+    int lut[256];
+    for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
+    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, 5 * 8) || ensure(c, c->counters, 8 * 8) ||
+        ensure(c, c->totals, 4 * 8)) { bmbs_destroy(c); return nullptr; }
+    (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
+    (void)hipMemset(c->stats.p, 0, 5 * 8);
+    (void)hipMemset(c->counters.p, 0, 8 * 8);
+    return c;
+}
+
+extern "C" void bmbs_destroy(bmbs_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->pen_lut, &c->mapq_lut, &c->verdict,
+                     &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
+                     &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
+                     &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->ferr, &c->fend,
+                     &c->job_read, &c->H, &c->E, &c->z, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
+                     &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
+                     &c->stats, &c->counters};
+    for (DevBuf* b : all) release(*b);
+    for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* bmbs_last_error(const bmbs_ctx* c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
+
+extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
+{
+    if (!c || !v) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 G = v->ref_len, n = 2 * G, rows = n + 1;
+    if (v->sa_length != rows) { c->err = "index view: sa_length != 2*ref_len + 1"; return BMBS_EINVAL; }
+    if (rows >= (1ull << 32)) { c->err = "genome too large for the 32-bit suffix array of this build"; return BMBS_EINVAL; }
+    // upload the reference layouts verbatim, re-pack on the device, drop the originals
+    DevBuf t_bwt, t_ho, t_hh, t_hl, t_sa, t_fl, t_pac;
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        int rc = ensure(c, b, bytes + 64);
+        if (rc) return rc;
+        if (hipMemsetAsync(b.p, 0, b.cap, c->stream) != hipSuccess) return BMBS_ENODEV;
+        if (hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return BMBS_ENODEV;
+        return BMBS_OK;
+    };
+    int rc = 0;
+    rc |= up(t_bwt, v->bwt, v->bwt_words * 8);
+    rc |= up(t_ho, v->high_occ, v->high_occ_words * 8);
+    rc |= up(t_hh, v->hash_hi, v->hash_entries * 4);
+    rc |= up(t_hl, v->hash_lo, v->hash_entries);
+    rc |= up(t_sa, v->sa, v->sa_entries * 4);
+    rc |= up(t_fl, v->sa_flag, v->sa_flag_words * 8);
+    rc |= up(t_pac, v->pac, v->pac_bytes);
+    auto drop = [&]() { release(t_bwt); release(t_ho); release(t_hh); release(t_hl); release(t_sa); release(t_fl); release(t_pac); };
+    if (rc) { drop(); c->err = "index upload failed"; return BMBS_ENOMEM; }
+    RefIndexDev R;
+    R.bwt = t_bwt.as<u64>(); R.high_occ = t_ho.as<u64>(); R.hash_hi = t_hh.as<u32>(); R.hash_lo = t_hl.as<u8>();
+    R.sa = t_sa.as<u32>(); R.sa_flag = t_fl.as<u64>(); R.pac = t_pac.as<u8>();
+    const u64 n_blk = n / 192 + 1;
+    const u64 gen_words = (n + 31) / 32 + 2;
+    std::vector<u64> cs(v->n_chrom + 1, 0);
+    for (int i = 0; i < v->n_chrom; i++) cs[i + 1] = cs[i] + v->chrom_len[i];
+    if (ensure(c, c->occ, n_blk * 64) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * 4) ||
+        ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8)) { drop(); return BMBS_ENOMEM; }
+    HIPCHK(c, hipMemcpyAsync(c->chrom_start.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, c->occ.as<u64>());
+    hipLaunchKernelGGL(k_repack_hash, dim3(nblk(v->hash_entries, 256)), dim3(256), 0, c->stream, R, v->hash_entries, c->hash.as<u64>());
+    hipLaunchKernelGGL(k_build_gen2, dim3(nblk(gen_words, 256)), dim3(256), 0, c->stream, R, G, gen_words, c->gen2.as<u64>());
+    DevIndex ix;
+    ix.occ = c->occ.as<uint4>(); ix.hash = c->hash.as<u64>(); ix.sa = c->sa.as<u32>(); ix.gen2 = c->gen2.as<u64>();
+    ix.chrom_start = c->chrom_start.as<u64>(); ix.G = G; ix.total = n; ix.shapline = v->shapline;
+    ix.C[0] = v->nacgt[0]; ix.C[1] = v->nacgt[1]; ix.C[2] = v->nacgt[2]; ix.n_chrom = v->n_chrom;
+    hipLaunchKernelGGL(k_expand_sa, dim3(nblk(rows, 256)), dim3(256), 0, c->stream, ix, R, rows, c->sa.as<u32>());
+    hipError_t e = hipStreamSynchronize(c->stream);
+    drop();
+    if (e != hipSuccess) { c->err = std::string("index re-pack: ") + hipGetErrorString(e); return BMBS_ENODEV; }
+    c->ix = ix; c->rows = rows; c->attached = true;
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_sync(bmbs_ctx* c)
+{
+    if (!c) return BMBS_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMBS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, int32_t L, int32_t stride,
+                                  int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+{
+    if (!c) return BMBS_EINVAL;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    const char* d_seq = reinterpret_cast<const char*>(d_seq_);
+    const char* d_qual = reinterpret_cast<const char*>(d_qual_);
+    const u64 n = (u64)n_reads;
+    c->n_prof_used = 0;
+    if (n == 0) return BMBS_OK;
+    const int k = threshold_k(c->prm, L);
+    int rc = prepare_luts(c, k);
+    if (rc) return rc;
+    rc = per_read_workspace(c, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * 8, c->stream));
+    ReadState st = read_state(c);
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    u64 tot = 0;
+    rc = run_seed_stages(c, d_seq, L, stride, n, k, &tot);
+    if (rc) return rc;
+    c->last_total_cand = tot;
+    if (tot) {
+        prof_begin(c, "k_filter");
+        hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, k, tot,
+                           c->slot_read.as<u32>(), c->votes.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), cnt);
+        prof_end(c);
+    }
+    prof_begin(c, "k_reduce");
+    hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, c->votes.as<bmbs_vote>(),
+                       c->ferr.as<u32>(), c->fend.as<int>());
+    prof_end(c);
+    prof_begin(c, "scan_jobs");
+    rc = scan_u32(c, st.job_flag, n, st.job_off, 1);
+    if (rc) return rc;
+    prof_end(c);
+    u64 n_jobs = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_n_jobs = n_jobs;
+    const int max_ops = 2 * k + 8;
+    c->last_max_ops = max_ops;
+    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small"; return BMBS_ENOMEM; }
+    AlignScratch sc;
+    rc = align_scratch(c, n_jobs, L, k, sc);
+    if (rc) return rc;
+    ENS(c, c->job_read, (n_jobs ? n_jobs : 1) * 4);
+    if (n_jobs) {
+        prof_begin(c, "k_job_list");
+        hipLaunchKernelGGL(k_job_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, c->job_read.as<u32>());
+        prof_end(c);
+        prof_begin(c, "k_align");
+        hipLaunchKernelGGL(k_align, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
+                           d_seq, d_qual, L, stride, k, n_jobs, c->job_read.as<u32>(), st, sc,
+                           reinterpret_cast<u32*>(d_cigar_pool), max_ops, c->a_start.as<int>(), c->a_end.as<int>(),
+                           c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), cnt);
+        prof_end(c);
+    }
+    prof_begin(c, "k_finalize");
+    hipLaunchKernelGGL(k_finalize, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
+                       c->mapq_lut.as<u8>(), c->mapq_range, d_seq, d_qual, L, stride, k, (long)n, st, c->a_start.as<int>(),
+                       c->a_end.as<int>(), c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), max_ops,
+                       reinterpret_cast<bmbs_result_dev*>(d_results), c->stats.as<unsigned long long>());
+    prof_end(c);
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
+                           bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (!c) return BMBS_EINVAL;
+    static_assert(sizeof(bmbs_result) == 32 && sizeof(bmbs_result_dev) == 32, "result record is 32 bytes");
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 n = (u64)n_reads, bytes = n * (u64)stride;
+    if (n_cigar_used) *n_cigar_used = 0;
+    if (n == 0) return BMBS_OK;
+    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_qual, bytes + 64); ENS(c, c->out_res, n * 32);
+    const int k = threshold_k(c->prm, L);
+    const u64 pool = n * (u64)(2 * k + 8);           // worst case: every read needs K12
+    ENS(c, c->cig_pool, pool * 4);
+    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_qual.p, qual, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = bmbs_map_se_device(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, L, stride, n_reads,
+                                (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+    const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
+    if (used > (u64)cigar_cap) { c->err = "host cigar pool too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
+    if (used) HIPCHK(c, hipMemcpyAsync(cigar_pool, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_cigar_used) *n_cigar_used = (int64_t)used;
+    return BMBS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int bmbs_filter_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
+                                 const uint32_t* read_of, const uint64_t* site, int64_t n_cand, uint32_t* err,
+                                 int32_t* end_site)
+{
+    if (!c) return BMBS_EINVAL;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (n_cand <= 0) return BMBS_OK;
+    const u64 bytes = (u64)n_reads * stride, m = (u64)n_cand;
+    const int k = threshold_k(c->prm, L);
+    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->ferr, m * 4); ENS(c, c->fend, m * 4);
+    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_a.p, read_of, m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_b.p, site, m * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_filter_pairs, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_seq.as<char>(), L, stride, k, m,
+                       c->in_a.as<u32>(), c->in_b.as<u64>(), c->ferr.as<u32>(), c->fend.as<int>());
+    HIPCHK(c, hipMemcpyAsync(err, c->ferr.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(end_site, c->fend.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
+                                const uint32_t* read_of, const uint64_t* site, const int32_t* end_site_in,
+                                const uint32_t* err_in, int64_t n_jobs, int32_t* start_site, int32_t* end_site,
+                                uint32_t* nm, int32_t* score, uint32_t* cigar_ops, int32_t* n_ops, int32_t max_ops)
+{
+    if (!c) return BMBS_EINVAL;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (n_jobs <= 0) return BMBS_OK;
+    const u64 bytes = (u64)n_reads * stride, m = (u64)n_jobs;
+    const int k = threshold_k(c->prm, L);
+    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_qual, bytes + 64);
+    ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->in_c, m * 4); ENS(c, c->in_d, m * 4);
+    ENS(c, c->cig_pool, m * (u64)max_ops * 4);
+    AlignScratch sc;
+    int rc = align_scratch(c, m, L, k, sc);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_qual.p, qual, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_a.p, read_of, m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_b.p, site, m * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_c.p, end_site_in, m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_d.p, err_in, m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->cig_pool.p, 0, m * (u64)max_ops * 4, c->stream));
+    hipLaunchKernelGGL(k_align_pairs, dim3(nblk(m, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
+                       c->in_seq.as<char>(), c->in_qual.as<char>(), L, stride, k, m, c->in_a.as<u32>(), c->in_b.as<u64>(),
+                       c->in_c.as<int>(), c->in_d.as<u32>(), sc, c->cig_pool.as<u32>(), max_ops, c->a_start.as<int>(),
+                       c->a_end.as<int>(), c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>());
+    HIPCHK(c, hipMemcpyAsync(start_site, c->a_start.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(end_site, c->a_end.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nm, c->a_nm.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(score, c->a_score.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(n_ops, c->a_nops.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cigar_ops, c->cig_pool.p, m * (u64)max_ops * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads, uint8_t* verdict,
+                               uint64_t* exit_site, uint64_t* seg_off, uint32_t* n_votes, uint64_t* vote_site,
+                               uint32_t* vote_cnt, int64_t vote_cap, int64_t* total_slots)
+{
+    if (!c) return BMBS_EINVAL;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 n = (u64)n_reads, bytes = n * (u64)stride;
+    if (total_slots) *total_slots = 0;
+    if (n == 0) return BMBS_OK;
+    const int k = threshold_k(c->prm, L);
+    c->n_prof_used = 0;
+    int rc = per_read_workspace(c, n);
+    if (rc) return rc;
+    ENS(c, c->in_seq, bytes + 64);
+    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->exit_site.p, 0, n * 8, c->stream));
+    u64 tot = 0;
+    rc = run_seed_stages(c, c->in_seq.as<char>(), L, stride, n, k, &tot);
+    if (rc) return rc;
+    if (total_slots) *total_slots = (int64_t)tot;
+    if ((u64)vote_cap < tot) { c->err = "vote buffers too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
+    HIPCHK(c, hipMemcpyAsync(verdict, c->verdict.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(exit_site, c->exit_site.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(seg_off, c->cand_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(n_votes, c->n_votes.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<bmbs_vote> hv(tot ? tot : 1);
+    if (tot) HIPCHK(c, hipMemcpyAsync(hv.data(), c->votes.p, tot * sizeof(bmbs_vote), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (u64 i = 0; i < tot; i++) { vote_site[i] = hv[i].site; vote_cnt[i] = hv[i].vote; }
+    return BMBS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int bmbs_stats_get(bmbs_ctx* c, int64_t stats[5])
+{
+    if (!c) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(stats, c->stats.p, 5 * 8, hipMemcpyDeviceToHost));
+    return BMBS_OK;
+}
+extern "C" int bmbs_stats_reset(bmbs_ctx* c)
+{
+    if (!c) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipMemsetAsync(c->stats.p, 0, 5 * 8, c->stream));
+    return BMBS_OK;
+}
+extern "C" int bmbs_stats_allreduce(bmbs_ctx** ctxs, int n, int64_t stats[5])
+{
+    for (int j = 0; j < 5; j++) stats[j] = 0;
+    for (int i = 0; i < n; i++) {
+        int64_t s[5];
+        int rc = bmbs_stats_get(ctxs[i], s);
+        if (rc) return rc;
+        for (int j = 0; j < 5; j++) stats[j] += s[j];
+    }
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_profile_last(bmbs_ctx* c, const char** names, float* ms, int* n)
+{
+    if (!c || !n) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int cap = *n, cntp = 0;
+    for (int i = 0; i < c->n_prof_used && cntp < cap; i++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->prof[i].a, c->prof[i].b) != hipSuccess) t = -1.f;
+        names[cntp] = c->prof[i].name; ms[cntp] = t; cntp++;
+    }
+    *n = cntp;
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_counters_last(bmbs_ctx* c, uint64_t out[8])
+{
+    if (!c) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->counters.p, 8 * 8, hipMemcpyDeviceToHost));
+    out[6] = c->last_total_cand;
+    out[7] = c->last_n_jobs;
+    return BMBS_OK;
+}

@@ -1,0 +1,66 @@
+// bitmapperbs_amd/csrc/bmbs_dev.h -- device-side data layouts of the gfx950 mapping path.
+#ifndef BMBS_DEV_H
+#define BMBS_DEV_H
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef uint8_t u8;
+
+// ---- index as laid out in HBM ------------------------------------------------------------------
+// The reference streams 40-byte blocks (4 x 16-bit relative counters + two 64-symbol bit-plane
+// pairs) plus a 65 536-row super-block table, and keeps every 8th SA entry (bwt.h:1007-1136,
+// 2449-2560).  On MI355X the dependent random gather is what costs, and HBM capacity (288 GB) is not
+// a constraint, so the index is re-packed at attach time into:
+//   occ   : one 64-byte, 64-byte-aligned block per 192 BWT symbols =
+//           { u64 count(T) before the block, u64 count(A) before the block,
+//             3 x { u64 plane_T, u64 plane_A } }  (symbol j of a word = bit 63-j, as the reference)
+//           -> every rank query is exactly one aligned 64 B transaction, no second-level table;
+//   hash  : the 3^16+1 16-mer entries fused to one u64 each (36-bit row | gap nibble << 60), so a
+//           lookup (entries key, key+1) is one 16-byte read;
+//   sa    : the FULL suffix array (u32 per row), expanded once on the GPU from the sampled SA, so
+//           locate is one 4-byte read instead of <=7 dependent LF steps;
+//   gen2  : the doubled genome (forward ++ reverse complement) 2 bits/base, 32 bases per u64
+//           LSB-first (A0 C1 G2 T3), so both strands' windows are forward reads.
+struct DevIndex {
+    const uint4* occ;
+    const u64*   hash;
+    const u32*   sa;
+    const u64*   gen2;
+    const u64*   chrom_start;   // n_chrom+1 cumulative starts (single strand)
+    u64 G;                      // one-strand length
+    u64 total;                  // 2G = total_SA_length
+    u64 shapline;
+    u64 C[3];                   // nacgt[0..2]: first row of G / T / A suffixes
+    int n_chrom;
+};
+
+// one seed as recorded by the seeding kernel: SA interval [sp, sp+hits), seed length and read offset
+struct SeedRec { u64 sp; u32 hits; u16 len; u16 off; };
+#define BMBS_MAX_SEEDS 28
+
+// per-read state carried between the stage kernels (SoA arrays indexed by read)
+struct ReadState {
+    u8*   verdict;      // 0 none, 1 exit A, 2 exit C, 3 general, 4 exact-ambiguous
+    u8*   n_seeds;
+    u8*   multi;        // is_mutiple_map
+    u16*  mm_site;      // one_mismatch_site (exit C)
+    u64*  exit_site;    // site for exit A / C
+    SeedRec* seeds;     // [n][BMBS_MAX_SEEDS]
+    u32*  n_cand;       // candidates to locate (general path)
+    u64*  cand_off;     // exclusive scan of n_cand, n+1 entries
+    u32*  n_votes;
+    // reduction output
+    u64*  best_site;
+    int32_t* best_end;
+    u32*  best_err;
+    u32*  sbd;          // second_best_diff
+    u8*   red_status;   // 0 none, 1 unique, 2 ambiguous
+    u32*  job_flag;     // 1 if the winner needs K11-K13
+    u64*  job_off;      // exclusive scan of job_flag
+};
+
+struct ScoreParams {
+    int mp_max, mp_min, np, gap_open, gap_ext, q_base;
+    int seed_len;
+};
+#endif

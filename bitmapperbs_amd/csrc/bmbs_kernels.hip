@@ -1,0 +1,911 @@
+// bitmapperbs_amd/csrc/bmbs_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the
+// bisulfite mapping hot path.  Integer / bit work only: no MFMA, HBM-gather bound.
+//
+// Stage split (one kernel per work granularity, exclusive scans in between so that every kernel runs
+// dense lanes):
+//   k_seed      one read per lane   K1-K5 + the seeding state machine of Map_Single_Seq_end_to_end
+//   k_locate    one SA row per lane K5/K6 + reverse_and_adjust_site
+//   k_vote      one read per lane   a9/a10: sort, run-length votes, std::sort-exact vote order
+//   k_filter    one candidate/lane  K7+K8: window fetch + BS banded Myers (64-bit words)
+//   k_reduce    one read per lane   K9: ordered min / ambiguity / second_best_diff scan
+//   k_align     one winner per lane K11-K13: un-gapped recheck, banded affine SW + CIGAR + NM
+//   k_finalize  one read per lane   MAPQ LUT, doubled -> chromosome coordinates, off-end, stats
+#include "bmbs_dev.h"
+#include "bmbs_sort.h"
+
+#define DEVI __device__ __forceinline__
+
+// ================================================================================================
+// index primitives
+// ================================================================================================
+
+// rank of T and of A in BWT stream [0, line): one aligned 64-byte block (see bmbs_dev.h).
+// Replaces get_occ_value* + the popcount tail of find_occ_fm_index (bwt.h:1007-1136, 1373-1465).
+DEVI void occ_TA(const DevIndex& ix, u64 line, u64& cT, u64& cA)
+{
+    const u64 blk = line / 192u;
+    const int r = (int)(line - blk * 192u);
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(ix.occ) + blk * 4;
+    const ulonglong2 h = p[0], w0 = p[1], w1 = p[2], w2 = p[3];
+    auto mk = [](int take) -> u64 { return take <= 0 ? 0ull : (take >= 64 ? ~0ull : (~0ull << (64 - take))); };
+    const u64 m0 = mk(r), m1 = mk(r - 64), m2 = mk(r - 128);
+    cT = h.x + __popcll(w0.x & m0) + __popcll(w1.x & m1) + __popcll(w2.x & m2);
+    cA = h.y + __popcll(w0.y & m0) + __popcll(w1.y & m1) + __popcll(w2.y & m2);
+}
+
+// one LF / backward-extension step: nacgt[c] + Occ(c, row), '$' row removed (bwt.h:1373-1465)
+DEVI u64 lf_step(const DevIndex& ix, u64 row, int c)
+{
+    const u64 line = row - (row > ix.shapline ? 1 : 0);
+    u64 cT, cA;
+    occ_TA(ix, line, cT, cA);
+    const u64 cnt = c == 1 ? cT : (c == 2 ? cA : line - cT - cA);
+    return ix.C[c] + cnt;
+}
+
+// BWT symbol of a row (access_bwt_delta, bwt.h:2413-2447); only used while expanding the SA
+DEVI int bwt_sym(const DevIndex& ix, u64 row)
+{
+    const u64 line = row - (row > ix.shapline ? 1 : 0);
+    const u64 blk = line / 192u;
+    const int r = (int)(line - blk * 192u);
+    const u64* p = reinterpret_cast<const u64*>(ix.occ) + blk * 8 + 2 + 2 * (r >> 6);
+    const int sh = 63 - (r & 63);
+    if ((p[0] >> sh) & 1) return 1;
+    if ((p[1] >> sh) & 1) return 2;
+    return 0;
+}
+
+// query_16_mer_hash_table (bwt.h:284-306) on the fused entries
+DEVI void hash_lookup(const DevIndex& ix, u64 key, u64& sp, u64& ep)
+{
+    const u64 e0 = ix.hash[key], e1 = ix.hash[key + 1];
+    const u64 m36 = (1ull << 36) - 1;
+    sp = e0 & m36;
+    ep = (e1 & m36) - (e1 >> 60);
+}
+
+// base code (A0 C1 G2 T3) at doubled coordinate d
+DEVI int gbase(const DevIndex& ix, u64 d) { return (int)((ix.gen2[d >> 5] >> ((d & 31) * 2)) & 3); }
+
+// window validity: get_actuall_genome / get_actuall_rc_genome return an all-zero window when the
+// request leaves the strand (Schema.cpp:5013-5019, 5076-5084; u64 wrap-around as in the reference)
+DEVI bool window_valid(const DevIndex& ix, u64 start, u64 len, bool fwd_strand)
+{
+    return fwd_strand ? (start + len <= ix.G) : (start - ix.G + len <= ix.G && start - ix.G < ix.G);
+}
+
+// bisulfite 3-letter code of a read character after C->T: G0 T1 A2, anything else 4
+// (C_to_T_forward, Schema.h:1534; ctoi, bwt.cpp:2376-2381)
+DEVI int code3(char ch) { return ch == 'G' ? 0 : (ch == 'T' || ch == 'C') ? 1 : ch == 'A' ? 2 : 4; }
+DEVI int code4(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
+
+// ================================================================================================
+// attach-time re-pack kernels
+// ================================================================================================
+struct RefIndexDev {            // reference on-disk layouts, uploaded verbatim
+    const u64* bwt; const u64* high_occ; const u32* hash_hi; const u8* hash_lo;
+    const u32* sa; const u64* sa_flag; const u8* pac;
+};
+
+// rank in the reference layout at a 64-aligned stream position (bwt.h:1007-1081)
+DEVI void ref_rank64(const RefIndexDev& R, u64 line, u64& cT, u64& cA)
+{
+    const u64 base = (line >> 7) * 5, half = (line & 127) >> 6, sb = (line >> 16) << 1;
+    const u64 w0 = R.bwt[base];
+    cT = R.high_occ[sb] + ((w0 >> (48 - 32 * half)) & 0xffff);
+    cA = R.high_occ[sb + 1] + ((w0 >> (32 - 32 * half)) & 0xffff);
+}
+
+__global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, u64* out)
+{
+    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blk) return;
+    const u64 s0 = b * 192;
+    u64 cT = 0, cA = 0;
+    u64 w[6] = {0, 0, 0, 0, 0, 0};
+    // s0 is a multiple of 64 and s0 <= n_stream (n_blk = n_stream/192 + 1): the reference stored the
+    // counters of every 64-boundary it reached while building (bwt.cpp:1437-1490)
+    ref_rank64(R, s0, cT, cA);
+    for (int j = 0; j < 3; j++) {
+        const u64 s = s0 + 64 * (u64)j;
+        if (s < n_stream) {
+            const u64 wi = (s >> 7) * 5 + 1 + 2 * ((s & 127) >> 6);
+            w[2 * j] = R.bwt[wi];
+            w[2 * j + 1] = R.bwt[wi + 1];
+        }
+    }
+    u64* o = out + b * 8;
+    o[0] = cT; o[1] = cA;
+    for (int j = 0; j < 6; j++) o[2 + j] = w[j];
+}
+
+__global__ void k_repack_hash(RefIndexDev R, u64 n, u64* out)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 hi = R.hash_hi[i];
+    out[i] = (((u64)(hi & 0x0fffffffu)) << 8) | R.hash_lo[i] | ((u64)(hi >> 28) << 60);
+}
+
+// doubled 2-bit genome: d < G forward base, else complement of base 2G-1-d; LSB-first in u64 words
+__global__ void k_build_gen2(RefIndexDev R, u64 G, u64 n_words, u64* out)
+{
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    u64 v = 0;
+    for (int j = 0; j < 32; j++) {
+        const u64 d = w * 32 + j;
+        int b = 0;
+        if (d < G) b = (R.pac[d >> 2] >> (6 - 2 * (d & 3))) & 3;
+        else if (d < 2 * G) { const u64 p = 2 * G - 1 - d; b = 3 - ((R.pac[p >> 2] >> (6 - 2 * (p & 3))) & 3); }
+        v |= (u64)b << (2 * j);
+    }
+    out[w] = v;
+}
+
+// full SA from the sampled SA: LF-walk to a flagged row (bwt_get_sa_restrict_steps_more_than_3,
+// bwt.h:2449-2560), done once per attach so that the mapping kernels never walk.
+__global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out)
+{
+    const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    u64 l = row, steps = 0, val = 0;
+    if (l == ix.shapline) { out[row] = 0; return; }
+    for (;;) {
+        const u64 blk = (l >> 8) * 5, last = l & 255;
+        const u64 w = R.sa_flag[blk + 1 + (last >> 6)];
+        if ((w << (last & 63)) >> 63) {
+            u64 rank = R.sa_flag[blk];
+            for (u64 j = 0; j < (last >> 6); j++) rank += __popcll(R.sa_flag[blk + 1 + j]);
+            if (last & 63) rank += __popcll(w >> (64 - (last & 63)));
+            val = (u64)(R.sa[rank] & 0x3fffffffu) * 8 + steps;
+            break;
+        }
+        const int c = bwt_sym(ix, l);
+        l = lf_step(ix, l, c);
+        steps++;
+        if (l == ix.shapline) { val = steps; break; }
+    }
+    out[row] = (u32)val;
+}
+
+// ================================================================================================
+// scan (exclusive, u32 -> u64), three launches; not a hot kernel
+// ================================================================================================
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8            // per thread
+__global__ void k_scan_partial(const u32* in, u64 n, u64* block_sums)
+{
+    __shared__ u64 sh[SCAN_BLOCK];
+    const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
+    u64 s = 0;
+    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) s += in[base + j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = SCAN_BLOCK / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+__global__ void k_scan_blocks(u64* block_sums, u64 nb, u64* total)
+{
+    // single block, serial over chunks of blockDim
+    __shared__ u64 sh[SCAN_BLOCK];
+    __shared__ u64 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < nb; base += SCAN_BLOCK) {
+        const u64 i = base + threadIdx.x;
+        const u64 v = i < nb ? block_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
+            u64 t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) block_sums[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_BLOCK - 1) carry += sh[SCAN_BLOCK - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out)
+{
+    __shared__ u64 sh[SCAN_BLOCK];
+    const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
+    u64 loc[SCAN_ITEMS];
+    u64 s = 0;
+    for (int j = 0; j < SCAN_ITEMS; j++) { loc[j] = s; if (base + j < n) s += in[base + j]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
+        u64 t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const u64 excl = sh[threadIdx.x] - s + block_sums[blockIdx.x];
+    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] = excl + loc[j];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = excl + s;
+}
+
+// ================================================================================================
+// K1-K5: seeding
+// ================================================================================================
+struct SeedHit { u64 hits, sp, ml; };
+
+// count_backward_as_much_1_terminate (bwt.h:2081-2209) in read coordinates: the pattern is
+// bsSeq[0, L-tm) = reverse(read[tm, L)) with C->T, so the 16-mer key is the little-endian base-3
+// number of read[tm .. tm+15] and extension consumes read[tm+16], read[tm+17], ....
+DEVI SeedHit count_terminate(const DevIndex& ix, const char* rd, int L, int tm, u32& n_hash, u32& n_ext)
+{
+    SeedHit r = {0, 0, 0};
+    const int len = L - tm;
+    if (len < 18) return r;
+    u64 key = 0;
+    bool bad = false;
+    for (int u = 15; u >= 0; u--) { const int d = code3(rd[tm + u]); bad |= d > 2; key = key * 3 + (u64)(d > 2 ? 0 : d); }
+    // the reference hashes bsSeq[len-16 ..] left to right and stops at the first non-AGT char
+    if (bad) return r;
+    u64 top, bot;
+    hash_lookup(ix, key, top, bot);
+    n_hash++;
+    if (bot <= top) return r;
+    u64 ptop = ~0ull, pbot = ~0ull;
+    int s = 0;
+    const int steps = len - 16;
+    u64 ml = (u64)len;
+    for (; s < steps; s++) {
+        ptop = top; pbot = bot;
+        if (bot - top == 1) { ml = 16 + s; break; }
+        const int d = code3(rd[tm + 16 + s]);
+        if (d > 2) { ml = 16 + s; bot = top; break; }
+        const u64 nt = lf_step(ix, top, d), nb = lf_step(ix, bot, d);
+        n_ext++;
+        top = nt; bot = nb;
+        if (bot <= top) { ml = 16 + s; break; }
+    }
+    if (bot <= top) { r.sp = ptop; r.hits = pbot - ptop; }
+    else { r.sp = top; r.hits = bot - top; }
+    r.ml = ml;
+    return r;
+}
+
+// count_hash_table (bwt.h:1848-1952): exact count of read[tm, L), no early stop
+DEVI SeedHit count_fixed(const DevIndex& ix, const char* rd, int L, int tm, u32& n_hash, u32& n_ext)
+{
+    SeedHit r = {0, 0, (u64)(L - tm)};
+    const int len = L - tm;
+    if (len < 17) return r;
+    u64 key = 0;
+    bool bad = false;
+    for (int u = 15; u >= 0; u--) { const int d = code3(rd[tm + u]); bad |= d > 2; key = key * 3 + (u64)(d > 2 ? 0 : d); }
+    if (bad) return r;
+    u64 top, bot;
+    hash_lookup(ix, key, top, bot);
+    n_hash++;
+    if (bot <= top) return r;
+    for (int s = 0; s < len - 16; s++) {
+        if (bot <= top) break;
+        const int d = code3(rd[tm + 16 + s]);
+        if (d > 2) return r;
+        const u64 nt = lf_step(ix, top, d), nb = lf_step(ix, bot, d);
+        n_ext++;
+        top = nt; bot = nb;
+    }
+    r.sp = top;
+    r.hits = bot <= top ? 0 : bot - top;
+    return r;
+}
+
+// determine_seed_offset_unmatch (Schema.h:1506-1531)
+DEVI int seed_offset_unmatch(int L, int pre, const char* rd, int step)
+{
+    if (L - pre < 18 || L - pre < step) return L;
+    const int ret = pre + step;
+    for (int i = 0; i < step; i++, pre++) if (rd[pre] == 'N') return pre + 1;
+    return ret;
+}
+
+// The seeding state machine of Map_Single_Seq_end_to_end (Schema.cpp:24588-24898) with the three
+// fast exits; seeds are recorded as SA intervals, k_locate expands them.
+__global__ void __launch_bounds__(256)
+k_seed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, ReadState st,
+       unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned int shc[4];
+    if (threadIdx.x < 4) shc[threadIdx.x] = 0;
+    __syncthreads();
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 n_hash = 0, n_ext = 0, n_sa = 0, n_ung = 0;
+    if (r < n) {
+    const char* rd = seq + (size_t)r * stride;
+    int firstC = L;
+    for (int i = 0; i < L; i++) if (rd[i] == 'C') { firstC = i; break; }
+    SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+    int ns = 0;
+    u64 ncand = 0;
+    int tm = 0, seed_id = 0;
+    int max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
+    int verdict = 0, multi = 0, get_error = -1, extra = 1;
+    u64 first_ml = 0, mm_site = 0, c0 = 0, c1 = 0, clen = 0;
+    const u64 max_hits = 1000;
+    auto record = [&](u64 sp, u64 hits, u64 len, u64 off) {
+        my[ns].sp = sp; my[ns].hits = (u32)hits; my[ns].len = (u16)len; my[ns].off = (u16)off; ns++;
+        ncand += hits;
+    };
+    bool done = false;
+    if (seed_id < max_seed && tm < L) {
+        SeedHit s = count_terminate(ix, rd, L, tm, n_hash, n_ext);
+        u64 ml = s.ml;
+        first_ml = ml;
+        if (s.hits == 1) {
+            // try_process_unique_mismatch_end_to_end (Schema.cpp:15164-15282)
+            const u64 p = ix.sa[s.sp];
+            n_sa++;
+            const u64 loc = ix.total - p - ml;
+            record(s.sp, 1, ml, 0);
+            c0 = loc; clen = 1;
+            int error = 0;
+            if (ml > (u64)firstC) ml = (u64)firstC;
+            if (ml != (u64)L) {
+                const int need = L - (int)ml;
+                const u64 start = loc + ml;
+                const bool valid = window_valid(ix, start, (u64)need, loc < ix.G);
+                n_ung++;
+                int read_i = (int)ml;
+                for (int i = 0; i < need; i++) {
+                    const char a = rd[read_i];
+                    bool mism = true;
+                    if (valid) { const int b = gbase(ix, start + i); mism = !(code4(a) == b || (a == 'T' && b == 1)); }
+                    if (mism) { error++; if (error == 1) ml = (u64)read_i; else break; }
+                    read_i++;
+                }
+            }
+            get_error = error;
+            if (error == 0) { verdict = 1; st.exit_site[r] = loc; done = true; }
+        }
+        if (!done) {
+            mm_site = ml;
+            if (ml == (u64)L && s.hits > 1) {
+                multi = 1;
+                if (firstC == L) { verdict = 4; done = true; }      // exact, ambiguous, no C in the read
+            }
+        }
+        if (!done) {
+            if (s.hits == 1) { /* recorded */ }
+            else if (ml >= (u64)seed_len && s.hits <= max_hits) { if (s.hits != 0) { record(s.sp, s.hits, ml, (u64)tm); clen += s.hits; } }
+            if (ml == 0) tm = seed_offset_unmatch(L, tm, rd, 8); else tm = tm + (int)(ml / 2);
+            seed_id++;
+        }
+    }
+    if (!done && get_error == 1) {
+        // second seed over the rest of the read after a 1-mismatch first seed (Schema.cpp:24734-24801)
+        const int second_len = L - (int)first_ml;
+        if (second_len >= 17) {
+            SeedHit s = count_fixed(ix, rd, L, (int)first_ml, n_hash, n_ext);
+            if (s.hits == 1) {
+                const u64 p = ix.sa[s.sp];
+                n_sa++;
+                c1 = ix.total - p - (u64)second_len - first_ml;
+                record(s.sp, 1, (u64)second_len, first_ml);
+                clen += 1; extra = 0;
+            } else if (s.hits <= max_hits) {
+                if (s.hits != 0) { record(s.sp, s.hits, (u64)second_len, first_ml); clen += s.hits; }
+                extra = 0;
+            } else extra = 1;
+        } else extra = 1;
+    }
+    if (!done && extra == 1) {
+        while (seed_id < max_seed && tm < L) {
+            const int cur_len = L - tm;
+            SeedHit s = count_terminate(ix, rd, L, tm, n_hash, n_ext);
+            const u64 ml = s.ml;
+            if (s.hits == 1) { record(s.sp, 1, ml, (u64)tm); clen += 1; }
+            else if (ml >= (u64)seed_len && s.hits <= max_hits) { if (s.hits != 0) { record(s.sp, s.hits, ml, (u64)tm); clen += s.hits; } }
+            else if ((u64)cur_len == ml) break;
+            if (ml == 0) tm = seed_offset_unmatch(L, tm, rd, 8); else tm = tm + (int)(ml / 2);
+            seed_id++;
+        }
+    }
+    if (!done) {
+        if (extra == 0 && (clen == 1 || (clen == 2 && c0 == c1))) {       // fast exit C (Schema.cpp:24894)
+            verdict = 2; st.exit_site[r] = c0;
+        } else if (clen != 0) verdict = 3;
+    }
+    st.verdict[r] = (u8)verdict;
+    st.n_seeds[r] = (u8)ns;
+    st.multi[r] = (u8)multi;
+    st.mm_site[r] = (u16)mm_site;
+    st.n_cand[r] = verdict == 3 ? (u32)ncand : 0u;
+    }
+    if (counters) {
+        atomicAdd(&shc[0], n_hash); atomicAdd(&shc[1], n_ext); atomicAdd(&shc[2], n_sa); atomicAdd(&shc[3], n_ung);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&counters[0], (unsigned long long)shc[0]);
+            atomicAdd(&counters[1], (unsigned long long)shc[1]);
+            atomicAdd(&counters[2], (unsigned long long)shc[2]);
+            atomicAdd(&counters[5], (unsigned long long)shc[3]);
+        }
+    }
+}
+
+// ================================================================================================
+// K5/K6 + a8: one candidate slot per lane
+// ================================================================================================
+__global__ void __launch_bounds__(256)
+k_locate(DevIndex ix, long n, u64 total_cand, ReadState st, u64* __restrict__ cand)
+{
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_cand) return;
+    // read r with cand_off[r] <= g < cand_off[r+1]
+    long lo = 0, hi = n;
+    while (hi - lo > 1) { const long mid = (lo + hi) >> 1; if (st.cand_off[mid] <= g) lo = mid; else hi = mid; }
+    const long r = lo;
+    u64 rel = g - st.cand_off[r];
+    const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+    const int ns = st.n_seeds[r];
+    u64 site = 0;
+    for (int s = 0; s < ns; s++) {
+        const u32 h = my[s].hits;
+        if (rel < h) {
+            const u64 p = ix.sa[my[s].sp + rel];
+            site = ix.total - p - (u64)my[s].len - (u64)my[s].off;     // reverse_and_adjust_site, Schema.cpp:4669
+            break;
+        }
+        rel -= h;
+    }
+    cand[g] = site;
+}
+
+// ================================================================================================
+// a9/a10: per-read candidate sort, run-length votes, reference vote order
+// ================================================================================================
+__global__ void __launch_bounds__(64)
+k_vote(long n, int k, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (st.verdict[r] != 3) { st.n_votes[r] = 0; return; }
+    const u64 off = st.cand_off[r];
+    const long nc = (long)st.n_cand[r];
+    u64* c = cand + off;
+    sort_u64_asc(c, nc);
+    // generate_candidate_votes_shift (Schema.cpp:4687-4773)
+    bmbs_vote* v = votes + off;
+    long nv = 0;
+    u64 pre = c[0];
+    u32 vote = 1;
+    for (long i = 1; i < nc; i++) {
+        if (c[i] == pre) vote++;
+        else { v[nv].site = pre < (u64)k ? 0 : pre - (u64)k; v[nv].vote = vote; v[nv].pad = 0; nv++; vote = 1; pre = c[i]; }
+    }
+    v[nv].site = pre >= (u64)k ? pre - (u64)k : 0; v[nv].vote = vote; v[nv].pad = 0; nv++;
+    intro_sort_desc(v, nv);             // std::sort(votes, compare_seed_votes), Schema.cpp:24986
+    st.n_votes[r] = (u32)nv;
+    for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+}
+
+// ================================================================================================
+// K7+K8: window fetch + BS banded Myers, one candidate per lane, 64-bit words
+// ================================================================================================
+// BS_Reserve_Banded_BPM (Levenshtein_Cal.h:351-567); the 4 x 64-bit and 8 x 32-bit AVX2 forms
+// (:1678, :2093) compute the same (err, end_site) per candidate.  pattern = window (L+2k bases from
+// the doubled 2-bit genome), text = read; read 'T' also matches window 'C' (:384,473).
+DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
+{
+    out_err = 0xffffffffu; out_end = -1;
+    const int p_len = L + 2 * k;
+    if (!window_valid(ix, site, (u64)p_len, site < ix.G)) return;
+    u64 P[4] = {0, 0, 0, 0};
+    // streaming 2-bit window reader
+    u64 pos = site;
+    u64 w = ix.gen2[pos >> 5] >> ((pos & 31) * 2);
+    int left = 32 - (int)(pos & 31);
+    auto next_base = [&]() -> int {
+        const int b = (int)(w & 3);
+        w >>= 2; pos++; left--;
+        if (left == 0) { w = ix.gen2[pos >> 5]; left = 32; }
+        return b;
+    };
+    u64 PA = 0, PC = 0, PG = 0, PT = 0;
+    const int band = 2 * k + 1;
+    for (int i = 0; i < band; i++) {
+        const int b = next_base();
+        const u64 bit = 1ull << i;
+        PA |= b == 0 ? bit : 0; PC |= b == 1 ? bit : 0; PG |= b == 2 ? bit : 0; PT |= b == 3 ? bit : 0;
+    }
+    (void)P;
+    PT |= PC;
+    const u64 Mask = 1ull << (2 * k);
+    u64 VP = 0, VN = 0;
+    int err = 0;
+    const int last_high = 2 * k;
+    for (int i = 0; i < L; i++) {
+        const char tc = rd[i];
+        const u64 eq = tc == 'A' ? PA : tc == 'C' ? PC : tc == 'G' ? PG : tc == 'T' ? PT : 0ull;
+        u64 X = eq | VN;
+        const u64 D0 = ((VP + (X & VP)) ^ VP) | X;
+        const u64 HN = VP & D0;
+        const u64 HP = VN | ~(VP | D0);
+        X = D0 >> 1;
+        VN = X & HP;
+        VP = HN | ~(X | HP);
+        if (!(D0 & 1)) {
+            ++err;
+            if (err - last_high > k) return;            // cannot come back under k (Levenshtein_Cal.h:455)
+        }
+        if (i + 1 < L) {
+            PA >>= 1; PC >>= 1; PG >>= 1; PT >>= 1;
+            const int b = next_base();
+            PA |= b == 0 ? Mask : 0; PC |= b == 1 ? Mask : 0; PG |= b == 2 ? Mask : 0; PT |= b == 3 ? Mask : 0;
+            PT |= PC;
+        }
+    }
+    // minimum over the last 2k+1 columns; later column wins ties, then the un-gapped diagonal
+    // (Levenshtein_Cal.h:511-563)
+    const int site_e = L - 1;
+    u32 best = 0xffffffffu;
+    int ret = -1;
+    if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e; }
+    int i = 0;
+    while (i < k) {
+        err += (int)((VP >> i) & 1); err -= (int)((VN >> i) & 1); ++i;
+        if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e + i; }
+    }
+    const u32 ungap = (u32)err;
+    while (i < last_high) {
+        err += (int)((VP >> i) & 1); err -= (int)((VN >> i) & 1); ++i;
+        if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e + i; }
+    }
+    if (ungap <= (u32)k && ungap == best) ret = site_e + k;
+    out_err = best; out_end = ret;
+}
+
+__global__ void __launch_bounds__(256)
+k_filter(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, u64 n_slots,
+         const u32* __restrict__ slot_read, const bmbs_vote* __restrict__ votes,
+         u32* __restrict__ ferr, int* __restrict__ fend, unsigned long long* __restrict__ counters)
+{
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_slots) return;
+    const u32 r = slot_read[g];
+    if (r == 0xffffffffu) return;
+    u32 e; int es;
+    bpm_one(ix, seq + (size_t)r * stride, L, k, votes[g].site, e, es);
+    ferr[g] = e; fend[g] = es;
+    if (counters) atomicAdd(&counters[3], 1ull);
+}
+
+// standalone form for bmbs_filter_batch: explicit (read, site) pairs
+__global__ void __launch_bounds__(256)
+k_filter_pairs(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, u64 n_cand,
+               const u32* __restrict__ read_of, const u64* __restrict__ site,
+               u32* __restrict__ ferr, int* __restrict__ fend)
+{
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_cand) return;
+    u32 e; int es;
+    bpm_one(ix, seq + (size_t)read_of[g] * stride, L, k, site[g], e, es);
+    ferr[g] = e; fend[g] = es;
+}
+
+// ================================================================================================
+// K9: ordered reduction over a read's votes (Schema.cpp:7847-8172 / 8335-8750)
+// ================================================================================================
+__global__ void __launch_bounds__(256)
+k_reduce(long n, ReadState st, const bmbs_vote* __restrict__ votes, const u32* __restrict__ ferr,
+         const int* __restrict__ fend)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    st.job_flag[r] = 0;
+    st.red_status[r] = 0;
+    if (st.verdict[r] != 3) return;
+    const u64 off = st.cand_off[r];
+    const long nv = (long)st.n_votes[r];
+    u32 min_err = 0xfffffffeu, sbd = 0;
+    long min_idx = -1;
+    u64 min_site = ~0ull;
+    for (long i = 0; i < nv; i++) {
+        const u32 e = ferr[off + i];
+        const u64 tmp_site = votes[off + i].site + (u64)(long long)fend[off + i];
+        if (e == min_err && min_site != tmp_site && min_idx >= 0) { sbd = 0; min_idx = -2 - min_idx; }
+        else if (e < min_err) { sbd = min_err - e; min_err = e; min_idx = i; min_site = tmp_site; }
+    }
+    if (min_idx >= 0) {
+        st.best_site[r] = votes[off + min_idx].site;
+        st.best_end[r] = fend[off + min_idx];
+        st.best_err[r] = min_err;
+        st.sbd[r] = sbd;
+        st.red_status[r] = 1;
+        st.job_flag[r] = min_err != 0 ? 1u : 0u;
+    } else if (min_idx != -1) st.red_status[r] = 2;
+}
+
+__global__ void k_job_list(long n, ReadState st, u32* __restrict__ job_read)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (st.job_flag[r]) job_read[st.job_off[r]] = (u32)r;
+}
+
+// ================================================================================================
+// K11-K13: un-gapped recheck, banded affine-gap semi-global alignment with traceback, CIGAR + NM
+// ================================================================================================
+struct AlignOut { int start, end; u32 nm; int score; int n_ops; };
+
+// scratch layout: interleaved by job so that a wave's accesses coalesce
+struct AlignScratch { int* H; int* E; u8* z; u64 n_jobs; };
+
+// fast_recalculate_bs_Cigar (ksw.cpp:2578-2876) = try_cigar_without_path (:2515) else
+// ksw_semi_global_quality_back (:1850-2045) + leading/trailing-I folding + NM recount.
+// pen_lut[q] = MismatchPenaltyByQuality(q) evaluated on the host in IEEE double (ksw.h:148-161); the
+// per-cell `(int)(mat_diff * Phred)` of the reference (ksw.cpp:1950) is the same product.
+DEVI void align_one(const DevIndex& ix, const ScoreParams& sp, const int* __restrict__ pen_lut,
+                    const char* rd, const char* ql, bool rev_qual, int L, int k, u64 site, int end_site, u32 err_in,
+                    const AlignScratch& sc, u64 job, u32* __restrict__ ops_out, int max_ops, AlignOut& out)
+{
+    const bool fwd = site < ix.G;
+    const int p_len = L + 2 * k;
+    auto qat = [&](int i) -> int { return (unsigned char)ql[rev_qual ? L - 1 - i : i]; };
+    auto wbase = [&](int j) -> int { return gbase(ix, site + (u64)j); };
+    // read char vs window base: equal letter, or read T on window C
+    auto is_match = [&](char a, int b) -> bool { return code4(a) == b || (a == 'T' && b == 1); };
+    out.n_ops = 0;
+    // ---- K11
+    {
+        int tmp_err = 0, score = 0;
+        const int start = end_site - L + 1;
+        bool ok = start >= 0;
+        if (ok) {
+            for (int i = 0; i < L; i++) {
+                const char a = rd[i];
+                if (!is_match(a, wbase(i + start))) {
+                    if (++tmp_err > (int)err_in) { ok = false; break; }
+                    score -= a == 'N' ? sp.np : pen_lut[qat(i)];
+                }
+            }
+            if (ok && tmp_err == (int)err_in) { out.start = start; out.end = end_site; out.nm = err_in; out.score = score; return; }
+        }
+    }
+    // ---- K12
+    const int MINUS_INF = -0x40000000;
+    const int gapoe = sp.gap_open + sp.gap_ext, gape = sp.gap_ext;
+    const int band = 2 * k + 1;
+    const int qlen = p_len, tlen = L;
+    const u64 NJ = sc.n_jobs;
+    auto Hx = [&](int j) -> int& { return sc.H[(u64)j * NJ + job]; };
+    auto Ex = [&](int j) -> int& { return sc.E[(u64)j * NJ + job]; };
+    auto Zx = [&](int i, int jj) -> u8& { return sc.z[((u64)i * band + jj) * NJ + job]; };
+    int j;
+    for (j = 0; j < band; ++j) { Hx(j) = 0; Ex(j) = -gapoe; }
+    for (; j <= qlen; ++j) { Hx(j) = MINUS_INF; Ex(j) = MINUS_INF; }
+    int beg = 0, end = 0;
+    for (int i = 0; i < tlen; ++i) {
+        int f = MINUS_INF, h1 = MINUS_INF;
+        const char a = rd[i];
+        const int ta = code4(a);
+        const int mis = ta == 4 ? -sp.np : -pen_lut[qat(i)];
+        beg = i; end = i + band;
+        for (j = beg; j < end; ++j) {
+            int m = Hx(j), e = Ex(j), h, t;
+            u8 d;
+            Hx(j) = h1;
+            const int b = wbase(j);
+            m += (ta == b || (ta == 3 && b == 1)) ? 0 : mis;
+            d = m >= e ? 0 : 1;
+            h = m >= e ? m : e;
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            h1 = h;
+            t = m - gapoe;
+            e -= gape;
+            d |= e > t ? 1 << 2 : 0;
+            e = e > t ? e : t;
+            Ex(j) = e;
+            f -= gape;
+            d |= f > t ? 2 << 4 : 0;
+            f = f > t ? f : t;
+            Zx(i, j - beg) = d;
+        }
+        Hx(end) = h1; Ex(end) = MINUS_INF;
+    }
+    int max_i = tlen + k, score = Hx(max_i);
+    for (int i = end; i > beg; i--) { const int h = Hx(i); if (h > score) { score = h; max_i = i; } }
+    int qe = max_i - 1;
+    // traceback into a local op list (built back to front)
+    const int LOCAL_OPS = 160;
+    u32 cg[LOCAL_OPS + 1];
+    int nc = 0;
+    bool overflow = false;
+    auto push = [&](int op, int len) {
+        if (nc == 0 || op != (int)(cg[nc - 1] & 0xf)) { if (nc < LOCAL_OPS) cg[nc++] = ((u32)len << 4) | (u32)op; else overflow = true; }
+        else cg[nc - 1] += (u32)len << 4;
+    };
+    {
+        int i = tlen - 1, kk = max_i - 1, which = 0;
+        while (i >= 0 && kk >= 0) {
+            which = (Zx(i, kk - i) >> (which << 1)) & 3;
+            if (which == 0) { push(0, 1); --i; --kk; }
+            else if (which == 1) { push(2, 1); --i; }
+            else { push(1, 1); --kk; }
+        }
+        if (i >= 0) push(2, i + 1);
+        for (int a2 = 0, b2 = nc - 1; a2 < b2; a2++, b2--) { const u32 t = cg[a2]; cg[a2] = cg[b2]; cg[b2] = t; }
+        cg[nc] = 0;
+        int qb = kk + 1;
+        // ---- K13: fold leading / trailing insertions into M (ksw.cpp:2677-2772)
+        int n_cigar = nc, ii, op, opl, ins = 0;
+        for (ii = 0; ii < n_cigar; ++ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+        if (ii != 0) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (op == 0) opl += ins; else { op = 0; opl = ins; ii--; }
+            cg[ii] = ((u32)opl << 4) | (u32)op;
+            qb -= ins;
+        }
+        const int cigar_b = ii;
+        ins = 0;
+        for (ii = n_cigar - 1; ii >= cigar_b; --ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+        if (ii != n_cigar - 1) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (op == 0) opl += ins; else { op = 0; opl = ins; ii++; }
+            cg[ii] = ((u32)opl << 4) | (u32)op;
+            qe += ins;
+        }
+        const int cigar_e = ii;
+        // NM recount under bisulfite matching + emit in SAM order (ksw.cpp:2779-2857)
+        int NM = 0, no = 0;
+        if (fwd) {
+            int qs = qb, ts = 0;
+            for (ii = cigar_b; ii <= cigar_e; ++ii) {
+                op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+                if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+                no++;
+                if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[ts], wbase(qs)) ) NM++; qs++; ts++; } }
+                else if (op == 1) { qs += opl; NM += opl; }
+                else { ts += opl; NM += opl; }
+            }
+        } else {
+            int qx = qe, te = tlen - 1;
+            for (ii = cigar_e; ii >= cigar_b; --ii) {
+                op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+                if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+                no++;
+                if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[te], wbase(qx))) NM++; qx--; te--; } }
+                else if (op == 1) { qx -= opl; NM += opl; }
+                else { te -= opl; NM += opl; }
+            }
+        }
+        out.start = qb; out.end = qe; out.nm = (u32)NM; out.score = score;
+        out.n_ops = overflow ? -1 : no;
+    }
+}
+
+// NOTE on the NM recount: the reference counts pattern != text unless (pattern == 'C' && text == 'T');
+// a window never holds 'N', so this equals !is_match(read, window).
+
+__global__ void __launch_bounds__(64)
+k_align(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
+        const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, const u32* __restrict__ job_read,
+        ReadState st, AlignScratch sc, u32* __restrict__ cigar_pool, int max_ops,
+        int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
+        int* __restrict__ a_nops, unsigned long long* __restrict__ counters)
+{
+    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb >= n_jobs) return;
+    const u32 r = job_read[jb];
+    AlignOut o;
+    align_one(ix, sp, pen_lut, seq + (size_t)r * stride, qual + (size_t)r * stride, false, L, k,
+              st.best_site[r], st.best_end[r], st.best_err[r], sc, jb, cigar_pool + jb * (u64)max_ops, max_ops, o);
+    a_start[jb] = o.start; a_end[jb] = o.end; a_nm[jb] = o.nm; a_score[jb] = o.score; a_nops[jb] = o.n_ops;
+    if (counters) atomicAdd(&counters[4], 1ull);
+}
+
+// standalone form for bmbs_align_batch
+__global__ void __launch_bounds__(64)
+k_align_pairs(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
+              const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, const u32* __restrict__ read_of,
+              const u64* __restrict__ site, const int* __restrict__ end_in, const u32* __restrict__ err_in,
+              AlignScratch sc, u32* __restrict__ cigar_pool, int max_ops,
+              int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
+              int* __restrict__ a_nops)
+{
+    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb >= n_jobs) return;
+    const u32 r = read_of[jb];
+    AlignOut o;
+    if (err_in[jb] == 0) {        // fast_recalculate_bs_Cigar's own err==0 branch (ksw.cpp:2607-2616)
+        o.start = end_in[jb] - L + 1; o.end = end_in[jb]; o.nm = 0; o.score = 0; o.n_ops = 0;
+    } else
+        align_one(ix, sp, pen_lut, seq + (size_t)r * stride, qual + (size_t)r * stride, false, L, k,
+                  site[jb], end_in[jb], err_in[jb], sc, jb, cigar_pool + jb * (u64)max_ops, max_ops, o);
+    a_start[jb] = o.start; a_end[jb] = o.end; a_nm[jb] = o.nm; a_score[jb] = o.score; a_nops[jb] = o.n_ops;
+}
+
+// ================================================================================================
+// finalize: MAPQ, placement, stats
+// ================================================================================================
+struct bmbs_result_dev {   // == bmbs_result (include/bmbs.h), 32 bytes
+    u64 pos; u32 cigar_off; int16_t chrom; u8 status; u8 mapq; u16 flag; u16 nm; int16_t score; u8 n_cigar; u8 path; u32 n_cand; u32 reserved;
+};
+
+// mapq_lut[(ed) * (range+1) + sd]: MAP_Calculation (Schema.cpp:168-405) tabulated on the host in
+// IEEE double for this k: ed = min(second_best_diff, k+1), sd = clamp(score + range, 0, range).
+__global__ void __launch_bounds__(256)
+k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u8* __restrict__ mapq_lut,
+           int range, const char* __restrict__ seq, const char* __restrict__ qual, int L, int stride, int k,
+           long n, ReadState st, const int* __restrict__ a_start, const int* __restrict__ a_end,
+           const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops,
+           int max_ops, bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
+{
+    __shared__ unsigned long long sh[5];
+    if (threadIdx.x < 5) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) {
+        bmbs_result_dev o;
+        o.pos = 0; o.cigar_off = 0; o.chrom = -1; o.status = 0; o.mapq = 0; o.flag = 0; o.nm = 0; o.score = 0;
+        o.n_cigar = 0; o.path = 0; o.n_cand = st.n_cand[r]; o.reserved = 0;
+        const int verdict = st.verdict[r];
+        bool have = false;
+        u64 site = 0; long long start_site = 0, end_site = 0;
+        u32 nm = 0; int score = 0; u32 sbd = 0; int mapq = 0;
+        if (verdict == 1) { have = true; site = st.exit_site[r]; start_site = 0; end_site = L - 1; nm = 0; score = 0; mapq = 42; o.path = 1; }
+        else if (verdict == 2) {
+            have = true; site = st.exit_site[r]; start_site = 0; end_site = L - 1; nm = 1; o.path = 2;
+            const int ms = st.mm_site[r];
+            const char a = seq[(size_t)r * stride + ms];
+            score = a == 'N' ? -sp.np : -pen_lut[(unsigned char)qual[(size_t)r * stride + ms]];
+            sbd = 0xffffffffu;
+        } else if (verdict == 4) { o.status = 2; o.path = 4; }
+        else if (verdict == 3) {
+            o.path = 3;
+            if (st.red_status[r] == 1) {
+                have = true; site = st.best_site[r]; sbd = st.sbd[r];
+                if (st.job_flag[r]) {
+                    const u64 jb = st.job_off[r];
+                    start_site = a_start[jb]; end_site = a_end[jb]; nm = a_nm[jb]; score = a_score[jb];
+                    const int no = a_nops[jb];
+                    o.cigar_off = (u32)(jb * (u64)max_ops);
+                    o.n_cigar = no < 0 ? 255 : (u8)no;
+                } else { end_site = st.best_end[r]; start_site = end_site - L + 1; nm = 0; score = 0; }
+            } else if (st.red_status[r] == 2) o.status = 2;
+        }
+        if (have) {
+            if (verdict != 1) {
+                int sd = score + range; if (sd < 0) sd = 0; if (sd > range) sd = range;
+                const u32 ed = sbd > (u32)k ? (u32)k + 1 : sbd;
+                mapq = mapq_lut[(size_t)ed * (range + 1) + sd];
+            }
+            // output_sam_end_to_end placement (Schema.cpp:11941-11986)
+            u64 loc = site; int flag;
+            if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; flag = 16; }
+            else { loc = loc + (u64)start_site; flag = 0; }
+            int c = 0;
+            for (; c < ix.n_chrom; ++c) if (loc >= ix.chrom_start[c] && loc < ix.chrom_start[c + 1]) break;
+            bool ok = c < ix.n_chrom;
+            u64 pos = 0;
+            if (ok) {
+                pos = loc + 1 - ix.chrom_start[c];
+                const u64 clen = ix.chrom_start[c + 1] - ix.chrom_start[c];
+                if (pos + (u64)end_site - (u64)start_site > clen) ok = false;
+            }
+            o.pos = pos; o.chrom = (int16_t)(c < ix.n_chrom ? c : -1); o.flag = (u16)flag; o.mapq = (u8)mapq;
+            o.nm = (u16)nm; o.score = (int16_t)score;
+            o.status = ok ? 1 : 3;
+        }
+        res[r] = o;
+        atomicAdd(&sh[0], 1ull);
+        if (o.status == 1) { atomicAdd(&sh[1], 1ull); atomicAdd(&sh[3], (unsigned long long)L); atomicAdd(&sh[4], (unsigned long long)nm); }
+        else if (o.status == 2) atomicAdd(&sh[2], 1ull);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&stats[threadIdx.x], sh[threadIdx.x]);
+}

@@ -1,0 +1,392 @@
+// bitmapperbs_amd/csrc/index_io.cpp
+// Host side of the index boundary: reader of the reference's on-disk index formats and a
+// psascan-free builder that writes them.  Formats (all little-endian raw arrays):
+//   <p>.index              chromosome table          Index.cpp:134-159 / 954-992
+//   <p>.index.bs.pac       2-bit forward genome      Index.cpp:731-830
+//   <p>.index.bs.index     SA_length, shapline, nacgt[5], 3 x u32   bwt.cpp:2563-2578
+//   <p>.index.bs.index.bwt bit-plane BWT + interleaved Occ, 16-mer table   bwt.cpp:2587-2605
+//   <p>.index.bs.index.sa  sampled SA + SA_flag      bwt.cpp:2612-2635
+//   <p>.index.bs.index.occ super-block Occ           bwt.cpp:2638-2643
+#include "../../include/bmbs.h"
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+typedef uint64_t u64; typedef uint32_t u32; typedef uint8_t u8;
+
+struct Chrom { std::string name; u64 len; };
+
+bool slurp_fasta(const char* path, std::vector<Chrom>& chroms, std::vector<char>& gen)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    std::vector<char> buf(1 << 22);
+    bool hdr = false;
+    std::string h;
+    size_t got;
+    while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) {
+        for (size_t i = 0; i < got; i++) {
+            char c = buf[i];
+            if (hdr) {
+                if (c == '\n') {
+                    hdr = false;
+                    size_t k = h.find(' ');
+                    Chrom ch; ch.name = k == std::string::npos ? h : h.substr(0, k); ch.len = 0;
+                    chroms.push_back(ch);
+                } else h.push_back(c);
+            } else if (c == '>') { hdr = true; h.clear(); }
+            else if (!isspace((unsigned char)c)) {
+                gen.push_back((char)toupper((unsigned char)c));
+                if (!chroms.empty()) chroms.back().len++;
+            }
+        }
+    }
+    fclose(f);
+    return !chroms.empty();
+}
+
+template <class T> void put(FILE* f, const T& v) { fwrite(&v, sizeof(T), 1, f); }
+template <class T> bool get(FILE* f, T& v) { return fread(&v, sizeof(T), 1, f) == 1; }
+
+// suffix array of a text over {0,1,2} (n < 2^32), shorter suffix first: 16-symbol radix key, then
+// prefix doubling restricted to the still-tied groups.
+void suffix_sort(const std::vector<u8>& T, u64 n, std::vector<u32>& sa, int n_threads)
+{
+    std::vector<u64> ks(n);
+    {
+        // rolling 32-bit key of 16 two-bit digits (symbol+1, 0 beyond the end)
+        auto fill = [&](u64 a, u64 b) {
+            if (a >= b) return;
+            u64 k = 0;
+            for (int j = 0; j < 16; j++) k = (k << 2) | (a + j < n ? (u64)(T[a + j] + 1) : 0);
+            ks[a] = (k << 32) | a;
+            for (u64 i = a + 1; i < b; i++) {
+                k = ((k << 2) & 0xffffffffULL) | (i + 15 < n ? (u64)(T[i + 15] + 1) : 0);
+                ks[i] = (k << 32) | i;
+            }
+        };
+        std::vector<std::thread> th;
+        u64 per = (n + n_threads - 1) / n_threads;
+        for (int t = 0; t < n_threads; t++) th.emplace_back(fill, std::min(n, t * per), std::min(n, (t + 1) * per));
+        for (auto& x : th) x.join();
+    }
+    {
+        // bucket by the first 3 symbols (top 6 key bits), sort buckets in parallel
+        u64 cnt[65] = {0};
+        for (u64 i = 0; i < n; i++) cnt[(ks[i] >> 58) + 1]++;
+        for (int b = 0; b < 64; b++) cnt[b + 1] += cnt[b];
+        std::vector<u64> tmp(n);
+        u64 pos[64];
+        for (int b = 0; b < 64; b++) pos[b] = cnt[b];
+        for (u64 i = 0; i < n; i++) tmp[pos[ks[i] >> 58]++] = ks[i];
+        ks.swap(tmp);
+        tmp.clear(); tmp.shrink_to_fit();
+        std::vector<std::thread> th;
+        std::vector<int> order(64);
+        for (int b = 0; b < 64; b++) order[b] = b;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a + 1] - cnt[a] > cnt[b + 1] - cnt[b]; });
+        std::vector<std::vector<int>> work(n_threads);
+        for (int i = 0; i < 64; i++) work[i % n_threads].push_back(order[i]);
+        for (int t = 0; t < n_threads; t++)
+            th.emplace_back([&, t]() { for (int b : work[t]) std::sort(ks.begin() + cnt[b], ks.begin() + cnt[b + 1]); });
+        for (auto& x : th) x.join();
+    }
+    sa.resize(n);
+    std::vector<u32> rank(n + 1, 0);
+    std::vector<std::pair<u64, u64>> groups, next;
+    {
+        u64 a = 0;
+        while (a < n) {
+            u64 b = a + 1;
+            u64 ka = ks[a] >> 32;
+            while (b < n && (ks[b] >> 32) == ka) b++;
+            for (u64 i = a; i < b; i++) { u32 idx = (u32)ks[i]; sa[i] = idx; rank[idx] = (u32)a + 1; }
+            if (b - a > 1) groups.push_back({a, b});
+            a = b;
+        }
+    }
+    ks.clear(); ks.shrink_to_fit();
+    std::vector<u32> key;
+    for (u64 h = 16; !groups.empty(); h *= 2) {
+        // phase A: order every tied group by the rank of the suffix h further on (old ranks only)
+        u64 tot = 0;
+        for (auto& g : groups) tot += g.second - g.first;
+        key.resize(tot);
+        u64 ko = 0;
+        std::vector<std::pair<u32, u32>> tmp;
+        for (auto& g : groups) {
+            u64 a = g.first, b = g.second;
+            tmp.resize(b - a);
+            for (u64 i = a; i < b; i++) { u64 j = (u64)sa[i] + h; tmp[i - a] = {j < n ? rank[j] : 0u, sa[i]}; }
+            std::sort(tmp.begin(), tmp.end());
+            for (u64 i = a; i < b; i++) { sa[i] = tmp[i - a].second; key[ko + i - a] = tmp[i - a].first; }
+            ko += b - a;
+        }
+        // phase B: split
+        next.clear();
+        ko = 0;
+        for (auto& g : groups) {
+            u64 a = g.first, b = g.second, s = a;
+            for (u64 i = a + 1; i <= b; i++) {
+                if (i == b || key[ko + i - a] != key[ko + s - a]) {
+                    for (u64 q = s; q < i; q++) rank[sa[q]] = (u32)s + 1;
+                    if (i - s > 1) next.push_back({s, i});
+                    s = i;
+                }
+            }
+            ko += b - a;
+        }
+        groups.swap(next);
+    }
+}
+
+struct Built {
+    std::vector<Chrom> chroms;
+    u64 G = 0;
+    std::vector<u8> pac;
+    u64 sa_length = 0, shapline = 0, nacgt[5] = {0, 0, 0, 0, 0};
+    std::vector<u64> bwt, high_occ, sa_flag;
+    std::vector<u32> hash_hi, sa;
+    std::vector<u8> hash_lo;
+};
+
+int write_files(const Built& B, const std::string& base)
+{
+    FILE* f = fopen(base.c_str(), "wb");
+    if (!f) return BMBS_EINVAL;
+    put<u64>(f, B.chroms.size());
+    for (auto& c : B.chroms) { put<u64>(f, c.name.size()); fwrite(c.name.data(), 1, c.name.size(), f); put<u64>(f, c.len); }
+    put<u64>(f, B.G);
+    fclose(f);
+    f = fopen((base + ".bs.pac").c_str(), "wb");
+    put<u64>(f, (u64)B.pac.size()); fwrite(B.pac.data(), 1, B.pac.size(), f); fclose(f);
+    f = fopen((base + ".bs.index").c_str(), "wb");
+    put<u64>(f, B.sa_length); put<u64>(f, B.shapline);
+    for (int j = 0; j < 5; j++) put<u64>(f, B.nacgt[j]);
+    put<u32>(f, 8); put<u32>(f, 64); put<u32>(f, 128);
+    fclose(f);
+    f = fopen((base + ".bs.index.bwt").c_str(), "wb");
+    put<u64>(f, (u64)B.bwt.size()); fwrite(B.bwt.data(), 8, B.bwt.size(), f);
+    put<u64>(f, (u64)B.hash_hi.size());
+    fwrite(B.hash_hi.data(), 4, B.hash_hi.size(), f); fwrite(B.hash_lo.data(), 1, B.hash_lo.size(), f);
+    fclose(f);
+    f = fopen((base + ".bs.index.sa").c_str(), "wb");
+    put<u64>(f, (u64)B.sa.size()); fwrite(B.sa.data(), 4, B.sa.size(), f);
+    put<u64>(f, (u64)B.sa_flag.size()); fwrite(B.sa_flag.data(), 8, B.sa_flag.size(), f);
+    fclose(f);
+    f = fopen((base + ".bs.index.occ").c_str(), "wb");
+    put<u64>(f, (u64)B.high_occ.size()); fwrite(B.high_occ.data(), 8, B.high_occ.size(), f);
+    fclose(f);
+    return BMBS_OK;
+}
+}  // namespace
+
+struct bmbs_index_file {
+    std::vector<Chrom> chroms;
+    std::vector<u64> chrom_len;
+    u64 G = 0;
+    std::vector<u8> pac;
+    u64 sa_length = 0, shapline = 0, nacgt[5] = {0, 0, 0, 0, 0};
+    std::vector<u64> bwt, high_occ, sa_flag;
+    std::vector<u32> hash_hi, sa;
+    std::vector<u8> hash_lo;
+};
+
+extern "C" int bmbs_index_build(const char* fasta, const char* prefix, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    Built B;
+    std::vector<char> gen;
+    if (!slurp_fasta(fasta, B.chroms, gen)) return BMBS_EINVAL;
+    const u64 G = gen.size();
+    B.G = G;
+    if (2 * G + 1 >= (1ULL << 32)) return BMBS_EINVAL;   // 32-bit suffix indices in this builder
+    // non-ACGT -> fixed pseudo-random base (the reference uses srand(time(0)), Index.cpp:703)
+    {
+        u64 s = 0x9E3779B97F4A7C15ULL;
+        for (u64 i = 0; i < G; i++) {
+            char c = gen[i];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { s = s * 6364136223846793005ULL + 1442695040888963407ULL; gen[i] = "ACGT"[(s >> 33) & 3]; }
+        }
+    }
+    B.pac.assign((G + 3) / 4, 0);
+    for (u64 i = 0; i < G; i++) {
+        u8 v = gen[i] == 'A' ? 0 : gen[i] == 'C' ? 1 : gen[i] == 'G' ? 2 : 3;
+        B.pac[i >> 2] |= v << (6 - 2 * (i & 3));
+    }
+    // text = complement(fwd) C->T ++ reverse(fwd) C->T, recoded G0 T1 A2 (Index.cpp:645-682, bwt.cpp:1135)
+    const u64 n = 2 * G;
+    std::vector<u8> T(n);
+    for (u64 i = 0; i < G; i++) {
+        char b = gen[i];
+        T[i] = b == 'A' ? 1 /*T*/ : b == 'C' ? 0 /*G*/ : b == 'G' ? 1 /*C->T*/ : 2 /*A*/;
+        char r = gen[G - 1 - i];
+        T[G + i] = r == 'G' ? 0 : (r == 'T' || r == 'C') ? 1 : 2;
+    }
+    gen.clear(); gen.shrink_to_fit();
+    std::vector<u32> sa;
+    suffix_sort(T, n, sa, n_threads);
+    const u64 rows = n + 1;
+    B.sa_length = rows;
+    auto SA = [&](u64 r) -> u64 { return r == 0 ? n : sa[r - 1]; };
+
+    // BWT planes + in-block counters + super-block table (bwt.cpp:1290-1500)
+    B.bwt.assign(1 + 2 * (n / 64) + (n / 128) + 2, 0);
+    B.bwt.reserve(B.bwt.size() + 8);
+    std::vector<u64> bw(B.bwt.size() + 8, 0);
+    B.high_occ.assign(2, 0);
+    u64 cnt[3] = {0, 0, 0}, t = 0;
+    for (u64 r = 0; r < rows; r++) {
+        u64 p = SA(r);
+        if (p == 0) { B.shapline = r; continue; }
+        u8 ch = T[p - 1];
+        u64 w = (t >> 7) * 5 + 1 + 2 * ((t & 127) >> 6), sh = 63 - (t & 63);
+        bw[w] |= (u64)(ch & 1) << sh;
+        bw[w + 1] |= (u64)(ch >> 1) << sh;
+        cnt[ch]++; t++;
+        if ((t & 65535) == 0) { B.high_occ.push_back(cnt[1]); B.high_occ.push_back(cnt[2]); }
+        if ((t & 63) == 0) {
+            u64 w0 = (t >> 7) * 5, half = (t & 127) >> 6, sb = (t >> 16) * 2;
+            bw[w0] |= (cnt[1] - B.high_occ[sb]) << (48 - 32 * half);
+            bw[w0] |= (cnt[2] - B.high_occ[sb + 1]) << (32 - 32 * half);
+        }
+    }
+    std::copy(bw.begin(), bw.begin() + B.bwt.size(), B.bwt.begin());
+    bw.clear(); bw.shrink_to_fit();
+    B.nacgt[0] = 1; B.nacgt[1] = 1 + cnt[0]; B.nacgt[2] = B.nacgt[1] + cnt[1]; B.nacgt[3] = B.nacgt[2] + cnt[2]; B.nacgt[4] = B.nacgt[3];
+
+    // SA_flag + samples (bwt.cpp:1580-1800)
+    {
+        std::vector<u64> fl((rows / 256 + 2) * 5 + 8, 0);
+        u64 it = 1, bits = 64, sparse = 0;
+        for (u64 r = 0; r < rows; r++) {
+            u64 p = SA(r);
+            if ((p & 7) == 0) {
+                sparse++;
+                fl[it] |= 1ULL << (63 - (bits & 63));
+                u32 ch = p != 0 ? T[p - 1] : 1;
+                B.sa.push_back((ch << 30) | (u32)(p >> 3));
+            }
+            bits++;
+            if ((bits & 63) == 0) it++;
+            if (((r + 1) & 255) == 0) { fl[it] = sparse; bits += 64; it++; }
+        }
+        if (bits & 63) it++;
+        it++;
+        fl.resize(it);
+        B.sa_flag.swap(fl);
+    }
+    // 16-mer table (bwt.cpp:1866-2010)
+    {
+        const u64 HS = 43046721ULL + 1;
+        B.hash_hi.assign(HS, 0); B.hash_lo.assign(HS, 0);
+        std::vector<u32> key16(n, 0xffffffffu);
+        if (n >= 16) {
+            u64 k = 0;
+            for (int j = 0; j < 16; j++) k = k * 3 + T[j];
+            key16[0] = (u32)k;
+            for (u64 p = 1; p + 16 <= n; p++) { k = (k - (u64)T[p - 1] * 14348907ULL) * 3 + T[p + 15]; key16[p] = (u32)k; }
+        }
+        u64 run = 1, r = 1;
+        B.hash_hi[0] = 0; B.hash_lo[0] = 1;
+        for (u64 key = 0; key < HS - 1; key++) {
+            u64 rr = r;
+            while (rr < rows && key16[sa[rr - 1]] == 0xffffffffu) rr++;
+            if (rr < rows && key16[sa[rr - 1]] == key) {
+                u64 top = rr, bot = rr;
+                while (bot < rows && key16[sa[bot - 1]] == key) bot++;
+                B.hash_hi[key] = (u32)(top >> 8) | ((u32)(top - run) << 28);
+                B.hash_lo[key] = (u8)top;
+                B.hash_hi[key + 1] = (u32)(bot >> 8); B.hash_lo[key + 1] = (u8)bot;
+                run = bot; r = bot;
+            } else {
+                B.hash_hi[key] = (u32)(run >> 8); B.hash_lo[key] = (u8)run;
+                B.hash_hi[key + 1] = (u32)(run >> 8); B.hash_lo[key + 1] = (u8)run;
+            }
+        }
+    }
+    return write_files(B, std::string(prefix) + ".index");
+}
+
+extern "C" bmbs_index_file* bmbs_index_file_load(const char* prefix)
+{
+    bmbs_index_file* ix = new bmbs_index_file();
+    std::string base = std::string(prefix) + ".index";
+    auto fail = [&](FILE* f) { if (f) fclose(f); delete ix; return (bmbs_index_file*)nullptr; };
+    FILE* f = fopen(base.c_str(), "rb");
+    if (!f) return fail(f);
+    u64 nch = 0;
+    if (!get(f, nch)) return fail(f);
+    for (u64 i = 0; i < nch; i++) {
+        u64 len = 0; get(f, len);
+        Chrom c; c.name.assign(len, 0);
+        if (len && fread(&c.name[0], 1, len, f) != len) return fail(f);
+        get(f, c.len);
+        ix->chroms.push_back(c); ix->chrom_len.push_back(c.len);
+    }
+    get(f, ix->G); fclose(f);
+    f = fopen((base + ".bs.pac").c_str(), "rb");
+    if (!f) return fail(f);
+    u64 nb = 0; get(f, nb);
+    ix->pac.assign(nb, 0);
+    if (fread(ix->pac.data(), 1, nb, f) != nb) return fail(f);
+    fclose(f);
+    f = fopen((base + ".bs.index").c_str(), "rb");
+    if (!f) return fail(f);
+    get(f, ix->sa_length); get(f, ix->shapline);
+    for (int j = 0; j < 5; j++) get(f, ix->nacgt[j]);
+    fclose(f);
+    f = fopen((base + ".bs.index.bwt").c_str(), "rb");
+    if (!f) return fail(f);
+    u64 nw = 0; get(f, nw);
+    ix->bwt.assign(nw, 0);
+    if (fread(ix->bwt.data(), 8, nw, f) != nw) return fail(f);
+    u64 hs = 0; get(f, hs);
+    ix->hash_hi.assign(hs, 0); ix->hash_lo.assign(hs, 0);
+    if (fread(ix->hash_hi.data(), 4, hs, f) != hs) return fail(f);
+    if (fread(ix->hash_lo.data(), 1, hs, f) != hs) return fail(f);
+    fclose(f);
+    f = fopen((base + ".bs.index.sa").c_str(), "rb");
+    if (!f) return fail(f);
+    u64 ns = 0; get(f, ns);
+    ix->sa.assign(ns, 0);
+    if (fread(ix->sa.data(), 4, ns, f) != ns) return fail(f);
+    u64 nf = 0; get(f, nf);
+    ix->sa_flag.assign(nf, 0);
+    if (fread(ix->sa_flag.data(), 8, nf, f) != nf) return fail(f);
+    fclose(f);
+    f = fopen((base + ".bs.index.occ").c_str(), "rb");
+    if (!f) return fail(f);
+    u64 no = 0; get(f, no);
+    ix->high_occ.assign(no, 0);
+    if (fread(ix->high_occ.data(), 8, no, f) != no) return fail(f);
+    fclose(f);
+    return ix;
+}
+
+extern "C" void bmbs_index_file_view(const bmbs_index_file* ix, bmbs_index_view* v)
+{
+    memset(v, 0, sizeof(*v));
+    v->ref_len = ix->G; v->pac = ix->pac.data(); v->pac_bytes = ix->pac.size();
+    v->sa_length = ix->sa_length; v->shapline = ix->shapline;
+    for (int j = 0; j < 5; j++) v->nacgt[j] = ix->nacgt[j];
+    v->bwt = ix->bwt.data(); v->bwt_words = ix->bwt.size();
+    v->high_occ = ix->high_occ.data(); v->high_occ_words = ix->high_occ.size();
+    v->hash_hi = ix->hash_hi.data(); v->hash_lo = ix->hash_lo.data(); v->hash_entries = ix->hash_hi.size();
+    v->sa = ix->sa.data(); v->sa_entries = ix->sa.size();
+    v->sa_flag = ix->sa_flag.data(); v->sa_flag_words = ix->sa_flag.size();
+    v->n_chrom = (int32_t)ix->chroms.size(); v->chrom_len = ix->chrom_len.data();
+}
+
+extern "C" const char* bmbs_index_file_chrom_name(const bmbs_index_file* ix, int i)
+{
+    return (i >= 0 && (size_t)i < ix->chroms.size()) ? ix->chroms[i].name.c_str() : nullptr;
+}
+
+extern "C" void bmbs_index_file_free(bmbs_index_file* ix) { delete ix; }

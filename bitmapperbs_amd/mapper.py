@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's `--search` mapping drivers over the C-ABI.
+
+`Index`   == Load_Index / load_index (Index.cpp:940, bwt.cpp:2458): the on-disk index files.
+`Mapper`  == Prepare_alignment + Map_Single_Seq (Schema.cpp:639, 26330) for one GPU: batches of
+             equal-length reads in, 32-byte result records + CIGAR pool out; SAM text is formatted on
+             the host from the records (output_sam_end_to_end, Schema.cpp:11989-12039).
+All mapping work happens in libbmbs_hip.so on the GPU; this module only moves buffers and prints.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGT", b"TGCA"):
+    _COMP[_a] = _b
+
+
+class Index:
+    def __init__(self, prefix: str):
+        self._lib = capi.lib()
+        self._h = self._lib.bmbs_index_file_load(prefix.encode())
+        if not self._h:
+            raise FileNotFoundError(f"cannot load BitMapperBS index files at {prefix}.index*")
+        self.view = capi.IndexView()
+        self._lib.bmbs_index_file_view(self._h, C.byref(self.view))
+        self.chrom_names = [self._lib.bmbs_index_file_chrom_name(self._h, i).decode()
+                            for i in range(self.view.n_chrom)]
+        self.chrom_len = np.ctypeslib.as_array(
+            C.cast(self.view.chrom_len, C.POINTER(C.c_uint64)), shape=(self.view.n_chrom,)).copy()
+        self.ref_len = int(self.view.ref_len)
+
+    @staticmethod
+    def build(fasta: str, prefix: str | None = None, threads: int = 8) -> None:
+        rc = capi.lib().bmbs_index_build(fasta.encode(), (prefix or fasta).encode(), threads)
+        if rc:
+            raise RuntimeError(f"bmbs_index_build failed ({rc})")
+
+    def close(self):
+        if self._h:
+            self._lib.bmbs_index_file_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mapper:
+    def __init__(self, index: Index, device: int = 0, **params):
+        self._lib = capi.lib()
+        self.params = capi.default_params(**params)
+        self._ctx = self._lib.bmbs_create(device, C.byref(self.params))
+        if not self._ctx:
+            raise RuntimeError("bmbs_create failed: no usable HIP device (the mapper has no CPU path)")
+        self.index = index
+        self._chk(self._lib.bmbs_index_attach(self._ctx, C.byref(index.view)))
+
+    def _chk(self, rc: int):
+        if rc:
+            raise RuntimeError(f"bmbs error {rc}: {self._lib.bmbs_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if self._ctx:
+            self._lib.bmbs_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def threshold(self, L: int) -> int:
+        k = int(np.uint64(self.params.e_f * L))   # Schema.cpp:24546
+        return min(k, 31)
+
+    # ---- fused single-end mapping ------------------------------------------------------------------
+    def map_se(self, seq: np.ndarray, qual: np.ndarray, L: int | None = None):
+        """seq/qual: uint8 [n, stride] (ASCII, upper case).  -> (results[n] RESULT_DTYPE, cigar_pool u32)"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        n, stride = seq.shape
+        L = stride if L is None else L
+        res = np.zeros(n, dtype=capi.RESULT_DTYPE)
+        cap = max(1, n * (2 * self.threshold(L) + 8))
+        pool = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        self._chk(self._lib.bmbs_map_se(self._ctx, capi.ptr(seq), capi.ptr(qual), L, stride, n, capi.ptr(res),
+                                        capi.ptr(pool), cap, C.byref(used)))
+        return res, pool[:used.value]
+
+    def map_se_device(self, d_seq: int, d_qual: int, L: int, stride: int, n: int, d_results: int,
+                      d_cigar_pool: int, cigar_cap: int):
+        self._chk(self._lib.bmbs_map_se_device(self._ctx, d_seq, d_qual, L, stride, n, d_results, d_cigar_pool, cigar_cap))
+
+    def sync(self):
+        self._chk(self._lib.bmbs_sync(self._ctx))
+
+    # ---- stages -------------------------------------------------------------------------------------
+    def filter(self, seq: np.ndarray, L: int, read_of: np.ndarray, site: np.ndarray):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        read_of = np.ascontiguousarray(read_of, dtype=np.uint32)
+        site = np.ascontiguousarray(site, dtype=np.uint64)
+        m = read_of.size
+        err = np.zeros(m, dtype=np.uint32)
+        end = np.zeros(m, dtype=np.int32)
+        self._chk(self._lib.bmbs_filter_batch(self._ctx, capi.ptr(seq), L, seq.shape[1], seq.shape[0], capi.ptr(read_of),
+                                              capi.ptr(site), m, capi.ptr(err), capi.ptr(end)))
+        return err, end
+
+    def align(self, seq, qual, L, read_of, site, end_in, err_in):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        read_of = np.ascontiguousarray(read_of, dtype=np.uint32)
+        site = np.ascontiguousarray(site, dtype=np.uint64)
+        end_in = np.ascontiguousarray(end_in, dtype=np.int32)
+        err_in = np.ascontiguousarray(err_in, dtype=np.uint32)
+        m = read_of.size
+        max_ops = 2 * self.threshold(L) + 8
+        out = {k: np.zeros(m, dtype=t) for k, t in (("start", np.int32), ("end", np.int32), ("nm", np.uint32),
+                                                     ("score", np.int32), ("n_ops", np.int32))}
+        ops = np.zeros((m, max_ops), dtype=np.uint32)
+        self._chk(self._lib.bmbs_align_batch(self._ctx, capi.ptr(seq), capi.ptr(qual), L, seq.shape[1], seq.shape[0],
+                                             capi.ptr(read_of), capi.ptr(site), capi.ptr(end_in), capi.ptr(err_in), m,
+                                             capi.ptr(out["start"]), capi.ptr(out["end"]), capi.ptr(out["nm"]),
+                                             capi.ptr(out["score"]), capi.ptr(ops), capi.ptr(out["n_ops"]), max_ops))
+        out["ops"] = ops
+        return out
+
+    def seed(self, seq: np.ndarray, L: int, vote_cap: int | None = None):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        n, stride = seq.shape
+        cap = vote_cap or max(1024, 64 * n)
+        verdict = np.zeros(n, dtype=np.uint8)
+        exit_site = np.zeros(n, dtype=np.uint64)
+        seg_off = np.zeros(n + 1, dtype=np.uint64)
+        n_votes = np.zeros(n, dtype=np.uint32)
+        vsite = np.zeros(cap, dtype=np.uint64)
+        vcnt = np.zeros(cap, dtype=np.uint32)
+        tot = C.c_int64(0)
+        self._chk(self._lib.bmbs_seed_batch(self._ctx, capi.ptr(seq), L, stride, n, capi.ptr(verdict), capi.ptr(exit_site),
+                                            capi.ptr(seg_off), capi.ptr(n_votes), capi.ptr(vsite), capi.ptr(vcnt), cap,
+                                            C.byref(tot)))
+        return dict(verdict=verdict, exit_site=exit_site, seg_off=seg_off, n_votes=n_votes, vote_site=vsite[:tot.value],
+                    vote_cnt=vcnt[:tot.value])
+
+    # ---- stats / measurement -----------------------------------------------------------------------
+    def stats(self) -> np.ndarray:
+        s = np.zeros(5, dtype=np.int64)
+        self._chk(self._lib.bmbs_stats_get(self._ctx, capi.ptr(s)))
+        return s
+
+    def reset_stats(self):
+        self._chk(self._lib.bmbs_stats_reset(self._ctx))
+
+    def profile(self) -> list[tuple[str, float]]:
+        n = C.c_int(64)
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        self._chk(self._lib.bmbs_profile_last(self._ctx, names, ms, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def counters(self) -> dict:
+        c = np.zeros(8, dtype=np.uint64)
+        self._chk(self._lib.bmbs_counters_last(self._ctx, capi.ptr(c)))
+        keys = ("n_hash", "n_ext", "n_sa", "n_filter", "n_sw", "n_ungapped", "n_cand_slots", "n_jobs")
+        return {k: int(v) for k, v in zip(keys, c)}
+
+
+# ---- SAM text (host emit) --------------------------------------------------------------------------
+def cigar_text(res_row, pool: np.ndarray, L: int) -> str:
+    n = int(res_row["n_cigar"])
+    if n == 0:
+        return "%dM" % L
+    ops = pool[int(res_row["cigar_off"]):int(res_row["cigar_off"]) + n]
+    return "".join("%d%s" % (int(o) >> 4, "MDISH"[int(o) & 0xf]) for o in ops)
+
+
+def sam_header(index: Index, command_line: str = "") -> str:
+    """OutPutSAM_Nounheader, Process_sam_out.cpp:1137-1153"""
+    out = ["@HD\tVN:1.4\tSO:unsorted"]
+    for nm, ln in zip(index.chrom_names, index.chrom_len):
+        out.append("@SQ\tSN:%s\tLN:%d" % (nm, int(ln)))
+    out.append("@PG\tID:BitMapperBS\tVN:1.0.2.3\tCL:%s" % command_line)
+    return "\n".join(out) + "\n"
+
+
+def sam_lines_se(index: Index, names, seq: np.ndarray, qual: np.ndarray, L: int, res: np.ndarray, pool: np.ndarray):
+    """output_sam_end_to_end text branch (Schema.cpp:11989-12039); one line per uniquely mapped read."""
+    out = []
+    for i in np.nonzero(res["status"] == capi.ST_UNIQUE)[0]:
+        r = res[i]
+        nm = names[i]
+        if isinstance(nm, bytes):
+            nm = nm.decode()
+        if nm.startswith("@"):
+            nm = nm[1:]
+        for cut in (" ", "/"):
+            j = nm.find(cut)
+            if j >= 0:
+                nm = nm[:j]
+        s, q = seq[i, :L], qual[i, :L]
+        if int(r["flag"]) & 16:
+            s = _COMP[s][::-1]
+            q = q[::-1]
+        out.append("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\n" % (
+            nm, int(r["flag"]), index.chrom_names[int(r["chrom"])], int(r["pos"]), int(r["mapq"]),
+            cigar_text(r, pool, L), s.tobytes().decode(), q.tobytes().decode(), int(r["nm"])))
+    return out

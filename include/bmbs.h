@@ -1,0 +1,174 @@
+/* include/bmbs.h -- C-ABI of the MI355X-native BitMapperBS mapping hot path (libbmbs_hip.so).
+ *
+ * BitMapperBS has no plugin/FFI layer: this is the boundary *cut* at L4 -> {L5,L6,L7}.
+ * A host driver that keeps BitMapperBS's CLI, FASTQ reader and SAM writer calls these entry points
+ * where the reference calls (per read, inline) the routines cited at each declaration; paths are
+ * relative to the reference tree.  Conventions kept from the reference side of the cut:
+ *   - index arrays are read-only after attach (Load_Index, Index.cpp:940);
+ *   - errors are status codes / sentinels, never exceptions: err = 0xFFFFFFFF, end_site = -1
+ *     (Levenshtein_Cal.h:354,512), calls return 0 or a negative BMBS_E*;
+ *   - the caller owns host buffers, the library owns device buffers; one bmbs_ctx per GPU;
+ *     calls on one ctx are serialised by the caller, different ctxs are fully concurrent.
+ * Plain C types only (no torch / HIP types in any signature).
+ */
+#ifndef BMBS_H
+#define BMBS_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMBS_OK            0
+#define BMBS_EINVAL      (-22)
+#define BMBS_ENOMEM      (-12)
+#define BMBS_ENODEV      (-19)   /* no HIP device / runtime error: the product never falls back to CPU */
+#define BMBS_ESTATE       (-1)   /* index not attached, batch too large, ... */
+
+typedef struct bmbs_ctx bmbs_ctx;
+
+/* mapping parameters == the reference's option globals (Process_CommandLines.cpp:40-75,88-132) */
+typedef struct bmbs_params {
+    double  e_f;        /* -e, thread_e_f: k = (uint64)(e_f * L) capped at 31 (Schema.cpp:24546)   */
+    int32_t mp_max;     /* --mp_max 6  */
+    int32_t mp_min;     /* --mp_min 2  */
+    int32_t np;         /* --np 1      */
+    int32_t gap_open;   /* --gap_open 5 */
+    int32_t gap_ext;    /* --gap_extension 3 */
+    int32_t q_base;     /* 33 | 64     */
+    int32_t seed_len;   /* --seed (over_all_seed_length) 30 */
+    int32_t min_ins;    /* --min 0     */
+    int32_t max_ins;    /* --max 500   */
+    int32_t sensitive;  /* --sensitive */
+    int32_t reserved;
+} bmbs_params;
+
+void bmbs_default_params(bmbs_params* p);
+
+/* host view of the reference's loaded index: global `bitmapper_index_params` (bwt.h:34-163, filled by
+ * load_index, bwt.cpp:2563-2643), the 2-bit genome `_ih_refGen` and the chromosome table
+ * (Load_Index, Index.cpp:940-1045).  All pointers are host memory in the on-disk layouts. */
+typedef struct bmbs_index_view {
+    uint64_t        ref_len;            /* refGenLength (one strand) */
+    const uint8_t*  pac;                /* .bs.pac payload, 4 bases/byte MSB first */
+    uint64_t        pac_bytes;
+    uint64_t        sa_length;          /* rows = 2*ref_len + 1 */
+    uint64_t        shapline;
+    uint64_t        nacgt[5];
+    const uint64_t* bwt;                /* 5 x u64 per 128 rows */
+    uint64_t        bwt_words;
+    const uint64_t* high_occ;           /* 2 x u64 per 65536 rows */
+    uint64_t        high_occ_words;
+    const uint32_t* hash_hi;            /* 16-mer table, 3^16+1 entries */
+    const uint8_t*  hash_lo;
+    uint64_t        hash_entries;
+    const uint32_t* sa;                 /* sampled SA (every 8th text position) */
+    uint64_t        sa_entries;
+    const uint64_t* sa_flag;            /* 5 x u64 per 256 rows */
+    uint64_t        sa_flag_words;
+    int32_t         n_chrom;
+    const uint64_t* chrom_len;          /* _rg_chrome_length[n_chrom] */
+} bmbs_index_view;
+
+/* one mapped read; 32 bytes.  What output_sam_end_to_end (Schema.cpp:11928) is handed, after the
+ * chromosome lookup and the off-end check it performs (11962-11986). */
+typedef struct bmbs_result {
+    uint64_t pos;          /* 1-based position on `chrom`                                    */
+    uint32_t cigar_off;    /* first op in the cigar pool (only when n_cigar > 0; else "<L>M") */
+    int16_t  chrom;        /* chromosome id                                                  */
+    uint8_t  status;       /* BMBS_ST_*                                                      */
+    uint8_t  mapq;
+    uint16_t flag;         /* 0 | 16 (SE)                                                    */
+    uint16_t nm;           /* NM:i                                                           */
+    int16_t  score;        /* alignment score (<= 0)                                         */
+    uint8_t  n_cigar;      /* ops in the pool; 0 means the single op <L>M                    */
+    uint8_t  path;         /* 1 exact-unique exit, 2 one-mismatch exit, 3 general, 4 exact-ambiguous */
+    uint32_t n_cand;       /* candidate sites located for this read (diagnostic)             */
+    uint32_t reserved;
+} bmbs_result;
+
+#define BMBS_ST_UNMAPPED  0
+#define BMBS_ST_UNIQUE    1   /* a SAM record is emitted                                       */
+#define BMBS_ST_AMBIG     2   /* counted as ambiguous, nothing emitted (no --ambiguous_out)     */
+#define BMBS_ST_OFFEND    3   /* alignment crosses a chromosome end: rejected at emit           */
+
+/* cigar op = len << 4 | op, op 0 M, 1 D, 2 I, already in SAM (left-to-right on the forward strand)
+ * order (ksw.cpp:2785-2857 prints them forward or reversed by strand) */
+
+/* ---- lifecycle -------------------------------------------------------------------------------- */
+/* replaces Prepare_alignment (Schema.cpp:639: LUTs, score matrices) for one GPU                 */
+bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params);
+void      bmbs_destroy(bmbs_ctx*);
+const char* bmbs_last_error(const bmbs_ctx*);
+/* replaces the in-memory result of Load_Index + load_index: uploads once, re-packs for HBM        */
+int bmbs_index_attach(bmbs_ctx*, const bmbs_index_view*);
+
+/* ---- stage entry points (host buffers in, host buffers out; used by the parity tests) ---------- */
+/* reads: n rows of `stride` bytes ASCII upper-case (as produced by inputReads_single_directly,
+ * Process_Reads.cpp:810), all of length L. */
+
+/* K7+K8: get_actuall_[rc_]genome + BS_Reserve_Banded_BPM{,_4_SSE,_8_SSE}
+ * (Schema.cpp:4998-5115; Levenshtein_Cal.h:351,1678,2093): candidate i = (read_of[i], site[i]).   */
+int bmbs_filter_batch(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
+                      const uint32_t* read_of, const uint64_t* site, int64_t n_cand,
+                      uint32_t* err, int32_t* end_site);
+
+/* K11-K13: fast_recalculate_bs_Cigar (ksw.cpp:2578) for job i = (read_of[i], site[i], end_site[i],
+ * err[i]); cigar ops: max_ops per job, SAM order.                                                  */
+int bmbs_align_batch(bmbs_ctx*, const char* seq, const char* qual, int32_t L, int32_t stride,
+                     int64_t n_reads, const uint32_t* read_of, const uint64_t* site,
+                     const int32_t* end_site_in, const uint32_t* err_in, int64_t n_jobs,
+                     int32_t* start_site, int32_t* end_site, uint32_t* nm, int32_t* score,
+                     uint32_t* cigar_ops, int32_t* n_ops, int32_t max_ops);
+
+/* K1-K6 (+a8-a10): the seeding state machine of Map_Single_Seq_end_to_end (Schema.cpp:24588-24986).
+ * verdict[i]: 0 no candidate, 1 exact-unique exit (exit_site), 2 one-mismatch exit (exit_site),
+ * 3 general path, 4 exact but ambiguous.  For verdict 3 the read's votes, in the reference's visiting
+ * order (std::sort by vote, Schema.cpp:24986), are vote_site/vote_cnt[seg_off[i] .. seg_off[i]+n_votes[i]). */
+int bmbs_seed_batch(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
+                    uint8_t* verdict, uint64_t* exit_site, uint64_t* seg_off, uint32_t* n_votes,
+                    uint64_t* vote_site, uint32_t* vote_cnt, int64_t vote_cap, int64_t* total_slots);
+
+/* ---- fused single-end mapping (Map_Single_Seq_end_to_end loop body, Schema.cpp:24488-25119) ---- */
+/* host buffers: copies in, maps, copies results out.  cigar_pool[cigar_cap] receives the ops.      */
+int bmbs_map_se(bmbs_ctx*, const char* seq, const char* qual, int32_t L, int32_t stride,
+                int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
+                int64_t* n_cigar_used);
+/* device-resident variant: d_seq/d_qual/d_results/d_cigar_pool are device addresses (e.g. from
+ * torch tensors); nothing crosses PCIe; asynchronous on the ctx stream until bmbs_sync().          */
+int bmbs_map_se_device(bmbs_ctx*, uint64_t d_seq, uint64_t d_qual, int32_t L, int32_t stride,
+                       int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap);
+int bmbs_sync(bmbs_ctx*);
+
+/* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
+ * error bases} (Schema.cpp:25141-25146); bmbs_stats_allreduce sums them over the ctxs one process
+ * drives (get_mapping_informations, Schema.cpp:451-476).  Multi-process jobs sum the five int64 with
+ * one RCCL all-reduce in the host layer (bitmapperbs_amd.distributed).                             */
+int bmbs_stats_get(bmbs_ctx*, int64_t stats[5]);
+int bmbs_stats_reset(bmbs_ctx*);
+int bmbs_stats_allreduce(bmbs_ctx** ctxs, int n, int64_t stats[5]);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+/* per-kernel HIP-event timings of the last bmbs_map_se[_device] call, on the ctx stream.
+ * names/ms arrays of length >= *n (in: capacity, out: count).                                     */
+int bmbs_profile_last(bmbs_ctx*, const char** names, float* ms, int* n);
+/* event counters of the last call for the algorithmic-byte model:
+ * c[0]=n_hash c[1]=n_ext(LF pairs) c[2]=n_sa c[3]=n_cand(windows filtered) c[4]=n_sw c[5]=n_ungapped
+ * c[6]=window bytes                                                                               */
+int bmbs_counters_last(bmbs_ctx*, uint64_t c[8]);
+
+/* ---- index files (next-row (f)2: reader/writer of the reference's on-disk formats) ------------- */
+typedef struct bmbs_index_file bmbs_index_file;
+/* Load_Index/load_index equivalents: reads <prefix>.index, .index.bs.pac, .index.bs.index{,.bwt,.sa,.occ} */
+bmbs_index_file* bmbs_index_file_load(const char* prefix);
+void bmbs_index_file_view(const bmbs_index_file*, bmbs_index_view* out);
+const char* bmbs_index_file_chrom_name(const bmbs_index_file*, int i);
+void bmbs_index_file_free(bmbs_index_file*);
+/* createIndex equivalent (Index.cpp:832-938) without the psascan dependency: FASTA -> the six files */
+int bmbs_index_build(const char* fasta, const char* prefix, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""ctypes binding of oracle/liboracle.so -- the CHECKER.  Only tests/, smoke() and bench.py's
+cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("e_f", C.c_double), ("mp_max", C.c_int), ("mp_min", C.c_int), ("np", C.c_int), ("gap_open", C.c_int),
+                ("gap_ext", C.c_int), ("q_base", C.c_int), ("seed_len", C.c_int), ("min_ins", C.c_int),
+                ("max_ins", C.c_int), ("sensitive", C.c_int)]
+
+
+REC_DTYPE = np.dtype([("status", "<i4"), ("chrom", "<i4"), ("pos", "<u8"), ("site", "<u8"), ("start_site", "<i4"),
+                      ("end_site", "<i4"), ("flag", "<i4"), ("mapq", "<i4"), ("nm", "<i4"), ("score", "<i4"),
+                      ("path", "<i4"), ("n_cand", "<i4"), ("n_votes", "<i4"), ("cigar", "S256"), ("_pad", "<i4")])
+COUNTER_KEYS = ("n_reads", "n_hash", "n_ext", "n_lf", "n_sa1", "n_locate_rows", "n_cand", "n_sw", "n_ungapped")
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ODIR], check=True)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(ODIR, "liboracle.so")
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".cpp", ".h"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        build()
+    L = C.CDLL(so)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
+    L.orc_index_build.argtypes = [C.c_char_p, C.c_char_p]
+    L.orc_index_load.argtypes = [C.c_char_p]
+    L.orc_index_load.restype = vp
+    L.orc_index_free.argtypes = [vp]
+    L.orc_index_genome_len.argtypes = [vp]
+    L.orc_index_genome_len.restype = C.c_uint64
+    L.orc_window.argtypes = [vp, C.c_uint64, i32, vp]
+    L.orc_bpm.argtypes = [vp, i32, vp, i32, i32, vp]
+    L.orc_align.argtypes = [C.POINTER(OrcParams), vp, i32, vp, vp, i32, i32, i32, C.c_uint, i32, i32, vp, vp, vp, vp, vp]
+    L.orc_mapq.argtypes = [C.POINTER(OrcParams), C.c_uint, C.c_uint, i32]
+    L.orc_sa_at.argtypes = [vp, C.c_uint64]
+    L.orc_sa_at.restype = C.c_uint64
+    L.orc_map_se.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, i32, i64, vp, vp, vp]
+    L.orc_search_se.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, vp]
+    L.orc_search_pe.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp]
+    assert C.sizeof(OrcParams) == 48
+    _lib = L
+    return L
+
+
+def params(**kw):
+    p = OrcParams()
+    load().orc_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class OrcIndex:
+    def __init__(self, prefix):
+        self.L = load()
+        self.h = self.L.orc_index_load(prefix.encode())
+        if not self.h:
+            raise FileNotFoundError(prefix)
+        self.G = int(self.L.orc_index_genome_len(self.h))
+
+    def window(self, site, n):
+        buf = np.zeros(n + 8, dtype=np.uint8)
+        self.L.orc_window(self.h, int(site), n, buf.ctypes.data)
+        return buf[:n]
+
+    def map_se(self, prm, seq, qual, L):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        n, stride = seq.shape
+        ln = np.full(n, L, dtype=np.int32)
+        recs = np.zeros(n, dtype=REC_DTYPE)
+        assert REC_DTYPE.itemsize == 320, REC_DTYPE.itemsize
+        st = np.zeros(5, dtype=np.int64)
+        cnt = np.zeros(len(COUNTER_KEYS), dtype=np.uint64)
+        rc = self.L.orc_map_se(self.h, C.byref(prm), seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, stride, n,
+                               recs.ctypes.data, st.ctypes.data, cnt.ctypes.data)
+        assert rc == 0
+        return recs, st, dict(zip(COUNTER_KEYS, (int(x) for x in cnt)))
+
+    def close(self):
+        if self.h:
+            self.L.orc_index_free(self.h)
+            self.h = None
+
+
+def bpm(window, read, k):
+    L = load()
+    w = np.ascontiguousarray(window, dtype=np.uint8)
+    r = np.ascontiguousarray(read, dtype=np.uint8)
+    wbuf = np.concatenate([w, np.zeros(8, np.uint8)])
+    err = C.c_uint(0)
+    end = L.orc_bpm(wbuf.ctypes.data, w.size, r.ctypes.data, r.size, k, C.byref(err))
+    return err.value, end
+
+
+def align(prm, window, read, qual, k, end_site, err, is_forward, reverse_quality=0):
+    L = load()
+    w = np.concatenate([np.ascontiguousarray(window, dtype=np.uint8), np.zeros(8, np.uint8)])
+    r = np.ascontiguousarray(read, dtype=np.uint8)
+    q = np.ascontiguousarray(qual, dtype=np.uint8)
+    s, e, nm, sc = C.c_int(0), C.c_int(0), C.c_uint(0), C.c_int(0)
+    cg = C.create_string_buffer(1024)
+    L.orc_align(C.byref(prm), w.ctypes.data, w.size - 8, r.ctypes.data, q.ctypes.data, r.size, k, end_site, err, is_forward,
+                reverse_quality, C.byref(s), C.byref(e), C.byref(nm), C.byref(sc), cg)
+    return dict(start=s.value, end=e.value, nm=nm.value, score=sc.value, cigar=cg.value.decode())
