@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the MI355X bisulfite mapping hot path.
+
+Workload (BASELINE.json configs[1]): synthetic 150 bp single-end bisulfite reads against a
+chr21-size (46 Mb, 4 chromosomes, N-free) synthetic genome, -e 0.04; one "step" = one pass of the
+whole device pipeline (seed -> locate -> vote -> Myers filter -> reduce -> align -> finalize) over one
+batch of reads that is already resident in HBM; results (32-byte records + CIGAR pool) stay in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--genome G]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU); reads shard by rank (weak scaling,
+index replicated per GPU, no data-path collective); the only collective is the RCCL all-reduce of
+the five mapstats counters (Schema.cpp:451-476).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--genome", type=int, default=46_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("-e", type=float, default=0.04)
+    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed on the host CPU baseline (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("BMBS_BENCH_DIR", "/tmp/bmbs_bench"))
+    return ap.parse_args()
+
+
+def ensure_index(args, rank, world, dist):
+    from bitmapperbs_amd import synth, mapper
+    wd = os.path.join(args.workdir, "g%d" % args.genome)
+    fa = os.path.join(wd, "g.fa")
+    names, chroms = synth.make_genome(args.genome, 4, seed=20240229)
+    if rank == 0:
+        os.makedirs(wd, exist_ok=True)
+        if not os.path.exists(fa + ".index.bs.index.sa"):
+            synth.write_fasta(fa, names, chroms)
+            t = time.time()
+            mapper.Index.build(fa, fa, threads=min(16, os.cpu_count() or 1))
+            sys.stderr.write("[bench] index built in %.1fs\n" % (time.time() - t))
+    if world > 1:
+        dist.barrier()
+    return fa, names, chroms
+
+
+def write_fastq_sample(path, seq, qual, L):
+    """vectorised FASTQ writer: fixed-width names s%08d -> fixed record length"""
+    n = seq.shape[0]
+    rec = np.empty((n, 1 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("s")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(8):
+        rec[:, 2 + d] = (idx // 10 ** (7 - d)) % 10 + ord("0")
+    rec[:, 10] = 10
+    rec[:, 11:11 + L] = seq[:, :L]
+    rec[:, 11 + L] = 10; rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
+    rec[:, 14 + L:14 + 2 * L] = qual[:, :L]
+    rec[:, 14 + 2 * L] = 10
+    rec.tofile(path)
+
+
+def cpu_baseline(args, fa, seq_h, qual_h, L):
+    """Time the reference's own CPU path (oracle/_ref/bitmapperBS, kind 'reference') -- or, when it has
+    not been built, the scalar restatement (oracle/liboracle.so, kind 'port') -- on a bounded sample."""
+    n = seq_h.shape[0]
+    ref = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS")
+    sample = "first %d reads of the step batch (150 bp SE, e=%.2f)" % (n, args.e)
+    if os.path.exists(ref):
+        fq = os.path.join(args.workdir, "cpu_sample.fq")
+        write_fastq_sample(fq, seq_h, qual_h, L)
+        cores = min(8, os.cpu_count() or 1)
+        out = os.path.join(args.workdir, "cpu_sample.sam")
+        p = subprocess.run([ref, "--search", fa, "--seq", fq, "-e", str(args.e), "-t", str(cores), "-o", out],
+                           capture_output=True, text=True, cwd=args.workdir)
+        secs = None
+        for line in p.stderr.splitlines():
+            if line.strip().startswith("Total:"):
+                secs = float(line.split()[2])          # "Total: <load s> <map s>" (Bitmapper_main.cpp:262)
+        if p.returncode == 0 and secs and secs > 0:
+            return {"value": n / secs / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
+                    "sample": sample + ", bitmapperBS -t %d, mapping seconds as printed by main" % cores}, out
+    # port
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    oix = orc.OrcIndex(fa)
+    m = min(n, 300_000)
+    t = time.time()
+    oix.map_se(orc.params(e_f=args.e), seq_h[:m], qual_h[:m], L)
+    dt = time.time() - t
+    return {"value": m / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the step batch, scalar CPU restatement (oracle/)" % m}, None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the mapping path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    from bitmapperbs_amd import mapper, gpusynth, capi
+
+    fa, names, chroms = ensure_index(args, rank, world, dist)
+    L = args.read_len
+    stride = (L + 15) // 16 * 16
+    n = args.reads
+    ix = mapper.Index(fa)
+    m = mapper.Mapper(ix, device=local, e_f=args.e)
+    k = m.threshold(L)
+    genome_d, lens_d = gpusynth.upload_genome(chroms)
+    seq_d, qual_d = gpusynth.make_reads_se(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank)
+    del genome_d
+    max_ops = 2 * k + 8
+    cig_cap = n * max_ops
+    res_d = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    cig_d = torch.empty((cig_cap,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        m.map_se_device(seq_d.data_ptr(), qual_d.data_ptr(), L, stride, n, res_d.data_ptr(), cig_d.data_ptr(), cig_cap)
+        m.sync()
+
+    for _ in range(args.warmup):
+        step()
+    m.reset_stats()
+    m.sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kern_ms: dict[str, float] = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, ms in m.profile():
+            kern_ms[name] = kern_ms.get(name, 0.0) + ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = torch.from_numpy(m.stats()).cuda()
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)        # the only collective: 5 x int64 mapstats
+    dt = float(tt.item())
+    stats = stats.cpu().numpy()
+    cnt = m.counters()
+    for kname in kern_ms:
+        kern_ms[kname] /= max(1, args.steps)
+
+    if rank == 0:
+        total_reads = n * world * args.steps
+        value = total_reads / dt / 1e6
+        dom = max(kern_ms, key=kern_ms.get) if kern_ms else "k_seed"
+        # algorithmic bytes of one launch (SURVEY.md §8d per-unit figures x this launch's event counts)
+        win = (L + 2 * k + 3) // 4 + 1
+        alg = {
+            "k_seed": L * n + 10 * cnt["n_hash"] + 80 * cnt["n_ext"] + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1) * cnt["n_ungapped"],
+            "k_locate": 4 * cnt["n_cand_slots"] + 8 * cnt["n_cand_slots"],
+            "k_vote": 8 * cnt["n_cand_slots"] + 16 * cnt["n_cand_slots"],
+            "k_filter": (win + L + 16 + 8) * cnt["n_filter"],
+            "k_align": (win + 2 * L + 4 * max_ops) * cnt["n_sw"],
+            "k_finalize": 32 * n,
+        }
+        bytes_dom = alg.get(dom, 0)
+        ach = bytes_dom / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0
+        out = {
+            "metric": "M 150bp reads aligned/s", "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic %d bp SE bisulfite reads per GPU per step vs %d bp "
+                                   "4-chromosome synthetic (chr21-size) genome, -e %.2f (k=%d), inputs and results resident in HBM"
+                                   % (n, L, args.genome, args.e, k),
+                       "reads_per_gpu_per_step": n, "read_len": L, "genome_bp": args.genome,
+                       "parallelism": "reads sharded by rank, index replicated, RCCL all-reduce of 5 mapstats counters"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(bytes_dom), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4)},
+            "kernels_ms_per_step": {a: round(b, 4) for a, b in kern_ms.items()},
+            "counters_per_step": cnt,
+            "mapstats": {"reads": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
+                         "unmapped": int(stats[0] - stats[1] - stats[2]), "mapped_bases": int(stats[3]), "error_bases": int(stats[4])},
+        }
+        if world == 1 and not args.no_cpu:
+            ns = min(n, args.cpu_sample)
+            seq_h = seq_d[:ns].cpu().numpy()
+            qual_h = qual_d[:ns].cpu().numpy()
+            cb, ref_sam = cpu_baseline(args, fa, seq_h, qual_h, L)
+            out["cpu_baseline"] = cb
+            if ref_sam:
+                # bonus check: the GPU records of the same sample print the same SAM lines as the reference
+                nchk = min(ns, 200_000)
+                res_h = res_d[:nchk].cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1)
+                cig_h = cig_d.cpu().numpy().view(np.uint32)
+                names_s = [b"s%08d" % i for i in range(nchk)]
+                mine = set(mapper.sam_lines_se(ix, names_s, seq_h[:nchk], qual_h[:nchk], L, res_h, cig_h))
+                with open(ref_sam) as f:
+                    theirs = set(x for x in f if not x.startswith("@") and int(x[1:x.index("\t")]) < nchk)
+                out["sample_sam_identical_to_reference"] = (mine == theirs)
+                out["sample_sam_lines_compared"] = len(theirs)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
