@@ -1,0 +1,84 @@
+"""shared helpers for the test-suite"""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+
+
+def gunzip_to(src, dst):
+    with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+        g.write(f.read())
+
+
+def golden_args():
+    return json.load(open(os.path.join(GOLD, "se_args.json")))
+
+
+def e_of(args):
+    return float(args[args.index("-e") + 1]) if "-e" in args else 0.08
+
+
+def read_fastq(path):
+    """-> names(list[bytes]), seq[n,L] u8, qual[n,L] u8 (all reads equal length)"""
+    names, seqs, quals = [], [], []
+    with open(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            s = f.readline().rstrip(b"\n"); f.readline(); q = f.readline().rstrip(b"\n")
+            names.append(h.rstrip(b"\n")[1:]); seqs.append(s.upper()); quals.append(q)
+    L = len(seqs[0])
+    assert all(len(s) == L for s in seqs)
+    return names, np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(-1, L).copy(), \
+        np.frombuffer(b"".join(quals), dtype=np.uint8).reshape(-1, L).copy()
+
+
+def sha_file(path, drop_tail=0):
+    b = open(path, "rb").read()
+    if drop_tail:
+        b = b[:-drop_tail]
+    return hashlib.sha256(b).hexdigest()
+
+
+def plant_repeats(chroms, seed=202, spec=((400, 40, 0.03), (1500, 6, 0.01), (150, 60, 0.0), (60, 80, 0.0))):
+    from bitmapperbs_amd import synth
+    rng = np.random.default_rng(seed)
+    for (elen, copies, div) in spec:
+        el = synth._ACGT[rng.integers(0, 4, elen)]
+        for c in range(copies):
+            ch = chroms[rng.integers(0, len(chroms))]
+            p = int(rng.integers(0, ch.size - elen))
+            e = el.copy(); m = rng.random(elen) < rng.random() * div
+            e[m] = synth._ACGT[rng.integers(0, 4, int(m.sum()))]
+            if rng.random() < 0.5:
+                e = synth.revcomp(e)
+            ch[p:p + elen] = e
+
+
+def orc_sam_lines(index_names, names, seq, qual, L, recs):
+    """SAM lines from ORACLE records, for comparisons with host-side emit"""
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    out = []
+    for i in np.nonzero(recs["status"] == 1)[0]:
+        r = recs[i]
+        nm = names[i].decode()
+        for cut in (" ", "/"):
+            j = nm.find(cut)
+            if j >= 0:
+                nm = nm[:j]
+        s, q = seq[i, :L], qual[i, :L]
+        if int(r["flag"]) & 16:
+            s = comp[s][::-1]; q = q[::-1]
+        out.append("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\n" % (
+            nm, int(r["flag"]), index_names[int(r["chrom"])], int(r["pos"]), int(r["mapq"]), r["cigar"].decode(),
+            s.tobytes().decode(), q.tobytes().decode(), int(r["nm"])))
+    return out

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory by RUNNING THE REAL REFERENCE here.
+
+  python tests/golden/make_golden.py [--psascan /path/to/psascan]
+
+Needs oracle/_ref/bitmapperBS (oracle/build_ref.sh; /root/reference present).  Fixtures are data only:
+  genome.fa.gz                   seeded synthetic genome (2 x 150 kb + planted repeats)
+  se_<name>.fq.gz                seeded synthetic reads
+  se_<name>.ref.sam.gz           SAM written by the reference (`bitmapperBS --search ... -t 1`)
+  se_<name>.ref.stats            the reference's mapstats text
+  index_ref_sha256.json          sha256 of the index files the REFERENCE's own `--index` wrote for
+                                 genome.fa (needs the reference's external ./psascan binary, which is
+                                 built from its vendored pSAscan/libdivsufsort with cmake -- not part of
+                                 oracle/build_ref.sh; pass --psascan to refresh this file only).
+The index the search runs use is built by the oracle builder (its byte-identity with the reference-built
+index is exactly what index_ref_sha256.json pins).
+"""
+import argparse, gzip, hashlib, json, os, shutil, subprocess, sys, tempfile
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bitmapperbs_amd import synth
+import orc
+
+SETS = {
+    "a100": dict(reads=dict(n=1500, L=100, seed=1, sub=0.005, indel=0.0002, qual="const"), args=[]),
+    "b150": dict(reads=dict(n=1500, L=150, seed=2, sub=0.02, indel=0.002, qual="random", n_rate=0.002), args=["-e", "0.04"]),
+    "c150": dict(reads=dict(n=1200, L=150, seed=3, sub=0.03, indel=0.003, qual="random", conv=0.9), args=[]),
+    "d250": dict(reads=dict(n=600, L=250, seed=4, sub=0.03, indel=0.001, qual="random"), args=[]),
+    "e75": dict(reads=dict(n=1500, L=75, seed=5, sub=0.04, indel=0.004, qual="random", n_rate=0.01), args=[]),
+}
+
+def genome():
+    names, chroms = synth.make_genome(300_000, 2, seed=101)
+    rng = np.random.default_rng(202)
+    for (elen, copies, div) in [(400, 40, 0.03), (1500, 6, 0.01), (150, 60, 0.0), (60, 80, 0.0)]:
+        el = synth._ACGT[rng.integers(0, 4, elen)]
+        for c in range(copies):
+            ch = chroms[rng.integers(0, len(chroms))]
+            p = int(rng.integers(0, ch.size - elen))
+            e = el.copy(); m = rng.random(elen) < rng.random() * div
+            e[m] = synth._ACGT[rng.integers(0, 4, int(m.sum()))]
+            if rng.random() < 0.5: e = synth.revcomp(e)
+            ch[p:p + elen] = e
+    return names, chroms
+
+def sha(path, drop_tail=0):
+    b = open(path, "rb").read()
+    if drop_tail: b = b[:-drop_tail]
+    return hashlib.sha256(b).hexdigest()
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--psascan"); a = ap.parse_args()
+    ref = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS")
+    assert os.path.exists(ref), "build the reference first: oracle/build_ref.sh"
+    wd = tempfile.mkdtemp(prefix="golden_")
+    names, chroms = genome()
+    fa = os.path.join(wd, "genome.fa")
+    synth.write_fasta(fa, names, chroms)
+    with open(fa, "rb") as f, gzip.GzipFile(os.path.join(HERE, "genome.fa.gz"), "wb", mtime=0) as g: g.write(f.read())
+    if a.psascan:
+        iw = os.path.join(wd, "refidx"); os.makedirs(iw)
+        shutil.copy(fa, os.path.join(iw, "genome.fa")); shutil.copy(a.psascan, os.path.join(iw, "psascan"))
+        subprocess.run([ref, "--index", "genome.fa"], cwd=iw, check=True, capture_output=True)
+        h = {}
+        for s in ("index", "index.bs.pac", "index.bs.index", "index.bs.index.occ", "index.bs.index.bwt"):
+            h[s] = sha(os.path.join(iw, "genome.fa." + s))
+        # the reference writes one uninitialised trailing SA_flag word (bwt.cpp:1690-1700): hash without it
+        h["index.bs.index.sa[:-8]"] = sha(os.path.join(iw, "genome.fa.index.bs.index.sa"), 8)
+        json.dump(h, open(os.path.join(HERE, "index_ref_sha256.json"), "w"), indent=1)
+    orc.load().orc_index_build(fa.encode(), fa.encode())
+    for name, cfg in SETS.items():
+        r = synth.make_reads_se(chroms, **cfg["reads"])
+        fq = os.path.join(wd, "se_%s.fq" % name)
+        synth.write_fastq(fq, r)
+        sam = os.path.join(wd, "se_%s.sam" % name)
+        p = subprocess.run([ref, "--search", fa, "--seq", fq, "-t", "1", "-o", sam] + cfg["args"], capture_output=True, text=True, cwd=wd)
+        assert p.returncode == 0, p.stderr
+        with open(fq, "rb") as f, gzip.GzipFile(os.path.join(HERE, "se_%s.fq.gz" % name), "wb", mtime=0) as g: g.write(f.read())
+        body = "".join(l for l in open(sam) if not l.startswith("@PG"))
+        with gzip.GzipFile(os.path.join(HERE, "se_%s.ref.sam.gz" % name), "wb", mtime=0) as g: g.write(body.encode())
+        stats = "".join(l for l in p.stderr.splitlines(True) if l.startswith("No. of") or l.startswith("Mismatch"))
+        open(os.path.join(HERE, "se_%s.ref.stats" % name), "w").write(stats)
+        print(name, "lines", body.count("\n"), stats.splitlines()[1])
+    json.dump({k: v["args"] for k, v in SETS.items()}, open(os.path.join(HERE, "se_args.json"), "w"))
+    shutil.rmtree(wd)
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,42 @@
+"""The C-ABI library loads and exports every symbol include/bmbs.h declares (no compute calls)."""
+import os
+import re
+
+from common import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from bitmapperbs_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "bmbs.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(bmbs_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = capi.lib()
+    for s in declared:
+        assert hasattr(lib, s), "libbmbs_hip.so does not export %s" % s
+    assert sorted(capi.SYMBOLS) == declared
+
+
+def test_result_record_is_32_bytes():
+    from bitmapperbs_amd import capi
+    assert capi.RESULT_DTYPE.itemsize == 32
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a HIP device bmbs_create must fail (NULL), never silently fall back."""
+    import ctypes as C
+    from bitmapperbs_amd import capi
+    import torch
+    if torch.cuda.is_available():
+        return
+    assert not capi.lib().bmbs_create(0, C.byref(capi.default_params()))
+
+
+def test_product_does_not_reference_oracle():
+    """nothing under bitmapperbs_amd/ may import, link or execute oracle/"""
+    pk = os.path.join(ROOT, "bitmapperbs_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liboracle" not in txt and "orc_" not in txt and "import orc" not in txt, os.path.join(dp, f)

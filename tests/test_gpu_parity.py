@@ -1,0 +1,238 @@
+"""-m gpu: parity of the HIP path (through the C-ABI) with the oracle on identical seeded inputs, against
+the committed golden SAM of the reference, and -- at BASELINE.json's full batch size -- through
+size-independent properties.  Bit-exact everywhere: integer / byte / index work."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from common import GOLD, e_of, golden_args, gunzip_to, plant_repeats, read_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+def compare_records(res, pool, recs, L):
+    from bitmapperbs_amd import mapper
+    bad = []
+    assert res.size == recs.size
+    st_ok = res["status"].astype(np.int64) == recs["status"].astype(np.int64)
+    for i in np.nonzero(~st_ok)[0][:5]:
+        bad.append((int(i), "status", int(res[i]["status"]), int(recs[i]["status"])))
+    mapped = np.nonzero(st_ok & ((recs["status"] == 1) | (recs["status"] == 3)))[0]
+    for f in ("chrom", "pos", "flag", "mapq", "nm", "score", "path"):
+        neq = mapped[res[f][mapped].astype(np.int64) != recs[f][mapped].astype(np.int64)]
+        for i in neq[:5]:
+            bad.append((int(i), f, int(res[i][f]), int(recs[i][f])))
+    for i in mapped:
+        if int(res[i]["n_cigar"]) or recs[i]["cigar"] != b"%dM" % L:
+            if mapper.cigar_text(res[i], pool, L) != recs[i]["cigar"].decode():
+                bad.append((int(i), "cigar", mapper.cigar_text(res[i], pool, L), recs[i]["cigar"].decode()))
+    return bad
+
+
+@pytest.fixture(scope="module")
+def env(tmp_path_factory):
+    """a repeat-rich 3-chromosome genome + product-built index + both handles"""
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from bitmapperbs_amd import synth, mapper
+    wd = tmp_path_factory.mktemp("gpu")
+    names, chroms = synth.make_genome(1_500_000, 3, seed=77)
+    plant_repeats(chroms, seed=78)
+    fa = str(wd / "g.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=8)
+    return dict(fa=fa, chroms=chroms, ix=mapper.Index(fa), oix=orc.OrcIndex(fa), wd=str(wd))
+
+
+CASES = [
+    dict(n=30000, L=100, seed=1, sub=0.005, indel=0.0002, qual="const", e=0.08),
+    dict(n=30000, L=150, seed=2, sub=0.02, indel=0.002, qual="random", n_rate=0.002, e=0.04),
+    dict(n=20000, L=150, seed=3, sub=0.04, indel=0.003, qual="random", conv=0.8, e=0.08),
+    dict(n=8000, L=250, seed=4, sub=0.03, indel=0.001, qual="random", e=0.08),
+    dict(n=20000, L=75, seed=5, sub=0.04, indel=0.004, qual="random", n_rate=0.01, e=0.08),
+    dict(n=10000, L=36, seed=6, sub=0.02, indel=0.0, qual="random", e=0.1),
+    dict(n=2000, L=400, seed=7, sub=0.03, indel=0.001, qual="random", e=0.08),        # k = 31 cap... (32 -> 31)
+    dict(n=5000, L=150, seed=8, sub=0.0, indel=0.0, qual="const", conv=0.0, e=0.0),   # k = 0
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "L%d_e%.2f_s%d" % (c["L"], c["e"], c["seed"]))
+def test_map_se_records_and_stats_match_oracle(case, env):
+    from bitmapperbs_amd import synth, mapper
+    c = dict(case); e = c.pop("e")
+    r = synth.make_reads_se(env["chroms"], **c)
+    L = c["L"]
+    m = mapper.Mapper(env["ix"], 0, e_f=e)
+    res, pool = m.map_se(r["seq"], r["qual"], L)
+    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=e), r["seq"], r["qual"], L)
+    bad = compare_records(res, pool, recs, L)
+    assert not bad, bad[:10]
+    assert (m.stats() == ost).all()
+    g = m.counters()
+    assert (g["n_hash"], g["n_ext"], g["n_filter"], g["n_sw"], g["n_ungapped"]) == \
+           (cnt["n_hash"], cnt["n_ext"], cnt["n_cand"], cnt["n_sw"], cnt["n_ungapped"])
+    m.close()
+
+
+@pytest.mark.parametrize("name", sorted(golden_args()))
+def test_gpu_sam_equals_reference_golden(name, tmp_path):
+    """FASTQ -> GPU -> SAM text == the SAM the real reference wrote for the same input"""
+    from bitmapperbs_amd import mapper
+    fa = str(tmp_path / "genome.fa"); fq = str(tmp_path / "r.fq")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % name), fq)
+    mapper.Index.build(fa, fa, threads=4)
+    ix = mapper.Index(fa)
+    names, seq, qual = read_fastq(fq)
+    L = seq.shape[1]
+    m = mapper.Mapper(ix, 0, e_f=e_of(golden_args()[name]))
+    res, pool = m.map_se(seq, qual, L)
+    text = mapper.sam_header(ix, "") + "".join(mapper.sam_lines_se(ix, names, seq, qual, L, res, pool))
+    mine = "".join(l + "\n" for l in text.split("\n")[:-1] if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "se_%s.ref.sam.gz" % name), "rt").read()
+    from bitmapperbs_amd import distributed
+    assert distributed.mapstats_text(m.stats()) == open(os.path.join(GOLD, "se_%s.ref.stats" % name)).read()
+    m.close()
+
+
+def test_filter_stage_matches_oracle_incl_invalid_sites(env):
+    """K7+K8 through bmbs_filter_batch on arbitrary (read, site) pairs, incl. strand ends and wild sites"""
+    from bitmapperbs_amd import synth, mapper
+    L, e = 120, 0.08
+    r = synth.make_reads_se(env["chroms"], n=3000, L=L, seed=21, sub=0.03, indel=0.004, qual="const", n_rate=0.003)
+    m = mapper.Mapper(env["ix"], 0, e_f=e)
+    k = m.threshold(L)
+    G = env["ix"].ref_len
+    c, p, minus = r["truth"]
+    offs = np.concatenate([[0], np.cumsum([ch.size for ch in env["chroms"]])])[:-1]
+    true_site = np.where(minus, 2 * G - (offs[c] + p + L + 8) + 8, offs[c] + p).astype(np.int64) - k
+    rng = np.random.default_rng(5)
+    read_of, site = [], []
+    for i in range(3000):
+        for d in (0, int(rng.integers(-k, k + 1)), int(rng.integers(-40, 40))):
+            read_of.append(i); site.append(np.uint64(max(0, int(true_site[i]) + d)))
+    edge = [0, 1, G - L - 2 * k, G - L - 2 * k + 1, G - 1, G, G + 1, 2 * G - L - 2 * k, 2 * G - L - 2 * k + 1, 2 * G - 1, 2 * G,
+            2 * G + 5, (1 << 64) - 3, (1 << 63), G - 5, 2 * G - 40]
+    for j, s in enumerate(edge):
+        read_of.append(j); site.append(np.uint64(s))
+    read_of = np.array(read_of, dtype=np.uint32); site = np.array(site, dtype=np.uint64)
+    err, end = m.filter(r["seq"], L, read_of, site)
+    for j in range(read_of.size):
+        w = env["oix"].window(int(site[j]), L + 2 * k)
+        oe, oend = orc.bpm(w, r["seq"][read_of[j]], k)
+        assert (int(err[j]), int(end[j])) == (oe, oend), (j, int(site[j]))
+    assert (err != 0xFFFFFFFF).sum() > 2000          # the test really exercised accepted candidates
+    m.close()
+
+
+def test_align_stage_matches_oracle(env):
+    """K11-K13 through bmbs_align_batch: jobs = every accepted candidate of the filter stage with err > 0"""
+    from bitmapperbs_amd import synth, mapper
+    L, e = 150, 0.08
+    r = synth.make_reads_se(env["chroms"], n=4000, L=L, seed=31, sub=0.02, indel=0.006, qual="random", n_rate=0.002)
+    m = mapper.Mapper(env["ix"], 0, e_f=e)
+    k = m.threshold(L)
+    G = env["ix"].ref_len
+    c, p, minus = r["truth"]
+    offs = np.concatenate([[0], np.cumsum([ch.size for ch in env["chroms"]])])[:-1]
+    true_site = np.maximum(0, np.where(minus, 2 * G - (offs[c] + p + L + 8) + 8, offs[c] + p).astype(np.int64) - k).astype(np.uint64)
+    read_of = np.arange(4000, dtype=np.uint32)
+    err, end = m.filter(r["seq"], L, read_of, true_site)
+    keep = np.nonzero((err != 0xFFFFFFFF))[0]
+    out = m.align(r["seq"], r["qual"], L, read_of[keep], true_site[keep], end[keep], err[keep])
+    prm = orc.params(e_f=e)
+    n_sw = 0
+    for jj, i in enumerate(keep):
+        if err[i] == 0:
+            continue
+        w = env["oix"].window(int(true_site[i]), L + 2 * k)
+        o = orc.align(prm, w, r["seq"][i], r["qual"][i], k, int(end[i]), int(err[i]), int(true_site[i] < G))
+        n_ops = int(out["n_ops"][jj])
+        cg = "%dM" % L if n_ops == 0 else "".join("%d%s" % (int(x) >> 4, "MDISH"[int(x) & 15]) for x in out["ops"][jj][:n_ops])
+        assert (int(out["start"][jj]), int(out["end"][jj]), int(out["nm"][jj]), int(out["score"][jj]), cg) == \
+               (o["start"], o["end"], o["nm"], o["score"], o["cigar"]), int(i)
+        n_sw += n_ops != 0
+    assert n_sw > 300
+    m.close()
+
+
+def test_seed_stage_verdicts_and_vote_counts(env):
+    from bitmapperbs_amd import synth, mapper
+    L, e = 100, 0.08
+    r = synth.make_reads_se(env["chroms"], n=20000, L=L, seed=41, sub=0.01, indel=0.001, qual="const", n_rate=0.002)
+    m = mapper.Mapper(env["ix"], 0, e_f=e)
+    s = m.seed(r["seq"], L)
+    recs, _, _ = env["oix"].map_se(orc.params(e_f=e), r["seq"], r["qual"], L)
+    # oracle path: 1 exit A, 2 exit C, 3 general (incl. "no unique"), 4 exact ambiguous, 0 nothing
+    v = s["verdict"].astype(np.int64)
+    op = recs["path"].astype(np.int64)
+    gen = (op == 3) | ((op == 0) & (recs["n_cand"] > 0))
+    assert (v[op == 1] == 1).all() and (v[op == 2] == 2).all() and (v[op == 4] == 4).all()
+    assert (v[gen] == 3).all()
+    assert (s["n_votes"][gen].astype(np.int64) == recs["n_votes"][gen]).all()
+    # every vote segment is ordered by vote, descending (the reference's visiting order)
+    for i in np.nonzero(v == 3)[0][:2000]:
+        a = int(s["seg_off"][i]); cnts = s["vote_cnt"][a:a + int(s["n_votes"][i])]
+        assert (np.diff(cnts.astype(np.int64)) <= 0).all()
+    m.close()
+
+
+def test_edge_cases_empty_single_allN_short(env):
+    from bitmapperbs_amd import mapper
+    m = mapper.Mapper(env["ix"], 0)
+    res, pool = m.map_se(np.zeros((0, 112), np.uint8), np.zeros((0, 112), np.uint8), 100)
+    assert res.size == 0 and pool.size == 0
+    for L in (16, 17, 18, 30):
+        seq = np.full((3, 32), ord("N"), dtype=np.uint8)
+        seq[1, :L] = np.frombuffer(b"ACGT" * 8, dtype=np.uint8)[:L]
+        seq[2, :L] = env["chroms"][0][1000:1000 + L]
+        q = np.full((3, 32), ord("I"), dtype=np.uint8)
+        res, pool = m.map_se(seq, q, L)
+        recs, ost, _ = env["oix"].map_se(orc.params(), seq, q, L)
+        assert not compare_records(res, pool, recs, L)
+    m.close()
+
+
+def test_full_size_properties_idempotent_and_split_invariant(env):
+    """at a BASELINE-scale batch (2 M x 150 bp on the test genome): run-to-run identical bytes, and the
+    batch result equals the concatenation of two half-batches (reads are independent units)"""
+    import torch
+    from bitmapperbs_amd import gpusynth, mapper, capi
+    L, stride, n = 150, 160, 2_000_000
+    gd, ld = gpusynth.upload_genome(env["chroms"])
+    seq, qual = gpusynth.make_reads_se(gd, ld, n, L, stride, seed=99, sub=0.01, indel=0.0005)
+    m = mapper.Mapper(env["ix"], 0, e_f=0.04)
+    k = m.threshold(L); cap = n * (2 * k + 8)
+
+    def run(a, b):
+        res = torch.zeros((b - a, 32), dtype=torch.uint8, device="cuda")
+        cig = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+        m.reset_stats()
+        m.map_se_device(seq[a:b].data_ptr(), qual[a:b].data_ptr(), L, stride, b - a, res.data_ptr(), cig.data_ptr(), cap)
+        m.sync()
+        return res.cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1), cig.cpu().numpy().view(np.uint32), m.stats()
+
+    r1, c1, s1 = run(0, n)
+    r2, c2, s2 = run(0, n)
+    assert r1.tobytes() == r2.tobytes() and (s1 == s2).all()
+    ra, ca, sa = run(0, n // 2)
+    rb, cb, sb = run(n // 2, n)
+    assert ((sa + sb) == s1).all() and s1[0] == n
+    f = [x for x in capi.RESULT_DTYPE.names if x not in ("cigar_off",)]
+    whole = np.concatenate([ra, rb])
+    for x in f:
+        assert (whole[x] == r1[x]).all(), x
+    # cigars of a sample of gapped reads agree too
+    idx = np.nonzero(r1["n_cigar"] > 0)[0][:5000]
+    for i in idx:
+        part, pc = (ra, ca) if i < n // 2 else (rb, cb)
+        j = i if i < n // 2 else i - n // 2
+        assert mapper.cigar_text(r1[i], c1, L) == mapper.cigar_text(part[j], pc, L)
+    # oracle spot-check on a slice of the big batch
+    sl = slice(1000, 21000)
+    recs, _, _ = env["oix"].map_se(orc.params(e_f=0.04), seq[sl].cpu().numpy(), qual[sl].cpu().numpy(), L)
+    assert not compare_records(r1[sl], c1, recs, L)
+    m.close()

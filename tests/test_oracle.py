@@ -1,0 +1,106 @@
+"""The oracle (CPU restatement) is pinned: (1) against the committed golden SAM the REAL reference wrote
+(tests/golden/make_golden.py), (2) against the reference binary itself on fresh seeded data when
+oracle/_ref/bitmapperBS is present."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from common import GOLD, ROOT, e_of, golden_args, gunzip_to, plant_repeats
+from conftest import ref_binary
+
+
+@pytest.fixture(scope="module")
+def golden_index(tmp_path_factory, oracle):
+    wd = tmp_path_factory.mktemp("gold")
+    fa = str(wd / "genome.fa")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    assert oracle.orc_index_build(fa.encode(), fa.encode()) == 0
+    return fa
+
+
+@pytest.mark.parametrize("name", sorted(golden_args()))
+def test_oracle_reproduces_reference_golden_sam(name, golden_index, tmp_path, oracle):
+    args = golden_args()[name]
+    fq = str(tmp_path / "r.fq"); out = str(tmp_path / "o.sam")
+    gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % name), fq)
+    ix = orc.OrcIndex(golden_index)
+    st = np.zeros(5, dtype=np.int64)
+    import ctypes as C
+    prm = orc.params(e_f=e_of(args))
+    assert oracle.orc_search_se(ix.h, C.byref(prm), fq.encode(), out.encode(), b"", st.ctypes.data) == 0
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    gold = gzip.open(os.path.join(GOLD, "se_%s.ref.sam.gz" % name), "rt").read()
+    assert mine == gold
+    # mapstats (Bitmapper_main.cpp:275-284)
+    ref_stats = open(os.path.join(GOLD, "se_%s.ref.stats" % name)).read().split("\n")
+    assert int(ref_stats[0].split()[-1]) == st[0]
+    assert int(ref_stats[1].split()[5]) == st[1] and int(ref_stats[2].split()[5]) == st[2]
+
+
+@pytest.mark.skipif(ref_binary() is None, reason="oracle/_ref/bitmapperBS not built")
+@pytest.mark.parametrize("cfg", [
+    dict(n=20000, L=100, seed=11, sub=0.01, indel=0.001, qual="random", e=0.08),
+    dict(n=15000, L=150, seed=12, sub=0.02, indel=0.002, qual="random", n_rate=0.003, e=0.04),
+    dict(n=6000, L=250, seed=13, sub=0.03, indel=0.001, qual="random", e=0.08),
+    dict(n=8000, L=60, seed=14, sub=0.03, indel=0.002, qual="const", e=0.1),
+])
+def test_oracle_vs_reference_binary_fresh_data(cfg, tmp_path, oracle):
+    from bitmapperbs_amd import synth
+    cfg = dict(cfg); e = cfg.pop("e")
+    names, chroms = synth.make_genome(600_000, 3, seed=31 + cfg["seed"])
+    plant_repeats(chroms, seed=cfg["seed"])
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, chroms)
+    assert oracle.orc_index_build(fa.encode(), fa.encode()) == 0
+    r = synth.make_reads_se(chroms, **cfg)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, r)
+    ref_sam = str(tmp_path / "ref.sam"); my_sam = str(tmp_path / "orc.sam")
+    p = subprocess.run([ref_binary(), "--search", fa, "--seq", fq, "-t", "1", "-e", str(e), "-o", ref_sam],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    q = subprocess.run([os.path.join(ROOT, "oracle", "bmbs_oracle"), "search", fa, "--seq", fq, "-e", str(e), "-o", my_sam],
+                       capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr
+    a = [l for l in open(ref_sam) if not l.startswith("@PG")]
+    b = [l for l in open(my_sam) if not l.startswith("@PG")]
+    assert a == b
+    sa = [l.split() for l in p.stderr.splitlines() if l.startswith("No. of")]
+    sb = [l.split() for l in q.stderr.splitlines() if l.startswith("No. of")]
+    assert sa == sb
+
+
+def test_bpm_known_answers():
+    """hand-checked cases of the BS banded Myers rules (Levenshtein_Cal.h:351-567)"""
+    k = 2
+    read = np.frombuffer(b"ACGTTGCA", dtype=np.uint8)
+    # exact match on the un-gapped diagonal: window = 2 pad + read + 2 pad
+    w = np.frombuffer(b"GG" + b"ACGTTGCA" + b"GG", dtype=np.uint8)
+    assert orc.bpm(w, read, k) == (0, len(read) - 1 + k)
+    # read T on window C is a match (bisulfite), read C on window T is not
+    w2 = np.frombuffer(b"GG" + b"ACGCCGCA" + b"GG", dtype=np.uint8)
+    assert orc.bpm(w2, read, k)[0] == 0
+    read_c = np.frombuffer(b"ACGCCGCA", dtype=np.uint8)
+    assert orc.bpm(w, read_c, k)[0] == 2
+    # more than k errors -> (0xFFFFFFFF, -1)
+    w3 = np.frombuffer(b"GG" + b"TTTTTTTT" + b"GG", dtype=np.uint8)
+    assert orc.bpm(w3, np.frombuffer(b"AAAAAAAA", dtype=np.uint8), k) == (0xFFFFFFFF, -1)
+    # all-zero (out-of-range) window never matches
+    assert orc.bpm(np.zeros(12, np.uint8), read, k) == (0xFFFFFFFF, -1)
+
+
+def test_mapq_table_spot_values():
+    """MAP_Calculation (Schema.cpp:168-405) spot values"""
+    L = orc.load()
+    import ctypes as C
+    p = orc.params()
+    assert L.orc_mapq(C.byref(p), 0xFFFFFFFF, 6, 0) == 42
+    assert L.orc_mapq(C.byref(p), 0xFFFFFFFF, 6, -6) == 42      # 42/48 = 0.875
+    assert L.orc_mapq(C.byref(p), 0xFFFFFFFF, 6, -12) == 40     # 36/48 = 0.75
+    assert L.orc_mapq(C.byref(p), 0, 6, 0) == 1
+    assert L.orc_mapq(C.byref(p), 6, 6, 0) == 39
+    assert L.orc_mapq(C.byref(p), 3, 6, -6) == 25               # rank_error 0.5, rank 0.875
