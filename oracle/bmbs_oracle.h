@@ -86,6 +86,24 @@ int orc_map_se(const orc_index*, const orc_params*, const char* seq, const char*
                const int32_t* len, int stride, int64_t n, orc_rec* recs, int64_t stats[5],
                orc_counters* counters);
 
+/* paired-end record (fast mode, Map_Pair_Seq_end_to_end_fast, Schema.cpp:18570) */
+typedef struct orc_pe_rec {
+    int32_t  status;        /* 0 unmapped, 1 unique pair (emitted), 2 ambiguous, 3 rejected by TLEN / chromosome-end check */
+    int32_t  n_pairs;       /* mapping_pair */
+    int32_t  mapq, tlen;
+    int32_t  flag1, flag2, chrom1, chrom2;
+    uint64_t pos1, pos2;
+    int32_t  nm1, nm2, score1, score2, matched1, matched2;
+    char     cigar1[256], cigar2[256];
+} orc_pe_rec;
+
+/* PE mapping of n pairs (SoA, common stride).  seq2 = mate 2 as the reference's reader hands it on, i.e.
+ * the REVERSE COMPLEMENT of the FASTQ record (Process_Reads.cpp:262-267); qual2 in FASTQ order.
+ * stats[5] = pairs, unique, ambiguous, mapped bases, error bases (Schema.cpp:19531-19537).          */
+int orc_map_pe(const orc_index*, const orc_params*, const char* seq1, const char* qual1, const char* seq2,
+               const char* qual2, int L1, int L2, int stride, int64_t n, orc_pe_rec* recs, int64_t stats[5],
+               orc_counters* counters);
+
 /* whole-program equivalents (FASTQ -> SAM); return 0 on success.  argv_line is printed in @PG CL */
 int orc_search_se(const orc_index*, const orc_params*, const char* fastq, const char* out_sam,
                   const char* argv_line, int64_t stats[5]);

@@ -3,6 +3,7 @@
 #define ORC_INTERNAL_H
 #include "bmbs_oracle.h"
 #include <stdint.h>
+#include <stdio.h>
 #include <string>
 #include <vector>
 
@@ -32,4 +33,18 @@ void orc_hash_query(const orc_index* ix, u64 key, u64* sp, u64* ep);
 u64  orc_lf(const orc_index* ix, u64 row, int c);
 u64  orc_sa_row(const orc_index* ix, u64 row);
 u64  orc_sa_row_counted(const orc_index* ix, u64 row, u64* n_lf);
+
+// ---- shared by orc_map.cpp (SE) and orc_pe.cpp (PE) ---------------------------------------------
+struct seed_res { u64 hits, sp, ep, match_len; };
+struct vote_t { u64 site, vote; unsigned err; u64 end_site; };      // seed_votes, Schema.h:169-176
+struct fq_rec { std::string name, seq, rseq, qual; };
+void window_at(const orc_index* ix, u64 site, u64 len, char* out);
+int  mismatch_penalty(const orc_params* P, int Q);
+seed_res count_terminate(const orc_index* ix, const char* pat, u64 length, orc_counters* C);
+seed_res count_fixed(const orc_index* ix, const char* pat, u64 length, orc_counters* C);
+void locate_rows(const orc_index* ix, u64 sp, u64 ep, u64 seed_len, u64 seed_off, std::vector<u64>& out, orc_counters* C);
+int  seed_offset_unmatch(int readLen, int pre, const char* read, int step);
+void make_votes(const std::vector<u64>& cand, u64 k, std::vector<vote_t>& votes);
+bool getline_(FILE* f, std::string& s);
+void sam_header(FILE* o, const orc_index* ix, const char* argv_line);
 #endif

@@ -35,7 +35,7 @@ static void window_rc(const orc_index* ix, u64 rc_start, u64 len, char* out)
         out[i] = "TGCA"[(ix->pac[p >> 2] >> (6 - 2 * (p & 3))) & 3];
     }
 }
-static void window_at(const orc_index* ix, u64 site, u64 len, char* out)
+void window_at(const orc_index* ix, u64 site, u64 len, char* out)
 {
     if (site < ix->G) window_fwd(ix, site, len, out);
     else window_rc(ix, site - ix->G, len, out);
@@ -105,7 +105,7 @@ extern "C" int orc_bpm(const char* pattern, int p_length, const char* text, int 
 
 // ------------------------------------------------------------------------------------------------
 // MismatchPenaltyByQuality (ksw.h:148-161): IEEE double arithmetic, truncation toward zero
-static int mismatch_penalty(const orc_params* P, int Q)
+int mismatch_penalty(const orc_params* P, int Q)
 {
     double Phred = Q - P->q_base;
     if (Phred > 40) Phred = 40;
@@ -347,10 +347,9 @@ static u64 hash16(const char* p)
     return h;
 }
 
-struct seed_res { u64 hits, sp, ep, match_len; };
 
 // K3  count_backward_as_much_1_terminate  (bwt.h:2081-2209)
-static seed_res count_terminate(const orc_index* ix, const char* pat, u64 length, orc_counters* C)
+seed_res count_terminate(const orc_index* ix, const char* pat, u64 length, orc_counters* C)
 {
     seed_res r = {0, 0, 0, 0};
     if (length < 18) return r;
@@ -379,7 +378,7 @@ static seed_res count_terminate(const orc_index* ix, const char* pat, u64 length
 }
 
 // K4  count_hash_table  (bwt.h:1848-1952): fixed-length count, no early stop
-static seed_res count_fixed(const orc_index* ix, const char* pat, u64 length, orc_counters* C)
+seed_res count_fixed(const orc_index* ix, const char* pat, u64 length, orc_counters* C)
 {
     seed_res r = {0, 0, 0, length};
     if (length < 17) return r;
@@ -414,7 +413,7 @@ extern "C" uint64_t orc_count_terminate(const orc_index* ix, const char* bsseq, 
 // K5/K6: positions of the rows [sp,ep) as doubled-coordinate read-start sites
 // (locate + reverse_and_adjust_site, bwt.cpp:4620 / Schema.cpp:4657; locate_one_position_direct,
 // bwt.h:2585).  The FMtree traversal of the reference enumerates exactly {SA[r]}; callers sort.
-static void locate_rows(const orc_index* ix, u64 sp, u64 ep, u64 seed_len, u64 seed_off,
+void locate_rows(const orc_index* ix, u64 sp, u64 ep, u64 seed_len, u64 seed_off,
                         std::vector<u64>& out, orc_counters* C)
 {
     for (u64 r = sp; r < ep; r++) {
@@ -426,7 +425,7 @@ static void locate_rows(const orc_index* ix, u64 sp, u64 ep, u64 seed_len, u64 s
 }
 
 // determine_seed_offset_unmatch, Schema.h:1506-1531
-static int seed_offset_unmatch(int readLen, int pre, const char* read, int step)
+int seed_offset_unmatch(int readLen, int pre, const char* read, int step)
 {
     if (readLen - pre < 18 || readLen - pre < step) return readLen;
     int ret = pre + step;
@@ -436,11 +435,10 @@ static int seed_offset_unmatch(int readLen, int pre, const char* read, int step)
 }
 
 // the reference's vote record (Schema.h:169-176)
-struct vote_t { u64 site, vote; unsigned err; u64 end_site; };
 static bool vote_gt(const vote_t& a, const vote_t& b) { return a.vote > b.vote; }   // compare_seed_votes, Schema.cpp:560
 
 // generate_candidate_votes_shift, Schema.cpp:4687-4773
-static void make_votes(const std::vector<u64>& cand, u64 k, std::vector<vote_t>& votes)
+void make_votes(const std::vector<u64>& cand, u64 k, std::vector<vote_t>& votes)
 {
     votes.clear();
     size_t n = cand.size(), i = 1;
@@ -652,8 +650,7 @@ extern "C" int orc_map_se(const orc_index* ix, const orc_params* P, const char* 
 
 // ------------------------------------------------------------------------------------------------
 // FASTQ reader (inputReads_single_directly, Process_Reads.cpp:810-890) and SAM text
-struct fq_rec { std::string name, seq, rseq, qual; };
-static bool getline_(FILE* f, std::string& s)
+bool getline_(FILE* f, std::string& s)
 {
     s.clear();
     int c;
@@ -676,7 +673,7 @@ static bool read_fastq(FILE* f, fq_rec& r, bool cut_name)
 }
 
 // OutPutSAM_Nounheader, Process_sam_out.cpp:1137-1153
-static void sam_header(FILE* o, const orc_index* ix, const char* argv_line)
+void sam_header(FILE* o, const orc_index* ix, const char* argv_line)
 {
     fprintf(o, "@HD\tVN:1.4\tSO:unsorted\n");
     for (auto& c : ix->chroms) fprintf(o, "@SQ\tSN:%s\tLN:%llu\n", c.name.c_str(), (unsigned long long)c.len);
