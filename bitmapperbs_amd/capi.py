@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libbmbs_hip.so")
 SYMBOLS = [
     "bmbs_default_params", "bmbs_create", "bmbs_destroy", "bmbs_last_error", "bmbs_index_attach",
     "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se", "bmbs_map_se_device",
+    "bmbs_map_pe", "bmbs_map_pe_device",
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build",
@@ -77,6 +78,8 @@ def lib() -> C.CDLL:
     L.bmbs_seed_batch.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_map_se.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_map_se_device.argtypes = [vp, u64, u64, i32, i32, i64, u64, u64, i64]
+    L.bmbs_map_pe.argtypes = [vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]
+    L.bmbs_map_pe_device.argtypes = [vp, u64, u64, u64, u64, i32, i32, i64, u64, u64, i64]
     L.bmbs_sync.argtypes = [vp]
     L.bmbs_stats_get.argtypes = [vp, vp]
     L.bmbs_stats_reset.argtypes = [vp]
@@ -93,6 +96,7 @@ def lib() -> C.CDLL:
     L.bmbs_index_file_free.restype = None
     L.bmbs_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     for name in ("bmbs_index_attach", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se",
+                 "bmbs_map_pe", "bmbs_map_pe_device",
                  "bmbs_map_se_device", "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce",
                  "bmbs_profile_last", "bmbs_counters_last", "bmbs_index_build"):
         getattr(L, name).restype = C.c_int

@@ -42,6 +42,8 @@ struct bmbs_ctx {
     DevBuf cand, votes, slot_read, ferr, fend, job_read, H, E, z, a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d;
+    // paired-end workspace
+    DevBuf pe_seq, pe_qual, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
     DevBuf stats, counters;
     std::vector<Prof> prof;
     int n_prof_used = 0;
@@ -159,6 +161,7 @@ int threshold_k(const bmbs_params& P, int L)
     return (int)k;
 }
 
+// kthr = k for single-end, k1+k2 for pairs (MAP_Calculation's error_threshold argument)
 int prepare_luts(bmbs_ctx* c, int k)
 {
     if (c->mapq_k == k) return BMBS_OK;
@@ -210,13 +213,13 @@ int align_scratch(bmbs_ctx* c, u64 n_jobs, int L, int k, AlignScratch& sc)
 }
 
 // stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
-int run_seed_stages(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int k, u64* total_cand)
+int run_seed_stages(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int k, u64* total_cand, int pe_mode = 0)
 {
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     prof_begin(c, "k_seed");
     hipLaunchKernelGGL(k_seed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
-                       c->prm.seed_len, st, cnt);
+                       c->prm.seed_len, pe_mode, st, cnt);
     prof_end(c);
     prof_begin(c, "scan_cand");
     int rc = scan_u32(c, st.n_cand, n, st.cand_off, 0);
@@ -282,7 +285,8 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->ferr, &c->fend,
                      &c->job_read, &c->H, &c->E, &c->z, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
-                     &c->stats, &c->counters};
+                     &c->stats, &c->counters, &c->pe_seq, &c->pe_qual, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
+                     &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -407,7 +411,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
         hipLaunchKernelGGL(k_align, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
                            d_seq, d_qual, L, stride, k, n_jobs, c->job_read.as<u32>(), st, sc,
                            reinterpret_cast<u32*>(d_cigar_pool), max_ops, c->a_start.as<int>(), c->a_end.as<int>(),
-                           c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), cnt);
+                           c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), cnt, 0xffffffffu);
         prof_end(c);
     }
     prof_begin(c, "k_finalize");
@@ -438,6 +442,156 @@ extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32
                                 (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+    const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
+    if (used > (u64)cigar_cap) { c->err = "host cigar pool too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
+    if (used) HIPCHK(c, hipMemcpyAsync(cigar_pool, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_cigar_used) *n_cigar_used = (int64_t)used;
+    return BMBS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// paired-end fast mode (Map_Pair_Seq_end_to_end_fast, Schema.cpp:18570)
+extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2,
+                                  int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
+                                  int64_t cigar_cap)
+{
+    if (!c) return BMBS_EINVAL;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    if (c->prm.sensitive) { c->err = "--sensitive (re-seeding, Schema.cpp:16678) is not implemented on the device yet"; return BMBS_ESTATE; }
+    if (L <= 0 || L > 1000 || stride < L || n_pairs < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 n = (u64)n_pairs, n2 = 2 * n;
+    c->n_prof_used = 0;
+    if (n == 0) return BMBS_OK;
+    const int k = threshold_k(c->prm, L);
+    int rc = prepare_luts(c, 2 * k);
+    if (rc) return rc;
+    rc = per_read_workspace(c, n2);
+    if (rc) return rc;
+    ENS(c, c->pe_seq, n2 * (u64)stride + 64); ENS(c, c->pe_qual, n2 * (u64)stride + 64);
+    ENS(c, c->pe_occ, n2 * 4); ENS(c, c->pe_len, n2 * 4); ENS(c, c->pe_cur, n2); ENS(c, c->pe_vround, n2);
+    ENS(c, c->pe_dead, n); ENS(c, c->pe_both, n); ENS(c, c->pe_npair, n * 4); ENS(c, c->pe_sbd, n * 4);
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * 8, c->stream));
+    char* seq_all = c->pe_seq.as<char>();
+    char* qual_all = c->pe_qual.as<char>();
+    prof_begin(c, "k_pe_prepare");
+    hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * stride, 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
+                       reinterpret_cast<const char*>(d_qual1), reinterpret_cast<const char*>(d_seq2),
+                       reinterpret_cast<const char*>(d_qual2), L, stride, (long)n, seq_all, qual_all);
+    prof_end(c);
+    ReadState st = read_state(c);
+    PeState ps;
+    ps.occ = c->pe_occ.as<int>(); ps.len = c->pe_len.as<u32>(); ps.cur = c->pe_cur.as<u8>(); ps.vround = c->pe_vround.as<u8>();
+    ps.dead = c->pe_dead.as<u8>(); ps.both = c->pe_both.as<u8>(); ps.npair = c->pe_npair.as<int>(); ps.sbd = c->pe_sbd.as<u32>();
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    // seeding of all 2n reads; candidate slots by scan; locate
+    prof_begin(c, "k_seed");
+    hipLaunchKernelGGL(k_seed, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, (long)n2,
+                       c->prm.seed_len, 1, st, cnt);
+    prof_end(c);
+    prof_begin(c, "scan_cand");
+    rc = scan_u32(c, st.n_cand, n2, st.cand_off, 0);
+    if (rc) return rc;
+    prof_end(c);
+    u64 tot = 0;
+    HIPCHK(c, hipMemcpyAsync(&tot, c->totals.as<u64>(), 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_total_cand = tot;
+    const u64 t1 = tot ? tot : 1;
+    ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(PeCand)); ENS(c, c->pe_B, t1 * sizeof(PeCand));
+    PeCand* A = c->votes.as<PeCand>();
+    PeCand* B = c->pe_B.as<PeCand>();
+    if (tot) {
+        prof_begin(c, "k_locate");
+        hipLaunchKernelGGL(k_locate, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, (long)n2, tot, st, c->cand.as<u64>());
+        prof_end(c);
+    }
+    const long long maxd = (long long)c->prm.max_ins + 2LL * k;
+    const long long mind = (long long)c->prm.min_ins - 2LL * k - L;
+    prof_begin(c, "k_vote_pe");
+    hipLaunchKernelGGL(k_vote_pe, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n2, L, k, st, ps, c->cand.as<u64>(), A);
+    prof_end(c);
+    prof_begin(c, "k_pe_filter_pairs");
+    hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+    prof_end(c);
+    for (int round = 1; round <= 2; round++) {
+        if (tot) {
+            prof_begin(c, round == 1 ? "k_filter_pe_r1" : "k_filter_pe_r2");
+            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, k, (long)n,
+                               (long)n2, round, st, ps, A, B, tot, cnt);
+            prof_end(c);
+        }
+        prof_begin(c, round == 1 ? "k_pe_compact_r1" : "k_pe_compact_r2");
+        hipLaunchKernelGGL(k_pe_compact, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n, (long)n2, k, round, st, ps, A, B);
+        prof_end(c);
+        if (round == 1) {
+            prof_begin(c, "k_pe_prune");
+            hipLaunchKernelGGL(k_pe_prune, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+            prof_end(c);
+        }
+    }
+    prof_begin(c, "k_pe_pair");
+    hipLaunchKernelGGL(k_pe_pair, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, k, maxd, mind, st, ps, A, B);
+    prof_end(c);
+    prof_begin(c, "scan_jobs");
+    rc = scan_u32(c, st.job_flag, n2, st.job_off, 1);
+    if (rc) return rc;
+    prof_end(c);
+    u64 n_jobs = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_n_jobs = n_jobs;
+    const int max_ops = 2 * k + 8;
+    c->last_max_ops = max_ops;
+    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small"; return BMBS_ENOMEM; }
+    AlignScratch sc;
+    rc = align_scratch(c, n_jobs, L, k, sc);
+    if (rc) return rc;
+    ENS(c, c->job_read, (n_jobs ? n_jobs : 1) * 4);
+    if (n_jobs) {
+        prof_begin(c, "k_job_list");
+        hipLaunchKernelGGL(k_job_list, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, st, c->job_read.as<u32>());
+        prof_end(c);
+        prof_begin(c, "k_align");
+        hipLaunchKernelGGL(k_align, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
+                           seq_all, qual_all, L, stride, k, n_jobs, c->job_read.as<u32>(), st, sc,
+                           reinterpret_cast<u32*>(d_cigar_pool), max_ops, c->a_start.as<int>(), c->a_end.as<int>(),
+                           c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), cnt, (u32)n);
+        prof_end(c);
+    }
+    prof_begin(c, "k_finalize_pe");
+    hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->mapq_lut.as<u8>(), c->mapq_range, L, k,
+                       c->prm.min_ins, c->prm.max_ins, (long)n, st, ps, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                       c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, reinterpret_cast<bmbs_result_dev*>(d_results),
+                       c->stats.as<unsigned long long>());
+    prof_end(c);
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_map_pe(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2, int32_t L,
+                           int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
+                           int64_t* n_cigar_used)
+{
+    if (!c) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 n = (u64)n_pairs, bytes = n * (u64)stride;
+    if (n_cigar_used) *n_cigar_used = 0;
+    if (n == 0) return BMBS_OK;
+    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_qual, bytes + 64); ENS(c, c->in_seq2, bytes + 64); ENS(c, c->in_qual2, bytes + 64);
+    ENS(c, c->out_res, 2 * n * 32);
+    const int k = threshold_k(c->prm, L);
+    const u64 pool = 2 * n * (u64)(2 * k + 8);
+    ENS(c, c->cig_pool, pool * 4);
+    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq1, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_qual.p, qual1, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_seq2.p, seq2, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_qual2.p, qual2, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = bmbs_map_pe_device(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, (uint64_t)c->in_seq2.p, (uint64_t)c->in_qual2.p,
+                                L, stride, n_pairs, (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, 2 * n * 32, hipMemcpyDeviceToHost, c->stream));
     const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
     if (used > (u64)cigar_cap) { c->err = "host cigar pool too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
     if (used) HIPCHK(c, hipMemcpyAsync(cigar_pool, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));

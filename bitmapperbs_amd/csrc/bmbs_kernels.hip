@@ -315,7 +315,7 @@ DEVI int seed_offset_unmatch(int L, int pre, const char* rd, int step)
 // The seeding state machine of Map_Single_Seq_end_to_end (Schema.cpp:24588-24898) with the three
 // fast exits; seeds are recorded as SA intervals, k_locate expands them.
 __global__ void __launch_bounds__(256)
-k_seed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, ReadState st,
+k_seed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, int pe_mode, ReadState st,
        unsigned long long* __restrict__ counters)
 {
     __shared__ unsigned int shc[4];
@@ -372,9 +372,15 @@ k_seed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int
         }
         if (!done) {
             mm_site = ml;
-            if (ml == (u64)L && s.hits > 1) {
+            if (!pe_mode) {
+                if (ml == (u64)L && s.hits > 1) {
+                    multi = 1;
+                    if (firstC == L) { verdict = 4; done = true; }      // exact, ambiguous, no C in the read
+                }
+            } else if (ml == (u64)L && s.hits > 1 && s.hits <= 10000) {
+                // get_candidates (Schema.cpp:18260-18290): every exact hit becomes a verified candidate
                 multi = 1;
-                if (firstC == L) { verdict = 4; done = true; }      // exact, ambiguous, no C in the read
+                if (firstC == L) { record(s.sp, s.hits, ml, 0); verdict = 4; done = true; }
             }
         }
         if (!done) {
@@ -422,7 +428,7 @@ k_seed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int
     st.n_seeds[r] = (u8)ns;
     st.multi[r] = (u8)multi;
     st.mm_site[r] = (u16)mm_site;
-    st.n_cand[r] = verdict == 3 ? (u32)ncand : 0u;
+    st.n_cand[r] = verdict == 3 ? (u32)ncand : (pe_mode ? (verdict == 4 ? (u32)ncand : (verdict == 1 || verdict == 2) ? 1u : 0u) : 0u);
     }
     if (counters) {
         atomicAdd(&shc[0], n_hash); atomicAdd(&shc[1], n_ext); atomicAdd(&shc[2], n_sa); atomicAdd(&shc[3], n_ung);
@@ -655,7 +661,8 @@ DEVI void align_one(const DevIndex& ix, const ScoreParams& sp, const int* __rest
     const bool fwd = site < ix.G;
     const int p_len = L + 2 * k;
     auto qat = [&](int i) -> int { return (unsigned char)ql[rev_qual ? L - 1 - i : i]; };
-    auto wbase = [&](int j) -> int { return gbase(ix, site + (u64)j); };
+    const bool wvalid = window_valid(ix, site, (u64)p_len, fwd);
+    auto wbase = [&](int j) -> int { return wvalid ? gbase(ix, site + (u64)j) : 4; };   // all-zero window: nt4[0] = 4
     // read char vs window base: equal letter, or read T on window C
     auto is_match = [&](char a, int b) -> bool { return code4(a) == b || (a == 'T' && b == 1); };
     out.n_ops = 0;
@@ -699,7 +706,7 @@ DEVI void align_one(const DevIndex& ix, const ScoreParams& sp, const int* __rest
             u8 d;
             Hx(j) = h1;
             const int b = wbase(j);
-            m += (ta == b || (ta == 3 && b == 1)) ? 0 : mis;
+            m += (ta == b || (ta == 3 && b == 1)) ? 0 : (b == 4 ? -sp.np : mis);
             d = m >= e ? 0 : 1;
             h = m >= e ? m : e;
             d = h >= f ? d : 2;
@@ -796,13 +803,15 @@ k_align(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char
         const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, const u32* __restrict__ job_read,
         ReadState st, AlignScratch sc, u32* __restrict__ cigar_pool, int max_ops,
         int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
-        int* __restrict__ a_nops, unsigned long long* __restrict__ counters)
+        int* __restrict__ a_nops, unsigned long long* __restrict__ counters, u32 rev_qual_from)
 {
     const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (jb >= n_jobs) return;
     const u32 r = job_read[jb];
     AlignOut o;
-    align_one(ix, sp, pen_lut, seq + (size_t)r * stride, qual + (size_t)r * stride, false, L, k,
+    // mate 2 rows (r >= rev_qual_from) carry the reverse-complemented read with FASTQ-order qualities:
+    // need_reverse_quality = 1 (Schema.cpp:19370-19378)
+    align_one(ix, sp, pen_lut, seq + (size_t)r * stride, qual + (size_t)r * stride, r >= rev_qual_from, L, k,
               st.best_site[r], st.best_end[r], st.best_err[r], sc, jb, cigar_pool + jb * (u64)max_ops, max_ops, o);
     a_start[jb] = o.start; a_end[jb] = o.end; a_nm[jb] = o.nm; a_score[jb] = o.score; a_nops[jb] = o.n_ops;
     if (counters) atomicAdd(&counters[4], 1ull);
@@ -905,6 +914,335 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
         atomicAdd(&sh[0], 1ull);
         if (o.status == 1) { atomicAdd(&sh[1], 1ull); atomicAdd(&sh[3], (unsigned long long)L); atomicAdd(&sh[4], (unsigned long long)nm); }
         else if (o.status == 2) atomicAdd(&sh[2], 1ull);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&stats[threadIdx.x], sh[threadIdx.x]);
+}
+
+// ================================================================================================
+// Paired-end fast mode (Map_Pair_Seq_end_to_end_fast, Schema.cpp:18570-19546)
+// ================================================================================================
+// Reads of a PE batch are rows [0,n) = mate 1 and [n,2n) = mate 2 AS THE REFERENCE'S READER HANDS IT ON:
+// reverse complement of the FASTQ record (Process_Reads.cpp:262-267), qualities in FASTQ order.
+struct PeCand { u64 site; u32 err; int32_t end; };      // seed_votes fields used by the PE path
+
+struct PeState {
+    int*  occ;        // per read: best_mapp_occ (>0 verified, -1 to verify, 0 none)
+    u32*  len;        // per read: current list length
+    u8*   cur;        // per read: 0 list lives in buffer A, 1 in buffer B
+    u8*   vround;     // per read: verification round (0 none, 1, 2)
+    u8*   dead;       // per pair
+    u8*   both;       // per pair: both mates had to be verified
+    int*  npair;      // per pair: mapping_pair
+    u32*  sbd;        // per pair: second_best_diff
+};
+
+// mate 2: reverse complement of the FASTQ read (rc_table, Process_Reads.cpp:1603-1613: identity for non-ACGT)
+__global__ void __launch_bounds__(256)
+k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const char* __restrict__ s2raw,
+             const char* __restrict__ q2, int L, int stride, long n, char* __restrict__ seq_all, char* __restrict__ qual_all)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = n * stride;
+    if (i >= total) return;
+    const long r = i / stride;
+    const int j = (int)(i - r * stride);
+    seq_all[i] = s1[i];
+    qual_all[i] = q1[i];
+    char c = 0;
+    if (j < L) {
+        const char a = s2raw[r * stride + (L - 1 - j)];
+        c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a;
+    }
+    seq_all[total + i] = c;
+    qual_all[total + i] = q2[i];
+}
+
+// get_candidates' list construction (Schema.cpp:18510-18545): site-sorted votes (NOT re-sorted by vote)
+__global__ void __launch_bounds__(64)
+k_vote_pe(long n2, int L, int k, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n2) return;
+    const int v = st.verdict[r];
+    const u64 off = st.cand_off[r];
+    ps.cur[r] = 0; ps.vround[r] = 0;
+    if (v == 1 || v == 2) {
+        A[off].site = st.exit_site[r]; A[off].err = v == 1 ? 0u : 1u; A[off].end = L - 1;
+        ps.occ[r] = 1; ps.len[r] = 1;
+    } else if (v == 4) {
+        const long nc = (long)st.n_cand[r];
+        sort_u64_asc(cand + off, nc);
+        for (long i = 0; i < nc; i++) { A[off + i].site = cand[off + i]; A[off + i].err = 0; A[off + i].end = L - 1; }
+        ps.occ[r] = (int)nc; ps.len[r] = (u32)nc;
+    } else if (v == 3) {
+        const long nc = (long)st.n_cand[r];
+        u64* c = cand + off;
+        sort_u64_asc(c, nc);
+        PeCand* o = A + off;
+        long nv = 0;
+        u64 pre = c[0];
+        for (long i = 1; i < nc; i++)
+            if (c[i] != pre) { o[nv].site = pre < (u64)k ? 0 : pre - (u64)k; o[nv].err = 0; o[nv].end = 0; nv++; pre = c[i]; }
+        o[nv].site = pre >= (u64)k ? pre - (u64)k : 0; o[nv].err = 0; o[nv].end = 0; nv++;
+        ps.occ[r] = -1; ps.len[r] = (u32)nv;
+    } else { ps.occ[r] = 0; ps.len[r] = 0; }
+}
+
+DEVI PeCand* pe_list(const PeState& ps, const ReadState& st, PeCand* A, PeCand* B, long r) { return (ps.cur[r] ? B : A) + st.cand_off[r]; }
+
+// filter_pairs (Schema.cpp:16052-16180) + the driver's choice of what to verify (19050-19290)
+__global__ void __launch_bounds__(64)
+k_pe_filter_pairs(long n, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const long r1 = p, r2 = p + n;
+    int occ1 = ps.occ[r1], occ2 = ps.occ[r2];
+    ps.dead[p] = 0; ps.both[p] = 0; ps.npair[p] = 0; ps.sbd[p] = 0;
+    if (occ1 > 0 && occ2 > 0) return;
+    if (occ1 == 0 || occ2 == 0) { ps.dead[p] = 1; return; }
+    const PeCand* a = A + st.cand_off[r1];
+    const PeCand* b = A + st.cand_off[r2];
+    PeCand* ra = B + st.cand_off[r1];
+    PeCand* rb = B + st.cand_off[r2];
+    const long na = ps.len[r1], nb = ps.len[r2];
+    long la = 0, lb = 0, first = 0;
+    for (long i = 0; i < na; i++) {
+        for (long j = first; j < nb; j++) {
+            bool hit = false;
+            if (a[i].site > b[j].site) {
+                const long long d = (long long)(a[i].site - b[j].site);
+                if (d > maxd) first = j + 1;
+                else if (d >= mind) hit = true;
+            } else {
+                const long long d = (long long)(b[j].site - a[i].site);
+                if (d > maxd) break;
+                if (d >= mind) hit = true;
+            }
+            if (hit) {
+                if (la == 0 || a[i].site > ra[la - 1].site) ra[la++] = a[i];
+                if (lb == 0 || b[j].site > rb[lb - 1].site) rb[lb++] = b[j];
+            }
+        }
+    }
+    ps.cur[r1] = 1; ps.cur[r2] = 1;
+    ps.len[r1] = (u32)la; ps.len[r2] = (u32)lb;
+    if (la == 0 || lb == 0) { ps.dead[p] = 1; return; }
+    if (occ1 == -1 && occ2 == -1) {
+        ps.both[p] = 1;
+        if (la <= lb) { ps.vround[r1] = 1; ps.vround[r2] = 2; } else { ps.vround[r2] = 1; ps.vround[r1] = 2; }
+    } else if (occ1 != -1) {
+        if (la < occ1) ps.occ[r1] = (int)la;
+        ps.vround[r2] = 1;
+    } else {
+        if (lb < occ2) ps.occ[r2] = (int)lb;
+        ps.vround[r1] = 1;
+    }
+}
+
+// verify_candidate_locations' Myers pass for the mates scheduled in `round`
+__global__ void __launch_bounds__(256)
+k_filter_pe(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, long n, long n2, int round, ReadState st,
+            PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B, u64 n_slots, unsigned long long* __restrict__ counters)
+{
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_slots) return;
+    long lo = 0, hi = n2;
+    while (hi - lo > 1) { const long mid = (lo + hi) >> 1; if (st.cand_off[mid] <= g) lo = mid; else hi = mid; }
+    const long r = lo;
+    if (ps.vround[r] != round) return;
+    const long p = r < n ? r : r - n;
+    if (ps.dead[p]) return;
+    const u64 rel = g - st.cand_off[r];
+    if (rel >= ps.len[r]) return;
+    PeCand* e = pe_list(ps, st, A, B, r) + rel;
+    u32 er; int es;
+    bpm_one(ix, seq + (size_t)r * stride, L, k, e->site, er, es);
+    e->err = er; e->end = es;
+    if (counters) atomicAdd(&counters[3], 1ull);
+}
+
+// the PE compaction (Schema.cpp:7480-7690): keep err <= k whose site+end differs from the previous candidate's
+__global__ void __launch_bounds__(64)
+k_pe_compact(long n, long n2, int k, int round, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n2) return;
+    if (ps.vround[r] != round) return;
+    const long p = r < n ? r : r - n;
+    if (ps.dead[p]) return;
+    PeCand* l = pe_list(ps, st, A, B, r);
+    const long m = ps.len[r];
+    u64 pre = ~0ull;
+    int occ = 0;
+    for (long i = 0; i < m; i++) {
+        const PeCand c = l[i];
+        const u64 t = c.site + (u64)(long long)c.end;
+        if (c.err <= (u32)k && pre != t) { l[occ] = c; occ++; }
+        pre = t;
+    }
+    ps.occ[r] = occ;
+}
+
+// after round 1 of a both-unverified pair: filter_pairs_single_side (Schema.cpp:16186-16270)
+__global__ void __launch_bounds__(64)
+k_pe_prune(long n, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (ps.dead[p] || !ps.both[p]) return;
+    const long rs = ps.vround[p] == 1 ? p : p + n;       // verified side
+    const long ro = ps.vround[p] == 1 ? p + n : p;       // side still to verify
+    const int occ_s = ps.occ[rs];
+    if (occ_s == 0) { ps.dead[p] = 1; return; }
+    const PeCand* a = pe_list(ps, st, A, B, rs);
+    PeCand* b = pe_list(ps, st, A, B, ro);
+    const long nb = ps.len[ro];
+    long len2 = 0, first = 0;
+    for (long i = 0; i < occ_s; i++) {
+        for (long j = first; j < nb; j++) {
+            if (a[i].site > b[j].site) {
+                const long long d = (long long)(a[i].site - b[j].site);
+                if (d > maxd) first = j + 1;
+                else if (d >= mind) { b[len2] = b[j]; len2++; first = j + 1; }
+            } else {
+                const long long d = (long long)(b[j].site - a[i].site);
+                if (d > maxd) break;
+                if (d >= mind) { b[len2] = b[j]; len2++; first = j + 1; }
+            }
+        }
+    }
+    ps.len[ro] = (u32)len2;
+}
+
+// new_faster_verify_pairs (Schema.cpp:15773-15900) + hand-over of the winning candidates to K11-K13
+__global__ void __launch_bounds__(64)
+k_pe_pair(long n, int large_k, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const long r1 = p, r2 = p + n;
+    st.job_flag[r1] = 0; st.job_flag[r2] = 0;
+    st.red_status[r1] = 0; st.red_status[r2] = 0;
+    if (ps.dead[p]) return;
+    const int n1 = ps.occ[r1], n2 = ps.occ[r2];
+    const PeCand* a = pe_list(ps, st, A, B, r1);
+    const PeCand* b = pe_list(ps, st, A, B, r2);
+    int mapping_pair = 0;
+    int best_sum = 4 * large_k + 2;
+    long long second = (long long)best_sum * 2, bi = 0, bj = 0;
+    u32 sbd = 0;
+    bool early = false;
+    if (n1 > 0 && n2 > 0) {
+        long first = 0;
+        for (long i = 0; i < n1 && !early; i++) {
+            for (long j = first; j < n2; j++) {
+                bool hit = false;
+                if (a[i].site > b[j].site) {
+                    const long long d = (long long)(a[i].site - b[j].site);
+                    if (d > maxd) first = j + 1;
+                    else if (d >= mind) hit = true;
+                } else {
+                    const long long d = (long long)(b[j].site - a[i].site);
+                    if (d > maxd) break;
+                    if (d >= mind) hit = true;
+                }
+                if (hit) {
+                    const long long cur = (long long)a[i].err + (long long)b[j].err;
+                    if (cur < best_sum) { second = best_sum; best_sum = (int)cur; bi = i; bj = j; mapping_pair = 1; }
+                    else if (cur == best_sum) {
+                        second = best_sum; mapping_pair++;
+                        if (best_sum == 0) { early = true; break; }
+                    }
+                }
+            }
+        }
+    }
+    if (early) sbd = 0;
+    else if (mapping_pair != 0) sbd = (u32)(second - best_sum);
+    ps.npair[p] = mapping_pair; ps.sbd[p] = sbd;
+    if (mapping_pair == 1) {
+        st.best_site[r1] = a[bi].site; st.best_end[r1] = a[bi].end; st.best_err[r1] = a[bi].err;
+        st.best_site[r2] = b[bj].site; st.best_end[r2] = b[bj].end; st.best_err[r2] = b[bj].err;
+        st.red_status[r1] = 1; st.red_status[r2] = 1;
+        st.job_flag[r1] = a[bi].err != 0 ? 1u : 0u;
+        st.job_flag[r2] = b[bj].err != 0 ? 1u : 0u;
+    }
+}
+
+// per-pair post-processing (Schema.cpp:19330-19480): placement of both mates (output_sam_end_to_end_return,
+// 9188), TLEN (Schema.h:1587), insert/chromosome-end checks, MAPQ over k1+k2, flags 99/83/147/163, stats
+__global__ void __launch_bounds__(256)
+k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, int k, int min_ins, int max_ins, long n,
+              ReadState st, PeState ps, const int* __restrict__ a_start, const int* __restrict__ a_end,
+              const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops, int max_ops,
+              bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
+{
+    __shared__ unsigned long long sh[5];
+    if (threadIdx.x < 5) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        bmbs_result_dev o[2];
+        for (int m = 0; m < 2; m++) {
+            o[m].pos = 0; o[m].cigar_off = 0; o[m].chrom = -1; o[m].status = 0; o[m].mapq = 0; o[m].flag = 0; o[m].nm = 0;
+            o[m].score = 0; o[m].n_cigar = 0; o[m].path = 0; o[m].n_cand = st.n_cand[p + m * n]; o[m].reserved = 0;
+        }
+        const int np = ps.dead[p] ? 0 : ps.npair[p];
+        int status = 0;
+        if (np > 1) status = 2;
+        else if (np == 1) {
+            long long site_pos[2], matched[2];
+            int rflag[2], chrom[2], score[2]; u32 nm[2];
+            bool inrange = true;
+            for (int m = 0; m < 2; m++) {
+                const long r = p + m * n;
+                const u64 site = st.best_site[r];
+                long long start_site, end_site;
+                if (st.job_flag[r]) {
+                    const u64 jb = st.job_off[r];
+                    start_site = a_start[jb]; end_site = a_end[jb]; nm[m] = a_nm[jb]; score[m] = a_score[jb];
+                    const int no = a_nops[jb];
+                    o[m].cigar_off = (u32)(jb * (u64)max_ops);
+                    o[m].n_cigar = no < 0 ? 255 : (u8)no;
+                } else { end_site = st.best_end[r]; start_site = end_site - L + 1; nm[m] = 0; score[m] = 0; }
+                u64 loc = site;
+                if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; rflag[m] = 16; }
+                else { loc = loc + (u64)start_site; rflag[m] = 0; }
+                int c = 0;
+                for (; c < ix.n_chrom; ++c) if (loc >= ix.chrom_start[c] && loc < ix.chrom_start[c + 1]) break;
+                if (c >= ix.n_chrom) { c = ix.n_chrom - 1; inrange = false; }
+                chrom[m] = c;
+                site_pos[m] = (long long)(loc + 1 - ix.chrom_start[c]);
+                matched[m] = end_site - start_site + 1;
+                const long long clen = (long long)(ix.chrom_start[c + 1] - ix.chrom_start[c]);
+                if ((u64)site_pos[m] + (u64)matched[m] > (u64)clen + 1) inrange = false;
+            }
+            long long mn = site_pos[0], mx = site_pos[0] + matched[0] - 1;
+            if (site_pos[0] > site_pos[1]) mn = site_pos[1];
+            if (mx < site_pos[1] + matched[1] - 1) mx = site_pos[1] + matched[1] - 1;
+            const int tlen = (int)(mx - mn + 1);
+            if (tlen <= max_ins && tlen >= min_ins && inrange) {
+                status = 1;
+                int sd = score[0] + score[1] + range; if (sd < 0) sd = 0; if (sd > range) sd = range;
+                const u32 kk = 2u * (u32)k, sb = ps.sbd[p];
+                const u32 ed = sb > kk ? kk + 1 : sb;
+                const int mapq = mapq_lut[(size_t)ed * (range + 1) + sd];
+                for (int m = 0; m < 2; m++) {
+                    o[m].pos = (u64)site_pos[m]; o[m].chrom = (int16_t)chrom[m]; o[m].mapq = (u8)mapq; o[m].nm = (u16)nm[m];
+                    o[m].score = (int16_t)score[m]; o[m].reserved = (u32)tlen; o[m].path = 3;
+                }
+                o[0].flag = (u16)(rflag[0] == 0 ? (1 | 2 | 32 | 64) : (1 | 2 | 16 | 64));
+                o[1].flag = (u16)(rflag[1] == 0 ? (1 | 2 | 16 | 128) : (1 | 2 | 32 | 128));
+                atomicAdd(&sh[1], 1ull); atomicAdd(&sh[3], 2ull * (unsigned long long)L);
+                atomicAdd(&sh[4], (unsigned long long)(nm[0] + nm[1]));
+            } else status = 3;
+        }
+        if (status == 2) atomicAdd(&sh[2], 1ull);
+        atomicAdd(&sh[0], 1ull);
+        o[0].status = (u8)status; o[1].status = (u8)status;
+        res[2 * p] = o[0]; res[2 * p + 1] = o[1];
     }
     __syncthreads();
     if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&stats[threadIdx.x], sh[threadIdx.x]);

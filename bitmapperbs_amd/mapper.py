@@ -99,6 +99,24 @@ class Mapper:
                       d_cigar_pool: int, cigar_cap: int):
         self._chk(self._lib.bmbs_map_se_device(self._ctx, d_seq, d_qual, L, stride, n, d_results, d_cigar_pool, cigar_cap))
 
+    # ---- fused paired-end mapping (fast mode) ------------------------------------------------------
+    def map_pe(self, seq1, qual1, seq2, qual2, L: int | None = None):
+        """seq2/qual2 = mate 2 as in the FASTQ file.  -> (results[2n] (mate1, mate2 interleaved), cigar_pool)"""
+        a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (seq1, qual1, seq2, qual2)]
+        n, stride = a[0].shape
+        L = stride if L is None else L
+        res = np.zeros(2 * n, dtype=capi.RESULT_DTYPE)
+        cap = max(1, 2 * n * (2 * self.threshold(L) + 8))
+        pool = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        self._chk(self._lib.bmbs_map_pe(self._ctx, capi.ptr(a[0]), capi.ptr(a[1]), capi.ptr(a[2]), capi.ptr(a[3]), L, stride, n,
+                                        capi.ptr(res), capi.ptr(pool), cap, C.byref(used)))
+        return res, pool[:used.value]
+
+    def map_pe_device(self, d_seq1, d_qual1, d_seq2, d_qual2, L, stride, n, d_results, d_cigar_pool, cigar_cap):
+        self._chk(self._lib.bmbs_map_pe_device(self._ctx, d_seq1, d_qual1, d_seq2, d_qual2, L, stride, n, d_results,
+                                               d_cigar_pool, cigar_cap))
+
     def sync(self):
         self._chk(self._lib.bmbs_sync(self._ctx))
 
@@ -212,4 +230,44 @@ def sam_lines_se(index: Index, names, seq: np.ndarray, qual: np.ndarray, L: int,
         out.append("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\n" % (
             nm, int(r["flag"]), index.chrom_names[int(r["chrom"])], int(r["pos"]), int(r["mapq"]),
             cigar_text(r, pool, L), s.tobytes().decode(), q.tobytes().decode(), int(r["nm"])))
+    return out
+
+
+def pe_name(n1, n2) -> str:
+    """inputReads_paired_directly (Process_Reads.cpp:296-307): cut at the first differing char, ' ' or '/'"""
+    a = n1.decode() if isinstance(n1, bytes) else n1
+    b = n2.decode() if isinstance(n2, bytes) else n2
+    j = 0
+    while j < len(a) and j < len(b) and a[j] == b[j] and a[j] not in " /":
+        j += 1
+    a = a[:j]
+    return a[1:] if a.startswith("@") else a
+
+
+def sam_lines_pe(index: Index, names1, names2, seq1, qual1, seq2, qual2, L: int, res: np.ndarray, pool: np.ndarray):
+    """directly_output_read1 / directly_output_read2 (Schema.cpp:10537-10640, 11494-11590); two lines per unique pair"""
+    out = []
+    n = seq1.shape[0]
+    for i in range(n):
+        r1, r2 = res[2 * i], res[2 * i + 1]
+        if int(r1["status"]) != capi.ST_UNIQUE:
+            continue
+        nm = pe_name(names1[i], names2[i])
+        tlen = int(r1["reserved"])
+        p1, p2 = int(r1["pos"]), int(r2["pos"])
+        t1 = "-%d" % tlen if p2 < p1 else "%d" % tlen           # read 1: negative only if the mate lies to the left
+        t2 = "%d" % tlen if p1 > p2 else "-%d" % tlen           # read 2: positive only if the mate lies to the right
+        s1, q1 = seq1[i, :L], qual1[i, :L]
+        if not (int(r1["flag"]) & 32):
+            s1 = _COMP[s1][::-1]; q1 = q1[::-1]
+        s2, q2 = seq2[i, :L], qual2[i, :L]                       # FASTQ orientation
+        if int(r2["flag"]) & 16:
+            s2 = _COMP[s2][::-1]; q2 = q2[::-1]
+        chrom1 = index.chrom_names[int(r1["chrom"])]; chrom2 = index.chrom_names[int(r2["chrom"])]
+        out.append("%s\t%d\t%s\t%d\t%d\t%s\t=\t%d\t%s\t%s\t%s\tNM:i:%d\n" % (
+            nm, int(r1["flag"]), chrom1, p1, int(r1["mapq"]), cigar_text(r1, pool, L), p2, t1,
+            s1.tobytes().decode(), q1.tobytes().decode(), int(r1["nm"])))
+        out.append("%s\t%d\t%s\t%d\t%d\t%s\t=\t%d\t%s\t%s\t%s\tNM:i:%d\n" % (
+            nm, int(r2["flag"]), chrom2, p2, int(r2["mapq"]), cigar_text(r2, pool, L), p1, t2,
+            s2.tobytes().decode(), q2.tobytes().decode(), int(r2["nm"])))
     return out

@@ -141,6 +141,20 @@ int bmbs_map_se_device(bmbs_ctx*, uint64_t d_seq, uint64_t d_qual, int32_t L, in
                        int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap);
 int bmbs_sync(bmbs_ctx*);
 
+/* ---- fused paired-end mapping, default (fast) mode: Map_Pair_Seq_end_to_end_fast (Schema.cpp:18570-19546)
+ * = get_candidates x2 (18172), filter_pairs (16052), verify_candidate_locations (18130) on the smaller side,
+ * filter_pairs_single_side (16186), new_faster_verify_pairs (15773), calculate_best_map_cigar_end_to_end_return
+ * (14602), TLEN / insert / chromosome-end checks and MAPQ over k1+k2 (19400-19440).
+ * seq2/qual2 = mate 2 exactly as in the FASTQ file (the library builds the reverse complement the reference's
+ * reader builds, Process_Reads.cpp:262-267).  Both mates have length L.  results[2*i], results[2*i+1] = mate 1,
+ * mate 2 of pair i: flag 99/83 and 147/163, `reserved` = |TLEN|, status BMBS_ST_* for the PAIR
+ * (BMBS_ST_OFFEND also covers the insert-size rejection).  Stats count pairs (Schema.cpp:19531-19537).   */
+int bmbs_map_pe(bmbs_ctx*, const char* seq1, const char* qual1, const char* seq2, const char* qual2, int32_t L,
+                int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
+                int64_t* n_cigar_used);
+int bmbs_map_pe_device(bmbs_ctx*, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, int32_t L,
+                       int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap);
+
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
  * error bases} (Schema.cpp:25141-25146); bmbs_stats_allreduce sums them over the ctxs one process
  * drives (get_mapping_informations, Schema.cpp:451-476).  Multi-process jobs sum the five int64 with

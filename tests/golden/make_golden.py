@@ -31,6 +31,12 @@ SETS = {
     "e75": dict(reads=dict(n=1500, L=75, seed=5, sub=0.04, indel=0.004, qual="random", n_rate=0.01), args=[]),
 }
 
+PE_SETS = {
+    "p150": dict(reads=dict(n=800, L=150, seed=11, sub=0.01, indel=0.001, qual="random"), args=[]),
+    "p100": dict(reads=dict(n=800, L=100, seed=12, sub=0.02, indel=0.002, qual="random", ins_hi=560), args=["-e", "0.04", "--max", "520"]),
+    "p75": dict(reads=dict(n=800, L=75, seed=13, sub=0.005, indel=0.0, qual="const", ins_lo=60, ins_hi=300), args=["--min", "100", "--max", "250"]),
+}
+
 def genome():
     names, chroms = synth.make_genome(300_000, 2, seed=101)
     rng = np.random.default_rng(202)
@@ -84,6 +90,22 @@ def main():
         open(os.path.join(HERE, "se_%s.ref.stats" % name), "w").write(stats)
         print(name, "lines", body.count("\n"), stats.splitlines()[1])
     json.dump({k: v["args"] for k, v in SETS.items()}, open(os.path.join(HERE, "se_args.json"), "w"))
+    # paired-end (default = fast mode)
+    for name, cfg in PE_SETS.items():
+        m1, m2 = synth.make_reads_pe(chroms, **cfg["reads"])
+        f1 = os.path.join(wd, "pe_%s_1.fq" % name); f2 = os.path.join(wd, "pe_%s_2.fq" % name)
+        synth.write_fastq(f1, m1); synth.write_fastq(f2, m2)
+        sam = os.path.join(wd, "pe_%s.sam" % name)
+        p = subprocess.run([ref, "--search", fa, "--seq1", f1, "--seq2", f2, "-t", "1", "-o", sam] + cfg["args"], capture_output=True, text=True, cwd=wd)
+        assert p.returncode == 0, p.stderr
+        for src, dst in ((f1, "pe_%s_1.fq.gz" % name), (f2, "pe_%s_2.fq.gz" % name)):
+            with open(src, "rb") as f, gzip.GzipFile(os.path.join(HERE, dst), "wb", mtime=0) as g: g.write(f.read())
+        body = "".join(l for l in open(sam) if not l.startswith("@PG"))
+        with gzip.GzipFile(os.path.join(HERE, "pe_%s.ref.sam.gz" % name), "wb", mtime=0) as g: g.write(body.encode())
+        stats = "".join(l for l in p.stderr.splitlines(True) if l.startswith("No. of") or l.startswith("Mismatch"))
+        open(os.path.join(HERE, "pe_%s.ref.stats" % name), "w").write(stats)
+        print("PE", name, "lines", body.count("\n"), stats.splitlines()[1])
+    json.dump({k: v["args"] for k, v in PE_SETS.items()}, open(os.path.join(HERE, "pe_args.json"), "w"))
     shutil.rmtree(wd)
 
 if __name__ == "__main__":

@@ -19,6 +19,10 @@ class OrcParams(C.Structure):
 REC_DTYPE = np.dtype([("status", "<i4"), ("chrom", "<i4"), ("pos", "<u8"), ("site", "<u8"), ("start_site", "<i4"),
                       ("end_site", "<i4"), ("flag", "<i4"), ("mapq", "<i4"), ("nm", "<i4"), ("score", "<i4"),
                       ("path", "<i4"), ("n_cand", "<i4"), ("n_votes", "<i4"), ("cigar", "S256"), ("_pad", "<i4")])
+PE_REC_DTYPE = np.dtype([("status", "<i4"), ("n_pairs", "<i4"), ("mapq", "<i4"), ("tlen", "<i4"), ("flag1", "<i4"), ("flag2", "<i4"),
+                         ("chrom1", "<i4"), ("chrom2", "<i4"), ("pos1", "<u8"), ("pos2", "<u8"), ("nm1", "<i4"), ("nm2", "<i4"),
+                         ("score1", "<i4"), ("score2", "<i4"), ("matched1", "<i4"), ("matched2", "<i4"), ("cigar1", "S256"),
+                         ("cigar2", "S256")])
 COUNTER_KEYS = ("n_reads", "n_hash", "n_ext", "n_lf", "n_sa1", "n_locate_rows", "n_cand", "n_sw", "n_ungapped")
 
 _lib = None
@@ -52,6 +56,7 @@ def load():
     L.orc_sa_at.argtypes = [vp, C.c_uint64]
     L.orc_sa_at.restype = C.c_uint64
     L.orc_map_se.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, i32, i64, vp, vp, vp]
+    L.orc_map_pe.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp]
     L.orc_search_se.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, vp]
     L.orc_search_pe.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp]
     assert C.sizeof(OrcParams) == 48
@@ -92,6 +97,23 @@ class OrcIndex:
         rc = self.L.orc_map_se(self.h, C.byref(prm), seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, stride, n,
                                recs.ctypes.data, st.ctypes.data, cnt.ctypes.data)
         assert rc == 0
+        return recs, st, dict(zip(COUNTER_KEYS, (int(x) for x in cnt)))
+
+    def map_pe(self, prm, seq1, qual1, seq2_fastq, qual2, L):
+        """seq2_fastq = mate 2 as in the FASTQ; the reverse complement the reference's reader builds is made here"""
+        comp = np.arange(256, dtype=np.uint8)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (seq1, qual1, seq2_fastq, qual2)]
+        n, stride = a[0].shape
+        s2 = np.zeros_like(a[2]); s2[:, :L] = comp[a[2][:, :L]][:, ::-1]
+        recs = np.zeros(n, dtype=PE_REC_DTYPE)
+        assert PE_REC_DTYPE.itemsize == 584, PE_REC_DTYPE.itemsize
+        st = np.zeros(5, dtype=np.int64)
+        cnt = np.zeros(len(COUNTER_KEYS), dtype=np.uint64)
+        rc = self.L.orc_map_pe(self.h, C.byref(prm), a[0].ctypes.data, a[1].ctypes.data, s2.ctypes.data, a[3].ctypes.data, L, L, stride, n,
+                               recs.ctypes.data, st.ctypes.data, cnt.ctypes.data)
+        assert rc == 0, rc
         return recs, st, dict(zip(COUNTER_KEYS, (int(x) for x in cnt)))
 
     def close(self):

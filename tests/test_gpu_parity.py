@@ -236,3 +236,75 @@ def test_full_size_properties_idempotent_and_split_invariant(env):
     recs, _, _ = env["oix"].map_se(orc.params(e_f=0.04), seq[sl].cpu().numpy(), qual[sl].cpu().numpy(), L)
     assert not compare_records(r1[sl], c1, recs, L)
     m.close()
+
+
+# ---- paired end (fast mode) ------------------------------------------------------------------------
+def compare_pe(res, pool, recs, L):
+    from bitmapperbs_amd import mapper
+    bad = []
+    n = recs.size
+    for i in range(n):
+        a1, a2, b = res[2 * i], res[2 * i + 1], recs[i]
+        if int(a1["status"]) != int(b["status"]) or int(a2["status"]) != int(b["status"]):
+            bad.append((i, "status", int(a1["status"]), int(b["status"]))); continue
+        if int(b["status"]) != 1:
+            continue
+        got = (int(a1["flag"]), int(a2["flag"]), int(a1["chrom"]), int(a2["chrom"]), int(a1["pos"]), int(a2["pos"]), int(a1["mapq"]),
+               int(a2["mapq"]), int(a1["nm"]), int(a2["nm"]), int(a1["score"]), int(a2["score"]), int(a1["reserved"]),
+               mapper.cigar_text(a1, pool, L), mapper.cigar_text(a2, pool, L))
+        exp = (int(b["flag1"]), int(b["flag2"]), int(b["chrom1"]), int(b["chrom2"]), int(b["pos1"]), int(b["pos2"]), int(b["mapq"]),
+               int(b["mapq"]), int(b["nm1"]), int(b["nm2"]), int(b["score1"]), int(b["score2"]), int(b["tlen"]),
+               b["cigar1"].decode(), b["cigar2"].decode())
+        if got != exp:
+            bad.append((i, got, exp))
+    return bad
+
+
+PE_CASES = [
+    dict(n=20000, L=150, seed=1, sub=0.01, indel=0.001, qual="random", prm={}),
+    dict(n=20000, L=100, seed=2, sub=0.02, indel=0.002, qual="random", ins_hi=560, prm=dict(e_f=0.04, max_ins=520)),
+    dict(n=6000, L=250, seed=3, sub=0.03, indel=0.001, qual="random", ins_hi=700, prm=dict(max_ins=800)),
+    dict(n=15000, L=75, seed=4, sub=0.005, indel=0.0, qual="const", ins_lo=60, ins_hi=300, prm=dict(min_ins=100, max_ins=250)),
+    dict(n=10000, L=150, seed=5, sub=0.0, indel=0.0, qual="const", conv=0.0, prm={}),     # exact reads, no conversion: exit A/B heavy
+]
+
+
+@pytest.mark.parametrize("case", PE_CASES, ids=lambda c: "L%d_s%d" % (c["L"], c["seed"]))
+def test_map_pe_records_and_stats_match_oracle(case, env):
+    from bitmapperbs_amd import synth, mapper
+    c = dict(case); prm = c.pop("prm")
+    m1, m2 = synth.make_reads_pe(env["chroms"], **c)
+    L = c["L"]
+    m = mapper.Mapper(env["ix"], 0, **prm)
+    res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+    recs, ost, cnt = env["oix"].map_pe(orc.params(**prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+    bad = compare_pe(res, pool, recs, L)
+    assert not bad, bad[:5]
+    assert (m.stats() == ost).all(), (m.stats(), ost)
+    m.close()
+
+
+def pe_golden_args():
+    import json
+    return json.load(open(os.path.join(GOLD, "pe_args.json")))
+
+
+@pytest.mark.parametrize("name", sorted(pe_golden_args()))
+def test_gpu_pe_sam_equals_reference_golden(name, tmp_path):
+    from bitmapperbs_amd import mapper, distributed
+    from test_oracle import pe_params
+    fa = str(tmp_path / "genome.fa"); f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1)
+    gunzip_to(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), f2)
+    mapper.Index.build(fa, fa, threads=4)
+    ix = mapper.Index(fa)
+    n1, s1, q1 = read_fastq(f1); n2, s2, q2 = read_fastq(f2)
+    L = s1.shape[1]
+    m = mapper.Mapper(ix, 0, **pe_params(pe_golden_args()[name]))
+    res, pool = m.map_pe(s1, q1, s2, q2, L)
+    text = mapper.sam_header(ix, "") + "".join(mapper.sam_lines_pe(ix, n1, n2, s1, q1, s2, q2, L, res, pool))
+    mine = "".join(l + "\n" for l in text.split("\n")[:-1] if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "pe_%s.ref.sam.gz" % name), "rt").read()
+    assert distributed.mapstats_text(m.stats()) == open(os.path.join(GOLD, "pe_%s.ref.stats" % name)).read()
+    m.close()

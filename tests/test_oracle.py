@@ -104,3 +104,63 @@ def test_mapq_table_spot_values():
     assert L.orc_mapq(C.byref(p), 0, 6, 0) == 1
     assert L.orc_mapq(C.byref(p), 6, 6, 0) == 39
     assert L.orc_mapq(C.byref(p), 3, 6, -6) == 25               # rank_error 0.5, rank 0.875
+
+
+def pe_golden_args():
+    import json
+    return json.load(open(os.path.join(GOLD, "pe_args.json")))
+
+
+def pe_params(args):
+    kw = dict(e_f=e_of(args))
+    if "--min" in args:
+        kw["min_ins"] = int(args[args.index("--min") + 1])
+    if "--max" in args:
+        kw["max_ins"] = int(args[args.index("--max") + 1])
+    return kw
+
+
+@pytest.mark.parametrize("name", sorted(pe_golden_args()))
+def test_oracle_reproduces_reference_golden_sam_paired_end(name, golden_index, tmp_path, oracle):
+    import ctypes as C
+    args = pe_golden_args()[name]
+    f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq"); out = str(tmp_path / "o.sam")
+    gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1)
+    gunzip_to(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), f2)
+    ix = orc.OrcIndex(golden_index)
+    st = np.zeros(5, dtype=np.int64)
+    prm = orc.params(**pe_params(args))
+    assert oracle.orc_search_pe(ix.h, C.byref(prm), f1.encode(), f2.encode(), out.encode(), b"", st.ctypes.data) == 0
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "pe_%s.ref.sam.gz" % name), "rt").read()
+    from bitmapperbs_amd import distributed
+    assert distributed.mapstats_text(st) == open(os.path.join(GOLD, "pe_%s.ref.stats" % name)).read()
+
+
+@pytest.mark.skipif(ref_binary() is None, reason="oracle/_ref/bitmapperBS not built")
+@pytest.mark.parametrize("cfg", [
+    dict(n=15000, L=150, seed=21, sub=0.01, indel=0.001, qual="random", args=[]),
+    dict(n=15000, L=100, seed=22, sub=0.02, indel=0.002, qual="random", ins_hi=560, args=["-e", "0.04", "--max", "520"]),
+    dict(n=5000, L=250, seed=23, sub=0.03, indel=0.001, qual="random", ins_hi=700, args=["--max", "800"]),
+])
+def test_oracle_vs_reference_binary_fresh_data_paired_end(cfg, tmp_path, oracle):
+    from bitmapperbs_amd import synth
+    cfg = dict(cfg); args = cfg.pop("args")
+    names, chroms = synth.make_genome(600_000, 3, seed=41 + cfg["seed"])
+    plant_repeats(chroms, seed=cfg["seed"])
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, chroms)
+    assert oracle.orc_index_build(fa.encode(), fa.encode()) == 0
+    m1, m2 = synth.make_reads_pe(chroms, **cfg)
+    f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq")
+    synth.write_fastq(f1, m1); synth.write_fastq(f2, m2)
+    ref_sam = str(tmp_path / "ref.sam"); my_sam = str(tmp_path / "orc.sam")
+    p = subprocess.run([ref_binary(), "--search", fa, "--seq1", f1, "--seq2", f2, "-t", "1", "-o", ref_sam] + args,
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    q = subprocess.run([os.path.join(ROOT, "oracle", "bmbs_oracle"), "search", fa, "--seq1", f1, "--seq2", f2, "-o", my_sam] + args,
+                       capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr
+    assert [l for l in open(ref_sam) if not l.startswith("@PG")] == [l for l in open(my_sam) if not l.startswith("@PG")]
+    assert [l.split() for l in p.stderr.splitlines() if l.startswith("No. of")] == \
+           [l.split() for l in q.stderr.splitlines() if l.startswith("No. of")]
