@@ -39,7 +39,8 @@ struct bmbs_ctx {
     DevBuf verdict, n_seeds, multi, mm_site, exit_site, seeds, n_cand, cand_off, n_votes, best_site,
         best_end, best_err, sbd, red_status, job_flag, job_off, scan_tmp, totals;
     // per-candidate / per-job workspace
-    DevBuf cand, votes, slot_read, ferr, fend, job_read, H, E, z, a_start, a_end, a_nm, a_score, a_nops;
+    DevBuf cand, votes, slot_read, ferr, fend, job_read, job_site, job_end, job_err, need_sw, sw_off, sw_job, trace,
+        a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d;
     // paired-end workspace
@@ -201,14 +202,48 @@ ReadState read_state(bmbs_ctx* c)
     return s;
 }
 
-int align_scratch(bmbs_ctx* c, u64 n_jobs, int L, int k, AlignScratch& sc)
+template <int KB>
+void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int stride, int k, u64 n_jobs, const Jobs& jobs,
+               u32 rev_from, u32* d_cigar_pool, int max_ops)
+{
+    hipLaunchKernelGGL(k_align_sw<KB>, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+                       d_qual, L, stride, k, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
+                       n_jobs, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                       c->a_score.as<int>(), c->a_nops.as<int>());
+}
+
+// K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the
+// register-band DP kernel instantiated for the smallest KB >= k.  No host round-trip inside.
+int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int stride, int k, u64 n_jobs, const Jobs& jobs,
+              u32 rev_from, u32* d_cigar_pool, int max_ops)
 {
     const u64 nj = n_jobs ? n_jobs : 1;
-    const u64 qlen = (u64)L + 2 * k;
-    ENS(c, c->H, (qlen + 2) * nj * 4); ENS(c, c->E, (qlen + 2) * nj * 4);
-    ENS(c, c->z, (u64)(2 * k + 1) * L * nj);
+    const u64 nwk = (u64)((2 * k + 1 + 15) / 16);
     ENS(c, c->a_start, nj * 4); ENS(c, c->a_end, nj * 4); ENS(c, c->a_nm, nj * 4); ENS(c, c->a_score, nj * 4); ENS(c, c->a_nops, nj * 4);
-    sc.H = c->H.as<int>(); sc.E = c->E.as<int>(); sc.z = c->z.as<u8>(); sc.n_jobs = nj;
+    ENS(c, c->need_sw, nj * 4); ENS(c, c->sw_off, (nj + 1) * 8); ENS(c, c->sw_job, nj * 4);
+    if (!n_jobs) return BMBS_OK;
+    ENS(c, c->trace, nj * (u64)L * nwk * 8);
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    prof_begin(c, "k_align_ungapped");
+    hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+                       d_qual, L, stride, k, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                       c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
+    prof_end(c);
+    prof_begin(c, "scan_sw");
+    int rc = scan_u32(c, c->need_sw.as<u32>(), n_jobs, c->sw_off.as<u64>(), 2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sw_list, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, n_jobs, c->need_sw.as<u32>(), c->sw_off.as<u64>(),
+                       c->sw_job.as<u32>());
+    prof_end(c);
+    prof_begin(c, "k_align_sw");
+    if (k <= 4) launch_sw<4>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else launch_sw<31>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    prof_end(c);
     return BMBS_OK;
 }
 
@@ -283,7 +318,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->ferr, &c->fend,
-                     &c->job_read, &c->H, &c->E, &c->z, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
+                     &c->job_read, &c->job_site, &c->job_end, &c->job_err, &c->need_sw, &c->sw_off, &c->sw_job, &c->trace, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
                      &c->stats, &c->counters, &c->pe_seq, &c->pe_qual, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
                      &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2};
@@ -399,20 +434,18 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     const int max_ops = 2 * k + 8;
     c->last_max_ops = max_ops;
     if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small"; return BMBS_ENOMEM; }
-    AlignScratch sc;
-    rc = align_scratch(c, n_jobs, L, k, sc);
-    if (rc) return rc;
-    ENS(c, c->job_read, (n_jobs ? n_jobs : 1) * 4);
-    if (n_jobs) {
-        prof_begin(c, "k_job_list");
-        hipLaunchKernelGGL(k_job_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, c->job_read.as<u32>());
-        prof_end(c);
-        prof_begin(c, "k_align");
-        hipLaunchKernelGGL(k_align, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
-                           d_seq, d_qual, L, stride, k, n_jobs, c->job_read.as<u32>(), st, sc,
-                           reinterpret_cast<u32*>(d_cigar_pool), max_ops, c->a_start.as<int>(), c->a_end.as<int>(),
-                           c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), cnt, 0xffffffffu);
-        prof_end(c);
+    {
+        const u64 nj = n_jobs ? n_jobs : 1;
+        ENS(c, c->job_read, nj * 4); ENS(c, c->job_site, nj * 8); ENS(c, c->job_end, nj * 4); ENS(c, c->job_err, nj * 4);
+        if (n_jobs) {
+            prof_begin(c, "k_job_list");
+            hipLaunchKernelGGL(k_job_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, c->job_read.as<u32>(),
+                               c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>());
+            prof_end(c);
+        }
+        Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
+        rc = run_align(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, 0xffffffffu, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
+        if (rc) return rc;
     }
     prof_begin(c, "k_finalize");
     hipLaunchKernelGGL(k_finalize, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
@@ -546,20 +579,19 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     const int max_ops = 2 * k + 8;
     c->last_max_ops = max_ops;
     if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small"; return BMBS_ENOMEM; }
-    AlignScratch sc;
-    rc = align_scratch(c, n_jobs, L, k, sc);
-    if (rc) return rc;
-    ENS(c, c->job_read, (n_jobs ? n_jobs : 1) * 4);
-    if (n_jobs) {
-        prof_begin(c, "k_job_list");
-        hipLaunchKernelGGL(k_job_list, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, st, c->job_read.as<u32>());
-        prof_end(c);
-        prof_begin(c, "k_align");
-        hipLaunchKernelGGL(k_align, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
-                           seq_all, qual_all, L, stride, k, n_jobs, c->job_read.as<u32>(), st, sc,
-                           reinterpret_cast<u32*>(d_cigar_pool), max_ops, c->a_start.as<int>(), c->a_end.as<int>(),
-                           c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), cnt, (u32)n);
-        prof_end(c);
+    {
+        const u64 nj = n_jobs ? n_jobs : 1;
+        ENS(c, c->job_read, nj * 4); ENS(c, c->job_site, nj * 8); ENS(c, c->job_end, nj * 4); ENS(c, c->job_err, nj * 4);
+        if (n_jobs) {
+            prof_begin(c, "k_job_list");
+            hipLaunchKernelGGL(k_job_list, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, st, c->job_read.as<u32>(),
+                               c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>());
+            prof_end(c);
+        }
+        Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
+        // mate 2 rows (>= n) carry FASTQ-order qualities for a reverse-complemented read: need_reverse_quality = 1
+        rc = run_align(c, seq_all, qual_all, L, stride, k, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
+        if (rc) return rc;
     }
     prof_begin(c, "k_finalize_pe");
     hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->mapq_lut.as<u8>(), c->mapq_range, L, k,
@@ -637,9 +669,6 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_qual, bytes + 64);
     ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->in_c, m * 4); ENS(c, c->in_d, m * 4);
     ENS(c, c->cig_pool, m * (u64)max_ops * 4);
-    AlignScratch sc;
-    int rc = align_scratch(c, m, L, k, sc);
-    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_qual.p, qual, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_a.p, read_of, m * 4, hipMemcpyHostToDevice, c->stream));
@@ -647,10 +676,10 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     HIPCHK(c, hipMemcpyAsync(c->in_c.p, end_site_in, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_d.p, err_in, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->cig_pool.p, 0, m * (u64)max_ops * 4, c->stream));
-    hipLaunchKernelGGL(k_align_pairs, dim3(nblk(m, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
-                       c->in_seq.as<char>(), c->in_qual.as<char>(), L, stride, k, m, c->in_a.as<u32>(), c->in_b.as<u64>(),
-                       c->in_c.as<int>(), c->in_d.as<u32>(), sc, c->cig_pool.as<u32>(), max_ops, c->a_start.as<int>(),
-                       c->a_end.as<int>(), c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>());
+    c->n_prof_used = 0;
+    Jobs jobs = {c->in_a.as<u32>(), c->in_b.as<u64>(), c->in_c.as<int>(), c->in_d.as<u32>()};
+    int rc = run_align(c, c->in_seq.as<char>(), c->in_qual.as<char>(), L, stride, k, m, jobs, 0xffffffffu, c->cig_pool.as<u32>(), max_ops);
+    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(start_site, c->a_start.p, m * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(end_site, c->a_end.p, m * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(nm, c->a_nm.p, m * 4, hipMemcpyDeviceToHost, c->stream));

@@ -635,99 +635,190 @@ k_reduce(long n, ReadState st, const bmbs_vote* __restrict__ votes, const u32* _
     } else if (min_idx != -1) st.red_status[r] = 2;
 }
 
-__global__ void k_job_list(long n, ReadState st, u32* __restrict__ job_read)
+// job arrays shared by the fused path and bmbs_align_batch
+struct Jobs {
+    const u32* read;      // read (row) of the job
+    const u64* site;      // window start (doubled coordinate)
+    const int* end;       // end_site from the filter
+    const u32* err;       // err from the filter
+};
+
+__global__ void k_job_list(long n, ReadState st, u32* __restrict__ job_read, u64* __restrict__ job_site,
+                           int* __restrict__ job_end, u32* __restrict__ job_err)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    if (st.job_flag[r]) job_read[st.job_off[r]] = (u32)r;
+    if (st.job_flag[r]) {
+        const u64 j = st.job_off[r];
+        job_read[j] = (u32)r; job_site[j] = st.best_site[r]; job_end[j] = st.best_end[r]; job_err[j] = st.best_err[r];
+    }
 }
 
 // ================================================================================================
 // K11-K13: un-gapped recheck, banded affine-gap semi-global alignment with traceback, CIGAR + NM
 // ================================================================================================
-struct AlignOut { int start, end; u32 nm; int score; int n_ops; };
-
-// scratch layout: interleaved by job so that a wave's accesses coalesce
-struct AlignScratch { int* H; int* E; u8* z; u64 n_jobs; };
-
 // fast_recalculate_bs_Cigar (ksw.cpp:2578-2876) = try_cigar_without_path (:2515) else
 // ksw_semi_global_quality_back (:1850-2045) + leading/trailing-I folding + NM recount.
 // pen_lut[q] = MismatchPenaltyByQuality(q) evaluated on the host in IEEE double (ksw.h:148-161); the
 // per-cell `(int)(mat_diff * Phred)` of the reference (ksw.cpp:1950) is the same product.
-DEVI void align_one(const DevIndex& ix, const ScoreParams& sp, const int* __restrict__ pen_lut,
-                    const char* rd, const char* ql, bool rev_qual, int L, int k, u64 site, int end_site, u32 err_in,
-                    const AlignScratch& sc, u64 job, u32* __restrict__ ops_out, int max_ops, AlignOut& out)
+//
+// Two kernels so that lanes stay dense: k_align_ungapped (every job; most succeed) marks the jobs
+// that really need the DP, k_align_sw runs only those (compacted by a scan, no host round-trip).
+// k_align_sw keeps the whole DP band (H, E of 2k+2 cells, the 2-bit window, the row's trace nibbles)
+// in REGISTERS: the band loop is fully unrolled for a compile-time bound KB >= k, cell b of row i
+// reads slot b and writes slot b-1 (the band slides one column per row), and the only memory traffic
+// of the DP is one packed trace word (4 bits per cell) per 16 cells per row, interleaved by job.
+
+// window base with the all-zero-window rule (out-of-strand request: every base compares unequal and
+// scores as N, nt4[0] = 4)
+struct WinReader {
+    const u64* g; u64 pos, w; int left; bool valid;
+    DEVI void init(const DevIndex& ix, u64 start, bool v) { g = ix.gen2; valid = v; pos = start; if (v) { w = g[pos >> 5] >> ((pos & 31) * 2); left = 32 - (int)(pos & 31); } else { w = 0; left = 32; } }
+    DEVI int next() { if (!valid) return 4; const int b = (int)(w & 3); w >>= 2; pos++; left--; if (left == 0) { w = g[pos >> 5]; left = 32; } return b; }
+};
+
+__global__ void __launch_bounds__(256)
+k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
+                 const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
+                 int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
+                 int* __restrict__ a_nops, u32* __restrict__ need_sw, unsigned long long* __restrict__ counters)
 {
-    const bool fwd = site < ix.G;
-    const int p_len = L + 2 * k;
-    auto qat = [&](int i) -> int { return (unsigned char)ql[rev_qual ? L - 1 - i : i]; };
-    const bool wvalid = window_valid(ix, site, (u64)p_len, fwd);
-    auto wbase = [&](int j) -> int { return wvalid ? gbase(ix, site + (u64)j) : 4; };   // all-zero window: nt4[0] = 4
-    // read char vs window base: equal letter, or read T on window C
-    auto is_match = [&](char a, int b) -> bool { return code4(a) == b || (a == 'T' && b == 1); };
-    out.n_ops = 0;
-    // ---- K11
-    {
-        int tmp_err = 0, score = 0;
-        const int start = end_site - L + 1;
-        bool ok = start >= 0;
-        if (ok) {
-            for (int i = 0; i < L; i++) {
-                const char a = rd[i];
-                if (!is_match(a, wbase(i + start))) {
-                    if (++tmp_err > (int)err_in) { ok = false; break; }
-                    score -= a == 'N' ? sp.np : pen_lut[qat(i)];
-                }
-            }
-            if (ok && tmp_err == (int)err_in) { out.start = start; out.end = end_site; out.nm = err_in; out.score = score; return; }
-        }
+    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb >= n_jobs) return;
+    const u32 r = jb_.read[jb];
+    const u64 site = jb_.site[jb];
+    const int end_site = jb_.end[jb];
+    const u32 err_in = jb_.err[jb];
+    need_sw[jb] = 0;
+    if (err_in == 0) {          // fast_recalculate_bs_Cigar's own err == 0 branch (ksw.cpp:2607-2616)
+        a_start[jb] = end_site - L + 1; a_end[jb] = end_site; a_nm[jb] = 0; a_score[jb] = 0; a_nops[jb] = 0;
+        return;
     }
-    // ---- K12
+    const char* rd = seq + (size_t)r * stride;
+    const char* ql = qual + (size_t)r * stride;
+    const bool rev = r >= rev_qual_from;
+    const int p_len = L + 2 * k;
+    const bool wvalid = window_valid(ix, site, (u64)p_len, site < ix.G);
+    const int start = end_site - L + 1;
+    bool ok = start >= 0;
+    int tmp_err = 0, score = 0;
+    if (ok) {
+        WinReader wr; wr.init(ix, site + (u64)start, wvalid);
+        for (int i = 0; i < L; i++) {
+            const char a = rd[i];
+            const int b = wr.next();
+            if (!(code4(a) == b || (a == 'T' && b == 1))) {
+                if (++tmp_err > (int)err_in) { ok = false; break; }
+                score -= a == 'N' ? sp.np : pen_lut[(unsigned char)ql[rev ? L - 1 - i : i]];
+            }
+        }
+        if (ok && tmp_err != (int)err_in) ok = false;
+    }
+    if (ok) { a_start[jb] = start; a_end[jb] = end_site; a_nm[jb] = err_in; a_score[jb] = score; a_nops[jb] = 0; }
+    else need_sw[jb] = 1;
+    if (counters) atomicAdd(&counters[4], 1ull);
+}
+
+__global__ void k_sw_list(u64 n_jobs, const u32* __restrict__ need_sw, const u64* __restrict__ sw_off, u32* __restrict__ sw_job)
+{
+    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb >= n_jobs) return;
+    if (need_sw[jb]) sw_job[sw_off[jb]] = (u32)jb;
+}
+
+template <int KB>
+__global__ void __launch_bounds__(64)
+k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
+           const char* __restrict__ qual, int L, int stride, int k, const u64* __restrict__ n_sw_ptr,
+           const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride,
+           u32* __restrict__ cigar_pool, int max_ops,
+           int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
+           int* __restrict__ a_nops)
+{
+    constexpr int BW = 2 * KB + 1;          // compile-time bound of the band width
+    constexpr int NW = (BW + 15) / 16;      // trace words per row (4 bits per cell)
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *n_sw_ptr) return;
+    const u64 jb = sw_job[t];
+    const u32 r = jb_.read[jb];
+    const u64 site = jb_.site[jb];
+    const char* rd = seq + (size_t)r * stride;
+    const char* ql = qual + (size_t)r * stride;
+    const bool rev = r >= rev_qual_from;
+    const bool fwd = site < ix.G;
+    const int band = 2 * k + 1;
+    const int p_len = L + 2 * k, tlen = L;
+    const bool wvalid = window_valid(ix, site, (u64)p_len, fwd);
     const int MINUS_INF = -0x40000000;
     const int gapoe = sp.gap_open + sp.gap_ext, gape = sp.gap_ext;
-    const int band = 2 * k + 1;
-    const int qlen = p_len, tlen = L;
-    const u64 NJ = sc.n_jobs;
-    auto Hx = [&](int j) -> int& { return sc.H[(u64)j * NJ + job]; };
-    auto Ex = [&](int j) -> int& { return sc.E[(u64)j * NJ + job]; };
-    auto Zx = [&](int i, int jj) -> u8& { return sc.z[((u64)i * band + jj) * NJ + job]; };
-    int j;
-    for (j = 0; j < band; ++j) { Hx(j) = 0; Ex(j) = -gapoe; }
-    for (; j <= qlen; ++j) { Hx(j) = MINUS_INF; Ex(j) = MINUS_INF; }
-    int beg = 0, end = 0;
+    int RH[BW + 1], RE[BW + 1];
+#pragma unroll
+    for (int b = 0; b <= BW; b++) { RH[b] = b < band ? 0 : MINUS_INF; RE[b] = b < band ? -gapoe : MINUS_INF; }
+    // window bases i .. i+band-1 of the current row as 3-bit codes (4 = out-of-strand) in two u64 x 2 ... keep
+    // it simple: 4 bits per base, up to 63 bases -> four u64
+    u64 wq[(BW + 15) / 16];
+#pragma unroll
+    for (int q = 0; q < NW; q++) wq[q] = 0;
+    WinReader wr; wr.init(ix, site, wvalid);
+    for (int b = 0; b < band; b++) { const u64 v = (u64)wr.next(); wq[b >> 4] |= v << (4 * (b & 15)); }
+    u64* tz = trace + t;                    // word (i*NWk + q) lives at tz[(i*NWk + q) * trace_stride]
+    const int NWk = (band + 15) / 16;
+    int h1_last = MINUS_INF;
     for (int i = 0; i < tlen; ++i) {
         int f = MINUS_INF, h1 = MINUS_INF;
         const char a = rd[i];
         const int ta = code4(a);
-        const int mis = ta == 4 ? -sp.np : -pen_lut[qat(i)];
-        beg = i; end = i + band;
-        for (j = beg; j < end; ++j) {
-            int m = Hx(j), e = Ex(j), h, t;
-            u8 d;
-            Hx(j) = h1;
-            const int b = wbase(j);
-            m += (ta == b || (ta == 3 && b == 1)) ? 0 : (b == 4 ? -sp.np : mis);
-            d = m >= e ? 0 : 1;
-            h = m >= e ? m : e;
-            d = h >= f ? d : 2;
-            h = h >= f ? h : f;
-            h1 = h;
-            t = m - gapoe;
-            e -= gape;
-            d |= e > t ? 1 << 2 : 0;
-            e = e > t ? e : t;
-            Ex(j) = e;
-            f -= gape;
-            d |= f > t ? 2 << 4 : 0;
-            f = f > t ? f : t;
-            Zx(i, j - beg) = d;
+        const int mis = ta == 4 ? -sp.np : -pen_lut[(unsigned char)ql[rev ? L - 1 - i : i]];
+        u64 tw[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) tw[q] = 0;
+#pragma unroll
+        for (int b = 0; b < BW; b++) {
+            if (b < band) {
+                int m = RH[b], e = RE[b], h, tt;
+                const int wb = (int)((wq[b >> 4] >> (4 * (b & 15))) & 15);
+                m += (ta == wb || (ta == 3 && wb == 1)) ? 0 : (wb == 4 ? -sp.np : mis);
+                int d = m >= e ? 0 : 1;
+                h = m >= e ? m : e;
+                d = h >= f ? d : 2;
+                h = h >= f ? h : f;
+                tt = m - gapoe;
+                e -= gape;
+                d |= e > tt ? 4 : 0;
+                e = e > tt ? e : tt;
+                f -= gape;
+                d |= f > tt ? 8 : 0;
+                f = f > tt ? f : tt;
+                // eh[j].h = h1 (H(i, j-1)), eh[j].e = e: next row reads them one slot to the left
+                if (b > 0) { RH[b - 1] = h1; RE[b - 1] = e; }
+                h1 = h;
+                tw[b >> 4] |= (u64)d << (4 * (b & 15));
+            }
         }
-        Hx(end) = h1; Ex(end) = MINUS_INF;
+        // eh[end] = { h1, -inf }
+#pragma unroll
+        for (int b = 0; b <= BW; b++) if (b == band - 1) { RH[b] = h1; RE[b] = MINUS_INF; }
+        h1_last = h1;
+#pragma unroll
+        for (int q = 0; q < NW; q++) if (q < NWk) tz[((u64)i * NWk + q) * trace_stride] = tw[q];
+        // slide the window one base
+#pragma unroll
+        for (int q = 0; q < NW; q++) { wq[q] >>= 4; if (q + 1 < NW) wq[q] |= (wq[q + 1] & 15) << 60; }
+        if (i + 1 < tlen) {
+            const u64 v = (u64)wr.next();
+#pragma unroll
+            for (int q = 0; q < NW; q++) if (q == ((band - 1) >> 4)) wq[q] |= v << (4 * ((band - 1) & 15));
+        }
     }
-    int max_i = tlen + k, score = Hx(max_i);
-    for (int i = end; i > beg; i--) { const int h = Hx(i); if (h > score) { score = h; max_i = i; } }
+    (void)h1_last;
+    // score: un-gapped diagonal wins ties, then the highest column (ksw.cpp:2001-2010)
+    int max_i = tlen + k, score = MINUS_INF;
+#pragma unroll
+    for (int b = 0; b < BW; b++) if (b == k) score = RH[b];
+#pragma unroll
+    for (int bp = BW; bp >= 1; bp--) if (bp <= band) { const int h = RH[bp - 1]; if (h > score) { score = h; max_i = tlen - 1 + bp; } }
     int qe = max_i - 1;
-    // traceback into a local op list (built back to front)
+    // traceback
     const int LOCAL_OPS = 160;
     u32 cg[LOCAL_OPS + 1];
     int nc = 0;
@@ -736,106 +827,65 @@ DEVI void align_one(const DevIndex& ix, const ScoreParams& sp, const int* __rest
         if (nc == 0 || op != (int)(cg[nc - 1] & 0xf)) { if (nc < LOCAL_OPS) cg[nc++] = ((u32)len << 4) | (u32)op; else overflow = true; }
         else cg[nc - 1] += (u32)len << 4;
     };
-    {
-        int i = tlen - 1, kk = max_i - 1, which = 0;
-        while (i >= 0 && kk >= 0) {
-            which = (Zx(i, kk - i) >> (which << 1)) & 3;
-            if (which == 0) { push(0, 1); --i; --kk; }
-            else if (which == 1) { push(2, 1); --i; }
-            else { push(1, 1); --kk; }
-        }
-        if (i >= 0) push(2, i + 1);
-        for (int a2 = 0, b2 = nc - 1; a2 < b2; a2++, b2--) { const u32 t = cg[a2]; cg[a2] = cg[b2]; cg[b2] = t; }
-        cg[nc] = 0;
-        int qb = kk + 1;
-        // ---- K13: fold leading / trailing insertions into M (ksw.cpp:2677-2772)
-        int n_cigar = nc, ii, op, opl, ins = 0;
-        for (ii = 0; ii < n_cigar; ++ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
-        if (ii != 0) {
-            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
-            if (op == 0) opl += ins; else { op = 0; opl = ins; ii--; }
-            cg[ii] = ((u32)opl << 4) | (u32)op;
-            qb -= ins;
-        }
-        const int cigar_b = ii;
-        ins = 0;
-        for (ii = n_cigar - 1; ii >= cigar_b; --ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
-        if (ii != n_cigar - 1) {
-            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
-            if (op == 0) opl += ins; else { op = 0; opl = ins; ii++; }
-            cg[ii] = ((u32)opl << 4) | (u32)op;
-            qe += ins;
-        }
-        const int cigar_e = ii;
-        // NM recount under bisulfite matching + emit in SAM order (ksw.cpp:2779-2857)
-        int NM = 0, no = 0;
-        if (fwd) {
-            int qs = qb, ts = 0;
-            for (ii = cigar_b; ii <= cigar_e; ++ii) {
-                op = cg[ii] & 0xf; opl = cg[ii] >> 4;
-                if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
-                no++;
-                if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[ts], wbase(qs)) ) NM++; qs++; ts++; } }
-                else if (op == 1) { qs += opl; NM += opl; }
-                else { ts += opl; NM += opl; }
-            }
-        } else {
-            int qx = qe, te = tlen - 1;
-            for (ii = cigar_e; ii >= cigar_b; --ii) {
-                op = cg[ii] & 0xf; opl = cg[ii] >> 4;
-                if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
-                no++;
-                if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[te], wbase(qx))) NM++; qx--; te--; } }
-                else if (op == 1) { qx -= opl; NM += opl; }
-                else { te -= opl; NM += opl; }
-            }
-        }
-        out.start = qb; out.end = qe; out.nm = (u32)NM; out.score = score;
-        out.n_ops = overflow ? -1 : no;
+    int i = tlen - 1, kk = max_i - 1, which = 0;
+    while (i >= 0 && kk >= 0) {
+        const int b = kk - i;
+        const int d = (int)((tz[((u64)i * NWk + (b >> 4)) * trace_stride] >> (4 * (b & 15))) & 15);
+        which = which == 0 ? (d & 3) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
+        if (which == 0) { push(0, 1); --i; --kk; }
+        else if (which == 1) { push(2, 1); --i; }
+        else { push(1, 1); --kk; }
     }
-}
-
-// NOTE on the NM recount: the reference counts pattern != text unless (pattern == 'C' && text == 'T');
-// a window never holds 'N', so this equals !is_match(read, window).
-
-__global__ void __launch_bounds__(64)
-k_align(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
-        const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, const u32* __restrict__ job_read,
-        ReadState st, AlignScratch sc, u32* __restrict__ cigar_pool, int max_ops,
-        int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
-        int* __restrict__ a_nops, unsigned long long* __restrict__ counters, u32 rev_qual_from)
-{
-    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (jb >= n_jobs) return;
-    const u32 r = job_read[jb];
-    AlignOut o;
-    // mate 2 rows (r >= rev_qual_from) carry the reverse-complemented read with FASTQ-order qualities:
-    // need_reverse_quality = 1 (Schema.cpp:19370-19378)
-    align_one(ix, sp, pen_lut, seq + (size_t)r * stride, qual + (size_t)r * stride, r >= rev_qual_from, L, k,
-              st.best_site[r], st.best_end[r], st.best_err[r], sc, jb, cigar_pool + jb * (u64)max_ops, max_ops, o);
-    a_start[jb] = o.start; a_end[jb] = o.end; a_nm[jb] = o.nm; a_score[jb] = o.score; a_nops[jb] = o.n_ops;
-    if (counters) atomicAdd(&counters[4], 1ull);
-}
-
-// standalone form for bmbs_align_batch
-__global__ void __launch_bounds__(64)
-k_align_pairs(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
-              const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, const u32* __restrict__ read_of,
-              const u64* __restrict__ site, const int* __restrict__ end_in, const u32* __restrict__ err_in,
-              AlignScratch sc, u32* __restrict__ cigar_pool, int max_ops,
-              int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
-              int* __restrict__ a_nops)
-{
-    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (jb >= n_jobs) return;
-    const u32 r = read_of[jb];
-    AlignOut o;
-    if (err_in[jb] == 0) {        // fast_recalculate_bs_Cigar's own err==0 branch (ksw.cpp:2607-2616)
-        o.start = end_in[jb] - L + 1; o.end = end_in[jb]; o.nm = 0; o.score = 0; o.n_ops = 0;
-    } else
-        align_one(ix, sp, pen_lut, seq + (size_t)r * stride, qual + (size_t)r * stride, false, L, k,
-                  site[jb], end_in[jb], err_in[jb], sc, jb, cigar_pool + jb * (u64)max_ops, max_ops, o);
-    a_start[jb] = o.start; a_end[jb] = o.end; a_nm[jb] = o.nm; a_score[jb] = o.score; a_nops[jb] = o.n_ops;
+    if (i >= 0) push(2, i + 1);
+    for (int a2 = 0, b2 = nc - 1; a2 < b2; a2++, b2--) { const u32 x = cg[a2]; cg[a2] = cg[b2]; cg[b2] = x; }
+    cg[nc] = 0;
+    int qb = kk + 1;
+    // K13: fold leading / trailing insertions into M (ksw.cpp:2677-2772)
+    int n_cigar = nc, ii, op, opl, ins = 0;
+    for (ii = 0; ii < n_cigar; ++ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+    if (ii != 0) {
+        op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+        if (op == 0) opl += ins; else { op = 0; opl = ins; ii--; }
+        cg[ii] = ((u32)opl << 4) | (u32)op;
+        qb -= ins;
+    }
+    const int cigar_b = ii;
+    ins = 0;
+    for (ii = n_cigar - 1; ii >= cigar_b; --ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+    if (ii != n_cigar - 1) {
+        op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+        if (op == 0) opl += ins; else { op = 0; opl = ins; ii++; }
+        cg[ii] = ((u32)opl << 4) | (u32)op;
+        qe += ins;
+    }
+    const int cigar_e = ii;
+    // NM recount under bisulfite matching + ops in SAM order (ksw.cpp:2779-2857); a window never holds 'N'
+    auto wbase = [&](int j) -> int { return wvalid ? gbase(ix, site + (u64)j) : 4; };
+    auto is_match = [&](char a, int b) -> bool { return code4(a) == b || (a == 'T' && b == 1); };
+    u32* ops_out = cigar_pool + jb * (u64)max_ops;
+    int NM = 0, no = 0;
+    if (fwd) {
+        int qs = qb, ts = 0;
+        for (ii = cigar_b; ii <= cigar_e; ++ii) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+            no++;
+            if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[ts], wbase(qs))) NM++; qs++; ts++; } }
+            else if (op == 1) { qs += opl; NM += opl; }
+            else { ts += opl; NM += opl; }
+        }
+    } else {
+        int qx = qe, te = tlen - 1;
+        for (ii = cigar_e; ii >= cigar_b; --ii) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+            no++;
+            if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[te], wbase(qx))) NM++; qx--; te--; } }
+            else if (op == 1) { qx -= opl; NM += opl; }
+            else { te -= opl; NM += opl; }
+        }
+    }
+    a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
 }
 
 // ================================================================================================
