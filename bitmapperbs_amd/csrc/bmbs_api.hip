@@ -44,6 +44,7 @@ struct bmbs_ctx {
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d;
     // paired-end workspace
+    DevBuf sd_sp0, sd_hits0, sd_ml0, sd_tm, sd_seed_id, sd_clen, sd_first_ml, sd_flag_c, sd_flag_d, sd_off_c, sd_off_d, sd_list_c, sd_list_d;
     DevBuf pe_seq, pe_qual, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
     DevBuf stats, counters;
     std::vector<Prof> prof;
@@ -247,15 +248,52 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int str
     return BMBS_OK;
 }
 
+// K1-K5: the four seeding kernels with their two work-list compactions (no host round-trip)
+int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int pe_mode)
+{
+    ENS(c, c->sd_sp0, n * 8); ENS(c, c->sd_hits0, n * 4); ENS(c, c->sd_ml0, n * 2); ENS(c, c->sd_tm, n * 2); ENS(c, c->sd_seed_id, n);
+    ENS(c, c->sd_clen, n * 4); ENS(c, c->sd_first_ml, n * 2); ENS(c, c->sd_flag_c, n * 4); ENS(c, c->sd_flag_d, n * 4);
+    ENS(c, c->sd_off_c, (n + 1) * 8); ENS(c, c->sd_off_d, (n + 1) * 8); ENS(c, c->sd_list_c, n * 4); ENS(c, c->sd_list_d, n * 4);
+    SeedCarry sc;
+    sc.sp0 = c->sd_sp0.as<u64>(); sc.hits0 = c->sd_hits0.as<u32>(); sc.ml0 = c->sd_ml0.as<u16>(); sc.tm = c->sd_tm.as<u16>();
+    sc.seed_id = c->sd_seed_id.as<u8>(); sc.clen = c->sd_clen.as<u32>(); sc.first_ml = c->sd_first_ml.as<u16>();
+    sc.flag_c = c->sd_flag_c.as<u32>(); sc.flag_d = c->sd_flag_d.as<u32>(); sc.off_c = c->sd_off_c.as<u64>(); sc.off_d = c->sd_off_d.as<u64>();
+    sc.list_c = c->sd_list_c.as<u32>(); sc.list_d = c->sd_list_d.as<u32>();
+    ReadState st = read_state(c);
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    const unsigned chunks = nblk(n, SEED_CHUNK);
+    prof_begin(c, "k_seed_first");
+    hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, (long)n, sc, cnt);
+    prof_end(c);
+    prof_begin(c, "k_seed_decide");
+    hipLaunchKernelGGL(k_seed_decide, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n, c->prm.seed_len,
+                       pe_mode, st, sc, cnt);
+    prof_end(c);
+    prof_begin(c, "k_seed_second");
+    int rc = scan_u32(c, sc.flag_c, n, sc.off_c, 3);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_c, sc.off_c, sc.list_c);
+    hipLaunchKernelGGL(k_seed_second, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 3, pe_mode,
+                       st, sc, cnt);
+    prof_end(c);
+    prof_begin(c, "k_seed_extra");
+    rc = scan_u32(c, sc.flag_d, n, sc.off_d, 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_d, sc.off_d, sc.list_d);
+    hipLaunchKernelGGL(k_seed_extra, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 4,
+                       c->prm.seed_len, pe_mode, st, sc, cnt);
+    prof_end(c);
+    return BMBS_OK;
+}
+
 // stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
 int run_seed_stages(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int k, u64* total_cand, int pe_mode = 0)
 {
     ReadState st = read_state(c);
-    unsigned long long* cnt = c->counters.as<unsigned long long>();
-    prof_begin(c, "k_seed");
-    hipLaunchKernelGGL(k_seed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
-                       c->prm.seed_len, pe_mode, st, cnt);
-    prof_end(c);
+    {
+        int rcs = launch_seeding(c, d_seq, L, stride, n, pe_mode);
+        if (rcs) return rcs;
+    }
     prof_begin(c, "scan_cand");
     int rc = scan_u32(c, st.n_cand, n, st.cand_off, 0);
     if (rc) return rc;
@@ -303,7 +341,7 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
     if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, 5 * 8) || ensure(c, c->counters, 8 * 8) ||
-        ensure(c, c->totals, 4 * 8)) { bmbs_destroy(c); return nullptr; }
+        ensure(c, c->totals, 8 * 8)) { bmbs_destroy(c); return nullptr; }
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
     (void)hipMemset(c->stats.p, 0, 5 * 8);
     (void)hipMemset(c->counters.p, 0, 8 * 8);
@@ -321,7 +359,8 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->job_read, &c->job_site, &c->job_end, &c->job_err, &c->need_sw, &c->sw_off, &c->sw_job, &c->trace, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
                      &c->stats, &c->counters, &c->pe_seq, &c->pe_qual, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
-                     &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2};
+                     &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
+                     &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -520,10 +559,8 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     ps.dead = c->pe_dead.as<u8>(); ps.both = c->pe_both.as<u8>(); ps.npair = c->pe_npair.as<int>(); ps.sbd = c->pe_sbd.as<u32>();
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     // seeding of all 2n reads; candidate slots by scan; locate
-    prof_begin(c, "k_seed");
-    hipLaunchKernelGGL(k_seed, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, (long)n2,
-                       c->prm.seed_len, 1, st, cnt);
-    prof_end(c);
+    rc = launch_seeding(c, seq_all, L, stride, n2, 1);
+    if (rc) return rc;
     prof_begin(c, "scan_cand");
     rc = scan_u32(c, st.n_cand, n2, st.cand_off, 0);
     if (rc) return rc;

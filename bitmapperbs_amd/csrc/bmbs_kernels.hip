@@ -75,10 +75,34 @@ DEVI bool window_valid(const DevIndex& ix, u64 start, u64 len, bool fwd_strand)
     return fwd_strand ? (start + len <= ix.G) : (start - ix.G + len <= ix.G && start - ix.G < ix.G);
 }
 
+// window base with the all-zero-window rule (out-of-strand request: every base compares unequal and
+// scores as N, nt4[0] = 4)
+struct WinReader {
+    const u64* g; u64 pos, w; int left; bool valid;
+    DEVI void init(const DevIndex& ix, u64 start, bool v) { g = ix.gen2; valid = v; pos = start; if (v) { w = g[pos >> 5] >> ((pos & 31) * 2); left = 32 - (int)(pos & 31); } else { w = 0; left = 32; } }
+    DEVI int next() { if (!valid) return 4; const int b = (int)(w & 3); w >>= 2; pos++; left--; if (left == 0) { w = g[pos >> 5]; left = 32; } return b; }
+};
+
 // bisulfite 3-letter code of a read character after C->T: G0 T1 A2, anything else 4
 // (C_to_T_forward, Schema.h:1534; ctoi, bwt.cpp:2376-2381)
 DEVI int code3(char ch) { return ch == 'G' ? 0 : (ch == 'T' || ch == 'C') ? 1 : ch == 'A' ? 2 : 4; }
 DEVI int code4(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
+
+// sequential reader of a read's characters, 8 bytes per global load (rows are 16-byte aligned and
+// padded to a multiple of 16, so the aligned u64 that holds any position < stride is in the row).
+// One read per lane means a byte load touches 64 different cache lines per wave instruction; wide
+// loads cut the number of such instructions by 8.
+struct ReadCur {
+    const char* rd; u64 buf; int pos, lim;
+    DEVI void seek(const char* r, int p, int L) { rd = r; pos = p; lim = L; buf = p < L ? *reinterpret_cast<const u64*>(rd + (p & ~7)) >> (8 * (p & 7)) : 0ull; }
+    DEVI char next()
+    {
+        const char c = (char)(buf & 0xff);
+        pos++;
+        if ((pos & 7) == 0) buf = pos < lim ? *reinterpret_cast<const u64*>(rd + pos) : 0ull; else buf >>= 8;   // never past the read
+        return c;
+    }
+};
 
 // ================================================================================================
 // attach-time re-pack kernels
@@ -237,70 +261,77 @@ __global__ void k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* o
 // ================================================================================================
 // K1-K5: seeding
 // ================================================================================================
+// The seeding state machine of Map_Single_Seq_end_to_end (Schema.cpp:24588-24898) / get_candidates
+// (18172-18565) is data dependent per read: ~half of the reads leave after one short seed (exact-unique
+// exit), a third need one long second seed (1-mismatch path), the rest run up to 25 more seeds.  One
+// read per lane in ONE kernel makes every wave as slow as its slowest read.  It is therefore split
+// by read class, with scan-compacted work lists in between (no host round-trip):
+//   k_seed_first   all reads          first seed (count_backward_as_much_1_terminate)
+//   k_seed_decide  all reads          exact-unique / exact-ambiguous exits, 1-mismatch detection
+//   k_seed_second  1-mismatch reads   second seed (count_hash_table) + 1-mismatch exit
+//   k_seed_extra   everything else    the remaining seeds
+// The three search kernels share one engine: a wave owns a contiguous chunk of its work list and
+// every lane that finishes an item immediately takes the next one of the chunk (wave-local counter,
+// no global atomics), so the lanes of a wave keep stepping in lock-step through the LF loop -- the
+// only hot code -- whatever the individual seed lengths are.
 struct SeedHit { u64 hits, sp, ml; };
 
-// count_backward_as_much_1_terminate (bwt.h:2081-2209) in read coordinates: the pattern is
-// bsSeq[0, L-tm) = reverse(read[tm, L)) with C->T, so the 16-mer key is the little-endian base-3
-// number of read[tm .. tm+15] and extension consumes read[tm+16], read[tm+17], ....
-DEVI SeedHit count_terminate(const DevIndex& ix, const char* rd, int L, int tm, u32& n_hash, u32& n_ext)
+// search state of one lane: count_backward_as_much_1_terminate (bwt.h:2081-2209) or count_hash_table
+// (bwt.h:1848-1952) over read[tm, L), advanced one backward-extension at a time.  In read coordinates
+// the pattern bsSeq[0, L-tm) = reverse(read[tm, L)) with C->T, so the 16-mer key is the little-endian
+// base-3 number of read[tm .. tm+15] and extension consumes read[tm+16], read[tm+17], ....
+struct Search { u64 top, bot, ptop, pbot; int s, steps, tm; ReadCur cur; };
+
+// returns true when the search has to be stepped; false when it is already decided (out filled)
+template <bool FIXED>
+DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search& S, SeedHit& out, u32& n_hash)
 {
-    SeedHit r = {0, 0, 0};
     const int len = L - tm;
-    if (len < 18) return r;
-    u64 key = 0;
+    out.hits = 0; out.sp = 0; out.ml = FIXED ? (u64)len : 0;
+    if (len < (FIXED ? 17 : 18)) return false;
+    // key = sum code(read[tm+u]) * 3^u
+    u64 key = 0, p3 = 1;
     bool bad = false;
-    for (int u = 15; u >= 0; u--) { const int d = code3(rd[tm + u]); bad |= d > 2; key = key * 3 + (u64)(d > 2 ? 0 : d); }
-    // the reference hashes bsSeq[len-16 ..] left to right and stops at the first non-AGT char
-    if (bad) return r;
-    u64 top, bot;
-    hash_lookup(ix, key, top, bot);
+    S.cur.seek(rd, tm, L);
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int d = code3(S.cur.next()); bad |= d > 2; key += (u64)(d > 2 ? 0 : d) * p3; p3 *= 3; }
+    if (bad) return false;                      // get_3_letter_hash_value returned -1 (bwt.h:309-332)
+    hash_lookup(ix, key, S.top, S.bot);
     n_hash++;
-    if (bot <= top) return r;
-    u64 ptop = ~0ull, pbot = ~0ull;
-    int s = 0;
-    const int steps = len - 16;
-    u64 ml = (u64)len;
-    for (; s < steps; s++) {
-        ptop = top; pbot = bot;
-        if (bot - top == 1) { ml = 16 + s; break; }
-        const int d = code3(rd[tm + 16 + s]);
-        if (d > 2) { ml = 16 + s; bot = top; break; }
-        const u64 nt = lf_step(ix, top, d), nb = lf_step(ix, bot, d);
-        n_ext++;
-        top = nt; bot = nb;
-        if (bot <= top) { ml = 16 + s; break; }
-    }
-    if (bot <= top) { r.sp = ptop; r.hits = pbot - ptop; }
-    else { r.sp = top; r.hits = bot - top; }
-    r.ml = ml;
-    return r;
+    if (S.bot <= S.top) return false;
+    S.ptop = ~0ull; S.pbot = ~0ull; S.s = 0; S.steps = len - 16; S.tm = tm;
+    return true;
 }
 
-// count_hash_table (bwt.h:1848-1952): exact count of read[tm, L), no early stop
-DEVI SeedHit count_fixed(const DevIndex& ix, const char* rd, int L, int tm, u32& n_hash, u32& n_ext)
+// one loop iteration of the reference; returns true when the search is finished (out filled)
+template <bool FIXED>
+DEVI bool search_step(const DevIndex& ix, const char* rd, int L, Search& S, SeedHit& out, u32& n_ext)
 {
-    SeedHit r = {0, 0, (u64)(L - tm)};
-    const int len = L - tm;
-    if (len < 17) return r;
-    u64 key = 0;
-    bool bad = false;
-    for (int u = 15; u >= 0; u--) { const int d = code3(rd[tm + u]); bad |= d > 2; key = key * 3 + (u64)(d > 2 ? 0 : d); }
-    if (bad) return r;
-    u64 top, bot;
-    hash_lookup(ix, key, top, bot);
-    n_hash++;
-    if (bot <= top) return r;
-    for (int s = 0; s < len - 16; s++) {
-        if (bot <= top) break;
-        const int d = code3(rd[tm + 16 + s]);
-        if (d > 2) return r;
-        const u64 nt = lf_step(ix, top, d), nb = lf_step(ix, bot, d);
+    const int len = L - S.tm;
+    if (!FIXED) {
+        S.ptop = S.top; S.pbot = S.bot;
+        if (S.bot - S.top == 1) { out.ml = 16 + S.s; out.sp = S.top; out.hits = 1; return true; }
+        const int d = code3(S.cur.next());          // read[tm + 16 + s]
+        if (d > 2) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
+        const u64 nt = lf_step(ix, S.top, d), nb = lf_step(ix, S.bot, d);
         n_ext++;
-        top = nt; bot = nb;
+        S.top = nt; S.bot = nb;
+        if (S.bot <= S.top) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
+        S.s++;
+        if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
+        return false;
+    } else {
+        out.ml = (u64)len;
+        const int d = code3(S.cur.next());          // read[tm + 16 + s]
+        if (d > 2) { out.hits = 0; out.sp = 0; return true; }
+        const u64 nt = lf_step(ix, S.top, d), nb = lf_step(ix, S.bot, d);
+        n_ext++;
+        S.top = nt; S.bot = nb;
+        if (S.bot <= S.top) { out.hits = 0; out.sp = S.top; return true; }      // the remaining iterations only break
+        S.s++;
+        if (S.s == S.steps) { out.sp = S.top; out.hits = S.bot - S.top; return true; }
+        return false;
     }
-    r.sp = top;
-    r.hits = bot <= top ? 0 : bot - top;
-    return r;
 }
 
 // determine_seed_offset_unmatch (Schema.h:1506-1531)
@@ -312,134 +343,310 @@ DEVI int seed_offset_unmatch(int L, int pre, const char* rd, int step)
     return ret;
 }
 
-// The seeding state machine of Map_Single_Seq_end_to_end (Schema.cpp:24588-24898) with the three
-// fast exits; seeds are recorded as SA intervals, k_locate expands them.
-__global__ void __launch_bounds__(256)
-k_seed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, int pe_mode, ReadState st,
-       unsigned long long* __restrict__ counters)
+// per-read state carried between the seeding kernels
+struct SeedCarry {
+    u64* sp0; u32* hits0; u16* ml0;        // first seed result
+    u16* tm; u8* seed_id; u32* clen; u16* first_ml;
+    u32* flag_c; u32* flag_d;              // needs k_seed_second / k_seed_extra (scan inputs)
+    u64* off_c; u64* off_d;                // exclusive scans
+    u32* list_c; u32* list_d;              // compacted read lists
+};
+
+DEVI void seed_record(SeedRec* my, int& ns, u64& ncand, u64 sp, u64 hits, u64 len, u64 off)
 {
-    __shared__ unsigned int shc[4];
-    if (threadIdx.x < 4) shc[threadIdx.x] = 0;
-    __syncthreads();
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 n_hash = 0, n_ext = 0, n_sa = 0, n_ung = 0;
-    if (r < n) {
-    const char* rd = seq + (size_t)r * stride;
-    int firstC = L;
-    for (int i = 0; i < L; i++) if (rd[i] == 'C') { firstC = i; break; }
-    SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
-    int ns = 0;
-    u64 ncand = 0;
-    int tm = 0, seed_id = 0;
-    int max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
-    int verdict = 0, multi = 0, get_error = -1, extra = 1;
-    u64 first_ml = 0, mm_site = 0, c0 = 0, c1 = 0, clen = 0;
-    const u64 max_hits = 1000;
-    auto record = [&](u64 sp, u64 hits, u64 len, u64 off) {
-        my[ns].sp = sp; my[ns].hits = (u32)hits; my[ns].len = (u16)len; my[ns].off = (u16)off; ns++;
-        ncand += hits;
-    };
-    bool done = false;
-    if (seed_id < max_seed && tm < L) {
-        SeedHit s = count_terminate(ix, rd, L, tm, n_hash, n_ext);
-        u64 ml = s.ml;
-        first_ml = ml;
-        if (s.hits == 1) {
-            // try_process_unique_mismatch_end_to_end (Schema.cpp:15164-15282)
-            const u64 p = ix.sa[s.sp];
-            n_sa++;
-            const u64 loc = ix.total - p - ml;
-            record(s.sp, 1, ml, 0);
-            c0 = loc; clen = 1;
-            int error = 0;
-            if (ml > (u64)firstC) ml = (u64)firstC;
-            if (ml != (u64)L) {
-                const int need = L - (int)ml;
-                const u64 start = loc + ml;
-                const bool valid = window_valid(ix, start, (u64)need, loc < ix.G);
-                n_ung++;
-                int read_i = (int)ml;
-                for (int i = 0; i < need; i++) {
-                    const char a = rd[read_i];
-                    bool mism = true;
-                    if (valid) { const int b = gbase(ix, start + i); mism = !(code4(a) == b || (a == 'T' && b == 1)); }
-                    if (mism) { error++; if (error == 1) ml = (u64)read_i; else break; }
-                    read_i++;
-                }
-            }
-            get_error = error;
-            if (error == 0) { verdict = 1; st.exit_site[r] = loc; done = true; }
-        }
-        if (!done) {
-            mm_site = ml;
-            if (!pe_mode) {
-                if (ml == (u64)L && s.hits > 1) {
-                    multi = 1;
-                    if (firstC == L) { verdict = 4; done = true; }      // exact, ambiguous, no C in the read
-                }
-            } else if (ml == (u64)L && s.hits > 1 && s.hits <= 10000) {
-                // get_candidates (Schema.cpp:18260-18290): every exact hit becomes a verified candidate
-                multi = 1;
-                if (firstC == L) { record(s.sp, s.hits, ml, 0); verdict = 4; done = true; }
-            }
-        }
-        if (!done) {
-            if (s.hits == 1) { /* recorded */ }
-            else if (ml >= (u64)seed_len && s.hits <= max_hits) { if (s.hits != 0) { record(s.sp, s.hits, ml, (u64)tm); clen += s.hits; } }
-            if (ml == 0) tm = seed_offset_unmatch(L, tm, rd, 8); else tm = tm + (int)(ml / 2);
-            seed_id++;
-        }
-    }
-    if (!done && get_error == 1) {
-        // second seed over the rest of the read after a 1-mismatch first seed (Schema.cpp:24734-24801)
-        const int second_len = L - (int)first_ml;
-        if (second_len >= 17) {
-            SeedHit s = count_fixed(ix, rd, L, (int)first_ml, n_hash, n_ext);
-            if (s.hits == 1) {
-                const u64 p = ix.sa[s.sp];
-                n_sa++;
-                c1 = ix.total - p - (u64)second_len - first_ml;
-                record(s.sp, 1, (u64)second_len, first_ml);
-                clen += 1; extra = 0;
-            } else if (s.hits <= max_hits) {
-                if (s.hits != 0) { record(s.sp, s.hits, (u64)second_len, first_ml); clen += s.hits; }
-                extra = 0;
-            } else extra = 1;
-        } else extra = 1;
-    }
-    if (!done && extra == 1) {
-        while (seed_id < max_seed && tm < L) {
-            const int cur_len = L - tm;
-            SeedHit s = count_terminate(ix, rd, L, tm, n_hash, n_ext);
-            const u64 ml = s.ml;
-            if (s.hits == 1) { record(s.sp, 1, ml, (u64)tm); clen += 1; }
-            else if (ml >= (u64)seed_len && s.hits <= max_hits) { if (s.hits != 0) { record(s.sp, s.hits, ml, (u64)tm); clen += s.hits; } }
-            else if ((u64)cur_len == ml) break;
-            if (ml == 0) tm = seed_offset_unmatch(L, tm, rd, 8); else tm = tm + (int)(ml / 2);
-            seed_id++;
-        }
-    }
-    if (!done) {
-        if (extra == 0 && (clen == 1 || (clen == 2 && c0 == c1))) {       // fast exit C (Schema.cpp:24894)
-            verdict = 2; st.exit_site[r] = c0;
-        } else if (clen != 0) verdict = 3;
-    }
+    my[ns].sp = sp; my[ns].hits = (u32)hits; my[ns].len = (u16)len; my[ns].off = (u16)off; ns++;
+    ncand += hits;
+}
+
+DEVI void seed_finish(const ReadState& st, long r, int verdict, int ns, u64 ncand, int pe_mode)
+{
     st.verdict[r] = (u8)verdict;
     st.n_seeds[r] = (u8)ns;
-    st.multi[r] = (u8)multi;
-    st.mm_site[r] = (u16)mm_site;
     st.n_cand[r] = verdict == 3 ? (u32)ncand : (pe_mode ? (verdict == 4 ? (u32)ncand : (verdict == 1 || verdict == 2) ? 1u : 0u) : 0u);
+}
+
+#define SEED_CHUNK 1024           // items per wave
+
+struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung; };
+DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c)
+{
+    // 64-thread blocks: one wave; reduce with shuffles, one atomic per wave and counter
+    u32 a = c.n_hash, b = c.n_ext, d = c.n_sa, e = c.n_ung;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); e += __shfl_down(e, o); }
+    if ((threadIdx.x & 63) == 0 && counters) {
+        if (a) atomicAdd(&counters[0], (unsigned long long)a);
+        if (b) atomicAdd(&counters[1], (unsigned long long)b);
+        if (d) atomicAdd(&counters[2], (unsigned long long)d);
+        if (e) atomicAdd(&counters[5], (unsigned long long)e);
     }
-    if (counters) {
-        atomicAdd(&shc[0], n_hash); atomicAdd(&shc[1], n_ext); atomicAdd(&shc[2], n_sa); atomicAdd(&shc[3], n_ung);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(&counters[0], (unsigned long long)shc[0]);
-            atomicAdd(&counters[1], (unsigned long long)shc[1]);
-            atomicAdd(&counters[2], (unsigned long long)shc[2]);
-            atomicAdd(&counters[5], (unsigned long long)shc[3]);
+}
+
+// ---- first seed of every read ------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, SeedCarry sc,
+             unsigned long long* __restrict__ counters)
+{
+    const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
+    const long chunk_end = chunk_begin + SEED_CHUNK < n ? chunk_begin + SEED_CHUNK : n;
+    long next = chunk_begin;
+    LaneCounters lc = {0, 0, 0, 0};
+    bool active = false;
+    long r = 0;
+    const char* rd = seq;
+    Search S; SeedHit h;
+    for (;;) {
+        const unsigned long long need = __ballot(!active);
+        if (need) {
+            const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1));
+            const long it = next + rank;
+            next += __popcll(need);
+            if (!active && it < chunk_end) {
+                r = it; rd = seq + (size_t)r * stride;
+                if (search_begin<false>(ix, rd, L, 0, S, h, lc.n_hash)) active = true;
+                else { sc.sp0[r] = h.sp; sc.hits0[r] = (u32)h.hits; sc.ml0[r] = (u16)h.ml; }
+            }
+        }
+        if (!__any(active)) { if (next >= chunk_end) break; else continue; }
+        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) {
+            sc.sp0[r] = h.sp; sc.hits0[r] = (u32)h.hits; sc.ml0[r] = (u16)h.ml;
+            active = false;
         }
     }
+    flush_counters(counters, lc);
+}
+
+// ---- exits after the first seed (Schema.cpp:24599-24727 / 18225-18330) ---------------------------
+__global__ void __launch_bounds__(256)
+k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, int pe_mode, ReadState st,
+              SeedCarry sc, unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned int shc[2];
+    if (threadIdx.x < 2) shc[threadIdx.x] = 0;
+    __syncthreads();
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 n_sa = 0, n_ung = 0;
+    if (r < n) {
+        const char* rd = seq + (size_t)r * stride;
+        int firstC = L;
+        for (int i = 0; i < L; i += 8) {
+            // lowest byte equal to 'C' in this 8-byte word (exact for the lowest-order zero byte)
+            const u64 x = *reinterpret_cast<const u64*>(rd + i) ^ 0x4343434343434343ull;
+            const u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+            if (z) { const int j = i + (__ffsll((long long)z) - 1) / 8; if (j < L) firstC = j; break; }
+        }
+        SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+        int ns = 0;
+        u64 ncand = 0, clen = 0;
+        const int max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
+        int verdict = 0, multi = 0, get_error = -1, tm = 0, seed_id = 0;
+        u64 mm_site = 0, c0 = 0, first_ml = 0;
+        const u64 max_hits = 1000;
+        bool done = false;
+        u32 fc = 0, fd = 0;
+        if (seed_id < max_seed && tm < L) {
+            const u64 hits = sc.hits0[r], sp = sc.sp0[r];
+            u64 ml = sc.ml0[r];
+            first_ml = ml;
+            if (hits == 1) {
+                // try_process_unique_mismatch_end_to_end (Schema.cpp:15164-15282)
+                const u64 p = ix.sa[sp];
+                n_sa++;
+                const u64 loc = ix.total - p - ml;
+                seed_record(my, ns, ncand, sp, 1, ml, 0);
+                c0 = loc; clen = 1;
+                int error = 0;
+                if (ml > (u64)firstC) ml = (u64)firstC;
+                if (ml != (u64)L) {
+                    const int need = L - (int)ml;
+                    const u64 start = loc + ml;
+                    WinReader wr; wr.init(ix, start, window_valid(ix, start, (u64)need, loc < ix.G));
+                    n_ung++;
+                    int read_i = (int)ml;
+                    ReadCur rc; rc.seek(rd, read_i, L);
+                    for (int i = 0; i < need; i++) {
+                        const char a = rc.next();
+                        const int b = wr.next();                 // 4 when the window leaves the strand: never equal
+                        if (!(code4(a) == b || (a == 'T' && b == 1))) { error++; if (error == 1) ml = (u64)read_i; else break; }
+                        read_i++;
+                    }
+                }
+                get_error = error;
+                if (error == 0) { verdict = 1; st.exit_site[r] = loc; done = true; }
+            }
+            if (!done) {
+                mm_site = ml;
+                if (!pe_mode) {
+                    if (ml == (u64)L && hits > 1) {
+                        multi = 1;
+                        if (firstC == L) { verdict = 4; done = true; }      // exact, ambiguous, no C in the read
+                    }
+                } else if (ml == (u64)L && hits > 1 && hits <= 10000) {
+                    // get_candidates (Schema.cpp:18260-18290): every exact hit becomes a verified candidate
+                    multi = 1;
+                    if (firstC == L) { seed_record(my, ns, ncand, sp, hits, ml, 0); verdict = 4; done = true; }
+                }
+            }
+            if (!done) {
+                if (hits == 1) { /* recorded */ }
+                else if (ml >= (u64)seed_len && hits <= max_hits) { if (hits != 0) { seed_record(my, ns, ncand, sp, hits, ml, (u64)tm); clen += hits; } }
+                if (ml == 0) tm = seed_offset_unmatch(L, tm, rd, 8); else tm = tm + (int)(ml / 2);
+                seed_id++;
+            }
+        }
+        st.multi[r] = (u8)multi;
+        st.mm_site[r] = (u16)mm_site;
+        if (done) seed_finish(st, r, verdict, ns, ncand, pe_mode);
+        else {
+            st.exit_site[r] = c0;
+            st.n_seeds[r] = (u8)ns; st.n_cand[r] = (u32)ncand;
+            sc.tm[r] = (u16)tm; sc.seed_id[r] = (u8)seed_id; sc.clen[r] = (u32)clen; sc.first_ml[r] = (u16)first_ml;
+            // 1-mismatch first seed: second seed over the rest of the read (Schema.cpp:24734-24801)
+            if (get_error == 1 && L - (int)first_ml >= 17) fc = 1; else fd = 1;
+        }
+        sc.flag_c[r] = fc; sc.flag_d[r] = fd;
+    }
+    if (counters) {
+        atomicAdd(&shc[0], n_sa); atomicAdd(&shc[1], n_ung);
+        __syncthreads();
+        if (threadIdx.x == 0) { atomicAdd(&counters[2], (unsigned long long)shc[0]); atomicAdd(&counters[5], (unsigned long long)shc[1]); }
+    }
+}
+
+__global__ void k_flag_list(long n, const u32* __restrict__ flag, const u64* __restrict__ off, u32* __restrict__ list)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (flag[r]) list[off[r]] = (u32)r;
+}
+
+// ---- second seed of the 1-mismatch reads + fast exit C (Schema.cpp:24734-24801, 24894-24898) -----
+__global__ void __launch_bounds__(64)
+k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int pe_mode,
+              ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
+{
+    const long total = (long)*count_ptr;
+    const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
+    if (chunk_begin >= total) return;
+    const long chunk_end = chunk_begin + SEED_CHUNK < total ? chunk_begin + SEED_CHUNK : total;
+    long next = chunk_begin;
+    LaneCounters lc = {0, 0, 0, 0};
+    bool active = false;
+    long r = 0;
+    const char* rd = seq;
+    Search S; SeedHit h;
+    const u64 max_hits = 1000;
+    auto finish = [&]() {
+        // the second seed is over: record it and decide (Schema.cpp:24748-24791)
+        SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+        int ns = st.n_seeds[r];
+        u64 ncand = st.n_cand[r], clen = sc.clen[r];
+        const u64 first_ml = sc.first_ml[r];
+        const u64 second_len = (u64)L - first_ml;
+        const u64 c0 = st.exit_site[r];
+        u64 c1 = 0;
+        int extra = 1;
+        if (h.hits == 1) {
+            const u64 p = ix.sa[h.sp];
+            lc.n_sa++;
+            c1 = ix.total - p - second_len - first_ml;
+            seed_record(my, ns, ncand, h.sp, 1, second_len, first_ml);
+            clen += 1; extra = 0;
+        } else if (h.hits <= max_hits) {
+            if (h.hits != 0) { seed_record(my, ns, ncand, h.sp, h.hits, second_len, first_ml); clen += h.hits; }
+            extra = 0;
+        }
+        if (extra == 0) {
+            int verdict = 0;
+            if (clen == 1 || (clen == 2 && c0 == c1)) verdict = 2;            // fast exit C: exit_site = c0 already stored
+            else if (clen != 0) verdict = 3;
+            seed_finish(st, r, verdict, ns, ncand, pe_mode);
+            sc.flag_d[r] = 0;
+        } else {
+            st.n_seeds[r] = (u8)ns; st.n_cand[r] = (u32)ncand; sc.clen[r] = (u32)clen;
+            sc.flag_d[r] = 1;
+        }
+    };
+    for (;;) {
+        const unsigned long long need = __ballot(!active);
+        if (need) {
+            const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1));
+            const long it = next + rank;
+            next += __popcll(need);
+            if (!active && it < chunk_end) {
+                r = sc.list_c[it]; rd = seq + (size_t)r * stride;
+                if (search_begin<true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) active = true;
+                else finish();
+            }
+        }
+        if (!__any(active)) { if (next >= chunk_end) break; else continue; }
+        if (active && search_step<true>(ix, rd, L, S, h, lc.n_ext)) { finish(); active = false; }
+    }
+    flush_counters(counters, lc);
+}
+
+// ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int seed_len,
+             int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
+{
+    const long total = (long)*count_ptr;
+    const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
+    if (chunk_begin >= total) return;
+    const long chunk_end = chunk_begin + SEED_CHUNK < total ? chunk_begin + SEED_CHUNK : total;
+    long next = chunk_begin;
+    LaneCounters lc = {0, 0, 0, 0};
+    bool active = false, have = false;
+    long r = 0;
+    const char* rd = seq;
+    Search S; SeedHit h;
+    SeedRec* my = nullptr;
+    int ns = 0, tm = 0, seed_id = 0, max_seed = 0;
+    u64 ncand = 0, clen = 0;
+    const u64 max_hits = 1000;
+    // after a seed: record, advance (Schema.cpp:24830-24882); returns false when the read is finished
+    auto after_seed = [&]() -> bool {
+        const int cur_len = L - tm;
+        const u64 ml = h.ml;
+        if (h.hits == 1) { seed_record(my, ns, ncand, h.sp, 1, ml, (u64)tm); clen += 1; }
+        else if (ml >= (u64)seed_len && h.hits <= max_hits) { if (h.hits != 0) { seed_record(my, ns, ncand, h.sp, h.hits, ml, (u64)tm); clen += h.hits; } }
+        else if ((u64)cur_len == ml) return false;
+        if (ml == 0) tm = seed_offset_unmatch(L, tm, rd, 8); else tm = tm + (int)(ml / 2);
+        seed_id++;
+        return true;
+    };
+    // start seeds until one needs stepping or the read is finished
+    auto advance = [&]() {
+        for (;;) {
+            if (!(seed_id < max_seed && tm < L)) break;
+            if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash)) { active = true; return; }
+            if (!after_seed()) break;
+        }
+        seed_finish(st, r, clen != 0 ? 3 : 0, ns, ncand, pe_mode);
+        have = false;
+    };
+    for (;;) {
+        const unsigned long long need = __ballot(!have);
+        if (need) {
+            const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1));
+            const long it = next + rank;
+            next += __popcll(need);
+            if (!have && it < chunk_end) {
+                r = sc.list_d[it]; rd = seq + (size_t)r * stride;
+                my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+                ns = st.n_seeds[r]; ncand = st.n_cand[r]; clen = sc.clen[r]; tm = sc.tm[r]; seed_id = sc.seed_id[r];
+                max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
+                have = true; active = false;
+                advance();
+            }
+        }
+        if (!__any(have)) { if (next >= chunk_end) break; else continue; }
+        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) {
+            active = false;
+            if (after_seed()) advance();
+            else { seed_finish(st, r, clen != 0 ? 3 : 0, ns, ncand, pe_mode); have = false; }
+        }
+    }
+    flush_counters(counters, lc);
 }
 
 // ================================================================================================
@@ -533,8 +740,9 @@ DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u3
     u64 VP = 0, VN = 0;
     int err = 0;
     const int last_high = 2 * k;
+    ReadCur rc; rc.seek(rd, 0, L);
     for (int i = 0; i < L; i++) {
-        const char tc = rd[i];
+        const char tc = rc.next();
         const u64 eq = tc == 'A' ? PA : tc == 'C' ? PC : tc == 'G' ? PG : tc == 'T' ? PT : 0ull;
         u64 X = eq | VN;
         const u64 D0 = ((VP + (X & VP)) ^ VP) | X;
@@ -669,14 +877,6 @@ __global__ void k_job_list(long n, ReadState st, u32* __restrict__ job_read, u64
 // reads slot b and writes slot b-1 (the band slides one column per row), and the only memory traffic
 // of the DP is one packed trace word (4 bits per cell) per 16 cells per row, interleaved by job.
 
-// window base with the all-zero-window rule (out-of-strand request: every base compares unequal and
-// scores as N, nt4[0] = 4)
-struct WinReader {
-    const u64* g; u64 pos, w; int left; bool valid;
-    DEVI void init(const DevIndex& ix, u64 start, bool v) { g = ix.gen2; valid = v; pos = start; if (v) { w = g[pos >> 5] >> ((pos & 31) * 2); left = 32 - (int)(pos & 31); } else { w = 0; left = 32; } }
-    DEVI int next() { if (!valid) return 4; const int b = (int)(w & 3); w >>= 2; pos++; left--; if (left == 0) { w = g[pos >> 5]; left = 32; } return b; }
-};
-
 __global__ void __launch_bounds__(256)
 k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
                  const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
@@ -704,8 +904,9 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
     int tmp_err = 0, score = 0;
     if (ok) {
         WinReader wr; wr.init(ix, site + (u64)start, wvalid);
+        ReadCur rc; rc.seek(rd, 0, L);
         for (int i = 0; i < L; i++) {
-            const char a = rd[i];
+            const char a = rc.next();
             const int b = wr.next();
             if (!(code4(a) == b || (a == 'T' && b == 1))) {
                 if (++tmp_err > (int)err_in) { ok = false; break; }
