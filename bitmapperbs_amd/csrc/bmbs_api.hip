@@ -340,11 +340,11 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
-    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, 5 * 8) || ensure(c, c->counters, 8 * 8) ||
+    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, 5 * 8) || ensure(c, c->counters, 16 * 8) ||
         ensure(c, c->totals, 8 * 8)) { bmbs_destroy(c); return nullptr; }
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
     (void)hipMemset(c->stats.p, 0, 5 * 8);
-    (void)hipMemset(c->counters.p, 0, 8 * 8);
+    (void)hipMemset(c->counters.p, 0, 16 * 8);
     return c;
 }
 
@@ -398,14 +398,15 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     RefIndexDev R;
     R.bwt = t_bwt.as<u64>(); R.high_occ = t_ho.as<u64>(); R.hash_hi = t_hh.as<u32>(); R.hash_lo = t_hl.as<u8>();
     R.sa = t_sa.as<u32>(); R.sa_flag = t_fl.as<u64>(); R.pac = t_pac.as<u8>();
-    const u64 n_blk = n / 192 + 1;
+    if (n >= (1ull << 32)) { c->err = "32-bit Occ counters: text too long"; return BMBS_EINVAL; }
+    const u64 n_blk = n / 32 + 2;
     const u64 gen_words = (n + 31) / 32 + 2;
     std::vector<u64> cs(v->n_chrom + 1, 0);
     for (int i = 0; i < v->n_chrom; i++) cs[i + 1] = cs[i] + v->chrom_len[i];
-    if (ensure(c, c->occ, n_blk * 64) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * 4) ||
+    if (ensure(c, c->occ, n_blk * 16) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * 4) ||
         ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8)) { drop(); return BMBS_ENOMEM; }
     HIPCHK(c, hipMemcpyAsync(c->chrom_start.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, c->occ.as<u64>());
+    hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, c->occ.as<uint4>());
     hipLaunchKernelGGL(k_repack_hash, dim3(nblk(v->hash_entries, 256)), dim3(256), 0, c->stream, R, v->hash_entries, c->hash.as<u64>());
     hipLaunchKernelGGL(k_build_gen2, dim3(nblk(gen_words, 256)), dim3(256), 0, c->stream, R, G, gen_words, c->gen2.as<u64>());
     DevIndex ix;
@@ -445,7 +446,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     if (rc) return rc;
     rc = per_read_workspace(c, n);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16 * 8, c->stream));
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     u64 tot = 0;
@@ -545,7 +546,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     ENS(c, c->pe_seq, n2 * (u64)stride + 64); ENS(c, c->pe_qual, n2 * (u64)stride + 64);
     ENS(c, c->pe_occ, n2 * 4); ENS(c, c->pe_len, n2 * 4); ENS(c, c->pe_cur, n2); ENS(c, c->pe_vround, n2);
     ENS(c, c->pe_dead, n); ENS(c, c->pe_both, n); ENS(c, c->pe_npair, n * 4); ENS(c, c->pe_sbd, n * 4);
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16 * 8, c->stream));
     char* seq_all = c->pe_seq.as<char>();
     char* qual_all = c->pe_qual.as<char>();
     prof_begin(c, "k_pe_prepare");
@@ -743,7 +744,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     if (rc) return rc;
     ENS(c, c->in_seq, bytes + 64);
     HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16 * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->exit_site.p, 0, n * 8, c->stream));
     u64 tot = 0;
     rc = run_seed_stages(c, c->in_seq.as<char>(), L, stride, n, k, &tot);
@@ -809,7 +810,13 @@ extern "C" int bmbs_counters_last(bmbs_ctx* c, uint64_t out[8])
     if (!c) return BMBS_EINVAL;
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->counters.p, 8 * 8, hipMemcpyDeviceToHost));
+    uint64_t all[16];
+    HIPCHK(c, hipMemcpy(all, c->counters.p, 16 * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = all[i];
+    if (getenv("BMBS_UTIL_PRINT"))
+        fprintf(stderr, "[util] first: iters %llu active %llu | second: iters %llu active %llu | extra: iters %llu active %llu\n",
+                (unsigned long long)all[8], (unsigned long long)all[9], (unsigned long long)all[10], (unsigned long long)all[11],
+                (unsigned long long)all[12], (unsigned long long)all[13]);
     out[6] = c->last_total_cand;
     out[7] = c->last_n_jobs;
     return BMBS_OK;

@@ -11,10 +11,11 @@ typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef uint8_
 // pairs) plus a 65 536-row super-block table, and keeps every 8th SA entry (bwt.h:1007-1136,
 // 2449-2560).  On MI355X the dependent random gather is what costs, and HBM capacity (288 GB) is not
 // a constraint, so the index is re-packed at attach time into:
-//   occ   : one 64-byte, 64-byte-aligned block per 192 BWT symbols =
-//           { u64 count(T) before the block, u64 count(A) before the block,
-//             3 x { u64 plane_T, u64 plane_A } }  (symbol j of a word = bit 63-j, as the reference)
-//           -> every rank query is exactly one aligned 64 B transaction, no second-level table;
+//   occ   : one 16-byte block per 32 BWT symbols = { u32 count(T) before the block, u32 count(A) before the
+//           block, u32 plane_T, u32 plane_A } (symbol j of a word = bit 31-j, absolute counts while the
+//           text has < 2^32 symbols) -> every rank query is exactly ONE 16-byte lane load, no second-level
+//           table; with one read per lane a wave-wide load costs one cache-line request per lane whatever
+//           its width, so what matters is the number of pieces per query, not bytes (4 bit/symbol);
 //   hash  : the 3^16+1 16-mer entries fused to one u64 each (36-bit row | gap nibble << 60), so a
 //           lookup (entries key, key+1) is one 16-byte read;
 //   sa    : the FULL suffix array (u32 per row), expanded once on the GPU from the sampled SA, so

@@ -19,18 +19,15 @@
 // index primitives
 // ================================================================================================
 
-// rank of T and of A in BWT stream [0, line): one aligned 64-byte block (see bmbs_dev.h).
+// rank of T and of A in BWT stream [0, line): ONE aligned 16-byte load (see bmbs_dev.h).
 // Replaces get_occ_value* + the popcount tail of find_occ_fm_index (bwt.h:1007-1136, 1373-1465).
 DEVI void occ_TA(const DevIndex& ix, u64 line, u64& cT, u64& cA)
 {
-    const u64 blk = line / 192u;
-    const int r = (int)(line - blk * 192u);
-    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(ix.occ) + blk * 4;
-    const ulonglong2 h = p[0], w0 = p[1], w1 = p[2], w2 = p[3];
-    auto mk = [](int take) -> u64 { return take <= 0 ? 0ull : (take >= 64 ? ~0ull : (~0ull << (64 - take))); };
-    const u64 m0 = mk(r), m1 = mk(r - 64), m2 = mk(r - 128);
-    cT = h.x + __popcll(w0.x & m0) + __popcll(w1.x & m1) + __popcll(w2.x & m2);
-    cA = h.y + __popcll(w0.y & m0) + __popcll(w1.y & m1) + __popcll(w2.y & m2);
+    const uint4 h = ix.occ[line >> 5];
+    const u32 r = (u32)line & 31u;
+    const u32 m = r ? (~0u << (32 - r)) : 0u;
+    cT = (u64)h.x + __popc(h.z & m);
+    cA = (u64)h.y + __popc(h.w & m);
 }
 
 // one LF / backward-extension step: nacgt[c] + Occ(c, row), '$' row removed (bwt.h:1373-1465)
@@ -43,16 +40,31 @@ DEVI u64 lf_step(const DevIndex& ix, u64 row, int c)
     return ix.C[c] + cnt;
 }
 
+// both ends of an SA interval in one go (find_occ_fm_index_combine, bwt.h:1473-1596): when top and
+// bot fall into the same 32-symbol block -- the usual case once the interval is small -- one load serves both
+DEVI void lf_pair(const DevIndex& ix, u64& top, u64& bot, int c)
+{
+    const u64 lt = top - (top > ix.shapline ? 1 : 0), lb = bot - (bot > ix.shapline ? 1 : 0);
+    const uint4 ht = ix.occ[lt >> 5];
+    uint4 hb = ht;
+    if ((lb >> 5) != (lt >> 5)) hb = ix.occ[lb >> 5];
+    const u32 rt = (u32)lt & 31u, rb = (u32)lb & 31u;
+    const u32 mt = rt ? (~0u << (32 - rt)) : 0u, mb = rb ? (~0u << (32 - rb)) : 0u;
+    const u64 tT = (u64)ht.x + __popc(ht.z & mt), tA = (u64)ht.y + __popc(ht.w & mt);
+    const u64 bT = (u64)hb.x + __popc(hb.z & mb), bA = (u64)hb.y + __popc(hb.w & mb);
+    const u64 ct = c == 1 ? tT : (c == 2 ? tA : lt - tT - tA);
+    const u64 cb = c == 1 ? bT : (c == 2 ? bA : lb - bT - bA);
+    top = ix.C[c] + ct; bot = ix.C[c] + cb;
+}
+
 // BWT symbol of a row (access_bwt_delta, bwt.h:2413-2447); only used while expanding the SA
 DEVI int bwt_sym(const DevIndex& ix, u64 row)
 {
     const u64 line = row - (row > ix.shapline ? 1 : 0);
-    const u64 blk = line / 192u;
-    const int r = (int)(line - blk * 192u);
-    const u64* p = reinterpret_cast<const u64*>(ix.occ) + blk * 8 + 2 + 2 * (r >> 6);
-    const int sh = 63 - (r & 63);
-    if ((p[0] >> sh) & 1) return 1;
-    if ((p[1] >> sh) & 1) return 2;
+    const uint4 h = ix.occ[line >> 5];
+    const int sh = 31 - (int)(line & 31);
+    if ((h.z >> sh) & 1) return 1;
+    if ((h.w >> sh) & 1) return 2;
     return 0;
 }
 
@@ -121,27 +133,23 @@ DEVI void ref_rank64(const RefIndexDev& R, u64 line, u64& cT, u64& cA)
     cA = R.high_occ[sb + 1] + ((w0 >> (32 - 32 * half)) & 0xffff);
 }
 
-__global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, u64* out)
+// one 16-byte block per 32 BWT symbols: { u32 count(T) before, u32 count(A) before, u32 plane_T, u32 plane_A }
+__global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, uint4* out)
 {
     const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
-    const u64 s0 = b * 192;
+    const u64 s0 = b * 32;
+    const u64 s64 = s0 & ~63ull;          // the reference stores counters at every 64-boundary it reached (bwt.cpp:1437-1490)
     u64 cT = 0, cA = 0;
-    u64 w[6] = {0, 0, 0, 0, 0, 0};
-    // s0 is a multiple of 64 and s0 <= n_stream (n_blk = n_stream/192 + 1): the reference stored the
-    // counters of every 64-boundary it reached while building (bwt.cpp:1437-1490)
-    ref_rank64(R, s0, cT, cA);
-    for (int j = 0; j < 3; j++) {
-        const u64 s = s0 + 64 * (u64)j;
-        if (s < n_stream) {
-            const u64 wi = (s >> 7) * 5 + 1 + 2 * ((s & 127) >> 6);
-            w[2 * j] = R.bwt[wi];
-            w[2 * j + 1] = R.bwt[wi + 1];
-        }
+    ref_rank64(R, s64, cT, cA);
+    u32 pT = 0, pA = 0;
+    if (s64 < n_stream) {
+        const u64 wi = (s64 >> 7) * 5 + 1 + 2 * ((s64 & 127) >> 6);
+        const u64 wT = R.bwt[wi], wA = R.bwt[wi + 1];
+        if (s0 & 32) { cT += __popcll(wT >> 32); cA += __popcll(wA >> 32); pT = (u32)wT; pA = (u32)wA; }
+        else { pT = (u32)(wT >> 32); pA = (u32)(wA >> 32); }
     }
-    u64* o = out + b * 8;
-    o[0] = cT; o[1] = cA;
-    for (int j = 0; j < 6; j++) o[2 + j] = w[j];
+    out[b] = make_uint4((u32)cT, (u32)cA, pT, pA);
 }
 
 __global__ void k_repack_hash(RefIndexDev R, u64 n, u64* out)
@@ -313,9 +321,8 @@ DEVI bool search_step(const DevIndex& ix, const char* rd, int L, Search& S, Seed
         if (S.bot - S.top == 1) { out.ml = 16 + S.s; out.sp = S.top; out.hits = 1; return true; }
         const int d = code3(S.cur.next());          // read[tm + 16 + s]
         if (d > 2) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
-        const u64 nt = lf_step(ix, S.top, d), nb = lf_step(ix, S.bot, d);
+        lf_pair(ix, S.top, S.bot, d);
         n_ext++;
-        S.top = nt; S.bot = nb;
         if (S.bot <= S.top) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
         S.s++;
         if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
@@ -324,9 +331,8 @@ DEVI bool search_step(const DevIndex& ix, const char* rd, int L, Search& S, Seed
         out.ml = (u64)len;
         const int d = code3(S.cur.next());          // read[tm + 16 + s]
         if (d > 2) { out.hits = 0; out.sp = 0; return true; }
-        const u64 nt = lf_step(ix, S.top, d), nb = lf_step(ix, S.bot, d);
+        lf_pair(ix, S.top, S.bot, d);
         n_ext++;
-        S.top = nt; S.bot = nb;
         if (S.bot <= S.top) { out.hits = 0; out.sp = S.top; return true; }      // the remaining iterations only break
         S.s++;
         if (S.s == S.steps) { out.sp = S.top; out.hits = S.bot - S.top; return true; }
@@ -366,6 +372,7 @@ DEVI void seed_finish(const ReadState& st, long r, int verdict, int ns, u64 ncan
 }
 
 #define SEED_CHUNK 1024           // items per wave
+#define SEED_BATCH 16             // pending lanes that trigger a transition batch
 
 struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung; };
 DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c)
@@ -394,23 +401,32 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
     long r = 0;
     const char* rd = seq;
     Search S; SeedHit h;
+    // lanes whose search ended wait (`pending`) until SEED_BATCH of them can run the divergent
+    // store / refill / hash-lookup code together: one straggler must not stall 63 stepping lanes
+    bool pending = true, have = false;
     for (;;) {
-        const unsigned long long need = __ballot(!active);
-        if (need) {
-            const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1));
+        const unsigned long long pm = __ballot(pending);
+        if (__popcll(pm) >= SEED_BATCH || !__any(active)) {
+            if (pm == 0) break;
+            const int rank = __popcll(pm & ((1ull << (threadIdx.x & 63)) - 1));
             const long it = next + rank;
-            next += __popcll(need);
-            if (!active && it < chunk_end) {
-                r = it; rd = seq + (size_t)r * stride;
-                if (search_begin<false>(ix, rd, L, 0, S, h, lc.n_hash)) active = true;
-                else { sc.sp0[r] = h.sp; sc.hits0[r] = (u32)h.hits; sc.ml0[r] = (u16)h.ml; }
+            next += __popcll(pm);
+            if (pending) {
+                if (have) { sc.sp0[r] = h.sp; sc.hits0[r] = (u32)h.hits; sc.ml0[r] = (u16)h.ml; have = false; }
+                if (it < chunk_end) {
+                    r = it; rd = seq + (size_t)r * stride; have = true;
+                    if (search_begin<false>(ix, rd, L, 0, S, h, lc.n_hash)) { active = true; pending = false; }
+                    // else: decided at once; stays pending, stored at the next batch
+                } else pending = false;
             }
+            if (!__any(active) && !__any(pending)) break;
+            continue;
         }
-        if (!__any(active)) { if (next >= chunk_end) break; else continue; }
-        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) {
-            sc.sp0[r] = h.sp; sc.hits0[r] = (u32)h.hits; sc.ml0[r] = (u16)h.ml;
-            active = false;
-        }
+#ifdef BMBS_UTIL
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counters[8], 1ull);
+        if (active) atomicAdd(&counters[9], 1ull);
+#endif
+        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
     }
     flush_counters(counters, lc);
 }
@@ -566,20 +582,29 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
             sc.flag_d[r] = 1;
         }
     };
+    bool pending = true, have = false;
     for (;;) {
-        const unsigned long long need = __ballot(!active);
-        if (need) {
-            const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1));
+        const unsigned long long pm = __ballot(pending);
+        if (__popcll(pm) >= SEED_BATCH || !__any(active)) {
+            if (pm == 0) break;
+            const int rank = __popcll(pm & ((1ull << (threadIdx.x & 63)) - 1));
             const long it = next + rank;
-            next += __popcll(need);
-            if (!active && it < chunk_end) {
-                r = sc.list_c[it]; rd = seq + (size_t)r * stride;
-                if (search_begin<true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) active = true;
-                else finish();
+            next += __popcll(pm);
+            if (pending) {
+                if (have) { finish(); have = false; }
+                if (it < chunk_end) {
+                    r = sc.list_c[it]; rd = seq + (size_t)r * stride; have = true;
+                    if (search_begin<true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) { active = true; pending = false; }
+                } else pending = false;
             }
+            if (!__any(active) && !__any(pending)) break;
+            continue;
         }
-        if (!__any(active)) { if (next >= chunk_end) break; else continue; }
-        if (active && search_step<true>(ix, rd, L, S, h, lc.n_ext)) { finish(); active = false; }
+#ifdef BMBS_UTIL
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counters[10], 1ull);
+        if (active) atomicAdd(&counters[11], 1ull);
+#endif
+        if (active && search_step<true>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
     }
     flush_counters(counters, lc);
 }
@@ -598,7 +623,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const
     bool active = false, have = false;
     long r = 0;
     const char* rd = seq;
-    Search S; SeedHit h;
+    Search S; SeedHit h = {0, 0, 0};
     SeedRec* my = nullptr;
     int ns = 0, tm = 0, seed_id = 0, max_seed = 0;
     u64 ncand = 0, clen = 0;
@@ -614,37 +639,45 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const
         seed_id++;
         return true;
     };
-    // start seeds until one needs stepping or the read is finished
-    auto advance = [&]() {
-        for (;;) {
-            if (!(seed_id < max_seed && tm < L)) break;
-            if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash)) { active = true; return; }
-            if (!after_seed()) break;
-        }
-        seed_finish(st, r, clen != 0 ? 3 : 0, ns, ncand, pe_mode);
-        have = false;
-    };
+    // one transition of a pending lane: book the finished seed, start the next one or the next read.
+    // `pending` stays set when the new seed was decided without stepping (handled in the next batch).
+    bool pending = true, seed_done = false;
     for (;;) {
-        const unsigned long long need = __ballot(!have);
-        if (need) {
-            const int rank = __popcll(need & ((1ull << (threadIdx.x & 63)) - 1));
-            const long it = next + rank;
-            next += __popcll(need);
-            if (!have && it < chunk_end) {
-                r = sc.list_d[it]; rd = seq + (size_t)r * stride;
-                my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
-                ns = st.n_seeds[r]; ncand = st.n_cand[r]; clen = sc.clen[r]; tm = sc.tm[r]; seed_id = sc.seed_id[r];
-                max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
-                have = true; active = false;
-                advance();
+        const unsigned long long pm = __ballot(pending);
+        if (__popcll(pm) >= SEED_BATCH || !__any(active)) {
+            if (pm == 0) break;
+            if (pending && have && seed_done) {
+                seed_done = false;
+                if (!after_seed()) { seed_finish(st, r, clen != 0 ? 3 : 0, ns, ncand, pe_mode); have = false; }
             }
+            if (pending && have && !(seed_id < max_seed && tm < L)) { seed_finish(st, r, clen != 0 ? 3 : 0, ns, ncand, pe_mode); have = false; }
+            // lanes without a read take the next ones of the chunk
+            const unsigned long long want = __ballot(pending && !have);
+            const int rank = __popcll(want & ((1ull << (threadIdx.x & 63)) - 1));
+            const long it = next + rank;
+            next += __popcll(want);
+            if (pending && !have) {
+                if (it < chunk_end) {
+                    r = sc.list_d[it]; rd = seq + (size_t)r * stride;
+                    my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+                    ns = st.n_seeds[r]; ncand = st.n_cand[r]; clen = sc.clen[r]; tm = sc.tm[r]; seed_id = sc.seed_id[r];
+                    max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
+                    have = true;
+                    if (!(seed_id < max_seed && tm < L)) { seed_finish(st, r, clen != 0 ? 3 : 0, ns, ncand, pe_mode); have = false; }
+                } else pending = false;         // chunk exhausted: this lane is done
+            }
+            if (pending && have) {
+                if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash)) { active = true; pending = false; }
+                else seed_done = true;              // decided without stepping: booked in the next batch
+            }
+            if (!__any(active) && !__any(pending)) break;
+            continue;
         }
-        if (!__any(have)) { if (next >= chunk_end) break; else continue; }
-        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) {
-            active = false;
-            if (after_seed()) advance();
-            else { seed_finish(st, r, clen != 0 ? 3 : 0, ns, ncand, pe_mode); have = false; }
-        }
+#ifdef BMBS_UTIL
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counters[12], 1ull);
+        if (active) atomicAdd(&counters[13], 1ull);
+#endif
+        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; seed_done = true; }
     }
     flush_counters(counters, lc);
 }
