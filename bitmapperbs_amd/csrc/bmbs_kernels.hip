@@ -371,7 +371,7 @@ DEVI void seed_finish(const ReadState& st, long r, int verdict, int ns, u64 ncan
     st.n_cand[r] = verdict == 3 ? (u32)ncand : (pe_mode ? (verdict == 4 ? (u32)ncand : (verdict == 1 || verdict == 2) ? 1u : 0u) : 0u);
 }
 
-#define SEED_CHUNK 1024           // items per wave
+#define SEED_CHUNK 256            // items per wave
 #define SEED_BATCH 16             // pending lanes that trigger a transition batch
 
 struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung; };
