@@ -39,7 +39,7 @@ struct bmbs_ctx {
     DevBuf verdict, n_seeds, multi, mm_site, exit_site, seeds, n_cand, cand_off, n_votes, best_site,
         best_end, best_err, sbd, red_status, job_flag, job_off, scan_tmp, totals;
     // per-candidate / per-job workspace
-    DevBuf cand, votes, slot_read, ferr, fend, job_read, job_site, job_end, job_err, need_sw, sw_off, sw_job, trace,
+    DevBuf cand, votes, slot_read, vote_off, votes_dense, dense_read, ferr, fend, job_read, job_site, job_end, job_err, need_sw, sw_off, sw_job, trace,
         a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d;
@@ -355,7 +355,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
     DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
-                     &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->ferr, &c->fend,
+                     &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
                      &c->job_read, &c->job_site, &c->job_end, &c->job_err, &c->need_sw, &c->sw_off, &c->sw_job, &c->trace, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
                      &c->stats, &c->counters, &c->pe_seq, &c->pe_qual, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
@@ -453,15 +453,27 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     rc = run_seed_stages(c, d_seq, L, stride, n, k, &tot);
     if (rc) return rc;
     c->last_total_cand = tot;
+    ENS(c, c->vote_off, (n + 1) * 8);
+    {
+        const u64 t1 = tot ? tot : 1;
+        ENS(c, c->votes_dense, t1 * sizeof(bmbs_vote)); ENS(c, c->dense_read, t1 * 4);
+    }
+    prof_begin(c, "vote_compact");
+    rc = scan_u32(c, st.n_votes, n, c->vote_off.as<u64>(), 5);
+    if (rc) return rc;
+    if (tot)
+        hipLaunchKernelGGL(k_vote_compact, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, tot, st, c->vote_off.as<u64>(),
+                           c->slot_read.as<u32>(), c->votes.as<bmbs_vote>(), c->votes_dense.as<bmbs_vote>(), c->dense_read.as<u32>());
+    prof_end(c);
     if (tot) {
         prof_begin(c, "k_filter");
-        hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, k, tot,
-                           c->slot_read.as<u32>(), c->votes.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), cnt);
+        hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, k, c->totals.as<u64>() + 5,
+                           c->dense_read.as<u32>(), c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), cnt);
         prof_end(c);
     }
     prof_begin(c, "k_reduce");
-    hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, c->votes.as<bmbs_vote>(),
-                       c->ferr.as<u32>(), c->fend.as<int>());
+    hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, c->vote_off.as<u64>(),
+                       c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>());
     prof_end(c);
     prof_begin(c, "scan_jobs");
     rc = scan_u32(c, st.job_flag, n, st.job_off, 1);

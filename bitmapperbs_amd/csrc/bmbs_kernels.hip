@@ -738,49 +738,56 @@ k_vote(long n, int k, ReadState st, u64* __restrict__ cand, bmbs_vote* __restric
     for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
 }
 
+// the vote lists are shorter than the candidate segments they were built in: pack them densely
+// (vote_off = exclusive scan of n_votes) so that the filter runs on full waves
+__global__ void __launch_bounds__(256)
+k_vote_compact(u64 n_slots, ReadState st, const u64* __restrict__ vote_off, const u32* __restrict__ slot_read,
+               const bmbs_vote* __restrict__ votes, bmbs_vote* __restrict__ dense, u32* __restrict__ dense_read)
+{
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_slots) return;
+    const u32 r = slot_read[g];
+    if (r == 0xffffffffu) return;
+    const u64 d = vote_off[r] + (g - st.cand_off[r]);
+    dense[d] = votes[g];
+    dense_read[d] = r;
+}
+
 // ================================================================================================
 // K7+K8: window fetch + BS banded Myers, one candidate per lane, 64-bit words
 // ================================================================================================
 // BS_Reserve_Banded_BPM (Levenshtein_Cal.h:351-567); the 4 x 64-bit and 8 x 32-bit AVX2 forms
 // (:1678, :2093) compute the same (err, end_site) per candidate.  pattern = window (L+2k bases from
 // the doubled 2-bit genome), text = read; read 'T' also matches window 'C' (:384,473).
-DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
+// W = u32 when the band (2k+1 bits) fits 32 bits (k <= 15, exactly the case in which the reference runs
+// its 8 x 32-bit AVX2 form), else u64.
+template <class W>
+DEVI void bpm_core(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
 {
     out_err = 0xffffffffu; out_end = -1;
     const int p_len = L + 2 * k;
     if (!window_valid(ix, site, (u64)p_len, site < ix.G)) return;
-    u64 P[4] = {0, 0, 0, 0};
-    // streaming 2-bit window reader
-    u64 pos = site;
-    u64 w = ix.gen2[pos >> 5] >> ((pos & 31) * 2);
-    int left = 32 - (int)(pos & 31);
-    auto next_base = [&]() -> int {
-        const int b = (int)(w & 3);
-        w >>= 2; pos++; left--;
-        if (left == 0) { w = ix.gen2[pos >> 5]; left = 32; }
-        return b;
-    };
-    u64 PA = 0, PC = 0, PG = 0, PT = 0;
+    WinReader wr; wr.init(ix, site, true);
+    W PA = 0, PC = 0, PG = 0, PT = 0;
     const int band = 2 * k + 1;
     for (int i = 0; i < band; i++) {
-        const int b = next_base();
-        const u64 bit = 1ull << i;
-        PA |= b == 0 ? bit : 0; PC |= b == 1 ? bit : 0; PG |= b == 2 ? bit : 0; PT |= b == 3 ? bit : 0;
+        const int b = wr.next();
+        const W bit = (W)1 << i;
+        PA |= b == 0 ? bit : (W)0; PC |= b == 1 ? bit : (W)0; PG |= b == 2 ? bit : (W)0; PT |= b == 3 ? bit : (W)0;
     }
-    (void)P;
     PT |= PC;
-    const u64 Mask = 1ull << (2 * k);
-    u64 VP = 0, VN = 0;
+    const W Mask = (W)1 << (2 * k);
+    W VP = 0, VN = 0;
     int err = 0;
     const int last_high = 2 * k;
     ReadCur rc; rc.seek(rd, 0, L);
     for (int i = 0; i < L; i++) {
         const char tc = rc.next();
-        const u64 eq = tc == 'A' ? PA : tc == 'C' ? PC : tc == 'G' ? PG : tc == 'T' ? PT : 0ull;
-        u64 X = eq | VN;
-        const u64 D0 = ((VP + (X & VP)) ^ VP) | X;
-        const u64 HN = VP & D0;
-        const u64 HP = VN | ~(VP | D0);
+        const W eq = tc == 'A' ? PA : tc == 'C' ? PC : tc == 'G' ? PG : tc == 'T' ? PT : (W)0;
+        W X = eq | VN;
+        const W D0 = ((VP + (X & VP)) ^ VP) | X;
+        const W HN = VP & D0;
+        const W HP = VN | ~(VP | D0);
         X = D0 >> 1;
         VN = X & HP;
         VP = HN | ~(X | HP);
@@ -790,8 +797,8 @@ DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u3
         }
         if (i + 1 < L) {
             PA >>= 1; PC >>= 1; PG >>= 1; PT >>= 1;
-            const int b = next_base();
-            PA |= b == 0 ? Mask : 0; PC |= b == 1 ? Mask : 0; PG |= b == 2 ? Mask : 0; PT |= b == 3 ? Mask : 0;
+            const int b = wr.next();
+            PA |= b == 0 ? Mask : (W)0; PC |= b == 1 ? Mask : (W)0; PG |= b == 2 ? Mask : (W)0; PT |= b == 3 ? Mask : (W)0;
             PT |= PC;
         }
     }
@@ -815,17 +822,22 @@ DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u3
     out_err = best; out_end = ret;
 }
 
+DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
+{
+    if (k <= 15) bpm_core<u32>(ix, rd, L, k, site, out_err, out_end);       // k is wave-uniform
+    else bpm_core<u64>(ix, rd, L, k, site, out_err, out_end);
+}
+
 __global__ void __launch_bounds__(256)
-k_filter(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, u64 n_slots,
-         const u32* __restrict__ slot_read, const bmbs_vote* __restrict__ votes,
-         u32* __restrict__ ferr, int* __restrict__ fend, unsigned long long* __restrict__ counters)
+k_filter(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, const u64* __restrict__ n_votes_total,
+         const u32* __restrict__ dense_read, const bmbs_vote* __restrict__ dense, u32* __restrict__ ferr,
+         int* __restrict__ fend, unsigned long long* __restrict__ counters)
 {
     const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_slots) return;
-    const u32 r = slot_read[g];
-    if (r == 0xffffffffu) return;
+    if (g >= *n_votes_total) return;
+    const u32 r = dense_read[g];
     u32 e; int es;
-    bpm_one(ix, seq + (size_t)r * stride, L, k, votes[g].site, e, es);
+    bpm_one(ix, seq + (size_t)r * stride, L, k, dense[g].site, e, es);
     ferr[g] = e; fend[g] = es;
     if (counters) atomicAdd(&counters[3], 1ull);
 }
@@ -847,15 +859,15 @@ k_filter_pairs(DevIndex ix, const char* __restrict__ seq, int L, int stride, int
 // K9: ordered reduction over a read's votes (Schema.cpp:7847-8172 / 8335-8750)
 // ================================================================================================
 __global__ void __launch_bounds__(256)
-k_reduce(long n, ReadState st, const bmbs_vote* __restrict__ votes, const u32* __restrict__ ferr,
-         const int* __restrict__ fend)
+k_reduce(long n, ReadState st, const u64* __restrict__ vote_off, const bmbs_vote* __restrict__ votes,
+         const u32* __restrict__ ferr, const int* __restrict__ fend)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     st.job_flag[r] = 0;
     st.red_status[r] = 0;
     if (st.verdict[r] != 3) return;
-    const u64 off = st.cand_off[r];
+    const u64 off = vote_off[r];
     const long nv = (long)st.n_votes[r];
     u32 min_err = 0xfffffffeu, sbd = 0;
     long min_idx = -1;
