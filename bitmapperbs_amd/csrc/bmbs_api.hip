@@ -266,8 +266,10 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, (long)n, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_decide");
-    hipLaunchKernelGGL(k_seed_decide, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n, c->prm.seed_len,
-                       pe_mode, st, sc, cnt);
+    // (an LDS-staged variant of this kernel, k_seed_decide<true>, measured 20 % slower on MI355X: the per-lane row
+    // scans are not what bounds it)
+    hipLaunchKernelGGL(k_seed_decide<false>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+                       c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_second");
     int rc = scan_u32(c, sc.flag_c, n, sc.off_c, 3);
@@ -307,13 +309,24 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, in
     ENS(c, c->ferr, t1 * 4); ENS(c, c->fend, t1 * 4);
     if (tot) {
         prof_begin(c, "k_locate");
-        hipLaunchKernelGGL(k_locate, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, (long)n, tot, st, c->cand.as<u64>());
+        hipLaunchKernelGGL(k_locate, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, (long)n, st, c->cand.as<u64>());
         prof_end(c);
     }
     prof_begin(c, "k_vote");
     hipLaunchKernelGGL(k_vote, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, k, st, c->cand.as<u64>(),
                        c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
     prof_end(c);
+    return BMBS_OK;
+}
+
+// host rows (stride bytes apart) -> device rows padded to a multiple of 16 bytes
+int upload_rows(bmbs_ctx* c, DevBuf& dst, const char* src, int L, int stride, u64 n, int* dstride)
+{
+    const int ds = (L + 15) / 16 * 16;
+    *dstride = ds;
+    ENS(c, dst, n * (u64)ds + 64);
+    HIPCHK(c, hipMemsetAsync(dst.p, 0, n * (u64)ds + 64, c->stream));
+    if (n) HIPCHK(c, hipMemcpy2DAsync(dst.p, ds, src, stride, L, n, hipMemcpyHostToDevice, c->stream));
     return BMBS_OK;
 }
 
@@ -435,6 +448,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
     if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if ((stride & 15) || (d_seq_ & 15) || (d_qual_ & 15)) { c->err = "device read buffers must be 16-byte aligned with a stride that is a multiple of 16"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
     const char* d_seq = reinterpret_cast<const char*>(d_seq_);
     const char* d_qual = reinterpret_cast<const char*>(d_qual_);
@@ -517,12 +531,14 @@ extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32
     const u64 n = (u64)n_reads, bytes = n * (u64)stride;
     if (n_cigar_used) *n_cigar_used = 0;
     if (n == 0) return BMBS_OK;
-    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_qual, bytes + 64); ENS(c, c->out_res, n * 32);
+    ENS(c, c->out_res, n * 32);
     const int k = threshold_k(c->prm, L);
     const u64 pool = n * (u64)(2 * k + 8);           // worst case: every read needs K12
     ENS(c, c->cig_pool, pool * 4);
-    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->in_qual.p, qual, bytes, hipMemcpyHostToDevice, c->stream));
+    int ds = 0;
+    { int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; r1 = upload_rows(c, c->in_qual, qual, L, stride, n, &ds); if (r1) return r1; }
+    (void)bytes;
+    stride = ds;
     int rc = bmbs_map_se_device(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, L, stride, n_reads,
                                 (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
     if (rc) return rc;
@@ -546,6 +562,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
     if (c->prm.sensitive) { c->err = "--sensitive (re-seeding, Schema.cpp:16678) is not implemented on the device yet"; return BMBS_ESTATE; }
     if (L <= 0 || L > 1000 || stride < L || n_pairs < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if ((stride & 15) || ((d_seq1 | d_qual1 | d_seq2 | d_qual2) & 15)) { c->err = "device read buffers must be 16-byte aligned with a stride that is a multiple of 16"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
     const u64 n = (u64)n_pairs, n2 = 2 * n;
     c->n_prof_used = 0;
@@ -588,7 +605,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     PeCand* B = c->pe_B.as<PeCand>();
     if (tot) {
         prof_begin(c, "k_locate");
-        hipLaunchKernelGGL(k_locate, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, (long)n2, tot, st, c->cand.as<u64>());
+        hipLaunchKernelGGL(k_locate, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, c->ix, (long)n2, st, c->cand.as<u64>());
         prof_end(c);
     }
     const long long maxd = (long long)c->prm.max_ins + 2LL * k;
@@ -661,15 +678,19 @@ extern "C" int bmbs_map_pe(bmbs_ctx* c, const char* seq1, const char* qual1, con
     const u64 n = (u64)n_pairs, bytes = n * (u64)stride;
     if (n_cigar_used) *n_cigar_used = 0;
     if (n == 0) return BMBS_OK;
-    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_qual, bytes + 64); ENS(c, c->in_seq2, bytes + 64); ENS(c, c->in_qual2, bytes + 64);
     ENS(c, c->out_res, 2 * n * 32);
     const int k = threshold_k(c->prm, L);
     const u64 pool = 2 * n * (u64)(2 * k + 8);
     ENS(c, c->cig_pool, pool * 4);
-    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq1, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->in_qual.p, qual1, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->in_seq2.p, seq2, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->in_qual2.p, qual2, bytes, hipMemcpyHostToDevice, c->stream));
+    int ds = 0;
+    {
+        int r1 = upload_rows(c, c->in_seq, seq1, L, stride, n, &ds); if (r1) return r1;
+        r1 = upload_rows(c, c->in_qual, qual1, L, stride, n, &ds); if (r1) return r1;
+        r1 = upload_rows(c, c->in_seq2, seq2, L, stride, n, &ds); if (r1) return r1;
+        r1 = upload_rows(c, c->in_qual2, qual2, L, stride, n, &ds); if (r1) return r1;
+    }
+    (void)bytes;
+    stride = ds;
     int rc = bmbs_map_pe_device(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, (uint64_t)c->in_seq2.p, (uint64_t)c->in_qual2.p,
                                 L, stride, n_pairs, (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
     if (rc) return rc;
@@ -693,8 +714,8 @@ extern "C" int bmbs_filter_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_
     if (n_cand <= 0) return BMBS_OK;
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_cand;
     const int k = threshold_k(c->prm, L);
-    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->ferr, m * 4); ENS(c, c->fend, m * 4);
-    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
+    ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->ferr, m * 4); ENS(c, c->fend, m * 4);
+    { int ds = 0; int r1 = upload_rows(c, c->in_seq, seq, L, stride, (u64)n_reads, &ds); if (r1) return r1; stride = ds; (void)bytes; }
     HIPCHK(c, hipMemcpyAsync(c->in_a.p, read_of, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_b.p, site, m * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_filter_pairs, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_seq.as<char>(), L, stride, k, m,
@@ -716,11 +737,14 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     if (n_jobs <= 0) return BMBS_OK;
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_jobs;
     const int k = threshold_k(c->prm, L);
-    ENS(c, c->in_seq, bytes + 64); ENS(c, c->in_qual, bytes + 64);
     ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->in_c, m * 4); ENS(c, c->in_d, m * 4);
     ENS(c, c->cig_pool, m * (u64)max_ops * 4);
-    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->in_qual.p, qual, bytes, hipMemcpyHostToDevice, c->stream));
+    {
+        int ds = 0;
+        int r1 = upload_rows(c, c->in_seq, seq, L, stride, (u64)n_reads, &ds); if (r1) return r1;
+        r1 = upload_rows(c, c->in_qual, qual, L, stride, (u64)n_reads, &ds); if (r1) return r1;
+        stride = ds; (void)bytes;
+    }
     HIPCHK(c, hipMemcpyAsync(c->in_a.p, read_of, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_b.p, site, m * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_c.p, end_site_in, m * 4, hipMemcpyHostToDevice, c->stream));
@@ -754,8 +778,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     c->n_prof_used = 0;
     int rc = per_read_workspace(c, n);
     if (rc) return rc;
-    ENS(c, c->in_seq, bytes + 64);
-    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, seq, bytes, hipMemcpyHostToDevice, c->stream));
+    { int ds = 0; int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; stride = ds; (void)bytes; }
     HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16 * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->exit_site.p, 0, n * 8, c->stream));
     u64 tot = 0;

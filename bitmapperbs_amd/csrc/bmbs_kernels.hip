@@ -432,6 +432,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
 }
 
 // ---- exits after the first seed (Schema.cpp:24599-24727 / 18225-18330) ---------------------------
+template <bool USE_LDS>
 __global__ void __launch_bounds__(256)
 k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, int pe_mode, ReadState st,
               SeedCarry sc, unsigned long long* __restrict__ counters)
@@ -441,8 +442,29 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long
     __syncthreads();
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     u32 n_sa = 0, n_ung = 0;
+    // the block's 256 reads are contiguous in memory: copy them into LDS with fully coalesced 16-byte loads
+    // (rows re-padded by 8 bytes against bank conflicts); each lane then scans ITS row out of LDS instead of
+    // issuing 64-cache-line gathers per instruction
+    extern __shared__ __align__(16) char lds_rows[];
+    const int lstride = stride + 8;
+    if (USE_LDS) {
+        const long row0 = (long)blockIdx.x * blockDim.x;
+        const long rows = n - row0 < (long)blockDim.x ? n - row0 : (long)blockDim.x;
+        const int per_row = stride / 16;
+        const long total16 = rows * per_row;
+        const uint4* src = reinterpret_cast<const uint4*>(seq + (size_t)row0 * stride);
+        for (long q = threadIdx.x; q < total16; q += blockDim.x) {
+            const uint4 v = src[q];
+            const long rr = q / per_row;
+            const int cc = (int)(q - rr * per_row);
+            u64* dst = reinterpret_cast<u64*>(lds_rows + rr * lstride + cc * 16);
+            dst[0] = ((u64)v.y << 32) | v.x;
+            dst[1] = ((u64)v.w << 32) | v.z;
+        }
+    }
+    __syncthreads();
     if (r < n) {
-        const char* rd = seq + (size_t)r * stride;
+        const char* rd = USE_LDS ? lds_rows + (size_t)threadIdx.x * lstride : seq + (size_t)r * stride;
         int firstC = L;
         for (int i = 0; i < L; i += 8) {
             // lowest byte equal to 'C' in this 8-byte word (exact for the lowest-order zero byte)
@@ -686,28 +708,21 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const
 // K5/K6 + a8: one candidate slot per lane
 // ================================================================================================
 __global__ void __launch_bounds__(256)
-k_locate(DevIndex ix, long n, u64 total_cand, ReadState st, u64* __restrict__ cand)
+k_locate(DevIndex ix, long n, ReadState st, u64* __restrict__ cand)
 {
-    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_cand) return;
-    // read r with cand_off[r] <= g < cand_off[r+1]
-    long lo = 0, hi = n;
-    while (hi - lo > 1) { const long mid = (lo + hi) >> 1; if (st.cand_off[mid] <= g) lo = mid; else hi = mid; }
-    const long r = lo;
-    u64 rel = g - st.cand_off[r];
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (st.n_cand[r] == 0) return;
     const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
     const int ns = st.n_seeds[r];
-    u64 site = 0;
-    for (int s = 0; s < ns; s++) {
+    u64 o = st.cand_off[r];
+    const u64 o_end = st.cand_off[r + 1];
+    for (int s = 0; s < ns && o < o_end; s++) {
+        const u64 sp = my[s].sp, adj = (u64)my[s].len + (u64)my[s].off;
         const u32 h = my[s].hits;
-        if (rel < h) {
-            const u64 p = ix.sa[my[s].sp + rel];
-            site = ix.total - p - (u64)my[s].len - (u64)my[s].off;     // reverse_and_adjust_site, Schema.cpp:4669
-            break;
-        }
-        rel -= h;
+        for (u32 j = 0; j < h && o < o_end; j++)
+            cand[o++] = ix.total - (u64)ix.sa[sp + j] - adj;       // reverse_and_adjust_site, Schema.cpp:4669
     }
-    cand[g] = site;
 }
 
 // ================================================================================================
