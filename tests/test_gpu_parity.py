@@ -308,3 +308,46 @@ def test_gpu_pe_sam_equals_reference_golden(name, tmp_path):
     assert mine == gzip.open(os.path.join(GOLD, "pe_%s.ref.sam.gz" % name), "rt").read()
     assert distributed.mapstats_text(m.stats()) == open(os.path.join(GOLD, "pe_%s.ref.stats" % name)).read()
     m.close()
+
+
+# ---- the C++ driver: FASTQ -> GPU -> SAM file, whole-program drop-in for `bitmapperBS --search` --------
+def _driver():
+    from common import ROOT
+    p = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
+    assert os.path.exists(p), "bmbs_search not built (make -C bitmapperbs_amd/csrc)"
+    return p
+
+
+@pytest.mark.parametrize("name", ["b150", "e75"])
+def test_cpp_driver_se_sam_file_equals_reference_golden(name, tmp_path):
+    import shutil
+    import subprocess
+    from bitmapperbs_amd import mapper
+    fa = str(tmp_path / "genome.fa"); fq = str(tmp_path / "r.fq"); out = str(tmp_path / "o.sam"); ms = str(tmp_path / "ms.txt")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    # the driver reads gzipped FASTQ directly (Process_Reads.cpp:1455-1514)
+    shutil.copy(os.path.join(GOLD, "se_%s.fq.gz" % name), fq + ".gz")
+    mapper.Index.build(fa, fa, threads=4)
+    p = subprocess.run([_driver(), "--search", fa, "--seq", fq + ".gz", "-o", out, "--mapstats", ms, "--batch", "700"] + golden_args()[name],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "se_%s.ref.sam.gz" % name), "rt").read()
+    assert open(ms).read() == open(os.path.join(GOLD, "se_%s.ref.stats" % name)).read()
+
+
+def test_cpp_driver_pe_sam_file_equals_reference_golden(tmp_path):
+    import subprocess
+    from bitmapperbs_amd import mapper
+    name = "p100"
+    fa = str(tmp_path / "genome.fa"); f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq"); out = str(tmp_path / "o.sam")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1)
+    gunzip_to(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), f2)
+    mapper.Index.build(fa, fa, threads=4)
+    p = subprocess.run([_driver(), "--search", fa, "--seq1", f1, "--seq2", f2, "-o", out] + pe_golden_args()[name], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "pe_%s.ref.sam.gz" % name), "rt").read()
+    stats = "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
+    assert stats == open(os.path.join(GOLD, "pe_%s.ref.stats" % name)).read()
