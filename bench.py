@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("-e", type=float, default=0.04)
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed on the host CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pe", action="store_true", help="paired-end fast mode: --reads pairs per GPU per step (value counts 2 reads per pair)")
     ap.add_argument("--workdir", default=os.environ.get("BMBS_BENCH_DIR", "/tmp/bmbs_bench"))
     return ap.parse_args()
 
@@ -134,16 +135,25 @@ def main():
     m = mapper.Mapper(ix, device=local, e_f=args.e)
     k = m.threshold(L)
     genome_d, lens_d = gpusynth.upload_genome(chroms)
-    seq_d, qual_d = gpusynth.make_reads_se(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank)
-    del genome_d
     max_ops = 2 * k + 8
-    cig_cap = n * max_ops
-    res_d = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    if not args.pe:
+        seq_d, qual_d = gpusynth.make_reads_se(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank)
+        cig_cap = n * max_ops
+        res_d = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    else:
+        seq_d, qual_d, seq2_d, qual2_d = gpusynth.make_reads_pe(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank)
+        cig_cap = 2 * n * max_ops
+        res_d = torch.empty((2 * n, 32), dtype=torch.uint8, device="cuda")
+    del genome_d
     cig_d = torch.empty((cig_cap,), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
 
     def step():
-        m.map_se_device(seq_d.data_ptr(), qual_d.data_ptr(), L, stride, n, res_d.data_ptr(), cig_d.data_ptr(), cig_cap)
+        if not args.pe:
+            m.map_se_device(seq_d.data_ptr(), qual_d.data_ptr(), L, stride, n, res_d.data_ptr(), cig_d.data_ptr(), cig_cap)
+        else:
+            m.map_pe_device(seq_d.data_ptr(), qual_d.data_ptr(), seq2_d.data_ptr(), qual2_d.data_ptr(), L, stride, n,
+                            res_d.data_ptr(), cig_d.data_ptr(), cig_cap)
         m.sync()
 
     for _ in range(args.warmup):
@@ -175,39 +185,53 @@ def main():
         kern_ms[kname] /= max(1, args.steps)
 
     if rank == 0:
-        total_reads = n * world * args.steps
+        reads_per_unit = 2 if args.pe else 1
+        nr = n * reads_per_unit                     # reads seeded per launch
+        total_reads = nr * world * args.steps
         value = total_reads / dt / 1e6
-        dom = max(kern_ms, key=kern_ms.get) if kern_ms else "k_seed"
-        # algorithmic bytes of one launch (SURVEY.md §8d per-unit figures x this launch's event counts)
+        mapping = {kn: v for kn, v in kern_ms.items() if kn.startswith("k_")}
+        dom = max(mapping, key=mapping.get) if mapping else "k_seed_first"
+        # ALGORITHMIC bytes of one launch = SURVEY.md §8d per-unit figures x this launch's event counts
+        # (10 B per 16-mer lookup, 80 B per backward extension = two 40-B Occ blocks, 4 B per SA read,
+        #  ceil(len/4)+1 B per fetched window, read characters actually consumed, 16 B per recorded seed)
         win = (L + 2 * k + 3) // 4 + 1
+        def seed_bytes(c):
+            return 10 * c["n_hash"] + 80 * c["n_ext"] + 16 * c["n_hash"] + c["n_ext"] + 16 * c["n_hash"]
         alg = {
-            "k_seed": L * n + 10 * cnt["n_hash"] + 80 * cnt["n_ext"] + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1) * cnt["n_ungapped"],
-            "k_locate": 4 * cnt["n_cand_slots"] + 8 * cnt["n_cand_slots"],
-            "k_vote": 8 * cnt["n_cand_slots"] + 16 * cnt["n_cand_slots"],
+            "k_seed_first": seed_bytes(cnt["k_seed_first"]) + 14 * nr,
+            "k_seed_decide": (L + 14 + 40) * nr + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1 + L) * cnt["n_ungapped"],
+            "k_seed_second": seed_bytes(cnt["k_seed_second"]) + 4 * cnt["k_seed_second"]["n_sa"] + 24 * cnt["k_seed_second"]["n_hash"],
+            "k_seed_extra": seed_bytes(cnt["k_seed_extra"]),
+            "k_locate": (4 + 8) * cnt["n_cand_slots"],
+            "k_vote": (8 + 16 + 4) * cnt["n_cand_slots"],
             "k_filter": (win + L + 16 + 8) * cnt["n_filter"],
-            "k_align": (win + 2 * L + 4 * max_ops) * cnt["n_sw"],
-            "k_finalize": 32 * n,
+            "k_align_ungapped": (win + 2 * L + 16) * cnt["n_sw"],
+            "k_align_sw": (win + 2 * L + 16) * cnt["n_sw"],
+            "k_finalize": 32 * nr,
         }
         bytes_dom = alg.get(dom, 0)
         ach = bytes_dom / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0
+        rl_all = {kn: round(alg[kn] / (kern_ms[kn] * 1e-3) / 1e9, 2) for kn in alg if kern_ms.get(kn, 0) > 0}
         out = {
-            "metric": "M 150bp reads aligned/s", "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world,
+            "metric": "M 150bp %s reads aligned/s" % ("PE" if args.pe else "SE"), "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic %d bp SE bisulfite reads per GPU per step vs %d bp "
-                                   "4-chromosome synthetic (chr21-size) genome, -e %.2f (k=%d), inputs and results resident in HBM"
-                                   % (n, L, args.genome, args.e, k),
+            "config": {"workload": ("BASELINE configs[1]: %d synthetic %d bp SE bisulfite reads" % (n, L) if not args.pe else
+                                    "%d synthetic %d bp read PAIRS (fast PE mode, insert 170-400)" % (n, L)) +
+                                   " per GPU per step vs %d bp 4-chromosome synthetic (chr21-size) genome, -e %.2f (k=%d), inputs and "
+                                   "results resident in HBM" % (args.genome, args.e, k),
                        "reads_per_gpu_per_step": n, "read_len": L, "genome_bp": args.genome,
                        "parallelism": "reads sharded by rank, index replicated, RCCL all-reduce of 5 mapstats counters"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": int(bytes_dom), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4)},
             "kernels_ms_per_step": {a: round(b, 4) for a, b in kern_ms.items()},
+            "kernels_algorithmic_GBps": rl_all,
             "counters_per_step": cnt,
             "mapstats": {"reads": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                          "unmapped": int(stats[0] - stats[1] - stats[2]), "mapped_bases": int(stats[3]), "error_bases": int(stats[4])},
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.pe:
             ns = min(n, args.cpu_sample)
             seq_h = seq_d[:ns].cpu().numpy()
             qual_h = qual_d[:ns].cpu().numpy()

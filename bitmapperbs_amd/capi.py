@@ -20,7 +20,7 @@ SYMBOLS = [
     "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se", "bmbs_map_se_device",
     "bmbs_map_pe", "bmbs_map_pe_device",
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
-    "bmbs_counters_last", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
+    "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build",
 ]
 
@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
     L.bmbs_stats_allreduce.argtypes = [C.POINTER(vp), C.c_int, vp]
     L.bmbs_profile_last.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.bmbs_counters_last.argtypes = [vp, vp]
+    L.bmbs_counters_all.argtypes = [vp, vp]
     L.bmbs_index_file_load.argtypes = [C.c_char_p]
     L.bmbs_index_file_load.restype = vp
     L.bmbs_index_file_view.argtypes = [vp, C.POINTER(IndexView)]
@@ -98,7 +99,7 @@ def lib() -> C.CDLL:
     for name in ("bmbs_index_attach", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se",
                  "bmbs_map_pe", "bmbs_map_pe_device",
                  "bmbs_map_se_device", "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce",
-                 "bmbs_profile_last", "bmbs_counters_last", "bmbs_index_build"):
+                 "bmbs_profile_last", "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_build"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -353,11 +353,11 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
-    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, 5 * 8) || ensure(c, c->counters, 16 * 8) ||
+    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, 5 * 8) || ensure(c, c->counters, 32 * 8) ||
         ensure(c, c->totals, 8 * 8)) { bmbs_destroy(c); return nullptr; }
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
     (void)hipMemset(c->stats.p, 0, 5 * 8);
-    (void)hipMemset(c->counters.p, 0, 16 * 8);
+    (void)hipMemset(c->counters.p, 0, 32 * 8);
     return c;
 }
 
@@ -460,7 +460,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     if (rc) return rc;
     rc = per_read_workspace(c, n);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32 * 8, c->stream));
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     u64 tot = 0;
@@ -575,7 +575,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     ENS(c, c->pe_seq, n2 * (u64)stride + 64); ENS(c, c->pe_qual, n2 * (u64)stride + 64);
     ENS(c, c->pe_occ, n2 * 4); ENS(c, c->pe_len, n2 * 4); ENS(c, c->pe_cur, n2); ENS(c, c->pe_vround, n2);
     ENS(c, c->pe_dead, n); ENS(c, c->pe_both, n); ENS(c, c->pe_npair, n * 4); ENS(c, c->pe_sbd, n * 4);
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32 * 8, c->stream));
     char* seq_all = c->pe_seq.as<char>();
     char* qual_all = c->pe_qual.as<char>();
     prof_begin(c, "k_pe_prepare");
@@ -779,7 +779,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     int rc = per_read_workspace(c, n);
     if (rc) return rc;
     { int ds = 0; int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; stride = ds; (void)bytes; }
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32 * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->exit_site.p, 0, n * 8, c->stream));
     u64 tot = 0;
     rc = run_seed_stages(c, c->in_seq.as<char>(), L, stride, n, k, &tot);
@@ -842,16 +842,19 @@ extern "C" int bmbs_profile_last(bmbs_ctx* c, const char** names, float* ms, int
 
 extern "C" int bmbs_counters_last(bmbs_ctx* c, uint64_t out[8])
 {
+    uint64_t all[32];
+    int rc = bmbs_counters_all(c, all);
+    if (rc) return rc;
+    for (int i = 0; i < 8; i++) out[i] = all[i];
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_counters_all(bmbs_ctx* c, uint64_t out[32])
+{
     if (!c) return BMBS_EINVAL;
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint64_t all[16];
-    HIPCHK(c, hipMemcpy(all, c->counters.p, 16 * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; i++) out[i] = all[i];
-    if (getenv("BMBS_UTIL_PRINT"))
-        fprintf(stderr, "[util] first: iters %llu active %llu | second: iters %llu active %llu | extra: iters %llu active %llu\n",
-                (unsigned long long)all[8], (unsigned long long)all[9], (unsigned long long)all[10], (unsigned long long)all[11],
-                (unsigned long long)all[12], (unsigned long long)all[13]);
+    HIPCHK(c, hipMemcpy(out, c->counters.p, 32 * 8, hipMemcpyDeviceToHost));
     out[6] = c->last_total_cand;
     out[7] = c->last_n_jobs;
     return BMBS_OK;

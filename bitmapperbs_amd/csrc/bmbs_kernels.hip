@@ -375,16 +375,18 @@ DEVI void seed_finish(const ReadState& st, long r, int verdict, int ns, u64 ncan
 #define SEED_BATCH 16             // pending lanes that trigger a transition batch
 
 struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung; };
-DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c)
+// totals in counters[0,1,2,5]; per-kernel copies in counters[16 + 4*kid ..] (kid 0 first, 1 second, 2 extra)
+DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c, int kid)
 {
     // 64-thread blocks: one wave; reduce with shuffles, one atomic per wave and counter
     u32 a = c.n_hash, b = c.n_ext, d = c.n_sa, e = c.n_ung;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); e += __shfl_down(e, o); }
     if ((threadIdx.x & 63) == 0 && counters) {
-        if (a) atomicAdd(&counters[0], (unsigned long long)a);
-        if (b) atomicAdd(&counters[1], (unsigned long long)b);
-        if (d) atomicAdd(&counters[2], (unsigned long long)d);
-        if (e) atomicAdd(&counters[5], (unsigned long long)e);
+        unsigned long long* k = counters + 16 + 4 * kid;
+        if (a) { atomicAdd(&counters[0], (unsigned long long)a); atomicAdd(&k[0], (unsigned long long)a); }
+        if (b) { atomicAdd(&counters[1], (unsigned long long)b); atomicAdd(&k[1], (unsigned long long)b); }
+        if (d) { atomicAdd(&counters[2], (unsigned long long)d); atomicAdd(&k[2], (unsigned long long)d); }
+        if (e) { atomicAdd(&counters[5], (unsigned long long)e); atomicAdd(&k[3], (unsigned long long)e); }
     }
 }
 
@@ -428,7 +430,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
 #endif
         if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
     }
-    flush_counters(counters, lc);
+    flush_counters(counters, lc, 0);
 }
 
 // ---- exits after the first seed (Schema.cpp:24599-24727 / 18225-18330) ---------------------------
@@ -628,7 +630,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
 #endif
         if (active && search_step<true>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
     }
-    flush_counters(counters, lc);
+    flush_counters(counters, lc, 1);
 }
 
 // ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
@@ -701,7 +703,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const
 #endif
         if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; seed_done = true; }
     }
-    flush_counters(counters, lc);
+    flush_counters(counters, lc, 2);
 }
 
 // ================================================================================================

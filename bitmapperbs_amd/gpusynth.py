@@ -64,3 +64,48 @@ def make_reads_se(genome: torch.Tensor, lens: torch.Tensor, n: int, L: int, stri
     else:
         q = (torch.randint(2, 41, (n, stride), generator=g, device=dev) + 33).to(torch.uint8)
     return seq, q
+
+
+@torch.no_grad()
+def make_reads_pe(genome: torch.Tensor, lens: torch.Tensor, n: int, L: int, stride: int, seed: int,
+                  sub: float = 0.005, conv: float = 0.99, ins_lo: int | None = None, ins_hi: int = 400):
+    """-> (seq1, qual1, seq2, qual2) [n, stride] uint8 on the device; mate 2 as it would appear in the FASTQ
+    (reverse-complement end of the converted fragment); substitutions only (no indels) in this generator."""
+    dev = genome.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    ins_lo = L + 20 if ins_lo is None else ins_lo
+    offs = torch.cumsum(lens, 0) - lens
+    c = torch.randint(0, lens.numel(), (n,), generator=g, device=dev)
+    ins = torch.randint(ins_lo, ins_hi, (n,), generator=g, device=dev)
+    hi = (lens[c] - ins - 8).to(torch.float64)
+    p = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * hi).to(torch.int64)
+    start = offs[c] + p
+    minus = torch.rand(n, generator=g, device=dev) < 0.5
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.arange(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    s1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    s2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    j = torch.arange(L, device=dev)[None, :]
+    T = torch.tensor(ord("T"), dtype=torch.uint8, device=dev)
+    chunk = 1 << 20
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        m = minus[a:b, None]; st = start[a:b, None]; il = ins[a:b, None]
+        def frag(f):                                   # fragment base f of the sequenced strand, bisulfite converted
+            gi = torch.where(m, st + il - 1 - f, st + f)
+            base = genome[gi]
+            base = torch.where(m, comp[base.long()], base)
+            # conversion decided per (pair, fragment position) so that overlapping mates agree
+            h = ((torch.arange(a, b, device=dev)[:, None] * 2654435761 + f * 40503 + seed) % 1000003).to(torch.float32) / 1000003.0
+            return torch.where((base == ord("C")) & (h < conv), T, base)
+        r1 = frag(j + 0 * il)
+        r2 = comp[frag(il - 1 - j).long()]
+        for r, dst in ((r1, s1), (r2, s2)):
+            sm = torch.rand((b - a, L), generator=g, device=dev) < sub
+            rb = acgt[torch.randint(0, 4, (b - a, L), generator=g, device=dev)]
+            dst[a:b, :L] = torch.where(sm, rb, r)
+    q = torch.full((n, stride), ord("I"), dtype=torch.uint8, device=dev)
+    return s1, q, s2, q.clone()

@@ -185,10 +185,13 @@ class Mapper:
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
 
     def counters(self) -> dict:
-        c = np.zeros(8, dtype=np.uint64)
-        self._chk(self._lib.bmbs_counters_last(self._ctx, capi.ptr(c)))
+        c = np.zeros(32, dtype=np.uint64)
+        self._chk(self._lib.bmbs_counters_all(self._ctx, capi.ptr(c)))
         keys = ("n_hash", "n_ext", "n_sa", "n_filter", "n_sw", "n_ungapped", "n_cand_slots", "n_jobs")
-        return {k: int(v) for k, v in zip(keys, c)}
+        d = {k: int(v) for k, v in zip(keys, c[:8])}
+        for kid, nm in enumerate(("k_seed_first", "k_seed_second", "k_seed_extra")):
+            d[nm] = {"n_hash": int(c[16 + 4 * kid]), "n_ext": int(c[17 + 4 * kid]), "n_sa": int(c[18 + 4 * kid])}
+        return d
 
 
 # ---- SAM text (host emit) --------------------------------------------------------------------------
