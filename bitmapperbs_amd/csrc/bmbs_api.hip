@@ -266,10 +266,12 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, (long)n, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_decide");
-    // (an LDS-staged variant of this kernel, k_seed_decide<true>, measured 20 % slower on MI355X: the per-lane row
-    // scans are not what bounds it)
-    hipLaunchKernelGGL(k_seed_decide<false>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
-                       c->prm.seed_len, pe_mode, st, sc, cnt);
+    if (getenv("BMBS_DECIDE_LDS"))
+        hipLaunchKernelGGL(k_seed_decide<true>, dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, L, stride,
+                           (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
+    else
+        hipLaunchKernelGGL(k_seed_decide<false>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+                           c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_second");
     int rc = scan_u32(c, sc.flag_c, n, sc.off_c, 3);

@@ -435,7 +435,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
 
 // ---- exits after the first seed (Schema.cpp:24599-24727 / 18225-18330) ---------------------------
 template <bool USE_LDS>
-__global__ void __launch_bounds__(256)
+__global__ void
 k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, int pe_mode, ReadState st,
               SeedCarry sc, unsigned long long* __restrict__ counters)
 {
@@ -1027,11 +1027,14 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     u64* tz = trace + t;                    // word (i*NWk + q) lives at tz[(i*NWk + q) * trace_stride]
     const int NWk = (band + 15) / 16;
     int h1_last = MINUS_INF;
+    ReadCur rcur; rcur.seek(rd, 0, L);
+    ReadCur qcur; if (!rev) qcur.seek(ql, 0, L);
     for (int i = 0; i < tlen; ++i) {
         int f = MINUS_INF, h1 = MINUS_INF;
-        const char a = rd[i];
+        const char a = rcur.next();
         const int ta = code4(a);
-        const int mis = ta == 4 ? -sp.np : -pen_lut[(unsigned char)ql[rev ? L - 1 - i : i]];
+        const unsigned char qc = rev ? (unsigned char)ql[L - 1 - i] : (unsigned char)qcur.next();
+        const int mis = ta == 4 ? -sp.np : -pen_lut[qc];
         u64 tw[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) tw[q] = 0;
