@@ -581,7 +581,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     char* seq_all = c->pe_seq.as<char>();
     char* qual_all = c->pe_qual.as<char>();
     prof_begin(c, "k_pe_prepare");
-    hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * stride, 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
+    hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * (stride / 16), 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
                        reinterpret_cast<const char*>(d_qual1), reinterpret_cast<const char*>(d_seq2),
                        reinterpret_cast<const char*>(d_qual2), L, stride, (long)n, seq_all, qual_all);
     prof_end(c);
@@ -602,7 +602,8 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->last_total_cand = tot;
     const u64 t1 = tot ? tot : 1;
-    ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(PeCand)); ENS(c, c->pe_B, t1 * sizeof(PeCand));
+    ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(PeCand)); ENS(c, c->pe_B, t1 * sizeof(PeCand)); ENS(c, c->slot_read, t1 * 4);
+    ENS(c, c->dense_read, t1 * 4); ENS(c, c->ferr, t1 * 4);
     PeCand* A = c->votes.as<PeCand>();
     PeCand* B = c->pe_B.as<PeCand>();
     if (tot) {
@@ -613,7 +614,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     const long long maxd = (long long)c->prm.max_ins + 2LL * k;
     const long long mind = (long long)c->prm.min_ins - 2LL * k - L;
     prof_begin(c, "k_vote_pe");
-    hipLaunchKernelGGL(k_vote_pe, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n2, L, k, st, ps, c->cand.as<u64>(), A);
+    hipLaunchKernelGGL(k_vote_pe, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n2, L, k, st, ps, c->cand.as<u64>(), A, c->slot_read.as<u32>());
     prof_end(c);
     prof_begin(c, "k_pe_filter_pairs");
     hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
@@ -621,8 +622,15 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     for (int round = 1; round <= 2; round++) {
         if (tot) {
             prof_begin(c, round == 1 ? "k_filter_pe_r1" : "k_filter_pe_r2");
-            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, k, (long)n,
-                               (long)n2, round, st, ps, A, B, tot, cnt);
+            u32* wcnt = c->sd_flag_c.as<u32>();
+            u64* woff = c->sd_off_c.as<u64>();
+            hipLaunchKernelGGL(k_pe_count, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n, (long)n2, round, ps, wcnt);
+            rc = scan_u32(c, wcnt, n2, woff, 6);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_pe_worklist, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, wcnt, woff, c->dense_read.as<u32>(),
+                               c->ferr.as<u32>());
+            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, k, st, ps, A, B,
+                               c->totals.as<u64>() + 6, c->dense_read.as<u32>(), c->ferr.as<u32>(), cnt);
             prof_end(c);
         }
         prof_begin(c, round == 1 ? "k_pe_compact_r1" : "k_pe_compact_r2");

@@ -1258,30 +1258,42 @@ __global__ void __launch_bounds__(256)
 k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const char* __restrict__ s2raw,
              const char* __restrict__ q2, int L, int stride, long n, char* __restrict__ seq_all, char* __restrict__ qual_all)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // one 16-byte piece per thread (rows are 16-byte aligned, stride % 16 == 0)
+    const long i16 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total16 = n * (stride / 16);
+    if (i16 >= total16) return;
     const long total = n * stride;
-    if (i >= total) return;
+    const long i = i16 * 16;
     const long r = i / stride;
-    const int j = (int)(i - r * stride);
-    seq_all[i] = s1[i];
-    qual_all[i] = q1[i];
-    char c = 0;
-    if (j < L) {
-        const char a = s2raw[r * stride + (L - 1 - j)];
-        c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a;
+    const int j0 = (int)(i - r * stride);
+    reinterpret_cast<uint4*>(seq_all)[i16] = reinterpret_cast<const uint4*>(s1)[i16];
+    reinterpret_cast<uint4*>(qual_all)[i16] = reinterpret_cast<const uint4*>(q1)[i16];
+    reinterpret_cast<uint4*>(qual_all + total)[i16] = reinterpret_cast<const uint4*>(q2)[i16];
+    unsigned char o[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int j = j0 + t;
+        char c = 0;
+        if (j < L) { const char a = s2raw[r * stride + (L - 1 - j)]; c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a; }
+        o[t] = (unsigned char)c;
     }
-    seq_all[total + i] = c;
-    qual_all[total + i] = q2[i];
+    uint4 v;
+    v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
+    v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
+    v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
+    v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
+    reinterpret_cast<uint4*>(seq_all + total)[i16] = v;
 }
 
 // get_candidates' list construction (Schema.cpp:18510-18545): site-sorted votes (NOT re-sorted by vote)
 __global__ void __launch_bounds__(64)
-k_vote_pe(long n2, int L, int k, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A)
+k_vote_pe(long n2, int L, int k, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A, u32* __restrict__ slot_read)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n2) return;
     const int v = st.verdict[r];
     const u64 off = st.cand_off[r];
+    for (u64 g = off; g < st.cand_off[r + 1]; g++) slot_read[g] = (u32)r;
     ps.cur[r] = 0; ps.vround[r] = 0;
     if (v == 1 || v == 2) {
         A[off].site = st.exit_site[r]; A[off].err = v == 1 ? 0u : 1u; A[off].end = L - 1;
@@ -1357,22 +1369,34 @@ k_pe_filter_pairs(long n, long long maxd, long long mind, ReadState st, PeState 
     }
 }
 
-// verify_candidate_locations' Myers pass for the mates scheduled in `round`
+// verify_candidate_locations' Myers pass for the mates scheduled in `round`: a dense work list
+// (read, list index) is built by count -> scan -> scatter so that the filter runs on full waves
 __global__ void __launch_bounds__(256)
-k_filter_pe(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, long n, long n2, int round, ReadState st,
-            PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B, u64 n_slots, unsigned long long* __restrict__ counters)
+k_pe_count(long n, long n2, int round, PeState ps, u32* __restrict__ cnt)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n2) return;
+    const long p = r < n ? r : r - n;
+    cnt[r] = (ps.vround[r] == round && !ps.dead[p]) ? ps.len[r] : 0u;
+}
+__global__ void __launch_bounds__(256)
+k_pe_worklist(long n2, const u32* __restrict__ cnt, const u64* __restrict__ off, u32* __restrict__ work_r, u32* __restrict__ work_i)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n2) return;
+    const u32 m = cnt[r];
+    const u64 o = off[r];
+    for (u32 i = 0; i < m; i++) { work_r[o + i] = (u32)r; work_i[o + i] = i; }
+}
+__global__ void __launch_bounds__(256)
+k_filter_pe(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, ReadState st, PeState ps,
+            PeCand* __restrict__ A, PeCand* __restrict__ B, const u64* __restrict__ n_work, const u32* __restrict__ work_r,
+            const u32* __restrict__ work_i, unsigned long long* __restrict__ counters)
 {
     const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_slots) return;
-    long lo = 0, hi = n2;
-    while (hi - lo > 1) { const long mid = (lo + hi) >> 1; if (st.cand_off[mid] <= g) lo = mid; else hi = mid; }
-    const long r = lo;
-    if (ps.vround[r] != round) return;
-    const long p = r < n ? r : r - n;
-    if (ps.dead[p]) return;
-    const u64 rel = g - st.cand_off[r];
-    if (rel >= ps.len[r]) return;
-    PeCand* e = pe_list(ps, st, A, B, r) + rel;
+    if (g >= *n_work) return;
+    const long r = (long)work_r[g];
+    PeCand* e = pe_list(ps, st, A, B, r) + work_i[g];
     u32 er; int es;
     bpm_one(ix, seq + (size_t)r * stride, L, k, e->site, er, es);
     e->err = er; e->end = es;
