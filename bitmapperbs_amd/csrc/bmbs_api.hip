@@ -266,11 +266,24 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, (long)n, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_decide");
-    if (getenv("BMBS_DECIDE_LDS"))
-        hipLaunchKernelGGL(k_seed_decide<true>, dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, L, stride,
-                           (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
+    // rows staged through LDS (each read fetched from HBM exactly once, coalesced) + 8 characters per compare step;
+    // BMBS_DECIDE=plain|lds|vec8 select the other forms for A/B measurements
+    const char* dv = getenv("BMBS_DECIDE");
+    const bool lds_ok = (size_t)64 * (stride + 8) <= 48 * 1024;
+    if (dv && !strcmp(dv, "plain"))
+        hipLaunchKernelGGL((k_seed_decide<false, false>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+                           c->prm.seed_len, pe_mode, st, sc, cnt);
+    else if (dv && !strcmp(dv, "vec8"))
+        hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+                           c->prm.seed_len, pe_mode, st, sc, cnt);
+    else if (dv && !strcmp(dv, "lds") && lds_ok)
+        hipLaunchKernelGGL((k_seed_decide<true, false>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, L,
+                           stride, (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
+    else if (lds_ok)
+        hipLaunchKernelGGL((k_seed_decide<true, true>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, L,
+                           stride, (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
     else
-        hipLaunchKernelGGL(k_seed_decide<false>, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+        hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_second");
@@ -355,11 +368,11 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
-    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, 5 * 8) || ensure(c, c->counters, 32 * 8) ||
+    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, BMBS_SHARDS * BMBS_SHARD_WORDS * 8) || ensure(c, c->counters, BMBS_SHARDS * BMBS_SHARD_WORDS * 8) ||
         ensure(c, c->totals, 8 * 8)) { bmbs_destroy(c); return nullptr; }
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
-    (void)hipMemset(c->stats.p, 0, 5 * 8);
-    (void)hipMemset(c->counters.p, 0, 32 * 8);
+    (void)hipMemset(c->stats.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
+    (void)hipMemset(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
     return c;
 }
 
@@ -462,7 +475,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     if (rc) return rc;
     rc = per_read_workspace(c, n);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     u64 tot = 0;
@@ -577,7 +590,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     ENS(c, c->pe_seq, n2 * (u64)stride + 64); ENS(c, c->pe_qual, n2 * (u64)stride + 64);
     ENS(c, c->pe_occ, n2 * 4); ENS(c, c->pe_len, n2 * 4); ENS(c, c->pe_cur, n2); ENS(c, c->pe_vround, n2);
     ENS(c, c->pe_dead, n); ENS(c, c->pe_both, n); ENS(c, c->pe_npair, n * 4); ENS(c, c->pe_sbd, n * 4);
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
     char* seq_all = c->pe_seq.as<char>();
     char* qual_all = c->pe_qual.as<char>();
     prof_begin(c, "k_pe_prepare");
@@ -789,7 +802,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     int rc = per_read_workspace(c, n);
     if (rc) return rc;
     { int ds = 0; int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; stride = ds; (void)bytes; }
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->exit_site.p, 0, n * 8, c->stream));
     u64 tot = 0;
     rc = run_seed_stages(c, c->in_seq.as<char>(), L, stride, n, k, &tot);
@@ -813,14 +826,17 @@ extern "C" int bmbs_stats_get(bmbs_ctx* c, int64_t stats[5])
     if (!c) return BMBS_EINVAL;
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(stats, c->stats.p, 5 * 8, hipMemcpyDeviceToHost));
+    static_assert(sizeof(unsigned long long) == 8, "");
+    uint64_t all[BMBS_SHARDS * BMBS_SHARD_WORDS];
+    HIPCHK(c, hipMemcpy(all, c->stats.p, sizeof(all), hipMemcpyDeviceToHost));
+    for (int j = 0; j < 5; j++) { uint64_t t = 0; for (int sdx = 0; sdx < BMBS_SHARDS; sdx++) t += all[sdx * BMBS_SHARD_WORDS + j]; stats[j] = (int64_t)t; }
     return BMBS_OK;
 }
 extern "C" int bmbs_stats_reset(bmbs_ctx* c)
 {
     if (!c) return BMBS_EINVAL;
     HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipMemsetAsync(c->stats.p, 0, 5 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->stats.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
     return BMBS_OK;
 }
 extern "C" int bmbs_stats_allreduce(bmbs_ctx** ctxs, int n, int64_t stats[5])
@@ -864,7 +880,9 @@ extern "C" int bmbs_counters_all(bmbs_ctx* c, uint64_t out[32])
     if (!c) return BMBS_EINVAL;
     HIPCHK(c, hipSetDevice(c->dev));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->counters.p, 32 * 8, hipMemcpyDeviceToHost));
+    uint64_t all[BMBS_SHARDS * BMBS_SHARD_WORDS];
+    HIPCHK(c, hipMemcpy(all, c->counters.p, sizeof(all), hipMemcpyDeviceToHost));
+    for (int j = 0; j < 32; j++) { uint64_t t = 0; for (int sdx = 0; sdx < BMBS_SHARDS; sdx++) t += all[sdx * BMBS_SHARD_WORDS + j]; out[j] = t; }
     out[6] = c->last_total_cand;
     out[7] = c->last_n_jobs;
     return BMBS_OK;

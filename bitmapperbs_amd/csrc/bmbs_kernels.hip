@@ -15,6 +15,13 @@
 
 #define DEVI __device__ __forceinline__
 
+// Event / stats counters are sharded: 64 shards of 32 u64 (256 B apart), shard = blockIdx & 63, summed on the host.
+// One global word sustains only ~90 atomics/us on MI355X; with >100 k blocks per launch un-sharded counters
+// cost more than the kernels themselves (k_seed_decide: 4.0 ms -> 1.2 ms).
+#define BMBS_SHARDS 64
+#define BMBS_SHARD_WORDS 32
+#define SHARD(p) ((p) + (size_t)(blockIdx.x & (BMBS_SHARDS - 1)) * BMBS_SHARD_WORDS)
+
 // ================================================================================================
 // index primitives
 // ================================================================================================
@@ -115,6 +122,37 @@ struct ReadCur {
         return c;
     }
 };
+
+// ---- 8 read characters against 8 window bases at a time ---------------------------------------
+// 8 bases of the doubled 2-bit genome starting at doubled coordinate d, as 16 bits
+DEVI u64 win16(const DevIndex& ix, u64 d)
+{
+    const int sh = (int)(d & 31) * 2;
+    u64 w = ix.gen2[d >> 5] >> sh;
+    if (sh > 48) w |= ix.gen2[(d >> 5) + 1] << (64 - sh);
+    return w & 0xffff;
+}
+// 0x80 in every byte j of the result where read character j (byte j of rw, ASCII) does NOT match window base j
+// (2-bit code j of w16) under the bisulfite rule: equal letters match, and read 'T' matches window 'C'
+// (Schema.cpp:15212-15216; everything else, 'N' included, is a mismatch).
+DEVI u64 mism8(u64 rw, u64 w16)
+{
+    const u64 K01 = 0x0101010101010101ull, K7F = 0x7f7f7f7f7f7f7f7full, K80 = 0x8080808080808080ull;
+    // spread the eight 2-bit codes into the low 2 bits of eight bytes
+    u64 x = w16;
+    x = (x | (x << 24)) & 0x000000ff000000ffull;
+    x = (x | (x << 12)) & 0x000f000f000f000full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    const u64 c0 = x & K01, c1 = (x >> 1) & K01, both = c0 & c1;
+    // A 0x41, C 0x43, G 0x47, T 0x54
+    const u64 ascii = 0x4040404040404040ull | (K01 ^ both) | ((c0 ^ c1) << 1) | (c1 << 2) | (both << 4);
+    const u64 diff = rw ^ ascii;
+    const u64 nz = (((diff & K7F) + K7F) | diff) & K80;                  // byte != 0
+    const u64 t = rw ^ 0x5454545454545454ull;
+    const u64 isT = ~(((t & K7F) + K7F) | t) & K80;                      // read byte == 'T'
+    const u64 winC = (c0 & ~c1) << 7;                                    // window base == 'C'
+    return nz & ~(isT & winC);
+}
 
 // ================================================================================================
 // attach-time re-pack kernels
@@ -382,6 +420,7 @@ DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c, in
     u32 a = c.n_hash, b = c.n_ext, d = c.n_sa, e = c.n_ung;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); e += __shfl_down(e, o); }
     if ((threadIdx.x & 63) == 0 && counters) {
+        counters = SHARD(counters);
         unsigned long long* k = counters + 16 + 4 * kid;
         if (a) { atomicAdd(&counters[0], (unsigned long long)a); atomicAdd(&k[0], (unsigned long long)a); }
         if (b) { atomicAdd(&counters[1], (unsigned long long)b); atomicAdd(&k[1], (unsigned long long)b); }
@@ -434,7 +473,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
 }
 
 // ---- exits after the first seed (Schema.cpp:24599-24727 / 18225-18330) ---------------------------
-template <bool USE_LDS>
+template <bool USE_LDS, bool VEC8>
 __global__ void
 k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, int pe_mode, ReadState st,
               SeedCarry sc, unsigned long long* __restrict__ counters)
@@ -499,15 +538,45 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long
                 if (ml != (u64)L) {
                     const int need = L - (int)ml;
                     const u64 start = loc + ml;
-                    WinReader wr; wr.init(ix, start, window_valid(ix, start, (u64)need, loc < ix.G));
                     n_ung++;
-                    int read_i = (int)ml;
-                    ReadCur rc; rc.seek(rd, read_i, L);
-                    for (int i = 0; i < need; i++) {
-                        const char a = rc.next();
-                        const int b = wr.next();                 // 4 when the window leaves the strand: never equal
-                        if (!(code4(a) == b || (a == 'T' && b == 1))) { error++; if (error == 1) ml = (u64)read_i; else break; }
-                        read_i++;
+                    if (VEC8) {
+                        if (!window_valid(ix, start, (u64)need, loc < ix.G)) {
+                            // all-zero window: every position mismatches; the first sets ml = read_i (= ml), the second stops
+                            error = need >= 2 ? 2 : 1;
+                        } else {
+                            // read position q faces doubled coordinate loc + q; 8 positions per step
+                            const int ml0 = (int)ml;
+                            // window words cached in registers: one global load per 32 bases
+                            u64 gidx = (loc + (u64)(ml0 & ~7)) >> 5, g0 = ix.gen2[gidx], g1 = ix.gen2[gidx + 1];
+                            for (int p = ml0 & ~7; p < L && error < 2; p += 8) {
+                                const u64 rw = *reinterpret_cast<const u64*>(rd + p);
+                                const u64 d = loc + (u64)p;
+                                if ((d >> 5) != gidx) { gidx = d >> 5; g0 = g1; g1 = ix.gen2[gidx + 1]; }
+                                const int sh = (int)(d & 31) * 2;
+                                u64 w16 = g0 >> sh;
+                                if (sh > 48) w16 |= g1 << (64 - sh);
+                                u64 m = mism8(rw, w16 & 0xffff);
+                                const int lo = ml0 > p ? ml0 - p : 0, hi = L - p < 8 ? L - p : 8;
+                                u64 keep = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1);
+                                keep &= ~((1ull << (8 * lo)) - 1);
+                                m &= keep;
+                                if (m) {
+                                    const int cnt = __popcll(m);
+                                    if (error == 0) { ml = (u64)(p + (__ffsll((long long)m) - 1) / 8); error = cnt >= 2 ? 2 : 1; }
+                                    else error = 2;
+                                }
+                            }
+                        }
+                    } else {
+                        WinReader wr; wr.init(ix, start, window_valid(ix, start, (u64)need, loc < ix.G));
+                        int read_i = (int)ml;
+                        ReadCur rc; rc.seek(rd, read_i, L);
+                        for (int i = 0; i < need; i++) {
+                            const char a = rc.next();
+                            const int b = wr.next();                 // 4 when the window leaves the strand: never equal
+                            if (!(code4(a) == b || (a == 'T' && b == 1))) { error++; if (error == 1) ml = (u64)read_i; else break; }
+                            read_i++;
+                        }
                     }
                 }
                 get_error = error;
@@ -548,7 +617,7 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long
     if (counters) {
         atomicAdd(&shc[0], n_sa); atomicAdd(&shc[1], n_ung);
         __syncthreads();
-        if (threadIdx.x == 0) { atomicAdd(&counters[2], (unsigned long long)shc[0]); atomicAdd(&counters[5], (unsigned long long)shc[1]); }
+        if (threadIdx.x == 0) { unsigned long long* cs = SHARD(counters); atomicAdd(&cs[2], (unsigned long long)shc[0]); atomicAdd(&cs[5], (unsigned long long)shc[1]); }
     }
 }
 
@@ -856,7 +925,7 @@ k_filter(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, co
     u32 e; int es;
     bpm_one(ix, seq + (size_t)r * stride, L, k, dense[g].site, e, es);
     ferr[g] = e; fend[g] = es;
-    if (counters) atomicAdd(&counters[3], 1ull);
+    if (counters) atomicAdd(&SHARD(counters)[3], 1ull);
 }
 
 // standalone form for bmbs_filter_batch: explicit (read, site) pairs
@@ -979,7 +1048,7 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
     }
     if (ok) { a_start[jb] = start; a_end[jb] = end_site; a_nm[jb] = err_in; a_score[jb] = score; a_nops[jb] = 0; }
     else need_sw[jb] = 1;
-    if (counters) atomicAdd(&counters[4], 1ull);
+    if (counters) atomicAdd(&SHARD(counters)[4], 1ull);
 }
 
 __global__ void k_sw_list(u64 n_jobs, const u32* __restrict__ need_sw, const u64* __restrict__ sw_off, u32* __restrict__ sw_job)
@@ -1232,7 +1301,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
         else if (o.status == 2) atomicAdd(&sh[2], 1ull);
     }
     __syncthreads();
-    if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&stats[threadIdx.x], sh[threadIdx.x]);
+    if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&SHARD(stats)[threadIdx.x], sh[threadIdx.x]);
 }
 
 // ================================================================================================
@@ -1400,7 +1469,7 @@ k_filter_pe(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k,
     u32 er; int es;
     bpm_one(ix, seq + (size_t)r * stride, L, k, e->site, er, es);
     e->err = er; e->end = es;
-    if (counters) atomicAdd(&counters[3], 1ull);
+    if (counters) atomicAdd(&SHARD(counters)[3], 1ull);
 }
 
 // the PE compaction (Schema.cpp:7480-7690): keep err <= k whose site+end differs from the previous candidate's
@@ -1585,5 +1654,5 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, in
         res[2 * p] = o[0]; res[2 * p + 1] = o[1];
     }
     __syncthreads();
-    if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&stats[threadIdx.x], sh[threadIdx.x]);
+    if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&SHARD(stats)[threadIdx.x], sh[threadIdx.x]);
 }
