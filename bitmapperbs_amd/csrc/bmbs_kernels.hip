@@ -154,6 +154,29 @@ DEVI u64 mism8(u64 rw, u64 w16)
     return nz & ~(isT & winC);
 }
 
+// 0x80 in byte j where read character j does NOT equal window base j in the 3-letter (C->T) alphabet the FM index
+// is built over: A=A, G=G, {C,T}={C,T}; any other read character never matches (ctoi > 2, bwt.h:1894).
+DEVI u64 mism8_3letter(u64 rw, u64 w16)
+{
+    const u64 K01 = 0x0101010101010101ull, K7F = 0x7f7f7f7f7f7f7f7full, K80 = 0x8080808080808080ull;
+    u64 x = w16;
+    x = (x | (x << 24)) & 0x000000ff000000ffull;
+    x = (x | (x << 12)) & 0x000f000f000f000full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    const u64 c0 = x & K01, c1 = (x >> 1) & K01, both = c0 & c1;
+    // window letter with C folded into T: A 0x41, G 0x47, C/T 0x54
+    const u64 isCT = c0;                                   // codes 1 (C) and 3 (T) have bit 0 set
+    const u64 isG = c1 & ~c0;
+    const u64 wl = 0x4141414141414141ull ^ (isG * 0x06) ^ (isCT * 0x15);      // 0x41^0x47 = 0x06, 0x41^0x54 = 0x15
+    (void)both;
+    // read letter with C folded into T: bytes equal to 'C' (0x43) become 'T' (0x54): 0x43 ^ 0x54 = 0x17
+    const u64 t = rw ^ 0x4343434343434343ull;
+    const u64 isC = (~(((t & K7F) + K7F) | t) & K80) >> 7;               // 0x01 where read byte == 'C'
+    const u64 rl = rw ^ (isC * 0x17);
+    const u64 diff = rl ^ wl;
+    return (((diff & K7F) + K7F) | diff) & K80;
+}
+
 // ================================================================================================
 // attach-time re-pack kernels
 // ================================================================================================
@@ -644,6 +667,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
     const char* rd = seq;
     Search S; SeedHit h;
     const u64 max_hits = 1000;
+    bool verify = false;          // the interval shrank to one row: finish the count against the genome itself
     auto finish = [&]() {
         // the second seed is over: record it and decide (Schema.cpp:24748-24791)
         SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
@@ -654,9 +678,44 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
         const u64 c0 = st.exit_site[r];
         u64 c1 = 0;
         int extra = 1;
-        if (h.hits == 1) {
-            const u64 p = ix.sa[h.sp];
+        if (verify) {
+            // A single-row interval: every further backward extension only tests whether the text character in
+            // front of that ONE occurrence equals the next read character.  Instead of one dependent random
+            // Occ gather per character (count_hash_table, bwt.h:1889-1933) locate the row once and compare the
+            // rest of the read with the doubled genome in the index alphabet (C folded into T), 8 bases a step.
+            verify = false;
+            const u64 p = ix.sa[S.top];
             lc.n_sa++;
+            const int done_chars = 16 + S.s;                       // read[tm, tm+done_chars) is matched at text position p
+            const int tm = S.tm;
+            const u64 site = ix.total - p - (u64)done_chars;       // doubled coordinate of read[tm]
+            bool ok = true;
+            for (int q = (tm + done_chars) & ~7; q < L && ok; q += 8) {
+                const u64 rw = *reinterpret_cast<const u64*>(rd + q);
+                const u64 d = site + (u64)(q - tm);                 // doubled coordinate facing read[q] (u64 wrap = out of range)
+                u64 m;
+                if (d + 8 <= ix.total) m = mism8_3letter(rw, win16(ix, d));
+                else {                                               // runs off the end of the text: '$' never matches
+                    m = 0;
+                    for (int j = 0; j < 8; j++) {
+                        const u64 dj = d + (u64)j;
+                        const char a = (char)((rw >> (8 * j)) & 0xff);
+                        const bool eq = dj < ix.total && code3(a) <= 2 && code3(a) == code3("ACGT"[gbase(ix, dj)]);
+                        if (!eq) m |= 0x80ull << (8 * j);
+                    }
+                }
+                const int lo = tm + done_chars > q ? tm + done_chars - q : 0, hi = L - q < 8 ? L - q : 8;
+                u64 keep = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1);
+                keep &= ~((1ull << (8 * lo)) - 1);
+                if (m & keep) ok = false;
+            }
+            if (ok) { h.hits = 1; h.sp = (p - (u64)(S.steps - S.s)) | (1ull << 63); }     // located: text position of the full seed
+            else { h.hits = 0; h.sp = 0; }
+        }
+        if (h.hits == 1) {
+            u64 p;
+            if (h.sp >> 63) p = h.sp & ~(1ull << 63);
+            else { p = ix.sa[h.sp]; lc.n_sa++; }
             c1 = ix.total - p - second_len - first_ml;
             seed_record(my, ns, ncand, h.sp, 1, second_len, first_ml);
             clen += 1; extra = 0;
@@ -687,7 +746,10 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
                 if (have) { finish(); have = false; }
                 if (it < chunk_end) {
                     r = sc.list_c[it]; rd = seq + (size_t)r * stride; have = true;
-                    if (search_begin<true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) { active = true; pending = false; }
+                    if (search_begin<true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) {
+                        if (S.bot - S.top == 1) verify = true;          // already a single row: stays pending, verified next batch
+                        else { active = true; pending = false; }
+                    }
                 } else pending = false;
             }
             if (!__any(active) && !__any(pending)) break;
@@ -697,7 +759,10 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
         if ((threadIdx.x & 63) == 0) atomicAdd(&counters[10], 1ull);
         if (active) atomicAdd(&counters[11], 1ull);
 #endif
-        if (active && search_step<true>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
+        if (active) {
+            if (search_step<true>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
+            else if (S.bot - S.top == 1) { verify = true; active = false; pending = true; }
+        }
     }
     flush_counters(counters, lc, 1);
 }
@@ -792,7 +857,7 @@ k_locate(DevIndex ix, long n, ReadState st, u64* __restrict__ cand)
         const u64 sp = my[s].sp, adj = (u64)my[s].len + (u64)my[s].off;
         const u32 h = my[s].hits;
         for (u32 j = 0; j < h && o < o_end; j++)
-            cand[o++] = ix.total - (u64)ix.sa[sp + j] - adj;       // reverse_and_adjust_site, Schema.cpp:4669
+            cand[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;   // reverse_and_adjust_site, Schema.cpp:4669
     }
 }
 
