@@ -29,6 +29,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_fetch_write.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units as
+    rocprofv3 reports them).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (>=16 B/lane) coalesced
+    streams by 2x; the mapping kernels issue 4-16 B per-lane gathers, for which the guide gives no calibration,
+    so the raw (FETCH_SIZE + WRITE_SIZE) * 1024 is reported.  None when no profile has been committed."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.csv")
+    if not os.path.exists(path):
+        return None
+    for row in csv.DictReader(open(path)):
+        if row["kernel"].split("<")[0] == kernel:
+            return int((float(row["FETCH_SIZE_KB_last_launch"]) + float(row["WRITE_SIZE_KB_last_launch"])) * 1024)
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +239,7 @@ def main():
                        "reads_per_gpu_per_step": n, "read_len": L, "genome_bp": args.genome,
                        "parallelism": "reads sharded by rank, index replicated, RCCL all-reduce of 5 mapstats counters"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": int(bytes_dom), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4)},
             "kernels_ms_per_step": {a: round(b, 4) for a, b in kern_ms.items()},
             "kernels_algorithmic_GBps": rl_all,

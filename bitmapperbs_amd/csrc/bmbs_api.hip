@@ -286,17 +286,21 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
         hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
-    prof_begin(c, "k_seed_second");
+    prof_begin(c, "list_second");
     int rc = scan_u32(c, sc.flag_c, n, sc.off_c, 3);
     if (rc) return rc;
     hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_c, sc.off_c, sc.list_c);
+    prof_end(c);
+    prof_begin(c, "k_seed_second");
     hipLaunchKernelGGL(k_seed_second, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 3, pe_mode,
                        st, sc, cnt);
     prof_end(c);
-    prof_begin(c, "k_seed_extra");
+    prof_begin(c, "list_extra");
     rc = scan_u32(c, sc.flag_d, n, sc.off_d, 4);
     if (rc) return rc;
     hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_d, sc.off_d, sc.list_d);
+    prof_end(c);
+    prof_begin(c, "k_seed_extra");
     hipLaunchKernelGGL(k_seed_extra, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 4,
                        c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
