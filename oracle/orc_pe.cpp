@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -252,6 +253,194 @@ void finish_mate(const orc_index* ix, const orc_params* P, const char* read, con
     r->matched = (int)r->end_site - start_site + 1;
 }
 
+// ---- --sensitive: Map_Pair_Seq_end_to_end (Schema.cpp:19953-21459) -------------------------------
+// state of one mate after its first seed (Schema.cpp:20395-20600 / 20602-20862)
+struct mate_t {
+    const char* read; int L; u64 k;
+    std::string bs; int C_site;
+    int jump = 0, occ = 0, get_error = -1;
+    u64 total_match = 0, seed_id = 0, max_seed = 0, first_seed_match = 0;
+    std::vector<u64> cand;                 // candidates1 after the first seed
+    std::vector<cand_t> list;              // candidates_votes
+    std::vector<int> seed_start, seed_len; // read1_seed_start / read1_seed_length[0 .. full_seed_id)
+};
+
+void first_seed(const orc_index* ix, const orc_params* P, mate_t& m, orc_counters* C)
+{
+    const int L = m.L; const char* read = m.read;
+    m.bs.assign(L, 0); m.C_site = -1;
+    for (int i = 0; i < L; i++) { m.bs[i] = read[L - 1 - i]; if (m.bs[i] == 'C') { m.C_site = i; m.bs[i] = 'T'; } }
+    m.max_seed = (u64)L / 10 - 1; if (m.max_seed > 25) m.max_seed = 25;
+    const u64 max_candidates_occ = 10000, max_hits = 1000, avail_len = (u64)P->seed_len;
+    std::vector<char> win;
+    if (m.seed_id < m.max_seed && m.total_match < (u64)L) {
+        u64 cur_len = L - m.total_match;
+        seed_res s = count_terminate(ix, m.bs.data(), cur_len, C);
+        u64 match_length = s.match_len;
+        m.first_seed_match = match_length;
+        m.seed_start.push_back((int)m.total_match); m.seed_len.push_back((int)match_length);
+        if (s.hits == 1) {
+            u64 p = orc_sa_row(ix, s.sp);
+            u64 loc = ix->total - p - match_length;
+            m.cand.push_back(loc);
+            int first_C_site = L - m.C_site - 1, error = 0;
+            if (match_length > (u64)first_C_site) match_length = first_C_site;
+            if (match_length != (u64)L) {
+                int need = L - (int)match_length;
+                win.assign(need + 8, 0);
+                window_at(ix, loc + match_length, need, win.data());
+                int read_i = (int)match_length;
+                for (int i = 0; i < need; i++) {
+                    if (read[read_i] != win[i] && !(read[read_i] == 'T' && win[i] == 'C')) { error++; if (error == 1) match_length = read_i; else break; }
+                    read_i++;
+                }
+            }
+            m.get_error = error;
+            if (error == 0) { m.list.push_back({loc, 0u, (u64)(L - 1)}); m.occ = 1; m.jump = 1; m.cand.clear(); return; }
+        }
+        if (match_length == (u64)L && s.hits > 1 && s.hits <= max_candidates_occ && m.C_site == -1) {
+            std::vector<u64> loc;
+            locate_rows(ix, s.sp, s.ep, match_length, m.total_match, loc, C);
+            std::sort(loc.begin(), loc.end());
+            for (u64 x : loc) m.list.push_back({x, 0u, (u64)(L - 1)});
+            m.occ = (int)loc.size(); m.jump = 1; m.cand.clear();
+            return;
+        }
+        if (s.hits == 1) { /* cand[0] holds it */ }
+        else if (match_length >= avail_len && s.hits <= max_hits) { if (s.hits != 0) locate_rows(ix, s.sp, s.ep, match_length, m.total_match, m.cand, C); }
+        else { m.seed_start.pop_back(); m.seed_len.pop_back(); }           // full_seed_id--
+        if (match_length == 0) m.total_match = seed_offset_unmatch(L, (int)m.total_match, read, 8);
+        else m.total_match = m.total_match + match_length / 2;
+        m.seed_id++;
+    }
+}
+
+// votes of a sorted candidate array, optionally kept only when a verified hit of the mate lies within the insert
+// window (generate_candidate_votes_shift[_filter] + select_suit_candidates, Schema.cpp:4687, 4884, 4775)
+void votes_filtered(const std::vector<u64>& cand, u64 k, const std::vector<cand_t>* mate, int mate_occ, long long maxd, long long mind,
+                    std::vector<cand_t>& out)
+{
+    out.clear();
+    int next_start = 0;
+    auto suit = [&](u64 site) -> bool {
+        if (!mate) return true;
+        for (int i = next_start; i < mate_occ; i++) {
+            if ((*mate)[i].site > site) {
+                long long d = (long long)((*mate)[i].site - site);
+                if (d > maxd) return false;
+                if (d <= maxd && d >= mind) return true;
+            } else {
+                long long d = (long long)(site - (*mate)[i].site);
+                if (d > maxd) next_start = i + 1;
+                else if (d >= mind) return true;
+            }
+        }
+        return false;
+    };
+    size_t n = cand.size(), i = 1;
+    u64 pre = cand[0];
+    while (i < n) {
+        if (cand[i] == pre) i++;
+        else { u64 site = pre < k ? 0 : pre - k; if (suit(site)) out.push_back({site, 0u, 0}); pre = cand[i]; i++; }
+    }
+    u64 site = pre >= k ? pre - k : 0;
+    if (suit(site)) out.push_back({site, 0u, 0});
+}
+
+// process_rest_seed_debug / process_rest_seed_filter_debug (Schema.cpp:17574, 16298)
+int process_rest(const orc_index* ix, const orc_params* P, mate_t& m, const std::vector<cand_t>* mate, int mate_occ,
+                 long long maxd, long long mind, orc_counters* C)
+{
+    const int L = m.L; const char* read = m.read;
+    const u64 max_hits = 1000, avail_len = (u64)P->seed_len;
+    int extra = 1;
+    u64 total_match = m.total_match, seed_id = m.seed_id;      // by-value parameters of the reference
+    if (m.get_error == 1) {
+        u64 second_len = L - m.first_seed_match;
+        if (second_len >= 17) {
+            seed_res s = count_fixed(ix, m.bs.data(), second_len, C);
+            if (s.hits == 1) { locate_rows(ix, s.sp, s.ep, second_len, m.first_seed_match, m.cand, C); extra = 0; }
+            else if (s.hits <= max_hits) { if (s.hits != 0) locate_rows(ix, s.sp, s.ep, second_len, m.first_seed_match, m.cand, C); extra = 0; }
+        }
+    }
+    if (extra == 1) {
+        while (seed_id < m.max_seed && total_match < (u64)L) {
+            u64 cur_len = L - total_match;
+            seed_res s = count_terminate(ix, m.bs.data(), cur_len, C);
+            u64 ml = s.match_len;
+            m.seed_start.push_back((int)total_match); m.seed_len.push_back((int)ml);
+            if (s.hits == 1) locate_rows(ix, s.sp, s.ep, ml, total_match, m.cand, C);
+            else if (ml >= avail_len && s.hits <= max_hits) { if (s.hits != 0) locate_rows(ix, s.sp, s.ep, ml, total_match, m.cand, C); }
+            else { m.seed_start.pop_back(); m.seed_len.pop_back(); if (cur_len == ml) break; }
+            if (ml == 0) total_match = seed_offset_unmatch(L, (int)total_match, read, 8);
+            else total_match = total_match + ml / 2;
+            seed_id++;
+        }
+    }
+    if (extra == 0 && (m.cand.size() == 1 || (m.cand.size() == 2 && m.cand[0] == m.cand[1]))) {
+        m.list.clear(); m.list.push_back({m.cand[0], 1u, (u64)(L - 1)});
+        return 1;
+    }
+    if (!m.cand.empty()) {
+        std::sort(m.cand.begin(), m.cand.end());
+        votes_filtered(m.cand, m.k, mate, mate_occ, maxd, mind, m.list);
+        return verify(ix, read, L, m.k, m.list, m.list.size(), C);
+    }
+    return 0;
+}
+
+// reseed_filter + select_best_seeds (Schema.cpp:16678, 16630)
+int reseed(const orc_index* ix, const orc_params* P, mate_t& m, const std::vector<cand_t>& mate, int mate_occ, long long maxd,
+           long long mind, orc_counters* C)
+{
+    (void)P;
+    const int L = m.L; const char* read = m.read;
+    const u64 avail_len = 20, max_hits = 1000, match_step = 8;
+    const int full = (int)m.seed_start.size();
+    int rs[4], rl[4], rn = 0;
+    // select_best_seeds
+    if (full >= 2) {
+        rn = 2;
+        rs[0] = m.seed_start[0]; rl[0] = m.seed_start[1] - m.seed_start[0];
+        rs[1] = m.seed_start[full - 2] + m.seed_len[full - 2]; rl[1] = L - rs[1];
+    } else if (full == 1) {
+        rn = 2;
+        rs[0] = m.seed_start[0]; rl[0] = L / 2;
+        rs[1] = rs[0] + rl[0]; rl[1] = L - rs[1];
+    }
+    // With no recorded seed (full == 0) the reference indexes both malloc'ed int arrays at [-1] (Schema.cpp:16657;
+    // full_seed_id is unsigned).  That word is the upper half of glibc's chunk-size field, i.e. 0, so the reference
+    // deterministically adds the whole read (0, L) as one fixed seed -- which also consumes one seed_id.  Reproduced.
+    const int last_start = full >= 1 ? m.seed_start[full - 1] : 0, last_len = full >= 1 ? m.seed_len[full - 1] : 0;
+    if (last_start + last_len < L) { rs[rn] = last_start + last_len; rl[rn] = L - rs[rn]; rn++; }
+    std::vector<u64> cand;
+    u64 seed_id = 0, total_match = 0;
+    while ((int)seed_id < rn) {
+        total_match = (u64)rs[seed_id];
+        const u64 cur_len = (u64)L - total_match, ml = (u64)rl[seed_id];
+        seed_res s = count_fixed(ix, m.bs.data() + (cur_len - ml), ml, C);
+        if (s.hits == 1) locate_rows(ix, s.sp, s.ep, ml, total_match, cand, C);
+        else if (ml >= avail_len && s.hits <= max_hits) { if (s.hits != 0) locate_rows(ix, s.sp, s.ep, ml, total_match, cand, C); }
+        else if (cur_len == ml) break;
+        seed_id++;
+    }
+    total_match = full > 1 ? (u64)((m.seed_start[0] + m.seed_start[1]) / 2) : match_step / 2;
+    while (seed_id < m.max_seed && total_match < (u64)L) {
+        const u64 cur_len = (u64)L - total_match;
+        seed_res s = count_terminate(ix, m.bs.data(), cur_len, C);
+        const u64 ml = s.match_len;
+        if (s.hits == 1) locate_rows(ix, s.sp, s.ep, ml, total_match, cand, C);
+        else if (ml >= avail_len && s.hits <= max_hits) { if (s.hits != 0) locate_rows(ix, s.sp, s.ep, ml, total_match, cand, C); }
+        else if (cur_len == ml) break;
+        total_match += match_step;
+        seed_id++;
+    }
+    if (cand.empty()) return 0;
+    std::sort(cand.begin(), cand.end());
+    votes_filtered(cand, m.k, &mate, mate_occ, maxd, mind, m.list);
+    return verify(ix, read, L, m.k, m.list, m.list.size(), C);
+}
+
 static inline char rc_char(char c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }
 
 }  // namespace
@@ -271,9 +460,30 @@ static void map_one_pe(const orc_index* ix, const orc_params* P, const char* seq
     const long long inner_max = P->max_ins + (long long)large * 2;
     const long long inner_min = P->min_ins - (long long)large * 2 - max_length;
     std::vector<cand_t> l1, l2;
+    int occ1, occ2;
+    if (P->sensitive) {
+        mate_t m1, m2;
+        m1.read = seq1; m1.L = L1; m1.k = k1; m2.read = seq2; m2.L = L2; m2.k = k2;
+        first_seed(ix, P, m1, C);
+        first_seed(ix, P, m2, C);
+        occ1 = m1.occ; occ2 = m2.occ;
+        // the mate with fewer first-seed candidates is finished and verified first (Schema.cpp:20870-21030)
+        if (m1.cand.size() <= m2.cand.size()) {
+            if (!m1.jump) occ1 = process_rest(ix, P, m1, nullptr, 0, inner_max, inner_min, C);
+            if (occ1 == 0) return;
+            if (!m2.jump) occ2 = process_rest(ix, P, m2, &m1.list, occ1, inner_max, inner_min, C);
+        } else {
+            if (!m2.jump) occ2 = process_rest(ix, P, m2, nullptr, 0, inner_max, inner_min, C);
+            if (occ2 == 0) return;
+            if (!m1.jump) occ1 = process_rest(ix, P, m1, &m2.list, occ2, inner_max, inner_min, C);
+        }
+        if (occ2 == 0) occ2 = reseed(ix, P, m2, m1.list, occ1, inner_max, inner_min, C);
+        else if (occ1 == 0) occ1 = reseed(ix, P, m1, m2.list, occ2, inner_max, inner_min, C);
+        l1.swap(m1.list); l2.swap(m2.list);
+    } else {
     std::vector<u64> cand; std::vector<vote_t> votes;
-    int occ1 = get_candidates(ix, P, seq1, L1, k1, l1, cand, votes, C);
-    int occ2 = get_candidates(ix, P, seq2, L2, k2, l2, cand, votes, C);
+    occ1 = get_candidates(ix, P, seq1, L1, k1, l1, cand, votes, C);
+    occ2 = get_candidates(ix, P, seq2, L2, k2, l2, cand, votes, C);
     u64 n1 = l1.size(), n2 = l2.size();
     if (occ1 > 0 && occ2 > 0) { occ1 = (int)n1; occ2 = (int)n2; }
     else {
@@ -299,6 +509,7 @@ static void map_one_pe(const orc_index* ix, const orc_params* P, const char* seq
             if ((long long)n2 < occ2) occ2 = (int)n2;
             if (occ1 == -1) occ1 = verify(ix, seq1, L1, k1, l1, n1, C);
         }
+    }
     }
     long long b1 = 0, b2 = 0;
     unsigned sbd = 0;
@@ -335,7 +546,6 @@ extern "C" int orc_map_pe(const orc_index* ix, const orc_params* P, const char* 
                           const char* qual2, int L1, int L2, int stride, int64_t n, orc_pe_rec* recs, int64_t stats[5],
                           orc_counters* counters)
 {
-    if (P->sensitive) return -101;          // a18 re-seed: not restated yet
     int64_t st[5] = {0, 0, 0, 0, 0};
     if (counters) memset(counters, 0, sizeof(*counters));
     for (int64_t i = 0; i < n; i++)
@@ -349,7 +559,6 @@ extern "C" int orc_map_pe(const orc_index* ix, const orc_params* P, const char* 
 extern "C" int orc_search_pe(const orc_index* ix, const orc_params* P, const char* fq1, const char* fq2,
                              const char* out_sam, const char* argv_line, int64_t stats[5])
 {
-    if (P->sensitive) return -101;
     FILE* f1 = fopen(fq1, "rb"); FILE* f2 = fopen(fq2, "rb");
     if (!f1 || !f2) return -1;
     FILE* o = fopen(out_sam, "wb");
