@@ -35,6 +35,9 @@ PE_SETS = {
     "p150": dict(reads=dict(n=800, L=150, seed=11, sub=0.01, indel=0.001, qual="random"), args=[]),
     "p100": dict(reads=dict(n=800, L=100, seed=12, sub=0.02, indel=0.002, qual="random", ins_hi=560), args=["-e", "0.04", "--max", "520"]),
     "p75": dict(reads=dict(n=800, L=75, seed=13, sub=0.005, indel=0.0, qual="const", ins_lo=60, ins_hi=300), args=["--min", "100", "--max", "250"]),
+    # --sensitive (Map_Pair_Seq_end_to_end rescue + reseed_filter): high-error pairs so that the rescue paths run
+    "s100": dict(reads=dict(n=1200, L=100, seed=14, sub=0.06, indel=0.003, qual="random"), args=["--sensitive"]),
+    "s150": dict(reads=dict(n=800, L=150, seed=15, sub=0.07, indel=0.004, qual="random", ins_hi=450), args=["--sensitive", "-e", "0.1", "--max", "450"]),
 }
 
 def genome():
@@ -90,7 +93,7 @@ def main():
         open(os.path.join(HERE, "se_%s.ref.stats" % name), "w").write(stats)
         print(name, "lines", body.count("\n"), stats.splitlines()[1])
     json.dump({k: v["args"] for k, v in SETS.items()}, open(os.path.join(HERE, "se_args.json"), "w"))
-    # paired-end (default = fast mode)
+    # paired-end (default = fast mode; s* sets run --sensitive)
     for name, cfg in PE_SETS.items():
         m1, m2 = synth.make_reads_pe(chroms, **cfg["reads"])
         f1 = os.path.join(wd, "pe_%s_1.fq" % name); f2 = os.path.join(wd, "pe_%s_2.fq" % name)

@@ -117,6 +117,8 @@ def pe_params(args):
         kw["min_ins"] = int(args[args.index("--min") + 1])
     if "--max" in args:
         kw["max_ins"] = int(args[args.index("--max") + 1])
+    if "--sensitive" in args:
+        kw["sensitive"] = 1
     return kw
 
 
@@ -142,6 +144,9 @@ def test_oracle_reproduces_reference_golden_sam_paired_end(name, golden_index, t
     dict(n=15000, L=150, seed=21, sub=0.01, indel=0.001, qual="random", args=[]),
     dict(n=15000, L=100, seed=22, sub=0.02, indel=0.002, qual="random", ins_hi=560, args=["-e", "0.04", "--max", "520"]),
     dict(n=5000, L=250, seed=23, sub=0.03, indel=0.001, qual="random", ins_hi=700, args=["--max", "800"]),
+    dict(n=12000, L=100, seed=24, sub=0.06, indel=0.003, qual="random", args=["--sensitive"]),
+    dict(n=8000, L=150, seed=25, sub=0.07, indel=0.004, qual="random", ins_hi=450, args=["--sensitive", "-e", "0.1", "--max", "450"]),
+    dict(n=8000, L=100, seed=26, sub=0.02, indel=0.002, qual="random", ins_hi=560, args=["--sensitive", "-e", "0.04", "--max", "520"]),
 ])
 def test_oracle_vs_reference_binary_fresh_data_paired_end(cfg, tmp_path, oracle):
     from bitmapperbs_amd import synth
