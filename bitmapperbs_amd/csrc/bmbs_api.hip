@@ -46,6 +46,8 @@ struct bmbs_ctx {
     // paired-end workspace
     DevBuf sd_sp0, sd_hits0, sd_ml0, sd_tm, sd_seed_id, sd_clen, sd_first_ml, sd_flag_c, sd_flag_d, sd_off_c, sd_off_d, sd_list_c, sd_list_d;
     DevBuf pe_seq, pe_qual, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
+    DevBuf pe_first, pe_full, pe_R, pe_roff, pe_rflag, pe_rscan, pe_rlist, pe_rcnt, pe_ritem_off, pe_rcand;     // --sensitive
+    u64 last_reseeded = 0, last_reseed_cand = 0;
     DevBuf stats, counters;
     std::vector<Prof> prof;
     int n_prof_used = 0;
@@ -249,16 +251,22 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int str
 }
 
 // K1-K5: the four seeding kernels with their two work-list compactions (no host round-trip)
-int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int pe_mode)
+SeedCarry seed_carry(bmbs_ctx* c)
 {
-    ENS(c, c->sd_sp0, n * 8); ENS(c, c->sd_hits0, n * 4); ENS(c, c->sd_ml0, n * 2); ENS(c, c->sd_tm, n * 2); ENS(c, c->sd_seed_id, n);
-    ENS(c, c->sd_clen, n * 4); ENS(c, c->sd_first_ml, n * 2); ENS(c, c->sd_flag_c, n * 4); ENS(c, c->sd_flag_d, n * 4);
-    ENS(c, c->sd_off_c, (n + 1) * 8); ENS(c, c->sd_off_d, (n + 1) * 8); ENS(c, c->sd_list_c, n * 4); ENS(c, c->sd_list_d, n * 4);
     SeedCarry sc;
     sc.sp0 = c->sd_sp0.as<u64>(); sc.hits0 = c->sd_hits0.as<u32>(); sc.ml0 = c->sd_ml0.as<u16>(); sc.tm = c->sd_tm.as<u16>();
     sc.seed_id = c->sd_seed_id.as<u8>(); sc.clen = c->sd_clen.as<u32>(); sc.first_ml = c->sd_first_ml.as<u16>();
     sc.flag_c = c->sd_flag_c.as<u32>(); sc.flag_d = c->sd_flag_d.as<u32>(); sc.off_c = c->sd_off_c.as<u64>(); sc.off_d = c->sd_off_d.as<u64>();
     sc.list_c = c->sd_list_c.as<u32>(); sc.list_d = c->sd_list_d.as<u32>();
+    return sc;
+}
+
+int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int pe_mode)
+{
+    ENS(c, c->sd_sp0, n * 8); ENS(c, c->sd_hits0, n * 4); ENS(c, c->sd_ml0, n * 2); ENS(c, c->sd_tm, n * 2); ENS(c, c->sd_seed_id, n);
+    ENS(c, c->sd_clen, n * 4); ENS(c, c->sd_first_ml, n * 2); ENS(c, c->sd_flag_c, n * 4); ENS(c, c->sd_flag_d, n * 4);
+    ENS(c, c->sd_off_c, (n + 1) * 8); ENS(c, c->sd_off_d, (n + 1) * 8); ENS(c, c->sd_list_c, n * 4); ENS(c, c->sd_list_d, n * 4);
+    SeedCarry sc = seed_carry(c);
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     const unsigned chunks = nblk(n, SEED_CHUNK);
@@ -373,7 +381,7 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
     if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, BMBS_SHARDS * BMBS_SHARD_WORDS * 8) || ensure(c, c->counters, BMBS_SHARDS * BMBS_SHARD_WORDS * 8) ||
-        ensure(c, c->totals, 8 * 8)) { bmbs_destroy(c); return nullptr; }
+        ensure(c, c->totals, 16 * 8)) { bmbs_destroy(c); return nullptr; }
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
     (void)hipMemset(c->stats.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
     (void)hipMemset(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
@@ -392,7 +400,8 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
                      &c->stats, &c->counters, &c->pe_seq, &c->pe_qual, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
-                     &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2};
+                     &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
+                     &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -579,7 +588,6 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
-    if (c->prm.sensitive) { c->err = "--sensitive (re-seeding, Schema.cpp:16678) is not implemented on the device yet"; return BMBS_ESTATE; }
     if (L <= 0 || L > 1000 || stride < L || n_pairs < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     if ((stride & 15) || ((d_seq1 | d_qual1 | d_seq2 | d_qual2) & 15)) { c->err = "device read buffers must be 16-byte aligned with a stride that is a multiple of 16"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
@@ -606,6 +614,13 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     PeState ps;
     ps.occ = c->pe_occ.as<int>(); ps.len = c->pe_len.as<u32>(); ps.cur = c->pe_cur.as<u8>(); ps.vround = c->pe_vround.as<u8>();
     ps.dead = c->pe_dead.as<u8>(); ps.both = c->pe_both.as<u8>(); ps.npair = c->pe_npair.as<int>(); ps.sbd = c->pe_sbd.as<u32>();
+    const bool sensitive = c->prm.sensitive != 0;
+    if (sensitive) {
+        ENS(c, c->pe_first, n); ENS(c, c->pe_full, n2); ENS(c, c->pe_roff, n2 * 8); ENS(c, c->pe_rflag, n * 4); ENS(c, c->pe_rscan, (n + 1) * 8);
+        ENS(c, c->pe_rlist, n * 4); ENS(c, c->pe_rcnt, n * 4); ENS(c, c->pe_ritem_off, (n + 1) * 8);
+    }
+    ps.first = c->pe_first.as<u8>(); ps.full = c->pe_full.as<u8>(); ps.R = c->pe_R.as<PeCand>(); ps.roff = c->pe_roff.as<u64>();
+    c->last_reseeded = 0; c->last_reseed_cand = 0;
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     // seeding of all 2n reads; candidate slots by scan; locate
     rc = launch_seeding(c, seq_all, L, stride, n2, 1);
@@ -633,30 +648,79 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     prof_begin(c, "k_vote_pe");
     hipLaunchKernelGGL(k_vote_pe, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n2, L, k, st, ps, c->cand.as<u64>(), A, c->slot_read.as<u32>());
     prof_end(c);
-    prof_begin(c, "k_pe_filter_pairs");
-    hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
-    prof_end(c);
-    for (int round = 1; round <= 2; round++) {
-        if (tot) {
-            prof_begin(c, round == 1 ? "k_filter_pe_r1" : "k_filter_pe_r2");
+    // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
+    auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {
+        if (cap) {
+            prof_begin(c, name_f);
             u32* wcnt = c->sd_flag_c.as<u32>();
             u64* woff = c->sd_off_c.as<u64>();
             hipLaunchKernelGGL(k_pe_count, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n, (long)n2, round, ps, wcnt);
-            rc = scan_u32(c, wcnt, n2, woff, 6);
-            if (rc) return rc;
+            int r_ = scan_u32(c, wcnt, n2, woff, 6);
+            if (r_) return r_;
             hipLaunchKernelGGL(k_pe_worklist, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, wcnt, woff, c->dense_read.as<u32>(),
                                c->ferr.as<u32>());
-            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, k, st, ps, A, B,
+            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(cap, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, k, st, ps, A, B,
                                c->totals.as<u64>() + 6, c->dense_read.as<u32>(), c->ferr.as<u32>(), cnt);
             prof_end(c);
         }
-        prof_begin(c, round == 1 ? "k_pe_compact_r1" : "k_pe_compact_r2");
+        prof_begin(c, name_c);
         hipLaunchKernelGGL(k_pe_compact, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n, (long)n2, k, round, st, ps, A, B);
         prof_end(c);
-        if (round == 1) {
-            prof_begin(c, "k_pe_prune");
-            hipLaunchKernelGGL(k_pe_prune, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+        return BMBS_OK;
+    };
+    if (!sensitive) {
+        prof_begin(c, "k_pe_filter_pairs");
+        hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+        prof_end(c);
+        rc = verify_round(1, tot, "k_filter_pe_r1", "k_pe_compact_r1");
+        if (rc) return rc;
+        prof_begin(c, "k_pe_prune");
+        hipLaunchKernelGGL(k_pe_prune, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+        prof_end(c);
+        rc = verify_round(2, tot, "k_filter_pe_r2", "k_pe_compact_r2");
+        if (rc) return rc;
+    } else {
+        // Map_Pair_Seq_end_to_end: first mate verified in full, second mate filtered by it, rescue by re-seeding
+        prof_begin(c, "k_pes_order");
+        hipLaunchKernelGGL(k_pes_order, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, seed_carry(c), ps);
+        prof_end(c);
+        rc = verify_round(1, tot, "k_filter_pe_r1", "k_pe_compact_r1");
+        if (rc) return rc;
+        prof_begin(c, "k_pes_second");
+        hipLaunchKernelGGL(k_pes_second, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+        prof_end(c);
+        rc = verify_round(2, tot, "k_filter_pe_r2", "k_pe_compact_r2");
+        if (rc) return rc;
+        prof_begin(c, "k_pes_reseed");
+        u32* rflag = c->pe_rflag.as<u32>();
+        u32* rlist = c->pe_rlist.as<u32>();
+        u32* rcnt = c->pe_rcnt.as<u32>();
+        u64* n_reseed = c->totals.as<u64>() + 7;
+        hipLaunchKernelGGL(k_pes_reseed_flag, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, ps, rflag);
+        rc = scan_u32(c, rflag, n, c->pe_rscan.as<u64>(), 7);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, rflag, c->pe_rscan.as<u64>(), rlist);
+        HIPCHK(c, hipMemsetAsync(rcnt, 0, n * 4, c->stream));
+        hipLaunchKernelGGL(k_pes_reseed, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, L, stride, (long)n, n_reseed, rlist, st, ps,
+                           rcnt, cnt);
+        rc = scan_u32(c, rcnt, n, c->pe_ritem_off.as<u64>(), 8);
+        if (rc) return rc;
+        prof_end(c);
+        u64 rt[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(rt, c->totals.as<u64>() + 7, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->last_reseeded = rt[0]; c->last_reseed_cand = rt[1];
+        if (rt[0]) {
+            const u64 rtot = rt[1] ? rt[1] : 1;
+            ENS(c, c->pe_R, rtot * sizeof(PeCand)); ENS(c, c->pe_rcand, rtot * 8);
+            ENS(c, c->dense_read, rtot * 4); ENS(c, c->ferr, rtot * 4);
+            ps.R = c->pe_R.as<PeCand>();
+            prof_begin(c, "k_pes_vote");
+            hipLaunchKernelGGL(k_pes_vote, dim3(nblk(rt[0], 64)), dim3(64), 0, c->stream, c->ix, (long)n, k, maxd, mind, n_reseed, rlist,
+                               c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
             prof_end(c);
+            rc = verify_round(3, rt[1], "k_filter_pe_r3", "k_pe_compact_r3");
+            if (rc) return rc;
         }
     }
     prof_begin(c, "k_pe_pair");

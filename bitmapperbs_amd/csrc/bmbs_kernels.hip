@@ -1385,6 +1385,11 @@ struct PeState {
     u8*   both;       // per pair: both mates had to be verified
     int*  npair;      // per pair: mapping_pair
     u32*  sbd;        // per pair: second_best_diff
+    // --sensitive only
+    u8*   first;      // per pair: 0 = mate 1 is finished and verified first, 1 = mate 2
+    u8*   full;       // per read: full_seed_id (seeds recorded in read?_seed_start/length)
+    PeCand* R;        // lists of re-seeded mates (cur == 2), at roff[read]
+    u64*  roff;       // per read
 };
 
 // mate 2: reverse complement of the FASTQ read (rc_table, Process_Reads.cpp:1603-1613: identity for non-ACGT)
@@ -1451,7 +1456,11 @@ k_vote_pe(long n2, int L, int k, ReadState st, PeState ps, u64* __restrict__ can
     } else { ps.occ[r] = 0; ps.len[r] = 0; }
 }
 
-DEVI PeCand* pe_list(const PeState& ps, const ReadState& st, PeCand* A, PeCand* B, long r) { return (ps.cur[r] ? B : A) + st.cand_off[r]; }
+DEVI PeCand* pe_list(const PeState& ps, const ReadState& st, PeCand* A, PeCand* B, long r)
+{
+    const int cur = ps.cur[r];
+    return cur == 2 ? ps.R + ps.roff[r] : (cur ? B : A) + st.cand_off[r];
+}
 
 // filter_pairs (Schema.cpp:16052-16180) + the driver's choice of what to verify (19050-19290)
 __global__ void __launch_bounds__(64)
@@ -1588,6 +1597,197 @@ k_pe_prune(long n, long long maxd, long long mind, ReadState st, PeState ps, PeC
         }
     }
     ps.len[ro] = (u32)len2;
+}
+
+// ================================================================================================
+// Paired-end sensitive mode (Map_Pair_Seq_end_to_end, Schema.cpp:19953-21459)
+// ================================================================================================
+// Seeding of both mates is the same state machine as fast mode (first seed, 1-mismatch second seed, remaining
+// seeds; process_rest_seed[_filter]_debug, Schema.cpp:17574 / 16298), so k_seed_* + k_locate + k_vote_pe are
+// shared.  What differs is the order of verification -- the mate with fewer first-seed candidates is verified
+// completely (round 1), the other mate's votes are kept only where a verified hit of the first lies within the
+// insert window (select_suit_candidates, 4775) and verified (round 2) -- and the rescue: a mate left without a
+// hit is re-seeded (reseed_filter, 16678) with fixed segments chosen from its recorded seeds (select_best_seeds,
+// 16630) plus seeds sliding by 8, filtered by the verified mate and verified (round 3).
+
+// exists a verified hit of the mate with mind <= |distance| <= maxd; `next_start` is the reference's running
+// lower bound (sites arrive in ascending order)
+DEVI bool pes_suit(const PeCand* mate, int mate_occ, int& next_start, u64 site, long long maxd, long long mind)
+{
+    for (int i = next_start; i < mate_occ; i++) {
+        const u64 ms = mate[i].site;
+        if (ms > site) {
+            const long long d = (long long)(ms - site);
+            if (d > maxd) return false;
+            if (d >= mind) return true;
+        } else {
+            const long long d = (long long)(site - ms);
+            if (d > maxd) next_start = i + 1;
+            else if (d >= mind) return true;
+        }
+    }
+    return false;
+}
+
+// which mate goes first (Schema.cpp:20870): the one with fewer candidates after its FIRST seed
+__global__ void __launch_bounds__(256)
+k_pes_order(long n, ReadState st, SeedCarry sc, PeState ps)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    ps.dead[p] = 0; ps.both[p] = 0; ps.npair[p] = 0; ps.sbd[p] = 0;
+    u32 c[2];
+    for (int m = 0; m < 2; m++) {
+        const long r = p + m * n;
+        const int v = st.verdict[r], ns = st.n_seeds[r];
+        const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+        // first seed recorded <=> seeds[0].off == 0 (every later seed starts at an offset >= 1)
+        c[m] = (v == 1 || v == 4) ? 0u : (ns >= 1 && my[0].off == 0 ? my[0].hits : 0u);
+        // full_seed_id: the terminate seeds that produced candidates; the fixed second seed of a 1-mismatch read
+        // is not among them, and when it was usable no further seed was run (extra_seed_flag == 0)
+        ps.full[r] = (u8)((sc.flag_c[r] && !sc.flag_d[r]) ? 1 : ns);
+        ps.roff[r] = 0;
+    }
+    const int f = c[0] <= c[1] ? 0 : 1;
+    ps.first[p] = (u8)f;
+    const long rF = p + (long)f * n;
+    const int vF = st.verdict[rF];
+    if (vF == 0) ps.dead[p] = 1;                 // best_mapp_occ == 0 -> next pair
+    else if (vF == 3) ps.vround[rF] = 1;
+}
+
+// after round 1: filter the second mate's votes by the first mate's verified hits (generate_candidate_votes_shift_filter)
+__global__ void __launch_bounds__(64)
+k_pes_second(long n, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (ps.dead[p]) return;
+    const int f = ps.first[p];
+    const long rF = p + (long)f * n, rS = p + (long)(1 - f) * n;
+    const int occF = ps.occ[rF];
+    if (occF == 0) { ps.dead[p] = 1; return; }
+    if (st.verdict[rS] != 3) return;             // direct hits / 1-mismatch exit / nothing: no verification
+    const PeCand* a = pe_list(ps, st, A, B, rF);
+    PeCand* b = pe_list(ps, st, A, B, rS);
+    const long nb = ps.len[rS];
+    long kept = 0;
+    int next_start = 0;
+    for (long j = 0; j < nb; j++) {
+        const PeCand cj = b[j];
+        if (pes_suit(a, occF, next_start, cj.site, maxd, mind)) b[kept++] = cj;
+    }
+    ps.len[rS] = (u32)kept;
+    ps.vround[rS] = 2;
+}
+
+// pairs whose second mate has no hit are re-seeded
+__global__ void __launch_bounds__(256)
+k_pes_reseed_flag(long n, PeState ps, u32* __restrict__ flag)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const long rS = p + (long)(1 - ps.first[p]) * n;
+    flag[p] = (!ps.dead[p] && ps.occ[rS] == 0) ? 1u : 0u;
+}
+
+// reseed_filter's seeding (Schema.cpp:16678-16900) with select_best_seeds (16630): up to three fixed segments
+// (count_hash_table) and then count_backward_as_much_1_terminate seeds sliding by 8.  One re-seeded mate per lane.
+__global__ void __launch_bounds__(64)
+k_pes_reseed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, const u64* __restrict__ count_ptr,
+             const u32* __restrict__ plist, ReadState st, PeState ps, u32* __restrict__ rcnt, unsigned long long* __restrict__ counters)
+{
+    const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    LaneCounters lc = {0, 0, 0, 0};
+    if (it < (long)*count_ptr) {
+        const long p = plist[it];
+        const long r = p + (long)(1 - ps.first[p]) * n;
+        const char* rd = seq + (size_t)r * stride;
+        SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+        const int full = ps.full[r];
+        int rs[3], rl[3], rn = 0;
+        int s0 = 0, s1 = 0;
+        if (full >= 1) s0 = my[0].off;
+        if (full >= 2) {
+            s1 = my[1].off;
+            rn = 2;
+            rs[0] = s0; rl[0] = s1 - s0;
+            rs[1] = (int)my[full - 2].off + (int)my[full - 2].len; rl[1] = L - rs[1];
+        } else if (full == 1) {
+            rn = 2;
+            rs[0] = s0; rl[0] = L / 2;
+            rs[1] = rs[0] + rl[0]; rl[1] = L - rs[1];
+        }
+        // full == 0: the reference reads index -1 of two malloc'ed int arrays (Schema.cpp:16657), which is the zero
+        // upper half of the allocator's chunk-size word: the whole read becomes one fixed seed
+        const int last = full >= 1 ? (int)my[full - 1].off + (int)my[full - 1].len : 0;
+        if (last < L) { rs[rn] = last; rl[rn] = L - last; rn++; }
+        const int max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
+        const u64 max_hits = 1000, avail = 20;
+        int ns = 0, seed_id = 0;
+        u64 ncand = 0;
+        Search S; SeedHit h;
+        while (seed_id < rn) {
+            const int tm = rs[seed_id], ml = rl[seed_id];
+            if (search_begin<true>(ix, rd, tm + ml, tm, S, h, lc.n_hash))
+                while (!search_step<true>(ix, rd, tm + ml, S, h, lc.n_ext)) {}
+            if (h.hits == 1) seed_record(my, ns, ncand, h.sp, 1, (u64)ml, (u64)tm);
+            else if ((u64)ml >= avail && h.hits <= max_hits) { if (h.hits != 0) seed_record(my, ns, ncand, h.sp, h.hits, (u64)ml, (u64)tm); }
+            else if (L - tm == ml) break;
+            seed_id++;
+        }
+        int tm = full > 1 ? (s0 + s1) / 2 : 4;
+        while (seed_id < max_seed && tm < L) {
+            if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash))
+                while (!search_step<false>(ix, rd, L, S, h, lc.n_ext)) {}
+            if (h.hits == 1) seed_record(my, ns, ncand, h.sp, 1, h.ml, (u64)tm);
+            else if (h.ml >= avail && h.hits <= max_hits) { if (h.hits != 0) seed_record(my, ns, ncand, h.sp, h.hits, h.ml, (u64)tm); }
+            else if ((u64)(L - tm) == h.ml) break;
+            tm += 8;
+            seed_id++;
+        }
+        st.n_seeds[r] = (u8)ns;
+        rcnt[it] = (u32)ncand;
+    }
+    flush_counters(counters, lc, 2);
+}
+
+// locate + sort + filtered votes of one re-seeded mate; the list goes to the R buffer (cur = 2)
+__global__ void __launch_bounds__(64)
+k_pes_vote(DevIndex ix, long n, int k, long long maxd, long long mind, const u64* __restrict__ count_ptr, const u32* __restrict__ plist,
+           const u64* __restrict__ roff, ReadState st, PeState ps, u64* __restrict__ rcand, PeCand* __restrict__ A, PeCand* __restrict__ B)
+{
+    const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= (long)*count_ptr) return;
+    const long p = plist[it];
+    const int f = ps.first[p];
+    const long rF = p + (long)f * n, r = p + (long)(1 - f) * n;
+    const u64 o0 = roff[it], o1 = roff[it + 1];
+    ps.roff[r] = o0;
+    const long nc = (long)(o1 - o0);
+    if (nc == 0) { ps.len[r] = 0; ps.vround[r] = 0; return; }       // no candidate: best_mapp_occ stays 0
+    const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+    const int ns = st.n_seeds[r];
+    u64* c = rcand + o0;
+    long o = 0;
+    for (int s = 0; s < ns; s++) {
+        const u64 sp = my[s].sp, adj = (u64)my[s].len + (u64)my[s].off;
+        for (u32 j = 0; j < my[s].hits; j++) c[o++] = ix.total - (u64)ix.sa[sp + j] - adj;
+    }
+    sort_u64_asc(c, nc);
+    const PeCand* a = pe_list(ps, st, A, B, rF);
+    const int occF = ps.occ[rF];
+    PeCand* out = ps.R + o0;
+    long nv = 0;
+    int next_start = 0;
+    u64 pre = c[0];
+    for (long i = 1; i <= nc; i++) {
+        if (i < nc && c[i] == pre) continue;
+        const u64 site = (i < nc) ? (pre < (u64)k ? 0 : pre - (u64)k) : (pre >= (u64)k ? pre - (u64)k : 0);
+        if (pes_suit(a, occF, next_start, site, maxd, mind)) { out[nv].site = site; out[nv].err = 0; out[nv].end = 0; nv++; }
+        if (i < nc) pre = c[i];
+    }
+    ps.cur[r] = 2; ps.len[r] = (u32)nv; ps.vround[r] = 3;
 }
 
 // new_faster_verify_pairs (Schema.cpp:15773-15900) + hand-over of the winning candidates to K11-K13

@@ -269,10 +269,16 @@ PE_CASES = [
     dict(n=6000, L=250, seed=3, sub=0.03, indel=0.001, qual="random", ins_hi=700, prm=dict(max_ins=800)),
     dict(n=15000, L=75, seed=4, sub=0.005, indel=0.0, qual="const", ins_lo=60, ins_hi=300, prm=dict(min_ins=100, max_ins=250)),
     dict(n=10000, L=150, seed=5, sub=0.0, indel=0.0, qual="const", conv=0.0, prm={}),     # exact reads, no conversion: exit A/B heavy
+    # --sensitive (Map_Pair_Seq_end_to_end): ordered verification, mate-filtered votes, re-seeding rescue
+    dict(n=20000, L=100, seed=6, sub=0.06, indel=0.003, qual="random", prm=dict(sensitive=1)),
+    dict(n=12000, L=150, seed=7, sub=0.07, indel=0.004, qual="random", ins_hi=450, prm=dict(sensitive=1, e_f=0.1, max_ins=450)),
+    dict(n=20000, L=100, seed=8, sub=0.02, indel=0.002, qual="random", ins_hi=560, prm=dict(sensitive=1, e_f=0.04, max_ins=520)),
+    dict(n=10000, L=150, seed=9, sub=0.0, indel=0.0, qual="const", conv=0.0, prm=dict(sensitive=1)),
+    dict(n=8000, L=75, seed=10, sub=0.08, indel=0.0, qual="const", ins_lo=60, ins_hi=300, prm=dict(sensitive=1, min_ins=100, max_ins=250)),
 ]
 
 
-@pytest.mark.parametrize("case", PE_CASES, ids=lambda c: "L%d_s%d" % (c["L"], c["seed"]))
+@pytest.mark.parametrize("case", PE_CASES, ids=lambda c: "L%d_s%d%s" % (c["L"], c["seed"], "_sens" if c["prm"].get("sensitive") else ""))
 def test_map_pe_records_and_stats_match_oracle(case, env):
     from bitmapperbs_amd import synth, mapper
     c = dict(case); prm = c.pop("prm")
@@ -339,10 +345,10 @@ def test_cpp_driver_se_sam_file_equals_reference_golden(name, tmp_path):
     assert open(ms).read() == open(os.path.join(GOLD, "se_%s.ref.stats" % name)).read()
 
 
-def test_cpp_driver_pe_sam_file_equals_reference_golden(tmp_path):
+@pytest.mark.parametrize("name", ["p100", "s100"])
+def test_cpp_driver_pe_sam_file_equals_reference_golden(name, tmp_path):
     import subprocess
     from bitmapperbs_amd import mapper
-    name = "p100"
     fa = str(tmp_path / "genome.fa"); f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq"); out = str(tmp_path / "o.sam")
     gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
     gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1)
