@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed on the host CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pe", action="store_true", help="paired-end fast mode: --reads pairs per GPU per step (value counts 2 reads per pair)")
+    ap.add_argument("--sensitive", action="store_true", help="with --pe: Map_Pair_Seq_end_to_end (--sensitive) instead of fast mode")
+    ap.add_argument("--sub", type=float, default=0.005, help="substitution rate of the synthetic reads (SURVEY.md 8d: 0.5 %%)")
     ap.add_argument("--workdir", default=os.environ.get("BMBS_BENCH_DIR", "/tmp/bmbs_bench"))
     return ap.parse_args()
 
@@ -148,16 +150,16 @@ def main():
     stride = (L + 15) // 16 * 16
     n = args.reads
     ix = mapper.Index(fa)
-    m = mapper.Mapper(ix, device=local, e_f=args.e)
+    m = mapper.Mapper(ix, device=local, e_f=args.e, sensitive=1 if args.sensitive else 0)
     k = m.threshold(L)
     genome_d, lens_d = gpusynth.upload_genome(chroms)
     max_ops = 2 * k + 8
     if not args.pe:
-        seq_d, qual_d = gpusynth.make_reads_se(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank)
+        seq_d, qual_d = gpusynth.make_reads_se(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank, sub=args.sub)
         cig_cap = n * max_ops
         res_d = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
     else:
-        seq_d, qual_d, seq2_d, qual2_d = gpusynth.make_reads_pe(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank)
+        seq_d, qual_d, seq2_d, qual2_d = gpusynth.make_reads_pe(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank, sub=args.sub)
         cig_cap = 2 * n * max_ops
         res_d = torch.empty((2 * n, 32), dtype=torch.uint8, device="cuda")
     del genome_d
@@ -233,7 +235,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: %d synthetic %d bp SE bisulfite reads" % (n, L) if not args.pe else
-                                    "%d synthetic %d bp read PAIRS (fast PE mode, insert 170-400)" % (n, L)) +
+                                    "%d synthetic %d bp read PAIRS (%s PE mode, insert 170-400, substitutions %.3f)" % (n, L, "sensitive" if args.sensitive else "fast", args.sub)) +
                                    " per GPU per step vs %d bp 4-chromosome synthetic (chr21-size) genome, -e %.2f (k=%d), inputs and "
                                    "results resident in HBM" % (args.genome, args.e, k),
                        "reads_per_gpu_per_step": n, "read_len": L, "genome_bp": args.genome,

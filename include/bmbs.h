@@ -148,7 +148,11 @@ int bmbs_sync(bmbs_ctx*);
  * seq2/qual2 = mate 2 exactly as in the FASTQ file (the library builds the reverse complement the reference's
  * reader builds, Process_Reads.cpp:262-267).  Both mates have length L.  results[2*i], results[2*i+1] = mate 1,
  * mate 2 of pair i: flag 99/83 and 147/163, `reserved` = |TLEN|, status BMBS_ST_* for the PAIR
- * (BMBS_ST_OFFEND also covers the insert-size rejection).  Stats count pairs (Schema.cpp:19531-19537).   */
+ * (BMBS_ST_OFFEND also covers the insert-size rejection).  Stats count pairs (Schema.cpp:19531-19537).
+ * With bmbs_params.sensitive = 1 the same entry points run --sensitive: Map_Pair_Seq_end_to_end (Schema.cpp:19953-21459)
+ * = first seeds of both mates, process_rest_seed_debug (17574) on the mate with fewer first-seed candidates,
+ * process_rest_seed_filter_debug (16298) on the other, reseed_filter / select_best_seeds (16678 / 16630) for a mate
+ * left without a hit, then the same pairing and post-processing.                                          */
 int bmbs_map_pe(bmbs_ctx*, const char* seq1, const char* qual1, const char* seq2, const char* qual2, int32_t L,
                 int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
                 int64_t* n_cigar_used);
