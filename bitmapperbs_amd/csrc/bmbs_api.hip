@@ -955,3 +955,11 @@ extern "C" int bmbs_counters_all(bmbs_ctx* c, uint64_t out[32])
     out[7] = c->last_n_jobs;
     return BMBS_OK;
 }
+
+extern "C" void* bmbs_host_alloc(uint64_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void bmbs_host_free(void* p) { if (p) (void)hipHostFree(p); }

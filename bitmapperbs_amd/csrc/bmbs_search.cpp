@@ -5,63 +5,294 @@
 // libbmbs_hip.so.  Record order is the input order (== the reference at -t 1).
 //
 //   bmbs_search --search <index prefix | dir> --seq r.fq[.gz] [-o out.sam] [-e 0.08] [--mapstats f]
-//   bmbs_search --search <index> --seq1 a.fq --seq2 b.fq [--min 0] [--max 500] ...
-//   extra: --device N, --batch N (reads per GPU batch, default 4 M)
+//   bmbs_search --search <index> --seq1 a.fq --seq2 b.fq [--min 0] [--max 500] [--sensitive] ...
+//   extra: --device N, --batch N (records per GPU batch, default 1 M), -t N (host I/O threads), --verbose
+//
+// The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
+// what limits it.  Here the host side is a three-stage, order-preserving pipeline so that
+// the GPU is fed at memory speed:
+//   stage R  window of the (mmap'ed) FASTQ -> newline index built by the I/O threads -> records grouped by read
+//            length (k = (uint64)(e*L) is per length, Schema.cpp:24546) and packed into page-locked staging rows
+//   stage G  one bmbs_map_se / bmbs_map_pe call per length group (the only stage that touches the GPU)
+//   stage W  SAM text formatted by the I/O threads into per-slice buffers, written with pwrite at prefix offsets
+// Batches circulate through hand-over queues, so stage R of batch i+1 and stage W of batch i-1 overlap stage G of i.
 #include "../../include/bmbs.h"
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
+#include <ctime>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <queue>
 #include <string>
-#include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 namespace {
 
-struct Reader {                       // .fq / .fastq / .fq.gz / .fastq.gz (gzread handles plain files too)
-    gzFile f = nullptr;
-    std::vector<char> buf;
-    size_t pos = 0, len = 0;
-    bool open(const char* path) { f = gzopen(path, "rb"); if (f) { gzbuffer(f, 1 << 20); buf.resize(1 << 22); } return f != nullptr; }
-    bool getline(std::string& s)
+// ---- a small persistent thread pool: run(n, f) executes f(0..n-1) and returns when all are done -------------
+class Pool {
+public:
+    explicit Pool(int extra_threads)
     {
-        s.clear();
-        bool any = false;
+        for (int i = 0; i < extra_threads; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int size() const { return (int)th_.size() + 1; }
+    void run(int n, const std::function<void(int)>& f)
+    {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) f(i); return; }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &f; ntask_ = n; next_ = 0; pending_ = n; gen_++;
+        }
+        cv_.notify_all();
+        work();                                   // the caller helps
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void work()
+    {
         for (;;) {
-            if (pos == len) { int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n <= 0) return any; len = (size_t)n; pos = 0; }
-            any = true;
-            char* p = (char*)memchr(buf.data() + pos, '\n', len - pos);
-            if (p) { s.append(buf.data() + pos, p - (buf.data() + pos)); pos = p - buf.data() + 1; return true; }
-            s.append(buf.data() + pos, len - pos); pos = len;
+            int i;
+            const std::function<void(int)>* f;
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (!fn_ || next_ >= ntask_) return;
+                i = next_++; f = fn_;
+            }
+            (*f)(i);
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
         }
     }
-    void close() { if (f) gzclose(f); f = nullptr; }
+    void loop()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    bool stop_ = false;
+    unsigned long gen_ = 0;
+    int pending_ = 0, next_ = 0, ntask_ = 0;
+    const std::function<void(int)>* fn_ = nullptr;
 };
 
-struct Rec { std::string name, seq, qual; };
+template <class T> class Chan {                  // hand-over queue between the pipeline stages
+public:
+    void put(T v) { { std::lock_guard<std::mutex> l(m_); q_.push(v); } cv_.notify_one(); }
+    T get() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [this] { return !q_.empty(); }); T v = q_.front(); q_.pop(); return v; }
+private:
+    std::mutex m_; std::condition_variable cv_; std::queue<T> q_;
+};
 
-bool next_record(Reader& r, Rec& x)
+// ---- FASTQ text source: plain files are mmap'ed (windows are views), .gz goes through gzread --------------------
+struct Source {
+    bool gz = false;
+    int fd = -1;
+    const char* map = nullptr;
+    size_t size = 0, off = 0;
+    gzFile gzf = nullptr;
+    std::vector<char> carry;
+    bool gz_eof = false;
+
+    bool open(const char* path)
+    {
+        FILE* f = fopen(path, "rb");
+        if (!f) return false;
+        unsigned char mg[2] = {0, 0};
+        const size_t got = fread(mg, 1, 2, f);
+        fclose(f);
+        gz = got == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
+        if (gz) { gzf = gzopen(path, "rb"); if (gzf) gzbuffer(gzf, 1 << 20); return gzf != nullptr; }
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        if (fstat(fd, &sb)) return false;
+        size = (size_t)sb.st_size;
+        if (size) {
+            void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p == MAP_FAILED) return false;
+            map = (const char*)p;
+            madvise((void*)map, size, MADV_SEQUENTIAL);
+        }
+        return true;
+    }
+    // text starting at the current record boundary; `last` when it reaches the end of the input.
+    // For .gz the bytes live in `keep` (owned by the batch until its SAM text has been written).
+    void window(size_t want, const char*& p, size_t& len, bool& last, std::shared_ptr<std::vector<char>>& keep)
+    {
+        if (!gz) { p = map + off; len = std::min(want, size - off); last = off + len == size; return; }
+        keep = std::make_shared<std::vector<char>>();
+        keep->resize(carry.size() + want);
+        if (!carry.empty()) memcpy(keep->data(), carry.data(), carry.size());
+        size_t have = carry.size();
+        carry.clear();
+        while (!gz_eof && have < keep->size()) {
+            const int n = gzread(gzf, keep->data() + have, (unsigned)std::min<size_t>(keep->size() - have, 1u << 30));
+            if (n <= 0) { gz_eof = true; break; }
+            have += (size_t)n;
+        }
+        p = keep->data(); len = have; last = gz_eof;
+    }
+    void consumed(const char* p, size_t len, size_t used)
+    {
+        if (!gz) { off += used; return; }
+        carry.assign(p + used, p + len);
+    }
+    void close() { if (gzf) gzclose(gzf); if (map) munmap((void*)map, size); if (fd >= 0) ::close(fd); }
+};
+
+struct Lines {                                   // newline index of one window
+    const char* p = nullptr;
+    size_t len = 0, used = 0;                    // used = bytes consumed by the batch's records
+    bool mapped = false;                         // p points into an mmap'ed file
+    std::vector<size_t> nl;                      // position of the '\n' ending line i (or len for an unterminated last line)
+    size_t start(size_t line) const { return line == 0 ? 0 : nl[line - 1] + 1; }
+    size_t end(size_t line) const { return nl[line]; }
+};
+
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+
+// `part` is caller-owned scratch that keeps its capacity from batch to batch (fresh allocations of this size
+// are mmap'ed and page-faulted in again on every call)
+void index_lines(Pool& pool, const char* p, size_t len, bool last, bool mapped, Lines& out, std::vector<std::vector<size_t>>& part)
 {
-    std::string plus;
-    if (!r.getline(x.name)) return false;
-    r.getline(x.seq); r.getline(plus); r.getline(x.qual);
-    for (auto& c : x.seq) c = (char)toupper((unsigned char)c);
-    x.qual.resize(x.seq.size(), ' ');
-    return true;
+    out.p = p; out.len = len; out.mapped = mapped; out.used = 0;
+    const int T = pool.size() * 4;
+    part.resize((size_t)T);
+    const size_t per = (len + (size_t)T - 1) / (size_t)T;
+    pool.run(T, [&](int t) {
+        const size_t a = std::min(len, per * (size_t)t), b = std::min(len, a + per);
+        std::vector<size_t>& v = part[(size_t)t];
+        v.clear();
+        v.reserve((b - a) / 64 + 16);
+        const char* q = p + a;
+        const char* e = p + b;
+        if (mapped && b > a) {
+            // pre-fault this slice of the file mapping in one call instead of one minor fault per 4 KB page
+            const size_t pg = 4096, lo = ((size_t)(p + a)) & ~(pg - 1), hi = (((size_t)(p + b)) + pg - 1) & ~(pg - 1);
+            (void)madvise((void*)lo, hi - lo, MADV_POPULATE_READ);
+        }
+        while (q < e) {
+            const char* h = (const char*)memchr(q, '\n', (size_t)(e - q));
+            if (!h) break;
+            v.push_back((size_t)(h - p));
+            q = h + 1;
+        }
+    });
+    std::vector<size_t> base((size_t)T + 1, 0);
+    for (int t = 0; t < T; t++) base[(size_t)t + 1] = base[(size_t)t] + part[(size_t)t].size();
+    const size_t total = base[(size_t)T];
+    const bool open_tail = last && len > 0 && p[len - 1] != '\n';
+    out.nl.resize(total + (open_tail ? 1 : 0));
+    pool.run(T, [&](int t) {
+        if (!part[(size_t)t].empty()) memcpy(&out.nl[base[(size_t)t]], part[(size_t)t].data(), part[(size_t)t].size() * sizeof(size_t));
+    });
+    if (open_tail) out.nl[total] = len;
 }
+
+struct Group { int L; long count; int stride; size_t row0; size_t byte0; size_t pool0; int k; };
+
+struct Pinned {                                  // page-locked staging (bmbs_host_alloc)
+    char* p = nullptr; size_t cap = 0;
+    bool need(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) bmbs_host_free(p);
+        cap = bytes + bytes / 4 + 4096;
+        p = (char*)bmbs_host_alloc(cap);
+        if (!p) { cap = 0; return false; }
+        return true;
+    }
+    void release() { if (p) bmbs_host_free(p); p = nullptr; cap = 0; }
+};
+
+struct Batch {
+    long n = 0;                                  // records
+    bool end = false;                            // no more input after this batch
+    Lines l1, l2;
+    std::shared_ptr<std::vector<char>> keep1, keep2;
+    std::vector<Group> groups;
+    std::vector<uint32_t> row;                   // record -> staging row (global over the groups); ~0u = not mapped
+    std::vector<uint16_t> grp;                   // record -> group
+    Pinned seq1, qual1, seq2, qual2, res, pool;
+    std::vector<std::vector<char>> text;         // SAM text per formatter slice (capacity kept from batch to batch)
+    std::vector<size_t> text_len;
+};
+
+const uint32_t NOROW = 0xffffffffu;
 
 inline char rc_char(char c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }   // rc_table, Process_Reads.cpp:1603
-std::string revcomp(const std::string& s) { std::string r(s.rbegin(), s.rend()); for (auto& c : r) c = rc_char(c); return r; }
 
-std::string cigar_text(const bmbs_result& r, const uint32_t* pool, int L)
+inline void put_uint(std::string& s, unsigned long long v)
 {
-    if (r.n_cigar == 0) return std::to_string(L) + "M";
-    std::string s;
-    for (int i = 0; i < r.n_cigar; i++) { uint32_t o = pool[r.cigar_off + i]; s += std::to_string(o >> 4); s += "MDISH"[o & 15]; }
-    return s;
+    char b[24]; int i = 24;
+    do { b[--i] = (char)('0' + v % 10); v /= 10; } while (v);
+    s.append(b + i, (size_t)(24 - i));
 }
+
+// raw cursor into a pre-sized slice buffer (the formatter computes an upper bound first)
+struct Out {
+    char* p;
+    void ch(char c) { *p++ = c; }
+    void mem(const char* s, size_t n) { memcpy(p, s, n); p += n; }
+    void str(const std::string& s) { mem(s.data(), s.size()); }
+    template <size_t N> void lit(const char (&s)[N]) { memcpy(p, s, N - 1); p += N - 1; }
+    void num(unsigned long long v)
+    {
+        char b[24]; int i = 24;
+        do { b[--i] = (char)('0' + v % 10); v /= 10; } while (v);
+        mem(b + i, (size_t)(24 - i));
+    }
+    void cigar(const bmbs_result& r, const uint32_t* pool, int L)
+    {
+        if (r.n_cigar == 0) { num((unsigned)L); ch('M'); return; }
+        for (int i = 0; i < r.n_cigar; i++) { const uint32_t o = pool[r.cigar_off + i]; num(o >> 4); ch("MDISH"[o & 15]); }
+    }
+    // SEQ \t QUAL, as read or reverse-complemented with reversed qualities
+    void seq(const char* sq, const char* ql, int L, bool rc)
+    {
+        if (!rc) { memcpy(p, sq, (size_t)L); p[L] = '\t'; memcpy(p + L + 1, ql, (size_t)L); }
+        else {
+            for (int i = 0; i < L; i++) p[i] = rc_char(sq[L - 1 - i]);
+            p[L] = '\t';
+            for (int i = 0; i < L; i++) p[L + 1 + i] = ql[L - 1 - i];
+        }
+        p += 2 * (size_t)L + 1;
+    }
+};
 
 void print_stats(FILE* o, const int64_t st[5])
 {
@@ -75,14 +306,17 @@ void print_stats(FILE* o, const int64_t st[5])
 
 bool is_dir(const std::string& p) { struct stat sb; return stat(p.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode); }
 
+double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
     bmbs_params P; bmbs_default_params(&P);
     std::string index, seq, seq1, seq2, out = "output", mapstats;
-    int device = 0;
-    long batch = 4000000;
+    int device = 0, io_threads = 0;
+    long batch = 1000000;
+    bool verbose = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -105,16 +339,21 @@ int main(int argc, char** argv)
         else if (a == "--sensitive") P.sensitive = 1;
         else if (a == "--fast") P.sensitive = 0;
         else if (a == "--pe") {}
-        else if (a == "-t") val();                       // CPU threads: not used, the GPU maps
+        else if (a == "-t") io_threads = atoi(val());    // the reference's mapping threads; here: host I/O threads (the GPU maps)
         else if (a == "--mapstats") mapstats = val();
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch") batch = atol(val());
+        else if (a == "--verbose") verbose = true;
         else { fprintf(stderr, "bmbs_search: unsupported option %s\n", a.c_str()); return 2; }
     }
     if (index.empty() || (seq.empty() && (seq1.empty() || seq2.empty()))) {
-        fprintf(stderr, "usage: bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--mapstats f]\n");
+        fprintf(stderr, "usage: bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--mapstats f] [-t io_threads]\n");
         return 2;
     }
+    if (batch < 1) batch = 1;
+    if (io_threads <= 0) { io_threads = (int)std::thread::hardware_concurrency(); if (io_threads > 32) io_threads = 32; }
+    if (io_threads < 1) io_threads = 1;
+    const double t_start = now();
     if (is_dir(index)) index += "/genome";           // Index.cpp:1048-1069
     bmbs_index_file* ixf = bmbs_index_file_load(index.c_str());
     if (!ixf) { fprintf(stderr, "Cannot open index %s.index*\n", index.c_str()); return 1; }
@@ -122,101 +361,338 @@ int main(int argc, char** argv)
     bmbs_ctx* ctx = bmbs_create(device, &P);
     if (!ctx) { fprintf(stderr, "bmbs_search: no usable HIP device %d (this driver has no CPU mapping path)\n", device); return 1; }
     if (bmbs_index_attach(ctx, &view)) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); return 1; }
-    FILE* o = fopen(out.c_str(), "wb");
-    if (!o) { fprintf(stderr, "Cannot open %s\n", out.c_str()); return 1; }
-    std::vector<char> obuf(1 << 24);
-    setvbuf(o, obuf.data(), _IOFBF, obuf.size());
-    // OutPutSAM_Nounheader (Process_sam_out.cpp:1137-1153)
-    fprintf(o, "@HD\tVN:1.4\tSO:unsorted\n");
-    for (int i = 0; i < view.n_chrom; i++) fprintf(o, "@SQ\tSN:%s\tLN:%llu\n", bmbs_index_file_chrom_name(ixf, i), (unsigned long long)view.chrom_len[i]);
-    fprintf(o, "@PG\tID:BitMapperBS\tVN:1.0.2.3\tCL:");
-    for (int i = 0; i < argc; i++) fprintf(o, "%s ", argv[i]);
-    fprintf(o, "\n");
-    const bool pe = seq.empty();
-    Reader r1, r2;
-    if (!r1.open(pe ? seq1.c_str() : seq.c_str()) || (pe && !r2.open(seq2.c_str()))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
-    std::vector<Rec> a(batch), b(pe ? batch : 0);
-    std::vector<char> s1, q1, s2, q2;
-    std::vector<bmbs_result> res;
-    std::vector<uint32_t> pool;
-    std::vector<std::string> lines;
-    for (;;) {
-        long n = 0;
-        while (n < batch && next_record(r1, a[n]) && (!pe || next_record(r2, b[n]))) n++;
-        if (n == 0) break;
-        // equal-length sub-batches (k = (uint64)(e*L) is per length, Schema.cpp:24546); output keeps the input order
-        std::map<std::pair<int, int>, std::vector<long>> groups;
-        for (long i = 0; i < n; i++) groups[{(int)a[i].seq.size(), pe ? (int)b[i].seq.size() : 0}].push_back(i);
-        lines.assign(n, std::string());
-        for (auto& g : groups) {
-            const int L = g.first.first;
-            const std::vector<long>& ids = g.second;
-            const long m = (long)ids.size();
-            if (pe && g.first.second != L) { fprintf(stderr, "bmbs_search: mates of different lengths (%d/%d) are not supported by the device path yet; %ld pairs skipped\n", L, g.first.second, m); continue; }
-            if (L <= 0) continue;
-            const int stride = (L + 15) / 16 * 16;
-            s1.assign((size_t)m * stride, 0); q1.assign((size_t)m * stride, 0);
-            for (long j = 0; j < m; j++) { memcpy(&s1[(size_t)j * stride], a[ids[j]].seq.data(), L); memcpy(&q1[(size_t)j * stride], a[ids[j]].qual.data(), L); }
-            int k = (int)(uint64_t)(P.e_f * L); if (k > 31) k = 31;
-            int64_t used = 0;
-            if (!pe) {
-                res.resize(m); pool.resize((size_t)m * (2 * k + 8));
-                if (bmbs_map_se(ctx, s1.data(), q1.data(), L, stride, m, res.data(), pool.data(), (int64_t)pool.size(), &used)) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); return 1; }
-                for (long j = 0; j < m; j++) {
-                    const bmbs_result& r = res[j];
-                    if (r.status != BMBS_ST_UNIQUE) continue;
-                    const Rec& x = a[ids[j]];
-                    std::string nm = x.name;                       // cut at the first ' ' or '/' (Process_Reads.cpp:843-850)
-                    size_t c = nm.find_first_of(" /"); if (c != std::string::npos) nm.resize(c);
-                    const char* nmp = nm.c_str(); if (nmp[0] == '@') nmp++;
-                    std::string& ln = lines[ids[j]];
-                    char head[512];
-                    snprintf(head, sizeof(head), "\t%d\t%s\t%llu\t%d\t", (int)r.flag, bmbs_index_file_chrom_name(ixf, r.chrom), (unsigned long long)r.pos, (int)r.mapq);
-                    ln = nmp; ln += head; ln += cigar_text(r, pool.data(), L); ln += "\t*\t0\t0\t";
-                    if (r.flag & 16) { ln += revcomp(x.seq); ln += '\t'; ln.append(x.qual.rbegin(), x.qual.rend()); }
-                    else { ln += x.seq; ln += '\t'; ln += x.qual; }
-                    ln += "\tNM:i:" + std::to_string((int)r.nm) + "\n";
-                }
-            } else {
-                s2.assign((size_t)m * stride, 0); q2.assign((size_t)m * stride, 0);
-                for (long j = 0; j < m; j++) { memcpy(&s2[(size_t)j * stride], b[ids[j]].seq.data(), L); memcpy(&q2[(size_t)j * stride], b[ids[j]].qual.data(), L); }
-                res.resize(2 * m); pool.resize((size_t)2 * m * (2 * k + 8));
-                if (bmbs_map_pe(ctx, s1.data(), q1.data(), s2.data(), q2.data(), L, stride, m, res.data(), pool.data(), (int64_t)pool.size(), &used)) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); return 1; }
-                for (long j = 0; j < m; j++) {
-                    const bmbs_result &x1 = res[2 * j], &x2 = res[2 * j + 1];
-                    if (x1.status != BMBS_ST_UNIQUE) continue;
-                    const Rec &m1 = a[ids[j]], &m2 = b[ids[j]];
-                    size_t c = 0;                               // name: first differing char, ' ' or '/' (Process_Reads.cpp:296-307)
-                    while (c < m1.name.size() && c < m2.name.size() && m1.name[c] == m2.name[c] && m1.name[c] != ' ' && m1.name[c] != '/') c++;
-                    std::string nm = m1.name.substr(0, c);
-                    const char* nmp = nm.c_str(); if (nmp[0] == '@') nmp++;
-                    const unsigned tlen = x1.reserved;
-                    char buf[512];
-                    std::string& ln = lines[ids[j]];
-                    snprintf(buf, sizeof(buf), "%s\t%d\t%s\t%llu\t%d\t", nmp, (int)x1.flag, bmbs_index_file_chrom_name(ixf, x1.chrom), (unsigned long long)x1.pos, (int)x1.mapq);
-                    ln = buf; ln += cigar_text(x1, pool.data(), L);
-                    snprintf(buf, sizeof(buf), "\t=\t%llu\t%s%u\t", (unsigned long long)x2.pos, x2.pos < x1.pos ? "-" : "", tlen);
-                    ln += buf;
-                    if (x1.flag & 32) { ln += m1.seq; ln += '\t'; ln += m1.qual; } else { ln += revcomp(m1.seq); ln += '\t'; ln.append(m1.qual.rbegin(), m1.qual.rend()); }
-                    ln += "\tNM:i:" + std::to_string((int)x1.nm) + "\n";
-                    snprintf(buf, sizeof(buf), "%s\t%d\t%s\t%llu\t%d\t", nmp, (int)x2.flag, bmbs_index_file_chrom_name(ixf, x2.chrom), (unsigned long long)x2.pos, (int)x2.mapq);
-                    ln += buf; ln += cigar_text(x2, pool.data(), L);
-                    snprintf(buf, sizeof(buf), "\t=\t%llu\t%s%u\t", (unsigned long long)x1.pos, x1.pos > x2.pos ? "" : "-", tlen);
-                    ln += buf;
-                    if (x2.flag & 16) { ln += revcomp(m2.seq); ln += '\t'; ln.append(m2.qual.rbegin(), m2.qual.rend()); } else { ln += m2.seq; ln += '\t'; ln += m2.qual; }
-                    ln += "\tNM:i:" + std::to_string((int)x2.nm) + "\n";
-                }
-            }
-        }
-        for (long i = 0; i < n; i++) if (!lines[i].empty()) fwrite(lines[i].data(), 1, lines[i].size(), o);
-        if (n < batch) break;
+    const double t_loaded = now();
+    std::vector<std::string> chrom_names;
+    for (int i = 0; i < view.n_chrom; i++) chrom_names.push_back(bmbs_index_file_chrom_name(ixf, i));
+    const int ofd = ::open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (ofd < 0) { fprintf(stderr, "Cannot open %s\n", out.c_str()); return 1; }
+    size_t out_off = 0;
+    {
+        // OutPutSAM_Nounheader (Process_sam_out.cpp:1137-1153)
+        std::string h = "@HD\tVN:1.4\tSO:unsorted\n";
+        for (int i = 0; i < view.n_chrom; i++) { h += "@SQ\tSN:" + chrom_names[(size_t)i] + "\tLN:"; put_uint(h, view.chrom_len[i]); h += '\n'; }
+        h += "@PG\tID:BitMapperBS\tVN:1.0.2.3\tCL:";
+        for (int i = 0; i < argc; i++) { h += argv[i]; h += ' '; }
+        h += '\n';
+        if (pwrite(ofd, h.data(), h.size(), 0) != (ssize_t)h.size()) { fprintf(stderr, "write error on %s\n", out.c_str()); return 1; }
+        out_off = h.size();
     }
-    fclose(o);
-    r1.close(); if (pe) r2.close();
+    const bool pe = seq.empty();
+    Source src1, src2;
+    if (!src1.open(pe ? seq1.c_str() : seq.c_str()) || (pe && !src2.open(seq2.c_str()))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
+
+    const int n_batches = 5;
+    std::vector<Batch> batches((size_t)n_batches);
+    Chan<Batch*> free_q, gpu_q, out_q, wr_q;
+    for (auto& b : batches) free_q.put(&b);
+    std::atomic<bool> failed(false);
+    double t_read = 0, t_gpu = 0, t_write = 0, t_index = 0, t_format = 0;
+    struct Ev { char stage; long n; double a, b; };
+    std::vector<Ev> ev_r, ev_g, ev_f, ev_w;
+
+    // ---------------- stage R: window -> line index -> length groups -> packed staging rows ----------------------
+    std::thread reader([&] {
+        Pool pool(std::max(1, io_threads / 2) - 1);
+        size_t est = 400;                                               // bytes per record, refined from the data
+        std::vector<std::vector<size_t>> part;                          // scratch reused by every batch
+        std::vector<uint32_t> lens;
+        for (;;) {
+            Batch* b = free_q.get();
+            const double t0 = now();
+            b->n = 0; b->end = false; b->groups.clear(); b->keep1.reset(); b->keep2.reset();
+            const size_t want = (size_t)batch * est + (1u << 16);
+            const char *p1 = nullptr, *p2 = nullptr;
+            size_t n1 = 0, n2 = 0;
+            bool last1 = true, last2 = true;
+            src1.window(want, p1, n1, last1, b->keep1);
+            index_lines(pool, p1, n1, last1, !src1.gz, b->l1, part);
+            t_index += now() - t0;
+            long avail1 = (long)(b->l1.nl.size() / 4), avail2 = 0;
+            long nrec = avail1;
+            if (pe) {
+                src2.window(want, p2, n2, last2, b->keep2);
+                index_lines(pool, p2, n2, last2, !src2.gz, b->l2, part);
+                avail2 = (long)(b->l2.nl.size() / 4);
+                nrec = std::min(nrec, avail2);
+            }
+            if (nrec > batch) nrec = batch;
+            // the input ends with this batch when a file has no complete record left after it (PE: the shorter file decides)
+            b->end = (last1 && avail1 == nrec) || (pe && last2 && avail2 == nrec);
+            if (nrec == 0) {
+                if (!b->end) { fprintf(stderr, "bmbs_search: FASTQ record larger than the %zu-byte window\n", want); failed = true; b->end = true; }
+                gpu_q.put(b);
+                return;
+            }
+            const size_t used1 = std::min(n1, b->l1.nl[(size_t)nrec * 4 - 1] + 1);
+            src1.consumed(p1, n1, used1);
+            b->l1.used = used1;
+            if (pe) { b->l2.used = std::min(n2, b->l2.nl[(size_t)nrec * 4 - 1] + 1); src2.consumed(p2, n2, b->l2.used); }
+            est = std::max<size_t>(64, used1 / (size_t)nrec + 16);
+            b->n = nrec;
+            // ---- length groups (counting sort by read length, input order kept inside a group)
+            const int T = pool.size();
+            const long per = (nrec + T - 1) / T;
+            lens.resize((size_t)nrec);
+            int maxL = 0;
+            {
+                std::vector<int> mx((size_t)T, 0);
+                pool.run(T, [&](int t) {
+                    const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
+                    int m = 0;
+                    for (long r = a; r < e; r++) {
+                        const uint32_t L1 = (uint32_t)(b->l1.end((size_t)r * 4 + 1) - b->l1.start((size_t)r * 4 + 1));
+                        uint32_t key = L1;
+                        if (pe) {
+                            const uint32_t L2 = (uint32_t)(b->l2.end((size_t)r * 4 + 1) - b->l2.start((size_t)r * 4 + 1));
+                            if (L2 != L1) key = NOROW;                // mates of different lengths: not mapped (reported below)
+                        }
+                        if (L1 == 0 || L1 > 1000) key = NOROW;
+                        lens[(size_t)r] = key;
+                        if (key != NOROW && (int)key > m) m = (int)key;
+                    }
+                    mx[(size_t)t] = m;
+                });
+                for (int m : mx) maxL = std::max(maxL, m);
+            }
+            std::vector<std::vector<long>> hist((size_t)T, std::vector<long>((size_t)maxL + 1, 0));
+            std::vector<long> skipped((size_t)T, 0);
+            pool.run(T, [&](int t) {
+                const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
+                for (long r = a; r < e; r++) { if (lens[(size_t)r] == NOROW) skipped[(size_t)t]++; else hist[(size_t)t][lens[(size_t)r]]++; }
+            });
+            long nskip = 0;
+            for (long s : skipped) nskip += s;
+            if (nskip) fprintf(stderr, "bmbs_search: %ld %s skipped (%s)\n", nskip, pe ? "pairs" : "reads",
+                               pe ? "mates of different lengths are not supported by the device path yet, or empty / longer than 1000" : "empty or longer than 1000");
+            std::vector<int> group_of_len((size_t)maxL + 1, -1);
+            size_t row0 = 0, byte0 = 0, pool0 = 0;
+            for (int L = 1; L <= maxL; L++) {
+                long c = 0;
+                for (int t = 0; t < T; t++) c += hist[(size_t)t][(size_t)L];
+                if (!c) continue;
+                Group g; g.L = L; g.count = c; g.stride = (L + 15) / 16 * 16; g.row0 = row0; g.byte0 = byte0; g.pool0 = pool0;
+                int k = (int)(uint64_t)(P.e_f * L); if (k > 31) k = 31;
+                g.k = k;
+                group_of_len[(size_t)L] = (int)b->groups.size();
+                b->groups.push_back(g);
+                row0 += (size_t)c; byte0 += (size_t)c * (size_t)g.stride; pool0 += (size_t)c * (size_t)(2 * k + 8) * (pe ? 2 : 1);
+            }
+            std::vector<std::vector<long>> first((size_t)T, std::vector<long>(b->groups.size(), 0));    // first row of slice t in group g
+            for (size_t g = 0; g < b->groups.size(); g++) {
+                long acc = 0;
+                for (int t = 0; t < T; t++) { first[(size_t)t][g] = acc; acc += hist[(size_t)t][(size_t)b->groups[g].L]; }
+            }
+            if (!b->seq1.need(byte0 + 64) || !b->qual1.need(byte0 + 64) || (pe && (!b->seq2.need(byte0 + 64) || !b->qual2.need(byte0 + 64))) ||
+                !b->res.need(row0 * sizeof(bmbs_result) * (pe ? 2 : 1) + 64) || !b->pool.need(pool0 * 4 + 64)) {
+                fprintf(stderr, "bmbs_search: cannot allocate page-locked staging memory\n");
+                failed = true; b->end = true; b->n = 0; b->groups.clear(); gpu_q.put(b); return;
+            }
+            b->row.resize((size_t)nrec); b->grp.resize((size_t)nrec);
+            pool.run(T, [&](int t) {
+                const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
+                std::vector<long> nextrow = first[(size_t)t];
+                for (long r = a; r < e; r++) {
+                    const uint32_t key = lens[(size_t)r];
+                    if (key == NOROW) { b->row[(size_t)r] = NOROW; b->grp[(size_t)r] = 0; continue; }
+                    const int gi = group_of_len[key];
+                    const Group& g = b->groups[(size_t)gi];
+                    const long j = nextrow[(size_t)gi]++;
+                    b->row[(size_t)r] = (uint32_t)(g.row0 + (size_t)j); b->grp[(size_t)r] = (uint16_t)gi;
+                    const int L = g.L;
+                    const size_t at = g.byte0 + (size_t)j * (size_t)g.stride;
+                    auto pack = [&](const Lines& ln, char* sdst, char* qdst) {
+                        const char* s = ln.p + ln.start((size_t)r * 4 + 1);
+                        for (int i = 0; i < L; i++) { const char c = s[i]; sdst[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+                        for (int i = L; i < g.stride; i++) sdst[i] = 0;
+                        const size_t qs = ln.start((size_t)r * 4 + 3), qe = ln.end((size_t)r * 4 + 3);
+                        const int ql = (int)std::min<size_t>((size_t)L, qe - qs);
+                        memcpy(qdst, ln.p + qs, (size_t)ql);
+                        for (int i = ql; i < L; i++) qdst[i] = ' ';      // qual.resize(seq.size(), ' ')
+                        for (int i = L; i < g.stride; i++) qdst[i] = 0;
+                    };
+                    pack(b->l1, b->seq1.p + at, b->qual1.p + at);
+                    if (pe) pack(b->l2, b->seq2.p + at, b->qual2.p + at);
+                }
+            });
+            t_read += now() - t0;
+            ev_r.push_back({'R', nrec, t0, now()});
+            const bool end = b->end;
+            gpu_q.put(b);
+            if (end) return;
+        }
+    });
+
+    // ---------------- stage F: SAM text, formatted by the I/O threads into per-slice buffers ---------------------
+    std::thread formatter([&] {
+        Pool pool(std::max(1, io_threads - io_threads / 2) - 1);
+        size_t max_chrom = 0;
+        for (const auto& c : chrom_names) max_chrom = std::max(max_chrom, c.size());
+        for (;;) {
+            Batch* b = out_q.get();
+            const double t0 = now();
+            const long nrec = b->n;
+            const bool end = b->end;
+            const int T = pool.size() * 2;
+            b->text.resize((size_t)T); b->text_len.assign((size_t)T, 0);
+            if (nrec && !failed) {
+                const long per = (nrec + T - 1) / T;
+                const bmbs_result* res = (const bmbs_result*)b->res.p;
+                const uint32_t* cpool = (const uint32_t*)b->pool.p;
+                pool.run(T, [&](int t) {
+                    const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
+                    // upper bound of this slice's text: name + fixed columns + CIGAR + SEQ + QUAL per line
+                    size_t bound = 64;
+                    for (long r = a; r < e; r++) {
+                        if (b->row[(size_t)r] == NOROW) continue;
+                        const Group& g = b->groups[b->grp[(size_t)r]];
+                        const size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
+                        bound += ((size_t)(pe ? 2 : 1)) * (nl + max_chrom + 2 * (size_t)g.L + 6 * (size_t)(2 * g.k + 8) + 128);
+                    }
+                    std::vector<char>& buf = b->text[(size_t)t];
+                    if (buf.size() < bound) buf.resize(bound + bound / 8);
+                    Out o{buf.data()};
+                    for (long r = a; r < e; r++) {
+                        const uint32_t row = b->row[(size_t)r];
+                        if (row == NOROW) continue;
+                        const Group& g = b->groups[b->grp[(size_t)r]];
+                        const int L = g.L;
+                        const size_t j = (size_t)row - g.row0;
+                        const size_t at = g.byte0 + j * (size_t)g.stride;
+                        const uint32_t* gp = cpool + g.pool0;
+                        const char* nm = b->l1.p + b->l1.start((size_t)r * 4);
+                        size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
+                        if (!pe) {
+                            const bmbs_result& x = res[row];
+                            if (x.status != BMBS_ST_UNIQUE) continue;
+                            size_t c = 0;                               // cut at the first ' ' or '/' (Process_Reads.cpp:843-850)
+                            while (c < nl && nm[c] != ' ' && nm[c] != '/') c++;
+                            nl = c;
+                            if (nl && nm[0] == '@') { nm++; nl--; }
+                            o.mem(nm, nl); o.ch('\t');
+                            o.num(x.flag); o.ch('\t'); o.str(chrom_names[(size_t)x.chrom]); o.ch('\t'); o.num(x.pos); o.ch('\t');
+                            o.num(x.mapq); o.ch('\t'); o.cigar(x, gp, L); o.lit("\t*\t0\t0\t");
+                            o.seq(b->seq1.p + at, b->qual1.p + at, L, (x.flag & 16) != 0);
+                            o.lit("\tNM:i:"); o.num(x.nm); o.ch('\n');
+                        } else {
+                            const bmbs_result* gr = res + 2 * g.row0;
+                            const bmbs_result &x1 = gr[2 * j], &x2 = gr[2 * j + 1];
+                            if (x1.status != BMBS_ST_UNIQUE) continue;
+                            const char* nm2 = b->l2.p + b->l2.start((size_t)r * 4);
+                            const size_t nl2 = b->l2.end((size_t)r * 4) - b->l2.start((size_t)r * 4);
+                            size_t c = 0;                               // first differing char, ' ' or '/' (Process_Reads.cpp:296-307)
+                            while (c < nl && c < nl2 && nm[c] == nm2[c] && nm[c] != ' ' && nm[c] != '/') c++;
+                            nl = c;
+                            if (nl && nm[0] == '@') { nm++; nl--; }
+                            const unsigned tlen = x1.reserved;
+                            o.mem(nm, nl); o.ch('\t');
+                            o.num(x1.flag); o.ch('\t'); o.str(chrom_names[(size_t)x1.chrom]); o.ch('\t'); o.num(x1.pos); o.ch('\t');
+                            o.num(x1.mapq); o.ch('\t'); o.cigar(x1, gp, L); o.lit("\t=\t"); o.num(x2.pos); o.ch('\t');
+                            if (x2.pos < x1.pos) o.ch('-');             // TLEN sign, Schema.cpp:10575-10600
+                            o.num(tlen); o.ch('\t');
+                            o.seq(b->seq1.p + at, b->qual1.p + at, L, !(x1.flag & 32));
+                            o.lit("\tNM:i:"); o.num(x1.nm); o.ch('\n');
+                            o.mem(nm, nl); o.ch('\t');
+                            o.num(x2.flag); o.ch('\t'); o.str(chrom_names[(size_t)x2.chrom]); o.ch('\t'); o.num(x2.pos); o.ch('\t');
+                            o.num(x2.mapq); o.ch('\t'); o.cigar(x2, gp, L); o.lit("\t=\t"); o.num(x1.pos); o.ch('\t');
+                            if (!(x1.pos > x2.pos)) o.ch('-');           // Schema.cpp:11530-11555
+                            o.num(tlen); o.ch('\t');
+                            o.seq(b->seq2.p + at, b->qual2.p + at, L, (x2.flag & 16) != 0);
+                            o.lit("\tNM:i:"); o.num(x2.nm); o.ch('\n');
+                        }
+                    }
+                    b->text_len[(size_t)t] = (size_t)(o.p - buf.data());
+                });
+            }
+            t_format += now() - t0;
+            ev_f.push_back({'F', nrec, t0, now()});
+            wr_q.put(b);
+            if (end) return;
+        }
+    });
+
+    // ---------------- stage W: pwrite of the slices at prefix offsets; consumed input pages are released -------
+    std::thread writer([&] {
+        Pool pool(std::max(1, io_threads / 4) - 1);
+        for (;;) {
+            Batch* b = wr_q.get();
+            const double t0 = now();
+            const bool end = b->end;
+            const int T = (int)b->text.size();
+            if (b->n && !failed) {
+                std::vector<size_t> at((size_t)T + 1, out_off);
+                for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + b->text_len[(size_t)t];
+                pool.run(T, [&](int t) {
+                    const char* d = b->text[(size_t)t].data();
+                    const size_t len = b->text_len[(size_t)t];
+                    size_t done = 0;
+                    while (done < len) {
+                        const ssize_t w = pwrite(ofd, d + done, len - done, (off_t)(at[(size_t)t] + done));
+                        if (w <= 0) { failed = true; break; }
+                        done += (size_t)w;
+                    }
+                });
+                out_off = at[(size_t)T];
+            }
+            // the text of this batch is no longer needed: drop the whole pages of its input windows now (in the
+            // shadow of the pipeline) instead of paying for one big munmap at exit
+            for (const Lines* ln : {&b->l1, &b->l2}) {
+                if (!ln->p || !ln->mapped || !b->n) continue;
+                const size_t pg = 4096, lo = ((size_t)ln->p + pg - 1) & ~(pg - 1), hi = ((size_t)ln->p + ln->used) & ~(pg - 1);
+                if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
+            }
+            t_write += now() - t0;
+            ev_w.push_back({'W', b->n, t0, now()});
+            b->keep1.reset(); b->keep2.reset();
+            free_q.put(b);
+            if (end) return;
+        }
+    });
+
+    // ---------------- stage G (this thread): one library call per length group -------------------------------
+    long total_records = 0;
+    for (;;) {
+        Batch* b = gpu_q.get();
+        const double t0 = now();
+        if (!failed)
+            for (const Group& g : b->groups) {
+                int64_t used = 0;
+                int rc;
+                if (!pe)
+                    rc = bmbs_map_se(ctx, b->seq1.p + g.byte0, b->qual1.p + g.byte0, g.L, g.stride, g.count, (bmbs_result*)b->res.p + g.row0,
+                                     (uint32_t*)b->pool.p + g.pool0, (int64_t)g.count * (2 * g.k + 8), &used);
+                else
+                    rc = bmbs_map_pe(ctx, b->seq1.p + g.byte0, b->qual1.p + g.byte0, b->seq2.p + g.byte0, b->qual2.p + g.byte0, g.L, g.stride,
+                                     g.count, (bmbs_result*)b->res.p + 2 * g.row0, (uint32_t*)b->pool.p + g.pool0,
+                                     (int64_t)g.count * 2 * (2 * g.k + 8), &used);
+                if (rc) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); failed = true; break; }
+            }
+        total_records += b->n;
+        t_gpu += now() - t0;
+        ev_g.push_back({'G', b->n, t0, now()});
+        const bool end = b->end;
+        out_q.put(b);
+        if (end) break;
+    }
+    reader.join();
+    formatter.join();
+    writer.join();
+    const double t_joined = now();
+    ::close(ofd);
+    src1.close();
+    if (pe) src2.close();
+    if (failed) { fprintf(stderr, "bmbs_search: failed\n"); return 1; }
     int64_t st[5];
     bmbs_stats_get(ctx, st);
     print_stats(stderr, st);
     if (!mapstats.empty()) { FILE* m = fopen(mapstats.c_str(), "w"); if (m) { print_stats(m, st); fclose(m); } }
+    const double t_end = now();
+    if (verbose)
+        fprintf(stderr, "[bmbs_search] records %ld  load+attach %.3fs  mapping wall %.3fs  (pipeline %.3fs; stage busy: read/pack %.3fs of which line index %.3fs, gpu %.3fs, format %.3fs, write %.3fs)  %d I/O threads, batch %ld\n",
+                total_records, t_loaded - t_start, t_end - t_loaded, t_joined - t_loaded, t_read, t_index, t_gpu, t_format, t_write, io_threads, batch);
+    if (verbose && getenv("BMBS_TRACE"))
+        for (const auto* v : {&ev_r, &ev_g, &ev_f, &ev_w})
+            for (const Ev& e : *v) fprintf(stderr, "[trace] %c n=%ld %.4f .. %.4f\n", e.stage, e.n, e.a - t_loaded, e.b - t_loaded);
+    for (auto& b : batches) { b.seq1.release(); b.qual1.release(); b.seq2.release(); b.qual2.release(); b.res.release(); b.pool.release(); }
     bmbs_destroy(ctx);
     bmbs_index_file_free(ixf);
     return 0;

@@ -189,6 +189,12 @@ void bmbs_index_file_free(bmbs_index_file*);
 /* createIndex equivalent (Index.cpp:832-938) without the psascan dependency: FASTA -> the six files */
 int bmbs_index_build(const char* fasta, const char* prefix, int n_threads);
 
+/* Page-locked host buffers for the host-pointer entry points (bmbs_map_se / bmbs_map_pe copy from and to them at
+ * full link speed).  The reference's per-thread scratch is plain malloc (Schema.cpp:24344-24362); a caller that
+ * keeps malloc'ed buffers still works, only slower.  NULL on failure.                                     */
+void* bmbs_host_alloc(uint64_t bytes);
+void  bmbs_host_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif
