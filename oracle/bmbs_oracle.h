@@ -34,6 +34,9 @@ typedef struct orc_params {
     int     min_ins;      /* --min 0   */
     int     max_ins;      /* --max 500 */
     int     sensitive;    /* --sensitive */
+    int     unmapped_out; /* --unmapped_out  (search entry points only: extra SAM records) */
+    int     ambiguous_out;/* --ambiguous_out (one hit of each ambiguous read / pair is aligned and reported) */
+    int     pbat;         /* --pbat */
 } orc_params;
 
 void orc_default_params(orc_params* p);
@@ -64,7 +67,7 @@ uint64_t orc_sa_at(const orc_index*, uint64_t row);
 
 /* per-read mapping record: what the SAM line is printed from */
 typedef struct orc_rec {
-    int32_t  status;        /* 0 unmapped/none, 1 unique (emitted), 2 ambiguous, 3 off-end rejected */
+    int32_t  status;        /* 0 unmapped/none, 1 unique (emitted), 2 ambiguous (fields valid only with ambiguous_out), 3 off-end rejected */
     int32_t  chrom;         /* chromosome id                                  */
     uint64_t pos;           /* 1-based position                               */
     uint64_t site;          /* doubled-coordinate window start (candidate.site) */

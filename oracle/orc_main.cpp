@@ -1,6 +1,6 @@
 // oracle/orc_main.cpp -- TEST INFRASTRUCTURE: command-line front end of the CPU restatement.
 //   bmbs_oracle index  <genome.fa> [<prefix>]        (prefix defaults to the FASTA path)
-//   bmbs_oracle search <prefix> --seq r.fq | --seq1 a.fq --seq2 b.fq  -o out.sam [-e f] [--sensitive]
+//   bmbs_oracle search <prefix> --seq r.fq | --seq1 a.fq --seq2 b.fq  -o out.sam [-e f] [--sensitive] [--unmapped_out] [--ambiguous_out] [--pbat]
 //                      [--min n] [--max n] [--phred64] [--mapstats file]
 // Option names follow Process_CommandLines.cpp:88-132.
 #include "bmbs_oracle.h"
@@ -38,6 +38,9 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--min") && i + 1 < argc) P.min_ins = atoi(argv[++i]);
             else if (!strcmp(argv[i], "--max") && i + 1 < argc) P.max_ins = atoi(argv[++i]);
             else if (!strcmp(argv[i], "--sensitive")) P.sensitive = 1;
+            else if (!strcmp(argv[i], "--unmapped_out")) P.unmapped_out = 1;
+            else if (!strcmp(argv[i], "--ambiguous_out")) P.ambiguous_out = 1;
+            else if (!strcmp(argv[i], "--pbat")) P.pbat = 1;
             else if (!strcmp(argv[i], "--phred64")) P.q_base = 64;
             else if (!strcmp(argv[i], "--mapstats") && i + 1 < argc) mapstats = argv[++i];
             else if (!strcmp(argv[i], "--cl") && i + 1 < argc) cl = argv[++i];

@@ -14,6 +14,7 @@ extern "C" void orc_default_params(orc_params* p)
 {
     p->e_f = 0.08; p->mp_max = 6; p->mp_min = 2; p->np = 1; p->gap_open = 5; p->gap_ext = 3;
     p->q_base = 33; p->seed_len = 30; p->min_ins = 0; p->max_ins = 500; p->sensitive = 0;
+    p->unmapped_out = 0; p->ambiguous_out = 0; p->pbat = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -540,7 +541,20 @@ static void map_one_se(const orc_index* ix, const orc_params* P, const read_t& r
         one_mismatch_site = match_length;
         if (match_length == (u64)L && s.hits > 1) {
             is_multiple = 1;
-            if (C_site == -1) { rec->status = 2; rec->path = 4; st[2]++; return; }   // ambiguous exact (fast exit B)
+            if (C_site == -1) {                                                      // ambiguous exact (fast exit B)
+                rec->path = 4;
+                if (!P->ambiguous_out) { rec->status = 2; st[2]++; return; }
+                // output_ambiguous_exact_map (Schema.cpp:24072-24115): the first row, in SA order, whose placement
+                // does not cross a chromosome end; MAPQ 1
+                u64 nh = s.hits > max_hits ? max_hits : s.hits;
+                char cg[32]; sprintf(cg, "%dM", L);
+                rec->status = 3;
+                for (u64 i = 0; i < nh; i++) {
+                    u64 p = orc_sa_row(ix, s.sp + i);
+                    if (finish_unique(ix->total - p - match_length, L - 1, 0, 0, cg, 1, 0, 4)) { rec->status = 2; st[2]++; break; }
+                }
+                return;
+            }
         }
         if (s.hits == 1) { /* already located into cand[0] */ }
         else if (match_length >= avail_len && s.hits <= max_hits) {
@@ -629,7 +643,24 @@ static void map_one_se(const orc_index* ix, const orc_params* P, const read_t& r
         if (finish_unique(best.site, (u64)(long long)end_site, (u64)(long long)start_site, nm, cigar, mapq, score, 3)) {
             st[1]++; st[3] += L; st[4] += nm;
         }
-    } else if (min_err_index != -1) { rec->status = 2; rec->path = 3; st[2]++; }
+    } else if (min_err_index != -1) {
+        rec->path = 3;
+        if (!P->ambiguous_out) { rec->status = 2; st[2]++; return; }
+        // Schema.cpp:25095-25118: the first candidate that reached the minimum is aligned and reported (second_best_diff = 0)
+        vote_t best = votes[-2 - min_err_index];
+        int score = 0, start_site;
+        char cigar[256];
+        unsigned nm = best.err;
+        int end_site = (int)best.end_site;
+        if (best.err != 0) {
+            window_at(ix, best.site, p_length, win.data());
+            if (C) C->n_sw++;
+            orc_align(P, win.data(), p_length, read, rd.qual, L, (int)k, end_site, best.err, best.site < ix->G, 0,
+                      &start_site, &end_site, &nm, &score, cigar);
+        } else { start_site = end_site - L + 1; sprintf(cigar, "%dM", L); }
+        int mapq = orc_mapq(P, second_best_diff, (unsigned)k, score);
+        if (finish_unique(best.site, (u64)(long long)end_site, (u64)(long long)start_site, nm, cigar, mapq, score, 3)) { rec->status = 2; st[2]++; }
+    }
 }
 
 extern "C" int orc_map_se(const orc_index* ix, const orc_params* P, const char* seq, const char* qual,
@@ -659,16 +690,25 @@ bool getline_(FILE* f, std::string& s)
     return any;
 }
 static inline char rc_char(char c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }
-static bool read_fastq(FILE* f, fq_rec& r, bool cut_name)
+// pbat (inputReads_single_directly_pbat, Process_Reads.cpp:986-1075): seq = reverse complement of the record, rseq = the
+// record; every quality access of the pbat path is mirrored (Schema.cpp:15102 need_reverse_quality = 1, 26066).  That is
+// the normal path run on the reverse-complemented read with reversed qualities, which is how it is restated here.
+static bool read_fastq(FILE* f, fq_rec& r, bool cut_name, bool pbat = false)
 {
     std::string plus;
     if (!getline_(f, r.name)) return false;
     getline_(f, r.seq); getline_(f, plus); getline_(f, r.qual);
     if (cut_name) for (size_t j = 0; j < r.name.size(); j++) if (r.name[j] == ' ' || r.name[j] == '/') { r.name.resize(j); break; }
     for (auto& ch : r.seq) ch = (char)toupper(ch);
+    r.qual.resize(r.seq.size(), ' ');
+    if (pbat) {
+        std::string t(r.seq.rbegin(), r.seq.rend());
+        for (auto& ch : t) ch = rc_char(ch);
+        r.seq.swap(t);
+        std::reverse(r.qual.begin(), r.qual.end());
+    }
     r.rseq.assign(r.seq.rbegin(), r.seq.rend());
     for (auto& ch : r.rseq) ch = rc_char(ch);
-    r.qual.resize(r.seq.size(), ' ');
     return true;
 }
 
@@ -703,10 +743,19 @@ extern "C" int orc_search_se(const orc_index* ix, const orc_params* P, const cha
     std::vector<u64> cand; std::vector<vote_t> votes; std::vector<char> win;
     int64_t st[5] = {0, 0, 0, 0, 0};
     fq_rec r; orc_rec m;
-    while (read_fastq(f, r, true)) {
+    while (read_fastq(f, r, true, P->pbat != 0)) {
         read_t rd = {r.seq.data(), r.qual.data(), (int)r.seq.size()};
         map_one_se(ix, P, rd, &m, st, nullptr, cand, votes, win);
-        if (m.status == 1) sam_se(o, ix, r, m);
+        if (m.status == 1 || (m.status == 2 && P->ambiguous_out)) sam_se(o, ix, r, m);
+        else if (P->unmapped_out && m.status != 2) {
+            // output_sam_unmapped (Schema.cpp:23955-23975); the pbat path hands over the record as read from the file
+            // (rseq and the un-mirrored qualities, Schema.cpp:25538-25543)
+            const char* nm = r.name.c_str();
+            if (nm[0] == '@') nm++;
+            std::string q = r.qual;
+            if (P->pbat) std::reverse(q.begin(), q.end());
+            fprintf(o, "%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n", nm, P->pbat ? r.rseq.c_str() : r.seq.c_str(), q.c_str());
+        }
     }
     fclose(f); fclose(o);
     for (int j = 0; j < 5; j++) stats[j] = st[j];

@@ -515,7 +515,7 @@ static void map_one_pe(const orc_index* ix, const orc_params* P, const char* seq
     unsigned sbd = 0;
     int mapping_pair = verify_pairs(l1, occ1, l2, occ2, (int)large, &b1, &b2, inner_max, inner_min, &sbd);
     rec->n_pairs = mapping_pair;
-    if (mapping_pair == 1) {
+    if (mapping_pair == 1 || (P->ambiguous_out && mapping_pair > 1)) {        // Schema.cpp:19342-19347
         mate_res r1, r2;
         finish_mate(ix, P, seq1, qual1, L1, k1, l1[b1], 0, &r1, C);
         finish_mate(ix, P, seq2, qual2, L2, k2, l2[b2], 1, &r2, C);
@@ -526,8 +526,8 @@ static void map_one_pe(const orc_index* ix, const orc_params* P, const char* seq
         const int tlen = (int)(mx - mn + 1);
         if (tlen <= P->max_ins && tlen >= P->min_ins &&
             r1.site + (u64)r1.matched <= ix->chroms[r1.chrom].len + 1 && r2.site + (u64)r2.matched <= ix->chroms[r2.chrom].len + 1) {
-            st[1]++; st[3] += L1 + L2; st[4] += r1.err + r2.err;
-            rec->status = 1;
+            if (mapping_pair == 1) { st[1]++; rec->status = 1; } else { st[2]++; rec->status = 2; }
+            st[3] += L1 + L2; st[4] += r1.err + r2.err;
             rec->mapq = orc_mapq(P, sbd, (unsigned)(k1 + k2), r1.score + r2.score);
             rec->tlen = tlen;
             // directly_output_read1 / read2 flags (Schema.cpp:10552-10560, 11503-11511)
@@ -559,6 +559,7 @@ extern "C" int orc_map_pe(const orc_index* ix, const orc_params* P, const char* 
 extern "C" int orc_search_pe(const orc_index* ix, const orc_params* P, const char* fq1, const char* fq2,
                              const char* out_sam, const char* argv_line, int64_t stats[5])
 {
+    if (P->pbat) { const char* t = fq1; fq1 = fq2; fq2 = t; }               // exchange_two_reads (Process_Reads.cpp:1628)
     FILE* f1 = fopen(fq1, "rb"); FILE* f2 = fopen(fq2, "rb");
     if (!f1 || !f2) return -1;
     FILE* o = fopen(out_sam, "wb");
@@ -582,7 +583,15 @@ extern "C" int orc_search_pe(const orc_index* ix, const orc_params* P, const cha
         if (j == n1.size() || j == n2.size()) nm = n1.substr(0, std::min(n1.size(), n2.size()));
         const char* name = nm.c_str(); if (name[0] == '@') name++;
         map_one_pe(ix, P, s1.data(), q1.data(), (int)s1.size(), seq2.data(), q2.data(), (int)s2.size(), &m, st, nullptr);
-        if (m.status != 1) continue;
+        if (m.status == 0 || m.status == 3) {
+            // directly_output_unmapped_PE (Schema.cpp:10392-10430): flags 77 / 141, mate 2 as in its FASTQ record
+            if (P->unmapped_out) {
+                fprintf(o, "%s\t77\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n", name, s1.c_str(), q1.c_str());
+                fprintf(o, "%s\t141\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n", name, s2.c_str(), q2.c_str());
+            }
+            continue;
+        }
+        if (m.status == 2 && !P->ambiguous_out) continue;
         // TLEN sign: Schema.cpp:10575-10600 (read 1) and 11530-11555 (read 2)
         const char* t1 = m.pos2 < m.pos1 ? "-" : "";          // read 1: negative only when the mate lies to the left
         const char* t2 = m.pos1 > m.pos2 ? "" : "-";          // read 2: positive only when the mate lies to the right

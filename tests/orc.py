@@ -13,7 +13,8 @@ ODIR = os.path.join(ROOT, "oracle")
 class OrcParams(C.Structure):
     _fields_ = [("e_f", C.c_double), ("mp_max", C.c_int), ("mp_min", C.c_int), ("np", C.c_int), ("gap_open", C.c_int),
                 ("gap_ext", C.c_int), ("q_base", C.c_int), ("seed_len", C.c_int), ("min_ins", C.c_int),
-                ("max_ins", C.c_int), ("sensitive", C.c_int)]
+                ("max_ins", C.c_int), ("sensitive", C.c_int), ("unmapped_out", C.c_int), ("ambiguous_out", C.c_int),
+                ("pbat", C.c_int)]
 
 
 REC_DTYPE = np.dtype([("status", "<i4"), ("chrom", "<i4"), ("pos", "<u8"), ("site", "<u8"), ("start_site", "<i4"),
