@@ -29,7 +29,7 @@ class Params(C.Structure):
     _fields_ = [("e_f", C.c_double), ("mp_max", C.c_int32), ("mp_min", C.c_int32), ("np", C.c_int32),
                 ("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("q_base", C.c_int32),
                 ("seed_len", C.c_int32), ("min_ins", C.c_int32), ("max_ins", C.c_int32),
-                ("sensitive", C.c_int32), ("reserved", C.c_int32)]
+                ("sensitive", C.c_int32), ("ambiguous_out", C.c_int32)]
 
 
 class IndexView(C.Structure):

@@ -363,7 +363,7 @@ int upload_rows(bmbs_ctx* c, DevBuf& dst, const char* src, int L, int stride, u6
 extern "C" void bmbs_default_params(bmbs_params* p)
 {
     p->e_f = 0.08; p->mp_max = 6; p->mp_min = 2; p->np = 1; p->gap_open = 5; p->gap_ext = 3; p->q_base = 33;
-    p->seed_len = 30; p->min_ins = 0; p->max_ins = 500; p->sensitive = 0; p->reserved = 0;
+    p->seed_len = 30; p->min_ins = 0; p->max_ins = 500; p->sensitive = 0; p->ambiguous_out = 0;
 }
 
 extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
@@ -514,7 +514,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
         prof_end(c);
     }
     prof_begin(c, "k_reduce");
-    hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, st, c->vote_off.as<u64>(),
+    hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, c->prm.ambiguous_out, st, c->vote_off.as<u64>(),
                        c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>());
     prof_end(c);
     prof_begin(c, "scan_jobs");
@@ -545,6 +545,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     hipLaunchKernelGGL(k_finalize, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
                        c->mapq_lut.as<u8>(), c->mapq_range, d_seq, d_qual, L, stride, k, (long)n, st, c->a_start.as<int>(),
                        c->a_end.as<int>(), c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), max_ops,
+                       c->prm.ambiguous_out, c->sd_sp0.as<u64>(), c->sd_hits0.as<u32>(),
                        reinterpret_cast<bmbs_result_dev*>(d_results), c->stats.as<unsigned long long>());
     prof_end(c);
     return BMBS_OK;
@@ -724,7 +725,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
         }
     }
     prof_begin(c, "k_pe_pair");
-    hipLaunchKernelGGL(k_pe_pair, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, k, maxd, mind, st, ps, A, B);
+    hipLaunchKernelGGL(k_pe_pair, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, k, c->prm.ambiguous_out, maxd, mind, st, ps, A, B);
     prof_end(c);
     prof_begin(c, "scan_jobs");
     rc = scan_u32(c, st.job_flag, n2, st.job_off, 1);
@@ -753,7 +754,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     }
     prof_begin(c, "k_finalize_pe");
     hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->mapq_lut.as<u8>(), c->mapq_range, L, k,
-                       c->prm.min_ins, c->prm.max_ins, (long)n, st, ps, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                       c->prm.min_ins, c->prm.max_ins, c->prm.ambiguous_out, (long)n, st, ps, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, reinterpret_cast<bmbs_result_dev*>(d_results),
                        c->stats.as<unsigned long long>());
     prof_end(c);

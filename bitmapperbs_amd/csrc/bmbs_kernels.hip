@@ -1010,7 +1010,7 @@ k_filter_pairs(DevIndex ix, const char* __restrict__ seq, int L, int stride, int
 // K9: ordered reduction over a read's votes (Schema.cpp:7847-8172 / 8335-8750)
 // ================================================================================================
 __global__ void __launch_bounds__(256)
-k_reduce(long n, ReadState st, const u64* __restrict__ vote_off, const bmbs_vote* __restrict__ votes,
+k_reduce(long n, int ambiguous_out, ReadState st, const u64* __restrict__ vote_off, const bmbs_vote* __restrict__ votes,
          const u32* __restrict__ ferr, const int* __restrict__ fend)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1036,7 +1036,18 @@ k_reduce(long n, ReadState st, const u64* __restrict__ vote_off, const bmbs_vote
         st.sbd[r] = sbd;
         st.red_status[r] = 1;
         st.job_flag[r] = min_err != 0 ? 1u : 0u;
-    } else if (min_idx != -1) st.red_status[r] = 2;
+    } else if (min_idx != -1) {
+        st.red_status[r] = 2;
+        if (ambiguous_out) {
+            // --ambiguous_out (Schema.cpp:25095-25118): the first candidate that reached the minimum is aligned and reported
+            const long a = -2 - min_idx;
+            st.best_site[r] = votes[off + a].site;
+            st.best_end[r] = fend[off + a];
+            st.best_err[r] = min_err;
+            st.sbd[r] = 0;
+            st.job_flag[r] = min_err != 0 ? 1u : 0u;
+        }
+    }
 }
 
 // job arrays shared by the fused path and bmbs_align_batch
@@ -1302,7 +1313,8 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
            int range, const char* __restrict__ seq, const char* __restrict__ qual, int L, int stride, int k,
            long n, ReadState st, const int* __restrict__ a_start, const int* __restrict__ a_end,
            const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops,
-           int max_ops, bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
+           int max_ops, int ambiguous_out, const u64* __restrict__ sp0, const u32* __restrict__ hits0,
+           bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
 {
     __shared__ unsigned long long sh[5];
     if (threadIdx.x < 5) sh[threadIdx.x] = 0;
@@ -1313,7 +1325,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
         o.pos = 0; o.cigar_off = 0; o.chrom = -1; o.status = 0; o.mapq = 0; o.flag = 0; o.nm = 0; o.score = 0;
         o.n_cigar = 0; o.path = 0; o.n_cand = st.n_cand[r]; o.reserved = 0;
         const int verdict = st.verdict[r];
-        bool have = false;
+        bool have = false, amb = false;
         u64 site = 0; long long start_site = 0, end_site = 0;
         u32 nm = 0; int score = 0; u32 sbd = 0; int mapq = 0;
         if (verdict == 1) { have = true; site = st.exit_site[r]; start_site = 0; end_site = L - 1; nm = 0; score = 0; mapq = 42; o.path = 1; }
@@ -1323,10 +1335,33 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
             const char a = seq[(size_t)r * stride + ms];
             score = a == 'N' ? -sp.np : -pen_lut[(unsigned char)qual[(size_t)r * stride + ms]];
             sbd = 0xffffffffu;
-        } else if (verdict == 4) { o.status = 2; o.path = 4; }
+        } else if (verdict == 4) {
+            o.status = 2; o.path = 4;
+            if (ambiguous_out) {
+                // output_ambiguous_exact_map (Schema.cpp:24072-24115): first row in SA order whose placement stays inside
+                // its chromosome, MAPQ 1; none -> the read counts as unmapped
+                const u64 sp_ = sp0[r];
+                u32 nh = hits0[r]; if (nh > 1000u) nh = 1000u;
+                o.status = 3;
+                for (u32 i = 0; i < nh; i++) {
+                    const u64 s_ = ix.total - (u64)ix.sa[sp_ + i] - (u64)L;
+                    u64 loc = s_; int flag;
+                    if (loc >= ix.G) { loc = ix.G * 2 - (loc + (u64)(L - 1)) - 1; flag = 16; } else flag = 0;
+                    int c = 0;
+                    for (; c < ix.n_chrom; ++c) if (loc >= ix.chrom_start[c] && loc < ix.chrom_start[c + 1]) break;
+                    if (c >= ix.n_chrom) continue;
+                    const u64 pos = loc + 1 - ix.chrom_start[c];
+                    if (pos + (u64)(L - 1) > ix.chrom_start[c + 1] - ix.chrom_start[c]) continue;
+                    o.pos = pos; o.chrom = (int16_t)c; o.flag = (u16)flag; o.mapq = 1; o.status = 2;
+                    break;
+                }
+            }
+        }
         else if (verdict == 3) {
             o.path = 3;
-            if (st.red_status[r] == 1) {
+            const int rs = st.red_status[r];
+            if (rs == 1 || (rs == 2 && ambiguous_out)) {
+                amb = rs == 2;
                 have = true; site = st.best_site[r]; sbd = st.sbd[r];
                 if (st.job_flag[r]) {
                     const u64 jb = st.job_off[r];
@@ -1335,7 +1370,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
                     o.cigar_off = (u32)(jb * (u64)max_ops);
                     o.n_cigar = no < 0 ? 255 : (u8)no;
                 } else { end_site = st.best_end[r]; start_site = end_site - L + 1; nm = 0; score = 0; }
-            } else if (st.red_status[r] == 2) o.status = 2;
+            } else if (rs == 2) o.status = 2;
         }
         if (have) {
             if (verdict != 1) {
@@ -1358,7 +1393,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
             }
             o.pos = pos; o.chrom = (int16_t)(c < ix.n_chrom ? c : -1); o.flag = (u16)flag; o.mapq = (u8)mapq;
             o.nm = (u16)nm; o.score = (int16_t)score;
-            o.status = ok ? 1 : 3;
+            o.status = ok ? (amb ? 2 : 1) : 3;
         }
         res[r] = o;
         atomicAdd(&sh[0], 1ull);
@@ -1792,7 +1827,7 @@ k_pes_vote(DevIndex ix, long n, int k, long long maxd, long long mind, const u64
 
 // new_faster_verify_pairs (Schema.cpp:15773-15900) + hand-over of the winning candidates to K11-K13
 __global__ void __launch_bounds__(64)
-k_pe_pair(long n, int large_k, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+k_pe_pair(long n, int large_k, int ambiguous_out, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -1836,7 +1871,7 @@ k_pe_pair(long n, int large_k, long long maxd, long long mind, ReadState st, PeS
     if (early) sbd = 0;
     else if (mapping_pair != 0) sbd = (u32)(second - best_sum);
     ps.npair[p] = mapping_pair; ps.sbd[p] = sbd;
-    if (mapping_pair == 1) {
+    if (mapping_pair == 1 || (ambiguous_out && mapping_pair > 1)) {          // Schema.cpp:19342-19347
         st.best_site[r1] = a[bi].site; st.best_end[r1] = a[bi].end; st.best_err[r1] = a[bi].err;
         st.best_site[r2] = b[bj].site; st.best_end[r2] = b[bj].end; st.best_err[r2] = b[bj].err;
         st.red_status[r1] = 1; st.red_status[r2] = 1;
@@ -1848,7 +1883,7 @@ k_pe_pair(long n, int large_k, long long maxd, long long mind, ReadState st, PeS
 // per-pair post-processing (Schema.cpp:19330-19480): placement of both mates (output_sam_end_to_end_return,
 // 9188), TLEN (Schema.h:1587), insert/chromosome-end checks, MAPQ over k1+k2, flags 99/83/147/163, stats
 __global__ void __launch_bounds__(256)
-k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, int k, int min_ins, int max_ins, long n,
+k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, int k, int min_ins, int max_ins, int ambiguous_out, long n,
               ReadState st, PeState ps, const int* __restrict__ a_start, const int* __restrict__ a_end,
               const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops, int max_ops,
               bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
@@ -1865,8 +1900,8 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, in
         }
         const int np = ps.dead[p] ? 0 : ps.npair[p];
         int status = 0;
-        if (np > 1) status = 2;
-        else if (np == 1) {
+        if (np > 1 && !ambiguous_out) status = 2;
+        else if (np >= 1) {
             long long site_pos[2], matched[2];
             int rflag[2], chrom[2], score[2]; u32 nm[2];
             bool inrange = true;
@@ -1898,7 +1933,7 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, in
             if (mx < site_pos[1] + matched[1] - 1) mx = site_pos[1] + matched[1] - 1;
             const int tlen = (int)(mx - mn + 1);
             if (tlen <= max_ins && tlen >= min_ins && inrange) {
-                status = 1;
+                status = np == 1 ? 1 : 2;
                 int sd = score[0] + score[1] + range; if (sd < 0) sd = 0; if (sd > range) sd = range;
                 const u32 kk = 2u * (u32)k, sb = ps.sbd[p];
                 const u32 ed = sb > kk ? kk + 1 : sb;
@@ -1909,7 +1944,8 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, in
                 }
                 o[0].flag = (u16)(rflag[0] == 0 ? (1 | 2 | 32 | 64) : (1 | 2 | 16 | 64));
                 o[1].flag = (u16)(rflag[1] == 0 ? (1 | 2 | 16 | 128) : (1 | 2 | 32 | 128));
-                atomicAdd(&sh[1], 1ull); atomicAdd(&sh[3], 2ull * (unsigned long long)L);
+                if (np == 1) atomicAdd(&sh[1], 1ull);
+                atomicAdd(&sh[3], 2ull * (unsigned long long)L);
                 atomicAdd(&sh[4], (unsigned long long)(nm[0] + nm[1]));
             } else status = 3;
         }

@@ -6,6 +6,7 @@
 //
 //   bmbs_search --search <index prefix | dir> --seq r.fq[.gz] [-o out.sam] [-e 0.08] [--mapstats f]
 //   bmbs_search --search <index> --seq1 a.fq --seq2 b.fq [--min 0] [--max 500] [--sensitive] ...
+//   output variants (Process_CommandLines.cpp:93-105): --pbat, --unmapped_out, --ambiguous_out
 //   extra: --device N, --batch N (records per GPU batch, default 1 M), -t N (host I/O threads), --verbose
 //
 // The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
@@ -316,7 +317,7 @@ int main(int argc, char** argv)
     std::string index, seq, seq1, seq2, out = "output", mapstats;
     int device = 0, io_threads = 0;
     long batch = 1000000;
-    bool verbose = false;
+    bool verbose = false, unmapped_out = false, pbat = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -344,10 +345,13 @@ int main(int argc, char** argv)
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch") batch = atol(val());
         else if (a == "--verbose") verbose = true;
+        else if (a == "--unmapped_out") unmapped_out = true;          // Process_CommandLines.cpp:104-105
+        else if (a == "--ambiguous_out") P.ambiguous_out = 1;
+        else if (a == "--pbat") pbat = true;                          // Process_CommandLines.cpp:93
         else { fprintf(stderr, "bmbs_search: unsupported option %s\n", a.c_str()); return 2; }
     }
     if (index.empty() || (seq.empty() && (seq1.empty() || seq2.empty()))) {
-        fprintf(stderr, "usage: bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--mapstats f] [-t io_threads]\n");
+        fprintf(stderr, "usage: bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--pbat] [--unmapped_out] [--ambiguous_out] [--mapstats f] [-t io_threads]\n");
         return 2;
     }
     if (batch < 1) batch = 1;
@@ -378,6 +382,12 @@ int main(int argc, char** argv)
         out_off = h.size();
     }
     const bool pe = seq.empty();
+    const bool ambiguous_out = P.ambiguous_out != 0;
+    // --pbat: single-end reads are mapped as their reverse complement with mirrored qualities (inputReads_single_directly_pbat,
+    // Process_Reads.cpp:986-1075; Schema.cpp:15102 need_reverse_quality = 1); paired-end input files swap roles
+    // (exchange_two_reads, Process_Reads.cpp:1628, called from Bitmapper_main.cpp:169)
+    if (pbat && pe) std::swap(seq1, seq2);
+    const bool pbat_se = pbat && !pe;
     Source src1, src2;
     if (!src1.open(pe ? seq1.c_str() : seq.c_str()) || (pe && !src2.open(seq2.c_str()))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
 
@@ -502,13 +512,18 @@ int main(int argc, char** argv)
                     const size_t at = g.byte0 + (size_t)j * (size_t)g.stride;
                     auto pack = [&](const Lines& ln, char* sdst, char* qdst) {
                         const char* s = ln.p + ln.start((size_t)r * 4 + 1);
-                        for (int i = 0; i < L; i++) { const char c = s[i]; sdst[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
-                        for (int i = L; i < g.stride; i++) sdst[i] = 0;
                         const size_t qs = ln.start((size_t)r * 4 + 3), qe = ln.end((size_t)r * 4 + 3);
                         const int ql = (int)std::min<size_t>((size_t)L, qe - qs);
-                        memcpy(qdst, ln.p + qs, (size_t)ql);
-                        for (int i = ql; i < L; i++) qdst[i] = ' ';      // qual.resize(seq.size(), ' ')
-                        for (int i = L; i < g.stride; i++) qdst[i] = 0;
+                        if (!pbat_se) {
+                            for (int i = 0; i < L; i++) { const char c = s[i]; sdst[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+                            memcpy(qdst, ln.p + qs, (size_t)ql);
+                            for (int i = ql; i < L; i++) qdst[i] = ' ';      // qual.resize(seq.size(), ' ')
+                        } else {
+                            for (int i = 0; i < L; i++) { const char c = s[L - 1 - i]; sdst[i] = rc_char((c >= 'a' && c <= 'z') ? (char)(c - 32) : c); }
+                            const char* q = ln.p + qs;
+                            for (int i = 0; i < L; i++) { const int j = L - 1 - i; qdst[i] = j < ql ? q[j] : ' '; }
+                        }
+                        for (int i = L; i < g.stride; i++) { sdst[i] = 0; qdst[i] = 0; }
                     };
                     pack(b->l1, b->seq1.p + at, b->qual1.p + at);
                     if (pe) pack(b->l2, b->seq2.p + at, b->qual2.p + at);
@@ -563,12 +578,20 @@ int main(int argc, char** argv)
                         size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
                         if (!pe) {
                             const bmbs_result& x = res[row];
-                            if (x.status != BMBS_ST_UNIQUE) continue;
+                            const bool mapped = x.status == BMBS_ST_UNIQUE || (x.status == BMBS_ST_AMBIG && ambiguous_out);
+                            if (!mapped && !(unmapped_out && x.status != BMBS_ST_AMBIG)) continue;
                             size_t c = 0;                               // cut at the first ' ' or '/' (Process_Reads.cpp:843-850)
                             while (c < nl && nm[c] != ' ' && nm[c] != '/') c++;
                             nl = c;
                             if (nl && nm[0] == '@') { nm++; nl--; }
                             o.mem(nm, nl); o.ch('\t');
+                            if (!mapped) {
+                                // output_sam_unmapped (Schema.cpp:23955-23975); pbat prints the record as it was read (25538-25543)
+                                o.lit("4\t*\t0\t0\t*\t*\t0\t0\t");
+                                o.seq(b->seq1.p + at, b->qual1.p + at, L, pbat_se);
+                                o.ch('\n');
+                                continue;
+                            }
                             o.num(x.flag); o.ch('\t'); o.str(chrom_names[(size_t)x.chrom]); o.ch('\t'); o.num(x.pos); o.ch('\t');
                             o.num(x.mapq); o.ch('\t'); o.cigar(x, gp, L); o.lit("\t*\t0\t0\t");
                             o.seq(b->seq1.p + at, b->qual1.p + at, L, (x.flag & 16) != 0);
@@ -576,13 +599,22 @@ int main(int argc, char** argv)
                         } else {
                             const bmbs_result* gr = res + 2 * g.row0;
                             const bmbs_result &x1 = gr[2 * j], &x2 = gr[2 * j + 1];
-                            if (x1.status != BMBS_ST_UNIQUE) continue;
+                            const bool mapped = x1.status == BMBS_ST_UNIQUE || (x1.status == BMBS_ST_AMBIG && ambiguous_out);
+                            if (!mapped && !(unmapped_out && x1.status != BMBS_ST_AMBIG)) continue;
                             const char* nm2 = b->l2.p + b->l2.start((size_t)r * 4);
                             const size_t nl2 = b->l2.end((size_t)r * 4) - b->l2.start((size_t)r * 4);
                             size_t c = 0;                               // first differing char, ' ' or '/' (Process_Reads.cpp:296-307)
                             while (c < nl && c < nl2 && nm[c] == nm2[c] && nm[c] != ' ' && nm[c] != '/') c++;
                             nl = c;
                             if (nl && nm[0] == '@') { nm++; nl--; }
+                            if (!mapped) {
+                                // directly_output_unmapped_PE (Schema.cpp:10392-10430)
+                                o.mem(nm, nl); o.lit("\t77\t*\t0\t0\t*\t*\t0\t0\t");
+                                o.seq(b->seq1.p + at, b->qual1.p + at, L, false); o.ch('\n');
+                                o.mem(nm, nl); o.lit("\t141\t*\t0\t0\t*\t*\t0\t0\t");
+                                o.seq(b->seq2.p + at, b->qual2.p + at, L, false); o.ch('\n');
+                                continue;
+                            }
                             const unsigned tlen = x1.reserved;
                             o.mem(nm, nl); o.ch('\t');
                             o.num(x1.flag); o.ch('\t'); o.str(chrom_names[(size_t)x1.chrom]); o.ch('\t'); o.num(x1.pos); o.ch('\t');

@@ -41,7 +41,11 @@ typedef struct bmbs_params {
     int32_t min_ins;    /* --min 0     */
     int32_t max_ins;    /* --max 500   */
     int32_t sensitive;  /* --sensitive */
-    int32_t reserved;
+    int32_t ambiguous_out; /* --ambiguous_out: one hit of every ambiguous read / pair is aligned and returned with status
+                            * BMBS_ST_AMBIG (Schema.cpp:24639, 25095, 19345); 0 = ambiguous reads carry no alignment.
+                            * --unmapped_out and --pbat need nothing from the device: the former prints the records whose
+                            * status is BMBS_ST_UNMAPPED / BMBS_ST_OFFEND, the latter maps the reverse complement of each
+                            * read with mirrored qualities (Process_Reads.cpp:986-1075; see bmbs_search.cpp) */
 } bmbs_params;
 
 void bmbs_default_params(bmbs_params* p);

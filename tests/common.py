@@ -82,3 +82,12 @@ def orc_sam_lines(index_names, names, seq, qual, L, recs):
             nm, int(r["flag"]), index_names[int(r["chrom"])], int(r["pos"]), int(r["mapq"]), r["cigar"].decode(),
             s.tobytes().decode(), q.tobytes().decode(), int(r["nm"])))
     return out
+
+
+def pbat_fastq(src, dst):
+    """FASTQ of the reverse-complemented reads with reversed qualities (what a pbat library of the same fragments yields)"""
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    with open(src, "rb") as f, open(dst, "wb") as o:
+        lines = f.read().split(b"\n")
+        for i in range(0, len(lines) - 3, 4):
+            o.write(lines[i] + b"\n" + lines[i + 1].translate(comp)[::-1] + b"\n" + lines[i + 2] + b"\n" + lines[i + 3][::-1] + b"\n")

@@ -40,6 +40,17 @@ PE_SETS = {
     "s150": dict(reads=dict(n=800, L=150, seed=15, sub=0.07, indel=0.004, qual="random", ins_hi=450), args=["--sensitive", "-e", "0.1", "--max", "450"]),
 }
 
+# output variants (Process_CommandLines.cpp:93-105) run on the read sets above; only the reference's SAM + mapstats are stored.
+# "pbat": the FASTQ handed to the reference is the set's reverse complement with reversed qualities (common.pbat_fastq).
+VARIANTS = {
+    "se_e75_ua": dict(kind="se", base="e75", args=["--unmapped_out", "--ambiguous_out"]),
+    "se_b150_pbat": dict(kind="se", base="b150", pbat=True, args=["-e", "0.04", "--pbat", "--unmapped_out", "--ambiguous_out"]),
+    "pe_p75_ua": dict(kind="pe", base="p75", args=["--min", "100", "--max", "250", "--unmapped_out", "--ambiguous_out"]),
+    "pe_s100_ua": dict(kind="pe", base="s100", args=["--sensitive", "--unmapped_out", "--ambiguous_out"]),
+    # PE pbat = the two files swap roles (exchange_two_reads): hand them over swapped so that the pairs map
+    "pe_p100_pbat": dict(kind="pe", base="p100", swap=True, args=["-e", "0.04", "--max", "520", "--pbat", "--unmapped_out"]),
+}
+
 def genome():
     names, chroms = synth.make_genome(300_000, 2, seed=101)
     rng = np.random.default_rng(202)
@@ -109,6 +120,25 @@ def main():
         open(os.path.join(HERE, "pe_%s.ref.stats" % name), "w").write(stats)
         print("PE", name, "lines", body.count("\n"), stats.splitlines()[1])
     json.dump({k: v["args"] for k, v in PE_SETS.items()}, open(os.path.join(HERE, "pe_args.json"), "w"))
+    from common import pbat_fastq
+    for name, v in VARIANTS.items():
+        sam = os.path.join(wd, name + ".sam")
+        if v["kind"] == "se":
+            fq = os.path.join(wd, "se_%s.fq" % v["base"])
+            if v.get("pbat"):
+                pbat_fastq(fq, fq[:-3] + "_pbat.fq"); fq = fq[:-3] + "_pbat.fq"
+            inp = ["--seq", fq]
+        else:
+            a, b = (2, 1) if v.get("swap") else (1, 2)
+            inp = ["--seq1", os.path.join(wd, "pe_%s_%d.fq" % (v["base"], a)), "--seq2", os.path.join(wd, "pe_%s_%d.fq" % (v["base"], b))]
+        p = subprocess.run([ref, "--search", fa] + inp + ["-t", "1", "-o", sam] + v["args"], capture_output=True, text=True, cwd=wd)
+        assert p.returncode == 0, p.stderr
+        body = "".join(l for l in open(sam) if not l.startswith("@PG"))
+        with gzip.GzipFile(os.path.join(HERE, "var_%s.ref.sam.gz" % name), "wb", mtime=0) as g: g.write(body.encode())
+        stats = "".join(l for l in p.stderr.splitlines(True) if l.startswith("No. of") or l.startswith("Mismatch"))
+        open(os.path.join(HERE, "var_%s.ref.stats" % name), "w").write(stats)
+        print("VARIANT", name, "lines", body.count("\n"), stats.splitlines()[1], stats.splitlines()[2])
+    json.dump(VARIANTS, open(os.path.join(HERE, "variants.json"), "w"), indent=1)
     shutil.rmtree(wd)
 
 if __name__ == "__main__":

@@ -60,7 +60,7 @@ def load():
     L.orc_map_pe.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp]
     L.orc_search_se.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, vp]
     L.orc_search_pe.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp]
-    assert C.sizeof(OrcParams) == 48
+    assert C.sizeof(OrcParams) == 64
     _lib = L
     return L
 

@@ -13,14 +13,18 @@ from common import GOLD, e_of, golden_args, gunzip_to, plant_repeats, read_fastq
 pytestmark = pytest.mark.gpu
 
 
-def compare_records(res, pool, recs, L):
+def compare_records(res, pool, recs, L, amb=False):
+    """amb: --ambiguous_out, ambiguous records (status 2) carry a full alignment too"""
     from bitmapperbs_amd import mapper
     bad = []
     assert res.size == recs.size
     st_ok = res["status"].astype(np.int64) == recs["status"].astype(np.int64)
     for i in np.nonzero(~st_ok)[0][:5]:
         bad.append((int(i), "status", int(res[i]["status"]), int(recs[i]["status"])))
-    mapped = np.nonzero(st_ok & ((recs["status"] == 1) | (recs["status"] == 3)))[0]
+    sel = (recs["status"] == 1) | ((recs["status"] == 3) & (recs["path"] != 4))
+    if amb:
+        sel |= recs["status"] == 2
+    mapped = np.nonzero(st_ok & sel)[0]
     for f in ("chrom", "pos", "flag", "mapq", "nm", "score", "path"):
         neq = mapped[res[f][mapped].astype(np.int64) != recs[f][mapped].astype(np.int64)]
         for i in neq[:5]:
@@ -56,19 +60,24 @@ CASES = [
     dict(n=10000, L=36, seed=6, sub=0.02, indel=0.0, qual="random", e=0.1),
     dict(n=2000, L=400, seed=7, sub=0.03, indel=0.001, qual="random", e=0.08),        # k = 31 cap... (32 -> 31)
     dict(n=5000, L=150, seed=8, sub=0.0, indel=0.0, qual="const", conv=0.0, e=0.0),   # k = 0
+    # --ambiguous_out: one hit of each ambiguous read is aligned and returned (exact-ambiguous and tie-in-the-filter forms)
+    dict(n=30000, L=100, seed=9, sub=0.01, indel=0.001, qual="random", e=0.08, amb=1),
+    dict(n=20000, L=60, seed=10, sub=0.0, indel=0.0, qual="const", conv=0.0, e=0.08, amb=1),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "L%d_e%.2f_s%d" % (c["L"], c["e"], c["seed"]))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "L%d_e%.2f_s%d%s" % (c["L"], c["e"], c["seed"], "_amb" if c.get("amb") else ""))
 def test_map_se_records_and_stats_match_oracle(case, env):
     from bitmapperbs_amd import synth, mapper
-    c = dict(case); e = c.pop("e")
+    c = dict(case); e = c.pop("e"); amb = c.pop("amb", 0)
     r = synth.make_reads_se(env["chroms"], **c)
     L = c["L"]
-    m = mapper.Mapper(env["ix"], 0, e_f=e)
+    m = mapper.Mapper(env["ix"], 0, e_f=e, ambiguous_out=amb)
     res, pool = m.map_se(r["seq"], r["qual"], L)
-    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=e), r["seq"], r["qual"], L)
-    bad = compare_records(res, pool, recs, L)
+    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=e, ambiguous_out=amb), r["seq"], r["qual"], L)
+    if amb:
+        assert (recs["status"] == 2).sum() > 20          # the case really has ambiguous reads
+    bad = compare_records(res, pool, recs, L, amb=bool(amb))
     assert not bad, bad[:10]
     assert (m.stats() == ost).all()
     g = m.counters()
@@ -250,7 +259,7 @@ def compare_pe(res, pool, recs, L):
         a1, a2, b = res[2 * i], res[2 * i + 1], recs[i]
         if int(a1["status"]) != int(b["status"]) or int(a2["status"]) != int(b["status"]):
             bad.append((i, "status", int(a1["status"]), int(b["status"]))); continue
-        if int(b["status"]) != 1:
+        if int(b["status"]) != 1 and not (int(b["status"]) == 2 and b["cigar1"] != b""):
             continue
         got = (int(a1["flag"]), int(a2["flag"]), int(a1["chrom"]), int(a2["chrom"]), int(a1["pos"]), int(a2["pos"]), int(a1["mapq"]),
                int(a2["mapq"]), int(a1["nm"]), int(a2["nm"]), int(a1["score"]), int(a2["score"]), int(a1["reserved"]),
@@ -275,6 +284,9 @@ PE_CASES = [
     dict(n=20000, L=100, seed=8, sub=0.02, indel=0.002, qual="random", ins_hi=560, prm=dict(sensitive=1, e_f=0.04, max_ins=520)),
     dict(n=10000, L=150, seed=9, sub=0.0, indel=0.0, qual="const", conv=0.0, prm=dict(sensitive=1)),
     dict(n=8000, L=75, seed=10, sub=0.08, indel=0.0, qual="const", ins_lo=60, ins_hi=300, prm=dict(sensitive=1, min_ins=100, max_ins=250)),
+    # --ambiguous_out for pairs (Schema.cpp:19345 / 21251)
+    dict(n=20000, L=75, seed=11, sub=0.01, indel=0.001, qual="random", ins_lo=60, ins_hi=300, prm=dict(ambiguous_out=1, min_ins=100, max_ins=250)),
+    dict(n=15000, L=100, seed=12, sub=0.05, indel=0.002, qual="random", prm=dict(sensitive=1, ambiguous_out=1)),
 ]
 
 
@@ -360,3 +372,21 @@ def test_cpp_driver_pe_sam_file_equals_reference_golden(name, tmp_path):
     assert mine == gzip.open(os.path.join(GOLD, "pe_%s.ref.sam.gz" % name), "rt").read()
     stats = "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
     assert stats == open(os.path.join(GOLD, "pe_%s.ref.stats" % name)).read()
+
+
+@pytest.mark.parametrize("name", sorted(__import__("test_oracle").variants()))
+def test_cpp_driver_output_variants_equal_reference_golden(name, tmp_path):
+    """--unmapped_out / --ambiguous_out / --pbat through the C++ driver (device: bmbs_params.ambiguous_out)"""
+    import subprocess
+    from bitmapperbs_amd import mapper
+    from test_oracle import variants, variant_inputs
+    v = variants()[name]
+    fa = str(tmp_path / "genome.fa"); out = str(tmp_path / "o.sam")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    mapper.Index.build(fa, fa, threads=4)
+    p = subprocess.run([_driver(), "--search", fa] + variant_inputs(v, tmp_path) + ["-o", out, "--batch", "500"] + v["args"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "var_%s.ref.sam.gz" % name), "rt").read()
+    stats = "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
+    assert stats == open(os.path.join(GOLD, "var_%s.ref.stats" % name)).read()

@@ -169,3 +169,37 @@ def test_oracle_vs_reference_binary_fresh_data_paired_end(cfg, tmp_path, oracle)
     assert [l for l in open(ref_sam) if not l.startswith("@PG")] == [l for l in open(my_sam) if not l.startswith("@PG")]
     assert [l.split() for l in p.stderr.splitlines() if l.startswith("No. of")] == \
            [l.split() for l in q.stderr.splitlines() if l.startswith("No. of")]
+
+
+# ---- output variants: --unmapped_out / --ambiguous_out / --pbat (Process_CommandLines.cpp:93-105) ---------------
+def variants():
+    import json
+    return json.load(open(os.path.join(GOLD, "variants.json")))
+
+
+def variant_inputs(v, tmp_path):
+    """FASTQ arguments of a variant, built from the committed read sets"""
+    from common import pbat_fastq
+    if v["kind"] == "se":
+        fq = str(tmp_path / "r.fq")
+        gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % v["base"]), fq)
+        if v.get("pbat"):
+            pbat_fastq(fq, str(tmp_path / "r_pbat.fq")); fq = str(tmp_path / "r_pbat.fq")
+        return ["--seq", fq]
+    f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq")
+    gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % v["base"]), f1)
+    gunzip_to(os.path.join(GOLD, "pe_%s_2.fq.gz" % v["base"]), f2)
+    return ["--seq1", f2, "--seq2", f1] if v.get("swap") else ["--seq1", f1, "--seq2", f2]
+
+
+@pytest.mark.parametrize("name", sorted(variants()))
+def test_oracle_cli_reproduces_reference_output_variants(name, golden_index, tmp_path, oracle):
+    v = variants()[name]
+    out = str(tmp_path / "o.sam")
+    q = subprocess.run([os.path.join(ROOT, "oracle", "bmbs_oracle"), "search", golden_index] + variant_inputs(v, tmp_path) + ["-o", out] + v["args"],
+                       capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "var_%s.ref.sam.gz" % name), "rt").read()
+    stats = "".join(l + "\n" for l in q.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
+    assert stats == open(os.path.join(GOLD, "var_%s.ref.stats" % name)).read()
