@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GATHER_CEILING_GREQ = 54.0   # measured on this chip: dependent divergent gathers/s (tools/gather_bench.hip, profiles/r01_gather_bench.txt)
 
 
 def pmc_traffic(kernel):
@@ -43,6 +44,17 @@ def pmc_traffic(kernel):
         if row["kernel"].split("<")[0] == kernel:
             return int((float(row["FETCH_SIZE_KB_last_launch"]) + float(row["WRITE_SIZE_KB_last_launch"])) * 1024)
     return None
+
+
+def gather_roofline(kernel, cnt, kern_ms):
+    c = cnt.get(kernel)
+    if not isinstance(c, dict) or kern_ms.get(kernel, 0) <= 0:
+        return None
+    req = c["n_hash"] + c["n_ext"] + c["n_sa"]
+    ach = req / (kern_ms[kernel] * 1e-3) / 1e9
+    return {"index_requests_per_launch": int(req), "achieved_Greq_s": round(ach, 2), "ceiling_Greq_s": GATHER_CEILING_GREQ,
+            "frac": round(ach / GATHER_CEILING_GREQ, 4),
+            "note": "counts index gathers only; read-character loads and result stores are further requests of the same kind"}
 
 
 def parse():
@@ -242,7 +254,10 @@ def main():
                        "parallelism": "reads sharded by rank, index replicated, RCCL all-reduce of 5 mapstats counters"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom),
-                         "algorithmic_bytes_per_launch": int(bytes_dom), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4)},
+                         "algorithmic_bytes_per_launch": int(bytes_dom), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4),
+                         # the same kernel against the bound that really applies to an index walk: divergent gather requests/s
+                         # (index lookups only: one per 16-mer table access, backward extension, SA read) vs the measured ceiling
+                         "gather": gather_roofline(dom, cnt, kern_ms)},
             "kernels_ms_per_step": {a: round(b, 4) for a, b in kern_ms.items()},
             "kernels_algorithmic_GBps": rl_all,
             "counters_per_step": cnt,

@@ -270,6 +270,9 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     const unsigned chunks = nblk(n, SEED_CHUNK);
+    const unsigned chunks_min = nblk(n, SEED_CHUNK_MIN);      // grid for the device-sized chunks of the two work lists
+    const char* tw_env = getenv("BMBS_SEED_WAVES");
+    const int target_waves = tw_env ? atoi(tw_env) : 65536;
     prof_begin(c, "k_seed_first");
     hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, (long)n, sc, cnt);
     prof_end(c);
@@ -300,7 +303,7 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_c, sc.off_c, sc.list_c);
     prof_end(c);
     prof_begin(c, "k_seed_second");
-    hipLaunchKernelGGL(k_seed_second, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 3, pe_mode,
+    hipLaunchKernelGGL(k_seed_second, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 3, target_waves, pe_mode,
                        st, sc, cnt);
     prof_end(c);
     prof_begin(c, "list_extra");
@@ -309,7 +312,7 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_d, sc.off_d, sc.list_d);
     prof_end(c);
     prof_begin(c, "k_seed_extra");
-    hipLaunchKernelGGL(k_seed_extra, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 4,
+    hipLaunchKernelGGL(k_seed_extra, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 4, target_waves,
                        c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
     return BMBS_OK;

@@ -432,7 +432,15 @@ DEVI void seed_finish(const ReadState& st, long r, int verdict, int ns, u64 ncan
     st.n_cand[r] = verdict == 3 ? (u32)ncand : (pe_mode ? (verdict == 4 ? (u32)ncand : (verdict == 1 || verdict == 2) ? 1u : 0u) : 0u);
 }
 
-#define SEED_CHUNK 256            // items per wave
+#define SEED_CHUNK 256            // items per wave (upper bound)
+#define SEED_CHUNK_MIN 64
+// items per wave for a work list of `total` items: enough waves to fill the chip a few times over (the second / extra
+// lists hold 10-30 % of the batch; with 256-item chunks they gave fewer waves than the 8192 wave slots of the chip)
+DEVI long seed_chunk(long total, int target_waves)
+{
+    long c = (total + target_waves - 1) / target_waves;
+    return c < SEED_CHUNK_MIN ? SEED_CHUNK_MIN : (c > SEED_CHUNK ? SEED_CHUNK : c);
+}
 #define SEED_BATCH 16             // pending lanes that trigger a transition batch
 
 struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung; };
@@ -653,13 +661,14 @@ __global__ void k_flag_list(long n, const u32* __restrict__ flag, const u64* __r
 
 // ---- second seed of the 1-mismatch reads + fast exit C (Schema.cpp:24734-24801, 24894-24898) -----
 __global__ void __launch_bounds__(64)
-k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int pe_mode,
-              ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
+k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int target_waves,
+              int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
 {
     const long total = (long)*count_ptr;
-    const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
+    const long chunk = seed_chunk(total, target_waves);
+    const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
-    const long chunk_end = chunk_begin + SEED_CHUNK < total ? chunk_begin + SEED_CHUNK : total;
+    const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
     LaneCounters lc = {0, 0, 0, 0};
     bool active = false;
@@ -769,13 +778,14 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
 
 // ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int seed_len,
-             int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
+k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int target_waves,
+             int seed_len, int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
 {
     const long total = (long)*count_ptr;
-    const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
+    const long chunk = seed_chunk(total, target_waves);
+    const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
-    const long chunk_end = chunk_begin + SEED_CHUNK < total ? chunk_begin + SEED_CHUNK : total;
+    const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
     LaneCounters lc = {0, 0, 0, 0};
     bool active = false, have = false;
