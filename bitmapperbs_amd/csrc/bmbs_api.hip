@@ -34,7 +34,9 @@ struct bmbs_ctx {
     DevBuf occ, hash, sa, gen2, chrom_start;
     // LUTs
     DevBuf pen_lut, mapq_lut;
-    int mapq_k = -1, mapq_range = 0;
+    bool luts_ready = false;
+    int mapq_unit = 0;                         // max(gap_open + gap_ext, mp_max): score range per unit of threshold
+    DevBuf mapq_off, klut;                     // per-threshold table offsets; threshold per read length
     // per-read workspace
     DevBuf verdict, n_seeds, multi, mm_site, exit_site, seeds, n_cand, cand_off, n_votes, best_site,
         best_end, best_err, sbd, red_status, job_flag, job_off, scan_tmp, totals;
@@ -42,7 +44,7 @@ struct bmbs_ctx {
     DevBuf cand, votes, slot_read, vote_off, votes_dense, dense_read, ferr, fend, job_read, job_site, job_end, job_err, need_sw, sw_off, sw_job, trace,
         a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
-    DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d;
+    DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d, in_len;
     // paired-end workspace
     DevBuf sd_sp0, sd_hits0, sd_ml0, sd_tm, sd_seed_id, sd_clen, sd_first_ml, sd_flag_c, sd_flag_d, sd_off_c, sd_off_d, sd_list_c, sd_list_d;
     DevBuf pe_seq, pe_qual, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
@@ -165,22 +167,42 @@ int threshold_k(const bmbs_params& P, int L)
     return (int)k;
 }
 
-// kthr = k for single-end, k1+k2 for pairs (MAP_Calculation's error_threshold argument)
-int prepare_luts(bmbs_ctx* c, int k)
+// MAP_Calculation tables for every error_threshold 0..62 (k for single-end, k1+k2 for pairs), concatenated:
+// table t = (t+2) x (unit*t+1) bytes at mapq_off[t]; plus klut[L] = the threshold of a read of length L.  Built once.
+int prepare_luts(bmbs_ctx* c)
 {
-    if (c->mapq_k == k) return BMBS_OK;
+    if (c->luts_ready) return BMBS_OK;
     int unit = c->prm.gap_open + c->prm.gap_ext;
     if (unit < c->prm.mp_max) unit = c->prm.mp_max;
-    const int range = unit * k;
-    std::vector<u8> lut((size_t)(k + 2) * (range + 1));
-    for (int ed = 0; ed <= k + 1; ed++)
-        for (int sd = 0; sd <= range; sd++)
-            lut[(size_t)ed * (range + 1) + sd] = (u8)map_calculation(c->prm, (unsigned)ed, (unsigned)k, sd - range);
-    ENS(c, c->mapq_lut, lut.size());
+    c->mapq_unit = unit;
+    std::vector<u32> off(64, 0);
+    std::vector<u8> lut;
+    for (int k = 0; k <= 62; k++) {
+        const int range = unit * k;
+        off[k] = (u32)lut.size();
+        lut.resize(lut.size() + (size_t)(k + 2) * (range + 1));
+        u8* t = lut.data() + off[k];
+        for (int ed = 0; ed <= k + 1; ed++)
+            for (int sd = 0; sd <= range; sd++)
+                t[(size_t)ed * (range + 1) + sd] = (u8)map_calculation(c->prm, (unsigned)ed, (unsigned)k, sd - range);
+    }
+    std::vector<u8> kl(1002);
+    for (int L = 0; L <= 1001; L++) kl[L] = (u8)threshold_k(c->prm, L);
+    ENS(c, c->mapq_lut, lut.size()); ENS(c, c->mapq_off, off.size() * 4); ENS(c, c->klut, kl.size());
     HIPCHK(c, hipMemcpyAsync(c->mapq_lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->mapq_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->klut.p, kl.data(), kl.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->mapq_k = k; c->mapq_range = range;
+    c->luts_ready = true;
     return BMBS_OK;
+}
+
+// geometry of a batch: fixed length (d_len == nullptr) or per-read lengths with L = the longest
+ReadGeom geom(bmbs_ctx* c, int L, const u16* d_len)
+{
+    ReadGeom g;
+    g.len = d_len; g.klut = c->klut.as<u8>(); g.L = L; g.k = threshold_k(c->prm, L);
+    return g;
 }
 
 int per_read_workspace(bmbs_ctx* c, u64 n)
@@ -206,20 +228,21 @@ ReadState read_state(bmbs_ctx* c)
 }
 
 template <int KB>
-void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int stride, int k, u64 n_jobs, const Jobs& jobs,
+void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
                u32 rev_from, u32* d_cigar_pool, int max_ops)
 {
     hipLaunchKernelGGL(k_align_sw<KB>, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                       d_qual, L, stride, k, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
+                       d_qual, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                        n_jobs, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>());
 }
 
 // K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the
 // register-band DP kernel instantiated for the smallest KB >= k.  No host round-trip inside.
-int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int stride, int k, u64 n_jobs, const Jobs& jobs,
+int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
               u32 rev_from, u32* d_cigar_pool, int max_ops)
 {
+    const int L = gm.L, k = gm.k;              // the longest read and the largest threshold size the workspace
     const u64 nj = n_jobs ? n_jobs : 1;
     const u64 nwk = (u64)((2 * k + 1 + 15) / 16);
     ENS(c, c->a_start, nj * 4); ENS(c, c->a_end, nj * 4); ENS(c, c->a_nm, nj * 4); ENS(c, c->a_score, nj * 4); ENS(c, c->a_nops, nj * 4);
@@ -229,7 +252,7 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int str
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     prof_begin(c, "k_align_ungapped");
     hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                       d_qual, L, stride, k, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                       d_qual, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
     prof_end(c);
     prof_begin(c, "scan_sw");
@@ -239,13 +262,13 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, int L, int str
                        c->sw_job.as<u32>());
     prof_end(c);
     prof_begin(c, "k_align_sw");
-    if (k <= 4) launch_sw<4>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else launch_sw<31>(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    if (k <= 4) launch_sw<4>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else launch_sw<31>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
     prof_end(c);
     return BMBS_OK;
 }
@@ -261,7 +284,7 @@ SeedCarry seed_carry(bmbs_ctx* c)
     return sc;
 }
 
-int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int pe_mode)
+int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, int pe_mode)
 {
     ENS(c, c->sd_sp0, n * 8); ENS(c, c->sd_hits0, n * 4); ENS(c, c->sd_ml0, n * 2); ENS(c, c->sd_tm, n * 2); ENS(c, c->sd_seed_id, n);
     ENS(c, c->sd_clen, n * 4); ENS(c, c->sd_first_ml, n * 2); ENS(c, c->sd_flag_c, n * 4); ENS(c, c->sd_flag_d, n * 4);
@@ -274,7 +297,7 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     const char* tw_env = getenv("BMBS_SEED_WAVES");
     const int target_waves = tw_env ? atoi(tw_env) : 65536;
     prof_begin(c, "k_seed_first");
-    hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, (long)n, sc, cnt);
+    hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, (long)n, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_decide");
     // rows staged through LDS (each read fetched from HBM exactly once, coalesced) + 8 characters per compare step;
@@ -282,19 +305,19 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     const char* dv = getenv("BMBS_DECIDE");
     const bool lds_ok = (size_t)64 * (stride + 8) <= 48 * 1024;
     if (dv && !strcmp(dv, "plain"))
-        hipLaunchKernelGGL((k_seed_decide<false, false>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+        hipLaunchKernelGGL((k_seed_decide<false, false>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
     else if (dv && !strcmp(dv, "vec8"))
-        hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+        hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
     else if (dv && !strcmp(dv, "lds") && lds_ok)
-        hipLaunchKernelGGL((k_seed_decide<true, false>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, L,
+        hipLaunchKernelGGL((k_seed_decide<true, false>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, gm,
                            stride, (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
     else if (lds_ok)
-        hipLaunchKernelGGL((k_seed_decide<true, true>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, L,
+        hipLaunchKernelGGL((k_seed_decide<true, true>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, gm,
                            stride, (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
     else
-        hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, (long)n,
+        hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
     prof_begin(c, "list_second");
@@ -303,7 +326,7 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_c, sc.off_c, sc.list_c);
     prof_end(c);
     prof_begin(c, "k_seed_second");
-    hipLaunchKernelGGL(k_seed_second, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 3, target_waves, pe_mode,
+    hipLaunchKernelGGL(k_seed_second, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode,
                        st, sc, cnt);
     prof_end(c);
     prof_begin(c, "list_extra");
@@ -312,18 +335,18 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int
     hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_d, sc.off_d, sc.list_d);
     prof_end(c);
     prof_begin(c, "k_seed_extra");
-    hipLaunchKernelGGL(k_seed_extra, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, L, stride, c->totals.as<u64>() + 4, target_waves,
+    hipLaunchKernelGGL(k_seed_extra, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 4, target_waves,
                        c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
     return BMBS_OK;
 }
 
 // stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
-int run_seed_stages(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, int k, u64* total_cand, int pe_mode = 0)
+int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, u64* total_cand, int pe_mode = 0)
 {
     ReadState st = read_state(c);
     {
-        int rcs = launch_seeding(c, d_seq, L, stride, n, pe_mode);
+        int rcs = launch_seeding(c, d_seq, gm, stride, n, pe_mode);
         if (rcs) return rcs;
     }
     prof_begin(c, "scan_cand");
@@ -343,7 +366,7 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, int L, int stride, u64 n, in
         prof_end(c);
     }
     prof_begin(c, "k_vote");
-    hipLaunchKernelGGL(k_vote, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, k, st, c->cand.as<u64>(),
+    hipLaunchKernelGGL(k_vote, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, st, c->cand.as<u64>(),
                        c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
     prof_end(c);
     return BMBS_OK;
@@ -473,8 +496,9 @@ extern "C" int bmbs_sync(bmbs_ctx* c)
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, int32_t L, int32_t stride,
-                                  int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+namespace {
+int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int32_t L, int32_t stride,
+               int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -486,16 +510,17 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     const u64 n = (u64)n_reads;
     c->n_prof_used = 0;
     if (n == 0) return BMBS_OK;
-    const int k = threshold_k(c->prm, L);
-    int rc = prepare_luts(c, k);
+    int rc = prepare_luts(c);
     if (rc) return rc;
+    const ReadGeom gm = geom(c, L, d_len);
+    const int k = gm.k;
     rc = per_read_workspace(c, n);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     u64 tot = 0;
-    rc = run_seed_stages(c, d_seq, L, stride, n, k, &tot);
+    rc = run_seed_stages(c, d_seq, gm, stride, n, &tot);
     if (rc) return rc;
     c->last_total_cand = tot;
     ENS(c, c->vote_off, (n + 1) * 8);
@@ -512,7 +537,7 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     prof_end(c);
     if (tot) {
         prof_begin(c, "k_filter");
-        hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, L, stride, k, c->totals.as<u64>() + 5,
+        hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 5,
                            c->dense_read.as<u32>(), c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), cnt);
         prof_end(c);
     }
@@ -541,12 +566,12 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
             prof_end(c);
         }
         Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
-        rc = run_align(c, d_seq, d_qual, L, stride, k, n_jobs, jobs, 0xffffffffu, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
+        rc = run_align(c, d_seq, d_qual, gm, stride, n_jobs, jobs, 0xffffffffu, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize");
     hipLaunchKernelGGL(k_finalize, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
-                       c->mapq_lut.as<u8>(), c->mapq_range, d_seq, d_qual, L, stride, k, (long)n, st, c->a_start.as<int>(),
+                       c->mapq_lut.as<u8>(), c->mapq_off.as<u32>(), c->mapq_unit, d_seq, d_qual, gm, stride, (long)n, st, c->a_start.as<int>(),
                        c->a_end.as<int>(), c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), max_ops,
                        c->prm.ambiguous_out, c->sd_sp0.as<u64>(), c->sd_hits0.as<u32>(),
                        reinterpret_cast<bmbs_result_dev*>(d_results), c->stats.as<unsigned long long>());
@@ -554,8 +579,17 @@ extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_
     return BMBS_OK;
 }
 
-extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
-                           bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+// host lengths -> device (u16 per read)
+int upload_lens(bmbs_ctx* c, const uint16_t* len, u64 n, u64 at, u64 total, int L)
+{
+    for (u64 i = 0; i < n; i++) if (len[i] == 0 || len[i] > L) { c->err = "read length 0 or longer than L_max"; return BMBS_EINVAL; }
+    ENS(c, c->in_len, total * 2 + 16);           // sized for the whole batch up front: growing would drop the first part
+    HIPCHK(c, hipMemcpyAsync(c->in_len.as<u16>() + at, len, n * 2, hipMemcpyHostToDevice, c->stream));
+    return BMBS_OK;
+}
+
+int map_se_host(bmbs_ctx* c, const char* seq, const char* qual, const uint16_t* len, int32_t L, int32_t stride, int64_t n_reads,
+                bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
 {
     if (!c) return BMBS_EINVAL;
     static_assert(sizeof(bmbs_result) == 32 && sizeof(bmbs_result_dev) == 32, "result record is 32 bytes");
@@ -563,16 +597,18 @@ extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32
     const u64 n = (u64)n_reads, bytes = n * (u64)stride;
     if (n_cigar_used) *n_cigar_used = 0;
     if (n == 0) return BMBS_OK;
+    if (L <= 0 || L > 1000 || stride < L) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     ENS(c, c->out_res, n * 32);
     const int k = threshold_k(c->prm, L);
     const u64 pool = n * (u64)(2 * k + 8);           // worst case: every read needs K12
     ENS(c, c->cig_pool, pool * 4);
     int ds = 0;
     { int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; r1 = upload_rows(c, c->in_qual, qual, L, stride, n, &ds); if (r1) return r1; }
+    if (len) { int r1 = upload_lens(c, len, n, 0, n, L); if (r1) return r1; }
     (void)bytes;
     stride = ds;
-    int rc = bmbs_map_se_device(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, L, stride, n_reads,
-                                (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
+    int rc = map_se_dev(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, len ? c->in_len.as<u16>() : nullptr, L, stride, n_reads,
+                        (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n * 32, hipMemcpyDeviceToHost, c->stream));
     const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
@@ -582,13 +618,37 @@ extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32
     if (n_cigar_used) *n_cigar_used = (int64_t)used;
     return BMBS_OK;
 }
+}  // namespace
 
+extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq, uint64_t d_qual, int32_t L, int32_t stride,
+                                  int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+{
+    return map_se_dev(c, d_seq, d_qual, nullptr, L, stride, n_reads, d_results, d_cigar_pool, cigar_cap);
+}
+extern "C" int bmbs_map_se_var_device(bmbs_ctx* c, uint64_t d_seq, uint64_t d_qual, uint64_t d_len, int32_t L_max, int32_t stride,
+                                      int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+{
+    if (c && !d_len) { c->err = "d_len is NULL"; return BMBS_EINVAL; }
+    return map_se_dev(c, d_seq, d_qual, reinterpret_cast<const u16*>(d_len), L_max, stride, n_reads, d_results, d_cigar_pool, cigar_cap);
+}
+extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
+                           bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    return map_se_host(c, seq, qual, nullptr, L, stride, n_reads, results, cigar_pool, cigar_cap, n_cigar_used);
+}
+extern "C" int bmbs_map_se_var(bmbs_ctx* c, const char* seq, const char* qual, const uint16_t* len, int32_t L_max, int32_t stride,
+                               int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (c && !len) { c->err = "len is NULL"; return BMBS_EINVAL; }
+    return map_se_host(c, seq, qual, len, L_max, stride, n_reads, results, cigar_pool, cigar_cap, n_cigar_used);
+}
 
 // ------------------------------------------------------------------------------------------------
 // paired-end fast mode (Map_Pair_Seq_end_to_end_fast, Schema.cpp:18570)
-extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2,
-                                  int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
-                                  int64_t cigar_cap)
+namespace {
+// d_len: NULL, or u16[2n] = the lengths of the n first mates followed by those of the n second mates
+int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, const u16* d_len,
+               int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -598,9 +658,11 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     const u64 n = (u64)n_pairs, n2 = 2 * n;
     c->n_prof_used = 0;
     if (n == 0) return BMBS_OK;
-    const int k = threshold_k(c->prm, L);
-    int rc = prepare_luts(c, 2 * k);
+    int rc = prepare_luts(c);
     if (rc) return rc;
+    const ReadGeom gm = geom(c, L, d_len);
+    const PeIns pi = {c->prm.min_ins, c->prm.max_ins};
+    const int k = gm.k;
     rc = per_read_workspace(c, n2);
     if (rc) return rc;
     ENS(c, c->pe_seq, n2 * (u64)stride + 64); ENS(c, c->pe_qual, n2 * (u64)stride + 64);
@@ -612,7 +674,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     prof_begin(c, "k_pe_prepare");
     hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * (stride / 16), 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
                        reinterpret_cast<const char*>(d_qual1), reinterpret_cast<const char*>(d_seq2),
-                       reinterpret_cast<const char*>(d_qual2), L, stride, (long)n, seq_all, qual_all);
+                       reinterpret_cast<const char*>(d_qual2), gm, stride, (long)n, seq_all, qual_all);
     prof_end(c);
     ReadState st = read_state(c);
     PeState ps;
@@ -627,7 +689,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     c->last_reseeded = 0; c->last_reseed_cand = 0;
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     // seeding of all 2n reads; candidate slots by scan; locate
-    rc = launch_seeding(c, seq_all, L, stride, n2, 1);
+    rc = launch_seeding(c, seq_all, gm, stride, n2, 1);
     if (rc) return rc;
     prof_begin(c, "scan_cand");
     rc = scan_u32(c, st.n_cand, n2, st.cand_off, 0);
@@ -647,10 +709,8 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
         hipLaunchKernelGGL(k_locate, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, c->ix, (long)n2, st, c->cand.as<u64>());
         prof_end(c);
     }
-    const long long maxd = (long long)c->prm.max_ins + 2LL * k;
-    const long long mind = (long long)c->prm.min_ins - 2LL * k - L;
     prof_begin(c, "k_vote_pe");
-    hipLaunchKernelGGL(k_vote_pe, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n2, L, k, st, ps, c->cand.as<u64>(), A, c->slot_read.as<u32>());
+    hipLaunchKernelGGL(k_vote_pe, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n2, gm, st, ps, c->cand.as<u64>(), A, c->slot_read.as<u32>());
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {
@@ -663,23 +723,23 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
             if (r_) return r_;
             hipLaunchKernelGGL(k_pe_worklist, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, wcnt, woff, c->dense_read.as<u32>(),
                                c->ferr.as<u32>());
-            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(cap, 256)), dim3(256), 0, c->stream, c->ix, seq_all, L, stride, k, st, ps, A, B,
+            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(cap, 256)), dim3(256), 0, c->stream, c->ix, seq_all, gm, stride, st, ps, A, B,
                                c->totals.as<u64>() + 6, c->dense_read.as<u32>(), c->ferr.as<u32>(), cnt);
             prof_end(c);
         }
         prof_begin(c, name_c);
-        hipLaunchKernelGGL(k_pe_compact, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n, (long)n2, k, round, st, ps, A, B);
+        hipLaunchKernelGGL(k_pe_compact, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n, (long)n2, gm, round, st, ps, A, B);
         prof_end(c);
         return BMBS_OK;
     };
     if (!sensitive) {
         prof_begin(c, "k_pe_filter_pairs");
-        hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+        hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B);
         prof_end(c);
         rc = verify_round(1, tot, "k_filter_pe_r1", "k_pe_compact_r1");
         if (rc) return rc;
         prof_begin(c, "k_pe_prune");
-        hipLaunchKernelGGL(k_pe_prune, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+        hipLaunchKernelGGL(k_pe_prune, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B);
         prof_end(c);
         rc = verify_round(2, tot, "k_filter_pe_r2", "k_pe_compact_r2");
         if (rc) return rc;
@@ -691,7 +751,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
         rc = verify_round(1, tot, "k_filter_pe_r1", "k_pe_compact_r1");
         if (rc) return rc;
         prof_begin(c, "k_pes_second");
-        hipLaunchKernelGGL(k_pes_second, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, maxd, mind, st, ps, A, B);
+        hipLaunchKernelGGL(k_pes_second, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B);
         prof_end(c);
         rc = verify_round(2, tot, "k_filter_pe_r2", "k_pe_compact_r2");
         if (rc) return rc;
@@ -705,7 +765,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
         if (rc) return rc;
         hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, rflag, c->pe_rscan.as<u64>(), rlist);
         HIPCHK(c, hipMemsetAsync(rcnt, 0, n * 4, c->stream));
-        hipLaunchKernelGGL(k_pes_reseed, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, L, stride, (long)n, n_reseed, rlist, st, ps,
+        hipLaunchKernelGGL(k_pes_reseed, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, gm, stride, (long)n, n_reseed, rlist, st, ps,
                            rcnt, cnt);
         rc = scan_u32(c, rcnt, n, c->pe_ritem_off.as<u64>(), 8);
         if (rc) return rc;
@@ -720,7 +780,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
             ENS(c, c->dense_read, rtot * 4); ENS(c, c->ferr, rtot * 4);
             ps.R = c->pe_R.as<PeCand>();
             prof_begin(c, "k_pes_vote");
-            hipLaunchKernelGGL(k_pes_vote, dim3(nblk(rt[0], 64)), dim3(64), 0, c->stream, c->ix, (long)n, k, maxd, mind, n_reseed, rlist,
+            hipLaunchKernelGGL(k_pes_vote, dim3(nblk(rt[0], 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, pi, n_reseed, rlist,
                                c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
             prof_end(c);
             rc = verify_round(3, rt[1], "k_filter_pe_r3", "k_pe_compact_r3");
@@ -728,7 +788,7 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
         }
     }
     prof_begin(c, "k_pe_pair");
-    hipLaunchKernelGGL(k_pe_pair, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, k, c->prm.ambiguous_out, maxd, mind, st, ps, A, B);
+    hipLaunchKernelGGL(k_pe_pair, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, c->prm.ambiguous_out, st, ps, A, B);
     prof_end(c);
     prof_begin(c, "scan_jobs");
     rc = scan_u32(c, st.job_flag, n2, st.job_off, 1);
@@ -752,11 +812,11 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
         }
         Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
         // mate 2 rows (>= n) carry FASTQ-order qualities for a reverse-complemented read: need_reverse_quality = 1
-        rc = run_align(c, seq_all, qual_all, L, stride, k, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
+        rc = run_align(c, seq_all, qual_all, gm, stride, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize_pe");
-    hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->mapq_lut.as<u8>(), c->mapq_range, L, k,
+    hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->mapq_lut.as<u8>(), c->mapq_off.as<u32>(), c->mapq_unit, gm,
                        c->prm.min_ins, c->prm.max_ins, c->prm.ambiguous_out, (long)n, st, ps, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, reinterpret_cast<bmbs_result_dev*>(d_results),
                        c->stats.as<unsigned long long>());
@@ -764,15 +824,16 @@ extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1
     return BMBS_OK;
 }
 
-extern "C" int bmbs_map_pe(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2, int32_t L,
-                           int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
-                           int64_t* n_cigar_used)
+int map_pe_host(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2, const uint16_t* len1,
+                const uint16_t* len2, int32_t L, int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool,
+                int64_t cigar_cap, int64_t* n_cigar_used)
 {
     if (!c) return BMBS_EINVAL;
     HIPCHK(c, hipSetDevice(c->dev));
     const u64 n = (u64)n_pairs, bytes = n * (u64)stride;
     if (n_cigar_used) *n_cigar_used = 0;
     if (n == 0) return BMBS_OK;
+    if (L <= 0 || L > 1000 || stride < L) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     ENS(c, c->out_res, 2 * n * 32);
     const int k = threshold_k(c->prm, L);
     const u64 pool = 2 * n * (u64)(2 * k + 8);
@@ -783,11 +844,12 @@ extern "C" int bmbs_map_pe(bmbs_ctx* c, const char* seq1, const char* qual1, con
         r1 = upload_rows(c, c->in_qual, qual1, L, stride, n, &ds); if (r1) return r1;
         r1 = upload_rows(c, c->in_seq2, seq2, L, stride, n, &ds); if (r1) return r1;
         r1 = upload_rows(c, c->in_qual2, qual2, L, stride, n, &ds); if (r1) return r1;
+        if (len1) { r1 = upload_lens(c, len1, n, 0, 2 * n, L); if (r1) return r1; r1 = upload_lens(c, len2, n, n, 2 * n, L); if (r1) return r1; }
     }
     (void)bytes;
     stride = ds;
-    int rc = bmbs_map_pe_device(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, (uint64_t)c->in_seq2.p, (uint64_t)c->in_qual2.p,
-                                L, stride, n_pairs, (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
+    int rc = map_pe_dev(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, (uint64_t)c->in_seq2.p, (uint64_t)c->in_qual2.p,
+                        len1 ? c->in_len.as<u16>() : nullptr, L, stride, n_pairs, (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, 2 * n * 32, hipMemcpyDeviceToHost, c->stream));
     const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
@@ -796,6 +858,35 @@ extern "C" int bmbs_map_pe(bmbs_ctx* c, const char* seq1, const char* qual1, con
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (n_cigar_used) *n_cigar_used = (int64_t)used;
     return BMBS_OK;
+}
+}  // namespace
+
+extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2,
+                                  int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
+                                  int64_t cigar_cap)
+{
+    return map_pe_dev(c, d_seq1, d_qual1, d_seq2, d_qual2, nullptr, L, stride, n_pairs, d_results, d_cigar_pool, cigar_cap);
+}
+extern "C" int bmbs_map_pe_var_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, uint64_t d_len,
+                                      int32_t L_max, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
+                                      int64_t cigar_cap)
+{
+    if (c && !d_len) { c->err = "d_len is NULL"; return BMBS_EINVAL; }
+    return map_pe_dev(c, d_seq1, d_qual1, d_seq2, d_qual2, reinterpret_cast<const u16*>(d_len), L_max, stride, n_pairs, d_results,
+                      d_cigar_pool, cigar_cap);
+}
+extern "C" int bmbs_map_pe(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2, int32_t L,
+                           int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
+                           int64_t* n_cigar_used)
+{
+    return map_pe_host(c, seq1, qual1, seq2, qual2, nullptr, nullptr, L, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
+}
+extern "C" int bmbs_map_pe_var(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2,
+                               const uint16_t* len1, const uint16_t* len2, int32_t L_max, int32_t stride, int64_t n_pairs,
+                               bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (c && (!len1 || !len2)) { c->err = "len1 / len2 is NULL"; return BMBS_EINVAL; }
+    return map_pe_host(c, seq1, qual1, seq2, qual2, len1, len2, L_max, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -808,12 +899,12 @@ extern "C" int bmbs_filter_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_cand <= 0) return BMBS_OK;
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_cand;
-    const int k = threshold_k(c->prm, L);
+    { const int r0 = prepare_luts(c); if (r0) return r0; }
     ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->ferr, m * 4); ENS(c, c->fend, m * 4);
     { int ds = 0; int r1 = upload_rows(c, c->in_seq, seq, L, stride, (u64)n_reads, &ds); if (r1) return r1; stride = ds; (void)bytes; }
     HIPCHK(c, hipMemcpyAsync(c->in_a.p, read_of, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_b.p, site, m * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_filter_pairs, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_seq.as<char>(), L, stride, k, m,
+    hipLaunchKernelGGL(k_filter_pairs, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_seq.as<char>(), geom(c, L, nullptr), stride, m,
                        c->in_a.as<u32>(), c->in_b.as<u64>(), c->ferr.as<u32>(), c->fend.as<int>());
     HIPCHK(c, hipMemcpyAsync(err, c->ferr.p, m * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(end_site, c->fend.p, m * 4, hipMemcpyDeviceToHost, c->stream));
@@ -831,7 +922,7 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_jobs <= 0) return BMBS_OK;
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_jobs;
-    const int k = threshold_k(c->prm, L);
+    { const int r0 = prepare_luts(c); if (r0) return r0; }
     ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->in_c, m * 4); ENS(c, c->in_d, m * 4);
     ENS(c, c->cig_pool, m * (u64)max_ops * 4);
     {
@@ -847,7 +938,7 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     HIPCHK(c, hipMemsetAsync(c->cig_pool.p, 0, m * (u64)max_ops * 4, c->stream));
     c->n_prof_used = 0;
     Jobs jobs = {c->in_a.as<u32>(), c->in_b.as<u64>(), c->in_c.as<int>(), c->in_d.as<u32>()};
-    int rc = run_align(c, c->in_seq.as<char>(), c->in_qual.as<char>(), L, stride, k, m, jobs, 0xffffffffu, c->cig_pool.as<u32>(), max_ops);
+    int rc = run_align(c, c->in_seq.as<char>(), c->in_qual.as<char>(), geom(c, L, nullptr), stride, m, jobs, 0xffffffffu, c->cig_pool.as<u32>(), max_ops);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(start_site, c->a_start.p, m * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(end_site, c->a_end.p, m * 4, hipMemcpyDeviceToHost, c->stream));
@@ -869,7 +960,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     const u64 n = (u64)n_reads, bytes = n * (u64)stride;
     if (total_slots) *total_slots = 0;
     if (n == 0) return BMBS_OK;
-    const int k = threshold_k(c->prm, L);
+    { const int r0 = prepare_luts(c); if (r0) return r0; }
     c->n_prof_used = 0;
     int rc = per_read_workspace(c, n);
     if (rc) return rc;
@@ -877,7 +968,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->exit_site.p, 0, n * 8, c->stream));
     u64 tot = 0;
-    rc = run_seed_stages(c, c->in_seq.as<char>(), L, stride, n, k, &tot);
+    rc = run_seed_stages(c, c->in_seq.as<char>(), geom(c, L, nullptr), stride, n, &tot);
     if (rc) return rc;
     if (total_slots) *total_slots = (int64_t)tot;
     if ((u64)vote_cap < tot) { c->err = "vote buffers too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }

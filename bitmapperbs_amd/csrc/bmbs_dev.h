@@ -60,6 +60,15 @@ struct ReadState {
     u64*  job_off;      // exclusive scan of job_flag
 };
 
+// read lengths of a batch.  len == nullptr: every read has length L and threshold k (the fixed-length entry points);
+// otherwise read r has length len[r] <= L and threshold klut[len[r]] = min(31, (u64)(e_f * len)) tabulated on the host
+// in the reference's double arithmetic (Schema.cpp:24546), L = the longest length and k = klut[L] (the largest).
+struct ReadGeom {
+    const u16* len; const u8* klut; int L; int k;
+    __device__ __forceinline__ int rl(long r) const { return len ? (int)len[r] : L; }
+    __device__ __forceinline__ int rk(int Lr) const { return len ? (int)klut[Lr] : k; }
+};
+
 struct ScoreParams {
     int mp_max, mp_min, np, gap_open, gap_ext, q_base;
     int seed_len;

@@ -462,9 +462,10 @@ DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c, in
 
 // ---- first seed of every read ------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, SeedCarry sc,
+k_seed_first(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, long n, SeedCarry sc,
              unsigned long long* __restrict__ counters)
 {
+    int L = gm.L;                                     // length of the lane's current read
     const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
     const long chunk_end = chunk_begin + SEED_CHUNK < n ? chunk_begin + SEED_CHUNK : n;
     long next = chunk_begin;
@@ -486,7 +487,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
             if (pending) {
                 if (have) { sc.sp0[r] = h.sp; sc.hits0[r] = (u32)h.hits; sc.ml0[r] = (u16)h.ml; have = false; }
                 if (it < chunk_end) {
-                    r = it; rd = seq + (size_t)r * stride; have = true;
+                    r = it; rd = seq + (size_t)r * stride; have = true; L = gm.rl(r);
                     if (search_begin<false>(ix, rd, L, 0, S, h, lc.n_hash)) { active = true; pending = false; }
                     // else: decided at once; stays pending, stored at the next batch
                 } else pending = false;
@@ -506,7 +507,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
 // ---- exits after the first seed (Schema.cpp:24599-24727 / 18225-18330) ---------------------------
 template <bool USE_LDS, bool VEC8>
 __global__ void
-k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, int seed_len, int pe_mode, ReadState st,
+k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, long n, int seed_len, int pe_mode, ReadState st,
               SeedCarry sc, unsigned long long* __restrict__ counters)
 {
     __shared__ unsigned int shc[2];
@@ -537,6 +538,7 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, int L, int stride, long
     __syncthreads();
     if (r < n) {
         const char* rd = USE_LDS ? lds_rows + (size_t)threadIdx.x * lstride : seq + (size_t)r * stride;
+        const int L = gm.rl(r);
         int firstC = L;
         for (int i = 0; i < L; i += 8) {
             // lowest byte equal to 'C' in this 8-byte word (exact for the lowest-order zero byte)
@@ -661,9 +663,10 @@ __global__ void k_flag_list(long n, const u32* __restrict__ flag, const u64* __r
 
 // ---- second seed of the 1-mismatch reads + fast exit C (Schema.cpp:24734-24801, 24894-24898) -----
 __global__ void __launch_bounds__(64)
-k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int target_waves,
+k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
               int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
 {
+    int L = gm.L;                                     // length of the lane's current read
     const long total = (long)*count_ptr;
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
@@ -754,7 +757,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
             if (pending) {
                 if (have) { finish(); have = false; }
                 if (it < chunk_end) {
-                    r = sc.list_c[it]; rd = seq + (size_t)r * stride; have = true;
+                    r = sc.list_c[it]; rd = seq + (size_t)r * stride; have = true; L = gm.rl(r);
                     if (search_begin<true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) {
                         if (S.bot - S.top == 1) verify = true;          // already a single row: stays pending, verified next batch
                         else { active = true; pending = false; }
@@ -778,9 +781,10 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, int L, int stride, cons
 
 // ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const u64* __restrict__ count_ptr, int target_waves,
+k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
              int seed_len, int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
 {
+    int L = gm.L;                                     // length of the lane's current read
     const long total = (long)*count_ptr;
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
@@ -826,7 +830,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, int L, int stride, const
             next += __popcll(want);
             if (pending && !have) {
                 if (it < chunk_end) {
-                    r = sc.list_d[it]; rd = seq + (size_t)r * stride;
+                    r = sc.list_d[it]; rd = seq + (size_t)r * stride; L = gm.rl(r);
                     my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
                     ns = st.n_seeds[r]; ncand = st.n_cand[r]; clen = sc.clen[r]; tm = sc.tm[r]; seed_id = sc.seed_id[r];
                     max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
@@ -875,10 +879,11 @@ k_locate(DevIndex ix, long n, ReadState st, u64* __restrict__ cand)
 // a9/a10: per-read candidate sort, run-length votes, reference vote order
 // ================================================================================================
 __global__ void __launch_bounds__(64)
-k_vote(long n, int k, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read)
+k_vote(long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    const int k = gm.rk(gm.rl(r));
     if (st.verdict[r] != 3) { st.n_votes[r] = 0; return; }
     const u64 off = st.cand_off[r];
     const long nc = (long)st.n_cand[r];
@@ -985,12 +990,12 @@ DEVI void bpm_core(const DevIndex& ix, const char* rd, int L, int k, u64 site, u
 
 DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
 {
-    if (k <= 15) bpm_core<u32>(ix, rd, L, k, site, out_err, out_end);       // k is wave-uniform
+    if (k <= 15) bpm_core<u32>(ix, rd, L, k, site, out_err, out_end);       // k is wave-uniform unless lengths are mixed
     else bpm_core<u64>(ix, rd, L, k, site, out_err, out_end);
 }
 
 __global__ void __launch_bounds__(256)
-k_filter(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, const u64* __restrict__ n_votes_total,
+k_filter(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, const u64* __restrict__ n_votes_total,
          const u32* __restrict__ dense_read, const bmbs_vote* __restrict__ dense, u32* __restrict__ ferr,
          int* __restrict__ fend, unsigned long long* __restrict__ counters)
 {
@@ -998,6 +1003,7 @@ k_filter(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, co
     if (g >= *n_votes_total) return;
     const u32 r = dense_read[g];
     u32 e; int es;
+    const int L = gm.rl(r), k = gm.rk(L);
     bpm_one(ix, seq + (size_t)r * stride, L, k, dense[g].site, e, es);
     ferr[g] = e; fend[g] = es;
     if (counters) atomicAdd(&SHARD(counters)[3], 1ull);
@@ -1005,13 +1011,14 @@ k_filter(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, co
 
 // standalone form for bmbs_filter_batch: explicit (read, site) pairs
 __global__ void __launch_bounds__(256)
-k_filter_pairs(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, u64 n_cand,
+k_filter_pairs(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, u64 n_cand,
                const u32* __restrict__ read_of, const u64* __restrict__ site,
                u32* __restrict__ ferr, int* __restrict__ fend)
 {
     const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_cand) return;
     u32 e; int es;
+    const int L = gm.rl(read_of[g]), k = gm.rk(L);
     bpm_one(ix, seq + (size_t)read_of[g] * stride, L, k, site[g], e, es);
     ferr[g] = e; fend[g] = es;
 }
@@ -1096,7 +1103,7 @@ __global__ void k_job_list(long n, ReadState st, u32* __restrict__ job_read, u64
 
 __global__ void __launch_bounds__(256)
 k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
-                 const char* __restrict__ qual, int L, int stride, int k, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
+                 const char* __restrict__ qual, ReadGeom gm, int stride, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
                  int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
                  int* __restrict__ a_nops, u32* __restrict__ need_sw, unsigned long long* __restrict__ counters)
 {
@@ -1106,6 +1113,7 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
     const u64 site = jb_.site[jb];
     const int end_site = jb_.end[jb];
     const u32 err_in = jb_.err[jb];
+    const int L = gm.rl(r), k = gm.rk(L);
     need_sw[jb] = 0;
     if (err_in == 0) {          // fast_recalculate_bs_Cigar's own err == 0 branch (ksw.cpp:2607-2616)
         a_start[jb] = end_site - L + 1; a_end[jb] = end_site; a_nm[jb] = 0; a_score[jb] = 0; a_nops[jb] = 0;
@@ -1147,7 +1155,7 @@ __global__ void k_sw_list(u64 n_jobs, const u32* __restrict__ need_sw, const u64
 template <int KB>
 __global__ void __launch_bounds__(64)
 k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
-           const char* __restrict__ qual, int L, int stride, int k, const u64* __restrict__ n_sw_ptr,
+           const char* __restrict__ qual, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
            const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride,
            u32* __restrict__ cigar_pool, int max_ops,
            int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
@@ -1164,6 +1172,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     const char* ql = qual + (size_t)r * stride;
     const bool rev = r >= rev_qual_from;
     const bool fwd = site < ix.G;
+    const int L = gm.rl(r), k = gm.rk(L);          // k <= KB: the unrolled band is masked to the job's own width
     const int band = 2 * k + 1;
     const int p_len = L + 2 * k, tlen = L;
     const bool wvalid = window_valid(ix, site, (u64)p_len, fwd);
@@ -1320,8 +1329,8 @@ struct bmbs_result_dev {   // == bmbs_result (include/bmbs.h), 32 bytes
 // IEEE double for this k: ed = min(second_best_diff, k+1), sd = clamp(score + range, 0, range).
 __global__ void __launch_bounds__(256)
 k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u8* __restrict__ mapq_lut,
-           int range, const char* __restrict__ seq, const char* __restrict__ qual, int L, int stride, int k,
-           long n, ReadState st, const int* __restrict__ a_start, const int* __restrict__ a_end,
+           const u32* __restrict__ mapq_off, int unit, const char* __restrict__ seq, const char* __restrict__ qual, ReadGeom gm,
+           int stride, long n, ReadState st, const int* __restrict__ a_start, const int* __restrict__ a_end,
            const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops,
            int max_ops, int ambiguous_out, const u64* __restrict__ sp0, const u32* __restrict__ hits0,
            bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
@@ -1335,6 +1344,9 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
         o.pos = 0; o.cigar_off = 0; o.chrom = -1; o.status = 0; o.mapq = 0; o.flag = 0; o.nm = 0; o.score = 0;
         o.n_cigar = 0; o.path = 0; o.n_cand = st.n_cand[r]; o.reserved = 0;
         const int verdict = st.verdict[r];
+        const int L = gm.rl(r), k = gm.rk(L);
+        const int range = unit * k;
+        mapq_lut += mapq_off[k];                  // MAP_Calculation table of this read's own threshold
         bool have = false, amb = false;
         u64 site = 0; long long start_site = 0, end_site = 0;
         u32 nm = 0; int score = 0; u32 sbd = 0; int mapq = 0;
@@ -1421,6 +1433,18 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
 // reverse complement of the FASTQ record (Process_Reads.cpp:262-267), qualities in FASTQ order.
 struct PeCand { u64 site; u32 err; int32_t end; };      // seed_votes fields used by the PE path
 
+// inner_maxDistance_pair / inner_minDistance_pair of pair p (Schema.cpp:18900-18935): the insert bounds widened by
+// twice the larger threshold, the lower one also by the longer mate
+struct PeIns { int min_ins, max_ins; };
+DEVI void pe_bounds(const ReadGeom& gm, const PeIns& pi, long p, long n, long long& maxd, long long& mind, int& large_k)
+{
+    const int L1 = gm.rl(p), L2 = gm.rl(p + n);
+    const int k1 = gm.rk(L1), k2 = gm.rk(L2);
+    large_k = k1 > k2 ? k1 : k2;
+    maxd = (long long)pi.max_ins + 2LL * large_k;
+    mind = (long long)pi.min_ins - 2LL * large_k - (L1 > L2 ? L1 : L2);
+}
+
 struct PeState {
     int*  occ;        // per read: best_mapp_occ (>0 verified, -1 to verify, 0 none)
     u32*  len;        // per read: current list length
@@ -1440,7 +1464,7 @@ struct PeState {
 // mate 2: reverse complement of the FASTQ read (rc_table, Process_Reads.cpp:1603-1613: identity for non-ACGT)
 __global__ void __launch_bounds__(256)
 k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const char* __restrict__ s2raw,
-             const char* __restrict__ q2, int L, int stride, long n, char* __restrict__ seq_all, char* __restrict__ qual_all)
+             const char* __restrict__ q2, ReadGeom gm, int stride, long n, char* __restrict__ seq_all, char* __restrict__ qual_all)
 {
     // one 16-byte piece per thread (rows are 16-byte aligned, stride % 16 == 0)
     const long i16 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1450,6 +1474,7 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const cha
     const long i = i16 * 16;
     const long r = i / stride;
     const int j0 = (int)(i - r * stride);
+    const int L = gm.rl(n + r);                    // mate 2 of pair r
     reinterpret_cast<uint4*>(seq_all)[i16] = reinterpret_cast<const uint4*>(s1)[i16];
     reinterpret_cast<uint4*>(qual_all)[i16] = reinterpret_cast<const uint4*>(q1)[i16];
     reinterpret_cast<uint4*>(qual_all + total)[i16] = reinterpret_cast<const uint4*>(q2)[i16];
@@ -1471,10 +1496,11 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const cha
 
 // get_candidates' list construction (Schema.cpp:18510-18545): site-sorted votes (NOT re-sorted by vote)
 __global__ void __launch_bounds__(64)
-k_vote_pe(long n2, int L, int k, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A, u32* __restrict__ slot_read)
+k_vote_pe(long n2, ReadGeom gm, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A, u32* __restrict__ slot_read)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n2) return;
+    const int L = gm.rl(r), k = gm.rk(L);
     const int v = st.verdict[r];
     const u64 off = st.cand_off[r];
     for (u64 g = off; g < st.cand_off[r + 1]; g++) slot_read[g] = (u32)r;
@@ -1509,10 +1535,12 @@ DEVI PeCand* pe_list(const PeState& ps, const ReadState& st, PeCand* A, PeCand* 
 
 // filter_pairs (Schema.cpp:16052-16180) + the driver's choice of what to verify (19050-19290)
 __global__ void __launch_bounds__(64)
-k_pe_filter_pairs(long n, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+k_pe_filter_pairs(long n, ReadGeom gm, PeIns pi, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    long long maxd, mind; int large_k;
+    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
     const long r1 = p, r2 = p + n;
     int occ1 = ps.occ[r1], occ2 = ps.occ[r2];
     ps.dead[p] = 0; ps.both[p] = 0; ps.npair[p] = 0; ps.sbd[p] = 0;
@@ -1577,7 +1605,7 @@ k_pe_worklist(long n2, const u32* __restrict__ cnt, const u64* __restrict__ off,
     for (u32 i = 0; i < m; i++) { work_r[o + i] = (u32)r; work_i[o + i] = i; }
 }
 __global__ void __launch_bounds__(256)
-k_filter_pe(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k, ReadState st, PeState ps,
+k_filter_pe(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, ReadState st, PeState ps,
             PeCand* __restrict__ A, PeCand* __restrict__ B, const u64* __restrict__ n_work, const u32* __restrict__ work_r,
             const u32* __restrict__ work_i, unsigned long long* __restrict__ counters)
 {
@@ -1586,6 +1614,7 @@ k_filter_pe(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k,
     const long r = (long)work_r[g];
     PeCand* e = pe_list(ps, st, A, B, r) + work_i[g];
     u32 er; int es;
+    const int L = gm.rl(r), k = gm.rk(L);
     bpm_one(ix, seq + (size_t)r * stride, L, k, e->site, er, es);
     e->err = er; e->end = es;
     if (counters) atomicAdd(&SHARD(counters)[3], 1ull);
@@ -1593,10 +1622,11 @@ k_filter_pe(DevIndex ix, const char* __restrict__ seq, int L, int stride, int k,
 
 // the PE compaction (Schema.cpp:7480-7690): keep err <= k whose site+end differs from the previous candidate's
 __global__ void __launch_bounds__(64)
-k_pe_compact(long n, long n2, int k, int round, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+k_pe_compact(long n, long n2, ReadGeom gm, int round, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n2) return;
+    const int k = gm.rk(gm.rl(r));
     if (ps.vround[r] != round) return;
     const long p = r < n ? r : r - n;
     if (ps.dead[p]) return;
@@ -1615,10 +1645,12 @@ k_pe_compact(long n, long n2, int k, int round, ReadState st, PeState ps, PeCand
 
 // after round 1 of a both-unverified pair: filter_pairs_single_side (Schema.cpp:16186-16270)
 __global__ void __launch_bounds__(64)
-k_pe_prune(long n, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+k_pe_prune(long n, ReadGeom gm, PeIns pi, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    long long maxd, mind; int large_k;
+    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
     if (ps.dead[p] || !ps.both[p]) return;
     const long rs = ps.vround[p] == 1 ? p : p + n;       // verified side
     const long ro = ps.vround[p] == 1 ? p + n : p;       // side still to verify
@@ -1703,10 +1735,12 @@ k_pes_order(long n, ReadState st, SeedCarry sc, PeState ps)
 
 // after round 1: filter the second mate's votes by the first mate's verified hits (generate_candidate_votes_shift_filter)
 __global__ void __launch_bounds__(64)
-k_pes_second(long n, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+k_pes_second(long n, ReadGeom gm, PeIns pi, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    long long maxd, mind; int large_k;
+    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
     if (ps.dead[p]) return;
     const int f = ps.first[p];
     const long rF = p + (long)f * n, rS = p + (long)(1 - f) * n;
@@ -1739,7 +1773,7 @@ k_pes_reseed_flag(long n, PeState ps, u32* __restrict__ flag)
 // reseed_filter's seeding (Schema.cpp:16678-16900) with select_best_seeds (16630): up to three fixed segments
 // (count_hash_table) and then count_backward_as_much_1_terminate seeds sliding by 8.  One re-seeded mate per lane.
 __global__ void __launch_bounds__(64)
-k_pes_reseed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long n, const u64* __restrict__ count_ptr,
+k_pes_reseed(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, long n, const u64* __restrict__ count_ptr,
              const u32* __restrict__ plist, ReadState st, PeState ps, u32* __restrict__ rcnt, unsigned long long* __restrict__ counters)
 {
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1748,6 +1782,7 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
         const long p = plist[it];
         const long r = p + (long)(1 - ps.first[p]) * n;
         const char* rd = seq + (size_t)r * stride;
+        const int L = gm.rl(r);
         SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
         const int full = ps.full[r];
         int rs[3], rl[3], rn = 0;
@@ -1799,7 +1834,7 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, int L, int stride, long 
 
 // locate + sort + filtered votes of one re-seeded mate; the list goes to the R buffer (cur = 2)
 __global__ void __launch_bounds__(64)
-k_pes_vote(DevIndex ix, long n, int k, long long maxd, long long mind, const u64* __restrict__ count_ptr, const u32* __restrict__ plist,
+k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ count_ptr, const u32* __restrict__ plist,
            const u64* __restrict__ roff, ReadState st, PeState ps, u64* __restrict__ rcand, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1807,6 +1842,9 @@ k_pes_vote(DevIndex ix, long n, int k, long long maxd, long long mind, const u64
     const long p = plist[it];
     const int f = ps.first[p];
     const long rF = p + (long)f * n, r = p + (long)(1 - f) * n;
+    const int k = gm.rk(gm.rl(r));
+    long long maxd, mind; int large_k;
+    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
     const u64 o0 = roff[it], o1 = roff[it + 1];
     ps.roff[r] = o0;
     const long nc = (long)(o1 - o0);
@@ -1837,10 +1875,12 @@ k_pes_vote(DevIndex ix, long n, int k, long long maxd, long long mind, const u64
 
 // new_faster_verify_pairs (Schema.cpp:15773-15900) + hand-over of the winning candidates to K11-K13
 __global__ void __launch_bounds__(64)
-k_pe_pair(long n, int large_k, int ambiguous_out, long long maxd, long long mind, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+k_pe_pair(long n, ReadGeom gm, PeIns pi, int ambiguous_out, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    long long maxd, mind; int large_k;
+    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
     const long r1 = p, r2 = p + n;
     st.job_flag[r1] = 0; st.job_flag[r2] = 0;
     st.red_status[r1] = 0; st.red_status[r2] = 0;
@@ -1893,7 +1933,8 @@ k_pe_pair(long n, int large_k, int ambiguous_out, long long maxd, long long mind
 // per-pair post-processing (Schema.cpp:19330-19480): placement of both mates (output_sam_end_to_end_return,
 // 9188), TLEN (Schema.h:1587), insert/chromosome-end checks, MAPQ over k1+k2, flags 99/83/147/163, stats
 __global__ void __launch_bounds__(256)
-k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, int k, int min_ins, int max_ins, int ambiguous_out, long n,
+k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, const u32* __restrict__ mapq_off, int unit, ReadGeom gm, int min_ins, int max_ins,
+              int ambiguous_out, long n,
               ReadState st, PeState ps, const int* __restrict__ a_start, const int* __restrict__ a_end,
               const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops, int max_ops,
               bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
@@ -1925,7 +1966,7 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, in
                     const int no = a_nops[jb];
                     o[m].cigar_off = (u32)(jb * (u64)max_ops);
                     o[m].n_cigar = no < 0 ? 255 : (u8)no;
-                } else { end_site = st.best_end[r]; start_site = end_site - L + 1; nm[m] = 0; score[m] = 0; }
+                } else { end_site = st.best_end[r]; start_site = end_site - gm.rl(r) + 1; nm[m] = 0; score[m] = 0; }
                 u64 loc = site;
                 if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; rflag[m] = 16; }
                 else { loc = loc + (u64)start_site; rflag[m] = 0; }
@@ -1944,10 +1985,13 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, in
             const int tlen = (int)(mx - mn + 1);
             if (tlen <= max_ins && tlen >= min_ins && inrange) {
                 status = np == 1 ? 1 : 2;
+                // MAP_Calculation over error_threshold1 + error_threshold2 (Schema.cpp:19445)
+                const int L1 = gm.rl(p), L2 = gm.rl(p + n);
+                const u32 kk = (u32)(gm.rk(L1) + gm.rk(L2)), sb = ps.sbd[p];
+                const int range = unit * (int)kk;
                 int sd = score[0] + score[1] + range; if (sd < 0) sd = 0; if (sd > range) sd = range;
-                const u32 kk = 2u * (u32)k, sb = ps.sbd[p];
                 const u32 ed = sb > kk ? kk + 1 : sb;
-                const int mapq = mapq_lut[(size_t)ed * (range + 1) + sd];
+                const int mapq = mapq_lut[mapq_off[kk] + (size_t)ed * (range + 1) + sd];
                 for (int m = 0; m < 2; m++) {
                     o[m].pos = (u64)site_pos[m]; o[m].chrom = (int16_t)chrom[m]; o[m].mapq = (u8)mapq; o[m].nm = (u16)nm[m];
                     o[m].score = (int16_t)score[m]; o[m].reserved = (u32)tlen; o[m].path = 3;
@@ -1955,7 +1999,7 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, int range, int L, in
                 o[0].flag = (u16)(rflag[0] == 0 ? (1 | 2 | 32 | 64) : (1 | 2 | 16 | 64));
                 o[1].flag = (u16)(rflag[1] == 0 ? (1 | 2 | 16 | 128) : (1 | 2 | 32 | 128));
                 if (np == 1) atomicAdd(&sh[1], 1ull);
-                atomicAdd(&sh[3], 2ull * (unsigned long long)L);
+                atomicAdd(&sh[3], (unsigned long long)(L1 + L2));
                 atomicAdd(&sh[4], (unsigned long long)(nm[0] + nm[1]));
             } else status = 3;
         }

@@ -12,9 +12,9 @@
 // The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
 // what limits it.  Here the host side is a three-stage, order-preserving pipeline so that
 // the GPU is fed at memory speed:
-//   stage R  window of the (mmap'ed) FASTQ -> newline index built by the I/O threads -> records grouped by read
-//            length (k = (uint64)(e*L) is per length, Schema.cpp:24546) and packed into page-locked staging rows
-//   stage G  one bmbs_map_se / bmbs_map_pe call per length group (the only stage that touches the GPU)
+//   stage R  window of the (mmap'ed) FASTQ -> newline index built by the I/O threads -> records packed into page-locked
+//            staging rows, every read with its own length (k = (uint64)(e*L) is per read, Schema.cpp:24546)
+//   stage G  one bmbs_map_se[_var] / bmbs_map_pe[_var] call per batch (the only stage that touches the GPU)
 //   stage W  SAM text formatted by the I/O threads into per-slice buffers, written with pwrite at prefix offsets
 // Batches circulate through hand-over queues, so stage R of batch i+1 and stage W of batch i-1 overlap stage G of i.
 #include "../../include/bmbs.h"
@@ -248,6 +248,8 @@ struct Batch {
     std::vector<Group> groups;
     std::vector<uint32_t> row;                   // record -> staging row (global over the groups); ~0u = not mapped
     std::vector<uint16_t> grp;                   // record -> group
+    std::vector<uint16_t> len1, len2;            // row -> read length (mate 1 / mate 2)
+    bool uniform = true;                         // every read of the batch has the same length
     Pinned seq1, qual1, seq2, qual2, res, pool;
     std::vector<std::vector<char>> text;         // SAM text per formatter slice (capacity kept from batch to batch)
     std::vector<size_t> text_len;
@@ -439,94 +441,76 @@ int main(int argc, char** argv)
             if (pe) { b->l2.used = std::min(n2, b->l2.nl[(size_t)nrec * 4 - 1] + 1); src2.consumed(p2, n2, b->l2.used); }
             est = std::max<size_t>(64, used1 / (size_t)nrec + 16);
             b->n = nrec;
-            // ---- length groups (counting sort by read length, input order kept inside a group)
+            // ---- one batch = one library call: every record keeps its own length (bmbs_map_*_var), rows in input order
             const int T = pool.size();
             const long per = (nrec + T - 1) / T;
-            lens.resize((size_t)nrec);
-            int maxL = 0;
-            {
-                std::vector<int> mx((size_t)T, 0);
-                pool.run(T, [&](int t) {
-                    const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
-                    int m = 0;
-                    for (long r = a; r < e; r++) {
-                        const uint32_t L1 = (uint32_t)(b->l1.end((size_t)r * 4 + 1) - b->l1.start((size_t)r * 4 + 1));
-                        uint32_t key = L1;
-                        if (pe) {
-                            const uint32_t L2 = (uint32_t)(b->l2.end((size_t)r * 4 + 1) - b->l2.start((size_t)r * 4 + 1));
-                            if (L2 != L1) key = NOROW;                // mates of different lengths: not mapped (reported below)
-                        }
-                        if (L1 == 0 || L1 > 1000) key = NOROW;
-                        lens[(size_t)r] = key;
-                        if (key != NOROW && (int)key > m) m = (int)key;
-                    }
-                    mx[(size_t)t] = m;
-                });
-                for (int m : mx) maxL = std::max(maxL, m);
-            }
-            std::vector<std::vector<long>> hist((size_t)T, std::vector<long>((size_t)maxL + 1, 0));
-            std::vector<long> skipped((size_t)T, 0);
+            lens.resize((size_t)nrec * 2);                                  // L1, L2 (0 = not mapped)
+            std::vector<int> mx((size_t)T, 0), mn((size_t)T, 1 << 30);
+            std::vector<long> valid((size_t)T + 1, 0);
             pool.run(T, [&](int t) {
                 const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
-                for (long r = a; r < e; r++) { if (lens[(size_t)r] == NOROW) skipped[(size_t)t]++; else hist[(size_t)t][lens[(size_t)r]]++; }
+                int m = 0, lo = 1 << 30;
+                long v = 0;
+                for (long r = a; r < e; r++) {
+                    uint32_t L1 = (uint32_t)(b->l1.end((size_t)r * 4 + 1) - b->l1.start((size_t)r * 4 + 1)), L2 = 0;
+                    bool ok = L1 >= 1 && L1 <= 1000;
+                    if (pe) { L2 = (uint32_t)(b->l2.end((size_t)r * 4 + 1) - b->l2.start((size_t)r * 4 + 1)); ok = ok && L2 >= 1 && L2 <= 1000; }
+                    if (!ok) { L1 = 0; L2 = 0; }
+                    lens[(size_t)r * 2] = L1; lens[(size_t)r * 2 + 1] = L2;
+                    if (ok) { v++; m = std::max(m, (int)std::max(L1, L2)); lo = std::min(lo, (int)L1); if (pe) lo = std::min(lo, (int)L2); }
+                }
+                mx[(size_t)t] = m; mn[(size_t)t] = lo; valid[(size_t)t + 1] = v;
             });
-            long nskip = 0;
-            for (long s : skipped) nskip += s;
-            if (nskip) fprintf(stderr, "bmbs_search: %ld %s skipped (%s)\n", nskip, pe ? "pairs" : "reads",
-                               pe ? "mates of different lengths are not supported by the device path yet, or empty / longer than 1000" : "empty or longer than 1000");
-            std::vector<int> group_of_len((size_t)maxL + 1, -1);
-            size_t row0 = 0, byte0 = 0, pool0 = 0;
-            for (int L = 1; L <= maxL; L++) {
-                long c = 0;
-                for (int t = 0; t < T; t++) c += hist[(size_t)t][(size_t)L];
-                if (!c) continue;
-                Group g; g.L = L; g.count = c; g.stride = (L + 15) / 16 * 16; g.row0 = row0; g.byte0 = byte0; g.pool0 = pool0;
-                int k = (int)(uint64_t)(P.e_f * L); if (k > 31) k = 31;
+            int maxL = 0, minL = 1 << 30;
+            for (int t = 0; t < T; t++) { maxL = std::max(maxL, mx[(size_t)t]); minL = std::min(minL, mn[(size_t)t]); valid[(size_t)t + 1] += valid[(size_t)t]; }
+            const long nvalid = valid[(size_t)T];
+            if (nvalid != nrec) fprintf(stderr, "bmbs_search: %ld %s skipped (empty or longer than 1000 characters)\n", nrec - nvalid, pe ? "pairs" : "reads");
+            size_t byte0 = 0, pool0 = 0;
+            if (nvalid) {
+                Group g; g.L = maxL; g.count = nvalid; g.stride = (maxL + 15) / 16 * 16; g.row0 = 0; g.byte0 = 0; g.pool0 = 0;
+                int k = (int)(uint64_t)(P.e_f * maxL); if (k > 31) k = 31;
                 g.k = k;
-                group_of_len[(size_t)L] = (int)b->groups.size();
                 b->groups.push_back(g);
-                row0 += (size_t)c; byte0 += (size_t)c * (size_t)g.stride; pool0 += (size_t)c * (size_t)(2 * k + 8) * (pe ? 2 : 1);
+                byte0 = (size_t)nvalid * (size_t)g.stride; pool0 = (size_t)nvalid * (size_t)(2 * k + 8) * (pe ? 2 : 1);
             }
-            std::vector<std::vector<long>> first((size_t)T, std::vector<long>(b->groups.size(), 0));    // first row of slice t in group g
-            for (size_t g = 0; g < b->groups.size(); g++) {
-                long acc = 0;
-                for (int t = 0; t < T; t++) { first[(size_t)t][g] = acc; acc += hist[(size_t)t][(size_t)b->groups[g].L]; }
-            }
+            b->uniform = minL == maxL;
             if (!b->seq1.need(byte0 + 64) || !b->qual1.need(byte0 + 64) || (pe && (!b->seq2.need(byte0 + 64) || !b->qual2.need(byte0 + 64))) ||
-                !b->res.need(row0 * sizeof(bmbs_result) * (pe ? 2 : 1) + 64) || !b->pool.need(pool0 * 4 + 64)) {
+                !b->res.need((size_t)nvalid * sizeof(bmbs_result) * (pe ? 2 : 1) + 64) || !b->pool.need(pool0 * 4 + 64)) {
                 fprintf(stderr, "bmbs_search: cannot allocate page-locked staging memory\n");
                 failed = true; b->end = true; b->n = 0; b->groups.clear(); gpu_q.put(b); return;
             }
             b->row.resize((size_t)nrec); b->grp.resize((size_t)nrec);
+            b->len1.resize((size_t)nvalid + 1); b->len2.resize(pe ? (size_t)nvalid + 1 : 1);
             pool.run(T, [&](int t) {
                 const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
-                std::vector<long> nextrow = first[(size_t)t];
+                long j = valid[(size_t)t];
                 for (long r = a; r < e; r++) {
-                    const uint32_t key = lens[(size_t)r];
-                    if (key == NOROW) { b->row[(size_t)r] = NOROW; b->grp[(size_t)r] = 0; continue; }
-                    const int gi = group_of_len[key];
-                    const Group& g = b->groups[(size_t)gi];
-                    const long j = nextrow[(size_t)gi]++;
-                    b->row[(size_t)r] = (uint32_t)(g.row0 + (size_t)j); b->grp[(size_t)r] = (uint16_t)gi;
-                    const int L = g.L;
-                    const size_t at = g.byte0 + (size_t)j * (size_t)g.stride;
-                    auto pack = [&](const Lines& ln, char* sdst, char* qdst) {
+                    const int L1 = (int)lens[(size_t)r * 2], L2 = (int)lens[(size_t)r * 2 + 1];
+                    b->grp[(size_t)r] = 0;
+                    if (L1 == 0) { b->row[(size_t)r] = NOROW; continue; }
+                    const Group& g = b->groups[0];
+                    b->row[(size_t)r] = (uint32_t)j;
+                    b->len1[(size_t)j] = (uint16_t)L1;
+                    if (pe) b->len2[(size_t)j] = (uint16_t)L2;
+                    const size_t at = (size_t)j * (size_t)g.stride;
+                    j++;
+                    auto pack = [&](const Lines& ln, int L, bool rc, char* sdst, char* qdst) {
                         const char* s = ln.p + ln.start((size_t)r * 4 + 1);
                         const size_t qs = ln.start((size_t)r * 4 + 3), qe = ln.end((size_t)r * 4 + 3);
                         const int ql = (int)std::min<size_t>((size_t)L, qe - qs);
-                        if (!pbat_se) {
+                        if (!rc) {
                             for (int i = 0; i < L; i++) { const char c = s[i]; sdst[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
                             memcpy(qdst, ln.p + qs, (size_t)ql);
                             for (int i = ql; i < L; i++) qdst[i] = ' ';      // qual.resize(seq.size(), ' ')
                         } else {
                             for (int i = 0; i < L; i++) { const char c = s[L - 1 - i]; sdst[i] = rc_char((c >= 'a' && c <= 'z') ? (char)(c - 32) : c); }
                             const char* q = ln.p + qs;
-                            for (int i = 0; i < L; i++) { const int j = L - 1 - i; qdst[i] = j < ql ? q[j] : ' '; }
+                            for (int i = 0; i < L; i++) { const int jj = L - 1 - i; qdst[i] = jj < ql ? q[jj] : ' '; }
                         }
                         for (int i = L; i < g.stride; i++) { sdst[i] = 0; qdst[i] = 0; }
                     };
-                    pack(b->l1, b->seq1.p + at, b->qual1.p + at);
-                    if (pe) pack(b->l2, b->seq2.p + at, b->qual2.p + at);
+                    pack(b->l1, L1, pbat_se, b->seq1.p + at, b->qual1.p + at);
+                    if (pe) pack(b->l2, L2, false, b->seq2.p + at, b->qual2.p + at);
                 }
             });
             t_read += now() - t0;
@@ -570,8 +554,8 @@ int main(int argc, char** argv)
                         const uint32_t row = b->row[(size_t)r];
                         if (row == NOROW) continue;
                         const Group& g = b->groups[b->grp[(size_t)r]];
-                        const int L = g.L;
                         const size_t j = (size_t)row - g.row0;
+                        const int L = (int)b->len1[j], L2 = pe ? (int)b->len2[j] : 0;
                         const size_t at = g.byte0 + j * (size_t)g.stride;
                         const uint32_t* gp = cpool + g.pool0;
                         const char* nm = b->l1.p + b->l1.start((size_t)r * 4);
@@ -612,7 +596,7 @@ int main(int argc, char** argv)
                                 o.mem(nm, nl); o.lit("\t77\t*\t0\t0\t*\t*\t0\t0\t");
                                 o.seq(b->seq1.p + at, b->qual1.p + at, L, false); o.ch('\n');
                                 o.mem(nm, nl); o.lit("\t141\t*\t0\t0\t*\t*\t0\t0\t");
-                                o.seq(b->seq2.p + at, b->qual2.p + at, L, false); o.ch('\n');
+                                o.seq(b->seq2.p + at, b->qual2.p + at, L2, false); o.ch('\n');
                                 continue;
                             }
                             const unsigned tlen = x1.reserved;
@@ -625,10 +609,10 @@ int main(int argc, char** argv)
                             o.lit("\tNM:i:"); o.num(x1.nm); o.ch('\n');
                             o.mem(nm, nl); o.ch('\t');
                             o.num(x2.flag); o.ch('\t'); o.str(chrom_names[(size_t)x2.chrom]); o.ch('\t'); o.num(x2.pos); o.ch('\t');
-                            o.num(x2.mapq); o.ch('\t'); o.cigar(x2, gp, L); o.lit("\t=\t"); o.num(x1.pos); o.ch('\t');
+                            o.num(x2.mapq); o.ch('\t'); o.cigar(x2, gp, L2); o.lit("\t=\t"); o.num(x1.pos); o.ch('\t');
                             if (!(x1.pos > x2.pos)) o.ch('-');           // Schema.cpp:11530-11555
                             o.num(tlen); o.ch('\t');
-                            o.seq(b->seq2.p + at, b->qual2.p + at, L, (x2.flag & 16) != 0);
+                            o.seq(b->seq2.p + at, b->qual2.p + at, L2, (x2.flag & 16) != 0);
                             o.lit("\tNM:i:"); o.num(x2.nm); o.ch('\n');
                         }
                     }
@@ -689,13 +673,19 @@ int main(int argc, char** argv)
             for (const Group& g : b->groups) {
                 int64_t used = 0;
                 int rc;
-                if (!pe)
-                    rc = bmbs_map_se(ctx, b->seq1.p + g.byte0, b->qual1.p + g.byte0, g.L, g.stride, g.count, (bmbs_result*)b->res.p + g.row0,
-                                     (uint32_t*)b->pool.p + g.pool0, (int64_t)g.count * (2 * g.k + 8), &used);
+                // equal lengths take the fixed-length entry points, a trimmed library the per-read-length ones
+                if (!pe && b->uniform)
+                    rc = bmbs_map_se(ctx, b->seq1.p, b->qual1.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p,
+                                     (int64_t)g.count * (2 * g.k + 8), &used);
+                else if (!pe)
+                    rc = bmbs_map_se_var(ctx, b->seq1.p, b->qual1.p, b->len1.data(), g.L, g.stride, g.count, (bmbs_result*)b->res.p,
+                                         (uint32_t*)b->pool.p, (int64_t)g.count * (2 * g.k + 8), &used);
+                else if (b->uniform)
+                    rc = bmbs_map_pe(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p,
+                                     (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
                 else
-                    rc = bmbs_map_pe(ctx, b->seq1.p + g.byte0, b->qual1.p + g.byte0, b->seq2.p + g.byte0, b->qual2.p + g.byte0, g.L, g.stride,
-                                     g.count, (bmbs_result*)b->res.p + 2 * g.row0, (uint32_t*)b->pool.p + g.pool0,
-                                     (int64_t)g.count * 2 * (2 * g.k + 8), &used);
+                    rc = bmbs_map_pe_var(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, b->len1.data(), b->len2.data(), g.L, g.stride,
+                                         g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
                 if (rc) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); failed = true; break; }
             }
         total_records += b->n;

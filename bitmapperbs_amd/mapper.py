@@ -117,6 +117,35 @@ class Mapper:
         self._chk(self._lib.bmbs_map_pe_device(self._ctx, d_seq1, d_qual1, d_seq2, d_qual2, L, stride, n, d_results,
                                                d_cigar_pool, cigar_cap))
 
+    # ---- reads of different lengths in one batch (trimmed libraries) -------------------------------
+    def map_se_var(self, seq: np.ndarray, qual: np.ndarray, lens: np.ndarray):
+        """seq/qual: uint8 [n, stride]; lens[i] <= stride valid characters in row i"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        n, stride = seq.shape
+        L = int(lens.max()) if n else 1
+        res = np.zeros(n, dtype=capi.RESULT_DTYPE)
+        cap = max(1, n * (2 * self.threshold(L) + 8))
+        pool = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        self._chk(self._lib.bmbs_map_se_var(self._ctx, capi.ptr(seq), capi.ptr(qual), capi.ptr(lens), L, stride, n, capi.ptr(res),
+                                            capi.ptr(pool), cap, C.byref(used)))
+        return res, pool[:used.value]
+
+    def map_pe_var(self, seq1, qual1, seq2, qual2, lens1, lens2):
+        a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (seq1, qual1, seq2, qual2)]
+        l1 = np.ascontiguousarray(lens1, dtype=np.uint16); l2 = np.ascontiguousarray(lens2, dtype=np.uint16)
+        n, stride = a[0].shape
+        L = int(max(l1.max(), l2.max())) if n else 1
+        res = np.zeros(2 * n, dtype=capi.RESULT_DTYPE)
+        cap = max(1, 2 * n * (2 * self.threshold(L) + 8))
+        pool = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        self._chk(self._lib.bmbs_map_pe_var(self._ctx, capi.ptr(a[0]), capi.ptr(a[1]), capi.ptr(a[2]), capi.ptr(a[3]), capi.ptr(l1),
+                                            capi.ptr(l2), L, stride, n, capi.ptr(res), capi.ptr(pool), cap, C.byref(used)))
+        return res, pool[:used.value]
+
     def sync(self):
         self._chk(self._lib.bmbs_sync(self._ctx))
 

@@ -145,6 +145,23 @@ int bmbs_map_se_device(bmbs_ctx*, uint64_t d_seq, uint64_t d_qual, int32_t L, in
                        int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap);
 int bmbs_sync(bmbs_ctx*);
 
+/* ---- reads of different lengths in ONE batch (reads_soa.len of SURVEY.md section 8b; a trimmed library).  The reference maps
+ * read by read and derives everything from current_read.length (error_threshold1 = thread_e_f * length, Schema.cpp:24546;
+ * seed count L/10-1; p_length = L + 2k; MAP_Calculation over that read's threshold).  len[i] in [1, L_max], rows are still
+ * `stride` bytes apart (stride >= L_max), bytes past len[i] are ignored.  The CIGAR pool reserves 2*k(L_max)+8 ops per read.
+ * Paired-end: mates of one pair may have different lengths (the insert window uses the larger threshold and the longer
+ * mate, Schema.cpp:18900-18935).  d_len of the device form = u16[2n]: the n first mates, then the n second mates.     */
+int bmbs_map_se_var(bmbs_ctx*, const char* seq, const char* qual, const uint16_t* len, int32_t L_max, int32_t stride,
+                    int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used);
+int bmbs_map_se_var_device(bmbs_ctx*, uint64_t d_seq, uint64_t d_qual, uint64_t d_len, int32_t L_max, int32_t stride,
+                           int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap);
+int bmbs_map_pe_var(bmbs_ctx*, const char* seq1, const char* qual1, const char* seq2, const char* qual2,
+                    const uint16_t* len1, const uint16_t* len2, int32_t L_max, int32_t stride, int64_t n_pairs,
+                    bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used);
+int bmbs_map_pe_var_device(bmbs_ctx*, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, uint64_t d_len,
+                           int32_t L_max, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
+                           int64_t cigar_cap);
+
 /* ---- fused paired-end mapping, default (fast) mode: Map_Pair_Seq_end_to_end_fast (Schema.cpp:18570-19546)
  * = get_candidates x2 (18172), filter_pairs (16052), verify_candidate_locations (18130) on the smaller side,
  * filter_pairs_single_side (16186), new_faster_verify_pairs (15773), calculate_best_map_cigar_end_to_end_return

@@ -107,6 +107,10 @@ int orc_map_pe(const orc_index*, const orc_params*, const char* seq1, const char
                const char* qual2, int L1, int L2, int stride, int64_t n, orc_pe_rec* recs, int64_t stats[5],
                orc_counters* counters);
 
+int orc_map_pe_var(const orc_index*, const orc_params*, const char* seq1, const char* qual1, const char* seq2,
+                   const char* qual2, const int32_t* len1, const int32_t* len2, int stride, int64_t n, orc_pe_rec* recs,
+                   int64_t stats[5], orc_counters* counters);
+
 /* whole-program equivalents (FASTQ -> SAM); return 0 on success.  argv_line is printed in @PG CL */
 int orc_search_se(const orc_index*, const orc_params*, const char* fastq, const char* out_sam,
                   const char* argv_line, int64_t stats[5]);

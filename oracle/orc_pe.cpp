@@ -555,6 +555,20 @@ extern "C" int orc_map_pe(const orc_index* ix, const orc_params* P, const char* 
     return 0;
 }
 
+// the same with per-pair mate lengths (mates of one pair may differ, Schema.cpp:18900-18935 uses both lengths)
+extern "C" int orc_map_pe_var(const orc_index* ix, const orc_params* P, const char* seq1, const char* qual1, const char* seq2,
+                              const char* qual2, const int32_t* len1, const int32_t* len2, int stride, int64_t n,
+                              orc_pe_rec* recs, int64_t stats[5], orc_counters* counters)
+{
+    int64_t st[5] = {0, 0, 0, 0, 0};
+    if (counters) memset(counters, 0, sizeof(*counters));
+    for (int64_t i = 0; i < n; i++)
+        map_one_pe(ix, P, seq1 + (size_t)i * stride, qual1 + (size_t)i * stride, len1[i], seq2 + (size_t)i * stride,
+                   qual2 + (size_t)i * stride, len2[i], &recs[i], st, counters);
+    for (int j = 0; j < 5; j++) stats[j] = st[j];
+    return 0;
+}
+
 // inputReads_paired_directly (Process_Reads.cpp:155-317) + the two record writers
 extern "C" int orc_search_pe(const orc_index* ix, const orc_params* P, const char* fq1, const char* fq2,
                              const char* out_sam, const char* argv_line, int64_t stats[5])

@@ -91,3 +91,15 @@ def pbat_fastq(src, dst):
         lines = f.read().split(b"\n")
         for i in range(0, len(lines) - 3, 4):
             o.write(lines[i] + b"\n" + lines[i + 1].translate(comp)[::-1] + b"\n" + lines[i + 2] + b"\n" + lines[i + 3][::-1] + b"\n")
+
+
+def trim_fastq(src, dst, seed, lo=30):
+    """every record cut to a seeded random length in [lo, len] at its 3' end (what an adapter/quality trimmer leaves)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    with open(src, "rb") as f, open(dst, "wb") as o:
+        lines = f.read().split(b"\n")
+        for i in range(0, len(lines) - 3, 4):
+            n = len(lines[i + 1])
+            k = int(rng.integers(min(lo, n), n + 1)) if rng.random() < 0.7 else n
+            o.write(lines[i] + b"\n" + lines[i + 1][:k] + b"\n" + lines[i + 2] + b"\n" + lines[i + 3][:k] + b"\n")

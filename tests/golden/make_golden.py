@@ -48,6 +48,10 @@ VARIANTS = {
     "pe_p75_ua": dict(kind="pe", base="p75", args=["--min", "100", "--max", "250", "--unmapped_out", "--ambiguous_out"]),
     "pe_s100_ua": dict(kind="pe", base="s100", args=["--sensitive", "--unmapped_out", "--ambiguous_out"]),
     # PE pbat = the two files swap roles (exchange_two_reads): hand them over swapped so that the pairs map
+    # trimmed libraries: every read its own length (common.trim_fastq); mates of a pair trimmed independently
+    "se_b150_trim": dict(kind="se", base="b150", trim=[7], args=["-e", "0.04", "--unmapped_out"]),
+    "pe_p100_trim": dict(kind="pe", base="p100", trim=[8, 9], args=["-e", "0.04", "--max", "520", "--ambiguous_out"]),
+    "pe_s100_trim": dict(kind="pe", base="s100", trim=[10, 11], args=["--sensitive"]),
     "pe_p100_pbat": dict(kind="pe", base="p100", swap=True, args=["-e", "0.04", "--max", "520", "--pbat", "--unmapped_out"]),
 }
 
@@ -120,17 +124,23 @@ def main():
         open(os.path.join(HERE, "pe_%s.ref.stats" % name), "w").write(stats)
         print("PE", name, "lines", body.count("\n"), stats.splitlines()[1])
     json.dump({k: v["args"] for k, v in PE_SETS.items()}, open(os.path.join(HERE, "pe_args.json"), "w"))
-    from common import pbat_fastq
+    from common import pbat_fastq, trim_fastq
     for name, v in VARIANTS.items():
         sam = os.path.join(wd, name + ".sam")
         if v["kind"] == "se":
             fq = os.path.join(wd, "se_%s.fq" % v["base"])
             if v.get("pbat"):
                 pbat_fastq(fq, fq[:-3] + "_pbat.fq"); fq = fq[:-3] + "_pbat.fq"
+            if v.get("trim"):
+                trim_fastq(fq, fq[:-3] + "_trim.fq", v["trim"][0]); fq = fq[:-3] + "_trim.fq"
             inp = ["--seq", fq]
         else:
             a, b = (2, 1) if v.get("swap") else (1, 2)
-            inp = ["--seq1", os.path.join(wd, "pe_%s_%d.fq" % (v["base"], a)), "--seq2", os.path.join(wd, "pe_%s_%d.fq" % (v["base"], b))]
+            fa_, fb_ = os.path.join(wd, "pe_%s_%d.fq" % (v["base"], a)), os.path.join(wd, "pe_%s_%d.fq" % (v["base"], b))
+            if v.get("trim"):
+                trim_fastq(fa_, fa_[:-3] + "_trim.fq", v["trim"][0]); trim_fastq(fb_, fb_[:-3] + "_trim.fq", v["trim"][1])
+                fa_, fb_ = fa_[:-3] + "_trim.fq", fb_[:-3] + "_trim.fq"
+            inp = ["--seq1", fa_, "--seq2", fb_]
         p = subprocess.run([ref, "--search", fa] + inp + ["-t", "1", "-o", sam] + v["args"], capture_output=True, text=True, cwd=wd)
         assert p.returncode == 0, p.stderr
         body = "".join(l for l in open(sam) if not l.startswith("@PG"))

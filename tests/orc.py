@@ -58,6 +58,7 @@ def load():
     L.orc_sa_at.restype = C.c_uint64
     L.orc_map_se.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, i32, i64, vp, vp, vp]
     L.orc_map_pe.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp]
+    L.orc_map_pe_var.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp]
     L.orc_search_se.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, vp]
     L.orc_search_pe.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp]
     assert C.sizeof(OrcParams) == 64
@@ -98,6 +99,38 @@ class OrcIndex:
         rc = self.L.orc_map_se(self.h, C.byref(prm), seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, stride, n,
                                recs.ctypes.data, st.ctypes.data, cnt.ctypes.data)
         assert rc == 0
+        return recs, st, dict(zip(COUNTER_KEYS, (int(x) for x in cnt)))
+
+    def map_se_var(self, prm, seq, qual, lens):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        n, stride = seq.shape
+        ln = np.ascontiguousarray(lens, dtype=np.int32)
+        recs = np.zeros(n, dtype=REC_DTYPE)
+        st = np.zeros(5, dtype=np.int64)
+        cnt = np.zeros(len(COUNTER_KEYS), dtype=np.uint64)
+        rc = self.L.orc_map_se(self.h, C.byref(prm), seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, stride, n,
+                               recs.ctypes.data, st.ctypes.data, cnt.ctypes.data)
+        assert rc == 0
+        return recs, st, dict(zip(COUNTER_KEYS, (int(x) for x in cnt)))
+
+    def map_pe_var(self, prm, seq1, qual1, seq2_fastq, qual2, lens1, lens2):
+        """per-pair mate lengths; seq2_fastq = mate 2 as in the FASTQ (left-aligned rows)"""
+        comp = np.arange(256, dtype=np.uint8)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (seq1, qual1, seq2_fastq, qual2)]
+        n, stride = a[0].shape
+        l1 = np.ascontiguousarray(lens1, dtype=np.int32); l2 = np.ascontiguousarray(lens2, dtype=np.int32)
+        s2 = np.zeros_like(a[2])
+        for i in range(n):
+            s2[i, :l2[i]] = comp[a[2][i, :l2[i]]][::-1]
+        recs = np.zeros(n, dtype=PE_REC_DTYPE)
+        st = np.zeros(5, dtype=np.int64)
+        cnt = np.zeros(len(COUNTER_KEYS), dtype=np.uint64)
+        rc = self.L.orc_map_pe_var(self.h, C.byref(prm), a[0].ctypes.data, a[1].ctypes.data, s2.ctypes.data, a[3].ctypes.data,
+                                   l1.ctypes.data, l2.ctypes.data, stride, n, recs.ctypes.data, st.ctypes.data, cnt.ctypes.data)
+        assert rc == 0, rc
         return recs, st, dict(zip(COUNTER_KEYS, (int(x) for x in cnt)))
 
     def map_pe(self, prm, seq1, qual1, seq2_fastq, qual2, L):

@@ -29,10 +29,12 @@ def compare_records(res, pool, recs, L, amb=False):
         neq = mapped[res[f][mapped].astype(np.int64) != recs[f][mapped].astype(np.int64)]
         for i in neq[:5]:
             bad.append((int(i), f, int(res[i][f]), int(recs[i][f])))
+    Ls = np.broadcast_to(np.asarray(L), (res.size,))           # scalar or per-read lengths
     for i in mapped:
-        if int(res[i]["n_cigar"]) or recs[i]["cigar"] != b"%dM" % L:
-            if mapper.cigar_text(res[i], pool, L) != recs[i]["cigar"].decode():
-                bad.append((int(i), "cigar", mapper.cigar_text(res[i], pool, L), recs[i]["cigar"].decode()))
+        Li = int(Ls[i])
+        if int(res[i]["n_cigar"]) or recs[i]["cigar"] != b"%dM" % Li:
+            if mapper.cigar_text(res[i], pool, Li) != recs[i]["cigar"].decode():
+                bad.append((int(i), "cigar", mapper.cigar_text(res[i], pool, Li), recs[i]["cigar"].decode()))
     return bad
 
 
@@ -251,10 +253,11 @@ def test_full_size_properties_idempotent_and_split_invariant(env):
 
 
 # ---- paired end (fast mode) ------------------------------------------------------------------------
-def compare_pe(res, pool, recs, L):
+def compare_pe(res, pool, recs, L, L2=None):
     from bitmapperbs_amd import mapper
     bad = []
     n = recs.size
+    La = np.broadcast_to(np.asarray(L), (n,)); Lb = La if L2 is None else np.broadcast_to(np.asarray(L2), (n,))
     for i in range(n):
         a1, a2, b = res[2 * i], res[2 * i + 1], recs[i]
         if int(a1["status"]) != int(b["status"]) or int(a2["status"]) != int(b["status"]):
@@ -263,7 +266,7 @@ def compare_pe(res, pool, recs, L):
             continue
         got = (int(a1["flag"]), int(a2["flag"]), int(a1["chrom"]), int(a2["chrom"]), int(a1["pos"]), int(a2["pos"]), int(a1["mapq"]),
                int(a2["mapq"]), int(a1["nm"]), int(a2["nm"]), int(a1["score"]), int(a2["score"]), int(a1["reserved"]),
-               mapper.cigar_text(a1, pool, L), mapper.cigar_text(a2, pool, L))
+               mapper.cigar_text(a1, pool, int(La[i])), mapper.cigar_text(a2, pool, int(Lb[i])))
         exp = (int(b["flag1"]), int(b["flag2"]), int(b["chrom1"]), int(b["chrom2"]), int(b["pos1"]), int(b["pos2"]), int(b["mapq"]),
                int(b["mapq"]), int(b["nm1"]), int(b["nm2"]), int(b["score1"]), int(b["score2"]), int(b["tlen"]),
                b["cigar1"].decode(), b["cigar2"].decode())
@@ -390,3 +393,50 @@ def test_cpp_driver_output_variants_equal_reference_golden(name, tmp_path):
     assert mine == gzip.open(os.path.join(GOLD, "var_%s.ref.sam.gz" % name), "rt").read()
     stats = "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
     assert stats == open(os.path.join(GOLD, "var_%s.ref.stats" % name)).read()
+
+
+# ---- reads of different lengths in one batch (bmbs_map_se_var / bmbs_map_pe_var) ----------------------------------------
+def _trim(rows, lens):
+    out = rows.copy()
+    cols = np.arange(rows.shape[1])[None, :]
+    out[cols >= lens[:, None]] = 0
+    return out
+
+
+@pytest.mark.parametrize("e", [0.08, 0.04, 0.12])
+def test_map_se_mixed_lengths_match_oracle(e, env):
+    """a trimmed library: every read its own length, threshold, seed count and MAPQ table"""
+    from bitmapperbs_amd import synth, mapper
+    r = synth.make_reads_se(env["chroms"], n=30000, L=150, seed=31, sub=0.02, indel=0.002, qual="random", n_rate=0.002)
+    rng = np.random.default_rng(32)
+    lens = rng.integers(20, 151, 30000).astype(np.uint16)
+    lens[:2000] = 150; lens[2000:2100] = 17; lens[2100:2200] = 36
+    seq, qual = _trim(r["seq"], lens), _trim(r["qual"], lens)
+    m = mapper.Mapper(env["ix"], 0, e_f=e)
+    res, pool = m.map_se_var(seq, qual, lens)
+    recs, ost, cnt = env["oix"].map_se_var(orc.params(e_f=e), seq, qual, lens)
+    assert (recs["status"] == 1).sum() > 15000
+    bad = compare_records(res, pool, recs, lens)
+    assert not bad, bad[:10]
+    assert (m.stats() == ost).all(), (m.stats(), ost)
+    m.close()
+
+
+@pytest.mark.parametrize("prm", [dict(), dict(sensitive=1), dict(e_f=0.04, max_ins=520, ambiguous_out=1)], ids=["fast", "sensitive", "e004_amb"])
+def test_map_pe_mixed_lengths_match_oracle(prm, env):
+    """mates trimmed independently: pairs whose mates have different lengths"""
+    from bitmapperbs_amd import synth, mapper
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=20000, L=125, seed=33, sub=0.02, indel=0.002, qual="random", ins_hi=480)
+    rng = np.random.default_rng(34)
+    l1 = rng.integers(30, 126, 20000).astype(np.uint16); l2 = rng.integers(30, 126, 20000).astype(np.uint16)
+    l1[:3000] = 125; l2[:3000] = 125
+    # mate 2 is trimmed at its 3' end too: the FASTQ record keeps its first l2 characters
+    s1, q1, s2, q2 = _trim(m1["seq"], l1), _trim(m1["qual"], l1), _trim(m2["seq"], l2), _trim(m2["qual"], l2)
+    m = mapper.Mapper(env["ix"], 0, **prm)
+    res, pool = m.map_pe_var(s1, q1, s2, q2, l1, l2)
+    recs, ost, cnt = env["oix"].map_pe_var(orc.params(**prm), s1, q1, s2, q2, l1, l2)
+    assert (recs["status"] == 1).sum() > 8000
+    bad = compare_pe(res, pool, recs, l1, l2)
+    assert not bad, bad[:5]
+    assert (m.stats() == ost).all(), (m.stats(), ost)
+    m.close()

@@ -179,17 +179,25 @@ def variants():
 
 def variant_inputs(v, tmp_path):
     """FASTQ arguments of a variant, built from the committed read sets"""
-    from common import pbat_fastq
+    from common import pbat_fastq, trim_fastq
     if v["kind"] == "se":
         fq = str(tmp_path / "r.fq")
         gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % v["base"]), fq)
         if v.get("pbat"):
             pbat_fastq(fq, str(tmp_path / "r_pbat.fq")); fq = str(tmp_path / "r_pbat.fq")
+        if v.get("trim"):
+            trim_fastq(fq, str(tmp_path / "r_trim.fq"), v["trim"][0]); fq = str(tmp_path / "r_trim.fq")
         return ["--seq", fq]
     f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq")
     gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % v["base"]), f1)
     gunzip_to(os.path.join(GOLD, "pe_%s_2.fq.gz" % v["base"]), f2)
-    return ["--seq1", f2, "--seq2", f1] if v.get("swap") else ["--seq1", f1, "--seq2", f2]
+    if v.get("swap"):
+        f1, f2 = f2, f1
+    if v.get("trim"):
+        t1 = str(tmp_path / "1t.fq"); t2 = str(tmp_path / "2t.fq")
+        trim_fastq(f1, t1, v["trim"][0]); trim_fastq(f2, t2, v["trim"][1])
+        f1, f2 = t1, t2
+    return ["--seq1", f1, "--seq2", f2]
 
 
 @pytest.mark.parametrize("name", sorted(variants()))
