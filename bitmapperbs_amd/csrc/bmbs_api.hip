@@ -31,7 +31,7 @@ struct bmbs_ctx {
     DevIndex ix;
     u64 rows = 0;
     // index buffers
-    DevBuf occ, hash, sa, gen2, chrom_start;
+    DevBuf occ, hash, sa, gen2, chrom_start, t20;
     // LUTs
     DevBuf pen_lut, mapq_lut;
     bool luts_ready = false;
@@ -418,7 +418,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->pen_lut, &c->mapq_lut, &c->verdict,
+    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
@@ -481,6 +481,19 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     ix.chrom_start = c->chrom_start.as<u64>(); ix.G = G; ix.total = n; ix.shapline = v->shapline;
     ix.C[0] = v->nacgt[0]; ix.C[1] = v->nacgt[1]; ix.C[2] = v->nacgt[2]; ix.n_chrom = v->n_chrom;
     hipLaunchKernelGGL(k_expand_sa, dim3(nblk(rows, 256)), dim3(256), 0, c->stream, ix, R, rows, c->sa.as<u32>());
+    // 20-mer outcome table (27.9 GB): built when the device has the room; BMBS_T20=0 turns it off (A/B runs, small devices)
+    ix.t20 = nullptr;
+    {
+        const char* t20_env = getenv("BMBS_T20");
+        const u64 n_keys = v->hash_entries - 1;                 // 3^16
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const u64 need = n_keys * T20_EXT * 8;
+        if (!(t20_env && !strcmp(t20_env, "0")) && n_keys == 43046721ull && free_b > need + (48ull << 30) && ensure(c, c->t20, need) == BMBS_OK) {
+            hipLaunchKernelGGL(k_build_t20, dim3(nblk(n_keys, 256)), dim3(256), 0, c->stream, ix, n_keys, c->t20.as<u64>());
+            ix.t20 = c->t20.as<u64>();
+        }
+    }
     hipError_t e = hipStreamSynchronize(c->stream);
     drop();
     if (e != hipSuccess) { c->err = std::string("index re-pack: ") + hipGetErrorString(e); return BMBS_ENODEV; }

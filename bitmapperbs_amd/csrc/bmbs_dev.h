@@ -20,6 +20,10 @@ typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef uint8_
 //           lookup (entries key, key+1) is one 16-byte read;
 //   sa    : the FULL suffix array (u32 per row), expanded once on the GPU from the sampled SA, so
 //           locate is one 4-byte read instead of <=7 dependent LF steps;
+//   t20   : 3^16 * 81 u64 (27.9 GB): for every 16-mer and every 4-letter continuation, what count_backward_as_much_1_terminate
+//           (bwt.h:2081-2209) has decided after those four backward extensions -- stopped unique at depth 16..19, stopped
+//           because the next letter does not occur, or still going with the depth-20 interval.  One lookup replaces the 16-mer
+//           lookup plus up to four dependent Occ gathers of a seed; 288 GB of HBM is what makes the table affordable;
 //   gen2  : the doubled genome (forward ++ reverse complement) 2 bits/base, 32 bases per u64
 //           LSB-first (A0 C1 G2 T3), so both strands' windows are forward reads.
 struct DevIndex {
@@ -27,6 +31,7 @@ struct DevIndex {
     const u64*   hash;
     const u32*   sa;
     const u64*   gen2;
+    const u64*   t20;           // optional: outcome of the first four extensions of every 20-mer (k_build_t20), else nullptr
     const u64*   chrom_start;   // n_chrom+1 cumulative starts (single strand)
     u64 G;                      // one-strand length
     u64 total;                  // 2G = total_SA_length

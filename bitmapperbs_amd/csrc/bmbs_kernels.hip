@@ -221,6 +221,63 @@ __global__ void k_repack_hash(RefIndexDev R, u64 n, u64* out)
     out[i] = (((u64)(hi & 0x0fffffffu)) << 8) | R.hash_lo[i] | ((u64)(hi >> 28) << 60);
 }
 
+// ---- 20-mer outcome table ----------------------------------------------------------------------------
+// entry = row (36 bits) | hits (24 bits) << 36 | tag << 60.  With I16 the interval of the 16-mer and c16..c19 the next four
+// letters, count_backward_as_much_1_terminate does, for s = 0, 1, ...: stop if |I| == 1 (match length 16+s, 1 hit);
+// extend by c(16+s); stop if that is empty (match length 16+s, hits of the interval before).  Tags:
+//   1..4  stopped unique before consuming c16 / c17 / c18 / c19      (row = that single row, match length 15 + tag)
+//   5..8  stopped because c16 / c17 / c18 / c19 does not occur       (row, hits = interval before, match length 11 + tag)
+//   0     all four letters consumed: row, hits = depth-20 interval (the caller carries on with s = 4)
+//   15    the 16-mer itself does not occur;   14  hits do not fit 24 bits: use the 16-mer path
+#define T20_EXT 81
+DEVI u64 t20_entry(u64 row, u64 hits, int tag) { return hits >= (1ull << 24) ? (14ull << 60) : (row | (hits << 36) | ((u64)tag << 60)); }
+
+__global__ void __launch_bounds__(256)
+k_build_t20(DevIndex ix, u64 n_keys, u64* __restrict__ t20)
+{
+    const u64 key = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= n_keys) return;
+    u64* o = t20 + key * T20_EXT;
+    u64 t0, b0;
+    hash_lookup(ix, key, t0, b0);
+    if (b0 <= t0) { for (int e = 0; e < T20_EXT; e++) o[e] = 15ull << 60; return; }
+    // depth-first over c16..c19; a stopped prefix decides all of its continuations
+    for (int d0 = 0; d0 < 3; d0++) {
+        u64 v0 = 0, t1 = t0, b1 = b0;
+        bool s0 = true;
+        if (b0 - t0 == 1) v0 = t20_entry(t0, 1, 1);
+        else { lf_pair(ix, t1, b1, d0); if (b1 <= t1) v0 = t20_entry(t0, b0 - t0, 5); else s0 = false; }
+        for (int d1 = 0; d1 < 3; d1++) {
+            u64 v1 = v0, t2 = t1, b2 = b1;
+            bool s1 = s0;
+            if (!s1) {
+                if (b1 - t1 == 1) { v1 = t20_entry(t1, 1, 2); s1 = true; }
+                else { lf_pair(ix, t2, b2, d1); if (b2 <= t2) { v1 = t20_entry(t1, b1 - t1, 6); s1 = true; } }
+            }
+            for (int d2 = 0; d2 < 3; d2++) {
+                u64 v2 = v1, t3 = t2, b3 = b2;
+                bool s2 = s1;
+                if (!s2) {
+                    if (b2 - t2 == 1) { v2 = t20_entry(t2, 1, 3); s2 = true; }
+                    else { lf_pair(ix, t3, b3, d2); if (b3 <= t3) { v2 = t20_entry(t2, b2 - t2, 7); s2 = true; } }
+                }
+                for (int d3 = 0; d3 < 3; d3++) {
+                    u64 v3 = v2;
+                    if (!s2) {
+                        if (b3 - t3 == 1) v3 = t20_entry(t3, 1, 4);
+                        else {
+                            u64 t4 = t3, b4 = b3;
+                            lf_pair(ix, t4, b4, d3);
+                            v3 = b4 <= t4 ? t20_entry(t3, b3 - t3, 8) : t20_entry(t4, b4 - t4, 0);
+                        }
+                    }
+                    o[d0 + 3 * d1 + 9 * d2 + 27 * d3] = v3;
+                }
+            }
+        }
+    }
+}
+
 // doubled 2-bit genome: d < G forward base, else complement of base 2G-1-d; LSB-first in u64 words
 __global__ void k_build_gen2(RefIndexDev R, u64 G, u64 n_words, u64* out)
 {
@@ -351,6 +408,19 @@ struct SeedHit { u64 hits, sp, ml; };
 // base-3 number of read[tm .. tm+15] and extension consumes read[tm+16], read[tm+17], ....
 struct Search { u64 top, bot, ptop, pbot; int s, steps, tm; ReadCur cur; };
 
+// eight ASCII characters -> eight 3-letter digits (G0 T1 A2, C folded into T), one per byte, and 0x80 in every byte that
+// holds one of A C G T.  (c >> 1) & 3 is A0 C1 T2 G3, and the digit is 2 - popcount of that.
+DEVI void swar_code3(u64 w, u64& digits, u64& valid)
+{
+    const u64 K01 = 0x0101010101010101ull, K7F = 0x7f7f7f7f7f7f7f7full;
+    digits = 0x0202020202020202ull - ((w >> 1) & K01) - ((w >> 2) & K01);
+    auto zero_bytes = [&](u64 x) -> u64 { return ~(((x & K7F) + K7F) | x | K7F); };          // 0x80 exactly where a byte is 0
+    valid = zero_bytes(w ^ 0x4141414141414141ull) | zero_bytes(w ^ 0x4343434343434343ull) |
+            zero_bytes(w ^ 0x4747474747474747ull) | zero_bytes(w ^ 0x5454545454545454ull);
+}
+// four digits (one per byte of x) -> d0 + 3 d1 + 9 d2 + 27 d3 in one multiply
+DEVI u32 base3_of4(u32 x) { return (x * 0x0103091Bu) >> 24; }
+
 // returns true when the search has to be stepped; false when it is already decided (out filled)
 template <bool FIXED>
 DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search& S, SeedHit& out, u32& n_hash)
@@ -358,17 +428,41 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     const int len = L - tm;
     out.hits = 0; out.sp = 0; out.ml = FIXED ? (u64)len : 0;
     if (len < (FIXED ? 17 : 18)) return false;
-    // key = sum code(read[tm+u]) * 3^u
-    u64 key = 0, p3 = 1;
-    bool bad = false;
-    S.cur.seek(rd, tm, L);
-#pragma unroll
-    for (int u = 0; u < 16; u++) { const int d = code3(S.cur.next()); bad |= d > 2; key += (u64)(d > 2 ? 0 : d) * p3; p3 *= 3; }
-    if (bad) return false;                      // get_3_letter_hash_value returned -1 (bwt.h:309-332)
+    // key = sum code(read[tm+u]) * 3^u over the 16 characters read[tm .. tm+15], eight characters per load and step
+    // (rows are padded, so the unaligned 8-byte loads stay inside the buffer; characters >= L are never used)
+    u64 d0, v0, d1, v1;
+    swar_code3(*reinterpret_cast<const u64*>(rd + tm), d0, v0);
+    swar_code3(*reinterpret_cast<const u64*>(rd + tm + 8), d1, v1);
+    if ((v0 & v1) != 0x8080808080808080ull) return false;          // get_3_letter_hash_value returned -1 (bwt.h:309-332)
+    const u64 key = (u64)base3_of4((u32)d0) + 81ull * base3_of4((u32)(d0 >> 32)) + 6561ull * base3_of4((u32)d1) +
+                    531441ull * base3_of4((u32)(d1 >> 32));
+    S.steps = len - 16; S.tm = tm;
+    if (!FIXED && ix.t20 && len >= 20) {
+        // the 16-mer lookup and the first four extensions in one table read
+        u64 d2, v2;
+        swar_code3((u64)*reinterpret_cast<const u32*>(rd + tm + 16), d2, v2);
+        if ((v2 & 0x80808080ull) == 0x80808080ull) {
+            const u64 v = ix.t20[key * T20_EXT + (u64)base3_of4((u32)d2)];
+            const int tag = (int)(v >> 60);
+            if (tag != 14) {
+                n_hash++;
+                const u64 row = v & ((1ull << 36) - 1), hits = (v >> 36) & ((1ull << 24) - 1);
+                if (tag == 15) return false;                                           // hits 0, match length 0
+                if (tag >= 1 && tag <= 4) { out.ml = (u64)(15 + tag); out.sp = row; out.hits = 1; return false; }
+                if (tag >= 5) { out.ml = (u64)(11 + tag); out.sp = row; out.hits = hits; return false; }
+                S.top = row; S.bot = row + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = 4;
+                if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
+                S.cur.seek(rd, tm + 20, L);
+                return true;
+            }
+        }
+        // a letter outside the alphabet among the four, or an oversized interval: the 16-mer path
+    }
     hash_lookup(ix, key, S.top, S.bot);
     n_hash++;
     if (S.bot <= S.top) return false;
-    S.ptop = ~0ull; S.pbot = ~0ull; S.s = 0; S.steps = len - 16; S.tm = tm;
+    S.ptop = ~0ull; S.pbot = ~0ull; S.s = 0;
+    S.cur.seek(rd, tm + 16, L);
     return true;
 }
 
