@@ -234,6 +234,7 @@ def main():
             "k_seed_extra": seed_bytes(cnt["k_seed_extra"]),
             "k_locate": (4 + 8) * cnt["n_cand_slots"],
             "k_vote": (8 + 16 + 4) * cnt["n_cand_slots"],
+            "k_vote_fused": (4 + 16 + 4) * cnt["n_cand_slots"],
             "k_filter": (win + L + 16 + 8) * cnt["n_filter"],
             "k_align_ungapped": (win + 2 * L + 16) * cnt["n_sw"],
             "k_align_sw": (win + 2 * L + 16) * cnt["n_sw"],

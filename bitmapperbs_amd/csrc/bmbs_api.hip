@@ -360,15 +360,24 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
     const u64 t1 = tot ? tot : 1;
     ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(bmbs_vote)); ENS(c, c->slot_read, t1 * 4);
     ENS(c, c->ferr, t1 * 4); ENS(c, c->fend, t1 * 4);
-    if (tot) {
-        prof_begin(c, "k_locate");
-        hipLaunchKernelGGL(k_locate, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, (long)n, st, c->cand.as<u64>());
+    // locate + sort + votes; BMBS_VOTE=split runs the two-kernel form (k_locate, k_vote) for A/B measurements
+    const char* vm = getenv("BMBS_VOTE");
+    if (vm && !strcmp(vm, "split")) {
+        if (tot) {
+            prof_begin(c, "k_locate");
+            hipLaunchKernelGGL(k_locate, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, (long)n, st, c->cand.as<u64>());
+            prof_end(c);
+        }
+        prof_begin(c, "k_vote");
+        hipLaunchKernelGGL(k_vote, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, st, c->cand.as<u64>(),
+                           c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
+        prof_end(c);
+    } else {
+        prof_begin(c, "k_vote_fused");
+        hipLaunchKernelGGL(k_vote_fused, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, st, c->cand.as<u64>(),
+                           c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
         prof_end(c);
     }
-    prof_begin(c, "k_vote");
-    hipLaunchKernelGGL(k_vote, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, st, c->cand.as<u64>(),
-                       c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
-    prof_end(c);
     return BMBS_OK;
 }
 

@@ -97,9 +97,22 @@ DEVI bool window_valid(const DevIndex& ix, u64 start, u64 len, bool fwd_strand)
 // window base with the all-zero-window rule (out-of-strand request: every base compares unequal and
 // scores as N, nt4[0] = 4)
 struct WinReader {
-    const u64* g; u64 pos, w; int left; bool valid;
-    DEVI void init(const DevIndex& ix, u64 start, bool v) { g = ix.gen2; valid = v; pos = start; if (v) { w = g[pos >> 5] >> ((pos & 31) * 2); left = 32 - (int)(pos & 31); } else { w = 0; left = 32; } }
-    DEVI int next() { if (!valid) return 4; const int b = (int)(w & 3); w >>= 2; pos++; left--; if (left == 0) { w = g[pos >> 5]; left = 32; } return b; }
+    // the word after the current one is requested as soon as the current one is taken into use, so that its latency
+    // overlaps the 32 bases of work in between (one read per lane: nothing else would hide it)
+    const u64* g; u64 pos, w, nxt; int left; bool valid;
+    DEVI void init(const DevIndex& ix, u64 start, bool v)
+    {
+        g = ix.gen2; valid = v; pos = start;
+        if (v) { w = g[pos >> 5] >> ((pos & 31) * 2); nxt = g[(pos >> 5) + 1]; left = 32 - (int)(pos & 31); } else { w = 0; nxt = 0; left = 32; }
+    }
+    DEVI int next()
+    {
+        if (!valid) return 4;
+        const int b = (int)(w & 3);
+        w >>= 2; pos++; left--;
+        if (left == 0) { w = nxt; nxt = g[(pos >> 5) + 1]; left = 32; }      // gen2 carries two spare words at its end
+        return b;
+    }
 };
 
 // bisulfite 3-letter code of a read character after C->T: G0 T1 A2, anything else 4
@@ -112,13 +125,20 @@ DEVI int code4(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 :
 // One read per lane means a byte load touches 64 different cache lines per wave instruction; wide
 // loads cut the number of such instructions by 8.
 struct ReadCur {
-    const char* rd; u64 buf; int pos, lim;
-    DEVI void seek(const char* r, int p, int L) { rd = r; pos = p; lim = L; buf = p < L ? *reinterpret_cast<const u64*>(rd + (p & ~7)) >> (8 * (p & 7)) : 0ull; }
+    // like WinReader: the next 8 characters are on their way while the current 8 are consumed
+    const char* rd; u64 buf, nxt; int pos, lim;
+    DEVI void seek(const char* r, int p, int L)
+    {
+        rd = r; pos = p; lim = L;
+        buf = p < L ? *reinterpret_cast<const u64*>(rd + (p & ~7)) >> (8 * (p & 7)) : 0ull;
+        nxt = (p & ~7) + 8 < L ? *reinterpret_cast<const u64*>(rd + (p & ~7) + 8) : 0ull;
+    }
     DEVI char next()
     {
         const char c = (char)(buf & 0xff);
         pos++;
-        if ((pos & 7) == 0) buf = pos < lim ? *reinterpret_cast<const u64*>(rd + pos) : 0ull; else buf >>= 8;   // never past the read
+        if ((pos & 7) == 0) { buf = nxt; nxt = pos + 8 < lim ? *reinterpret_cast<const u64*>(rd + pos + 8) : 0ull; }   // never past the read
+        else buf >>= 8;
         return c;
     }
 };
@@ -985,6 +1005,104 @@ k_vote(long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __r
     sort_u64_asc(c, nc);
     // generate_candidate_votes_shift (Schema.cpp:4687-4773)
     bmbs_vote* v = votes + off;
+    long nv = 0;
+    u64 pre = c[0];
+    u32 vote = 1;
+    for (long i = 1; i < nc; i++) {
+        if (c[i] == pre) vote++;
+        else { v[nv].site = pre < (u64)k ? 0 : pre - (u64)k; v[nv].vote = vote; v[nv].pad = 0; nv++; vote = 1; pre = c[i]; }
+    }
+    v[nv].site = pre >= (u64)k ? pre - (u64)k : 0; v[nv].vote = vote; v[nv].pad = 0; nv++;
+    intro_sort_desc(v, nv);             // std::sort(votes, compare_seed_votes), Schema.cpp:24986
+    st.n_votes[r] = (u32)nv;
+    for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+}
+
+// k_locate + k_vote in one pass for the usual small candidate lists: up to VOTE_REG candidates are located straight into
+// registers, sorted by a fixed compare-exchange network and ranked (std::sort on <= 16 elements is libstdc++'s plain
+// insertion sort, i.e. stable: rank = votes larger + equal votes earlier), so the candidate array never goes through
+// memory and no per-lane sort runs on global memory.  Longer lists take the two-step path inside the same kernel.
+#define VOTE_REG 16
+__global__ void __launch_bounds__(64)
+k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes,
+             u32* __restrict__ slot_read)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (st.verdict[r] != 3) { st.n_votes[r] = 0; return; }
+    const int k = gm.rk(gm.rl(r));
+    const u64 off = st.cand_off[r];
+    const long nc = (long)st.n_cand[r];
+    const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+    const int ns = st.n_seeds[r];
+    bmbs_vote* v = votes + off;
+    if (nc <= VOTE_REG) {
+        u64 c[VOTE_REG];
+        // slot j of the list = hit h of seed s, in seed order (locate + reverse_and_adjust_site, Schema.cpp:4669)
+        int sidx = 0; u32 h = 0;
+        u64 sp = 0, adj = 0; u32 hits = 0;
+        if (ns > 0) { sp = my[0].sp; adj = (u64)my[0].len + (u64)my[0].off; hits = my[0].hits; }
+#pragma unroll
+        for (int j = 0; j < VOTE_REG; j++) {
+            c[j] = ~0ull;
+            if (j < nc) {
+                while (h == hits && sidx + 1 < ns) { sidx++; h = 0; sp = my[sidx].sp; adj = (u64)my[sidx].len + (u64)my[sidx].off; hits = my[sidx].hits; }
+                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + h]) - adj;
+                h++;
+            }
+        }
+        // Batcher odd-even merge sort, 16 keys, ascending (padding ~0 sinks to the end)
+#define CE(a, b) { const u64 x_ = c[a], y_ = c[b]; c[a] = x_ < y_ ? x_ : y_; c[b] = x_ < y_ ? y_ : x_; }
+        CE(0,1) CE(2,3) CE(4,5) CE(6,7) CE(8,9) CE(10,11) CE(12,13) CE(14,15)
+        CE(0,2) CE(1,3) CE(4,6) CE(5,7) CE(8,10) CE(9,11) CE(12,14) CE(13,15)
+        CE(1,2) CE(5,6) CE(9,10) CE(13,14)
+        CE(0,4) CE(1,5) CE(2,6) CE(3,7) CE(8,12) CE(9,13) CE(10,14) CE(11,15)
+        CE(2,4) CE(3,5) CE(10,12) CE(11,13)
+        CE(1,2) CE(3,4) CE(5,6) CE(9,10) CE(11,12) CE(13,14)
+        CE(0,8) CE(1,9) CE(2,10) CE(3,11) CE(4,12) CE(5,13) CE(6,14) CE(7,15)
+        CE(4,8) CE(5,9) CE(6,10) CE(7,11)
+        CE(2,4) CE(3,5) CE(6,8) CE(7,9) CE(10,12) CE(11,13)
+        CE(1,2) CE(3,4) CE(5,6) CE(7,8) CE(9,10) CE(11,12) CE(13,14)
+#undef CE
+        // generate_candidate_votes_shift (Schema.cpp:4687-4773): one vote entry per run of equal sites, at the run's end
+        u32 vote[VOTE_REG];
+        bool last[VOTE_REG];
+        u32 run = 0;
+        int nv = 0;
+#pragma unroll
+        for (int i = 0; i < VOTE_REG; i++) {
+            run = (i > 0 && c[i] == c[i - 1]) ? run + 1 : 1;
+            vote[i] = run;
+            last[i] = i < nc && (i + 1 >= nc || (i + 1 < VOTE_REG && c[i + 1] != c[i]));
+            nv += last[i] ? 1 : 0;
+        }
+        // std::sort(votes, compare_seed_votes) (Schema.cpp:24986) on <= 16 entries: stable, descending by vote
+#pragma unroll
+        for (int i = 0; i < VOTE_REG; i++) {
+            if (last[i]) {
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < VOTE_REG; j++) rank += (last[j] && (vote[j] > vote[i] || (vote[j] == vote[i] && j < i))) ? 1 : 0;
+                bmbs_vote o;
+                o.site = c[i] < (u64)k ? 0 : c[i] - (u64)k; o.vote = vote[i]; o.pad = 0;
+                v[rank] = o;
+            }
+        }
+        st.n_votes[r] = (u32)nv;
+        for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+        return;
+    }
+    // long lists: locate into the candidate array, sort there
+    u64* c = cand + off;
+    {
+        u64 o = 0;
+        for (int s2 = 0; s2 < ns && o < (u64)nc; s2++) {
+            const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
+            const u32 hh = my[s2].hits;
+            for (u32 j = 0; j < hh && o < (u64)nc; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;
+        }
+    }
+    sort_u64_asc(c, nc);
     long nv = 0;
     u64 pre = c[0];
     u32 vote = 1;
