@@ -726,13 +726,9 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     ENS(c, c->dense_read, t1 * 4); ENS(c, c->ferr, t1 * 4);
     PeCand* A = c->votes.as<PeCand>();
     PeCand* B = c->pe_B.as<PeCand>();
-    if (tot) {
-        prof_begin(c, "k_locate");
-        hipLaunchKernelGGL(k_locate, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, c->ix, (long)n2, st, c->cand.as<u64>());
-        prof_end(c);
-    }
-    prof_begin(c, "k_vote_pe");
-    hipLaunchKernelGGL(k_vote_pe, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, (long)n2, gm, st, ps, c->cand.as<u64>(), A, c->slot_read.as<u32>());
+    prof_begin(c, "k_vote_pe_fused");
+    hipLaunchKernelGGL(k_vote_pe_fused, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, c->ix, (long)n2, gm, st, ps, c->cand.as<u64>(), A,
+                       c->slot_read.as<u32>());
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {
@@ -810,7 +806,7 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         }
     }
     prof_begin(c, "k_pe_pair");
-    hipLaunchKernelGGL(k_pe_pair, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, c->prm.ambiguous_out, st, ps, A, B);
+    hipLaunchKernelGGL(k_pe_pair, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, pi, c->prm.ambiguous_out, st, ps, A, B);
     prof_end(c);
     prof_begin(c, "scan_jobs");
     rc = scan_u32(c, st.job_flag, n2, st.job_off, 1);
@@ -838,7 +834,8 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize_pe");
-    hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->mapq_lut.as<u8>(), c->mapq_off.as<u32>(), c->mapq_unit, gm,
+    hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), seq_all, qual_all, stride,
+                       c->mapq_lut.as<u8>(), c->mapq_off.as<u32>(), c->mapq_unit, gm,
                        c->prm.min_ins, c->prm.max_ins, c->prm.ambiguous_out, (long)n, st, ps, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, reinterpret_cast<bmbs_result_dev*>(d_results),
                        c->stats.as<unsigned long long>());

@@ -1690,19 +1690,36 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const cha
     reinterpret_cast<uint4*>(seq_all)[i16] = reinterpret_cast<const uint4*>(s1)[i16];
     reinterpret_cast<uint4*>(qual_all)[i16] = reinterpret_cast<const uint4*>(q1)[i16];
     reinterpret_cast<uint4*>(qual_all + total)[i16] = reinterpret_cast<const uint4*>(q2)[i16];
-    unsigned char o[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const int j = j0 + t;
-        char c = 0;
-        if (j < L) { const char a = s2raw[r * stride + (L - 1 - j)]; c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a; }
-        o[t] = (unsigned char)c;
-    }
+    // out[j] = complement(in[L-1-j]) for j < L, 0 beyond: one reversed 16-byte piece per thread.  complement = c ^ 0x15 for
+    // A/T, c ^ 0x04 for C/G, identity otherwise (rc_table), eight characters per step.
+    auto comp8 = [](u64 w) -> u64 {
+        const u64 K7F = 0x7f7f7f7f7f7f7f7full;
+        auto zb = [&](u64 x) -> u64 { return ~(((x & K7F) + K7F) | x | K7F); };                 // 0x80 where a byte is 0
+        const u64 at = zb(w ^ 0x4141414141414141ull) | zb(w ^ 0x5454545454545454ull);
+        const u64 cg = zb(w ^ 0x4343434343434343ull) | zb(w ^ 0x4747474747474747ull);
+        return w ^ ((at >> 7) * 0x15) ^ ((cg >> 7) * 0x04);
+    };
+    const char* row = s2raw + r * stride;
+    const int src = L - 16 - j0;                       // in[src .. src+15] reversed = out[j0 .. j0+15]
     uint4 v;
-    v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
-    v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
-    v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
-    v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
+    if (src >= 0) {
+        const u64 lo = *reinterpret_cast<const u64*>(row + src), hi = *reinterpret_cast<const u64*>(row + src + 8);
+        const u64 a = comp8(__builtin_bswap64(hi)), b2 = comp8(__builtin_bswap64(lo));
+        v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)b2; v.w = (u32)(b2 >> 32);
+    } else {
+        unsigned char o[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int j = j0 + t;
+            char c = 0;
+            if (j < L) { const char a = row[L - 1 - j]; c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a; }
+            o[t] = (unsigned char)c;
+        }
+        v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
+        v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
+        v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
+        v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
+    }
     reinterpret_cast<uint4*>(seq_all + total)[i16] = v;
 }
 
@@ -1737,6 +1754,92 @@ k_vote_pe(long n2, ReadGeom gm, ReadState st, PeState ps, u64* __restrict__ cand
         o[nv].site = pre >= (u64)k ? pre - (u64)k : 0; o[nv].err = 0; o[nv].end = 0; nv++;
         ps.occ[r] = -1; ps.len[r] = (u32)nv;
     } else { ps.occ[r] = 0; ps.len[r] = 0; }
+}
+
+// k_locate + k_vote_pe for lists of up to VOTE_REG candidates: located into registers, sorted by the same network as
+// k_vote_fused; general reads emit one entry per distinct site (no vote order), exact-ambiguous reads every hit
+__global__ void __launch_bounds__(64)
+k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A,
+                u32* __restrict__ slot_read)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n2) return;
+    const int L = gm.rl(r), k = gm.rk(L);
+    const int v = st.verdict[r];
+    const u64 off = st.cand_off[r];
+    for (u64 g = off; g < st.cand_off[r + 1]; g++) slot_read[g] = (u32)r;
+    ps.cur[r] = 0; ps.vround[r] = 0;
+    if (v == 1 || v == 2) {
+        A[off].site = st.exit_site[r]; A[off].err = v == 1 ? 0u : 1u; A[off].end = L - 1;
+        ps.occ[r] = 1; ps.len[r] = 1;
+        return;
+    }
+    if (v != 3 && v != 4) { ps.occ[r] = 0; ps.len[r] = 0; return; }
+    const long nc = (long)st.n_cand[r];
+    const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+    const int ns = st.n_seeds[r];
+    PeCand* o = A + off;
+    if (nc <= VOTE_REG) {
+        u64 c[VOTE_REG];
+        int sidx = 0; u32 h = 0;
+        u64 sp = 0, adj = 0; u32 hits = 0;
+        if (ns > 0) { sp = my[0].sp; adj = (u64)my[0].len + (u64)my[0].off; hits = my[0].hits; }
+#pragma unroll
+        for (int j = 0; j < VOTE_REG; j++) {
+            c[j] = ~0ull;
+            if (j < nc) {
+                while (h == hits && sidx + 1 < ns) { sidx++; h = 0; sp = my[sidx].sp; adj = (u64)my[sidx].len + (u64)my[sidx].off; hits = my[sidx].hits; }
+                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + h]) - adj;
+                h++;
+            }
+        }
+#define CE(a, b) { const u64 x_ = c[a], y_ = c[b]; c[a] = x_ < y_ ? x_ : y_; c[b] = x_ < y_ ? y_ : x_; }
+        CE(0,1) CE(2,3) CE(4,5) CE(6,7) CE(8,9) CE(10,11) CE(12,13) CE(14,15)
+        CE(0,2) CE(1,3) CE(4,6) CE(5,7) CE(8,10) CE(9,11) CE(12,14) CE(13,15)
+        CE(1,2) CE(5,6) CE(9,10) CE(13,14)
+        CE(0,4) CE(1,5) CE(2,6) CE(3,7) CE(8,12) CE(9,13) CE(10,14) CE(11,15)
+        CE(2,4) CE(3,5) CE(10,12) CE(11,13)
+        CE(1,2) CE(3,4) CE(5,6) CE(9,10) CE(11,12) CE(13,14)
+        CE(0,8) CE(1,9) CE(2,10) CE(3,11) CE(4,12) CE(5,13) CE(6,14) CE(7,15)
+        CE(4,8) CE(5,9) CE(6,10) CE(7,11)
+        CE(2,4) CE(3,5) CE(6,8) CE(7,9) CE(10,12) CE(11,13)
+        CE(1,2) CE(3,4) CE(5,6) CE(7,8) CE(9,10) CE(11,12) CE(13,14)
+#undef CE
+        int nv = 0;
+#pragma unroll
+        for (int i = 0; i < VOTE_REG; i++) {
+            if (i < nc) {
+                if (v == 4) { o[i].site = c[i]; o[i].err = 0; o[i].end = L - 1; }
+                else if (i + 1 >= nc || (i + 1 < VOTE_REG && c[i + 1] != c[i])) {
+                    o[nv].site = c[i] < (u64)k ? 0 : c[i] - (u64)k; o[nv].err = 0; o[nv].end = 0; nv++;
+                }
+            }
+        }
+        if (v == 4) { ps.occ[r] = (int)nc; ps.len[r] = (u32)nc; }
+        else { ps.occ[r] = -1; ps.len[r] = (u32)nv; }
+        return;
+    }
+    u64* c = cand + off;
+    {
+        u64 w = 0;
+        for (int s2 = 0; s2 < ns && w < (u64)nc; s2++) {
+            const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
+            const u32 hh = my[s2].hits;
+            for (u32 j = 0; j < hh && w < (u64)nc; j++) c[w++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;
+        }
+    }
+    sort_u64_asc(c, nc);
+    if (v == 4) {
+        for (long i = 0; i < nc; i++) { o[i].site = c[i]; o[i].err = 0; o[i].end = L - 1; }
+        ps.occ[r] = (int)nc; ps.len[r] = (u32)nc;
+    } else {
+        long nv = 0;
+        u64 pre = c[0];
+        for (long i = 1; i < nc; i++)
+            if (c[i] != pre) { o[nv].site = pre < (u64)k ? 0 : pre - (u64)k; o[nv].err = 0; o[nv].end = 0; nv++; pre = c[i]; }
+        o[nv].site = pre >= (u64)k ? pre - (u64)k : 0; o[nv].err = 0; o[nv].end = 0; nv++;
+        ps.occ[r] = -1; ps.len[r] = (u32)nv;
+    }
 }
 
 DEVI PeCand* pe_list(const PeState& ps, const ReadState& st, PeCand* A, PeCand* B, long r)
@@ -2087,7 +2190,7 @@ k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ c
 
 // new_faster_verify_pairs (Schema.cpp:15773-15900) + hand-over of the winning candidates to K11-K13
 __global__ void __launch_bounds__(64)
-k_pe_pair(long n, ReadGeom gm, PeIns pi, int ambiguous_out, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
+k_pe_pair(DevIndex ix, long n, ReadGeom gm, PeIns pi, int ambiguous_out, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -2137,15 +2240,24 @@ k_pe_pair(long n, ReadGeom gm, PeIns pi, int ambiguous_out, ReadState st, PeStat
         st.best_site[r1] = a[bi].site; st.best_end[r1] = a[bi].end; st.best_err[r1] = a[bi].err;
         st.best_site[r2] = b[bj].site; st.best_end[r2] = b[bj].end; st.best_err[r2] = b[bj].err;
         st.red_status[r1] = 1; st.red_status[r2] = 1;
-        st.job_flag[r1] = a[bi].err != 0 ? 1u : 0u;
-        st.job_flag[r2] = b[bj].err != 0 ? 1u : 0u;
+        // a mate that left through the 1-mismatch exit has exactly one mismatch, at mm_site, on the un-gapped diagonal:
+        // fast_recalculate_bs_Cigar (ksw.cpp:2578) would only re-derive NM 1 / <L>M / minus one penalty, which k_finalize_pe
+        // writes directly -- unless its window leaves the strand, where the reference aligns against an all-zero window
+        const long rr[2] = {r1, r2};
+        const PeCand w2[2] = {a[bi], b[bj]};
+        for (int m = 0; m < 2; m++) {
+            const int Lm = gm.rl(rr[m]), km = gm.rk(Lm);
+            const bool direct = st.verdict[rr[m]] == 2 && window_valid(ix, w2[m].site, (u64)(Lm + 2 * km), w2[m].site < ix.G);
+            st.job_flag[rr[m]] = (w2[m].err != 0 && !direct) ? 1u : 0u;
+        }
     }
 }
 
 // per-pair post-processing (Schema.cpp:19330-19480): placement of both mates (output_sam_end_to_end_return,
 // 9188), TLEN (Schema.h:1587), insert/chromosome-end checks, MAPQ over k1+k2, flags 99/83/147/163, stats
 __global__ void __launch_bounds__(256)
-k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, const u32* __restrict__ mapq_off, int unit, ReadGeom gm, int min_ins, int max_ins,
+k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq, const char* __restrict__ qual,
+              int stride, const u8* __restrict__ mapq_lut, const u32* __restrict__ mapq_off, int unit, ReadGeom gm, int min_ins, int max_ins,
               int ambiguous_out, long n,
               ReadState st, PeState ps, const int* __restrict__ a_start, const int* __restrict__ a_end,
               const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops, int max_ops,
@@ -2178,7 +2290,19 @@ k_finalize_pe(DevIndex ix, const u8* __restrict__ mapq_lut, const u32* __restric
                     const int no = a_nops[jb];
                     o[m].cigar_off = (u32)(jb * (u64)max_ops);
                     o[m].n_cigar = no < 0 ? 255 : (u8)no;
-                } else { end_site = st.best_end[r]; start_site = end_site - gm.rl(r) + 1; nm[m] = 0; score[m] = 0; }
+                } else {
+                    const int Lm = gm.rl(r);
+                    end_site = st.best_end[r]; start_site = end_site - Lm + 1; nm[m] = 0; score[m] = 0;
+                    if (st.best_err[r] != 0) {
+                        // 1-mismatch exit (see k_pe_pair): NM 1, score = minus the penalty at mm_site; mate 2 rows carry their
+                        // qualities in FASTQ order for a reverse-complemented read (need_reverse_quality = 1)
+                        const int ms = st.mm_site[r];
+                        const char a = seq[(size_t)r * stride + ms];
+                        const int qi = m == 1 ? Lm - 1 - ms : ms;
+                        nm[m] = 1;
+                        score[m] = a == 'N' ? -sp.np : -pen_lut[(unsigned char)qual[(size_t)r * stride + qi]];
+                    }
+                }
                 u64 loc = site;
                 if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; rflag[m] = 16; }
                 else { loc = loc + (u64)start_site; rflag[m] = 0; }
