@@ -262,8 +262,12 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
                        c->sw_job.as<u32>());
     prof_end(c);
     prof_begin(c, "k_align_sw");
-    if (k <= 4) launch_sw<4>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    // the band loop is unrolled for KB: a tighter bound wastes fewer masked cells (k = 6 in a KB = 8 kernel idles 4 of 17)
+    if (k <= 2) launch_sw<2>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 6) launch_sw<6>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
     else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 10) launch_sw<10>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
     else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
     else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
     else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
@@ -301,7 +305,8 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     prof_end(c);
     prof_begin(c, "k_seed_decide");
     // rows staged through LDS (each read fetched from HBM exactly once, coalesced) + 8 characters per compare step;
-    // BMBS_DECIDE=plain|lds|vec8 select the other forms for A/B measurements
+    // BMBS_DECIDE=plain|lds|vec8 select the other forms for A/B measurements.  (An 8-lanes-per-read form without
+    // staging was measured at 2.07 ms against 1.36 ms: the per-read bookkeeping, replicated eight times, costs more than it saves.)
     const char* dv = getenv("BMBS_DECIDE");
     const bool lds_ok = (size_t)64 * (stride + 8) <= 48 * 1024;
     if (dv && !strcmp(dv, "plain"))
@@ -476,7 +481,7 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     R.sa = t_sa.as<u32>(); R.sa_flag = t_fl.as<u64>(); R.pac = t_pac.as<u8>();
     if (n >= (1ull << 32)) { c->err = "32-bit Occ counters: text too long"; return BMBS_EINVAL; }
     const u64 n_blk = n / 32 + 2;
-    const u64 gen_words = (n + 31) / 32 + 2;
+    const u64 gen_words = ((n + 63) / 64 + 3) * 2;          // whole 16-byte pieces plus spare ones for the look-ahead loads
     std::vector<u64> cs(v->n_chrom + 1, 0);
     for (int i = 0; i < v->n_chrom; i++) cs[i + 1] = cs[i] + v->chrom_len[i];
     if (ensure(c, c->occ, n_blk * 16) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * 4) ||

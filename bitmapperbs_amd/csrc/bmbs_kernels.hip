@@ -693,15 +693,21 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
                         } else {
                             // read position q faces doubled coordinate loc + q; 8 positions per step
                             const int ml0 = (int)ml;
-                            // window words cached in registers: one global load per 32 bases
-                            u64 gidx = (loc + (u64)(ml0 & ~7)) >> 5, g0 = ix.gen2[gidx], g1 = ix.gen2[gidx + 1];
+                            // window bases cached in registers, 64 per 16-byte global load, the next block already on its way
+                            // (every per-lane load is a request of its own: 3 wide loads instead of 6 narrow ones per read)
+                            const uint4* g4 = reinterpret_cast<const uint4*>(ix.gen2);
+                            u64 gidx = (loc + (u64)(ml0 & ~7)) >> 6;
+                            uint4 cb = g4[gidx], nb = g4[gidx + 1];
                             for (int p = ml0 & ~7; p < L && error < 2; p += 8) {
                                 const u64 rw = *reinterpret_cast<const u64*>(rd + p);
                                 const u64 d = loc + (u64)p;
-                                if ((d >> 5) != gidx) { gidx = d >> 5; g0 = g1; g1 = ix.gen2[gidx + 1]; }
-                                const int sh = (int)(d & 31) * 2;
-                                u64 w16 = g0 >> sh;
-                                if (sh > 48) w16 |= g1 << (64 - sh);
+                                if ((d >> 6) != gidx) { gidx = d >> 6; cb = nb; nb = g4[gidx + 1]; }
+                                const int o = (int)(d & 63) * 2;
+                                const u64 c0 = ((u64)cb.y << 32) | cb.x, c1 = ((u64)cb.w << 32) | cb.z, n0 = ((u64)nb.y << 32) | nb.x;
+                                const u64 lo64 = o < 64 ? c0 : c1, hi64 = o < 64 ? c1 : n0;
+                                const int sh = o & 63;
+                                u64 w16 = lo64 >> sh;
+                                if (sh > 48) w16 |= hi64 << (64 - sh);
                                 u64 m = mism8(rw, w16 & 0xffff);
                                 const int lo = ml0 > p ? ml0 - p : 0, hi = L - p < 8 ? L - p : 8;
                                 u64 keep = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1);
