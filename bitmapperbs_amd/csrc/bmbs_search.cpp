@@ -6,7 +6,7 @@
 //
 //   bmbs_search --search <index prefix | dir> --seq r.fq[.gz] [-o out.sam] [-e 0.08] [--mapstats f]
 //   bmbs_search --search <index> --seq1 a.fq --seq2 b.fq [--min 0] [--max 500] [--sensitive] ...
-//   output variants (Process_CommandLines.cpp:93-105): --pbat, --unmapped_out, --ambiguous_out
+//   output variants (Process_CommandLines.cpp:93-105): --pbat, --unmapped_out, --ambiguous_out, --bam (BGZF-compressed BAM)
 //   extra: --device N, --batch N (records per GPU batch, default 1 M), -t N (host I/O threads), --verbose
 //
 // The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
@@ -253,6 +253,7 @@ struct Batch {
     Pinned seq1, qual1, seq2, qual2, res, pool;
     std::vector<std::vector<char>> text;         // SAM text per formatter slice (capacity kept from batch to batch)
     std::vector<size_t> text_len;
+    std::vector<std::vector<char>> bam_rec, bam_z;   // --bam: records and BGZF blocks of a slice
 };
 
 const uint32_t NOROW = 0xffffffffu;
@@ -297,6 +298,121 @@ struct Out {
     }
 };
 
+// ---- --bam (Process_CommandLines.cpp:94; the reference hands each SAM line to htslib's sam_parse1 and bam_write1,
+// bam_prase.cpp:201-221): the same conversion here, line by line, then BGZF blocks compressed by the I/O threads ----------
+int reg2bin(long long beg, long long end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+inline void put_le32(std::vector<char>& o, uint32_t v) { char b[4] = {(char)v, (char)(v >> 8), (char)(v >> 16), (char)(v >> 24)}; o.insert(o.end(), b, b + 4); }
+inline void put_le16(std::vector<char>& o, uint16_t v) { o.push_back((char)v); o.push_back((char)(v >> 8)); }
+
+struct BamNames { std::vector<std::string> names; int id(const char* s, size_t n) const { for (size_t i = 0; i < names.size(); i++) if (names[i].size() == n && !memcmp(names[i].data(), s, n)) return (int)i; return -1; } };
+
+// one SAM line of ours (11 mandatory columns + optional NM:i) -> one BAM record appended to o
+void sam_line_to_bam(const char* l, size_t n, const BamNames& refs, std::vector<char>& o)
+{
+    const char* f[13]; size_t fl[13]; int nf = 0;
+    const char* s = l; const char* e = l + n;
+    while (nf < 13) {
+        const char* t = (const char*)memchr(s, '\t', (size_t)(e - s));
+        f[nf] = s; fl[nf] = t ? (size_t)(t - s) : (size_t)(e - s); nf++;
+        if (!t) break;
+        s = t + 1;
+    }
+    auto num = [&](int i) -> long long { long long v = 0; bool neg = false; size_t j = 0; if (fl[i] && f[i][0] == '-') { neg = true; j = 1; } for (; j < fl[i]; j++) v = v * 10 + (f[i][j] - '0'); return neg ? -v : v; };
+    const int flag = (int)num(1);
+    const int refid = (fl[2] == 1 && f[2][0] == '*') ? -1 : refs.id(f[2], fl[2]);
+    const long long pos = num(3) - 1;
+    const int mapq = (int)num(4);
+    // CIGAR
+    std::vector<uint32_t> cig;
+    long long reflen = 0;
+    if (!(fl[5] == 1 && f[5][0] == '*')) {
+        uint32_t len = 0;
+        for (size_t j = 0; j < fl[5]; j++) {
+            const char c = f[5][j];
+            if (c >= '0' && c <= '9') { len = len * 10 + (uint32_t)(c - '0'); continue; }
+            const int op = c == 'M' ? 0 : c == 'I' ? 1 : c == 'D' ? 2 : c == 'N' ? 3 : c == 'S' ? 4 : c == 'H' ? 5 : c == 'P' ? 6 : c == '=' ? 7 : 8;
+            cig.push_back((len << 4) | (uint32_t)op);
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += len;
+            len = 0;
+        }
+    }
+    const int next_ref = (fl[6] == 1 && f[6][0] == '=') ? refid : (fl[6] == 1 && f[6][0] == '*') ? -1 : refs.id(f[6], fl[6]);
+    const long long next_pos = num(7) - 1;
+    const long long tlen = num(8);
+    const size_t lseq = (fl[9] == 1 && f[9][0] == '*') ? 0 : fl[9];
+    const size_t at = o.size();
+    put_le32(o, 0);                                                  // block_size, patched below
+    put_le32(o, (uint32_t)refid); put_le32(o, (uint32_t)pos);
+    o.push_back((char)(fl[0] + 1)); o.push_back((char)mapq);
+    put_le16(o, (uint16_t)reg2bin(pos, pos + (cig.empty() || reflen == 0 ? 1 : reflen)));
+    put_le16(o, (uint16_t)cig.size()); put_le16(o, (uint16_t)flag);
+    put_le32(o, (uint32_t)lseq); put_le32(o, (uint32_t)next_ref); put_le32(o, (uint32_t)next_pos); put_le32(o, (uint32_t)tlen);
+    o.insert(o.end(), f[0], f[0] + fl[0]); o.push_back(0);
+    for (uint32_t c : cig) put_le32(o, c);
+    static const unsigned char nt16[256] = {
+        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 1,2,4,8,15,15,15,15,15,15,15,15,15,0,15,15,
+        15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
+        15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
+        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15};
+    for (size_t j = 0; j < lseq; j += 2) {
+        const unsigned char hi = nt16[(unsigned char)f[9][j]], lo = j + 1 < lseq ? nt16[(unsigned char)f[9][j + 1]] : 0;
+        o.push_back((char)((hi << 4) | lo));
+    }
+    if (fl[10] == 1 && f[10][0] == '*') o.insert(o.end(), lseq, (char)0xff);
+    else for (size_t j = 0; j < lseq; j++) o.push_back((char)(f[10][j] - 33));
+    if (nf > 11 && fl[11] > 5 && !memcmp(f[11], "NM:i:", 5)) {
+        long long v = 0;
+        for (size_t j = 5; j < fl[11]; j++) v = v * 10 + (f[11][j] - '0');
+        o.push_back('N'); o.push_back('M');
+        if (v <= 0xff) { o.push_back('C'); o.push_back((char)v); }
+        else if (v <= 0xffff) { o.push_back('S'); put_le16(o, (uint16_t)v); }
+        else { o.push_back('I'); put_le32(o, (uint32_t)v); }
+    }
+    const uint32_t bs = (uint32_t)(o.size() - at - 4);
+    o[at] = (char)bs; o[at + 1] = (char)(bs >> 8); o[at + 2] = (char)(bs >> 16); o[at + 3] = (char)(bs >> 24);
+}
+
+// BGZF: independent gzip members of at most 0xff00 input bytes with the BC extra field (SAM spec 4.1)
+void bgzf_append(const char* in, size_t n, std::vector<char>& out)
+{
+    size_t done = 0;
+    do {
+        const size_t chunk = std::min<size_t>(n - done, 0xff00);
+        const size_t at = out.size();
+        out.resize(at + 18 + compressBound((uLong)chunk) + 8);
+        z_stream zs; memset(&zs, 0, sizeof(zs));
+        deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = (Bytef*)(in + done); zs.avail_in = (uInt)chunk;
+        zs.next_out = (Bytef*)(out.data() + at + 18); zs.avail_out = (uInt)(out.size() - at - 18 - 8);
+        deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(out.data() + at, hdr, 16);
+        const uint16_t bsize = (uint16_t)(clen + 25);
+        out[at + 16] = (char)bsize; out[at + 17] = (char)(bsize >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(in + done), (uInt)chunk);
+        char* t = out.data() + at + 18 + clen;
+        t[0] = (char)crc; t[1] = (char)(crc >> 8); t[2] = (char)(crc >> 16); t[3] = (char)(crc >> 24);
+        t[4] = (char)chunk; t[5] = (char)(chunk >> 8); t[6] = (char)(chunk >> 16); t[7] = (char)(chunk >> 24);
+        out.resize(at + 18 + clen + 8);
+        done += chunk;
+    } while (done < n);
+}
+
 void print_stats(FILE* o, const int64_t st[5])
 {
     long long reads = st[0], uniq = st[1], amb = st[2], unm = st[0] - st[1] - st[2];
@@ -319,7 +435,7 @@ int main(int argc, char** argv)
     std::string index, seq, seq1, seq2, out = "output", mapstats;
     int device = 0, io_threads = 0;
     long batch = 1000000;
-    bool verbose = false, unmapped_out = false, pbat = false;
+    bool verbose = false, unmapped_out = false, pbat = false, bam = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -350,10 +466,12 @@ int main(int argc, char** argv)
         else if (a == "--unmapped_out") unmapped_out = true;          // Process_CommandLines.cpp:104-105
         else if (a == "--ambiguous_out") P.ambiguous_out = 1;
         else if (a == "--pbat") pbat = true;                          // Process_CommandLines.cpp:93
+        else if (a == "--bam") bam = true;                            // Process_CommandLines.cpp:94-95
+        else if (a == "--sam") bam = false;
         else { fprintf(stderr, "bmbs_search: unsupported option %s\n", a.c_str()); return 2; }
     }
     if (index.empty() || (seq.empty() && (seq1.empty() || seq2.empty()))) {
-        fprintf(stderr, "usage: bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--pbat] [--unmapped_out] [--ambiguous_out] [--mapstats f] [-t io_threads]\n");
+        fprintf(stderr, "usage: bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--pbat] [--unmapped_out] [--ambiguous_out] [--bam] [--mapstats f] [-t io_threads]\n");
         return 2;
     }
     if (batch < 1) batch = 1;
@@ -380,9 +498,23 @@ int main(int argc, char** argv)
         h += "@PG\tID:BitMapperBS\tVN:1.0.2.3\tCL:";
         for (int i = 0; i < argc; i++) { h += argv[i]; h += ' '; }
         h += '\n';
+        if (bam) {
+            // BAM header: magic, the same text, the reference dictionary; one BGZF block series
+            std::vector<char> hb = {'B', 'A', 'M', 1}, z;
+            put_le32(hb, (uint32_t)h.size()); hb.insert(hb.end(), h.begin(), h.end());
+            put_le32(hb, (uint32_t)view.n_chrom);
+            for (int i = 0; i < view.n_chrom; i++) {
+                const std::string& nm = chrom_names[(size_t)i];
+                put_le32(hb, (uint32_t)nm.size() + 1); hb.insert(hb.end(), nm.begin(), nm.end()); hb.push_back(0);
+                put_le32(hb, (uint32_t)view.chrom_len[i]);
+            }
+            bgzf_append(hb.data(), hb.size(), z);
+            h.assign(z.begin(), z.end());
+        }
         if (pwrite(ofd, h.data(), h.size(), 0) != (ssize_t)h.size()) { fprintf(stderr, "write error on %s\n", out.c_str()); return 1; }
         out_off = h.size();
     }
+    BamNames bam_refs; bam_refs.names = chrom_names;
     const bool pe = seq.empty();
     const bool ambiguous_out = P.ambiguous_out != 0;
     // --pbat: single-end reads are mapped as their reverse complement with mirrored qualities (inputReads_single_directly_pbat,
@@ -533,6 +665,7 @@ int main(int argc, char** argv)
             const bool end = b->end;
             const int T = pool.size() * 2;
             b->text.resize((size_t)T); b->text_len.assign((size_t)T, 0);
+            if (bam) { b->bam_rec.resize((size_t)T); b->bam_z.resize((size_t)T); }
             if (nrec && !failed) {
                 const long per = (nrec + T - 1) / T;
                 const bmbs_result* res = (const bmbs_result*)b->res.p;
@@ -616,7 +749,26 @@ int main(int argc, char** argv)
                             o.lit("\tNM:i:"); o.num(x2.nm); o.ch('\n');
                         }
                     }
-                    b->text_len[(size_t)t] = (size_t)(o.p - buf.data());
+                    size_t tl = (size_t)(o.p - buf.data());
+                    if (bam && tl) {
+                        // the slice's SAM lines -> BAM records -> BGZF blocks (records may straddle blocks)
+                        std::vector<char>& rec = b->bam_rec[(size_t)t];
+                        std::vector<char>& z = b->bam_z[(size_t)t];
+                        rec.clear(); z.clear();
+                        const char* q = buf.data();
+                        const char* e2 = q + tl;
+                        while (q < e2) {
+                            const char* nlp = (const char*)memchr(q, '\n', (size_t)(e2 - q));
+                            const size_t ll = nlp ? (size_t)(nlp - q) : (size_t)(e2 - q);
+                            sam_line_to_bam(q, ll, bam_refs, rec);
+                            q += ll + 1;
+                        }
+                        bgzf_append(rec.data(), rec.size(), z);
+                        if (buf.size() < z.size()) buf.resize(z.size());
+                        memcpy(buf.data(), z.data(), z.size());
+                        tl = z.size();
+                    }
+                    b->text_len[(size_t)t] = tl;
                 });
             }
             t_format += now() - t0;
@@ -698,6 +850,11 @@ int main(int argc, char** argv)
     reader.join();
     formatter.join();
     writer.join();
+    if (bam && !failed) {
+        static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (pwrite(ofd, eof_block, 28, (off_t)out_off) != 28) failed = true;
+        out_off += 28;
+    }
     const double t_joined = now();
     ::close(ofd);
     src1.close();

@@ -103,3 +103,19 @@ def trim_fastq(src, dst, seed, lo=30):
             n = len(lines[i + 1])
             k = int(rng.integers(min(lo, n), n + 1)) if rng.random() < 0.7 else n
             o.write(lines[i] + b"\n" + lines[i + 1][:k] + b"\n" + lines[i + 2] + b"\n" + lines[i + 3][:k] + b"\n")
+
+
+def bam_payload(path):
+    """BGZF-decompressed BAM split into (reference dictionary bytes, record stream bytes); the header text (it holds the
+    command line) is dropped"""
+    import gzip, struct
+    d = gzip.open(path, "rb").read()
+    assert d[:4] == b"BAM\x01"
+    l_text = struct.unpack("<i", d[4:8])[0]
+    p = 8 + l_text
+    n_ref = struct.unpack("<i", d[p:p + 4])[0]
+    q = p + 4
+    for _ in range(n_ref):
+        ln = struct.unpack("<i", d[q:q + 4])[0]
+        q += 8 + ln
+    return d[p:q], d[q:]

@@ -52,6 +52,9 @@ VARIANTS = {
     "se_b150_trim": dict(kind="se", base="b150", trim=[7], args=["-e", "0.04", "--unmapped_out"]),
     "pe_p100_trim": dict(kind="pe", base="p100", trim=[8, 9], args=["-e", "0.04", "--max", "520", "--ambiguous_out"]),
     "pe_s100_trim": dict(kind="pe", base="s100", trim=[10, 11], args=["--sensitive"]),
+    # --bam: the reference's BAM file itself is the fixture (compared after BGZF decompression, minus the @PG command line)
+    "se_e75_bam": dict(kind="se", base="e75", bam=True, args=["--bam", "--unmapped_out", "--ambiguous_out"]),
+    "pe_p75_bam": dict(kind="pe", base="p75", bam=True, args=["--bam", "--min", "100", "--max", "250", "--unmapped_out"]),
     "pe_p100_pbat": dict(kind="pe", base="p100", swap=True, args=["-e", "0.04", "--max", "520", "--pbat", "--unmapped_out"]),
 }
 
@@ -143,10 +146,14 @@ def main():
             inp = ["--seq1", fa_, "--seq2", fb_]
         p = subprocess.run([ref, "--search", fa] + inp + ["-t", "1", "-o", sam] + v["args"], capture_output=True, text=True, cwd=wd)
         assert p.returncode == 0, p.stderr
-        body = "".join(l for l in open(sam) if not l.startswith("@PG"))
-        with gzip.GzipFile(os.path.join(HERE, "var_%s.ref.sam.gz" % name), "wb", mtime=0) as g: g.write(body.encode())
         stats = "".join(l for l in p.stderr.splitlines(True) if l.startswith("No. of") or l.startswith("Mismatch"))
         open(os.path.join(HERE, "var_%s.ref.stats" % name), "w").write(stats)
+        if v.get("bam"):
+            shutil.copy(sam, os.path.join(HERE, "var_%s.ref.bam" % name))
+            print("VARIANT", name, "bam bytes", os.path.getsize(sam), stats.splitlines()[1])
+            continue
+        body = "".join(l for l in open(sam) if not l.startswith("@PG"))
+        with gzip.GzipFile(os.path.join(HERE, "var_%s.ref.sam.gz" % name), "wb", mtime=0) as g: g.write(body.encode())
         print("VARIANT", name, "lines", body.count("\n"), stats.splitlines()[1], stats.splitlines()[2])
     json.dump(VARIANTS, open(os.path.join(HERE, "variants.json"), "w"), indent=1)
     shutil.rmtree(wd)

@@ -389,8 +389,14 @@ def test_cpp_driver_output_variants_equal_reference_golden(name, tmp_path):
     mapper.Index.build(fa, fa, threads=4)
     p = subprocess.run([_driver(), "--search", fa] + variant_inputs(v, tmp_path) + ["-o", out, "--batch", "500"] + v["args"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
-    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
-    assert mine == gzip.open(os.path.join(GOLD, "var_%s.ref.sam.gz" % name), "rt").read()
+    if v.get("bam"):
+        # --bam: same reference dictionary and byte-identical record stream as the reference's (htslib-written) BAM
+        from common import bam_payload
+        assert bam_payload(out) == bam_payload(os.path.join(GOLD, "var_%s.ref.bam" % name))
+        assert open(out, "rb").read()[-28:] == open(os.path.join(GOLD, "var_%s.ref.bam" % name), "rb").read()[-28:]     # BGZF EOF marker
+    else:
+        mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+        assert mine == gzip.open(os.path.join(GOLD, "var_%s.ref.sam.gz" % name), "rt").read()
     stats = "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
     assert stats == open(os.path.join(GOLD, "var_%s.ref.stats" % name)).read()
 
