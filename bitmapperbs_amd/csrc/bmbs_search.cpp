@@ -871,8 +871,12 @@ int main(int argc, char** argv)
     if (verbose && getenv("BMBS_TRACE"))
         for (const auto* v : {&ev_r, &ev_g, &ev_f, &ev_w})
             for (const Ev& e : *v) fprintf(stderr, "[trace] %c n=%ld %.4f .. %.4f\n", e.stage, e.n, e.a - t_loaded, e.b - t_loaded);
+    const double t0 = now();
     for (auto& b : batches) { b.seq1.release(); b.qual1.release(); b.seq2.release(); b.qual2.release(); b.res.release(); b.pool.release(); }
+    const double t1 = now();
     bmbs_destroy(ctx);
+    const double t2 = now();
     bmbs_index_file_free(ixf);
+    if (verbose) fprintf(stderr, "[bmbs_search] teardown: unpin %.3fs, destroy ctx %.3fs, free index %.3fs\n", t1 - t0, t2 - t1, now() - t2);
     return 0;
 }
