@@ -260,6 +260,38 @@ const uint32_t NOROW = 0xffffffffu;
 
 inline char rc_char(char c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }   // rc_table, Process_Reads.cpp:1603
 
+// eight characters at a time: reverse complement (A<->T = ^0x15, C<->G = ^0x04, everything else unchanged) and upper-casing
+inline uint64_t zero_bytes(uint64_t x) { const uint64_t K7F = 0x7f7f7f7f7f7f7f7full; return ~(((x & K7F) + K7F) | x | K7F); }   // 0x80 where a byte is 0
+inline uint64_t comp8(uint64_t w)
+{
+    const uint64_t at = zero_bytes(w ^ 0x4141414141414141ull) | zero_bytes(w ^ 0x5454545454545454ull);
+    const uint64_t cg = zero_bytes(w ^ 0x4343434343434343ull) | zero_bytes(w ^ 0x4747474747474747ull);
+    return w ^ ((at >> 7) * 0x15) ^ ((cg >> 7) * 0x04);
+}
+// dst[i] = complement(src[L-1-i])
+inline void revcomp_copy(char* dst, const char* src, int L)
+{
+    int i = 0;
+    for (; i + 8 <= L; i += 8) { uint64_t w; memcpy(&w, src + L - 8 - i, 8); w = comp8(__builtin_bswap64(w)); memcpy(dst + i, &w, 8); }
+    for (; i < L; i++) dst[i] = rc_char(src[L - 1 - i]);
+}
+inline void reverse_copy(char* dst, const char* src, int L)
+{
+    int i = 0;
+    for (; i + 8 <= L; i += 8) { uint64_t w; memcpy(&w, src + L - 8 - i, 8); w = __builtin_bswap64(w); memcpy(dst + i, &w, 8); }
+    for (; i < L; i++) dst[i] = src[L - 1 - i];
+}
+// toupper over a buffer: a character with bit 0x20 set is rare in FASTQ sequence lines, so test 8 at a time
+inline void upper_inplace(char* d, int L)
+{
+    int i = 0;
+    for (; i + 8 <= L; i += 8) {
+        uint64_t w; memcpy(&w, d + i, 8);
+        if (w & 0x2020202020202020ull) for (int j = 0; j < 8; j++) { const char c = d[i + j]; if (c >= 'a' && c <= 'z') d[i + j] = (char)(c - 32); }
+    }
+    for (; i < L; i++) { const char c = d[i]; if (c >= 'a' && c <= 'z') d[i] = (char)(c - 32); }
+}
+
 inline void put_uint(std::string& s, unsigned long long v)
 {
     char b[24]; int i = 24;
@@ -289,11 +321,7 @@ struct Out {
     void seq(const char* sq, const char* ql, int L, bool rc)
     {
         if (!rc) { memcpy(p, sq, (size_t)L); p[L] = '\t'; memcpy(p + L + 1, ql, (size_t)L); }
-        else {
-            for (int i = 0; i < L; i++) p[i] = rc_char(sq[L - 1 - i]);
-            p[L] = '\t';
-            for (int i = 0; i < L; i++) p[L + 1 + i] = ql[L - 1 - i];
-        }
+        else { revcomp_copy(p, sq, L); p[L] = '\t'; reverse_copy(p + L + 1, ql, L); }
         p += 2 * (size_t)L + 1;
     }
 };
@@ -631,15 +659,19 @@ int main(int argc, char** argv)
                         const size_t qs = ln.start((size_t)r * 4 + 3), qe = ln.end((size_t)r * 4 + 3);
                         const int ql = (int)std::min<size_t>((size_t)L, qe - qs);
                         if (!rc) {
-                            for (int i = 0; i < L; i++) { const char c = s[i]; sdst[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+                            memcpy(sdst, s, (size_t)L);
+                            upper_inplace(sdst, L);
                             memcpy(qdst, ln.p + qs, (size_t)ql);
                             for (int i = ql; i < L; i++) qdst[i] = ' ';      // qual.resize(seq.size(), ' ')
                         } else {
-                            for (int i = 0; i < L; i++) { const char c = s[L - 1 - i]; sdst[i] = rc_char((c >= 'a' && c <= 'z') ? (char)(c - 32) : c); }
+                            memcpy(qdst, s, (size_t)L);                      // qdst as scratch: upper-case first, then reverse-complement
+                            upper_inplace(qdst, L);
+                            revcomp_copy(sdst, qdst, L);
                             const char* q = ln.p + qs;
-                            for (int i = 0; i < L; i++) { const int jj = L - 1 - i; qdst[i] = jj < ql ? q[jj] : ' '; }
+                            if (ql == L) reverse_copy(qdst, q, L);
+                            else for (int i = 0; i < L; i++) { const int jj = L - 1 - i; qdst[i] = jj < ql ? q[jj] : ' '; }
                         }
-                        for (int i = L; i < g.stride; i++) { sdst[i] = 0; qdst[i] = 0; }
+                        if (L < g.stride) { memset(sdst + L, 0, (size_t)(g.stride - L)); memset(qdst + L, 0, (size_t)(g.stride - L)); }
                     };
                     pack(b->l1, L1, pbat_se, b->seq1.p + at, b->qual1.p + at);
                     if (pe) pack(b->l2, L2, false, b->seq2.p + at, b->qual2.p + at);

@@ -78,7 +78,7 @@ def main():
             dt = time.time() - t0
             if p.returncode:
                 print(p.stderr[-2000:]); sys.exit(1)
-        line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]")][-1]
+        line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
         map_wall = float(line.split("mapping wall")[1].split("s")[0])
         res["runs"].append({"program": "bmbs_search (1 MI355X)", "io_threads": t, "wall_s": round(dt, 3), "mapping_wall_s": map_wall,
                             "Mreads_per_s_wall": round(n_reads / dt / 1e6, 3), "Mreads_per_s_mapping": round(n_reads / map_wall / 1e6, 3),
