@@ -125,20 +125,32 @@ DEVI int code4(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 :
 // One read per lane means a byte load touches 64 different cache lines per wave instruction; wide
 // loads cut the number of such instructions by 8.
 struct ReadCur {
-    // like WinReader: the next 8 characters are on their way while the current 8 are consumed
-    const char* rd; u64 buf, nxt; int pos, lim;
+    // 16 characters per global load (rows are 16-byte aligned); the second half waits in `hi` until the first eight
+    // characters are used up
+    const char* rd; u64 buf, hi; int pos, lim;
+    DEVI void fill(int at)                        // at: multiple of 16, < lim
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(rd + at);
+        buf = ((u64)v.y << 32) | v.x; hi = ((u64)v.w << 32) | v.z;
+    }
     DEVI void seek(const char* r, int p, int L)
     {
-        rd = r; pos = p; lim = L;
-        buf = p < L ? *reinterpret_cast<const u64*>(rd + (p & ~7)) >> (8 * (p & 7)) : 0ull;
-        nxt = (p & ~7) + 8 < L ? *reinterpret_cast<const u64*>(rd + (p & ~7) + 8) : 0ull;
+        rd = r; pos = p; lim = L; buf = 0; hi = 0;
+        if (p < L) {
+            fill(p & ~15);
+            if (p & 8) buf = hi;
+            buf >>= 8 * (p & 7);
+        }
     }
     DEVI char next()
     {
         const char c = (char)(buf & 0xff);
         pos++;
-        if ((pos & 7) == 0) { buf = nxt; nxt = pos + 8 < lim ? *reinterpret_cast<const u64*>(rd + pos + 8) : 0ull; }   // never past the read
-        else buf >>= 8;
+        if ((pos & 7) == 0) {
+            if (pos & 8) buf = hi;
+            else if (pos < lim) fill(pos);        // never past the read's last 16-byte piece
+            else buf = 0;
+        } else buf >>= 8;
         return c;
     }
 };
