@@ -107,7 +107,7 @@ int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot)
     ENS(c, c->scan_tmp, (nb + 1) * 8);
     u64* bs = c->scan_tmp.as<u64>();
     hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, bs, nb, c->totals.as<u64>() + slot);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bs, nb, c->totals.as<u64>() + slot);
     hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out);
     return BMBS_OK;
 }

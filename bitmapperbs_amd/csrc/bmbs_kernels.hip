@@ -357,63 +357,82 @@ __global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out)
 // ================================================================================================
 #define SCAN_BLOCK 256
 #define SCAN_ITEMS 8            // per thread
-__global__ void k_scan_partial(const u32* in, u64 n, u64* block_sums)
+// block-wide inclusive scan of one u64 per thread (wave shuffles + one LDS hop); returns the inclusive value, *total the block sum
+DEVI u64 block_scan_incl(u64 v, u64* sh_waves, u64& total)
 {
-    __shared__ u64 sh[SCAN_BLOCK];
-    const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
-    u64 s = 0;
-    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) s += in[base + j];
-    sh[threadIdx.x] = s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    for (int d = 1; d < 64; d <<= 1) { const u64 t = __shfl_up(v, d); if (lane >= d) v += t; }
+    if (lane == 63) sh_waves[w] = v;
     __syncthreads();
-    for (int d = SCAN_BLOCK / 2; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+    u64 add = 0, tot = 0;
+    for (int i = 0; i < nw; i++) { const u64 x = sh_waves[i]; if (i < w) add += x; tot += x; }
+    __syncthreads();
+    total = tot;
+    return v + add;
 }
-__global__ void k_scan_blocks(u64* block_sums, u64 nb, u64* total)
+// eight consecutive u32 of a thread, two 16-byte loads when whole (the inputs are hipMalloc'ed: 16-byte aligned)
+DEVI void scan_load8(const u32* in, u64 base, u64 n, u32 x[SCAN_ITEMS])
 {
-    // single block, serial over chunks of blockDim
-    __shared__ u64 sh[SCAN_BLOCK];
-    __shared__ u64 carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (u64 base = 0; base < nb; base += SCAN_BLOCK) {
-        const u64 i = base + threadIdx.x;
-        const u64 v = i < nb ? block_sums[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
-            u64 t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nb) block_sums[i] = carry + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == SCAN_BLOCK - 1) carry += sh[SCAN_BLOCK - 1];
-        __syncthreads();
+    if (base + SCAN_ITEMS <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(in + base), b = *reinterpret_cast<const uint4*>(in + base + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) x[j] = base + j < n ? in[base + j] : 0u;
     }
-    if (threadIdx.x == 0) *total = carry;
 }
-__global__ void k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partial(const u32* in, u64 n, u64* block_sums)
 {
-    __shared__ u64 sh[SCAN_BLOCK];
+    __shared__ u64 sh[SCAN_BLOCK / 64];
     const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
-    u64 loc[SCAN_ITEMS];
+    u32 x[SCAN_ITEMS];
+    scan_load8(in, base, n, x);
     u64 s = 0;
-    for (int j = 0; j < SCAN_ITEMS; j++) { loc[j] = s; if (base + j < n) s += in[base + j]; }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
-        u64 t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) s += x[j];
+    u64 total;
+    (void)block_scan_incl(s, sh, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+// one block of 1024 threads: thread t owns a contiguous run of block sums, scanned serially, runs combined by one block scan
+__global__ void __launch_bounds__(1024) k_scan_blocks(u64* block_sums, u64 nb, u64* total)
+{
+    __shared__ u64 sh[16];
+    const u64 per = (nb + blockDim.x - 1) / blockDim.x;
+    const u64 a = (u64)threadIdx.x * per, b = a + per < nb ? a + per : nb;
+    u64 s = 0;
+    for (u64 i = a; i < b; i++) s += block_sums[i];
+    u64 tot;
+    const u64 incl = block_scan_incl(s, sh, tot);
+    u64 run = incl - s;
+    for (u64 i = a; i < b; i++) { const u64 v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (threadIdx.x == 0) *total = tot;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out)
+{
+    __shared__ u64 sh[SCAN_BLOCK / 64];
+    const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 x[SCAN_ITEMS];
+    scan_load8(in, base, n, x);
+    u64 s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) s += x[j];
+    u64 tot;
+    const u64 incl = block_scan_incl(s, sh, tot);
+    u64 run = incl - s + block_sums[blockIdx.x];
+    if (base + SCAN_ITEMS <= n) {
+        u64 o[SCAN_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) { o[j] = run; run += x[j]; }
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(out + base);        // out is 16-byte aligned, base a multiple of 8
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j += 2) dst[j >> 1] = make_ulonglong2(o[j], o[j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) { out[base + j] = run; run += x[j]; }
     }
-    const u64 excl = sh[threadIdx.x] - s + block_sums[blockIdx.x];
-    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] = excl + loc[j];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = excl + s;
+    if (base <= n && n < base + SCAN_ITEMS) out[n] = run;                   // the thread that owns position n writes the total
+    if (n % ((u64)SCAN_BLOCK * SCAN_ITEMS) == 0 && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = run;
 }
 
 // ================================================================================================
