@@ -71,15 +71,29 @@ def parse():
     ap.add_argument("--pe", action="store_true", help="paired-end fast mode: --reads pairs per GPU per step (value counts 2 reads per pair)")
     ap.add_argument("--sensitive", action="store_true", help="with --pe: Map_Pair_Seq_end_to_end (--sensitive) instead of fast mode")
     ap.add_argument("--sub", type=float, default=0.005, help="substitution rate of the synthetic reads (SURVEY.md 8d: 0.5 %%)")
+    ap.add_argument("--repeats", type=int, default=0, help="stress: plant this many diverged copies of 300-bp elements (5 families, 2-8 %% divergence) into the genome")
     ap.add_argument("--workdir", default=os.environ.get("BMBS_BENCH_DIR", "/tmp/bmbs_bench"))
     return ap.parse_args()
 
 
 def ensure_index(args, rank, world, dist):
     from bitmapperbs_amd import synth, mapper
-    wd = os.path.join(args.workdir, "g%d" % args.genome)
+    rep = getattr(args, "repeats", 0)
+    wd = os.path.join(args.workdir, "g%d%s" % (args.genome, "_r%d" % rep if rep else ""))
     fa = os.path.join(wd, "g.fa")
     names, chroms = synth.make_genome(args.genome, 4, seed=20240229)
+    if rep:
+        # interspersed-repeat stress (Alu-like): seeds inside a copy hit hundreds of places, candidate lists get long
+        rng = np.random.default_rng(77)
+        for fam in range(5):
+            el = synth._ACGT[rng.integers(0, 4, 300)]
+            for _ in range(rep // 5):
+                ch = chroms[int(rng.integers(0, len(chroms)))]
+                p = int(rng.integers(0, ch.size - 300))
+                e = el.copy()
+                m = rng.random(300) < rng.uniform(0.02, 0.08)
+                e[m] = synth._ACGT[rng.integers(0, 4, int(m.sum()))]
+                ch[p:p + 300] = synth.revcomp(e) if rng.random() < 0.5 else e
     if rank == 0:
         os.makedirs(wd, exist_ok=True)
         if not os.path.exists(fa + ".index.bs.index.sa"):

@@ -50,7 +50,7 @@ struct bmbs_ctx {
     DevBuf pe_seq, pe_qual, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
     DevBuf pe_first, pe_full, pe_R, pe_roff, pe_rflag, pe_rscan, pe_rlist, pe_rcnt, pe_ritem_off, pe_rcand;     // --sensitive
     u64 last_reseeded = 0, last_reseed_cand = 0;
-    DevBuf stats, counters;
+    DevBuf stats, counters, long_flag, long_off, long_list;     // long_*: reads whose candidate lists go to k_vote_long
     std::vector<Prof> prof;
     int n_prof_used = 0;
     u64 last_total_cand = 0, last_n_jobs = 0;
@@ -378,9 +378,21 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
                            c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
         prof_end(c);
     } else {
+        ENS(c, c->long_flag, n * 4); ENS(c, c->long_off, (n + 1) * 8); ENS(c, c->long_list, n * 4);
         prof_begin(c, "k_vote_fused");
         hipLaunchKernelGGL(k_vote_fused, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, st, c->cand.as<u64>(),
-                           c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
+                           c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->long_flag.as<u32>());
+        prof_end(c);
+        // reads with more than 16 candidates (repeats): one block per read
+        prof_begin(c, "k_vote_long");
+        int rl = scan_u32(c, c->long_flag.as<u32>(), n, c->long_off.as<u64>(), 9);
+        if (rl) return rl;
+        hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, c->long_flag.as<u32>(), c->long_off.as<u64>(),
+                           c->long_list.as<u32>());
+        hipLaunchKernelGGL((k_vote_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
+                           c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
+        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
+                           c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
         prof_end(c);
     }
     return BMBS_OK;
@@ -441,7 +453,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->stats, &c->counters, &c->pe_seq, &c->pe_qual, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
-                     &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand};
+                     &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);

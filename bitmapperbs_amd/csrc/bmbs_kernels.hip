@@ -1062,10 +1062,11 @@ k_vote(long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __r
 #define VOTE_REG 16
 __global__ void __launch_bounds__(64)
 k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes,
-             u32* __restrict__ slot_read)
+             u32* __restrict__ slot_read, u32* __restrict__ long_flag)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    if (long_flag) long_flag[r] = 0;
     if (st.verdict[r] != 3) { st.n_votes[r] = 0; return; }
     const int k = gm.rk(gm.rl(r));
     const u64 off = st.cand_off[r];
@@ -1129,7 +1130,9 @@ k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ c
         for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
         return;
     }
-    // long lists: locate into the candidate array, sort there
+    // long lists (repeats): a whole block sorts each of them out of LDS (k_vote_long)
+    if (long_flag) { long_flag[r] = 1; st.n_votes[r] = 0; return; }
+    // single-lane form (stage API without the list buffers, and lists beyond the LDS capacity of k_vote_long)
     u64* c = cand + off;
     {
         u64 o = 0;
@@ -1151,6 +1154,145 @@ k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ c
     intro_sort_desc(v, nv);             // std::sort(votes, compare_seed_votes), Schema.cpp:24986
     st.n_votes[r] = (u32)nv;
     for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+}
+
+// ---- long candidate lists (reads inside repeats: up to 25 seeds x 1000 hits) -----------------------------------------------
+// One lane sorting thousands of sites in global memory holds its whole wave for milliseconds; on a repeat-rich genome that was
+// 10-40 ms per batch.  Here a 256-thread block takes one such read: the sites are located straight into LDS, sorted by a
+// bitonic network, run-length encoded in parallel -- and only the vote order, which must be std::sort's exact (unstable)
+// permutation (bmbs_sort.h), is produced by a single lane, on 4-byte (vote, index) items in LDS.
+#define VL_CAP 4096           // block form: 256 threads per read
+#define VL_BLOCK 256
+#define VM_CAP 256            // wave form: 64 threads per read (most repeat reads have a few dozen candidates)
+#define VM_BLOCK 64
+// block-wide exclusive prefix of a 0/1 flag; returns the prefix, `total` the block count.  sh_w: one word per wave
+DEVI int vl_prefix(bool flag, int* sh_w, int& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) sh_w[w] = __popcll(m);
+    __syncthreads();
+    int add = 0, tot = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) { const int x = sh_w[i]; if (i < w) add += x; tot += x; }
+    __syncthreads();
+    total = tot;
+    return add + __popcll(m & ((1ull << lane) - 1));
+}
+// locate the nc <= VL_CAP candidates of a read into keys[0, np2) (padded with ~0) and sort them ascending; returns np2
+DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u64* keys, u32* sh_pref)
+{
+    if (threadIdx.x == 0) { u32 a = 0; for (int s2 = 0; s2 < ns; s2++) { sh_pref[s2] = a; a += my[s2].hits; } sh_pref[ns] = a; }
+    __syncthreads();
+    int np2 = 32;
+    while (np2 < nc) np2 <<= 1;
+    for (int j = threadIdx.x; j < np2; j += blockDim.x) {
+        u64 key = ~0ull;
+        if (j < nc) {
+            int s2 = 0;
+            while (s2 + 1 < ns && sh_pref[s2 + 1] <= (u32)j) s2++;
+            const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
+            key = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + ((u32)j - sh_pref[s2])]) - adj;
+        }
+        keys[j] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool asc = (i & size) == 0;
+                const u64 a = keys[i], b = keys[j];
+                if ((a > b) == asc) { keys[i] = b; keys[j] = a; }
+            }
+            __syncthreads();
+        }
+    return np2;
+}
+// positions of the run ends of the sorted keys[0, nc), in order, into endpos; returns their number (block-uniform)
+DEVI int vl_run_ends(const u64* keys, int nc, u16* endpos, int* sh_w)
+{
+    int running = 0;
+    for (int base = 0; base < nc; base += blockDim.x) {
+        const int i = base + (int)threadIdx.x;
+        const bool flag = i < nc && (i == nc - 1 || keys[i + 1] != keys[i]);
+        int total;
+        const int pre = vl_prefix(flag, sh_w, total);
+        if (flag) endpos[running + pre] = (u16)i;
+        running += total;
+    }
+    __syncthreads();
+    return running;
+}
+
+// CAP, BLOCK = (VM_CAP, VM_BLOCK): lists of up to 256 candidates, one wave each; (VL_CAP, VL_BLOCK): the longer ones, one
+// block each (the two instances walk the same list and take the reads of their size class: LO < nc <= CAP, the last one also beyond)
+template <int CAP, int BLOCK, int LO>
+__global__ void __launch_bounds__(BLOCK)
+k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
+            u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read)
+{
+    __shared__ u64 keys[CAP];
+    __shared__ u16 endpos[CAP];
+    __shared__ bmbs_vk items[CAP];
+    __shared__ u32 sh_pref[BMBS_MAX_SEEDS + 1];
+    __shared__ int sh_w[BLOCK / 64 + 1];
+    const long total_items = (long)*count_ptr;
+    for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const long r = list[item];
+        const long nc = (long)st.n_cand[r];
+        if (nc <= LO || (CAP != VL_CAP && nc > CAP)) continue;          // another instance's size class
+        const int k = gm.rk(gm.rl(r));
+        const u64 off = st.cand_off[r];
+        const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+        const int ns = st.n_seeds[r];
+        bmbs_vote* v = votes + off;
+        if (nc > CAP) {
+            // beyond the LDS capacity: the single-lane form
+            if (threadIdx.x == 0) {
+                u64* c = cand + off;
+                u64 o = 0;
+                for (int s2 = 0; s2 < ns && o < (u64)nc; s2++) {
+                    const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
+                    const u32 hh = my[s2].hits;
+                    for (u32 j = 0; j < hh && o < (u64)nc; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;
+                }
+                sort_u64_asc(c, nc);
+                long nv = 0;
+                u64 pre = c[0];
+                u32 vote = 1;
+                for (long i = 1; i < nc; i++) {
+                    if (c[i] == pre) vote++;
+                    else { v[nv].site = pre < (u64)k ? 0 : pre - (u64)k; v[nv].vote = vote; v[nv].pad = 0; nv++; vote = 1; pre = c[i]; }
+                }
+                v[nv].site = pre >= (u64)k ? pre - (u64)k : 0; v[nv].vote = vote; v[nv].pad = 0; nv++;
+                intro_sort_desc(v, nv);
+                st.n_votes[r] = (u32)nv;
+                for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+            }
+            __syncthreads();
+            continue;
+        }
+        vl_locate_sort(ix, my, ns, (int)nc, keys, sh_pref);
+        const int nv = vl_run_ends(keys, (int)nc, endpos, sh_w);
+        // (vote, entry) items in site order; a site collects at most one vote per seed, so the vote fits 8 bits
+        for (int e = threadIdx.x; e < nv; e += BLOCK) {
+            const u32 vote = (u32)endpos[e] - (e ? (u32)endpos[e - 1] : 0xffffffffu);
+            items[e].x = (vote << 24) | (u32)e;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);      // std::sort(votes, compare_seed_votes), Schema.cpp:24986
+        __syncthreads();
+        for (int j = threadIdx.x; j < nv; j += BLOCK) {
+            const u32 it = items[j].x;
+            const u64 site = keys[endpos[it & 0xffffffu]];
+            bmbs_vote o;
+            o.site = site < (u64)k ? 0 : site - (u64)k; o.vote = it >> 24; o.pad = 0;
+            v[j] = o;
+        }
+        for (long i = threadIdx.x; i < nc; i += BLOCK) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+        if (threadIdx.x == 0) st.n_votes[r] = (u32)nv;
+        __syncthreads();
+    }
 }
 
 // the vote lists are shorter than the candidate segments they were built in: pack them densely

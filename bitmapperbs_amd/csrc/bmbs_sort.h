@@ -21,30 +21,34 @@
 
 // vote record as sorted: key = vote (descending), payload = site
 struct bmbs_vote { uint64_t site; uint32_t vote; uint32_t pad; };
+// compact element for sorting long lists out of LDS: vote in the top 8 bits, the entry's index below (the comparator only
+// looks at the vote, so the algorithm performs exactly the moves it would perform on the full records)
+struct bmbs_vk { uint32_t x; };
 
 namespace bmbs_sort_detail {
 BMBS_HD bool before(const bmbs_vote& a, const bmbs_vote& b) { return a.vote > b.vote; }
-BMBS_HD void swp(bmbs_vote* v, long a, long b) { bmbs_vote t = v[a]; v[a] = v[b]; v[b] = t; }
+BMBS_HD bool before(const bmbs_vk& a, const bmbs_vk& b) { return (a.x >> 24) > (b.x >> 24); }
+template <class T> BMBS_HD void swp(T* v, long a, long b) { T t = v[a]; v[a] = v[b]; v[b] = t; }
 
-BMBS_HD void unguarded_linear_insert(bmbs_vote* v, long last)
+template <class T> BMBS_HD void unguarded_linear_insert(T* v, long last)
 {
-    bmbs_vote val = v[last];
+    T val = v[last];
     long next = last - 1;
     while (before(val, v[next])) { v[last] = v[next]; last = next; --next; }
     v[last] = val;
 }
-BMBS_HD void insertion_sort(bmbs_vote* v, long first, long last)
+template <class T> BMBS_HD void insertion_sort(T* v, long first, long last)
 {
     if (first == last) return;
     for (long i = first + 1; i != last; ++i) {
         if (before(v[i], v[first])) {
-            bmbs_vote val = v[i];
+            T val = v[i];
             for (long q = i; q > first; --q) v[q] = v[q - 1];
             v[first] = val;
         } else unguarded_linear_insert(v, i);
     }
 }
-BMBS_HD void push_heap(bmbs_vote* v, long first, long hole, long top, bmbs_vote value)
+template <class T> BMBS_HD void push_heap(T* v, long first, long hole, long top, T value)
 {
     long parent = (hole - 1) / 2;
     while (hole > top && before(v[first + parent], value)) {
@@ -54,7 +58,7 @@ BMBS_HD void push_heap(bmbs_vote* v, long first, long hole, long top, bmbs_vote 
     }
     v[first + hole] = value;
 }
-BMBS_HD void adjust_heap(bmbs_vote* v, long first, long hole, long len, bmbs_vote value)
+template <class T> BMBS_HD void adjust_heap(T* v, long first, long hole, long len, T value)
 {
     const long top = hole;
     long child = hole;
@@ -71,13 +75,13 @@ BMBS_HD void adjust_heap(bmbs_vote* v, long first, long hole, long len, bmbs_vot
     }
     push_heap(v, first, hole, top, value);
 }
-BMBS_HD void heap_sort(bmbs_vote* v, long first, long last)
+template <class T> BMBS_HD void heap_sort(T* v, long first, long last)
 {
     long len = last - first;
     if (len >= 2) {
         long parent = (len - 2) / 2;
         for (;;) {
-            bmbs_vote val = v[first + parent];
+            T val = v[first + parent];
             adjust_heap(v, first, parent, len, val);
             if (parent == 0) break;
             parent--;
@@ -85,12 +89,12 @@ BMBS_HD void heap_sort(bmbs_vote* v, long first, long last)
     }
     while (last - first > 1) {
         --last;
-        bmbs_vote val = v[last];
+        T val = v[last];
         v[last] = v[first];
         adjust_heap(v, first, 0, last - first, val);
     }
 }
-BMBS_HD long partition_pivot(bmbs_vote* v, long first, long last)
+template <class T> BMBS_HD long partition_pivot(T* v, long first, long last)
 {
     long mid = first + (last - first) / 2;
     long a = first + 1, b = mid, c = last - 1;
@@ -115,7 +119,7 @@ BMBS_HD long partition_pivot(bmbs_vote* v, long first, long last)
 }  // namespace bmbs_sort_detail
 
 // sorts v[0..n) by vote descending with std::sort's exact permutation
-BMBS_HD void intro_sort_desc(bmbs_vote* v, long n)
+template <class T> BMBS_HD void intro_sort_desc(T* v, long n)
 {
     using namespace bmbs_sort_detail;
     if (n <= 1) return;
