@@ -743,9 +743,20 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     ENS(c, c->dense_read, t1 * 4); ENS(c, c->ferr, t1 * 4);
     PeCand* A = c->votes.as<PeCand>();
     PeCand* B = c->pe_B.as<PeCand>();
+    ENS(c, c->long_flag, n2 * 4); ENS(c, c->long_off, (n2 + 1) * 8); ENS(c, c->long_list, n2 * 4);
     prof_begin(c, "k_vote_pe_fused");
     hipLaunchKernelGGL(k_vote_pe_fused, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, c->ix, (long)n2, gm, st, ps, c->cand.as<u64>(), A,
-                       c->slot_read.as<u32>());
+                       c->slot_read.as<u32>(), c->long_flag.as<u32>());
+    prof_end(c);
+    prof_begin(c, "k_vote_pe_long");
+    rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_flag_list, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, c->long_flag.as<u32>(), c->long_off.as<u64>(),
+                       c->long_list.as<u32>());
+    hipLaunchKernelGGL((k_vote_pe_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, ps,
+                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A);
+    hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
+                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A);
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {

@@ -1939,10 +1939,11 @@ k_vote_pe(long n2, ReadGeom gm, ReadState st, PeState ps, u64* __restrict__ cand
 // k_vote_fused; general reads emit one entry per distinct site (no vote order), exact-ambiguous reads every hit
 __global__ void __launch_bounds__(64)
 k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A,
-                u32* __restrict__ slot_read)
+                u32* __restrict__ slot_read, u32* __restrict__ long_flag)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n2) return;
+    long_flag[r] = 0;
     const int L = gm.rl(r), k = gm.rk(L);
     const int v = st.verdict[r];
     const u64 off = st.cand_off[r];
@@ -1998,6 +1999,7 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
         else { ps.occ[r] = -1; ps.len[r] = (u32)nv; }
         return;
     }
+    if (nc <= VL_CAP) { long_flag[r] = 1; return; }          // repeats: k_vote_pe_long sorts the list out of LDS
     u64* c = cand + off;
     {
         u64 w = 0;
@@ -2018,6 +2020,42 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
             if (c[i] != pre) { o[nv].site = pre < (u64)k ? 0 : pre - (u64)k; o[nv].err = 0; o[nv].end = 0; nv++; pre = c[i]; }
         o[nv].site = pre >= (u64)k ? pre - (u64)k : 0; o[nv].err = 0; o[nv].end = 0; nv++;
         ps.occ[r] = -1; ps.len[r] = (u32)nv;
+    }
+}
+
+// the paired-end counterpart of k_vote_long: no vote order here, so everything is parallel (general reads: one entry per
+// distinct site; exact-ambiguous reads: every hit)
+template <int CAP, int BLOCK, int LO>
+__global__ void __launch_bounds__(BLOCK)
+k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
+               PeCand* __restrict__ A)
+{
+    __shared__ u64 keys[CAP];
+    __shared__ u16 endpos[CAP];
+    __shared__ u32 sh_pref[BMBS_MAX_SEEDS + 1];
+    __shared__ int sh_w[BLOCK / 64 + 1];
+    const long total_items = (long)*count_ptr;
+    for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const long r = list[item];
+        const long nc = (long)st.n_cand[r];
+        if (nc <= LO || nc > CAP) continue;                          // another instance's size class
+        const int L = gm.rl(r), k = gm.rk(L);
+        const int v = st.verdict[r];
+        PeCand* o = A + st.cand_off[r];
+        vl_locate_sort(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], (int)nc, keys, sh_pref);
+        if (v == 4) {
+            for (long i = threadIdx.x; i < nc; i += BLOCK) { PeCand e; e.site = keys[i]; e.err = 0; e.end = L - 1; o[i] = e; }
+            if (threadIdx.x == 0) { ps.occ[r] = (int)nc; ps.len[r] = (u32)nc; }
+        } else {
+            const int nv = vl_run_ends(keys, (int)nc, endpos, sh_w);
+            for (int e2 = threadIdx.x; e2 < nv; e2 += BLOCK) {
+                const u64 site = keys[endpos[e2]];
+                PeCand e; e.site = site < (u64)k ? 0 : site - (u64)k; e.err = 0; e.end = 0;
+                o[e2] = e;
+            }
+            if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)nv; }
+        }
+        __syncthreads();
     }
 }
 
