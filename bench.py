@@ -99,7 +99,7 @@ def ensure_index(args, rank, world, dist):
         if not os.path.exists(fa + ".index.bs.index.sa"):
             synth.write_fasta(fa, names, chroms)
             t = time.time()
-            mapper.Index.build(fa, fa, threads=min(16, os.cpu_count() or 1))
+            mapper.Index.build(fa, fa, threads=min(64, os.cpu_count() or 1))
             sys.stderr.write("[bench] index built in %.1fs\n" % (time.time() - t))
     if world > 1:
         dist.barrier()
