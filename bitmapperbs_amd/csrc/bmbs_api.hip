@@ -31,7 +31,7 @@ struct bmbs_ctx {
     DevIndex ix;
     u64 rows = 0;
     // index buffers
-    DevBuf occ, hash, sa, gen2, chrom_start, t20;
+    DevBuf occ, hash, sa, gen2, chrom_start, t20, occ_super;
     // LUTs
     DevBuf pen_lut, mapq_lut;
     bool luts_ready = false;
@@ -444,7 +444,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
+    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->occ_super, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
@@ -468,7 +468,11 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     HIPCHK(c, hipSetDevice(c->dev));
     const u64 G = v->ref_len, n = 2 * G, rows = n + 1;
     if (v->sa_length != rows) { c->err = "index view: sa_length != 2*ref_len + 1"; return BMBS_EINVAL; }
-    if (rows >= (1ull << 32)) { c->err = "genome too large for the 32-bit suffix array of this build"; return BMBS_EINVAL; }
+    if (rows >= (1ull << 36)) { c->err = "genome too large: rows must fit the 36-bit fields of the 16-mer table"; return BMBS_EINVAL; }
+    // texts of 2^32 symbols and more (GRCh38) take the wide forms: 64-bit suffix array, Occ counts relative to the reference's
+    // super-block table; BMBS_WIDE=1 forces them on a small index (tests)
+    const char* wide_env = getenv("BMBS_WIDE");
+    const bool wide = rows >= (1ull << 32) || (wide_env && !strcmp(wide_env, "1"));
     // upload the reference layouts verbatim, re-pack on the device, drop the originals
     DevBuf t_bwt, t_ho, t_hh, t_hl, t_sa, t_fl, t_pac;
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
@@ -491,22 +495,26 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     RefIndexDev R;
     R.bwt = t_bwt.as<u64>(); R.high_occ = t_ho.as<u64>(); R.hash_hi = t_hh.as<u32>(); R.hash_lo = t_hl.as<u8>();
     R.sa = t_sa.as<u32>(); R.sa_flag = t_fl.as<u64>(); R.pac = t_pac.as<u8>();
-    if (n >= (1ull << 32)) { c->err = "32-bit Occ counters: text too long"; return BMBS_EINVAL; }
     const u64 n_blk = n / 32 + 2;
     const u64 gen_words = ((n + 63) / 64 + 3) * 2;          // whole 16-byte pieces plus spare ones for the look-ahead loads
     std::vector<u64> cs(v->n_chrom + 1, 0);
     for (int i = 0; i < v->n_chrom; i++) cs[i + 1] = cs[i] + v->chrom_len[i];
-    if (ensure(c, c->occ, n_blk * 16) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * 4) ||
-        ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8)) { drop(); return BMBS_ENOMEM; }
+    if (ensure(c, c->occ, n_blk * 16) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * (wide ? 8 : 4)) ||
+        ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8) ||
+        (wide && ensure(c, c->occ_super, v->high_occ_words * 8 + 64))) { drop(); return BMBS_ENOMEM; }
+    if (wide) HIPCHK(c, hipMemcpyAsync(c->occ_super.p, t_ho.p, v->high_occ_words * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->chrom_start.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, c->occ.as<uint4>());
+    hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, wide ? 1 : 0, c->occ.as<uint4>());
     hipLaunchKernelGGL(k_repack_hash, dim3(nblk(v->hash_entries, 256)), dim3(256), 0, c->stream, R, v->hash_entries, c->hash.as<u64>());
     hipLaunchKernelGGL(k_build_gen2, dim3(nblk(gen_words, 256)), dim3(256), 0, c->stream, R, G, gen_words, c->gen2.as<u64>());
     DevIndex ix;
-    ix.occ = c->occ.as<uint4>(); ix.hash = c->hash.as<u64>(); ix.sa = c->sa.as<u32>(); ix.gen2 = c->gen2.as<u64>();
+    ix.occ = c->occ.as<uint4>(); ix.hash = c->hash.as<u64>(); ix.gen2 = c->gen2.as<u64>();
+    ix.sa = wide ? nullptr : c->sa.as<u32>(); ix.sa64 = wide ? c->sa.as<u64>() : nullptr;
+    ix.occ_super = wide ? c->occ_super.as<u64>() : nullptr;
     ix.chrom_start = c->chrom_start.as<u64>(); ix.G = G; ix.total = n; ix.shapline = v->shapline;
     ix.C[0] = v->nacgt[0]; ix.C[1] = v->nacgt[1]; ix.C[2] = v->nacgt[2]; ix.n_chrom = v->n_chrom;
-    hipLaunchKernelGGL(k_expand_sa, dim3(nblk(rows, 256)), dim3(256), 0, c->stream, ix, R, rows, c->sa.as<u32>());
+    hipLaunchKernelGGL(k_expand_sa, dim3(nblk(rows, 256)), dim3(256), 0, c->stream, ix, R, rows, wide ? nullptr : c->sa.as<u32>(),
+                       wide ? c->sa.as<u64>() : nullptr);
     // 20-mer outcome table (27.9 GB): built when the device has the room; BMBS_T20=0 turns it off (A/B runs, small devices)
     ix.t20 = nullptr;
     {

@@ -30,6 +30,8 @@ struct DevIndex {
     const uint4* occ;
     const u64*   hash;
     const u32*   sa;
+    const u64*   sa64;          // texts of >= 2^32 symbols: 64-bit suffix array instead of sa
+    const u64*   occ_super;     // ... and the counts of occ are relative to this {T, A} table per 65 536 symbols
     const u64*   gen2;
     const u64*   t20;           // optional: outcome of the first four extensions of every 20-mer (k_build_t20), else nullptr
     const u64*   chrom_start;   // n_chrom+1 cumulative starts (single strand)

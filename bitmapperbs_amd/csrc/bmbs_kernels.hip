@@ -28,6 +28,9 @@
 
 // rank of T and of A in BWT stream [0, line): ONE aligned 16-byte load (see bmbs_dev.h).
 // Replaces get_occ_value* + the popcount tail of find_occ_fm_index (bwt.h:1007-1136, 1373-1465).
+// Texts of 2^32 symbols and more (GRCh38: 2G = 6.2 G): the block counts are relative to the 65 536-symbol super-block
+// table of the reference layout (ix.occ_super, 1.5 MB for GRCh38), the suffix array is 64-bit (ix.sa64); both pointers are
+// null for smaller texts and the branches are wave-uniform.
 DEVI void occ_TA(const DevIndex& ix, u64 line, u64& cT, u64& cA)
 {
     const uint4 h = ix.occ[line >> 5];
@@ -35,7 +38,9 @@ DEVI void occ_TA(const DevIndex& ix, u64 line, u64& cT, u64& cA)
     const u32 m = r ? (~0u << (32 - r)) : 0u;
     cT = (u64)h.x + __popc(h.z & m);
     cA = (u64)h.y + __popc(h.w & m);
+    if (ix.occ_super) { const u64 sb = (line >> 16) << 1; cT += ix.occ_super[sb]; cA += ix.occ_super[sb + 1]; }
 }
+DEVI u64 sa_at(const DevIndex& ix, u64 row) { return ix.sa64 ? ix.sa64[row] : (u64)ix.sa[row]; }
 
 // one LF / backward-extension step: nacgt[c] + Occ(c, row), '$' row removed (bwt.h:1373-1465)
 DEVI u64 lf_step(const DevIndex& ix, u64 row, int c)
@@ -57,8 +62,12 @@ DEVI void lf_pair(const DevIndex& ix, u64& top, u64& bot, int c)
     if ((lb >> 5) != (lt >> 5)) hb = ix.occ[lb >> 5];
     const u32 rt = (u32)lt & 31u, rb = (u32)lb & 31u;
     const u32 mt = rt ? (~0u << (32 - rt)) : 0u, mb = rb ? (~0u << (32 - rb)) : 0u;
-    const u64 tT = (u64)ht.x + __popc(ht.z & mt), tA = (u64)ht.y + __popc(ht.w & mt);
-    const u64 bT = (u64)hb.x + __popc(hb.z & mb), bA = (u64)hb.y + __popc(hb.w & mb);
+    u64 tT = (u64)ht.x + __popc(ht.z & mt), tA = (u64)ht.y + __popc(ht.w & mt);
+    u64 bT = (u64)hb.x + __popc(hb.z & mb), bA = (u64)hb.y + __popc(hb.w & mb);
+    if (ix.occ_super) {
+        const u64 st_ = (lt >> 16) << 1, sb_ = (lb >> 16) << 1;
+        tT += ix.occ_super[st_]; tA += ix.occ_super[st_ + 1]; bT += ix.occ_super[sb_]; bA += ix.occ_super[sb_ + 1];
+    }
     const u64 ct = c == 1 ? tT : (c == 2 ? tA : lt - tT - tA);
     const u64 cb = c == 1 ? bT : (c == 2 ? bA : lb - bT - bA);
     top = ix.C[c] + ct; bot = ix.C[c] + cb;
@@ -227,7 +236,7 @@ DEVI void ref_rank64(const RefIndexDev& R, u64 line, u64& cT, u64& cA)
 }
 
 // one 16-byte block per 32 BWT symbols: { u32 count(T) before, u32 count(A) before, u32 plane_T, u32 plane_A }
-__global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, uint4* out)
+__global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, int wide, uint4* out)
 {
     const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
@@ -235,6 +244,7 @@ __global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, uint4* out)
     const u64 s64 = s0 & ~63ull;          // the reference stores counters at every 64-boundary it reached (bwt.cpp:1437-1490)
     u64 cT = 0, cA = 0;
     ref_rank64(R, s64, cT, cA);
+    if (wide) { const u64 sb = (s64 >> 16) << 1; cT -= R.high_occ[sb]; cA -= R.high_occ[sb + 1]; }     // relative to the super-block
     u32 pT = 0, pA = 0;
     if (s64 < n_stream) {
         const u64 wi = (s64 >> 7) * 5 + 1 + 2 * ((s64 & 127) >> 6);
@@ -328,12 +338,12 @@ __global__ void k_build_gen2(RefIndexDev R, u64 G, u64 n_words, u64* out)
 
 // full SA from the sampled SA: LF-walk to a flagged row (bwt_get_sa_restrict_steps_more_than_3,
 // bwt.h:2449-2560), done once per attach so that the mapping kernels never walk.
-__global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out)
+__global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out, u64* out64)
 {
     const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     u64 l = row, steps = 0, val = 0;
-    if (l == ix.shapline) { out[row] = 0; return; }
+    if (l == ix.shapline) { if (out64) out64[row] = 0; else out[row] = 0; return; }
     for (;;) {
         const u64 blk = (l >> 8) * 5, last = l & 255;
         const u64 w = R.sa_flag[blk + 1 + (last >> 6)];
@@ -349,7 +359,7 @@ __global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out)
         steps++;
         if (l == ix.shapline) { val = steps; break; }
     }
-    out[row] = (u32)val;
+    if (out64) out64[row] = val; else out[row] = (u32)val;
 }
 
 // ================================================================================================
@@ -706,7 +716,7 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             first_ml = ml;
             if (hits == 1) {
                 // try_process_unique_mismatch_end_to_end (Schema.cpp:15164-15282)
-                const u64 p = ix.sa[sp];
+                const u64 p = sa_at(ix, sp);
                 n_sa++;
                 const u64 loc = ix.total - p - ml;
                 seed_record(my, ns, ncand, sp, 1, ml, 0);
@@ -847,7 +857,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             // Occ gather per character (count_hash_table, bwt.h:1889-1933) locate the row once and compare the
             // rest of the read with the doubled genome in the index alphabet (C folded into T), 8 bases a step.
             verify = false;
-            const u64 p = ix.sa[S.top];
+            const u64 p = sa_at(ix, S.top);
             lc.n_sa++;
             const int done_chars = 16 + S.s;                       // read[tm, tm+done_chars) is matched at text position p
             const int tm = S.tm;
@@ -878,7 +888,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
         if (h.hits == 1) {
             u64 p;
             if (h.sp >> 63) p = h.sp & ~(1ull << 63);
-            else { p = ix.sa[h.sp]; lc.n_sa++; }
+            else { p = sa_at(ix, h.sp); lc.n_sa++; }
             c1 = ix.total - p - second_len - first_ml;
             seed_record(my, ns, ncand, h.sp, 1, second_len, first_ml);
             clen += 1; extra = 0;
@@ -1022,7 +1032,7 @@ k_locate(DevIndex ix, long n, ReadState st, u64* __restrict__ cand)
         const u64 sp = my[s].sp, adj = (u64)my[s].len + (u64)my[s].off;
         const u32 h = my[s].hits;
         for (u32 j = 0; j < h && o < o_end; j++)
-            cand[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;   // reverse_and_adjust_site, Schema.cpp:4669
+            cand[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;   // reverse_and_adjust_site, Schema.cpp:4669
     }
 }
 
@@ -1085,7 +1095,7 @@ k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ c
             c[j] = ~0ull;
             if (j < nc) {
                 while (h == hits && sidx + 1 < ns) { sidx++; h = 0; sp = my[sidx].sp; adj = (u64)my[sidx].len + (u64)my[sidx].off; hits = my[sidx].hits; }
-                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + h]) - adj;
+                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + h)) - adj;
                 h++;
             }
         }
@@ -1139,7 +1149,7 @@ k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ c
         for (int s2 = 0; s2 < ns && o < (u64)nc; s2++) {
             const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
             const u32 hh = my[s2].hits;
-            for (u32 j = 0; j < hh && o < (u64)nc; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;
+            for (u32 j = 0; j < hh && o < (u64)nc; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;
         }
     }
     sort_u64_asc(c, nc);
@@ -1191,7 +1201,7 @@ DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u
             int s2 = 0;
             while (s2 + 1 < ns && sh_pref[s2 + 1] <= (u32)j) s2++;
             const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
-            key = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + ((u32)j - sh_pref[s2])]) - adj;
+            key = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + ((u32)j - sh_pref[s2]))) - adj;
         }
         keys[j] = key;
     }
@@ -1254,7 +1264,7 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
                 for (int s2 = 0; s2 < ns && o < (u64)nc; s2++) {
                     const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
                     const u32 hh = my[s2].hits;
-                    for (u32 j = 0; j < hh && o < (u64)nc; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;
+                    for (u32 j = 0; j < hh && o < (u64)nc; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;
                 }
                 sort_u64_asc(c, nc);
                 long nv = 0;
@@ -1757,7 +1767,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
                 u32 nh = hits0[r]; if (nh > 1000u) nh = 1000u;
                 o.status = 3;
                 for (u32 i = 0; i < nh; i++) {
-                    const u64 s_ = ix.total - (u64)ix.sa[sp_ + i] - (u64)L;
+                    const u64 s_ = ix.total - sa_at(ix, sp_ + i) - (u64)L;
                     u64 loc = s_; int flag;
                     if (loc >= ix.G) { loc = ix.G * 2 - (loc + (u64)(L - 1)) - 1; flag = 16; } else flag = 0;
                     int c = 0;
@@ -1969,7 +1979,7 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
             c[j] = ~0ull;
             if (j < nc) {
                 while (h == hits && sidx + 1 < ns) { sidx++; h = 0; sp = my[sidx].sp; adj = (u64)my[sidx].len + (u64)my[sidx].off; hits = my[sidx].hits; }
-                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + h]) - adj;
+                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + h)) - adj;
                 h++;
             }
         }
@@ -2006,7 +2016,7 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
         for (int s2 = 0; s2 < ns && w < (u64)nc; s2++) {
             const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
             const u32 hh = my[s2].hits;
-            for (u32 j = 0; j < hh && w < (u64)nc; j++) c[w++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : (u64)ix.sa[sp + j]) - adj;
+            for (u32 j = 0; j < hh && w < (u64)nc; j++) c[w++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;
         }
     }
     sort_u64_asc(c, nc);
@@ -2387,7 +2397,7 @@ k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ c
     long o = 0;
     for (int s = 0; s < ns; s++) {
         const u64 sp = my[s].sp, adj = (u64)my[s].len + (u64)my[s].off;
-        for (u32 j = 0; j < my[s].hits; j++) c[o++] = ix.total - (u64)ix.sa[sp + j] - adj;
+        for (u32 j = 0; j < my[s].hits; j++) c[o++] = ix.total - sa_at(ix, sp + j) - adj;
     }
     sort_u64_asc(c, nc);
     const PeCand* a = pe_list(ps, st, A, B, rF);

@@ -54,21 +54,25 @@ bool slurp_fasta(const char* path, std::vector<Chrom>& chroms, std::vector<char>
 template <class T> void put(FILE* f, const T& v) { fwrite(&v, sizeof(T), 1, f); }
 template <class T> bool get(FILE* f, T& v) { return fread(&v, sizeof(T), 1, f) == 1; }
 
-// suffix array of a text over {0,1,2} (n < 2^32), shorter suffix first: 16-symbol radix key, then
-// prefix doubling restricted to the still-tied groups.
-void suffix_sort(const std::vector<u8>& T, u64 n, std::vector<u32>& sa, int n_threads)
+// suffix array of a text over {0,1,2}, shorter suffix first: radix key of the first K symbols packed above the suffix index
+// in one u64 (Idx = u32: K = 16, 32 index bits; Idx = u64 for texts of 2^32 symbols and more: K = 15, 34 index bits), then
+// prefix doubling restricted to the still-tied groups (groups sorted in parallel).
+template <class Idx>
+void suffix_sort(const std::vector<u8>& T, u64 n, std::vector<Idx>& sa, int n_threads)
 {
+    const int K = sizeof(Idx) == 4 ? 16 : 15, IB = 64 - 2 * K;          // key symbols, index bits
+    const u64 KMASK = (1ULL << (2 * K)) - 1, IMASK = (1ULL << IB) - 1;
     std::vector<u64> ks(n);
     {
-        // rolling 32-bit key of 16 two-bit digits (symbol+1, 0 beyond the end)
+        // rolling key of K two-bit digits (symbol+1, 0 beyond the end)
         auto fill = [&](u64 a, u64 b) {
             if (a >= b) return;
             u64 k = 0;
-            for (int j = 0; j < 16; j++) k = (k << 2) | (a + j < n ? (u64)(T[a + j] + 1) : 0);
-            ks[a] = (k << 32) | a;
+            for (int j = 0; j < K; j++) k = (k << 2) | (a + j < n ? (u64)(T[a + j] + 1) : 0);
+            ks[a] = (k << IB) | a;
             for (u64 i = a + 1; i < b; i++) {
-                k = ((k << 2) & 0xffffffffULL) | (i + 15 < n ? (u64)(T[i + 15] + 1) : 0);
-                ks[i] = (k << 32) | i;
+                k = ((k << 2) & KMASK) | (i + K - 1 < n ? (u64)(T[i + K - 1] + 1) : 0);
+                ks[i] = (k << IB) | i;
             }
         };
         std::vector<std::thread> th;
@@ -98,50 +102,71 @@ void suffix_sort(const std::vector<u8>& T, u64 n, std::vector<u32>& sa, int n_th
         for (auto& x : th) x.join();
     }
     sa.resize(n);
-    std::vector<u32> rank(n + 1, 0);
+    std::vector<Idx> rank(n + 1, 0);
     std::vector<std::pair<u64, u64>> groups, next;
     {
         u64 a = 0;
         while (a < n) {
             u64 b = a + 1;
-            u64 ka = ks[a] >> 32;
-            while (b < n && (ks[b] >> 32) == ka) b++;
-            for (u64 i = a; i < b; i++) { u32 idx = (u32)ks[i]; sa[i] = idx; rank[idx] = (u32)a + 1; }
+            u64 ka = ks[a] >> IB;
+            while (b < n && (ks[b] >> IB) == ka) b++;
+            for (u64 i = a; i < b; i++) { const u64 idx = ks[i] & IMASK; sa[i] = (Idx)idx; rank[idx] = (Idx)(a + 1); }
             if (b - a > 1) groups.push_back({a, b});
             a = b;
         }
     }
     ks.clear(); ks.shrink_to_fit();
-    std::vector<u32> key;
-    for (u64 h = 16; !groups.empty(); h *= 2) {
-        // phase A: order every tied group by the rank of the suffix h further on (old ranks only)
-        u64 tot = 0;
-        for (auto& g : groups) tot += g.second - g.first;
-        key.resize(tot);
-        u64 ko = 0;
-        std::vector<std::pair<u32, u32>> tmp;
-        for (auto& g : groups) {
-            u64 a = g.first, b = g.second;
-            tmp.resize(b - a);
-            for (u64 i = a; i < b; i++) { u64 j = (u64)sa[i] + h; tmp[i - a] = {j < n ? rank[j] : 0u, sa[i]}; }
-            std::sort(tmp.begin(), tmp.end());
-            for (u64 i = a; i < b; i++) { sa[i] = tmp[i - a].second; key[ko + i - a] = tmp[i - a].first; }
-            ko += b - a;
+    std::vector<Idx> key;
+    std::vector<u64> goff;
+    for (u64 h = (u64)K; !groups.empty(); h *= 2) {
+        // phase A: order every tied group by the rank of the suffix h further on (old ranks only); the groups are disjoint
+        // ranges of sa, so threads take contiguous runs of groups
+        const u64 ng = groups.size();
+        goff.resize(ng + 1);
+        goff[0] = 0;
+        for (u64 g = 0; g < ng; g++) goff[g + 1] = goff[g] + (groups[g].second - groups[g].first);
+        key.resize(goff[ng]);
+        const int nt = (int)std::min<u64>((u64)n_threads, ng);
+        auto span = [&](int t) { return std::make_pair(ng * (u64)t / (u64)nt, ng * (u64)(t + 1) / (u64)nt); };
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    std::vector<std::pair<Idx, Idx>> tmp;
+                    const auto sp = span(t);
+                    for (u64 g = sp.first; g < sp.second; g++) {
+                        const u64 a = groups[g].first, b = groups[g].second, ko = goff[g];
+                        tmp.resize(b - a);
+                        for (u64 i = a; i < b; i++) { const u64 j = (u64)sa[i] + h; tmp[i - a] = {j < n ? rank[j] : (Idx)0, sa[i]}; }
+                        std::sort(tmp.begin(), tmp.end());
+                        for (u64 i = a; i < b; i++) { sa[i] = tmp[i - a].second; key[ko + i - a] = tmp[i - a].first; }
+                    }
+                });
+            for (auto& x : th) x.join();
         }
-        // phase B: split
+        // phase B: split (new ranks are written only after every group has been ordered by the old ones)
+        std::vector<std::vector<std::pair<u64, u64>>> parts((size_t)nt);
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    const auto sp = span(t);
+                    for (u64 g = sp.first; g < sp.second; g++) {
+                        const u64 a = groups[g].first, b = groups[g].second, ko = goff[g];
+                        u64 s = a;
+                        for (u64 i = a + 1; i <= b; i++) {
+                            if (i == b || key[ko + i - a] != key[ko + s - a]) {
+                                for (u64 q = s; q < i; q++) rank[sa[q]] = (Idx)(s + 1);
+                                if (i - s > 1) parts[(size_t)t].push_back({s, i});
+                                s = i;
+                            }
+                        }
+                    }
+                });
+            for (auto& x : th) x.join();
+        }
         next.clear();
-        ko = 0;
-        for (auto& g : groups) {
-            u64 a = g.first, b = g.second, s = a;
-            for (u64 i = a + 1; i <= b; i++) {
-                if (i == b || key[ko + i - a] != key[ko + s - a]) {
-                    for (u64 q = s; q < i; q++) rank[sa[q]] = (u32)s + 1;
-                    if (i - s > 1) next.push_back({s, i});
-                    s = i;
-                }
-            }
-            ko += b - a;
-        }
+        for (auto& pv : parts) next.insert(next.end(), pv.begin(), pv.end());
         groups.swap(next);
     }
 }
@@ -198,6 +223,8 @@ struct bmbs_index_file {
     std::vector<u8> hash_lo;
 };
 
+namespace { template <class Idx> int build_tail(Built& B, const std::vector<u8>& T, u64 n, const char* prefix, int n_threads); }
+
 extern "C" int bmbs_index_build(const char* fasta, const char* prefix, int n_threads)
 {
     if (n_threads < 1) n_threads = 1;
@@ -206,7 +233,7 @@ extern "C" int bmbs_index_build(const char* fasta, const char* prefix, int n_thr
     if (!slurp_fasta(fasta, B.chroms, gen)) return BMBS_EINVAL;
     const u64 G = gen.size();
     B.G = G;
-    if (2 * G + 1 >= (1ULL << 32)) return BMBS_EINVAL;   // 32-bit suffix indices in this builder
+    if (2 * G + 1 >= (1ULL << 33)) return BMBS_EINVAL;   // the sampled SA stores position / 8 in 30 bits (bwt.cpp:1793)
     // non-ACGT -> fixed pseudo-random base (the reference uses srand(time(0)), Index.cpp:703)
     {
         u64 s = 0x9E3779B97F4A7C15ULL;
@@ -230,8 +257,18 @@ extern "C" int bmbs_index_build(const char* fasta, const char* prefix, int n_thr
         T[G + i] = r == 'G' ? 0 : (r == 'T' || r == 'C') ? 1 : 2;
     }
     gen.clear(); gen.shrink_to_fit();
-    std::vector<u32> sa;
-    suffix_sort(T, n, sa, n_threads);
+    // texts of 2^32 symbols and more (GRCh38) need 64-bit suffix indices; BMBS_BUILD_WIDE=1 forces them (tests)
+    const char* we = getenv("BMBS_BUILD_WIDE");
+    if (n + 1 >= (1ULL << 32) || (we && !strcmp(we, "1"))) return build_tail<u64>(B, T, n, prefix, n_threads);
+    return build_tail<u32>(B, T, n, prefix, n_threads);
+}
+
+namespace {
+template <class Idx>
+int build_tail(Built& B, const std::vector<u8>& T, u64 n, const char* prefix, int n_threads)
+{
+    std::vector<Idx> sa;
+    suffix_sort<Idx>(T, n, sa, n_threads);
     const u64 rows = n + 1;
     B.sa_length = rows;
     auto SA = [&](u64 r) -> u64 { return r == 0 ? n : sa[r - 1]; };
@@ -313,6 +350,7 @@ extern "C" int bmbs_index_build(const char* fasta, const char* prefix, int n_thr
     }
     return write_files(B, std::string(prefix) + ".index");
 }
+}  // namespace
 
 extern "C" bmbs_index_file* bmbs_index_file_load(const char* prefix)
 {

@@ -446,3 +446,24 @@ def test_map_pe_mixed_lengths_match_oracle(prm, env):
     assert not bad, bad[:5]
     assert (m.stats() == ost).all(), (m.stats(), ost)
     m.close()
+
+
+def test_wide_index_forms_match_oracle(env, monkeypatch):
+    """texts of 2^32 symbols and more (GRCh38): 64-bit suffix array + super-block relative Occ counts, forced on the test
+    genome with BMBS_WIDE=1 (read by bmbs_index_attach)"""
+    from bitmapperbs_amd import synth, mapper
+    monkeypatch.setenv("BMBS_WIDE", "1")
+    r = synth.make_reads_se(env["chroms"], n=20000, L=120, seed=41, sub=0.02, indel=0.002, qual="random", n_rate=0.002)
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    res, pool = m.map_se(r["seq"], r["qual"], 120)
+    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 120)
+    assert not compare_records(res, pool, recs, 120)
+    assert (m.stats() == ost).all()
+    m.close()
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=8000, L=100, seed=42, sub=0.03, indel=0.002, qual="random")
+    m = mapper.Mapper(env["ix"], 0, sensitive=1)
+    res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+    recs, ost, cnt = env["oix"].map_pe(orc.params(sensitive=1), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+    assert not compare_pe(res, pool, recs, 100)
+    assert (m.stats() == ost).all()
+    m.close()
