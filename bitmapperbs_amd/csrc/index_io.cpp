@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <functional>
 #include <vector>
 
 namespace {
@@ -273,75 +274,135 @@ int build_tail(Built& B, const std::vector<u8>& T, u64 n, const char* prefix, in
     B.sa_length = rows;
     auto SA = [&](u64 r) -> u64 { return r == 0 ? n : sa[r - 1]; };
 
-    // BWT planes + in-block counters + super-block table (bwt.cpp:1290-1500)
-    B.bwt.assign(1 + 2 * (n / 64) + (n / 128) + 2, 0);
-    B.bwt.reserve(B.bwt.size() + 8);
-    std::vector<u64> bw(B.bwt.size() + 8, 0);
-    B.high_occ.assign(2, 0);
-    u64 cnt[3] = {0, 0, 0}, t = 0;
-    for (u64 r = 0; r < rows; r++) {
-        u64 p = SA(r);
-        if (p == 0) { B.shapline = r; continue; }
-        u8 ch = T[p - 1];
-        u64 w = (t >> 7) * 5 + 1 + 2 * ((t & 127) >> 6), sh = 63 - (t & 63);
-        bw[w] |= (u64)(ch & 1) << sh;
-        bw[w + 1] |= (u64)(ch >> 1) << sh;
-        cnt[ch]++; t++;
-        if ((t & 65535) == 0) { B.high_occ.push_back(cnt[1]); B.high_occ.push_back(cnt[2]); }
-        if ((t & 63) == 0) {
-            u64 w0 = (t >> 7) * 5, half = (t & 127) >> 6, sb = (t >> 16) * 2;
-            bw[w0] |= (cnt[1] - B.high_occ[sb]) << (48 - 32 * half);
-            bw[w0] |= (cnt[2] - B.high_occ[sb + 1]) << (32 - 32 * half);
-        }
+    // run f(t) for t in [0, nt) on nt threads
+    auto par = [&](int nt, const std::function<void(int)>& f) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back(f, t);
+        for (auto& x : th) x.join();
+    };
+    const int NT = n_threads;
+    // the row of the whole text ('$' precedes it): SA(r) == 0
+    {
+        std::vector<u64> found((size_t)NT, ~0ULL);
+        par(NT, [&](int t) { for (u64 r = rows * (u64)t / NT; r < rows * (u64)(t + 1) / NT; r++) if (SA(r) == 0) { found[(size_t)t] = r; break; } });
+        for (u64 f : found) if (f != ~0ULL) B.shapline = f;
     }
+    const u64 shap = B.shapline;
+
+    // BWT planes + in-block counters + super-block table (bwt.cpp:1290-1500).  BWT stream position t = row minus the '$' row;
+    // chunks of 65 536 stream positions own their words and their super-block entry, so they fill in parallel once the
+    // symbol counts in front of every chunk are known.
+    B.bwt.assign(1 + 2 * (n / 64) + (n / 128) + 2, 0);
+    std::vector<u64> bw(B.bwt.size() + 8, 0);
+    const u64 n_chunk = (n + 65535) / 65536;
+    B.high_occ.assign(2 * (n / 65536 + 1), 0);
+    std::vector<u64> c1(n_chunk + 1, 0), c2(n_chunk + 1, 0), c0(n_chunk + 1, 0);
+    auto row_of = [&](u64 t) -> u64 { return t < shap ? t : t + 1; };          // stream position -> row
+    par(NT, [&](int th) {
+        for (u64 c = n_chunk * (u64)th / NT; c < n_chunk * (u64)(th + 1) / NT; c++) {
+            u64 k0 = 0, k1 = 0, k2 = 0;
+            const u64 ta = c * 65536, tb = std::min(n, ta + 65536);
+            for (u64 t = ta; t < tb; t++) { const u8 ch = T[SA(row_of(t)) - 1]; k0 += ch == 0; k1 += ch == 1; k2 += ch == 2; }
+            c0[c + 1] = k0; c1[c + 1] = k1; c2[c + 1] = k2;
+        }
+    });
+    for (u64 c = 0; c < n_chunk; c++) { c0[c + 1] += c0[c]; c1[c + 1] += c1[c]; c2[c + 1] += c2[c]; }
+    for (u64 c = 1; c <= n / 65536; c++) { B.high_occ[2 * c] = c1[c]; B.high_occ[2 * c + 1] = c2[c]; }   // counts in front of position 65536 c
+    par(NT, [&](int th) {
+        for (u64 c = n_chunk * (u64)th / NT; c < n_chunk * (u64)(th + 1) / NT; c++) {
+            u64 cnt1 = c1[c], cnt2 = c2[c];
+            const u64 ta = c * 65536, tb = std::min(n, ta + 65536);
+            const u64 base1 = cnt1, base2 = cnt2;                               // == high_occ of this super-block
+            for (u64 t0 = ta; t0 < tb; t0++) {
+                const u8 ch = T[SA(row_of(t0)) - 1];
+                const u64 w = (t0 >> 7) * 5 + 1 + 2 * ((t0 & 127) >> 6), sh = 63 - (t0 & 63);
+                bw[w] |= (u64)(ch & 1) << sh;
+                bw[w + 1] |= (u64)(ch >> 1) << sh;
+                cnt1 += ch == 1; cnt2 += ch == 2;
+                const u64 t = t0 + 1;
+                if ((t & 63) == 0 && (t & 65535) != 0) {
+                    const u64 w0 = (t >> 7) * 5, half = (t & 127) >> 6;
+                    bw[w0] |= (cnt1 - base1) << (48 - 32 * half);
+                    bw[w0] |= (cnt2 - base2) << (32 - 32 * half);
+                }
+                // at a super-block boundary the in-block counters are relative to the NEW super-block entry: zero
+            }
+        }
+    });
     std::copy(bw.begin(), bw.begin() + B.bwt.size(), B.bwt.begin());
     bw.clear(); bw.shrink_to_fit();
+    const u64 cnt[3] = {c0[n_chunk], c1[n_chunk], c2[n_chunk]};
     B.nacgt[0] = 1; B.nacgt[1] = 1 + cnt[0]; B.nacgt[2] = B.nacgt[1] + cnt[1]; B.nacgt[3] = B.nacgt[2] + cnt[2]; B.nacgt[4] = B.nacgt[3];
 
-    // SA_flag + samples (bwt.cpp:1580-1800)
+    // SA_flag + samples (bwt.cpp:1580-1800): blocks of 256 rows = one count word (samples in front of the block) + 4 bit words
     {
-        std::vector<u64> fl((rows / 256 + 2) * 5 + 8, 0);
-        u64 it = 1, bits = 64, sparse = 0;
-        for (u64 r = 0; r < rows; r++) {
-            u64 p = SA(r);
-            if ((p & 7) == 0) {
-                sparse++;
-                fl[it] |= 1ULL << (63 - (bits & 63));
-                u32 ch = p != 0 ? T[p - 1] : 1;
-                B.sa.push_back((ch << 30) | (u32)(p >> 3));
+        const u64 q = rows / 256, rem = rows % 256;
+        const u64 words = 1 + 5 * q + rem / 64 + ((rem % 64) ? 1 : 0) + 1;
+        std::vector<u64> fl(words + 8, 0);
+        const u64 n_blk = (rows + 255) / 256;
+        std::vector<u64> sc(n_blk + 1, 0);
+        par(NT, [&](int th) {
+            for (u64 bl = n_blk * (u64)th / NT; bl < n_blk * (u64)(th + 1) / NT; bl++) {
+                u64 k = 0;
+                for (u64 r = bl * 256; r < std::min(rows, bl * 256 + 256); r++) k += (SA(r) & 7) == 0;
+                sc[bl + 1] = k;
             }
-            bits++;
-            if ((bits & 63) == 0) it++;
-            if (((r + 1) & 255) == 0) { fl[it] = sparse; bits += 64; it++; }
-        }
-        if (bits & 63) it++;
-        it++;
-        fl.resize(it);
+        });
+        for (u64 bl = 0; bl < n_blk; bl++) sc[bl + 1] += sc[bl];
+        B.sa.assign(sc[n_blk], 0);
+        par(NT, [&](int th) {
+            for (u64 bl = n_blk * (u64)th / NT; bl < n_blk * (u64)(th + 1) / NT; bl++) {
+                u64 sparse = sc[bl];
+                if (5 * bl < words) fl[5 * bl] = sparse;
+                for (u64 r = bl * 256; r < std::min(rows, bl * 256 + 256); r++) {
+                    const u64 p = SA(r);
+                    if ((p & 7) == 0) {
+                        const u64 j = r - bl * 256;
+                        fl[5 * bl + 1 + (j >> 6)] |= 1ULL << (63 - (j & 63));
+                        const u32 ch = p != 0 ? T[p - 1] : 1;
+                        B.sa[sparse++] = (ch << 30) | (u32)(p >> 3);
+                    }
+                }
+            }
+        });
+        if (rem == 0 && 5 * n_blk < words) fl[5 * n_blk] = sc[n_blk];          // count word written after a complete last block
+        fl.resize(words);
         B.sa_flag.swap(fl);
     }
-    // 16-mer table (bwt.cpp:1866-2010)
+    // 16-mer table (bwt.cpp:1866-2010): rows of a 16-mer are contiguous; the (at most 15) suffixes shorter than 16 lie between runs
     {
         const u64 HS = 43046721ULL + 1;
+        const u32 NONE = 0xffffffffu;
         B.hash_hi.assign(HS, 0); B.hash_lo.assign(HS, 0);
-        std::vector<u32> key16(n, 0xffffffffu);
-        if (n >= 16) {
+        std::vector<u32> key16(n, NONE);
+        par(NT, [&](int th) {
+            const u64 a = n * (u64)th / NT, b2 = n * (u64)(th + 1) / NT;
+            if (a >= b2 || a + 16 > n) return;
             u64 k = 0;
-            for (int j = 0; j < 16; j++) k = k * 3 + T[j];
-            key16[0] = (u32)k;
-            for (u64 p = 1; p + 16 <= n; p++) { k = (k - (u64)T[p - 1] * 14348907ULL) * 3 + T[p + 15]; key16[p] = (u32)k; }
-        }
-        u64 run = 1, r = 1;
+            for (int j = 0; j < 16; j++) k = k * 3 + T[a + j];
+            key16[a] = (u32)k;
+            for (u64 p = a + 1; p < b2 && p + 16 <= n; p++) { k = (k - (u64)T[p - 1] * 14348907ULL) * 3 + T[p + 15]; key16[p] = (u32)k; }
+        });
+        auto krow = [&](u64 r) -> u32 { return key16[sa[r - 1]]; };                // rows 1 .. rows-1
+        std::vector<u64> top(HS, 0), bot(HS, 0);                                   // bot == 0: the 16-mer does not occur
+        par(NT, [&](int th) {
+            const u64 a = 1 + (rows - 1) * (u64)th / NT, b2 = 1 + (rows - 1) * (u64)(th + 1) / NT;
+            for (u64 r = a; r < b2; r++) {
+                const u32 k = krow(r);
+                if (k == NONE) continue;
+                if (r == 1 || krow(r - 1) != k) top[k] = r;
+                if (r + 1 == rows || krow(r + 1) != k) bot[k] = r + 1;
+            }
+        });
+        u64 run = 1;
         B.hash_hi[0] = 0; B.hash_lo[0] = 1;
         for (u64 key = 0; key < HS - 1; key++) {
-            u64 rr = r;
-            while (rr < rows && key16[sa[rr - 1]] == 0xffffffffu) rr++;
-            if (rr < rows && key16[sa[rr - 1]] == key) {
-                u64 top = rr, bot = rr;
-                while (bot < rows && key16[sa[bot - 1]] == key) bot++;
-                B.hash_hi[key] = (u32)(top >> 8) | ((u32)(top - run) << 28);
-                B.hash_lo[key] = (u8)top;
-                B.hash_hi[key + 1] = (u32)(bot >> 8); B.hash_lo[key + 1] = (u8)bot;
-                run = bot; r = bot;
+            if (bot[key]) {
+                const u64 tp = top[key], bt = bot[key];
+                B.hash_hi[key] = (u32)(tp >> 8) | ((u32)(tp - run) << 28);
+                B.hash_lo[key] = (u8)tp;
+                B.hash_hi[key + 1] = (u32)(bt >> 8); B.hash_lo[key + 1] = (u8)bt;
+                run = bt;
             } else {
                 B.hash_hi[key] = (u32)(run >> 8); B.hash_lo[key] = (u8)run;
                 B.hash_hi[key + 1] = (u32)(run >> 8); B.hash_lo[key + 1] = (u8)run;
