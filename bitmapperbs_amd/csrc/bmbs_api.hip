@@ -513,7 +513,7 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     ix.occ_super = wide ? c->occ_super.as<u64>() : nullptr;
     ix.chrom_start = c->chrom_start.as<u64>(); ix.G = G; ix.total = n; ix.shapline = v->shapline;
     ix.C[0] = v->nacgt[0]; ix.C[1] = v->nacgt[1]; ix.C[2] = v->nacgt[2]; ix.n_chrom = v->n_chrom;
-    hipLaunchKernelGGL(k_expand_sa, dim3(nblk(rows, 256)), dim3(256), 0, c->stream, ix, R, rows, wide ? nullptr : c->sa.as<u32>(),
+    hipLaunchKernelGGL(k_expand_sa, dim3(nblk(std::min<u64>(rows, 1ull << 30), 256)), dim3(256), 0, c->stream, ix, R, rows, wide ? nullptr : c->sa.as<u32>(),
                        wide ? c->sa.as<u64>() : nullptr);
     // 20-mer outcome table (27.9 GB): built when the device has the room; BMBS_T20=0 turns it off (A/B runs, small devices)
     ix.t20 = nullptr;
@@ -945,6 +945,37 @@ extern "C" int bmbs_map_pe_var(bmbs_ctx* c, const char* seq1, const char* qual1,
 }
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int bmbs_locate_batch(bmbs_ctx* c, const uint64_t* row, int64_t n_rows, uint64_t* pos)
+{
+    if (!c) return BMBS_EINVAL;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    if (n_rows <= 0) return BMBS_OK;
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 m = (u64)n_rows;
+    ENS(c, c->in_a, m * 8); ENS(c, c->in_b, m * 8);
+    HIPCHK(c, hipMemcpyAsync(c->in_a.p, row, m * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_locate_rows, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_a.as<u64>(), (long)m, c->in_b.as<u64>());
+    HIPCHK(c, hipMemcpyAsync(pos, c->in_b.p, m * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_window_batch(bmbs_ctx* c, const uint64_t* site, int64_t n_sites, int32_t len, char* out)
+{
+    if (!c) return BMBS_EINVAL;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    if (n_sites <= 0) return BMBS_OK;
+    if (len <= 0 || len > 1024) { c->err = "window length out of range"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 m = (u64)n_sites;
+    ENS(c, c->in_b, m * 8); ENS(c, c->in_seq, m * (u64)len + 64);
+    HIPCHK(c, hipMemcpyAsync(c->in_b.p, site, m * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_window, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_b.as<u64>(), (long)m, len, c->in_seq.as<char>());
+    HIPCHK(c, hipMemcpyAsync(out, c->in_seq.p, m * (u64)len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMBS_OK;
+}
+
 extern "C" int bmbs_filter_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
                                  const uint32_t* read_of, const uint64_t* site, int64_t n_cand, uint32_t* err,
                                  int32_t* end_site)

@@ -338,12 +338,12 @@ __global__ void k_build_gen2(RefIndexDev R, u64 G, u64 n_words, u64* out)
 
 // full SA from the sampled SA: LF-walk to a flagged row (bwt_get_sa_restrict_steps_more_than_3,
 // bwt.h:2449-2560), done once per attach so that the mapping kernels never walk.
+// (grid-stride: a launch may not exceed 2^32 threads, GRCh38 has 6.2 G rows)
 __global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out, u64* out64)
 {
-    const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
+  for (u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (u64)gridDim.x * blockDim.x) {
     u64 l = row, steps = 0, val = 0;
-    if (l == ix.shapline) { if (out64) out64[row] = 0; else out[row] = 0; return; }
+    if (l == ix.shapline) { if (out64) out64[row] = 0; else out[row] = 0; continue; }
     for (;;) {
         const u64 blk = (l >> 8) * 5, last = l & 255;
         const u64 w = R.sa_flag[blk + 1 + (last >> 6)];
@@ -360,6 +360,7 @@ __global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out, u64*
         if (l == ix.shapline) { val = steps; break; }
     }
     if (out64) out64[row] = val; else out[row] = (u32)val;
+  }
 }
 
 // ================================================================================================
@@ -1408,6 +1409,26 @@ k_filter(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, con
     bpm_one(ix, seq + (size_t)r * stride, L, k, dense[g].site, e, es);
     ferr[g] = e; fend[g] = es;
     if (counters) atomicAdd(&SHARD(counters)[3], 1ull);
+}
+
+// K5 on its own (bmbs_locate_batch)
+__global__ void __launch_bounds__(256)
+k_locate_rows(DevIndex ix, const u64* __restrict__ row, long n, u64* __restrict__ pos)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[i] = row[i] <= ix.total ? sa_at(ix, row[i]) : ~0ull;
+}
+
+// K7 on its own (bmbs_window_batch): one window per thread
+__global__ void __launch_bounds__(256)
+k_window(DevIndex ix, const u64* __restrict__ site, long n, int len, char* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 s0 = site[i];
+    const bool valid = window_valid(ix, s0, (u64)len, s0 < ix.G);
+    WinReader wr; wr.init(ix, s0, valid);
+    for (int j = 0; j < len; j++) { const int b = wr.next(); out[(size_t)i * len + j] = b > 3 ? 0 : "ACGT"[b]; }
 }
 
 // standalone form for bmbs_filter_batch: explicit (read, site) pairs

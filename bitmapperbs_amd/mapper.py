@@ -150,6 +150,20 @@ class Mapper:
         self._chk(self._lib.bmbs_sync(self._ctx))
 
     # ---- stages -------------------------------------------------------------------------------------
+    def locate(self, rows: np.ndarray) -> np.ndarray:
+        """K5: text position SA[row] of suffix-array rows"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(rows.size, dtype=np.uint64)
+        self._chk(self._lib.bmbs_locate_batch(self._ctx, capi.ptr(rows), rows.size, capi.ptr(out)))
+        return out
+
+    def windows(self, site: np.ndarray, length: int) -> np.ndarray:
+        """K7: the doubled-genome windows starting at `site` (uint64), uint8 [n, length] (0 bytes = out-of-strand)"""
+        site = np.ascontiguousarray(site, dtype=np.uint64)
+        out = np.zeros((site.size, length), dtype=np.uint8)
+        self._chk(self._lib.bmbs_window_batch(self._ctx, capi.ptr(site), site.size, length, capi.ptr(out)))
+        return out
+
     def filter(self, seq: np.ndarray, L: int, read_of: np.ndarray, site: np.ndarray):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         read_of = np.ascontiguousarray(read_of, dtype=np.uint32)

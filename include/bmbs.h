@@ -112,6 +112,15 @@ int bmbs_index_attach(bmbs_ctx*, const bmbs_index_view*);
 /* reads: n rows of `stride` bytes ASCII upper-case (as produced by inputReads_single_directly,
  * Process_Reads.cpp:810), all of length L. */
 
+/* K7 alone: get_actuall_genome / get_actuall_rc_genome (Schema.cpp:4998-5115): the `len` bases (len <= 1024) of the doubled
+ * genome that start at doubled coordinate site[i], as ASCII into out + i*len; an out-of-strand request gives the reference's
+ * all-zero window (bytes 0).  Used by the parity tests to check the HBM genome against the index files.                 */
+int bmbs_window_batch(bmbs_ctx*, const uint64_t* site, int64_t n_sites, int32_t len, char* out);
+
+/* K5 alone: locate_one_position_direct (bwt.h:2585) without the seed adjustment: the text position SA[row] of each
+ * suffix-array row (0 <= row <= 2*ref_len).                                                                            */
+int bmbs_locate_batch(bmbs_ctx*, const uint64_t* row, int64_t n_rows, uint64_t* pos);
+
 /* K7+K8: get_actuall_[rc_]genome + BS_Reserve_Banded_BPM{,_4_SSE,_8_SSE}
  * (Schema.cpp:4998-5115; Levenshtein_Cal.h:351,1678,2093): candidate i = (read_of[i], site[i]).   */
 int bmbs_filter_batch(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int64_t n_reads,

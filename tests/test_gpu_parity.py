@@ -467,3 +467,25 @@ def test_wide_index_forms_match_oracle(env, monkeypatch):
     assert not compare_pe(res, pool, recs, 100)
     assert (m.stats() == ost).all()
     m.close()
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_locate_and_window_stages_match_oracle(wide, env, monkeypatch):
+    """K5 (SA[row]) and K7 (genome window) through their stage entry points, against the oracle's reading of the index files;
+    also in the wide (>= 2^32 symbols) device forms"""
+    from bitmapperbs_amd import mapper
+    monkeypatch.setenv("BMBS_WIDE", wide)
+    m = mapper.Mapper(env["ix"], 0)
+    G = env["ix"].ref_len
+    rng = np.random.default_rng(11)
+    rows = np.concatenate([rng.integers(0, 2 * G + 1, 20000), [0, 1, 2 * G - 1, 2 * G]]).astype(np.uint64)
+    got = m.locate(rows)
+    oix = env["oix"]
+    exp = np.array([oix.L.orc_sa_at(oix.h, int(r)) for r in rows], dtype=np.uint64)
+    assert (got == exp).all()
+    sites = np.concatenate([rng.integers(0, 2 * G, 5000), [0, G - 130, G - 129, G - 1, G, 2 * G - 130, 2 * G - 129, 2 * G + 7]]).astype(np.uint64)
+    W = m.windows(sites, 130)
+    for j in range(sites.size):
+        w = oix.window(int(sites[j]), 130)
+        assert bytes(W[j]) == bytes(w[:130]), int(sites[j])
+    m.close()
