@@ -960,6 +960,31 @@ extern "C" int bmbs_locate_batch(bmbs_ctx* c, const uint64_t* row, int64_t n_row
     return BMBS_OK;
 }
 
+extern "C" int bmbs_vote_order_batch(bmbs_ctx* c, const uint8_t* vote, const int64_t* seg_off, int64_t n_seg, int32_t form,
+                                     uint32_t* perm)
+{
+    if (!c) return BMBS_EINVAL;
+    if (n_seg <= 0) return BMBS_OK;
+    if (form != 0 && form != 1) { c->err = "vote order: form is 0 (wave) or 1 (block)"; return BMBS_EINVAL; }
+    const int64_t cap = form ? VL_CAP : VM_CAP;
+    for (int64_t s = 0; s < n_seg; s++)
+        if (seg_off[s + 1] < seg_off[s] || seg_off[s + 1] - seg_off[s] > cap) { c->err = "vote order: list longer than the form's capacity"; return BMBS_EINVAL; }
+    const u64 m = (u64)seg_off[n_seg] - (u64)seg_off[0];
+    if (m == 0) return BMBS_OK;
+    HIPCHK(c, hipSetDevice(c->dev));
+    ENS(c, c->in_a, ((u64)n_seg + 1) * 8); ENS(c, c->in_b, m * 4); ENS(c, c->in_seq, (u64)seg_off[n_seg] + 64);
+    HIPCHK(c, hipMemcpyAsync(c->in_a.p, seg_off, ((u64)n_seg + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_seq.p, vote, (u64)seg_off[n_seg], hipMemcpyHostToDevice, c->stream));
+    const u64 grid = (u64)n_seg < 65536 ? (u64)n_seg : 65536;
+    // perm is indexed like vote (seg_off[0] may be > 0): the kernel writes perm[a + j], so shift the base
+    u32* dperm = c->in_b.as<u32>() - seg_off[0];
+    if (form) hipLaunchKernelGGL((k_vote_order<VL_CAP, VL_BLOCK>), dim3(grid), dim3(VL_BLOCK), 0, c->stream, c->in_seq.as<uint8_t>(), c->in_a.as<long>(), (long)n_seg, dperm);
+    else hipLaunchKernelGGL((k_vote_order<VM_CAP, VM_BLOCK>), dim3(grid), dim3(VM_BLOCK), 0, c->stream, c->in_seq.as<uint8_t>(), c->in_a.as<long>(), (long)n_seg, dperm);
+    HIPCHK(c, hipMemcpyAsync(perm + seg_off[0], c->in_b.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMBS_OK;
+}
+
 extern "C" int bmbs_window_batch(bmbs_ctx* c, const uint64_t* site, int64_t n_sites, int32_t len, char* out)
 {
     if (!c) return BMBS_EINVAL;

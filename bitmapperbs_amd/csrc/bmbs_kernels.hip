@@ -1235,6 +1235,160 @@ DEVI int vl_run_ends(const u64* keys, int nc, u16* endpos, int* sh_w)
     return running;
 }
 
+// ---- std::sort's permutation, in parallel ------------------------------------------------------------------------------------
+// The vote order must be the exact permutation of libstdc++'s introsort (bmbs_sort.h).  Its moves are data-parallel all the
+// same: in one __unguarded_partition pass the left cursor stops exactly at the positions whose vote is <= the pivot's (in
+// ascending order: Lpos) and the right cursor at those >= it (descending: Rpos); the pass swaps Lpos[t] <-> Rpos[t] for
+// every t with Lpos[t] < Rpos[t] (a prefix, T of them, since one list ascends and the other descends) and returns
+// cut = min(Lpos[T], Rpos[T-1]) (Lpos[0] when T = 0).  Ranges above SMALL elements are partitioned by the whole block that
+// way; the disjoint ranges of 17..SMALL elements that remain are finished by one lane each with the serial loop; the final
+// insertion sort of std::sort is the stable sort of what the loop left, done with a bitonic network on (vote, position) keys.
+// tests/test_sort_order.py checks this formulation against std::sort on the CPU.
+struct VlRange { u16 f, l; int d; };
+DEVI void vl_prefix2(bool f0, bool f1, int* sh_w, int& p0, int& p1, int& t0, int& t1)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+    if (lane == 0) { sh_w[w] = __popcll(m0); sh_w[nw + w] = __popcll(m1); }
+    __syncthreads();
+    int a0 = 0, a1 = 0, s0 = 0, s1 = 0;
+    for (int i = 0; i < nw; i++) { const int x = sh_w[i], y = sh_w[nw + i]; if (i < w) { a0 += x; a1 += y; } s0 += x; s1 += y; }
+    __syncthreads();
+    t0 = s0; t1 = s1;
+    const unsigned long long below = (1ull << lane) - 1;
+    p0 = a0 + __popcll(m0 & below); p1 = a1 + __popcll(m1 & below);
+}
+// std::__unguarded_partition_pivot on items[first, last) by the whole block; returns the cut (block-uniform)
+DEVI int vl_partition(bmbs_vk* items, int first, int last, u16* Lpos, u16* Rpos, int* sh_w)
+{
+    if (threadIdx.x == 0) {
+        using namespace bmbs_sort_detail;
+        move_median_to_first(items, (long)first, (long)first + 1, (long)first + (last - first) / 2, (long)last - 1);
+    }
+    __syncthreads();
+    const u32 pv = items[first].x >> 24;
+    const int n = last - first - 1;
+    int nL = 0, nR = 0;
+    for (int base = 0; base < n; base += (int)blockDim.x) {
+        const int j = base + (int)threadIdx.x;
+        const int iL = first + 1 + j, iR = last - 1 - j;
+        const bool fl = j < n && (items[iL].x >> 24) <= pv;
+        const bool fr = j < n && (items[iR].x >> 24) >= pv;
+        int pl, pr, tl, tr;
+        vl_prefix2(fl, fr, sh_w, pl, pr, tl, tr);
+        if (fl) Lpos[nL + pl] = (u16)iL;
+        if (fr) Rpos[nR + pr] = (u16)iR;
+        nL += tl; nR += tr;
+    }
+    __syncthreads();
+    const int m = nL < nR ? nL : nR;
+    int T = 0;
+    for (int base = 0; base < m; base += (int)blockDim.x) {
+        const int t = base + (int)threadIdx.x;
+        const bool c = t < m && Lpos[t] < Rpos[t];
+        int tot;
+        vl_prefix(c, sh_w, tot);
+        T += tot;
+        const int span = m - base < (int)blockDim.x ? m - base : (int)blockDim.x;
+        if (tot < span) break;                      // the condition is monotone in t
+    }
+    for (int t = threadIdx.x; t < T; t += (int)blockDim.x) {
+        const int a = Lpos[t], b = Rpos[t];
+        const bmbs_vk x = items[a]; items[a] = items[b]; items[b] = x;
+    }
+    int cut;
+    if (T == 0) cut = Lpos[0];
+    else { const int lt = T < nL ? (int)Lpos[T] : 0x7fffffff, rt = Rpos[T - 1]; cut = lt < rt ? lt : rt; }
+    __syncthreads();
+    return cut;
+}
+// the serial introsort loop on a short range (<= 128 elements: the pending ranges are disjoint and each above 16)
+DEVI void vl_intro_small(bmbs_vk* v, int first0, int last0, int depth0)
+{
+    using namespace bmbs_sort_detail;
+    int sf[8], sl[8], sd[8];
+    int sp = 1;
+    sf[0] = first0; sl[0] = last0; sd[0] = depth0;
+    while (sp > 0) {
+        --sp;
+        int first = sf[sp], last = sl[sp], depth = sd[sp];
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort(v, (long)first, (long)last); break; }
+            --depth;
+            const int cut = (int)partition_pivot(v, (long)first, (long)last);
+            if (last - cut > 16) { sf[sp] = cut; sl[sp] = last; sd[sp] = depth; ++sp; }
+            last = cut;
+        }
+    }
+}
+// items[0, nv) -> std::sort(.., vote descending)'s permutation.  scratch: 4*CAP + 512 + CAP/2 bytes.  Returns false when a
+// large range ran out of depth budget (heapsort fallback): the caller then takes the serial path.
+template <int CAP, int SMALL>
+DEVI bool vl_sort_votes(bmbs_vk* items, int nv, void* scratch, int* sh_w, int* ctl)
+{
+    u16* Lpos = (u16*)scratch;
+    u16* Rpos = Lpos + CAP;
+    VlRange* big = (VlRange*)(Rpos + CAP);
+    VlRange* small = big + 64;
+    if (nv > 16) {
+        if (threadIdx.x == 0) {
+            int lg = 0;
+            for (int t = nv; t > 1; t >>= 1) lg++;
+            VlRange rg; rg.f = 0; rg.l = (u16)nv; rg.d = 2 * lg;
+            ctl[0] = 0; ctl[1] = 0; ctl[2] = 0;
+            if (nv > SMALL) { big[0] = rg; ctl[0] = 1; } else { small[0] = rg; ctl[1] = 1; }
+        }
+        __syncthreads();
+        while (true) {
+            const int nb = ctl[0];
+            if (nb == 0 || ctl[2]) break;
+            const VlRange rg = big[nb - 1];
+            __syncthreads();
+            if (threadIdx.x == 0) ctl[0] = nb - 1;
+            int first = rg.f, last = rg.l, depth = rg.d;
+            while (last - first > SMALL) {
+                if (depth == 0) { if (threadIdx.x == 0) ctl[2] = 1; break; }
+                --depth;
+                const int cut = vl_partition(items, first, last, Lpos, Rpos, sh_w);
+                if (threadIdx.x == 0) {
+                    VlRange q; q.f = (u16)cut; q.l = (u16)last; q.d = depth;
+                    if (last - cut > SMALL) big[ctl[0]++] = q;
+                    else if (last - cut > 16) small[ctl[1]++] = q;
+                }
+                last = cut;
+            }
+            if (threadIdx.x == 0 && last - first > 16 && last - first <= SMALL) {
+                VlRange q; q.f = (u16)first; q.l = (u16)last; q.d = depth;
+                small[ctl[1]++] = q;
+            }
+            __syncthreads();
+        }
+        if (ctl[2]) return false;
+        const int n_small = ctl[1];
+        for (int s2 = threadIdx.x; s2 < n_small; s2 += (int)blockDim.x) vl_intro_small(items, small[s2].f, small[s2].l, small[s2].d);
+        __syncthreads();
+    }
+    // the final insertion sort = stable sort by vote descending of the current arrangement
+    int np2 = 32;
+    while (np2 < nv) np2 <<= 1;
+    for (int j = threadIdx.x; j < np2; j += (int)blockDim.x)
+        items[j].x = j < nv ? ((255u - (items[j].x >> 24)) << 24) | ((u32)j << 12) | (items[j].x & 0xfffu) : 0xffffffffu;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < np2 / 2; t += (int)blockDim.x) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool asc = (i & size) == 0;
+                const u32 a = items[i].x, b = items[j].x;
+                if ((a > b) == asc) { items[i].x = b; items[j].x = a; }
+            }
+            __syncthreads();
+        }
+    for (int j = threadIdx.x; j < nv; j += (int)blockDim.x) { const u32 x = items[j].x; items[j].x = ((255u - (x >> 24)) << 24) | (x & 0xfffu); }
+    __syncthreads();
+    return true;
+}
+
 // CAP, BLOCK = (VM_CAP, VM_BLOCK): lists of up to 256 candidates, one wave each; (VL_CAP, VL_BLOCK): the longer ones, one
 // block each (the two instances walk the same list and take the reads of their size class: LO < nc <= CAP, the last one also beyond)
 template <int CAP, int BLOCK, int LO>
@@ -1246,7 +1400,8 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
     __shared__ u16 endpos[CAP];
     __shared__ bmbs_vk items[CAP];
     __shared__ u32 sh_pref[BMBS_MAX_SEEDS + 1];
-    __shared__ int sh_w[BLOCK / 64 + 1];
+    __shared__ int sh_w[2 * (BLOCK / 64) + 1];
+    __shared__ int sh_ctl[4];
     const long total_items = (long)*count_ptr;
     for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
         const long r = list[item];
@@ -1290,18 +1445,55 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
             const u32 vote = (u32)endpos[e] - (e ? (u32)endpos[e - 1] : 0xffffffffu);
             items[e].x = (vote << 24) | (u32)e;
         }
+        // the sites move to the candidate segment in global memory: the sort below needs the LDS they occupy
+        u64* c = cand + off;
+        for (int e = threadIdx.x; e < nv; e += BLOCK) c[e] = keys[endpos[e]];
         __syncthreads();
-        if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);      // std::sort(votes, compare_seed_votes), Schema.cpp:24986
-        __syncthreads();
+        // std::sort(votes, compare_seed_votes), Schema.cpp:24986
+        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32)>(items, nv, keys, sh_w, sh_ctl)) {
+            for (int e = threadIdx.x; e < nv; e += BLOCK) {
+                const u32 vote = (u32)endpos[e] - (e ? (u32)endpos[e - 1] : 0xffffffffu);
+                items[e].x = (vote << 24) | (u32)e;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);
+            __syncthreads();
+        }
         for (int j = threadIdx.x; j < nv; j += BLOCK) {
             const u32 it = items[j].x;
-            const u64 site = keys[endpos[it & 0xffffffu]];
+            const u64 site = c[it & 0xffffffu];
             bmbs_vote o;
             o.site = site < (u64)k ? 0 : site - (u64)k; o.vote = it >> 24; o.pad = 0;
             v[j] = o;
         }
         for (long i = threadIdx.x; i < nc; i += BLOCK) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
         if (threadIdx.x == 0) st.n_votes[r] = (u32)nv;
+        __syncthreads();
+    }
+}
+
+// a9 alone (stage API, parity tests): the visiting order of given vote lists, one block per list
+template <int CAP, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_vote_order(const uint8_t* __restrict__ vote, const long* __restrict__ seg_off, long n_seg, u32* __restrict__ perm)
+{
+    __shared__ u64 scratch[CAP];
+    __shared__ bmbs_vk items[CAP];
+    __shared__ int sh_w[2 * (BLOCK / 64) + 1];
+    __shared__ int sh_ctl[4];
+    for (long sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
+        const long a = seg_off[sg];
+        const int nv = (int)(seg_off[sg + 1] - a);
+        if (nv <= 0 || nv > CAP) continue;
+        for (int e = threadIdx.x; e < nv; e += BLOCK) items[e].x = ((u32)vote[a + e] << 24) | (u32)e;
+        __syncthreads();
+        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32)>(items, nv, scratch, sh_w, sh_ctl)) {
+            for (int e = threadIdx.x; e < nv; e += BLOCK) items[e].x = ((u32)vote[a + e] << 24) | (u32)e;
+            __syncthreads();
+            if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);
+            __syncthreads();
+        }
+        for (int j = threadIdx.x; j < nv; j += BLOCK) perm[a + j] = items[j].x & 0xffffffu;
         __syncthreads();
     }
 }
@@ -2064,7 +2256,7 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
     __shared__ u64 keys[CAP];
     __shared__ u16 endpos[CAP];
     __shared__ u32 sh_pref[BMBS_MAX_SEEDS + 1];
-    __shared__ int sh_w[BLOCK / 64 + 1];
+    __shared__ int sh_w[2 * (BLOCK / 64) + 1];
     const long total_items = (long)*count_ptr;
     for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
         const long r = list[item];

@@ -94,11 +94,9 @@ template <class T> BMBS_HD void heap_sort(T* v, long first, long last)
         adjust_heap(v, first, 0, last - first, val);
     }
 }
-template <class T> BMBS_HD long partition_pivot(T* v, long first, long last)
+// median of (a, b, c) moved to `first`
+template <class T> BMBS_HD void move_median_to_first(T* v, long first, long a, long b, long c)
 {
-    long mid = first + (last - first) / 2;
-    long a = first + 1, b = mid, c = last - 1;
-    // median of (a, b, c) moved to `first`
     if (before(v[a], v[b])) {
         if (before(v[b], v[c])) swp(v, first, b);
         else if (before(v[a], v[c])) swp(v, first, c);
@@ -106,6 +104,10 @@ template <class T> BMBS_HD long partition_pivot(T* v, long first, long last)
     } else if (before(v[a], v[c])) swp(v, first, a);
     else if (before(v[b], v[c])) swp(v, first, c);
     else swp(v, first, b);
+}
+template <class T> BMBS_HD long partition_pivot(T* v, long first, long last)
+{
+    move_median_to_first(v, first, first + 1, first + (last - first) / 2, last - 1);
     long lo = first + 1, hi = last;
     for (;;) {
         while (before(v[lo], v[first])) ++lo;
@@ -118,6 +120,27 @@ template <class T> BMBS_HD long partition_pivot(T* v, long first, long last)
 }
 }  // namespace bmbs_sort_detail
 
+// std::__introsort_loop on v[first0, last0) with the given depth budget (explicit stack; the sub-ranges are disjoint, so
+// the order in which they are finished does not change the result)
+template <class T> BMBS_HD void intro_loop(T* v, long first0, long last0, int depth0)
+{
+    using namespace bmbs_sort_detail;
+    long sf[64], sl[64]; int sd[64];
+    int sp = 0;
+    sf[0] = first0; sl[0] = last0; sd[0] = depth0; sp = 1;
+    while (sp > 0) {
+        --sp;
+        long first = sf[sp], last = sl[sp]; int depth = sd[sp];
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort(v, first, last); break; }
+            --depth;
+            long cut = partition_pivot(v, first, last);
+            sf[sp] = cut; sl[sp] = last; sd[sp] = depth; ++sp;      // "recursive" call on [cut,last)
+            last = cut;
+        }
+    }
+}
+
 // sorts v[0..n) by vote descending with std::sort's exact permutation
 template <class T> BMBS_HD void intro_sort_desc(T* v, long n)
 {
@@ -126,22 +149,7 @@ template <class T> BMBS_HD void intro_sort_desc(T* v, long n)
     if (n > 16) {
         int lg = 0;
         for (long t = n; t > 1; t >>= 1) lg++;
-        // explicit stack of (first, last, depth); sub-ranges are disjoint so the order in which
-        // they are finished does not change the result
-        long sf[64], sl[64]; int sd[64];
-        int sp = 0;
-        sf[0] = 0; sl[0] = n; sd[0] = 2 * lg; sp = 1;
-        while (sp > 0) {
-            --sp;
-            long first = sf[sp], last = sl[sp]; int depth = sd[sp];
-            while (last - first > 16) {
-                if (depth == 0) { heap_sort(v, first, last); break; }
-                --depth;
-                long cut = partition_pivot(v, first, last);
-                sf[sp] = cut; sl[sp] = last; sd[sp] = depth; ++sp;      // "recursive" call on [cut,last)
-                last = cut;
-            }
-        }
+        intro_loop(v, 0, n, 2 * lg);
         insertion_sort(v, 0, 16);
         for (long i = 16; i < n; ++i) unguarded_linear_insert(v, i);
     } else insertion_sort(v, 0, n);

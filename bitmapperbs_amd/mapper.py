@@ -157,6 +157,14 @@ class Mapper:
         self._chk(self._lib.bmbs_locate_batch(self._ctx, capi.ptr(rows), rows.size, capi.ptr(out)))
         return out
 
+    def vote_order(self, vote: np.ndarray, seg_off: np.ndarray, form: int) -> np.ndarray:
+        """a9: the visiting order std::sort gives each vote list vote[seg_off[s]:seg_off[s+1]] (form 0: wave kernel, 1: block kernel)"""
+        vote = np.ascontiguousarray(vote, dtype=np.uint8)
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+        perm = np.zeros(vote.size, dtype=np.uint32)
+        self._chk(self._lib.bmbs_vote_order_batch(self._ctx, capi.ptr(vote), capi.ptr(seg_off), seg_off.size - 1, form, capi.ptr(perm)))
+        return perm
+
     def windows(self, site: np.ndarray, length: int) -> np.ndarray:
         """K7: the doubled-genome windows starting at `site` (uint64), uint8 [n, length] (0 bytes = out-of-strand)"""
         site = np.ascontiguousarray(site, dtype=np.uint64)

@@ -121,6 +121,12 @@ int bmbs_window_batch(bmbs_ctx*, const uint64_t* site, int64_t n_sites, int32_t 
  * suffix-array row (0 <= row <= 2*ref_len).                                                                            */
 int bmbs_locate_batch(bmbs_ctx*, const uint64_t* row, int64_t n_rows, uint64_t* pos);
 
+/* a9 alone: the order in which `std::sort(votes, votes + n, compare_seed_votes)` (Schema.cpp:560-563, 24986 -- an unstable sort:
+ * libstdc++'s introsort) visits vote lists.  List s is vote[seg_off[s] .. seg_off[s+1]) (counts 1..255); perm[seg_off[s] + j] =
+ * index within list s of the entry visited j-th.  form 0: the one-wave kernel (lists of up to 256 entries), form 1: the
+ * one-block kernel (up to 4096) -- the two forms k_vote_long runs on the candidate lists of repeat reads.               */
+int bmbs_vote_order_batch(bmbs_ctx*, const uint8_t* vote, const int64_t* seg_off, int64_t n_seg, int32_t form, uint32_t* perm);
+
 /* K7+K8: get_actuall_[rc_]genome + BS_Reserve_Banded_BPM{,_4_SSE,_8_SSE}
  * (Schema.cpp:4998-5115; Levenshtein_Cal.h:351,1678,2093): candidate i = (read_of[i], site[i]).   */
 int bmbs_filter_batch(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int64_t n_reads,

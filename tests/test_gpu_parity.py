@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import orc
-from common import GOLD, e_of, golden_args, gunzip_to, plant_repeats, read_fastq
+from common import GOLD, ROOT, e_of, golden_args, gunzip_to, plant_repeats, read_fastq
 
 pytestmark = pytest.mark.gpu
 
@@ -489,3 +489,60 @@ def test_locate_and_window_stages_match_oracle(wide, env, monkeypatch):
         w = oix.window(int(sites[j]), 130)
         assert bytes(W[j]) == bytes(w[:130]), int(sites[j])
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [0, 1], ids=["wave", "block"])
+def test_vote_order_kernels_give_std_sort_permutation(form, env, tmp_path):
+    """a9: the parallel vote sort of k_vote_long (block-wide partition passes + per-lane short ranges + stable final pass)
+    visits every list in exactly the order libstdc++'s std::sort does -- random, structured and adversarial lists"""
+    import ctypes as C
+    import subprocess
+    from bitmapperbs_amd import mapper
+    so = str(tmp_path / "std_order.so")
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "csrc", "std_order.cpp")], check=True)
+    ref = C.CDLL(so)
+    cap = 4096 if form else 256
+    rng = np.random.default_rng(900 + form)
+    lists = []
+    for c in range(1500 if form else 6000):
+        if c % 7 == 0:
+            n = int(rng.integers(cap // 2, cap + 1))
+        elif c % 3 == 0:
+            n = int(rng.integers(17, min(cap, 600) + 1))
+        else:
+            n = int(rng.integers(1, 48))
+        maxv = (2, 6, 25, 255)[c % 4]
+        kind = c % 8
+        i = np.arange(n)
+        if kind <= 2:
+            v = 1 + rng.integers(0, maxv, n)
+        elif kind == 3:
+            v = 1 + (i * maxv) // n
+        elif kind == 4:
+            v = maxv - (i * maxv) // n
+        elif kind == 5:
+            v = 1 + np.minimum(i, n - i) % maxv
+        elif kind == 6:
+            v = np.ones(n, dtype=np.int64)
+        else:
+            v = 1 + np.where(rng.random(n) < 0.9, 0, rng.integers(0, maxv, n))
+        lists.append(v.astype(np.uint8))
+    for n in (17, 33, 64, 120, 129, 200, 255):          # depth-limit / heapsort branch (serial fallback or per-lane heapsort)
+        kv = np.zeros(n, dtype=np.uint8)
+        ref.killer_votes(n, kv.ctypes.data_as(C.c_void_p))
+        lists.append(kv)
+        if form:                                        # an adversarial stretch inside a long list of larger votes... and of equal ones
+            lists.append(np.concatenate([kv, np.full(3000, 1, np.uint8)]))
+            lists.append(np.concatenate([np.full(500, 255, np.uint8), kv, rng.integers(1, 3, 2000).astype(np.uint8)]))
+    seg = np.zeros(len(lists) + 1, dtype=np.int64)
+    seg[1:] = np.cumsum([x.size for x in lists])
+    vote = np.concatenate(lists)
+    want = np.zeros(vote.size, dtype=np.uint32)
+    ref.std_order(vote.ctypes.data_as(C.c_void_p), seg.ctypes.data_as(C.c_void_p), C.c_int64(len(lists)), want.ctypes.data_as(C.c_void_p))
+    m = mapper.Mapper(env["ix"], 0)
+    got = m.vote_order(vote, seg, form)
+    m.close()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first difference in list %d (length %d)" % (np.searchsorted(seg, bad[0], "right") - 1,
+                                                                        lists[np.searchsorted(seg, bad[0], "right") - 1].size)
