@@ -460,7 +460,7 @@ double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)
 int main(int argc, char** argv)
 {
     bmbs_params P; bmbs_default_params(&P);
-    std::string index, seq, seq1, seq2, out = "output", mapstats;
+    std::string index, seq, seq1, seq2, out = "output", mapstats, build_fasta, index_folder;
     int device = 0, io_threads = 0;
     long batch = 1000000;
     bool verbose = false, unmapped_out = false, pbat = false, bam = false;
@@ -468,6 +468,8 @@ int main(int argc, char** argv)
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "--search") index = val();
+        else if (a == "--index") build_fasta = val();                 // Process_CommandLines.cpp:107, 364-381
+        else if (a == "--index_folder") index_folder = val();
         else if (a == "--seq") seq = val();
         else if (a == "--seq1") seq1 = val();
         else if (a == "--seq2") seq2 = val();
@@ -498,8 +500,23 @@ int main(int argc, char** argv)
         else if (a == "--sam") bam = false;
         else { fprintf(stderr, "bmbs_search: unsupported option %s\n", a.c_str()); return 2; }
     }
+    if (!build_fasta.empty()) {
+        // bitmapperBS --index <fasta> [--index_folder <dir>]: <fasta>.index* or <dir>/genome.index* (Index.cpp:832-938)
+        std::string prefix = build_fasta;
+        if (!index_folder.empty()) {
+            while (index_folder.size() > 1 && index_folder.back() == '/') index_folder.pop_back();
+            ::mkdir(index_folder.c_str(), 0755);
+            prefix = index_folder + "/genome";
+        }
+        if (io_threads <= 0) io_threads = (int)std::thread::hardware_concurrency();
+        const double t0 = now();
+        const int rc = bmbs_index_build(build_fasta.c_str(), prefix.c_str(), io_threads < 1 ? 1 : io_threads);
+        if (rc) { fprintf(stderr, "bmbs_search: index build failed (%d)\n", rc); return 1; }
+        fprintf(stderr, "index written to %s.index* in %.1f s\n", prefix.c_str(), now() - t0);
+        return 0;
+    }
     if (index.empty() || (seq.empty() && (seq1.empty() || seq2.empty()))) {
-        fprintf(stderr, "usage: bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--pbat] [--unmapped_out] [--ambiguous_out] [--bam] [--mapstats f] [-t io_threads]\n");
+        fprintf(stderr, "usage: bmbs_search --index <genome.fa> [--index_folder dir] [-t threads]\n       bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--pbat] [--unmapped_out] [--ambiguous_out] [--bam] [--mapstats f] [-t io_threads]\n");
         return 2;
     }
     if (batch < 1) batch = 1;
