@@ -250,7 +250,7 @@ def main():
             "k_vote": (8 + 16 + 4) * cnt["n_cand_slots"],
             "k_vote_fused": (4 + 16 + 4) * cnt["n_cand_slots"],
             "k_filter": (win + L + 16 + 8) * cnt["n_filter"],
-            "k_align_ungapped": (win + 2 * L + 16) * cnt["n_sw"],
+            "k_align_ungapped": (win + 2 * L + 16) * cnt["n_jobs"],
             "k_align_sw": (win + 2 * L + 16) * cnt["n_sw"],
             "k_finalize": 32 * nr,
         }

@@ -218,6 +218,33 @@ DEVI u64 mism8_3letter(u64 rw, u64 w16)
     return (((diff & K7F) + K7F) | diff) & K80;
 }
 
+// sequential reader of the doubled 2-bit genome, 16 bases (32 bits) per step; two words are kept in registers and one
+// global load is issued per 32 bases (gen2 carries two spare words at its end)
+struct Win32Cur {
+    const u64* g; u64 lo, hi; long idx;
+    DEVI void init(const DevIndex& ix, u64 d) { g = ix.gen2; idx = (long)(d >> 5); lo = g[idx]; hi = g[idx + 1]; }
+    DEVI u32 at(u64 d)                          // the 16 bases starting at d; d never decreases and advances by <= 32 per call
+    {
+        const long id2 = (long)(d >> 5);
+        if (id2 != idx) { lo = hi; hi = g[id2 + 1]; idx = id2; }
+        const int sh = (int)(d & 31) * 2;
+        u64 w = lo >> sh;
+        if (sh) w |= hi << (64 - sh);
+        return (u32)w;
+    }
+};
+// number of positions j < len (len <= 8) where read character rd[ts + j] does not match window base d + j (mism8's rule);
+// rd + (ts & ~7) is an aligned u64 inside the read's row, the following one is touched only when the span crosses into it
+DEVI int mism_span(const DevIndex& ix, const char* rd, int ts, u64 d, int len)
+{
+    const u64* p = reinterpret_cast<const u64*>(rd + (ts & ~7));
+    const int sh = (ts & 7) * 8;
+    u64 rw = p[0] >> sh;
+    if (sh && (ts & 7) + len > 8) rw |= p[1] << (64 - sh);
+    const u64 keep = len >= 8 ? ~0ull : ((1ull << (8 * len)) - 1);
+    return __popcll(mism8(rw, win16(ix, d)) & keep & 0x8080808080808080ull);
+}
+
 // ================================================================================================
 // attach-time re-pack kernels
 // ================================================================================================
@@ -1739,24 +1766,40 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
     const int p_len = L + 2 * k;
     const bool wvalid = window_valid(ix, site, (u64)p_len, site < ix.G);
     const int start = end_site - L + 1;
-    bool ok = start >= 0;
+    // an out-of-strand window compares unequal everywhere (err_in <= k < L mismatches can never account for that)
+    bool ok = start >= 0 && wvalid;
     int tmp_err = 0, score = 0;
     if (ok) {
-        WinReader wr; wr.init(ix, site + (u64)start, wvalid);
-        ReadCur rc; rc.seek(rd, 0, L);
-        for (int i = 0; i < L; i++) {
-            const char a = rc.next();
-            const int b = wr.next();
-            if (!(code4(a) == b || (a == 'T' && b == 1))) {
-                if (++tmp_err > (int)err_in) { ok = false; break; }
-                score -= a == 'N' ? sp.np : pen_lut[(unsigned char)ql[rev ? L - 1 - i : i]];
+        // 16 read characters (one 16-byte load) against 16 window bases per step; the quality penalties of the few mismatching
+        // positions are picked up from the mask
+        Win32Cur wc; wc.init(ix, site + (u64)start);
+        for (int p = 0; p < L && ok; p += 16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(rd + p);
+            const u64 r0 = ((u64)v.y << 32) | v.x, r1 = ((u64)v.w << 32) | v.z;
+            const u32 w32 = wc.at(site + (u64)start + (u64)p);
+            u64 m0 = mism8(r0, w32 & 0xffff), m1 = mism8(r1, w32 >> 16);
+            const int left = L - p;
+            if (left < 16) {
+                if (left <= 8) { m1 = 0; if (left < 8) m0 &= (1ull << (8 * left)) - 1; }
+                else m1 &= (1ull << (8 * (left - 8))) - 1;
+            }
+            tmp_err += __popcll(m0) + __popcll(m1);
+            if (tmp_err > (int)err_in) { ok = false; break; }
+            while (m0) {
+                const int i = p + (__ffsll((unsigned long long)m0) - 1) / 8;
+                m0 &= m0 - 1;
+                score -= rd[i] == 'N' ? sp.np : pen_lut[(unsigned char)ql[rev ? L - 1 - i : i]];
+            }
+            while (m1) {
+                const int i = p + 8 + (__ffsll((unsigned long long)m1) - 1) / 8;
+                m1 &= m1 - 1;
+                score -= rd[i] == 'N' ? sp.np : pen_lut[(unsigned char)ql[rev ? L - 1 - i : i]];
             }
         }
         if (ok && tmp_err != (int)err_in) ok = false;
     }
     if (ok) { a_start[jb] = start; a_end[jb] = end_site; a_nm[jb] = err_in; a_score[jb] = score; a_nops[jb] = 0; }
-    else need_sw[jb] = 1;
-    if (counters) atomicAdd(&SHARD(counters)[4], 1ull);
+    else { need_sw[jb] = 1; if (counters) atomicAdd(&SHARD(counters)[4], 1ull); }
 }
 
 __global__ void k_sw_list(u64 n_jobs, const u32* __restrict__ need_sw, const u64* __restrict__ sw_off, u32* __restrict__ sw_job)
@@ -1872,13 +1915,32 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         else cg[nc - 1] += (u32)len << 4;
     };
     int i = tlen - 1, kk = max_i - 1, which = 0;
-    while (i >= 0 && kk >= 0) {
-        const int b = kk - i;
-        const int d = (int)((tz[((u64)i * NWk + (b >> 4)) * trace_stride] >> (4 * (b & 15))) & 15);
-        which = which == 0 ? (d & 3) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
-        if (which == 0) { push(0, 1); --i; --kk; }
-        else if (which == 1) { push(2, 1); --i; }
-        else { push(1, 1); --kk; }
+    if (NW == 1) {
+        // one trace word per row and the rows are visited in descending order: an 8-deep software pipeline of row loads
+        // (each step would otherwise wait out a full memory round trip)
+        u64 tb[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) tb[q] = i - q >= 0 ? tz[(u64)(i - q) * trace_stride] : 0;
+        while (i >= 0 && kk >= 0) {
+            const int b = kk - i;
+            const int d = (int)((tb[0] >> (4 * (b & 15))) & 15);
+            which = which == 0 ? (d & 3) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
+            if (which == 2) { push(1, 1); --kk; continue; }
+            if (which == 0) { push(0, 1); --kk; } else push(2, 1);
+            --i;
+#pragma unroll
+            for (int q = 0; q < 7; q++) tb[q] = tb[q + 1];
+            tb[7] = i - 7 >= 0 ? tz[(u64)(i - 7) * trace_stride] : 0;
+        }
+    } else {
+        while (i >= 0 && kk >= 0) {
+            const int b = kk - i;
+            const int d = (int)((tz[((u64)i * NWk + (b >> 4)) * trace_stride] >> (4 * (b & 15))) & 15);
+            which = which == 0 ? (d & 3) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
+            if (which == 0) { push(0, 1); --i; --kk; }
+            else if (which == 1) { push(2, 1); --i; }
+            else { push(1, 1); --kk; }
+        }
     }
     if (i >= 0) push(2, i + 1);
     for (int a2 = 0, b2 = nc - 1; a2 < b2; a2++, b2--) { const u32 x = cg[a2]; cg[a2] = cg[b2]; cg[b2] = x; }
@@ -1904,8 +1966,13 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     }
     const int cigar_e = ii;
     // NM recount under bisulfite matching + ops in SAM order (ksw.cpp:2779-2857); a window never holds 'N'
-    auto wbase = [&](int j) -> int { return wvalid ? gbase(ix, site + (u64)j) : 4; };
-    auto is_match = [&](char a, int b) -> bool { return code4(a) == b || (a == 'T' && b == 1); };
+    // mismatches of an M run: read [ts, ts + len) against window [qs, qs + len), eight positions per step
+    auto m_run = [&](int ts, int qs, int len) -> int {
+        if (!wvalid) return len;
+        int c = 0;
+        for (int o = 0; o < len; o += 8) c += mism_span(ix, rd, ts + o, site + (u64)(qs + o), len - o < 8 ? len - o : 8);
+        return c;
+    };
     u32* ops_out = cigar_pool + jb * (u64)max_ops;
     int NM = 0, no = 0;
     if (fwd) {
@@ -1914,7 +1981,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
             op = cg[ii] & 0xf; opl = cg[ii] >> 4;
             if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
             no++;
-            if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[ts], wbase(qs))) NM++; qs++; ts++; } }
+            if (op == 0) { NM += m_run(ts, qs, opl); qs += opl; ts += opl; }
             else if (op == 1) { qs += opl; NM += opl; }
             else { ts += opl; NM += opl; }
         }
@@ -1924,7 +1991,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
             op = cg[ii] & 0xf; opl = cg[ii] >> 4;
             if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
             no++;
-            if (op == 0) { for (int q = 0; q < opl; q++) { if (!is_match(rd[te], wbase(qx))) NM++; qx--; te--; } }
+            if (op == 0) { NM += m_run(te - opl + 1, qx - opl + 1, opl); qx -= opl; te -= opl; }
             else if (op == 1) { qx -= opl; NM += opl; }
             else { te -= opl; NM += opl; }
         }

@@ -208,7 +208,7 @@ int bmbs_stats_allreduce(bmbs_ctx** ctxs, int n, int64_t stats[5]);
  * names/ms arrays of length >= *n (in: capacity, out: count).                                     */
 int bmbs_profile_last(bmbs_ctx*, const char** names, float* ms, int* n);
 /* event counters of the last call for the algorithmic-byte model:
- * c[0]=n_hash c[1]=n_ext(LF pairs) c[2]=n_sa c[3]=n_cand(windows filtered) c[4]=n_sw c[5]=n_ungapped
+ * c[0]=n_hash c[1]=n_ext(LF pairs) c[2]=n_sa c[3]=n_cand(windows filtered) c[4]=n_sw(jobs that ran the DP) c[5]=n_ungapped
  * c[6]=window bytes                                                                               */
 int bmbs_counters_last(bmbs_ctx*, uint64_t c[8]);
 /* all 32 words: c[0..7] as above, c[8..15] lane-utilisation probes (diagnostic builds), c[16+4*kid+{0,1,2,3}] =

@@ -85,7 +85,7 @@ def test_map_se_records_and_stats_match_oracle(case, env):
     g = m.counters()
     # event counts that do not depend on how the device walks the index (n_ext does: single-row intervals are
     # finished against the genome instead of by LF steps)
-    assert (g["n_hash"], g["n_filter"], g["n_sw"], g["n_ungapped"]) == \
+    assert (g["n_hash"], g["n_filter"], g["n_jobs"], g["n_ungapped"]) == \
            (cnt["n_hash"], cnt["n_cand"], cnt["n_sw"], cnt["n_ungapped"])
     assert g["n_ext"] <= cnt["n_ext"]
     m.close()
