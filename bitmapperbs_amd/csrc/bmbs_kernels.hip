@@ -1864,7 +1864,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
             if (b < band) {
                 int m = RH[b], e = RE[b], h, tt;
                 const int wb = (int)((wq[b >> 4] >> (4 * (b & 15))) & 15);
-                m += (ta == wb || (ta == 3 && wb == 1)) ? 0 : (wb == 4 ? -sp.np : mis);
+                m += ((ta == wb && ta < 4) || (ta == 3 && wb == 1)) ? 0 : (wb == 4 ? -sp.np : mis);      // mat[] of Schema.cpp:830-850: N never matches
                 int d = m >= e ? 0 : 1;
                 h = m >= e ? m : e;
                 d = h >= f ? d : 2;
@@ -1910,9 +1910,12 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     u32 cg[LOCAL_OPS + 1];
     int nc = 0;
     bool overflow = false;
+    // the run being extended stays in registers (cur_op, cur_len); it goes to cg[] only when the operation changes
+    int cur_op = -1, cur_len = 0;
+    auto flush = [&]() { if (cur_op >= 0) { if (nc < LOCAL_OPS) cg[nc++] = ((u32)cur_len << 4) | (u32)cur_op; else overflow = true; } };
     auto push = [&](int op, int len) {
-        if (nc == 0 || op != (int)(cg[nc - 1] & 0xf)) { if (nc < LOCAL_OPS) cg[nc++] = ((u32)len << 4) | (u32)op; else overflow = true; }
-        else cg[nc - 1] += (u32)len << 4;
+        if (op != cur_op) { flush(); cur_op = op; cur_len = len; }
+        else cur_len += len;
     };
     int i = tlen - 1, kk = max_i - 1, which = 0;
     if (NW == 1) {
@@ -1943,6 +1946,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         }
     }
     if (i >= 0) push(2, i + 1);
+    flush();
     for (int a2 = 0, b2 = nc - 1; a2 < b2; a2++, b2--) { const u32 x = cg[a2]; cg[a2] = cg[b2]; cg[b2] = x; }
     cg[nc] = 0;
     int qb = kk + 1;
