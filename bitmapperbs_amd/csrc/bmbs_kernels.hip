@@ -1609,9 +1609,103 @@ DEVI void bpm_core(const DevIndex& ix, const char* rd, int L, int k, u64 site, u
     out_err = best; out_end = ret;
 }
 
+// The k <= 15 form (band <= 31 bits).  k_filter is bound by VALU issue, not by memory (profiles/: ~85 % of its time is VALU
+// issue), so this form spends fewer instructions per read character than sliding four Peq vectors does: the window is kept
+// as two bit planes (bit 0 / bit 1 of the 2-bit letters; 64 bases per register pair, re-filled every 32 rows), the row's Peq
+// is derived from them with the bisulfite rule folded in (T: plane 0 alone = {C, T}), and the characters come 16 per load.
+// Same recurrences, same results as bpm_core<u32>.
+DEVI void planes32(const DevIndex& ix, u64 d, u32& lo, u32& hi)      // the 32 bases starting at doubled coordinate d
+{
+    const int sh = (int)(d & 31) * 2;
+    u64 w = ix.gen2[d >> 5] >> sh;
+    if (sh) w |= ix.gen2[(d >> 5) + 1] << (64 - sh);
+    auto squeeze = [](u32 x) -> u32 {           // bits 0, 2, 4 .. 30 -> bits 0 .. 15
+        x &= 0x55555555u;
+        x = (x | (x >> 1)) & 0x33333333u;
+        x = (x | (x >> 2)) & 0x0f0f0f0fu;
+        x = (x | (x >> 4)) & 0x00ff00ffu;
+        x = (x | (x >> 8)) & 0x0000ffffu;
+        return x;
+    };
+    const u32 a = (u32)w, b = (u32)(w >> 32);
+    lo = squeeze(a) | (squeeze(b) << 16);
+    hi = squeeze(a >> 1) | (squeeze(b >> 1) << 16);
+}
+DEVI void bpm_core32(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
+{
+    out_err = 0xffffffffu; out_end = -1;
+    const int p_len = L + 2 * k;
+    if (!window_valid(ix, site, (u64)p_len, site < ix.G)) return;
+    const int band = 2 * k + 1;
+    const u32 bmask = (1u << band) - 1;                 // band <= 31
+    u64 loS, hiS;                                       // bit j = plane bit of base site + i0 + j
+    {
+        u32 l0, h0, l1, h1;
+        planes32(ix, site, l0, h0); planes32(ix, site + 32, l1, h1);
+        loS = ((u64)l1 << 32) | l0; hiS = ((u64)h1 << 32) | h0;
+    }
+    u32 VP = 0, VN = 0;
+    int err = 0;
+    const int last_high = 2 * k;
+    for (int i0 = 0; i0 < L; i0 += 32) {
+        if (i0) {
+            u32 nl, nh;
+            planes32(ix, site + (u64)i0 + 32, nl, nh);
+            loS = (loS >> 32) | ((u64)nl << 32); hiS = (hiS >> 32) | ((u64)nh << 32);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int ib = i0 + 16 * half;
+            if (ib >= L) break;
+            const uint4 v = *reinterpret_cast<const uint4*>(rd + ib);       // rows are 16-byte aligned and padded
+            const u32 cw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int i = ib + c;
+                if (i >= L) break;
+                const u32 tc = (cw[c >> 2] >> (8 * (c & 3))) & 0xffu;
+                const u32 lo = (u32)(loS >> (i - i0)) & bmask, hi = (u32)(hiS >> (i - i0)) & bmask;
+                const u32 xl = (tc == 'A' || tc == 'G') ? (lo ^ bmask) : lo;
+                const u32 xh = tc == 'G' ? hi : ~hi;
+                u32 eq = tc == 'T' ? lo : (xl & xh);
+                if (!(tc == 'A' || tc == 'C' || tc == 'G' || tc == 'T')) eq = 0;
+                u32 X = eq | VN;
+                const u32 D0 = ((VP + (X & VP)) ^ VP) | X;
+                const u32 HN = VP & D0;
+                const u32 HP = VN | ~(VP | D0);
+                X = D0 >> 1;
+                VN = X & HP;
+                VP = HN | ~(X | HP);
+                if (!(D0 & 1)) {
+                    ++err;
+                    if (err - last_high > k) return;            // cannot come back under k (Levenshtein_Cal.h:455)
+                }
+            }
+        }
+    }
+    // minimum over the last 2k+1 columns; later column wins ties, then the un-gapped diagonal
+    // (Levenshtein_Cal.h:511-563)
+    const int site_e = L - 1;
+    u32 best = 0xffffffffu;
+    int ret = -1;
+    if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e; }
+    int i = 0;
+    while (i < k) {
+        err += (int)((VP >> i) & 1); err -= (int)((VN >> i) & 1); ++i;
+        if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e + i; }
+    }
+    const u32 ungap = (u32)err;
+    while (i < last_high) {
+        err += (int)((VP >> i) & 1); err -= (int)((VN >> i) & 1); ++i;
+        if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e + i; }
+    }
+    if (ungap <= (u32)k && ungap == best) ret = site_e + k;
+    out_err = best; out_end = ret;
+}
+
 DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
 {
-    if (k <= 15) bpm_core<u32>(ix, rd, L, k, site, out_err, out_end);       // k is wave-uniform unless lengths are mixed
+    if (k <= 15) bpm_core32(ix, rd, L, k, site, out_err, out_end);          // k is wave-uniform unless lengths are mixed
     else bpm_core<u64>(ix, rd, L, k, site, out_err, out_end);
 }
 
