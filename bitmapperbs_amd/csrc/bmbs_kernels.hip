@@ -12,6 +12,7 @@
 //   k_finalize  one read per lane   MAPQ LUT, doubled -> chromosome coordinates, off-end, stats
 #include "bmbs_dev.h"
 #include "bmbs_sort.h"
+#include <type_traits>
 
 #define DEVI __device__ __forceinline__
 
@@ -1647,6 +1648,26 @@ DEVI void bpm_core32(const DevIndex& ix, const char* rd, int L, int k, u64 site,
     u32 VP = 0, VN = 0;
     int err = 0;
     const int last_high = 2 * k;
+    // one read character: CHECKED also tests the read's end and that the character is one of A, C, G, T
+    auto step = [&](u32 tc, int i, int i0, auto checked) {
+        const u32 lo = (u32)(loS >> (i - i0)) & bmask, hi = (u32)(hiS >> (i - i0)) & bmask;
+        const u32 xl = (tc == 'A' || tc == 'G') ? (lo ^ bmask) : lo;
+        const u32 xh = tc == 'G' ? hi : ~hi;
+        u32 eq = tc == 'T' ? lo : (xl & xh);
+        if (decltype(checked)::value) {
+            const u32 idx = tc ^ 0x40u;                                         // 'A' 1, 'C' 3, 'G' 7, 'T' 20
+            const u32 okc = idx < 32u ? (0x0010008au >> idx) & 1u : 0u;
+            eq &= 0u - okc;
+        }
+        u32 X = eq | VN;
+        const u32 D0 = ((VP + (X & VP)) ^ VP) | X;
+        const u32 HN = VP & D0;
+        const u32 HP = VN | ~(VP | D0);
+        X = D0 >> 1;
+        const u32 VN2 = X & HP, VP2 = HN | ~(X | HP);
+        if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
+        else { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); }
+    };
     for (int i0 = 0; i0 < L; i0 += 32) {
         if (i0) {
             u32 nl, nh;
@@ -1659,30 +1680,29 @@ DEVI void bpm_core32(const DevIndex& ix, const char* rd, int L, int k, u64 site,
             if (ib >= L) break;
             const uint4 v = *reinterpret_cast<const uint4*>(rd + ib);       // rows are 16-byte aligned and padded
             const u32 cw[4] = {v.x, v.y, v.z, v.w};
+            // a wave whose lanes all hold 16 characters of A/C/G/T inside their reads runs the unchecked steps.  The letter a
+            // byte would have to be, rebuilt from its bits 1-2 (A 00, C 01, G 11, T 10): 0x41 | bits 1-2, T: ^ 0x11
+            u32 bad = 0;
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int i = ib + c;
-                if (i >= L) break;
-                const u32 tc = (cw[c >> 2] >> (8 * (c & 3))) & 0xffu;
-                const u32 lo = (u32)(loS >> (i - i0)) & bmask, hi = (u32)(hiS >> (i - i0)) & bmask;
-                const u32 xl = (tc == 'A' || tc == 'G') ? (lo ^ bmask) : lo;
-                const u32 xh = tc == 'G' ? hi : ~hi;
-                u32 eq = tc == 'T' ? lo : (xl & xh);
-                if (!(tc == 'A' || tc == 'C' || tc == 'G' || tc == 'T')) eq = 0;
-                u32 X = eq | VN;
-                const u32 D0 = ((VP + (X & VP)) ^ VP) | X;
-                const u32 HN = VP & D0;
-                const u32 HP = VN | ~(VP | D0);
-                X = D0 >> 1;
-                VN = X & HP;
-                VP = HN | ~(X | HP);
-                if (!(D0 & 1)) {
-                    ++err;
-                    if (err - last_high > k) return;            // cannot come back under k (Levenshtein_Cal.h:455)
-                }
+            for (int q = 0; q < 4; q++) {
+                const u32 x = cw[q];
+                const u32 isT = (x >> 2) & ~(x >> 1) & 0x01010101u;
+                bad |= x ^ ((0x41414141u | (x & 0x06060606u)) ^ (isT * 0x11u));
             }
+            const bool plain = bad == 0 && ib + 16 <= L;
+            if (__all(plain)) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) step((cw[c >> 2] >> (8 * (c & 3))) & 0xffu, ib + c, i0, std::false_type());
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; c++) step((cw[c >> 2] >> (8 * (c & 3))) & 0xffu, ib + c, i0, std::true_type());
+            }
+            // a candidate that cannot come back under k (Levenshtein_Cal.h:455) ends with err = ~0 below whether or not it
+            // goes on; the wave stops once that is every lane
+            if (__all(err - last_high > k)) return;
         }
     }
+    if (err - last_high > k) return;
     // minimum over the last 2k+1 columns; later column wins ties, then the un-gapped diagonal
     // (Levenshtein_Cal.h:511-563)
     const int site_e = L - 1;
