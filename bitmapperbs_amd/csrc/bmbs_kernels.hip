@@ -177,46 +177,33 @@ DEVI u64 win16(const DevIndex& ix, u64 d)
 // 0x80 in every byte j of the result where read character j (byte j of rw, ASCII) does NOT match window base j
 // (2-bit code j of w16) under the bisulfite rule: equal letters match, and read 'T' matches window 'C'
 // (Schema.cpp:15212-15216; everything else, 'N' included, is a mismatch).
+// Four positions at a time in 32-bit registers: the four 2-bit codes become a byte selector, v_perm_b32 turns the selector into
+// the letters the read may show there -- the window letter itself, and 'T' where the window has 'C' -- and a position
+// mismatches when the read byte differs from both.
+template <u32 LUT1, u32 LUT2>
+DEVI u32 mism4(u32 rw, u32 w8)
+{
+    u32 sel = (w8 | (w8 << 12)) & 0x000f000fu;
+    sel = (sel | (sel << 6)) & 0x03030303u;
+    const u32 d1 = rw ^ __builtin_amdgcn_perm(0u, LUT1, sel);
+    const u32 d2 = rw ^ __builtin_amdgcn_perm(0u, LUT2, sel);
+    const u32 K7F = 0x7f7f7f7fu;
+    return (((d1 & K7F) + K7F) | d1) & (((d2 & K7F) + K7F) | d2) & 0x80808080u;      // byte != 0, both times
+}
 DEVI u64 mism8(u64 rw, u64 w16)
 {
-    const u64 K01 = 0x0101010101010101ull, K7F = 0x7f7f7f7f7f7f7f7full, K80 = 0x8080808080808080ull;
-    // spread the eight 2-bit codes into the low 2 bits of eight bytes
-    u64 x = w16;
-    x = (x | (x << 24)) & 0x000000ff000000ffull;
-    x = (x | (x << 12)) & 0x000f000f000f000full;
-    x = (x | (x << 6)) & 0x0303030303030303ull;
-    const u64 c0 = x & K01, c1 = (x >> 1) & K01, both = c0 & c1;
-    // A 0x41, C 0x43, G 0x47, T 0x54
-    const u64 ascii = 0x4040404040404040ull | (K01 ^ both) | ((c0 ^ c1) << 1) | (c1 << 2) | (both << 4);
-    const u64 diff = rw ^ ascii;
-    const u64 nz = (((diff & K7F) + K7F) | diff) & K80;                  // byte != 0
-    const u64 t = rw ^ 0x5454545454545454ull;
-    const u64 isT = ~(((t & K7F) + K7F) | t) & K80;                      // read byte == 'T'
-    const u64 winC = (c0 & ~c1) << 7;                                    // window base == 'C'
-    return nz & ~(isT & winC);
+    // "ACGT" and "ATGT"
+    return (u64)mism4<0x54474341u, 0x54475441u>((u32)rw, (u32)w16 & 0xffu) |
+           ((u64)mism4<0x54474341u, 0x54475441u>((u32)(rw >> 32), ((u32)w16 >> 8) & 0xffu) << 32);
 }
 
 // 0x80 in byte j where read character j does NOT equal window base j in the 3-letter (C->T) alphabet the FM index
 // is built over: A=A, G=G, {C,T}={C,T}; any other read character never matches (ctoi > 2, bwt.h:1894).
+// Same scheme: the read may show the window letter with C folded into T ("ATGT") or with T folded into C ("ACGC").
 DEVI u64 mism8_3letter(u64 rw, u64 w16)
 {
-    const u64 K01 = 0x0101010101010101ull, K7F = 0x7f7f7f7f7f7f7f7full, K80 = 0x8080808080808080ull;
-    u64 x = w16;
-    x = (x | (x << 24)) & 0x000000ff000000ffull;
-    x = (x | (x << 12)) & 0x000f000f000f000full;
-    x = (x | (x << 6)) & 0x0303030303030303ull;
-    const u64 c0 = x & K01, c1 = (x >> 1) & K01, both = c0 & c1;
-    // window letter with C folded into T: A 0x41, G 0x47, C/T 0x54
-    const u64 isCT = c0;                                   // codes 1 (C) and 3 (T) have bit 0 set
-    const u64 isG = c1 & ~c0;
-    const u64 wl = 0x4141414141414141ull ^ (isG * 0x06) ^ (isCT * 0x15);      // 0x41^0x47 = 0x06, 0x41^0x54 = 0x15
-    (void)both;
-    // read letter with C folded into T: bytes equal to 'C' (0x43) become 'T' (0x54): 0x43 ^ 0x54 = 0x17
-    const u64 t = rw ^ 0x4343434343434343ull;
-    const u64 isC = (~(((t & K7F) + K7F) | t) & K80) >> 7;               // 0x01 where read byte == 'C'
-    const u64 rl = rw ^ (isC * 0x17);
-    const u64 diff = rl ^ wl;
-    return (((diff & K7F) + K7F) | diff) & K80;
+    return (u64)mism4<0x54475441u, 0x43474341u>((u32)rw, (u32)w16 & 0xffu) |
+           ((u64)mism4<0x54475441u, 0x43474341u>((u32)(rw >> 32), ((u32)w16 >> 8) & 0xffu) << 32);
 }
 
 // sequential reader of the doubled 2-bit genome, 16 bases (32 bits) per step; two words are kept in registers and one
