@@ -76,8 +76,25 @@ void run(const uint4* tab, u64 entries, u64* out, long lanes, int steps, const c
     printf("%-28s table %6.0f MB  lanes %9ld  ILP %d  %2d B : %7.3f ms  %6.1f G accesses/s\n", label, entries * 16.0 / 1e6, lanes, ILP, BYTES, ms, acc / ms / 1e6);
 }
 
-int main()
+__global__ void k_fill(u32* p, u64 n) { for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = (u32)(i * 2654435761ull >> 7) ^ (u32)(i >> 13) * 40503u; }
+
+int main(int argc, char** argv)
 {
+    if (argc > 1) {
+        // `gather_bench big`: a table of the size of the 20-mer outcome table (2^31 x 16 B = 34 GB): does the reach of the TLBs show?
+        const u64 entries = 1ull << 31;
+        uint4* tab; u64* out;
+        if (hipMalloc(&tab, entries * 16) != hipSuccess) { printf("cannot allocate 34 GB\n"); return 1; }
+        k_fill<<<dim3(65536), dim3(256)>>>((u32*)tab, entries * 4);
+        hipDeviceSynchronize();
+        const long lanes = 1 << 22;
+        hipMalloc(&out, lanes * 8 * 4);
+        run<1, 16>(tab, entries, out, lanes, 32, "dependent chain");
+        run<1, 4>(tab, entries, out, lanes, 32, "dependent chain");
+        run<2, 16>(tab, entries, out, lanes, 32, "2 chains per lane");
+        run<1, 16>(tab, entries, out, lanes * 4, 16, "4x lanes");
+        return 0;
+    }
     for (u64 entries : {1ull << 22, 1ull << 25, 1ull << 28}) {         // 64 MB (fits Infinity Cache), 512 MB, 4 GB
         uint4* tab; u64* out;
         hipMalloc(&tab, entries * 16);
