@@ -152,6 +152,16 @@ struct ReadCur {
             buf >>= 8 * (p & 7);
         }
     }
+    // seek with the 16-byte piece that holds position p already in registers
+    DEVI void seek_with(const char* r, int p, int L, const uint4& v)
+    {
+        rd = r; pos = p; lim = L; buf = 0; hi = 0;
+        if (p < L) {
+            buf = ((u64)v.y << 32) | v.x; hi = ((u64)v.w << 32) | v.z;
+            if (p & 8) buf = hi;
+            buf >>= 8 * (p & 7);
+        }
+    }
     DEVI char next()
     {
         const char c = (char)(buf & 0xff);
@@ -505,11 +515,24 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     const int len = L - tm;
     out.hits = 0; out.sp = 0; out.ml = FIXED ? (u64)len : 0;
     if (len < (FIXED ? 17 : 18)) return false;
-    // key = sum code(read[tm+u]) * 3^u over the 16 characters read[tm .. tm+15], eight characters per load and step
-    // (rows are padded, so the unaligned 8-byte loads stay inside the buffer; characters >= L are never used)
+    // key = sum code(read[tm+u]) * 3^u over the 16 characters read[tm .. tm+15].  Every per-lane load is a request of its
+    // own to the memory pipeline whether it hits or not (tools/gather_bench.hip: a row load costs 3/4 of a random gather), so the
+    // 20 characters of the key and the cursor's first piece come from two aligned 16-byte loads (a third one when tm sits in
+    // the last quarter of its piece) instead of three unaligned loads plus the cursor's own.
+    const int a16 = tm & ~15, o = tm & 15;
+    const uint4 B0 = *reinterpret_cast<const uint4*>(rd + a16), B1 = *reinterpret_cast<const uint4*>(rd + a16 + 16);
+    uint4 B2 = make_uint4(0, 0, 0, 0);
+    if (o >= 12 && a16 + 32 < L) B2 = *reinterpret_cast<const uint4*>(rd + a16 + 32);
+    const u64 q0 = ((u64)B0.y << 32) | B0.x, q1 = ((u64)B0.w << 32) | B0.z, q2 = ((u64)B1.y << 32) | B1.x,
+              q3 = ((u64)B1.w << 32) | B1.z, q4 = ((u64)B2.y << 32) | B2.x;
+    const int sh8 = (o & 7) * 8;
+    auto funnel = [&](u64 lo, u64 hi) -> u64 { return sh8 ? (lo >> sh8) | (hi << (64 - sh8)) : lo; };
+    const bool up = o >= 8;
+    const u64 c0 = up ? q1 : q0, c1 = up ? q2 : q1, c2 = up ? q3 : q2, c3 = up ? q4 : q3;
+    const u64 w0 = funnel(c0, c1), w1 = funnel(c1, c2);          // read[tm .. tm+7], read[tm+8 .. tm+15]
     u64 d0, v0, d1, v1;
-    swar_code3(*reinterpret_cast<const u64*>(rd + tm), d0, v0);
-    swar_code3(*reinterpret_cast<const u64*>(rd + tm + 8), d1, v1);
+    swar_code3(w0, d0, v0);
+    swar_code3(w1, d1, v1);
     if ((v0 & v1) != 0x8080808080808080ull) return false;          // get_3_letter_hash_value returned -1 (bwt.h:309-332)
     const u64 key = (u64)base3_of4((u32)d0) + 81ull * base3_of4((u32)(d0 >> 32)) + 6561ull * base3_of4((u32)d1) +
                     531441ull * base3_of4((u32)(d1 >> 32));
@@ -517,7 +540,7 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     if (!FIXED && ix.t20 && len >= 20) {
         // the 16-mer lookup and the first four extensions in one table read
         u64 d2, v2;
-        swar_code3((u64)*reinterpret_cast<const u32*>(rd + tm + 16), d2, v2);
+        swar_code3(funnel(c2, c3) & 0xffffffffull, d2, v2);          // read[tm+16 .. tm+19]
         if ((v2 & 0x80808080ull) == 0x80808080ull) {
             const u64 v = ix.t20[key * T20_EXT + (u64)base3_of4((u32)d2)];
             const int tag = (int)(v >> 60);
@@ -529,7 +552,7 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
                 if (tag >= 5) { out.ml = (u64)(11 + tag); out.sp = row; out.hits = hits; return false; }
                 S.top = row; S.bot = row + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = 4;
                 if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
-                S.cur.seek(rd, tm + 20, L);
+                S.cur.seek_with(rd, tm + 20, L, o < 12 ? B1 : B2);
                 return true;
             }
         }
@@ -539,7 +562,7 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     n_hash++;
     if (S.bot <= S.top) return false;
     S.ptop = ~0ull; S.pbot = ~0ull; S.s = 0;
-    S.cur.seek(rd, tm + 16, L);
+    S.cur.seek_with(rd, tm + 16, L, B1);
     return true;
 }
 
