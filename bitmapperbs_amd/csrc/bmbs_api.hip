@@ -340,8 +340,17 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_d, sc.off_d, sc.list_d);
     prof_end(c);
     prof_begin(c, "k_seed_extra");
-    hipLaunchKernelGGL(k_seed_extra, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 4, target_waves,
-                       c->prm.seed_len, pe_mode, st, sc, cnt);
+    {
+        // the rows of a wave's 64 reads staged in LDS (k_seed_extra); rows too long for 64 KB stay in global memory
+        const size_t lds = 64 * (size_t)(stride + 16);
+        const int rows_in_lds = lds <= 48 * 1024 && !getenv("BMBS_EXTRA_NOLDS");
+        if (rows_in_lds)
+            hipLaunchKernelGGL(k_seed_extra<true>, dim3(chunks_min), dim3(64), lds, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 4,
+                               target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
+        else
+            hipLaunchKernelGGL(k_seed_extra<false>, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 4,
+                               target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
+    }
     prof_end(c);
     return BMBS_OK;
 }

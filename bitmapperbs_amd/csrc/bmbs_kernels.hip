@@ -980,6 +980,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
 }
 
 // ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
+template <bool ROWS_LDS>
 __global__ void __launch_bounds__(64)
 k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
              int seed_len, int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
@@ -994,7 +995,17 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
     LaneCounters lc = {0, 0, 0, 0};
     bool active = false, have = false;
     long r = 0;
-    const char* rd = seq;
+    // A lane keeps its read for all the remaining seeds (about eight), and every seed start reads the row at a new offset.
+    // Each such per-lane load is a request of its own to the memory pipeline (tools/gather_bench.hip), two thirds of all the
+    // requests of this kernel.  So the wave copies the rows of the lanes that take a new read into LDS, with 16-byte loads
+    // that run along the rows (about three cache lines per row instead of ~18 requests), and the searches read LDS
+    // (ROWS_LDS = false: rows too long for the LDS of a 64-lane block; the lanes then read global memory as before.  A
+    // template flag, so that the row pointer has one address space and the reads compile to ds_read, not to flat loads.)
+    extern __shared__ __align__(16) char lds_rows[];
+    __shared__ u32 take_row[64];
+    __shared__ u8 take_lane[64];
+    const int lstride = stride + 16;                  // 16-byte aligned rows, shifted against bank conflicts
+    const char* rd = ROWS_LDS ? lds_rows + (size_t)(threadIdx.x & 63) * lstride : seq;
     Search S; SeedHit h = {0, 0, 0};
     SeedRec* my = nullptr;
     int ns = 0, tm = 0, seed_id = 0, max_seed = 0;
@@ -1027,10 +1038,25 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
             const unsigned long long want = __ballot(pending && !have);
             const int rank = __popcll(want & ((1ull << (threadIdx.x & 63)) - 1));
             const long it = next + rank;
+            const long avail = chunk_end - next;
+            const int n_take = (long)__popcll(want) < avail ? __popcll(want) : (int)(avail > 0 ? avail : 0);
             next += __popcll(want);
+            if (ROWS_LDS && n_take > 0) {
+                // (source row, destination lane) of every taker, then the copy: lane t moves piece t % per_row of taker t / per_row
+                if (pending && !have && it < chunk_end) { take_row[rank] = sc.list_d[it]; take_lane[rank] = (u8)(threadIdx.x & 63); }
+                __syncthreads();
+                const int per_row = stride / 16, pieces = n_take * per_row;
+                for (int t = threadIdx.x & 63; t < pieces; t += 64) {
+                    const int w = t / per_row, cc = t - w * per_row;
+                    const uint4 v = *reinterpret_cast<const uint4*>(seq + (size_t)take_row[w] * stride + (size_t)cc * 16);
+                    *reinterpret_cast<uint4*>(lds_rows + (size_t)take_lane[w] * lstride + cc * 16) = v;
+                }
+                __syncthreads();
+            }
             if (pending && !have) {
                 if (it < chunk_end) {
-                    r = sc.list_d[it]; rd = seq + (size_t)r * stride; L = gm.rl(r);
+                    r = sc.list_d[it]; L = gm.rl(r);
+                    if (!ROWS_LDS) rd = seq + (size_t)r * stride;
                     my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
                     ns = st.n_seeds[r]; ncand = st.n_cand[r]; clen = sc.clen[r]; tm = sc.tm[r]; seed_id = sc.seed_id[r];
                     max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
