@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GATHER_CEILING_GREQ = 54.0   # measured on this chip: dependent divergent gathers/s (tools/gather_bench.hip, profiles/r01_gather_bench.txt)
+SECTOR_CEILING_GBS = 3100.0  # the same measurement in bytes: 48.4 G gathers/s over a 34 GB table x one 64-byte sector each
 
 
 def pmc_traffic(kernel):
@@ -55,6 +56,14 @@ def gather_roofline(kernel, cnt, kern_ms):
     return {"index_requests_per_launch": int(req), "achieved_Greq_s": round(ach, 2), "ceiling_Greq_s": GATHER_CEILING_GREQ,
             "frac": round(ach / GATHER_CEILING_GREQ, 4),
             "note": "counts index gathers only; read-character loads and result stores are further requests of the same kind"}
+
+
+def sector_roofline(kernel, kern_ms):
+    t = pmc_traffic(kernel)
+    if t is None or kern_ms.get(kernel, 0) <= 0:
+        return None
+    gbs = t / (kern_ms[kernel] * 1e-3) / 1e9
+    return {"traffic_GBps": round(gbs, 1), "random_sector_ceiling_GBps": SECTOR_CEILING_GBS, "frac": round(gbs / SECTOR_CEILING_GBS, 4)}
 
 
 def parse():
@@ -272,7 +281,10 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_dom), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4),
                          # the same kernel against the bound that really applies to an index walk: divergent gather requests/s
                          # (index lookups only: one per 16-mer table access, backward extension, SA read) vs the measured ceiling
-                         "gather": gather_roofline(dom, cnt, kern_ms)},
+                         "gather": gather_roofline(dom, cnt, kern_ms),
+                         # and in bytes: the HBM-side traffic of the committed PMC pass over the live launch time, against
+                         # what the chip delivers when every 64-byte sector is a random access of its own
+                         "sectors": sector_roofline(dom, kern_ms)},
             "kernels_ms_per_step": {a: round(b, 4) for a, b in kern_ms.items()},
             "kernels_algorithmic_GBps": rl_all,
             "counters_per_step": cnt,

@@ -100,7 +100,7 @@ void prof_begin(bmbs_ctx* c, const char* name)
 void prof_end(bmbs_ctx* c) { (void)hipEventRecord(c->prof[c->n_prof_used].b, c->stream); c->n_prof_used++; }
 
 // exclusive scan u32[n] -> u64[n+1], total left in c->totals[slot]
-int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot)
+int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot, u32* list = nullptr)
 {
     const u64 per = (u64)SCAN_BLOCK * SCAN_ITEMS;
     const u64 nb = (n + per - 1) / per;
@@ -108,7 +108,7 @@ int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot)
     u64* bs = c->scan_tmp.as<u64>();
     hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bs, nb, c->totals.as<u64>() + slot);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list);
     return BMBS_OK;
 }
 
@@ -256,10 +256,8 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
                        c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
     prof_end(c);
     prof_begin(c, "scan_sw");
-    int rc = scan_u32(c, c->need_sw.as<u32>(), n_jobs, c->sw_off.as<u64>(), 2);
+    int rc = scan_u32(c, c->need_sw.as<u32>(), n_jobs, c->sw_off.as<u64>(), 2, c->sw_job.as<u32>());
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sw_list, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, n_jobs, c->need_sw.as<u32>(), c->sw_off.as<u64>(),
-                       c->sw_job.as<u32>());
     prof_end(c);
     prof_begin(c, "k_align_sw");
     // the band loop is unrolled for KB: a tighter bound wastes fewer masked cells (k = 6 in a KB = 8 kernel idles 4 of 17)
@@ -326,18 +324,16 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
                            c->prm.seed_len, pe_mode, st, sc, cnt);
     prof_end(c);
     prof_begin(c, "list_second");
-    int rc = scan_u32(c, sc.flag_c, n, sc.off_c, 3);
+    int rc = scan_u32(c, sc.flag_c, n, sc.off_c, 3, sc.list_c);          // scan + list in one pass
     if (rc) return rc;
-    hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_c, sc.off_c, sc.list_c);
     prof_end(c);
     prof_begin(c, "k_seed_second");
     hipLaunchKernelGGL(k_seed_second, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode,
                        st, sc, cnt);
     prof_end(c);
     prof_begin(c, "list_extra");
-    rc = scan_u32(c, sc.flag_d, n, sc.off_d, 4);
+    rc = scan_u32(c, sc.flag_d, n, sc.off_d, 4, sc.list_d);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, sc.flag_d, sc.off_d, sc.list_d);
     prof_end(c);
     prof_begin(c, "k_seed_extra");
     {
@@ -394,10 +390,8 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
         prof_end(c);
         // reads with more than 16 candidates (repeats): one block per read
         prof_begin(c, "k_vote_long");
-        int rl = scan_u32(c, c->long_flag.as<u32>(), n, c->long_off.as<u64>(), 9);
+        int rl = scan_u32(c, c->long_flag.as<u32>(), n, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
         if (rl) return rl;
-        hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, c->long_flag.as<u32>(), c->long_off.as<u64>(),
-                           c->long_list.as<u32>());
         hipLaunchKernelGGL((k_vote_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
                            c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
         hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
@@ -766,10 +760,8 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
                        c->slot_read.as<u32>(), c->long_flag.as<u32>());
     prof_end(c);
     prof_begin(c, "k_vote_pe_long");
-    rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9);
+    rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
     if (rc) return rc;
-    hipLaunchKernelGGL(k_flag_list, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, c->long_flag.as<u32>(), c->long_off.as<u64>(),
-                       c->long_list.as<u32>());
     hipLaunchKernelGGL((k_vote_pe_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 9, c->long_list.as<u32>(), A);
     hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
@@ -824,9 +816,8 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         u32* rcnt = c->pe_rcnt.as<u32>();
         u64* n_reseed = c->totals.as<u64>() + 7;
         hipLaunchKernelGGL(k_pes_reseed_flag, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, ps, rflag);
-        rc = scan_u32(c, rflag, n, c->pe_rscan.as<u64>(), 7);
+        rc = scan_u32(c, rflag, n, c->pe_rscan.as<u64>(), 7, rlist);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_flag_list, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, rflag, c->pe_rscan.as<u64>(), rlist);
         HIPCHK(c, hipMemsetAsync(rcnt, 0, n * 4, c->stream));
         hipLaunchKernelGGL(k_pes_reseed, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, gm, stride, (long)n, n_reseed, rlist, st, ps,
                            rcnt, cnt);

@@ -444,7 +444,9 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(u64* block_sums, u64 nb, u
     for (u64 i = a; i < b; i++) { const u64 v = block_sums[i]; block_sums[i] = run; run += v; }
     if (threadIdx.x == 0) *total = tot;
 }
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out)
+// list != nullptr: `in` holds 0/1 flags and the positions of the ones are written, in order, to list[]; the offsets
+// themselves are not stored (the work lists of the seeding stages need nothing else)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out, u32* list)
 {
     __shared__ u64 sh[SCAN_BLOCK / 64];
     const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
@@ -456,6 +458,11 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n,
     u64 tot;
     const u64 incl = block_scan_incl(s, sh, tot);
     u64 run = incl - s + block_sums[blockIdx.x];
+    if (list) {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n && x[j]) { list[run] = (u32)(base + j); run += x[j]; }
+        return;
+    }
     if (base + SCAN_ITEMS <= n) {
         u64 o[SCAN_ITEMS];
 #pragma unroll
@@ -852,13 +859,6 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
         __syncthreads();
         if (threadIdx.x == 0) { unsigned long long* cs = SHARD(counters); atomicAdd(&cs[2], (unsigned long long)shc[0]); atomicAdd(&cs[5], (unsigned long long)shc[1]); }
     }
-}
-
-__global__ void k_flag_list(long n, const u32* __restrict__ flag, const u64* __restrict__ off, u32* __restrict__ list)
-{
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (flag[r]) list[off[r]] = (u32)r;
 }
 
 // ---- second seed of the 1-mismatch reads + fast exit C (Schema.cpp:24734-24801, 24894-24898) -----
@@ -1950,13 +1950,6 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
     }
     if (ok) { a_start[jb] = start; a_end[jb] = end_site; a_nm[jb] = err_in; a_score[jb] = score; a_nops[jb] = 0; }
     else { need_sw[jb] = 1; if (counters) atomicAdd(&SHARD(counters)[4], 1ull); }
-}
-
-__global__ void k_sw_list(u64 n_jobs, const u32* __restrict__ need_sw, const u64* __restrict__ sw_off, u32* __restrict__ sw_job)
-{
-    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (jb >= n_jobs) return;
-    if (need_sw[jb]) sw_job[sw_off[jb]] = (u32)jb;
 }
 
 template <int KB>
