@@ -252,7 +252,8 @@ def main():
             return 10 * c["n_hash"] + 80 * c["n_ext"] + 16 * c["n_hash"] + c["n_ext"] + 16 * c["n_hash"]
         alg = {
             "k_seed_first": seed_bytes(cnt["k_seed_first"]) + 14 * nr,
-            "k_seed_decide": (L + 14 + 40) * nr + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1 + L) * cnt["n_ungapped"],
+            # every read row once (staged through LDS), carry-in + verdict records, one SA word and one window per verified read
+            "k_seed_decide": (L + 14 + 40) * nr + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1) * cnt["n_ungapped"],
             "k_seed_second": seed_bytes(cnt["k_seed_second"]) + 4 * cnt["k_seed_second"]["n_sa"] + 24 * cnt["k_seed_second"]["n_hash"],
             "k_seed_extra": seed_bytes(cnt["k_seed_extra"]),
             "k_locate": (4 + 8) * cnt["n_cand_slots"],
