@@ -228,11 +228,11 @@ ReadState read_state(bmbs_ctx* c)
 }
 
 template <int KB>
-void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
-               u32 rev_from, u32* d_cigar_pool, int max_ops)
+void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
+               const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops)
 {
     hipLaunchKernelGGL(k_align_sw<KB>, dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                       d_qual, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
+                       d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                        n_jobs, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>());
 }
@@ -240,7 +240,7 @@ void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeo
 // K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the
 // register-band DP kernel instantiated for the smallest KB >= k.  No host round-trip inside.
 int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
-              u32 rev_from, u32* d_cigar_pool, int max_ops)
+              u32 rev_from, u32* d_cigar_pool, int max_ops, const char* d_qual2 = nullptr)
 {
     const int L = gm.L, k = gm.k;              // the longest read and the largest threshold size the workspace
     const u64 nj = n_jobs ? n_jobs : 1;
@@ -252,7 +252,7 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     prof_begin(c, "k_align_ungapped");
     hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                       d_qual, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                       d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
     prof_end(c);
     prof_begin(c, "scan_sw");
@@ -261,16 +261,16 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     prof_end(c);
     prof_begin(c, "k_align_sw");
     // the band loop is unrolled for KB: a tighter bound wastes fewer masked cells (k = 6 in a KB = 8 kernel idles 4 of 17)
-    if (k <= 2) launch_sw<2>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 6) launch_sw<6>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 10) launch_sw<10>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else launch_sw<31>(c, d_seq, d_qual, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    if (k <= 2) launch_sw<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 6) launch_sw<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 10) launch_sw<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    else launch_sw<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
     prof_end(c);
     return BMBS_OK;
 }
@@ -715,16 +715,17 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     const int k = gm.k;
     rc = per_read_workspace(c, n2);
     if (rc) return rc;
-    ENS(c, c->pe_seq, n2 * (u64)stride + 64); ENS(c, c->pe_qual, n2 * (u64)stride + 64);
+    ENS(c, c->pe_seq, n2 * (u64)stride + 64);
     ENS(c, c->pe_occ, n2 * 4); ENS(c, c->pe_len, n2 * 4); ENS(c, c->pe_cur, n2); ENS(c, c->pe_vround, n2);
     ENS(c, c->pe_dead, n); ENS(c, c->pe_both, n); ENS(c, c->pe_npair, n * 4); ENS(c, c->pe_sbd, n * 4);
     HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
     char* seq_all = c->pe_seq.as<char>();
-    char* qual_all = c->pe_qual.as<char>();
+    // the qualities are read where the caller put them (qual_row): mate 1 rows in d_qual1, mate 2 rows in d_qual2
+    const char* qual_1 = reinterpret_cast<const char*>(d_qual1);
+    const char* qual_2 = reinterpret_cast<const char*>(d_qual2);
     prof_begin(c, "k_pe_prepare");
     hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * (stride / 16), 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
-                       reinterpret_cast<const char*>(d_qual1), reinterpret_cast<const char*>(d_seq2),
-                       reinterpret_cast<const char*>(d_qual2), gm, stride, (long)n, seq_all, qual_all);
+                       reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all);
     prof_end(c);
     ReadState st = read_state(c);
     PeState ps;
@@ -866,11 +867,11 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         }
         Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
         // mate 2 rows (>= n) carry FASTQ-order qualities for a reverse-complemented read: need_reverse_quality = 1
-        rc = run_align(c, seq_all, qual_all, gm, stride, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
+        rc = run_align(c, seq_all, qual_1, gm, stride, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops, qual_2);
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize_pe");
-    hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), seq_all, qual_all, stride,
+    hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), seq_all, qual_1, qual_2, stride,
                        c->mapq_lut.as<u8>(), c->mapq_off.as<u32>(), c->mapq_unit, gm,
                        c->prm.min_ins, c->prm.max_ins, c->prm.ambiguous_out, (long)n, st, ps, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                        c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, reinterpret_cast<bmbs_result_dev*>(d_results),

@@ -1892,9 +1892,16 @@ __global__ void k_job_list(long n, ReadState st, u32* __restrict__ job_read, u64
 // reads slot b and writes slot b-1 (the band slides one column per row), and the only memory traffic
 // of the DP is one packed trace word (4 bits per cell) per 16 cells per row, interleaved by job.
 
+// quality row of read r.  Paired-end calls hand over the caller's two buffers as they are (qual: mate 1, qual2: mate 2 of pair
+// r - rev_qual_from) instead of copying 2 x n rows into one: the alignment kernels touch the qualities of a few reads only.
+DEVI const char* qual_row(const char* qual, const char* qual2, u32 rev_qual_from, u32 r, int stride)
+{
+    return (qual2 && r >= rev_qual_from) ? qual2 + (size_t)(r - rev_qual_from) * stride : qual + (size_t)r * stride;
+}
+
 __global__ void __launch_bounds__(256)
 k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
-                 const char* __restrict__ qual, ReadGeom gm, int stride, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
+                 const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
                  int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
                  int* __restrict__ a_nops, u32* __restrict__ need_sw, unsigned long long* __restrict__ counters)
 {
@@ -1911,7 +1918,7 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
         return;
     }
     const char* rd = seq + (size_t)r * stride;
-    const char* ql = qual + (size_t)r * stride;
+    const char* ql = qual_row(qual, qual2, rev_qual_from, r, stride);
     const bool rev = r >= rev_qual_from;
     const int p_len = L + 2 * k;
     const bool wvalid = window_valid(ix, site, (u64)p_len, site < ix.G);
@@ -1955,7 +1962,7 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
 template <int KB>
 __global__ void __launch_bounds__(64)
 k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
-           const char* __restrict__ qual, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
+           const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
            const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride,
            u32* __restrict__ cigar_pool, int max_ops,
            int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
@@ -1969,7 +1976,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     const u32 r = jb_.read[jb];
     const u64 site = jb_.site[jb];
     const char* rd = seq + (size_t)r * stride;
-    const char* ql = qual + (size_t)r * stride;
+    const char* ql = qual_row(qual, qual2, rev_qual_from, r, stride);
     const bool rev = r >= rev_qual_from;
     const bool fwd = site < ix.G;
     const int L = gm.rl(r), k = gm.rk(L);          // k <= KB: the unrolled band is masked to the job's own width
@@ -2291,8 +2298,7 @@ struct PeState {
 
 // mate 2: reverse complement of the FASTQ read (rc_table, Process_Reads.cpp:1603-1613: identity for non-ACGT)
 __global__ void __launch_bounds__(256)
-k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const char* __restrict__ s2raw,
-             const char* __restrict__ q2, ReadGeom gm, int stride, long n, char* __restrict__ seq_all, char* __restrict__ qual_all)
+k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all)
 {
     // one 16-byte piece per thread (rows are 16-byte aligned, stride % 16 == 0)
     const long i16 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2303,9 +2309,7 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ q1, const cha
     const long r = i / stride;
     const int j0 = (int)(i - r * stride);
     const int L = gm.rl(n + r);                    // mate 2 of pair r
-    reinterpret_cast<uint4*>(seq_all)[i16] = reinterpret_cast<const uint4*>(s1)[i16];
-    reinterpret_cast<uint4*>(qual_all)[i16] = reinterpret_cast<const uint4*>(q1)[i16];
-    reinterpret_cast<uint4*>(qual_all + total)[i16] = reinterpret_cast<const uint4*>(q2)[i16];
+    reinterpret_cast<uint4*>(seq_all)[i16] = reinterpret_cast<const uint4*>(s1)[i16];          // the qualities stay where they are (qual_row)
     // out[j] = complement(in[L-1-j]) for j < L, 0 beyond: one reversed 16-byte piece per thread.  complement = c ^ 0x15 for
     // A/T, c ^ 0x04 for C/G, identity otherwise (rc_table), eight characters per step.
     auto comp8 = [](u64 w) -> u64 {
@@ -2911,6 +2915,7 @@ k_pe_pair(DevIndex ix, long n, ReadGeom gm, PeIns pi, int ambiguous_out, ReadSta
 // 9188), TLEN (Schema.h:1587), insert/chromosome-end checks, MAPQ over k1+k2, flags 99/83/147/163, stats
 __global__ void __launch_bounds__(256)
 k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq, const char* __restrict__ qual,
+              const char* __restrict__ qual2,
               int stride, const u8* __restrict__ mapq_lut, const u32* __restrict__ mapq_off, int unit, ReadGeom gm, int min_ins, int max_ins,
               int ambiguous_out, long n,
               ReadState st, PeState ps, const int* __restrict__ a_start, const int* __restrict__ a_end,
@@ -2954,7 +2959,7 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
                         const char a = seq[(size_t)r * stride + ms];
                         const int qi = m == 1 ? Lm - 1 - ms : ms;
                         nm[m] = 1;
-                        score[m] = a == 'N' ? -sp.np : -pen_lut[(unsigned char)qual[(size_t)r * stride + qi]];
+                        score[m] = a == 'N' ? -sp.np : -pen_lut[(unsigned char)qual_row(qual, qual2, (u32)n, (u32)r, stride)[qi]];
                     }
                 }
                 u64 loc = site;

@@ -155,7 +155,8 @@ int bmbs_map_se(bmbs_ctx*, const char* seq, const char* qual, int32_t L, int32_t
                 int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
                 int64_t* n_cigar_used);
 /* device-resident variant: d_seq/d_qual/d_results/d_cigar_pool are device addresses (e.g. from
- * torch tensors); nothing crosses PCIe; asynchronous on the ctx stream until bmbs_sync().          */
+ * torch tensors); nothing crosses PCIe; asynchronous on the ctx stream until bmbs_sync(): the input
+ * buffers are read throughout the call (also by the paired-end variants) and have to stay untouched until then. */
 int bmbs_map_se_device(bmbs_ctx*, uint64_t d_seq, uint64_t d_qual, int32_t L, int32_t stride,
                        int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap);
 int bmbs_sync(bmbs_ctx*);
