@@ -47,7 +47,7 @@ struct bmbs_ctx {
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d, in_len;
     // paired-end workspace
     DevBuf sd_sp0, sd_hits0, sd_ml0, sd_tm, sd_seed_id, sd_clen, sd_first_ml, sd_flag_c, sd_flag_d, sd_off_c, sd_off_d, sd_list_c, sd_list_d;
-    DevBuf pe_seq, pe_qual, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
+    DevBuf pe_seq, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
     DevBuf pe_first, pe_full, pe_R, pe_roff, pe_rflag, pe_rscan, pe_rlist, pe_rcnt, pe_ritem_off, pe_rcand;     // --sensitive
     u64 last_reseeded = 0, last_reseed_cand = 0;
     DevBuf stats, counters, long_flag, long_off, long_list;     // long_*: reads whose candidate lists go to k_vote_long
@@ -453,7 +453,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
                      &c->job_read, &c->job_site, &c->job_end, &c->job_err, &c->need_sw, &c->sw_off, &c->sw_job, &c->trace, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
-                     &c->stats, &c->counters, &c->pe_seq, &c->pe_qual, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
+                     &c->stats, &c->counters, &c->pe_seq, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
                      &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list};

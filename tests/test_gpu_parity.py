@@ -546,3 +546,17 @@ def test_vote_order_kernels_give_std_sort_permutation(form, env, tmp_path):
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, "first difference in list %d (length %d)" % (np.searchsorted(seg, bad[0], "right") - 1,
                                                                         lists[np.searchsorted(seg, bad[0], "right") - 1].size)
+
+
+@pytest.mark.gpu
+def test_seed_extra_without_lds_rows_matches_oracle(env, monkeypatch):
+    """k_seed_extra<false>: the form for reads too long to stage 64 rows in LDS (forced here with BMBS_EXTRA_NOLDS=1)"""
+    from bitmapperbs_amd import synth, mapper
+    monkeypatch.setenv("BMBS_EXTRA_NOLDS", "1")
+    r = synth.make_reads_se(env["chroms"], n=20000, L=150, seed=77, sub=0.04, indel=0.003, qual="random", n_rate=0.003)
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    res, pool = m.map_se(r["seq"], r["qual"], 150)
+    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 150)
+    assert not compare_records(res, pool, recs, 150)
+    assert (m.stats() == ost).all()
+    m.close()
