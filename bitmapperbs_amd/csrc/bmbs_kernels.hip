@@ -292,7 +292,9 @@ __global__ void k_repack_hash(RefIndexDev R, u64 n, u64* out)
 // entry = row (36 bits) | hits (24 bits) << 36 | tag << 60.  With I16 the interval of the 16-mer and c16..c19 the next four
 // letters, count_backward_as_much_1_terminate does, for s = 0, 1, ...: stop if |I| == 1 (match length 16+s, 1 hit);
 // extend by c(16+s); stop if that is empty (match length 16+s, hits of the interval before).  Tags:
-//   1..4  stopped unique before consuming c16 / c17 / c18 / c19      (row = that single row, match length 15 + tag)
+//   1..4  stopped unique before consuming c16 / c17 / c18 / c19      (match length 15 + tag; the field holds SA[row], the TEXT
+//         POSITION of that single row: whoever gets a unique seed needs nothing else from the row, and the suffix-array
+//         gather -- one 64-byte sector for 4 bytes, per read -- is paid once, here, instead of per lookup)
 //   5..8  stopped because c16 / c17 / c18 / c19 does not occur       (row, hits = interval before, match length 11 + tag)
 //   0     all four letters consumed: row, hits = depth-20 interval (the caller carries on with s = 4)
 //   15    the 16-mer itself does not occur;   14  hits do not fit 24 bits: use the 16-mer path
@@ -312,26 +314,26 @@ k_build_t20(DevIndex ix, u64 n_keys, u64* __restrict__ t20)
     for (int d0 = 0; d0 < 3; d0++) {
         u64 v0 = 0, t1 = t0, b1 = b0;
         bool s0 = true;
-        if (b0 - t0 == 1) v0 = t20_entry(t0, 1, 1);
+        if (b0 - t0 == 1) v0 = t20_entry(sa_at(ix, t0), 1, 1);
         else { lf_pair(ix, t1, b1, d0); if (b1 <= t1) v0 = t20_entry(t0, b0 - t0, 5); else s0 = false; }
         for (int d1 = 0; d1 < 3; d1++) {
             u64 v1 = v0, t2 = t1, b2 = b1;
             bool s1 = s0;
             if (!s1) {
-                if (b1 - t1 == 1) { v1 = t20_entry(t1, 1, 2); s1 = true; }
+                if (b1 - t1 == 1) { v1 = t20_entry(sa_at(ix, t1), 1, 2); s1 = true; }
                 else { lf_pair(ix, t2, b2, d1); if (b2 <= t2) { v1 = t20_entry(t1, b1 - t1, 6); s1 = true; } }
             }
             for (int d2 = 0; d2 < 3; d2++) {
                 u64 v2 = v1, t3 = t2, b3 = b2;
                 bool s2 = s1;
                 if (!s2) {
-                    if (b2 - t2 == 1) { v2 = t20_entry(t2, 1, 3); s2 = true; }
+                    if (b2 - t2 == 1) { v2 = t20_entry(sa_at(ix, t2), 1, 3); s2 = true; }
                     else { lf_pair(ix, t3, b3, d2); if (b3 <= t3) { v2 = t20_entry(t2, b2 - t2, 7); s2 = true; } }
                 }
                 for (int d3 = 0; d3 < 3; d3++) {
                     u64 v3 = v2;
                     if (!s2) {
-                        if (b3 - t3 == 1) v3 = t20_entry(t3, 1, 4);
+                        if (b3 - t3 == 1) v3 = t20_entry(sa_at(ix, t3), 1, 4);
                         else {
                             u64 t4 = t3, b4 = b3;
                             lf_pair(ix, t4, b4, d3);
@@ -555,7 +557,7 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
                 n_hash++;
                 const u64 row = v & ((1ull << 36) - 1), hits = (v >> 36) & ((1ull << 24) - 1);
                 if (tag == 15) return false;                                           // hits 0, match length 0
-                if (tag >= 1 && tag <= 4) { out.ml = (u64)(15 + tag); out.sp = row; out.hits = 1; return false; }
+                if (tag >= 1 && tag <= 4) { out.ml = (u64)(15 + tag); out.sp = row | (1ull << 63); out.hits = 1; return false; }     // located (bit 63): text position
                 if (tag >= 5) { out.ml = (u64)(11 + tag); out.sp = row; out.hits = hits; return false; }
                 S.top = row; S.bot = row + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = 4;
                 if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
@@ -762,8 +764,9 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             first_ml = ml;
             if (hits == 1) {
                 // try_process_unique_mismatch_end_to_end (Schema.cpp:15164-15282)
-                const u64 p = sa_at(ix, sp);
-                n_sa++;
+                u64 p;
+                if (sp >> 63) p = sp & ~(1ull << 63);          // the 20-mer table had the text position
+                else { p = sa_at(ix, sp); n_sa++; }
                 const u64 loc = ix.total - p - ml;
                 seed_record(my, ns, ncand, sp, 1, ml, 0);
                 c0 = loc; clen = 1;
@@ -2828,7 +2831,7 @@ k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ c
     long o = 0;
     for (int s = 0; s < ns; s++) {
         const u64 sp = my[s].sp, adj = (u64)my[s].len + (u64)my[s].off;
-        for (u32 j = 0; j < my[s].hits; j++) c[o++] = ix.total - sa_at(ix, sp + j) - adj;
+        for (u32 j = 0; j < my[s].hits; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;
     }
     sort_u64_asc(c, nc);
     const PeCand* a = pe_list(ps, st, A, B, rF);
