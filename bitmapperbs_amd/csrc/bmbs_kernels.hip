@@ -297,6 +297,8 @@ __global__ void k_repack_hash(RefIndexDev R, u64 n, u64* out)
 //         gather -- one 64-byte sector for 4 bytes, per read -- is paid once, here, instead of per lookup)
 //   5..8  stopped because c16 / c17 / c18 / c19 does not occur       (row, hits = interval before, match length 11 + tag)
 //   0     all four letters consumed: row, hits = depth-20 interval (the caller carries on with s = 4)
+//   9     all four letters consumed and the depth-20 interval is one row: the next iteration would stop there (match length 20,
+//         1 hit); the field holds the text position, as for tags 1..4
 //   15    the 16-mer itself does not occur;   14  hits do not fit 24 bits: use the 16-mer path
 #define T20_EXT 81
 DEVI u64 t20_entry(u64 row, u64 hits, int tag) { return hits >= (1ull << 24) ? (14ull << 60) : (row | (hits << 36) | ((u64)tag << 60)); }
@@ -337,7 +339,7 @@ k_build_t20(DevIndex ix, u64 n_keys, u64* __restrict__ t20)
                         else {
                             u64 t4 = t3, b4 = b3;
                             lf_pair(ix, t4, b4, d3);
-                            v3 = b4 <= t4 ? t20_entry(t3, b3 - t3, 8) : t20_entry(t4, b4 - t4, 0);
+                            v3 = b4 <= t4 ? t20_entry(t3, b3 - t3, 8) : b4 - t4 == 1 ? t20_entry(sa_at(ix, t4), 1, 9) : t20_entry(t4, b4 - t4, 0);
                         }
                     }
                     o[d0 + 3 * d1 + 9 * d2 + 27 * d3] = v3;
@@ -558,6 +560,7 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
                 const u64 row = v & ((1ull << 36) - 1), hits = (v >> 36) & ((1ull << 24) - 1);
                 if (tag == 15) return false;                                           // hits 0, match length 0
                 if (tag >= 1 && tag <= 4) { out.ml = (u64)(15 + tag); out.sp = row | (1ull << 63); out.hits = 1; return false; }     // located (bit 63): text position
+                if (tag == 9) { out.ml = 20; out.sp = row | (1ull << 63); out.hits = 1; return false; }
                 if (tag >= 5) { out.ml = (u64)(11 + tag); out.sp = row; out.hits = hits; return false; }
                 S.top = row; S.bot = row + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = 4;
                 if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
