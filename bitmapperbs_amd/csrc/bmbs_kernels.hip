@@ -520,7 +520,9 @@ DEVI void swar_code3(u64 w, u64& digits, u64& valid)
 DEVI u32 base3_of4(u32 x) { return (x * 0x0103091Bu) >> 24; }
 
 // returns true when the search has to be stepped; false when it is already decided (out filled)
-template <bool FIXED>
+// LOCATED (with FIXED): the caller finishes single-row intervals against the genome and takes them with the text position
+// in S.top (bit 63 set) -- k_seed_second; without it the full-length search does not touch the 20-mer table.
+template <bool FIXED, bool LOCATED = false>
 DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search& S, SeedHit& out, u32& n_hash)
 {
     const int len = L - tm;
@@ -548,7 +550,7 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     const u64 key = (u64)base3_of4((u32)d0) + 81ull * base3_of4((u32)(d0 >> 32)) + 6561ull * base3_of4((u32)d1) +
                     531441ull * base3_of4((u32)(d1 >> 32));
     S.steps = len - 16; S.tm = tm;
-    if (!FIXED && ix.t20 && len >= 20) {
+    if ((!FIXED || LOCATED) && ix.t20 && len >= 20) {
         // the 16-mer lookup and the first four extensions in one table read
         u64 d2, v2;
         swar_code3(funnel(c2, c3) & 0xffffffffull, d2, v2);          // read[tm+16 .. tm+19]
@@ -559,9 +561,19 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
                 n_hash++;
                 const u64 row = v & ((1ull << 36) - 1), hits = (v >> 36) & ((1ull << 24) - 1);
                 if (tag == 15) return false;                                           // hits 0, match length 0
-                if (tag >= 1 && tag <= 4) { out.ml = (u64)(15 + tag); out.sp = row | (1ull << 63); out.hits = 1; return false; }     // located (bit 63): text position
-                if (tag == 9) { out.ml = 20; out.sp = row | (1ull << 63); out.hits = 1; return false; }
-                if (tag >= 5) { out.ml = (u64)(11 + tag); out.sp = row; out.hits = hits; return false; }
+                if (FIXED) {
+                    // count_hash_table goes through the whole pattern: a missing letter is 0 hits; a single row carries on --
+                    // the caller finishes it against the genome (k_seed_second), from the text position the table holds
+                    if (tag >= 5 && tag <= 8) return false;
+                    if (tag != 0) {
+                        S.top = row | (1ull << 63); S.bot = S.top + 1; S.ptop = ~0ull; S.pbot = ~0ull; S.s = tag == 9 ? 4 : tag - 1;
+                        return true;
+                    }
+                } else {
+                    if (tag >= 1 && tag <= 4) { out.ml = (u64)(15 + tag); out.sp = row | (1ull << 63); out.hits = 1; return false; }     // located (bit 63): text position
+                    if (tag == 9) { out.ml = 20; out.sp = row | (1ull << 63); out.hits = 1; return false; }
+                    if (tag >= 5) { out.ml = (u64)(11 + tag); out.sp = row; out.hits = hits; return false; }
+                }
                 S.top = row; S.bot = row + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = 4;
                 if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
                 S.cur.seek_with(rd, tm + 20, L, o < 12 ? B1 : B2);
@@ -902,8 +914,9 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             // Occ gather per character (count_hash_table, bwt.h:1889-1933) locate the row once and compare the
             // rest of the read with the doubled genome in the index alphabet (C folded into T), 8 bases a step.
             verify = false;
-            const u64 p = sa_at(ix, S.top);
-            lc.n_sa++;
+            u64 p;
+            if (S.top >> 63) p = S.top & ~(1ull << 63);            // the 20-mer table had the text position
+            else { p = sa_at(ix, S.top); lc.n_sa++; }
             const int done_chars = 16 + S.s;                       // read[tm, tm+done_chars) is matched at text position p
             const int tm = S.tm;
             const u64 site = ix.total - p - (u64)done_chars;       // doubled coordinate of read[tm]
@@ -964,7 +977,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
                 if (have) { finish(); have = false; }
                 if (it < chunk_end) {
                     r = sc.list_c[it]; rd = seq + (size_t)r * stride; have = true; L = gm.rl(r);
-                    if (search_begin<true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) {
+                    if (search_begin<true, true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) {
                         if (S.bot - S.top == 1) verify = true;          // already a single row: stays pending, verified next batch
                         else { active = true; pending = false; }
                     }
