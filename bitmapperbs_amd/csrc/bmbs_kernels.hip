@@ -1978,7 +1978,9 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
     else { need_sw[jb] = 1; if (counters) atomicAdd(&SHARD(counters)[4], 1ull); }
 }
 
-template <int KB>
+// UNIFORM: all reads of the launch have one length, so k is a kernel argument (a scalar register) and the band tests of the
+// unrolled loop are scalar branches; with per-read lengths they are per-lane and cost an exec-mask save/restore per cell.
+template <int KB, bool UNIFORM>
 __global__ void __launch_bounds__(64)
 k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
            const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
@@ -1998,7 +2000,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     const char* ql = qual_row(qual, qual2, rev_qual_from, r, stride);
     const bool rev = r >= rev_qual_from;
     const bool fwd = site < ix.G;
-    const int L = gm.rl(r), k = gm.rk(L);          // k <= KB: the unrolled band is masked to the job's own width
+    const int L = UNIFORM ? gm.L : gm.rl(r), k = UNIFORM ? gm.k : gm.rk(L);          // k <= KB: the unrolled band is masked to the job's own width
     const int band = 2 * k + 1;
     const int p_len = L + 2 * k, tlen = L;
     const bool wvalid = window_valid(ix, site, (u64)p_len, fwd);
