@@ -41,6 +41,7 @@ struct bmbs_ctx {
     DevBuf verdict, n_seeds, multi, mm_site, exit_site, seeds, n_cand, cand_off, n_votes, best_site,
         best_end, best_err, sbd, red_status, job_flag, job_off, scan_tmp, totals;
     // per-candidate / per-job workspace
+    DevBuf vote_list;
     DevBuf cand, votes, slot_read, vote_off, votes_dense, dense_read, ferr, fend, job_read, job_site, job_end, job_err, need_sw, sw_off, sw_job, trace,
         a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
@@ -100,15 +101,15 @@ void prof_begin(bmbs_ctx* c, const char* name)
 void prof_end(bmbs_ctx* c) { (void)hipEventRecord(c->prof[c->n_prof_used].b, c->stream); c->n_prof_used++; }
 
 // exclusive scan u32[n] -> u64[n+1], total left in c->totals[slot]
-int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot, u32* list = nullptr)
+int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot, u32* list = nullptr, int nz = 0)
 {
     const u64 per = (u64)SCAN_BLOCK * SCAN_ITEMS;
     const u64 nb = (n + per - 1) / per;
     ENS(c, c->scan_tmp, (nb + 1) * 8);
     u64* bs = c->scan_tmp.as<u64>();
-    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs);
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, nz);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bs, nb, c->totals.as<u64>() + slot);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list, nz);
     return BMBS_OK;
 }
 
@@ -389,10 +390,18 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
                            c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
         prof_end(c);
     } else {
-        ENS(c, c->long_flag, n * 4); ENS(c, c->long_off, (n + 1) * 8); ENS(c, c->long_list, n * 4);
+        ENS(c, c->long_flag, n * 4); ENS(c, c->long_off, (n + 1) * 8); ENS(c, c->long_list, n * 4); ENS(c, c->vote_list, n * 4);
         prof_begin(c, "k_vote_fused");
+        // the reads that have candidates, compacted (the scan's list mode on n_cand != 0), so that the vote kernel's waves are dense
+        HIPCHK(c, hipMemsetAsync(c->long_flag.p, 0, n * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(st.n_votes, 0, n * 4, c->stream));
+        {
+            int rv = scan_u32(c, st.n_cand, n, c->long_off.as<u64>(), 10, c->vote_list.as<u32>(), 1);
+            if (rv) return rv;
+        }
         hipLaunchKernelGGL(k_vote_fused, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, st, c->cand.as<u64>(),
-                           c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->long_flag.as<u32>());
+                           c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->long_flag.as<u32>(), c->totals.as<u64>() + 10,
+                           c->vote_list.as<u32>());
         prof_end(c);
         // reads with more than 16 candidates (repeats): one block per read
         prof_begin(c, "k_vote_long");
@@ -462,7 +471,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->stats, &c->counters, &c->pe_seq, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
-                     &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list};
+                     &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -421,12 +421,17 @@ DEVI void scan_load8(const u32* in, u64 base, u64 n, u32 x[SCAN_ITEMS])
         for (int j = 0; j < SCAN_ITEMS; j++) x[j] = base + j < n ? in[base + j] : 0u;
     }
 }
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partial(const u32* in, u64 n, u64* block_sums)
+// nz: the values count as flags (x != 0)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partial(const u32* in, u64 n, u64* block_sums, int nz)
 {
     __shared__ u64 sh[SCAN_BLOCK / 64];
     const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
     u32 x[SCAN_ITEMS];
     scan_load8(in, base, n, x);
+    if (nz) {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) x[j] = x[j] != 0;
+    }
     u64 s = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) s += x[j];
@@ -450,12 +455,16 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(u64* block_sums, u64 nb, u
 }
 // list != nullptr: `in` holds 0/1 flags and the positions of the ones are written, in order, to list[]; the offsets
 // themselves are not stored (the work lists of the seeding stages need nothing else)
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out, u32* list)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out, u32* list, int nz)
 {
     __shared__ u64 sh[SCAN_BLOCK / 64];
     const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
     u32 x[SCAN_ITEMS];
     scan_load8(in, base, n, x);
+    if (nz) {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) x[j] = x[j] != 0;
+    }
     u64 s = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) s += x[j];
@@ -1156,11 +1165,17 @@ k_vote(long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __r
 #define VOTE_REG 16
 __global__ void __launch_bounds__(64)
 k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes,
-             u32* __restrict__ slot_read, u32* __restrict__ long_flag)
+             u32* __restrict__ slot_read, u32* __restrict__ long_flag, const u64* __restrict__ count_ptr, const u32* __restrict__ list)
 {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (long_flag) long_flag[r] = 0;
+    // list != nullptr: the reads that have candidates, compacted (a quarter of a batch: with one lane per read of the whole
+    // batch every wave ran the sort for a few busy lanes); n_votes and long_flag of the others were zeroed by the caller
+    const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long r = it;
+    if (list) { if (it >= (long)*count_ptr) return; r = list[it]; }
+    else {
+        if (r >= n) return;
+        if (long_flag) long_flag[r] = 0;
+    }
     if (st.verdict[r] != 3) { st.n_votes[r] = 0; return; }
     const int k = gm.rk(gm.rl(r));
     const u64 off = st.cand_off[r];
