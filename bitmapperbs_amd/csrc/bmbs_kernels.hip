@@ -805,32 +805,39 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
                             // all-zero window: every position mismatches; the first sets ml = read_i (= ml), the second stops
                             error = need >= 2 ? 2 : 1;
                         } else {
-                            // read position q faces doubled coordinate loc + q; 8 positions per step
+                            // read position q faces doubled coordinate loc + q; 16 positions per step
                             const int ml0 = (int)ml;
                             // window bases cached in registers, 64 per 16-byte global load, the next block already on its way
                             // (every per-lane load is a request of its own: 3 wide loads instead of 6 narrow ones per read)
                             const uint4* g4 = reinterpret_cast<const uint4*>(ix.gen2);
-                            u64 gidx = (loc + (u64)(ml0 & ~7)) >> 6;
+                            u64 gidx = (loc + (u64)(ml0 & ~15)) >> 6;
                             uint4 cb = g4[gidx], nb = g4[gidx + 1];
-                            for (int p = ml0 & ~7; p < L && error < 2; p += 8) {
-                                const u64 rw = *reinterpret_cast<const u64*>(rd + p);
+                            for (int p = ml0 & ~15; p < L && error < 2; p += 16) {
+                                const u64 r0 = *reinterpret_cast<const u64*>(rd + p), r1 = *reinterpret_cast<const u64*>(rd + p + 8);
                                 const u64 d = loc + (u64)p;
                                 if ((d >> 6) != gidx) { gidx = d >> 6; cb = nb; nb = g4[gidx + 1]; }
                                 const int o = (int)(d & 63) * 2;
                                 const u64 c0 = ((u64)cb.y << 32) | cb.x, c1 = ((u64)cb.w << 32) | cb.z, n0 = ((u64)nb.y << 32) | nb.x;
                                 const u64 lo64 = o < 64 ? c0 : c1, hi64 = o < 64 ? c1 : n0;
                                 const int sh = o & 63;
-                                u64 w16 = lo64 >> sh;
-                                if (sh > 48) w16 |= hi64 << (64 - sh);
-                                u64 m = mism8(rw, w16 & 0xffff);
-                                const int lo = ml0 > p ? ml0 - p : 0, hi = L - p < 8 ? L - p : 8;
-                                u64 keep = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1);
-                                keep &= ~((1ull << (8 * lo)) - 1);
-                                m &= keep;
-                                if (m) {
-                                    const int cnt = __popcll(m);
-                                    if (error == 0) { ml = (u64)(p + (__ffsll((long long)m) - 1) / 8); error = cnt >= 2 ? 2 : 1; }
-                                    else error = 2;
+                                u64 w = lo64 >> sh;
+                                if (sh > 32) w |= hi64 << (64 - sh);
+                                const u32 w32 = (u32)w;
+                                u64 m0 = mism8(r0, w32 & 0xffffu), m1 = mism8(r1, w32 >> 16);
+                                if (p < ml0) {                                   // positions before ml0 are matched already
+                                    const int lo = ml0 - p;
+                                    if (lo >= 8) { m0 = 0; m1 &= ~((1ull << (8 * (lo - 8))) - 1); } else m0 &= ~((1ull << (8 * lo)) - 1);
+                                }
+                                if (p + 16 > L) {                                // the read ends inside this piece
+                                    const int hi = L - p;
+                                    if (hi <= 8) { m1 = 0; if (hi < 8) m0 &= (1ull << (8 * hi)) - 1; } else m1 &= (1ull << (8 * (hi - 8))) - 1;
+                                }
+                                if (m0 | m1) {
+                                    const int cnt = __popcll(m0) + __popcll(m1);
+                                    if (error == 0) {
+                                        ml = (u64)(m0 ? p + (__ffsll((long long)m0) - 1) / 8 : p + 8 + (__ffsll((long long)m1) - 1) / 8);
+                                        error = cnt >= 2 ? 2 : 1;
+                                    } else error = 2;
                                 }
                             }
                         }
