@@ -751,15 +751,19 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
         const long row0 = (long)blockIdx.x * blockDim.x;
         const long rows = n - row0 < (long)blockDim.x ? n - row0 : (long)blockDim.x;
         const int per_row = stride / 16;
-        const long total16 = rows * per_row;
+        const int total16 = (int)rows * per_row;
         const uint4* src = reinterpret_cast<const uint4*>(seq + (size_t)row0 * stride);
-        for (long q = threadIdx.x; q < total16; q += blockDim.x) {
+        // piece q = (row rr, column cc); q advances by the block size, so (rr, cc) advance by its quotient and remainder -- one
+        // division per thread instead of one (64-bit) per piece
+        const int dq = (int)blockDim.x / per_row, dr = (int)blockDim.x - dq * per_row;
+        int rr = (int)threadIdx.x / per_row, cc = (int)threadIdx.x - rr * per_row;
+        for (int q = threadIdx.x; q < total16; q += blockDim.x) {
             const uint4 v = src[q];
-            const long rr = q / per_row;
-            const int cc = (int)(q - rr * per_row);
             u64* dst = reinterpret_cast<u64*>(lds_rows + rr * lstride + cc * 16);
             dst[0] = ((u64)v.y << 32) | v.x;
             dst[1] = ((u64)v.w << 32) | v.z;
+            rr += dq; cc += dr;
+            if (cc >= per_row) { cc -= per_row; rr++; }
         }
     }
     __syncthreads();
