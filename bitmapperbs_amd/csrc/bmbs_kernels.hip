@@ -941,24 +941,37 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             const int tm = S.tm;
             const u64 site = ix.total - p - (u64)done_chars;       // doubled coordinate of read[tm]
             bool ok = true;
-            for (int q = (tm + done_chars) & ~7; q < L && ok; q += 8) {
-                const u64 rw = *reinterpret_cast<const u64*>(rd + q);
+            // 16 positions per step: one 16-byte row load, the window through a two-word cursor (one load per 32 bases)
+            const int start = tm + done_chars;
+            Win32Cur wc; wc.init(ix, site + (u64)((start & ~15) - tm));
+            for (int q = start & ~15; q < L && ok; q += 16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(rd + q);
+                const u64 rw[2] = {((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z};
                 const u64 d = site + (u64)(q - tm);                 // doubled coordinate facing read[q] (u64 wrap = out of range)
-                u64 m;
-                if (d + 8 <= ix.total) m = mism8_3letter(rw, win16(ix, d));
-                else {                                               // runs off the end of the text: '$' never matches
-                    m = 0;
-                    for (int j = 0; j < 8; j++) {
-                        const u64 dj = d + (u64)j;
-                        const char a = (char)((rw >> (8 * j)) & 0xff);
-                        const bool eq = dj < ix.total && code3(a) <= 2 && code3(a) == code3("ACGT"[gbase(ix, dj)]);
-                        if (!eq) m |= 0x80ull << (8 * j);
+                u64 m[2];
+                if (d + 16 <= ix.total) {
+                    const u32 w32 = wc.at(d);
+                    m[0] = mism8_3letter(rw[0], w32 & 0xffffu); m[1] = mism8_3letter(rw[1], w32 >> 16);
+                } else {                                             // runs off the end of the text: '$' never matches
+                    for (int hf = 0; hf < 2; hf++) {
+                        m[hf] = 0;
+                        for (int j = 0; j < 8; j++) {
+                            const u64 dj = d + (u64)(8 * hf + j);
+                            const char a = (char)((rw[hf] >> (8 * j)) & 0xff);
+                            const bool eq = dj < ix.total && code3(a) <= 2 && code3(a) == code3("ACGT"[gbase(ix, dj)]);
+                            if (!eq) m[hf] |= 0x80ull << (8 * j);
+                        }
                     }
                 }
-                const int lo = tm + done_chars > q ? tm + done_chars - q : 0, hi = L - q < 8 ? L - q : 8;
-                u64 keep = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1);
-                keep &= ~((1ull << (8 * lo)) - 1);
-                if (m & keep) ok = false;
+                if (q < start) {                                     // positions before `start` are matched already
+                    const int lo = start - q;
+                    if (lo >= 8) { m[0] = 0; m[1] &= ~((1ull << (8 * (lo - 8))) - 1); } else m[0] &= ~((1ull << (8 * lo)) - 1);
+                }
+                if (q + 16 > L) {                                    // the read ends inside this piece
+                    const int hi = L - q;
+                    if (hi <= 8) { m[1] = 0; if (hi < 8) m[0] &= (1ull << (8 * hi)) - 1; } else m[1] &= (1ull << (8 * (hi - 8))) - 1;
+                }
+                if (m[0] | m[1]) ok = false;
             }
             if (ok) { h.hits = 1; h.sp = (p - (u64)(S.steps - S.s)) | (1ull << 63); }     // located: text position of the full seed
             else { h.hits = 0; h.sp = 0; }
