@@ -881,7 +881,9 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             }
         }
         st.multi[r] = (u8)multi;
-        st.mm_site[r] = (u16)mm_site;
+        // bit 15: the read character there is 'N' (L <= 1000).  k_finalize prices the 1-mismatch exit with it and need not touch the
+        // read row again (one sector per such read)
+        st.mm_site[r] = (u16)(mm_site | ((mm_site < (u64)L && rd[mm_site] == 'N') ? 0x8000u : 0u));
         if (done) seed_finish(st, r, verdict, ns, ncand, pe_mode);
         else {
             st.exit_site[r] = c0;
@@ -2248,9 +2250,8 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
         if (verdict == 1) { have = true; site = st.exit_site[r]; start_site = 0; end_site = L - 1; nm = 0; score = 0; mapq = 42; o.path = 1; }
         else if (verdict == 2) {
             have = true; site = st.exit_site[r]; start_site = 0; end_site = L - 1; nm = 1; o.path = 2;
-            const int ms = st.mm_site[r];
-            const char a = seq[(size_t)r * stride + ms];
-            score = a == 'N' ? -sp.np : -pen_lut[(unsigned char)qual[(size_t)r * stride + ms]];
+            const int mv = st.mm_site[r], ms = mv & 0x7fff;          // bit 15: the read has 'N' there (k_seed_decide)
+            score = (mv & 0x8000) ? -sp.np : -pen_lut[(unsigned char)qual[(size_t)r * stride + ms]];
             sbd = 0xffffffffu;
         } else if (verdict == 4) {
             o.status = 2; o.path = 4;
@@ -3015,11 +3016,10 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
                     if (st.best_err[r] != 0) {
                         // 1-mismatch exit (see k_pe_pair): NM 1, score = minus the penalty at mm_site; mate 2 rows carry their
                         // qualities in FASTQ order for a reverse-complemented read (need_reverse_quality = 1)
-                        const int ms = st.mm_site[r];
-                        const char a = seq[(size_t)r * stride + ms];
+                        const int mv = st.mm_site[r], ms = mv & 0x7fff;          // bit 15: the read has 'N' there (k_seed_decide)
                         const int qi = m == 1 ? Lm - 1 - ms : ms;
                         nm[m] = 1;
-                        score[m] = a == 'N' ? -sp.np : -pen_lut[(unsigned char)qual_row(qual, qual2, (u32)n, (u32)r, stride)[qi]];
+                        score[m] = (mv & 0x8000) ? -sp.np : -pen_lut[(unsigned char)qual_row(qual, qual2, (u32)n, (u32)r, stride)[qi]];
                     }
                 }
                 u64 loc = site;
