@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("-e", type=float, default=0.04)
     ap.add_argument("--pe", action="store_true")
+    ap.add_argument("--sensitive", action="store_true", help="with --pe: --sensitive for both programs")
+    ap.add_argument("--sub", type=float, default=0.005, help="substitution rate of the synthetic reads")
+    ap.add_argument("--repeats", type=int, default=0, help="plant this many diverged repeat copies into the genome (as bench.py --repeats)")
+    ap.add_argument("--extra", default="", help="further options handed to both programs, e.g. '--unmapped_out --ambiguous_out'")
     ap.add_argument("--ref-threads", default="8")
     ap.add_argument("--io-threads", default="32")
     ap.add_argument("--batch", type=int, default=1_000_000)
@@ -47,23 +51,26 @@ def main():
     wd = args.workdir
     files = []
     if not args.pe:
-        s, q = gpusynth.make_reads_se(genome_d, lens_d, args.reads, L, stride, seed=7)
+        s, q = gpusynth.make_reads_se(genome_d, lens_d, args.reads, L, stride, seed=7, sub=args.sub)
         fq = os.path.join(wd, "e2e.fq")
         bench.write_fastq_sample(fq, s.cpu().numpy(), q.cpu().numpy(), L)
         files = [fq]
         in_args = ["--seq", fq]
     else:
-        s1, q1, s2, q2 = gpusynth.make_reads_pe(genome_d, lens_d, args.reads, L, stride, seed=7)
+        s1, q1, s2, q2 = gpusynth.make_reads_pe(genome_d, lens_d, args.reads, L, stride, seed=7, sub=args.sub)
         f1 = os.path.join(wd, "e2e_1.fq"); f2 = os.path.join(wd, "e2e_2.fq")
         bench.write_fastq_sample(f1, s1.cpu().numpy(), q1.cpu().numpy(), L)
         bench.write_fastq_sample(f2, s2.cpu().numpy(), q2.cpu().numpy(), L)
         files = [f1, f2]
-        in_args = ["--seq1", f1, "--seq2", f2]
+        in_args = ["--seq1", f1, "--seq2", f2] + (["--sensitive"] if args.sensitive else [])
+    in_args += args.extra.split()
     del genome_d
     torch.cuda.empty_cache()
     in_bytes = sum(os.path.getsize(f) for f in files)
     n_reads = args.reads * (2 if args.pe else 1)
-    res = {"workload": "%d %s of %d bp, genome %d bp, -e %.2f, FASTQ %.2f GB on %s" % (args.reads, "pairs" if args.pe else "SE reads", L, args.genome, args.e, in_bytes / 1e9, wd),
+    res = {"workload": "%d %s of %d bp, genome %d bp%s, -e %.2f, substitutions %.3f%s%s, FASTQ %.2f GB on %s" % (
+               args.reads, "pairs" if args.pe else "SE reads", L, args.genome, " + %d repeat copies" % args.repeats if args.repeats else "", args.e, args.sub,
+               ", --sensitive" if args.sensitive else "", " " + args.extra if args.extra else "", in_bytes / 1e9, wd),
            "runs": []}
     drv = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
     digests = {}
