@@ -515,15 +515,15 @@ struct SeedHit { u64 hits, sp, ml; };
 // base-3 number of read[tm .. tm+15] and extension consumes read[tm+16], read[tm+17], ....
 struct Search { u64 top, bot, ptop, pbot; int s, steps, tm; ReadCur cur; };
 
-// eight ASCII characters -> eight 3-letter digits (G0 T1 A2, C folded into T), one per byte, and 0x80 in every byte that
-// holds one of A C G T.  (c >> 1) & 3 is A0 C1 T2 G3, and the digit is 2 - popcount of that.
-DEVI void swar_code3(u64 w, u64& digits, u64& valid)
+// eight ASCII characters -> eight 3-letter digits (G0 T1 A2, C folded into T), one per byte.  (c >> 1) & 3 is A0 C1 T2 G3, and
+// the digit is 2 - popcount of that.  `bad` is non-zero in every byte that does not hold one of A C G T: the letter a byte would
+// have to be is rebuilt from its bits 1-2 (0x41 | bits 1-2; T: ^ 0x11) and compared with it.
+DEVI void swar_code3(u64 w, u64& digits, u64& bad)
 {
-    const u64 K01 = 0x0101010101010101ull, K7F = 0x7f7f7f7f7f7f7f7full;
+    const u64 K01 = 0x0101010101010101ull;
     digits = 0x0202020202020202ull - ((w >> 1) & K01) - ((w >> 2) & K01);
-    auto zero_bytes = [&](u64 x) -> u64 { return ~(((x & K7F) + K7F) | x | K7F); };          // 0x80 exactly where a byte is 0
-    valid = zero_bytes(w ^ 0x4141414141414141ull) | zero_bytes(w ^ 0x4343434343434343ull) |
-            zero_bytes(w ^ 0x4747474747474747ull) | zero_bytes(w ^ 0x5454545454545454ull);
+    const u64 isT = (w >> 2) & ~(w >> 1) & K01;
+    bad = w ^ (0x4141414141414141ull | (w & 0x0606060606060606ull)) ^ (isT | (isT << 4));
 }
 // four digits (one per byte of x) -> d0 + 3 d1 + 9 d2 + 27 d3 in one multiply
 DEVI u32 base3_of4(u32 x) { return (x * 0x0103091Bu) >> 24; }
@@ -555,15 +555,15 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     u64 d0, v0, d1, v1;
     swar_code3(w0, d0, v0);
     swar_code3(w1, d1, v1);
-    if ((v0 & v1) != 0x8080808080808080ull) return false;          // get_3_letter_hash_value returned -1 (bwt.h:309-332)
-    const u64 key = (u64)base3_of4((u32)d0) + 81ull * base3_of4((u32)(d0 >> 32)) + 6561ull * base3_of4((u32)d1) +
-                    531441ull * base3_of4((u32)(d1 >> 32));
+    if ((v0 | v1) != 0) return false;                              // get_3_letter_hash_value returned -1 (bwt.h:309-332)
+    // < 3^16: 32-bit arithmetic
+    const u64 key = base3_of4((u32)d0) + 81u * base3_of4((u32)(d0 >> 32)) + 6561u * base3_of4((u32)d1) + 531441u * base3_of4((u32)(d1 >> 32));
     S.steps = len - 16; S.tm = tm;
     if ((!FIXED || LOCATED) && ix.t20 && len >= 20) {
         // the 16-mer lookup and the first four extensions in one table read
         u64 d2, v2;
         swar_code3(funnel(c2, c3) & 0xffffffffull, d2, v2);          // read[tm+16 .. tm+19]
-        if ((v2 & 0x80808080ull) == 0x80808080ull) {
+        if ((u32)v2 == 0) {
             const u64 v = ix.t20[key * T20_EXT + (u64)base3_of4((u32)d2)];
             const int tag = (int)(v >> 60);
             if (tag != 14) {
