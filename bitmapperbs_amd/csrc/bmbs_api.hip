@@ -399,10 +399,23 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
             int rv = scan_u32(c, st.n_cand, n, c->long_off.as<u64>(), 10, c->vote_list.as<u32>(), 1);
             if (rv) return rv;
         }
+        // long reads (up to 25 seeds): lists of 17..32 candidates are the rule, not the repeat case -- they get a kernel of their
+        // own (k_vote_mid); its flag and list live in the seeding work-list buffers, free by now
+        const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !getenv("BMBS_VOTE_NOMID");
+        u32* mid_flag = use_mid ? c->sd_flag_c.as<u32>() : nullptr;
+        if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n * 4, c->stream));
         hipLaunchKernelGGL(k_vote_fused, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, st, c->cand.as<u64>(),
                            c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->long_flag.as<u32>(), c->totals.as<u64>() + 10,
-                           c->vote_list.as<u32>());
+                           c->vote_list.as<u32>(), mid_flag);
         prof_end(c);
+        if (use_mid) {
+            prof_begin(c, "k_vote_mid");
+            int rm = scan_u32(c, mid_flag, n, c->long_off.as<u64>(), 11, c->sd_list_c.as<u32>());
+            if (rm) return rm;
+            hipLaunchKernelGGL(k_vote_mid, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 11, c->sd_list_c.as<u32>(),
+                               c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
+            prof_end(c);
+        }
         // reads with more than 16 candidates (repeats): one block per read
         prof_begin(c, "k_vote_long");
         int rl = scan_u32(c, c->long_flag.as<u32>(), n, c->long_off.as<u64>(), 9, c->long_list.as<u32>());

@@ -1189,9 +1189,11 @@ k_vote(long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __r
 // insertion sort, i.e. stable: rank = votes larger + equal votes earlier), so the candidate array never goes through
 // memory and no per-lane sort runs on global memory.  Longer lists take the two-step path inside the same kernel.
 #define VOTE_REG 16
+#define VOTE_MID 32
 __global__ void __launch_bounds__(64)
 k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes,
-             u32* __restrict__ slot_read, u32* __restrict__ long_flag, const u64* __restrict__ count_ptr, const u32* __restrict__ list)
+             u32* __restrict__ slot_read, u32* __restrict__ long_flag, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
+             u32* __restrict__ mid_flag)
 {
     // list != nullptr: the reads that have candidates, compacted (a quarter of a batch: with one lane per read of the whole
     // batch every wave ran the sort for a few busy lanes); n_votes and long_flag of the others were zeroed by the caller
@@ -1265,6 +1267,8 @@ k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ c
         for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
         return;
     }
+    // 17..32 candidates -- the usual case of a long read, which places up to 25 seeds: k_vote_mid, still one lane per read
+    if (mid_flag && nc <= VOTE_MID) { mid_flag[r] = 1; st.n_votes[r] = 0; return; }
     // long lists (repeats): a whole block sorts each of them out of LDS (k_vote_long)
     if (long_flag) { long_flag[r] = 1; st.n_votes[r] = 0; return; }
     // single-lane form (stage API without the list buffers, and lists beyond the LDS capacity of k_vote_long)
@@ -1287,6 +1291,99 @@ k_vote_fused(DevIndex ix, long n, ReadGeom gm, ReadState st, u64* __restrict__ c
     }
     v[nv].site = pre >= (u64)k ? pre - (u64)k : 0; v[nv].vote = vote; v[nv].pad = 0; nv++;
     intro_sort_desc(v, nv);             // std::sort(votes, compare_seed_votes), Schema.cpp:24986
+    st.n_votes[r] = (u32)nv;
+    for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+}
+
+// ---- 17..32 candidates: one lane per read, keys in registers ---------------------------------------------------------------
+// A read of 180 bases and more places up to 25 seeds, so most of its lists have 17..32 entries; giving each of them a whole wave
+// (k_vote_long) made the vote stage the largest kernel of a 250-bp batch.  Same scheme as the 16-key path of k_vote_fused with a
+// bitonic network of 32; above 16 DISTINCT sites std::sort is no longer an insertion sort, and the order comes from the
+// introsort emulation (bmbs_sort.h) on (vote, entry) items, the sites parked in the read's own candidate segment meanwhile.
+__global__ void __launch_bounds__(64)
+k_vote_mid(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
+           u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read)
+{
+    const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= (long)*count_ptr) return;
+    const long r = list[it];
+    const int k = gm.rk(gm.rl(r));
+    const u64 off = st.cand_off[r];
+    const long nc = (long)st.n_cand[r];
+    const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+    const int ns = st.n_seeds[r];
+    bmbs_vote* v = votes + off;
+    u64 c[VOTE_MID];
+    {
+        int sidx = 0; u32 h = 0;
+        u64 sp = 0, adj = 0; u32 hits = 0;
+        if (ns > 0) { sp = my[0].sp; adj = (u64)my[0].len + (u64)my[0].off; hits = my[0].hits; }
+#pragma unroll
+        for (int j = 0; j < VOTE_MID; j++) {
+            c[j] = ~0ull;
+            if (j < nc) {
+                while (h == hits && sidx + 1 < ns) { sidx++; h = 0; sp = my[sidx].sp; adj = (u64)my[sidx].len + (u64)my[sidx].off; hits = my[sidx].hits; }
+                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + h)) - adj;
+                h++;
+            }
+        }
+    }
+    // bitonic network, 32 keys, ascending (padding ~0 sinks to the end); every index is a compile-time constant once unrolled
+#pragma unroll
+    for (int size = 2; size <= VOTE_MID; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int t = 0; t < VOTE_MID / 2; t++) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool asc = (i & size) == 0;
+                const u64 x_ = c[i], y_ = c[j];
+                const bool sw = asc ? x_ > y_ : x_ < y_;
+                c[i] = sw ? y_ : x_; c[j] = sw ? x_ : y_;
+            }
+        }
+    }
+    u32 vote[VOTE_MID];
+    bool last[VOTE_MID];
+    u32 run = 0;
+    int nv = 0;
+#pragma unroll
+    for (int i = 0; i < VOTE_MID; i++) {
+        run = (i > 0 && c[i] == c[i - 1]) ? run + 1 : 1;
+        vote[i] = run;
+        last[i] = i < nc && (i + 1 >= nc || (i + 1 < VOTE_MID && c[i + 1] != c[i]));
+        nv += last[i] ? 1 : 0;
+    }
+    if (nv <= 16) {
+        // std::sort on <= 16 entries is an insertion sort: stable, descending by vote
+#pragma unroll
+        for (int i = 0; i < VOTE_MID; i++) {
+            if (last[i]) {
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < VOTE_MID; j++) rank += (last[j] && (vote[j] > vote[i] || (vote[j] == vote[i] && j < i))) ? 1 : 0;
+                bmbs_vote o;
+                o.site = c[i] < (u64)k ? 0 : c[i] - (u64)k; o.vote = vote[i]; o.pad = 0;
+                v[rank] = o;
+            }
+        }
+    } else {
+        bmbs_vk items[VOTE_MID];
+        u64* park = cand + off;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < VOTE_MID; i++) {
+            if (last[i]) { park[e] = c[i]; items[e].x = (vote[i] << 24) | (u32)e; e++; }
+        }
+        intro_sort_desc(items, (long)nv);          // std::sort(votes, compare_seed_votes), Schema.cpp:24986
+        for (int j = 0; j < nv; j++) {
+            const u32 x = items[j].x;
+            const u64 site = park[x & 0xffffffu];
+            bmbs_vote o;
+            o.site = site < (u64)k ? 0 : site - (u64)k; o.vote = x >> 24; o.pad = 0;
+            v[j] = o;
+        }
+    }
     st.n_votes[r] = (u32)nv;
     for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
 }
