@@ -1742,72 +1742,10 @@ k_vote_compact(u64 n_slots, ReadState st, const u64* __restrict__ vote_off, cons
 // the doubled 2-bit genome), text = read; read 'T' also matches window 'C' (:384,473).
 // W = u32 when the band (2k+1 bits) fits 32 bits (k <= 15, exactly the case in which the reference runs
 // its 8 x 32-bit AVX2 form), else u64.
-template <class W>
-DEVI void bpm_core(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
-{
-    out_err = 0xffffffffu; out_end = -1;
-    const int p_len = L + 2 * k;
-    if (!window_valid(ix, site, (u64)p_len, site < ix.G)) return;
-    WinReader wr; wr.init(ix, site, true);
-    W PA = 0, PC = 0, PG = 0, PT = 0;
-    const int band = 2 * k + 1;
-    for (int i = 0; i < band; i++) {
-        const int b = wr.next();
-        const W bit = (W)1 << i;
-        PA |= b == 0 ? bit : (W)0; PC |= b == 1 ? bit : (W)0; PG |= b == 2 ? bit : (W)0; PT |= b == 3 ? bit : (W)0;
-    }
-    PT |= PC;
-    const W Mask = (W)1 << (2 * k);
-    W VP = 0, VN = 0;
-    int err = 0;
-    const int last_high = 2 * k;
-    ReadCur rc; rc.seek(rd, 0, L);
-    for (int i = 0; i < L; i++) {
-        const char tc = rc.next();
-        const W eq = tc == 'A' ? PA : tc == 'C' ? PC : tc == 'G' ? PG : tc == 'T' ? PT : (W)0;
-        W X = eq | VN;
-        const W D0 = ((VP + (X & VP)) ^ VP) | X;
-        const W HN = VP & D0;
-        const W HP = VN | ~(VP | D0);
-        X = D0 >> 1;
-        VN = X & HP;
-        VP = HN | ~(X | HP);
-        if (!(D0 & 1)) {
-            ++err;
-            if (err - last_high > k) return;            // cannot come back under k (Levenshtein_Cal.h:455)
-        }
-        if (i + 1 < L) {
-            PA >>= 1; PC >>= 1; PG >>= 1; PT >>= 1;
-            const int b = wr.next();
-            PA |= b == 0 ? Mask : (W)0; PC |= b == 1 ? Mask : (W)0; PG |= b == 2 ? Mask : (W)0; PT |= b == 3 ? Mask : (W)0;
-            PT |= PC;
-        }
-    }
-    // minimum over the last 2k+1 columns; later column wins ties, then the un-gapped diagonal
-    // (Levenshtein_Cal.h:511-563)
-    const int site_e = L - 1;
-    u32 best = 0xffffffffu;
-    int ret = -1;
-    if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e; }
-    int i = 0;
-    while (i < k) {
-        err += (int)((VP >> i) & 1); err -= (int)((VN >> i) & 1); ++i;
-        if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e + i; }
-    }
-    const u32 ungap = (u32)err;
-    while (i < last_high) {
-        err += (int)((VP >> i) & 1); err -= (int)((VN >> i) & 1); ++i;
-        if (err <= k && (u32)err <= best) { best = (u32)err; ret = site_e + i; }
-    }
-    if (ungap <= (u32)k && ungap == best) ret = site_e + k;
-    out_err = best; out_end = ret;
-}
-
-// The k <= 15 form (band <= 31 bits).  k_filter is bound by VALU issue, not by memory (profiles/: ~85 % of its time is VALU
-// issue), so this form spends fewer instructions per read character than sliding four Peq vectors does: the window is kept
-// as two bit planes (bit 0 / bit 1 of the 2-bit letters; 64 bases per register pair, re-filled every 32 rows), the row's Peq
-// is derived from them with the bisulfite rule folded in (T: plane 0 alone = {C, T}), and the characters come 16 per load.
-// Same recurrences, same results as bpm_core<u32>.
+// k_filter is bound by VALU issue, not by memory (profiles/: ~85 % of its time was VALU issue with four sliding Peq vectors), so this
+// form spends fewer instructions per read character: the window is kept as two bit planes (bit 0 / bit 1 of the 2-bit letters;
+// 64 or 96 bases per register set, re-filled every 32 rows), the row's Peq is derived from them with the bisulfite rule folded in
+// (T: plane 0 alone = {C, T}), and the characters come 16 per load.
 DEVI void planes32(const DevIndex& ix, u64 d, u32& lo, u32& hi)      // the 32 bases starting at doubled coordinate d
 {
     const int sh = (int)(d & 31) * 2;
@@ -1825,47 +1763,60 @@ DEVI void planes32(const DevIndex& ix, u64 d, u32& lo, u32& hi)      // the 32 b
     lo = squeeze(a) | (squeeze(b) << 16);
     hi = squeeze(a >> 1) | (squeeze(b >> 1) << 16);
 }
-DEVI void bpm_core32(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
+// W = u32: band <= 31 bits (k <= 15), 64 bases of each plane in a register pair; W = u64: band <= 63 bits (k <= 31), 96 bases.
+template <class W>
+DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
 {
+    constexpr bool WIDE = sizeof(W) == 8;
     out_err = 0xffffffffu; out_end = -1;
     const int p_len = L + 2 * k;
     if (!window_valid(ix, site, (u64)p_len, site < ix.G)) return;
     const int band = 2 * k + 1;
-    const u32 bmask = (1u << band) - 1;                 // band <= 31
+    const W bmask = ((W)1 << band) - 1;
     u64 loS, hiS;                                       // bit j = plane bit of base site + i0 + j
+    u32 loT = 0, hiT = 0;                               // WIDE: bits 64..95
     {
         u32 l0, h0, l1, h1;
         planes32(ix, site, l0, h0); planes32(ix, site + 32, l1, h1);
         loS = ((u64)l1 << 32) | l0; hiS = ((u64)h1 << 32) | h0;
+        if (WIDE) planes32(ix, site + 64, loT, hiT);
     }
-    u32 VP = 0, VN = 0;
+    W VP = 0, VN = 0;
     int err = 0;
     const int last_high = 2 * k;
     // one read character: CHECKED also tests the read's end and that the character is one of A, C, G, T
     auto step = [&](u32 tc, int i, int i0, auto checked) {
-        const u32 lo = (u32)(loS >> (i - i0)) & bmask, hi = (u32)(hiS >> (i - i0)) & bmask;
-        const u32 xl = (tc == 'A' || tc == 'G') ? (lo ^ bmask) : lo;
-        const u32 xh = tc == 'G' ? hi : ~hi;
-        u32 eq = tc == 'T' ? lo : (xl & xh);
+        const int sh = i - i0;
+        W lo, hi;
+        if (WIDE) {
+            lo = (W)(sh ? (loS >> sh) | ((u64)loT << (64 - sh)) : loS) & bmask;
+            hi = (W)(sh ? (hiS >> sh) | ((u64)hiT << (64 - sh)) : hiS) & bmask;
+        } else { lo = (W)(loS >> sh) & bmask; hi = (W)(hiS >> sh) & bmask; }
+        const W xl = (tc == 'A' || tc == 'G') ? (lo ^ bmask) : lo;
+        const W xh = tc == 'G' ? hi : ~hi;
+        W eq = tc == 'T' ? lo : (xl & xh);
         if (decltype(checked)::value) {
             const u32 idx = tc ^ 0x40u;                                         // 'A' 1, 'C' 3, 'G' 7, 'T' 20
             const u32 okc = idx < 32u ? (0x0010008au >> idx) & 1u : 0u;
-            eq &= 0u - okc;
+            eq &= (W)0 - (W)okc;
         }
-        u32 X = eq | VN;
-        const u32 D0 = ((VP + (X & VP)) ^ VP) | X;
-        const u32 HN = VP & D0;
-        const u32 HP = VN | ~(VP | D0);
+        W X = eq | VN;
+        const W D0 = ((VP + (X & VP)) ^ VP) | X;
+        const W HN = VP & D0;
+        const W HP = VN | ~(VP | D0);
         X = D0 >> 1;
-        const u32 VN2 = X & HP, VP2 = HN | ~(X | HP);
+        const W VN2 = X & HP, VP2 = HN | ~(X | HP);
         if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
         else { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); }
     };
     for (int i0 = 0; i0 < L; i0 += 32) {
         if (i0) {
             u32 nl, nh;
-            planes32(ix, site + (u64)i0 + 32, nl, nh);
-            loS = (loS >> 32) | ((u64)nl << 32); hiS = (hiS >> 32) | ((u64)nh << 32);
+            planes32(ix, site + (u64)i0 + (WIDE ? 64 : 32), nl, nh);
+            if (WIDE) {
+                loS = (loS >> 32) | ((u64)loT << 32); hiS = (hiS >> 32) | ((u64)hiT << 32);
+                loT = nl; hiT = nh;
+            } else { loS = (loS >> 32) | ((u64)nl << 32); hiS = (hiS >> 32) | ((u64)nh << 32); }
         }
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -1918,8 +1869,8 @@ DEVI void bpm_core32(const DevIndex& ix, const char* rd, int L, int k, u64 site,
 
 DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
 {
-    if (k <= 15) bpm_core32(ix, rd, L, k, site, out_err, out_end);          // k is wave-uniform unless lengths are mixed
-    else bpm_core<u64>(ix, rd, L, k, site, out_err, out_end);
+    if (k <= 15) bpm_planes<u32>(ix, rd, L, k, site, out_err, out_end);          // k is wave-uniform unless lengths are mixed
+    else bpm_planes<u64>(ix, rd, L, k, site, out_err, out_end);
 }
 
 __global__ void __launch_bounds__(256)
