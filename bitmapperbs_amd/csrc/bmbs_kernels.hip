@@ -1,15 +1,19 @@
 // bitmapperbs_amd/csrc/bmbs_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the
 // bisulfite mapping hot path.  Integer / bit work only: no MFMA, HBM-gather bound.
 //
-// Stage split (one kernel per work granularity, exclusive scans in between so that every kernel runs
+// Stage split (one kernel per work granularity, exclusive scans / compacted lists in between so that every kernel runs
 // dense lanes):
-//   k_seed      one read per lane   K1-K5 + the seeding state machine of Map_Single_Seq_end_to_end
-//   k_locate    one SA row per lane K5/K6 + reverse_and_adjust_site
-//   k_vote      one read per lane   a9/a10: sort, run-length votes, std::sort-exact vote order
-//   k_filter    one candidate/lane  K7+K8: window fetch + BS banded Myers (64-bit words)
-//   k_reduce    one read per lane   K9: ordered min / ambiguity / second_best_diff scan
-//   k_align     one winner per lane K11-K13: un-gapped recheck, banded affine SW + CIGAR + NM
-//   k_finalize  one read per lane   MAPQ LUT, doubled -> chromosome coordinates, off-end, stats
+//   k_seed_first / k_seed_decide / k_seed_second / k_seed_extra
+//                      read per lane (wave-owned chunks)  K1-K5 + the seeding state machine of Map_Single_Seq_end_to_end
+//   k_vote_fused / k_vote_mid / k_vote_long
+//                      read (<= 16, <= 32 candidates) per lane, wave or block per read beyond
+//                                                          K5/K6 + a9/a10: locate, sort, run-length votes, std::sort-exact order
+//   k_filter           candidate per lane                  K7+K8: window fetch + BS banded Myers on bit planes
+//   k_reduce           read per lane                       K9: ordered min / ambiguity / second_best_diff scan
+//   k_align_ungapped / k_align_sw<KB>
+//                      winner per lane                     K11-K13: un-gapped recheck, banded affine SW + CIGAR + NM
+//   k_finalize         read per lane                       MAPQ LUT, doubled -> chromosome coordinates, off-end, stats
+//   k_pe_* / k_pes_* / k_*_pe                              the paired-end (fast and --sensitive) counterparts
 #include "bmbs_dev.h"
 #include "bmbs_sort.h"
 #include <type_traits>
