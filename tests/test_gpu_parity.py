@@ -560,3 +560,25 @@ def test_seed_extra_without_lds_rows_matches_oracle(env, monkeypatch):
     assert not compare_records(res, pool, recs, 150)
     assert (m.stats() == ost).all()
     m.close()
+
+
+@pytest.mark.gpu
+def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
+    """BMBS_T20=0 (what bmbs_index_attach also falls back to when the device lacks 76 GB of free memory): the 16-mer lookup +
+    backward extensions do all the seeding; single-end and --sensitive paired-end"""
+    from bitmapperbs_amd import synth, mapper
+    monkeypatch.setenv("BMBS_T20", "0")
+    r = synth.make_reads_se(env["chroms"], n=20000, L=150, seed=91, sub=0.03, indel=0.002, qual="random", n_rate=0.003)
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    res, pool = m.map_se(r["seq"], r["qual"], 150)
+    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 150)
+    assert not compare_records(res, pool, recs, 150)
+    assert (m.stats() == ost).all()
+    m.close()
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=8000, L=100, seed=92, sub=0.03, indel=0.002, qual="random")
+    m = mapper.Mapper(env["ix"], 0, sensitive=1)
+    res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+    recs, ost, cnt = env["oix"].map_pe(orc.params(sensitive=1), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+    assert not compare_pe(res, pool, recs, 100)
+    assert (m.stats() == ost).all()
+    m.close()
