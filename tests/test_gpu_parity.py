@@ -582,3 +582,20 @@ def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
     assert not compare_pe(res, pool, recs, 100)
     assert (m.stats() == ost).all()
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["BMBS_DECIDE=plain", "BMBS_DECIDE=lds", "BMBS_DECIDE=vec8", "BMBS_VOTE=split", "BMBS_VOTE_NOMID=1", "BMBS_SEED_WAVES=4096"])
+def test_ab_switches_give_identical_records(knob, env, monkeypatch):
+    """the alternative kernel forms kept for A/B measurements map exactly like the default ones"""
+    from bitmapperbs_amd import synth, mapper
+    name, val = knob.split("=")
+    monkeypatch.setenv(name, val)
+    L = 250 if name == "BMBS_VOTE_NOMID" else 150
+    r = synth.make_reads_se(env["chroms"], n=12000, L=L, seed=300 + len(knob), sub=0.03, indel=0.002, qual="random", n_rate=0.003)
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    res, pool = m.map_se(r["seq"], r["qual"], L)
+    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], L)
+    assert not compare_records(res, pool, recs, L)
+    assert (m.stats() == ost).all()
+    m.close()
