@@ -620,8 +620,18 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
         prof_end(c);
     }
     prof_begin(c, "k_reduce");
-    hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, c->prm.ambiguous_out, st, c->vote_off.as<u64>(),
-                       c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>());
+    {
+        // over the compacted list of reads with candidates when the vote stage built one (BMBS_VOTE=split does not)
+        const char* vm2 = getenv("BMBS_VOTE");
+        const bool listed = !(vm2 && !strcmp(vm2, "split"));
+        if (listed) {
+            HIPCHK(c, hipMemsetAsync(st.job_flag, 0, n * 4, c->stream));
+            HIPCHK(c, hipMemsetAsync(st.red_status, 0, n, c->stream));
+        }
+        hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, c->prm.ambiguous_out, st, c->vote_off.as<u64>(),
+                           c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), c->totals.as<u64>() + 10,
+                           listed ? c->vote_list.as<u32>() : (const u32*)nullptr);
+    }
     prof_end(c);
     prof_begin(c, "scan_jobs");
     rc = scan_u32(c, st.job_flag, n, st.job_off, 1);

@@ -1931,12 +1931,17 @@ k_filter_pairs(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int strid
 // ================================================================================================
 __global__ void __launch_bounds__(256)
 k_reduce(long n, int ambiguous_out, ReadState st, const u64* __restrict__ vote_off, const bmbs_vote* __restrict__ votes,
-         const u32* __restrict__ ferr, const int* __restrict__ fend)
+         const u32* __restrict__ ferr, const int* __restrict__ fend, const u64* __restrict__ count_ptr, const u32* __restrict__ list)
 {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    st.job_flag[r] = 0;
-    st.red_status[r] = 0;
+    // list != nullptr: the compacted list of reads with candidates (k_vote_fused's); job_flag / red_status of the others were zeroed
+    const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long r = it;
+    if (list) { if (it >= (long)*count_ptr) return; r = list[it]; }
+    else {
+        if (r >= n) return;
+        st.job_flag[r] = 0;
+        st.red_status[r] = 0;
+    }
     if (st.verdict[r] != 3) return;
     const u64 off = vote_off[r];
     const long nv = (long)st.n_votes[r];
