@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libbmbs_hip.so")
 
 # every symbol include/bmbs.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "bmbs_default_params", "bmbs_create", "bmbs_destroy", "bmbs_last_error", "bmbs_index_attach",
+    "bmbs_default_params", "bmbs_create", "bmbs_destroy", "bmbs_last_error", "bmbs_index_attach", "bmbs_index_share",
     "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se", "bmbs_map_se_device",
     "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
     L.bmbs_last_error.argtypes = [vp]
     L.bmbs_last_error.restype = C.c_char_p
     L.bmbs_index_attach.argtypes = [vp, C.POINTER(IndexView)]
+    L.bmbs_index_share.argtypes = [vp, vp]
     L.bmbs_locate_batch.argtypes = [vp, vp, i64, vp]
     L.bmbs_window_batch.argtypes = [vp, vp, i64, i32, vp]
     L.bmbs_vote_order_batch.argtypes = [vp, vp, vp, i64, i32, vp]
@@ -107,7 +108,7 @@ def lib() -> C.CDLL:
     L.bmbs_host_alloc.restype = vp
     L.bmbs_host_free.argtypes = [vp]
     L.bmbs_host_free.restype = None
-    for name in ("bmbs_index_attach", "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se",
+    for name in ("bmbs_index_attach", "bmbs_index_share", "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se",
                  "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
                  "bmbs_map_se_device", "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce",
                  "bmbs_profile_last", "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_build"):

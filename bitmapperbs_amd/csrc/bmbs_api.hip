@@ -999,6 +999,19 @@ extern "C" int bmbs_locate_batch(bmbs_ctx* c, const uint64_t* row, int64_t n_row
     return BMBS_OK;
 }
 
+// A second context on the index of another one (same device): it takes the device pointers, owns none of the index memory and
+// has its own stream and work buffers.  Two such contexts driven by two host threads keep two batches in flight: the kernels of
+// one hide the memory waits and the low-occupancy phases of the other's.
+extern "C" int bmbs_index_share(bmbs_ctx* c, const bmbs_ctx* owner)
+{
+    if (!c || !owner) return BMBS_EINVAL;
+    if (!owner->attached) { c->err = "index share: the owner has no index attached"; return BMBS_ESTATE; }
+    if (c->dev != owner->dev) { c->err = "index share: contexts on different devices"; return BMBS_EINVAL; }
+    if (c->attached) { c->err = "index share: this context already has an index"; return BMBS_ESTATE; }
+    c->ix = owner->ix; c->rows = owner->rows; c->attached = true;
+    return BMBS_OK;
+}
+
 extern "C" int bmbs_vote_order_batch(bmbs_ctx* c, const uint8_t* vote, const int64_t* seg_off, int64_t n_seg, int32_t form,
                                      uint32_t* perm)
 {

@@ -52,14 +52,20 @@ class Index:
 
 
 class Mapper:
-    def __init__(self, index: Index, device: int = 0, **params):
+    def __init__(self, index: Index, device: int = 0, share: "Mapper | None" = None, **params):
+        """share: another Mapper on the same device whose attached index this one uses (bmbs_index_share) -- for two batches
+        in flight from two host threads; `share` has to stay open for as long as this one is used"""
         self._lib = capi.lib()
         self.params = capi.default_params(**params)
         self._ctx = self._lib.bmbs_create(device, C.byref(self.params))
         if not self._ctx:
             raise RuntimeError("bmbs_create failed: no usable HIP device (the mapper has no CPU path)")
         self.index = index
-        self._chk(self._lib.bmbs_index_attach(self._ctx, C.byref(index.view)))
+        self._owner = share
+        if share is None:
+            self._chk(self._lib.bmbs_index_attach(self._ctx, C.byref(index.view)))
+        else:
+            self._chk(self._lib.bmbs_index_share(self._ctx, share._ctx))
 
     def _chk(self, rc: int):
         if rc:

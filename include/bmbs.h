@@ -107,6 +107,9 @@ void      bmbs_destroy(bmbs_ctx*);
 const char* bmbs_last_error(const bmbs_ctx*);
 /* replaces the in-memory result of Load_Index + load_index: uploads once, re-packs for HBM        */
 int bmbs_index_attach(bmbs_ctx*, const bmbs_index_view*);
+/* a further context on the index `owner` has attached (same device): shares the index in HBM, owns its stream and work buffers.
+ * For keeping two batches in flight from two host threads; `owner` has to outlive it.                                  */
+int bmbs_index_share(bmbs_ctx*, const bmbs_ctx* owner);
 
 /* ---- stage entry points (host buffers in, host buffers out; used by the parity tests) ---------- */
 /* reads: n rows of `stride` bytes ASCII upper-case (as produced by inputReads_single_directly,

@@ -599,3 +599,27 @@ def test_ab_switches_give_identical_records(knob, env, monkeypatch):
     assert not compare_records(res, pool, recs, L)
     assert (m.stats() == ost).all()
     m.close()
+
+
+@pytest.mark.gpu
+def test_shared_index_contexts_map_concurrently(env):
+    """bmbs_index_share: three contexts on one attached index, driven by three host threads at once, give the oracle's records"""
+    from concurrent.futures import ThreadPoolExecutor
+    from bitmapperbs_amd import synth, mapper
+    owner = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    ms = [owner] + [mapper.Mapper(env["ix"], 0, share=owner, e_f=0.08) for _ in range(2)]
+    batches = [synth.make_reads_se(env["chroms"], n=15000, L=150, seed=500 + i, sub=0.03, indel=0.002, qual="random", n_rate=0.002) for i in range(3)]
+
+    def run(i):
+        out = None
+        for _ in range(3):                      # several calls per context while the others are busy too
+            out = ms[i].map_se(batches[i]["seq"], batches[i]["qual"], 150)
+        return out
+    with ThreadPoolExecutor(3) as ex:
+        outs = list(ex.map(run, range(3)))
+    for i in range(3):
+        recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), batches[i]["seq"], batches[i]["qual"], 150)
+        assert not compare_records(outs[i][0], outs[i][1], recs, 150)
+    for mm in ms[1:]:
+        mm.close()
+    owner.close()
