@@ -101,6 +101,19 @@ DEVI void hash_lookup(const DevIndex& ix, u64 key, u64& sp, u64& ep)
 // base code (A0 C1 G2 T3) at doubled coordinate d
 DEVI int gbase(const DevIndex& ix, u64 d) { return (int)((ix.gen2[d >> 5] >> ((d & 31) * 2)) & 3); }
 
+// chromosome of a forward-strand coordinate: the c with chrom_start[c] <= loc < chrom_start[c + 1], n_chrom when there is none.
+// Binary search: an assembly with its alternate contigs and decoys has thousands of sequences, and this runs once per read.
+DEVI int chrom_of(const DevIndex& ix, u64 loc)
+{
+    if (loc >= ix.chrom_start[ix.n_chrom]) return ix.n_chrom;
+    int lo = 0, hi = ix.n_chrom;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ix.chrom_start[mid] <= loc) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // window validity: get_actuall_genome / get_actuall_rc_genome return an all-zero window when the
 // request leaves the strand (Schema.cpp:5013-5019, 5076-5084; u64 wrap-around as in the reference)
 DEVI bool window_valid(const DevIndex& ix, u64 start, u64 len, bool fwd_strand)
@@ -2323,7 +2336,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
                     u64 loc = s_; int flag;
                     if (loc >= ix.G) { loc = ix.G * 2 - (loc + (u64)(L - 1)) - 1; flag = 16; } else flag = 0;
                     int c = 0;
-                    for (; c < ix.n_chrom; ++c) if (loc >= ix.chrom_start[c] && loc < ix.chrom_start[c + 1]) break;
+                    c = chrom_of(ix, loc);
                     if (c >= ix.n_chrom) continue;
                     const u64 pos = loc + 1 - ix.chrom_start[c];
                     if (pos + (u64)(L - 1) > ix.chrom_start[c + 1] - ix.chrom_start[c]) continue;
@@ -2358,7 +2371,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
             if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; flag = 16; }
             else { loc = loc + (u64)start_site; flag = 0; }
             int c = 0;
-            for (; c < ix.n_chrom; ++c) if (loc >= ix.chrom_start[c] && loc < ix.chrom_start[c + 1]) break;
+            c = chrom_of(ix, loc);
             bool ok = c < ix.n_chrom;
             u64 pos = 0;
             if (ok) {
@@ -3083,7 +3096,7 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
                 if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; rflag[m] = 16; }
                 else { loc = loc + (u64)start_site; rflag[m] = 0; }
                 int c = 0;
-                for (; c < ix.n_chrom; ++c) if (loc >= ix.chrom_start[c] && loc < ix.chrom_start[c + 1]) break;
+                c = chrom_of(ix, loc);
                 if (c >= ix.n_chrom) { c = ix.n_chrom - 1; inrange = false; }
                 chrom[m] = c;
                 site_pos[m] = (long long)(loc + 1 - ix.chrom_start[c]);

@@ -623,3 +623,29 @@ def test_shared_index_contexts_map_concurrently(env):
     for mm in ms[1:]:
         mm.close()
     owner.close()
+
+
+@pytest.mark.gpu
+def test_many_contigs_match_oracle(tmp_path):
+    """an assembly of 500 short sequences: placement by binary search over the contig starts (SE and PE)"""
+    from bitmapperbs_amd import synth, mapper
+    names, chroms = synth.make_genome(1_200_000, 500, seed=611)
+    fa = str(tmp_path / "contigs.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=8)
+    ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
+    r = synth.make_reads_se(chroms, n=30000, L=100, seed=612, sub=0.02, indel=0.002, qual="random", n_rate=0.002)
+    m = mapper.Mapper(ix, 0, e_f=0.08)
+    res, pool = m.map_se(r["seq"], r["qual"], 100)
+    recs, ost, cnt = oix.map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 100)
+    assert not compare_records(res, pool, recs, 100)
+    assert (m.stats() == ost).all()
+    assert len(set(int(x) for x in res["chrom"][res["status"] == 1])) > 300          # the reads really land on many contigs
+    m.close()
+    m1, m2 = synth.make_reads_pe(chroms, n=10000, L=100, seed=613, sub=0.02, indel=0.002, qual="random")
+    m = mapper.Mapper(ix, 0)
+    res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+    recs, ost, cnt = oix.map_pe(orc.params(), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+    assert not compare_pe(res, pool, recs, 100)
+    assert (m.stats() == ost).all()
+    m.close()
