@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement of the MI355X bisulfite mapping hot path.
 
-Workload (BASELINE.json configs[1]): synthetic 150 bp single-end bisulfite reads against a
-chr21-size (46 Mb, 4 chromosomes, N-free) synthetic genome, -e 0.04; one "step" = one pass of the
-whole device pipeline (seed -> locate -> vote -> Myers filter -> reduce -> align -> finalize) over one
-batch of reads that is already resident in HBM; results (32-byte records + CIGAR pool) stay in HBM.
+Default workload = BASELINE.json configs[2]: 50 M synthetic 150 bp read PAIRS against a GRCh38-size index (3.1 Gb random
+genome, 24 chromosomes, N-free: repeat-poor, unlike the real GRCh38 -- stated in `config.workload`), default (fast) paired-end
+mode, default -e 0.08 (k = 12), one MI355X.  One "step" = the whole 50 M-pair job: five launches of 10 M pairs, each one pass of
+the device pipeline (prepare -> seed -> locate/vote -> pair filter -> Myers -> pairing -> align -> finalize) over pairs that
+are already resident in HBM; the 32-byte records and the CIGAR pool stay in HBM.  `--config 1` = configs[1] (10 M 150 bp SE
+reads, 46 Mb genome, -e 0.04), `--config 3` = configs[3]'s per-GPU share (--sensitive), `--config 4` = configs[4] (250 bp).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--genome G]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] ...
 
-N > 1 is launched by torch.distributed.run (one rank per GPU); reads shard by rank (weak scaling,
-index replicated per GPU, no data-path collective); the only collective is the RCCL all-reduce of
-the five mapstats counters (Schema.cpp:451-476).  Rank 0 prints ONE JSON line.
+N > 1 without WORLD_SIZE in the environment: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a CHILD process before anything touches the GPU and exits with its code (a process that has initialised the GPU is never
+re-exec'ed).  One rank per GPU; pairs shard by rank (weak scaling, index replicated per GPU, no data-path collective); the only
+collective is the RCCL all-reduce of the five mapstats counters (Schema.cpp:451-476).  Rank 0 prints ONE JSON line.
+
+The index is built on the GPU (bmbs_index_build_device: 6.2 G suffixes in seconds) and cached under --workdir.
 """
 from __future__ import annotations
 
@@ -29,90 +34,118 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GATHER_CEILING_GREQ = 54.0   # measured on this chip: dependent divergent gathers/s (tools/gather_bench.hip, profiles/r01_gather_bench.txt)
 SECTOR_CEILING_GBS = 3100.0  # the same measurement in bytes: 48.4 G gathers/s over a 34 GB table x one 64-byte sector each
+MIN_TIMED_S = 2.0            # the timed region is stretched to at least this (whole extra passes per step) whatever --steps says
+
+CONFIGS = {
+    1: dict(pe=False, sensitive=False, genome=46_000_000, n_chrom=4, read_len=150, e=0.04, units=10_000_000, launches=1,
+            label="BASELINE configs[1]: 10 M synthetic 150 bp SE reads vs chr21-size genome, -e 0.04"),
+    2: dict(pe=True, sensitive=False, genome=3_100_000_000, n_chrom=24, read_len=150, e=0.08, units=10_000_000, launches=5,
+            label="BASELINE configs[2]: 50 M synthetic 150 bp PE read pairs vs GRCh38-size genome, default (fast) mode"),
+    3: dict(pe=True, sensitive=True, genome=3_100_000_000, n_chrom=24, read_len=150, e=0.08, units=5_000_000, launches=5,
+            label="BASELINE configs[3] per-GPU share: 25 M synthetic 150 bp PE read pairs vs GRCh38-size genome, --sensitive"),
+    4: dict(pe=True, sensitive=False, genome=3_100_000_000, n_chrom=24, read_len=250, e=0.08, units=2_500_000, launches=5,
+            label="BASELINE configs[4] share: 12.5 M synthetic 250 bp PE read pairs, -e 0.08 (k = 20), vs GRCh38-size genome"),
+}
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_fetch_write.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units as
-    rocprofv3 reports them).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (>=16 B/lane) coalesced
-    streams by 2x; the mapping kernels issue 4-16 B per-lane gathers, for which the guide gives no calibration,
-    so the raw (FETCH_SIZE + WRITE_SIZE) * 1024 is reported.  None when no profile has been committed."""
-    import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.csv")
-    if not os.path.exists(path):
-        return None
-    for row in csv.DictReader(open(path)):
-        if row["kernel"].split("<")[0] == kernel:
-            return int((float(row["FETCH_SIZE_KB_last_launch"]) + float(row["WRITE_SIZE_KB_last_launch"])) * 1024)
-    return None
-
-
-def gather_roofline(kernel, cnt, kern_ms):
-    c = cnt.get(kernel)
-    if not isinstance(c, dict) or kern_ms.get(kernel, 0) <= 0:
-        return None
-    req = c["n_hash"] + c["n_ext"] + c["n_sa"]
-    ach = req / (kern_ms[kernel] * 1e-3) / 1e9
-    return {"index_requests_per_launch": int(req), "achieved_Greq_s": round(ach, 2), "ceiling_Greq_s": GATHER_CEILING_GREQ,
-            "frac": round(ach / GATHER_CEILING_GREQ, 4),
-            "note": "counts index gathers only; read-character loads and result stores are further requests of the same kind"}
-
-
-def sector_roofline(kernel, kern_ms):
-    t = pmc_traffic(kernel)
-    if t is None or kern_ms.get(kernel, 0) <= 0:
-        return None
-    gbs = t / (kern_ms[kernel] * 1e-3) / 1e9
-    return {"traffic_GBps": round(gbs, 1), "random_sector_ceiling_GBps": SECTOR_CEILING_GBS, "frac": round(gbs / SECTOR_CEILING_GBS, 4)}
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--genome", type=int, default=46_000_000)
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("-e", type=float, default=0.04)
-    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed on the host CPU baseline (rank 0, N=1)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--pe", action="store_true", help="paired-end fast mode: --reads pairs per GPU per step (value counts 2 reads per pair)")
-    ap.add_argument("--sensitive", action="store_true", help="with --pe: Map_Pair_Seq_end_to_end (--sensitive) instead of fast mode")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--units", type=int, default=None, help="reads (SE) or pairs (PE) per launch per GPU")
+    ap.add_argument("--launches", type=int, default=None, help="launches per step (step = launches x units)")
+    ap.add_argument("--genome", type=int, default=None)
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("-e", type=float, default=None)
+    ap.add_argument("--pe", action="store_true", default=None)
+    ap.add_argument("--se", dest="pe", action="store_false")
+    ap.add_argument("--sensitive", action="store_true", default=None)
     ap.add_argument("--sub", type=float, default=0.005, help="substitution rate of the synthetic reads (SURVEY.md 8d: 0.5 %%)")
-    ap.add_argument("--repeats", type=int, default=0, help="stress: plant this many diverged copies of 300-bp elements (5 families, 2-8 %% divergence) into the genome")
+    ap.add_argument("--indel", type=float, default=0.0002, help="indel rate per base (SURVEY.md 8d: 0.02 %%; at most one per read)")
+    ap.add_argument("--qual", default="const", choices=["const", "random"])
+    ap.add_argument("--repeats", type=int, default=0, help="stress: plant this many diverged copies of 300-bp elements into the genome")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="reads / pairs timed on the host CPU baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-threads", type=int, default=None)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1] SE line, stress keys)")
+    ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S)
+    ap.add_argument("--host-index", action="store_true", help="build the index with the host builder (bmbs_index_build)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / collective check without a GPU: gloo, no mapping (tests)")
     ap.add_argument("--workdir", default=os.environ.get("BMBS_BENCH_DIR", "/tmp/bmbs_bench"))
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    cfg = dict(CONFIGS[a.config])
+    for key, attr in (("units", "units"), ("launches", "launches"), ("genome", "genome"), ("read_len", "read_len"), ("e", "e"),
+                      ("pe", "pe"), ("sensitive", "sensitive")):
+        v = getattr(a, attr)
+        if v is not None:
+            if cfg[key] != v:
+                cfg["label"] = "custom (from configs[%d])" % a.config
+            cfg[key] = v
+    if a.genome is not None and a.genome < 1_000_000_000:
+        cfg["n_chrom"] = 4
+    a.cfg = cfg
+    return a
 
 
-def ensure_index(args, rank, world, dist):
-    from bitmapperbs_amd import synth, mapper
-    rep = getattr(args, "repeats", 0)
-    wd = os.path.join(args.workdir, "g%d%s" % (args.genome, "_r%d" % rep if rep else ""))
-    fa = os.path.join(wd, "g.fa")
-    names, chroms = synth.make_genome(args.genome, 4, seed=20240229)
-    if rep:
+# ---- N > 1 launcher ------------------------------------------------------------------------------------------------------------
+def launch_children(args) -> int:
+    """--gpus N without a torchrun environment: start the N ranks as a child process tree.  Nothing in this process has
+    touched the GPU yet (torch is not even imported), and the child is a fresh interpreter."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- workload ------------------------------------------------------------------------------------------------------------------
+def make_genome(cfg, repeats=0):
+    from bitmapperbs_amd import synth
+    names, chroms = synth.make_genome(cfg["genome"], cfg["n_chrom"], seed=20240229)
+    if repeats:
         # interspersed-repeat stress (Alu-like): seeds inside a copy hit hundreds of places, candidate lists get long
         rng = np.random.default_rng(77)
         for fam in range(5):
             el = synth._ACGT[rng.integers(0, 4, 300)]
-            for _ in range(rep // 5):
+            for _ in range(repeats // 5):
                 ch = chroms[int(rng.integers(0, len(chroms)))]
                 p = int(rng.integers(0, ch.size - 300))
                 e = el.copy()
                 m = rng.random(300) < rng.uniform(0.02, 0.08)
                 e[m] = synth._ACGT[rng.integers(0, 4, int(m.sum()))]
                 ch[p:p + 300] = synth.revcomp(e) if rng.random() < 0.5 else e
+    return names, chroms
+
+
+def ensure_index(args, cfg, rank, local, world, dist, repeats=0):
+    """-> (fasta/prefix path, names, chroms, seconds spent building or 0 when cached)"""
+    from bitmapperbs_amd import synth, mapper
+    wd = os.path.join(args.workdir, "g%d_c%d%s" % (cfg["genome"], cfg["n_chrom"], "_r%d" % repeats if repeats else ""))
+    fa = os.path.join(wd, "g.fa")
+    names, chroms = make_genome(cfg, repeats)
+    built = 0.0
     if rank == 0:
         os.makedirs(wd, exist_ok=True)
-        if not os.path.exists(fa + ".index.bs.index.sa"):
-            synth.write_fasta(fa, names, chroms)
+        if not os.path.exists(fa + ".index.bs.index.sa.ok"):
             t = time.time()
-            mapper.Index.build(fa, fa, threads=min(64, os.cpu_count() or 1))
-            sys.stderr.write("[bench] index built in %.1fs\n" % (time.time() - t))
+            synth.write_fasta(fa, names, chroms)
+            threads = min(64, os.cpu_count() or 1)
+            if args.host_index:
+                mapper.Index.build(fa, fa, threads=threads)
+            else:
+                mapper.Index.build(fa, fa, threads=threads, device=local)
+            open(fa + ".index.bs.index.sa.ok", "w").write("ok\n")
+            built = time.time() - t
+            sys.stderr.write("[bench] %d bp index built in %.1f s (%s builder, FASTA write included)\n" %
+                             (cfg["genome"], built, "host" if args.host_index else "GPU"))
     if world > 1:
         dist.barrier()
-    return fa, names, chroms
+    return fa, names, chroms, built
 
 
 def write_fastq_sample(path, seq, qual, L):
@@ -131,101 +164,295 @@ def write_fastq_sample(path, seq, qual, L):
     rec.tofile(path)
 
 
-def cpu_baseline(args, fa, seq_h, qual_h, L):
-    """Time the reference's own CPU path (oracle/_ref/bitmapperBS, kind 'reference') -- or, when it has
-    not been built, the scalar restatement (oracle/liboracle.so, kind 'port') -- on a bounded sample."""
-    n = seq_h.shape[0]
+def cpu_baseline(args, cfg, fa, host_reads, L):
+    """Time the reference's own CPU path (oracle/_ref/bitmapperBS, kind 'reference') -- or, when it has not been built, the
+    scalar restatement (oracle/liboracle.so, kind 'port') -- on a bounded sample of the step's first launch.
+    host_reads = (seq, qual) or (seq1, qual1, seq2, qual2) numpy arrays."""
+    n = host_reads[0].shape[0]
+    pe = cfg["pe"]
     ref = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS")
-    sample = "first %d reads of the step batch (150 bp SE, e=%.2f)" % (n, args.e)
+    unit = "pairs" if pe else "reads"
+    sample = "first %d %s of the step's first launch (%d bp %s, -e %.2f%s)" % (
+        n, unit, L, "PE" if pe else "SE", cfg["e"], ", --sensitive" if cfg["sensitive"] else "")
     if os.path.exists(ref):
-        fq = os.path.join(args.workdir, "cpu_sample.fq")
-        write_fastq_sample(fq, seq_h, qual_h, L)
-        cores = min(8, os.cpu_count() or 1)
+        cores = args.cpu_threads or min(32, os.cpu_count() or 1)
         out = os.path.join(args.workdir, "cpu_sample.sam")
-        p = subprocess.run([ref, "--search", fa, "--seq", fq, "-e", str(args.e), "-t", str(cores), "-o", out],
-                           capture_output=True, text=True, cwd=args.workdir)
-        secs = None
+        cmd = [ref, "--search", fa]
+        if pe:
+            f1 = os.path.join(args.workdir, "cpu_sample_1.fq"); f2 = os.path.join(args.workdir, "cpu_sample_2.fq")
+            write_fastq_sample(f1, host_reads[0], host_reads[1], L)
+            write_fastq_sample(f2, host_reads[2], host_reads[3], L)
+            cmd += ["--seq1", f1, "--seq2", f2]
+            if cfg["sensitive"]:
+                cmd += ["--sensitive"]
+        else:
+            fq = os.path.join(args.workdir, "cpu_sample.fq")
+            write_fastq_sample(fq, host_reads[0], host_reads[1], L)
+            cmd += ["--seq", fq]
+        cmd += ["-e", str(cfg["e"]), "-t", str(cores), "-o", out]
+        t = time.time()
+        p = subprocess.run(cmd, capture_output=True, text=True, cwd=args.workdir)
+        wall = time.time() - t
+        secs = load = None
         for line in p.stderr.splitlines():
             if line.strip().startswith("Total:"):
-                secs = float(line.split()[2])          # "Total: <load s> <map s>" (Bitmapper_main.cpp:262)
+                load = float(line.split()[1]); secs = float(line.split()[2])   # "Total: <load s> <map s>" (Bitmapper_main.cpp:262)
         if p.returncode == 0 and secs and secs > 0:
-            return {"value": n / secs / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
-                    "sample": sample + ", bitmapperBS -t %d, mapping seconds as printed by main" % cores}, out
-    # port
+            nr = n * (2 if pe else 1)
+            return {"value": round(nr / secs / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "reference",
+                    "sample": sample + ", bitmapperBS -t %d, mapping seconds as printed by main (%.1f s; index load %.1f s; wall %.1f s)" % (
+                        cores, secs, load, wall)}, out
+        sys.stderr.write("[bench] reference run failed (rc %d): %s\n" % (p.returncode, p.stderr[-400:]))
+    if pe:
+        return None, None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     oix = orc.OrcIndex(fa)
     m = min(n, 300_000)
     t = time.time()
-    oix.map_se(orc.params(e_f=args.e), seq_h[:m], qual_h[:m], L)
+    oix.map_se(orc.params(e_f=cfg["e"]), host_reads[0][:m], host_reads[1][:m], L)
     dt = time.time() - t
-    return {"value": m / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads of the step batch, scalar CPU restatement (oracle/)" % m}, None
+    return {"value": round(m / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the step's first launch, scalar CPU restatement (oracle/)" % m}, None
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the mapping path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    from bitmapperbs_amd import mapper, gpusynth, capi
+# ---- roofline accounting --------------------------------------------------------------------------------------------------------
+def pmc_traffic(kernel, tag):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/<tag>_pmc_fetch_write.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units as rocprofv3
+    reports them).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (>= 16 B/lane) coalesced streams by 2x; the
+    mapping kernels issue 4-16 B per-lane gathers, for which the guide gives no calibration; tools/gather_bench (known byte
+    count, same access shape) reads 1.0x, so the raw (FETCH_SIZE + WRITE_SIZE) * 1024 is reported.  None when no profile of
+    this configuration has been committed."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write.csv" % tag)
+    if not os.path.exists(path):
+        return None
+    for row in csv.DictReader(open(path)):
+        if row["kernel"].split("<")[0] == kernel and row["FETCH_SIZE_KB_last_launch"] and row["WRITE_SIZE_KB_last_launch"]:
+            return int((float(row["FETCH_SIZE_KB_last_launch"]) + float(row["WRITE_SIZE_KB_last_launch"])) * 1024)
+    return None
 
-    fa, names, chroms = ensure_index(args, rank, world, dist)
-    L = args.read_len
-    stride = (L + 15) // 16 * 16
-    n = args.reads
-    ix = mapper.Index(fa)
-    m = mapper.Mapper(ix, device=local, e_f=args.e, sensitive=1 if args.sensitive else 0)
-    k = m.threshold(L)
-    genome_d, lens_d = gpusynth.upload_genome(chroms)
-    max_ops = 2 * k + 8
-    if not args.pe:
-        seq_d, qual_d = gpusynth.make_reads_se(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank, sub=args.sub)
-        cig_cap = n * max_ops
-        res_d = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
-    else:
-        seq_d, qual_d, seq2_d, qual2_d = gpusynth.make_reads_pe(genome_d, lens_d, n, L, stride, seed=7 + 1000 * rank, sub=args.sub)
-        cig_cap = 2 * n * max_ops
-        res_d = torch.empty((2 * n, 32), dtype=torch.uint8, device="cuda")
-    del genome_d
-    cig_d = torch.empty((cig_cap,), dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
 
-    def step():
-        if not args.pe:
-            m.map_se_device(seq_d.data_ptr(), qual_d.data_ptr(), L, stride, n, res_d.data_ptr(), cig_d.data_ptr(), cig_cap)
+def algorithmic_bytes(cnt, nr, L, k, pe):
+    """per-launch ALGORITHMIC bytes of every mapping kernel, two models side by side:
+    `s8d`  = SURVEY.md section 8(d)'s terms only: 10 B per 16-mer lookup, 80 B per backward extension (two 40-B Occ blocks), 4 B
+             per suffix-array read, (ceil((L+2k)/4)+1) B per fetched window, the read characters a kernel consumes (1 B each;
+             8(d)'s "2L seq+qual in"), 32 B per result record;
+    `own`  = the builder's model of round 1: the same plus the 16-byte seed record written per lookup and the carry /
+             verdict records between the seeding kernels (traffic this design adds and has to pay for)."""
+    win = (L + 2 * k + 3) // 4 + 1
+    def seed_idx(c):
+        return 10 * c["n_hash"] + 80 * c["n_ext"] + 4 * c["n_sa"]
+    def seed_chars(c):
+        return 16 * c["n_hash"] + c["n_ext"]
+    s8d, own = {}, {}
+    for kn in ("k_seed_first", "k_seed_second", "k_seed_extra"):
+        c = cnt[kn]
+        s8d[kn] = seed_idx(c) + seed_chars(c)
+        own[kn] = s8d[kn] + 16 * c["n_hash"] + (14 * nr if kn == "k_seed_first" else 24 * c["n_hash"] if kn == "k_seed_second" else 0)
+    s8d["k_seed_decide"] = L * nr + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1) * cnt["n_ungapped"]
+    own["k_seed_decide"] = s8d["k_seed_decide"] + (14 + 40) * nr
+    cand = cnt["n_cand_slots"]
+    for kn in ("k_vote_fused", "k_vote_pe_fused"):
+        s8d[kn] = 4 * cand; own[kn] = (4 + 16 + 4) * cand
+    for kn in ("k_filter", "k_filter_pe_r1"):
+        s8d[kn] = (win + L) * cnt["n_filter"]; own[kn] = (win + L + 24) * cnt["n_filter"]
+    s8d["k_align_ungapped"] = (win + 2 * L) * cnt["n_jobs"]; own["k_align_ungapped"] = (win + 2 * L + 16) * cnt["n_jobs"]
+    s8d["k_align_sw"] = (win + 2 * L) * cnt["n_sw"]; own["k_align_sw"] = (win + 2 * L + 16) * cnt["n_sw"]
+    for kn in ("k_finalize", "k_finalize_pe"):
+        s8d[kn] = 32 * nr; own[kn] = 32 * nr
+    if pe:
+        s8d["k_pe_prepare"] = 2 * L * nr; own["k_pe_prepare"] = 2 * L * nr       # both mates read, the working copy written
+    return s8d, own
+
+
+def gather_roofline(kernel, cnt, kern_ms):
+    c = cnt.get(kernel)
+    if not isinstance(c, dict) or kern_ms.get(kernel, 0) <= 0:
+        return None
+    req = c["n_hash"] + c["n_ext"] + c["n_sa"]
+    ach = req / (kern_ms[kernel] * 1e-3) / 1e9
+    return {"index_requests_per_launch": int(req), "achieved_Greq_s": round(ach, 2), "ceiling_Greq_s": GATHER_CEILING_GREQ,
+            "frac": round(ach / GATHER_CEILING_GREQ, 4),
+            "note": "counts index gathers only; read-character loads and result stores are further requests of the same kind"}
+
+
+# ---- one measured configuration ---------------------------------------------------------------------------------------------------
+class Job:
+    """reads of one configuration resident in HBM + the launch closure"""
+
+    def __init__(self, m, cfg, chroms, rank, sub, indel, qual, genome_d=None):
+        import torch
+        from bitmapperbs_amd import gpusynth
+        self.m, self.cfg = m, cfg
+        L = cfg["read_len"]
+        self.L = L
+        self.stride = (L + 15) // 16 * 16
+        self.n = cfg["units"]
+        self.k = m.threshold(L)
+        self.max_ops = 2 * self.k + 8
+        own = genome_d is None
+        if own:
+            genome_d = gpusynth.upload_genome(chroms)
+        g, lens = genome_d
+        self.batches = []
+        for b in range(cfg["launches"]):
+            seed = 7 + 1000 * rank + 101 * b
+            if cfg["pe"]:
+                self.batches.append(gpusynth.make_reads_pe(g, lens, self.n, L, self.stride, seed=seed, sub=sub, indel=indel, qual=qual))
+            else:
+                self.batches.append(gpusynth.make_reads_se(g, lens, self.n, L, self.stride, seed=seed, sub=sub, indel=indel, qual=qual))
+        if own:
+            del g, lens, genome_d
+            torch.cuda.empty_cache()
+        nrec = self.n * (2 if cfg["pe"] else 1)
+        self.reads_per_launch = nrec
+        self.cig_cap = nrec * self.max_ops
+        self.res_d = torch.empty((nrec, 32), dtype=torch.uint8, device="cuda")
+        self.cig_d = torch.empty((self.cig_cap,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+
+    def launch(self, b):
+        t = self.batches[b]
+        if self.cfg["pe"]:
+            self.m.map_pe_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), self.L, self.stride, self.n,
+                                 self.res_d.data_ptr(), self.cig_d.data_ptr(), self.cig_cap)
         else:
-            m.map_pe_device(seq_d.data_ptr(), qual_d.data_ptr(), seq2_d.data_ptr(), qual2_d.data_ptr(), L, stride, n,
-                            res_d.data_ptr(), cig_d.data_ptr(), cig_cap)
-        m.sync()
+            self.m.map_se_device(t[0].data_ptr(), t[1].data_ptr(), self.L, self.stride, self.n, self.res_d.data_ptr(),
+                                 self.cig_d.data_ptr(), self.cig_cap)
 
-    for _ in range(args.warmup):
-        step()
-    m.reset_stats()
-    m.sync()
+    def step(self, kern_ms=None):
+        for b in range(len(self.batches)):
+            self.launch(b)
+            if kern_ms is not None:
+                for name, ms in self.m.profile():
+                    kern_ms[name] = kern_ms.get(name, 0.0) + ms
+        self.m.sync()
+
+    def reads_per_step(self):
+        return self.reads_per_launch * len(self.batches)
+
+
+def timed(job, steps, warmup, min_seconds, world, dist, torch):
+    """W warm-up steps, then K timed steps between barrier + synchronize; a step is repeated `passes` whole times when K steps
+    would take less than min_seconds.  -> (seconds, passes, per-launch kernel ms averages)"""
+    t_w = None
+    for _ in range(max(1, warmup)):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        job.step()
+        torch.cuda.synchronize()
+        t_w = time.perf_counter() - t
+    passes = 1
+    if min_seconds > 0 and t_w * steps < min_seconds:
+        passes = int(np.ceil(min_seconds / (t_w * steps)))
+    if world > 1:
+        pt = torch.tensor([passes], dtype=torch.int64, device="cuda")
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        passes = int(pt.item())
+    job.m.reset_stats()
+    job.m.sync()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     kern_ms: dict[str, float] = {}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for name, ms in m.profile():
-            kern_ms[name] = kern_ms.get(name, 0.0) + ms
+    for _ in range(steps):
+        for _ in range(passes):
+            job.step(kern_ms)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    launches = steps * passes * len(job.batches)
+    for kname in kern_ms:
+        kern_ms[kname] /= max(1, launches)
+    return dt, passes, kern_ms
+
+
+def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3):
+    """a short secondary measurement on its own index / mapper: -> dict(value, ms_per_launch, ...)"""
+    import torch
+    from bitmapperbs_amd import mapper
+    old = {}
+    for k_, v_ in (env or {}).items():
+        old[k_] = os.environ.get(k_); os.environ[k_] = v_
+    try:
+        fa, names, chroms, built = ensure_index(args, cfg, rank, local, 1, None, repeats=repeats)
+        ix = mapper.Index(fa)
+        m = mapper.Mapper(ix, device=local, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0)
+        job = Job(m, cfg, chroms, rank, args.sub if sub is None else sub, args.indel, qual)
+        dt, passes, kern_ms = timed(job, steps, 1, 0.5, 1, None, torch)
+        nreads = job.reads_per_step() * steps * passes
+        top = sorted(((v, k_) for k_, v in kern_ms.items() if k_.startswith("k_")), reverse=True)[:3]
+        out = {"what": label, "value": round(nreads / dt / 1e6, 2), "unit": "Mreads/s", "timed_s": round(dt, 3),
+               "ms_per_launch": round(dt / (steps * passes * len(job.batches)) * 1e3, 3),
+               "top_kernels_ms": {k_: round(v, 3) for v, k_ in top}}
+        m.close(); ix.close()
+        del job
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        for k_, v_ in old.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(args))
+    cfg = args.cfg
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("[bench] --gpus %d but WORLD_SIZE=%d: reporting the world size the process group has\n" % (args.gpus, world))
+    import torch
+    dist = None
+    if args.dry_run:
+        # launcher / collective plumbing only (CPU tests): gloo, no device, no mapping
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        st = torch.tensor([rank + 1, 1, 0, 0, 0], dtype=torch.int64)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "n_gpus": dist.get_world_size(), "mapstats_sum": st.tolist()}), flush=True)
+        dist.destroy_process_group()
+        return
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        world = dist.get_world_size()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the mapping path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    from bitmapperbs_amd import mapper, capi
+
+    t_all = time.time()
+    fa, names, chroms, built_s = ensure_index(args, cfg, rank, local, world, dist, repeats=args.repeats)
+    L = cfg["read_len"]
+    t = time.time()
+    ix = mapper.Index(fa)
+    load_s = time.time() - t
+    t = time.time()
+    m = mapper.Mapper(ix, device=local, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0)
+    m.sync()
+    attach_s = time.time() - t
+    k = m.threshold(L)
+    t = time.time()
+    job = Job(m, cfg, chroms, rank, args.sub, args.indel, args.qual)
+    synth_s = time.time() - t
+    del chroms
+
+    dt, passes, kern_ms = timed(job, args.steps, args.warmup, args.min_seconds, world, dist, torch)
     stats = torch.from_numpy(m.stats()).cuda()
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -233,86 +460,103 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)        # the only collective: 5 x int64 mapstats
     dt = float(tt.item())
     stats = stats.cpu().numpy()
-    cnt = m.counters()
-    for kname in kern_ms:
-        kern_ms[kname] /= max(1, args.steps)
+    cnt = m.counters()                                       # event counters of the LAST launch
 
     if rank == 0:
-        reads_per_unit = 2 if args.pe else 1
-        nr = n * reads_per_unit                     # reads seeded per launch
-        total_reads = nr * world * args.steps
+        pe = cfg["pe"]
+        nr = job.reads_per_launch                            # reads seeded per launch
+        reads_per_step = job.reads_per_step() * passes
+        total_reads = reads_per_step * world * args.steps
         value = total_reads / dt / 1e6
         mapping = {kn: v for kn, v in kern_ms.items() if kn.startswith("k_")}
         dom = max(mapping, key=mapping.get) if mapping else "k_seed_first"
-        # ALGORITHMIC bytes of one launch = SURVEY.md §8d per-unit figures x this launch's event counts
-        # (10 B per 16-mer lookup, 80 B per backward extension = two 40-B Occ blocks, 4 B per SA read,
-        #  ceil(len/4)+1 B per fetched window, read characters actually consumed, 16 B per recorded seed)
-        win = (L + 2 * k + 3) // 4 + 1
-        def seed_bytes(c):
-            return 10 * c["n_hash"] + 80 * c["n_ext"] + 16 * c["n_hash"] + c["n_ext"] + 16 * c["n_hash"]
-        alg = {
-            "k_seed_first": seed_bytes(cnt["k_seed_first"]) + 14 * nr,
-            # every read row once (staged through LDS), carry-in + verdict records, one SA word and one window per verified read
-            "k_seed_decide": (L + 14 + 40) * nr + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1) * cnt["n_ungapped"],
-            "k_seed_second": seed_bytes(cnt["k_seed_second"]) + 4 * cnt["k_seed_second"]["n_sa"] + 24 * cnt["k_seed_second"]["n_hash"],
-            "k_seed_extra": seed_bytes(cnt["k_seed_extra"]),
-            "k_locate": (4 + 8) * cnt["n_cand_slots"],
-            "k_vote": (8 + 16 + 4) * cnt["n_cand_slots"],
-            "k_vote_fused": (4 + 16 + 4) * cnt["n_cand_slots"],
-            "k_filter": (win + L + 16 + 8) * cnt["n_filter"],
-            "k_align_ungapped": (win + 2 * L + 16) * cnt["n_jobs"],
-            "k_align_sw": (win + 2 * L + 16) * cnt["n_sw"],
-            "k_finalize": 32 * nr,
-        }
-        bytes_dom = alg.get(dom, 0)
-        ach = bytes_dom / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0
-        rl_all = {kn: round(alg[kn] / (kern_ms[kn] * 1e-3) / 1e9, 2) for kn in alg if kern_ms.get(kn, 0) > 0}
+        s8d, own = algorithmic_bytes(cnt, nr, L, k, pe)
+        tag = "r02_c%d" % args.config
+        def rl(model):
+            b = model.get(dom, 0)
+            a = b / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0
+            return b, a
+        b8, a8 = rl(s8d)
+        bo, ao = rl(own)
+        traffic = pmc_traffic(dom, tag)
         out = {
-            "metric": "M 150bp %s reads aligned/s" % ("PE" if args.pe else "SE"), "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "metric": "M %dbp %s reads aligned/s" % (L, "PE" if pe else "SE"), "value": round(value, 4), "unit": "Mreads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: %d synthetic %d bp SE bisulfite reads" % (n, L) if not args.pe else
-                                    "%d synthetic %d bp read PAIRS (%s PE mode, insert 170-400, substitutions %.3f)" % (n, L, "sensitive" if args.sensitive else "fast", args.sub)) +
-                                   " per GPU per step vs %d bp 4-chromosome synthetic (chr21-size) genome, -e %.2f (k=%d), inputs and "
-                                   "results resident in HBM" % (args.genome, args.e, k),
-                       "reads_per_gpu_per_step": n, "read_len": L, "genome_bp": args.genome,
-                       "parallelism": "reads sharded by rank, index replicated, RCCL all-reduce of 5 mapstats counters"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom),
-                         "algorithmic_bytes_per_launch": int(bytes_dom), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4),
-                         # the same kernel against the bound that really applies to an index walk: divergent gather requests/s
-                         # (index lookups only: one per 16-mer table access, backward extension, SA read) vs the measured ceiling
+            "config": {"workload": "%s; one step = %d launch(es) x %d %s%s per GPU; %d bp %d-chromosome uniform-random N-free synthetic genome "
+                                   "(repeat-poor: NOT representative of GRCh38's repeat structure), -e %.2f (k=%d), %s, substitutions %.3f, "
+                                   "indels %.4f/bp, qualities %s; inputs and results resident in HBM" % (
+                                       cfg["label"], len(job.batches), job.n, "pairs" if pe else "reads",
+                                       " x %d passes (timed region stretched to >= %.1f s)" % (passes, args.min_seconds) if passes > 1 else "",
+                                       cfg["genome"], cfg["n_chrom"], cfg["e"], k,
+                                       ("PE --sensitive" if cfg["sensitive"] else "PE fast mode") if pe else "SE", args.sub, args.indel, args.qual),
+                       "reads_per_gpu_per_step": reads_per_step, "units_per_launch": job.n, "launches_per_step": len(job.batches) * passes,
+                       "read_len": L, "genome_bp": cfg["genome"], "timed_s": round(dt, 3),
+                       "parallelism": "pairs sharded by rank, index replicated, RCCL all-reduce of 5 mapstats counters"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(a8, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(a8 / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(b8), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4),
+                         "model": "SURVEY 8(d) terms: 10 B/16-mer lookup, 80 B/extension, 4 B/SA read, window bytes, read characters consumed, 32 B/record",
+                         # the builder's own model (adds the seed / carry records this design writes) next to it
+                         "builder_model": {"algorithmic_bytes_per_launch": int(bo), "achieved": round(ao, 3), "frac": round(ao / HBM_PEAK_GBS, 6)},
+                         "traffic_over_algorithmic": round(traffic / b8, 3) if traffic and b8 else None,
+                         # the same kernel against the bound that applies to an index walk: divergent gather requests/s
                          "gather": gather_roofline(dom, cnt, kern_ms),
-                         # and in bytes: the HBM-side traffic of the committed PMC pass over the live launch time, against
-                         # what the chip delivers when every 64-byte sector is a random access of its own
-                         "sectors": sector_roofline(dom, kern_ms)},
-            "kernels_ms_per_step": {a: round(b, 4) for a, b in kern_ms.items()},
-            "kernels_algorithmic_GBps": rl_all,
-            "counters_per_step": cnt,
-            "mapstats": {"reads": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
+                         "sectors": ({"traffic_GBps": round(traffic / (kern_ms[dom] * 1e-3) / 1e9, 1), "random_sector_ceiling_GBps": SECTOR_CEILING_GBS,
+                                      "frac": round(traffic / (kern_ms[dom] * 1e-3) / 1e9 / SECTOR_CEILING_GBS, 4)} if traffic else None)},
+            "kernels_ms_per_launch": {a: round(b, 4) for a, b in kern_ms.items()},
+            "kernels_algorithmic_GBps": {kn: round(s8d[kn] / (kern_ms[kn] * 1e-3) / 1e9, 2) for kn in s8d if kern_ms.get(kn, 0) > 0},
+            "counters_last_launch": cnt,
+            "mapstats": {"reads_or_pairs": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                          "unmapped": int(stats[0] - stats[1] - stats[2]), "mapped_bases": int(stats[3]), "error_bases": int(stats[4])},
+            "index": {"build_s": round(built_s, 1), "builder": "host" if args.host_index else "gpu", "files_load_s": round(load_s, 1),
+                      "attach_s": round(attach_s, 1), "read_synthesis_s": round(synth_s, 1)},
         }
-        if world == 1 and not args.no_cpu and not args.pe:
-            ns = min(n, args.cpu_sample)
-            seq_h = seq_d[:ns].cpu().numpy()
-            qual_h = qual_d[:ns].cpu().numpy()
-            cb, ref_sam = cpu_baseline(args, fa, seq_h, qual_h, L)
+        if world == 1 and not args.no_cpu:
+            ns = min(job.n, args.cpu_sample or (1_000_000 if pe else 8_000_000))
+            host = [x[:ns].cpu().numpy() for x in job.batches[0]]
+            cb, ref_sam = cpu_baseline(args, cfg, fa, host, L)
             out["cpu_baseline"] = cb
             if ref_sam:
-                # bonus check: the GPU records of the same sample print the same SAM lines as the reference
-                nchk = min(ns, 200_000)
-                res_h = res_d[:nchk].cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1)
-                cig_h = cig_d.cpu().numpy().view(np.uint32)
+                # the GPU records of the same sample print the same SAM lines as the reference
+                nchk = min(ns, 100_000 if pe else 200_000)
+                job.launch(0); m.sync()
+                nrec = nchk * (2 if pe else 1)
+                res_h = job.res_d[:nrec].cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1)
+                cig_h = job.cig_d.cpu().numpy().view(np.uint32)
                 names_s = [b"s%08d" % i for i in range(nchk)]
-                mine = set(mapper.sam_lines_se(ix, names_s, seq_h[:nchk], qual_h[:nchk], L, res_h, cig_h))
+                if pe:
+                    mine = set(mapper.sam_lines_pe(ix, names_s, names_s, host[0][:nchk], host[1][:nchk], host[2][:nchk], host[3][:nchk], L, res_h, cig_h))
+                else:
+                    mine = set(mapper.sam_lines_se(ix, names_s, host[0][:nchk], host[1][:nchk], L, res_h, cig_h))
                 with open(ref_sam) as f:
                     theirs = set(x for x in f if not x.startswith("@") and int(x[1:x.index("\t")]) < nchk)
                 out["sample_sam_identical_to_reference"] = (mine == theirs)
                 out["sample_sam_lines_compared"] = len(theirs)
         else:
             out["cpu_baseline"] = None
+    m.close(); ix.close()
+    del job
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_secondary:
+            # secondary keys: the configs[1] line of round 1 and the stress cases (each on its own short timed region)
+            sec = {}
+            c1 = dict(CONFIGS[1])
+            small = dict(cfg, genome=46_000_000, n_chrom=4, launches=1, units=min(cfg["units"], 5_000_000))
+            try:
+                if args.config != 1:
+                    sec["configs1_se_chr21"] = secondary(args, CONFIGS[1]["label"], c1, rank, local)
+                one = dict(cfg, launches=1)
+                sec["random_qualities"] = secondary(args, "main configuration, Phred 2..40 uniform-random qualities", one, rank, local, qual="random")
+                sec["sub_5pct"] = secondary(args, "main configuration, 5 % substitutions", one, rank, local, sub=0.05)
+                sec["no_20mer_table"] = secondary(args, "main configuration, BMBS_T20=0 (16-mer table + Occ walk only)", one, rank, local, env={"BMBS_T20": "0"})
+                sec["repeats_50000"] = secondary(args, "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)
+            except Exception as ex:      # a secondary key must never lose the headline line
+                sec["error"] = repr(ex)
+            out["secondary"] = sec
+        out["wall_s"] = round(time.time() - t_all, 1)
         print(json.dumps(out), flush=True)
-    m.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -21,7 +21,7 @@ SYMBOLS = [
     "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
-    "bmbs_index_file_free", "bmbs_index_build", "bmbs_host_alloc", "bmbs_host_free",
+    "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free",
 ]
 
 
@@ -104,6 +104,7 @@ def lib() -> C.CDLL:
     L.bmbs_index_file_free.argtypes = [vp]
     L.bmbs_index_file_free.restype = None
     L.bmbs_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.bmbs_index_build_device.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     L.bmbs_host_alloc.argtypes = [u64]
     L.bmbs_host_alloc.restype = vp
     L.bmbs_host_free.argtypes = [vp]
@@ -111,7 +112,7 @@ def lib() -> C.CDLL:
     for name in ("bmbs_index_attach", "bmbs_index_share", "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se",
                  "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
                  "bmbs_map_se_device", "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce",
-                 "bmbs_profile_last", "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_build"):
+                 "bmbs_profile_last", "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_build", "bmbs_index_build_device"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

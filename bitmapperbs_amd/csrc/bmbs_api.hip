@@ -484,7 +484,8 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->stats, &c->counters, &c->pe_seq, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
-                     &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list};
+                     &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list,
+                     &c->mapq_off, &c->klut, &c->in_len};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -500,12 +501,19 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     const u64 G = v->ref_len, n = 2 * G, rows = n + 1;
     if (v->sa_length != rows) { c->err = "index view: sa_length != 2*ref_len + 1"; return BMBS_EINVAL; }
     if (rows >= (1ull << 36)) { c->err = "genome too large: rows must fit the 36-bit fields of the 16-mer table"; return BMBS_EINVAL; }
+    if (v->n_chrom < 1 || v->n_chrom > 32767) { c->err = "index view: n_chrom must be 1..32767 (bmbs_result.chrom is a 16-bit field)"; return BMBS_EINVAL; }
     // texts of 2^32 symbols and more (GRCh38) take the wide forms: 64-bit suffix array, Occ counts relative to the reference's
     // super-block table; BMBS_WIDE=1 forces them on a small index (tests)
     const char* wide_env = getenv("BMBS_WIDE");
     const bool wide = rows >= (1ull << 32) || (wide_env && !strcmp(wide_env, "1"));
     // upload the reference layouts verbatim, re-pack on the device, drop the originals
     DevBuf t_bwt, t_ho, t_hh, t_hl, t_sa, t_fl, t_pac;
+    // the staging copies are released on every path out of this function (also the HIPCHK early returns)
+    struct Staging {
+        DevBuf* b[7];
+        ~Staging() { for (DevBuf* x : b) release(*x); }
+    } staging = {{&t_bwt, &t_ho, &t_hh, &t_hl, &t_sa, &t_fl, &t_pac}};
+    (void)staging;
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         int rc = ensure(c, b, bytes + 64);
         if (rc) return rc;
@@ -521,8 +529,7 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     rc |= up(t_sa, v->sa, v->sa_entries * 4);
     rc |= up(t_fl, v->sa_flag, v->sa_flag_words * 8);
     rc |= up(t_pac, v->pac, v->pac_bytes);
-    auto drop = [&]() { release(t_bwt); release(t_ho); release(t_hh); release(t_hl); release(t_sa); release(t_fl); release(t_pac); };
-    if (rc) { drop(); c->err = "index upload failed"; return BMBS_ENOMEM; }
+    if (rc) { c->err = "index upload failed"; return BMBS_ENOMEM; }
     RefIndexDev R;
     R.bwt = t_bwt.as<u64>(); R.high_occ = t_ho.as<u64>(); R.hash_hi = t_hh.as<u32>(); R.hash_lo = t_hl.as<u8>();
     R.sa = t_sa.as<u32>(); R.sa_flag = t_fl.as<u64>(); R.pac = t_pac.as<u8>();
@@ -532,7 +539,7 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     for (int i = 0; i < v->n_chrom; i++) cs[i + 1] = cs[i] + v->chrom_len[i];
     if (ensure(c, c->occ, n_blk * 16) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * (wide ? 8 : 4)) ||
         ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8) ||
-        (wide && ensure(c, c->occ_super, v->high_occ_words * 8 + 64))) { drop(); return BMBS_ENOMEM; }
+        (wide && ensure(c, c->occ_super, v->high_occ_words * 8 + 64))) return BMBS_ENOMEM;
     if (wide) HIPCHK(c, hipMemcpyAsync(c->occ_super.p, t_ho.p, v->high_occ_words * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->chrom_start.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, wide ? 1 : 0, c->occ.as<uint4>());
@@ -560,7 +567,6 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
         }
     }
     hipError_t e = hipStreamSynchronize(c->stream);
-    drop();
     if (e != hipSuccess) { c->err = std::string("index re-pack: ") + hipGetErrorString(e); return BMBS_ENODEV; }
     c->ix = ix; c->rows = rows; c->attached = true;
     return BMBS_OK;
@@ -1061,6 +1067,9 @@ extern "C" int bmbs_filter_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_cand <= 0) return BMBS_OK;
+    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (!seq || !read_of || !site || !err || !end_site) { c->err = "filter batch: NULL buffer"; return BMBS_EINVAL; }
+    for (int64_t i = 0; i < n_cand; i++) if ((int64_t)read_of[i] >= n_reads) { c->err = "filter batch: read_of out of range"; return BMBS_EINVAL; }
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_cand;
     { const int r0 = prepare_luts(c); if (r0) return r0; }
     ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->ferr, m * 4); ENS(c, c->fend, m * 4);
@@ -1084,6 +1093,9 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_jobs <= 0) return BMBS_OK;
+    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (max_ops < 2 * threshold_k(c->prm, L) + 8) { c->err = "align batch: max_ops must be at least 2*k+8"; return BMBS_EINVAL; }
+    for (int64_t i = 0; i < n_jobs; i++) if ((int64_t)read_of[i] >= n_reads) { c->err = "align batch: read_of out of range"; return BMBS_EINVAL; }
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_jobs;
     { const int r0 = prepare_luts(c); if (r0) return r0; }
     ENS(c, c->in_a, m * 4); ENS(c, c->in_b, m * 8); ENS(c, c->in_c, m * 4); ENS(c, c->in_d, m * 4);
@@ -1123,6 +1135,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     const u64 n = (u64)n_reads, bytes = n * (u64)stride;
     if (total_slots) *total_slots = 0;
     if (n == 0) return BMBS_OK;
+    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     { const int r0 = prepare_luts(c); if (r0) return r0; }
     c->n_prof_used = 0;
     int rc = per_read_workspace(c, n);

@@ -8,6 +8,7 @@
 //   <p>.index.bs.index.sa  sampled SA + SA_flag      bwt.cpp:2612-2635
 //   <p>.index.bs.index.occ super-block Occ           bwt.cpp:2638-2643
 #include "../../include/bmbs.h"
+#include "index_io.h"
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -18,34 +19,52 @@
 #include <functional>
 #include <vector>
 
-namespace {
-typedef uint64_t u64; typedef uint32_t u32; typedef uint8_t u8;
+using namespace bmbs_io;
 
-struct Chrom { std::string name; u64 len; };
+namespace bmbs_io {
 
+// FASTA -> chromosome table + upper-cased bases (header = first word of the '>' line)
 bool slurp_fasta(const char* path, std::vector<Chrom>& chroms, std::vector<char>& gen)
 {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
-    std::vector<char> buf(1 << 22);
+    if (fseek(f, 0, SEEK_END) == 0) { long sz = ftell(f); if (sz > 0) gen.reserve((size_t)sz); }
+    rewind(f);
+    static unsigned char up[256];
+    for (int i = 0; i < 256; i++) up[i] = (unsigned char)toupper(i);
+    std::vector<char> buf(1 << 24);
     bool hdr = false;
     std::string h;
     size_t got;
     while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) {
-        for (size_t i = 0; i < got; i++) {
-            char c = buf[i];
+        size_t i = 0;
+        while (i < got) {
             if (hdr) {
-                if (c == '\n') {
-                    hdr = false;
+                const char* nl = (const char*)memchr(buf.data() + i, '\n', got - i);
+                const size_t e = nl ? (size_t)(nl - buf.data()) : got;
+                h.append(buf.data() + i, e - i);
+                i = e;
+                if (nl) {
+                    hdr = false; i++;
                     size_t k = h.find(' ');
                     Chrom ch; ch.name = k == std::string::npos ? h : h.substr(0, k); ch.len = 0;
+                    while (!ch.name.empty() && isspace((unsigned char)ch.name.back())) ch.name.pop_back();
                     chroms.push_back(ch);
-                } else h.push_back(c);
-            } else if (c == '>') { hdr = true; h.clear(); }
-            else if (!isspace((unsigned char)c)) {
-                gen.push_back((char)toupper((unsigned char)c));
-                if (!chroms.empty()) chroms.back().len++;
+                }
+                continue;
             }
+            if (buf[i] == '>') { hdr = true; h.clear(); i++; continue; }
+            // one sequence line (or the rest of the buffer)
+            const char* nl = (const char*)memchr(buf.data() + i, '\n', got - i);
+            size_t e = nl ? (size_t)(nl - buf.data()) : got;
+            const size_t before = gen.size();
+            gen.resize(before + (e - i));
+            char* o = gen.data() + before;
+            size_t m = 0;
+            for (size_t q = i; q < e; q++) { const unsigned char c = (unsigned char)buf[q]; if (c > ' ') o[m++] = (char)up[c]; }
+            gen.resize(before + m);
+            if (!chroms.empty()) chroms.back().len += m;
+            i = nl ? e + 1 : e;
         }
     }
     fclose(f);
@@ -172,16 +191,6 @@ void suffix_sort(const std::vector<u8>& T, u64 n, std::vector<Idx>& sa, int n_th
     }
 }
 
-struct Built {
-    std::vector<Chrom> chroms;
-    u64 G = 0;
-    std::vector<u8> pac;
-    u64 sa_length = 0, shapline = 0, nacgt[5] = {0, 0, 0, 0, 0};
-    std::vector<u64> bwt, high_occ, sa_flag;
-    std::vector<u32> hash_hi, sa;
-    std::vector<u8> hash_lo;
-};
-
 int write_files(const Built& B, const std::string& base)
 {
     FILE* f = fopen(base.c_str(), "wb");
@@ -211,7 +220,7 @@ int write_files(const Built& B, const std::string& base)
     fclose(f);
     return BMBS_OK;
 }
-}  // namespace
+}  // namespace bmbs_io
 
 struct bmbs_index_file {
     std::vector<Chrom> chroms;
@@ -226,6 +235,69 @@ struct bmbs_index_file {
 
 namespace { template <class Idx> int build_tail(Built& B, const std::vector<u8>& T, u64 n, const char* prefix, int n_threads); }
 
+namespace bmbs_io {
+void fill_hash_table(Built& B, const u64* top, const u64* bot)
+{
+    const u64 HS = 43046721ULL + 1;
+    B.hash_hi.assign(HS, 0); B.hash_lo.assign(HS, 0);
+    u64 run = 1;
+    B.hash_hi[0] = 0; B.hash_lo[0] = 1;
+    for (u64 key = 0; key < HS - 1; key++) {
+        if (bot[key]) {
+            const u64 tp = top[key], bt = bot[key];
+            B.hash_hi[key] = (u32)(tp >> 8) | ((u32)(tp - run) << 28);
+            B.hash_lo[key] = (u8)tp;
+            B.hash_hi[key + 1] = (u32)(bt >> 8); B.hash_lo[key + 1] = (u8)bt;
+            run = bt;
+        } else {
+            B.hash_hi[key] = (u32)(run >> 8); B.hash_lo[key] = (u8)run;
+            B.hash_hi[key + 1] = (u32)(run >> 8); B.hash_lo[key + 1] = (u8)run;
+        }
+    }
+}
+
+// non-ACGT -> fixed pseudo-random base (the reference uses srand(time(0)), Index.cpp:703), then the 2-bit .bs.pac image
+void prepare_genome(Built& B, std::vector<char>& gen, int n_threads)
+{
+    const u64 G = gen.size();
+    B.G = G;
+    if (n_threads < 1) n_threads = 1;
+    // positions of the non-ACGT characters, found in parallel, replaced in text order by one LCG stream
+    std::vector<std::vector<u64>> bad((size_t)n_threads);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++)
+            th.emplace_back([&, t]() {
+                for (u64 i = G * (u64)t / n_threads; i < G * (u64)(t + 1) / n_threads; i++) {
+                    const char c = gen[i];
+                    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') bad[(size_t)t].push_back(i);
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+    u64 s = 0x9E3779B97F4A7C15ULL;
+    for (auto& v : bad)
+        for (u64 i : v) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; gen[i] = "ACGT"[(s >> 33) & 3]; }
+    B.pac.assign((G + 3) / 4, 0);
+    {
+        const u64 nb = (G + 3) / 4;
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++)
+            th.emplace_back([&, t]() {
+                for (u64 b = nb * (u64)t / n_threads; b < nb * (u64)(t + 1) / n_threads; b++) {
+                    u8 acc = 0;
+                    for (u64 i = 4 * b; i < std::min(G, 4 * b + 4); i++) {
+                        const u8 v = gen[i] == 'A' ? 0 : gen[i] == 'C' ? 1 : gen[i] == 'G' ? 2 : 3;
+                        acc |= v << (6 - 2 * (i & 3));
+                    }
+                    B.pac[b] = acc;
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+}
+}  // namespace bmbs_io
+
 extern "C" int bmbs_index_build(const char* fasta, const char* prefix, int n_threads)
 {
     if (n_threads < 1) n_threads = 1;
@@ -233,21 +305,8 @@ extern "C" int bmbs_index_build(const char* fasta, const char* prefix, int n_thr
     std::vector<char> gen;
     if (!slurp_fasta(fasta, B.chroms, gen)) return BMBS_EINVAL;
     const u64 G = gen.size();
-    B.G = G;
     if (2 * G + 1 >= (1ULL << 33)) return BMBS_EINVAL;   // the sampled SA stores position / 8 in 30 bits (bwt.cpp:1793)
-    // non-ACGT -> fixed pseudo-random base (the reference uses srand(time(0)), Index.cpp:703)
-    {
-        u64 s = 0x9E3779B97F4A7C15ULL;
-        for (u64 i = 0; i < G; i++) {
-            char c = gen[i];
-            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { s = s * 6364136223846793005ULL + 1442695040888963407ULL; gen[i] = "ACGT"[(s >> 33) & 3]; }
-        }
-    }
-    B.pac.assign((G + 3) / 4, 0);
-    for (u64 i = 0; i < G; i++) {
-        u8 v = gen[i] == 'A' ? 0 : gen[i] == 'C' ? 1 : gen[i] == 'G' ? 2 : 3;
-        B.pac[i >> 2] |= v << (6 - 2 * (i & 3));
-    }
+    prepare_genome(B, gen, n_threads);
     // text = complement(fwd) C->T ++ reverse(fwd) C->T, recoded G0 T1 A2 (Index.cpp:645-682, bwt.cpp:1135)
     const u64 n = 2 * G;
     std::vector<u8> T(n);
@@ -373,7 +432,6 @@ int build_tail(Built& B, const std::vector<u8>& T, u64 n, const char* prefix, in
     {
         const u64 HS = 43046721ULL + 1;
         const u32 NONE = 0xffffffffu;
-        B.hash_hi.assign(HS, 0); B.hash_lo.assign(HS, 0);
         std::vector<u32> key16(n, NONE);
         par(NT, [&](int th) {
             const u64 a = n * (u64)th / NT, b2 = n * (u64)(th + 1) / NT;
@@ -394,20 +452,7 @@ int build_tail(Built& B, const std::vector<u8>& T, u64 n, const char* prefix, in
                 if (r + 1 == rows || krow(r + 1) != k) bot[k] = r + 1;
             }
         });
-        u64 run = 1;
-        B.hash_hi[0] = 0; B.hash_lo[0] = 1;
-        for (u64 key = 0; key < HS - 1; key++) {
-            if (bot[key]) {
-                const u64 tp = top[key], bt = bot[key];
-                B.hash_hi[key] = (u32)(tp >> 8) | ((u32)(tp - run) << 28);
-                B.hash_lo[key] = (u8)tp;
-                B.hash_hi[key + 1] = (u32)(bt >> 8); B.hash_lo[key + 1] = (u8)bt;
-                run = bt;
-            } else {
-                B.hash_hi[key] = (u32)(run >> 8); B.hash_lo[key] = (u8)run;
-                B.hash_hi[key + 1] = (u32)(run >> 8); B.hash_lo[key + 1] = (u8)run;
-            }
-        }
+        fill_hash_table(B, top.data(), bot.data());
     }
     return write_files(B, std::string(prefix) + ".index");
 }

@@ -68,13 +68,15 @@ def make_reads_se(genome: torch.Tensor, lens: torch.Tensor, n: int, L: int, stri
 
 @torch.no_grad()
 def make_reads_pe(genome: torch.Tensor, lens: torch.Tensor, n: int, L: int, stride: int, seed: int,
-                  sub: float = 0.005, conv: float = 0.99, ins_lo: int | None = None, ins_hi: int = 400):
+                  sub: float = 0.005, conv: float = 0.99, ins_lo: int | None = None, ins_hi: int = 400,
+                  indel: float = 0.0, qual: str = "const"):
     """-> (seq1, qual1, seq2, qual2) [n, stride] uint8 on the device; mate 2 as it would appear in the FASTQ
-    (reverse-complement end of the converted fragment); substitutions only (no indels) in this generator."""
+    (reverse-complement end of the converted fragment); substitutions and at most one single-base indel per mate."""
     dev = genome.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     ins_lo = L + 20 if ins_lo is None else ins_lo
+    ins_hi = max(ins_hi, ins_lo + 150)
     offs = torch.cumsum(lens, 0) - lens
     c = torch.randint(0, lens.numel(), (n,), generator=g, device=dev)
     ins = torch.randint(ins_lo, ins_hi, (n,), generator=g, device=dev)
@@ -101,11 +103,30 @@ def make_reads_pe(genome: torch.Tensor, lens: torch.Tensor, n: int, L: int, stri
             # conversion decided per (pair, fragment position) so that overlapping mates agree
             h = ((torch.arange(a, b, device=dev)[:, None] * 2654435761 + f * 40503 + seed) % 1000003).to(torch.float32) / 1000003.0
             return torch.where((base == ord("C")) & (h < conv), T, base)
-        r1 = frag(j + 0 * il)
-        r2 = comp[frag(il - 1 - j).long()]
-        for r, dst in ((r1, s1), (r2, s2)):
+        # single indel per mate: kind 0 none, 1 deletion (template base skipped), 2 insertion; t = template offset of read base j
+        ts = []
+        for _mate in range(2):
+            if indel > 0:
+                has = torch.rand((b - a, 1), generator=g, device=dev) < indel * L
+                kind = torch.where(has, torch.randint(1, 3, (b - a, 1), generator=g, device=dev), torch.zeros((b - a, 1), dtype=torch.int64, device=dev))
+                ip = torch.randint(5, L - 5, (b - a, 1), generator=g, device=dev)
+                t = j + ((kind == 1) & (j >= ip)).to(torch.int64) - ((kind == 2) & (j > ip)).to(torch.int64)
+                ts.append((t, (kind == 2) & (j == ip)))
+            else:
+                ts.append((j + 0 * il, None))
+        r1 = frag(ts[0][0])
+        r2 = comp[frag(il - 1 - ts[1][0]).long()]
+        for r, dst, (t_, insm) in ((r1, s1, ts[0]), (r2, s2, ts[1])):
             sm = torch.rand((b - a, L), generator=g, device=dev) < sub
             rb = acgt[torch.randint(0, 4, (b - a, L), generator=g, device=dev)]
-            dst[a:b, :L] = torch.where(sm, rb, r)
-    q = torch.full((n, stride), ord("I"), dtype=torch.uint8, device=dev)
-    return s1, q, s2, q.clone()
+            r = torch.where(sm, rb, r)
+            if insm is not None:
+                r = torch.where(insm, acgt[torch.randint(0, 4, (b - a, L), generator=g, device=dev)], r)
+            dst[a:b, :L] = r
+    if qual == "const":
+        q = torch.full((n, stride), ord("I"), dtype=torch.uint8, device=dev)
+        q2 = q.clone()
+    else:
+        q = (torch.randint(2, 41, (n, stride), generator=g, device=dev) + 33).to(torch.uint8)
+        q2 = (torch.randint(2, 41, (n, stride), generator=g, device=dev) + 33).to(torch.uint8)
+    return s1, q, s2, q2

@@ -34,10 +34,14 @@ class Index:
         self.ref_len = int(self.view.ref_len)
 
     @staticmethod
-    def build(fasta: str, prefix: str | None = None, threads: int = 8) -> None:
-        rc = capi.lib().bmbs_index_build(fasta.encode(), (prefix or fasta).encode(), threads)
+    def build(fasta: str, prefix: str | None = None, threads: int = 8, device: int | None = None) -> None:
+        """createIndex equivalent; device=None: host cores (bmbs_index_build), device=d: the GPU builder (same files)"""
+        if device is None:
+            rc = capi.lib().bmbs_index_build(fasta.encode(), (prefix or fasta).encode(), threads)
+        else:
+            rc = capi.lib().bmbs_index_build_device(device, fasta.encode(), (prefix or fasta).encode(), threads)
         if rc:
-            raise RuntimeError(f"bmbs_index_build failed ({rc})")
+            raise RuntimeError(f"bmbs_index_build{'' if device is None else '_device'} failed ({rc})")
 
     def close(self):
         if self._h:

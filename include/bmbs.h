@@ -228,6 +228,11 @@ const char* bmbs_index_file_chrom_name(const bmbs_index_file*, int i);
 void bmbs_index_file_free(bmbs_index_file*);
 /* createIndex equivalent (Index.cpp:832-938) without the psascan dependency: FASTA -> the six files */
 int bmbs_index_build(const char* fasta, const char* prefix, int n_threads);
+/* the same builder with the suffix sort and every array-sized derivation (BWT planes, Occ counters, SA_flag, samples, 16-mer
+ * rows) on HIP device `device_id`: the same six files byte for byte; a GRCh38-size genome (6.2 G suffixes) in well under a
+ * minute instead of six on 64 host cores.  Needs about 60 bytes of device memory per base.  n_threads: host threads of the
+ * FASTA / .pac preparation.  BMBS_ENODEV without a device (no silent fall-back to the host builder).                       */
+int bmbs_index_build_device(int device_id, const char* fasta, const char* prefix, int n_threads);
 
 /* Page-locked host buffers for the host-pointer entry points (bmbs_map_se / bmbs_map_pe copy from and to them at
  * full link speed).  The reference's per-thread scratch is plain malloc (Schema.cpp:24344-24362); a caller that

@@ -135,3 +135,37 @@ def test_world_size_2_gloo_shard_reduce_concat(gold, tmp_path):
     mine = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert mine == gzip.open(os.path.join(GOLD, "se_c150.ref.sam.gz"), "rt").read()
     assert open(out + ".stats").read() == open(os.path.join(GOLD, "se_c150.ref.stats")).read()
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (as a child torch.distributed.run,
+    before anything touches a GPU) and report the world size the process group has; --dry-run = gloo, no mapping"""
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2
+    assert d["mapstats_sum"][:2] == [3, 2]          # ranks contributed (rank + 1, 1): one all-reduce over both
+
+
+def test_bench_configs_match_baseline_json():
+    """the default bench workload is BASELINE.json's metric configuration (configs[2]: 150 bp PE, GRCh38-size, fast mode)"""
+    import importlib.util
+    import json
+    from common import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    a = b.parse([])
+    assert a.config == 2 and a.cfg["pe"] and not a.cfg["sensitive"] and a.cfg["read_len"] == 150
+    assert a.cfg["genome"] >= 3_000_000_000 and a.cfg["units"] * a.cfg["launches"] == 50_000_000
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "150bp PE" in base["metric"] and "50 M synthetic 150 bp PE reads vs GRCh38" in base["configs"][2]
+    a1 = b.parse(["--config", "1"])
+    assert not a1.cfg["pe"] and a1.cfg["units"] == 10_000_000 and abs(a1.cfg["e"] - 0.04) < 1e-12
