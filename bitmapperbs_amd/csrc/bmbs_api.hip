@@ -255,7 +255,11 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     ENS(c, c->a_start, nj * 4); ENS(c, c->a_end, nj * 4); ENS(c, c->a_nm, nj * 4); ENS(c, c->a_score, nj * 4); ENS(c, c->a_nops, nj * 4);
     ENS(c, c->need_sw, nj * 4); ENS(c, c->sw_off, (nj + 1) * 8); ENS(c, c->sw_job, nj * 4);
     if (!n_jobs) return BMBS_OK;
-    ENS(c, c->trace, nj * (u64)L * nwk * 8);
+    // BMBS_SW=reg: the round-1 form (one job per lane, band in registers, trace words in HBM) for A/B runs; the default is the
+    // wave-cooperative kernel with the trace in LDS (k_align_sw_wave)
+    const char* swm = getenv("BMBS_SW");
+    const bool reg_form = swm && !strcmp(swm, "reg");
+    if (reg_form) ENS(c, c->trace, nj * (u64)L * nwk * 8);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     prof_begin(c, "k_align_ungapped");
     hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
@@ -267,6 +271,21 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     if (rc) return rc;
     prof_end(c);
     prof_begin(c, "k_align_sw");
+    if (!reg_form) {
+        // one alignment per 16 / 32 / 64 lanes (band of 2k+1 cells), trace + CIGAR in LDS
+        const size_t words = (size_t)sww_lds_words(L, k);
+#define SWW_LAUNCH(LANES)                                                                                                             \
+        hipLaunchKernelGGL((k_align_sw_wave<LANES>), dim3(nblk(n_jobs, 64 / LANES)), dim3(64), words * 4 * (64 / LANES), c->stream, c->ix, \
+                           c->sp, c->pen_lut.as<int>(), d_seq, d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(),   \
+                           jobs, rev_from, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),          \
+                           c->a_score.as<int>(), c->a_nops.as<int>())
+        if (k <= 7) SWW_LAUNCH(16);
+        else if (k <= 15) SWW_LAUNCH(32);
+        else SWW_LAUNCH(64);
+#undef SWW_LAUNCH
+        prof_end(c);
+        return BMBS_OK;
+    }
     // the band loop is unrolled for KB: a tighter bound wastes fewer masked cells (k = 6 in a KB = 8 kernel idles 4 of 17)
     if (k <= 2) launch_sw<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
     else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);

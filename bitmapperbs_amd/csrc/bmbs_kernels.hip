@@ -2285,6 +2285,216 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_align_sw_wave<LANES>: the same DP as k_align_sw, wave-cooperative with the trace in LDS (north_star (c)).
+//
+// One alignment per group of LANES lanes (16 / 32 / 64 for k <= 7 / 15 / 31: four, two or one alignment per wave); lane b
+// owns band cell b of the current row, i.e. window column j = i + b.  Dependencies of cell (i, j) in ksw_semi_global_quality_back
+// (ksw.cpp:1850-2045): the diagonal H(i-1, j-1) is the SAME lane's h of the previous row, E(i, j) was produced by lane b+1 in
+// the previous row (one DPP wave shift), and F runs along the row.  The reference opens gaps from the diagonal term alone
+// (t = M - gapoe with M = H(i-1,j-1) + s(i,j), not from max(M, E, F)), so the F chain  f(b+1) = max(f(b) - gape, t(b))  is a
+// max-plus prefix over values every lane already has:  f(b) = max_{b' < b} (t(b') + gape * b') - gape * (b - 1)  -- one
+// wave prefix-max (4-6 DPP steps) replaces the serial sweep of the anti-diagonal formulation, and a whole band row is one
+// step of the wave.  H, E, F live in registers; the four trace bits of a cell (ksw.cpp:1966-1990) are packed eight cells to a
+// 32-bit word by three DPP shifts and written to LDS (ceil(band/8) words per row: 2.4 KB at L = 150, k = 12; 6 KB at L = 250,
+// k = 20), the traceback walks them there, the run-length CIGAR is assembled in LDS, and the only HBM traffic of a job is its
+// read row, its window and the ops it emits.  (The register kernel wrote and re-read 1.25 GB of trace words per 10 M-read
+// batch: 11.6x its algorithmic bytes, profiles/r01_pmc_fetch_write.csv.)
+template <int CTRL, int ROW_MASK>
+DEVI int dpp_i32(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false); }
+
+template <int LANES>
+DEVI int group_prefix_max(int x, int minf)
+{
+    x = max(x, dpp_i32<0x111, 0xf>(minf, x));          // row_shr:1
+    x = max(x, dpp_i32<0x112, 0xf>(minf, x));          // row_shr:2
+    x = max(x, dpp_i32<0x114, 0xf>(minf, x));          // row_shr:4
+    x = max(x, dpp_i32<0x118, 0xf>(minf, x));          // row_shr:8
+    if (LANES >= 32) x = max(x, dpp_i32<0x142, 0xa>(minf, x));   // row_bcast:15 into rows 1 and 3
+    if (LANES >= 64) x = max(x, dpp_i32<0x143, 0xc>(minf, x));   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+#define SWW_CG_WORDS 164
+// LDS words per job: row constants (u16 per read position, padded to 4) + trace + CIGAR ops; even, so that jobs stay 8-byte aligned
+__host__ __device__ inline int sww_lds_words(int L, int k)
+{
+    const int rw = (2 * k + 1 + 7) / 8;
+    return ((L + 3) / 4) * 2 + L * rw + SWW_CG_WORDS;
+}
+
+template <int LANES>
+__global__ void __launch_bounds__(64)
+k_align_sw_wave(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
+                const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
+                const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u32* __restrict__ cigar_pool, int max_ops,
+                int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
+                int* __restrict__ a_nops)
+{
+    extern __shared__ u32 sww_lds[];
+    constexpr int JPB = 64 / LANES;
+    const int lane = (int)(threadIdx.x & 63), grp = lane / LANES, b = lane % LANES;
+    const u64 n_sw = *n_sw_ptr;
+    const u64 t0 = (u64)blockIdx.x * JPB;
+    if (t0 >= n_sw) return;                               // the whole wave has nothing to do
+    const bool live = t0 + (u64)grp < n_sw;
+    const u64 t = live ? t0 + (u64)grp : t0;              // idle groups shadow the block's first job (DPP needs every lane in step)
+    const u64 jb = sw_job[t];
+    const u32 r = jb_.read[jb];
+    const u64 site = jb_.site[jb];
+    const char* rd = seq + (size_t)r * stride;
+    const char* ql = qual_row(qual, qual2, rev_qual_from, r, stride);
+    const bool rev = r >= rev_qual_from;
+    const bool fwd = site < ix.G;
+    const int L = gm.rl(r), k = gm.rk(L);
+    const int band = 2 * k + 1, tlen = L;
+    const int RW = (2 * gm.k + 1 + 7) / 8;                // trace words per row, sized for the launch's largest band
+    const bool wvalid = window_valid(ix, site, (u64)(L + 2 * k), fwd);
+    const int MINUS_INF = -0x40000000;
+    const int gapoe = sp.gap_open + sp.gap_ext, gape = sp.gap_ext;
+    u32* base = sww_lds + (size_t)grp * sww_lds_words(gm.L, gm.k);
+    u16* rc = reinterpret_cast<u16*>(base);                        // row constants: read code | penalty << 3
+    u32* tr = base + ((gm.L + 3) / 4) * 2;                         // trace, RW words per row
+    u32* cg = tr + (size_t)gm.L * RW;                              // CIGAR ops of the traceback
+    for (int i = b; i < ((L + 3) & ~3); i += LANES) {
+        u16 v = 4;
+        if (i < L) {
+            const int ta = code4(rd[i]);
+            const unsigned char qc = (unsigned char)ql[rev ? L - 1 - i : i];
+            const int pen = ta == 4 ? sp.np : pen_lut[qc];
+            v = (u16)(ta | (pen << 3));
+        }
+        rc[i] = v;
+    }
+    __syncthreads();
+    // rows: the longest job of the wave sets the trip count, shorter ones stop updating
+    int Lmax = L;
+    if (JPB > 1 && gm.len) {
+#pragma unroll
+        for (int o = LANES; o < 64; o <<= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o));
+    }
+    WinReader wr; wr.init(ix, site + (u64)b, wvalid);
+    const int gb = gape * b;
+    const bool in_band = b < band;
+    int hprev = 0, e_next = -gapoe;
+    u64 rc4 = 0;
+    for (int i = 0; i < Lmax; ++i) {
+        if ((i & 3) == 0) rc4 = *reinterpret_cast<const u64*>(rc + (i < L ? i : 0));
+        const u32 x = (u32)(rc4 >> (16 * (i & 3))) & 0xffffu;
+        const int ta = (int)(x & 7), mis = -(int)(x >> 3);
+        const int wb = wr.next();
+        const int sc = ((ta == wb && ta < 4) || (ta == 3 && wb == 1)) ? 0 : (wb == 4 ? -sp.np : mis);   // mat[] of Schema.cpp:830-850
+        const int m = hprev + sc, e = e_next;
+        const int tt = m - gapoe;
+        const int P = group_prefix_max<LANES>(in_band ? tt + gb : MINUS_INF, MINUS_INF);
+        int Pex = dpp_i32<0x138, 0xf>(MINUS_INF, P);                // wave_shr:1
+        const int f = b == 0 ? MINUS_INF : Pex - gb + gape;
+        int d = m >= e ? 0 : 1;
+        int h = m >= e ? m : e;
+        d = h >= f ? d : 2;
+        h = h >= f ? h : f;
+        const int e2 = e - gape;
+        d |= e2 > tt ? 4 : 0;
+        const int e_new = e2 > tt ? e2 : tt;
+        d |= (f - gape) > tt ? 8 : 0;
+        const int e_shl = dpp_i32<0x130, 0xf>(MINUS_INF, e_new);    // wave_shl:1: E(i+1, j) comes from lane b+1
+        // eight cells per trace word
+        int pk = d | (dpp_i32<0x101, 0xf>(0, d) << 4);              // row_shl:1
+        pk |= dpp_i32<0x102, 0xf>(0, pk) << 8;                      // row_shl:2
+        pk |= dpp_i32<0x104, 0xf>(0, pk) << 16;                     // row_shl:4
+        if (i < L) {
+            hprev = h;
+            e_next = b == band - 1 ? MINUS_INF : e_shl;
+            if ((b & 7) == 0 && in_band) tr[(size_t)i * RW + (b >> 3)] = (u32)pk;
+        }
+    }
+    // score: the un-gapped diagonal wins ties, then the highest column (ksw.cpp:2001-2010)
+    int best = in_band ? hprev : MINUS_INF;
+#pragma unroll
+    for (int o = 1; o < LANES; o <<= 1) best = max(best, __shfl_xor(best, o));
+    const u64 eq = __ballot(in_band && hprev == best);
+    const u64 geq = LANES == 64 ? eq : (eq >> (grp * LANES)) & ((1ull << LANES) - 1);
+    const int s_col = ((geq >> k) & 1) ? k : 63 - __clzll((long long)geq);
+    __syncthreads();
+    if (b != 0 || !live) return;
+    // ---- one lane per job from here: traceback over the LDS trace, CIGAR in LDS ----
+    const int score = best;
+    int qe = tlen - 1 + s_col;
+    const int LOCAL_OPS = SWW_CG_WORDS - 4;
+    int nc = 0;
+    bool overflow = false;
+    int cur_op = -1, cur_len = 0;
+    auto flush = [&]() { if (cur_op >= 0) { if (nc < LOCAL_OPS) cg[nc++] = ((u32)cur_len << 4) | (u32)cur_op; else overflow = true; } };
+    auto push = [&](int op, int len) {
+        if (op != cur_op) { flush(); cur_op = op; cur_len = len; }
+        else cur_len += len;
+    };
+    int i = tlen - 1, kk = qe, which = 0;
+    while (i >= 0 && kk >= 0) {
+        const int bb = kk - i;
+        const int d = (int)((tr[(size_t)i * RW + (bb >> 3)] >> (4 * (bb & 7))) & 15);
+        which = which == 0 ? (d & 3) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
+        if (which == 0) { push(0, 1); --i; --kk; }
+        else if (which == 1) { push(2, 1); --i; }
+        else { push(1, 1); --kk; }
+    }
+    if (i >= 0) push(2, i + 1);
+    flush();
+    for (int a2 = 0, b2 = nc - 1; a2 < b2; a2++, b2--) { const u32 x = cg[a2]; cg[a2] = cg[b2]; cg[b2] = x; }
+    cg[nc] = 0;
+    int qb = kk + 1;
+    // K13: fold leading / trailing insertions into M (ksw.cpp:2677-2772)
+    int n_cigar = nc, ii, op, opl, ins = 0;
+    for (ii = 0; ii < n_cigar; ++ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+    if (ii != 0) {
+        op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+        if (op == 0) opl += ins; else { op = 0; opl = ins; ii--; }
+        cg[ii] = ((u32)opl << 4) | (u32)op;
+        qb -= ins;
+    }
+    const int cigar_b = ii;
+    ins = 0;
+    for (ii = n_cigar - 1; ii >= cigar_b; --ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+    if (ii != n_cigar - 1) {
+        op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+        if (op == 0) opl += ins; else { op = 0; opl = ins; ii++; }
+        cg[ii] = ((u32)opl << 4) | (u32)op;
+        qe += ins;
+    }
+    const int cigar_e = ii;
+    // NM recount under bisulfite matching + ops in SAM order (ksw.cpp:2779-2857); a window never holds 'N'
+    auto m_run = [&](int ts, int qs, int len) -> int {
+        if (!wvalid) return len;
+        int c = 0;
+        for (int o = 0; o < len; o += 8) c += mism_span(ix, rd, ts + o, site + (u64)(qs + o), len - o < 8 ? len - o : 8);
+        return c;
+    };
+    u32* ops_out = cigar_pool + jb * (u64)max_ops;
+    int NM = 0, no = 0;
+    if (fwd) {
+        int qs = qb, ts = 0;
+        for (ii = cigar_b; ii <= cigar_e; ++ii) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+            no++;
+            if (op == 0) { NM += m_run(ts, qs, opl); qs += opl; ts += opl; }
+            else if (op == 1) { qs += opl; NM += opl; }
+            else { ts += opl; NM += opl; }
+        }
+    } else {
+        int qx = qe, te = tlen - 1;
+        for (ii = cigar_e; ii >= cigar_b; --ii) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+            no++;
+            if (op == 0) { NM += m_run(te - opl + 1, qx - opl + 1, opl); qx -= opl; te -= opl; }
+            else if (op == 1) { qx -= opl; NM += opl; }
+            else { te -= opl; NM += opl; }
+        }
+    }
+    a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
+}
+
 // ================================================================================================
 // finalize: MAPQ, placement, stats
 // ================================================================================================

@@ -34,6 +34,12 @@ using namespace bmbs_io;
 
 namespace {
 
+// A launch cannot carry 2^32 threads and GRCh38 has 6.2 G suffixes: every per-element kernel is a grid-stride loop over a
+// capped grid.  IB_FOR_WAVE keeps whole waves in step (ballots inside): lanes beyond the end run the body with their index
+// >= the bound.
+#define IB_FOR(i, m) for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < (m); i += (u64)gridDim.x * blockDim.x)
+#define IB_FOR_WAVE(i, m) for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; (i & ~63ull) < (m); i += (u64)gridDim.x * blockDim.x)
+
 struct IbText {
     const u64* tx;   // packed text, n/32 + 3 words
     u64 n;
@@ -137,79 +143,76 @@ __global__ void k_ib_emit(IbText t, u64 n_words, unsigned bucket, unsigned long 
 // h[j] = j where a new key starts (else 0) -> max-scan gives the position of the first suffix with the same key
 __global__ void k_ib_head(const u64* __restrict__ keys, u64 m, u64* __restrict__ h)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    h[j] = (j == 0 || keys[j] != keys[j - 1]) ? j : 0;
+    IB_FOR(j, m) h[j] = (j == 0 || keys[j] != keys[j - 1]) ? j : 0;
 }
 __global__ void k_ib_place(const u64* __restrict__ vals, const u64* __restrict__ headpos, u64 m, u64 base,
                            u64* __restrict__ sa, u64* __restrict__ isa)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const u64 idx = vals[j];
-    sa[base + j] = idx;
-    isa[idx] = base + headpos[j] + 1;
+    IB_FOR(j, m) {
+        const u64 idx = vals[j];
+        sa[base + j] = idx;
+        isa[idx] = base + headpos[j] + 1;
+    }
 }
 
 // tied suffix = member of a group of two or more (rank = 1 + first position of its group)
 __global__ void k_ib_tieflag(const u64* __restrict__ sa, const u64* __restrict__ isa, u64 n, u32* __restrict__ flag)
 {
-    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const bool head = isa[sa[p]] == p + 1;
-    const bool next_head = p + 1 >= n || isa[sa[p + 1]] == p + 2;
-    flag[p] = (head && next_head) ? 0u : 1u;
+    IB_FOR(p, n) {
+        const bool head = isa[sa[p]] == p + 1;
+        const bool next_head = p + 1 >= n || isa[sa[p + 1]] == p + 2;
+        flag[p] = (head && next_head) ? 0u : 1u;
+    }
 }
 __global__ void k_ib_tielist(const u64* __restrict__ sa, const u64* __restrict__ isa, u64 n, const u32* __restrict__ flag,
                              const u64* __restrict__ off, u64* __restrict__ l_pos, u64* __restrict__ l_grp, u64* __restrict__ l_idx)
 {
-    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || !flag[p]) return;
-    const u64 o = off[p], idx = sa[p];
-    l_pos[o] = p; l_idx[o] = idx; l_grp[o] = isa[idx] - 1;
+    IB_FOR(p, n) {
+        if (!flag[p]) continue;
+        const u64 o = off[p], idx = sa[p];
+        l_pos[o] = p; l_idx[o] = idx; l_grp[o] = isa[idx] - 1;
+    }
 }
 __global__ void k_ib_dkey(const u64* __restrict__ l_idx, const u64* __restrict__ isa, u64 n, u64 h, u64 m, u64* __restrict__ key,
                           u64* __restrict__ val)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const u64 q = l_idx[j] + h;
-    key[j] = q < n ? isa[q] : 0;
-    if (val) val[j] = j;
+    IB_FOR(j, m) {
+        const u64 q = l_idx[j] + h;
+        key[j] = q < n ? isa[q] : 0;
+        if (val) val[j] = j;
+    }
 }
 __global__ void k_ib_gather(const u64* __restrict__ src, const u64* __restrict__ perm, u64 m, u64* __restrict__ dst)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m) dst[j] = src[perm[j]];
+    IB_FOR(j, m) dst[j] = src[perm[j]];
 }
 __global__ void k_ib_dhead(const u64* __restrict__ l_grp, const u64* __restrict__ l_pos, const u64* __restrict__ key, u64 m,
                            u64* __restrict__ h)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    h[j] = (j == 0 || l_grp[j] != l_grp[j - 1] || key[j] != key[j - 1]) ? l_pos[j] + 1 : 0;     // +1: position 0 is a valid head
+    IB_FOR(j, m) h[j] = (j == 0 || l_grp[j] != l_grp[j - 1] || key[j] != key[j - 1]) ? l_pos[j] + 1 : 0;     // +1: position 0 is a valid head
 }
 // writes the re-ordered suffixes and their new ranks; flags the ones that are still tied
 __global__ void k_ib_dplace(const u64* __restrict__ l_pos, const u64* __restrict__ n_idx, const u64* __restrict__ ngrp1, u64 m,
                             u64* __restrict__ sa, u64* __restrict__ isa, u32* __restrict__ flag)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const u64 idx = n_idx[j], g1 = ngrp1[j];            // g1 = group head position + 1 = the rank
-    sa[l_pos[j]] = idx;
-    isa[idx] = g1;
-    const bool head = g1 == l_pos[j] + 1;
-    const bool next_head = j + 1 >= m || ngrp1[j + 1] == l_pos[j + 1] + 1;
-    flag[j] = (head && next_head) ? 0u : 1u;
+    IB_FOR(j, m) {
+        const u64 idx = n_idx[j], g1 = ngrp1[j];            // g1 = group head position + 1 = the rank
+        sa[l_pos[j]] = idx;
+        isa[idx] = g1;
+        const bool head = g1 == l_pos[j] + 1;
+        const bool next_head = j + 1 >= m || ngrp1[j + 1] == l_pos[j + 1] + 1;
+        flag[j] = (head && next_head) ? 0u : 1u;
+    }
 }
 __global__ void k_ib_dcompact(const u32* __restrict__ flag, const u64* __restrict__ off, u64 m, const u64* __restrict__ l_pos,
                               const u64* __restrict__ ngrp1, const u64* __restrict__ n_idx, u64* __restrict__ o_pos,
                               u64* __restrict__ o_grp, u64* __restrict__ o_idx)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m || !flag[j]) return;
-    const u64 o = off[j];
-    o_pos[o] = l_pos[j]; o_grp[o] = ngrp1[j] - 1; o_idx[o] = n_idx[j];
+    IB_FOR(j, m) {
+        if (!flag[j]) continue;
+        const u64 o = off[j];
+        o_pos[o] = l_pos[j]; o_grp[o] = ngrp1[j] - 1; o_idx[o] = n_idx[j];
+    }
 }
 
 // ---- outputs ------------------------------------------------------------------------------------------------------------
@@ -219,17 +222,18 @@ __device__ __forceinline__ u64 ib_row(const IbSa& s, u64 r) { return r == 0 ? s.
 // BWT bit planes (bwt.cpp:1290-1500): stream position t = row minus the '$' row; 64 rows per wave -> two ballot words
 __global__ void k_ib_bwt(IbText t, IbSa s, u64 shap, u64* __restrict__ bw)
 {
-    const u64 t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned ch = 0;
-    if (t0 < s.n) {
-        const u64 row = t0 < shap ? t0 : t0 + 1;
-        ch = ib_sym(t, ib_row(s, row) - 1);
-    }
-    const u64 b0 = __ballot(ch & 1), b1 = __ballot(ch >> 1);
-    if ((threadIdx.x & 63) == 0 && t0 < s.n) {
-        const u64 w = (t0 >> 7) * 5 + 1 + 2 * ((t0 & 127) >> 6);
-        bw[w] = __brevll(b0);
-        bw[w + 1] = __brevll(b1);
+    IB_FOR_WAVE(t0, s.n) {
+        unsigned ch = 0;
+        if (t0 < s.n) {
+            const u64 row = t0 < shap ? t0 : t0 + 1;
+            ch = ib_sym(t, ib_row(s, row) - 1);
+        }
+        const u64 b0 = __ballot(ch & 1), b1 = __ballot(ch >> 1);
+        if ((threadIdx.x & 63) == 0 && t0 < s.n) {
+            const u64 w = (t0 >> 7) * 5 + 1 + 2 * ((t0 & 127) >> 6);
+            bw[w] = __brevll(b0);
+            bw[w + 1] = __brevll(b1);
+        }
     }
 }
 // in-block counters (relative to the super-block of 65 536 positions) + the super-block sums; one block = one super-block
@@ -265,30 +269,32 @@ __global__ void __launch_bounds__(1024) k_ib_occ(u64 n, u64* __restrict__ bw, u6
 // SA_flag bit words (bwt.cpp:1580-1800) and the number of samples per 64 rows
 __global__ void k_ib_flag(IbSa s, u64 rows, u64 words, u64* __restrict__ fl, u32* __restrict__ cnt64)
 {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool f = r < rows && (ib_row(s, r) & 7) == 0;
-    const u64 b = __ballot(f);
-    if ((threadIdx.x & 63) == 0 && r < rows) {
-        const u64 w = 5 * (r >> 8) + 1 + ((r & 255) >> 6);
-        if (w < words + 8) fl[w] = __brevll(b);
-        cnt64[r >> 6] = __popcll(b);
+    IB_FOR_WAVE(r, rows) {
+        const bool f = r < rows && (ib_row(s, r) & 7) == 0;
+        const u64 b = __ballot(f);
+        if ((threadIdx.x & 63) == 0 && r < rows) {
+            const u64 w = 5 * (r >> 8) + 1 + ((r & 255) >> 6);
+            if (w < words + 8) fl[w] = __brevll(b);
+            cnt64[r >> 6] = __popcll(b);
+        }
     }
 }
 __global__ void k_ib_samples(IbText t, IbSa s, u64 rows, u64 words, const u64* __restrict__ off64, u64* __restrict__ fl,
                              u32* __restrict__ samp)
 {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 p = 0;
-    bool f = false;
-    if (r < rows) { p = ib_row(s, r); f = (p & 7) == 0; }
-    const u64 b = __ballot(f);
-    if (r < rows) {
-        if ((r & 255) == 0 && 5 * (r >> 8) < words) fl[5 * (r >> 8)] = off64[r >> 6];      // samples in front of the block
-        if (f) {
-            const unsigned lane = threadIdx.x & 63;
-            const u64 o = off64[r >> 6] + __popcll(b & ((1ull << lane) - 1));
-            const u32 ch = p != 0 ? ib_sym(t, p - 1) : 1u;
-            samp[o] = (ch << 30) | (u32)(p >> 3);
+    IB_FOR_WAVE(r, rows) {
+        u64 p = 0;
+        bool f = false;
+        if (r < rows) { p = ib_row(s, r); f = (p & 7) == 0; }
+        const u64 b = __ballot(f);
+        if (r < rows) {
+            if ((r & 255) == 0 && 5 * (r >> 8) < words) fl[5 * (r >> 8)] = off64[r >> 6];      // samples in front of the block
+            if (f) {
+                const unsigned lane = threadIdx.x & 63;
+                const u64 o = off64[r >> 6] + __popcll(b & ((1ull << lane) - 1));
+                const u32 ch = p != 0 ? ib_sym(t, p - 1) : 1u;
+                samp[o] = (ch << 30) | (u32)(p >> 3);
+            }
         }
     }
 }
@@ -296,28 +302,29 @@ __global__ void k_ib_samples(IbText t, IbSa s, u64 rows, u64 words, const u64* _
 // 16-mer of every row (bwt.cpp:1866-2010): base-3 number of the first 16 symbols, NONE for suffixes shorter than 16
 __global__ void k_ib_key16(IbText t, IbSa s, u64 rows, u32* __restrict__ kr)
 {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    u32 k = 0xffffffffu;
-    if (r >= 1) {
-        const u64 p = s.sa[r - 1];
-        if (p + 16 <= s.n) {
-            const u64 key = ib_key32(t, p);
-            u32 v = 0;
-            for (int j = 0; j < 16; j++) v = v * 3 + ((u32)((key >> (62 - 2 * j)) & 3) - 1u);
-            k = v;
+    IB_FOR(r, rows) {
+        u32 k = 0xffffffffu;
+        if (r >= 1) {
+            const u64 p = s.sa[r - 1];
+            if (p + 16 <= s.n) {
+                const u64 key = ib_key32(t, p);
+                u32 v = 0;
+                for (int j = 0; j < 16; j++) v = v * 3 + ((u32)((key >> (62 - 2 * j)) & 3) - 1u);
+                k = v;
+            }
         }
+        kr[r] = k;
     }
-    kr[r] = k;
 }
 __global__ void k_ib_toprow(const u32* __restrict__ kr, u64 rows, u64* __restrict__ top, u64* __restrict__ bot)
 {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < 1 || r >= rows) return;
-    const u32 k = kr[r];
-    if (k == 0xffffffffu) return;
-    if (r == 1 || kr[r - 1] != k) top[k] = r;
-    if (r + 1 == rows || kr[r + 1] != k) bot[k] = r + 1;
+    IB_FOR(r, rows) {
+        if (r < 1) continue;
+        const u32 k = kr[r];
+        if (k == 0xffffffffu) continue;
+        if (r == 1 || kr[r - 1] != k) top[k] = r;
+        if (r + 1 == rows || kr[r + 1] != k) bot[k] = r + 1;
+    }
 }
 
 struct Dev {
@@ -339,7 +346,7 @@ struct Dev {
     ~Dev() { for (void* p : all) if (p) (void)hipFree(p); }
 };
 
-inline unsigned nb(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+inline unsigned nb(u64 n, unsigned bs) { const u64 b = (n + bs - 1) / bs; return (unsigned)(b < (1u << 22) ? (b ? b : 1) : (1u << 22)); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define IB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "bmbs_index_build_device: %s: %s\n", #call, hipGetErrorString(e_)); return BMBS_ENODEV; } } while (0)
@@ -465,6 +472,7 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
             hipLaunchKernelGGL(k_ib_place, dim3(nb(m, 256)), dim3(256), 0, 0, vb, va, m, base, d_sa, d_isa);
             base += m;
         }
+        IB_HIP(hipGetLastError());
         IB_HIP(hipDeviceSynchronize());
         if (base != n) { fprintf(stderr, "bmbs_index_build_device: bucket sizes do not add up\n"); return BMBS_ESTATE; }
         D.drop(ka); D.drop(kb); D.drop(va); D.drop(vb);
@@ -534,6 +542,7 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
             D.drop(o_pos); D.drop(o_grp); D.drop(o_idx); D.drop(tflag);
         } else { D.drop(flag); D.drop(off); }
     }
+    IB_HIP(hipGetLastError());
     lap("prefix doubling");
 
     // the row of the whole text ('$' precedes it)
@@ -568,6 +577,7 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
         B.nacgt[0] = 1; B.nacgt[1] = 1 + c0; B.nacgt[2] = B.nacgt[1] + c1; B.nacgt[3] = B.nacgt[2] + c2; B.nacgt[4] = B.nacgt[3];
         D.drop(d_bw); D.drop(d_t1); D.drop(d_t2);
     }
+    IB_HIP(hipGetLastError());
     lap("BWT + Occ");
 
     // ---- SA_flag + sampled SA ----
@@ -596,6 +606,7 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
         B.sa_flag.swap(fl);
         D.drop(d_fl); D.drop(d_c64); D.drop(d_o64); D.drop(d_samp);
     }
+    IB_HIP(hipGetLastError());
     lap("SA_flag + samples");
 
     // ---- 16-mer table ----
@@ -613,6 +624,7 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
         IB_HIP(hipMemcpy(bot.data(), d_bot, HS * 8, hipMemcpyDeviceToHost));
         fill_hash_table(B, top.data(), bot.data());
     }
+    IB_HIP(hipGetLastError());
     lap("16-mer table");
     const int rc = write_files(B, std::string(prefix) + ".index");
     lap("files written");

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Regenerates the golden fixtures in this directory by RUNNING THE REAL REFERENCE here.
 
-  python tests/golden/make_golden.py [--psascan /path/to/psascan]
+  python tests/golden/make_golden.py [--psascan /path/to/psascan] [--only small|big]
 
-Needs oracle/_ref/bitmapperBS (oracle/build_ref.sh; /root/reference present).  Fixtures are data only:
+Needs oracle/_ref/bitmapperBS (oracle/build_ref.sh; /root/reference present) and, for the index pins, the reference's external
+suffix sorter oracle/_ref/psascan (oracle/build_psascan.sh; used by default when it is there).  Fixtures are data only:
   genome.fa.gz                   seeded synthetic genome (2 x 150 kb + planted repeats)
   se_<name>.fq.gz                seeded synthetic reads
   se_<name>.ref.sam.gz           SAM written by the reference (`bitmapperBS --search ... -t 1`)
@@ -14,6 +15,13 @@ Needs oracle/_ref/bitmapperBS (oracle/build_ref.sh; /root/reference present).  F
                                  oracle/build_ref.sh; pass --psascan to refresh this file only).
 The index the search runs use is built by the oracle builder (its byte-identity with the reference-built
 index is exactly what index_ref_sha256.json pins).
+
+The BIG family (big_*.json / big_*.ref.fields.gz): a 5 Mb genome with thousands of planted repeat copies, 20 000 reads / pairs
+per mode, so that long candidate lists, vote-order ties and the --sensitive rescue paths are pinned by the reference itself.
+Genome and reads are NOT stored: they are regenerated from their seeds (numpy PCG64 streams) and checked against the sha256
+recorded here; of the reference's SAM the fixture keeps every column except QNAME / SEQ / QUAL (derivable from the inputs) plus
+the sha256 of the complete SAM body, which is what the tests compare the product's complete SAM text with.  The big index is
+written by the REFERENCE's own `--index` (psascan) and its file hashes are recorded as a second pin of our builders.
 """
 import argparse, gzip, hashlib, json, os, shutil, subprocess, sys, tempfile
 import numpy as np
@@ -77,10 +85,86 @@ def sha(path, drop_tail=0):
     if drop_tail: b = b[:-drop_tail]
     return hashlib.sha256(b).hexdigest()
 
+BIG_SE = {
+    "se150": dict(reads=dict(n=20000, L=150, seed=31, sub=0.02, indel=0.002, qual="random"), args=[]),
+    "se100": dict(reads=dict(n=20000, L=100, seed=32, sub=0.03, indel=0.003, qual="random", n_rate=0.002), args=["-e", "0.06"]),
+}
+BIG_PE = {
+    "pe150": dict(reads=dict(n=20000, L=150, seed=33, sub=0.015, indel=0.002, qual="random"), args=[]),
+    "pes100": dict(reads=dict(n=20000, L=100, seed=34, sub=0.05, indel=0.003, qual="random"), args=["--sensitive"]),
+}
+
+def big_genome():
+    names, chroms = synth.make_genome(5_000_000, 3, seed=303)
+    rng = np.random.default_rng(404)
+    for (elen, copies, div) in [(300, 2000, 0.06), (1000, 200, 0.02), (6000, 20, 0.01), (100, 3000, 0.0), (45, 2000, 0.0)]:
+        el = synth._ACGT[rng.integers(0, 4, elen)]
+        for c in range(copies):
+            ch = chroms[rng.integers(0, len(chroms))]
+            p = int(rng.integers(0, ch.size - elen))
+            e = el.copy(); m = rng.random(elen) < rng.random() * div
+            e[m] = synth._ACGT[rng.integers(0, 4, int(m.sum()))]
+            if rng.random() < 0.5: e = synth.revcomp(e)
+            ch[p:p + elen] = e
+    return names, chroms
+
+def sam_fields(sam_path):
+    """-> (sha256 of the SAM body without @PG, text of every record line without QNAME / SEQ / QUAL)"""
+    h = hashlib.sha256(); out = []
+    for l in open(sam_path):
+        if l.startswith("@PG"): continue
+        h.update(l.encode())
+        if l.startswith("@"): continue
+        c = l.rstrip("\n").split("\t")
+        out.append("\t".join(c[1:9] + c[11:]) + "\n")
+    return h.hexdigest(), "".join(out)
+
+def big_family(ref, psascan):
+    assert psascan, "the big family lets the reference build its own index: oracle/build_psascan.sh first"
+    wd = tempfile.mkdtemp(prefix="golden_big_")
+    names, chroms = big_genome()
+    fa = os.path.join(wd, "big.fa")
+    synth.write_fasta(fa, names, chroms)
+    shutil.copy(psascan, os.path.join(wd, "psascan"))
+    subprocess.run([ref, "--index", "big.fa"], cwd=wd, check=True, capture_output=True)
+    meta = {"genome_sha256": sha(fa), "index": {}, "sets": {}}
+    for s_ in ("index", "index.bs.pac", "index.bs.index", "index.bs.index.occ", "index.bs.index.bwt"):
+        meta["index"][s_] = sha(fa + "." + s_)
+    meta["index"]["index.bs.index.sa[:-8]"] = sha(fa + ".index.bs.index.sa", 8)
+    for name, cfg in list(BIG_SE.items()) + list(BIG_PE.items()):
+        pe = name in BIG_PE
+        sam = os.path.join(wd, name + ".sam")
+        if pe:
+            m1, m2 = synth.make_reads_pe(chroms, **cfg["reads"])
+            f1 = os.path.join(wd, name + "_1.fq"); f2 = os.path.join(wd, name + "_2.fq")
+            synth.write_fastq(f1, m1); synth.write_fastq(f2, m2)
+            inp = ["--seq1", f1, "--seq2", f2]; insha = [sha(f1), sha(f2)]
+        else:
+            r = synth.make_reads_se(chroms, **cfg["reads"])
+            fq = os.path.join(wd, name + ".fq"); synth.write_fastq(fq, r)
+            inp = ["--seq", fq]; insha = [sha(fq)]
+        p = subprocess.run([ref, "--search", fa] + inp + ["-t", "1", "-o", sam] + cfg["args"], capture_output=True, text=True, cwd=wd)
+        assert p.returncode == 0, p.stderr
+        digest, fields = sam_fields(sam)
+        with gzip.GzipFile(os.path.join(HERE, "big_%s.ref.fields.gz" % name), "wb", mtime=0) as g: g.write(fields.encode())
+        stats = "".join(l for l in p.stderr.splitlines(True) if l.startswith("No. of") or l.startswith("Mismatch"))
+        meta["sets"][name] = {"kind": "pe" if pe else "se", "reads": cfg["reads"], "args": cfg["args"], "fastq_sha256": insha,
+                              "sam_body_sha256": digest, "stats": stats, "records": fields.count("\n")}
+        print("BIG", name, "records", fields.count("\n"), stats.splitlines()[1], stats.splitlines()[2])
+    json.dump(meta, open(os.path.join(HERE, "big_family.json"), "w"), indent=1)
+    shutil.rmtree(wd)
+
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--psascan"); a = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--psascan"); ap.add_argument("--only", choices=["small", "big"])
+    a = ap.parse_args()
     ref = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS")
     assert os.path.exists(ref), "build the reference first: oracle/build_ref.sh"
+    if not a.psascan and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "psascan")):
+        a.psascan = os.path.join(ROOT, "oracle", "_ref", "psascan")
+    if a.only != "small":
+        big_family(ref, a.psascan)
+        if a.only == "big":
+            return
     wd = tempfile.mkdtemp(prefix="golden_")
     names, chroms = genome()
     fa = os.path.join(wd, "genome.fa")

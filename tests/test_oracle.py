@@ -211,3 +211,32 @@ def test_oracle_cli_reproduces_reference_output_variants(name, golden_index, tmp
     assert mine == gzip.open(os.path.join(GOLD, "var_%s.ref.sam.gz" % name), "rt").read()
     stats = "".join(l + "\n" for l in q.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
     assert stats == open(os.path.join(GOLD, "var_%s.ref.stats" % name)).read()
+
+
+# ---- the `return 0;` splices of oracle/build_ref.sh are behaviour-neutral -----------------------------------------------------------
+@pytest.mark.skipif(ref_binary() is None or not os.path.isdir(os.environ.get("BMBS_REFERENCE_DIR", "/root/reference")),
+                    reason="needs /root/reference (this container) to compile the control binary")
+@pytest.mark.parametrize("kind,name", [("se", "b150"), ("se", "e75"), ("pe", "s100"), ("pe", "p150")])
+def test_unpatched_O0_reference_writes_the_committed_goldens(kind, name, golden_index, tmp_path):
+    """oracle/build_ref.sh splices `return 0;` into 33 non-void functions that fall off their end (with g++ >= 8 the -O3 binary
+    otherwise crashes).  Control: the same four sources compiled WITHOUT any splice at -O0 (oracle/build_ref_unpatched.sh), where
+    the compiler does not exploit the undefined behaviour, must write the SAM the spliced -O3 binary wrote into tests/golden/."""
+    subprocess.run([os.path.join(ROOT, "oracle", "build_ref_unpatched.sh")], check=True, capture_output=True)
+    exe = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS_unpatched_O0")
+    assert os.path.exists(exe)
+    out = str(tmp_path / "o.sam")
+    if kind == "se":
+        fq = str(tmp_path / "r.fq")
+        gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % name), fq)
+        cmd = [exe, "--search", golden_index, "--seq", fq, "-t", "1", "-o", out] + golden_args()[name]
+        gold = os.path.join(GOLD, "se_%s.ref.sam.gz" % name)
+    else:
+        f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq")
+        gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1)
+        gunzip_to(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), f2)
+        cmd = [exe, "--search", golden_index, "--seq1", f1, "--seq2", f2, "-t", "1", "-o", out] + pe_golden_args()[name]
+        gold = os.path.join(GOLD, "pe_%s.ref.sam.gz" % name)
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert mine == gzip.open(gold, "rt").read()
