@@ -513,7 +513,7 @@ def main():
                       "attach_s": round(attach_s, 1), "read_synthesis_s": round(synth_s, 1)},
         }
         if world == 1 and not args.no_cpu:
-            ns = min(job.n, args.cpu_sample or (1_000_000 if pe else 8_000_000))
+            ns = min(job.n, args.cpu_sample or (5_000_000 if pe else 8_000_000))
             host = [x[:ns].cpu().numpy() for x in job.batches[0]]
             cb, ref_sam = cpu_baseline(args, cfg, fa, host, L)
             out["cpu_baseline"] = cb

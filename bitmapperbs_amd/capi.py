@@ -53,11 +53,27 @@ ST_UNMAPPED, ST_UNIQUE, ST_AMBIG, ST_OFFEND = 0, 1, 2, 3
 _lib = None
 
 
+def _torch_runtime_first() -> None:
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, no versioned soname) next to the system one
+    this library links (/opt/rocm/lib/libamdhip64.so.7); both sit on ONE libhsa-runtime64.so.1 -- whichever copy the process
+    loads first.  With the system ROCr loaded first, torch's older HIP runtime finds no device afterwards
+    (torch.cuda.is_available() turns False); the other order works.  So when torch is importable it is initialised before
+    libbmbs_hip.so is opened.  Plumbing only: nothing here computes with torch.  BMBS_SKIP_TORCH_PRELOAD=1 skips it."""
+    if os.environ.get("BMBS_SKIP_TORCH_PRELOAD"):
+        return
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
+
+
 def lib() -> C.CDLL:
     """Load libbmbs_hip.so; raises if it has not been built (no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
+    _torch_runtime_first()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

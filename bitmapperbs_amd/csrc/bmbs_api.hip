@@ -228,19 +228,23 @@ ReadState read_state(bmbs_ctx* c)
     return s;
 }
 
+// trace slots of the register-band DP kernel: one per launched thread (<= 1 M: 16 k waves fill the chip several times over)
+inline u64 sw_trace_slots(u64 n_jobs) { const u64 t = (u64)nblk(n_jobs, 64) * 64; return t < (1ull << 20) ? t : (1ull << 20); }
+
 template <int KB>
 void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
                const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops)
 {
+    const u64 slots = sw_trace_slots(n_jobs);
     if (!gm.len)
-        hipLaunchKernelGGL((k_align_sw<KB, true>), dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+        hipLaunchKernelGGL((k_align_sw<KB, true>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                            d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
-                           n_jobs, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                           slots, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                            c->a_score.as<int>(), c->a_nops.as<int>());
     else
-        hipLaunchKernelGGL((k_align_sw<KB, false>), dim3(nblk(n_jobs, 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+        hipLaunchKernelGGL((k_align_sw<KB, false>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                            d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
-                           n_jobs, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                           slots, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                            c->a_score.as<int>(), c->a_nops.as<int>());
 }
 
@@ -255,11 +259,14 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     ENS(c, c->a_start, nj * 4); ENS(c, c->a_end, nj * 4); ENS(c, c->a_nm, nj * 4); ENS(c, c->a_score, nj * 4); ENS(c, c->a_nops, nj * 4);
     ENS(c, c->need_sw, nj * 4); ENS(c, c->sw_off, (nj + 1) * 8); ENS(c, c->sw_job, nj * 4);
     if (!n_jobs) return BMBS_OK;
-    // BMBS_SW=reg: the round-1 form (one job per lane, band in registers, trace words in HBM) for A/B runs; the default is the
-    // wave-cooperative kernel with the trace in LDS (k_align_sw_wave)
+    // Two forms of the DP.  Default (BMBS_SW=reg): one job per lane, band in registers, trace words in HBM -- 1.3 k wave
+    // instructions per job at k = 12, which is the VALU issue peak of the chip for this batch (0.65 ms per 300 k jobs).
+    // BMBS_SW=wave: one job per 16 / 32 / 64 lanes, a band row per step, trace + CIGAR in LDS, nothing but the ops written to HBM
+    // (north_star (c)); measured 6.4x the instructions per job (lanes beyond the band idle, the F prefix scan and its DPP
+    // wait states), so it is the better form only when there are too few jobs to fill the lanes.
     const char* swm = getenv("BMBS_SW");
-    const bool reg_form = swm && !strcmp(swm, "reg");
-    if (reg_form) ENS(c, c->trace, nj * (u64)L * nwk * 8);
+    const bool reg_form = !(swm && !strcmp(swm, "wave"));
+    if (reg_form) ENS(c, c->trace, sw_trace_slots(n_jobs) * (u64)L * nwk * 8);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     prof_begin(c, "k_align_ungapped");
     hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,

@@ -2102,8 +2102,11 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
 {
     constexpr int BW = 2 * KB + 1;          // compile-time bound of the band width
     constexpr int NW = (BW + 15) / 16;      // trace words per row (4 bits per cell)
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *n_sw_ptr) return;
+    // a thread owns one trace slot and takes the jobs slot, slot + threads, ...: the trace buffer is sized by the launch (at
+    // most 1 M slots), not by the number of jobs (which only the device knows)
+    const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n_sw_total = *n_sw_ptr;
+    for (u64 t = slot; t < n_sw_total; t += trace_stride) {
     const u64 jb = sw_job[t];
     const u32 r = jb_.read[jb];
     const u64 site = jb_.site[jb];
@@ -2127,7 +2130,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     for (int q = 0; q < NW; q++) wq[q] = 0;
     WinReader wr; wr.init(ix, site, wvalid);
     for (int b = 0; b < band; b++) { const u64 v = (u64)wr.next(); wq[b >> 4] |= v << (4 * (b & 15)); }
-    u64* tz = trace + t;                    // word (i*NWk + q) lives at tz[(i*NWk + q) * trace_stride]
+    u64* tz = trace + slot;                 // word (i*NWk + q) lives at tz[(i*NWk + q) * trace_stride]
     const int NWk = (band + 15) / 16;
     int h1_last = MINUS_INF;
     ReadCur rcur; rcur.seek(rd, 0, L);
@@ -2283,6 +2286,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         }
     }
     a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -7,14 +7,19 @@
 //   bmbs_search --search <index prefix | dir> --seq r.fq[.gz] [-o out.sam] [-e 0.08] [--mapstats f]
 //   bmbs_search --search <index> --seq1 a.fq --seq2 b.fq [--min 0] [--max 500] [--sensitive] ...
 //   output variants (Process_CommandLines.cpp:93-105): --pbat, --unmapped_out, --ambiguous_out, --bam (BGZF-compressed BAM)
-//   extra: --device N, --batch N (records per GPU batch, default 1 M), -t N (host I/O threads), --verbose
+//   extra: --device N | --devices a,b,... (one index copy per listed device, batches dealt to whichever context is free, output
+//          order kept), --contexts S (contexts per device sharing its index: S batches in flight per GPU so that the copies of
+//          one overlap the kernels of another; default 2), --batch N (records per GPU batch, default 1 M), -t N (host I/O
+//          threads), --verbose
 //
 // The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
 // what limits it.  Here the host side is a three-stage, order-preserving pipeline so that
 // the GPU is fed at memory speed:
 //   stage R  window of the (mmap'ed) FASTQ -> newline index built by the I/O threads -> records packed into page-locked
 //            staging rows, every read with its own length (k = (uint64)(e*L) is per read, Schema.cpp:24546)
-//   stage G  one bmbs_map_se[_var] / bmbs_map_pe[_var] call per batch (the only stage that touches the GPU)
+//   stage G  one bmbs_map_se[_var] / bmbs_map_pe[_var] call per batch (the only stage that touches the GPU); one worker thread
+//            per context -- the reference's parallel axis (N pthreads over sub-blocks, Schema.cpp:26336-26633) becomes
+//            N contexts over batches, and the five counters are summed over them at the end (Schema.cpp:451-476)
 //   stage W  SAM text formatted by the I/O threads into per-slice buffers, written with pwrite at prefix offsets
 // Batches circulate through hand-over queues, so stage R of batch i+1 and stage W of batch i-1 overlap stage G of i.
 #include "../../include/bmbs.h"
@@ -31,6 +36,7 @@
 #include <cstring>
 #include <ctime>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <queue>
@@ -114,6 +120,20 @@ public:
     T get() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [this] { return !q_.empty(); }); T v = q_.front(); q_.pop(); return v; }
 private:
     std::mutex m_; std::condition_variable cv_; std::queue<T> q_;
+};
+
+template <class T> class OrderedChan {           // hands items out in sequence-number order whatever order they arrive in
+public:
+    void put(long seq, T v) { { std::lock_guard<std::mutex> l(m_); q_[seq] = v; } cv_.notify_all(); }
+    T get()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return q_.count(next_) != 0; });
+        T v = q_[next_]; q_.erase(next_); next_++;
+        return v;
+    }
+private:
+    std::mutex m_; std::condition_variable cv_; std::map<long, T> q_; long next_ = 0;
 };
 
 // ---- FASTQ text source: plain files are mmap'ed (windows are views), .gz goes through gzread --------------------
@@ -241,6 +261,7 @@ struct Pinned {                                  // page-locked staging (bmbs_ho
 };
 
 struct Batch {
+    long seq = 0;                                // position in the input (output order)
     long n = 0;                                  // records
     bool end = false;                            // no more input after this batch
     Lines l1, l2;
@@ -461,7 +482,8 @@ int main(int argc, char** argv)
 {
     bmbs_params P; bmbs_default_params(&P);
     std::string index, seq, seq1, seq2, out = "output", mapstats, build_fasta, index_folder;
-    int device = 0, io_threads = 0;
+    int device = 0, io_threads = 0, contexts = 2;
+    std::vector<int> devices;
     long batch = 1000000;
     bool verbose = false, unmapped_out = false, pbat = false, bam = false;
     for (int i = 1; i < argc; i++) {
@@ -491,6 +513,12 @@ int main(int argc, char** argv)
         else if (a == "-t") io_threads = atoi(val());    // the reference's mapping threads; here: host I/O threads (the GPU maps)
         else if (a == "--mapstats") mapstats = val();
         else if (a == "--device") device = atoi(val());
+        else if (a == "--devices") {                                  // comma-separated device ids, one index copy each
+            const char* v = val();
+            devices.clear();
+            for (const char* q = v; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+        }
+        else if (a == "--contexts") contexts = atoi(val());
         else if (a == "--batch") batch = atol(val());
         else if (a == "--verbose") verbose = true;
         else if (a == "--unmapped_out") unmapped_out = true;          // Process_CommandLines.cpp:104-105
@@ -527,9 +555,30 @@ int main(int argc, char** argv)
     bmbs_index_file* ixf = bmbs_index_file_load(index.c_str());
     if (!ixf) { fprintf(stderr, "Cannot open index %s.index*\n", index.c_str()); return 1; }
     bmbs_index_view view; bmbs_index_file_view(ixf, &view);
-    bmbs_ctx* ctx = bmbs_create(device, &P);
-    if (!ctx) { fprintf(stderr, "bmbs_search: no usable HIP device %d (this driver has no CPU mapping path)\n", device); return 1; }
-    if (bmbs_index_attach(ctx, &view)) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); return 1; }
+    // one owner context per listed device (attached in parallel: each uploads and re-packs its own index copy), plus
+    // contexts-1 further contexts per device on the owner's index (bmbs_index_share)
+    if (devices.empty()) devices.push_back(device);
+    if (contexts < 1) contexts = 1;
+    std::vector<bmbs_ctx*> ctxs;                  // owners first
+    for (int d : devices) {
+        bmbs_ctx* c = bmbs_create(d, &P);
+        if (!c) { fprintf(stderr, "bmbs_search: no usable HIP device %d (this driver has no CPU mapping path)\n", d); return 1; }
+        ctxs.push_back(c);
+    }
+    {
+        std::vector<int> rcs(ctxs.size(), 0);
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < ctxs.size(); i++) th.emplace_back([&, i] { rcs[i] = bmbs_index_attach(ctxs[i], &view); });
+        for (auto& t : th) t.join();
+        for (size_t i = 0; i < ctxs.size(); i++) if (rcs[i]) { fprintf(stderr, "%s\n", bmbs_last_error(ctxs[i])); return 1; }
+    }
+    const size_t n_owner = ctxs.size();
+    for (size_t i = 0; i < n_owner; i++)
+        for (int s = 1; s < contexts; s++) {
+            bmbs_ctx* c = bmbs_create(devices[i], &P);
+            if (!c || bmbs_index_share(c, ctxs[i])) { fprintf(stderr, "bmbs_search: cannot create a shared context on device %d\n", devices[i]); return 1; }
+            ctxs.push_back(c);
+        }
     const double t_loaded = now();
     std::vector<std::string> chrom_names;
     for (int i = 0; i < view.n_chrom; i++) chrom_names.push_back(bmbs_index_file_chrom_name(ixf, i));
@@ -570,9 +619,11 @@ int main(int argc, char** argv)
     Source src1, src2;
     if (!src1.open(pe ? seq1.c_str() : seq.c_str()) || (pe && !src2.open(seq2.c_str()))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
 
-    const int n_batches = 5;
+    const int n_batches = 4 + (int)ctxs.size();
     std::vector<Batch> batches((size_t)n_batches);
-    Chan<Batch*> free_q, gpu_q, out_q, wr_q;
+    Chan<Batch*> free_q, gpu_q, wr_q;
+    OrderedChan<Batch*> out_q;                    // the G workers finish in any order; formatting and writing follow the input order
+    long next_seq = 0;
     for (auto& b : batches) free_q.put(&b);
     std::atomic<bool> failed(false);
     double t_read = 0, t_gpu = 0, t_write = 0, t_index = 0, t_format = 0;
@@ -588,6 +639,7 @@ int main(int argc, char** argv)
         for (;;) {
             Batch* b = free_q.get();
             const double t0 = now();
+            b->seq = next_seq++;
             b->n = 0; b->end = false; b->groups.clear(); b->keep1.reset(); b->keep2.reset();
             const size_t want = (size_t)batch * est + (1u << 16);
             const char *p1 = nullptr, *p2 = nullptr;
@@ -865,37 +917,51 @@ int main(int argc, char** argv)
         }
     });
 
-    // ---------------- stage G (this thread): one library call per length group -------------------------------
-    long total_records = 0;
-    for (;;) {
-        Batch* b = gpu_q.get();
-        const double t0 = now();
-        if (!failed)
-            for (const Group& g : b->groups) {
-                int64_t used = 0;
-                int rc;
-                // equal lengths take the fixed-length entry points, a trimmed library the per-read-length ones
-                if (!pe && b->uniform)
-                    rc = bmbs_map_se(ctx, b->seq1.p, b->qual1.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p,
-                                     (int64_t)g.count * (2 * g.k + 8), &used);
-                else if (!pe)
-                    rc = bmbs_map_se_var(ctx, b->seq1.p, b->qual1.p, b->len1.data(), g.L, g.stride, g.count, (bmbs_result*)b->res.p,
-                                         (uint32_t*)b->pool.p, (int64_t)g.count * (2 * g.k + 8), &used);
-                else if (b->uniform)
-                    rc = bmbs_map_pe(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p,
-                                     (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
-                else
-                    rc = bmbs_map_pe_var(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, b->len1.data(), b->len2.data(), g.L, g.stride,
-                                         g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
-                if (rc) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); failed = true; break; }
+    // ---------------- stage G: one worker per context, one library call per batch ---------------------------------------
+    std::atomic<long> total_records_a(0);
+    std::mutex g_mu;
+    auto g_worker = [&](bmbs_ctx* ctx) {
+        for (;;) {
+            Batch* b = gpu_q.get();
+            if (!b) return;                                                // another worker has seen the last batch
+            const double t0 = now();
+            if (!failed)
+                for (const Group& g : b->groups) {
+                    int64_t used = 0;
+                    int rc;
+                    // equal lengths take the fixed-length entry points, a trimmed library the per-read-length ones
+                    if (!pe && b->uniform)
+                        rc = bmbs_map_se(ctx, b->seq1.p, b->qual1.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p,
+                                         (int64_t)g.count * (2 * g.k + 8), &used);
+                    else if (!pe)
+                        rc = bmbs_map_se_var(ctx, b->seq1.p, b->qual1.p, b->len1.data(), g.L, g.stride, g.count, (bmbs_result*)b->res.p,
+                                             (uint32_t*)b->pool.p, (int64_t)g.count * (2 * g.k + 8), &used);
+                    else if (b->uniform)
+                        rc = bmbs_map_pe(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p,
+                                         (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
+                    else
+                        rc = bmbs_map_pe_var(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, b->len1.data(), b->len2.data(), g.L, g.stride,
+                                             g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
+                    if (rc) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); failed = true; break; }
+                }
+            total_records_a += b->n;
+            {
+                std::lock_guard<std::mutex> l(g_mu);
+                t_gpu += now() - t0;
+                ev_g.push_back({'G', b->n, t0, now()});
             }
-        total_records += b->n;
-        t_gpu += now() - t0;
-        ev_g.push_back({'G', b->n, t0, now()});
-        const bool end = b->end;
-        out_q.put(b);
-        if (end) break;
+            const bool end = b->end;
+            out_q.put(b->seq, b);
+            if (end) { for (size_t i = 1; i < ctxs.size(); i++) gpu_q.put(nullptr); return; }
+        }
+    };
+    {
+        std::vector<std::thread> workers;
+        for (size_t i = 1; i < ctxs.size(); i++) workers.emplace_back(g_worker, ctxs[i]);
+        g_worker(ctxs[0]);
+        for (auto& t : workers) t.join();
     }
+    const long total_records = total_records_a.load();
     reader.join();
     formatter.join();
     writer.join();
@@ -910,20 +976,21 @@ int main(int argc, char** argv)
     if (pe) src2.close();
     if (failed) { fprintf(stderr, "bmbs_search: failed\n"); return 1; }
     int64_t st[5];
-    bmbs_stats_get(ctx, st);
+    bmbs_stats_allreduce(ctxs.data(), (int)ctxs.size(), st);      // get_mapping_informations: the counters of every worker summed
     print_stats(stderr, st);
     if (!mapstats.empty()) { FILE* m = fopen(mapstats.c_str(), "w"); if (m) { print_stats(m, st); fclose(m); } }
     const double t_end = now();
     if (verbose)
-        fprintf(stderr, "[bmbs_search] records %ld  load+attach %.3fs  mapping wall %.3fs  (pipeline %.3fs; stage busy: read/pack %.3fs of which line index %.3fs, gpu %.3fs, format %.3fs, write %.3fs)  %d I/O threads, batch %ld\n",
-                total_records, t_loaded - t_start, t_end - t_loaded, t_joined - t_loaded, t_read, t_index, t_gpu, t_format, t_write, io_threads, batch);
+        fprintf(stderr, "[bmbs_search] records %ld  load+attach %.3fs  mapping wall %.3fs  (pipeline %.3fs; stage busy: read/pack %.3fs of which line index %.3fs, gpu %.3fs, format %.3fs, write %.3fs)  %d I/O threads, batch %ld, %zu device(s) x %d context(s)\n",
+                total_records, t_loaded - t_start, t_end - t_loaded, t_joined - t_loaded, t_read, t_index, t_gpu, t_format, t_write, io_threads, batch,
+                n_owner, contexts);
     if (verbose && getenv("BMBS_TRACE"))
         for (const auto* v : {&ev_r, &ev_g, &ev_f, &ev_w})
             for (const Ev& e : *v) fprintf(stderr, "[trace] %c n=%ld %.4f .. %.4f\n", e.stage, e.n, e.a - t_loaded, e.b - t_loaded);
     const double t0 = now();
     for (auto& b : batches) { b.seq1.release(); b.qual1.release(); b.seq2.release(); b.qual2.release(); b.res.release(); b.pool.release(); }
     const double t1 = now();
-    bmbs_destroy(ctx);
+    for (size_t i = ctxs.size(); i-- > 0;) bmbs_destroy(ctxs[i]);     // the sharing contexts go before their owners
     const double t2 = now();
     bmbs_index_file_free(ixf);
     if (verbose) fprintf(stderr, "[bmbs_search] teardown: unpin %.3fs, destroy ctx %.3fs, free index %.3fs\n", t1 - t0, t2 - t1, now() - t2);

@@ -14,6 +14,6 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
 names = sorted({c for k in acc for c in acc[k]})
 print("kernel," + ",".join(names) + ",dispatches")
 for k in sorted(acc):
-    if k in ("k_repack_occ", "k_repack_hash", "k_build_gen2", "k_expand_sa", "k_build_t20"): continue
+    if k in ("k_repack_occ", "k_repack_hash", "k_build_gen2", "k_expand_sa", "k_build_t20") or k.startswith("k_ib_"): continue
     n = max(len(v) for v in acc[k].values())
     print(k + "," + ",".join("%.0f" % (sum(acc[k][c][-2:]) / max(1, len(acc[k][c][-2:]))) if c in acc[k] else "" for c in names) + ",%d" % n)

@@ -1,16 +1,20 @@
 #!/bin/bash
-# tools/profile_round.sh -- on the MI355X box: the bench line and the rocprofv3 evidence behind it (kernel stats of the SAME
-# command, then separate --pmc passes: FETCH_SIZE, WRITE_SIZE, SQ stall counters).  Output under gpurun_out/prof/.
+# tools/profile_round.sh [config] [tag] -- on the MI355X box: the bench line and the rocprofv3 evidence behind it (kernel stats of the
+# SAME command, then separate --pmc passes: FETCH_SIZE, WRITE_SIZE, SQ stall counters).  Output under gpurun_out/prof_<tag>/.
 set -u
+CFG=${1:-2}
+TAG=${2:-r02_c$CFG}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/prof
+O=$R/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu --steps 1 --warmup 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --no-cpu --steps 1 --warmup 1 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --no-cpu --steps 1 --warmup 1 > /dev/null 2>&1
+python3 $R/bench.py --config $CFG > $O/bench.json 2> $O/bench.err
+Q="--config $CFG --no-cpu --no-secondary"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $Q > $O/bench_under_rocprof.json 2>/dev/null
+P="$Q --steps 1 --warmup 1 --min-seconds 0"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $P > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py $P > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py $P > /dev/null 2>&1
 cd $R
 python3 tools/pmc_summary.py $O/pmc_fetch > $O/pmc_fetch.csv
 python3 tools/pmc_summary.py $O/pmc_write > $O/pmc_write.csv
@@ -22,12 +26,12 @@ O = "$O"
 f = glob.glob(os.path.join(O, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
-    keep = [r for r in rows if "k_" in r["Name"] and not r["Name"].startswith("void at::")]
+    keep = [r for r in rows if "k_" in r["Name"] and not r["Name"].startswith("void at::") and "k_ib_" not in r["Name"]]
     other = [r for r in rows if r not in keep]
     with open(os.path.join(O, "kernel_stats.csv"), "w") as o:
         w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
         for r in keep: w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]])
-        w.writerow(["(torch kernels that synthesise the workload)", sum(int(r["Calls"]) for r in other), sum(int(r["TotalDurationNs"]) for r in other), "", "", ""])
+        w.writerow(["(torch / rocPRIM / index-builder kernels that set the workload up)", sum(int(r["Calls"]) for r in other), sum(int(r["TotalDurationNs"]) for r in other), "", "", ""])
 # FETCH_SIZE + WRITE_SIZE of the last launch of every kernel, one file
 fe = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(O, "pmc_fetch.csv")))}
 wr = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(O, "pmc_write.csv")))}
@@ -36,5 +40,6 @@ with open(os.path.join(O, "pmc_fetch_write.csv"), "w") as o:
     for k in sorted(fe):
         w.writerow([k, fe[k]["dispatches"], fe[k].get("FETCH_SIZE", ""), wr.get(k, {}).get("WRITE_SIZE", "")])
 PY
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O | head -30
 tail -c 400 $O/bench.err
