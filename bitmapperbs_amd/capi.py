@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libbmbs_hip.so")
 SYMBOLS = [
     "bmbs_default_params", "bmbs_create", "bmbs_destroy", "bmbs_last_error", "bmbs_index_attach", "bmbs_index_share",
     "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se", "bmbs_map_se_device",
-    "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
+    "bmbs_map_se_fastq", "bmbs_map_pe_fastq", "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free",
@@ -30,6 +30,11 @@ class Params(C.Structure):
                 ("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("q_base", C.c_int32),
                 ("seed_len", C.c_int32), ("min_ins", C.c_int32), ("max_ins", C.c_int32),
                 ("sensitive", C.c_int32), ("ambiguous_out", C.c_int32)]
+
+
+class FastqView(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("text_bytes", C.c_uint64), ("seq_off", C.c_void_p), ("qual_off", C.c_void_p),
+                ("seq_len", C.c_void_p), ("qual_len", C.c_void_p)]
 
 
 class IndexView(C.Structure):
@@ -104,6 +109,8 @@ def lib() -> C.CDLL:
     L.bmbs_map_se_var_device.argtypes = [vp, u64, u64, u64, i32, i32, i64, u64, u64, i64]
     L.bmbs_map_pe_var.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_map_pe_var_device.argtypes = [vp, u64, u64, u64, u64, u64, i32, i32, i64, u64, u64, i64]
+    L.bmbs_map_se_fastq.argtypes = [vp, C.POINTER(FastqView), i64, i32, i32, i32, vp, vp, i64, C.POINTER(i64)]
+    L.bmbs_map_pe_fastq.argtypes = [vp, C.POINTER(FastqView), C.POINTER(FastqView), i64, i32, i32, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_sync.argtypes = [vp]
     L.bmbs_stats_get.argtypes = [vp, vp]
     L.bmbs_stats_reset.argtypes = [vp]
@@ -126,9 +133,10 @@ def lib() -> C.CDLL:
     L.bmbs_host_free.argtypes = [vp]
     L.bmbs_host_free.restype = None
     for name in ("bmbs_index_attach", "bmbs_index_share", "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se",
-                 "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
+                 "bmbs_map_se_fastq", "bmbs_map_pe_fastq", "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
                  "bmbs_map_se_device", "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce",
-                 "bmbs_profile_last", "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_build", "bmbs_index_build_device"):
+                 "bmbs_profile_last", "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_build", "bmbs_index_build_device",
+                 "bmbs_map_se_fastq", "bmbs_map_pe_fastq"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

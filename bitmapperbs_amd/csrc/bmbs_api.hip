@@ -46,6 +46,7 @@ struct bmbs_ctx {
         a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d, in_len;
+    DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // paired-end workspace
     DevBuf sd_sp0, sd_hits0, sd_ml0, sd_tm, sd_seed_id, sd_clen, sd_first_ml, sd_flag_c, sd_flag_d, sd_off_c, sd_off_d, sd_list_c, sd_list_d;
     DevBuf pe_seq, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
@@ -511,7 +512,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
                      &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list,
-                     &c->mapq_off, &c->klut, &c->in_len};
+                     &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -767,8 +768,10 @@ extern "C" int bmbs_map_se_var(bmbs_ctx* c, const char* seq, const char* qual, c
 // paired-end fast mode (Map_Pair_Seq_end_to_end_fast, Schema.cpp:18570)
 namespace {
 // d_len: NULL, or u16[2n] = the lengths of the n first mates followed by those of the n second mates
+// prepared: c->pe_seq already holds the 2n rows (mate 1, then reverse-complemented mate 2) -- the FASTQ-text entry point writes
+// them there straight from the text and k_pe_prepare is not run
 int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, const u16* d_len,
-               int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+               int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap, bool prepared = false)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -776,6 +779,7 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     if ((stride & 15) || ((d_seq1 | d_qual1 | d_seq2 | d_qual2) & 15)) { c->err = "device read buffers must be 16-byte aligned with a stride that is a multiple of 16"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
     const u64 n = (u64)n_pairs, n2 = 2 * n;
+    if (prepared && c->pe_seq.cap < n2 * (u64)stride + 64) { c->err = "internal: prepared rows missing"; return BMBS_ESTATE; }
     c->n_prof_used = 0;
     if (n == 0) return BMBS_OK;
     int rc = prepare_luts(c);
@@ -793,10 +797,12 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     // the qualities are read where the caller put them (qual_row): mate 1 rows in d_qual1, mate 2 rows in d_qual2
     const char* qual_1 = reinterpret_cast<const char*>(d_qual1);
     const char* qual_2 = reinterpret_cast<const char*>(d_qual2);
-    prof_begin(c, "k_pe_prepare");
-    hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * (stride / 16), 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
-                       reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all);
-    prof_end(c);
+    if (!prepared) {
+        prof_begin(c, "k_pe_prepare");
+        hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * (stride / 16), 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
+                           reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all);
+        prof_end(c);
+    }
     ReadState st = read_state(c);
     PeState ps;
     ps.occ = c->pe_occ.as<int>(); ps.len = c->pe_len.as<u32>(); ps.cur = c->pe_cur.as<u8>(); ps.vround = c->pe_vround.as<u8>();
@@ -1013,6 +1019,103 @@ extern "C" int bmbs_map_pe_var(bmbs_ctx* c, const char* seq1, const char* qual1,
 {
     if (c && (!len1 || !len2)) { c->err = "len1 / len2 is NULL"; return BMBS_EINVAL; }
     return map_pe_host(c, seq1, qual1, seq2, qual2, len1, len2, L_max, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FASTQ text in (the host only finds the line starts; the rows are cut out of the text on the device)
+namespace {
+struct FqDev { const char* text; const u32* seq_off; const u32* qual_off; const u16* seq_len; const u16* qual_len; };
+
+int fastq_check(bmbs_ctx* c, const bmbs_fastq_view* v, int64_t n)
+{
+    if (!v || !v->text || !v->seq_off || !v->qual_off || !v->seq_len || !v->qual_len) { c->err = "fastq view: NULL field"; return BMBS_EINVAL; }
+    if (v->text_bytes >= (1ull << 32)) { c->err = "fastq view: a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
+    (void)n;
+    return BMBS_OK;
+}
+// text + index arrays of one file to the device; idx_at = byte offset of this file's arrays inside c->fq_idx
+int fastq_upload(bmbs_ctx* c, DevBuf& dtext, const bmbs_fastq_view* v, u64 n, u64 idx_at, FqDev& out)
+{
+    ENS(c, dtext, v->text_bytes + 64);
+    HIPCHK(c, hipMemcpyAsync(dtext.p, v->text, v->text_bytes, hipMemcpyHostToDevice, c->stream));
+    char* base = c->fq_idx.as<char>() + idx_at;
+    HIPCHK(c, hipMemcpyAsync(base, v->seq_off, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + n * 4, v->qual_off, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + n * 8, v->seq_len, n * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + n * 10, v->qual_len, n * 2, hipMemcpyHostToDevice, c->stream));
+    out.text = dtext.as<char>(); out.seq_off = reinterpret_cast<const u32*>(base); out.qual_off = reinterpret_cast<const u32*>(base + n * 4);
+    out.seq_len = reinterpret_cast<const u16*>(base + n * 8); out.qual_len = reinterpret_cast<const u16*>(base + n * 10);
+    return BMBS_OK;
+}
+}  // namespace
+
+extern "C" int bmbs_map_se_fastq(bmbs_ctx* c, const bmbs_fastq_view* reads, int64_t n_reads, int32_t L_max, int32_t uniform, int32_t pbat,
+                                 bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (!c) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (n_cigar_used) *n_cigar_used = 0;
+    if (n_reads <= 0) return BMBS_OK;
+    if (L_max <= 0 || L_max > 1000) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    { const int r0 = fastq_check(c, reads, n_reads); if (r0) return r0; }
+    const u64 n = (u64)n_reads;
+    const int ds = (L_max + 15) / 16 * 16;
+    const int k = threshold_k(c->prm, L_max);
+    const u64 pool = n * (u64)(2 * k + 8);
+    ENS(c, c->out_res, n * 32); ENS(c, c->cig_pool, pool * 4);
+    ENS(c, c->in_seq, n * (u64)ds + 64); ENS(c, c->in_qual, n * (u64)ds + 64); ENS(c, c->in_len, n * 2 + 16);
+    ENS(c, c->fq_idx, n * 12 + 64);
+    FqDev f;
+    { const int r1 = fastq_upload(c, c->fq_text1, reads, n, 0, f); if (r1) return r1; }
+    hipLaunchKernelGGL(k_fastq_rows, dim3(nblk(n * (u64)(ds / 16), 256)), dim3(256), 0, c->stream, f.text, f.seq_off, f.qual_off, f.seq_len,
+                       f.qual_len, (long)n, ds, pbat ? 1 : 0, pbat ? 1 : 0, c->in_seq.as<char>(), c->in_qual.as<char>(), c->in_len.as<u16>());
+    int rc = map_se_dev(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, uniform ? nullptr : c->in_len.as<u16>(), L_max, ds, n_reads,
+                        (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+    const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
+    if (used > (u64)cigar_cap) { c->err = "host cigar pool too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
+    if (used) HIPCHK(c, hipMemcpyAsync(cigar_pool, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_cigar_used) *n_cigar_used = (int64_t)used;
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_map_pe_fastq(bmbs_ctx* c, const bmbs_fastq_view* mate1, const bmbs_fastq_view* mate2, int64_t n_pairs, int32_t L_max,
+                                 int32_t uniform, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (!c) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (n_cigar_used) *n_cigar_used = 0;
+    if (n_pairs <= 0) return BMBS_OK;
+    if (L_max <= 0 || L_max > 1000) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    { int r0 = fastq_check(c, mate1, n_pairs); if (r0) return r0; r0 = fastq_check(c, mate2, n_pairs); if (r0) return r0; }
+    const u64 n = (u64)n_pairs, n2 = 2 * n;
+    const int ds = (L_max + 15) / 16 * 16;
+    const int k = threshold_k(c->prm, L_max);
+    const u64 pool = n2 * (u64)(2 * k + 8);
+    ENS(c, c->out_res, n2 * 32); ENS(c, c->cig_pool, pool * 4);
+    ENS(c, c->pe_seq, n2 * (u64)ds + 64); ENS(c, c->in_qual, n * (u64)ds + 64); ENS(c, c->in_qual2, n * (u64)ds + 64); ENS(c, c->in_len, n2 * 2 + 16);
+    ENS(c, c->fq_idx, n2 * 12 + 128);
+    FqDev f1, f2;
+    { int r1 = fastq_upload(c, c->fq_text1, mate1, n, 0, f1); if (r1) return r1; r1 = fastq_upload(c, c->fq_text2, mate2, n, (n * 12 + 63) & ~63ull, f2); if (r1) return r1; }
+    // rows 0..n-1 = mate 1 as read, rows n..2n-1 = mate 2 reverse-complemented; the qualities stay in FASTQ order (qual_row)
+    char* seq_all = c->pe_seq.as<char>();
+    const unsigned g = nblk(n * (u64)(ds / 16), 256);
+    hipLaunchKernelGGL(k_fastq_rows, dim3(g), dim3(256), 0, c->stream, f1.text, f1.seq_off, f1.qual_off, f1.seq_len, f1.qual_len, (long)n, ds, 0, 0,
+                       seq_all, c->in_qual.as<char>(), c->in_len.as<u16>());
+    hipLaunchKernelGGL(k_fastq_rows, dim3(g), dim3(256), 0, c->stream, f2.text, f2.seq_off, f2.qual_off, f2.seq_len, f2.qual_len, (long)n, ds, 1, 0,
+                       seq_all + n * (u64)ds, c->in_qual2.as<char>(), c->in_len.as<u16>() + n);
+    int rc = map_pe_dev(c, (uint64_t)seq_all, (uint64_t)c->in_qual.p, (uint64_t)(seq_all + n * (u64)ds), (uint64_t)c->in_qual2.p,
+                        uniform ? nullptr : c->in_len.as<u16>(), L_max, ds, n_pairs, (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool, true);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n2 * 32, hipMemcpyDeviceToHost, c->stream));
+    const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
+    if (used > (u64)cigar_cap) { c->err = "host cigar pool too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
+    if (used) HIPCHK(c, hipMemcpyAsync(cigar_pool, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_cigar_used) *n_cigar_used = (int64_t)used;
+    return BMBS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

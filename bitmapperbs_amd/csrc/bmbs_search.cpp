@@ -15,12 +15,16 @@
 // The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
 // what limits it.  Here the host side is a three-stage, order-preserving pipeline so that
 // the GPU is fed at memory speed:
-//   stage R  window of the (mmap'ed) FASTQ -> newline index built by the I/O threads -> records packed into page-locked
-//            staging rows, every read with its own length (k = (uint64)(e*L) is per read, Schema.cpp:24546)
+//   stage R  window of the FASTQ read (parallel pread; .gz: gzread) into a page-locked buffer -> newline index built by the
+//            I/O threads -> per-record line starts and lengths.  The records are NOT packed on the host: the text window goes
+//            to the GPU as it is and the read rows are cut out of it there (bmbs_map_*_fastq), every read with its own length
+//            (k = (uint64)(e*L) is per read, Schema.cpp:24546)
 //   stage G  one bmbs_map_se[_var] / bmbs_map_pe[_var] call per batch (the only stage that touches the GPU); one worker thread
 //            per context -- the reference's parallel axis (N pthreads over sub-blocks, Schema.cpp:26336-26633) becomes
 //            N contexts over batches, and the five counters are summed over them at the end (Schema.cpp:451-476)
-//   stage W  SAM text formatted by the I/O threads into per-slice buffers, written with pwrite at prefix offsets
+//   stage F  SAM text formatted by the I/O threads into per-slice buffers (SEQ / QUAL straight from the FASTQ text)
+//   stage W  pwrite of the slices at their prefix offsets (buffered writes to ONE file serialise on its inode lock at the speed of
+//            one memcpy -- 10.5 GB/s on the MI355X box -- which is the ceiling of the whole pipeline)
 // Batches circulate through hand-over queues, so stage R of batch i+1 and stage W of batch i-1 overlap stage G of i.
 #include "../../include/bmbs.h"
 #include <zlib.h>
@@ -136,11 +140,11 @@ private:
     std::mutex m_; std::condition_variable cv_; std::map<long, T> q_; long next_ = 0;
 };
 
-// ---- FASTQ text source: plain files are mmap'ed (windows are views), .gz goes through gzread --------------------
+// ---- FASTQ text source: plain files are read with parallel pread()s straight into the batch's page-locked window, .gz goes
+// through gzread ---------------------------------------------------------------------------------------------------------------
 struct Source {
     bool gz = false;
     int fd = -1;
-    const char* map = nullptr;
     size_t size = 0, off = 0;
     gzFile gzf = nullptr;
     std::vector<char> carry;
@@ -160,57 +164,61 @@ struct Source {
         struct stat sb;
         if (fstat(fd, &sb)) return false;
         size = (size_t)sb.st_size;
-        if (size) {
-            void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (p == MAP_FAILED) return false;
-            map = (const char*)p;
-            madvise((void*)map, size, MADV_SEQUENTIAL);
-        }
+        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
         return true;
     }
-    // text starting at the current record boundary; `last` when it reaches the end of the input.
-    // For .gz the bytes live in `keep` (owned by the batch until its SAM text has been written).
-    void window(size_t want, const char*& p, size_t& len, bool& last, std::shared_ptr<std::vector<char>>& keep)
+    // up to `cap` bytes of text starting at the current record boundary into dst; `last` when they reach the end of the input
+    size_t window(Pool& pool, char* dst, size_t cap, bool& last)
     {
-        if (!gz) { p = map + off; len = std::min(want, size - off); last = off + len == size; return; }
-        keep = std::make_shared<std::vector<char>>();
-        keep->resize(carry.size() + want);
-        if (!carry.empty()) memcpy(keep->data(), carry.data(), carry.size());
+        if (!gz) {
+            const size_t len = std::min(cap, size - off);
+            const int T = pool.size() * 2;
+            const size_t per = ((len + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+            std::atomic<bool> bad(false);
+            pool.run(T, [&](int t) {
+                size_t a = std::min(len, per * (size_t)t);
+                const size_t e = std::min(len, a + per);
+                while (a < e) {
+                    const ssize_t g = pread(fd, dst + a, e - a, (off_t)(off + a));
+                    if (g <= 0) { bad = true; return; }
+                    a += (size_t)g;
+                }
+            });
+            last = off + len == size;
+            return bad ? 0 : len;
+        }
         size_t have = carry.size();
+        if (have) memcpy(dst, carry.data(), have);
         carry.clear();
-        while (!gz_eof && have < keep->size()) {
-            const int n = gzread(gzf, keep->data() + have, (unsigned)std::min<size_t>(keep->size() - have, 1u << 30));
+        while (!gz_eof && have < cap) {
+            const int n = gzread(gzf, dst + have, (unsigned)std::min<size_t>(cap - have, 1u << 30));
             if (n <= 0) { gz_eof = true; break; }
             have += (size_t)n;
         }
-        p = keep->data(); len = have; last = gz_eof;
+        last = gz_eof;
+        return have;
     }
     void consumed(const char* p, size_t len, size_t used)
     {
         if (!gz) { off += used; return; }
         carry.assign(p + used, p + len);
     }
-    void close() { if (gzf) gzclose(gzf); if (map) munmap((void*)map, size); if (fd >= 0) ::close(fd); }
+    void close() { if (gzf) gzclose(gzf); if (fd >= 0) ::close(fd); }
 };
 
 struct Lines {                                   // newline index of one window
     const char* p = nullptr;
     size_t len = 0, used = 0;                    // used = bytes consumed by the batch's records
-    bool mapped = false;                         // p points into an mmap'ed file
     std::vector<size_t> nl;                      // position of the '\n' ending line i (or len for an unterminated last line)
     size_t start(size_t line) const { return line == 0 ? 0 : nl[line - 1] + 1; }
     size_t end(size_t line) const { return nl[line]; }
 };
 
-#ifndef MADV_POPULATE_READ
-#define MADV_POPULATE_READ 22
-#endif
-
 // `part` is caller-owned scratch that keeps its capacity from batch to batch (fresh allocations of this size
 // are mmap'ed and page-faulted in again on every call)
-void index_lines(Pool& pool, const char* p, size_t len, bool last, bool mapped, Lines& out, std::vector<std::vector<size_t>>& part)
+void index_lines(Pool& pool, const char* p, size_t len, bool last, Lines& out, std::vector<std::vector<size_t>>& part)
 {
-    out.p = p; out.len = len; out.mapped = mapped; out.used = 0;
+    out.p = p; out.len = len; out.used = 0;
     const int T = pool.size() * 4;
     part.resize((size_t)T);
     const size_t per = (len + (size_t)T - 1) / (size_t)T;
@@ -221,11 +229,6 @@ void index_lines(Pool& pool, const char* p, size_t len, bool last, bool mapped, 
         v.reserve((b - a) / 64 + 16);
         const char* q = p + a;
         const char* e = p + b;
-        if (mapped && b > a) {
-            // pre-fault this slice of the file mapping in one call instead of one minor fault per 4 KB page
-            const size_t pg = 4096, lo = ((size_t)(p + a)) & ~(pg - 1), hi = (((size_t)(p + b)) + pg - 1) & ~(pg - 1);
-            (void)madvise((void*)lo, hi - lo, MADV_POPULATE_READ);
-        }
         while (q < e) {
             const char* h = (const char*)memchr(q, '\n', (size_t)(e - q));
             if (!h) break;
@@ -244,8 +247,6 @@ void index_lines(Pool& pool, const char* p, size_t len, bool last, bool mapped, 
     if (open_tail) out.nl[total] = len;
 }
 
-struct Group { int L; long count; int stride; size_t row0; size_t byte0; size_t pool0; int k; };
-
 struct Pinned {                                  // page-locked staging (bmbs_host_alloc)
     char* p = nullptr; size_t cap = 0;
     bool need(size_t bytes)
@@ -260,24 +261,33 @@ struct Pinned {                                  // page-locked staging (bmbs_ho
     void release() { if (p) bmbs_host_free(p); p = nullptr; cap = 0; }
 };
 
+// line index of one FASTQ file's records in a batch: offsets into the text window + lengths (what bmbs_fastq_view wants)
+struct RecIdx {
+    Pinned mem;
+    uint32_t *seq_off = nullptr, *qual_off = nullptr;
+    uint16_t *seq_len = nullptr, *qual_len = nullptr;
+    bool need(size_t n)
+    {
+        if (!mem.need(n * 12 + 64)) return false;
+        seq_off = (uint32_t*)mem.p; qual_off = seq_off + n; seq_len = (uint16_t*)(qual_off + n); qual_len = seq_len + n;
+        return true;
+    }
+};
+
 struct Batch {
     long seq = 0;                                // position in the input (output order)
     long n = 0;                                  // records
     bool end = false;                            // no more input after this batch
+    Pinned text1, text2;                         // the FASTQ text windows, as read from the files
     Lines l1, l2;
-    std::shared_ptr<std::vector<char>> keep1, keep2;
-    std::vector<Group> groups;
-    std::vector<uint32_t> row;                   // record -> staging row (global over the groups); ~0u = not mapped
-    std::vector<uint16_t> grp;                   // record -> group
-    std::vector<uint16_t> len1, len2;            // row -> read length (mate 1 / mate 2)
+    RecIdx r1, r2;
+    int maxL = 0, k = 0;                         // longest read of the batch, its threshold (sizes the CIGAR pool)
     bool uniform = true;                         // every read of the batch has the same length
-    Pinned seq1, qual1, seq2, qual2, res, pool;
+    Pinned res, pool;
     std::vector<std::vector<char>> text;         // SAM text per formatter slice (capacity kept from batch to batch)
     std::vector<size_t> text_len;
     std::vector<std::vector<char>> bam_rec, bam_z;   // --bam: records and BGZF blocks of a slice
 };
-
-const uint32_t NOROW = 0xffffffffu;
 
 inline char rc_char(char c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }   // rc_table, Process_Reads.cpp:1603
 
@@ -338,11 +348,22 @@ struct Out {
         if (r.n_cigar == 0) { num((unsigned)L); ch('M'); return; }
         for (int i = 0; i < r.n_cigar; i++) { const uint32_t o = pool[r.cigar_off + i]; num(o >> 4); ch("MDISH"[o & 15]); }
     }
-    // SEQ \t QUAL, as read or reverse-complemented with reversed qualities
-    void seq(const char* sq, const char* ql, int L, bool rc)
+    // SEQ \t QUAL from the FASTQ text: bases upper-cased (Process_Reads.cpp:836), a quality line shorter than the sequence
+    // padded with ' ' (qual.resize); as read, or reverse-complemented with reversed qualities
+    void seq(const char* sq, const char* ql, int L, int qlen, bool rc)
     {
-        if (!rc) { memcpy(p, sq, (size_t)L); p[L] = '\t'; memcpy(p + L + 1, ql, (size_t)L); }
-        else { revcomp_copy(p, sq, L); p[L] = '\t'; reverse_copy(p + L + 1, ql, L); }
+        char* qd = p + L + 1;
+        if (!rc) {
+            memcpy(p, sq, (size_t)L); upper_inplace(p, L);
+            memcpy(qd, ql, (size_t)qlen);
+            for (int i = qlen; i < L; i++) qd[i] = ' ';
+        } else {
+            memcpy(qd, sq, (size_t)L); upper_inplace(qd, L);            // the quality area as scratch
+            revcomp_copy(p, qd, L);
+            if (qlen == L) reverse_copy(qd, ql, L);
+            else for (int i = 0; i < L; i++) { const int jj = L - 1 - i; qd[i] = jj < qlen ? ql[jj] : ' '; }
+        }
+        p[L] = '\t';
         p += 2 * (size_t)L + 1;
     }
 };
@@ -551,14 +572,35 @@ int main(int argc, char** argv)
     if (io_threads <= 0) { io_threads = (int)std::thread::hardware_concurrency(); if (io_threads > 32) io_threads = 32; }
     if (io_threads < 1) io_threads = 1;
     const double t_start = now();
+    if (devices.empty()) devices.push_back(device);
+    if (contexts < 1) contexts = 1;
+    const bool pe = seq.empty();
+    const int n_batches = 4 + (int)devices.size() * contexts;
+    std::vector<Batch> batches((size_t)n_batches);
+    // page-locking memory costs ~0.2 ms per MB: the staging of every circulating batch is allocated once, here, by a few threads
+    // at a time (sized for 400-byte records of up to 250 bases; a batch that needs more grows its own)
+    std::thread prealloc([&] {
+        const size_t want = std::min<size_t>((size_t)batch * 400 + (1u << 16), (size_t)4000 << 20) + 64;
+        int k250 = (int)(uint64_t)(P.e_f * 250); if (k250 > 31) k250 = 31;
+        std::vector<std::thread> th;
+        for (auto& b : batches)
+            th.emplace_back([&, want, k250] {
+                Batch* bb = &b;
+                bb->text1.need(want); if (pe) bb->text2.need(want);
+                bb->r1.need((size_t)batch); if (pe) bb->r2.need((size_t)batch);
+                bb->res.need((size_t)batch * sizeof(bmbs_result) * (pe ? 2 : 1) + 64);
+                bb->pool.need((size_t)batch * (size_t)(2 * k250 + 8) * (pe ? 2 : 1) * 4 + 64);
+                bb->l1.nl.reserve((size_t)batch * 4 + 16); if (pe) bb->l2.nl.reserve((size_t)batch * 4 + 16);
+            });
+        for (auto& t : th) t.join();
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } prealloc_guard{prealloc};     // error returns below must not leave it running
     if (is_dir(index)) index += "/genome";           // Index.cpp:1048-1069
     bmbs_index_file* ixf = bmbs_index_file_load(index.c_str());
     if (!ixf) { fprintf(stderr, "Cannot open index %s.index*\n", index.c_str()); return 1; }
     bmbs_index_view view; bmbs_index_file_view(ixf, &view);
     // one owner context per listed device (attached in parallel: each uploads and re-packs its own index copy), plus
     // contexts-1 further contexts per device on the owner's index (bmbs_index_share)
-    if (devices.empty()) devices.push_back(device);
-    if (contexts < 1) contexts = 1;
     std::vector<bmbs_ctx*> ctxs;                  // owners first
     for (int d : devices) {
         bmbs_ctx* c = bmbs_create(d, &P);
@@ -609,7 +651,7 @@ int main(int argc, char** argv)
         out_off = h.size();
     }
     BamNames bam_refs; bam_refs.names = chrom_names;
-    const bool pe = seq.empty();
+    prealloc.join();
     const bool ambiguous_out = P.ambiguous_out != 0;
     // --pbat: single-end reads are mapped as their reverse complement with mirrored qualities (inputReads_single_directly_pbat,
     // Process_Reads.cpp:986-1075; Schema.cpp:15102 need_reverse_quality = 1); paired-end input files swap roles
@@ -619,40 +661,45 @@ int main(int argc, char** argv)
     Source src1, src2;
     if (!src1.open(pe ? seq1.c_str() : seq.c_str()) || (pe && !src2.open(seq2.c_str()))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
 
-    const int n_batches = 4 + (int)ctxs.size();
-    std::vector<Batch> batches((size_t)n_batches);
     Chan<Batch*> free_q, gpu_q, wr_q;
     OrderedChan<Batch*> out_q;                    // the G workers finish in any order; formatting and writing follow the input order
     long next_seq = 0;
     for (auto& b : batches) free_q.put(&b);
     std::atomic<bool> failed(false);
-    double t_read = 0, t_gpu = 0, t_write = 0, t_index = 0, t_format = 0;
+    double t_read = 0, t_gpu = 0, t_write = 0, t_index = 0, t_format = 0, t_window = 0, t_wait_r = 0, t_wait_f = 0, t_wait_w = 0, t_wait_g = 0;
     struct Ev { char stage; long n; double a, b; };
     std::vector<Ev> ev_r, ev_g, ev_f, ev_w;
 
-    // ---------------- stage R: window -> line index -> length groups -> packed staging rows ----------------------
+    // ---------------- stage R: text window -> line index -> per-record line starts and lengths ---------------------
     std::thread reader([&] {
-        Pool pool(std::max(1, io_threads / 2) - 1);
+        Pool pool(std::max(1, io_threads / 4) - 1);
         size_t est = 400;                                               // bytes per record, refined from the data
         std::vector<std::vector<size_t>> part;                          // scratch reused by every batch
-        std::vector<uint32_t> lens;
         for (;;) {
+            const double tw0 = now();
             Batch* b = free_q.get();
             const double t0 = now();
+            t_wait_r += t0 - tw0;
             b->seq = next_seq++;
-            b->n = 0; b->end = false; b->groups.clear(); b->keep1.reset(); b->keep2.reset();
-            const size_t want = (size_t)batch * est + (1u << 16);
-            const char *p1 = nullptr, *p2 = nullptr;
-            size_t n1 = 0, n2 = 0;
+            b->n = 0; b->end = false; b->maxL = 0; b->k = 0; b->uniform = true;
+            auto bail = [&](const char* why) {
+                if (why) fprintf(stderr, "bmbs_search: %s\n", why);
+                failed = true; b->end = true; b->n = 0; gpu_q.put(b);
+            };
+            // a window is handed to the library with 32-bit offsets: keep it below 4 GiB
+            const size_t want = std::min<size_t>((size_t)batch * est + (1u << 16), (size_t)4000 << 20);
+            if (!b->text1.need(want + 64) || (pe && !b->text2.need(want + 64))) { bail("cannot allocate page-locked staging memory"); return; }
             bool last1 = true, last2 = true;
-            src1.window(want, p1, n1, last1, b->keep1);
-            index_lines(pool, p1, n1, last1, !src1.gz, b->l1, part);
+            const size_t n1 = src1.window(pool, b->text1.p, want, last1);
+            t_window += now() - t0;
+            index_lines(pool, b->text1.p, n1, last1, b->l1, part);
             t_index += now() - t0;
             long avail1 = (long)(b->l1.nl.size() / 4), avail2 = 0;
             long nrec = avail1;
+            size_t n2 = 0;
             if (pe) {
-                src2.window(want, p2, n2, last2, b->keep2);
-                index_lines(pool, p2, n2, last2, !src2.gz, b->l2, part);
+                n2 = src2.window(pool, b->text2.p, want, last2);
+                index_lines(pool, b->text2.p, n2, last2, b->l2, part);
                 avail2 = (long)(b->l2.nl.size() / 4);
                 nrec = std::min(nrec, avail2);
             }
@@ -665,87 +712,49 @@ int main(int argc, char** argv)
                 return;
             }
             const size_t used1 = std::min(n1, b->l1.nl[(size_t)nrec * 4 - 1] + 1);
-            src1.consumed(p1, n1, used1);
+            src1.consumed(b->text1.p, n1, used1);
             b->l1.used = used1;
-            if (pe) { b->l2.used = std::min(n2, b->l2.nl[(size_t)nrec * 4 - 1] + 1); src2.consumed(p2, n2, b->l2.used); }
+            if (pe) { b->l2.used = std::min(n2, b->l2.nl[(size_t)nrec * 4 - 1] + 1); src2.consumed(b->text2.p, n2, b->l2.used); }
             est = std::max<size_t>(64, used1 / (size_t)nrec + 16);
             b->n = nrec;
-            // ---- one batch = one library call: every record keeps its own length (bmbs_map_*_var), rows in input order
+            if (!b->r1.need((size_t)nrec) || (pe && !b->r2.need((size_t)nrec))) { bail("cannot allocate page-locked staging memory"); return; }
+            // ---- one batch = one library call: every record keeps its own length, rows in input order
             const int T = pool.size();
             const long per = (nrec + T - 1) / T;
-            lens.resize((size_t)nrec * 2);                                  // L1, L2 (0 = not mapped)
             std::vector<int> mx((size_t)T, 0), mn((size_t)T, 1 << 30);
-            std::vector<long> valid((size_t)T + 1, 0);
+            std::vector<long> bad((size_t)T, -1);
             pool.run(T, [&](int t) {
                 const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
                 int m = 0, lo = 1 << 30;
-                long v = 0;
-                for (long r = a; r < e; r++) {
-                    uint32_t L1 = (uint32_t)(b->l1.end((size_t)r * 4 + 1) - b->l1.start((size_t)r * 4 + 1)), L2 = 0;
-                    bool ok = L1 >= 1 && L1 <= 1000;
-                    if (pe) { L2 = (uint32_t)(b->l2.end((size_t)r * 4 + 1) - b->l2.start((size_t)r * 4 + 1)); ok = ok && L2 >= 1 && L2 <= 1000; }
-                    if (!ok) { L1 = 0; L2 = 0; }
-                    lens[(size_t)r * 2] = L1; lens[(size_t)r * 2 + 1] = L2;
-                    if (ok) { v++; m = std::max(m, (int)std::max(L1, L2)); lo = std::min(lo, (int)L1); if (pe) lo = std::min(lo, (int)L2); }
-                }
-                mx[(size_t)t] = m; mn[(size_t)t] = lo; valid[(size_t)t + 1] = v;
+                auto one = [&](const Lines& ln, RecIdx& ri, long r) -> bool {
+                    const size_t s0 = ln.start((size_t)r * 4 + 1), e0 = ln.end((size_t)r * 4 + 1);
+                    const size_t q0 = ln.start((size_t)r * 4 + 3), q1 = ln.end((size_t)r * 4 + 3);
+                    const size_t L = e0 - s0;
+                    if (L < 1 || L > 1000) return false;
+                    ri.seq_off[r] = (uint32_t)s0; ri.qual_off[r] = (uint32_t)q0;
+                    ri.seq_len[r] = (uint16_t)L; ri.qual_len[r] = (uint16_t)std::min(L, q1 - q0);
+                    m = std::max(m, (int)L); lo = std::min(lo, (int)L);
+                    return true;
+                };
+                for (long r = a; r < e; r++)
+                    if (!one(b->l1, b->r1, r) || (pe && !one(b->l2, b->r2, r))) { if (bad[(size_t)t] < 0) bad[(size_t)t] = r; break; }
+                mx[(size_t)t] = m; mn[(size_t)t] = lo;
             });
             int maxL = 0, minL = 1 << 30;
-            for (int t = 0; t < T; t++) { maxL = std::max(maxL, mx[(size_t)t]); minL = std::min(minL, mn[(size_t)t]); valid[(size_t)t + 1] += valid[(size_t)t]; }
-            const long nvalid = valid[(size_t)T];
-            if (nvalid != nrec) fprintf(stderr, "bmbs_search: %ld %s skipped (empty or longer than 1000 characters)\n", nrec - nvalid, pe ? "pairs" : "reads");
-            size_t byte0 = 0, pool0 = 0;
-            if (nvalid) {
-                Group g; g.L = maxL; g.count = nvalid; g.stride = (maxL + 15) / 16 * 16; g.row0 = 0; g.byte0 = 0; g.pool0 = 0;
-                int k = (int)(uint64_t)(P.e_f * maxL); if (k > 31) k = 31;
-                g.k = k;
-                b->groups.push_back(g);
-                byte0 = (size_t)nvalid * (size_t)g.stride; pool0 = (size_t)nvalid * (size_t)(2 * k + 8) * (pe ? 2 : 1);
-            }
-            b->uniform = minL == maxL;
-            if (!b->seq1.need(byte0 + 64) || !b->qual1.need(byte0 + 64) || (pe && (!b->seq2.need(byte0 + 64) || !b->qual2.need(byte0 + 64))) ||
-                !b->res.need((size_t)nvalid * sizeof(bmbs_result) * (pe ? 2 : 1) + 64) || !b->pool.need(pool0 * 4 + 64)) {
-                fprintf(stderr, "bmbs_search: cannot allocate page-locked staging memory\n");
-                failed = true; b->end = true; b->n = 0; b->groups.clear(); gpu_q.put(b); return;
-            }
-            b->row.resize((size_t)nrec); b->grp.resize((size_t)nrec);
-            b->len1.resize((size_t)nvalid + 1); b->len2.resize(pe ? (size_t)nvalid + 1 : 1);
-            pool.run(T, [&](int t) {
-                const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
-                long j = valid[(size_t)t];
-                for (long r = a; r < e; r++) {
-                    const int L1 = (int)lens[(size_t)r * 2], L2 = (int)lens[(size_t)r * 2 + 1];
-                    b->grp[(size_t)r] = 0;
-                    if (L1 == 0) { b->row[(size_t)r] = NOROW; continue; }
-                    const Group& g = b->groups[0];
-                    b->row[(size_t)r] = (uint32_t)j;
-                    b->len1[(size_t)j] = (uint16_t)L1;
-                    if (pe) b->len2[(size_t)j] = (uint16_t)L2;
-                    const size_t at = (size_t)j * (size_t)g.stride;
-                    j++;
-                    auto pack = [&](const Lines& ln, int L, bool rc, char* sdst, char* qdst) {
-                        const char* s = ln.p + ln.start((size_t)r * 4 + 1);
-                        const size_t qs = ln.start((size_t)r * 4 + 3), qe = ln.end((size_t)r * 4 + 3);
-                        const int ql = (int)std::min<size_t>((size_t)L, qe - qs);
-                        if (!rc) {
-                            memcpy(sdst, s, (size_t)L);
-                            upper_inplace(sdst, L);
-                            memcpy(qdst, ln.p + qs, (size_t)ql);
-                            for (int i = ql; i < L; i++) qdst[i] = ' ';      // qual.resize(seq.size(), ' ')
-                        } else {
-                            memcpy(qdst, s, (size_t)L);                      // qdst as scratch: upper-case first, then reverse-complement
-                            upper_inplace(qdst, L);
-                            revcomp_copy(sdst, qdst, L);
-                            const char* q = ln.p + qs;
-                            if (ql == L) reverse_copy(qdst, q, L);
-                            else for (int i = 0; i < L; i++) { const int jj = L - 1 - i; qdst[i] = jj < ql ? q[jj] : ' '; }
-                        }
-                        if (L < g.stride) { memset(sdst + L, 0, (size_t)(g.stride - L)); memset(qdst + L, 0, (size_t)(g.stride - L)); }
-                    };
-                    pack(b->l1, L1, pbat_se, b->seq1.p + at, b->qual1.p + at);
-                    if (pe) pack(b->l2, L2, false, b->seq2.p + at, b->qual2.p + at);
+            for (int t = 0; t < T; t++) {
+                maxL = std::max(maxL, mx[(size_t)t]); minL = std::min(minL, mn[(size_t)t]);
+                if (bad[(size_t)t] >= 0) {
+                    // the reference's reader has no such limit on paper, its kernels do (SEQ_MAX_LENGTH 1000, Schema.h); a silently
+                    // dropped record would change the mapstats totals, so stop instead
+                    fprintf(stderr, "bmbs_search: record %ld of this batch has an empty or longer-than-1000-character sequence line: not supported\n", bad[(size_t)t]);
+                    bail(nullptr); return;
                 }
-            });
+            }
+            b->maxL = maxL; b->uniform = minL == maxL;
+            int k = (int)(uint64_t)(P.e_f * maxL); if (k > 31) k = 31;
+            b->k = k;
+            const size_t pool_ops = (size_t)nrec * (size_t)(2 * k + 8) * (pe ? 2 : 1);
+            if (!b->res.need((size_t)nrec * sizeof(bmbs_result) * (pe ? 2 : 1) + 64) || !b->pool.need(pool_ops * 4 + 64)) { bail("cannot allocate page-locked staging memory"); return; }
             t_read += now() - t0;
             ev_r.push_back({'R', nrec, t0, now()});
             const bool end = b->end;
@@ -756,12 +765,14 @@ int main(int argc, char** argv)
 
     // ---------------- stage F: SAM text, formatted by the I/O threads into per-slice buffers ---------------------
     std::thread formatter([&] {
-        Pool pool(std::max(1, io_threads - io_threads / 2) - 1);
+        Pool pool(std::max(1, io_threads - io_threads / 4 - 2) - 1);
         size_t max_chrom = 0;
         for (const auto& c : chrom_names) max_chrom = std::max(max_chrom, c.size());
         for (;;) {
+            const double tw0 = now();
             Batch* b = out_q.get();
             const double t0 = now();
+            t_wait_f += t0 - tw0;
             const long nrec = b->n;
             const bool end = b->end;
             const int T = pool.size() * 2;
@@ -776,26 +787,23 @@ int main(int argc, char** argv)
                     // upper bound of this slice's text: name + fixed columns + CIGAR + SEQ + QUAL per line
                     size_t bound = 64;
                     for (long r = a; r < e; r++) {
-                        if (b->row[(size_t)r] == NOROW) continue;
-                        const Group& g = b->groups[b->grp[(size_t)r]];
                         const size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
-                        bound += ((size_t)(pe ? 2 : 1)) * (nl + max_chrom + 2 * (size_t)g.L + 6 * (size_t)(2 * g.k + 8) + 128);
+                        bound += ((size_t)(pe ? 2 : 1)) * (nl + max_chrom + 2 * (size_t)b->maxL + 6 * (size_t)(2 * b->k + 8) + 128);
                     }
                     std::vector<char>& buf = b->text[(size_t)t];
                     if (buf.size() < bound) buf.resize(bound + bound / 8);
                     Out o{buf.data()};
+                    const char* t1 = b->l1.p;
+                    const char* t2 = b->l2.p;
                     for (long r = a; r < e; r++) {
-                        const uint32_t row = b->row[(size_t)r];
-                        if (row == NOROW) continue;
-                        const Group& g = b->groups[b->grp[(size_t)r]];
-                        const size_t j = (size_t)row - g.row0;
-                        const int L = (int)b->len1[j], L2 = pe ? (int)b->len2[j] : 0;
-                        const size_t at = g.byte0 + j * (size_t)g.stride;
-                        const uint32_t* gp = cpool + g.pool0;
-                        const char* nm = b->l1.p + b->l1.start((size_t)r * 4);
+                        const int L = (int)b->r1.seq_len[r], L2 = pe ? (int)b->r2.seq_len[r] : 0;
+                        const char* s1 = t1 + b->r1.seq_off[r];
+                        const char* q1 = t1 + b->r1.qual_off[r];
+                        const int ql1 = (int)b->r1.qual_len[r];
+                        const char* nm = t1 + b->l1.start((size_t)r * 4);
                         size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
                         if (!pe) {
-                            const bmbs_result& x = res[row];
+                            const bmbs_result& x = res[r];
                             const bool mapped = x.status == BMBS_ST_UNIQUE || (x.status == BMBS_ST_AMBIG && ambiguous_out);
                             if (!mapped && !(unmapped_out && x.status != BMBS_ST_AMBIG)) continue;
                             size_t c = 0;                               // cut at the first ' ' or '/' (Process_Reads.cpp:843-850)
@@ -806,20 +814,23 @@ int main(int argc, char** argv)
                             if (!mapped) {
                                 // output_sam_unmapped (Schema.cpp:23955-23975); pbat prints the record as it was read (25538-25543)
                                 o.lit("4\t*\t0\t0\t*\t*\t0\t0\t");
-                                o.seq(b->seq1.p + at, b->qual1.p + at, L, pbat_se);
+                                o.seq(s1, q1, L, ql1, false);
                                 o.ch('\n');
                                 continue;
                             }
                             o.num(x.flag); o.ch('\t'); o.str(chrom_names[(size_t)x.chrom]); o.ch('\t'); o.num(x.pos); o.ch('\t');
-                            o.num(x.mapq); o.ch('\t'); o.cigar(x, gp, L); o.lit("\t*\t0\t0\t");
-                            o.seq(b->seq1.p + at, b->qual1.p + at, L, (x.flag & 16) != 0);
+                            o.num(x.mapq); o.ch('\t'); o.cigar(x, cpool, L); o.lit("\t*\t0\t0\t");
+                            // a --pbat read was mapped as the reverse complement of the text: flag 16 prints the text as it is
+                            o.seq(s1, q1, L, ql1, ((x.flag & 16) != 0) != pbat_se);
                             o.lit("\tNM:i:"); o.num(x.nm); o.ch('\n');
                         } else {
-                            const bmbs_result* gr = res + 2 * g.row0;
-                            const bmbs_result &x1 = gr[2 * j], &x2 = gr[2 * j + 1];
+                            const bmbs_result &x1 = res[2 * r], &x2 = res[2 * r + 1];
                             const bool mapped = x1.status == BMBS_ST_UNIQUE || (x1.status == BMBS_ST_AMBIG && ambiguous_out);
                             if (!mapped && !(unmapped_out && x1.status != BMBS_ST_AMBIG)) continue;
-                            const char* nm2 = b->l2.p + b->l2.start((size_t)r * 4);
+                            const char* s2 = t2 + b->r2.seq_off[r];
+                            const char* q2 = t2 + b->r2.qual_off[r];
+                            const int ql2 = (int)b->r2.qual_len[r];
+                            const char* nm2 = t2 + b->l2.start((size_t)r * 4);
                             const size_t nl2 = b->l2.end((size_t)r * 4) - b->l2.start((size_t)r * 4);
                             size_t c = 0;                               // first differing char, ' ' or '/' (Process_Reads.cpp:296-307)
                             while (c < nl && c < nl2 && nm[c] == nm2[c] && nm[c] != ' ' && nm[c] != '/') c++;
@@ -828,25 +839,25 @@ int main(int argc, char** argv)
                             if (!mapped) {
                                 // directly_output_unmapped_PE (Schema.cpp:10392-10430)
                                 o.mem(nm, nl); o.lit("\t77\t*\t0\t0\t*\t*\t0\t0\t");
-                                o.seq(b->seq1.p + at, b->qual1.p + at, L, false); o.ch('\n');
+                                o.seq(s1, q1, L, ql1, false); o.ch('\n');
                                 o.mem(nm, nl); o.lit("\t141\t*\t0\t0\t*\t*\t0\t0\t");
-                                o.seq(b->seq2.p + at, b->qual2.p + at, L2, false); o.ch('\n');
+                                o.seq(s2, q2, L2, ql2, false); o.ch('\n');
                                 continue;
                             }
                             const unsigned tlen = x1.reserved;
                             o.mem(nm, nl); o.ch('\t');
                             o.num(x1.flag); o.ch('\t'); o.str(chrom_names[(size_t)x1.chrom]); o.ch('\t'); o.num(x1.pos); o.ch('\t');
-                            o.num(x1.mapq); o.ch('\t'); o.cigar(x1, gp, L); o.lit("\t=\t"); o.num(x2.pos); o.ch('\t');
+                            o.num(x1.mapq); o.ch('\t'); o.cigar(x1, cpool, L); o.lit("\t=\t"); o.num(x2.pos); o.ch('\t');
                             if (x2.pos < x1.pos) o.ch('-');             // TLEN sign, Schema.cpp:10575-10600
                             o.num(tlen); o.ch('\t');
-                            o.seq(b->seq1.p + at, b->qual1.p + at, L, !(x1.flag & 32));
+                            o.seq(s1, q1, L, ql1, !(x1.flag & 32));
                             o.lit("\tNM:i:"); o.num(x1.nm); o.ch('\n');
                             o.mem(nm, nl); o.ch('\t');
                             o.num(x2.flag); o.ch('\t'); o.str(chrom_names[(size_t)x2.chrom]); o.ch('\t'); o.num(x2.pos); o.ch('\t');
-                            o.num(x2.mapq); o.ch('\t'); o.cigar(x2, gp, L2); o.lit("\t=\t"); o.num(x1.pos); o.ch('\t');
+                            o.num(x2.mapq); o.ch('\t'); o.cigar(x2, cpool, L2); o.lit("\t=\t"); o.num(x1.pos); o.ch('\t');
                             if (!(x1.pos > x2.pos)) o.ch('-');           // Schema.cpp:11530-11555
                             o.num(tlen); o.ch('\t');
-                            o.seq(b->seq2.p + at, b->qual2.p + at, L2, (x2.flag & 16) != 0);
+                            o.seq(s2, q2, L2, ql2, (x2.flag & 16) != 0);
                             o.lit("\tNM:i:"); o.num(x2.nm); o.ch('\n');
                         }
                     }
@@ -879,39 +890,68 @@ int main(int argc, char** argv)
         }
     });
 
-    // ---------------- stage W: pwrite of the slices at prefix offsets; consumed input pages are released -------
+    // ---------------- stage W: the slices go into the output file at their prefix offsets -----------------------------
+    // write()/pwrite() to ONE file take its inode lock exclusively: N threads writing N slices run one after the other at the
+    // speed of one memcpy (tools/host_mem_probe on the MI355X box: 10.5 GB/s with 1, 8, 16 or 32 threads; tmpfs 5.4 GB/s) -- that,
+    // 30 M SAM records of 350 bytes per second, is the ceiling of a file-to-file run.  The alternative, a shared mapping of the
+    // file filled by several threads (BMBS_MMAP_OUT=1), measured WORSE on that box: 8.4 GB/s with one thread, 2.3 GB/s with 8-16
+    // (page-fault path of the overlay file system), so pwrite stays the default.
+    struct stat ost;
+    const bool out_mappable = fstat(ofd, &ost) == 0 && S_ISREG(ost.st_mode) && getenv("BMBS_MMAP_OUT");
     std::thread writer([&] {
-        Pool pool(std::max(1, io_threads / 4) - 1);
+        Pool pool(out_mappable ? std::max(1, io_threads / 4) - 1 : 1);     // pwrite()s to one file run one at a time anyway
         for (;;) {
+            const double tw0 = now();
             Batch* b = wr_q.get();
             const double t0 = now();
+            t_wait_w += t0 - tw0;
             const bool end = b->end;
             const int T = (int)b->text.size();
             if (b->n && !failed) {
                 std::vector<size_t> at((size_t)T + 1, out_off);
                 for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + b->text_len[(size_t)t];
-                pool.run(T, [&](int t) {
-                    const char* d = b->text[(size_t)t].data();
-                    const size_t len = b->text_len[(size_t)t];
-                    size_t done = 0;
-                    while (done < len) {
-                        const ssize_t w = pwrite(ofd, d + done, len - done, (off_t)(at[(size_t)t] + done));
-                        if (w <= 0) { failed = true; break; }
-                        done += (size_t)w;
+                const size_t total = at[(size_t)T] - out_off;
+                char* map = nullptr;
+                size_t map_lo = 0, map_len = 0;
+                if (out_mappable && total) {
+                    map_lo = out_off & ~(size_t)4095; map_len = at[(size_t)T] - map_lo;
+                    if (ftruncate(ofd, (off_t)at[(size_t)T]) == 0) {
+                        void* m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, ofd, (off_t)map_lo);
+                        if (m != MAP_FAILED) map = (char*)m;
                     }
-                });
+                }
+                if (map) {
+                    // equal byte ranges, not slices: the copy is balanced whatever the slices' sizes are
+                    const int W = pool.size() * 2;
+                    const size_t per = (total + (size_t)W - 1) / (size_t)W;
+                    pool.run(W, [&](int w) {
+                        size_t lo = out_off + std::min(total, per * (size_t)w);
+                        const size_t hi = out_off + std::min(total, per * (size_t)(w + 1));
+                        int t = (int)(std::upper_bound(at.begin(), at.end(), lo) - at.begin()) - 1;
+                        while (lo < hi && t < T) {
+                            const size_t stop = std::min(hi, at[(size_t)t + 1]);
+                            if (stop > lo) memcpy(map + (lo - map_lo), b->text[(size_t)t].data() + (lo - at[(size_t)t]), stop - lo);
+                            lo = std::max(lo, stop);
+                            t++;
+                        }
+                    });
+                    munmap(map, map_len);
+                } else {
+                    pool.run(T, [&](int t) {
+                        const char* d = b->text[(size_t)t].data();
+                        const size_t len = b->text_len[(size_t)t];
+                        size_t done = 0;
+                        while (done < len) {
+                            const ssize_t w = pwrite(ofd, d + done, len - done, (off_t)(at[(size_t)t] + done));
+                            if (w <= 0) { failed = true; break; }
+                            done += (size_t)w;
+                        }
+                    });
+                }
                 out_off = at[(size_t)T];
-            }
-            // the text of this batch is no longer needed: drop the whole pages of its input windows now (in the
-            // shadow of the pipeline) instead of paying for one big munmap at exit
-            for (const Lines* ln : {&b->l1, &b->l2}) {
-                if (!ln->p || !ln->mapped || !b->n) continue;
-                const size_t pg = 4096, lo = ((size_t)ln->p + pg - 1) & ~(pg - 1), hi = ((size_t)ln->p + ln->used) & ~(pg - 1);
-                if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
             }
             t_write += now() - t0;
             ev_w.push_back({'W', b->n, t0, now()});
-            b->keep1.reset(); b->keep2.reset();
             free_q.put(b);
             if (end) return;
         }
@@ -922,28 +962,24 @@ int main(int argc, char** argv)
     std::mutex g_mu;
     auto g_worker = [&](bmbs_ctx* ctx) {
         for (;;) {
+            const double tw0 = now();
             Batch* b = gpu_q.get();
             if (!b) return;                                                // another worker has seen the last batch
             const double t0 = now();
-            if (!failed)
-                for (const Group& g : b->groups) {
-                    int64_t used = 0;
-                    int rc;
-                    // equal lengths take the fixed-length entry points, a trimmed library the per-read-length ones
-                    if (!pe && b->uniform)
-                        rc = bmbs_map_se(ctx, b->seq1.p, b->qual1.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p,
-                                         (int64_t)g.count * (2 * g.k + 8), &used);
-                    else if (!pe)
-                        rc = bmbs_map_se_var(ctx, b->seq1.p, b->qual1.p, b->len1.data(), g.L, g.stride, g.count, (bmbs_result*)b->res.p,
-                                             (uint32_t*)b->pool.p, (int64_t)g.count * (2 * g.k + 8), &used);
-                    else if (b->uniform)
-                        rc = bmbs_map_pe(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, g.L, g.stride, g.count, (bmbs_result*)b->res.p,
-                                         (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
-                    else
-                        rc = bmbs_map_pe_var(ctx, b->seq1.p, b->qual1.p, b->seq2.p, b->qual2.p, b->len1.data(), b->len2.data(), g.L, g.stride,
-                                             g.count, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, (int64_t)g.count * 2 * (2 * g.k + 8), &used);
-                    if (rc) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); failed = true; break; }
+            { std::lock_guard<std::mutex> l(g_mu); t_wait_g += t0 - tw0; }
+            if (!failed && b->n) {
+                int64_t used = 0;
+                int rc;
+                bmbs_fastq_view v1 = {b->text1.p, (uint64_t)b->l1.used, b->r1.seq_off, b->r1.qual_off, b->r1.seq_len, b->r1.qual_len};
+                const int64_t cap = (int64_t)b->n * (2 * b->k + 8) * (pe ? 2 : 1);
+                if (!pe)
+                    rc = bmbs_map_se_fastq(ctx, &v1, b->n, b->maxL, b->uniform ? 1 : 0, pbat_se ? 1 : 0, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, cap, &used);
+                else {
+                    bmbs_fastq_view v2 = {b->text2.p, (uint64_t)b->l2.used, b->r2.seq_off, b->r2.qual_off, b->r2.seq_len, b->r2.qual_len};
+                    rc = bmbs_map_pe_fastq(ctx, &v1, &v2, b->n, b->maxL, b->uniform ? 1 : 0, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, cap, &used);
                 }
+                if (rc) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); failed = true; }
+            }
             total_records_a += b->n;
             {
                 std::lock_guard<std::mutex> l(g_mu);
@@ -984,11 +1020,14 @@ int main(int argc, char** argv)
         fprintf(stderr, "[bmbs_search] records %ld  load+attach %.3fs  mapping wall %.3fs  (pipeline %.3fs; stage busy: read/pack %.3fs of which line index %.3fs, gpu %.3fs, format %.3fs, write %.3fs)  %d I/O threads, batch %ld, %zu device(s) x %d context(s)\n",
                 total_records, t_loaded - t_start, t_end - t_loaded, t_joined - t_loaded, t_read, t_index, t_gpu, t_format, t_write, io_threads, batch,
                 n_owner, contexts);
+    if (verbose)
+        fprintf(stderr, "[bmbs_search] read stage: window %.3fs, line index %.3fs; stage idle (waiting for a batch): read %.3fs, gpu workers %.3fs (summed), format %.3fs, write %.3fs\n",
+                t_window, t_index - t_window, t_wait_r, t_wait_g, t_wait_f, t_wait_w);
     if (verbose && getenv("BMBS_TRACE"))
         for (const auto* v : {&ev_r, &ev_g, &ev_f, &ev_w})
             for (const Ev& e : *v) fprintf(stderr, "[trace] %c n=%ld %.4f .. %.4f\n", e.stage, e.n, e.a - t_loaded, e.b - t_loaded);
     const double t0 = now();
-    for (auto& b : batches) { b.seq1.release(); b.qual1.release(); b.seq2.release(); b.qual2.release(); b.res.release(); b.pool.release(); }
+    for (auto& b : batches) { b.text1.release(); b.text2.release(); b.r1.mem.release(); b.r2.mem.release(); b.res.release(); b.pool.release(); }
     const double t1 = now();
     for (size_t i = ctxs.size(); i-- > 0;) bmbs_destroy(ctxs[i]);     // the sharing contexts go before their owners
     const double t2 = now();

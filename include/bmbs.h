@@ -199,6 +199,27 @@ int bmbs_map_pe(bmbs_ctx*, const char* seq1, const char* qual1, const char* seq2
 int bmbs_map_pe_device(bmbs_ctx*, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, int32_t L,
                        int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap);
 
+/* ---- FASTQ text in: the reads are cut out of the text ON THE DEVICE -------------------------------------------------------------
+ * What the reference's reader does per record on one host thread (inputReads_single_directly / inputReads_paired_directly,
+ * Process_Reads.cpp:810-890, 155-317: kseq line splitting, toupper, `qual.resize(seq.size(), ' ')`, the reverse complement of
+ * mate 2 at :262-267 and of every --pbat read with mirrored qualities at :986-1075) is done by one kernel over the batch; the host
+ * hands over the text window as it came from the file plus the line starts it found.  A window is smaller than 4 GiB.
+ * Records keep their own lengths (1..L_max, L_max <= 1000); `uniform` != 0 promises that every read has length L_max (the
+ * fixed-length kernels are used).  results / cigar_pool as for bmbs_map_se / bmbs_map_pe.  Page-locked text buffers
+ * (bmbs_host_alloc) are copied at link speed.                                                                                  */
+typedef struct bmbs_fastq_view {
+    const char*     text;        /* FASTQ text window (host memory)                                                   */
+    uint64_t        text_bytes;
+    const uint32_t* seq_off;     /* [n] offset of the first base of record i                                          */
+    const uint32_t* qual_off;    /* [n] offset of its first quality character                                         */
+    const uint16_t* seq_len;     /* [n] bases of record i                                                             */
+    const uint16_t* qual_len;    /* [n] quality characters present (a shorter line is padded with ' ')                */
+} bmbs_fastq_view;
+int bmbs_map_se_fastq(bmbs_ctx*, const bmbs_fastq_view* reads, int64_t n_reads, int32_t L_max, int32_t uniform, int32_t pbat,
+                      bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used);
+int bmbs_map_pe_fastq(bmbs_ctx*, const bmbs_fastq_view* mate1, const bmbs_fastq_view* mate2, int64_t n_pairs, int32_t L_max,
+                      int32_t uniform, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used);
+
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
  * error bases} (Schema.cpp:25141-25146); bmbs_stats_allreduce sums them over the ctxs one process
  * drives (get_mapping_informations, Schema.cpp:451-476).  Multi-process jobs sum the five int64 with
