@@ -580,17 +580,27 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     ix.C[0] = v->nacgt[0]; ix.C[1] = v->nacgt[1]; ix.C[2] = v->nacgt[2]; ix.n_chrom = v->n_chrom;
     hipLaunchKernelGGL(k_expand_sa, dim3(nblk(std::min<u64>(rows, 1ull << 30), 256)), dim3(256), 0, c->stream, ix, R, rows, wide ? nullptr : c->sa.as<u32>(),
                        wide ? c->sa.as<u64>() : nullptr);
-    // 20-mer outcome table (27.9 GB): built when the device has the room; BMBS_T20=0 turns it off (A/B runs, small devices)
-    ix.t20 = nullptr;
+    // (16 + E)-mer outcome table: E = 5 (3^21 entries, 83.7 GB) for texts of 2^32 symbols and more when the device has the room,
+    // else E = 4 (3^20 entries, 27.9 GB), else none; BMBS_T20=0 turns it off, BMBS_TDEPTH=20|21 forces a depth (A/B runs, tests)
+    ix.t20 = nullptr; ix.t_e = 4;
     {
         const char* t20_env = getenv("BMBS_T20");
+        const char* td_env = getenv("BMBS_TDEPTH");
         const u64 n_keys = v->hash_entries - 1;                 // 3^16
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const u64 need = n_keys * T20_EXT * 8;
-        if (!(t20_env && !strcmp(t20_env, "0")) && n_keys == 43046721ull && free_b > need + (48ull << 30) && ensure(c, c->t20, need) == BMBS_OK) {
-            hipLaunchKernelGGL(k_build_t20, dim3(nblk(n_keys, 256)), dim3(256), 0, c->stream, ix, n_keys, c->t20.as<u64>());
-            ix.t20 = c->t20.as<u64>();
+        int want_e = wide ? 5 : 4;
+        if (td_env) want_e = atoi(td_env) == 21 ? 5 : 4;
+        if (!(t20_env && !strcmp(t20_env, "0")) && n_keys == 43046721ull) {
+            for (int e5 = want_e; e5 >= 4; e5--) {
+                const u64 need = n_keys * t20_width(e5) * 8;
+                if (free_b > need + (48ull << 30) && ensure(c, c->t20, need) == BMBS_OK) {
+                    ix.t_e = e5;
+                    hipLaunchKernelGGL(k_build_t20, dim3(nblk(n_keys, 256)), dim3(256), 0, c->stream, ix, n_keys, c->t20.as<u64>());
+                    ix.t20 = c->t20.as<u64>();
+                    break;
+                }
+            }
         }
     }
     hipError_t e = hipStreamSynchronize(c->stream);

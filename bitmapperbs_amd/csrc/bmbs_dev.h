@@ -33,7 +33,8 @@ struct DevIndex {
     const u64*   sa64;          // texts of >= 2^32 symbols: 64-bit suffix array instead of sa
     const u64*   occ_super;     // ... and the counts of occ are relative to this {T, A} table per 65 536 symbols
     const u64*   gen2;
-    const u64*   t20;           // optional: outcome of the first four extensions of every 20-mer (k_build_t20), else nullptr
+    const u64*   t20;           // optional: outcome of the first t_e extensions of every (16 + t_e)-mer (k_build_t20), else nullptr
+    int          t_e;           // letters the table looks ahead: 4 (3^20 entries, 27.9 GB) or 5 (3^21 entries, 83.7 GB; GRCh38-size texts)
     const u64*   chrom_start;   // n_chrom+1 cumulative starts (single strand)
     u64 G;                      // one-strand length
     u64 total;                  // 2G = total_SA_length

@@ -305,64 +305,65 @@ __global__ void k_repack_hash(RefIndexDev R, u64 n, u64* out)
     out[i] = (((u64)(hi & 0x0fffffffu)) << 8) | R.hash_lo[i] | ((u64)(hi >> 28) << 60);
 }
 
-// ---- 20-mer outcome table ----------------------------------------------------------------------------
-// entry = row (36 bits) | hits (24 bits) << 36 | tag << 60.  With I16 the interval of the 16-mer and c16..c19 the next four
+// ---- (16 + E)-mer outcome table, E = ix.t_e = 4 or 5 ---------------------------------------------------------------
+// entry = row (36 bits) | hits (24 bits) << 36 | tag << 60.  With I16 the interval of the 16-mer and c16, c17, ... the next E
 // letters, count_backward_as_much_1_terminate does, for s = 0, 1, ...: stop if |I| == 1 (match length 16+s, 1 hit);
 // extend by c(16+s); stop if that is empty (match length 16+s, hits of the interval before).  Tags:
-//   1..4  stopped unique before consuming c16 / c17 / c18 / c19      (match length 15 + tag; the field holds SA[row], the TEXT
-//         POSITION of that single row: whoever gets a unique seed needs nothing else from the row, and the suffix-array
-//         gather -- one 64-byte sector for 4 bytes, per read -- is paid once, here, instead of per lookup)
-//   5..8  stopped because c16 / c17 / c18 / c19 does not occur       (row, hits = interval before, match length 11 + tag)
-//   0     all four letters consumed: row, hits = depth-20 interval (the caller carries on with s = 4)
-//   9     all four letters consumed and the depth-20 interval is one row: the next iteration would stop there (match length 20,
-//         1 hit); the field holds the text position, as for tags 1..4
-//   15    the 16-mer itself does not occur;   14  hits do not fit 24 bits: use the 16-mer path
-#define T20_EXT 81
+//   1..E        stopped unique before consuming c(15 + tag)          (match length 15 + tag; the field holds SA[row], the TEXT
+//               POSITION of that single row: whoever gets a unique seed needs nothing else from the row, and the suffix-array
+//               gather -- one 64-byte sector for 4 or 8 bytes, per read -- is paid once, here, instead of per lookup)
+//   E+1..2E     stopped because c(15 + tag - E) does not occur       (row, hits = interval before, match length 15 - E + tag)
+//   0           all E letters consumed: row, hits = depth-(16+E) interval (the caller carries on with s = E)
+//   2E+1        all E letters consumed and that interval is one row: the next iteration would stop there (match length 16 + E,
+//               1 hit); the field holds the text position, as for tags 1..E
+//   15          the 16-mer itself does not occur;   14  hits do not fit 24 bits: use the 16-mer path
+// E = 4: 3^20 entries = 27.9 GB.  E = 5: 3^21 entries = 83.7 GB -- chosen for texts of 2^32 symbols and more, where a 20-mer
+// still has ~2 occurrences (6.2 G suffixes / 3.5 G 20-mers) and every seed would walk 2-3 more dependent Occ gathers.
+#define T20_MAX_E 5
 DEVI u64 t20_entry(u64 row, u64 hits, int tag) { return hits >= (1ull << 24) ? (14ull << 60) : (row | (hits << 36) | ((u64)tag << 60)); }
+__host__ __device__ inline u64 t20_width(int e) { return e == 5 ? 243ull : 81ull; }
 
 __global__ void __launch_bounds__(256)
 k_build_t20(DevIndex ix, u64 n_keys, u64* __restrict__ t20)
 {
     const u64 key = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= n_keys) return;
-    u64* o = t20 + key * T20_EXT;
+    const int E = ix.t_e;
+    const int W = (int)t20_width(E);
+    u64* o = t20 + key * (u64)W;
     u64 t0, b0;
     hash_lookup(ix, key, t0, b0);
-    if (b0 <= t0) { for (int e = 0; e < T20_EXT; e++) o[e] = 15ull << 60; return; }
-    // depth-first over c16..c19; a stopped prefix decides all of its continuations
-    for (int d0 = 0; d0 < 3; d0++) {
-        u64 v0 = 0, t1 = t0, b1 = b0;
-        bool s0 = true;
-        if (b0 - t0 == 1) v0 = t20_entry(sa_at(ix, t0), 1, 1);
-        else { lf_pair(ix, t1, b1, d0); if (b1 <= t1) v0 = t20_entry(t0, b0 - t0, 5); else s0 = false; }
-        for (int d1 = 0; d1 < 3; d1++) {
-            u64 v1 = v0, t2 = t1, b2 = b1;
-            bool s1 = s0;
-            if (!s1) {
-                if (b1 - t1 == 1) { v1 = t20_entry(sa_at(ix, t1), 1, 2); s1 = true; }
-                else { lf_pair(ix, t2, b2, d1); if (b2 <= t2) { v1 = t20_entry(t1, b1 - t1, 6); s1 = true; } }
-            }
-            for (int d2 = 0; d2 < 3; d2++) {
-                u64 v2 = v1, t3 = t2, b3 = b2;
-                bool s2 = s1;
-                if (!s2) {
-                    if (b2 - t2 == 1) { v2 = t20_entry(sa_at(ix, t2), 1, 3); s2 = true; }
-                    else { lf_pair(ix, t3, b3, d2); if (b3 <= t3) { v2 = t20_entry(t2, b2 - t2, 7); s2 = true; } }
-                }
-                for (int d3 = 0; d3 < 3; d3++) {
-                    u64 v3 = v2;
-                    if (!s2) {
-                        if (b3 - t3 == 1) v3 = t20_entry(sa_at(ix, t3), 1, 4);
-                        else {
-                            u64 t4 = t3, b4 = b3;
-                            lf_pair(ix, t4, b4, d3);
-                            v3 = b4 <= t4 ? t20_entry(t3, b3 - t3, 8) : b4 - t4 == 1 ? t20_entry(sa_at(ix, t4), 1, 9) : t20_entry(t4, b4 - t4, 0);
-                        }
-                    }
-                    o[d0 + 3 * d1 + 9 * d2 + 27 * d3] = v3;
-                }
-            }
+    if (b0 <= t0) { for (int e = 0; e < W; e++) o[e] = 15ull << 60; return; }
+    // depth-first over c16 .. c(15+E): level l consumes c(16+l) = digit l of the entry index (least significant first); a stopped
+    // prefix decides all of its continuations.  tp/bt[l] = interval after l letters, val[l] / stop[l] = outcome once decided.
+    u64 tp[T20_MAX_E + 1], bt[T20_MAX_E + 1], val[T20_MAX_E + 1];
+    bool stop[T20_MAX_E + 1];
+    int dig[T20_MAX_E];
+    int pw[T20_MAX_E];
+    { int x = 1; for (int l = 0; l < E; l++) { pw[l] = x; x *= 3; } }
+    tp[0] = t0; bt[0] = b0; val[0] = 0; stop[0] = false;
+    for (int l = 0; l < E; l++) dig[l] = 0;
+    int l = 0;                     // level being (re)computed
+    for (;;) {
+        // state after consuming digits dig[0..l] -> level l + 1
+        for (; l < E; l++) {
+            const int d = dig[l];
+            if (stop[l]) { stop[l + 1] = true; val[l + 1] = val[l]; tp[l + 1] = tp[l]; bt[l + 1] = bt[l]; continue; }
+            if (bt[l] - tp[l] == 1) { val[l + 1] = t20_entry(sa_at(ix, tp[l]), 1, 1 + l); stop[l + 1] = true; continue; }
+            u64 t = tp[l], b = bt[l];
+            lf_pair(ix, t, b, d);
+            if (b <= t) { val[l + 1] = t20_entry(tp[l], bt[l] - tp[l], E + 1 + l); stop[l + 1] = true; }
+            else { tp[l + 1] = t; bt[l + 1] = b; stop[l + 1] = false; val[l + 1] = 0; }
         }
+        int idx = 0;
+        for (int q = 0; q < E; q++) idx += dig[q] * pw[q];
+        o[idx] = stop[E] ? val[E] : (bt[E] - tp[E] == 1 ? t20_entry(sa_at(ix, tp[E]), 1, 2 * E + 1) : t20_entry(tp[E], bt[E] - tp[E], 0));
+        // next continuation: the deepest digit first (shares the longest prefix)
+        int q = E - 1;
+        while (q >= 0 && dig[q] == 2) { dig[q] = 0; q--; }
+        if (q < 0) break;
+        dig[q]++;
+        l = q;
     }
 }
 
@@ -561,7 +562,7 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     const int a16 = tm & ~15, o = tm & 15;
     const uint4 B0 = *reinterpret_cast<const uint4*>(rd + a16), B1 = *reinterpret_cast<const uint4*>(rd + a16 + 16);
     uint4 B2 = make_uint4(0, 0, 0, 0);
-    if (o >= 12 && a16 + 32 < L) B2 = *reinterpret_cast<const uint4*>(rd + a16 + 32);
+    if (o + 16 + ix.t_e >= 32 && a16 + 32 < L) B2 = *reinterpret_cast<const uint4*>(rd + a16 + 32);
     const u64 q0 = ((u64)B0.y << 32) | B0.x, q1 = ((u64)B0.w << 32) | B0.z, q2 = ((u64)B1.y << 32) | B1.x,
               q3 = ((u64)B1.w << 32) | B1.z, q4 = ((u64)B2.y << 32) | B2.x;
     const int sh8 = (o & 7) * 8;
@@ -576,12 +577,15 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
     // < 3^16: 32-bit arithmetic
     const u64 key = base3_of4((u32)d0) + 81u * base3_of4((u32)(d0 >> 32)) + 6561u * base3_of4((u32)d1) + 531441u * base3_of4((u32)(d1 >> 32));
     S.steps = len - 16; S.tm = tm;
-    if ((!FIXED || LOCATED) && ix.t20 && len >= 20) {
-        // the 16-mer lookup and the first four extensions in one table read
+    const int E = ix.t_e;
+    if ((!FIXED || LOCATED) && ix.t20 && len >= 16 + E) {
+        // the 16-mer lookup and the first E extensions in one table read
         u64 d2, v2;
-        swar_code3(funnel(c2, c3) & 0xffffffffull, d2, v2);          // read[tm+16 .. tm+19]
-        if ((u32)v2 == 0) {
-            const u64 v = ix.t20[key * T20_EXT + (u64)base3_of4((u32)d2)];
+        const u64 cmask = E == 5 ? 0xffffffffffull : 0xffffffffull;
+        swar_code3(funnel(c2, c3) & cmask, d2, v2);                  // read[tm+16 .. tm+15+E]
+        if ((v2 & cmask) == 0) {
+            const u64 code = (u64)base3_of4((u32)d2) + (E == 5 ? 81ull * ((d2 >> 32) & 0xffull) : 0ull);
+            const u64 v = ix.t20[key * t20_width(E) + code];
             const int tag = (int)(v >> 60);
             if (tag != 14) {
                 n_hash++;
@@ -590,23 +594,23 @@ DEVI bool search_begin(const DevIndex& ix, const char* rd, int L, int tm, Search
                 if (FIXED) {
                     // count_hash_table goes through the whole pattern: a missing letter is 0 hits; a single row carries on --
                     // the caller finishes it against the genome (k_seed_second), from the text position the table holds
-                    if (tag >= 5 && tag <= 8) return false;
+                    if (tag > E && tag <= 2 * E) return false;
                     if (tag != 0) {
-                        S.top = row | (1ull << 63); S.bot = S.top + 1; S.ptop = ~0ull; S.pbot = ~0ull; S.s = tag == 9 ? 4 : tag - 1;
+                        S.top = row | (1ull << 63); S.bot = S.top + 1; S.ptop = ~0ull; S.pbot = ~0ull; S.s = tag == 2 * E + 1 ? E : tag - 1;
                         return true;
                     }
                 } else {
-                    if (tag >= 1 && tag <= 4) { out.ml = (u64)(15 + tag); out.sp = row | (1ull << 63); out.hits = 1; return false; }     // located (bit 63): text position
-                    if (tag == 9) { out.ml = 20; out.sp = row | (1ull << 63); out.hits = 1; return false; }
-                    if (tag >= 5) { out.ml = (u64)(11 + tag); out.sp = row; out.hits = hits; return false; }
+                    if (tag >= 1 && tag <= E) { out.ml = (u64)(15 + tag); out.sp = row | (1ull << 63); out.hits = 1; return false; }     // located (bit 63): text position
+                    if (tag == 2 * E + 1) { out.ml = (u64)(16 + E); out.sp = row | (1ull << 63); out.hits = 1; return false; }
+                    if (tag > E) { out.ml = (u64)(15 - E + tag); out.sp = row; out.hits = hits; return false; }
                 }
-                S.top = row; S.bot = row + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = 4;
+                S.top = row; S.bot = row + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = E;
                 if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
-                S.cur.seek_with(rd, tm + 20, L, o < 12 ? B1 : B2);
+                S.cur.seek_with(rd, tm + 16 + E, L, o + 16 + E < 32 ? B1 : B2);
                 return true;
             }
         }
-        // a letter outside the alphabet among the four, or an oversized interval: the 16-mer path
+        // a letter outside the alphabet among them, or an oversized interval: the 16-mer path
     }
     hash_lookup(ix, key, S.top, S.bot);
     n_hash++;

@@ -89,6 +89,11 @@ int orc_map_se(const orc_index*, const orc_params*, const char* seq, const char*
                const int32_t* len, int stride, int64_t n, orc_rec* recs, int64_t stats[5],
                orc_counters* counters);
 
+/* orc_map_se plus the vote lists (site, count) of the general-path reads in the reference's visiting order (a9/a10) */
+int64_t orc_map_se_votes(const orc_index*, const orc_params*, const char* seq, const char* qual, const int32_t* len, int stride,
+                         int64_t n, orc_rec* recs, int64_t stats[5], uint64_t* vote_site, uint32_t* vote_cnt, uint64_t* vote_off,
+                         int64_t cap);
+
 /* paired-end record (fast mode, Map_Pair_Seq_end_to_end_fast, Schema.cpp:18570) */
 typedef struct orc_pe_rec {
     int32_t  status;        /* 0 unmapped, 1 unique pair (emitted), 2 ambiguous, 3 rejected by TLEN / chromosome-end check */

@@ -470,6 +470,9 @@ static bool place(const orc_index* ix, u64 site, u64 start_site, u64 end_site, i
 struct read_t { const char* seq; const char* qual; int len; };
 
 // one read through Map_Single_Seq_end_to_end's loop body (Schema.cpp:24488-25119)
+// orc_map_se_votes: when set, every general-path read appends its votes (site, count) in the visiting order of a9/a10
+static std::vector<std::pair<u64, u64>>* g_vote_sink = nullptr;
+
 static void map_one_se(const orc_index* ix, const orc_params* P, const read_t& rd, orc_rec* rec,
                        int64_t st[5], orc_counters* C, std::vector<u64>& cand, std::vector<vote_t>& votes,
                        std::vector<char>& win)
@@ -604,6 +607,7 @@ static void map_one_se(const orc_index* ix, const orc_params* P, const read_t& r
     make_votes(cand, k, votes);
     std::sort(votes.begin(), votes.end(), vote_gt);          // unstable, as the reference (Schema.cpp:24986)
     rec->n_votes = (int)votes.size();
+    if (g_vote_sink) for (const vote_t& v : votes) g_vote_sink->push_back({v.site, v.vote});
     if (C) C->n_cand += votes.size();
     // K7+K8+K9: map_candidate_votes_mutiple_[cut_]end_to_end_* (Schema.cpp:7707-8183, 8202-8750)
     const int p_length = L + 2 * (int)k;
@@ -677,6 +681,30 @@ extern "C" int orc_map_se(const orc_index* ix, const orc_params* P, const char* 
     // stats: reads, unique, ambiguous, mapped bases, error bases
     for (int j = 0; j < 5; j++) stats[j] = st[j];
     return 0;
+}
+
+/* orc_map_se plus the vote lists of the general-path reads (a9/a10: generate_candidate_votes_shift + std::sort by vote,
+ * Schema.cpp:4687, 24978-24986): read i's votes are vote_site/vote_cnt[vote_off[i] .. vote_off[i+1]) in visiting order.
+ * Returns the number of votes, or -1 when `cap` is too small. */
+extern "C" int64_t orc_map_se_votes(const orc_index* ix, const orc_params* P, const char* seq, const char* qual, const int32_t* len,
+                                    int stride, int64_t n, orc_rec* recs, int64_t stats[5], uint64_t* vote_site, uint32_t* vote_cnt,
+                                    uint64_t* vote_off, int64_t cap)
+{
+    std::vector<u64> cand; std::vector<vote_t> votes; std::vector<char> win;
+    std::vector<std::pair<u64, u64>> sink;
+    int64_t st[5] = {0, 0, 0, 0, 0};
+    g_vote_sink = &sink;
+    for (int64_t i = 0; i < n; i++) {
+        vote_off[i] = sink.size();
+        read_t rd = {seq + (size_t)i * stride, qual + (size_t)i * stride, len[i]};
+        map_one_se(ix, P, rd, &recs[i], st, nullptr, cand, votes, win);
+    }
+    vote_off[n] = sink.size();
+    g_vote_sink = nullptr;
+    for (int j = 0; j < 5; j++) stats[j] = st[j];
+    if ((int64_t)sink.size() > cap) return -1;
+    for (size_t j = 0; j < sink.size(); j++) { vote_site[j] = sink[j].first; vote_cnt[j] = (uint32_t)sink[j].second; }
+    return (int64_t)sink.size();
 }
 
 // ------------------------------------------------------------------------------------------------

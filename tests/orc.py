@@ -57,6 +57,8 @@ def load():
     L.orc_sa_at.argtypes = [vp, C.c_uint64]
     L.orc_sa_at.restype = C.c_uint64
     L.orc_map_se.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, i32, i64, vp, vp, vp]
+    L.orc_map_se_votes.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, i64]
+    L.orc_map_se_votes.restype = i64
     L.orc_map_pe.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp]
     L.orc_map_pe_var.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp]
     L.orc_search_se.argtypes = [vp, C.POINTER(OrcParams), C.c_char_p, C.c_char_p, C.c_char_p, vp]
@@ -100,6 +102,21 @@ class OrcIndex:
                                recs.ctypes.data, st.ctypes.data, cnt.ctypes.data)
         assert rc == 0
         return recs, st, dict(zip(COUNTER_KEYS, (int(x) for x in cnt)))
+
+    def map_se_votes(self, prm, seq, qual, L, cap=None):
+        """-> (recs, vote_site, vote_cnt, vote_off[n+1]): the vote lists of the general-path reads in visiting order"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        n, stride = seq.shape
+        ln = np.full(n, L, dtype=np.int32)
+        recs = np.zeros(n, dtype=REC_DTYPE)
+        st = np.zeros(5, dtype=np.int64)
+        cap = cap or max(1024, 256 * n)
+        vs = np.zeros(cap, dtype=np.uint64); vc = np.zeros(cap, dtype=np.uint32); vo = np.zeros(n + 1, dtype=np.uint64)
+        tot = self.L.orc_map_se_votes(self.h, C.byref(prm), seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, stride, n, recs.ctypes.data,
+                                      st.ctypes.data, vs.ctypes.data, vc.ctypes.data, vo.ctypes.data, cap)
+        assert tot >= 0, "vote capacity too small"
+        return recs, vs[:tot], vc[:tot], vo
 
     def map_se_var(self, prm, seq, qual, lens):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)

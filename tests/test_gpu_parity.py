@@ -179,13 +179,15 @@ def test_align_stage_matches_oracle(env, monkeypatch, form, L, e):
     m.close()
 
 
-def test_seed_stage_verdicts_and_vote_counts(env):
+@pytest.mark.parametrize("L,e,sub", [(100, 0.08, 0.01), (150, 0.08, 0.04), (250, 0.08, 0.03)])
+def test_seed_stage_verdicts_and_vote_sites(env, L, e, sub):
+    """K1-K6 + a8-a10 through bmbs_seed_batch: verdicts, and for every general-path read the vote list itself -- sites AND
+    counts, in the reference's visiting order (std::sort by vote, unstable) -- against the oracle's"""
     from bitmapperbs_amd import synth, mapper
-    L, e = 100, 0.08
-    r = synth.make_reads_se(env["chroms"], n=20000, L=L, seed=41, sub=0.01, indel=0.001, qual="const", n_rate=0.002)
+    r = synth.make_reads_se(env["chroms"], n=20000, L=L, seed=41, sub=sub, indel=0.001, qual="const", n_rate=0.002)
     m = mapper.Mapper(env["ix"], 0, e_f=e)
-    s = m.seed(r["seq"], L)
-    recs, _, _ = env["oix"].map_se(orc.params(e_f=e), r["seq"], r["qual"], L)
+    s = m.seed(r["seq"], L, vote_cap=4096 * 1024)
+    recs, ovs, ovc, ovo = env["oix"].map_se_votes(orc.params(e_f=e), r["seq"], r["qual"], L)
     # oracle path: 1 exit A, 2 exit C, 3 general (incl. "no unique"), 4 exact ambiguous, 0 nothing
     v = s["verdict"].astype(np.int64)
     op = recs["path"].astype(np.int64)
@@ -193,10 +195,16 @@ def test_seed_stage_verdicts_and_vote_counts(env):
     assert (v[op == 1] == 1).all() and (v[op == 2] == 2).all() and (v[op == 4] == 4).all()
     assert (v[gen] == 3).all()
     assert (s["n_votes"][gen].astype(np.int64) == recs["n_votes"][gen]).all()
-    # every vote segment is ordered by vote, descending (the reference's visiting order)
-    for i in np.nonzero(v == 3)[0][:2000]:
-        a = int(s["seg_off"][i]); cnts = s["vote_cnt"][a:a + int(s["n_votes"][i])]
-        assert (np.diff(cnts.astype(np.int64)) <= 0).all()
+    # the vote lists themselves: same sites, same counts, same (unstable-sort) order
+    n_lists = n_long = 0
+    for i in np.nonzero(gen)[0]:
+        a = int(s["seg_off"][i]); nv = int(s["n_votes"][i])
+        oa, ob = int(ovo[i]), int(ovo[i + 1])
+        assert ob - oa == nv, i
+        assert (s["vote_site"][a:a + nv] == ovs[oa:ob]).all(), i
+        assert (s["vote_cnt"][a:a + nv] == ovc[oa:ob]).all(), i
+        n_lists += 1; n_long += nv > 16
+    assert n_lists > 500 and (L < 150 or n_long > 0)
     m.close()
 
 
@@ -217,11 +225,11 @@ def test_edge_cases_empty_single_allN_short(env):
 
 
 def test_full_size_properties_idempotent_and_split_invariant(env):
-    """at a BASELINE-scale batch (2 M x 150 bp on the test genome): run-to-run identical bytes, and the
+    """at BASELINE configs[1]'s full batch (10 M x 150 bp, -e 0.04, on the test genome): run-to-run identical bytes, and the
     batch result equals the concatenation of two half-batches (reads are independent units)"""
     import torch
     from bitmapperbs_amd import gpusynth, mapper, capi
-    L, stride, n = 150, 160, 2_000_000
+    L, stride, n = 150, 160, 10_000_000
     gd, ld = gpusynth.upload_genome(env["chroms"])
     seq, qual = gpusynth.make_reads_se(gd, ld, n, L, stride, seed=99, sub=0.01, indel=0.0005)
     m = mapper.Mapper(env["ix"], 0, e_f=0.04)
@@ -255,6 +263,57 @@ def test_full_size_properties_idempotent_and_split_invariant(env):
     sl = slice(1000, 21000)
     recs, _, _ = env["oix"].map_se(orc.params(e_f=0.04), seq[sl].cpu().numpy(), qual[sl].cpu().numpy(), L)
     assert not compare_records(r1[sl], c1, recs, L)
+    m.close()
+
+
+@pytest.mark.parametrize("mode,L,n,e", [("fast", 150, 5_000_000, 0.08), ("sensitive", 150, 5_000_000, 0.08), ("fast", 250, 1_000_000, 0.08),
+                                       ("sensitive", 250, 1_000_000, 0.08)])
+def test_full_size_properties_paired_end(env, mode, L, n, e):
+    """BASELINE configs[2] / [3] launch sizes (5 M pairs of 150 bp, fast and --sensitive) and configs[4]'s shape (250 bp pairs,
+    -e 0.08: k = 20, 64-bit Myers words, band of 41): run-to-run identical bytes, split invariance (pairs are independent units),
+    stats add up, and an oracle slice"""
+    import torch
+    from bitmapperbs_amd import gpusynth, mapper, capi
+    stride = (L + 15) // 16 * 16
+    gd, ld = gpusynth.upload_genome(env["chroms"])
+    s1, q1, s2, q2 = gpusynth.make_reads_pe(gd, ld, n, L, stride, seed=123, sub=0.01, indel=0.0005, qual="random",
+                                             ins_hi=400 if L == 150 else 700)
+    prm = dict(e_f=e, sensitive=1 if mode == "sensitive" else 0)
+    if L == 250:
+        prm["max_ins"] = 800
+    m = mapper.Mapper(env["ix"], 0, **prm)
+    k = m.threshold(L); cap = 2 * n * (2 * k + 8)
+
+    def run(a, b):
+        res = torch.zeros((2 * (b - a), 32), dtype=torch.uint8, device="cuda")
+        cig = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+        m.reset_stats()
+        m.map_pe_device(s1[a:b].data_ptr(), q1[a:b].data_ptr(), s2[a:b].data_ptr(), q2[a:b].data_ptr(), L, stride, b - a, res.data_ptr(),
+                        cig.data_ptr(), cap)
+        m.sync()
+        return res.cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1), cig.cpu().numpy().view(np.uint32), m.stats()
+
+    r1, c1, st1 = run(0, n)
+    r2, c2, st2 = run(0, n)
+    assert r1.tobytes() == r2.tobytes() and (st1 == st2).all()
+    ra, ca, sa = run(0, n // 2)
+    rb, cb, sb = run(n // 2, n)
+    assert ((sa + sb) == st1).all() and st1[0] == n
+    whole = np.concatenate([ra, rb])
+    for x in [x for x in capi.RESULT_DTYPE.names if x not in ("cigar_off",)]:
+        assert (whole[x] == r1[x]).all(), x
+    idx = np.nonzero(r1["n_cigar"] > 0)[0][:3000]
+    for i in idx:
+        part, pc = (ra, ca) if i < n else (rb, cb)        # record 2*pair + mate: the first half holds pairs < n/2
+        j = i if i < n else i - n
+        assert mapper.cigar_text(r1[i], c1, L) == mapper.cigar_text(part[j], pc, L)
+    # oracle spot-check on a slice of the big batch
+    a, b = 2000, 12000
+    kw = dict(e_f=e, sensitive=1 if mode == "sensitive" else 0)
+    if L == 250:
+        kw["max_ins"] = 800
+    recs, _, _ = env["oix"].map_pe(orc.params(**kw), s1[a:b].cpu().numpy(), q1[a:b].cpu().numpy(), s2[a:b].cpu().numpy(), q2[a:b].cpu().numpy(), L)
+    assert not compare_pe(r1[2 * a:2 * b], c1, recs, L)
     m.close()
 
 
@@ -622,7 +681,8 @@ def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["BMBS_DECIDE=plain", "BMBS_DECIDE=lds", "BMBS_DECIDE=vec8", "BMBS_VOTE=split", "BMBS_VOTE_NOMID=1", "BMBS_SEED_WAVES=4096"])
+@pytest.mark.parametrize("knob", ["BMBS_DECIDE=plain", "BMBS_DECIDE=lds", "BMBS_DECIDE=vec8", "BMBS_VOTE=split", "BMBS_VOTE_NOMID=1", "BMBS_SEED_WAVES=4096",
+                                  "BMBS_TDEPTH=21", "BMBS_SW=wave"])
 def test_ab_switches_give_identical_records(knob, env, monkeypatch):
     """the alternative kernel forms kept for A/B measurements map exactly like the default ones"""
     from bitmapperbs_amd import synth, mapper
@@ -634,6 +694,22 @@ def test_ab_switches_give_identical_records(knob, env, monkeypatch):
     res, pool = m.map_se(r["seq"], r["qual"], L)
     recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], L)
     assert not compare_records(res, pool, recs, L)
+    assert (m.stats() == ost).all()
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensitive", [0, 1])
+def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive):
+    """the 21-mer form of the outcome table (3^21 entries, 84 GB: what a GRCh38-size index gets) forced on the test genome: the
+    seeding engine reads five letters ahead instead of four; pairs in both modes against the oracle"""
+    from bitmapperbs_amd import synth, mapper
+    monkeypatch.setenv("BMBS_TDEPTH", "21")
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=12000, L=150, seed=77 + sensitive, sub=0.03, indel=0.002, qual="random")
+    m = mapper.Mapper(env["ix"], 0, sensitive=sensitive)
+    res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+    recs, ost, _ = env["oix"].map_pe(orc.params(sensitive=sensitive), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+    assert not compare_pe(res, pool, recs, 150)
     assert (m.stats() == ost).all()
     m.close()
 
