@@ -401,6 +401,72 @@ def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", r
                 os.environ[k_] = v_
 
 
+def host_buffer_rate(m, job, torch):
+    """PCIe-inclusive rate through the host-pointer entry point (bmbs_map_se / bmbs_map_pe): page-locked host buffers in, records
+    and CIGAR pool back out, copy-in -> kernels -> copy-out serialised on one context (never `value`)."""
+    import ctypes as C
+    from bitmapperbs_amd import capi
+    lib = capi.lib()
+    n = min(job.n, 2_000_000)
+    host = [x[:n].cpu().numpy() for x in job.batches[0]]
+    nbytes = host[0].nbytes
+    pin = []
+    for h in host:
+        p_ = lib.bmbs_host_alloc(nbytes)
+        C.memmove(p_, h.ctypes.data, nbytes)
+        pin.append(p_)
+    nrec = n * (2 if job.cfg["pe"] else 1)
+    cap = nrec * job.max_ops
+    res = lib.bmbs_host_alloc(nrec * 32); pool = lib.bmbs_host_alloc(cap * 4)
+    used = C.c_int64(0)
+    def call():
+        if job.cfg["pe"]:
+            rc = lib.bmbs_map_pe(m._ctx, pin[0], pin[1], pin[2], pin[3], job.L, job.stride, n, res, pool, cap, C.byref(used))
+        else:
+            rc = lib.bmbs_map_se(m._ctx, pin[0], pin[1], job.L, job.stride, n, res, pool, cap, C.byref(used))
+        if rc:
+            raise RuntimeError(lib.bmbs_last_error(m._ctx).decode())
+    call()
+    t = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        call()
+    dt = time.perf_counter() - t
+    for p_ in pin + [res, pool]:
+        lib.bmbs_host_free(p_)
+    return {"what": "bmbs_map_%s on page-locked HOST buffers (%d %s per call, H2D + kernels + D2H serialised on one context)" % (
+                "pe" if job.cfg["pe"] else "se", n, "pairs" if job.cfg["pe"] else "reads"),
+            "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s"}
+
+
+def file_to_file_rate(args, cfg, fa, L):
+    """FASTQ file(s) -> SAM file through bitmapperbs_amd/bmbs_search (the drop-in driver) on the cpu_baseline sample files; the
+    SAM goes to --workdir's file system and, second run, to /dev/null (one buffered file takes ~10.5 GB/s on these boxes)"""
+    drv = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
+    if cfg["pe"]:
+        files = [os.path.join(args.workdir, "cpu_sample_1.fq"), os.path.join(args.workdir, "cpu_sample_2.fq")]
+        inp = ["--seq1", files[0], "--seq2", files[1]] + (["--sensitive"] if cfg["sensitive"] else [])
+    else:
+        files = [os.path.join(args.workdir, "cpu_sample.fq")]
+        inp = ["--seq", files[0]]
+    if not os.path.exists(drv) or not all(os.path.exists(f) for f in files):
+        return None
+    rec_bytes = 2 * L + 14
+    n = os.path.getsize(files[0]) // rec_bytes * (2 if cfg["pe"] else 1)
+    out = {}
+    for label, dst in (("file", os.path.join(args.workdir, "f2f.sam")), ("null_sink", "/dev/null")):
+        p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "16", "--verbose"], capture_output=True, text=True)
+        if p.returncode:
+            return {"error": p.stderr[-300:]}
+        line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
+        wall = float(line.split("mapping wall")[1].split("s")[0])
+        out[label] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n)}
+    if os.path.exists(os.path.join(args.workdir, "f2f.sam")):
+        os.unlink(os.path.join(args.workdir, "f2f.sam"))
+    out["what"] = "bmbs_search, FASTQ -> SAM, 1 GPU, 16 host I/O threads, index load + attach excluded (as the reference's own 'mapping time')"
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -533,6 +599,11 @@ def main():
                     theirs = set(x for x in f if not x.startswith("@") and int(x[1:x.index("\t")]) < nchk)
                 out["sample_sam_identical_to_reference"] = (mine == theirs)
                 out["sample_sam_lines_compared"] = len(theirs)
+            if not args.no_secondary:
+                try:
+                    out["e2e"] = {"host_buffers": host_buffer_rate(m, job, torch)}
+                except Exception as ex:
+                    out["e2e"] = {"error": repr(ex)}
         else:
             out["cpu_baseline"] = None
     m.close(); ix.close()
@@ -542,6 +613,11 @@ def main():
         if world == 1 and not args.no_secondary:
             # secondary keys: the configs[1] line of round 1 and the stress cases (each on its own short timed region)
             sec = {}
+            try:        # the driver attaches its own copy of the index: run it now that this process has released its own
+                if "e2e" in out and "error" not in out["e2e"] and out.get("cpu_baseline"):
+                    out["e2e"]["file_to_file"] = file_to_file_rate(args, cfg, fa, L)
+            except Exception as ex:
+                out["e2e"]["file_to_file"] = {"error": repr(ex)}
             c1 = dict(CONFIGS[1])
             small = dict(cfg, genome=46_000_000, n_chrom=4, launches=1, units=min(cfg["units"], 5_000_000))
             try:

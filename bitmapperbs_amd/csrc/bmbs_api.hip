@@ -237,16 +237,18 @@ void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d
                const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops)
 {
     const u64 slots = sw_trace_slots(n_jobs);
-    if (!gm.len)
-        hipLaunchKernelGGL((k_align_sw<KB, true>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                           d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
-                           slots, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
-                           c->a_score.as<int>(), c->a_nops.as<int>());
-    else
-        hipLaunchKernelGGL((k_align_sw<KB, false>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                           d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
-                           slots, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
-                           c->a_score.as<int>(), c->a_nops.as<int>());
+    for (u64 base = 0; base < n_jobs; base += slots) {
+        if (!gm.len)
+            hipLaunchKernelGGL((k_align_sw<KB, true>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+                               d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
+                               slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                               c->a_score.as<int>(), c->a_nops.as<int>());
+        else
+            hipLaunchKernelGGL((k_align_sw<KB, false>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+                               d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
+                               slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                               c->a_score.as<int>(), c->a_nops.as<int>());
+    }
 }
 
 // K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the

@@ -2099,18 +2099,19 @@ template <int KB, bool UNIFORM>
 __global__ void __launch_bounds__(64)
 k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
            const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
-           const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride,
+           const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride, u64 job_base,
            u32* __restrict__ cigar_pool, int max_ops,
            int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
            int* __restrict__ a_nops)
 {
     constexpr int BW = 2 * KB + 1;          // compile-time bound of the band width
     constexpr int NW = (BW + 15) / 16;      // trace words per row (4 bits per cell)
-    // a thread owns one trace slot and takes the jobs slot, slot + threads, ...: the trace buffer is sized by the launch (at
-    // most 1 M slots), not by the number of jobs (which only the device knows)
+    // a thread owns trace slot `slot` and takes job job_base + slot: the host issues one launch per trace_stride jobs of its upper
+    // bound, so the trace buffer is sized by the launch (at most 1 M slots), not by the number of jobs (which only the device
+    // knows; launches beyond it find nothing to do)
     const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 n_sw_total = *n_sw_ptr;
-    for (u64 t = slot; t < n_sw_total; t += trace_stride) {
+    const u64 t = job_base + slot;
+    if (t >= *n_sw_ptr) return;
     const u64 jb = sw_job[t];
     const u32 r = jb_.read[jb];
     const u64 site = jb_.site[jb];
@@ -2290,7 +2291,6 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         }
     }
     a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
