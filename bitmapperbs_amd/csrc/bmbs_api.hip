@@ -4,6 +4,7 @@
 // BMBS_ENODEV.
 #include "../../include/bmbs.h"
 #include "bmbs_kernels.hip"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -251,6 +252,19 @@ void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d
     }
 }
 
+// the packed form: two jobs per lane, so a launch of `slots` threads covers 2 * slots jobs
+template <int KB>
+void launch_sw2(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
+                const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops)
+{
+    const u64 slots = sw_trace_slots((n_jobs + 1) / 2);
+    for (u64 base = 0; base < n_jobs; base += 2 * slots)
+        hipLaunchKernelGGL((k_align_sw2<KB>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+                           d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
+                           slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                           c->a_score.as<int>(), c->a_nops.as<int>());
+}
+
 // K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the
 // register-band DP kernel instantiated for the smallest KB >= k.  No host round-trip inside.
 int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
@@ -262,14 +276,27 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     ENS(c, c->a_start, nj * 4); ENS(c, c->a_end, nj * 4); ENS(c, c->a_nm, nj * 4); ENS(c, c->a_score, nj * 4); ENS(c, c->a_nops, nj * 4);
     ENS(c, c->need_sw, nj * 4); ENS(c, c->sw_off, (nj + 1) * 8); ENS(c, c->sw_job, nj * 4);
     if (!n_jobs) return BMBS_OK;
-    // Two forms of the DP.  Default (BMBS_SW=reg): one job per lane, band in registers, trace words in HBM -- 1.3 k wave
-    // instructions per job at k = 12, which is the VALU issue peak of the chip for this batch (0.65 ms per 300 k jobs).
-    // BMBS_SW=wave: one job per 16 / 32 / 64 lanes, a band row per step, trace + CIGAR in LDS, nothing but the ops written to HBM
-    // (north_star (c)); measured 6.4x the instructions per job (lanes beyond the band idle, the F prefix scan and its DPP
-    // wait states), so it is the better form only when there are too few jobs to fill the lanes.
+    // Three forms of the DP (BMBS_SW=reg2|reg|wave), all with identical results:
+    //  reg2 (default for k >= 9): one PAIR of jobs per lane in packed 16-bit arithmetic, band in registers, trace bytes in HBM
+    //        (k_align_sw2) -- the DP is VALU-issue bound, so instructions per cell is what counts: 30 per cell against 52.  Needs
+    //        one read length per batch and scores that fit 16 bits.  Measured against `reg` on 10 M-pair / 10 M-read batches:
+    //        k = 20 (250 bp) 2.63 vs 3.50 ms, k = 12 2.53 vs 2.69 ms, k = 6 1.02 vs 0.83 ms (narrow bands: the per-row work of two
+    //        jobs outweighs the packed cells, and half as many waves balance worse) -- hence the threshold;
+    //  reg:  one job per lane, 32-bit (k_align_sw) -- batches of mixed lengths, extreme penalties;
+    //  wave: one job per 16 / 32 / 64 lanes, a band row per step, trace + CIGAR in LDS, nothing but the ops written to HBM
+    //        (north_star (c)); measured 6.4x the instructions per job of `reg` (lanes beyond the band idle, the F prefix scan and
+    //        its DPP wait states), so it only pays when there are too few jobs to fill the lanes.
     const char* swm = getenv("BMBS_SW");
-    const bool reg_form = !(swm && !strcmp(swm, "wave"));
-    if (reg_form) ENS(c, c->trace, sw_trace_slots(n_jobs) * (u64)L * nwk * 8);
+    const bool wave_form = swm && !strcmp(swm, "wave");
+    int maxpen = std::max(std::max(c->prm.mp_max, c->prm.np), c->prm.gap_open + c->prm.gap_ext);
+    const bool packed = !wave_form && !(swm && !strcmp(swm, "reg")) && (k >= 9 || (swm && !strcmp(swm, "reg2"))) && !gm.len && c->prm.gap_ext < 256 && (L + 64) * maxpen < 12000 &&
+                        c->prm.mp_min >= 0 && c->prm.gap_ext >= 0 && c->prm.gap_open >= 0 && c->prm.np >= 0;
+    const bool reg_form = !wave_form;
+    if (reg_form) {
+        const u64 nwords = packed ? (u64)((2 * k + 1 + 7) / 8) : nwk;
+        const u64 slots = packed ? sw_trace_slots((n_jobs + 1) / 2) : sw_trace_slots(n_jobs);
+        ENS(c, c->trace, slots * (u64)L * nwords * 8);
+    }
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     prof_begin(c, "k_align_ungapped");
     hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
@@ -293,6 +320,20 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
         else if (k <= 15) SWW_LAUNCH(32);
         else SWW_LAUNCH(64);
 #undef SWW_LAUNCH
+        prof_end(c);
+        return BMBS_OK;
+    }
+    if (packed) {
+        if (k <= 2) launch_sw2<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 4) launch_sw2<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 6) launch_sw2<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 8) launch_sw2<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 10) launch_sw2<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 12) launch_sw2<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 16) launch_sw2<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 20) launch_sw2<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else if (k <= 24) launch_sw2<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        else launch_sw2<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
         prof_end(c);
         return BMBS_OK;
     }

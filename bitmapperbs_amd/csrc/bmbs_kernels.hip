@@ -2111,6 +2111,12 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     // knows; launches beyond it find nothing to do)
     const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 t = job_base + slot;
+    if ((u64)blockIdx.x * blockDim.x + job_base >= *n_sw_ptr) return;          // the whole wave has nothing to do
+    // the mismatch penalty of a row is on the critical path of all its cells: the 256-entry table lives in LDS, not behind a
+    // global gather per row
+    __shared__ int s_pen[256];
+    for (int q = threadIdx.x; q < 256; q += 64) s_pen[q] = pen_lut[q];
+    __syncthreads();
     if (t >= *n_sw_ptr) return;
     const u64 jb = sw_job[t];
     const u32 r = jb_.read[jb];
@@ -2145,7 +2151,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         const char a = rcur.next();
         const int ta = code4(a);
         const unsigned char qc = rev ? (unsigned char)ql[L - 1 - i] : (unsigned char)qcur.next();
-        const int mis = ta == 4 ? -sp.np : -pen_lut[qc];
+        const int mis = ta == 4 ? -sp.np : -s_pen[qc];
         u64 tw[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) tw[q] = 0;
@@ -2208,31 +2214,28 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         else cur_len += len;
     };
     int i = tlen - 1, kk = max_i - 1, which = 0;
-    if (NW == 1) {
-        // one trace word per row and the rows are visited in descending order: an 8-deep software pipeline of row loads
-        // (each step would otherwise wait out a full memory round trip)
+    {
+        // the rows are visited in descending order and the path rarely changes its trace-word column: an 8-deep software pipeline
+        // of row loads for the current column (each step would otherwise wait out a full memory round trip), refilled when the
+        // column changes
+        int q = (kk - i) >> 4;
         u64 tb[8];
+        auto refill = [&]() {
 #pragma unroll
-        for (int q = 0; q < 8; q++) tb[q] = i - q >= 0 ? tz[(u64)(i - q) * trace_stride] : 0;
+            for (int p = 0; p < 8; p++) tb[p] = i - p >= 0 ? tz[((u64)(i - p) * NWk + q) * trace_stride] : 0;
+        };
+        refill();
         while (i >= 0 && kk >= 0) {
             const int b = kk - i;
+            if ((b >> 4) != q) { q = b >> 4; refill(); }
             const int d = (int)((tb[0] >> (4 * (b & 15))) & 15);
             which = which == 0 ? (d & 3) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
             if (which == 2) { push(1, 1); --kk; continue; }
             if (which == 0) { push(0, 1); --kk; } else push(2, 1);
             --i;
 #pragma unroll
-            for (int q = 0; q < 7; q++) tb[q] = tb[q + 1];
-            tb[7] = i - 7 >= 0 ? tz[(u64)(i - 7) * trace_stride] : 0;
-        }
-    } else {
-        while (i >= 0 && kk >= 0) {
-            const int b = kk - i;
-            const int d = (int)((tz[((u64)i * NWk + (b >> 4)) * trace_stride] >> (4 * (b & 15))) & 15);
-            which = which == 0 ? (d & 3) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
-            if (which == 0) { push(0, 1); --i; --kk; }
-            else if (which == 1) { push(2, 1); --i; }
-            else { push(1, 1); --kk; }
+            for (int p = 0; p < 7; p++) tb[p] = tb[p + 1];
+            tb[7] = i - 7 >= 0 ? tz[((u64)(i - 7) * NWk + q) * trace_stride] : 0;
         }
     }
     if (i >= 0) push(2, i + 1);
@@ -2291,6 +2294,259 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         }
     }
     a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_align_sw2<KB>: k_align_sw with TWO alignments per lane in packed 16-bit arithmetic (v_pk_add/sub/max_i16).
+// The register-band DP is VALU-issue bound (1.3 k wave instructions per job at k = 12: 0.65 ms per 300 k jobs is the chip's
+// issue peak), so the lever is instructions per cell.  Job A lives in the low halves of every H / E / F register, job B in the
+// high halves; one packed instruction advances both.  What does not pack is made cheap: the match test of a whole band row is
+// a handful of 64-bit logic ops per job (window bases one-hot in nibbles, AND with the set of bases the read letter accepts,
+// nibble -> bit), each cell then takes its score from a sign-extended bit field; the four comparison results of a cell are the
+// sign bits of four packed differences, collected into the trace byte (low nibble job A, high nibble job B) without a compare.
+// Scores are exact in 16 bits as long as L * max(penalty) + gap costs stay below 12 000 and the band's "minus infinity"
+// (-16 000) cannot wrap (the host checks; otherwise, and for batches of mixed read lengths, k_align_sw runs).  Same trace
+// volume as k_align_sw (8 bits per cell pair), same traceback, same results.
+typedef short bmbs_s2 __attribute__((ext_vector_type(2)));
+DEVI u32 pk_add(u32 a, u32 b) { bmbs_s2 x = __builtin_bit_cast(bmbs_s2, a) + __builtin_bit_cast(bmbs_s2, b); return __builtin_bit_cast(u32, x); }
+DEVI u32 pk_sub(u32 a, u32 b) { bmbs_s2 x = __builtin_bit_cast(bmbs_s2, a) - __builtin_bit_cast(bmbs_s2, b); return __builtin_bit_cast(u32, x); }
+DEVI u32 pk_max(u32 a, u32 b) { bmbs_s2 x = __builtin_elementwise_max(__builtin_bit_cast(bmbs_s2, a), __builtin_bit_cast(bmbs_s2, b)); return __builtin_bit_cast(u32, x); }
+DEVI u32 pk_make(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }
+DEVI int pk_lo(u32 x) { return (int)(short)(x & 0xffffu); }
+DEVI int pk_hi(u32 x) { return (int)x >> 16; }
+#define SW2_MINF (-16000)
+
+template <int KB>
+__global__ void __launch_bounds__(64)
+k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
+            const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
+            const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride, u64 job_base,
+            u32* __restrict__ cigar_pool, int max_ops,
+            int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
+            int* __restrict__ a_nops)
+{
+    constexpr int BW = 2 * KB + 1;          // compile-time bound of the band width
+    constexpr int NW = (BW + 15) / 16;      // window words per job (4 bits per base)
+    constexpr int NT = (BW + 7) / 8;        // trace words per row (8 bits per cell: both jobs)
+    const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n_sw = *n_sw_ptr;
+    const u64 tA = job_base + 2 * slot;
+    if (job_base + 2 * (u64)blockIdx.x * blockDim.x >= n_sw) return;            // the whole wave has nothing to do
+    __shared__ int s_pen[256];                                                  // as in k_align_sw
+    for (int q = threadIdx.x; q < 256; q += 64) s_pen[q] = pen_lut[q];
+    __syncthreads();
+    if (tA >= n_sw) return;
+    const bool haveB = tA + 1 < n_sw;
+    const int L = gm.L, k = gm.k;           // uniform batch: one length, one threshold
+    const int band = 2 * k + 1, tlen = L;
+    const int NTk = (band + 7) / 8;
+    u64 jbv[2]; u32 rv[2]; u64 sitev[2]; const char* rdv[2]; const char* qlv[2]; bool revv[2], fwdv[2], wval[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        jbv[j] = sw_job[(j == 1 && haveB) ? tA + 1 : tA];
+        rv[j] = jb_.read[jbv[j]];
+        sitev[j] = jb_.site[jbv[j]];
+        rdv[j] = seq + (size_t)rv[j] * stride;
+        qlv[j] = qual_row(qual, qual2, rev_qual_from, rv[j], stride);
+        revv[j] = rv[j] >= rev_qual_from;
+        fwdv[j] = sitev[j] < ix.G;
+        wval[j] = window_valid(ix, sitev[j], (u64)(L + 2 * k), fwdv[j]);
+    }
+    const int gapoe = sp.gap_open + sp.gap_ext, gape = sp.gap_ext;
+    const u32 gapoeP = pk_make(gapoe, gapoe), gapeP = pk_make(gape, gape);
+    const u32 MINFP = pk_make(SW2_MINF, SW2_MINF);
+    u32 RH[BW + 1], RE[BW + 1];
+#pragma unroll
+    for (int b = 0; b <= BW; b++) { RH[b] = b < band ? 0u : MINFP; RE[b] = b < band ? pk_make(-gapoe, -gapoe) : MINFP; }
+    // window bases of the current row, one-hot in nibbles (A1 C2 G4 T8, out-of-strand 0)
+    u64 wq[2][NW];
+    WinReader wr[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int q = 0; q < NW; q++) wq[j][q] = 0;
+        wr[j].init(ix, sitev[j], wval[j]);
+        for (int b = 0; b < band; b++) { const int v = wr[j].next(); const u64 oh = v < 4 ? (1ull << v) : 0ull; wq[j][b >> 4] |= oh << (4 * (b & 15)); }
+    }
+    u64* tz = trace + slot;                 // word (i*NTk + q) lives at tz[(i*NTk + q) * trace_stride]
+    ReadCur rcur[2], qcur[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) { rcur[j].seek(rdv[j], 0, L); if (!revv[j]) qcur[j].seek(qlv[j], 0, L); }
+    for (int i = 0; i < tlen; ++i) {
+        // per-row, per-job: mismatch penalty and the match bits of the whole band
+        int mis[2];
+        u64 Y[2][NW];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const char a = rcur[j].next();
+            const int ta = code4(a);
+            const unsigned char qc = revv[j] ? (unsigned char)qlv[j][L - 1 - i] : (unsigned char)qcur[j].next();
+            mis[j] = (ta == 4 || !wval[j]) ? -sp.np : -s_pen[qc];
+            const u64 racc = (u64)((0x0A421u >> (4 * ta)) & 15u) * 0x1111111111111111ull;      // read A C G T N accepts {A} {C} {G} {T,C} {}
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                u64 x = wq[j][q] & racc;
+                x |= x >> 1; x |= x >> 2;
+                Y[j][q] = x & 0x1111111111111111ull;
+            }
+        }
+        const u32 misP = pk_make(mis[0], mis[1]);
+        u32 f = MINFP, h1 = MINFP;
+        u64 tw[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) tw[q] = 0;
+#pragma unroll
+        for (int b = 0; b < BW; b++) {
+            if (b < band) {
+                // score of the cell pair: 0 where the job's match bit is set, the row's penalty elsewhere
+                const u32 yA = (u32)(Y[0][b >> 4] >> (32 * ((b & 15) >> 3))), yB = (u32)(Y[1][b >> 4] >> (32 * ((b & 15) >> 3)));
+                const int mA = __builtin_amdgcn_sbfe(yA, 4 * (b & 7), 1), mB = __builtin_amdgcn_sbfe(yB, 4 * (b & 7), 1);
+                const u32 mk = ((u32)mA & 0xffffu) | ((u32)mB & 0xffff0000u);
+                const u32 sc = misP & ~mk;
+                const u32 m = pk_add(RH[b], sc);
+                u32 e = RE[b];
+                const u32 t1 = pk_sub(m, e);                 // sign: m < e
+                u32 h = pk_max(m, e);
+                const u32 t2 = pk_sub(h, f);                 // sign: h < f
+                h = pk_max(h, f);
+                const u32 tt = pk_sub(m, gapoeP);
+                e = pk_sub(e, gapeP);
+                const u32 t3 = pk_sub(tt, e);                // sign: e > tt
+                e = pk_max(e, tt);
+                f = pk_sub(f, gapeP);
+                const u32 t4 = pk_sub(tt, f);                // sign: f > tt
+                f = pk_max(f, tt);
+                if (b > 0) { RH[b - 1] = h1; RE[b - 1] = e; }
+                h1 = h;
+                // trace nibble per job: bit 0 m < e, bit 1 h < f (then bit 0 is ignored), bit 2 e extended, bit 3 f extended
+                u32 z = (t1 >> 15) & 0x00010001u;
+                z |= (t2 >> 14) & 0x00020002u;
+                z |= (t3 >> 13) & 0x00040004u;
+                z |= (t4 >> 12) & 0x00080008u;
+                const u32 byte = (z | (z >> 12)) & 0xffu;
+                tw[b >> 3] |= (u64)byte << (8 * (b & 7));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b <= BW; b++) if (b == band - 1) { RH[b] = h1; RE[b] = MINFP; }
+#pragma unroll
+        for (int q = 0; q < NT; q++) if (q < NTk) tz[((u64)i * NTk + q) * trace_stride] = tw[q];
+        // slide both windows one base
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+            for (int q = 0; q < NW; q++) { wq[j][q] >>= 4; if (q + 1 < NW) wq[j][q] |= (wq[j][q + 1] & 15) << 60; }
+            if (i + 1 < tlen) {
+                const int v = wr[j].next();
+                const u64 oh = v < 4 ? (1ull << v) : 0ull;
+#pragma unroll
+                for (int q = 0; q < NW; q++) if (q == ((band - 1) >> 4)) wq[j][q] |= oh << (4 * ((band - 1) & 15));
+            }
+        }
+    }
+    // per job: score, traceback, CIGAR, NM -- as k_align_sw, on this job's half of the registers and nibbles of the trace
+    for (int j = 0; j < 2; j++) {
+        if (j == 1 && !haveB) break;
+        const u64 jb = jbv[j];
+        const char* rd = rdv[j];
+        const u64 site = sitev[j];
+        const bool fwd = fwdv[j], wvalid = wval[j];
+        auto half = [&](u32 x) -> int { return j ? pk_hi(x) : pk_lo(x); };
+        // score: un-gapped diagonal wins ties, then the highest column (ksw.cpp:2001-2010)
+        int max_i = tlen + k, score = SW2_MINF;
+#pragma unroll
+        for (int b = 0; b < BW; b++) if (b == k) score = half(RH[b]);
+#pragma unroll
+        for (int bp = BW; bp >= 1; bp--) if (bp <= band) { const int h = half(RH[bp - 1]); if (h > score) { score = h; max_i = tlen - 1 + bp; } }
+        int qe = max_i - 1;
+        const int LOCAL_OPS = 160;
+        u32 cg[LOCAL_OPS + 1];
+        int nc = 0;
+        bool overflow = false;
+        int cur_op = -1, cur_len = 0;
+        auto flush = [&]() { if (cur_op >= 0) { if (nc < LOCAL_OPS) cg[nc++] = ((u32)cur_len << 4) | (u32)cur_op; else overflow = true; } };
+        auto push = [&](int op, int len) {
+            if (op != cur_op) { flush(); cur_op = op; cur_len = len; }
+            else cur_len += len;
+        };
+        int i = tlen - 1, kk = max_i - 1, which = 0;
+        {
+            // 8-deep pipeline of row loads for the path's current trace-word column (as in k_align_sw)
+            int q = (kk - i) >> 3;
+            u64 tb[8];
+            auto refill = [&]() {
+#pragma unroll
+                for (int p = 0; p < 8; p++) tb[p] = i - p >= 0 ? tz[((u64)(i - p) * NTk + q) * trace_stride] : 0;
+            };
+            refill();
+            while (i >= 0 && kk >= 0) {
+                const int b = kk - i;
+                if ((b >> 3) != q) { q = b >> 3; refill(); }
+                const int d = (int)((tb[0] >> (8 * (b & 7) + 4 * j)) & 15);
+                which = which == 0 ? ((d & 2) ? 2 : (d & 1)) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
+                if (which == 2) { push(1, 1); --kk; continue; }
+                if (which == 0) { push(0, 1); --kk; } else push(2, 1);
+                --i;
+#pragma unroll
+                for (int p = 0; p < 7; p++) tb[p] = tb[p + 1];
+                tb[7] = i - 7 >= 0 ? tz[((u64)(i - 7) * NTk + q) * trace_stride] : 0;
+            }
+        }
+        if (i >= 0) push(2, i + 1);
+        flush();
+        for (int a2 = 0, b2 = nc - 1; a2 < b2; a2++, b2--) { const u32 x = cg[a2]; cg[a2] = cg[b2]; cg[b2] = x; }
+        cg[nc] = 0;
+        int qb = kk + 1;
+        // K13: fold leading / trailing insertions into M (ksw.cpp:2677-2772)
+        int n_cigar = nc, ii, op, opl, ins = 0;
+        for (ii = 0; ii < n_cigar; ++ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+        if (ii != 0) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (op == 0) opl += ins; else { op = 0; opl = ins; ii--; }
+            cg[ii] = ((u32)opl << 4) | (u32)op;
+            qb -= ins;
+        }
+        const int cigar_b = ii;
+        ins = 0;
+        for (ii = n_cigar - 1; ii >= cigar_b; --ii) { op = cg[ii] & 0xf; opl = cg[ii] >> 4; if (op != 2) break; ins += opl; }
+        if (ii != n_cigar - 1) {
+            op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+            if (op == 0) opl += ins; else { op = 0; opl = ins; ii++; }
+            cg[ii] = ((u32)opl << 4) | (u32)op;
+            qe += ins;
+        }
+        const int cigar_e = ii;
+        auto m_run = [&](int ts, int qs, int len) -> int {
+            if (!wvalid) return len;
+            int c = 0;
+            for (int o = 0; o < len; o += 8) c += mism_span(ix, rd, ts + o, site + (u64)(qs + o), len - o < 8 ? len - o : 8);
+            return c;
+        };
+        u32* ops_out = cigar_pool + jb * (u64)max_ops;
+        int NM = 0, no = 0;
+        if (fwd) {
+            int qs = qb, ts = 0;
+            for (ii = cigar_b; ii <= cigar_e; ++ii) {
+                op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+                if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+                no++;
+                if (op == 0) { NM += m_run(ts, qs, opl); qs += opl; ts += opl; }
+                else if (op == 1) { qs += opl; NM += opl; }
+                else { ts += opl; NM += opl; }
+            }
+        } else {
+            int qx = qe, te = tlen - 1;
+            for (ii = cigar_e; ii >= cigar_b; --ii) {
+                op = cg[ii] & 0xf; opl = cg[ii] >> 4;
+                if (no < max_ops) ops_out[no] = cg[ii]; else overflow = true;
+                no++;
+                if (op == 0) { NM += m_run(te - opl + 1, qx - opl + 1, opl); qx -= opl; te -= opl; }
+                else if (op == 1) { qx -= opl; NM += opl; }
+                else { te -= opl; NM += opl; }
+            }
+        }
+        a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

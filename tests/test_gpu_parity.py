@@ -142,14 +142,16 @@ def test_filter_stage_matches_oracle_incl_invalid_sites(env):
     m.close()
 
 
-@pytest.mark.parametrize("form,L,e", [("reg", 150, 0.08), ("wave", 150, 0.08),          # k = 12: 32 lanes per alignment
-                                      ("wave", 150, 0.04), ("reg", 150, 0.04),          # k = 6: 16 lanes
-                                      ("wave", 250, 0.08), ("reg", 250, 0.08),          # k = 20: a whole wave
-                                      ("wave", 100, 0.31), ("wave", 61, 0.05)])         # k = 31 (band 63), k = 3
+@pytest.mark.parametrize("form,L,e", [("reg2", 150, 0.08), ("reg", 150, 0.08), ("wave", 150, 0.08),          # k = 12: 32 lanes per alignment
+                                      ("reg2", 150, 0.04), ("wave", 150, 0.04), ("reg", 150, 0.04),          # k = 6: 16 lanes
+                                      ("reg2", 250, 0.08), ("wave", 250, 0.08), ("reg", 250, 0.08),          # k = 20: a whole wave
+                                      ("reg2", 100, 0.31), ("wave", 100, 0.31), ("reg2", 61, 0.05), ("wave", 61, 0.05),   # k = 31 (band 63), k = 3
+                                      ("reg2", 400, 0.08), ("reg2", 36, 0.1)])
 def test_align_stage_matches_oracle(env, monkeypatch, form, L, e):
     """K11-K13 through bmbs_align_batch: jobs = every accepted candidate of the filter stage with err > 0.
-    Both forms of the DP kernel: `reg` = one alignment per lane, band in registers, trace words in HBM (k_align_sw, the default:
-    it runs at the VALU issue peak) and `wave` = one alignment per 16 / 32 / 64 lanes with the trace in LDS (k_align_sw_wave)"""
+    The three forms of the DP kernel: `reg2` = two alignments per lane in packed 16-bit arithmetic (k_align_sw2, the default),
+    `reg` = one alignment per lane in 32 bits (k_align_sw: mixed-length batches, extreme penalties), `wave` = one alignment per
+    16 / 32 / 64 lanes with the trace in LDS (k_align_sw_wave)"""
     from bitmapperbs_amd import synth, mapper
     monkeypatch.setenv("BMBS_SW", form)
     r = synth.make_reads_se(env["chroms"], n=4000, L=L, seed=31, sub=0.02, indel=0.006, qual="random", n_rate=0.002)
@@ -682,7 +684,7 @@ def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knob", ["BMBS_DECIDE=plain", "BMBS_DECIDE=lds", "BMBS_DECIDE=vec8", "BMBS_VOTE=split", "BMBS_VOTE_NOMID=1", "BMBS_SEED_WAVES=4096",
-                                  "BMBS_TDEPTH=21", "BMBS_SW=wave"])
+                                  "BMBS_TDEPTH=21", "BMBS_SW=wave", "BMBS_SW=reg"])
 def test_ab_switches_give_identical_records(knob, env, monkeypatch):
     """the alternative kernel forms kept for A/B measurements map exactly like the default ones"""
     from bitmapperbs_amd import synth, mapper
