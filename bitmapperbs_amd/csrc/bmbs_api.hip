@@ -416,7 +416,11 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     {
         // the rows of a wave's 64 reads staged in LDS (k_seed_extra); rows too long for 64 KB stay in global memory
         const size_t lds = 64 * (size_t)(stride + 16);
-        const int rows_in_lds = lds <= 48 * 1024 && !getenv("BMBS_EXTRA_NOLDS");
+        // ... and, measured, only while the index gathers are short: on a GRCh38-size index (wide forms) every gather is an HBM
+        // round trip and the 11 KB of LDS per wave cost more occupancy (3.5 instead of 8 waves per SIMD) than the coalesced rows
+        // save: 4.20 ms with LDS rows, 3.93 ms without on the configs[2] batch (BMBS_EXTRA_LDS=1 / BMBS_EXTRA_NOLDS=1 force either)
+        const bool wide_ix = c->ix.sa64 != nullptr;
+        const int rows_in_lds = lds <= 48 * 1024 && !getenv("BMBS_EXTRA_NOLDS") && (!wide_ix || getenv("BMBS_EXTRA_LDS"));
         if (rows_in_lds)
             hipLaunchKernelGGL(k_seed_extra<true>, dim3(chunks_min), dim3(64), lds, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
