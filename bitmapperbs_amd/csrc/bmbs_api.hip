@@ -47,6 +47,7 @@ struct bmbs_ctx {
         a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d, in_len;
+    DevBuf prow, prow_dirty;                            // packed copy of the read rows (k_pack_rows), one dirty byte per read
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // paired-end workspace
     DevBuf sd_sp0, sd_hits0, sd_ml0, sd_tm, sd_seed_id, sd_clen, sd_first_ml, sd_flag_c, sd_flag_d, sd_off_c, sd_off_d, sd_list_c, sd_list_d;
@@ -363,7 +364,17 @@ SeedCarry seed_carry(bmbs_ctx* c)
     return sc;
 }
 
-int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, int pe_mode)
+// packed copy of the read rows for the seeding kernels?  BMBS_ROWS=packed|ascii forces; default: paired-end batches (the copy is
+// a by-product of k_pe_prepare there: +2.5 %), not single-end ones (a kernel of its own costs what it saves)
+bool use_packed_rows(int pe_mode)
+{
+    const char* e = getenv("BMBS_ROWS");
+    if (e && !strcmp(e, "ascii")) return false;
+    if (e && !strcmp(e, "packed")) return true;
+    return pe_mode != 0;
+}
+
+int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, int pe_mode, bool prepacked = false)
 {
     ENS(c, c->sd_sp0, n * 8); ENS(c, c->sd_hits0, n * 4); ENS(c, c->sd_ml0, n * 2); ENS(c, c->sd_tm, n * 2); ENS(c, c->sd_seed_id, n);
     ENS(c, c->sd_clen, n * 4); ENS(c, c->sd_first_ml, n * 2); ENS(c, c->sd_flag_c, n * 4); ENS(c, c->sd_flag_d, n * 4);
@@ -375,8 +386,25 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     const unsigned chunks_min = nblk(n, SEED_CHUNK_MIN);      // grid for the device-sized chunks of the two work lists
     const char* tw_env = getenv("BMBS_SEED_WAVES");
     const int target_waves = tw_env ? atoi(tw_env) : 65536;
+    // packed copy of the rows (2 bits per base + a not-ACGT bit plane, 64 bytes for 150 bases): what the seeding engine and
+    // k_seed_decide read instead of the ASCII rows; BMBS_ROWS=ascii keeps the round-1 forms (A/B runs)
+    const bool packed_rows = use_packed_rows(pe_mode);
+    PackedRows pr = {nullptr, nullptr, 0, 0};
+    if (packed_rows) {
+        const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
+        if (!prepacked) {
+            ENS(c, c->prow, n * (u64)pwords * 8 + 64); ENS(c, c->prow_dirty, n + 64);
+            HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n + 64, c->stream));
+            prof_begin(c, "k_pack_rows");
+            hipLaunchKernelGGL(k_pack_rows, dim3(nblk(n * (u64)(stride / 16), 256)), dim3(256), 0, c->stream, d_seq, gm, stride, (long)n,
+                               c->prow.as<u64>(), pwords, W, c->prow_dirty.as<u32>());
+            prof_end(c);
+        }
+        pr.base = c->prow.as<u64>(); pr.dirty = c->prow_dirty.as<u8>(); pr.pwords = pwords; pr.W = W;
+    }
     prof_begin(c, "k_seed_first");
-    hipLaunchKernelGGL(k_seed_first, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, (long)n, sc, cnt);
+    if (packed_rows) hipLaunchKernelGGL(k_seed_first<true>, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
+    else hipLaunchKernelGGL(k_seed_first<false>, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_decide");
     // rows staged through LDS (each read fetched from HBM exactly once, coalesced) + 8 characters per compare step;
@@ -384,7 +412,10 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     // staging was measured at 2.07 ms against 1.36 ms: the per-read bookkeeping, replicated eight times, costs more than it saves.)
     const char* dv = getenv("BMBS_DECIDE");
     const bool lds_ok = (size_t)64 * (stride + 8) <= 48 * 1024;
-    if (dv && !strcmp(dv, "plain"))
+    if (packed_rows && !dv)
+        hipLaunchKernelGGL(k_seed_decide_p, dim3(nblk(n, 64)), dim3(64), (size_t)64 * (pr.pwords + 1) * 8, c->stream, c->ix, d_seq, pr, gm, stride,
+                           (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
+    else if (dv && !strcmp(dv, "plain"))
         hipLaunchKernelGGL((k_seed_decide<false, false>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
     else if (dv && !strcmp(dv, "vec8"))
@@ -405,8 +436,8 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     if (rc) return rc;
     prof_end(c);
     prof_begin(c, "k_seed_second");
-    hipLaunchKernelGGL(k_seed_second, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode,
-                       st, sc, cnt);
+    if (packed_rows) hipLaunchKernelGGL(k_seed_second<true>, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode, st, sc, cnt);
+    else hipLaunchKernelGGL(k_seed_second<false>, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode, st, sc, cnt);
     prof_end(c);
     prof_begin(c, "list_extra");
     rc = scan_u32(c, sc.flag_d, n, sc.off_d, 4, sc.list_d);
@@ -421,11 +452,14 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
         // save: 4.20 ms with LDS rows, 3.93 ms without on the configs[2] batch (BMBS_EXTRA_LDS=1 / BMBS_EXTRA_NOLDS=1 force either)
         const bool wide_ix = c->ix.sa64 != nullptr;
         const int rows_in_lds = lds <= 48 * 1024 && !getenv("BMBS_EXTRA_NOLDS") && (!wide_ix || getenv("BMBS_EXTRA_LDS"));
-        if (rows_in_lds)
-            hipLaunchKernelGGL(k_seed_extra<true>, dim3(chunks_min), dim3(64), lds, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 4,
+        if (packed_rows)
+            hipLaunchKernelGGL((k_seed_extra<false, true>), dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
+                               target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
+        else if (rows_in_lds)
+            hipLaunchKernelGGL((k_seed_extra<true, false>), dim3(chunks_min), dim3(64), lds, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
         else
-            hipLaunchKernelGGL(k_seed_extra<false>, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 4,
+            hipLaunchKernelGGL((k_seed_extra<false, false>), dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
     }
     prof_end(c);
@@ -559,7 +593,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
                      &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list,
-                     &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx};
+                     &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx, &c->prow, &c->prow_dirty};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -854,10 +888,18 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     // the qualities are read where the caller put them (qual_row): mate 1 rows in d_qual1, mate 2 rows in d_qual2
     const char* qual_1 = reinterpret_cast<const char*>(d_qual1);
     const char* qual_2 = reinterpret_cast<const char*>(d_qual2);
+    bool prepacked = false;
     if (!prepared) {
+        u64* prow = nullptr; u32* pdirty = nullptr;
+        const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
+        if (use_packed_rows(1)) {
+            ENS(c, c->prow, n2 * (u64)pwords * 8 + 64); ENS(c, c->prow_dirty, n2 + 64);
+            HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n2 + 64, c->stream));
+            prow = c->prow.as<u64>(); pdirty = c->prow_dirty.as<u32>(); prepacked = true;
+        }
         prof_begin(c, "k_pe_prepare");
         hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * (stride / 16), 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
-                           reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all);
+                           reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all, prow, pwords, W, pdirty);
         prof_end(c);
     }
     ReadState st = read_state(c);
@@ -873,7 +915,7 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     c->last_reseeded = 0; c->last_reseed_cand = 0;
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     // seeding of all 2n reads; candidate slots by scan; locate
-    rc = launch_seeding(c, seq_all, gm, stride, n2, 1);
+    rc = launch_seeding(c, seq_all, gm, stride, n2, 1, prepacked);
     if (rc) return rc;
     prof_begin(c, "scan_cand");
     rc = scan_u32(c, st.n_cand, n2, st.cand_off, 0);

@@ -261,6 +261,143 @@ DEVI int mism_span(const DevIndex& ix, const char* rd, int ts, u64 d, int len)
 }
 
 // ================================================================================================
+// packed read rows (round 2)
+// ================================================================================================
+// Every kernel of the seeding engine starts a seed by reading 21 characters at a new offset of its read, and every such
+// per-lane load is a request of its own to the memory pipeline (a row load costs 3/4 of a random gather, tools/gather_bench):
+// with ASCII rows that is two or three 16-byte requests per seed start plus one per 16 characters walked.  k_pack_rows
+// therefore writes, once per batch, a packed copy of every row -- 2 bits per base (A0 C1 G2 T3, LSB first like gen2) followed by
+// one bit per base that says "this character is not one of ACGT" (then the base bits are 0): 64 bytes for a 150-base read,
+// ONE sector -- and a `dirty` byte per read that tells whether any such character exists at all.  A seed start is then one
+// 16-byte request (64 bases from the word that holds its first base), the walk one 8-byte request per 32 bases, the 16-mer key
+// falls out of the 2-bit codes with a few logic ops, and the comparisons with the 2-bit genome are XORs of whole words.  Only
+// what asks for the letter 'N' itself (penalty np, determine_seed_offset_unmatch) still looks at the ASCII row, and only for
+// dirty reads.
+struct PackedRows {
+    const u64* base;      // row r at base + r * pwords
+    const u8*  dirty;     // [n] 1 = the row holds a character outside ACGT
+    int pwords;           // u64 words per row (even: rows are 16-byte aligned)
+    int W;                // words of bases; the mask words follow
+};
+__host__ __device__ inline int pack_base_words(int L) { return (L + 31) / 32; }
+__host__ __device__ inline int pack_words(int L) { const int w = (L + 31) / 32 + (L + 63) / 64 + 1; return (w + 1) & ~1; }   // + one spare word for two-word loads at the end
+
+// two consecutive words from an 8-byte aligned address: one 16-byte request
+DEVI void load2(const u64* p, u64& a, u64& b)
+{
+    uint4 v;
+    __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), 16);
+    a = ((u64)v.y << 32) | v.x; b = ((u64)v.w << 32) | v.z;
+}
+// 32 bases (or 64 mask bits shifted) starting at an arbitrary position
+DEVI u64 prow_bases32(const u64* row, int pos)
+{
+    u64 a, b; load2(row + (pos >> 5), a, b);
+    const int sh = 2 * (pos & 31);
+    return sh ? (a >> sh) | (b << (64 - sh)) : a;
+}
+DEVI u32 prow_mask32(const u64* row, int W, int pos)      // mask bits of positions pos .. pos+31
+{
+    u64 a, b; load2(row + W + (pos >> 6), a, b);
+    const int sh = pos & 63;
+    return (u32)(sh ? (a >> sh) | (b << (64 - sh)) : a);
+}
+// 32 bases of the doubled genome starting at doubled coordinate d (gen2 carries spare words at its end)
+DEVI u64 gen_bases32(const DevIndex& ix, u64 d)
+{
+    u64 a, b; load2(ix.gen2 + (d >> 5), a, b);
+    const int sh = 2 * (int)(d & 31);
+    return sh ? (a >> sh) | (b << (64 - sh)) : a;
+}
+// 32 bits -> the even bit positions of 64 bits
+DEVI u64 spread32(u32 m)
+{
+    u64 x = m;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+#define PK_EVEN 0x5555555555555555ull
+// mismatches (bit 2j set = position j differs) of 32 read bases against 32 window bases
+//   mism_bs:  the alignment rule -- equal letters match, and read T matches window C (Schema.cpp:15212-15216)
+//   mism_3l:  the index alphabet -- A=A, G=G, {C,T}={C,T}
+DEVI u64 mism_bs(u64 r, u64 g) { const u64 x = r ^ g; return (x | ((x >> 1) & ~(r & (r >> 1)))) & PK_EVEN; }
+DEVI u64 mism_3l(u64 r, u64 g) { const u64 x = r ^ g; return (x | ((x >> 1) & ~r)) & PK_EVEN; }
+// fields lo .. hi-1 (hi <= 32) as a mask of even bits
+DEVI u64 field_range(int lo, int hi)
+{
+    const u64 up = hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1);
+    const u64 dn = lo <= 0 ? 0ull : ((1ull << (2 * lo)) - 1);
+    return up & ~dn & PK_EVEN;
+}
+
+// cursor over the bases of a packed row: 3-letter digit of the next base (G0 T1 A2, C folded into T; 4 = outside ACGT)
+struct PCur {
+    const u64* row; u64 buf; int W, pos, have; bool dirty;
+    DEVI int next3()
+    {
+        if (have == 0) { buf = row[pos >> 5] >> (2 * (pos & 31)); have = 32 - (pos & 31); }
+        const int c = (int)(buf & 3);
+        buf >>= 2; have--;
+        int d = (0x46 >> (2 * c)) & 3;
+        if (dirty && ((row[W + (pos >> 6)] >> (pos & 63)) & 1)) d = 4;
+        pos++;
+        return d;
+    }
+};
+
+// 16 characters (one 16-byte piece of an ASCII row) -> 32 bits of bases + 16 mask bits; characters at and beyond `valid` count as A
+DEVI void pack_piece(const uint4& v, int valid, u32& bases, u32& mask)
+{
+    const u64 w[2] = {((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z};
+    bases = 0; mask = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const u64 K01 = 0x0101010101010101ull;
+        // (c >> 1) & 3 is A0 C1 T2 G3; swapping 2 and 3 gives A0 C1 G2 T3
+        u64 c = (w[h] >> 1) & (3 * K01);
+        c ^= (c >> 1) & K01;
+        // a byte that is not one of A C G T: rebuild the letter its bits 1-2 stand for and compare (as swar_code3)
+        const u64 isT = (w[h] >> 2) & ~(w[h] >> 1) & K01;
+        u64 bad = w[h] ^ (0x4141414141414141ull | (w[h] & 0x0606060606060606ull)) ^ (isT | (isT << 4));
+        bad = ((bad | ((bad & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full)) >> 7) & K01;      // 1 per bad byte
+        const int left = valid - 8 * h;
+        const u64 keep = left >= 8 ? ~0ull : (left <= 0 ? 0ull : ((1ull << (8 * left)) - 1));
+        bad &= keep;
+        c &= keep & ~(bad * 3);
+        u64 x = c;
+        x = (x | (x >> 6)) & 0x000f000f000f000full;
+        x = (x | (x >> 12)) & 0x000000ff000000ffull;
+        x = (x | (x >> 24)) & 0xffffull;
+        bases |= (u32)x << (16 * h);
+        mask |= (u32)((bad * 0x0102040810204080ull) >> 56) << (8 * h);
+    }
+}
+
+// one thread per 16-byte piece of an ASCII row
+__global__ void __launch_bounds__(256)
+k_pack_rows(const char* __restrict__ seq, ReadGeom gm, int stride, long n, u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32)
+{
+    const long i16 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = stride / 16;
+    if (i16 >= n * per_row) return;
+    const long r = i16 / per_row;
+    const int piece = (int)(i16 - r * per_row);
+    const int L = gm.rl(r);
+    if (piece * 16 >= ((L + 63) & ~63)) return;                 // beyond the row's last mask word: nothing to write
+    const uint4 v = reinterpret_cast<const uint4*>(seq)[i16];
+    u32 bases, mask;
+    pack_piece(v, L - piece * 16, bases, mask);
+    u64* row = prow + (size_t)r * pwords;
+    if (piece * 16 < ((L + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = bases;
+    reinterpret_cast<u16*>(row + W)[piece] = (u16)mask;
+    if (mask) atomicOr(&dirty32[r >> 2], 1u << (8 * (int)(r & 3)));
+}
+
+// ================================================================================================
 // attach-time re-pack kernels
 // ================================================================================================
 struct RefIndexDev {            // reference on-disk layouts, uploaded verbatim
@@ -649,6 +786,127 @@ DEVI bool search_step(const DevIndex& ix, const char* rd, int L, Search& S, Seed
     }
 }
 
+// ---- the same two functions over a packed row (PackedRows) ----------------------------------------------------------------
+struct SearchP { u64 top, bot, ptop, pbot; int s, steps, tm; PCur cur; };
+
+// four 2-bit digits (d0 in bits 0-1) -> d0 + 3 d1 + 9 d2 + 27 d3
+DEVI u32 base3_of4x2(u32 v8)
+{
+    u32 t = (v8 | (v8 << 12)) & 0x000f000fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    return base3_of4(t);
+}
+
+template <bool FIXED, bool LOCATED = false>
+DEVI bool search_begin_p(const DevIndex& ix, const u64* row, int W, bool dirty, int L, int tm, SearchP& S, SeedHit& out, u32& n_hash)
+{
+    const int len = L - tm;
+    out.hits = 0; out.sp = 0; out.ml = FIXED ? (u64)len : 0;
+    if (len < (FIXED ? 17 : 18)) return false;
+    // the 64 bases from the word that holds read[tm]: the 16 of the key, the table's look-ahead and the cursor's first piece in
+    // ONE 16-byte request
+    const u64 x = prow_bases32(row, tm);                              // bases tm .. tm+31
+    const u32 mbits = dirty ? prow_mask32(row, W, tm) : 0u;
+    if (mbits & 0xffffu) return false;                               // get_3_letter_hash_value returned -1 (bwt.h:309-332)
+    // 3-letter digits in the 2-bit fields: A (00) -> 2, C / T (low bit) -> 1, G -> 0
+    const u64 D = ((((~x) & ((~x) >> 1)) & PK_EVEN) << 1) | (x & PK_EVEN);
+    const u32 d32 = (u32)D;
+    const u64 key = base3_of4x2(d32 & 0xffu) + 81u * base3_of4x2((d32 >> 8) & 0xffu) + 6561u * base3_of4x2((d32 >> 16) & 0xffu) +
+                    531441u * base3_of4x2(d32 >> 24);
+    S.steps = len - 16; S.tm = tm;
+    S.cur.row = row; S.cur.W = W; S.cur.dirty = dirty;
+    const int E = ix.t_e;
+    if ((!FIXED || LOCATED) && ix.t20 && len >= 16 + E) {
+        // the 16-mer lookup and the first E extensions in one table read
+        if (((mbits >> 16) & ((1u << E) - 1)) == 0) {
+            const u32 dE = (u32)(D >> 32);
+            const u64 code = (u64)base3_of4x2(dE & 0xffu) + (E == 5 ? 81ull * ((dE >> 8) & 3u) : 0ull);
+            const u64 v = ix.t20[key * t20_width(E) + code];
+            const int tag = (int)(v >> 60);
+            if (tag != 14) {
+                n_hash++;
+                const u64 rowv = v & ((1ull << 36) - 1), hits = (v >> 36) & ((1ull << 24) - 1);
+                if (tag == 15) return false;                                           // hits 0, match length 0
+                if (FIXED) {
+                    if (tag > E && tag <= 2 * E) return false;
+                    if (tag != 0) {
+                        S.top = rowv | (1ull << 63); S.bot = S.top + 1; S.ptop = ~0ull; S.pbot = ~0ull; S.s = tag == 2 * E + 1 ? E : tag - 1;
+                        return true;
+                    }
+                } else {
+                    if (tag >= 1 && tag <= E) { out.ml = (u64)(15 + tag); out.sp = rowv | (1ull << 63); out.hits = 1; return false; }
+                    if (tag == 2 * E + 1) { out.ml = (u64)(16 + E); out.sp = rowv | (1ull << 63); out.hits = 1; return false; }
+                    if (tag > E) { out.ml = (u64)(15 - E + tag); out.sp = rowv; out.hits = hits; return false; }
+                }
+                S.top = rowv; S.bot = rowv + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = E;
+                if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
+                S.cur.pos = tm + 16 + E; S.cur.buf = x >> (2 * (16 + E)); S.cur.have = 16 - E;
+                return true;
+            }
+        }
+    }
+    hash_lookup(ix, key, S.top, S.bot);
+    n_hash++;
+    if (S.bot <= S.top) return false;
+    S.ptop = ~0ull; S.pbot = ~0ull; S.s = 0;
+    S.cur.pos = tm + 16; S.cur.buf = x >> 32; S.cur.have = 16;
+    return true;
+}
+
+template <bool FIXED>
+DEVI bool search_step_p(const DevIndex& ix, int L, SearchP& S, SeedHit& out, u32& n_ext)
+{
+    const int len = L - S.tm;
+    if (!FIXED) {
+        S.ptop = S.top; S.pbot = S.bot;
+        if (S.bot - S.top == 1) { out.ml = 16 + S.s; out.sp = S.top; out.hits = 1; return true; }
+        const int d = S.cur.next3();
+        if (d > 2) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
+        lf_pair(ix, S.top, S.bot, d);
+        n_ext++;
+        if (S.bot <= S.top) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
+        S.s++;
+        if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
+        return false;
+    } else {
+        out.ml = (u64)len;
+        const int d = S.cur.next3();
+        if (d > 2) { out.hits = 0; out.sp = 0; return true; }
+        lf_pair(ix, S.top, S.bot, d);
+        n_ext++;
+        if (S.bot <= S.top) { out.hits = 0; out.sp = S.top; return true; }
+        S.s++;
+        if (S.s == S.steps) { out.sp = S.top; out.hits = S.bot - S.top; return true; }
+        return false;
+    }
+}
+
+// does read[q0 .. L) equal the text at doubled coordinate site0 + (q - tm) in the index alphabet?  (k_seed_second's single-row
+// shortcut, on a packed row: 32 bases per step)
+DEVI bool rest_matches_3l(const DevIndex& ix, const u64* row, int W, bool dirty, int L, int tm, int start, u64 site)
+{
+    for (int q = start & ~31; q < L; q += 32) {
+        const u64 rb = row[q >> 5];
+        const u64 d = site + (u64)(q - tm);                  // doubled coordinate facing read[q] (u64 wrap = out of range)
+        u64 mm;
+        if (d + 32 <= ix.total) mm = mism_3l(rb, gen_bases32(ix, d));
+        else {
+            // runs off the end of the text: '$' never matches
+            mm = 0;
+            for (int j = 0; j < 32; j++) {
+                const u64 dj = d + (u64)j;
+                const int rc = (int)((rb >> (2 * j)) & 3);
+                bool eq = false;
+                if (dj < ix.total) { const int g = gbase(ix, dj); eq = (rc == g) || ((rc & 1) && (g & 1)); }
+                if (!eq) mm |= 1ull << (2 * j);
+            }
+        }
+        if (dirty) mm |= spread32((u32)((row[W + (q >> 6)] >> (q & 63)) & 0xffffffffull));
+        if (mm & field_range(start - q, L - q)) return false;
+    }
+    return true;
+}
+
 // determine_seed_offset_unmatch (Schema.h:1506-1531)
 DEVI int seed_offset_unmatch(int L, int pre, const char* rd, int step)
 {
@@ -709,8 +967,9 @@ DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c, in
 }
 
 // ---- first seed of every read ------------------------------------------------------------------
+template <bool PACKED>
 __global__ void __launch_bounds__(64)
-k_seed_first(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, long n, SeedCarry sc,
+k_seed_first(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, SeedCarry sc,
              unsigned long long* __restrict__ counters)
 {
     int L = gm.L;                                     // length of the lane's current read
@@ -721,7 +980,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
     bool active = false;
     long r = 0;
     const char* rd = seq;
-    Search S; SeedHit h;
+    typename std::conditional<PACKED, SearchP, Search>::type S; SeedHit h;
     // lanes whose search ended wait (`pending`) until SEED_BATCH of them can run the divergent
     // store / refill / hash-lookup code together: one straggler must not stall 63 stepping lanes
     bool pending = true, have = false;
@@ -735,8 +994,11 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
             if (pending) {
                 if (have) { sc.sp0[r] = h.sp; sc.hits0[r] = (u32)h.hits; sc.ml0[r] = (u16)h.ml; have = false; }
                 if (it < chunk_end) {
-                    r = it; rd = seq + (size_t)r * stride; have = true; L = gm.rl(r);
-                    if (search_begin<false>(ix, rd, L, 0, S, h, lc.n_hash)) { active = true; pending = false; }
+                    r = it; have = true; L = gm.rl(r);
+                    bool go;
+                    if constexpr (PACKED) go = search_begin_p<false>(ix, pr.base + (size_t)r * pr.pwords, pr.W, pr.dirty[r] != 0, L, 0, S, h, lc.n_hash);
+                    else { rd = seq + (size_t)r * stride; go = search_begin<false>(ix, rd, L, 0, S, h, lc.n_hash); }
+                    if (go) { active = true; pending = false; }
                     // else: decided at once; stays pending, stored at the next batch
                 } else pending = false;
             }
@@ -747,7 +1009,11 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
         if ((threadIdx.x & 63) == 0) atomicAdd(&counters[8], 1ull);
         if (active) atomicAdd(&counters[9], 1ull);
 #endif
-        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
+        if (active) {
+            bool fin;
+            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
+            if (fin) { active = false; pending = true; }
+        }
     }
     flush_counters(counters, lc, 0);
 }
@@ -922,9 +1188,135 @@ k_seed_decide(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
     }
 }
 
-// ---- second seed of the 1-mismatch reads + fast exit C (Schema.cpp:24734-24801, 24894-24898) -----
+// ---- the same kernel over packed rows: 64 bytes per read through LDS instead of 160, comparisons by whole-word XOR -------------
 __global__ void __launch_bounds__(64)
-k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
+k_seed_decide_p(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, int seed_len, int pe_mode,
+                ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned int shc[2];
+    if (threadIdx.x < 2) shc[threadIdx.x] = 0;
+    extern __shared__ __align__(16) char lds_prows[];
+    const int lw = pr.pwords + 1;                                   // row stride in words, odd against bank conflicts
+    u64* lrows = reinterpret_cast<u64*>(lds_prows);
+    const long row0 = (long)blockIdx.x * blockDim.x;
+    const long rows = n - row0 < (long)blockDim.x ? n - row0 : (long)blockDim.x;
+    {
+        // the block's rows are contiguous in memory: copy them with coalesced 8-byte loads
+        const u64* src = pr.base + (size_t)row0 * pr.pwords;
+        const int total = (int)rows * pr.pwords;
+        for (int q = threadIdx.x; q < total; q += blockDim.x) { const int rr = q / pr.pwords, cc = q - rr * pr.pwords; lrows[rr * lw + cc] = src[q]; }
+    }
+    __syncthreads();
+    const long r = row0 + threadIdx.x;
+    u32 n_sa = 0, n_ung = 0;
+    if (r < n) {
+        const u64* row = lrows + (size_t)threadIdx.x * lw;
+        const int W = pr.W;
+        const bool dirty = pr.dirty[r] != 0;
+        const int L = gm.rl(r);
+        // first 'C' of the read (code 01)
+        int firstC = L;
+        for (int w = 0; w * 32 < L; w++) {
+            const u64 x = row[w];
+            const u64 z = x & ~(x >> 1) & PK_EVEN;
+            if (z) { const int j = w * 32 + (__ffsll((long long)z) - 1) / 2; if (j < L) firstC = j; break; }
+        }
+        SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+        int ns = 0;
+        u64 ncand = 0, clen = 0;
+        const int max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
+        int verdict = 0, multi = 0, get_error = -1, tm = 0, seed_id = 0;
+        u64 mm_site = 0, c0 = 0, first_ml = 0;
+        const u64 max_hits = 1000;
+        bool done = false;
+        u32 fc = 0, fd = 0;
+        if (seed_id < max_seed && tm < L) {
+            const u64 hits = sc.hits0[r], sp = sc.sp0[r];
+            u64 ml = sc.ml0[r];
+            first_ml = ml;
+            if (hits == 1) {
+                // try_process_unique_mismatch_end_to_end (Schema.cpp:15164-15282)
+                u64 p;
+                if (sp >> 63) p = sp & ~(1ull << 63);          // the outcome table had the text position
+                else { p = sa_at(ix, sp); n_sa++; }
+                const u64 loc = ix.total - p - ml;
+                seed_record(my, ns, ncand, sp, 1, ml, 0);
+                c0 = loc; clen = 1;
+                int error = 0;
+                if (ml > (u64)firstC) ml = (u64)firstC;
+                if (ml != (u64)L) {
+                    const int need = L - (int)ml;
+                    n_ung++;
+                    if (!window_valid(ix, loc + ml, (u64)need, loc < ix.G)) {
+                        // all-zero window: every position mismatches; the first sets ml = read_i (= ml), the second stops
+                        error = need >= 2 ? 2 : 1;
+                    } else {
+                        // read position q faces doubled coordinate loc + q; 32 positions per step
+                        const int ml0 = (int)ml;
+                        for (int q = ml0 & ~31; q < L && error < 2; q += 32) {
+                            u64 mm = mism_bs(row[q >> 5], gen_bases32(ix, loc + (u64)q));
+                            if (dirty) mm |= spread32((u32)((row[W + (q >> 6)] >> (q & 63)) & 0xffffffffull));
+                            mm &= field_range(ml0 - q, L - q);
+                            if (mm) {
+                                const int cnt = __popcll(mm);
+                                if (error == 0) { ml = (u64)(q + (__ffsll((long long)mm) - 1) / 2); error = cnt >= 2 ? 2 : 1; }
+                                else error = 2;
+                            }
+                        }
+                    }
+                }
+                get_error = error;
+                if (error == 0) { verdict = 1; st.exit_site[r] = loc; done = true; }
+            }
+            if (!done) {
+                mm_site = ml;
+                if (!pe_mode) {
+                    if (ml == (u64)L && hits > 1) {
+                        multi = 1;
+                        if (firstC == L) { verdict = 4; done = true; }      // exact, ambiguous, no C in the read
+                    }
+                } else if (ml == (u64)L && hits > 1 && hits <= 10000) {
+                    // get_candidates (Schema.cpp:18260-18290): every exact hit becomes a verified candidate
+                    multi = 1;
+                    if (firstC == L) { seed_record(my, ns, ncand, sp, hits, ml, 0); verdict = 4; done = true; }
+                }
+            }
+            if (!done) {
+                if (hits == 1) { /* recorded */ }
+                else if (ml >= (u64)seed_len && hits <= max_hits) { if (hits != 0) { seed_record(my, ns, ncand, sp, hits, ml, (u64)tm); clen += hits; } }
+                if (ml == 0) {
+                    if (!dirty) tm = (L - tm < 18) ? L : tm + 8;
+                    else tm = seed_offset_unmatch(L, tm, seq + (size_t)r * stride, 8);
+                } else tm = tm + (int)(ml / 2);
+                seed_id++;
+            }
+        }
+        st.multi[r] = (u8)multi;
+        // bit 15: the read character there is 'N' (only a dirty row can hold one: then the ASCII row is asked)
+        bool isN = false;
+        if (dirty && mm_site < (u64)L && ((row[W + (mm_site >> 6)] >> (mm_site & 63)) & 1)) isN = seq[(size_t)r * stride + mm_site] == 'N';
+        st.mm_site[r] = (u16)(mm_site | (isN ? 0x8000u : 0u));
+        if (done) seed_finish(st, r, verdict, ns, ncand, pe_mode);
+        else {
+            st.exit_site[r] = c0;
+            st.n_seeds[r] = (u8)ns; st.n_cand[r] = (u32)ncand;
+            sc.tm[r] = (u16)tm; sc.seed_id[r] = (u8)seed_id; sc.clen[r] = (u32)clen; sc.first_ml[r] = (u16)first_ml;
+            // 1-mismatch first seed: second seed over the rest of the read (Schema.cpp:24734-24801)
+            if (get_error == 1 && L - (int)first_ml >= 17) fc = 1; else fd = 1;
+        }
+        sc.flag_c[r] = fc; sc.flag_d[r] = fd;
+    }
+    if (counters) {
+        atomicAdd(&shc[0], n_sa); atomicAdd(&shc[1], n_ung);
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned long long* cs = SHARD(counters); atomicAdd(&cs[2], (unsigned long long)shc[0]); atomicAdd(&cs[5], (unsigned long long)shc[1]); }
+    }
+}
+
+// ---- second seed of the 1-mismatch reads + fast exit C (Schema.cpp:24734-24801, 24894-24898) -----
+template <bool PACKED>
+__global__ void __launch_bounds__(64)
+k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
               int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
 {
     int L = gm.L;                                     // length of the lane's current read
@@ -938,7 +1330,9 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
     bool active = false;
     long r = 0;
     const char* rd = seq;
-    Search S; SeedHit h;
+    const u64* prow = nullptr;
+    bool dirty = false;
+    typename std::conditional<PACKED, SearchP, Search>::type S; SeedHit h;
     const u64 max_hits = 1000;
     bool verify = false;          // the interval shrank to one row: finish the count against the genome itself
     auto finish = [&]() {
@@ -966,6 +1360,8 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             bool ok = true;
             // 16 positions per step: one 16-byte row load, the window through a two-word cursor (one load per 32 bases)
             const int start = tm + done_chars;
+            if constexpr (PACKED) ok = rest_matches_3l(ix, prow, pr.W, dirty, L, tm, start, site);
+            else {
             Win32Cur wc; wc.init(ix, site + (u64)((start & ~15) - tm));
             for (int q = start & ~15; q < L && ok; q += 16) {
                 const uint4 v = *reinterpret_cast<const uint4*>(rd + q);
@@ -995,6 +1391,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
                     if (hi <= 8) { m[1] = 0; if (hi < 8) m[0] &= (1ull << (8 * hi)) - 1; } else m[1] &= (1ull << (8 * (hi - 8))) - 1;
                 }
                 if (m[0] | m[1]) ok = false;
+            }
             }
             if (ok) { h.hits = 1; h.sp = (p - (u64)(S.steps - S.s)) | (1ull << 63); }     // located: text position of the full seed
             else { h.hits = 0; h.sp = 0; }
@@ -1032,8 +1429,13 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
             if (pending) {
                 if (have) { finish(); have = false; }
                 if (it < chunk_end) {
-                    r = sc.list_c[it]; rd = seq + (size_t)r * stride; have = true; L = gm.rl(r);
-                    if (search_begin<true, true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash)) {
+                    r = sc.list_c[it]; have = true; L = gm.rl(r);
+                    bool go;
+                    if constexpr (PACKED) {
+                        prow = pr.base + (size_t)r * pr.pwords; dirty = pr.dirty[r] != 0;
+                        go = search_begin_p<true, true>(ix, prow, pr.W, dirty, L, (int)sc.first_ml[r], S, h, lc.n_hash);
+                    } else { rd = seq + (size_t)r * stride; go = search_begin<true, true>(ix, rd, L, (int)sc.first_ml[r], S, h, lc.n_hash); }
+                    if (go) {
                         if (S.bot - S.top == 1) verify = true;          // already a single row: stays pending, verified next batch
                         else { active = true; pending = false; }
                     }
@@ -1047,7 +1449,9 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
         if (active) atomicAdd(&counters[11], 1ull);
 #endif
         if (active) {
-            if (search_step<true>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; }
+            bool fin;
+            if constexpr (PACKED) fin = search_step_p<true>(ix, L, S, h, lc.n_ext); else fin = search_step<true>(ix, rd, L, S, h, lc.n_ext);
+            if (fin) { active = false; pending = true; }
             else if (S.bot - S.top == 1) { verify = true; active = false; pending = true; }
         }
     }
@@ -1055,9 +1459,10 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride
 }
 
 // ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
-template <bool ROWS_LDS>
+// ROWS_LDS: ASCII rows staged in LDS (small indexes); PACKED: packed rows read from global memory (64 bytes per read)
+template <bool ROWS_LDS, bool PACKED = false>
 __global__ void __launch_bounds__(64)
-k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
+k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
              int seed_len, int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
 {
     int L = gm.L;                                     // length of the lane's current read
@@ -1081,7 +1486,9 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
     __shared__ u8 take_lane[64];
     const int lstride = stride + 16;                  // 16-byte aligned rows, shifted against bank conflicts
     const char* rd = ROWS_LDS ? lds_rows + (size_t)(threadIdx.x & 63) * lstride : seq;
-    Search S; SeedHit h = {0, 0, 0};
+    const u64* prow = nullptr;
+    bool dirty = false;
+    typename std::conditional<PACKED, SearchP, Search>::type S; SeedHit h = {0, 0, 0};
     SeedRec* my = nullptr;
     int ns = 0, tm = 0, seed_id = 0, max_seed = 0;
     u64 ncand = 0, clen = 0;
@@ -1093,7 +1500,11 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
         if (h.hits == 1) { seed_record(my, ns, ncand, h.sp, 1, ml, (u64)tm); clen += 1; }
         else if (ml >= (u64)seed_len && h.hits <= max_hits) { if (h.hits != 0) { seed_record(my, ns, ncand, h.sp, h.hits, ml, (u64)tm); clen += h.hits; } }
         else if ((u64)cur_len == ml) return false;
-        if (ml == 0) tm = seed_offset_unmatch(L, tm, rd, 8); else tm = tm + (int)(ml / 2);
+        if (ml == 0) {
+            // only a read with a character outside ACGT can hold the 'N' determine_seed_offset_unmatch looks for
+            if (PACKED && !dirty) tm = (L - tm < 18) ? L : tm + 8;
+            else tm = seed_offset_unmatch(L, tm, PACKED ? seq + (size_t)r * stride : rd, 8);
+        } else tm = tm + (int)(ml / 2);
         seed_id++;
         return true;
     };
@@ -1132,6 +1543,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
                 if (it < chunk_end) {
                     r = sc.list_d[it]; L = gm.rl(r);
                     if (!ROWS_LDS) rd = seq + (size_t)r * stride;
+                    if (PACKED) { prow = pr.base + (size_t)r * pr.pwords; dirty = pr.dirty[r] != 0; }
                     my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
                     ns = st.n_seeds[r]; ncand = st.n_cand[r]; clen = sc.clen[r]; tm = sc.tm[r]; seed_id = sc.seed_id[r];
                     max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
@@ -1140,7 +1552,9 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
                 } else pending = false;         // chunk exhausted: this lane is done
             }
             if (pending && have) {
-                if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash)) { active = true; pending = false; }
+                bool go;
+                if constexpr (PACKED) go = search_begin_p<false>(ix, prow, pr.W, dirty, L, tm, S, h, lc.n_hash); else go = search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash);
+                if (go) { active = true; pending = false; }
                 else seed_done = true;              // decided without stepping: booked in the next batch
             }
             if (!__any(active) && !__any(pending)) break;
@@ -1150,7 +1564,11 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
         if ((threadIdx.x & 63) == 0) atomicAdd(&counters[12], 1ull);
         if (active) atomicAdd(&counters[13], 1ull);
 #endif
-        if (active && search_step<false>(ix, rd, L, S, h, lc.n_ext)) { active = false; pending = true; seed_done = true; }
+        if (active) {
+            bool fin;
+            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
+            if (fin) { active = false; pending = true; seed_done = true; }
+        }
     }
     flush_counters(counters, lc, 2);
 }
@@ -2903,7 +3321,8 @@ struct PeState {
 
 // mate 2: reverse complement of the FASTQ read (rc_table, Process_Reads.cpp:1603-1613: identity for non-ACGT)
 __global__ void __launch_bounds__(256)
-k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all)
+k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all,
+             u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32)
 {
     // one 16-byte piece per thread (rows are 16-byte aligned, stride % 16 == 0)
     const long i16 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2914,7 +3333,20 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGe
     const long r = i / stride;
     const int j0 = (int)(i - r * stride);
     const int L = gm.rl(n + r);                    // mate 2 of pair r
-    reinterpret_cast<uint4*>(seq_all)[i16] = reinterpret_cast<const uint4*>(s1)[i16];          // the qualities stay where they are (qual_row)
+    const uint4 v1 = reinterpret_cast<const uint4*>(s1)[i16];
+    reinterpret_cast<uint4*>(seq_all)[i16] = v1;                                              // the qualities stay where they are (qual_row)
+    // the packed copy of both rows (what k_pack_rows would write), from the pieces this thread holds anyway
+    auto pack_out = [&](const uint4& pv, long row_id, int Lr) {
+        const int piece = j0 / 16;
+        if (!prow || piece * 16 >= ((Lr + 63) & ~63)) return;
+        u32 bases, mask;
+        pack_piece(pv, Lr - piece * 16, bases, mask);
+        u64* row = prow + (size_t)row_id * pwords;
+        if (piece * 16 < ((Lr + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = bases;
+        reinterpret_cast<u16*>(row + W)[piece] = (u16)mask;
+        if (mask) atomicOr(&dirty32[row_id >> 2], 1u << (8 * (int)(row_id & 3)));
+    };
+    pack_out(v1, r, gm.rl(r));
     // out[j] = complement(in[L-1-j]) for j < L, 0 beyond: one reversed 16-byte piece per thread.  complement = c ^ 0x15 for
     // A/T, c ^ 0x04 for C/G, identity otherwise (rc_table), eight characters per step.
     auto comp8 = [](u64 w) -> u64 {
@@ -2946,6 +3378,7 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGe
         v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
     }
     reinterpret_cast<uint4*>(seq_all + total)[i16] = v;
+    pack_out(v, n + r, L);
 }
 
 // ---- FASTQ text -> read rows (bmbs_map_*_fastq) --------------------------------------------------------------------------------

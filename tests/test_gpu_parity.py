@@ -684,7 +684,7 @@ def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knob", ["BMBS_DECIDE=plain", "BMBS_DECIDE=lds", "BMBS_DECIDE=vec8", "BMBS_VOTE=split", "BMBS_VOTE_NOMID=1", "BMBS_SEED_WAVES=4096",
-                                  "BMBS_TDEPTH=21", "BMBS_SW=wave", "BMBS_SW=reg"])
+                                  "BMBS_TDEPTH=21", "BMBS_SW=wave", "BMBS_SW=reg", "BMBS_ROWS=packed"])
 def test_ab_switches_give_identical_records(knob, env, monkeypatch):
     """the alternative kernel forms kept for A/B measurements map exactly like the default ones"""
     from bitmapperbs_amd import synth, mapper
@@ -701,13 +701,20 @@ def test_ab_switches_give_identical_records(knob, env, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sensitive", [0, 1])
-def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive):
+@pytest.mark.parametrize("sensitive,rows", [(0, "packed"), (1, "packed"), (0, "ascii"), (1, "ascii")])
+def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive, rows):
     """the 21-mer form of the outcome table (3^21 entries, 84 GB: what a GRCh38-size index gets) forced on the test genome: the
-    seeding engine reads five letters ahead instead of four; pairs in both modes against the oracle"""
+    seeding engine reads five letters ahead instead of four; pairs in both modes against the oracle, with the seeding kernels on
+    the packed rows k_pe_prepare writes (the paired-end default) and on the ASCII rows"""
     from bitmapperbs_amd import synth, mapper
     monkeypatch.setenv("BMBS_TDEPTH", "21")
+    monkeypatch.setenv("BMBS_ROWS", rows)
     m1, m2 = synth.make_reads_pe(env["chroms"], n=12000, L=150, seed=77 + sensitive, sub=0.03, indel=0.002, qual="random")
+    # a few characters outside ACGT, 'N' and others, so that the not-ACGT plane of the packed rows is exercised by pairs too
+    rng = np.random.default_rng(5)
+    for mm in (m1, m2):
+        pos = rng.random(mm["seq"].shape) < 0.003
+        mm["seq"][pos] = np.frombuffer(b"NNNR", dtype=np.uint8)[rng.integers(0, 4, int(pos.sum()))]
     m = mapper.Mapper(env["ix"], 0, sensitive=sensitive)
     res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
     recs, ost, _ = env["oix"].map_pe(orc.params(sensitive=sensitive), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
