@@ -575,6 +575,7 @@ def main():
             "counters_last_launch": cnt,
             "mapstats": {"reads_or_pairs": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                          "unmapped": int(stats[0] - stats[1] - stats[2]), "mapped_bases": int(stats[3]), "error_bases": int(stats[4])},
+            "library": {"build_id": capi.build_id(), "sources_id": capi.sources_id(), "built_from_these_sources": capi.build_id() == capi.sources_id()},
             "index": {"build_s": round(built_s, 1), "builder": "host" if args.host_index else "gpu", "files_load_s": round(load_s, 1),
                       "attach_s": round(attach_s, 1), "read_synthesis_s": round(synth_s, 1)},
         }

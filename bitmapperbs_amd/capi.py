@@ -21,7 +21,7 @@ SYMBOLS = [
     "bmbs_map_se_fastq", "bmbs_map_pe_fastq", "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
-    "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free",
+    "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
 ]
 
 
@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
     L.bmbs_index_file_free.restype = None
     L.bmbs_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.bmbs_index_build_device.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    L.bmbs_build_id.argtypes = []
+    L.bmbs_build_id.restype = C.c_char_p
     L.bmbs_host_alloc.argtypes = [u64]
     L.bmbs_host_alloc.restype = vp
     L.bmbs_host_free.argtypes = [vp]
@@ -140,6 +142,23 @@ def lib() -> C.CDLL:
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
+            "../../include/bmbs.h")
+
+
+def sources_id() -> str:
+    """what bmbs_build_id() of a library built from the sources in this tree returns (csrc/Makefile: LIB_SRCS, BUILD_ID)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in LIB_SRCS:
+        h.update(open(os.path.join(_HERE, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id() -> str:
+    return lib().bmbs_build_id().decode()
 
 
 def default_params(**kw) -> Params:

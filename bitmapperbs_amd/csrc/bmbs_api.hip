@@ -1455,6 +1455,11 @@ extern "C" int bmbs_counters_all(bmbs_ctx* c, uint64_t out[32])
     return BMBS_OK;
 }
 
+#ifndef BMBS_BUILD_ID
+#define BMBS_BUILD_ID "unknown"
+#endif
+extern "C" const char* bmbs_build_id(void) { return BMBS_BUILD_ID; }
+
 extern "C" void* bmbs_host_alloc(uint64_t bytes)
 {
     void* p = nullptr;

@@ -255,6 +255,10 @@ int bmbs_index_build(const char* fasta, const char* prefix, int n_threads);
  * FASTA / .pac preparation.  BMBS_ENODEV without a device (no silent fall-back to the host builder).                       */
 int bmbs_index_build_device(int device_id, const char* fasta, const char* prefix, int n_threads);
 
+/* first 16 hex digits of the sha256 over the library's sources (in the Makefile's LIB_SRCS order) at build time: lets a run show
+ * that the .so it loaded was built from the sources it sits next to (bitmapperbs_amd.capi.sources_id() recomputes it)          */
+const char* bmbs_build_id(void);
+
 /* Page-locked host buffers for the host-pointer entry points (bmbs_map_se / bmbs_map_pe copy from and to them at
  * full link speed).  The reference's per-thread scratch is plain malloc (Schema.cpp:24344-24362); a caller that
  * keeps malloc'ed buffers still works, only slower.  NULL on failure.                                     */

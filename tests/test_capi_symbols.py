@@ -40,3 +40,10 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "orc_" not in txt and "import orc" not in txt, os.path.join(dp, f)
+
+
+def test_library_was_built_from_the_sources_in_this_tree():
+    """bmbs_build_id() = sha256 over the library's sources at build time (csrc/Makefile); the .so is git-ignored but travels to the GPU
+    box, so every run can (and bench.py does) show that what it loaded matches the sources next to it"""
+    from bitmapperbs_amd import capi
+    assert capi.build_id() == capi.sources_id()
