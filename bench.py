@@ -451,7 +451,7 @@ def file_to_file_rate(args, cfg, fa, L):
         inp = ["--seq", files[0]]
     if not os.path.exists(drv) or not all(os.path.exists(f) for f in files):
         return None
-    rec_bytes = 2 * L + 14
+    rec_bytes = 2 * L + 15                      # write_fastq_sample: '@s%08d\n' + L + '\n+\n' + L + '\n'
     n = os.path.getsize(files[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     out = {}
     for label, dst in (("file", os.path.join(args.workdir, "f2f.sam")), ("null_sink", "/dev/null")):
