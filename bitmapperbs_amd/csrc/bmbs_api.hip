@@ -269,7 +269,7 @@ void launch_sw2(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* 
 // K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the
 // register-band DP kernel instantiated for the smallest KB >= k.  No host round-trip inside.
 int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
-              u32 rev_from, u32* d_cigar_pool, int max_ops, const char* d_qual2 = nullptr)
+              u32 rev_from, u32* d_cigar_pool, int max_ops, const char* d_qual2 = nullptr, const PackedRows* pr = nullptr)
 {
     const int L = gm.L, k = gm.k;              // the longest read and the largest threshold size the workspace
     const u64 nj = n_jobs ? n_jobs : 1;
@@ -300,9 +300,14 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     }
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     prof_begin(c, "k_align_ungapped");
-    hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                       d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
-                       c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
+    if (pr && pr->base)
+        hipLaunchKernelGGL(k_align_ungapped_p, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq, *pr,
+                           d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                           c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
+    else
+        hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+                           d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                           c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
     prof_end(c);
     prof_begin(c, "scan_sw");
     int rc = scan_u32(c, c->need_sw.as<u32>(), n_jobs, c->sw_off.as<u64>(), 2, c->sw_job.as<u32>());
@@ -778,7 +783,9 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
             prof_end(c);
         }
         Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
-        rc = run_align(c, d_seq, d_qual, gm, stride, n_jobs, jobs, 0xffffffffu, reinterpret_cast<u32*>(d_cigar_pool), max_ops);
+        PackedRows prw = {nullptr, nullptr, 0, 0};
+        if (use_packed_rows(0)) { prw.base = c->prow.as<u64>(); prw.dirty = c->prow_dirty.as<u8>(); prw.pwords = pack_words(gm.L); prw.W = pack_base_words(gm.L); }
+        rc = run_align(c, d_seq, d_qual, gm, stride, n_jobs, jobs, 0xffffffffu, reinterpret_cast<u32*>(d_cigar_pool), max_ops, nullptr, &prw);
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize");
@@ -1042,7 +1049,9 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         }
         Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
         // mate 2 rows (>= n) carry FASTQ-order qualities for a reverse-complemented read: need_reverse_quality = 1
-        rc = run_align(c, seq_all, qual_1, gm, stride, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops, qual_2);
+        PackedRows prw = {nullptr, nullptr, 0, 0};
+        if (use_packed_rows(1)) { prw.base = c->prow.as<u64>(); prw.dirty = c->prow_dirty.as<u8>(); prw.pwords = pack_words(gm.L); prw.W = pack_base_words(gm.L); }
+        rc = run_align(c, seq_all, qual_1, gm, stride, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops, qual_2, &prw);
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize_pe");
@@ -1125,11 +1134,18 @@ extern "C" int bmbs_map_pe_var(bmbs_ctx* c, const char* seq1, const char* qual1,
 namespace {
 struct FqDev { const char* text; const u32* seq_off; const u32* qual_off; const u16* seq_len; const u16* qual_len; };
 
-int fastq_check(bmbs_ctx* c, const bmbs_fastq_view* v, int64_t n)
+int fastq_check(bmbs_ctx* c, const bmbs_fastq_view* v, int64_t n, int L_max)
 {
     if (!v || !v->text || !v->seq_off || !v->qual_off || !v->seq_len || !v->qual_len) { c->err = "fastq view: NULL field"; return BMBS_EINVAL; }
     if (v->text_bytes >= (1ull << 32)) { c->err = "fastq view: a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
-    (void)n;
+    // every line the device is going to read lies inside the window (a bad index must not become an out-of-bounds device read)
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t sl = v->seq_len[i], ql = v->qual_len[i];
+        if (sl < 1 || sl > (uint64_t)L_max || ql > sl || (uint64_t)v->seq_off[i] + sl > v->text_bytes || (uint64_t)v->qual_off[i] + ql > v->text_bytes) {
+            c->err = "fastq view: record " + std::to_string(i) + " has a line outside the text window or a length outside 1..L_max";
+            return BMBS_EINVAL;
+        }
+    }
     return BMBS_OK;
 }
 // text + index arrays of one file to the device; idx_at = byte offset of this file's arrays inside c->fq_idx
@@ -1156,7 +1172,7 @@ extern "C" int bmbs_map_se_fastq(bmbs_ctx* c, const bmbs_fastq_view* reads, int6
     if (n_cigar_used) *n_cigar_used = 0;
     if (n_reads <= 0) return BMBS_OK;
     if (L_max <= 0 || L_max > 1000) { c->err = "bad read geometry"; return BMBS_EINVAL; }
-    { const int r0 = fastq_check(c, reads, n_reads); if (r0) return r0; }
+    { const int r0 = fastq_check(c, reads, n_reads, L_max); if (r0) return r0; }
     const u64 n = (u64)n_reads;
     const int ds = (L_max + 15) / 16 * 16;
     const int k = threshold_k(c->prm, L_max);
@@ -1188,7 +1204,7 @@ extern "C" int bmbs_map_pe_fastq(bmbs_ctx* c, const bmbs_fastq_view* mate1, cons
     if (n_cigar_used) *n_cigar_used = 0;
     if (n_pairs <= 0) return BMBS_OK;
     if (L_max <= 0 || L_max > 1000) { c->err = "bad read geometry"; return BMBS_EINVAL; }
-    { int r0 = fastq_check(c, mate1, n_pairs); if (r0) return r0; r0 = fastq_check(c, mate2, n_pairs); if (r0) return r0; }
+    { int r0 = fastq_check(c, mate1, n_pairs, L_max); if (r0) return r0; r0 = fastq_check(c, mate2, n_pairs, L_max); if (r0) return r0; }
     const u64 n = (u64)n_pairs, n2 = 2 * n;
     const int ds = (L_max + 15) / 16 * 16;
     const int k = threshold_k(c->prm, L_max);

@@ -966,6 +966,20 @@ DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c, in
     }
 }
 
+// five stats values of a lane -> one LDS atomic per wave and value (256 lanes hammering five LDS words with 64-bit atomics was
+// 40 % of k_finalize's issue time)
+DEVI void wave_stats_add(unsigned long long* sh, u32 v0, u32 v1, u32 v2, u32 v3, u32 v4)
+{
+    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_down(v0, o); v1 += __shfl_down(v1, o); v2 += __shfl_down(v2, o); v3 += __shfl_down(v3, o); v4 += __shfl_down(v4, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (v0) atomicAdd(&sh[0], (unsigned long long)v0);
+        if (v1) atomicAdd(&sh[1], (unsigned long long)v1);
+        if (v2) atomicAdd(&sh[2], (unsigned long long)v2);
+        if (v3) atomicAdd(&sh[3], (unsigned long long)v3);
+        if (v4) atomicAdd(&sh[4], (unsigned long long)v4);
+    }
+}
+
 // ---- first seed of every read ------------------------------------------------------------------
 template <bool PACKED>
 __global__ void __launch_bounds__(64)
@@ -2511,6 +2525,54 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
     else { need_sw[jb] = 1; if (counters) atomicAdd(&SHARD(counters)[4], 1ull); }
 }
 
+// the same kernel over packed rows: 64 bytes of read instead of 160, the window compare a whole-word XOR (32 positions per step),
+// the quality row touched only at the mismatching positions, the ASCII row only where a dirty read might hold an 'N'
+__global__ void __launch_bounds__(256)
+k_align_ungapped_p(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq, PackedRows pr,
+                   const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
+                   int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
+                   int* __restrict__ a_nops, u32* __restrict__ need_sw, unsigned long long* __restrict__ counters)
+{
+    const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb >= n_jobs) return;
+    const u32 r = jb_.read[jb];
+    const u64 site = jb_.site[jb];
+    const int end_site = jb_.end[jb];
+    const u32 err_in = jb_.err[jb];
+    const int L = gm.rl(r), k = gm.rk(L);
+    need_sw[jb] = 0;
+    if (err_in == 0) {          // fast_recalculate_bs_Cigar's own err == 0 branch (ksw.cpp:2607-2616)
+        a_start[jb] = end_site - L + 1; a_end[jb] = end_site; a_nm[jb] = 0; a_score[jb] = 0; a_nops[jb] = 0;
+        return;
+    }
+    const u64* row = pr.base + (size_t)r * pr.pwords;
+    const bool dirty = pr.dirty[r] != 0;
+    const char* ql = qual_row(qual, qual2, rev_qual_from, r, stride);
+    const bool rev = r >= rev_qual_from;
+    const bool wvalid = window_valid(ix, site, (u64)(L + 2 * k), site < ix.G);
+    const int start = end_site - L + 1;
+    bool ok = start >= 0 && wvalid;
+    int tmp_err = 0, score = 0;
+    if (ok) {
+        for (int p = 0; p < L && ok; p += 32) {
+            u64 mm = mism_bs(row[p >> 5], gen_bases32(ix, site + (u64)start + (u64)p));
+            if (dirty) mm |= spread32((u32)((row[pr.W + (p >> 6)] >> (p & 63)) & 0xffffffffull));
+            mm &= field_range(0, L - p);
+            tmp_err += __popcll(mm);
+            if (tmp_err > (int)err_in) { ok = false; break; }
+            while (mm) {
+                const int i = p + (__ffsll((unsigned long long)mm) - 1) / 2;
+                mm &= mm - 1;
+                const bool isN = dirty && ((row[pr.W + (i >> 6)] >> (i & 63)) & 1) && seq[(size_t)r * stride + i] == 'N';
+                score -= isN ? sp.np : pen_lut[(unsigned char)ql[rev ? L - 1 - i : i]];
+            }
+        }
+        if (ok && tmp_err != (int)err_in) ok = false;
+    }
+    if (ok) { a_start[jb] = start; a_end[jb] = end_site; a_nm[jb] = err_in; a_score[jb] = score; a_nops[jb] = 0; }
+    else { need_sw[jb] = 1; if (counters) atomicAdd(&SHARD(counters)[4], 1ull); }
+}
+
 // UNIFORM: all reads of the launch have one length, so k is a kernel argument (a scalar register) and the band tests of the
 // unrolled loop are scalar branches; with per-read lengths they are per-lane and cost an exec-mask save/restore per cell.
 template <int KB, bool UNIFORM>
@@ -3198,6 +3260,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
     if (threadIdx.x < 5) sh[threadIdx.x] = 0;
     __syncthreads();
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;          // this lane's contribution to the five counters
     if (r < n) {
         bmbs_result_dev o;
         o.pos = 0; o.cigar_off = 0; o.chrom = -1; o.status = 0; o.mapq = 0; o.flag = 0; o.nm = 0; o.score = 0;
@@ -3276,10 +3339,11 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
             o.status = ok ? (amb ? 2 : 1) : 3;
         }
         res[r] = o;
-        atomicAdd(&sh[0], 1ull);
-        if (o.status == 1) { atomicAdd(&sh[1], 1ull); atomicAdd(&sh[3], (unsigned long long)L); atomicAdd(&sh[4], (unsigned long long)nm); }
-        else if (o.status == 2) atomicAdd(&sh[2], 1ull);
+        s0 = 1;
+        if (o.status == 1) { s1 = 1; s3 = (u32)L; s4 = (u32)nm; }
+        else if (o.status == 2) s2 = 1;
     }
+    wave_stats_add(sh, s0, s1, s2, s3, s4);
     __syncthreads();
     if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&SHARD(stats)[threadIdx.x], sh[threadIdx.x]);
 }
@@ -4017,6 +4081,7 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
     if (threadIdx.x < 5) sh[threadIdx.x] = 0;
     __syncthreads();
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;          // this lane's contribution to the five counters
     if (p < n) {
         bmbs_result_dev o[2];
         for (int m = 0; m < 2; m++) {
@@ -4083,16 +4148,17 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
                 }
                 o[0].flag = (u16)(rflag[0] == 0 ? (1 | 2 | 32 | 64) : (1 | 2 | 16 | 64));
                 o[1].flag = (u16)(rflag[1] == 0 ? (1 | 2 | 16 | 128) : (1 | 2 | 32 | 128));
-                if (np == 1) atomicAdd(&sh[1], 1ull);
-                atomicAdd(&sh[3], (unsigned long long)(L1 + L2));
-                atomicAdd(&sh[4], (unsigned long long)(nm[0] + nm[1]));
+                if (np == 1) s1 = 1;
+                s3 = (u32)(L1 + L2);
+                s4 = nm[0] + nm[1];
             } else status = 3;
         }
-        if (status == 2) atomicAdd(&sh[2], 1ull);
-        atomicAdd(&sh[0], 1ull);
+        if (status == 2) s2 = 1;
+        s0 = 1;
         o[0].status = (u8)status; o[1].status = (u8)status;
         res[2 * p] = o[0]; res[2 * p + 1] = o[1];
     }
+    wave_stats_add(sh, s0, s1, s2, s3, s4);
     __syncthreads();
     if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&SHARD(stats)[threadIdx.x], sh[threadIdx.x]);
 }
