@@ -47,6 +47,7 @@ struct bmbs_ctx {
         a_start, a_end, a_nm, a_score, a_nops;
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d, in_len;
+    DevBuf pe_mid_flag, pe_mid_list;                    // k_vote_pe_mid work list
     DevBuf prow, prow_dirty;                            // packed copy of the read rows (k_pack_rows), one dirty byte per read
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // paired-end workspace
@@ -598,7 +599,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
                      &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list,
-                     &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx, &c->prow, &c->prow_dirty};
+                     &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx, &c->prow, &c->prow_dirty, &c->pe_mid_flag, &c->pe_mid_list};
     for (DevBuf* b : all) release(*b);
     for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -938,10 +939,23 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     PeCand* A = c->votes.as<PeCand>();
     PeCand* B = c->pe_B.as<PeCand>();
     ENS(c, c->long_flag, n2 * 4); ENS(c, c->long_off, (n2 + 1) * 8); ENS(c, c->long_list, n2 * 4);
+    // reads of 180 bases and more place up to 25 seeds: lists of 17..32 candidates are the rule there and get a kernel of their own
+    // (k_vote_pe_mid; buffers of its own: --sensitive still reads the seeding flags afterwards)
+    const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !getenv("BMBS_VOTE_NOMID");
+    if (use_mid) { ENS(c, c->pe_mid_flag, n2 * 4); ENS(c, c->pe_mid_list, n2 * 4); }
+    u32* mid_flag = use_mid ? c->pe_mid_flag.as<u32>() : nullptr;
+    if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n2 * 4, c->stream));
     prof_begin(c, "k_vote_pe_fused");
     hipLaunchKernelGGL(k_vote_pe_fused, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, c->ix, (long)n2, gm, st, ps, c->cand.as<u64>(), A,
-                       c->slot_read.as<u32>(), c->long_flag.as<u32>());
+                       c->slot_read.as<u32>(), c->long_flag.as<u32>(), mid_flag);
     prof_end(c);
+    if (use_mid) {
+        prof_begin(c, "k_vote_pe_mid");
+        rc = scan_u32(c, mid_flag, n2, c->long_off.as<u64>(), 11, c->pe_mid_list.as<u32>());
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_vote_pe_mid, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, c->ix, gm, st, ps, c->totals.as<u64>() + 11, c->pe_mid_list.as<u32>(), A);
+        prof_end(c);
+    }
     prof_begin(c, "k_vote_pe_long");
     rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
     if (rc) return rc;

@@ -3535,7 +3535,7 @@ k_vote_pe(long n2, ReadGeom gm, ReadState st, PeState ps, u64* __restrict__ cand
 // k_vote_fused; general reads emit one entry per distinct site (no vote order), exact-ambiguous reads every hit
 __global__ void __launch_bounds__(64)
 k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64* __restrict__ cand, PeCand* __restrict__ A,
-                u32* __restrict__ slot_read, u32* __restrict__ long_flag)
+                u32* __restrict__ slot_read, u32* __restrict__ long_flag, u32* __restrict__ mid_flag)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n2) return;
@@ -3595,6 +3595,7 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
         else { ps.occ[r] = -1; ps.len[r] = (u32)nv; }
         return;
     }
+    if (mid_flag && nc <= VOTE_MID) { mid_flag[r] = 1; return; }      // 17..32 candidates, the rule for reads of 180 bases and more: k_vote_pe_mid
     if (nc <= VL_CAP) { long_flag[r] = 1; return; }          // repeats: k_vote_pe_long sorts the list out of LDS
     u64* c = cand + off;
     {
@@ -3615,6 +3616,67 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
         for (long i = 1; i < nc; i++)
             if (c[i] != pre) { o[nv].site = pre < (u64)k ? 0 : pre - (u64)k; o[nv].err = 0; o[nv].end = 0; nv++; pre = c[i]; }
         o[nv].site = pre >= (u64)k ? pre - (u64)k : 0; o[nv].err = 0; o[nv].end = 0; nv++;
+        ps.occ[r] = -1; ps.len[r] = (u32)nv;
+    }
+}
+
+// lists of 17..32 candidates (reads of 180 bases and more place up to 25 seeds): one lane per read over the compacted list,
+// located into registers and sorted by a bitonic network -- the paired-end counterpart of k_vote_mid (no vote order here)
+__global__ void __launch_bounds__(64)
+k_vote_pe_mid(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
+              PeCand* __restrict__ A)
+{
+    const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= (long)*count_ptr) return;
+    const long r = list[it];
+    const int L = gm.rl(r), k = gm.rk(L);
+    const int v = st.verdict[r];
+    const long nc = (long)st.n_cand[r];
+    const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+    const int ns = st.n_seeds[r];
+    PeCand* o = A + st.cand_off[r];
+    u64 c[VOTE_MID];
+    {
+        int sidx = 0; u32 h = 0;
+        u64 sp = 0, adj = 0; u32 hits = 0;
+        if (ns > 0) { sp = my[0].sp; adj = (u64)my[0].len + (u64)my[0].off; hits = my[0].hits; }
+#pragma unroll
+        for (int j = 0; j < VOTE_MID; j++) {
+            c[j] = ~0ull;
+            if (j < nc) {
+                while (h == hits && sidx + 1 < ns) { sidx++; h = 0; sp = my[sidx].sp; adj = (u64)my[sidx].len + (u64)my[sidx].off; hits = my[sidx].hits; }
+                c[j] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + h)) - adj;
+                h++;
+            }
+        }
+    }
+#pragma unroll
+    for (int size = 2; size <= VOTE_MID; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int t = 0; t < VOTE_MID / 2; t++) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool asc = (i & size) == 0;
+                const u64 x_ = c[i], y_ = c[j];
+                const bool sw = asc ? x_ > y_ : x_ < y_;
+                c[i] = sw ? y_ : x_; c[j] = sw ? x_ : y_;
+            }
+        }
+    }
+    if (v == 4) {
+#pragma unroll
+        for (int i = 0; i < VOTE_MID; i++) if (i < nc) { PeCand e; e.site = c[i]; e.err = 0; e.end = L - 1; o[i] = e; }
+        ps.occ[r] = (int)nc; ps.len[r] = (u32)nc;
+    } else {
+        int nv = 0;
+#pragma unroll
+        for (int i = 0; i < VOTE_MID; i++) {
+            if (i < nc && (i + 1 >= nc || (i + 1 < VOTE_MID && c[i + 1] != c[i]))) {
+                PeCand e; e.site = c[i] < (u64)k ? 0 : c[i] - (u64)k; e.err = 0; e.end = 0;
+                o[nv++] = e;
+            }
+        }
         ps.occ[r] = -1; ps.len[r] = (u32)nv;
     }
 }
