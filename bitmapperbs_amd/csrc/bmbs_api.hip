@@ -1493,7 +1493,7 @@ extern "C" const char* bmbs_build_id(void) { return BMBS_BUILD_ID; }
 extern "C" void* bmbs_host_alloc(uint64_t bytes)
 {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) return nullptr;      // portable: contexts on several devices copy from it
     return p;
 }
 extern "C" void bmbs_host_free(void* p) { if (p) (void)hipHostFree(p); }

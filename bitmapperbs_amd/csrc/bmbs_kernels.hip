@@ -3543,7 +3543,7 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
     const int L = gm.rl(r), k = gm.rk(L);
     const int v = st.verdict[r];
     const u64 off = st.cand_off[r];
-    for (u64 g = off; g < st.cand_off[r + 1]; g++) slot_read[g] = (u32)r;
+    (void)slot_read;             // nothing downstream of the paired-end vote stage reads the slot -> read map (49 M scattered stores per launch)
     ps.cur[r] = 0; ps.vround[r] = 0;
     if (v == 1 || v == 2) {
         A[off].site = st.exit_site[r]; A[off].err = v == 1 ? 0u : 1u; A[off].end = L - 1;

@@ -427,6 +427,29 @@ def test_cpp_driver_se_sam_file_equals_reference_golden(name, tmp_path):
     assert open(ms).read() == open(os.path.join(GOLD, "se_%s.ref.stats" % name)).read()
 
 
+def test_cpp_driver_lower_case_bases(tmp_path):
+    """the reference's reader upper-cases the bases (Process_Reads.cpp:860); that happens on the device now (k_fastq_rows) and again
+    when SEQ is printed from the FASTQ text: lower-casing a third of the bases must not change a byte of the SAM.  (A quality line
+    shorter than its sequence leaves stale buffer bytes in the reference's record, :834-874 -- not a behaviour to pin.)"""
+    import subprocess
+    from bitmapperbs_amd import mapper
+    fa = str(tmp_path / "genome.fa"); fq = str(tmp_path / "r.fq"); out = str(tmp_path / "o.sam")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    mapper.Index.build(fa, fa, threads=4)
+    lines = gzip.open(os.path.join(GOLD, "se_b150.fq.gz"), "rt").read().split("\n")
+    rng = np.random.default_rng(3)
+    for i in range(1, len(lines) - 1, 4):
+        s_ = np.frombuffer(lines[i].encode(), dtype=np.uint8).copy()
+        m_ = rng.random(s_.size) < 0.33
+        s_[m_] |= 0x20
+        lines[i] = s_.tobytes().decode()
+    open(fq, "w").write("\n".join(lines))
+    p = subprocess.run([_driver(), "--search", fa, "--seq", fq, "-o", out, "--batch", "333"] + golden_args()["b150"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    mine = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert mine == gzip.open(os.path.join(GOLD, "se_b150.ref.sam.gz"), "rt").read()
+
+
 @pytest.mark.parametrize("name", ["p100", "s100"])
 def test_cpp_driver_pe_sam_file_equals_reference_golden(name, tmp_path):
     import subprocess
