@@ -370,14 +370,14 @@ SeedCarry seed_carry(bmbs_ctx* c)
     return sc;
 }
 
-// packed copy of the read rows for the seeding kernels?  BMBS_ROWS=packed|ascii forces; default: paired-end batches (the copy is
-// a by-product of k_pe_prepare there: +2.5 %), not single-end ones (a kernel of its own costs what it saves)
+// packed copy of the read rows for the seeding kernels, k_seed_decide and the un-gapped recheck (default); BMBS_ROWS=ascii keeps the
+// round-1 forms for A/B runs.  Paired end: the copy is a by-product of k_pe_prepare (+2.5 %); single end: a kernel of its own
+// (k_pack_rows, 0.53 ms per 10 M reads) that the consumers win back (+1.8 %: 1463 -> 1489 M reads/s on configs[1]).
 bool use_packed_rows(int pe_mode)
 {
+    (void)pe_mode;
     const char* e = getenv("BMBS_ROWS");
-    if (e && !strcmp(e, "ascii")) return false;
-    if (e && !strcmp(e, "packed")) return true;
-    return pe_mode != 0;
+    return !(e && !strcmp(e, "ascii"));
 }
 
 int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, int pe_mode, bool prepacked = false)
