@@ -73,6 +73,8 @@ def parse(argv=None):
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S)
     ap.add_argument("--host-index", action="store_true", help="build the index with the host builder (bmbs_index_build)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective check without a GPU: gloo, no mapping (tests)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the N > 1 run (gloo: tests)")
+    ap.add_argument("--same-device", action="store_true", help="every rank on GPU 0 (a functional test of the N > 1 path on a 1-GPU box; use with --dist-backend gloo)")
     ap.add_argument("--workdir", default=os.environ.get("BMBS_BENCH_DIR", "/tmp/bmbs_bench"))
     a = ap.parse_args(argv)
     cfg = dict(CONFIGS[a.config])
@@ -334,7 +336,7 @@ class Job:
         return self.reads_per_launch * len(self.batches)
 
 
-def timed(job, steps, warmup, min_seconds, world, dist, torch):
+def timed(job, steps, warmup, min_seconds, world, dist, torch, cdev="cuda"):
     """W warm-up steps, then K timed steps between barrier + synchronize; a step is repeated `passes` whole times when K steps
     would take less than min_seconds.  -> (seconds, passes, per-launch kernel ms averages)"""
     t_w = None
@@ -348,7 +350,7 @@ def timed(job, steps, warmup, min_seconds, world, dist, torch):
     if min_seconds > 0 and t_w * steps < min_seconds:
         passes = int(np.ceil(min_seconds / (t_w * steps)))
     if world > 1:
-        pt = torch.tensor([passes], dtype=torch.int64, device="cuda")
+        pt = torch.tensor([passes], dtype=torch.int64, device=cdev)
         dist.all_reduce(pt, op=dist.ReduceOp.MAX)
         passes = int(pt.item())
     job.m.reset_stats()
@@ -491,11 +493,14 @@ def main():
             print(json.dumps({"metric": "dry-run", "n_gpus": dist.get_world_size(), "mapstats_sum": st.tolist()}), flush=True)
         dist.destroy_process_group()
         return
+    if args.same_device:
+        local = 0
+    cdev = "cuda" if args.dist_backend == "nccl" else "cpu"          # where the tensors of the collectives live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
         world = dist.get_world_size()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the mapping path has no CPU fallback)")
@@ -518,9 +523,9 @@ def main():
     synth_s = time.time() - t
     del chroms
 
-    dt, passes, kern_ms = timed(job, args.steps, args.warmup, args.min_seconds, world, dist, torch)
-    stats = torch.from_numpy(m.stats()).cuda()
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dt, passes, kern_ms = timed(job, args.steps, args.warmup, args.min_seconds, world, dist, torch, cdev)
+    stats = torch.from_numpy(m.stats()).to(cdev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)        # the only collective: 5 x int64 mapstats
@@ -558,7 +563,7 @@ def main():
                                        ("PE --sensitive" if cfg["sensitive"] else "PE fast mode") if pe else "SE", args.sub, args.indel, args.qual),
                        "reads_per_gpu_per_step": reads_per_step, "units_per_launch": job.n, "launches_per_step": len(job.batches) * passes,
                        "read_len": L, "genome_bp": cfg["genome"], "timed_s": round(dt, 3),
-                       "parallelism": "pairs sharded by rank, index replicated, RCCL all-reduce of 5 mapstats counters"},
+                       "parallelism": "pairs sharded by rank, index replicated, %s all-reduce of 5 mapstats counters" % ("RCCL" if args.dist_backend == "nccl" else "gloo")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(a8, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(a8 / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(b8), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4),

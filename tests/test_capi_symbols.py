@@ -47,3 +47,16 @@ def test_library_was_built_from_the_sources_in_this_tree():
     box, so every run can (and bench.py does) show that what it loaded matches the sources next to it"""
     from bitmapperbs_amd import capi
     assert capi.build_id() == capi.sources_id()
+
+
+def test_device_index_builder_fails_loudly_without_a_gpu(tmp_path):
+    """no silent fall-back to the host builder: without a HIP device bmbs_index_build_device returns BMBS_ENODEV (-19)"""
+    import torch
+    from bitmapperbs_amd import capi
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    fa = tmp_path / "g.fa"
+    fa.write_text(">c\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    assert capi.lib().bmbs_index_build_device(0, str(fa).encode(), str(fa).encode(), 1) == -19
+    assert not (tmp_path / "g.fa.index").exists()

@@ -794,3 +794,25 @@ def test_many_contigs_match_oracle(tmp_path):
     assert not compare_pe(res, pool, recs, 100)
     assert (m.stats() == ost).all()
     m.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """the N > 1 path of bench.py end to end on a 1-GPU box: `--gpus 2` starts two ranks itself, rank 0 builds the index while the
+    other waits at the barrier, each rank attaches its own copy and maps its own reads, the mapstats are all-reduced (gloo here:
+    RCCL refuses two ranks on one device) and rank 0 prints ONE line whose totals are those of both ranks"""
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "1", "--units", "500000", "--steps", "2", "--warmup", "1",
+                        "--min-seconds", "0", "--no-cpu", "--no-secondary", "--dist-backend", "gloo", "--same-device", "--workdir", "/tmp/bmbs_bench_t2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["mapstats"]["reads_or_pairs"] == 2 * 2 * 500000          # two ranks x two steps x 500 k reads
+    assert d["value"] > 0 and d["config"]["reads_per_gpu_per_step"] == 500000
