@@ -745,7 +745,9 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
     prof_end(c);
     if (tot) {
         prof_begin(c, "k_filter");
-        hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, c->totals.as<u64>() + 5,
+        PackedRows prf = {nullptr, nullptr, 0, 0};
+        if (use_packed_rows(0)) { prf.base = c->prow.as<u64>(); prf.dirty = c->prow_dirty.as<u8>(); prf.pwords = pack_words(gm.L); prf.W = pack_base_words(gm.L); }
+        hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, prf, gm, stride, c->totals.as<u64>() + 5,
                            c->dense_read.as<u32>(), c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), cnt);
         prof_end(c);
     }
@@ -975,7 +977,9 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
             if (r_) return r_;
             hipLaunchKernelGGL(k_pe_worklist, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, wcnt, woff, c->dense_read.as<u32>(),
                                c->ferr.as<u32>());
-            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(cap, 256)), dim3(256), 0, c->stream, c->ix, seq_all, gm, stride, st, ps, A, B,
+            PackedRows prf = {nullptr, nullptr, 0, 0};
+            if (use_packed_rows(1)) { prf.base = c->prow.as<u64>(); prf.dirty = c->prow_dirty.as<u8>(); prf.pwords = pack_words(gm.L); prf.W = pack_base_words(gm.L); }
+            hipLaunchKernelGGL(k_filter_pe, dim3(nblk(cap, 256)), dim3(256), 0, c->stream, c->ix, seq_all, prf, gm, stride, st, ps, A, B,
                                c->totals.as<u64>() + 6, c->dense_read.as<u32>(), c->ferr.as<u32>(), cnt);
             prof_end(c);
         }

@@ -2228,8 +2228,10 @@ DEVI void planes32(const DevIndex& ix, u64 d, u32& lo, u32& hi)      // the 32 b
     hi = squeeze(a >> 1) | (squeeze(b >> 1) << 16);
 }
 // W = u32: band <= 31 bits (k <= 15), 64 bases of each plane in a register pair; W = u64: band <= 63 bits (k <= 31), 96 bases.
-template <class W>
-DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end)
+// PACKED: the read comes from a packed row (prow, 32 bases per word; pW = its base words; dirty = it holds characters outside ACGT)
+template <class W, bool PACKED = false>
+DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end,
+                     const u64* prow = nullptr, int pW = 0, bool dirty = false)
 {
     constexpr bool WIDE = sizeof(W) == 8;
     out_err = 0xffffffffu; out_end = -1;
@@ -2281,6 +2283,48 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
                 loS = (loS >> 32) | ((u64)loT << 32); hiS = (hiS >> 32) | ((u64)hiT << 32);
                 loT = nl; hiT = nh;
             } else { loS = (loS >> 32) | ((u64)nl << 32); hiS = (hiS >> 32) | ((u64)nh << 32); }
+        }
+        if constexpr (PACKED) {
+            // 32 bases per word; the per-character step sees the 2-bit code (A0 C1 G2 T3) and, for dirty rows, the not-ACGT bit
+            const u64 rb = prow[i0 >> 5];
+            const u32 mb = dirty ? (u32)((prow[pW + (i0 >> 6)] >> (i0 & 63)) & 0xffffffffull) : 0u;
+            auto step_p = [&](u32 c, u32 bad, int i, auto checked) {
+                const int sh = i - i0;
+                W lo, hi;
+                if (WIDE) {
+                    lo = (W)(sh ? (loS >> sh) | ((u64)loT << (64 - sh)) : loS) & bmask;
+                    hi = (W)(sh ? (hiS >> sh) | ((u64)hiT << (64 - sh)) : hiS) & bmask;
+                } else { lo = (W)(loS >> sh) & bmask; hi = (W)(hiS >> sh) & bmask; }
+                const W xl = (c & 1u) ? lo : (lo ^ bmask);
+                const W xh = (c & 2u) ? hi : ~hi;
+                W eq = c == 3u ? lo : (xl & xh);
+                if (decltype(checked)::value) eq &= (W)0 - (W)(bad ^ 1u);
+                W X = eq | VN;
+                const W D0 = ((VP + (X & VP)) ^ VP) | X;
+                const W HN = VP & D0;
+                const W HP = VN | ~(VP | D0);
+                X = D0 >> 1;
+                const W VN2 = X & HP, VP2 = HN | ~(X | HP);
+                if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
+                else { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); }
+            };
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int ib = i0 + 16 * half;
+                if (ib >= L) break;
+                const u32 c16 = (u32)(rb >> (32 * half));
+                const u32 m16 = (mb >> (16 * half)) & 0xffffu;
+                const bool plain = m16 == 0 && ib + 16 <= L;
+                if (__all(plain)) {
+#pragma unroll
+                    for (int c = 0; c < 16; c++) step_p((c16 >> (2 * c)) & 3u, 0u, ib + c, std::false_type());
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 16; c++) step_p((c16 >> (2 * c)) & 3u, (m16 >> c) & 1u, ib + c, std::true_type());
+                }
+                if (__all(err - last_high > k)) return;
+            }
+            continue;
         }
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -2336,9 +2380,19 @@ DEVI void bpm_one(const DevIndex& ix, const char* rd, int L, int k, u64 site, u3
     if (k <= 15) bpm_planes<u32>(ix, rd, L, k, site, out_err, out_end);          // k is wave-uniform unless lengths are mixed
     else bpm_planes<u64>(ix, rd, L, k, site, out_err, out_end);
 }
+// read r of a batch: from its packed row when the batch has them, else from the ASCII row
+DEVI void bpm_read(const DevIndex& ix, const char* seq, int stride, const PackedRows& pr, long r, int L, int k, u64 site, u32& out_err, int& out_end)
+{
+    if (pr.base) {
+        const u64* row = pr.base + (size_t)r * pr.pwords;
+        const bool dirty = pr.dirty[r] != 0;
+        if (k <= 15) bpm_planes<u32, true>(ix, nullptr, L, k, site, out_err, out_end, row, pr.W, dirty);
+        else bpm_planes<u64, true>(ix, nullptr, L, k, site, out_err, out_end, row, pr.W, dirty);
+    } else bpm_one(ix, seq + (size_t)r * stride, L, k, site, out_err, out_end);
+}
 
 __global__ void __launch_bounds__(256)
-k_filter(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, const u64* __restrict__ n_votes_total,
+k_filter(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, const u64* __restrict__ n_votes_total,
          const u32* __restrict__ dense_read, const bmbs_vote* __restrict__ dense, u32* __restrict__ ferr,
          int* __restrict__ fend, unsigned long long* __restrict__ counters)
 {
@@ -2347,7 +2401,7 @@ k_filter(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, con
     const u32 r = dense_read[g];
     u32 e; int es;
     const int L = gm.rl(r), k = gm.rk(L);
-    bpm_one(ix, seq + (size_t)r * stride, L, k, dense[g].site, e, es);
+    bpm_read(ix, seq, stride, pr, (long)r, L, k, dense[g].site, e, es);
     ferr[g] = e; fend[g] = es;
     if (counters) atomicAdd(&SHARD(counters)[3], 1ull);
 }
@@ -3806,7 +3860,7 @@ k_pe_worklist(long n2, const u32* __restrict__ cnt, const u64* __restrict__ off,
     for (u32 i = 0; i < m; i++) { work_r[o + i] = (u32)r; work_i[o + i] = i; }
 }
 __global__ void __launch_bounds__(256)
-k_filter_pe(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, ReadState st, PeState ps,
+k_filter_pe(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, ReadState st, PeState ps,
             PeCand* __restrict__ A, PeCand* __restrict__ B, const u64* __restrict__ n_work, const u32* __restrict__ work_r,
             const u32* __restrict__ work_i, unsigned long long* __restrict__ counters)
 {
@@ -3816,7 +3870,7 @@ k_filter_pe(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, 
     PeCand* e = pe_list(ps, st, A, B, r) + work_i[g];
     u32 er; int es;
     const int L = gm.rl(r), k = gm.rk(L);
-    bpm_one(ix, seq + (size_t)r * stride, L, k, e->site, er, es);
+    bpm_read(ix, seq, stride, pr, r, L, k, e->site, er, es);
     e->err = er; e->end = es;
     if (counters) atomicAdd(&SHARD(counters)[3], 1ull);
 }
