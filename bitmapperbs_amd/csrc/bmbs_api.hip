@@ -237,7 +237,7 @@ inline u64 sw_trace_slots(u64 n_jobs) { const u64 t = (u64)nblk(n_jobs, 64) * 64
 
 template <int KB>
 void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
-               const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops)
+               const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops, const PackedRows& prw)
 {
     const u64 slots = sw_trace_slots(n_jobs);
     for (u64 base = 0; base < n_jobs; base += slots) {
@@ -245,26 +245,26 @@ void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d
             hipLaunchKernelGGL((k_align_sw<KB, true>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                                d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                                slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
-                               c->a_score.as<int>(), c->a_nops.as<int>());
+                               c->a_score.as<int>(), c->a_nops.as<int>(), prw);
         else
             hipLaunchKernelGGL((k_align_sw<KB, false>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                                d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                                slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
-                               c->a_score.as<int>(), c->a_nops.as<int>());
+                               c->a_score.as<int>(), c->a_nops.as<int>(), prw);
     }
 }
 
 // the packed form: two jobs per lane, so a launch of `slots` threads covers 2 * slots jobs
 template <int KB>
 void launch_sw2(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
-                const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops)
+                const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops, const PackedRows& prw)
 {
     const u64 slots = sw_trace_slots((n_jobs + 1) / 2);
     for (u64 base = 0; base < n_jobs; base += 2 * slots)
         hipLaunchKernelGGL((k_align_sw2<KB>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                            d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                            slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
-                           c->a_score.as<int>(), c->a_nops.as<int>());
+                           c->a_score.as<int>(), c->a_nops.as<int>(), prw);
 }
 
 // K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the
@@ -300,6 +300,7 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
         ENS(c, c->trace, slots * (u64)L * nwords * 8);
     }
     unsigned long long* cnt = c->counters.as<unsigned long long>();
+    const PackedRows prw_ = (pr && pr->base) ? *pr : PackedRows{nullptr, nullptr, 0, 0};
     prof_begin(c, "k_align_ungapped");
     if (pr && pr->base)
         hipLaunchKernelGGL(k_align_ungapped_p, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq, *pr,
@@ -322,7 +323,7 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
         hipLaunchKernelGGL((k_align_sw_wave<LANES>), dim3(nblk(n_jobs, 64 / LANES)), dim3(64), words * 4 * (64 / LANES), c->stream, c->ix, \
                            c->sp, c->pen_lut.as<int>(), d_seq, d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(),   \
                            jobs, rev_from, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),          \
-                           c->a_score.as<int>(), c->a_nops.as<int>())
+                           c->a_score.as<int>(), c->a_nops.as<int>(), prw_)
         if (k <= 7) SWW_LAUNCH(16);
         else if (k <= 15) SWW_LAUNCH(32);
         else SWW_LAUNCH(64);
@@ -331,30 +332,30 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
         return BMBS_OK;
     }
     if (packed) {
-        if (k <= 2) launch_sw2<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 4) launch_sw2<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 6) launch_sw2<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 8) launch_sw2<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 10) launch_sw2<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 12) launch_sw2<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 16) launch_sw2<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 20) launch_sw2<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else if (k <= 24) launch_sw2<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-        else launch_sw2<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+        if (k <= 2) launch_sw2<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 4) launch_sw2<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 6) launch_sw2<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 8) launch_sw2<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 10) launch_sw2<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 12) launch_sw2<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 16) launch_sw2<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 20) launch_sw2<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 24) launch_sw2<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else launch_sw2<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
         prof_end(c);
         return BMBS_OK;
     }
     // the band loop is unrolled for KB: a tighter bound wastes fewer masked cells (k = 6 in a KB = 8 kernel idles 4 of 17)
-    if (k <= 2) launch_sw<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 6) launch_sw<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 10) launch_sw<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
-    else launch_sw<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops);
+    if (k <= 2) launch_sw<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 6) launch_sw<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 10) launch_sw<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else launch_sw<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
     prof_end(c);
     return BMBS_OK;
 }

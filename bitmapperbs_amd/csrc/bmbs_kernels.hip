@@ -349,6 +349,32 @@ struct PCur {
     }
 };
 
+// cursor over a packed row for the alignment kernels: next4() = A0 C1 G2 T3, 4 for a character outside ACGT (code4's values)
+struct PCode {
+    const u64* row; u64 buf; int W, pos, have; bool dirty;
+    DEVI void seek(const u64* r, int W_, bool d) { row = r; W = W_; dirty = d; pos = 0; have = 0; buf = 0; }
+    DEVI int next4()
+    {
+        if (have == 0) { buf = row[pos >> 5]; have = 32; }
+        int c = (int)(buf & 3);
+        buf >>= 2; have--;
+        if (dirty && ((row[W + (pos >> 6)] >> (pos & 63)) & 1)) c = 4;
+        pos++;
+        return c;
+    }
+};
+// positions j < len where read[ts + j] does not match the window base at doubled coordinate d + j (mism8's rule), on a packed row
+DEVI int count_mism_p(const DevIndex& ix, const u64* row, int W, bool dirty, int ts, u64 d, int len)
+{
+    int c = 0;
+    for (int o = 0; o < len; o += 32) {
+        u64 mm = mism_bs(prow_bases32(row, ts + o), gen_bases32(ix, d + (u64)o));
+        if (dirty) mm |= spread32(prow_mask32(row, W, ts + o));
+        c += __popcll(mm & field_range(0, len - o));
+    }
+    return c;
+}
+
 // 16 characters (one 16-byte piece of an ASCII row) -> 32 bits of bases + 16 mask bits; characters at and beyond `valid` count as A.
 // Fast path (every byte one of A C G T, the piece inside the read): a dozen 32-bit ops per four characters.
 DEVI void pack_piece(const uint4& v, int valid, u32& bases, u32& mask)
@@ -2647,7 +2673,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
            const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride, u64 job_base,
            u32* __restrict__ cigar_pool, int max_ops,
            int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
-           int* __restrict__ a_nops)
+           int* __restrict__ a_nops, PackedRows pr)
 {
     constexpr int BW = 2 * KB + 1;          // compile-time bound of the band width
     constexpr int NW = (BW + 15) / 16;      // trace words per row (4 bits per cell)
@@ -2689,12 +2715,15 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     u64* tz = trace + slot;                 // word (i*NWk + q) lives at tz[(i*NWk + q) * trace_stride]
     const int NWk = (band + 15) / 16;
     int h1_last = MINUS_INF;
-    ReadCur rcur; rcur.seek(rd, 0, L);
+    // the read's letters: from the packed row (2 bits per base) when the batch has one, else from the ASCII row
+    const u64* prow = pr.base ? pr.base + (size_t)r * pr.pwords : nullptr;
+    const bool pdirty = pr.base ? pr.dirty[r] != 0 : false;
+    ReadCur rcur; PCode pcur;
+    if (prow) pcur.seek(prow, pr.W, pdirty); else rcur.seek(rd, 0, L);
     ReadCur qcur; if (!rev) qcur.seek(ql, 0, L);
     for (int i = 0; i < tlen; ++i) {
         int f = MINUS_INF, h1 = MINUS_INF;
-        const char a = rcur.next();
-        const int ta = code4(a);
+        const int ta = prow ? pcur.next4() : code4(rcur.next());
         const unsigned char qc = rev ? (unsigned char)ql[L - 1 - i] : (unsigned char)qcur.next();
         const int mis = ta == 4 ? -sp.np : -s_pen[qc];
         u64 tw[NW];
@@ -2811,6 +2840,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     // mismatches of an M run: read [ts, ts + len) against window [qs, qs + len), eight positions per step
     auto m_run = [&](int ts, int qs, int len) -> int {
         if (!wvalid) return len;
+        if (prow) return count_mism_p(ix, prow, pr.W, pdirty, ts, site + (u64)qs, len);
         int c = 0;
         for (int o = 0; o < len; o += 8) c += mism_span(ix, rd, ts + o, site + (u64)(qs + o), len - o < 8 ? len - o : 8);
         return c;
@@ -2868,7 +2898,7 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
             const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u64* __restrict__ trace, u64 trace_stride, u64 job_base,
             u32* __restrict__ cigar_pool, int max_ops,
             int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
-            int* __restrict__ a_nops)
+            int* __restrict__ a_nops, PackedRows pr)
 {
     constexpr int BW = 2 * KB + 1;          // compile-time bound of the band width
     constexpr int NW = (BW + 15) / 16;      // window words per job (4 bits per base)
@@ -2915,16 +2945,23 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
     }
     u64* tz = trace + slot;                 // word (i*NTk + q) lives at tz[(i*NTk + q) * trace_stride]
     ReadCur rcur[2], qcur[2];
+    PCode pcur[2];
+    const bool packed_in = pr.base != nullptr;
+    const u64* prowv[2] = {nullptr, nullptr};
+    bool pdirtyv[2] = {false, false};
 #pragma unroll
-    for (int j = 0; j < 2; j++) { rcur[j].seek(rdv[j], 0, L); if (!revv[j]) qcur[j].seek(qlv[j], 0, L); }
+    for (int j = 0; j < 2; j++) {
+        if (packed_in) { prowv[j] = pr.base + (size_t)rv[j] * pr.pwords; pdirtyv[j] = pr.dirty[rv[j]] != 0; pcur[j].seek(prowv[j], pr.W, pdirtyv[j]); }
+        else rcur[j].seek(rdv[j], 0, L);
+        if (!revv[j]) qcur[j].seek(qlv[j], 0, L);
+    }
     for (int i = 0; i < tlen; ++i) {
         // per-row, per-job: mismatch penalty and the match bits of the whole band
         int mis[2];
         u64 Y[2][NW];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const char a = rcur[j].next();
-            const int ta = code4(a);
+            const int ta = packed_in ? pcur[j].next4() : code4(rcur[j].next());
             const unsigned char qc = revv[j] ? (unsigned char)qlv[j][L - 1 - i] : (unsigned char)qcur[j].next();
             mis[j] = (ta == 4 || !wval[j]) ? -sp.np : -s_pen[qc];
             const u64 racc = (u64)((0x0A421u >> (4 * ta)) & 15u) * 0x1111111111111111ull;      // read A C G T N accepts {A} {C} {G} {T,C} {}
@@ -3063,6 +3100,7 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
         const int cigar_e = ii;
         auto m_run = [&](int ts, int qs, int len) -> int {
             if (!wvalid) return len;
+            if (packed_in) return count_mism_p(ix, prowv[j], pr.W, pdirtyv[j], ts, site + (u64)qs, len);
             int c = 0;
             for (int o = 0; o < len; o += 8) c += mism_span(ix, rd, ts + o, site + (u64)(qs + o), len - o < 8 ? len - o : 8);
             return c;
@@ -3138,7 +3176,7 @@ k_align_sw_wave(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, co
                 const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
                 const u32* __restrict__ sw_job, Jobs jb_, u32 rev_qual_from, u32* __restrict__ cigar_pool, int max_ops,
                 int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
-                int* __restrict__ a_nops)
+                int* __restrict__ a_nops, PackedRows pr)
 {
     extern __shared__ u32 sww_lds[];
     constexpr int JPB = 64 / LANES;
@@ -3168,7 +3206,12 @@ k_align_sw_wave(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, co
     for (int i = b; i < ((L + 3) & ~3); i += LANES) {
         u16 v = 4;
         if (i < L) {
-            const int ta = code4(rd[i]);
+            int ta;
+            if (pr.base) {
+                const u64* prow = pr.base + (size_t)r * pr.pwords;
+                ta = (int)((prow[i >> 5] >> (2 * (i & 31))) & 3);
+                if (pr.dirty[r] && ((prow[pr.W + (i >> 6)] >> (i & 63)) & 1)) ta = 4;
+            } else ta = code4(rd[i]);
             const unsigned char qc = (unsigned char)ql[rev ? L - 1 - i : i];
             const int pen = ta == 4 ? sp.np : pen_lut[qc];
             v = (u16)(ta | (pen << 3));
@@ -3274,6 +3317,7 @@ k_align_sw_wave(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, co
     // NM recount under bisulfite matching + ops in SAM order (ksw.cpp:2779-2857); a window never holds 'N'
     auto m_run = [&](int ts, int qs, int len) -> int {
         if (!wvalid) return len;
+        if (pr.base) return count_mism_p(ix, pr.base + (size_t)r * pr.pwords, pr.W, pr.dirty[r] != 0, ts, site + (u64)qs, len);
         int c = 0;
         for (int o = 0; o < len; o += 8) c += mism_span(ix, rd, ts + o, site + (u64)(qs + o), len - o < 8 ? len - o : 8);
         return c;
