@@ -908,9 +908,20 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
             HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n2 + 64, c->stream));
             prow = c->prow.as<u64>(); pdirty = c->prow_dirty.as<u32>(); prepacked = true;
         }
+        // fast mode on packed rows: nothing reads the ASCII rows except under a set bit of the mask plane, so only those
+        // pieces are written (BMBS_PE_ASCII=full keeps the complete copy; --sensitive re-seeds on the ASCII rows and needs it)
+        static const bool full_ascii = [] { const char* e = getenv("BMBS_PE_ASCII"); return e && !strcmp(e, "full"); }();
+        const int sparse = prow && !c->prm.sensitive && !full_ascii;
         prof_begin(c, "k_pe_prepare");
+        const int ppr = stride / 16;
+        if (sparse && ppr <= 256) {
+            const int rpb = 256 / ppr;
+            hipLaunchKernelGGL(k_pe_prepare_p, dim3(nblk(n, rpb)), dim3(256), (size_t)rpb * (ppr + 1) * 8, c->stream,
+                               reinterpret_cast<const char*>(d_seq1), reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all, prow,
+                               pwords, W, pdirty);
+        } else
         hipLaunchKernelGGL(k_pe_prepare, dim3(nblk(n * (stride / 16), 256)), dim3(256), 0, c->stream, reinterpret_cast<const char*>(d_seq1),
-                           reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all, prow, pwords, W, pdirty);
+                           reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all, prow, pwords, W, pdirty, sparse);
         prof_end(c);
     }
     ReadState st = read_state(c);

@@ -952,6 +952,15 @@ DEVI int seed_offset_unmatch(int L, int pre, const char* rd, int step)
     for (int i = 0; i < step; i++, pre++) if (rd[pre] == 'N') return pre + 1;
     return ret;
 }
+// ... on packed rows: `mask` is the not-ACGT bit plane of the row; the ASCII row is asked only where a bit is set (the
+// paired-end rows keep their ASCII text only in the 16-byte pieces that hold such a character, k_pe_prepare)
+DEVI int seed_offset_unmatch_p(int L, int pre, const char* rd, int step, const u64* mask)
+{
+    if (L - pre < 18 || L - pre < step) return L;
+    const int ret = pre + step;
+    for (int i = 0; i < step; i++, pre++) if (((mask[pre >> 6] >> (pre & 63)) & 1) && rd[pre] == 'N') return pre + 1;
+    return ret;
+}
 
 // per-read state carried between the seeding kernels
 struct SeedCarry {
@@ -1337,7 +1346,7 @@ k_seed_decide_p(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGe
                 else if (ml >= (u64)seed_len && hits <= max_hits) { if (hits != 0) { seed_record(my, ns, ncand, sp, hits, ml, (u64)tm); clen += hits; } }
                 if (ml == 0) {
                     if (!dirty) tm = (L - tm < 18) ? L : tm + 8;
-                    else tm = seed_offset_unmatch(L, tm, seq + (size_t)r * stride, 8);
+                    else tm = seed_offset_unmatch_p(L, tm, seq + (size_t)r * stride, 8, row + W);
                 } else tm = tm + (int)(ml / 2);
                 seed_id++;
             }
@@ -1554,7 +1563,8 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
         if (ml == 0) {
             // only a read with a character outside ACGT can hold the 'N' determine_seed_offset_unmatch looks for
             if (PACKED && !dirty) tm = (L - tm < 18) ? L : tm + 8;
-            else tm = seed_offset_unmatch(L, tm, PACKED ? seq + (size_t)r * stride : rd, 8);
+            else if constexpr (PACKED) tm = seed_offset_unmatch_p(L, tm, seq + (size_t)r * stride, 8, prow + pr.W);
+            else tm = seed_offset_unmatch(L, tm, rd, 8);
         } else tm = tm + (int)(ml / 2);
         seed_id++;
         return true;
@@ -3495,8 +3505,11 @@ struct PeState {
 // mate 2: reverse complement of the FASTQ read (rc_table, Process_Reads.cpp:1603-1613: identity for non-ACGT)
 __global__ void __launch_bounds__(256)
 k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all,
-             u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32)
+             u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32, int sparse_ascii)
 {
+    // sparse_ascii (the packed rows are what every later kernel reads): the ASCII text of a 16-byte piece is stored only
+    // when the piece holds a character outside ACGT -- the only places the ASCII rows are asked then (is it 'N'?) sit
+    // under a set bit of the mask plane, so the other 99.9 % of the 2 x n x stride bytes are never written
     // one 16-byte piece per thread (rows are 16-byte aligned, stride % 16 == 0)
     const long i16 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total16 = n * (stride / 16);
@@ -3507,9 +3520,9 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGe
     const int j0 = (int)(i - r * stride);
     const int L = gm.rl(n + r);                    // mate 2 of pair r
     const uint4 v1 = reinterpret_cast<const uint4*>(s1)[i16];
-    reinterpret_cast<uint4*>(seq_all)[i16] = v1;                                              // the qualities stay where they are (qual_row)
+    if (!sparse_ascii) reinterpret_cast<uint4*>(seq_all)[i16] = v1;                           // the qualities stay where they are (qual_row)
     // the packed copy of both rows (what k_pack_rows would write), from the pieces this thread holds anyway
-    auto pack_out = [&](const uint4& pv, long row_id, int Lr) {
+    auto pack_out = [&](const uint4& pv, long row_id, int Lr, uint4* ascii) {
         const int piece = j0 / 16;
         if (!prow || piece * 16 >= ((Lr + 63) & ~63)) return;
         u32 bases, mask;
@@ -3517,9 +3530,12 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGe
         u64* row = prow + (size_t)row_id * pwords;
         if (piece * 16 < ((Lr + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = bases;
         reinterpret_cast<u16*>(row + W)[piece] = (u16)mask;
-        if (mask) atomicOr(&dirty32[row_id >> 2], 1u << (8 * (int)(row_id & 3)));
+        if (mask) {
+            atomicOr(&dirty32[row_id >> 2], 1u << (8 * (int)(row_id & 3)));
+            if (sparse_ascii) *ascii = pv;
+        }
     };
-    pack_out(v1, r, gm.rl(r));
+    pack_out(v1, r, gm.rl(r), reinterpret_cast<uint4*>(seq_all) + i16);
     // out[j] = complement(in[L-1-j]) for j < L, 0 beyond: one reversed 16-byte piece per thread.  complement = c ^ 0x15 for
     // A/T, c ^ 0x04 for C/G, identity otherwise (rc_table), eight characters per step.
     auto comp8 = [](u64 w) -> u64 {
@@ -3550,8 +3566,89 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGe
         v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
         v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
     }
-    reinterpret_cast<uint4*>(seq_all + total)[i16] = v;
-    pack_out(v, n + r, L);
+    if (!sparse_ascii) reinterpret_cast<uint4*>(seq_all + total)[i16] = v;
+    pack_out(v, n + r, L, reinterpret_cast<uint4*>(seq_all + total) + i16);
+}
+
+// k_pe_prepare for the packed fast path (sparse ASCII): mate 2 is packed FORWARD first (one aligned 16-byte piece per thread,
+// the same SWAR as mate 1), parked in LDS, and the reverse complement is then taken on the packed words -- a 32-bit funnel
+// window of the forward row, complemented under its valid-base mask and reversed by 2-bit groups.  The byte-wise complement
+// + byte swap of the ASCII form cost ~2.5x the instructions of everything else in the kernel, which was VALU-bound.
+// A block takes 256 / (stride / 16) whole pairs; only a piece that holds a character outside ACGT rebuilds its ASCII text.
+__global__ void __launch_bounds__(256)
+k_pe_prepare_p(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all,
+               u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32)
+{
+    extern __shared__ u32 lds_pp[];
+    const int ppr = stride / 16, rpb = 256 / ppr;
+    u32* lb = lds_pp;                                   // [rpb][ppr + 1] forward base words (+ one zero word)
+    u32* lm = lds_pp + rpb * (ppr + 1);                 // [rpb][ppr + 1] forward mask pieces (16 bits each, + one zero)
+    const int tid = threadIdx.x, rl = tid / ppr, piece = tid - rl * ppr;
+    const long r = (long)blockIdx.x * rpb + rl;
+    const bool on = rl < rpb && r < n;
+    const long total = n * stride;
+    int L2 = 0;
+    if (on) {
+        const size_t i16 = (size_t)r * ppr + piece;
+        const int L1 = gm.rl(r);
+        L2 = gm.rl(n + r);
+        const uint4 v1 = reinterpret_cast<const uint4*>(s1)[i16];
+        const uint4 v2 = reinterpret_cast<const uint4*>(s2raw)[i16];
+        u32 b1, m1, b2, m2;
+        pack_piece(v1, L1 - piece * 16, b1, m1);
+        pack_piece(v2, L2 - piece * 16, b2, m2);
+        lb[rl * (ppr + 1) + piece] = b2; lm[rl * (ppr + 1) + piece] = m2;
+        if (piece == 0) { lb[rl * (ppr + 1) + ppr] = 0; lm[rl * (ppr + 1) + ppr] = 0; }
+        if (piece * 16 < ((L1 + 63) & ~63)) {
+            u64* row = prow + (size_t)r * pwords;
+            if (piece * 16 < ((L1 + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = b1;
+            reinterpret_cast<u16*>(row + W)[piece] = (u16)m1;
+            if (m1) { atomicOr(&dirty32[r >> 2], 1u << (8 * (int)(r & 3))); reinterpret_cast<uint4*>(seq_all)[i16] = v1; }
+        }
+    }
+    __syncthreads();
+    if (!on || piece * 16 >= ((L2 + 63) & ~63)) return;
+    const int j0 = piece * 16, lo = L2 - 16 - j0;       // forward positions lo .. lo+15, reversed, are rc positions j0 .. j0+15
+    const u32* fb = lb + rl * (ppr + 1); const u32* fm = lm + rl * (ppr + 1);
+    u32 win, bad, inr;
+    if (lo >= 0) {
+        const int idx = lo >> 4, sh = lo & 15;
+        win = sh ? (fb[idx] >> (2 * sh)) | (fb[idx + 1] << (32 - 2 * sh)) : fb[idx];
+        bad = ((fm[idx] | (fm[idx + 1] << 16)) >> sh) & 0xffffu;
+        inr = 0xffffu;
+    } else if (lo > -16) {
+        win = fb[0] << (2 * -lo);
+        bad = (fm[0] << -lo) & 0xffffu;
+        inr = (0xffffu << -lo) & 0xffffu;
+    } else { win = 0; bad = 0; inr = 0; }
+    u32 x = inr & ~bad;                                 // real bases of the window -> both bits of their pair
+    x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    win ^= x | (x << 1);                                // complement: code -> 3 - code
+    u32 rv = __brev(win);
+    rv = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
+    const u32 om = __brev(bad & inr) >> 16;
+    const long row_id = n + r;
+    u64* row = prow + (size_t)row_id * pwords;
+    if (j0 < ((L2 + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = rv;
+    reinterpret_cast<u16*>(row + W)[piece] = (u16)om;
+    if (om) {
+        atomicOr(&dirty32[row_id >> 2], 1u << (8 * (int)(row_id & 3)));
+        const char* src = s2raw + r * stride;
+        unsigned char o[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int j = j0 + t;
+            char c = 0;
+            if (j < L2) { const char a = src[L2 - 1 - j]; c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a; }
+            o[t] = (unsigned char)c;
+        }
+        uint4 v;
+        v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
+        v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
+        v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
+        v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
+        reinterpret_cast<uint4*>(seq_all + total)[(size_t)r * ppr + piece] = v;
+    }
 }
 
 // ---- FASTQ text -> read rows (bmbs_map_*_fastq) --------------------------------------------------------------------------------

@@ -747,6 +747,38 @@ def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive, rows):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["sparse", "full"])
+@pytest.mark.parametrize("L", [40, 101, 150, 251])
+def test_pe_prepare_forms_on_odd_lengths(env, monkeypatch, L, form):
+    """k_pe_prepare_p (the fast-mode default: mate 2 reverse-complemented on the packed words, ASCII text kept only for the
+    16-byte pieces that hold a character outside ACGT) against the byte-wise form (BMBS_PE_ASCII=full): fixed lengths that are
+    and are not multiples of 16 / 32 / 64, then mates trimmed independently, with 'N' and other letters in both mates"""
+    from bitmapperbs_amd import synth, mapper
+    if form == "full":
+        monkeypatch.setenv("BMBS_PE_ASCII", "full")
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=6000, L=L, seed=900 + L, sub=0.02, indel=0.002, qual="random", ins_hi=max(500, 2 * L + 50))
+    rng = np.random.default_rng(L)
+    for mm in (m1, m2):
+        pos = rng.random(mm["seq"].shape) < 0.004
+        mm["seq"][pos] = np.frombuffer(b"NNNRY", dtype=np.uint8)[rng.integers(0, 5, int(pos.sum()))]
+    m = mapper.Mapper(env["ix"], 0)
+    res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+    recs, ost, _ = env["oix"].map_pe(orc.params(), m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+    assert (recs["status"] == 1).sum() > 2000
+    assert not compare_pe(res, pool, recs, L)
+    assert (m.stats() == ost).all()
+    l1 = rng.integers(max(20, L // 3), L + 1, 6000).astype(np.uint16); l2 = rng.integers(max(20, L // 3), L + 1, 6000).astype(np.uint16)
+    l1[:500] = L; l2[:500] = L
+    s1, q1, s2, q2 = _trim(m1["seq"], l1), _trim(m1["qual"], l1), _trim(m2["seq"], l2), _trim(m2["qual"], l2)
+    m.reset_stats() if hasattr(m, "reset_stats") else None
+    res, pool = m.map_pe_var(s1, q1, s2, q2, l1, l2)
+    recs, _, _ = env["oix"].map_pe_var(orc.params(), s1, q1, s2, q2, l1, l2)
+    bad = compare_pe(res, pool, recs, l1, l2)
+    assert not bad, bad[:5]
+    m.close()
+
+
+@pytest.mark.gpu
 def test_shared_index_contexts_map_concurrently(env):
     """bmbs_index_share: three contexts on one attached index, driven by three host threads at once, give the oracle's records"""
     from concurrent.futures import ThreadPoolExecutor
