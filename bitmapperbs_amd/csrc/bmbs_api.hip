@@ -48,6 +48,7 @@ struct bmbs_ctx {
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d, in_len;
     DevBuf pe_mid_flag, pe_mid_list;                    // k_vote_pe_mid work list
+    DevBuf wavelog_buf, wavelog_count; std::string wavelog_path;    // BMBS_WAVELOG diagnostic
     DevBuf prow, prow_dirty;                            // packed copy of the read rows (k_pack_rows), one dirty byte per read
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // paired-end workspace
@@ -235,19 +236,23 @@ ReadState read_state(bmbs_ctx* c)
 // trace slots of the register-band DP kernel: one per launched thread (<= 1 M: 16 k waves fill the chip several times over)
 inline u64 sw_trace_slots(u64 n_jobs) { const u64 t = (u64)nblk(n_jobs, 64) * 64; return t < (1ull << 20) ? t : (1ull << 20); }
 
+// LDS of the register-band DP kernels: the window words of every lane's alignment(s) (LdsWin)
+inline size_t sw_window_lds(const ReadGeom& gm, int jobs_per_lane) { return (size_t)jobs_per_lane * ((gm.L + 2 * gm.k + 62) / 32 + 1) * 64 * 8; }
+
 template <int KB>
 void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
                const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops, const PackedRows& prw)
 {
     const u64 slots = sw_trace_slots(n_jobs);
+    const size_t lds = sw_window_lds(gm, 1);
     for (u64 base = 0; base < n_jobs; base += slots) {
         if (!gm.len)
-            hipLaunchKernelGGL((k_align_sw<KB, true>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+            hipLaunchKernelGGL((gm.k == KB ? k_align_sw<KB, true, true> : k_align_sw<KB, true, false>), dim3((unsigned)(slots / 64)), dim3(64), lds, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                                d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                                slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                                c->a_score.as<int>(), c->a_nops.as<int>(), prw);
         else
-            hipLaunchKernelGGL((k_align_sw<KB, false>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+            hipLaunchKernelGGL((k_align_sw<KB, false>), dim3((unsigned)(slots / 64)), dim3(64), lds, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                                d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                                slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                                c->a_score.as<int>(), c->a_nops.as<int>(), prw);
@@ -260,8 +265,9 @@ void launch_sw2(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* 
                 const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops, const PackedRows& prw)
 {
     const u64 slots = sw_trace_slots((n_jobs + 1) / 2);
+    auto kern = !prw.base ? k_align_sw2<KB, false, false> : gm.k == KB ? k_align_sw2<KB, true, true> : k_align_sw2<KB, false, true>;
     for (u64 base = 0; base < n_jobs; base += 2 * slots)
-        hipLaunchKernelGGL((k_align_sw2<KB>), dim3((unsigned)(slots / 64)), dim3(64), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(slots / 64)), dim3(64), sw_window_lds(gm, 2), c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
                            d_qual, d_qual2, gm, stride, c->totals.as<u64>() + 2, c->sw_job.as<u32>(), jobs, rev_from, c->trace.as<u64>(),
                            slots, base, d_cigar_pool, max_ops, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                            c->a_score.as<int>(), c->a_nops.as<int>(), prw);
@@ -583,6 +589,15 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
     (void)hipMemset(c->stats.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
     (void)hipMemset(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
+    // diagnostic: per-wave timeline of the kernels that call wavelog_begin/_end (one context at a time; tools/wavelog.py)
+    if (const char* wl = getenv("BMBS_WAVELOG")) {
+        const unsigned cap = 1u << 21;
+        if (*wl && !ensure(c, c->wavelog_buf, (u64)cap * 32) && !ensure(c, c->wavelog_count, 64)) {
+            (void)hipMemset(c->wavelog_count.p, 0, 64);
+            WaveLogDev d = {c->wavelog_buf.as<unsigned long long>(), c->wavelog_count.as<unsigned int>(), cap};
+            if (hipMemcpyToSymbol(HIP_SYMBOL(g_wavelog), &d, sizeof(d)) == hipSuccess) c->wavelog_path = wl;
+        }
+    }
     return c;
 }
 
@@ -590,6 +605,18 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
+    if (!c->wavelog_path.empty()) {
+        (void)hipDeviceSynchronize();
+        unsigned cnt = 0;
+        (void)hipMemcpy(&cnt, c->wavelog_count.p, 4, hipMemcpyDeviceToHost);
+        if (cnt > (1u << 21)) cnt = 1u << 21;
+        std::vector<unsigned long long> h((size_t)cnt * 4);
+        if (cnt) (void)hipMemcpy(h.data(), c->wavelog_buf.p, (size_t)cnt * 32, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(c->wavelog_path.c_str(), "wb")) { fwrite(h.data(), 32, cnt, f); fclose(f); }
+        WaveLogDev d = {nullptr, nullptr, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wavelog), &d, sizeof(d));
+        release(c->wavelog_buf); release(c->wavelog_count);
+    }
     DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->occ_super, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,

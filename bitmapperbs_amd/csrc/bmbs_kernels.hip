@@ -27,6 +27,33 @@
 #define BMBS_SHARD_WORDS 32
 #define SHARD(p) ((p) + (size_t)(blockIdx.x & (BMBS_SHARDS - 1)) * BMBS_SHARD_WORDS)
 
+// ---- per-wave timeline (diagnostic, BMBS_WAVELOG=<file>) ------------------------------------------------------------------------
+// A kernel that calls wavelog_begin / wavelog_end records for each of its working waves where it ran (XCC, SE, CU, SIMD), when
+// (100 MHz wall clock) and for how many shader cycles: 4 u64 per wave, dumped by bmbs_destroy and read by tools/wavelog.py.
+// That is the only way to see occupancy rounds, dispatch imbalance and the actual shader clock of one kernel; with the variable
+// unset g_wavelog.buf is null and the cost is one scalar load per wave.
+struct WaveLogDev { unsigned long long* buf; unsigned int* count; unsigned int cap; };
+__device__ WaveLogDev g_wavelog;
+struct WaveLogT { u64 wall, cyc; bool on; };
+DEVI WaveLogT wavelog_begin()
+{
+    WaveLogT t; t.on = g_wavelog.buf != nullptr; t.wall = 0; t.cyc = 0;
+    if (t.on) { t.wall = wall_clock64(); t.cyc = __builtin_readcyclecounter(); }
+    return t;
+}
+DEVI void wavelog_end(const WaveLogT& t, int kernel_id)
+{
+    if (!t.on) return;
+    const u64 w1 = wall_clock64(), c1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) != 0) return;
+    const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    const u32 idx = atomicAdd(g_wavelog.count, 1u);
+    if (idx >= g_wavelog.cap) return;
+    unsigned long long* o = g_wavelog.buf + (size_t)idx * 4;
+    o[0] = ((u64)kernel_id << 56) | ((u64)(xcc & 0xffu) << 32) | hw;
+    o[1] = t.wall; o[2] = w1; o[3] = c1 - t.cyc;
+}
+
 // ================================================================================================
 // index primitives
 // ================================================================================================
@@ -139,6 +166,48 @@ struct WinReader {
         w >>= 2; pos++; left--;
         if (left == 0) { w = nxt; nxt = g[(pos >> 5) + 1]; left = 32; }      // gen2 carries two spare words at its end
         return b;
+    }
+};
+
+// The window of one banded alignment, staged in LDS (the DP kernels).  WinReader's prefetch does not survive the compiler: the
+// reload sits in a branch that some lane of the wave takes in nearly every row (each lane has its own phase, start & 31), and
+// the s_waitcnt for the loaded word is placed at the join right behind the load -- one exposed HBM latency per row, 53 % of
+// the wave cycles of k_align_sw2 (SQ_WAIT_ANY).  Here the lane copies the (L + 2k) / 32 + 2 words of its window to LDS once,
+// all loads in flight together, and a reload is a ds_read (lgkmcnt, ~100 cycles, independent of the trace stores' vmcnt).
+// Word m of lane l lives at base[m * 64 + l]: consecutive lanes, consecutive banks.
+struct LdsWin {
+    const u64* p; u64 w; int left; bool valid;
+    DEVI void init(const DevIndex& ix, u64 start, bool v, u64* lane_base, int nww)       // nww = (window length + 62) / 32
+    {
+        valid = v; w = 0; left = 32; p = lane_base;
+        if (!v) return;
+        const u64* g = ix.gen2 + (start >> 5);
+#pragma unroll 4
+        for (int m = 0; m < nww; m++) lane_base[m * 64] = g[m];                         // gen2 carries two spare words at its end
+        const int off = (int)(start & 31);
+        w = lane_base[0] >> (2 * off); left = 32 - off; p = lane_base + 64;
+    }
+    DEVI int next()
+    {
+        if (!valid) return 4;
+        const int b = (int)(w & 3);
+        w >>= 2;
+        if (--left == 0) { w = *p; p += 64; left = 32; }
+        return b;
+    }
+};
+// bytes of a 16-byte aligned row from position p downwards (the qualities of a reverse-strand read), 16 per global load
+struct RevCur {
+    const char* rd; u64 lo, hi; int pos;
+    DEVI void load(int at) { const uint4 v = *reinterpret_cast<const uint4*>(rd + at); lo = ((u64)v.y << 32) | v.x; hi = ((u64)v.w << 32) | v.z; }
+    DEVI void seek(const char* r, int p) { rd = r; pos = p; lo = 0; hi = 0; if (p >= 0) load(p & ~15); }
+    DEVI unsigned char next()
+    {
+        const int o = pos & 15;
+        const unsigned char c = (unsigned char)(((o & 8) ? hi : lo) >> (8 * (o & 7)));
+        pos--;
+        if (o == 0 && pos >= 0) load(pos & ~15);
+        return c;
     }
 };
 
@@ -984,16 +1053,21 @@ DEVI void seed_finish(const ReadState& st, long r, int verdict, int ns, u64 ncan
     st.n_cand[r] = verdict == 3 ? (u32)ncand : (pe_mode ? (verdict == 4 ? (u32)ncand : (verdict == 1 || verdict == 2) ? 1u : 0u) : 0u);
 }
 
+#define SEED_BATCH 16             // pending lanes that trigger a transition batch
 #define SEED_CHUNK 256            // items per wave (upper bound)
 #define SEED_CHUNK_MIN 64
 // items per wave for a work list of `total` items: enough waves to fill the chip a few times over (the second / extra
-// lists hold 10-30 % of the batch; with 256-item chunks they gave fewer waves than the 8192 wave slots of the chip)
+// lists hold 10-30 % of the batch; with 256-item chunks they gave fewer waves than the 8192 wave slots of the chip).
+// (Measured and rejected, round 2: persistent waves -- exactly as many as the chip holds -- walking the list in strided 64-item
+// chunks.  The per-wave timeline (BMBS_WAVELOG) then shows every wave slot occupied from start to end instead of 70-87 %, and
+// the kernels get SLOWER (k_seed_first 1.95 -> 2.40 ms, k_seed_extra 3.73 -> 3.85 ms): the engine is bound by the request rate of
+// the memory system, not by resident waves, and the long-lived waves end 20 % apart.  Chunks from a global atomic counter balance
+// perfectly and cost 4.5x: ~60 k returning device-scope atomics on one word take several ms on this chip.)
 DEVI long seed_chunk(long total, int target_waves)
 {
     long c = (total + target_waves - 1) / target_waves;
     return c < SEED_CHUNK_MIN ? SEED_CHUNK_MIN : (c > SEED_CHUNK ? SEED_CHUNK : c);
 }
-#define SEED_BATCH 16             // pending lanes that trigger a transition batch
 
 struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung; };
 // totals in counters[0,1,2,5]; per-kernel copies in counters[16 + 4*kid ..] (kid 0 first, 1 second, 2 extra)
@@ -1032,6 +1106,7 @@ __global__ void __launch_bounds__(64)
 k_seed_first(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, SeedCarry sc,
              unsigned long long* __restrict__ counters)
 {
+    const WaveLogT wl_t = wavelog_begin();
     int L = gm.L;                                     // length of the lane's current read
     const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
     const long chunk_end = chunk_begin + SEED_CHUNK < n ? chunk_begin + SEED_CHUNK : n;
@@ -1076,6 +1151,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
         }
     }
     flush_counters(counters, lc, 0);
+    wavelog_end(wl_t, 3);
 }
 
 // ---- exits after the first seed (Schema.cpp:24599-24727 / 18225-18330) ---------------------------
@@ -1384,6 +1460,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
+    const WaveLogT wl_t = wavelog_begin();
     const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
     LaneCounters lc = {0, 0, 0, 0};
@@ -1516,6 +1593,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
         }
     }
     flush_counters(counters, lc, 1);
+    wavelog_end(wl_t, 4);
 }
 
 // ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
@@ -1530,6 +1608,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
+    const WaveLogT wl_t = wavelog_begin();
     const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
     LaneCounters lc = {0, 0, 0, 0};
@@ -1632,6 +1711,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
         }
     }
     flush_counters(counters, lc, 2);
+    wavelog_end(wl_t, 5);
 }
 
 // ================================================================================================
@@ -2676,7 +2756,8 @@ k_align_ungapped_p(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut,
 
 // UNIFORM: all reads of the launch have one length, so k is a kernel argument (a scalar register) and the band tests of the
 // unrolled loop are scalar branches; with per-read lengths they are per-lane and cost an exec-mask save/restore per cell.
-template <int KB, bool UNIFORM>
+// EXACT (with UNIFORM): k == KB, the band width is a compile-time constant (see k_align_sw2).
+template <int KB, bool UNIFORM, bool EXACT = false>
 __global__ void __launch_bounds__(64)
 k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
            const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
@@ -2699,6 +2780,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     for (int q = threadIdx.x; q < 256; q += 64) s_pen[q] = pen_lut[q];
     __syncthreads();
     if (t >= *n_sw_ptr) return;
+    const WaveLogT wl_t = wavelog_begin();
     const u64 jb = sw_job[t];
     const u32 r = jb_.read[jb];
     const u64 site = jb_.site[jb];
@@ -2706,7 +2788,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     const char* ql = qual_row(qual, qual2, rev_qual_from, r, stride);
     const bool rev = r >= rev_qual_from;
     const bool fwd = site < ix.G;
-    const int L = UNIFORM ? gm.L : gm.rl(r), k = UNIFORM ? gm.k : gm.rk(L);          // k <= KB: the unrolled band is masked to the job's own width
+    const int L = UNIFORM ? gm.L : gm.rl(r), k = EXACT ? KB : UNIFORM ? gm.k : gm.rk(L);          // k <= KB: the unrolled band is masked to the job's own width
     const int band = 2 * k + 1;
     const int p_len = L + 2 * k, tlen = L;
     const bool wvalid = window_valid(ix, site, (u64)p_len, fwd);
@@ -2720,7 +2802,8 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     u64 wq[(BW + 15) / 16];
 #pragma unroll
     for (int q = 0; q < NW; q++) wq[q] = 0;
-    WinReader wr; wr.init(ix, site, wvalid);
+    extern __shared__ u64 lds_win[];        // [(gm.L + 2 gm.k + 62) / 32 + 1][64]: sized for the longest read of the batch
+    LdsWin wr; wr.init(ix, site, wvalid, lds_win + threadIdx.x, (p_len + 62) / 32);
     for (int b = 0; b < band; b++) { const u64 v = (u64)wr.next(); wq[b >> 4] |= v << (4 * (b & 15)); }
     u64* tz = trace + slot;                 // word (i*NWk + q) lives at tz[(i*NWk + q) * trace_stride]
     const int NWk = (band + 15) / 16;
@@ -2730,13 +2813,29 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     const bool pdirty = pr.base ? pr.dirty[r] != 0 : false;
     ReadCur rcur; PCode pcur;
     if (prow) pcur.seek(prow, pr.W, pdirty); else rcur.seek(rd, 0, L);
-    ReadCur qcur; if (!rev) qcur.seek(ql, 0, L);
+    ReadCur qcur; RevCur qrev;
+    if (!rev) qcur.seek(ql, 0, L); else qrev.seek(ql, L - 1);
+    // the trace words of a row are stored one row later, after the next row's loads (see k_align_sw2)
+    u64 tw[NW];
+#pragma unroll
+    for (int q = 0; q < NW; q++) tw[q] = 0;
     for (int i = 0; i < tlen; ++i) {
         int f = MINUS_INF, h1 = MINUS_INF;
+        if (i > 0) {
+            // slide the window one base
+#pragma unroll
+            for (int q = 0; q < NW; q++) { wq[q] >>= 4; if (q + 1 < NW) wq[q] |= (wq[q + 1] & 15) << 60; }
+            const u64 v = (u64)wr.next();
+#pragma unroll
+            for (int q = 0; q < NW; q++) if (q == ((band - 1) >> 4)) wq[q] |= v << (4 * ((band - 1) & 15));
+        }
         const int ta = prow ? pcur.next4() : code4(rcur.next());
-        const unsigned char qc = rev ? (unsigned char)ql[L - 1 - i] : (unsigned char)qcur.next();
+        const unsigned char qc = rev ? qrev.next() : (unsigned char)qcur.next();
         const int mis = ta == 4 ? -sp.np : -s_pen[qc];
-        u64 tw[NW];
+        if (i > 0) {
+#pragma unroll
+            for (int q = 0; q < NW; q++) if (q < NWk) tz[((u64)(i - 1) * NWk + q) * trace_stride] = tw[q];
+        }
 #pragma unroll
         for (int q = 0; q < NW; q++) tw[q] = 0;
 #pragma unroll
@@ -2766,16 +2865,10 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
 #pragma unroll
         for (int b = 0; b <= BW; b++) if (b == band - 1) { RH[b] = h1; RE[b] = MINUS_INF; }
         h1_last = h1;
+    }
+    if (tlen > 0) {
 #pragma unroll
-        for (int q = 0; q < NW; q++) if (q < NWk) tz[((u64)i * NWk + q) * trace_stride] = tw[q];
-        // slide the window one base
-#pragma unroll
-        for (int q = 0; q < NW; q++) { wq[q] >>= 4; if (q + 1 < NW) wq[q] |= (wq[q + 1] & 15) << 60; }
-        if (i + 1 < tlen) {
-            const u64 v = (u64)wr.next();
-#pragma unroll
-            for (int q = 0; q < NW; q++) if (q == ((band - 1) >> 4)) wq[q] |= v << (4 * ((band - 1) & 15));
-        }
+        for (int q = 0; q < NW; q++) if (q < NWk) tz[((u64)(tlen - 1) * NWk + q) * trace_stride] = tw[q];
     }
     (void)h1_last;
     // score: un-gapped diagonal wins ties, then the highest column (ksw.cpp:2001-2010)
@@ -2879,6 +2972,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
         }
     }
     a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
+    wavelog_end(wl_t, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2901,7 +2995,10 @@ DEVI int pk_lo(u32 x) { return (int)(short)(x & 0xffffu); }
 DEVI int pk_hi(u32 x) { return (int)x >> 16; }
 #define SW2_MINF (-16000)
 
-template <int KB>
+// EXACT: the batch's threshold k equals KB, so the band width is a compile-time constant and every "is this cell inside the
+// band" select / branch of the unrolled row disappears (the usual case: KB is instantiated for the thresholds the default -e
+// values give).  PACKED: the read letters come from the packed rows (the product path; ASCII rows only with BMBS_ROWS=ascii).
+template <int KB, bool EXACT = false, bool PACKED = true>
 __global__ void __launch_bounds__(64)
 k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
             const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, const u64* __restrict__ n_sw_ptr,
@@ -2921,8 +3018,9 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
     for (int q = threadIdx.x; q < 256; q += 64) s_pen[q] = pen_lut[q];
     __syncthreads();
     if (tA >= n_sw) return;
+    const WaveLogT wl_t = wavelog_begin();
     const bool haveB = tA + 1 < n_sw;
-    const int L = gm.L, k = gm.k;           // uniform batch: one length, one threshold
+    const int L = gm.L, k = EXACT ? KB : gm.k;           // uniform batch: one length, one threshold
     const int band = 2 * k + 1, tlen = L;
     const int NTk = (band + 7) / 8;
     u64 jbv[2]; u32 rv[2]; u64 sitev[2]; const char* rdv[2]; const char* qlv[2]; bool revv[2], fwdv[2], wval[2];
@@ -2945,34 +3043,57 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
     for (int b = 0; b <= BW; b++) { RH[b] = b < band ? 0u : MINFP; RE[b] = b < band ? pk_make(-gapoe, -gapoe) : MINFP; }
     // window bases of the current row, one-hot in nibbles (A1 C2 G4 T8, out-of-strand 0)
     u64 wq[2][NW];
-    WinReader wr[2];
+    extern __shared__ u64 lds_win[];        // [2][(L + 2k + 62) / 32 + 1][64]
+    const int nww = (L + 2 * k + 62) / 32;
+    LdsWin wr[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
 #pragma unroll
         for (int q = 0; q < NW; q++) wq[j][q] = 0;
-        wr[j].init(ix, sitev[j], wval[j]);
+        wr[j].init(ix, sitev[j], wval[j], lds_win + (size_t)j * (nww + 1) * 64 + threadIdx.x, nww);
         for (int b = 0; b < band; b++) { const int v = wr[j].next(); const u64 oh = v < 4 ? (1ull << v) : 0ull; wq[j][b >> 4] |= oh << (4 * (b & 15)); }
     }
     u64* tz = trace + slot;                 // word (i*NTk + q) lives at tz[(i*NTk + q) * trace_stride]
     ReadCur rcur[2], qcur[2];
+    RevCur qrev[2];
     PCode pcur[2];
-    const bool packed_in = pr.base != nullptr;
+    constexpr bool packed_in = PACKED;
     const u64* prowv[2] = {nullptr, nullptr};
     bool pdirtyv[2] = {false, false};
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         if (packed_in) { prowv[j] = pr.base + (size_t)rv[j] * pr.pwords; pdirtyv[j] = pr.dirty[rv[j]] != 0; pcur[j].seek(prowv[j], pr.W, pdirtyv[j]); }
         else rcur[j].seek(rdv[j], 0, L);
-        if (!revv[j]) qcur[j].seek(qlv[j], 0, L);
+        if (!revv[j]) qcur[j].seek(qlv[j], 0, L); else qrev[j].seek(qlv[j], L - 1);
     }
+    // Order inside a row: slide the windows and read the row's letter / quality (global loads, each followed by a
+    // wait on vmcnt, which on gfx9 counts stores too), THEN store the trace words of the PREVIOUS row, then the cells.  With the
+    // stores at the end of their own row every such wait also sat out the acknowledgement of stores issued a few instructions
+    // earlier: 53 % of the wave cycles of this kernel were SQ_WAIT_ANY.  Now a store has a whole row of cell arithmetic
+    // (plus the other waves' turns) behind it before anything waits.
+    u64 tw[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) tw[q] = 0;
     for (int i = 0; i < tlen; ++i) {
+        if (i > 0) {
+            // slide both windows one base
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+#pragma unroll
+                for (int q = 0; q < NW; q++) { wq[j][q] >>= 4; if (q + 1 < NW) wq[j][q] |= (wq[j][q + 1] & 15) << 60; }
+                const int v = wr[j].next();
+                const u64 oh = v < 4 ? (1ull << v) : 0ull;
+#pragma unroll
+                for (int q = 0; q < NW; q++) if (q == ((band - 1) >> 4)) wq[j][q] |= oh << (4 * ((band - 1) & 15));
+            }
+        }
         // per-row, per-job: mismatch penalty and the match bits of the whole band
         int mis[2];
         u64 Y[2][NW];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int ta = packed_in ? pcur[j].next4() : code4(rcur[j].next());
-            const unsigned char qc = revv[j] ? (unsigned char)qlv[j][L - 1 - i] : (unsigned char)qcur[j].next();
+            const unsigned char qc = revv[j] ? qrev[j].next() : (unsigned char)qcur[j].next();
             mis[j] = (ta == 4 || !wval[j]) ? -sp.np : -s_pen[qc];
             const u64 racc = (u64)((0x0A421u >> (4 * ta)) & 15u) * 0x1111111111111111ull;      // read A C G T N accepts {A} {C} {G} {T,C} {}
 #pragma unroll
@@ -2984,7 +3105,10 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
         }
         const u32 misP = pk_make(mis[0], mis[1]);
         u32 f = MINFP, h1 = MINFP;
-        u64 tw[NT];
+        if (i > 0) {
+#pragma unroll
+            for (int q = 0; q < NT; q++) if (q < NTk) tz[((u64)(i - 1) * NTk + q) * trace_stride] = tw[q];
+        }
 #pragma unroll
         for (int q = 0; q < NT; q++) tw[q] = 0;
 #pragma unroll
@@ -2992,7 +3116,11 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
             if (b < band) {
                 // score of the cell pair: 0 where the job's match bit is set, the row's penalty elsewhere
                 const u32 yA = (u32)(Y[0][b >> 4] >> (32 * ((b & 15) >> 3))), yB = (u32)(Y[1][b >> 4] >> (32 * ((b & 15) >> 3)));
-                const int mA = __builtin_amdgcn_sbfe(yA, 4 * (b & 7), 1), mB = __builtin_amdgcn_sbfe(yB, 4 * (b & 7), 1);
+                // (asm: left to itself the compiler turns "sign-extended bit & constant" into and + compare + wait state +
+                // select, eight instructions per cell pair where two v_bfe_i32, one v_bfi_b32 and one and-not do)
+                int mA, mB;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mA) : "v"(yA), "n"(4 * (b & 7)));
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mB) : "v"(yB), "n"(4 * (b & 7)));
                 const u32 mk = ((u32)mA & 0xffffu) | ((u32)mB & 0xffff0000u);
                 const u32 sc = misP & ~mk;
                 const u32 m = pk_add(RH[b], sc);
@@ -3021,20 +3149,10 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
         }
 #pragma unroll
         for (int b = 0; b <= BW; b++) if (b == band - 1) { RH[b] = h1; RE[b] = MINFP; }
+    }
+    if (tlen > 0) {
 #pragma unroll
-        for (int q = 0; q < NT; q++) if (q < NTk) tz[((u64)i * NTk + q) * trace_stride] = tw[q];
-        // slide both windows one base
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-#pragma unroll
-            for (int q = 0; q < NW; q++) { wq[j][q] >>= 4; if (q + 1 < NW) wq[j][q] |= (wq[j][q + 1] & 15) << 60; }
-            if (i + 1 < tlen) {
-                const int v = wr[j].next();
-                const u64 oh = v < 4 ? (1ull << v) : 0ull;
-#pragma unroll
-                for (int q = 0; q < NW; q++) if (q == ((band - 1) >> 4)) wq[j][q] |= oh << (4 * ((band - 1) & 15));
-            }
-        }
+        for (int q = 0; q < NT; q++) if (q < NTk) tz[((u64)(tlen - 1) * NTk + q) * trace_stride] = tw[q];
     }
     // per job: score, traceback, CIGAR, NM -- as k_align_sw, on this job's half of the registers and nibbles of the trace
     for (int j = 0; j < 2; j++) {
@@ -3140,6 +3258,7 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
         }
         a_start[jb] = qb; a_end[jb] = qe; a_nm[jb] = (u32)NM; a_score[jb] = score; a_nops[jb] = overflow ? -1 : no;
     }
+    wavelog_end(wl_t, 2);
 }
 
 // ------------------------------------------------------------------------------------------------
