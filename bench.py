@@ -454,18 +454,34 @@ def file_to_file_rate(args, cfg, fa, L):
     if not os.path.exists(drv) or not all(os.path.exists(f) for f in files):
         return None
     rec_bytes = 2 * L + 15                      # write_fastq_sample: '@s%08d\n' + L + '\n+\n' + L + '\n'
-    n = os.path.getsize(files[0]) // rec_bytes * (2 if cfg["pe"] else 1)
+    # the cpu_baseline sample four times over: a run of a few tenths of a second is mostly pipeline fill and first-call allocations
+    REP = 4
+    big = [f[:-3] + "_x%d.fq" % REP for f in files]
+    for src, dst in zip(files, big):
+        with open(dst, "wb") as o:
+            for _ in range(REP):
+                with open(src, "rb") as i:
+                    while True:
+                        blk = i.read(1 << 26)
+                        if not blk:
+                            break
+                        o.write(blk)
+    inp = [big[files.index(x)] if x in files else x for x in inp]
+    n = os.path.getsize(big[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     out = {}
     for label, dst in (("file", os.path.join(args.workdir, "f2f.sam")), ("null_sink", "/dev/null")):
-        p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "16", "--verbose"], capture_output=True, text=True)
+        p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "32", "--verbose"], capture_output=True, text=True)
         if p.returncode:
             return {"error": p.stderr[-300:]}
         line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
         wall = float(line.split("mapping wall")[1].split("s")[0])
-        out[label] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n)}
-    if os.path.exists(os.path.join(args.workdir, "f2f.sam")):
-        os.unlink(os.path.join(args.workdir, "f2f.sam"))
-    out["what"] = "bmbs_search, FASTQ -> SAM, 1 GPU, 16 host I/O threads, index load + attach excluded (as the reference's own 'mapping time')"
+        out[label] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n),
+                      "stages": " | ".join(x[len("[bmbs_search] "):] for x in p.stderr.splitlines() if x.startswith("[bmbs_search]"))[:900]}
+    for f in [os.path.join(args.workdir, "f2f.sam")] + big:
+        if os.path.exists(f):
+            os.unlink(f)
+    out["what"] = ("bmbs_search, FASTQ -> SAM, 1 GPU, 32 host I/O threads, the cpu_baseline sample %d times over, index load + attach excluded "
+                   "(as the reference's own 'mapping time')" % REP)
     return out
 
 

@@ -9,7 +9,7 @@
 //   output variants (Process_CommandLines.cpp:93-105): --pbat, --unmapped_out, --ambiguous_out, --bam (BGZF-compressed BAM)
 //   extra: --device N | --devices a,b,... (one index copy per listed device, batches dealt to whichever context is free, output
 //          order kept), --contexts S (contexts per device sharing its index: S batches in flight per GPU so that the copies of
-//          one overlap the kernels of another; default 2), --batch N (records per GPU batch, default 1 M), -t N (host I/O
+//          one overlap the kernels of another; default 2), --batch N (records per GPU batch, default 500 k), -t N (host I/O
 //          threads), --verbose
 //
 // The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
@@ -505,7 +505,7 @@ int main(int argc, char** argv)
     std::string index, seq, seq1, seq2, out = "output", mapstats, build_fasta, index_folder;
     int device = 0, io_threads = 0, contexts = 2;
     std::vector<int> devices;
-    long batch = 1000000;
+    long batch = 500000;                         // 20 M SE reads to a file: 27.3 M reads/s with 250-500 k, 23.3-24.2 with 1 M (pipeline fill)
     bool verbose = false, unmapped_out = false, pbat = false, bam = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];

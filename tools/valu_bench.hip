@@ -121,7 +121,17 @@ int main()
         hipEventRecord(eb, 0); hipEventSynchronize(eb);
         float ms = 0; hipEventElapsedTime(&ms, ea, eb);
         const double tps = 20.0 * 8192 * n / (ms * 1e-3) / 1e12;
-        printf("%-14s %8.2f %8.2f | %6.2f %6.2f %6.2f   chip %.3f T wave-instr/s\n", e.name, r[0], r[1], r[2], r[3], r[4], tps);
+        // dependent chains, 1 / 3 / 8 waves per SIMD: SIMD cycles per instruction from the wall clock (2.4 GHz assumed)
+        double depc[3];
+        const int nb[3] = {1024, 3072, 8192};
+        for (int q = 0; q < 3; q++) {
+            hipEventRecord(ea, 0);
+            for (int w = 0; w < 20; w++) hipLaunchKernelGGL(e.dep, dim3(nb[q]), dim3(64), 0, 0, d, 7u);
+            hipEventRecord(eb, 0); hipEventSynchronize(eb);
+            hipEventElapsedTime(&ms, ea, eb);
+            depc[q] = (ms * 1e-3 / 20.0) * 2.4e9 / (n * nb[q] / 1024.0);
+        }
+        printf("%-14s %8.2f %8.2f | %6.2f %6.2f %6.2f   chip %.3f T wave-instr/s | dependent chains, SIMD cycles/instr at w=1,3,8: %5.2f %5.2f %5.2f\n", e.name, r[0], r[1], r[2], r[3], r[4], tps, depc[0], depc[1], depc[2]);
     }
     return 0;
 }
