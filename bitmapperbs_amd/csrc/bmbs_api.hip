@@ -935,10 +935,10 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
             HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n2 + 64, c->stream));
             prow = c->prow.as<u64>(); pdirty = c->prow_dirty.as<u32>(); prepacked = true;
         }
-        // fast mode on packed rows: nothing reads the ASCII rows except under a set bit of the mask plane, so only those
-        // pieces are written (BMBS_PE_ASCII=full keeps the complete copy; --sensitive re-seeds on the ASCII rows and needs it)
+        // on packed rows nothing reads the ASCII rows except under a set bit of the mask plane, so only those pieces are written
+        // (BMBS_PE_ASCII=full keeps the complete copy)
         static const bool full_ascii = [] { const char* e = getenv("BMBS_PE_ASCII"); return e && !strcmp(e, "full"); }();
-        const int sparse = prow && !c->prm.sensitive && !full_ascii;
+        const int sparse = prow && !full_ascii;
         prof_begin(c, "k_pe_prepare");
         const int ppr = stride / 16;
         if (sparse && ppr <= 256) {
@@ -1059,8 +1059,12 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         rc = scan_u32(c, rflag, n, c->pe_rscan.as<u64>(), 7, rlist);
         if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(rcnt, 0, n * 4, c->stream));
-        hipLaunchKernelGGL(k_pes_reseed, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, gm, stride, (long)n, n_reseed, rlist, st, ps,
-                           rcnt, cnt);
+        {
+            PackedRows prs = {nullptr, nullptr, 0, 0};
+            if (use_packed_rows(1)) { prs.base = c->prow.as<u64>(); prs.dirty = c->prow_dirty.as<u8>(); prs.pwords = pack_words(gm.L); prs.W = pack_base_words(gm.L); }
+            hipLaunchKernelGGL((prs.base ? k_pes_reseed<true> : k_pes_reseed<false>), dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, prs, gm, stride,
+                               (long)n, n_reseed, rlist, st, ps, rcnt, cnt);
+        }
         rc = scan_u32(c, rcnt, n, c->pe_ritem_off.as<u64>(), 8);
         if (rc) return rc;
         prof_end(c);

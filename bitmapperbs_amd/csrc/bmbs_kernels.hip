@@ -3626,7 +3626,7 @@ __global__ void __launch_bounds__(256)
 k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all,
              u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32, int sparse_ascii)
 {
-    // sparse_ascii (the packed rows are what every later kernel reads): the ASCII text of a 16-byte piece is stored only
+    // sparse_ascii (the packed rows are what every later kernel reads, --sensitive's re-seeding included): the ASCII text of a 16-byte piece is stored only
     // when the piece holds a character outside ACGT -- the only places the ASCII rows are asked then (is it 'N'?) sit
     // under a set bit of the mask plane, so the other 99.9 % of the 2 x n x stride bytes are never written
     // one 16-byte piece per thread (rows are 16-byte aligned, stride % 16 == 0)
@@ -4287,8 +4287,9 @@ k_pes_reseed_flag(long n, PeState ps, u32* __restrict__ flag)
 
 // reseed_filter's seeding (Schema.cpp:16678-16900) with select_best_seeds (16630): up to three fixed segments
 // (count_hash_table) and then count_backward_as_much_1_terminate seeds sliding by 8.  One re-seeded mate per lane.
+template <bool PACKED>
 __global__ void __launch_bounds__(64)
-k_pes_reseed(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, long n, const u64* __restrict__ count_ptr,
+k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, const u64* __restrict__ count_ptr,
              const u32* __restrict__ plist, ReadState st, PeState ps, u32* __restrict__ rcnt, unsigned long long* __restrict__ counters)
 {
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -4297,6 +4298,8 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
         const long p = plist[it];
         const long r = p + (long)(1 - ps.first[p]) * n;
         const char* rd = seq + (size_t)r * stride;
+        const u64* prow = PACKED ? pr.base + (size_t)r * pr.pwords : nullptr;
+        const bool dirty = PACKED ? pr.dirty[r] != 0 : false;
         const int L = gm.rl(r);
         SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
         const int full = ps.full[r];
@@ -4321,11 +4324,16 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
         const u64 max_hits = 1000, avail = 20;
         int ns = 0, seed_id = 0;
         u64 ncand = 0;
-        Search S; SeedHit h;
+        typename std::conditional<PACKED, SearchP, Search>::type S; SeedHit h;
         while (seed_id < rn) {
             const int tm = rs[seed_id], ml = rl[seed_id];
-            if (search_begin<true>(ix, rd, tm + ml, tm, S, h, lc.n_hash))
-                while (!search_step<true>(ix, rd, tm + ml, S, h, lc.n_ext)) {}
+            if constexpr (PACKED) {
+                if (search_begin_p<true>(ix, prow, pr.W, dirty, tm + ml, tm, S, h, lc.n_hash))
+                    while (!search_step_p<true>(ix, tm + ml, S, h, lc.n_ext)) {}
+            } else {
+                if (search_begin<true>(ix, rd, tm + ml, tm, S, h, lc.n_hash))
+                    while (!search_step<true>(ix, rd, tm + ml, S, h, lc.n_ext)) {}
+            }
             if (h.hits == 1) seed_record(my, ns, ncand, h.sp, 1, (u64)ml, (u64)tm);
             else if ((u64)ml >= avail && h.hits <= max_hits) { if (h.hits != 0) seed_record(my, ns, ncand, h.sp, h.hits, (u64)ml, (u64)tm); }
             else if (L - tm == ml) break;
@@ -4333,8 +4341,13 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride,
         }
         int tm = full > 1 ? (s0 + s1) / 2 : 4;
         while (seed_id < max_seed && tm < L) {
-            if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash))
-                while (!search_step<false>(ix, rd, L, S, h, lc.n_ext)) {}
+            if constexpr (PACKED) {
+                if (search_begin_p<false>(ix, prow, pr.W, dirty, L, tm, S, h, lc.n_hash))
+                    while (!search_step_p<false>(ix, L, S, h, lc.n_ext)) {}
+            } else {
+                if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash))
+                    while (!search_step<false>(ix, rd, L, S, h, lc.n_ext)) {}
+            }
             if (h.hits == 1) seed_record(my, ns, ncand, h.sp, 1, h.ml, (u64)tm);
             else if (h.ml >= avail && h.hits <= max_hits) { if (h.hits != 0) seed_record(my, ns, ncand, h.sp, h.hits, h.ml, (u64)tm); }
             else if ((u64)(L - tm) == h.ml) break;

@@ -747,23 +747,26 @@ def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive, rows):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sensitive", [0, 1])
 @pytest.mark.parametrize("form", ["sparse", "full"])
 @pytest.mark.parametrize("L", [40, 101, 150, 251])
-def test_pe_prepare_forms_on_odd_lengths(env, monkeypatch, L, form):
-    """k_pe_prepare_p (the fast-mode default: mate 2 reverse-complemented on the packed words, ASCII text kept only for the
-    16-byte pieces that hold a character outside ACGT) against the byte-wise form (BMBS_PE_ASCII=full): fixed lengths that are
-    and are not multiples of 16 / 32 / 64, then mates trimmed independently, with 'N' and other letters in both mates"""
+def test_pe_prepare_forms_on_odd_lengths(env, monkeypatch, L, form, sensitive):
+    """k_pe_prepare_p (the default: mate 2 reverse-complemented on the packed words, ASCII text kept only for the 16-byte pieces
+    that hold a character outside ACGT) against the byte-wise form (BMBS_PE_ASCII=full): fixed lengths that are and are not
+    multiples of 16 / 32 / 64, then mates trimmed independently, with 'N' and other letters in both mates; fast mode and
+    --sensitive (whose re-seeding, k_pes_reseed, searches the packed rows too)"""
     from bitmapperbs_amd import synth, mapper
     if form == "full":
         monkeypatch.setenv("BMBS_PE_ASCII", "full")
-    m1, m2 = synth.make_reads_pe(env["chroms"], n=6000, L=L, seed=900 + L, sub=0.02, indel=0.002, qual="random", ins_hi=max(500, 2 * L + 50))
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=6000, L=L, seed=900 + L, sub=0.05 if sensitive else 0.02, indel=0.002, qual="random",
+                                 ins_hi=max(500, 2 * L + 50))
     rng = np.random.default_rng(L)
     for mm in (m1, m2):
         pos = rng.random(mm["seq"].shape) < 0.004
         mm["seq"][pos] = np.frombuffer(b"NNNRY", dtype=np.uint8)[rng.integers(0, 5, int(pos.sum()))]
-    m = mapper.Mapper(env["ix"], 0)
+    m = mapper.Mapper(env["ix"], 0, sensitive=sensitive)
     res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
-    recs, ost, _ = env["oix"].map_pe(orc.params(), m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+    recs, ost, _ = env["oix"].map_pe(orc.params(sensitive=sensitive), m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
     assert (recs["status"] == 1).sum() > 2000
     assert not compare_pe(res, pool, recs, L)
     assert (m.stats() == ost).all()
@@ -772,7 +775,7 @@ def test_pe_prepare_forms_on_odd_lengths(env, monkeypatch, L, form):
     s1, q1, s2, q2 = _trim(m1["seq"], l1), _trim(m1["qual"], l1), _trim(m2["seq"], l2), _trim(m2["qual"], l2)
     m.reset_stats() if hasattr(m, "reset_stats") else None
     res, pool = m.map_pe_var(s1, q1, s2, q2, l1, l2)
-    recs, _, _ = env["oix"].map_pe_var(orc.params(), s1, q1, s2, q2, l1, l2)
+    recs, _, _ = env["oix"].map_pe_var(orc.params(sensitive=sensitive), s1, q1, s2, q2, l1, l2)
     bad = compare_pe(res, pool, recs, l1, l2)
     assert not bad, bad[:5]
     m.close()
