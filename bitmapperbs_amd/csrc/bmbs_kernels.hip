@@ -70,7 +70,7 @@ DEVI void occ_TA(const DevIndex& ix, u64 line, u64& cT, u64& cA)
     const u32 m = r ? (~0u << (32 - r)) : 0u;
     cT = (u64)h.x + __popc(h.z & m);
     cA = (u64)h.y + __popc(h.w & m);
-    if (ix.occ_super) { const u64 sb = (line >> 16) << 1; cT += ix.occ_super[sb]; cA += ix.occ_super[sb + 1]; }
+    if (ix.occ_super) { const ulonglong2 sv = *reinterpret_cast<const ulonglong2*>(ix.occ_super + ((line >> 16) << 1)); cT += sv.x; cA += sv.y; }
 }
 DEVI u64 sa_at(const DevIndex& ix, u64 row) { return ix.sa64 ? ix.sa64[row] : (u64)ix.sa[row]; }
 
@@ -97,8 +97,12 @@ DEVI void lf_pair(const DevIndex& ix, u64& top, u64& bot, int c)
     u64 tT = (u64)ht.x + __popc(ht.z & mt), tA = (u64)ht.y + __popc(ht.w & mt);
     u64 bT = (u64)hb.x + __popc(hb.z & mb), bA = (u64)hb.y + __popc(hb.w & mb);
     if (ix.occ_super) {
-        const u64 st_ = (lt >> 16) << 1, sb_ = (lb >> 16) << 1;
-        tT += ix.occ_super[st_]; tA += ix.occ_super[st_ + 1]; bT += ix.occ_super[sb_]; bA += ix.occ_super[sb_ + 1];
+        // the {T, A} pair of a super-block is one 16-byte load, and the interval's two ends nearly always share it: every load is a
+        // request to the memory pipeline whether it hits or not, and this table took four of the six requests of a step
+        const ulonglong2 st_ = *reinterpret_cast<const ulonglong2*>(ix.occ_super + ((lt >> 16) << 1));
+        ulonglong2 sb_ = st_;
+        if ((lb >> 16) != (lt >> 16)) sb_ = *reinterpret_cast<const ulonglong2*>(ix.occ_super + ((lb >> 16) << 1));
+        tT += st_.x; tA += st_.y; bT += sb_.x; bA += sb_.y;
     }
     const u64 ct = c == 1 ? tT : (c == 2 ? tA : lt - tT - tA);
     const u64 cb = c == 1 ? bT : (c == 2 ? bA : lb - bT - bA);
@@ -378,6 +382,20 @@ DEVI u64 gen_bases32(const DevIndex& ix, u64 d)
     const int sh = 2 * (int)(d & 31);
     return sh ? (a >> sh) | (b << (64 - sh)) : a;
 }
+// the doubled genome from coordinate d on, 32 bases per call, ONE 16-byte request per 64 bases (gen_bases32 takes one per 32:
+// every load is a request to the memory pipeline whether it hits or not, and the window was 5 of the 7 divergent requests a read
+// costs in k_seed_decide).  Reads one pair of words past the last one used: gen2 carries spare pieces at its end.
+struct GenStream {
+    const u64* p; u64 a, b; int sh; bool second;
+    DEVI void init(const DevIndex& ix, u64 d) { p = ix.gen2 + (d >> 5); sh = 2 * (int)(d & 31); load2(p, a, b); p += 2; second = false; }
+    DEVI u64 next32()
+    {
+        u64 lo = a, hi = b;
+        if (second) { u64 na, nb; load2(p, na, nb); p += 2; lo = b; hi = na; a = na; b = nb; }
+        second = !second;
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    }
+};
 // 32 bits -> the even bit positions of 64 bits
 DEVI u64 spread32(u32 m)
 {
@@ -436,8 +454,9 @@ struct PCode {
 DEVI int count_mism_p(const DevIndex& ix, const u64* row, int W, bool dirty, int ts, u64 d, int len)
 {
     int c = 0;
+    GenStream gs; gs.init(ix, d);
     for (int o = 0; o < len; o += 32) {
-        u64 mm = mism_bs(prow_bases32(row, ts + o), gen_bases32(ix, d + (u64)o));
+        u64 mm = mism_bs(prow_bases32(row, ts + o), gs.next32());
         if (dirty) mm |= spread32(prow_mask32(row, W, ts + o));
         c += __popcll(mm & field_range(0, len - o));
     }
@@ -1389,8 +1408,9 @@ k_seed_decide_p(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGe
                     } else {
                         // read position q faces doubled coordinate loc + q; 32 positions per step
                         const int ml0 = (int)ml;
+                        GenStream gs; gs.init(ix, loc + (u64)(ml0 & ~31));
                         for (int q = ml0 & ~31; q < L && error < 2; q += 32) {
-                            u64 mm = mism_bs(row[q >> 5], gen_bases32(ix, loc + (u64)q));
+                            u64 mm = mism_bs(row[q >> 5], gs.next32());
                             if (dirty) mm |= spread32((u32)((row[W + (q >> 6)] >> (q & 63)) & 0xffffffffull));
                             mm &= field_range(ml0 - q, L - q);
                             if (mm) {
@@ -2735,8 +2755,9 @@ k_align_ungapped_p(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut,
     bool ok = start >= 0 && wvalid;
     int tmp_err = 0, score = 0;
     if (ok) {
+        GenStream gs; gs.init(ix, site + (u64)start);
         for (int p = 0; p < L && ok; p += 32) {
-            u64 mm = mism_bs(row[p >> 5], gen_bases32(ix, site + (u64)start + (u64)p));
+            u64 mm = mism_bs(row[p >> 5], gs.next32());
             if (dirty) mm |= spread32((u32)((row[pr.W + (p >> 6)] >> (p & 63)) & 0xffffffffull));
             mm &= field_range(0, L - p);
             tmp_err += __popcll(mm);
