@@ -293,7 +293,7 @@ class Job:
         self.stride = (L + 15) // 16 * 16
         self.n = cfg["units"]
         self.k = m.threshold(L)
-        self.max_ops = 2 * self.k + 8
+        self.max_ops = m.max_cigar_ops(L)
         own = genome_d is None
         if own:
             genome_d = gpusynth.upload_genome(chroms)

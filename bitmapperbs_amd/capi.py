@@ -22,6 +22,7 @@ SYMBOLS = [
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
+    "bmbs_max_cigar_ops",
 ]
 
 
@@ -130,6 +131,8 @@ def lib() -> C.CDLL:
     L.bmbs_index_build_device.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     L.bmbs_build_id.argtypes = []
     L.bmbs_build_id.restype = C.c_char_p
+    L.bmbs_max_cigar_ops.argtypes = [C.POINTER(Params), C.c_int32]
+    L.bmbs_max_cigar_ops.restype = C.c_int32
     L.bmbs_host_alloc.argtypes = [u64]
     L.bmbs_host_alloc.restype = vp
     L.bmbs_host_free.argtypes = [vp]

@@ -173,6 +173,23 @@ int threshold_k(const bmbs_params& P, int L)
     return (int)k;
 }
 
+// CIGAR operations one alignment can have, + slack: the slots per job in the cigar pool.  The DP (ksw.cpp:1850-2045) maximises the
+// score inside the band; the alignment with <= k edits that the Myers filter found lies inside the band and scores at least
+// -k * max(mp_max, np, gap_open + gap_ext), and every gap run of any alignment costs at least gap_open + gap_ext, so the optimum
+// holds at most k * max(...) / (gap_open + gap_ext) gap runs and twice that + 1 operations.  With the default penalties (6, 1,
+// 5 + 3) that is the 2k + 8 this code used for every parameter set -- until a random-parameter soak (tools/fuzz_parity.py) ran
+// --gap_open 1 with mismatches at 8-9: gaps cheaper than mismatches, alignments with more runs than slots.
+int cigar_ops_bound(const bmbs_params& P, int L, int k)
+{
+    const long goe = (long)P.gap_open + P.gap_ext;
+    const long worst = std::max<long>(std::max<long>(P.mp_max, P.np), goe);
+    long gaps = (long)L + 2 * k;
+    if (goe > 0) gaps = std::min<long>(gaps, (long)k * worst / goe);
+    return (int)std::min<long>(2 * gaps + 8, 1 << 20);
+}
+// n_cigar of a record is 8 bits, 255 marks "more operations than slots" (cannot happen with the bound above)
+#define BMBS_MAX_RECORD_OPS 254
+
 // MAP_Calculation tables for every error_threshold 0..62 (k for single-end, k1+k2 for pairs), concatenated:
 // table t = (t+2) x (unit*t+1) bytes at mapq_off[t]; plus klut[L] = the threshold of a read of length L.  Built once.
 int prepare_luts(bmbs_ctx* c)
@@ -634,6 +651,14 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
     delete c;
 }
 
+extern "C" int32_t bmbs_max_cigar_ops(const bmbs_params* params, int32_t L)
+{
+    if (L <= 0 || L > 1000) return -1;
+    bmbs_params P;
+    if (params) P = *params; else bmbs_default_params(&P);
+    return cigar_ops_bound(P, L, threshold_k(P, L));
+}
+
 extern "C" const char* bmbs_last_error(const bmbs_ctx* c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
 
 extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
@@ -801,9 +826,10 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
     HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->last_n_jobs = n_jobs;
-    const int max_ops = 2 * k + 8;
+    const int max_ops = cigar_ops_bound(c->prm, L, k);
     c->last_max_ops = max_ops;
-    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small"; return BMBS_ENOMEM; }
+    if (max_ops > BMBS_MAX_RECORD_OPS) { c->err = "these gap / mismatch penalties allow alignments with more CIGAR operations than a record holds (254)"; return BMBS_EINVAL; }
+    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small (it takes bmbs_max_cigar_ops() slots per read)"; return BMBS_ENOMEM; }
     {
         const u64 nj = n_jobs ? n_jobs : 1;
         ENS(c, c->job_read, nj * 4); ENS(c, c->job_site, nj * 8); ENS(c, c->job_end, nj * 4); ENS(c, c->job_err, nj * 4);
@@ -850,7 +876,7 @@ int map_se_host(bmbs_ctx* c, const char* seq, const char* qual, const uint16_t* 
     if (L <= 0 || L > 1000 || stride < L) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     ENS(c, c->out_res, n * 32);
     const int k = threshold_k(c->prm, L);
-    const u64 pool = n * (u64)(2 * k + 8);           // worst case: every read needs K12
+    const u64 pool = n * (u64)cigar_ops_bound(c->prm, L, k);           // worst case: every read needs K12
     ENS(c, c->cig_pool, pool * 4);
     int ds = 0;
     { int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; r1 = upload_rows(c, c->in_qual, qual, L, stride, n, &ds); if (r1) return r1; }
@@ -1096,9 +1122,10 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->last_n_jobs = n_jobs;
-    const int max_ops = 2 * k + 8;
+    const int max_ops = cigar_ops_bound(c->prm, L, k);
     c->last_max_ops = max_ops;
-    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small"; return BMBS_ENOMEM; }
+    if (max_ops > BMBS_MAX_RECORD_OPS) { c->err = "these gap / mismatch penalties allow alignments with more CIGAR operations than a record holds (254)"; return BMBS_EINVAL; }
+    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small (it takes bmbs_max_cigar_ops() slots per read)"; return BMBS_ENOMEM; }
     {
         const u64 nj = n_jobs ? n_jobs : 1;
         ENS(c, c->job_read, nj * 4); ENS(c, c->job_site, nj * 8); ENS(c, c->job_end, nj * 4); ENS(c, c->job_err, nj * 4);
@@ -1137,7 +1164,7 @@ int map_pe_host(bmbs_ctx* c, const char* seq1, const char* qual1, const char* se
     if (L <= 0 || L > 1000 || stride < L) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     ENS(c, c->out_res, 2 * n * 32);
     const int k = threshold_k(c->prm, L);
-    const u64 pool = 2 * n * (u64)(2 * k + 8);
+    const u64 pool = 2 * n * (u64)cigar_ops_bound(c->prm, L, k);
     ENS(c, c->cig_pool, pool * 4);
     int ds = 0;
     {
@@ -1237,7 +1264,7 @@ extern "C" int bmbs_map_se_fastq(bmbs_ctx* c, const bmbs_fastq_view* reads, int6
     const u64 n = (u64)n_reads;
     const int ds = (L_max + 15) / 16 * 16;
     const int k = threshold_k(c->prm, L_max);
-    const u64 pool = n * (u64)(2 * k + 8);
+    const u64 pool = n * (u64)cigar_ops_bound(c->prm, L_max, k);
     ENS(c, c->out_res, n * 32); ENS(c, c->cig_pool, pool * 4);
     ENS(c, c->in_seq, n * (u64)ds + 64); ENS(c, c->in_qual, n * (u64)ds + 64); ENS(c, c->in_len, n * 2 + 16);
     ENS(c, c->fq_idx, n * 12 + 64);
@@ -1269,7 +1296,7 @@ extern "C" int bmbs_map_pe_fastq(bmbs_ctx* c, const bmbs_fastq_view* mate1, cons
     const u64 n = (u64)n_pairs, n2 = 2 * n;
     const int ds = (L_max + 15) / 16 * 16;
     const int k = threshold_k(c->prm, L_max);
-    const u64 pool = n2 * (u64)(2 * k + 8);
+    const u64 pool = n2 * (u64)cigar_ops_bound(c->prm, L_max, k);
     ENS(c, c->out_res, n2 * 32); ENS(c, c->cig_pool, pool * 4);
     ENS(c, c->pe_seq, n2 * (u64)ds + 64); ENS(c, c->in_qual, n * (u64)ds + 64); ENS(c, c->in_qual2, n * (u64)ds + 64); ENS(c, c->in_len, n2 * 2 + 16);
     ENS(c, c->fq_idx, n2 * 12 + 128);
@@ -1399,7 +1426,7 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_jobs <= 0) return BMBS_OK;
     if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
-    if (max_ops < 2 * threshold_k(c->prm, L) + 8) { c->err = "align batch: max_ops must be at least 2*k+8"; return BMBS_EINVAL; }
+    if (max_ops < cigar_ops_bound(c->prm, L, threshold_k(c->prm, L))) { c->err = "align batch: max_ops must be at least bmbs_max_cigar_ops(L)"; return BMBS_EINVAL; }
     for (int64_t i = 0; i < n_jobs; i++) if ((int64_t)read_of[i] >= n_reads) { c->err = "align batch: read_of out of range"; return BMBS_EINVAL; }
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_jobs;
     { const int r0 = prepare_luts(c); if (r0) return r0; }

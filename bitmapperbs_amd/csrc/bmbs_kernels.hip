@@ -134,15 +134,26 @@ DEVI int gbase(const DevIndex& ix, u64 d) { return (int)((ix.gen2[d >> 5] >> ((d
 
 // chromosome of a forward-strand coordinate: the c with chrom_start[c] <= loc < chrom_start[c + 1], n_chrom when there is none.
 // Binary search: an assembly with its alternate contigs and decoys has thousands of sequences, and this runs once per read.
-DEVI int chrom_of(const DevIndex& ix, u64 loc)
+DEVI int chrom_of(const u64* chrom_start, int n_chrom, u64 loc)
 {
-    if (loc >= ix.chrom_start[ix.n_chrom]) return ix.n_chrom;
-    int lo = 0, hi = ix.n_chrom;
+    if (loc >= chrom_start[n_chrom]) return n_chrom;
+    int lo = 0, hi = n_chrom;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (ix.chrom_start[mid] <= loc) lo = mid; else hi = mid;
+        if (chrom_start[mid] <= loc) lo = mid; else hi = mid;
     }
     return lo;
+}
+DEVI int chrom_of(const DevIndex& ix, u64 loc) { return chrom_of(ix.chrom_start, ix.n_chrom, loc); }
+// The finalize kernels place every read by a binary search over the chromosome starts: five dependent loads plus two for the
+// chromosome's bounds, in kernels that are nothing but chains of dependent loads (k_finalize_pe: 61 % of its wave cycles parked
+// on memory).  Assemblies of up to BMBS_CS_LDS - 1 sequences get the table copied into LDS by every block first.
+#define BMBS_CS_LDS 1025
+DEVI const u64* chrom_table(const DevIndex& ix, u64* lds)
+{
+    if (ix.n_chrom + 1 > BMBS_CS_LDS) return ix.chrom_start;
+    for (int i = threadIdx.x; i <= ix.n_chrom; i += blockDim.x) lds[i] = ix.chrom_start[i];
+    return lds;
 }
 
 // window validity: get_actuall_genome / get_actuall_rc_genome return an all-zero window when the
@@ -2900,7 +2911,7 @@ k_align_sw(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const c
     for (int bp = BW; bp >= 1; bp--) if (bp <= band) { const int h = RH[bp - 1]; if (h > score) { score = h; max_i = tlen - 1 + bp; } }
     int qe = max_i - 1;
     // traceback
-    const int LOCAL_OPS = 160;
+    const int LOCAL_OPS = 256;            // >= the 254 operations a record can hold (cigar_ops_bound)
     u32 cg[LOCAL_OPS + 1];
     int nc = 0;
     bool overflow = false;
@@ -3190,7 +3201,7 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
 #pragma unroll
         for (int bp = BW; bp >= 1; bp--) if (bp <= band) { const int h = half(RH[bp - 1]); if (h > score) { score = h; max_i = tlen - 1 + bp; } }
         int qe = max_i - 1;
-        const int LOCAL_OPS = 160;
+        const int LOCAL_OPS = 256;            // >= the 254 operations a record can hold (cigar_ops_bound)
         u32 cg[LOCAL_OPS + 1];
         int nc = 0;
         bool overflow = false;
@@ -3312,7 +3323,7 @@ DEVI int group_prefix_max(int x, int minf)
     return x;
 }
 
-#define SWW_CG_WORDS 164
+#define SWW_CG_WORDS 260
 // LDS words per job: row constants (u16 per read position, padded to 4) + trace + CIGAR ops; even, so that jobs stay 8-byte aligned
 __host__ __device__ inline int sww_lds_words(int L, int k)
 {
@@ -3516,7 +3527,9 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
            bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
 {
     __shared__ unsigned long long sh[5];
+    __shared__ u64 s_cs[BMBS_CS_LDS];
     if (threadIdx.x < 5) sh[threadIdx.x] = 0;
+    const u64* cs = chrom_table(ix, s_cs);
     __syncthreads();
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;          // this lane's contribution to the five counters
@@ -3550,10 +3563,10 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
                     u64 loc = s_; int flag;
                     if (loc >= ix.G) { loc = ix.G * 2 - (loc + (u64)(L - 1)) - 1; flag = 16; } else flag = 0;
                     int c = 0;
-                    c = chrom_of(ix, loc);
+                    c = chrom_of(cs, ix.n_chrom, loc);
                     if (c >= ix.n_chrom) continue;
-                    const u64 pos = loc + 1 - ix.chrom_start[c];
-                    if (pos + (u64)(L - 1) > ix.chrom_start[c + 1] - ix.chrom_start[c]) continue;
+                    const u64 pos = loc + 1 - cs[c];
+                    if (pos + (u64)(L - 1) > cs[c + 1] - cs[c]) continue;
                     o.pos = pos; o.chrom = (int16_t)c; o.flag = (u16)flag; o.mapq = 1; o.status = 2;
                     break;
                 }
@@ -3585,12 +3598,12 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
             if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; flag = 16; }
             else { loc = loc + (u64)start_site; flag = 0; }
             int c = 0;
-            c = chrom_of(ix, loc);
+            c = chrom_of(cs, ix.n_chrom, loc);
             bool ok = c < ix.n_chrom;
             u64 pos = 0;
             if (ok) {
-                pos = loc + 1 - ix.chrom_start[c];
-                const u64 clen = ix.chrom_start[c + 1] - ix.chrom_start[c];
+                pos = loc + 1 - cs[c];
+                const u64 clen = cs[c + 1] - cs[c];
                 if (pos + (u64)end_site - (u64)start_site > clen) ok = false;
             }
             o.pos = pos; o.chrom = (int16_t)(c < ix.n_chrom ? c : -1); o.flag = (u16)flag; o.mapq = (u8)mapq;
@@ -4499,7 +4512,9 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
               bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
 {
     __shared__ unsigned long long sh[5];
+    __shared__ u64 s_cs[BMBS_CS_LDS];
     if (threadIdx.x < 5) sh[threadIdx.x] = 0;
+    const u64* cs = chrom_table(ix, s_cs);
     __syncthreads();
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;          // this lane's contribution to the five counters
@@ -4542,12 +4557,12 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
                 if (loc >= ix.G) { loc = loc + (u64)end_site; loc = ix.G * 2 - loc - 1; rflag[m] = 16; }
                 else { loc = loc + (u64)start_site; rflag[m] = 0; }
                 int c = 0;
-                c = chrom_of(ix, loc);
+                c = chrom_of(cs, ix.n_chrom, loc);
                 if (c >= ix.n_chrom) { c = ix.n_chrom - 1; inrange = false; }
                 chrom[m] = c;
-                site_pos[m] = (long long)(loc + 1 - ix.chrom_start[c]);
+                site_pos[m] = (long long)(loc + 1 - cs[c]);
                 matched[m] = end_site - start_site + 1;
-                const long long clen = (long long)(ix.chrom_start[c + 1] - ix.chrom_start[c]);
+                const long long clen = (long long)(cs[c + 1] - cs[c]);
                 if ((u64)site_pos[m] + (u64)matched[m] > (u64)clen + 1) inrange = false;
             }
             long long mn = site_pos[0], mx = site_pos[0] + matched[0] - 1;

@@ -281,7 +281,7 @@ struct Batch {
     Pinned text1, text2;                         // the FASTQ text windows, as read from the files
     Lines l1, l2;
     RecIdx r1, r2;
-    int maxL = 0, k = 0;                         // longest read of the batch, its threshold (sizes the CIGAR pool)
+    int maxL = 0, k = 0, max_ops = 8;            // longest read of the batch, its threshold, CIGAR pool slots per read (bmbs_max_cigar_ops)
     bool uniform = true;                         // every read of the batch has the same length
     Pinned res, pool;
     std::vector<std::vector<char>> text;         // SAM text per formatter slice (capacity kept from batch to batch)
@@ -346,6 +346,10 @@ struct Out {
     void cigar(const bmbs_result& r, const uint32_t* pool, int L)
     {
         if (r.n_cigar == 0) { num((unsigned)L); ch('M'); return; }
+        if (r.n_cigar == 255) {               // "more operations than pool slots": bmbs_max_cigar_ops rules it out; never print garbage
+            fprintf(stderr, "bmbs_search: internal error: an alignment overflowed its CIGAR slots\n");
+            std::_Exit(3);
+        }
         for (int i = 0; i < r.n_cigar; i++) { const uint32_t o = pool[r.cigar_off + i]; num(o >> 4); ch("MDISH"[o & 15]); }
     }
     // SEQ \t QUAL from the FASTQ text: bases upper-cased (Process_Reads.cpp:836), a quality line shorter than the sequence
@@ -595,15 +599,15 @@ int main(int argc, char** argv)
     }
     std::thread prealloc([&] {
         const size_t want = std::min<size_t>((size_t)batch * est0 + (1u << 16), (size_t)4000 << 20) + 64;
-        int k250 = (int)(uint64_t)(P.e_f * 250); if (k250 > 31) k250 = 31;
+        const int ops250 = std::max(8, (int)bmbs_max_cigar_ops(&P, 250));
         std::vector<std::thread> th;
         for (auto& b : batches)
-            th.emplace_back([&, want, k250] {
+            th.emplace_back([&, want, ops250] {
                 Batch* bb = &b;
                 bb->text1.need(want); if (pe) bb->text2.need(want);
                 bb->r1.need((size_t)batch); if (pe) bb->r2.need((size_t)batch);
                 bb->res.need((size_t)batch * sizeof(bmbs_result) * (pe ? 2 : 1) + 64);
-                bb->pool.need((size_t)batch * (size_t)(2 * k250 + 8) * (pe ? 2 : 1) * 4 + 64);
+                bb->pool.need((size_t)batch * (size_t)ops250 * (pe ? 2 : 1) * 4 + 64);
                 bb->l1.nl.reserve((size_t)batch * 4 + 16); if (pe) bb->l2.nl.reserve((size_t)batch * 4 + 16);
             });
         for (auto& t : th) t.join();
@@ -767,7 +771,8 @@ int main(int argc, char** argv)
             b->maxL = maxL; b->uniform = minL == maxL;
             int k = (int)(uint64_t)(P.e_f * maxL); if (k > 31) k = 31;
             b->k = k;
-            const size_t pool_ops = (size_t)nrec * (size_t)(2 * k + 8) * (pe ? 2 : 1);
+            b->max_ops = std::max(8, (int)bmbs_max_cigar_ops(&P, maxL));
+            const size_t pool_ops = (size_t)nrec * (size_t)b->max_ops * (pe ? 2 : 1);
             if (!b->res.need((size_t)nrec * sizeof(bmbs_result) * (pe ? 2 : 1) + 64) || !b->pool.need(pool_ops * 4 + 64)) { bail("cannot allocate page-locked staging memory"); return; }
             t_read += now() - t0;
             ev_r.push_back({'R', nrec, t0, now()});
@@ -802,7 +807,7 @@ int main(int argc, char** argv)
                     size_t bound = 64;
                     for (long r = a; r < e; r++) {
                         const size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
-                        bound += ((size_t)(pe ? 2 : 1)) * (nl + max_chrom + 2 * (size_t)b->maxL + 6 * (size_t)(2 * b->k + 8) + 128);
+                        bound += ((size_t)(pe ? 2 : 1)) * (nl + max_chrom + 2 * (size_t)b->maxL + 6 * (size_t)b->max_ops + 128);
                     }
                     std::vector<char>& buf = b->text[(size_t)t];
                     if (buf.size() < bound) buf.resize(bound + bound / 8);
@@ -985,7 +990,7 @@ int main(int argc, char** argv)
                 int64_t used = 0;
                 int rc;
                 bmbs_fastq_view v1 = {b->text1.p, (uint64_t)b->l1.used, b->r1.seq_off, b->r1.qual_off, b->r1.seq_len, b->r1.qual_len};
-                const int64_t cap = (int64_t)b->n * (2 * b->k + 8) * (pe ? 2 : 1);
+                const int64_t cap = (int64_t)b->n * b->max_ops * (pe ? 2 : 1);
                 if (!pe)
                     rc = bmbs_map_se_fastq(ctx, &v1, b->n, b->maxL, b->uniform ? 1 : 0, pbat_se ? 1 : 0, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, cap, &used);
                 else {

@@ -90,6 +90,10 @@ class Mapper:
         k = int(np.uint64(self.params.e_f * L))   # Schema.cpp:24546
         return min(k, 31)
 
+    def max_cigar_ops(self, L: int) -> int:
+        """slots per read the cigar pool needs (bmbs_max_cigar_ops): 2k + 8 with the default penalties"""
+        return int(self._lib.bmbs_max_cigar_ops(C.byref(self.params), int(L)))
+
     # ---- fused single-end mapping ------------------------------------------------------------------
     def map_se(self, seq: np.ndarray, qual: np.ndarray, L: int | None = None):
         """seq/qual: uint8 [n, stride] (ASCII, upper case).  -> (results[n] RESULT_DTYPE, cigar_pool u32)"""
@@ -98,7 +102,7 @@ class Mapper:
         n, stride = seq.shape
         L = stride if L is None else L
         res = np.zeros(n, dtype=capi.RESULT_DTYPE)
-        cap = max(1, n * (2 * self.threshold(L) + 8))
+        cap = max(1, n * self.max_cigar_ops(L))
         pool = np.zeros(cap, dtype=np.uint32)
         used = C.c_int64(0)
         self._chk(self._lib.bmbs_map_se(self._ctx, capi.ptr(seq), capi.ptr(qual), L, stride, n, capi.ptr(res),
@@ -116,7 +120,7 @@ class Mapper:
         n, stride = a[0].shape
         L = stride if L is None else L
         res = np.zeros(2 * n, dtype=capi.RESULT_DTYPE)
-        cap = max(1, 2 * n * (2 * self.threshold(L) + 8))
+        cap = max(1, 2 * n * self.max_cigar_ops(L))
         pool = np.zeros(cap, dtype=np.uint32)
         used = C.c_int64(0)
         self._chk(self._lib.bmbs_map_pe(self._ctx, capi.ptr(a[0]), capi.ptr(a[1]), capi.ptr(a[2]), capi.ptr(a[3]), L, stride, n,
@@ -136,7 +140,7 @@ class Mapper:
         n, stride = seq.shape
         L = int(lens.max()) if n else 1
         res = np.zeros(n, dtype=capi.RESULT_DTYPE)
-        cap = max(1, n * (2 * self.threshold(L) + 8))
+        cap = max(1, n * self.max_cigar_ops(L))
         pool = np.zeros(cap, dtype=np.uint32)
         used = C.c_int64(0)
         self._chk(self._lib.bmbs_map_se_var(self._ctx, capi.ptr(seq), capi.ptr(qual), capi.ptr(lens), L, stride, n, capi.ptr(res),
@@ -149,7 +153,7 @@ class Mapper:
         n, stride = a[0].shape
         L = int(max(l1.max(), l2.max())) if n else 1
         res = np.zeros(2 * n, dtype=capi.RESULT_DTYPE)
-        cap = max(1, 2 * n * (2 * self.threshold(L) + 8))
+        cap = max(1, 2 * n * self.max_cigar_ops(L))
         pool = np.zeros(cap, dtype=np.uint32)
         used = C.c_int64(0)
         self._chk(self._lib.bmbs_map_pe_var(self._ctx, capi.ptr(a[0]), capi.ptr(a[1]), capi.ptr(a[2]), capi.ptr(a[3]), capi.ptr(l1),
@@ -260,6 +264,8 @@ def cigar_text(res_row, pool: np.ndarray, L: int) -> str:
     n = int(res_row["n_cigar"])
     if n == 0:
         return "%dM" % L
+    if n == 255:
+        raise ValueError("an alignment overflowed its CIGAR slots (bmbs_max_cigar_ops rules this out: internal error)")
     ops = pool[int(res_row["cigar_off"]):int(res_row["cigar_off"]) + n]
     return "".join("%d%s" % (int(o) >> 4, "MDISH"[int(o) & 0xf]) for o in ops)
 

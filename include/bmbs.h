@@ -152,6 +152,13 @@ int bmbs_seed_batch(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int64
                     uint8_t* verdict, uint64_t* exit_site, uint64_t* seg_off, uint32_t* n_votes,
                     uint64_t* vote_site, uint32_t* vote_cnt, int64_t vote_cap, int64_t* total_slots);
 
+/* Slots per read (per mate) the cigar pool of the mapping calls needs for reads of length L under these parameters (NULL: the
+ * defaults): 2k + 8 with the default penalties, more when --gap_open / --gap_extension (Process_CommandLines.cpp:129-130) make
+ * gaps cheaper than mismatches; -1 for L outside 1..1000.  A pool of n_reads * bmbs_max_cigar_ops(params, L_max) entries (twice
+ * that for pairs) is always enough; parameter sets that allow more than 254 operations per alignment are refused by the mapping
+ * calls (BMBS_EINVAL): n_cigar of a record is 8 bits. */
+int32_t bmbs_max_cigar_ops(const bmbs_params* params, int32_t L);
+
 /* ---- fused single-end mapping (Map_Single_Seq_end_to_end loop body, Schema.cpp:24488-25119) ---- */
 /* host buffers: copies in, maps, copies results out.  cigar_pool[cigar_cap] receives the ops.      */
 int bmbs_map_se(bmbs_ctx*, const char* seq, const char* qual, int32_t L, int32_t stride,

@@ -75,7 +75,7 @@ typedef struct orc_rec {
     int32_t  flag, mapq, nm, score;
     int32_t  path;          /* 1 exit A (exact unique), 2 exit C (1-mismatch), 3 general, 4 exit B */
     int32_t  n_cand, n_votes;
-    char     cigar[256];
+    char     cigar[1024];    /* 254 operations (what a product record can hold) of up to 4 characters */
 } orc_rec;
 
 /* event counters for SURVEY.md §8d algorithmic-byte accounting */
@@ -102,7 +102,7 @@ typedef struct orc_pe_rec {
     int32_t  flag1, flag2, chrom1, chrom2;
     uint64_t pos1, pos2;
     int32_t  nm1, nm2, score1, score2, matched1, matched2;
-    char     cigar1[256], cigar2[256];
+    char     cigar1[1024], cigar2[1024];
 } orc_pe_rec;
 
 /* PE mapping of n pairs (SoA, common stride).  seq2 = mate 2 as the reference's reader hands it on, i.e.

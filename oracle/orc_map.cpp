@@ -634,7 +634,7 @@ static void map_one_se(const orc_index* ix, const orc_params* P, const read_t& r
     if (min_err_index >= 0) {
         vote_t best = votes[min_err_index];
         int score = 0, start_site;
-        char cigar[256];
+        char cigar[1024];
         unsigned nm = best.err;
         int end_site = (int)best.end_site;
         if (best.err != 0) {
@@ -653,7 +653,7 @@ static void map_one_se(const orc_index* ix, const orc_params* P, const read_t& r
         // Schema.cpp:25095-25118: the first candidate that reached the minimum is aligned and reported (second_best_diff = 0)
         vote_t best = votes[-2 - min_err_index];
         int score = 0, start_site;
-        char cigar[256];
+        char cigar[1024];
         unsigned nm = best.err;
         int end_site = (int)best.end_site;
         if (best.err != 0) {

@@ -215,7 +215,7 @@ int verify_pairs(const std::vector<cand_t>& r1, int n1, const std::vector<cand_t
     return mapping_pair;
 }
 
-struct mate_res { u64 origin_site, end_site, site; unsigned err; int score, flag, chrom, matched; char cigar[256]; };
+struct mate_res { u64 origin_site, end_site, site; unsigned err; int score, flag, chrom, matched; char cigar[1024]; };
 
 // output_sam_end_to_end_return (Schema.cpp:9188-9225)
 void place_return(const orc_index* ix, u64 site, u64 end_site, u64 start_site, mate_res* r)

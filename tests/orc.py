@@ -19,11 +19,11 @@ class OrcParams(C.Structure):
 
 REC_DTYPE = np.dtype([("status", "<i4"), ("chrom", "<i4"), ("pos", "<u8"), ("site", "<u8"), ("start_site", "<i4"),
                       ("end_site", "<i4"), ("flag", "<i4"), ("mapq", "<i4"), ("nm", "<i4"), ("score", "<i4"),
-                      ("path", "<i4"), ("n_cand", "<i4"), ("n_votes", "<i4"), ("cigar", "S256"), ("_pad", "<i4")])
+                      ("path", "<i4"), ("n_cand", "<i4"), ("n_votes", "<i4"), ("cigar", "S1024"), ("_pad", "<i4")])
 PE_REC_DTYPE = np.dtype([("status", "<i4"), ("n_pairs", "<i4"), ("mapq", "<i4"), ("tlen", "<i4"), ("flag1", "<i4"), ("flag2", "<i4"),
                          ("chrom1", "<i4"), ("chrom2", "<i4"), ("pos1", "<u8"), ("pos2", "<u8"), ("nm1", "<i4"), ("nm2", "<i4"),
-                         ("score1", "<i4"), ("score2", "<i4"), ("matched1", "<i4"), ("matched2", "<i4"), ("cigar1", "S256"),
-                         ("cigar2", "S256")])
+                         ("score1", "<i4"), ("score2", "<i4"), ("matched1", "<i4"), ("matched2", "<i4"), ("cigar1", "S1024"),
+                         ("cigar2", "S1024")])
 COUNTER_KEYS = ("n_reads", "n_hash", "n_ext", "n_lf", "n_sa1", "n_locate_rows", "n_cand", "n_sw", "n_ungapped")
 
 _lib = None
@@ -95,7 +95,7 @@ class OrcIndex:
         n, stride = seq.shape
         ln = np.full(n, L, dtype=np.int32)
         recs = np.zeros(n, dtype=REC_DTYPE)
-        assert REC_DTYPE.itemsize == 320, REC_DTYPE.itemsize
+        assert REC_DTYPE.itemsize == 1088, REC_DTYPE.itemsize
         st = np.zeros(5, dtype=np.int64)
         cnt = np.zeros(len(COUNTER_KEYS), dtype=np.uint64)
         rc = self.L.orc_map_se(self.h, C.byref(prm), seq.ctypes.data, qual.ctypes.data, ln.ctypes.data, stride, n,
@@ -159,7 +159,7 @@ class OrcIndex:
         n, stride = a[0].shape
         s2 = np.zeros_like(a[2]); s2[:, :L] = comp[a[2][:, :L]][:, ::-1]
         recs = np.zeros(n, dtype=PE_REC_DTYPE)
-        assert PE_REC_DTYPE.itemsize == 584, PE_REC_DTYPE.itemsize
+        assert PE_REC_DTYPE.itemsize == 2120, PE_REC_DTYPE.itemsize
         st = np.zeros(5, dtype=np.int64)
         cnt = np.zeros(len(COUNTER_KEYS), dtype=np.uint64)
         rc = self.L.orc_map_pe(self.h, C.byref(prm), a[0].ctypes.data, a[1].ctypes.data, s2.ctypes.data, a[3].ctypes.data, L, L, stride, n,

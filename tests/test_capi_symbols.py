@@ -60,3 +60,17 @@ def test_device_index_builder_fails_loudly_without_a_gpu(tmp_path):
     fa.write_text(">c\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
     assert capi.lib().bmbs_index_build_device(0, str(fa).encode(), str(fa).encode(), 1) == -19
     assert not (tmp_path / "g.fa.index").exists()
+
+
+def test_max_cigar_ops_bound_follows_the_penalties():
+    """host arithmetic only: 2k + 8 slots with the default penalties, more when gaps are cheaper than mismatches, -1 for bad lengths"""
+    import ctypes as C
+    from bitmapperbs_amd import capi
+    lib = capi.lib()
+    assert lib.bmbs_max_cigar_ops(None, 150) == 2 * 12 + 8          # -e 0.08 default: k = 12
+    assert lib.bmbs_max_cigar_ops(None, 0) == -1 and lib.bmbs_max_cigar_ops(None, 1001) == -1
+    p = capi.default_params(e_f=0.08, mp_max=9, mp_min=8, gap_open=1, gap_ext=3)
+    k = int(0.08 * 116)
+    assert lib.bmbs_max_cigar_ops(C.byref(p), 116) == 2 * (k * 9 // 4) + 8
+    p = capi.default_params(e_f=0.04)
+    assert lib.bmbs_max_cigar_ops(C.byref(p), 150) == 2 * 6 + 8
