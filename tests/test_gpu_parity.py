@@ -822,6 +822,24 @@ def test_cheap_gaps_many_cigar_operations(env, mode):
 
 
 @pytest.mark.gpu
+def test_fuzzed_files_and_options_equal_the_reference_binary(tmp_path):
+    """eight fixed draws of tools/fuzz_e2e.py: random FASTQ files and --search options through bmbs_search (GPU) and through the
+    real reference binary (oracle/_ref/bitmapperBS, -t 1) -- same SAM body, same --mapstats.  Independent of the oracle.  The
+    tool ran 60 + 400 such trials on the MI355X box in round 2 (profiles/r02_fuzz_e2e.txt)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_e2e", os.path.join(ROOT, "tools", "fuzz_e2e.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    if not os.path.exists(fz.REF):
+        pytest.skip("oracle/_ref/bitmapperBS has not travelled to this box")
+    env = fz.make_env(str(tmp_path))
+    rng = np.random.default_rng(99)
+    for i in range(8):
+        t = fz.draw(rng)
+        bad, lines = fz.run_trial(t, env, str(tmp_path))
+        assert not bad, (t, bad[:2])
+
+
+@pytest.mark.gpu
 def test_shared_index_contexts_map_concurrently(env):
     """bmbs_index_share: three contexts on one attached index, driven by three host threads at once, give the oracle's records"""
     from concurrent.futures import ThreadPoolExecutor

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""tools/fuzz_e2e.py [--trials N] [--seed S] -- file-level randomised parity against the REAL reference binary
+(oracle/_ref/bitmapperBS, which travels to the GPU box): random FASTQ files (read length 30-250, trimmed records, letters outside
+ACGT, lower case) and random `--search` options (-e, --mp_max/--mp_min/--np, --gap_open/--gap_extension, --min/--max, --sensitive,
+--pbat, --unmapped_out, --ambiguous_out) are mapped by the reference on the host cores (-t 1: input order) and by bmbs_search on
+the GPU; the SAM bodies (everything but @PG) and the --mapstats files must be the same bytes.  The oracle is not involved."""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS")
+DRV = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
+
+
+def body(path):
+    return [l for l in open(path, "rb") if not l.startswith(b"@PG")]
+
+
+def write_fq(path, reads, lens, rng, lower):
+    seq, qual = reads["seq"], reads["qual"]
+    with open(path, "wb") as f:
+        for i in range(seq.shape[0]):
+            s = seq[i, :lens[i]].tobytes()
+            if lower and rng.random() < 0.3:
+                s = s.lower()
+            f.write(b"@r%d some comment\n" % i + s + b"\n+\n" + qual[i, :lens[i]].tobytes() + b"\n")
+
+
+def draw(rng):
+    mode = ["se", "se_pbat", "pe", "pes"][int(rng.integers(0, 4))]
+    L = int(rng.choice([int(rng.integers(30, 70)), int(rng.integers(70, 160)), int(rng.integers(160, 251))]))
+    mp_max = int(rng.integers(2, 9))
+    goe_open = int(rng.integers(2, 9))
+    opt = ["-e", str(float(rng.choice([0.02, 0.04, 0.08, 0.1, 0.12])))]
+    if rng.random() < 0.6:
+        opt += ["--mp_max", str(mp_max), "--mp_min", str(int(rng.integers(0, mp_max + 1))), "--np", str(int(rng.integers(0, 3)))]
+    if rng.random() < 0.5:
+        opt += ["--gap_open", str(goe_open), "--gap_extension", str(int(rng.integers(1, 5)))]
+    if rng.random() < 0.4:
+        opt += ["--unmapped_out"]
+    if rng.random() < 0.4:
+        opt += ["--ambiguous_out"]
+    t = dict(mode=mode, L=L, n=int(rng.integers(1500, 5000)), seed=int(rng.integers(1, 1 << 30)), sub=float(rng.choice([0.0, 0.01, 0.04, 0.07])),
+             indel=float(rng.choice([0.0, 0.001, 0.003])), n_rate=float(rng.choice([0.0, 0.002, 0.02])), mixed=bool(rng.integers(0, 2)),
+             lower=bool(rng.integers(0, 4) == 0), opt=opt)
+    if mode in ("pe", "pes"):
+        # Not drawn: pairs whose mates have threshold k = 0.  new_faster_verify_pairs (Schema.cpp:15773-15950) starts from
+        # best_sum_err = 4k + 2 and, for a pair whose error sum EQUALS that start value, counts the pair without ever setting
+        # best_pair_1/2_index: the reference then reads two uninitialised stack words.  Reachable only with k = 0 and both mates
+        # on the 1-mismatch exit (err = 1 whatever k is); in the first 400-trial run the reference printed nothing for four such
+        # pairs in one trial and died with SIGSEGV in another (profiles/r02_fuzz_e2e.txt, trials 52 and 58).  Undefined in the
+        # reference, so not pinnable; the oracle and the product take indices 0, 0 and print the pair.
+        shortest = max(20, L // 3) if t["mixed"] else L
+        e = float(t["opt"][1])
+        while int(e * shortest) < 1:
+            e = round(e + 0.02, 2)
+        t["opt"][1] = str(e)
+        mx = int(rng.choice([400, 500, 700]))
+        t["opt"] += ["--min", str(int(rng.choice([0, 0, 80]))), "--max", str(mx)]
+        t["ins_hi"] = max(L + 40, mx + int(rng.integers(-50, 60)))
+        if mode == "pes":
+            t["opt"] += ["--sensitive"]
+    if mode == "se_pbat":
+        t["opt"] += ["--pbat"]
+    return t
+
+
+def run_trial(t, env, wd):
+    from bitmapperbs_amd import synth
+    rng = np.random.default_rng(t["seed"])
+    L, n = t["L"], t["n"]
+    if t["mode"].startswith("se"):
+        r = synth.make_reads_se(env["chroms"], n=n, L=L, seed=t["seed"], sub=t["sub"], indel=t["indel"], qual="random", n_rate=t["n_rate"])
+        lens = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
+        fq = os.path.join(wd, "r.fq"); write_fq(fq, r, lens, rng, t["lower"])
+        inp = ["--seq", fq]
+    else:
+        m1, m2 = synth.make_reads_pe(env["chroms"], n=n, L=L, seed=t["seed"], sub=t["sub"], indel=t["indel"], qual="random", ins_hi=t["ins_hi"])
+        m2f = m2                                   # make_reads_pe returns mate 2 as sequenced, i.e. as the FASTQ file holds it
+        if t["n_rate"]:
+            for mm in (m1, m2f):
+                pos = rng.random(mm["seq"].shape) < t["n_rate"]
+                mm["seq"][pos] = np.frombuffer(b"NNNRY", dtype=np.uint8)[rng.integers(0, 5, int(pos.sum()))]
+        l1 = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
+        l2 = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
+        f1 = os.path.join(wd, "r_1.fq"); f2 = os.path.join(wd, "r_2.fq")
+        write_fq(f1, m1, l1, rng, t["lower"]); write_fq(f2, m2f, l2, rng, t["lower"])
+        inp = ["--seq1", f1, "--seq2", f2]
+    outs = {}
+    for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", DRV, ["-t", "8", "--batch", "1777"])):
+        out = os.path.join(wd, who + ".sam"); ms = os.path.join(wd, who + ".ms")
+        for f in (out, ms):
+            if os.path.exists(f):
+                os.unlink(f)
+        p = subprocess.run([exe, "--search", env["fa"]] + inp + t["opt"] + ["-o", out, "--mapstats", ms] + extra, capture_output=True, text=True, cwd=wd)
+        if p.returncode:
+            return ["%s exit code %d: %s" % (who, p.returncode, p.stderr[-300:])], 0
+        outs[who] = (body(out), open(ms).read() if os.path.exists(ms) else "")
+    a, b = outs["ref"], outs["gpu"]
+    bad = []
+    if len(a[0]) != len(b[0]):
+        bad.append("line count %d vs %d" % (len(a[0]), len(b[0])))
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        if x != y:
+            bad.append("line %d:\n  ref %r\n  gpu %r" % (i, x[:300], y[:300]))
+            if len(bad) >= 3:
+                break
+    if a[1] != b[1]:
+        bad.append("mapstats differ:\n%s---\n%s" % (a[1], b[1]))
+    return bad, sum(1 for l in a[0] if not l.startswith(b"@"))
+
+
+def make_env(wd):
+    from bitmapperbs_amd import synth, mapper
+    from common import plant_repeats
+    names, chroms = synth.make_genome(1_500_000, 3, seed=77)
+    plant_repeats(chroms, seed=78)
+    fa = os.path.join(wd, "g.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=8)
+    return dict(fa=fa, chroms=chroms)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_e2e.json"))
+    a = ap.parse_args()
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/bitmapperBS is not here (oracle/build_ref.sh builds it where /root/reference exists)")
+    rng = np.random.default_rng(a.seed)
+    fails = []
+    with tempfile.TemporaryDirectory() as wd:
+        env = make_env(wd)
+        for i in range(a.trials):
+            t = draw(rng)
+            bad, lines = run_trial(t, env, wd)
+            print("trial %3d %-7s L=%3d n=%4d mixed=%d records=%5d %s  %s" % (i, t["mode"], t["L"], t["n"], t["mixed"], lines, "SAME" if not bad else "DIFF", " ".join(t["opt"])), flush=True)
+            if bad:
+                print("\n".join(bad)[:1500], flush=True)
+                fails.append(dict(trial=t, first=bad[:3]))
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(dict(trials=a.trials, seed=a.seed, failures=fails), open(a.out, "w"), indent=1)
+    print("%d trials, %d with differences" % (a.trials, len(fails)))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
