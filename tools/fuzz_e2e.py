@@ -95,7 +95,9 @@ def run_trial(t, env, wd):
         write_fq(f1, m1, l1, rng, t["lower"]); write_fq(f2, m2f, l2, rng, t["lower"])
         inp = ["--seq1", f1, "--seq2", f2]
     outs = {}
-    for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", DRV, ["-t", "8", "--batch", "1777"])):
+    # the driver's own knobs vary too: batch size (records per library call), host threads, contexts per device
+    drv_extra = ["-t", str(int(rng.choice([1, 3, 8, 16]))), "--batch", str(int(rng.choice([97, 333, 1777, 50000]))), "--contexts", str(int(rng.choice([1, 2, 3])))]
+    for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", DRV, drv_extra)):
         out = os.path.join(wd, who + ".sam"); ms = os.path.join(wd, who + ".ms")
         for f in (out, ms):
             if os.path.exists(f):
