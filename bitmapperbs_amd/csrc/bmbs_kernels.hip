@@ -3026,6 +3026,14 @@ DEVI u32 pk_make(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16);
 DEVI int pk_lo(u32 x) { return (int)(short)(x & 0xffffu); }
 DEVI int pk_hi(u32 x) { return (int)x >> 16; }
 #define SW2_MINF (-16000)
+// the trace nibble (bit 0 m < e, bit 1 h < f, bit 2 e extended, bit 3 f extended) of band cell b, job j, from the u64 trace word
+// that holds cells 8 (b >> 3) .. + 7 (layout: see the cell loop of k_align_sw2)
+DEVI int sw2_trace_nibble(u64 word, int b, int j)
+{
+    const u32 w = (u32)(word >> (32 * ((b >> 2) & 1))) >> (b & 3);
+    const int nb = 8 * j;                       // job B's four nibbles sit two nibbles above job A's
+    return (int)(((w >> nb) & 1u) | (((w >> (nb + 16)) & 1u) << 1) | (((w >> (nb + 4)) & 1u) << 2) | (((w >> (nb + 20)) & 1u) << 3));
+}
 
 // EXACT: the batch's threshold k equals KB, so the band width is a compile-time constant and every "is this cell inside the
 // band" select / branch of the unrolled row disappears (the usual case: KB is instantiated for the thresholds the default -e
@@ -3153,8 +3161,9 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
                 int mA, mB;
                 asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mA) : "v"(yA), "n"(4 * (b & 7)));
                 asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mB) : "v"(yB), "n"(4 * (b & 7)));
-                const u32 mk = ((u32)mA & 0xffffu) | ((u32)mB & 0xffff0000u);
-                const u32 sc = misP & ~mk;
+                u32 mk, sc;
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(mk) : "s"(0xffffu), "v"(mA), "v"(mB));          // A's mask in the low half, B's in the high
+                asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(sc) : "v"(mk), "v"(misP));                        // misP & ~mk
                 const u32 m = pk_add(RH[b], sc);
                 u32 e = RE[b];
                 const u32 t1 = pk_sub(m, e);                 // sign: m < e
@@ -3170,13 +3179,15 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
                 f = pk_max(f, tt);
                 if (b > 0) { RH[b - 1] = h1; RE[b - 1] = e; }
                 h1 = h;
-                // trace nibble per job: bit 0 m < e, bit 1 h < f (then bit 0 is ignored), bit 2 e extended, bit 3 f extended
-                u32 z = (t1 >> 15) & 0x00010001u;
-                z |= (t2 >> 14) & 0x00020002u;
-                z |= (t3 >> 13) & 0x00040004u;
-                z |= (t4 >> 12) & 0x00080008u;
-                const u32 byte = (z | (z >> 12)) & 0xffu;
-                tw[b >> 3] |= (u64)byte << (8 * (b & 7));
+                // The four comparison results of both jobs are the sign bits of t1..t4 (bits 15 and 31).  Two v_perm_b32 bring the eight
+                // bytes that hold them together, two shift + mask steps put one sign per nibble, and the cell's eight flags go to bit
+                // (b & 3) of the eight nibbles of the 32-bit trace word that four consecutive cells share -- seven instructions
+                // per cell pair where shifting and masking the four differences one by one took twelve.  Nibble order in the word:
+                // t1A t3A t1B t3B t2A t4A t2B t4B (t1: m < e, t2: h < f, t3: e extended, t4: f extended); sw2_trace_nibble undoes it.
+                const u32 P = __builtin_amdgcn_perm(t2, t1, 0x07050301u);          // bytes t1.1 t1.3 t2.1 t2.3
+                const u32 Q = __builtin_amdgcn_perm(t4, t3, 0x07050301u);          // bytes t3.1 t3.3 t4.1 t4.3
+                const u32 x = ((P >> 7) & 0x01010101u) | ((Q >> 3) & 0x10101010u);
+                if ((b >> 2) & 1) tw[b >> 3] |= (u64)(x << (b & 3)) << 32; else tw[b >> 3] |= (u64)(x << (b & 3));
             }
         }
 #pragma unroll
@@ -3224,7 +3235,7 @@ k_align_sw2(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const 
             while (i >= 0 && kk >= 0) {
                 const int b = kk - i;
                 if ((b >> 3) != q) { q = b >> 3; refill(); }
-                const int d = (int)((tb[0] >> (8 * (b & 7) + 4 * j)) & 15);
+                const int d = sw2_trace_nibble(tb[0], b, j);
                 which = which == 0 ? ((d & 2) ? 2 : (d & 1)) : which == 1 ? ((d >> 2) & 1) : ((d >> 3) & 1) * 2;
                 if (which == 2) { push(1, 1); --kk; continue; }
                 if (which == 0) { push(0, 1); --kk; } else push(2, 1);
