@@ -454,8 +454,10 @@ def file_to_file_rate(args, cfg, fa, L):
     if not os.path.exists(drv) or not all(os.path.exists(f) for f in files):
         return None
     rec_bytes = 2 * L + 15                      # write_fastq_sample: '@s%08d\n' + L + '\n+\n' + L + '\n'
-    # the cpu_baseline sample four times over: a run of a few tenths of a second is mostly pipeline fill and first-call allocations
-    REP = 4
+    # the cpu_baseline sample twice over: a run of a few tenths of a second is mostly pipeline fill and first-call allocations, while
+    # four times over (16 GB of SAM on configs[2]) ran into the box's dirty-page throttling in some runs (20.7 M reads/s in one, 7.6 in
+    # the next; the /dev/null run beside it 53-59 in both)
+    REP = 2
     big = [f[:-3] + "_x%d.fq" % REP for f in files]
     for src, dst in zip(files, big):
         with open(dst, "wb") as o:

@@ -302,7 +302,8 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     ENS(c, c->need_sw, nj * 4); ENS(c, c->sw_off, (nj + 1) * 8); ENS(c, c->sw_job, nj * 4);
     if (!n_jobs) return BMBS_OK;
     // Three forms of the DP (BMBS_SW=reg2|reg|wave), all with identical results:
-    //  reg2 (default for k >= 9): one PAIR of jobs per lane in packed 16-bit arithmetic, band in registers, trace bytes in HBM
+    //  reg2 (default for k >= 5; it was k >= 9 until the row loop lost a third of its instructions: k = 6 now 0.69 vs 0.73 ms):
+    //        one PAIR of jobs per lane in packed 16-bit arithmetic, band in registers, trace bytes in HBM
     //        (k_align_sw2) -- the DP is VALU-issue bound, so instructions per cell is what counts: 30 per cell against 52.  Needs
     //        one read length per batch and scores that fit 16 bits.  Measured against `reg` on 10 M-pair / 10 M-read batches:
     //        k = 20 (250 bp) 2.63 vs 3.50 ms, k = 12 2.53 vs 2.69 ms, k = 6 1.02 vs 0.83 ms (narrow bands: the per-row work of two
@@ -314,7 +315,7 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     const char* swm = getenv("BMBS_SW");
     const bool wave_form = swm && !strcmp(swm, "wave");
     int maxpen = std::max(std::max(c->prm.mp_max, c->prm.np), c->prm.gap_open + c->prm.gap_ext);
-    const bool packed = !wave_form && !(swm && !strcmp(swm, "reg")) && (k >= 9 || (swm && !strcmp(swm, "reg2"))) && !gm.len && c->prm.gap_ext < 256 && (L + 64) * maxpen < 12000 &&
+    const bool packed = !wave_form && !(swm && !strcmp(swm, "reg")) && (k >= 5 || (swm && !strcmp(swm, "reg2"))) && !gm.len && c->prm.gap_ext < 256 && (L + 64) * maxpen < 12000 &&
                         c->prm.mp_min >= 0 && c->prm.gap_ext >= 0 && c->prm.gap_open >= 0 && c->prm.np >= 0;
     const bool reg_form = !wave_form;
     if (reg_form) {
