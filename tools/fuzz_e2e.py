@@ -24,9 +24,32 @@ def body(path):
     return [l for l in open(path, "rb") if not l.startswith(b"@PG")]
 
 
+def bam_body(path):
+    """the BAM record stream: BGZF blocks inflated, header (whose text holds @PG) parsed away"""
+    import gzip
+    import struct
+    raw = gzip.open(path, "rb").read()
+    assert raw[:4] == b"BAM\1", raw[:4]
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text]
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]; o += 4
+    refs = []
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", raw, o)[0]; o += 4
+        refs.append(raw[o:o + l_name + 4]); o += l_name + 4
+    head = [l for l in text.split(b"\n") if l and not l.startswith(b"@PG")] + refs
+    recs = []
+    while o < len(raw):
+        bs = struct.unpack_from("<i", raw, o)[0]
+        recs.append(raw[o:o + 4 + bs]); o += 4 + bs
+    return head + recs
+
+
 def write_fq(path, reads, lens, rng, lower):
+    import gzip
     seq, qual = reads["seq"], reads["qual"]
-    with open(path, "wb") as f:
+    with (gzip.open(path, "wb", compresslevel=1) if path.endswith(".gz") else open(path, "wb")) as f:
         for i in range(seq.shape[0]):
             s = seq[i, :lens[i]].tobytes()
             if lower and rng.random() < 0.3:
@@ -70,6 +93,9 @@ def draw(rng):
             t["opt"] += ["--sensitive"]
     if mode == "se_pbat":
         t["opt"] += ["--pbat"]
+    t["gz"] = bool(rng.integers(0, 5) == 0)            # gzipped FASTQ input
+    if rng.integers(0, 5) == 0:
+        t["opt"] += ["--bam"]
     return t
 
 
@@ -80,7 +106,7 @@ def run_trial(t, env, wd):
     if t["mode"].startswith("se"):
         r = synth.make_reads_se(env["chroms"], n=n, L=L, seed=t["seed"], sub=t["sub"], indel=t["indel"], qual="random", n_rate=t["n_rate"])
         lens = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
-        fq = os.path.join(wd, "r.fq"); write_fq(fq, r, lens, rng, t["lower"])
+        fq = os.path.join(wd, "r.fq" + (".gz" if t.get("gz") else "")); write_fq(fq, r, lens, rng, t["lower"])
         inp = ["--seq", fq]
     else:
         m1, m2 = synth.make_reads_pe(env["chroms"], n=n, L=L, seed=t["seed"], sub=t["sub"], indel=t["indel"], qual="random", ins_hi=t["ins_hi"])
@@ -91,7 +117,7 @@ def run_trial(t, env, wd):
                 mm["seq"][pos] = np.frombuffer(b"NNNRY", dtype=np.uint8)[rng.integers(0, 5, int(pos.sum()))]
         l1 = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
         l2 = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
-        f1 = os.path.join(wd, "r_1.fq"); f2 = os.path.join(wd, "r_2.fq")
+        f1 = os.path.join(wd, "r_1.fq" + (".gz" if t.get("gz") else "")); f2 = os.path.join(wd, "r_2.fq" + (".gz" if t.get("gz") else ""))
         write_fq(f1, m1, l1, rng, t["lower"]); write_fq(f2, m2f, l2, rng, t["lower"])
         inp = ["--seq1", f1, "--seq2", f2]
     outs = {}
@@ -105,7 +131,7 @@ def run_trial(t, env, wd):
         p = subprocess.run([exe, "--search", env["fa"]] + inp + t["opt"] + ["-o", out, "--mapstats", ms] + extra, capture_output=True, text=True, cwd=wd)
         if p.returncode:
             return ["%s exit code %d: %s" % (who, p.returncode, p.stderr[-300:])], 0
-        outs[who] = (body(out), open(ms).read() if os.path.exists(ms) else "")
+        outs[who] = (bam_body(out) if "--bam" in t["opt"] else body(out), open(ms).read() if os.path.exists(ms) else "")
     a, b = outs["ref"], outs["gpu"]
     bad = []
     if len(a[0]) != len(b[0]):
@@ -117,7 +143,7 @@ def run_trial(t, env, wd):
                 break
     if a[1] != b[1]:
         bad.append("mapstats differ:\n%s---\n%s" % (a[1], b[1]))
-    return bad, sum(1 for l in a[0] if not l.startswith(b"@"))
+    return bad, sum(1 for l in a[0] if not l.startswith(b"@")) if "--bam" not in t["opt"] else len(a[0])
 
 
 def make_env(wd):
