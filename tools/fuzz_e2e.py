@@ -146,11 +146,18 @@ def run_trial(t, env, wd):
     return bad, sum(1 for l in a[0] if not l.startswith(b"@")) if "--bam" not in t["opt"] else len(a[0])
 
 
-def make_env(wd):
+def make_env(wd, big=False):
     from bitmapperbs_amd import synth, mapper
     from common import plant_repeats
-    names, chroms = synth.make_genome(1_500_000, 3, seed=77)
-    plant_repeats(chroms, seed=78)
+    if big:
+        # the BIG golden family's genome: 5 Mb with ~7 000 planted repeat copies (long candidate lists, vote-order ties, ambiguity)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+        mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+        names, chroms = mg.big_genome()
+    else:
+        names, chroms = synth.make_genome(1_500_000, 3, seed=77)
+        plant_repeats(chroms, seed=78)
     fa = os.path.join(wd, "g.fa")
     synth.write_fasta(fa, names, chroms)
     mapper.Index.build(fa, fa, threads=8)
@@ -161,6 +168,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="the repeat-rich 5 Mb genome of the BIG golden family instead of the 1.5 Mb one")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_e2e.json"))
     a = ap.parse_args()
     if not os.path.exists(REF):
@@ -168,7 +176,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     fails = []
     with tempfile.TemporaryDirectory() as wd:
-        env = make_env(wd)
+        env = make_env(wd, a.big)
         for i in range(a.trials):
             t = draw(rng)
             bad, lines = run_trial(t, env, wd)
