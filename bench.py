@@ -373,6 +373,53 @@ def timed(job, steps, warmup, min_seconds, world, dist, torch, cdev="cuda"):
     return dt, passes, kern_ms
 
 
+def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
+    """the main configuration's launches dealt to TWO contexts on one attached index (bmbs_index_share: own stream and work buffers
+    each), driven by two host threads -- how bmbs_search runs a device by default.  Kernels of different launches overlap (the DP
+    and Myers kernels are issue-bound, the seeding kernels wait on memory), and the host round trips of one call hide behind the
+    other.  A secondary key: `value` and the roofline are the single-context numbers."""
+    import threading
+    from bitmapperbs_amd import mapper
+    extra = [mapper.Mapper(ix, device=local, share=m, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0) for _ in range(n_ctx - 1)]
+    ctxs = [(m, job.res_d, job.cig_d)] + [(x, torch.empty_like(job.res_d), torch.empty_like(job.cig_d)) for x in extra]
+
+    def launch(c, b):
+        mm, res, cig = c
+        t = job.batches[b]
+        if cfg["pe"]:
+            mm.map_pe_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), job.L, job.stride, job.n, res.data_ptr(), cig.data_ptr(), job.cig_cap)
+        else:
+            mm.map_se_device(t[0].data_ptr(), t[1].data_ptr(), job.L, job.stride, job.n, res.data_ptr(), cig.data_ptr(), job.cig_cap)
+    for c in ctxs:                                   # the second context allocates its work buffers here, not in the timed part
+        launch(c, 0); c[0].sync()
+    torch.cuda.synchronize()
+    total = steps * len(job.batches)
+    nxt = [0]
+    lock = threading.Lock()
+
+    def worker(c):
+        while True:
+            with lock:
+                i = nxt[0]; nxt[0] += 1
+            if i >= total:
+                break
+            launch(c, i % len(job.batches))
+        c[0].sync()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+    for t in th: t.start()
+    for t in th: t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for x in extra:
+        x.close()
+    del ctxs
+    torch.cuda.empty_cache()
+    return {"what": "main configuration, launches dealt to %d contexts sharing one index (a stream, work buffers and a host thread each; bmbs_search runs 2 per device by default)" % n_ctx,
+            "value": round(job.reads_per_launch * total / dt / 1e6, 2), "unit": "Mreads/s", "timed_s": round(dt, 3),
+            "ms_per_launch": round(dt / total * 1e3, 3)}
+
+
 def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3):
     """a short secondary measurement on its own index / mapper: -> dict(value, ms_per_launch, ...)"""
     import torch
@@ -628,6 +675,11 @@ def main():
                     out["e2e"] = {"host_buffers": host_buffer_rate(m, job, torch)}
                 except Exception as ex:
                     out["e2e"] = {"error": repr(ex)}
+                try:
+                    out["two_contexts"] = two_context_rate(m, ix, job, cfg, local, torch, n_ctx=2)
+                    out["three_contexts"] = two_context_rate(m, ix, job, cfg, local, torch, n_ctx=3)
+                except Exception as ex:
+                    out["two_contexts"] = {"error": repr(ex)}
         else:
             out["cpu_baseline"] = None
     m.close(); ix.close()
