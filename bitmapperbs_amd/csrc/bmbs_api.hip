@@ -32,7 +32,7 @@ struct bmbs_ctx {
     DevIndex ix;
     u64 rows = 0;
     // index buffers
-    DevBuf occ, hash, sa, gen2, chrom_start, t20, occ_super;
+    DevBuf occ, hash, sa, gen2, chrom_start, t20;
     // LUTs
     DevBuf pen_lut, mapq_lut;
     bool luts_ready = false;
@@ -635,7 +635,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wavelog), &d, sizeof(d));
         release(c->wavelog_buf); release(c->wavelog_count);
     }
-    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->occ_super, &c->pen_lut, &c->mapq_lut, &c->verdict,
+    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
@@ -670,10 +670,23 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     if (v->sa_length != rows) { c->err = "index view: sa_length != 2*ref_len + 1"; return BMBS_EINVAL; }
     if (rows >= (1ull << 36)) { c->err = "genome too large: rows must fit the 36-bit fields of the 16-mer table"; return BMBS_EINVAL; }
     if (v->n_chrom < 1 || v->n_chrom > 32767) { c->err = "index view: n_chrom must be 1..32767 (bmbs_result.chrom is a 16-bit field)"; return BMBS_EINVAL; }
-    // texts of 2^32 symbols and more (GRCh38) take the wide forms: 64-bit suffix array, Occ counts relative to the reference's
-    // super-block table; BMBS_WIDE=1 forces them on a small index (tests)
+    // texts of 2^32 symbols and more (GRCh38) take the wide forms: 64-bit suffix array, Occ counts relative to super-blocks of 2^31
+    // symbols whose sums travel in the DevIndex; BMBS_WIDE=1 forces them on a small index and BMBS_SUPER_SHIFT=s (>= 16) makes the
+    // super-blocks small enough for such an index to have several (tests)
     const char* wide_env = getenv("BMBS_WIDE");
     const bool wide = rows >= (1ull << 32) || (wide_env && !strcmp(wide_env, "1"));
+    SuperSums sup; sup.shift = 0;
+    for (int q = 0; q < 4; q++) { sup.T[q] = 0; sup.A[q] = 0; }
+    if (wide) {
+        const char* ss = getenv("BMBS_SUPER_SHIFT");
+        sup.shift = ss ? atoi(ss) : 31;
+        if (sup.shift < 16 || sup.shift > 31 || (n >> sup.shift) >= 4) { c->err = "index attach: the text needs more than four Occ super-blocks"; return BMBS_EINVAL; }
+        for (u64 S = 0; S < 4 && (S << sup.shift) <= n; S++) {
+            const u64 e = ((S << sup.shift) >> 16) * 2;
+            if (e + 1 >= v->high_occ_words) break;
+            sup.T[S] = v->high_occ[e]; sup.A[S] = v->high_occ[e + 1];
+        }
+    }
     // upload the reference layouts verbatim, re-pack on the device, drop the originals
     DevBuf t_bwt, t_ho, t_hh, t_hl, t_sa, t_fl, t_pac;
     // the staging copies are released on every path out of this function (also the HIPCHK early returns)
@@ -706,17 +719,16 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     std::vector<u64> cs(v->n_chrom + 1, 0);
     for (int i = 0; i < v->n_chrom; i++) cs[i + 1] = cs[i] + v->chrom_len[i];
     if (ensure(c, c->occ, n_blk * 16) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * (wide ? 8 : 4)) ||
-        ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8) ||
-        (wide && ensure(c, c->occ_super, v->high_occ_words * 8 + 64))) return BMBS_ENOMEM;
-    if (wide) HIPCHK(c, hipMemcpyAsync(c->occ_super.p, t_ho.p, v->high_occ_words * 8, hipMemcpyDeviceToDevice, c->stream));
+        ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8)) return BMBS_ENOMEM;
     HIPCHK(c, hipMemcpyAsync(c->chrom_start.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, wide ? 1 : 0, c->occ.as<uint4>());
+    hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, sup, c->occ.as<uint4>());
     hipLaunchKernelGGL(k_repack_hash, dim3(nblk(v->hash_entries, 256)), dim3(256), 0, c->stream, R, v->hash_entries, c->hash.as<u64>());
     hipLaunchKernelGGL(k_build_gen2, dim3(nblk(gen_words, 256)), dim3(256), 0, c->stream, R, G, gen_words, c->gen2.as<u64>());
     DevIndex ix;
     ix.occ = c->occ.as<uint4>(); ix.hash = c->hash.as<u64>(); ix.gen2 = c->gen2.as<u64>();
     ix.sa = wide ? nullptr : c->sa.as<u32>(); ix.sa64 = wide ? c->sa.as<u64>() : nullptr;
-    ix.occ_super = wide ? c->occ_super.as<u64>() : nullptr;
+    ix.sup_shift = sup.shift;
+    for (int q = 0; q < 4; q++) { ix.supT[q] = sup.T[q]; ix.supA[q] = sup.A[q]; }
     ix.chrom_start = c->chrom_start.as<u64>(); ix.G = G; ix.total = n; ix.shapline = v->shapline;
     ix.C[0] = v->nacgt[0]; ix.C[1] = v->nacgt[1]; ix.C[2] = v->nacgt[2]; ix.n_chrom = v->n_chrom;
     hipLaunchKernelGGL(k_expand_sa, dim3(nblk(std::min<u64>(rows, 1ull << 30), 256)), dim3(256), 0, c->stream, ix, R, rows, wide ? nullptr : c->sa.as<u32>(),

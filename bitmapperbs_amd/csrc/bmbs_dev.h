@@ -31,7 +31,11 @@ struct DevIndex {
     const u64*   hash;
     const u32*   sa;
     const u64*   sa64;          // texts of >= 2^32 symbols: 64-bit suffix array instead of sa
-    const u64*   occ_super;     // ... and the counts of occ are relative to this {T, A} table per 65 536 symbols
+    // ... and the counts of occ are relative to super-blocks of 2^sup_shift symbols (2^31: relative counts fit 32 bits, and a text of
+    // up to 2^33 symbols has at most four super-blocks) whose {T, A} sums travel IN this struct, i.e. in scalar registers: the
+    // reference's 65 536-symbol super-block table in memory cost one more request per rank query.  sup_shift == 0: absolute counts.
+    int          sup_shift;
+    u64          supT[4], supA[4];
     const u64*   gen2;
     const u64*   t20;           // optional: outcome of the first t_e extensions of every (16 + t_e)-mer (k_build_t20), else nullptr
     int          t_e;           // letters the table looks ahead: 4 (3^20 entries, 27.9 GB) or 5 (3^21 entries, 83.7 GB; GRCh38-size texts)

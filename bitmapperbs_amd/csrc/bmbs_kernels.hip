@@ -60,9 +60,15 @@ DEVI void wavelog_end(const WaveLogT& t, int kernel_id)
 
 // rank of T and of A in BWT stream [0, line): ONE aligned 16-byte load (see bmbs_dev.h).
 // Replaces get_occ_value* + the popcount tail of find_occ_fm_index (bwt.h:1007-1136, 1373-1465).
-// Texts of 2^32 symbols and more (GRCh38: 2G = 6.2 G): the block counts are relative to the 65 536-symbol super-block
-// table of the reference layout (ix.occ_super, 1.5 MB for GRCh38), the suffix array is 64-bit (ix.sa64); both pointers are
-// null for smaller texts and the branches are wave-uniform.
+// Texts of 2^32 symbols and more (GRCh38: 2G = 6.2 G): the block counts are relative to super-blocks of 2^31 symbols whose
+// sums sit in the DevIndex itself (scalar registers, picked by compare + select: no memory request), the suffix array is 64-bit
+// (ix.sa64); the branches are wave-uniform.
+DEVI void super_add(const DevIndex& ix, u64 line, u64& cT, u64& cA)
+{
+    const u32 S = (u32)(line >> ix.sup_shift);
+    cT += S == 0 ? ix.supT[0] : S == 1 ? ix.supT[1] : S == 2 ? ix.supT[2] : ix.supT[3];
+    cA += S == 0 ? ix.supA[0] : S == 1 ? ix.supA[1] : S == 2 ? ix.supA[2] : ix.supA[3];
+}
 DEVI void occ_TA(const DevIndex& ix, u64 line, u64& cT, u64& cA)
 {
     const uint4 h = ix.occ[line >> 5];
@@ -70,7 +76,7 @@ DEVI void occ_TA(const DevIndex& ix, u64 line, u64& cT, u64& cA)
     const u32 m = r ? (~0u << (32 - r)) : 0u;
     cT = (u64)h.x + __popc(h.z & m);
     cA = (u64)h.y + __popc(h.w & m);
-    if (ix.occ_super) { const ulonglong2 sv = *reinterpret_cast<const ulonglong2*>(ix.occ_super + ((line >> 16) << 1)); cT += sv.x; cA += sv.y; }
+    if (ix.sup_shift) super_add(ix, line, cT, cA);
 }
 DEVI u64 sa_at(const DevIndex& ix, u64 row) { return ix.sa64 ? ix.sa64[row] : (u64)ix.sa[row]; }
 
@@ -96,14 +102,7 @@ DEVI void lf_pair(const DevIndex& ix, u64& top, u64& bot, int c)
     const u32 mt = rt ? (~0u << (32 - rt)) : 0u, mb = rb ? (~0u << (32 - rb)) : 0u;
     u64 tT = (u64)ht.x + __popc(ht.z & mt), tA = (u64)ht.y + __popc(ht.w & mt);
     u64 bT = (u64)hb.x + __popc(hb.z & mb), bA = (u64)hb.y + __popc(hb.w & mb);
-    if (ix.occ_super) {
-        // the {T, A} pair of a super-block is one 16-byte load, and the interval's two ends nearly always share it: every load is a
-        // request to the memory pipeline whether it hits or not, and this table took four of the six requests of a step
-        const ulonglong2 st_ = *reinterpret_cast<const ulonglong2*>(ix.occ_super + ((lt >> 16) << 1));
-        ulonglong2 sb_ = st_;
-        if ((lb >> 16) != (lt >> 16)) sb_ = *reinterpret_cast<const ulonglong2*>(ix.occ_super + ((lb >> 16) << 1));
-        tT += st_.x; tA += st_.y; bT += sb_.x; bA += sb_.y;
-    }
+    if (ix.sup_shift) { super_add(ix, lt, tT, tA); super_add(ix, lb, bT, bA); }
     const u64 ct = c == 1 ? tT : (c == 2 ? tA : lt - tT - tA);
     const u64 cb = c == 1 ? bT : (c == 2 ? bA : lb - bT - bA);
     top = ix.C[c] + ct; bot = ix.C[c] + cb;
@@ -551,7 +550,8 @@ DEVI void ref_rank64(const RefIndexDev& R, u64 line, u64& cT, u64& cA)
 }
 
 // one 16-byte block per 32 BWT symbols: { u32 count(T) before, u32 count(A) before, u32 plane_T, u32 plane_A }
-__global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, int wide, uint4* out)
+struct SuperSums { int shift; u64 T[4], A[4]; };
+__global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, SuperSums sup, uint4* out)
 {
     const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
@@ -559,7 +559,8 @@ __global__ void k_repack_occ(RefIndexDev R, u64 n_stream, u64 n_blk, int wide, u
     const u64 s64 = s0 & ~63ull;          // the reference stores counters at every 64-boundary it reached (bwt.cpp:1437-1490)
     u64 cT = 0, cA = 0;
     ref_rank64(R, s64, cT, cA);
-    if (wide) { const u64 sb = (s64 >> 16) << 1; cT -= R.high_occ[sb]; cA -= R.high_occ[sb + 1]; }     // relative to the super-block
+    if (sup.shift) { const u32 S = (u32)(s64 >> sup.shift); cT -= S == 0 ? sup.T[0] : S == 1 ? sup.T[1] : S == 2 ? sup.T[2] : sup.T[3];
+                     cA -= S == 0 ? sup.A[0] : S == 1 ? sup.A[1] : S == 2 ? sup.A[2] : sup.A[3]; }     // relative to the super-block
     u32 pT = 0, pA = 0;
     if (s64 < n_stream) {
         const u64 wi = (s64 >> 7) * 5 + 1 + 2 * ((s64 & 127) >> 6);

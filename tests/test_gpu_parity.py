@@ -569,11 +569,15 @@ def test_map_pe_mixed_lengths_match_oracle(prm, env):
     m.close()
 
 
-def test_wide_index_forms_match_oracle(env, monkeypatch):
-    """texts of 2^32 symbols and more (GRCh38): 64-bit suffix array + super-block relative Occ counts, forced on the test
-    genome with BMBS_WIDE=1 (read by bmbs_index_attach)"""
+@pytest.mark.parametrize("super_shift", [None, "20"])
+def test_wide_index_forms_match_oracle(env, monkeypatch, super_shift):
+    """texts of 2^32 symbols and more (GRCh38): 64-bit suffix array + Occ counts relative to super-blocks whose sums travel in
+    the index descriptor, forced on the test genome with BMBS_WIDE=1 (read by bmbs_index_attach).  The default super-block of 2^31
+    symbols leaves this 3 M-symbol text with one; BMBS_SUPER_SHIFT=20 gives it three, as GRCh38 has at 2^31."""
     from bitmapperbs_amd import synth, mapper
     monkeypatch.setenv("BMBS_WIDE", "1")
+    if super_shift:
+        monkeypatch.setenv("BMBS_SUPER_SHIFT", super_shift)
     r = synth.make_reads_se(env["chroms"], n=20000, L=120, seed=41, sub=0.02, indel=0.002, qual="random", n_rate=0.002)
     m = mapper.Mapper(env["ix"], 0, e_f=0.08)
     res, pool = m.map_se(r["seq"], r["qual"], 120)
