@@ -42,6 +42,11 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--ambiguous_out")) P.ambiguous_out = 1;
             else if (!strcmp(argv[i], "--pbat")) P.pbat = 1;
             else if (!strcmp(argv[i], "--phred64")) P.q_base = 64;
+            else if (!strcmp(argv[i], "--mp_max") && i + 1 < argc) P.mp_max = atoi(argv[++i]);        // Process_CommandLines.cpp:126-130
+            else if (!strcmp(argv[i], "--mp_min") && i + 1 < argc) P.mp_min = atoi(argv[++i]);
+            else if (!strcmp(argv[i], "--np") && i + 1 < argc) P.np = atoi(argv[++i]);
+            else if (!strcmp(argv[i], "--gap_open") && i + 1 < argc) P.gap_open = atoi(argv[++i]);
+            else if (!strcmp(argv[i], "--gap_extension") && i + 1 < argc) P.gap_ext = atoi(argv[++i]);
             else if (!strcmp(argv[i], "--mapstats") && i + 1 < argc) mapstats = argv[++i];
             else if (!strcmp(argv[i], "--cl") && i + 1 < argc) cl = argv[++i];
             else if (!strcmp(argv[i], "-t") && i + 1 < argc) ++i;

@@ -240,3 +240,25 @@ def test_unpatched_O0_reference_writes_the_committed_goldens(kind, name, golden_
     assert p.returncode == 0, p.stderr[-2000:]
     mine = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert mine == gzip.open(gold, "rt").read()
+
+
+def test_oracle_cli_equals_reference_on_random_files_and_options(tmp_path):
+    """six fixed draws of tools/fuzz_e2e.py --oracle: random FASTQ files (lengths 30-250, trimmed records, letters outside ACGT,
+    lower case) and random --search options (-e, mismatch / N / gap penalties, insert bounds, --sensitive, --pbat, --unmapped_out,
+    --ambiguous_out) through the real reference binary (-t 1) and through the oracle's command line: same SAM body, same
+    mapstats.  Pins the restatement to the reference beyond the committed goldens' parameter sets (400 such trials ran in round 2:
+    profiles/r02_fuzz_oracle_vs_reference.txt)."""
+    import importlib.util
+    import numpy as np
+    from common import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_e2e", os.path.join(ROOT, "tools", "fuzz_e2e.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    if not os.path.exists(fz.REF):
+        pytest.skip("oracle/_ref/bitmapperBS is not built here")
+    fz.USE_ORACLE = True
+    env = fz.make_env(str(tmp_path))
+    rng = np.random.default_rng(31337)
+    for _ in range(6):
+        t = fz.draw(rng)
+        bad, lines = fz.run_trial(t, env, str(tmp_path))
+        assert not bad, (t, bad[:2])

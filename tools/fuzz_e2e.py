@@ -18,6 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS")
 DRV = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
+ORC = os.path.join(ROOT, "oracle", "bmbs_oracle")
+# --oracle: the second program is the oracle's command line instead of bmbs_search (no GPU needed): the same random files and options
+# pin the ORACLE to the real reference; no --bam / gzipped input there (the oracle writes SAM from plain FASTQ)
+USE_ORACLE = False
 
 
 def body(path):
@@ -93,8 +97,8 @@ def draw(rng):
             t["opt"] += ["--sensitive"]
     if mode == "se_pbat":
         t["opt"] += ["--pbat"]
-    t["gz"] = bool(rng.integers(0, 5) == 0)            # gzipped FASTQ input
-    if rng.integers(0, 5) == 0:
+    t["gz"] = bool(rng.integers(0, 5) == 0) and not USE_ORACLE            # gzipped FASTQ input
+    if rng.integers(0, 5) == 0 and not USE_ORACLE:
         t["opt"] += ["--bam"]
     return t
 
@@ -123,12 +127,13 @@ def run_trial(t, env, wd):
     outs = {}
     # the driver's own knobs vary too: batch size (records per library call), host threads, contexts per device
     drv_extra = ["-t", str(int(rng.choice([1, 3, 8, 16]))), "--batch", str(int(rng.choice([97, 333, 1777, 50000]))), "--contexts", str(int(rng.choice([1, 2, 3])))]
-    for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", DRV, drv_extra)):
+    for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", ORC if USE_ORACLE else DRV, [] if USE_ORACLE else drv_extra)):
         out = os.path.join(wd, who + ".sam"); ms = os.path.join(wd, who + ".ms")
         for f in (out, ms):
             if os.path.exists(f):
                 os.unlink(f)
-        p = subprocess.run([exe, "--search", env["fa"]] + inp + t["opt"] + ["-o", out, "--mapstats", ms] + extra, capture_output=True, text=True, cwd=wd)
+        head = [exe, "search", env["fa"]] if exe == ORC else [exe, "--search", env["fa"]]
+        p = subprocess.run(head + inp + t["opt"] + ["-o", out, "--mapstats", ms] + extra, capture_output=True, text=True, cwd=wd)
         if p.returncode:
             return ["%s exit code %d: %s" % (who, p.returncode, p.stderr[-300:])], 0
         outs[who] = (bam_body(out) if "--bam" in t["opt"] else body(out), open(ms).read() if os.path.exists(ms) else "")
@@ -147,7 +152,9 @@ def run_trial(t, env, wd):
 
 
 def make_env(wd, big=False):
-    from bitmapperbs_amd import synth, mapper
+    from bitmapperbs_amd import synth
+    if not USE_ORACLE:
+        from bitmapperbs_amd import mapper
     from common import plant_repeats
     if big:
         # the BIG golden family's genome: 5 Mb with ~7 000 planted repeat copies (long candidate lists, vote-order ties, ambiguity)
@@ -160,7 +167,10 @@ def make_env(wd, big=False):
         plant_repeats(chroms, seed=78)
     fa = os.path.join(wd, "g.fa")
     synth.write_fasta(fa, names, chroms)
-    mapper.Index.build(fa, fa, threads=8)
+    if USE_ORACLE:
+        subprocess.run([ORC, "index", fa], check=True, capture_output=True)      # the oracle's own index builder (pinned to the reference's files)
+    else:
+        mapper.Index.build(fa, fa, threads=8)
     return dict(fa=fa, chroms=chroms)
 
 
@@ -168,9 +178,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--oracle", action="store_true", help="compare the ORACLE's command line (CPU) with the reference instead of bmbs_search")
     ap.add_argument("--big", action="store_true", help="the repeat-rich 5 Mb genome of the BIG golden family instead of the 1.5 Mb one")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_e2e.json"))
     a = ap.parse_args()
+    global USE_ORACLE
+    USE_ORACLE = a.oracle
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/bitmapperBS is not here (oracle/build_ref.sh builds it where /root/reference exists)")
     rng = np.random.default_rng(a.seed)
