@@ -109,6 +109,11 @@ def run_trial(t, env, wd):
     L, n = t["L"], t["n"]
     if t["mode"].startswith("se"):
         r = synth.make_reads_se(env["chroms"], n=n, L=L, seed=t["seed"], sub=t["sub"], indel=t["indel"], qual="random", n_rate=t["n_rate"])
+        if t["mode"] == "se_pbat":
+            # a PBAT library reads the strand complementary to the bisulfite-converted one: hand over the reverse complement of the
+            # ordinary synthetic read so that --pbat (which maps the record's reverse complement) has something to find
+            comp = np.arange(256, dtype=np.uint8); comp[ord("A")] = ord("T"); comp[ord("T")] = ord("A"); comp[ord("C")] = ord("G"); comp[ord("G")] = ord("C")
+            r = dict(seq=comp[r["seq"][:, ::-1]].copy(), qual=r["qual"][:, ::-1].copy())
         lens = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
         fq = os.path.join(wd, "r.fq" + (".gz" if t.get("gz") else "")); write_fq(fq, r, lens, rng, t["lower"])
         inp = ["--seq", fq]
