@@ -324,12 +324,11 @@ class Job:
             self.m.map_se_device(t[0].data_ptr(), t[1].data_ptr(), self.L, self.stride, self.n, self.res_d.data_ptr(),
                                  self.cig_d.data_ptr(), self.cig_cap)
 
-    def step(self, kern_ms=None):
+    def step(self):
+        # nothing waits inside a step: the calls go to the context's lanes one behind the other (per-kernel HIP-event times
+        # are summed by the library as the calls complete: Mapper.profile_total)
         for b in range(len(self.batches)):
             self.launch(b)
-            if kern_ms is not None:
-                for name, ms in self.m.profile():
-                    kern_ms[name] = kern_ms.get(name, 0.0) + ms
         self.m.sync()
 
     def reads_per_step(self):
@@ -354,20 +353,23 @@ def timed(job, steps, warmup, min_seconds, world, dist, torch, cdev="cuda"):
         dist.all_reduce(pt, op=dist.ReduceOp.MAX)
         passes = int(pt.item())
     job.m.reset_stats()
+    job.m.profile_reset()
     job.m.sync()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kern_ms: dict[str, float] = {}
     t0 = time.perf_counter()
     for _ in range(steps):
         for _ in range(passes):
-            job.step(kern_ms)
+            job.step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     launches = steps * passes * len(job.batches)
+    # HIP events around every kernel of every call of the timed region (recorded on the lanes' own streams), summed per kernel name
+    # over the chunks of a call, averaged per launch = per API call
+    kern_ms, _calls = job.m.profile_total()
     for kname in kern_ms:
         kern_ms[kname] /= max(1, launches)
     return dt, passes, kern_ms

@@ -22,7 +22,7 @@ SYMBOLS = [
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
-    "bmbs_max_cigar_ops",
+    "bmbs_max_cigar_ops", "bmbs_retries", "bmbs_profile_total", "bmbs_profile_reset",
 ]
 
 
@@ -49,9 +49,9 @@ class IndexView(C.Structure):
 
 
 # numpy view of bmbs_result (32 bytes)
-RESULT_DTYPE = np.dtype([("pos", "<u8"), ("cigar_off", "<u4"), ("chrom", "<i2"), ("status", "u1"),
-                         ("mapq", "u1"), ("flag", "<u2"), ("nm", "<u2"), ("score", "<i2"),
-                         ("n_cigar", "u1"), ("path", "u1"), ("n_cand", "<u4"), ("reserved", "<u4")])
+RESULT_DTYPE = np.dtype([("pos", "<u8"), ("cigar_off", "<u4"), ("chrom", "<i4"), ("flag", "<u2"), ("nm", "<u2"),
+                         ("score", "<i2"), ("status", "u1"), ("mapq", "u1"), ("n_cigar", "u1"), ("path", "u1"),
+                         ("n_cand", "<u2"), ("tlen", "<u4")])
 assert RESULT_DTYPE.itemsize == 32
 
 ST_UNMAPPED, ST_UNIQUE, ST_AMBIG, ST_OFFEND = 0, 1, 2, 3
@@ -133,6 +133,12 @@ def lib() -> C.CDLL:
     L.bmbs_build_id.restype = C.c_char_p
     L.bmbs_max_cigar_ops.argtypes = [C.POINTER(Params), C.c_int32]
     L.bmbs_max_cigar_ops.restype = C.c_int32
+    L.bmbs_profile_total.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(i64)]
+    L.bmbs_profile_total.restype = C.c_int
+    L.bmbs_profile_reset.argtypes = [vp]
+    L.bmbs_profile_reset.restype = C.c_int
+    L.bmbs_retries.argtypes = [vp]
+    L.bmbs_retries.restype = i64
     L.bmbs_host_alloc.argtypes = [u64]
     L.bmbs_host_alloc.restype = vp
     L.bmbs_host_free.argtypes = [vp]

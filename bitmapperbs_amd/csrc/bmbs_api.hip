@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -20,13 +21,66 @@ struct DevBuf {
 
 struct Prof { const char* name; hipEvent_t a, b; bool used; };
 
-}  // namespace
+// A/B switches (environment), read ONCE when a context is created -- never on the launch path.  All forms give identical results
+// (the GPU tests run them); DESIGN.md section 3 lists what each one selects.
+struct Knobs {
+    int sw_form = 0;            // BMBS_SW: 0 default (reg2 from k = 5), 1 reg, 2 reg2, 3 wave
+    bool rows_ascii = false;    // BMBS_ROWS=ascii
+    int seed_waves = 65536;     // BMBS_SEED_WAVES
+    int decide = 0;             // BMBS_DECIDE: 0 default, 1 plain, 2 lds, 3 vec8
+    bool extra_nolds = false, extra_lds = false, vote_split = false, vote_nomid = false, pe_ascii_full = false;
+    bool exact = false;         // BMBS_EXACT=1: every call waits for its stage counts (the round-2 launch sequence)
+    int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
+    long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
+    long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
+    double cap_scale = 1.0;     // BMBS_CAP_SCALE: scales the learned capacities (tests: a small value forces the repeat-with-exact-sizes path)
+    void read()
+    {
+        auto is = [](const char* e, const char* v) { return e && !strcmp(e, v); };
+        const char* e = getenv("BMBS_SW");
+        sw_form = is(e, "reg") ? 1 : is(e, "reg2") ? 2 : is(e, "wave") ? 3 : 0;
+        rows_ascii = is(getenv("BMBS_ROWS"), "ascii");
+        if ((e = getenv("BMBS_SEED_WAVES"))) seed_waves = atoi(e);
+        e = getenv("BMBS_DECIDE");
+        decide = is(e, "plain") ? 1 : is(e, "lds") ? 2 : is(e, "vec8") ? 3 : 0;
+        extra_nolds = getenv("BMBS_EXTRA_NOLDS") != nullptr; extra_lds = getenv("BMBS_EXTRA_LDS") != nullptr;
+        vote_split = is(getenv("BMBS_VOTE"), "split"); vote_nomid = getenv("BMBS_VOTE_NOMID") != nullptr;
+        pe_ascii_full = is(getenv("BMBS_PE_ASCII"), "full");
+        exact = is(getenv("BMBS_EXACT"), "1");
+        if ((e = getenv("BMBS_LANES"))) lanes = atoi(e);
+        if (lanes < 1) lanes = 1;
+        if (lanes > 8) lanes = 8;
+        if ((e = getenv("BMBS_CHUNK"))) chunk = atol(e);
+        if ((e = getenv("BMBS_SPLIT_MIN"))) split_min = atol(e);
+        if (split_min < 1) split_min = 1;
+        if ((e = getenv("BMBS_CAP_SCALE"))) cap_scale = atof(e);
+    }
+};
 
-struct bmbs_ctx {
+// one call that has been enqueued on a lane and not been waited for yet (bmbs_sync / the next call on the lane settles it)
+struct Pending {
+    bool pe = false, exact = false;
+    int slot = 0;
+    uint64_t a[4] = {0, 0, 0, 0};            // d_seq(1), d_qual(1), d_seq2, d_qual2
+    const u16* d_len = nullptr;
+    int32_t L = 0, stride = 0;
+    int64_t n = 0;
+    uint64_t d_results = 0, d_cigar_pool = 0;
+    int64_t cigar_cap = 0;
+    u32 cigar_base = 0;
+    bool prepared = false;                   // map_pe_dev: the lane's pe_seq already holds the rows (FASTQ-text entry point)
+    bool staged = false;                     // the call reads lane-owned staging buffers, which the lane's next call overwrites
+};
+
+// One lane = one stream with its own work buffers, counters and HIP-event profile: what a whole context was in round 2.  A context
+// owns BMBS_LANES of them on one attached index and deals the chunks of a call to them, so that the issue-bound kernels (DP, Myers,
+// row preparation) of one chunk run beside the memory-bound seeding kernels of another without a second context or host thread.
+struct Lane {
     int dev = 0;
     hipStream_t stream = nullptr;
     bmbs_params prm;
     ScoreParams sp;
+    Knobs kn;
     std::string err;
     bool attached = false;
     DevIndex ix;
@@ -56,12 +110,38 @@ struct bmbs_ctx {
     DevBuf pe_seq, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
     DevBuf pe_first, pe_full, pe_R, pe_roff, pe_rflag, pe_rscan, pe_rlist, pe_rcnt, pe_ritem_off, pe_rcand;     // --sensitive
     u64 last_reseeded = 0, last_reseed_cand = 0;
-    DevBuf stats, counters, long_flag, long_off, long_list;     // long_*: reads whose candidate lists go to k_vote_long
-    std::vector<Prof> prof;
-    int n_prof_used = 0;
+    DevBuf stats, call_stats, flags, counters, long_flag, long_off, long_list;     // long_*: reads whose candidate lists go to k_vote_long
+    // HIP-event profile: one set of event pairs per call in flight (slot); lane_settle reads a settled call's set into `last`
+    // (bmbs_profile_last) and adds it to `acc` (bmbs_profile_total: sums since the last reset, read without forcing a wait per call)
+    std::vector<Prof> profset[8];
+    int prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cur_slot = 0;
+    struct ProfSum { const char* name; double ms; };
+    std::vector<ProfSum> last, acc;
+    u64 acc_calls = 0;
     u64 last_total_cand = 0, last_n_jobs = 0;
     int last_max_ops = 0;
     u64 h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- launches without host round trips: what the stages of earlier calls needed, per read (0: nothing known yet -> the
+    // first call of a lane waits for its counts); the pinned words the device leaves its counts and guard flags in; the call in flight
+    double lr_cand = 0, lr_sw = 0, lr_rcand = 0;
+    u64* h_tot = nullptr;                      // page-locked: per call in flight, totals[16] followed by the flag words (call_end)
+    std::deque<Pending> inflight;
+    int next_slot = 0;
+    u64 n_retries = 0;
+};
+
+}  // namespace
+
+// the public handle: parameters + the lanes (lane 0 owns the index unless the context shares another one's)
+struct bmbs_ctx {
+    int dev = 0;
+    bmbs_params prm;
+    Knobs kn;
+    std::string err;
+    std::vector<Lane*> lanes;
+    int used_lanes = 1;                        // lanes the last mapping call ran on (profile / counters aggregate over them)
+    int next_lane = 0;
 };
 
 namespace {
@@ -75,7 +155,7 @@ namespace {
         }                                                                                                 \
     } while (0)
 
-int ensure(bmbs_ctx* c, DevBuf& b, size_t bytes)
+int ensure(Lane* c, DevBuf& b, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return BMBS_OK;
@@ -92,30 +172,54 @@ void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0;
 
 inline unsigned nblk(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
-void prof_begin(bmbs_ctx* c, const char* name)
+void prof_begin(Lane* c, const char* name)
 {
-    if ((size_t)c->n_prof_used == c->prof.size()) {
+    std::vector<Prof>& set = c->profset[c->cur_slot];
+    int& used = c->prof_used[c->cur_slot];
+    if ((size_t)used == set.size()) {
         Prof p; p.name = name; p.used = false;
         (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b);
-        c->prof.push_back(p);
+        set.push_back(p);
     }
-    Prof& p = c->prof[c->n_prof_used];
+    Prof& p = set[(size_t)used];
     p.name = name; p.used = true;
     (void)hipEventRecord(p.a, c->stream);
 }
-void prof_end(bmbs_ctx* c) { (void)hipEventRecord(c->prof[c->n_prof_used].b, c->stream); c->n_prof_used++; }
+void prof_end(Lane* c) { (void)hipEventRecord(c->profset[c->cur_slot][(size_t)c->prof_used[c->cur_slot]].b, c->stream); c->prof_used[c->cur_slot]++; }
+// the events of a call whose stream work has completed -> `last` and the running sums
+void prof_collect(Lane* c, int slot)
+{
+    c->last.clear();
+    for (int i = 0; i < c->prof_used[slot]; i++) {
+        const Prof& p = c->profset[slot][(size_t)i];
+        float t = 0;
+        if (hipEventElapsedTime(&t, p.a, p.b) != hipSuccess) t = 0.f;
+        c->last.push_back({p.name, (double)t});
+        bool found = false;
+        for (auto& a : c->acc) if (a.name == p.name || !strcmp(a.name, p.name)) { a.ms += t; found = true; break; }
+        if (!found) c->acc.push_back({p.name, (double)t});
+    }
+    c->acc_calls++;
+}
 
-// exclusive scan u32[n] -> u64[n+1], total left in c->totals[slot]
-int scan_u32(bmbs_ctx* c, const u32* in, u64 n, u64* out, int slot, u32* list = nullptr, int nz = 0)
+// exclusive scan u32[n] -> u64[n+1], total left in c->totals[slot]; n_dev: a device-side count that bounds n (see k_scan_partial)
+int scan_u32(Lane* c, const u32* in, u64 n, u64* out, int slot, u32* list = nullptr, int nz = 0, const u64* n_dev = nullptr)
 {
     const u64 per = (u64)SCAN_BLOCK * SCAN_ITEMS;
     const u64 nb = (n + per - 1) / per;
     ENS(c, c->scan_tmp, (nb + 1) * 8);
     u64* bs = c->scan_tmp.as<u64>();
-    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, nz);
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, nz, n_dev);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bs, nb, c->totals.as<u64>() + slot);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list, nz);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list, nz, n_dev);
     return BMBS_OK;
+}
+
+// capacity for a device-side count of a call that does not wait for it: what earlier calls needed per read, plus a margin
+inline u64 cap_from(double need_per_read, u64 n_reads, u64 floor_, double scale = 1.0)
+{
+    const u64 c = (u64)(scale * (need_per_read * 1.25 * (double)n_reads + 64.0 * std::sqrt((double)n_reads + 1.0) + 1024.0));
+    return c > floor_ ? c : floor_;
 }
 
 // MismatchPenaltyByQuality (ksw.h:148-161), evaluated here in IEEE double exactly as the reference
@@ -192,7 +296,7 @@ int cigar_ops_bound(const bmbs_params& P, int L, int k)
 
 // MAP_Calculation tables for every error_threshold 0..62 (k for single-end, k1+k2 for pairs), concatenated:
 // table t = (t+2) x (unit*t+1) bytes at mapq_off[t]; plus klut[L] = the threshold of a read of length L.  Built once.
-int prepare_luts(bmbs_ctx* c)
+int prepare_luts(Lane* c)
 {
     if (c->luts_ready) return BMBS_OK;
     int unit = c->prm.gap_open + c->prm.gap_ext;
@@ -221,14 +325,14 @@ int prepare_luts(bmbs_ctx* c)
 }
 
 // geometry of a batch: fixed length (d_len == nullptr) or per-read lengths with L = the longest
-ReadGeom geom(bmbs_ctx* c, int L, const u16* d_len)
+ReadGeom geom(Lane* c, int L, const u16* d_len)
 {
     ReadGeom g;
     g.len = d_len; g.klut = c->klut.as<u8>(); g.L = L; g.k = threshold_k(c->prm, L);
     return g;
 }
 
-int per_read_workspace(bmbs_ctx* c, u64 n)
+int per_read_workspace(Lane* c, u64 n)
 {
     ENS(c, c->verdict, n); ENS(c, c->n_seeds, n); ENS(c, c->multi, n); ENS(c, c->mm_site, n * 2);
     ENS(c, c->exit_site, n * 8); ENS(c, c->seeds, n * BMBS_MAX_SEEDS * sizeof(SeedRec));
@@ -238,7 +342,7 @@ int per_read_workspace(bmbs_ctx* c, u64 n)
     return BMBS_OK;
 }
 
-ReadState read_state(bmbs_ctx* c)
+ReadState read_state(Lane* c)
 {
     ReadState s;
     s.verdict = c->verdict.as<u8>(); s.n_seeds = c->n_seeds.as<u8>(); s.multi = c->multi.as<u8>();
@@ -257,7 +361,7 @@ inline u64 sw_trace_slots(u64 n_jobs) { const u64 t = (u64)nblk(n_jobs, 64) * 64
 inline size_t sw_window_lds(const ReadGeom& gm, int jobs_per_lane) { return (size_t)jobs_per_lane * ((gm.L + 2 * gm.k + 62) / 32 + 1) * 64 * 8; }
 
 template <int KB>
-void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
+void launch_sw(Lane* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
                const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops, const PackedRows& prw)
 {
     const u64 slots = sw_trace_slots(n_jobs);
@@ -278,7 +382,7 @@ void launch_sw(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d
 
 // the packed form: two jobs per lane, so a launch of `slots` threads covers 2 * slots jobs
 template <int KB>
-void launch_sw2(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
+void launch_sw2(Lane* c, const char* d_seq, const char* d_qual, const char* d_qual2, const ReadGeom& gm, int stride, u64 n_jobs,
                 const Jobs& jobs, u32 rev_from, u32* d_cigar_pool, int max_ops, const PackedRows& prw)
 {
     const u64 slots = sw_trace_slots((n_jobs + 1) / 2);
@@ -292,9 +396,13 @@ void launch_sw2(bmbs_ctx* c, const char* d_seq, const char* d_qual, const char* 
 
 // K11-K13 over n_jobs jobs: un-gapped recheck for all, scan-compact the ones that need the DP, run the
 // register-band DP kernel instantiated for the smallest KB >= k.  No host round-trip inside.
-int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
-              u32 rev_from, u32* d_cigar_pool, int max_ops, const char* d_qual2 = nullptr, const PackedRows* pr = nullptr)
+// n_jobs bounds the job arrays and grids; n_jobs_dev (or nullptr) is where the device keeps the real count; sw_bound = the DP jobs the
+// DP launches cover (a call that does not wait for its counts passes capacities here and lets k_guard_count check the last one)
+int run_align(Lane* c, const char* d_seq, const char* d_qual, const ReadGeom& gm, int stride, u64 n_jobs, const Jobs& jobs,
+              u32 rev_from, u32* d_cigar_pool, int max_ops, const char* d_qual2 = nullptr, const PackedRows* pr = nullptr,
+              const u64* n_jobs_dev = nullptr, u64 sw_bound = ~0ull)
 {
+    if (sw_bound > n_jobs) sw_bound = n_jobs;
     const int L = gm.L, k = gm.k;              // the longest read and the largest threshold size the workspace
     const u64 nj = n_jobs ? n_jobs : 1;
     const u64 nwk = (u64)((2 * k + 1 + 15) / 16);
@@ -312,15 +420,15 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     //  wave: one job per 16 / 32 / 64 lanes, a band row per step, trace + CIGAR in LDS, nothing but the ops written to HBM
     //        (north_star (c)); measured 6.4x the instructions per job of `reg` (lanes beyond the band idle, the F prefix scan and
     //        its DPP wait states), so it only pays when there are too few jobs to fill the lanes.
-    const char* swm = getenv("BMBS_SW");
-    const bool wave_form = swm && !strcmp(swm, "wave");
+    const int swm = c->kn.sw_form;
+    const bool wave_form = swm == 3;
     int maxpen = std::max(std::max(c->prm.mp_max, c->prm.np), c->prm.gap_open + c->prm.gap_ext);
-    const bool packed = !wave_form && !(swm && !strcmp(swm, "reg")) && (k >= 5 || (swm && !strcmp(swm, "reg2"))) && !gm.len && c->prm.gap_ext < 256 && (L + 64) * maxpen < 12000 &&
+    const bool packed = !wave_form && swm != 1 && (k >= 5 || swm == 2) && !gm.len && c->prm.gap_ext < 256 && (L + 64) * maxpen < 12000 &&
                         c->prm.mp_min >= 0 && c->prm.gap_ext >= 0 && c->prm.gap_open >= 0 && c->prm.np >= 0;
     const bool reg_form = !wave_form;
     if (reg_form) {
         const u64 nwords = packed ? (u64)((2 * k + 1 + 7) / 8) : nwk;
-        const u64 slots = packed ? sw_trace_slots((n_jobs + 1) / 2) : sw_trace_slots(n_jobs);
+        const u64 slots = packed ? sw_trace_slots((sw_bound + 1) / 2) : sw_trace_slots(sw_bound);
         ENS(c, c->trace, slots * (u64)L * nwords * 8);
     }
     unsigned long long* cnt = c->counters.as<unsigned long long>();
@@ -328,17 +436,19 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
     prof_begin(c, "k_align_ungapped");
     if (pr && pr->base)
         hipLaunchKernelGGL(k_align_ungapped_p, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq, *pr,
-                           d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                           d_qual, d_qual2, gm, stride, n_jobs, n_jobs_dev, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                            c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
     else
         hipLaunchKernelGGL(k_align_ungapped, dim3(nblk(n_jobs, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), d_seq,
-                           d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
+                           d_qual, d_qual2, gm, stride, n_jobs, n_jobs_dev, jobs, rev_from, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
                            c->a_score.as<int>(), c->a_nops.as<int>(), c->need_sw.as<u32>(), cnt);
     prof_end(c);
     prof_begin(c, "scan_sw");
-    int rc = scan_u32(c, c->need_sw.as<u32>(), n_jobs, c->sw_off.as<u64>(), 2, c->sw_job.as<u32>());
+    int rc = scan_u32(c, c->need_sw.as<u32>(), n_jobs, c->sw_off.as<u64>(), 2, c->sw_job.as<u32>(), 0, n_jobs_dev);
     if (rc) return rc;
     prof_end(c);
+    if (n_jobs_dev && reg_form && sw_bound < n_jobs)
+        hipLaunchKernelGGL(k_guard_count, dim3(1), dim3(1), 0, c->stream, c->totals.as<u64>() + 2, sw_bound, c->flags.as<u32>(), BMBS_FLAG_SW);
     prof_begin(c, "k_align_sw");
     if (!reg_form) {
         // one alignment per 16 / 32 / 64 lanes (band of 2k+1 cells), trace + CIGAR in LDS
@@ -356,36 +466,36 @@ int run_align(bmbs_ctx* c, const char* d_seq, const char* d_qual, const ReadGeom
         return BMBS_OK;
     }
     if (packed) {
-        if (k <= 2) launch_sw2<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 4) launch_sw2<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 6) launch_sw2<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 8) launch_sw2<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 10) launch_sw2<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 12) launch_sw2<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 16) launch_sw2<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 20) launch_sw2<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else if (k <= 24) launch_sw2<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-        else launch_sw2<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        if (k <= 2) launch_sw2<2>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 4) launch_sw2<4>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 6) launch_sw2<6>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 8) launch_sw2<8>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 10) launch_sw2<10>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 12) launch_sw2<12>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 16) launch_sw2<16>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 20) launch_sw2<20>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else if (k <= 24) launch_sw2<24>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+        else launch_sw2<31>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
         prof_end(c);
         return BMBS_OK;
     }
     // the band loop is unrolled for KB: a tighter bound wastes fewer masked cells (k = 6 in a KB = 8 kernel idles 4 of 17)
-    if (k <= 2) launch_sw<2>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 6) launch_sw<6>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 10) launch_sw<10>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
-    else launch_sw<31>(c, d_seq, d_qual, d_qual2, gm, stride, n_jobs, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    if (k <= 2) launch_sw<2>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 4) launch_sw<4>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 6) launch_sw<6>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 8) launch_sw<8>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 10) launch_sw<10>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 12) launch_sw<12>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 16) launch_sw<16>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 20) launch_sw<20>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else if (k <= 24) launch_sw<24>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
+    else launch_sw<31>(c, d_seq, d_qual, d_qual2, gm, stride, sw_bound, jobs, rev_from, d_cigar_pool, max_ops, prw_);
     prof_end(c);
     return BMBS_OK;
 }
 
 // K1-K5: the four seeding kernels with their two work-list compactions (no host round-trip)
-SeedCarry seed_carry(bmbs_ctx* c)
+SeedCarry seed_carry(Lane* c)
 {
     SeedCarry sc;
     sc.sp0 = c->sd_sp0.as<u64>(); sc.hits0 = c->sd_hits0.as<u32>(); sc.ml0 = c->sd_ml0.as<u16>(); sc.tm = c->sd_tm.as<u16>();
@@ -398,14 +508,9 @@ SeedCarry seed_carry(bmbs_ctx* c)
 // packed copy of the read rows for the seeding kernels, k_seed_decide and the un-gapped recheck (default); BMBS_ROWS=ascii keeps the
 // round-1 forms for A/B runs.  Paired end: the copy is a by-product of k_pe_prepare (+2.5 %); single end: a kernel of its own
 // (k_pack_rows, 0.53 ms per 10 M reads) that the consumers win back (+1.8 %: 1463 -> 1489 M reads/s on configs[1]).
-bool use_packed_rows(int pe_mode)
-{
-    (void)pe_mode;
-    const char* e = getenv("BMBS_ROWS");
-    return !(e && !strcmp(e, "ascii"));
-}
+bool use_packed_rows(const Lane* c) { return !c->kn.rows_ascii; }
 
-int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, int pe_mode, bool prepacked = false)
+int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, int pe_mode, bool prepacked = false)
 {
     ENS(c, c->sd_sp0, n * 8); ENS(c, c->sd_hits0, n * 4); ENS(c, c->sd_ml0, n * 2); ENS(c, c->sd_tm, n * 2); ENS(c, c->sd_seed_id, n);
     ENS(c, c->sd_clen, n * 4); ENS(c, c->sd_first_ml, n * 2); ENS(c, c->sd_flag_c, n * 4); ENS(c, c->sd_flag_d, n * 4);
@@ -415,11 +520,10 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     const unsigned chunks = nblk(n, SEED_CHUNK);
     const unsigned chunks_min = nblk(n, SEED_CHUNK_MIN);      // grid for the device-sized chunks of the two work lists
-    const char* tw_env = getenv("BMBS_SEED_WAVES");
-    const int target_waves = tw_env ? atoi(tw_env) : 65536;
+    const int target_waves = c->kn.seed_waves;
     // packed copy of the rows (2 bits per base + a not-ACGT bit plane, 64 bytes for 150 bases): what the seeding engine and
     // k_seed_decide read instead of the ASCII rows; BMBS_ROWS=ascii keeps the round-1 forms (A/B runs)
-    const bool packed_rows = use_packed_rows(pe_mode);
+    const bool packed_rows = use_packed_rows(c);
     PackedRows pr = {nullptr, nullptr, 0, 0};
     if (packed_rows) {
         const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
@@ -441,18 +545,18 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     // rows staged through LDS (each read fetched from HBM exactly once, coalesced) + 8 characters per compare step;
     // BMBS_DECIDE=plain|lds|vec8 select the other forms for A/B measurements.  (An 8-lanes-per-read form without
     // staging was measured at 2.07 ms against 1.36 ms: the per-read bookkeeping, replicated eight times, costs more than it saves.)
-    const char* dv = getenv("BMBS_DECIDE");
+    const int dv = c->kn.decide;
     const bool lds_ok = (size_t)64 * (stride + 8) <= 48 * 1024;
     if (packed_rows && !dv)
         hipLaunchKernelGGL(k_seed_decide_p, dim3(nblk(n, 64)), dim3(64), (size_t)64 * (pr.pwords + 1) * 8, c->stream, c->ix, d_seq, pr, gm, stride,
                            (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
-    else if (dv && !strcmp(dv, "plain"))
+    else if (dv == 1)
         hipLaunchKernelGGL((k_seed_decide<false, false>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
-    else if (dv && !strcmp(dv, "vec8"))
+    else if (dv == 3)
         hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
                            c->prm.seed_len, pe_mode, st, sc, cnt);
-    else if (dv && !strcmp(dv, "lds") && lds_ok)
+    else if (dv == 2 && lds_ok)
         hipLaunchKernelGGL((k_seed_decide<true, false>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, gm,
                            stride, (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
     else if (lds_ok)
@@ -482,7 +586,7 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
         // round trip and the 11 KB of LDS per wave cost more occupancy (3.5 instead of 8 waves per SIMD) than the coalesced rows
         // save: 4.20 ms with LDS rows, 3.93 ms without on the configs[2] batch (BMBS_EXTRA_LDS=1 / BMBS_EXTRA_NOLDS=1 force either)
         const bool wide_ix = c->ix.sa64 != nullptr;
-        const int rows_in_lds = lds <= 48 * 1024 && !getenv("BMBS_EXTRA_NOLDS") && (!wide_ix || getenv("BMBS_EXTRA_LDS"));
+        const int rows_in_lds = lds <= 48 * 1024 && !c->kn.extra_nolds && (!wide_ix || c->kn.extra_lds);
         if (packed_rows)
             hipLaunchKernelGGL((k_seed_extra<false, true>), dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
@@ -497,8 +601,26 @@ int launch_seeding(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int strid
     return BMBS_OK;
 }
 
+// the candidate total behind scan_cand: waited for (exact), or bounded by a capacity with a guard behind the scan (k_guard_cand)
+int cand_total(Lane* c, const ReadState& st, u64 n, bool exact, u64* tot_out)
+{
+    if (exact) {
+        u64 tot = 0;
+        HIPCHK(c, hipMemcpyAsync(&tot, c->totals.as<u64>(), 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *tot_out = tot;
+        return BMBS_OK;
+    }
+    const u64 cap = cap_from(c->lr_cand, n, n, c->kn.cap_scale);
+    hipLaunchKernelGGL(k_guard_cand, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->totals.as<u64>(), cap, c->flags.as<u32>(), (long)n, st.verdict,
+                       st.n_cand, st.cand_off);
+    hipLaunchKernelGGL(k_guard_done, dim3(1), dim3(1), 0, c->stream, c->totals.as<u64>(), c->flags.as<u32>(), BMBS_FLAG_CAND);
+    *tot_out = cap;
+    return BMBS_OK;
+}
+
 // stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
-int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, u64* total_cand, int pe_mode = 0)
+int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, u64* total_cand, int pe_mode = 0, bool exact = true)
 {
     ReadState st = read_state(c);
     {
@@ -510,15 +632,14 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
     if (rc) return rc;
     prof_end(c);
     u64 tot = 0;
-    HIPCHK(c, hipMemcpyAsync(&tot, c->totals.as<u64>(), 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = cand_total(c, st, n, exact, &tot);
+    if (rc) return rc;
     *total_cand = tot;
     const u64 t1 = tot ? tot : 1;
     ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(bmbs_vote)); ENS(c, c->slot_read, t1 * 4);
     ENS(c, c->ferr, t1 * 4); ENS(c, c->fend, t1 * 4);
     // locate + sort + votes; BMBS_VOTE=split runs the two-kernel form (k_locate, k_vote) for A/B measurements
-    const char* vm = getenv("BMBS_VOTE");
-    if (vm && !strcmp(vm, "split")) {
+    if (c->kn.vote_split) {
         if (tot) {
             prof_begin(c, "k_locate");
             hipLaunchKernelGGL(k_locate, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, (long)n, st, c->cand.as<u64>());
@@ -540,7 +661,7 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
         }
         // long reads (up to 25 seeds): lists of 17..32 candidates are the rule, not the repeat case -- they get a kernel of their
         // own (k_vote_mid); its flag and list live in the seeding work-list buffers, free by now
-        const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !getenv("BMBS_VOTE_NOMID");
+        const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !c->kn.vote_nomid;
         u32* mid_flag = use_mid ? c->sd_flag_c.as<u32>() : nullptr;
         if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n * 4, c->stream));
         hipLaunchKernelGGL(k_vote_fused, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, st, c->cand.as<u64>(),
@@ -569,11 +690,14 @@ int run_seed_stages(bmbs_ctx* c, const char* d_seq, const ReadGeom& gm, int stri
 }
 
 // host rows (stride bytes apart) -> device rows padded to a multiple of 16 bytes
-int upload_rows(bmbs_ctx* c, DevBuf& dst, const char* src, int L, int stride, u64 n, int* dstride)
+int upload_rows(Lane* c, DevBuf& dst, const char* src, int L, int stride, u64 n, int* dstride)
 {
     const int ds = (L + 15) / 16 * 16;
     *dstride = ds;
     ENS(c, dst, n * (u64)ds + 64);
+    // rows that are already `ds` bytes apart go over as ONE block (the bytes past L are ignored by every kernel); a 2-D copy of
+    // 150-byte rows out of a 160-byte pitch ran at half the link rate
+    if (n && stride == ds) { HIPCHK(c, hipMemcpyAsync(dst.p, src, n * (u64)ds, hipMemcpyHostToDevice, c->stream)); return BMBS_OK; }
     HIPCHK(c, hipMemsetAsync(dst.p, 0, n * (u64)ds + 64, c->stream));
     if (n) HIPCHK(c, hipMemcpy2DAsync(dst.p, ds, src, stride, L, n, hipMemcpyHostToDevice, c->stream));
     return BMBS_OK;
@@ -588,26 +712,33 @@ extern "C" void bmbs_default_params(bmbs_params* p)
     p->seed_len = 30; p->min_ins = 0; p->max_ins = 500; p->sensitive = 0; p->ambiguous_out = 0;
 }
 
-extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
+namespace {
+void lane_destroy(Lane* c);
+
+Lane* lane_create(int device_id, const bmbs_params& prm, const Knobs& kn, bool first)
 {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return nullptr;
-    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
-    bmbs_ctx* c = new bmbs_ctx();
+    Lane* c = new Lane();
     c->dev = device_id;
-    if (params) c->prm = *params; else bmbs_default_params(&c->prm);
+    c->prm = prm; c->kn = kn;
     c->sp.mp_max = c->prm.mp_max; c->sp.mp_min = c->prm.mp_min; c->sp.np = c->prm.np;
     c->sp.gap_open = c->prm.gap_open; c->sp.gap_ext = c->prm.gap_ext; c->sp.q_base = c->prm.q_base;
     c->sp.seed_len = c->prm.seed_len;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
-    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, BMBS_SHARDS * BMBS_SHARD_WORDS * 8) || ensure(c, c->counters, BMBS_SHARDS * BMBS_SHARD_WORDS * 8) ||
-        ensure(c, c->totals, 16 * 8)) { bmbs_destroy(c); return nullptr; }
+    const size_t shard_bytes = BMBS_SHARDS * BMBS_SHARD_WORDS * 8;
+    if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, shard_bytes) || ensure(c, c->call_stats, shard_bytes) || ensure(c, c->counters, shard_bytes) ||
+        ensure(c, c->totals, 16 * 8) || ensure(c, c->flags, BMBS_FLAG_WORDS * 4) ||
+        hipHostMalloc((void**)&c->h_tot, 8 * 20 * 8, hipHostMallocPortable) != hipSuccess) { lane_destroy(c); return nullptr; }
+    memset(c->h_tot, 0, 8 * 20 * 8);
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
-    (void)hipMemset(c->stats.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
-    (void)hipMemset(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8);
+    (void)hipMemset(c->stats.p, 0, shard_bytes);
+    (void)hipMemset(c->call_stats.p, 0, shard_bytes);
+    (void)hipMemset(c->counters.p, 0, shard_bytes);
+    (void)hipMemset(c->totals.p, 0, 16 * 8);
+    (void)hipMemset(c->flags.p, 0, BMBS_FLAG_WORDS * 4);
     // diagnostic: per-wave timeline of the kernels that call wavelog_begin/_end (one context at a time; tools/wavelog.py)
+    if (first)
     if (const char* wl = getenv("BMBS_WAVELOG")) {
         const unsigned cap = 1u << 21;
         if (*wl && !ensure(c, c->wavelog_buf, (u64)cap * 32) && !ensure(c, c->wavelog_count, 64)) {
@@ -619,10 +750,11 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     return c;
 }
 
-extern "C" void bmbs_destroy(bmbs_ctx* c)
+void lane_destroy(Lane* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->dev);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (!c->wavelog_path.empty()) {
         (void)hipDeviceSynchronize();
         unsigned cnt = 0;
@@ -641,15 +773,46 @@ extern "C" void bmbs_destroy(bmbs_ctx* c)
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
                      &c->job_read, &c->job_site, &c->job_end, &c->job_err, &c->need_sw, &c->sw_off, &c->sw_job, &c->trace, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
-                     &c->stats, &c->counters, &c->pe_seq, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
+                     &c->stats, &c->call_stats, &c->flags, &c->counters, &c->pe_seq, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
                      &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list,
                      &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx, &c->prow, &c->prow_dirty, &c->pe_mid_flag, &c->pe_mid_list};
     for (DevBuf* b : all) release(*b);
-    for (auto& p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& set : c->profset) for (auto& p : set) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+// the lane a stage entry point runs on; a failing call leaves its message in the context
+inline Lane* lane0(bmbs_ctx* X) { return X && !X->lanes.empty() ? X->lanes[0] : nullptr; }
+inline int fin(bmbs_ctx* X, Lane* c, int rc) { if (rc && X && c) X->err = c->err; return rc; }
+}  // namespace
+
+extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    bmbs_ctx* X = new bmbs_ctx();
+    X->dev = device_id;
+    if (params) X->prm = *params; else bmbs_default_params(&X->prm);
+    X->kn.read();                                  // the A/B environment is read here, once; the launch path never calls getenv
+    for (int i = 0; i < X->kn.lanes; i++) {
+        Lane* c = lane_create(device_id, X->prm, X->kn, i == 0);
+        if (!c) { bmbs_destroy(X); return nullptr; }
+        X->lanes.push_back(c);
+    }
+    return X;
+}
+
+extern "C" void bmbs_destroy(bmbs_ctx* X)
+{
+    if (!X) return;
+    (void)hipSetDevice(X->dev);
+    for (size_t i = X->lanes.size(); i-- > 0;) lane_destroy(X->lanes[i]);      // lane 0 (the index owner) last
+    delete X;
 }
 
 extern "C" int32_t bmbs_max_cigar_ops(const bmbs_params* params, int32_t L)
@@ -660,9 +823,9 @@ extern "C" int32_t bmbs_max_cigar_ops(const bmbs_params* params, int32_t L)
     return cigar_ops_bound(P, L, threshold_k(P, L));
 }
 
-extern "C" const char* bmbs_last_error(const bmbs_ctx* c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
+extern "C" const char* bmbs_last_error(const bmbs_ctx* X) { return X ? X->err.c_str() : "no context (no HIP device?)"; }
 
-extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
+static int lane_index_attach(Lane* c, const bmbs_index_view* v)
 {
     if (!c || !v) return BMBS_EINVAL;
     HIPCHK(c, hipSetDevice(c->dev));
@@ -762,17 +925,34 @@ extern "C" int bmbs_index_attach(bmbs_ctx* c, const bmbs_index_view* v)
     return BMBS_OK;
 }
 
-extern "C" int bmbs_sync(bmbs_ctx* c)
+// ------------------------------------------------------------------------------------------------
+namespace {
+// A mapping call on a lane: call_begin, the launch sequence, call_end.  call_end adds the call's five counters to the lane's
+// (unless a guard flag says the call is going to be repeated) and copies the stage counts and the flags into page-locked
+// words; lane_settle waits for the lane and reads them.
+int call_begin(Lane* c, int slot)
 {
-    if (!c) return BMBS_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cur_slot = slot; c->prof_used[slot] = 0;
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->flags.p, 0, BMBS_FLAG_WORDS * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->totals.p, 0, 16 * 8, c->stream));
+    return BMBS_OK;
+}
+#define BMBS_SLOTS 8                // calls a lane may have in flight: one set of page-locked words each
+#define BMBS_SLOT_WORDS 20          // 16 totals + the flag words
+int call_end(Lane* c, int slot)
+{
+    u64* h = c->h_tot + (size_t)slot * BMBS_SLOT_WORDS;
+    const int words = BMBS_SHARDS * BMBS_SHARD_WORDS;
+    hipLaunchKernelGGL(k_stats_commit, dim3(nblk(words, 256)), dim3(256), 0, c->stream, c->flags.as<u32>(), c->call_stats.as<unsigned long long>(),
+                       c->stats.as<unsigned long long>(), words);
+    HIPCHK(c, hipMemcpyAsync(h, c->totals.p, 16 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + 16, c->flags.p, BMBS_FLAG_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     return BMBS_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-namespace {
-int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int32_t L, int32_t stride,
-               int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+int map_se_dev(Lane* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int32_t L, int32_t stride,
+               int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap, bool exact = true, u32 cigar_base = 0, int slot = 0)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -782,19 +962,22 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
     const char* d_seq = reinterpret_cast<const char*>(d_seq_);
     const char* d_qual = reinterpret_cast<const char*>(d_qual_);
     const u64 n = (u64)n_reads;
-    c->n_prof_used = 0;
     if (n == 0) return BMBS_OK;
     int rc = prepare_luts(c);
     if (rc) return rc;
     const ReadGeom gm = geom(c, L, d_len);
     const int k = gm.k;
+    const int max_ops = cigar_ops_bound(c->prm, L, k);
+    c->last_max_ops = max_ops;
+    if (max_ops > BMBS_MAX_RECORD_OPS) { c->err = "these gap / mismatch penalties allow alignments with more CIGAR operations than a record holds (254)"; return BMBS_EINVAL; }
     rc = per_read_workspace(c, n);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
+    rc = call_begin(c, slot);
+    if (rc) return rc;
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
-    u64 tot = 0;
-    rc = run_seed_stages(c, d_seq, gm, stride, n, &tot);
+    u64 tot = 0;                     // candidate slots: the count itself (exact) or the capacity the buffers and grids are sized for
+    rc = run_seed_stages(c, d_seq, gm, stride, n, &tot, 0, exact);
     if (rc) return rc;
     c->last_total_cand = tot;
     ENS(c, c->vote_off, (n + 1) * 8);
@@ -806,13 +989,13 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
     rc = scan_u32(c, st.n_votes, n, c->vote_off.as<u64>(), 5);
     if (rc) return rc;
     if (tot)
-        hipLaunchKernelGGL(k_vote_compact, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, tot, st, c->vote_off.as<u64>(),
-                           c->slot_read.as<u32>(), c->votes.as<bmbs_vote>(), c->votes_dense.as<bmbs_vote>(), c->dense_read.as<u32>());
+        hipLaunchKernelGGL(k_vote_compact, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, tot, exact ? (const u64*)nullptr : c->totals.as<u64>(), st,
+                           c->vote_off.as<u64>(), c->slot_read.as<u32>(), c->votes.as<bmbs_vote>(), c->votes_dense.as<bmbs_vote>(), c->dense_read.as<u32>());
     prof_end(c);
     if (tot) {
         prof_begin(c, "k_filter");
         PackedRows prf = {nullptr, nullptr, 0, 0};
-        if (use_packed_rows(0)) { prf.base = c->prow.as<u64>(); prf.dirty = c->prow_dirty.as<u8>(); prf.pwords = pack_words(gm.L); prf.W = pack_base_words(gm.L); }
+        if (use_packed_rows(c)) { prf.base = c->prow.as<u64>(); prf.dirty = c->prow_dirty.as<u8>(); prf.pwords = pack_words(gm.L); prf.W = pack_base_words(gm.L); }
         hipLaunchKernelGGL(k_filter, dim3(nblk(tot, 256)), dim3(256), 0, c->stream, c->ix, d_seq, prf, gm, stride, c->totals.as<u64>() + 5,
                            c->dense_read.as<u32>(), c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), cnt);
         prof_end(c);
@@ -820,8 +1003,7 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
     prof_begin(c, "k_reduce");
     {
         // over the compacted list of reads with candidates when the vote stage built one (BMBS_VOTE=split does not)
-        const char* vm2 = getenv("BMBS_VOTE");
-        const bool listed = !(vm2 && !strcmp(vm2, "split"));
+        const bool listed = !c->kn.vote_split;
         if (listed) {
             HIPCHK(c, hipMemsetAsync(st.job_flag, 0, n * 4, c->stream));
             HIPCHK(c, hipMemsetAsync(st.red_status, 0, n, c->stream));
@@ -835,14 +1017,22 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
     rc = scan_u32(c, st.job_flag, n, st.job_off, 1);
     if (rc) return rc;
     prof_end(c);
-    u64 n_jobs = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // jobs: the count (exact), or one slot per read with the device-side count bounding every kernel and a guard on the caller's pool
+    u64 n_jobs = n, sw_bound = ~0ull;
+    const u64* n_jobs_dev = nullptr;
+    if (exact) {
+        HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small (it takes bmbs_max_cigar_ops() slots per read)"; return BMBS_ENOMEM; }
+    } else {
+        n_jobs_dev = c->totals.as<u64>() + 1;
+        sw_bound = cap_from(c->lr_sw, n, c->kn.cap_scale < 1.0 ? 64 : 16384, c->kn.cap_scale);
+        if ((u64)cigar_cap < n * (u64)max_ops) {
+            hipLaunchKernelGGL(k_guard_jobs, dim3(nblk(n, 256)), dim3(256), 0, c->stream, n_jobs_dev, (u64)max_ops, (u64)cigar_cap, c->flags.as<u32>(), (long)n, st.job_flag);
+            hipLaunchKernelGGL(k_guard_done, dim3(1), dim3(1), 0, c->stream, c->totals.as<u64>() + 1, c->flags.as<u32>(), BMBS_FLAG_CIGAR);
+        }
+    }
     c->last_n_jobs = n_jobs;
-    const int max_ops = cigar_ops_bound(c->prm, L, k);
-    c->last_max_ops = max_ops;
-    if (max_ops > BMBS_MAX_RECORD_OPS) { c->err = "these gap / mismatch penalties allow alignments with more CIGAR operations than a record holds (254)"; return BMBS_EINVAL; }
-    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small (it takes bmbs_max_cigar_ops() slots per read)"; return BMBS_ENOMEM; }
     {
         const u64 nj = n_jobs ? n_jobs : 1;
         ENS(c, c->job_read, nj * 4); ENS(c, c->job_site, nj * 8); ENS(c, c->job_end, nj * 4); ENS(c, c->job_err, nj * 4);
@@ -854,22 +1044,22 @@ int map_se_dev(bmbs_ctx* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len,
         }
         Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
         PackedRows prw = {nullptr, nullptr, 0, 0};
-        if (use_packed_rows(0)) { prw.base = c->prow.as<u64>(); prw.dirty = c->prow_dirty.as<u8>(); prw.pwords = pack_words(gm.L); prw.W = pack_base_words(gm.L); }
-        rc = run_align(c, d_seq, d_qual, gm, stride, n_jobs, jobs, 0xffffffffu, reinterpret_cast<u32*>(d_cigar_pool), max_ops, nullptr, &prw);
+        if (use_packed_rows(c)) { prw.base = c->prow.as<u64>(); prw.dirty = c->prow_dirty.as<u8>(); prw.pwords = pack_words(gm.L); prw.W = pack_base_words(gm.L); }
+        rc = run_align(c, d_seq, d_qual, gm, stride, n_jobs, jobs, 0xffffffffu, reinterpret_cast<u32*>(d_cigar_pool), max_ops, nullptr, &prw, n_jobs_dev, sw_bound);
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize");
     hipLaunchKernelGGL(k_finalize, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(),
                        c->mapq_lut.as<u8>(), c->mapq_off.as<u32>(), c->mapq_unit, d_seq, d_qual, gm, stride, (long)n, st, c->a_start.as<int>(),
-                       c->a_end.as<int>(), c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), max_ops,
+                       c->a_end.as<int>(), c->a_nm.as<u32>(), c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, cigar_base,
                        c->prm.ambiguous_out, c->sd_sp0.as<u64>(), c->sd_hits0.as<u32>(),
-                       reinterpret_cast<bmbs_result_dev*>(d_results), c->stats.as<unsigned long long>());
+                       reinterpret_cast<bmbs_result_dev*>(d_results), c->call_stats.as<unsigned long long>());
     prof_end(c);
-    return BMBS_OK;
+    return call_end(c, slot);
 }
 
 // host lengths -> device (u16 per read)
-int upload_lens(bmbs_ctx* c, const uint16_t* len, u64 n, u64 at, u64 total, int L)
+int upload_lens(Lane* c, const uint16_t* len, u64 n, u64 at, u64 total, int L)
 {
     for (u64 i = 0; i < n; i++) if (len[i] == 0 || len[i] > L) { c->err = "read length 0 or longer than L_max"; return BMBS_EINVAL; }
     ENS(c, c->in_len, total * 2 + 16);           // sized for the whole batch up front: growing would drop the first part
@@ -877,60 +1067,7 @@ int upload_lens(bmbs_ctx* c, const uint16_t* len, u64 n, u64 at, u64 total, int 
     return BMBS_OK;
 }
 
-int map_se_host(bmbs_ctx* c, const char* seq, const char* qual, const uint16_t* len, int32_t L, int32_t stride, int64_t n_reads,
-                bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
-{
-    if (!c) return BMBS_EINVAL;
-    static_assert(sizeof(bmbs_result) == 32 && sizeof(bmbs_result_dev) == 32, "result record is 32 bytes");
-    HIPCHK(c, hipSetDevice(c->dev));
-    const u64 n = (u64)n_reads, bytes = n * (u64)stride;
-    if (n_cigar_used) *n_cigar_used = 0;
-    if (n == 0) return BMBS_OK;
-    if (L <= 0 || L > 1000 || stride < L) { c->err = "bad read geometry"; return BMBS_EINVAL; }
-    ENS(c, c->out_res, n * 32);
-    const int k = threshold_k(c->prm, L);
-    const u64 pool = n * (u64)cigar_ops_bound(c->prm, L, k);           // worst case: every read needs K12
-    ENS(c, c->cig_pool, pool * 4);
-    int ds = 0;
-    { int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; r1 = upload_rows(c, c->in_qual, qual, L, stride, n, &ds); if (r1) return r1; }
-    if (len) { int r1 = upload_lens(c, len, n, 0, n, L); if (r1) return r1; }
-    (void)bytes;
-    stride = ds;
-    int rc = map_se_dev(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, len ? c->in_len.as<u16>() : nullptr, L, stride, n_reads,
-                        (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n * 32, hipMemcpyDeviceToHost, c->stream));
-    const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
-    if (used > (u64)cigar_cap) { c->err = "host cigar pool too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
-    if (used) HIPCHK(c, hipMemcpyAsync(cigar_pool, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (n_cigar_used) *n_cigar_used = (int64_t)used;
-    return BMBS_OK;
-}
 }  // namespace
-
-extern "C" int bmbs_map_se_device(bmbs_ctx* c, uint64_t d_seq, uint64_t d_qual, int32_t L, int32_t stride,
-                                  int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
-{
-    return map_se_dev(c, d_seq, d_qual, nullptr, L, stride, n_reads, d_results, d_cigar_pool, cigar_cap);
-}
-extern "C" int bmbs_map_se_var_device(bmbs_ctx* c, uint64_t d_seq, uint64_t d_qual, uint64_t d_len, int32_t L_max, int32_t stride,
-                                      int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
-{
-    if (c && !d_len) { c->err = "d_len is NULL"; return BMBS_EINVAL; }
-    return map_se_dev(c, d_seq, d_qual, reinterpret_cast<const u16*>(d_len), L_max, stride, n_reads, d_results, d_cigar_pool, cigar_cap);
-}
-extern "C" int bmbs_map_se(bmbs_ctx* c, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
-                           bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
-{
-    return map_se_host(c, seq, qual, nullptr, L, stride, n_reads, results, cigar_pool, cigar_cap, n_cigar_used);
-}
-extern "C" int bmbs_map_se_var(bmbs_ctx* c, const char* seq, const char* qual, const uint16_t* len, int32_t L_max, int32_t stride,
-                               int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
-{
-    if (c && !len) { c->err = "len is NULL"; return BMBS_EINVAL; }
-    return map_se_host(c, seq, qual, len, L_max, stride, n_reads, results, cigar_pool, cigar_cap, n_cigar_used);
-}
 
 // ------------------------------------------------------------------------------------------------
 // paired-end fast mode (Map_Pair_Seq_end_to_end_fast, Schema.cpp:18570)
@@ -938,8 +1075,9 @@ namespace {
 // d_len: NULL, or u16[2n] = the lengths of the n first mates followed by those of the n second mates
 // prepared: c->pe_seq already holds the 2n rows (mate 1, then reverse-complemented mate 2) -- the FASTQ-text entry point writes
 // them there straight from the text and k_pe_prepare is not run
-int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, const u16* d_len,
-               int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap, bool prepared = false)
+int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, const u16* d_len,
+               int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap, bool prepared = false,
+               bool exact = true, u32 cigar_base = 0, int slot = 0)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -948,19 +1086,22 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     HIPCHK(c, hipSetDevice(c->dev));
     const u64 n = (u64)n_pairs, n2 = 2 * n;
     if (prepared && c->pe_seq.cap < n2 * (u64)stride + 64) { c->err = "internal: prepared rows missing"; return BMBS_ESTATE; }
-    c->n_prof_used = 0;
     if (n == 0) return BMBS_OK;
     int rc = prepare_luts(c);
     if (rc) return rc;
     const ReadGeom gm = geom(c, L, d_len);
     const PeIns pi = {c->prm.min_ins, c->prm.max_ins};
     const int k = gm.k;
+    const int max_ops = cigar_ops_bound(c->prm, L, k);
+    c->last_max_ops = max_ops;
+    if (max_ops > BMBS_MAX_RECORD_OPS) { c->err = "these gap / mismatch penalties allow alignments with more CIGAR operations than a record holds (254)"; return BMBS_EINVAL; }
     rc = per_read_workspace(c, n2);
     if (rc) return rc;
     ENS(c, c->pe_seq, n2 * (u64)stride + 64);
     ENS(c, c->pe_occ, n2 * 4); ENS(c, c->pe_len, n2 * 4); ENS(c, c->pe_cur, n2); ENS(c, c->pe_vround, n2);
     ENS(c, c->pe_dead, n); ENS(c, c->pe_both, n); ENS(c, c->pe_npair, n * 4); ENS(c, c->pe_sbd, n * 4);
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
+    rc = call_begin(c, slot);
+    if (rc) return rc;
     char* seq_all = c->pe_seq.as<char>();
     // the qualities are read where the caller put them (qual_row): mate 1 rows in d_qual1, mate 2 rows in d_qual2
     const char* qual_1 = reinterpret_cast<const char*>(d_qual1);
@@ -969,15 +1110,15 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     if (!prepared) {
         u64* prow = nullptr; u32* pdirty = nullptr;
         const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
-        if (use_packed_rows(1)) {
+        if (use_packed_rows(c)) {
             ENS(c, c->prow, n2 * (u64)pwords * 8 + 64); ENS(c, c->prow_dirty, n2 + 64);
             HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n2 + 64, c->stream));
             prow = c->prow.as<u64>(); pdirty = c->prow_dirty.as<u32>(); prepacked = true;
         }
         // on packed rows nothing reads the ASCII rows except under a set bit of the mask plane, so only those pieces are written
         // (BMBS_PE_ASCII=full keeps the complete copy)
-        static const bool full_ascii = [] { const char* e = getenv("BMBS_PE_ASCII"); return e && !strcmp(e, "full"); }();
-        const int sparse = prow && !full_ascii;
+        // ... and BMBS_DECIDE selects an ASCII form of k_seed_decide, which reads whole rows: no sparse copy then
+        const int sparse = prow && !c->kn.pe_ascii_full && c->kn.decide == 0;
         prof_begin(c, "k_pe_prepare");
         const int ppr = stride / 16;
         if (sparse && ppr <= 256) {
@@ -1009,9 +1150,9 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     rc = scan_u32(c, st.n_cand, n2, st.cand_off, 0);
     if (rc) return rc;
     prof_end(c);
-    u64 tot = 0;
-    HIPCHK(c, hipMemcpyAsync(&tot, c->totals.as<u64>(), 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 tot = 0;                     // candidate slots: the count itself (exact) or the capacity the buffers and grids are sized for
+    rc = cand_total(c, st, n2, exact, &tot);
+    if (rc) return rc;
     c->last_total_cand = tot;
     const u64 t1 = tot ? tot : 1;
     ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(PeCand)); ENS(c, c->pe_B, t1 * sizeof(PeCand)); ENS(c, c->slot_read, t1 * 4);
@@ -1021,7 +1162,7 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     ENS(c, c->long_flag, n2 * 4); ENS(c, c->long_off, (n2 + 1) * 8); ENS(c, c->long_list, n2 * 4);
     // reads of 180 bases and more place up to 25 seeds: lists of 17..32 candidates are the rule there and get a kernel of their own
     // (k_vote_pe_mid; buffers of its own: --sensitive still reads the seeding flags afterwards)
-    const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !getenv("BMBS_VOTE_NOMID");
+    const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !c->kn.vote_nomid;
     if (use_mid) { ENS(c, c->pe_mid_flag, n2 * 4); ENS(c, c->pe_mid_list, n2 * 4); }
     u32* mid_flag = use_mid ? c->pe_mid_flag.as<u32>() : nullptr;
     if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n2 * 4, c->stream));
@@ -1056,7 +1197,7 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
             hipLaunchKernelGGL(k_pe_worklist, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, (long)n2, wcnt, woff, c->dense_read.as<u32>(),
                                c->ferr.as<u32>());
             PackedRows prf = {nullptr, nullptr, 0, 0};
-            if (use_packed_rows(1)) { prf.base = c->prow.as<u64>(); prf.dirty = c->prow_dirty.as<u8>(); prf.pwords = pack_words(gm.L); prf.W = pack_base_words(gm.L); }
+            if (use_packed_rows(c)) { prf.base = c->prow.as<u64>(); prf.dirty = c->prow_dirty.as<u8>(); prf.pwords = pack_words(gm.L); prf.W = pack_base_words(gm.L); }
             hipLaunchKernelGGL(k_filter_pe, dim3(nblk(cap, 256)), dim3(256), 0, c->stream, c->ix, seq_all, prf, gm, stride, st, ps, A, B,
                                c->totals.as<u64>() + 6, c->dense_read.as<u32>(), c->ferr.as<u32>(), cnt);
             prof_end(c);
@@ -1100,16 +1241,23 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         HIPCHK(c, hipMemsetAsync(rcnt, 0, n * 4, c->stream));
         {
             PackedRows prs = {nullptr, nullptr, 0, 0};
-            if (use_packed_rows(1)) { prs.base = c->prow.as<u64>(); prs.dirty = c->prow_dirty.as<u8>(); prs.pwords = pack_words(gm.L); prs.W = pack_base_words(gm.L); }
+            if (use_packed_rows(c)) { prs.base = c->prow.as<u64>(); prs.dirty = c->prow_dirty.as<u8>(); prs.pwords = pack_words(gm.L); prs.W = pack_base_words(gm.L); }
             hipLaunchKernelGGL((prs.base ? k_pes_reseed<true> : k_pes_reseed<false>), dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, prs, gm, stride,
                                (long)n, n_reseed, rlist, st, ps, rcnt, cnt);
         }
         rc = scan_u32(c, rcnt, n, c->pe_ritem_off.as<u64>(), 8);
         if (rc) return rc;
         prof_end(c);
-        u64 rt[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(rt, c->totals.as<u64>() + 7, 16, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        u64 rt[2] = {0, 0};          // pairs to re-seed, their candidates: counts (exact) or capacities with a guard
+        if (exact) {
+            HIPCHK(c, hipMemcpyAsync(rt, c->totals.as<u64>() + 7, 16, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        } else {
+            rt[0] = n; rt[1] = cap_from(c->lr_rcand, n2, c->kn.cap_scale < 1.0 ? 64 : 65536, c->kn.cap_scale);
+            hipLaunchKernelGGL(k_guard_rcand, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->totals.as<u64>() + 8, rt[1], c->flags.as<u32>(), (long)n, rcnt,
+                               c->pe_ritem_off.as<u64>());
+            hipLaunchKernelGGL(k_guard_done, dim3(1), dim3(1), 0, c->stream, c->totals.as<u64>() + 8, c->flags.as<u32>(), BMBS_FLAG_RCAND);
+        }
         c->last_reseeded = rt[0]; c->last_reseed_cand = rt[1];
         if (rt[0]) {
             const u64 rtot = rt[1] ? rt[1] : 1;
@@ -1131,14 +1279,21 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
     rc = scan_u32(c, st.job_flag, n2, st.job_off, 1);
     if (rc) return rc;
     prof_end(c);
-    u64 n_jobs = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 n_jobs = n2, sw_bound = ~0ull;
+    const u64* n_jobs_dev = nullptr;
+    if (exact) {
+        HIPCHK(c, hipMemcpyAsync(&n_jobs, c->totals.as<u64>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small (it takes bmbs_max_cigar_ops() slots per read)"; return BMBS_ENOMEM; }
+    } else {
+        n_jobs_dev = c->totals.as<u64>() + 1;
+        sw_bound = cap_from(c->lr_sw, n2, c->kn.cap_scale < 1.0 ? 64 : 16384, c->kn.cap_scale);
+        if ((u64)cigar_cap < n2 * (u64)max_ops) {
+            hipLaunchKernelGGL(k_guard_jobs, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, n_jobs_dev, (u64)max_ops, (u64)cigar_cap, c->flags.as<u32>(), (long)n2, st.job_flag);
+            hipLaunchKernelGGL(k_guard_done, dim3(1), dim3(1), 0, c->stream, c->totals.as<u64>() + 1, c->flags.as<u32>(), BMBS_FLAG_CIGAR);
+        }
+    }
     c->last_n_jobs = n_jobs;
-    const int max_ops = cigar_ops_bound(c->prm, L, k);
-    c->last_max_ops = max_ops;
-    if (max_ops > BMBS_MAX_RECORD_OPS) { c->err = "these gap / mismatch penalties allow alignments with more CIGAR operations than a record holds (254)"; return BMBS_EINVAL; }
-    if ((u64)cigar_cap < n_jobs * (u64)max_ops) { c->err = "cigar pool too small (it takes bmbs_max_cigar_ops() slots per read)"; return BMBS_ENOMEM; }
     {
         const u64 nj = n_jobs ? n_jobs : 1;
         ENS(c, c->job_read, nj * 4); ENS(c, c->job_site, nj * 8); ENS(c, c->job_end, nj * 4); ENS(c, c->job_err, nj * 4);
@@ -1151,83 +1306,307 @@ int map_pe_dev(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, 
         Jobs jobs = {c->job_read.as<u32>(), c->job_site.as<u64>(), c->job_end.as<int>(), c->job_err.as<u32>()};
         // mate 2 rows (>= n) carry FASTQ-order qualities for a reverse-complemented read: need_reverse_quality = 1
         PackedRows prw = {nullptr, nullptr, 0, 0};
-        if (use_packed_rows(1)) { prw.base = c->prow.as<u64>(); prw.dirty = c->prow_dirty.as<u8>(); prw.pwords = pack_words(gm.L); prw.W = pack_base_words(gm.L); }
-        rc = run_align(c, seq_all, qual_1, gm, stride, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops, qual_2, &prw);
+        if (use_packed_rows(c)) { prw.base = c->prow.as<u64>(); prw.dirty = c->prow_dirty.as<u8>(); prw.pwords = pack_words(gm.L); prw.W = pack_base_words(gm.L); }
+        rc = run_align(c, seq_all, qual_1, gm, stride, n_jobs, jobs, (u32)n, reinterpret_cast<u32*>(d_cigar_pool), max_ops, qual_2, &prw, n_jobs_dev, sw_bound);
         if (rc) return rc;
     }
     prof_begin(c, "k_finalize_pe");
     hipLaunchKernelGGL(k_finalize_pe, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, c->sp, c->pen_lut.as<int>(), seq_all, qual_1, qual_2, stride,
                        c->mapq_lut.as<u8>(), c->mapq_off.as<u32>(), c->mapq_unit, gm,
                        c->prm.min_ins, c->prm.max_ins, c->prm.ambiguous_out, (long)n, st, ps, c->a_start.as<int>(), c->a_end.as<int>(), c->a_nm.as<u32>(),
-                       c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, reinterpret_cast<bmbs_result_dev*>(d_results),
-                       c->stats.as<unsigned long long>());
+                       c->a_score.as<int>(), c->a_nops.as<int>(), max_ops, cigar_base, reinterpret_cast<bmbs_result_dev*>(d_results),
+                       c->call_stats.as<unsigned long long>());
     prof_end(c);
+    return call_end(c, slot);
+}
+
+// ---- calls in flight on a lane ------------------------------------------------------------------------------------------------
+int lane_issue(Lane* c, const Pending& P)
+{
+    return P.pe ? map_pe_dev(c, P.a[0], P.a[1], P.a[2], P.a[3], P.d_len, P.L, P.stride, P.n, P.d_results, P.d_cigar_pool, P.cigar_cap, P.prepared, P.exact,
+                             P.cigar_base, P.slot)
+                : map_se_dev(c, P.a[0], P.a[1], P.d_len, P.L, P.stride, P.n, P.d_results, P.d_cigar_pool, P.cigar_cap, P.exact, P.cigar_base, P.slot);
+}
+
+// Wait for the lane, then read what its calls left in their page-locked words: the stage counts (they size the next calls) and the
+// guard flags.  A call whose counts did not fit its capacities has done no harm (the guards took its work away and its counters
+// were not committed): it is issued again with exact sizes.  The caller's buffers of a *_device call have to stay untouched until
+// bmbs_sync() for exactly this reason.
+int lane_settle(Lane* c)
+{
+    HIPCHK(c, hipSetDevice(c->dev));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc_all = BMBS_OK;
+    while (!c->inflight.empty()) {
+        Pending P = c->inflight.front();
+        c->inflight.pop_front();
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const u64* t = c->h_tot + (size_t)P.slot * BMBS_SLOT_WORDS;
+            const u32* f = reinterpret_cast<const u32*>(t + 16);
+            if (f[BMBS_FLAG_CIGAR]) { c->err = "cigar pool too small (it takes bmbs_max_cigar_ops() slots per read)"; rc_all = BMBS_ENOMEM; break; }
+            if (!(f[BMBS_FLAG_CAND] | f[BMBS_FLAG_SW] | f[BMBS_FLAG_RCAND])) {
+                const double nr = (double)(P.pe ? 2 * P.n : P.n);
+                if (nr > 0) {
+                    c->lr_cand = std::max(c->lr_cand, std::max(1e-9, (double)t[0] / nr));
+                    c->lr_sw = std::max(c->lr_sw, (double)t[2] / nr);
+                    c->lr_rcand = std::max(c->lr_rcand, (double)t[8] / nr);
+                }
+                c->last_total_cand = t[0]; c->last_n_jobs = t[1];
+                prof_collect(c, P.slot);
+                break;
+            }
+            if (attempt == 1) { c->err = "internal error: a call issued with exact sizes raised a capacity flag"; rc_all = BMBS_ESTATE; break; }
+            c->n_retries++;
+            P.exact = true;
+            const int rc = lane_issue(c, P);
+            if (rc) { rc_all = rc; break; }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    return rc_all;
+}
+
+// P.staged: the call reads lane-owned staging buffers (host entry points, re-laid length arrays), which the next call overwrites
+int lane_enqueue(Lane* c, Pending P, bool staged)
+{
+    if (!c->inflight.empty() && (c->lr_cand == 0 || (int)c->inflight.size() >= BMBS_SLOTS || c->inflight.back().staged || c->inflight.back().prepared || staged)) {
+        const int rc = lane_settle(c);
+        if (rc) return rc;
+    }
+    P.exact = c->kn.exact || c->lr_cand == 0;          // nothing learned yet: wait for the counts this once
+    P.slot = c->next_slot;
+    c->next_slot = (c->next_slot + 1) % BMBS_SLOTS;
+    const int rc = lane_issue(c, P);
+    if (rc) return rc;
+    P.staged = staged;
+    c->inflight.push_back(P);
     return BMBS_OK;
 }
 
-int map_pe_host(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2, const uint16_t* len1,
-                const uint16_t* len2, int32_t L, int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool,
-                int64_t cigar_cap, int64_t* n_cigar_used)
+// what earlier calls needed per read is shared by the lanes of a context
+void share_needs(bmbs_ctx* X)
 {
-    if (!c) return BMBS_EINVAL;
-    HIPCHK(c, hipSetDevice(c->dev));
-    const u64 n = (u64)n_pairs, bytes = n * (u64)stride;
-    if (n_cigar_used) *n_cigar_used = 0;
+    double a = 0, b = 0, d = 0;
+    for (Lane* c : X->lanes) { a = std::max(a, c->lr_cand); b = std::max(b, c->lr_sw); d = std::max(d, c->lr_rcand); }
+    for (Lane* c : X->lanes) { c->lr_cand = a; c->lr_sw = b; c->lr_rcand = d; }
+}
+
+int settle_all(bmbs_ctx* X)
+{
+    int rc_all = BMBS_OK;
+    for (Lane* c : X->lanes) { const int rc = lane_settle(c); if (rc) { X->err = c->err; rc_all = rc; } }
+    return rc_all;
+}
+
+// units per chunk of a call: the whole call on lane 0 when it is small (or the caller's CIGAR pool has no room for every chunk's
+// worst case), otherwise n / lanes (BMBS_CHUNK overrides) so that every lane gets one chunk per call
+int64_t chunk_units(const bmbs_ctx* X, int64_t n, int64_t cigar_cap, int rpu, int max_ops)
+{
+    if (X->lanes.size() < 2 || n < 2 * X->kn.split_min || cigar_cap < n * rpu * (int64_t)max_ops) return n;
+    int64_t ch = X->kn.chunk > 0 ? X->kn.chunk : (n + (int64_t)X->lanes.size() - 1) / (int64_t)X->lanes.size();
+    if (ch < X->kn.split_min) ch = X->kn.split_min;
+    return ch < n ? ch : n;
+}
+
+// *_device entry points: the call is cut into chunks dealt to the lanes in turn; nothing waits (bmbs_sync does)
+int dispatch_device(bmbs_ctx* X, bool pe, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, const u16* d_len, int32_t L, int32_t stride, int64_t n,
+                    uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+{
+    if (!X || X->lanes.empty()) return BMBS_EINVAL;
+    Lane* c0 = X->lanes[0];
+    if (L <= 0 || L > 1000 || stride < L || n < 0) { X->err = "bad read geometry"; return BMBS_EINVAL; }
     if (n == 0) return BMBS_OK;
-    if (L <= 0 || L > 1000 || stride < L) { c->err = "bad read geometry"; return BMBS_EINVAL; }
-    ENS(c, c->out_res, 2 * n * 32);
-    const int k = threshold_k(c->prm, L);
-    const u64 pool = 2 * n * (u64)cigar_ops_bound(c->prm, L, k);
-    ENS(c, c->cig_pool, pool * 4);
-    int ds = 0;
-    {
-        int r1 = upload_rows(c, c->in_seq, seq1, L, stride, n, &ds); if (r1) return r1;
-        r1 = upload_rows(c, c->in_qual, qual1, L, stride, n, &ds); if (r1) return r1;
-        r1 = upload_rows(c, c->in_seq2, seq2, L, stride, n, &ds); if (r1) return r1;
-        r1 = upload_rows(c, c->in_qual2, qual2, L, stride, n, &ds); if (r1) return r1;
-        if (len1) { r1 = upload_lens(c, len1, n, 0, 2 * n, L); if (r1) return r1; r1 = upload_lens(c, len2, n, n, 2 * n, L); if (r1) return r1; }
+    const int rpu = pe ? 2 : 1;
+    const int max_ops = cigar_ops_bound(X->prm, L, threshold_k(X->prm, L));
+    const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops);
+    share_needs(X);
+    int li = 0, used = 0;
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t m = std::min(ch, n - off);
+        Lane* c = ch == n ? c0 : X->lanes[(size_t)li];
+        Pending P;
+        P.pe = pe; P.L = L; P.stride = stride; P.n = m;
+        const uint64_t ro = (uint64_t)off * (uint64_t)stride;
+        P.a[0] = a0 + ro; P.a[1] = a1 + ro; P.a[2] = pe ? a2 + ro : 0; P.a[3] = pe ? a3 + ro : 0;
+        P.d_results = d_results + (uint64_t)off * rpu * 32;
+        bool staged = false;
+        P.d_len = d_len;
+        if (d_len && ch != n) {
+            if (!pe) P.d_len = d_len + off;
+            else {
+                // a chunk of pairs wants its lengths as [m first mates][m second mates]: re-laid into the lane's own array
+                HIPCHK(c, hipSetDevice(c->dev));
+                if (!c->inflight.empty()) { const int rs = lane_settle(c); if (rs) { X->err = c->err; return rs; } }
+                ENS(c, c->in_len, (u64)m * 4 + 16);
+                HIPCHK(c, hipMemcpyAsync(c->in_len.as<u16>(), d_len + off, (size_t)m * 2, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->in_len.as<u16>() + m, d_len + n + off, (size_t)m * 2, hipMemcpyDeviceToDevice, c->stream));
+                P.d_len = c->in_len.as<u16>();
+                staged = true;
+            }
+        }
+        if (ch == n) { P.d_cigar_pool = d_cigar_pool; P.cigar_cap = cigar_cap; P.cigar_base = 0; }
+        else {
+            const uint64_t base = (uint64_t)off * rpu * (uint64_t)max_ops;
+            P.d_cigar_pool = d_cigar_pool + base * 4; P.cigar_cap = m * rpu * (int64_t)max_ops; P.cigar_base = (u32)base;
+        }
+        const int rc = lane_enqueue(c, P, staged);
+        if (rc) { X->err = c->err; return rc; }
+        used = std::max(used, (ch == n ? 0 : li) + 1);
+        li = (li + 1) % (int)X->lanes.size();
     }
-    (void)bytes;
-    stride = ds;
-    int rc = map_pe_dev(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, (uint64_t)c->in_seq2.p, (uint64_t)c->in_qual2.p,
-                        len1 ? c->in_len.as<u16>() : nullptr, L, stride, n_pairs, (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, 2 * n * 32, hipMemcpyDeviceToHost, c->stream));
-    const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
-    if (used > (u64)cigar_cap) { c->err = "host cigar pool too small"; (void)hipStreamSynchronize(c->stream); return BMBS_ENOMEM; }
-    if (used) HIPCHK(c, hipMemcpyAsync(cigar_pool, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (n_cigar_used) *n_cigar_used = (int64_t)used;
+    X->used_lanes = used;
+    return BMBS_OK;
+}
+
+// host entry points: chunk i is uploaded, mapped and read back on lane i % lanes -- its copies run beside the kernels of the
+// chunks on the other lanes (one direction of the link each: 48 GB/s both ways at once on the MI355X boxes, tools/pcie_probe)
+struct HostIn { const char *seq1, *qual1, *seq2, *qual2; const uint16_t *len1, *len2; };
+int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t stride, int64_t n, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
+                  int64_t* n_cigar_used)
+{
+    static_assert(sizeof(bmbs_result) == 32 && sizeof(bmbs_result_dev) == 32, "result record is 32 bytes");
+    if (!X || X->lanes.empty()) return BMBS_EINVAL;
+    if (n_cigar_used) *n_cigar_used = 0;
+    if (n <= 0) return BMBS_OK;
+    if (L <= 0 || L > 1000 || stride < L) { X->err = "bad read geometry"; return BMBS_EINVAL; }
+    const int rpu = pe ? 2 : 1;
+    const int max_ops = cigar_ops_bound(X->prm, L, threshold_k(X->prm, L));
+    const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops);
+    const int nl = (int)X->lanes.size();
+    share_needs(X);
+    struct Open { bool on = false; int64_t off = 0, m = 0; };
+    std::vector<Open> open((size_t)nl);
+    int64_t extent = 0;
+    auto finish = [&](int li) -> int {            // the chunk in flight on lane li: counts, then exactly the CIGAR operations it produced
+        Open& o = open[(size_t)li];
+        if (!o.on) return BMBS_OK;
+        o.on = false;
+        Lane* c = X->lanes[(size_t)li];
+        const u64 retries0 = c->n_retries;
+        int rc = lane_settle(c);
+        if (rc) return rc;
+        if (c->n_retries != retries0)               // the chunk was issued again with exact sizes: the records copied behind the first attempt are stale
+            HIPCHK(c, hipMemcpyAsync(results + o.off * rpu, c->out_res.p, (u64)o.m * rpu * 32, hipMemcpyDeviceToHost, c->stream));
+        const u64 used = c->last_n_jobs * (u64)max_ops;
+        const u64 base = ch == n ? 0 : (u64)o.off * rpu * (u64)max_ops;
+        if (base + used > (u64)cigar_cap) { c->err = "host cigar pool too small"; return BMBS_ENOMEM; }
+        if (used) {
+            HIPCHK(c, hipMemcpyAsync(cigar_pool + base, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
+            extent = std::max<int64_t>(extent, (int64_t)(base + used));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BMBS_OK;
+    };
+    int li = 0, used_lanes = 0, rc = BMBS_OK;
+    for (int64_t off = 0; off < n && !rc; off += ch) {
+        const int64_t m = std::min(ch, n - off);
+        const int lane_i = ch == n ? 0 : li;
+        Lane* c = X->lanes[(size_t)lane_i];
+        rc = finish(lane_i);
+        if (rc) { X->err = c->err; break; }
+        rc = [&]() -> int {
+            HIPCHK(c, hipSetDevice(c->dev));
+            const u64 um = (u64)m;
+            ENS(c, c->out_res, um * rpu * 32);
+            const u64 pool = um * rpu * (u64)max_ops;                     // worst case: every read needs K12
+            ENS(c, c->cig_pool, pool * 4);
+            int ds = 0;
+            const size_t ro = (size_t)off * (size_t)stride;
+            int r1 = upload_rows(c, c->in_seq, in.seq1 + ro, L, stride, um, &ds); if (r1) return r1;
+            r1 = upload_rows(c, c->in_qual, in.qual1 + ro, L, stride, um, &ds); if (r1) return r1;
+            if (pe) {
+                r1 = upload_rows(c, c->in_seq2, in.seq2 + ro, L, stride, um, &ds); if (r1) return r1;
+                r1 = upload_rows(c, c->in_qual2, in.qual2 + ro, L, stride, um, &ds); if (r1) return r1;
+            }
+            if (in.len1) {
+                r1 = upload_lens(c, in.len1 + off, um, 0, um * rpu, L); if (r1) return r1;
+                if (pe) { r1 = upload_lens(c, in.len2 + off, um, um, um * rpu, L); if (r1) return r1; }
+            }
+            Pending P;
+            P.pe = pe; P.L = L; P.stride = ds; P.n = m;
+            P.a[0] = (uint64_t)c->in_seq.p; P.a[1] = (uint64_t)c->in_qual.p; P.a[2] = pe ? (uint64_t)c->in_seq2.p : 0; P.a[3] = pe ? (uint64_t)c->in_qual2.p : 0;
+            P.d_len = in.len1 ? c->in_len.as<u16>() : nullptr;
+            P.d_results = (uint64_t)c->out_res.p; P.d_cigar_pool = (uint64_t)c->cig_pool.p; P.cigar_cap = (int64_t)pool;
+            P.cigar_base = ch == n ? 0u : (u32)((u64)off * rpu * (u64)max_ops);
+            r1 = lane_enqueue(c, P, true);
+            if (r1) return r1;
+            HIPCHK(c, hipMemcpyAsync(results + off * rpu, c->out_res.p, um * rpu * 32, hipMemcpyDeviceToHost, c->stream));
+            return BMBS_OK;
+        }();
+        if (rc) { X->err = c->err; break; }
+        open[(size_t)lane_i].on = true; open[(size_t)lane_i].off = off; open[(size_t)lane_i].m = m;
+        used_lanes = std::max(used_lanes, lane_i + 1);
+        li = (li + 1) % nl;
+    }
+    for (int i = 0; i < nl; i++) {
+        const int r2 = finish(i);
+        if (r2 && !rc) { rc = r2; X->err = X->lanes[(size_t)i]->err; }
+    }
+    if (rc) { for (Lane* c : X->lanes) { (void)hipStreamSynchronize(c->stream); c->inflight.clear(); } return rc; }
+    X->used_lanes = used_lanes ? used_lanes : 1;
+    if (n_cigar_used) *n_cigar_used = extent;
     return BMBS_OK;
 }
 }  // namespace
 
-extern "C" int bmbs_map_pe_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2,
+extern "C" int bmbs_sync(bmbs_ctx* X)
+{
+    if (!X) return BMBS_EINVAL;
+    return settle_all(X);
+}
+
+extern "C" int bmbs_map_se_device(bmbs_ctx* X, uint64_t d_seq, uint64_t d_qual, int32_t L, int32_t stride,
+                                  int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+{
+    return dispatch_device(X, false, d_seq, d_qual, 0, 0, nullptr, L, stride, n_reads, d_results, d_cigar_pool, cigar_cap);
+}
+extern "C" int bmbs_map_se_var_device(bmbs_ctx* X, uint64_t d_seq, uint64_t d_qual, uint64_t d_len, int32_t L_max, int32_t stride,
+                                      int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap)
+{
+    if (X && !d_len) { X->err = "d_len is NULL"; return BMBS_EINVAL; }
+    return dispatch_device(X, false, d_seq, d_qual, 0, 0, reinterpret_cast<const u16*>(d_len), L_max, stride, n_reads, d_results, d_cigar_pool, cigar_cap);
+}
+extern "C" int bmbs_map_se(bmbs_ctx* X, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
+                           bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    const HostIn in = {seq, qual, nullptr, nullptr, nullptr, nullptr};
+    return dispatch_host(X, false, in, L, stride, n_reads, results, cigar_pool, cigar_cap, n_cigar_used);
+}
+extern "C" int bmbs_map_se_var(bmbs_ctx* X, const char* seq, const char* qual, const uint16_t* len, int32_t L_max, int32_t stride,
+                               int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (X && !len) { X->err = "len is NULL"; return BMBS_EINVAL; }
+    const HostIn in = {seq, qual, nullptr, nullptr, len, nullptr};
+    return dispatch_host(X, false, in, L_max, stride, n_reads, results, cigar_pool, cigar_cap, n_cigar_used);
+}
+extern "C" int bmbs_map_pe_device(bmbs_ctx* X, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2,
                                   int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
                                   int64_t cigar_cap)
 {
-    return map_pe_dev(c, d_seq1, d_qual1, d_seq2, d_qual2, nullptr, L, stride, n_pairs, d_results, d_cigar_pool, cigar_cap);
+    return dispatch_device(X, true, d_seq1, d_qual1, d_seq2, d_qual2, nullptr, L, stride, n_pairs, d_results, d_cigar_pool, cigar_cap);
 }
-extern "C" int bmbs_map_pe_var_device(bmbs_ctx* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, uint64_t d_len,
+extern "C" int bmbs_map_pe_var_device(bmbs_ctx* X, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, uint64_t d_len,
                                       int32_t L_max, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
                                       int64_t cigar_cap)
 {
-    if (c && !d_len) { c->err = "d_len is NULL"; return BMBS_EINVAL; }
-    return map_pe_dev(c, d_seq1, d_qual1, d_seq2, d_qual2, reinterpret_cast<const u16*>(d_len), L_max, stride, n_pairs, d_results,
-                      d_cigar_pool, cigar_cap);
+    if (X && !d_len) { X->err = "d_len is NULL"; return BMBS_EINVAL; }
+    return dispatch_device(X, true, d_seq1, d_qual1, d_seq2, d_qual2, reinterpret_cast<const u16*>(d_len), L_max, stride, n_pairs, d_results,
+                           d_cigar_pool, cigar_cap);
 }
-extern "C" int bmbs_map_pe(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2, int32_t L,
+extern "C" int bmbs_map_pe(bmbs_ctx* X, const char* seq1, const char* qual1, const char* seq2, const char* qual2, int32_t L,
                            int32_t stride, int64_t n_pairs, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
                            int64_t* n_cigar_used)
 {
-    return map_pe_host(c, seq1, qual1, seq2, qual2, nullptr, nullptr, L, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
+    const HostIn in = {seq1, qual1, seq2, qual2, nullptr, nullptr};
+    return dispatch_host(X, true, in, L, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
 }
-extern "C" int bmbs_map_pe_var(bmbs_ctx* c, const char* seq1, const char* qual1, const char* seq2, const char* qual2,
+extern "C" int bmbs_map_pe_var(bmbs_ctx* X, const char* seq1, const char* qual1, const char* seq2, const char* qual2,
                                const uint16_t* len1, const uint16_t* len2, int32_t L_max, int32_t stride, int64_t n_pairs,
                                bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
 {
-    if (c && (!len1 || !len2)) { c->err = "len1 / len2 is NULL"; return BMBS_EINVAL; }
-    return map_pe_host(c, seq1, qual1, seq2, qual2, len1, len2, L_max, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
+    if (X && (!len1 || !len2)) { X->err = "len1 / len2 is NULL"; return BMBS_EINVAL; }
+    const HostIn in = {seq1, qual1, seq2, qual2, len1, len2};
+    return dispatch_host(X, true, in, L_max, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1235,7 +1614,7 @@ extern "C" int bmbs_map_pe_var(bmbs_ctx* c, const char* seq1, const char* qual1,
 namespace {
 struct FqDev { const char* text; const u32* seq_off; const u32* qual_off; const u16* seq_len; const u16* qual_len; };
 
-int fastq_check(bmbs_ctx* c, const bmbs_fastq_view* v, int64_t n, int L_max)
+int fastq_check(Lane* c, const bmbs_fastq_view* v, int64_t n, int L_max)
 {
     if (!v || !v->text || !v->seq_off || !v->qual_off || !v->seq_len || !v->qual_len) { c->err = "fastq view: NULL field"; return BMBS_EINVAL; }
     if (v->text_bytes >= (1ull << 32)) { c->err = "fastq view: a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
@@ -1250,7 +1629,7 @@ int fastq_check(bmbs_ctx* c, const bmbs_fastq_view* v, int64_t n, int L_max)
     return BMBS_OK;
 }
 // text + index arrays of one file to the device; idx_at = byte offset of this file's arrays inside c->fq_idx
-int fastq_upload(bmbs_ctx* c, DevBuf& dtext, const bmbs_fastq_view* v, u64 n, u64 idx_at, FqDev& out)
+int fastq_upload(Lane* c, DevBuf& dtext, const bmbs_fastq_view* v, u64 n, u64 idx_at, FqDev& out)
 {
     ENS(c, dtext, v->text_bytes + 64);
     HIPCHK(c, hipMemcpyAsync(dtext.p, v->text, v->text_bytes, hipMemcpyHostToDevice, c->stream));
@@ -1265,7 +1644,7 @@ int fastq_upload(bmbs_ctx* c, DevBuf& dtext, const bmbs_fastq_view* v, u64 n, u6
 }
 }  // namespace
 
-extern "C" int bmbs_map_se_fastq(bmbs_ctx* c, const bmbs_fastq_view* reads, int64_t n_reads, int32_t L_max, int32_t uniform, int32_t pbat,
+static int lane_map_se_fastq(Lane* c, const bmbs_fastq_view* reads, int64_t n_reads, int32_t L_max, int32_t uniform, int32_t pbat,
                                  bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
 {
     if (!c) return BMBS_EINVAL;
@@ -1285,8 +1664,13 @@ extern "C" int bmbs_map_se_fastq(bmbs_ctx* c, const bmbs_fastq_view* reads, int6
     { const int r1 = fastq_upload(c, c->fq_text1, reads, n, 0, f); if (r1) return r1; }
     hipLaunchKernelGGL(k_fastq_rows, dim3(nblk(n * (u64)(ds / 16), 256)), dim3(256), 0, c->stream, f.text, f.seq_off, f.qual_off, f.seq_len,
                        f.qual_len, (long)n, ds, pbat ? 1 : 0, pbat ? 1 : 0, c->in_seq.as<char>(), c->in_qual.as<char>(), c->in_len.as<u16>());
-    int rc = map_se_dev(c, (uint64_t)c->in_seq.p, (uint64_t)c->in_qual.p, uniform ? nullptr : c->in_len.as<u16>(), L_max, ds, n_reads,
-                        (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool);
+    Pending P;
+    P.pe = false; P.L = L_max; P.stride = ds; P.n = n_reads;
+    P.a[0] = (uint64_t)c->in_seq.p; P.a[1] = (uint64_t)c->in_qual.p; P.d_len = uniform ? nullptr : c->in_len.as<u16>();
+    P.d_results = (uint64_t)c->out_res.p; P.d_cigar_pool = (uint64_t)c->cig_pool.p; P.cigar_cap = (int64_t)pool;
+    int rc = lane_enqueue(c, P, true);
+    if (rc) return rc;
+    rc = lane_settle(c);                         // counts (and, rarely, the repeat with exact sizes) before anything is copied back
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n * 32, hipMemcpyDeviceToHost, c->stream));
     const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
@@ -1297,7 +1681,7 @@ extern "C" int bmbs_map_se_fastq(bmbs_ctx* c, const bmbs_fastq_view* reads, int6
     return BMBS_OK;
 }
 
-extern "C" int bmbs_map_pe_fastq(bmbs_ctx* c, const bmbs_fastq_view* mate1, const bmbs_fastq_view* mate2, int64_t n_pairs, int32_t L_max,
+static int lane_map_pe_fastq(Lane* c, const bmbs_fastq_view* mate1, const bmbs_fastq_view* mate2, int64_t n_pairs, int32_t L_max,
                                  int32_t uniform, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
 {
     if (!c) return BMBS_EINVAL;
@@ -1322,8 +1706,14 @@ extern "C" int bmbs_map_pe_fastq(bmbs_ctx* c, const bmbs_fastq_view* mate1, cons
                        seq_all, c->in_qual.as<char>(), c->in_len.as<u16>());
     hipLaunchKernelGGL(k_fastq_rows, dim3(g), dim3(256), 0, c->stream, f2.text, f2.seq_off, f2.qual_off, f2.seq_len, f2.qual_len, (long)n, ds, 1, 0,
                        seq_all + n * (u64)ds, c->in_qual2.as<char>(), c->in_len.as<u16>() + n);
-    int rc = map_pe_dev(c, (uint64_t)seq_all, (uint64_t)c->in_qual.p, (uint64_t)(seq_all + n * (u64)ds), (uint64_t)c->in_qual2.p,
-                        uniform ? nullptr : c->in_len.as<u16>(), L_max, ds, n_pairs, (uint64_t)c->out_res.p, (uint64_t)c->cig_pool.p, (int64_t)pool, true);
+    Pending P;
+    P.pe = true; P.L = L_max; P.stride = ds; P.n = n_pairs; P.prepared = true;
+    P.a[0] = (uint64_t)seq_all; P.a[1] = (uint64_t)c->in_qual.p; P.a[2] = (uint64_t)(seq_all + n * (u64)ds); P.a[3] = (uint64_t)c->in_qual2.p;
+    P.d_len = uniform ? nullptr : c->in_len.as<u16>();
+    P.d_results = (uint64_t)c->out_res.p; P.d_cigar_pool = (uint64_t)c->cig_pool.p; P.cigar_cap = (int64_t)pool;
+    int rc = lane_enqueue(c, P, true);
+    if (rc) return rc;
+    rc = lane_settle(c);                         // counts (and, rarely, the repeat with exact sizes) before anything is copied back
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->out_res.p, n2 * 32, hipMemcpyDeviceToHost, c->stream));
     const u64 used = c->last_n_jobs * (u64)c->last_max_ops;
@@ -1335,7 +1725,7 @@ extern "C" int bmbs_map_pe_fastq(bmbs_ctx* c, const bmbs_fastq_view* mate1, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int bmbs_locate_batch(bmbs_ctx* c, const uint64_t* row, int64_t n_rows, uint64_t* pos)
+static int lane_locate_batch(Lane* c, const uint64_t* row, int64_t n_rows, uint64_t* pos)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -1353,17 +1743,18 @@ extern "C" int bmbs_locate_batch(bmbs_ctx* c, const uint64_t* row, int64_t n_row
 // A second context on the index of another one (same device): it takes the device pointers, owns none of the index memory and
 // has its own stream and work buffers.  Two such contexts driven by two host threads keep two batches in flight: the kernels of
 // one hide the memory waits and the low-occupancy phases of the other's.
-extern "C" int bmbs_index_share(bmbs_ctx* c, const bmbs_ctx* owner)
+extern "C" int bmbs_index_share(bmbs_ctx* X, const bmbs_ctx* owner)
 {
-    if (!c || !owner) return BMBS_EINVAL;
-    if (!owner->attached) { c->err = "index share: the owner has no index attached"; return BMBS_ESTATE; }
-    if (c->dev != owner->dev) { c->err = "index share: contexts on different devices"; return BMBS_EINVAL; }
-    if (c->attached) { c->err = "index share: this context already has an index"; return BMBS_ESTATE; }
-    c->ix = owner->ix; c->rows = owner->rows; c->attached = true;
+    if (!X || !owner || X->lanes.empty() || owner->lanes.empty()) return BMBS_EINVAL;
+    const Lane* o = owner->lanes[0];
+    if (!o->attached) { X->err = "index share: the owner has no index attached"; return BMBS_ESTATE; }
+    if (X->dev != owner->dev) { X->err = "index share: contexts on different devices"; return BMBS_EINVAL; }
+    if (X->lanes[0]->attached) { X->err = "index share: this context already has an index"; return BMBS_ESTATE; }
+    for (Lane* c : X->lanes) { c->ix = o->ix; c->rows = o->rows; c->attached = true; }
     return BMBS_OK;
 }
 
-extern "C" int bmbs_vote_order_batch(bmbs_ctx* c, const uint8_t* vote, const int64_t* seg_off, int64_t n_seg, int32_t form,
+static int lane_vote_order_batch(Lane* c, const uint8_t* vote, const int64_t* seg_off, int64_t n_seg, int32_t form,
                                      uint32_t* perm)
 {
     if (!c) return BMBS_EINVAL;
@@ -1388,7 +1779,7 @@ extern "C" int bmbs_vote_order_batch(bmbs_ctx* c, const uint8_t* vote, const int
     return BMBS_OK;
 }
 
-extern "C" int bmbs_window_batch(bmbs_ctx* c, const uint64_t* site, int64_t n_sites, int32_t len, char* out)
+static int lane_window_batch(Lane* c, const uint64_t* site, int64_t n_sites, int32_t len, char* out)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -1404,7 +1795,7 @@ extern "C" int bmbs_window_batch(bmbs_ctx* c, const uint64_t* site, int64_t n_si
     return BMBS_OK;
 }
 
-extern "C" int bmbs_filter_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
+static int lane_filter_batch(Lane* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
                                  const uint32_t* read_of, const uint64_t* site, int64_t n_cand, uint32_t* err,
                                  int32_t* end_site)
 {
@@ -1429,7 +1820,7 @@ extern "C" int bmbs_filter_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_
     return BMBS_OK;
 }
 
-extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
+static int lane_align_batch(Lane* c, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads,
                                 const uint32_t* read_of, const uint64_t* site, const int32_t* end_site_in,
                                 const uint32_t* err_in, int64_t n_jobs, int32_t* start_site, int32_t* end_site,
                                 uint32_t* nm, int32_t* score, uint32_t* cigar_ops, int32_t* n_ops, int32_t max_ops)
@@ -1456,7 +1847,7 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     HIPCHK(c, hipMemcpyAsync(c->in_c.p, end_site_in, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_d.p, err_in, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->cig_pool.p, 0, m * (u64)max_ops * 4, c->stream));
-    c->n_prof_used = 0;
+    c->cur_slot = 0; c->prof_used[0] = 0;
     Jobs jobs = {c->in_a.as<u32>(), c->in_b.as<u64>(), c->in_c.as<int>(), c->in_d.as<u32>()};
     int rc = run_align(c, c->in_seq.as<char>(), c->in_qual.as<char>(), geom(c, L, nullptr), stride, m, jobs, 0xffffffffu, c->cig_pool.as<u32>(), max_ops);
     if (rc) return rc;
@@ -1467,10 +1858,11 @@ extern "C" int bmbs_align_batch(bmbs_ctx* c, const char* seq, const char* qual, 
     HIPCHK(c, hipMemcpyAsync(n_ops, c->a_nops.p, m * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cigar_ops, c->cig_pool.p, m * (u64)max_ops * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c, 0);
     return BMBS_OK;
 }
 
-extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads, uint8_t* verdict,
+static int lane_seed_batch(Lane* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads, uint8_t* verdict,
                                uint64_t* exit_site, uint64_t* seg_off, uint32_t* n_votes, uint64_t* vote_site,
                                uint32_t* vote_cnt, int64_t vote_cap, int64_t* total_slots)
 {
@@ -1482,7 +1874,7 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
     if (n == 0) return BMBS_OK;
     if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     { const int r0 = prepare_luts(c); if (r0) return r0; }
-    c->n_prof_used = 0;
+    c->cur_slot = 0; c->prof_used[0] = 0;
     int rc = per_read_workspace(c, n);
     if (rc) return rc;
     { int ds = 0; int r1 = upload_rows(c, c->in_seq, seq, L, stride, n, &ds); if (r1) return r1; stride = ds; (void)bytes; }
@@ -1505,22 +1897,28 @@ extern "C" int bmbs_seed_batch(bmbs_ctx* c, const char* seq, int32_t L, int32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int bmbs_stats_get(bmbs_ctx* c, int64_t stats[5])
+extern "C" int bmbs_stats_get(bmbs_ctx* X, int64_t stats[5])
 {
-    if (!c) return BMBS_EINVAL;
-    HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!X) return BMBS_EINVAL;
+    { const int rc = settle_all(X); if (rc) return rc; }
     static_assert(sizeof(unsigned long long) == 8, "");
-    uint64_t all[BMBS_SHARDS * BMBS_SHARD_WORDS];
-    HIPCHK(c, hipMemcpy(all, c->stats.p, sizeof(all), hipMemcpyDeviceToHost));
-    for (int j = 0; j < 5; j++) { uint64_t t = 0; for (int sdx = 0; sdx < BMBS_SHARDS; sdx++) t += all[sdx * BMBS_SHARD_WORDS + j]; stats[j] = (int64_t)t; }
+    for (int j = 0; j < 5; j++) stats[j] = 0;
+    for (Lane* c : X->lanes) {
+        uint64_t all[BMBS_SHARDS * BMBS_SHARD_WORDS];
+        HIPCHK(c, hipSetDevice(c->dev));
+        HIPCHK(c, hipMemcpy(all, c->stats.p, sizeof(all), hipMemcpyDeviceToHost));
+        for (int j = 0; j < 5; j++) { uint64_t t = 0; for (int sdx = 0; sdx < BMBS_SHARDS; sdx++) t += all[sdx * BMBS_SHARD_WORDS + j]; stats[j] += (int64_t)t; }
+    }
     return BMBS_OK;
 }
-extern "C" int bmbs_stats_reset(bmbs_ctx* c)
+extern "C" int bmbs_stats_reset(bmbs_ctx* X)
 {
-    if (!c) return BMBS_EINVAL;
-    HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipMemsetAsync(c->stats.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
+    if (!X) return BMBS_EINVAL;
+    { const int rc = settle_all(X); if (rc) return rc; }
+    for (Lane* c : X->lanes) {
+        HIPCHK(c, hipSetDevice(c->dev));
+        HIPCHK(c, hipMemsetAsync(c->stats.p, 0, BMBS_SHARDS * BMBS_SHARD_WORDS * 8, c->stream));
+    }
     return BMBS_OK;
 }
 extern "C" int bmbs_stats_allreduce(bmbs_ctx** ctxs, int n, int64_t stats[5])
@@ -1535,42 +1933,116 @@ extern "C" int bmbs_stats_allreduce(bmbs_ctx** ctxs, int n, int64_t stats[5])
     return BMBS_OK;
 }
 
-extern "C" int bmbs_profile_last(bmbs_ctx* c, const char** names, float* ms, int* n)
+// the kernels of the last mapping call, lane by lane (a split call has every kernel once per lane it ran on: the caller adds them up)
+extern "C" int bmbs_profile_last(bmbs_ctx* X, const char** names, float* ms, int* n)
 {
-    if (!c || !n) return BMBS_EINVAL;
-    HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!X || !n) return BMBS_EINVAL;
+    { const int rc = settle_all(X); if (rc) return rc; }
     int cap = *n, cntp = 0;
-    for (int i = 0; i < c->n_prof_used && cntp < cap; i++) {
-        float t = 0;
-        if (hipEventElapsedTime(&t, c->prof[i].a, c->prof[i].b) != hipSuccess) t = -1.f;
-        names[cntp] = c->prof[i].name; ms[cntp] = t; cntp++;
+    for (int li = 0; li < X->used_lanes && li < (int)X->lanes.size(); li++) {
+        Lane* c = X->lanes[(size_t)li];
+        for (size_t i = 0; i < c->last.size() && cntp < cap; i++) { names[cntp] = c->last[i].name; ms[cntp] = (float)c->last[i].ms; cntp++; }
     }
     *n = cntp;
     return BMBS_OK;
 }
 
-extern "C" int bmbs_counters_last(bmbs_ctx* c, uint64_t out[8])
+// sums over every mapping call settled since the last bmbs_profile_reset (all lanes): the bench reads per-kernel averages from
+// here once per timed region instead of waiting for the device after every call
+extern "C" int bmbs_profile_total(bmbs_ctx* X, const char** names, double* ms, int* n, int64_t* calls)
+{
+    if (!X || !n) return BMBS_EINVAL;
+    { const int rc = settle_all(X); if (rc) return rc; }
+    int cap = *n, cntp = 0;
+    int64_t nc = 0;
+    for (Lane* c : X->lanes) {
+        nc += (int64_t)c->acc_calls;
+        for (const auto& a : c->acc) {
+            int at = -1;
+            for (int j = 0; j < cntp; j++) if (!strcmp(names[j], a.name)) { at = j; break; }
+            if (at < 0) { if (cntp >= cap) continue; at = cntp++; names[at] = a.name; ms[at] = 0; }
+            ms[at] += a.ms;
+        }
+    }
+    *n = cntp;
+    if (calls) *calls = nc;
+    return BMBS_OK;
+}
+extern "C" int bmbs_profile_reset(bmbs_ctx* X)
+{
+    if (!X) return BMBS_EINVAL;
+    { const int rc = settle_all(X); if (rc) return rc; }
+    for (Lane* c : X->lanes) { c->acc.clear(); c->acc_calls = 0; }
+    return BMBS_OK;
+}
+
+extern "C" int bmbs_counters_last(bmbs_ctx* X, uint64_t out[8])
 {
     uint64_t all[32];
-    int rc = bmbs_counters_all(c, all);
+    int rc = bmbs_counters_all(X, all);
     if (rc) return rc;
     for (int i = 0; i < 8; i++) out[i] = all[i];
     return BMBS_OK;
 }
 
-extern "C" int bmbs_counters_all(bmbs_ctx* c, uint64_t out[32])
+extern "C" int bmbs_counters_all(bmbs_ctx* X, uint64_t out[32])
 {
-    if (!c) return BMBS_EINVAL;
-    HIPCHK(c, hipSetDevice(c->dev));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint64_t all[BMBS_SHARDS * BMBS_SHARD_WORDS];
-    HIPCHK(c, hipMemcpy(all, c->counters.p, sizeof(all), hipMemcpyDeviceToHost));
-    for (int j = 0; j < 32; j++) { uint64_t t = 0; for (int sdx = 0; sdx < BMBS_SHARDS; sdx++) t += all[sdx * BMBS_SHARD_WORDS + j]; out[j] = t; }
-    out[6] = c->last_total_cand;
-    out[7] = c->last_n_jobs;
+    if (!X) return BMBS_EINVAL;
+    { const int rc = settle_all(X); if (rc) return rc; }
+    for (int j = 0; j < 32; j++) out[j] = 0;
+    uint64_t cand = 0, jobs = 0;
+    for (int li = 0; li < X->used_lanes && li < (int)X->lanes.size(); li++) {
+        Lane* c = X->lanes[(size_t)li];
+        uint64_t all[BMBS_SHARDS * BMBS_SHARD_WORDS];
+        HIPCHK(c, hipSetDevice(c->dev));
+        HIPCHK(c, hipMemcpy(all, c->counters.p, sizeof(all), hipMemcpyDeviceToHost));
+        for (int j = 0; j < 32; j++) { uint64_t t = 0; for (int sdx = 0; sdx < BMBS_SHARDS; sdx++) t += all[sdx * BMBS_SHARD_WORDS + j]; out[j] += t; }
+        cand += c->last_total_cand; jobs += c->last_n_jobs;
+    }
+    out[6] = cand;
+    out[7] = jobs;
     return BMBS_OK;
 }
+
+// diagnostic: calls that were issued again with exact sizes because a stage count did not fit the capacity learned so far
+extern "C" int64_t bmbs_retries(bmbs_ctx* X)
+{
+    int64_t t = 0;
+    if (X) for (Lane* c : X->lanes) t += (int64_t)c->n_retries;
+    return t;
+}
+
+// ---- the stage entry points and the FASTQ-text calls run on lane 0 -----------------------------------------------------------
+#define ON_LANE0(call) Lane* c = lane0(X); if (!c) return BMBS_EINVAL; { const int rs_ = settle_all(X); if (rs_) return rs_; } X->used_lanes = 1; return fin(X, c, call)
+extern "C" int bmbs_index_attach(bmbs_ctx* X, const bmbs_index_view* v)
+{
+    Lane* c = lane0(X);
+    if (!c) return BMBS_EINVAL;
+    const int rc = lane_index_attach(c, v);
+    if (rc) return fin(X, c, rc);
+    for (size_t i = 1; i < X->lanes.size(); i++) { Lane* o = X->lanes[i]; o->ix = c->ix; o->rows = c->rows; o->attached = true; }
+    return BMBS_OK;
+}
+extern "C" int bmbs_locate_batch(bmbs_ctx* X, const uint64_t* row, int64_t n_rows, uint64_t* pos) { ON_LANE0(lane_locate_batch(c, row, n_rows, pos)); }
+extern "C" int bmbs_vote_order_batch(bmbs_ctx* X, const uint8_t* vote, const int64_t* seg_off, int64_t n_seg, int32_t form, uint32_t* perm)
+{ ON_LANE0(lane_vote_order_batch(c, vote, seg_off, n_seg, form, perm)); }
+extern "C" int bmbs_window_batch(bmbs_ctx* X, const uint64_t* site, int64_t n_sites, int32_t len, char* out) { ON_LANE0(lane_window_batch(c, site, n_sites, len, out)); }
+extern "C" int bmbs_filter_batch(bmbs_ctx* X, const char* seq, int32_t L, int32_t stride, int64_t n_reads, const uint32_t* read_of, const uint64_t* site,
+                                 int64_t n_cand, uint32_t* err, int32_t* end_site)
+{ ON_LANE0(lane_filter_batch(c, seq, L, stride, n_reads, read_of, site, n_cand, err, end_site)); }
+extern "C" int bmbs_align_batch(bmbs_ctx* X, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads, const uint32_t* read_of,
+                                const uint64_t* site, const int32_t* end_site_in, const uint32_t* err_in, int64_t n_jobs, int32_t* start_site,
+                                int32_t* end_site, uint32_t* nm, int32_t* score, uint32_t* cigar_ops, int32_t* n_ops, int32_t max_ops)
+{ ON_LANE0(lane_align_batch(c, seq, qual, L, stride, n_reads, read_of, site, end_site_in, err_in, n_jobs, start_site, end_site, nm, score, cigar_ops, n_ops, max_ops)); }
+extern "C" int bmbs_seed_batch(bmbs_ctx* X, const char* seq, int32_t L, int32_t stride, int64_t n_reads, uint8_t* verdict, uint64_t* exit_site,
+                               uint64_t* seg_off, uint32_t* n_votes, uint64_t* vote_site, uint32_t* vote_cnt, int64_t vote_cap, int64_t* total_slots)
+{ ON_LANE0(lane_seed_batch(c, seq, L, stride, n_reads, verdict, exit_site, seg_off, n_votes, vote_site, vote_cnt, vote_cap, total_slots)); }
+extern "C" int bmbs_map_se_fastq(bmbs_ctx* X, const bmbs_fastq_view* reads, int64_t n_reads, int32_t L_max, int32_t uniform, int32_t pbat,
+                                 bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{ ON_LANE0(lane_map_se_fastq(c, reads, n_reads, L_max, uniform, pbat, results, cigar_pool, cigar_cap, n_cigar_used)); }
+extern "C" int bmbs_map_pe_fastq(bmbs_ctx* X, const bmbs_fastq_view* mate1, const bmbs_fastq_view* mate2, int64_t n_pairs, int32_t L_max,
+                                 int32_t uniform, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{ ON_LANE0(lane_map_pe_fastq(c, mate1, mate2, n_pairs, L_max, uniform, results, cigar_pool, cigar_cap, n_cigar_used)); }
 
 #ifndef BMBS_BUILD_ID
 #define BMBS_BUILD_ID "unknown"

@@ -714,9 +714,12 @@ DEVI void scan_load8(const u32* in, u64 base, u64 n, u32 x[SCAN_ITEMS])
     }
 }
 // nz: the values count as flags (x != 0)
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partial(const u32* in, u64 n, u64* block_sums, int nz)
+// n_dev != nullptr: only the first min(n, *n_dev) entries exist (a count an earlier kernel of the same stream left in device
+// memory: the launch is sized for the capacity n and the host never waits for the count)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partial(const u32* in, u64 n, u64* block_sums, int nz, const u64* __restrict__ n_dev)
 {
     __shared__ u64 sh[SCAN_BLOCK / 64];
+    if (n_dev) { const u64 nd = *n_dev; if (nd < n) n = nd; }
     const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
     u32 x[SCAN_ITEMS];
     scan_load8(in, base, n, x);
@@ -747,9 +750,10 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(u64* block_sums, u64 nb, u
 }
 // list != nullptr: `in` holds 0/1 flags and the positions of the ones are written, in order, to list[]; the offsets
 // themselves are not stored (the work lists of the seeding stages need nothing else)
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out, u32* list, int nz)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out, u32* list, int nz, const u64* __restrict__ n_dev)
 {
     __shared__ u64 sh[SCAN_BLOCK / 64];
+    if (n_dev) { const u64 nd = *n_dev; if (nd < n) n = nd; }
     const u64 base = (u64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
     u32 x[SCAN_ITEMS];
     scan_load8(in, base, n, x);
@@ -780,7 +784,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n,
         for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) { out[base + j] = run; run += x[j]; }
     }
     if (base <= n && n < base + SCAN_ITEMS) out[n] = run;                   // the thread that owns position n writes the total
-    if (n % ((u64)SCAN_BLOCK * SCAN_ITEMS) == 0 && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = run;
+    if (n % ((u64)SCAN_BLOCK * SCAN_ITEMS) == 0 && n && base + SCAN_ITEMS == n) out[n] = run;
 }
 
 // ================================================================================================
@@ -2334,10 +2338,11 @@ k_vote_order(const uint8_t* __restrict__ vote, const long* __restrict__ seg_off,
 // the vote lists are shorter than the candidate segments they were built in: pack them densely
 // (vote_off = exclusive scan of n_votes) so that the filter runs on full waves
 __global__ void __launch_bounds__(256)
-k_vote_compact(u64 n_slots, ReadState st, const u64* __restrict__ vote_off, const u32* __restrict__ slot_read,
+k_vote_compact(u64 n_slots, const u64* __restrict__ n_slots_dev, ReadState st, const u64* __restrict__ vote_off, const u32* __restrict__ slot_read,
                const bmbs_vote* __restrict__ votes, bmbs_vote* __restrict__ dense, u32* __restrict__ dense_read)
 {
     const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_slots_dev) { const u64 nd = *n_slots_dev; if (nd < n_slots) n_slots = nd; }
     if (g >= n_slots) return;
     const u32 r = slot_read[g];
     if (r == 0xffffffffu) return;
@@ -2637,6 +2642,60 @@ k_reduce(long n, int ambiguous_out, ReadState st, const u64* __restrict__ vote_o
     }
 }
 
+// ---- launches without host round trips ------------------------------------------------------------------------------------------
+// The stage counts (candidate slots, jobs, DP jobs, re-seeded candidates) are only known on the device.  A call that does not
+// wait for them sizes its buffers and grids from what earlier calls of the same shape needed (plus a margin) and lets these
+// guards compare the real count with that capacity right after the scan that produced it.  On overflow the guard raises a
+// flag and takes the work away from every later kernel (nothing is written out of bounds); the host sees the flag when it next
+// synchronises and runs the batch again with exact sizes.  The statistics of a call are added to the context's counters by
+// k_stats_commit only when no flag is up, so a repeated batch counts once.
+#define BMBS_FLAG_CAND   0   // candidate slots > capacity
+#define BMBS_FLAG_SW     1   // DP jobs > capacity of the launches issued
+#define BMBS_FLAG_RCAND  2   // --sensitive: re-seeded candidates > capacity
+#define BMBS_FLAG_CIGAR  3   // the caller's CIGAR pool is too small for the jobs of this batch (an error, not a retry)
+#define BMBS_FLAG_WORDS  8
+__global__ void __launch_bounds__(256)
+k_guard_cand(u64* __restrict__ total, u64 cap, u32* __restrict__ flags, long n, u8* __restrict__ verdict, u32* __restrict__ n_cand,
+             u64* __restrict__ cand_off)
+{
+    if (*total <= cap && !flags[BMBS_FLAG_CAND]) return;
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) { verdict[r] = 0; n_cand[r] = 0; cand_off[r] = 0; }
+    if (r == 0) { cand_off[n] = 0; flags[BMBS_FLAG_CAND] = 1; }
+    // *total is cleared by k_guard_done (one thread, after this kernel: other blocks still read it here)
+}
+__global__ void k_guard_done(u64* __restrict__ total, const u32* __restrict__ flags, int flag) { if (flags[flag]) *total = 0; }
+// jobs: the arrays are sized for one job per read, only the caller's CIGAR pool can be too small
+__global__ void __launch_bounds__(256)
+k_guard_jobs(const u64* __restrict__ n_jobs, u64 max_ops, u64 cigar_cap, u32* __restrict__ flags, long n, u32* __restrict__ job_flag)
+{
+    if (*n_jobs * max_ops <= cigar_cap && !flags[BMBS_FLAG_CIGAR]) return;
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) job_flag[r] = 0;
+    if (r == 0) flags[BMBS_FLAG_CIGAR] = 1;
+}
+__global__ void k_guard_count(const u64* __restrict__ count, u64 cap, u32* __restrict__ flags, int flag) { if (*count > cap) flags[flag] = 1; }
+// --sensitive: candidates of the re-seeded mates
+__global__ void __launch_bounds__(256)
+k_guard_rcand(const u64* __restrict__ total, u64 cap, u32* __restrict__ flags, long n, u32* __restrict__ rcnt, u64* __restrict__ item_off)
+{
+    if (*total <= cap && !flags[BMBS_FLAG_RCAND]) return;
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) { rcnt[r] = 0; item_off[r] = 0; }
+    if (r == 0) { item_off[n] = 0; flags[BMBS_FLAG_RCAND] = 1; }
+}
+// the five mapstats counters of this call (sharded like the context's) -> the context's, unless the call is going to be repeated
+__global__ void __launch_bounds__(256)
+k_stats_commit(const u32* __restrict__ flags, unsigned long long* __restrict__ call_stats, unsigned long long* __restrict__ stats, int words)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    const bool again = flags[BMBS_FLAG_CAND] | flags[BMBS_FLAG_SW] | flags[BMBS_FLAG_RCAND] | flags[BMBS_FLAG_CIGAR];
+    const unsigned long long v = call_stats[i];
+    call_stats[i] = 0;
+    if (!again && v) stats[i] += v;
+}
+
 // job arrays shared by the fused path and bmbs_align_batch
 struct Jobs {
     const u32* read;      // read (row) of the job
@@ -2680,11 +2739,12 @@ DEVI const char* qual_row(const char* qual, const char* qual2, u32 rev_qual_from
 
 __global__ void __launch_bounds__(256)
 k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq,
-                 const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
+                 const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, u64 n_jobs, const u64* __restrict__ n_jobs_dev, Jobs jb_, u32 rev_qual_from,
                  int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
                  int* __restrict__ a_nops, u32* __restrict__ need_sw, unsigned long long* __restrict__ counters)
 {
     const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_jobs_dev) { const u64 nd = *n_jobs_dev; if (nd < n_jobs) n_jobs = nd; }
     if (jb >= n_jobs) return;
     const u32 r = jb_.read[jb];
     const u64 site = jb_.site[jb];
@@ -2742,11 +2802,12 @@ k_align_ungapped(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, c
 // the quality row touched only at the mismatching positions, the ASCII row only where a dirty read might hold an 'N'
 __global__ void __launch_bounds__(256)
 k_align_ungapped_p(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const char* __restrict__ seq, PackedRows pr,
-                   const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, u64 n_jobs, Jobs jb_, u32 rev_qual_from,
+                   const char* __restrict__ qual, const char* __restrict__ qual2, ReadGeom gm, int stride, u64 n_jobs, const u64* __restrict__ n_jobs_dev, Jobs jb_, u32 rev_qual_from,
                    int* __restrict__ a_start, int* __restrict__ a_end, u32* __restrict__ a_nm, int* __restrict__ a_score,
                    int* __restrict__ a_nops, u32* __restrict__ need_sw, unsigned long long* __restrict__ counters)
 {
     const u64 jb = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_jobs_dev) { const u64 nd = *n_jobs_dev; if (nd < n_jobs) n_jobs = nd; }
     if (jb >= n_jobs) return;
     const u32 r = jb_.read[jb];
     const u64 site = jb_.site[jb];
@@ -3524,8 +3585,9 @@ k_align_sw_wave(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, co
 // finalize: MAPQ, placement, stats
 // ================================================================================================
 struct bmbs_result_dev {   // == bmbs_result (include/bmbs.h), 32 bytes
-    u64 pos; u32 cigar_off; int16_t chrom; u8 status; u8 mapq; u16 flag; u16 nm; int16_t score; u8 n_cigar; u8 path; u32 n_cand; u32 reserved;
+    u64 pos; u32 cigar_off; int32_t chrom; u16 flag; u16 nm; int16_t score; u8 status; u8 mapq; u8 n_cigar; u8 path; u16 n_cand; u32 tlen;
 };
+DEVI u16 sat16(u32 v) { return v > 0xffffu ? (u16)0xffffu : (u16)v; }
 
 // mapq_lut[(ed) * (range+1) + sd]: MAP_Calculation (Schema.cpp:168-405) tabulated on the host in
 // IEEE double for this k: ed = min(second_best_diff, k+1), sd = clamp(score + range, 0, range).
@@ -3534,7 +3596,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
            const u32* __restrict__ mapq_off, int unit, const char* __restrict__ seq, const char* __restrict__ qual, ReadGeom gm,
            int stride, long n, ReadState st, const int* __restrict__ a_start, const int* __restrict__ a_end,
            const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops,
-           int max_ops, int ambiguous_out, const u64* __restrict__ sp0, const u32* __restrict__ hits0,
+           int max_ops, u32 cigar_base, int ambiguous_out, const u64* __restrict__ sp0, const u32* __restrict__ hits0,
            bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
 {
     __shared__ unsigned long long sh[5];
@@ -3547,7 +3609,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
     if (r < n) {
         bmbs_result_dev o;
         o.pos = 0; o.cigar_off = 0; o.chrom = -1; o.status = 0; o.mapq = 0; o.flag = 0; o.nm = 0; o.score = 0;
-        o.n_cigar = 0; o.path = 0; o.n_cand = st.n_cand[r]; o.reserved = 0;
+        o.n_cigar = 0; o.path = 0; o.n_cand = sat16(st.n_cand[r]); o.tlen = 0;
         const int verdict = st.verdict[r];
         const int L = gm.rl(r), k = gm.rk(L);
         const int range = unit * k;
@@ -3578,7 +3640,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
                     if (c >= ix.n_chrom) continue;
                     const u64 pos = loc + 1 - cs[c];
                     if (pos + (u64)(L - 1) > cs[c + 1] - cs[c]) continue;
-                    o.pos = pos; o.chrom = (int16_t)c; o.flag = (u16)flag; o.mapq = 1; o.status = 2;
+                    o.pos = pos; o.chrom = c; o.flag = (u16)flag; o.mapq = 1; o.status = 2;
                     break;
                 }
             }
@@ -3593,7 +3655,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
                     const u64 jb = st.job_off[r];
                     start_site = a_start[jb]; end_site = a_end[jb]; nm = a_nm[jb]; score = a_score[jb];
                     const int no = a_nops[jb];
-                    o.cigar_off = (u32)(jb * (u64)max_ops);
+                    o.cigar_off = cigar_base + (u32)(jb * (u64)max_ops);
                     o.n_cigar = no < 0 ? 255 : (u8)no;
                 } else { end_site = st.best_end[r]; start_site = end_site - L + 1; nm = 0; score = 0; }
             } else if (rs == 2) o.status = 2;
@@ -3617,7 +3679,7 @@ k_finalize(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, const u
                 const u64 clen = cs[c + 1] - cs[c];
                 if (pos + (u64)end_site - (u64)start_site > clen) ok = false;
             }
-            o.pos = pos; o.chrom = (int16_t)(c < ix.n_chrom ? c : -1); o.flag = (u16)flag; o.mapq = (u8)mapq;
+            o.pos = pos; o.chrom = c < ix.n_chrom ? c : -1; o.flag = (u16)flag; o.mapq = (u8)mapq;
             o.nm = (u16)nm; o.score = (int16_t)score;
             o.status = ok ? (amb ? 2 : 1) : 3;
         }
@@ -4519,7 +4581,7 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
               int stride, const u8* __restrict__ mapq_lut, const u32* __restrict__ mapq_off, int unit, ReadGeom gm, int min_ins, int max_ins,
               int ambiguous_out, long n,
               ReadState st, PeState ps, const int* __restrict__ a_start, const int* __restrict__ a_end,
-              const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops, int max_ops,
+              const u32* __restrict__ a_nm, const int* __restrict__ a_score, const int* __restrict__ a_nops, int max_ops, u32 cigar_base,
               bmbs_result_dev* __restrict__ res, unsigned long long* __restrict__ stats)
 {
     __shared__ unsigned long long sh[5];
@@ -4533,7 +4595,7 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
         bmbs_result_dev o[2];
         for (int m = 0; m < 2; m++) {
             o[m].pos = 0; o[m].cigar_off = 0; o[m].chrom = -1; o[m].status = 0; o[m].mapq = 0; o[m].flag = 0; o[m].nm = 0;
-            o[m].score = 0; o[m].n_cigar = 0; o[m].path = 0; o[m].n_cand = st.n_cand[p + m * n]; o[m].reserved = 0;
+            o[m].score = 0; o[m].n_cigar = 0; o[m].path = 0; o[m].n_cand = sat16(st.n_cand[p + m * n]); o[m].tlen = 0;
         }
         const int np = ps.dead[p] ? 0 : ps.npair[p];
         int status = 0;
@@ -4550,7 +4612,7 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
                     const u64 jb = st.job_off[r];
                     start_site = a_start[jb]; end_site = a_end[jb]; nm[m] = a_nm[jb]; score[m] = a_score[jb];
                     const int no = a_nops[jb];
-                    o[m].cigar_off = (u32)(jb * (u64)max_ops);
+                    o[m].cigar_off = cigar_base + (u32)(jb * (u64)max_ops);
                     o[m].n_cigar = no < 0 ? 255 : (u8)no;
                 } else {
                     const int Lm = gm.rl(r);
@@ -4590,8 +4652,8 @@ k_finalize_pe(DevIndex ix, ScoreParams sp, const int* __restrict__ pen_lut, cons
                 const u32 ed = sb > kk ? kk + 1 : sb;
                 const int mapq = mapq_lut[mapq_off[kk] + (size_t)ed * (range + 1) + sd];
                 for (int m = 0; m < 2; m++) {
-                    o[m].pos = (u64)site_pos[m]; o[m].chrom = (int16_t)chrom[m]; o[m].mapq = (u8)mapq; o[m].nm = (u16)nm[m];
-                    o[m].score = (int16_t)score[m]; o[m].reserved = (u32)tlen; o[m].path = 3;
+                    o[m].pos = (u64)site_pos[m]; o[m].chrom = chrom[m]; o[m].mapq = (u8)mapq; o[m].nm = (u16)nm[m];
+                    o[m].score = (int16_t)score[m]; o[m].tlen = (u32)tlen; o[m].path = 3;
                 }
                 o[0].flag = (u16)(rflag[0] == 0 ? (1 | 2 | 32 | 64) : (1 | 2 | 16 | 64));
                 o[1].flag = (u16)(rflag[1] == 0 ? (1 | 2 | 16 | 128) : (1 | 2 | 32 | 128));

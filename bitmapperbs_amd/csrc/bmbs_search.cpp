@@ -863,7 +863,7 @@ int main(int argc, char** argv)
                                 o.seq(s2, q2, L2, ql2, false); o.ch('\n');
                                 continue;
                             }
-                            const unsigned tlen = x1.reserved;
+                            const unsigned tlen = x1.tlen;
                             o.mem(nm, nl); o.ch('\t');
                             o.num(x1.flag); o.ch('\t'); o.str(chrom_names[(size_t)x1.chrom]); o.ch('\t'); o.num(x1.pos); o.ch('\t');
                             o.num(x1.mapq); o.ch('\t'); o.cigar(x1, cpool, L); o.lit("\t=\t"); o.num(x2.pos); o.ch('\t');

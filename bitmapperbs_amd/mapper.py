@@ -243,11 +243,27 @@ class Mapper:
         self._chk(self._lib.bmbs_stats_reset(self._ctx))
 
     def profile(self) -> list[tuple[str, float]]:
-        n = C.c_int(64)
-        names = (C.c_char_p * 64)()
-        ms = (C.c_float * 64)()
+        n = C.c_int(512)
+        names = (C.c_char_p * 512)()
+        ms = (C.c_float * 512)()
         self._chk(self._lib.bmbs_profile_last(self._ctx, names, ms, C.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def profile_total(self) -> tuple[dict, int]:
+        """({kernel: ms summed over the mapping calls since profile_reset()}, number of lane-calls)"""
+        n = C.c_int(512)
+        names = (C.c_char_p * 512)()
+        ms = (C.c_double * 512)()
+        calls = C.c_int64(0)
+        self._chk(self._lib.bmbs_profile_total(self._ctx, names, ms, C.byref(n), C.byref(calls)))
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}, int(calls.value)
+
+    def profile_reset(self):
+        self._chk(self._lib.bmbs_profile_reset(self._ctx))
+
+    def retries(self) -> int:
+        """calls that were issued again with exact sizes (a stage count exceeded the learned capacity); diagnostic"""
+        return int(self._lib.bmbs_retries(self._ctx))
 
     def counters(self) -> dict:
         c = np.zeros(32, dtype=np.uint64)
@@ -323,7 +339,7 @@ def sam_lines_pe(index: Index, names1, names2, seq1, qual1, seq2, qual2, L: int,
         if int(r1["status"]) != capi.ST_UNIQUE:
             continue
         nm = pe_name(names1[i], names2[i])
-        tlen = int(r1["reserved"])
+        tlen = int(r1["tlen"])
         p1, p2 = int(r1["pos"]), int(r2["pos"])
         t1 = "-%d" % tlen if p2 < p1 else "%d" % tlen           # read 1: negative only if the mate lies to the left
         t2 = "%d" % tlen if p1 > p2 else "-%d" % tlen           # read 2: positive only if the mate lies to the right

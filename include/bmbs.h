@@ -80,16 +80,16 @@ typedef struct bmbs_index_view {
 typedef struct bmbs_result {
     uint64_t pos;          /* 1-based position on `chrom`                                    */
     uint32_t cigar_off;    /* first op in the cigar pool (only when n_cigar > 0; else "<L>M") */
-    int16_t  chrom;        /* chromosome id                                                  */
-    uint8_t  status;       /* BMBS_ST_*                                                      */
-    uint8_t  mapq;
-    uint16_t flag;         /* 0 | 16 (SE)                                                    */
+    int32_t  chrom;        /* chromosome id (32 bits: scaffold-level assemblies have > 32 767 sequences) */
+    uint16_t flag;         /* 0 | 16 (SE); 99/147/83/163 (PE)                                */
     uint16_t nm;           /* NM:i                                                           */
     int16_t  score;        /* alignment score (<= 0)                                         */
+    uint8_t  status;       /* BMBS_ST_*                                                      */
+    uint8_t  mapq;
     uint8_t  n_cigar;      /* ops in the pool; 0 means the single op <L>M                    */
     uint8_t  path;         /* 1 exact-unique exit, 2 one-mismatch exit, 3 general, 4 exact-ambiguous */
-    uint32_t n_cand;       /* candidate sites located for this read (diagnostic)             */
-    uint32_t reserved;
+    uint16_t n_cand;       /* candidate sites located for this read (diagnostic, saturates at 65 535) */
+    uint32_t tlen;         /* paired end: |TLEN| of the pair; 0 for single-end records       */
 } bmbs_result;
 
 #define BMBS_ST_UNMAPPED  0
@@ -99,6 +99,15 @@ typedef struct bmbs_result {
 
 /* cigar op = len << 4 | op, op 0 M, 1 D, 2 I, already in SAM (left-to-right on the forward strand)
  * order (ksw.cpp:2785-2857 prints them forward or reversed by strand) */
+
+/* ---- launch sequence ----------------------------------------------------------------------------
+ * A context owns BMBS_LANES (environment, default 2) lanes: a stream, work buffers and counters each, on one attached index.  A
+ * mapping call of 500 000 units and more is cut into one chunk per lane, so that the issue-bound kernels of one chunk (DP, Myers,
+ * row preparation) run beside the memory-bound seeding kernels of the other; the host-pointer calls also overlap the copies of one
+ * chunk with the kernels of another.  After the first call of a context no call waits for its stage counts: buffers and grids
+ * are sized from what earlier calls needed per read (+25 %), guard kernels compare the real counts on the device, and a call that
+ * did not fit is issued again with exact sizes when the context is next synchronised -- results and statistics are the same either
+ * way.  BMBS_EXACT=1 makes every call wait for its counts (the round-2 sequence), BMBS_LANES=1 turns the split off.            */
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
 /* replaces Prepare_alignment (Schema.cpp:639: LUTs, score matrices) for one GPU                 */
@@ -194,7 +203,7 @@ int bmbs_map_pe_var_device(bmbs_ctx*, uint64_t d_seq1, uint64_t d_qual1, uint64_
  * (14602), TLEN / insert / chromosome-end checks and MAPQ over k1+k2 (19400-19440).
  * seq2/qual2 = mate 2 exactly as in the FASTQ file (the library builds the reverse complement the reference's
  * reader builds, Process_Reads.cpp:262-267).  Both mates have length L.  results[2*i], results[2*i+1] = mate 1,
- * mate 2 of pair i: flag 99/83 and 147/163, `reserved` = |TLEN|, status BMBS_ST_* for the PAIR
+ * mate 2 of pair i: flag 99/83 and 147/163, `tlen` = |TLEN|, status BMBS_ST_* for the PAIR
  * (BMBS_ST_OFFEND also covers the insert-size rejection).  Stats count pairs (Schema.cpp:19531-19537).
  * With bmbs_params.sensitive = 1 the same entry points run --sensitive: Map_Pair_Seq_end_to_end (Schema.cpp:19953-21459)
  * = first seeds of both mates, process_rest_seed_debug (17574) on the mate with fewer first-seed candidates,
@@ -239,6 +248,10 @@ int bmbs_stats_allreduce(bmbs_ctx** ctxs, int n, int64_t stats[5]);
 /* per-kernel HIP-event timings of the last bmbs_map_se[_device] call, on the ctx stream.
  * names/ms arrays of length >= *n (in: capacity, out: count).                                     */
 int bmbs_profile_last(bmbs_ctx*, const char** names, float* ms, int* n);
+/* the same HIP-event timings summed over every mapping call since bmbs_profile_reset (all lanes), and the number of calls (a
+ * call split over two lanes counts twice): per-kernel averages of a timed region without a wait after every call           */
+int bmbs_profile_total(bmbs_ctx*, const char** names, double* ms, int* n, int64_t* calls);
+int bmbs_profile_reset(bmbs_ctx*);
 /* event counters of the last call for the algorithmic-byte model:
  * c[0]=n_hash c[1]=n_ext(LF pairs) c[2]=n_sa c[3]=n_cand(windows filtered) c[4]=n_sw(jobs that ran the DP) c[5]=n_ungapped
  * c[6]=window bytes                                                                               */
@@ -246,6 +259,9 @@ int bmbs_counters_last(bmbs_ctx*, uint64_t c[8]);
 /* all 32 words: c[0..7] as above, c[8..15] lane-utilisation probes (diagnostic builds), c[16+4*kid+{0,1,2,3}] =
  * n_hash, n_ext, n_sa, n_ungapped of seeding kernel kid (0 k_seed_first, 1 k_seed_second, 2 k_seed_extra)          */
 int bmbs_counters_all(bmbs_ctx*, uint64_t c[32]);
+/* calls that were issued a second time with exact buffer sizes because a stage count (candidate slots, DP jobs, re-seeded
+ * candidates) exceeded the capacity learned from earlier calls (see "launch sequence" below); diagnostic                      */
+int64_t bmbs_retries(bmbs_ctx*);
 
 /* ---- index files (next-row (f)2: reader/writer of the reference's on-disk formats) ------------- */
 typedef struct bmbs_index_file bmbs_index_file;

@@ -332,7 +332,7 @@ def compare_pe(res, pool, recs, L, L2=None):
         if int(b["status"]) != 1 and not (int(b["status"]) == 2 and b["cigar1"] != b""):
             continue
         got = (int(a1["flag"]), int(a2["flag"]), int(a1["chrom"]), int(a2["chrom"]), int(a1["pos"]), int(a2["pos"]), int(a1["mapq"]),
-               int(a2["mapq"]), int(a1["nm"]), int(a2["nm"]), int(a1["score"]), int(a2["score"]), int(a1["reserved"]),
+               int(a2["mapq"]), int(a1["nm"]), int(a2["nm"]), int(a1["score"]), int(a2["score"]), int(a1["tlen"]),
                mapper.cigar_text(a1, pool, int(La[i])), mapper.cigar_text(a2, pool, int(Lb[i])))
         exp = (int(b["flag1"]), int(b["flag2"]), int(b["chrom1"]), int(b["chrom2"]), int(b["pos1"]), int(b["pos2"]), int(b["mapq"]),
                int(b["mapq"]), int(b["nm1"]), int(b["nm2"]), int(b["score1"]), int(b["score2"]), int(b["tlen"]),
@@ -915,3 +915,138 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["mapstats"]["reads_or_pairs"] == 2 * 2 * 500000          # two ranks x two steps x 500 k reads
     assert d["value"] > 0 and d["config"]["reads_per_gpu_per_step"] == 500000
+
+
+# ---- round 3: lanes, launches that do not wait for their stage counts, the repeat with exact sizes ---------------------------------
+def _se_reads(env, seed, sub, n=24000, L=150):
+    from bitmapperbs_amd import synth
+    return synth.make_reads_se(env["chroms"], n=n, L=L, seed=seed, sub=sub, indel=0.002, qual="random", n_rate=0.002)
+
+
+@pytest.mark.parametrize("lanes,chunk", [(1, 0), (2, 0), (3, 5000)])
+def test_split_calls_and_async_launch_sequence_se(env, monkeypatch, lanes, chunk):
+    """a context's later calls do not wait for their stage counts (capacities learned from the first call, guards on the device) and
+    a call is cut into chunks dealt to the lanes: same records, same statistics as the oracle, whatever the split"""
+    from bitmapperbs_amd import mapper
+    monkeypatch.setenv("BMBS_LANES", str(lanes))
+    monkeypatch.setenv("BMBS_SPLIT_MIN", "2000")
+    if chunk:
+        monkeypatch.setenv("BMBS_CHUNK", str(chunk))
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    tot = np.zeros(5, dtype=np.int64)
+    for rep, (seed, sub) in enumerate([(501, 0.02), (502, 0.02), (503, 0.03)]):
+        r = _se_reads(env, seed, sub)
+        res, pool = m.map_se(r["seq"], r["qual"], 150)
+        recs, ost, _ = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 150)
+        bad = compare_records(res, pool, recs, 150)
+        assert not bad, (rep, bad[:10])
+        tot += ost
+        assert (m.stats() == tot).all(), rep
+    m.close()
+
+
+def test_capacity_overflow_repeats_the_call_with_exact_sizes(env, monkeypatch):
+    """BMBS_CAP_SCALE shrinks the learned capacities so that the candidate and DP-job counts of the second and third call do not fit:
+    the guards take the work away, nothing is committed, and the call is issued again with exact sizes -- records and statistics
+    as if nothing had happened (single end, pairs, --sensitive with its re-seeding stage)"""
+    from bitmapperbs_amd import synth, mapper
+    monkeypatch.setenv("BMBS_CAP_SCALE", "0.02")
+    monkeypatch.setenv("BMBS_LANES", "2")
+    monkeypatch.setenv("BMBS_SPLIT_MIN", "3000")
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    tot = np.zeros(5, dtype=np.int64)
+    for seed, sub in [(601, 0.005), (602, 0.05), (603, 0.05)]:
+        r = _se_reads(env, seed, sub)
+        res, pool = m.map_se(r["seq"], r["qual"], 150)
+        recs, ost, _ = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 150)
+        assert not compare_records(res, pool, recs, 150)
+        tot += ost
+        assert (m.stats() == tot).all()
+    assert m.retries() > 0
+    m.close()
+    for sensitive in (0, 1):
+        m = mapper.Mapper(env["ix"], 0, sensitive=sensitive)
+        tot = np.zeros(5, dtype=np.int64)
+        for seed, sub in [(611, 0.005), (612, 0.05), (613, 0.06)]:
+            m1, m2 = synth.make_reads_pe(env["chroms"], n=9000, L=100, seed=seed + sensitive, sub=sub, indel=0.002, qual="random")
+            res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+            recs, ost, _ = env["oix"].map_pe(orc.params(sensitive=sensitive), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+            assert not compare_pe(res, pool, recs, 100)
+            tot += ost
+            assert (m.stats() == tot).all()
+        assert m.retries() > 0
+        m.close()
+
+
+@pytest.mark.parametrize("sensitive", [0, 1])
+def test_split_calls_and_async_launch_sequence_pe(env, monkeypatch, sensitive):
+    from bitmapperbs_amd import synth, mapper
+    monkeypatch.setenv("BMBS_LANES", "3")
+    monkeypatch.setenv("BMBS_SPLIT_MIN", "1500")
+    m = mapper.Mapper(env["ix"], 0, sensitive=sensitive)
+    tot = np.zeros(5, dtype=np.int64)
+    for seed in (701, 702, 703):
+        m1, m2 = synth.make_reads_pe(env["chroms"], n=10000, L=150, seed=seed, sub=0.03, indel=0.002, qual="random")
+        res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+        recs, ost, _ = env["oix"].map_pe(orc.params(sensitive=sensitive), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+        assert not compare_pe(res, pool, recs, 150)
+        tot += ost
+        assert (m.stats() == tot).all()
+    # trimmed mates, chunks with their own slices of the length arrays
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=8000, L=120, seed=704, sub=0.02, indel=0.002, qual="random")
+    rng = np.random.default_rng(9)
+    l1 = rng.integers(40, 121, 8000).astype(np.uint16); l2 = rng.integers(40, 121, 8000).astype(np.uint16)
+    s1, q1, s2, q2 = _trim(m1["seq"], l1), _trim(m1["qual"], l1), _trim(m2["seq"], l2), _trim(m2["qual"], l2)
+    res, pool = m.map_pe_var(s1, q1, s2, q2, l1, l2)
+    recs, ost, _ = env["oix"].map_pe_var(orc.params(sensitive=sensitive), s1, q1, s2, q2, l1, l2)
+    assert not compare_pe(res, pool, recs, l1, l2)
+    m.close()
+
+
+def test_device_entry_points_split_over_lanes(env, monkeypatch):
+    """bmbs_map_pe_device / _var_device with the batch resident in HBM (what bench.py times): chunks on three lanes, several calls
+    in flight before bmbs_sync, records equal to the single-lane exact run"""
+    import torch
+    from bitmapperbs_amd import synth, mapper, capi
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=12000, L=150, seed=801, sub=0.03, indel=0.002, qual="random")
+    n, L, stride = 12000, 150, 160
+
+    def dev(a):
+        t = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
+        t[:, :a.shape[1]] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return t
+    d = [dev(x) for x in (m1["seq"], m1["qual"], m2["seq"], m2["qual"])]
+    rng = np.random.default_rng(3)
+    lens = np.concatenate([rng.integers(50, 151, n), rng.integers(50, 151, n)]).astype(np.uint16)
+    d_len = torch.from_numpy(lens.view(np.int16)).cuda()
+    out = {}
+    for tag, envs in (("one", {"BMBS_LANES": "1", "BMBS_EXACT": "1"}), ("split", {"BMBS_LANES": "3", "BMBS_SPLIT_MIN": "1000"})):
+        for k_, v_ in envs.items():
+            monkeypatch.setenv(k_, v_)
+        m = mapper.Mapper(env["ix"], 0)
+        ops = m.max_cigar_ops(L)
+        res = torch.zeros((2 * n, 32), dtype=torch.uint8, device="cuda")
+        cig = torch.zeros((2 * n * ops,), dtype=torch.int32, device="cuda")
+        got = []
+        for rep in range(3):                         # the second and third call do not wait for their counts
+            m.map_pe_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), L, stride, n, res.data_ptr(), cig.data_ptr(), 2 * n * ops)
+        m.sync()
+        got.append((res.cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1).copy(), cig.cpu().numpy().view(np.uint32).copy()))
+        lib = capi.lib()
+        rc = lib.bmbs_map_pe_var_device(m._ctx, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_len.data_ptr(), L, stride, n,
+                                        res.data_ptr(), cig.data_ptr(), 2 * n * ops)
+        assert rc == 0
+        m.sync()
+        got.append((res.cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1).copy(), cig.cpu().numpy().view(np.uint32).copy()))
+        out[tag] = (got, m.stats().copy())
+        m.close()
+        for k_ in envs:
+            monkeypatch.delenv(k_)
+    assert (out["one"][1] == out["split"][1]).all()
+    for (ra, ca), (rb, cb), Ls in zip(out["one"][0], out["split"][0], (L, None)):
+        for f in ("status", "chrom", "pos", "flag", "mapq", "nm", "score", "path", "n_cigar", "tlen"):
+            assert (ra[f] == rb[f]).all(), f
+        for i in np.nonzero(ra["n_cigar"] > 0)[0]:
+            a = ca[int(ra[i]["cigar_off"]):int(ra[i]["cigar_off"]) + int(ra[i]["n_cigar"])]
+            b = cb[int(rb[i]["cigar_off"]):int(rb[i]["cigar_off"]) + int(rb[i]["n_cigar"])]
+            assert (a == b).all(), i
