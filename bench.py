@@ -520,19 +520,27 @@ def file_to_file_rate(args, cfg, fa, L):
     inp = [big[files.index(x)] if x in files else x for x in inp]
     n = os.path.getsize(big[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     out = {}
-    for label, dst in (("file", os.path.join(args.workdir, "f2f.sam")), ("null_sink", "/dev/null")):
-        p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "32", "--verbose"], capture_output=True, text=True)
+    parts = 4
+    for label, dst, extra in (("file", os.path.join(args.workdir, "f2f.sam"), []),
+                              ("file_%d_parts" % parts, os.path.join(args.workdir, "f2f.sam"), ["--out-parts", str(parts)]),
+                              ("null_sink", "/dev/null", [])):
+        p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "32", "--verbose"] + extra, capture_output=True, text=True)
         if p.returncode:
             return {"error": p.stderr[-300:]}
         line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
         wall = float(line.split("mapping wall")[1].split("s")[0])
         out[label] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n),
                       "stages": " | ".join(x[len("[bmbs_search] "):] for x in p.stderr.splitlines() if x.startswith("[bmbs_search]"))[:900]}
+        for k in range(parts):
+            f = os.path.join(args.workdir, "f2f.sam.part%03d" % k)
+            if os.path.exists(f):
+                os.unlink(f)
     for f in [os.path.join(args.workdir, "f2f.sam")] + big:
         if os.path.exists(f):
             os.unlink(f)
     out["what"] = ("bmbs_search, FASTQ -> SAM, 1 GPU, 32 host I/O threads, the cpu_baseline sample %d times over, index load + attach excluded "
-                   "(as the reference's own 'mapping time')" % REP)
+                   "(as the reference's own 'mapping time'); newline index and SAM text on the device, the host only reads and writes; "
+                   "`file` = one output file, `file_%d_parts` = --out-parts %d (as many inodes written at once), `null_sink` = -o /dev/null" % (REP, parts, parts))
     return out
 
 

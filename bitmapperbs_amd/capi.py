@@ -22,7 +22,7 @@ SYMBOLS = [
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
-    "bmbs_max_cigar_ops", "bmbs_retries", "bmbs_profile_total", "bmbs_profile_reset",
+    "bmbs_max_cigar_ops", "bmbs_retries", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset",
 ]
 
 
@@ -137,6 +137,12 @@ def lib() -> C.CDLL:
     L.bmbs_profile_total.restype = C.c_int
     L.bmbs_profile_reset.argtypes = [vp]
     L.bmbs_profile_reset.restype = C.c_int
+    L.bmbs_sam_refs.argtypes = [vp, C.POINTER(C.c_char_p), i32]
+    L.bmbs_sam_refs.restype = C.c_int
+    L.bmbs_map_se_text.argtypes = [vp, vp, u64, i64, i32, vp, u64, C.POINTER(u64), C.POINTER(i64)]
+    L.bmbs_map_se_text.restype = C.c_int
+    L.bmbs_map_pe_text.argtypes = [vp, vp, u64, vp, u64, i64, i32, vp, u64, C.POINTER(u64), C.POINTER(i64)]
+    L.bmbs_map_pe_text.restype = C.c_int
     L.bmbs_retries.argtypes = [vp]
     L.bmbs_retries.restype = i64
     L.bmbs_host_alloc.argtypes = [u64]
@@ -153,7 +159,7 @@ def lib() -> C.CDLL:
     return L
 
 
-LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
+LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_text.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
             "../../include/bmbs.h")
 
 

@@ -4,10 +4,12 @@
 // BMBS_ENODEV.
 #include "../../include/bmbs.h"
 #include "bmbs_kernels.hip"
+#include "bmbs_text.hip"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <string>
 #include <vector>
@@ -105,6 +107,10 @@ struct Lane {
     DevBuf wavelog_buf, wavelog_count; std::string wavelog_path;    // BMBS_WAVELOG diagnostic
     DevBuf prow, prow_dirty;                            // packed copy of the read rows (k_pack_rows), one dirty byte per read
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
+    // bmbs_map_*_text: newline index built on the device, SAM text written on the device
+    DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
+    u32* h_info = nullptr;                              // page-locked: 8 info words + 4 totals of the text path
+    int n_refs = 0, max_ref_len = 0;
     // paired-end workspace
     DevBuf sd_sp0, sd_hits0, sd_ml0, sd_tm, sd_seed_id, sd_clen, sd_first_ml, sd_flag_c, sd_flag_d, sd_off_c, sd_off_d, sd_list_c, sd_list_d;
     DevBuf pe_seq, pe_B, pe_occ, pe_len, pe_cur, pe_vround, pe_dead, pe_both, pe_npair, pe_sbd, in_seq2, in_qual2;
@@ -728,14 +734,15 @@ Lane* lane_create(int device_id, const bmbs_params& prm, const Knobs& kn, bool f
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
     const size_t shard_bytes = BMBS_SHARDS * BMBS_SHARD_WORDS * 8;
     if (ensure(c, c->pen_lut, sizeof(lut)) || ensure(c, c->stats, shard_bytes) || ensure(c, c->call_stats, shard_bytes) || ensure(c, c->counters, shard_bytes) ||
-        ensure(c, c->totals, 16 * 8) || ensure(c, c->flags, BMBS_FLAG_WORDS * 4) ||
+        ensure(c, c->totals, 32 * 8) || ensure(c, c->flags, BMBS_FLAG_WORDS * 4) || ensure(c, c->tx_info, 64) ||
+        hipHostMalloc((void**)&c->h_info, 128, hipHostMallocPortable) != hipSuccess ||
         hipHostMalloc((void**)&c->h_tot, 8 * 20 * 8, hipHostMallocPortable) != hipSuccess) { lane_destroy(c); return nullptr; }
     memset(c->h_tot, 0, 8 * 20 * 8);
     (void)hipMemcpy(c->pen_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice);
     (void)hipMemset(c->stats.p, 0, shard_bytes);
     (void)hipMemset(c->call_stats.p, 0, shard_bytes);
     (void)hipMemset(c->counters.p, 0, shard_bytes);
-    (void)hipMemset(c->totals.p, 0, 16 * 8);
+    (void)hipMemset(c->totals.p, 0, 32 * 8);
     (void)hipMemset(c->flags.p, 0, BMBS_FLAG_WORDS * 4);
     // diagnostic: per-wave timeline of the kernels that call wavelog_begin/_end (one context at a time; tools/wavelog.py)
     if (first)
@@ -781,6 +788,9 @@ void lane_destroy(Lane* c)
     for (DevBuf* b : all) release(*b);
     for (auto& set : c->profset) for (auto& p : set) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->h_tot) (void)hipHostFree(c->h_tot);
+    if (c->h_info) (void)hipHostFree(c->h_info);
+    { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off};
+      for (DevBuf* b : tx) release(*b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1400,10 +1410,12 @@ int settle_all(bmbs_ctx* X)
 
 // units per chunk of a call: the whole call on lane 0 when it is small (or the caller's CIGAR pool has no room for every chunk's
 // worst case), otherwise n / lanes (BMBS_CHUNK overrides) so that every lane gets one chunk per call
-int64_t chunk_units(const bmbs_ctx* X, int64_t n, int64_t cigar_cap, int rpu, int max_ops)
+// host_copies: the chunks carry their own H2D / D2H copies; smaller ones (500 k units) leave a shorter tail behind the last upload
+int64_t chunk_units(const bmbs_ctx* X, int64_t n, int64_t cigar_cap, int rpu, int max_ops, bool host_copies = false)
 {
     if (X->lanes.size() < 2 || n < 2 * X->kn.split_min || cigar_cap < n * rpu * (int64_t)max_ops) return n;
     int64_t ch = X->kn.chunk > 0 ? X->kn.chunk : (n + (int64_t)X->lanes.size() - 1) / (int64_t)X->lanes.size();
+    if (host_copies && X->kn.chunk <= 0 && ch > 500000) ch = 500000;
     if (ch < X->kn.split_min) ch = X->kn.split_min;
     return ch < n ? ch : n;
 }
@@ -1471,7 +1483,7 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
     if (L <= 0 || L > 1000 || stride < L) { X->err = "bad read geometry"; return BMBS_EINVAL; }
     const int rpu = pe ? 2 : 1;
     const int max_ops = cigar_ops_bound(X->prm, L, threshold_k(X->prm, L));
-    const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops);
+    const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops, true);
     const int nl = (int)X->lanes.size();
     share_needs(X);
     struct Open { bool on = false; int64_t off = 0, m = 0; };
@@ -1723,6 +1735,175 @@ static int lane_map_pe_fastq(Lane* c, const bmbs_fastq_view* mate1, const bmbs_f
     if (n_cigar_used) *n_cigar_used = (int64_t)used;
     return BMBS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// FASTQ text in, SAM text out (bmbs_text.hip): the host reads and writes files, everything between is on the device
+namespace {
+// newline index of one text window -> per-record fields; the totals slot gets the number of lines found
+int text_index(Lane* c, DevBuf& dtext, const char* text, u64 bytes, u64 n, int f, FqRec& rec)
+{
+    ENS(c, dtext, bytes + 64);
+    HIPCHK(c, hipMemcpyAsync(dtext.p, text, bytes, hipMemcpyHostToDevice, c->stream));
+    const u64 tiles = (bytes + FQ_TILE_BYTES - 1) / FQ_TILE_BYTES;
+    ENS(c, c->tx_tilecnt, tiles * 4 + 64); ENS(c, c->tx_tileoff, (tiles + 1) * 8 + 64);
+    ENS(c, c->tx_nl[f], (4 * n + 8) * 4); ENS(c, c->tx_rec[f], n * 18 + 256);
+    char* b = c->tx_rec[f].as<char>();
+    const u64 n4 = (n * 4 + 63) & ~63ull, n2 = (n * 2 + 63) & ~63ull;
+    ENS(c, c->tx_rec[f], 3 * n4 + 3 * n2 + 64);
+    b = c->tx_rec[f].as<char>();
+    rec.seq_off = reinterpret_cast<u32*>(b); rec.qual_off = reinterpret_cast<u32*>(b + n4); rec.name_off = reinterpret_cast<u32*>(b + 2 * n4);
+    rec.seq_len = reinterpret_cast<u16*>(b + 3 * n4); rec.qual_len = reinterpret_cast<u16*>(b + 3 * n4 + n2); rec.name_len = reinterpret_cast<u16*>(b + 3 * n4 + 2 * n2);
+    hipLaunchKernelGGL(k_fq_count, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tilecnt.as<u32>());
+    int rc = scan_u32(c, c->tx_tilecnt.as<u32>(), tiles, c->tx_tileoff.as<u64>(), 16 + f);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tileoff.as<u64>(), 4 * n, c->tx_nl[f].as<u32>());
+    return BMBS_OK;
+}
+// D2H in pieces: one 2 GiB device-to-host copy ran at a quarter of the link rate on the MI355X boxes (tools/pcie_probe)
+int d2h_chunked(Lane* c, char* dst, const char* src, u64 bytes)
+{
+    const u64 piece = 128ull << 20;
+    for (u64 o = 0; o < bytes; o += piece) HIPCHK(c, hipMemcpyAsync(dst + o, src + o, std::min(piece, bytes - o), hipMemcpyDeviceToHost, c->stream));
+    return BMBS_OK;
+}
+
+int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* text2, u64 bytes2, int64_t n_records, int32_t flags_in, char* sam,
+                  u64 sam_cap, u64* sam_bytes, int64_t* n_lines_out)
+{
+    if (!c) return BMBS_EINVAL;
+    if (sam_bytes) *sam_bytes = 0;
+    if (n_lines_out) *n_lines_out = 0;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    if (c->n_refs != c->ix.n_chrom) { c->err = "bmbs_sam_refs has not been given the index's reference names"; return BMBS_ESTATE; }
+    if (n_records <= 0) return BMBS_OK;
+    if (!text1 || (pe && !text2) || !sam) { c->err = "text call: NULL buffer"; return BMBS_EINVAL; }
+    if (bytes1 >= (1ull << 32) || bytes2 >= (1ull << 32)) { c->err = "a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    { const int rs = lane_settle(c); if (rs) return rs; }
+    const u64 n = (u64)n_records, n2 = pe ? 2 * n : n;
+    static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;       // diagnostic: host-side phase times of every text call
+    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tp[0] = wall();
+    FqRec rec[2] = {};
+    HIPCHK(c, hipMemsetAsync(c->tx_info.p, 0, 64, c->stream));
+    int rc = text_index(c, c->fq_text1, text1, bytes1, n, 0, rec[0]);
+    if (rc) return rc;
+    if (pe) { rc = text_index(c, c->fq_text2, text2, bytes2, n, 1, rec[1]); if (rc) return rc; }
+    // records can only be cut out once the host knows that every one of them is complete: the line counts first
+    HIPCHK(c, hipMemcpyAsync(c->h_info + 16, c->totals.as<u64>() + 16, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tp[1] = wall();
+    const u64* lines = reinterpret_cast<const u64*>(c->h_info + 16);
+    if (lines[0] < 4 * n || (pe && lines[1] < 4 * n)) { c->err = "text call: a window holds fewer than 4 lines per record"; return BMBS_EINVAL; }
+    hipLaunchKernelGGL(k_fq_records, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->tx_nl[0].as<u32>(), (long)n, rec[0], c->tx_info.as<u32>());
+    if (pe) hipLaunchKernelGGL(k_fq_records, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->tx_nl[1].as<u32>(), (long)n, rec[1], c->tx_info.as<u32>() + 4);
+    HIPCHK(c, hipMemcpyAsync(c->h_info, c->tx_info.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tp[2] = wall();
+    const u32* inf = c->h_info;
+    for (int f = 0; f < (pe ? 2 : 1); f++)
+        if (inf[4 * f + 2]) {
+            c->err = "record " + std::to_string(inf[4 * f + 2] - 1) + " of this batch has an empty or longer-than-1000-character sequence line: not supported";
+            return BMBS_EINVAL;
+        }
+    int maxL = (int)inf[0], minL = (int)~inf[1];
+    if (pe) { maxL = std::max(maxL, (int)inf[4]); minL = std::min(minL, (int)~inf[5]); }
+    const bool uniform = minL == maxL;
+    const int ds = (maxL + 15) / 16 * 16;
+    const int max_ops = cigar_ops_bound(c->prm, maxL, threshold_k(c->prm, maxL));
+    const u64 pool = n2 * (u64)max_ops;
+    ENS(c, c->out_res, n2 * 32); ENS(c, c->cig_pool, pool * 4); ENS(c, c->in_len, n2 * 2 + 16);
+    Pending P;
+    P.pe = pe; P.L = maxL; P.stride = ds; P.n = n_records;
+    const int pbat = (flags_in & BMBS_TEXT_PBAT) && !pe ? 1 : 0;
+    if (!pe) {
+        ENS(c, c->in_seq, n * (u64)ds + 64); ENS(c, c->in_qual, n * (u64)ds + 64);
+        hipLaunchKernelGGL(k_fastq_rows, dim3(nblk(n * (u64)(ds / 16), 256)), dim3(256), 0, c->stream, c->fq_text1.as<char>(), rec[0].seq_off, rec[0].qual_off,
+                           rec[0].seq_len, rec[0].qual_len, (long)n, ds, pbat, pbat, c->in_seq.as<char>(), c->in_qual.as<char>(), c->in_len.as<u16>());
+        P.a[0] = (uint64_t)c->in_seq.p; P.a[1] = (uint64_t)c->in_qual.p;
+    } else {
+        ENS(c, c->pe_seq, n2 * (u64)ds + 64); ENS(c, c->in_qual, n * (u64)ds + 64); ENS(c, c->in_qual2, n * (u64)ds + 64);
+        char* seq_all = c->pe_seq.as<char>();
+        const unsigned g = nblk(n * (u64)(ds / 16), 256);
+        hipLaunchKernelGGL(k_fastq_rows, dim3(g), dim3(256), 0, c->stream, c->fq_text1.as<char>(), rec[0].seq_off, rec[0].qual_off, rec[0].seq_len, rec[0].qual_len,
+                           (long)n, ds, 0, 0, seq_all, c->in_qual.as<char>(), c->in_len.as<u16>());
+        hipLaunchKernelGGL(k_fastq_rows, dim3(g), dim3(256), 0, c->stream, c->fq_text2.as<char>(), rec[1].seq_off, rec[1].qual_off, rec[1].seq_len, rec[1].qual_len,
+                           (long)n, ds, 1, 0, seq_all + n * (u64)ds, c->in_qual2.as<char>(), c->in_len.as<u16>() + n);
+        P.a[0] = (uint64_t)seq_all; P.a[1] = (uint64_t)c->in_qual.p; P.a[2] = (uint64_t)(seq_all + n * (u64)ds); P.a[3] = (uint64_t)c->in_qual2.p;
+        P.prepared = true;
+    }
+    P.d_len = uniform ? nullptr : c->in_len.as<u16>();
+    P.d_results = (uint64_t)c->out_res.p; P.d_cigar_pool = (uint64_t)c->cig_pool.p; P.cigar_cap = (int64_t)pool;
+    rc = lane_enqueue(c, P, true);
+    if (rc) return rc;
+    rc = lane_settle(c);
+    if (rc) return rc;
+    tp[3] = wall();
+    // ---- records -> SAM text
+    SamIn in;
+    in.text[0] = c->fq_text1.as<char>(); in.text[1] = pe ? c->fq_text2.as<char>() : nullptr;
+    in.rec[0] = rec[0]; in.rec[1] = rec[1];
+    in.res = c->out_res.as<bmbs_result_dev>(); in.cigar = c->cig_pool.as<u32>();
+    in.chrom_chars = c->chrom_chars.as<char>(); in.chrom_off = c->chrom_off.as<u32>();
+    in.n = (long)n;
+    in.flags = (flags_in & (BMBS_TEXT_PBAT | BMBS_TEXT_UNMAPPED)) | (c->prm.ambiguous_out ? BMBS_TEXT_AMBIG : 0) | (pe ? BMBS_TEXT_PE : 0);
+    ENS(c, c->sam_len, n2 * 4 + 64); ENS(c, c->sam_off, (n2 + 1) * 8 + 64);
+    prof_begin(c, "k_sam_len");
+    hipLaunchKernelGGL(k_sam_len, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, in, (long)n2, c->sam_len.as<u32>());
+    rc = scan_u32(c, c->sam_len.as<u32>(), n2, c->sam_off.as<u64>(), 18);
+    if (rc) return rc;
+    prof_end(c);
+    HIPCHK(c, hipMemcpyAsync(c->h_info + 24, c->totals.as<u64>() + 18, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tp[4] = wall();
+    const u64 total = *reinterpret_cast<const u64*>(c->h_info + 24);
+    if (sam_bytes) *sam_bytes = total;
+    if (n_lines_out) *n_lines_out = (int64_t)n2;
+    if (total > sam_cap) { c->err = "text call: the SAM buffer is too small (sam_bytes tells what this batch needs)"; return BMBS_ENOMEM; }
+    if (!total) return BMBS_OK;
+    ENS(c, c->sam_out, total + 64);
+    const int hb = (c->max_ref_len + 5 * std::max(max_ops, 1) + 96 + 15) & ~15;
+    int lpw = (int)((48 * 1024) / hb);
+    if (lpw > 64) lpw = 64;
+    if (lpw < 1) { c->err = "text call: reference names too long"; return BMBS_EINVAL; }
+    prof_begin(c, "k_sam_write");
+    hipLaunchKernelGGL(k_sam_write, dim3(nblk(n2, (unsigned)lpw)), dim3(64), (size_t)lpw * hb, c->stream, in, (long)n2, c->sam_off.as<u64>(), lpw, hb, c->sam_out.as<char>());
+    prof_end(c);
+    if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); tp[5] = wall(); }
+    rc = d2h_chunked(c, sam, c->sam_out.as<char>(), total);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tp[6] = wall();
+    if (trace)
+        fprintf(stderr, "[text] n=%ld in=%.1fMB out=%.1fMB  upload+lines %.2f  records %.2f  rows+map %.2f  len+scan %.2f  write %.2f  download %.2f  total %.2f ms\n",
+                (long)n2, (double)(bytes1 + bytes2) / 1e6, (double)total / 1e6, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3,
+                (tp[4] - tp[3]) * 1e3, (tp[5] - tp[4]) * 1e3, (tp[6] - tp[5]) * 1e3, (tp[6] - tp[0]) * 1e3);
+    return BMBS_OK;
+}
+
+// RNAME table of the SAM text: the names behind the index's sequences, in index order
+int lane_sam_refs(Lane* c, const char* const* names, int n_names)
+{
+    if (!names || n_names < 1) { c->err = "sam refs: no names"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    std::vector<u32> off((size_t)n_names + 1, 0);
+    std::string chars;
+    int mx = 0;
+    for (int i = 0; i < n_names; i++) {
+        const size_t l = names[i] ? strlen(names[i]) : 0;
+        if (l > 4096) { c->err = "sam refs: a reference name is longer than 4096 characters"; return BMBS_EINVAL; }
+        chars.append(names[i] ? names[i] : "", l);
+        off[(size_t)i + 1] = (u32)chars.size();
+        mx = std::max(mx, (int)l);
+    }
+    ENS(c, c->chrom_chars, chars.size() + 64); ENS(c, c->chrom_off, off.size() * 4);
+    HIPCHK(c, hipMemcpy(c->chrom_chars.p, chars.data(), chars.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->chrom_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    c->n_refs = n_names; c->max_ref_len = mx;
+    return BMBS_OK;
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 static int lane_locate_batch(Lane* c, const uint64_t* row, int64_t n_rows, uint64_t* pos)
@@ -2023,6 +2204,13 @@ extern "C" int bmbs_index_attach(bmbs_ctx* X, const bmbs_index_view* v)
     for (size_t i = 1; i < X->lanes.size(); i++) { Lane* o = X->lanes[i]; o->ix = c->ix; o->rows = c->rows; o->attached = true; }
     return BMBS_OK;
 }
+extern "C" int bmbs_sam_refs(bmbs_ctx* X, const char* const* names, int32_t n_names) { ON_LANE0(lane_sam_refs(c, names, n_names)); }
+extern "C" int bmbs_map_se_text(bmbs_ctx* X, const char* text, uint64_t text_bytes, int64_t n_records, int32_t flags, char* sam, uint64_t sam_cap,
+                                uint64_t* sam_bytes, int64_t* n_lines)
+{ ON_LANE0(lane_map_text(c, false, text, text_bytes, nullptr, 0, n_records, flags, sam, sam_cap, sam_bytes, n_lines)); }
+extern "C" int bmbs_map_pe_text(bmbs_ctx* X, const char* text1, uint64_t bytes1, const char* text2, uint64_t bytes2, int64_t n_pairs, int32_t flags,
+                                char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines)
+{ ON_LANE0(lane_map_text(c, true, text1, bytes1, text2, bytes2, n_pairs, flags, sam, sam_cap, sam_bytes, n_lines)); }
 extern "C" int bmbs_locate_batch(bmbs_ctx* X, const uint64_t* row, int64_t n_rows, uint64_t* pos) { ON_LANE0(lane_locate_batch(c, row, n_rows, pos)); }
 extern "C" int bmbs_vote_order_batch(bmbs_ctx* X, const uint8_t* vote, const int64_t* seg_off, int64_t n_seg, int32_t form, uint32_t* perm)
 { ON_LANE0(lane_vote_order_batch(c, vote, seg_off, n_seg, form, perm)); }

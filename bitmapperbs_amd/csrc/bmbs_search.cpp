@@ -9,23 +9,23 @@
 //   output variants (Process_CommandLines.cpp:93-105): --pbat, --unmapped_out, --ambiguous_out, --bam (BGZF-compressed BAM)
 //   extra: --device N | --devices a,b,... (one index copy per listed device, batches dealt to whichever context is free, output
 //          order kept), --contexts S (contexts per device sharing its index: S batches in flight per GPU so that the copies of
-//          one overlap the kernels of another; default 2), --batch N (records per GPU batch, default 500 k), -t N (host I/O
-//          threads), --verbose
+//          one overlap the kernels of another; default 3), --batch N (records per GPU batch, default 500 k), -t N (host I/O
+//          threads), --out-parts N (the input is cut into N contiguous record ranges, each written to its own file
+//          <out>.part000 ... concurrently; `cat` of the parts in order == the one-file output), --verbose
 //
-// The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp / Schema.cpp:26336-26633), which is
-// what limits it.  Here the host side is a three-stage, order-preserving pipeline so that
-// the GPU is fed at memory speed:
-//   stage R  window of the FASTQ read (parallel pread; .gz: gzread) into a page-locked buffer -> newline index built by the
-//            I/O threads -> per-record line starts and lengths.  The records are NOT packed on the host: the text window goes
-//            to the GPU as it is and the read rows are cut out of it there (bmbs_map_*_fastq), every read with its own length
-//            (k = (uint64)(e*L) is per read, Schema.cpp:24546)
-//   stage G  one bmbs_map_se[_var] / bmbs_map_pe[_var] call per batch (the only stage that touches the GPU); one worker thread
-//            per context -- the reference's parallel axis (N pthreads over sub-blocks, Schema.cpp:26336-26633) becomes
-//            N contexts over batches, and the five counters are summed over them at the end (Schema.cpp:451-476)
-//   stage F  SAM text formatted by the I/O threads into per-slice buffers (SEQ / QUAL straight from the FASTQ text)
-//   stage W  pwrite of the slices at their prefix offsets (buffered writes to ONE file serialise on its inode lock at the speed of
-//            one memcpy -- 10.5 GB/s on the MI355X box -- which is the ceiling of the whole pipeline)
-// Batches circulate through hand-over queues, so stage R of batch i+1 and stage W of batch i-1 overlap stage G of i.
+// The reference has ONE reader thread and ONE fprintf sink (Process_Reads.cpp:2057-2260, Process_sam_out.cpp:954-1006), which is
+// what limits it.  Round 2 of this driver indexed the lines and formatted the SAM text with the host's
+// I/O threads; those two stages were as long as the GPU stage.  Now the host touches file bytes only to move them:
+//   stage R  pread of a window of the FASTQ file(s) into a page-locked buffer (parallel; .gz: one inflate thread per file); the
+//            reader COUNTS the newlines (SWAR over the bytes it has just read) to know how many whole records the window holds
+//   stage G  one bmbs_map_se_text / bmbs_map_pe_text call per batch: text up, newline index + rows + mapping + SAM formatting on
+//            the device (bmbs_text.hip), finished SAM text down into a page-locked buffer; one worker thread per context
+//   stage W  pwrite of the SAM text at the part's running offset (--bam: the text is converted to BAM records and BGZF blocks by
+//            the I/O threads first, bam_prase.cpp:201-221)
+// Buffered writes to ONE file serialise on its inode lock at the speed of one memcpy (~10 GB/s = 28 M SAM records/s on the MI355X
+// boxes): --out-parts N gives N inodes.  Every part is a pipeline of its own (reader -> shared GPU workers -> writer) over its own
+// record range of the input; for pairs the ranges are cut at the same record in both files (found by the read names, by counting
+// lines when the names do not tell).
 #include "../../include/bmbs.h"
 #include <zlib.h>
 #include <fcntl.h>
@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -140,111 +141,25 @@ private:
     std::mutex m_; std::condition_variable cv_; std::map<long, T> q_; long next_ = 0;
 };
 
-// ---- FASTQ text source: plain files are read with parallel pread()s straight into the batch's page-locked window, .gz goes
-// through gzread ---------------------------------------------------------------------------------------------------------------
-struct Source {
-    bool gz = false;
-    int fd = -1;
-    size_t size = 0, off = 0;
-    gzFile gzf = nullptr;
-    std::vector<char> carry;
-    bool gz_eof = false;
 
-    bool open(const char* path)
-    {
-        FILE* f = fopen(path, "rb");
-        if (!f) return false;
-        unsigned char mg[2] = {0, 0};
-        const size_t got = fread(mg, 1, 2, f);
-        fclose(f);
-        gz = got == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
-        if (gz) { gzf = gzopen(path, "rb"); if (gzf) gzbuffer(gzf, 1 << 20); return gzf != nullptr; }
-        fd = ::open(path, O_RDONLY);
-        if (fd < 0) return false;
-        struct stat sb;
-        if (fstat(fd, &sb)) return false;
-        size = (size_t)sb.st_size;
-        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
-        return true;
-    }
-    // up to `cap` bytes of text starting at the current record boundary into dst; `last` when they reach the end of the input
-    size_t window(Pool& pool, char* dst, size_t cap, bool& last)
-    {
-        if (!gz) {
-            const size_t len = std::min(cap, size - off);
-            const int T = pool.size() * 2;
-            const size_t per = ((len + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
-            std::atomic<bool> bad(false);
-            pool.run(T, [&](int t) {
-                size_t a = std::min(len, per * (size_t)t);
-                const size_t e = std::min(len, a + per);
-                while (a < e) {
-                    const ssize_t g = pread(fd, dst + a, e - a, (off_t)(off + a));
-                    if (g <= 0) { bad = true; return; }
-                    a += (size_t)g;
-                }
-            });
-            last = off + len == size;
-            return bad ? 0 : len;
-        }
-        size_t have = carry.size();
-        if (have) memcpy(dst, carry.data(), have);
-        carry.clear();
-        while (!gz_eof && have < cap) {
-            const int n = gzread(gzf, dst + have, (unsigned)std::min<size_t>(cap - have, 1u << 30));
-            if (n <= 0) { gz_eof = true; break; }
-            have += (size_t)n;
-        }
-        last = gz_eof;
-        return have;
-    }
-    void consumed(const char* p, size_t len, size_t used)
-    {
-        if (!gz) { off += used; return; }
-        carry.assign(p + used, p + len);
-    }
-    void close() { if (gzf) gzclose(gzf); if (fd >= 0) ::close(fd); }
-};
-
-struct Lines {                                   // newline index of one window
-    const char* p = nullptr;
-    size_t len = 0, used = 0;                    // used = bytes consumed by the batch's records
-    std::vector<size_t> nl;                      // position of the '\n' ending line i (or len for an unterminated last line)
-    size_t start(size_t line) const { return line == 0 ? 0 : nl[line - 1] + 1; }
-    size_t end(size_t line) const { return nl[line]; }
-};
-
-// `part` is caller-owned scratch that keeps its capacity from batch to batch (fresh allocations of this size
-// are mmap'ed and page-faulted in again on every call)
-void index_lines(Pool& pool, const char* p, size_t len, bool last, Lines& out, std::vector<std::vector<size_t>>& part)
+// ---- newline counting: 8 bytes per step ---------------------------------------------------------------------------------------
+inline size_t count_nl(const char* p, size_t n)
 {
-    out.p = p; out.len = len; out.used = 0;
-    const int T = pool.size() * 4;
-    part.resize((size_t)T);
-    const size_t per = (len + (size_t)T - 1) / (size_t)T;
-    pool.run(T, [&](int t) {
-        const size_t a = std::min(len, per * (size_t)t), b = std::min(len, a + per);
-        std::vector<size_t>& v = part[(size_t)t];
-        v.clear();
-        v.reserve((b - a) / 64 + 16);
-        const char* q = p + a;
-        const char* e = p + b;
-        while (q < e) {
-            const char* h = (const char*)memchr(q, '\n', (size_t)(e - q));
-            if (!h) break;
-            v.push_back((size_t)(h - p));
-            q = h + 1;
-        }
-    });
-    std::vector<size_t> base((size_t)T + 1, 0);
-    for (int t = 0; t < T; t++) base[(size_t)t + 1] = base[(size_t)t] + part[(size_t)t].size();
-    const size_t total = base[(size_t)T];
-    const bool open_tail = last && len > 0 && p[len - 1] != '\n';
-    out.nl.resize(total + (open_tail ? 1 : 0));
-    pool.run(T, [&](int t) {
-        if (!part[(size_t)t].empty()) memcpy(&out.nl[base[(size_t)t]], part[(size_t)t].data(), part[(size_t)t].size() * sizeof(size_t));
-    });
-    if (open_tail) out.nl[total] = len;
+    size_t c = 0, i = 0;
+    const uint64_t K7F = 0x7f7f7f7f7f7f7f7full, NL = 0x0a0a0a0a0a0a0a0aull;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4]; memcpy(w, p + i, 32);
+        for (int j = 0; j < 4; j++) { const uint64_t x = w[j] ^ NL; c += (size_t)__builtin_popcountll(~(((x & K7F) + K7F) | x | K7F)); }
+    }
+    for (; i < n; i++) c += p[i] == '\n';
+    return c;
+}
+// offset just behind the k-th newline (k >= 1) of p[0, n), n when there are fewer
+inline size_t after_kth_nl(const char* p, size_t n, size_t k)
+{
+    const char* q = p; const char* e = p + n;
+    while (k && q < e) { const char* h = (const char*)memchr(q, '\n', (size_t)(e - q)); if (!h) return n; q = h + 1; k--; }
+    return k ? n : (size_t)(q - p);
 }
 
 struct Pinned {                                  // page-locked staging (bmbs_host_alloc)
@@ -261,66 +176,265 @@ struct Pinned {                                  // page-locked staging (bmbs_ho
     void release() { if (p) bmbs_host_free(p); p = nullptr; cap = 0; }
 };
 
-// line index of one FASTQ file's records in a batch: offsets into the text window + lengths (what bmbs_fastq_view wants)
-struct RecIdx {
-    Pinned mem;
-    uint32_t *seq_off = nullptr, *qual_off = nullptr;
-    uint16_t *seq_len = nullptr, *qual_len = nullptr;
-    bool need(size_t n)
+// ---- FASTQ text source over a byte range of a file.  Plain files: parallel pread()s straight into the batch's page-locked window,
+// the newlines counted per 64 KiB block by the thread that has just read it.  .gz: a thread of its own inflates into a queue of
+// chunks (so that the two files of a paired-end run inflate side by side) and the window is assembled from them. ---------------
+#define SUB_BLOCK ((size_t)1 << 16)
+struct Source {
+    bool gz = false;
+    int fd = -1;
+    size_t size = 0, off = 0, end = 0;           // plain: the part's byte range [off, end)
+    std::string err;
+    // .gz
+    gzFile gzf = nullptr;
+    std::thread inflater;
+    std::mutex m; std::condition_variable cv_data, cv_room;
+    std::deque<std::vector<char>> chunks;        // inflated text, in order
+    size_t queued = 0, front_used = 0;
+    bool gz_done = false, gz_stop = false;
+    std::vector<char> carry;
+
+    static bool is_gz(const char* path)
     {
-        if (!mem.need(n * 12 + 64)) return false;
-        seq_off = (uint32_t*)mem.p; qual_off = seq_off + n; seq_len = (uint16_t*)(qual_off + n); qual_len = seq_len + n;
+        FILE* f = fopen(path, "rb");
+        if (!f) return false;
+        unsigned char mg[2] = {0, 0};
+        const size_t got = fread(mg, 1, 2, f);
+        fclose(f);
+        return got == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
+    }
+    bool open(const char* path, size_t lo, size_t hi)
+    {
+        gz = is_gz(path);
+        if (gz) {
+            gzf = gzopen(path, "rb");
+            if (!gzf) return false;
+            gzbuffer(gzf, 1 << 20);
+            inflater = std::thread([this] {
+                for (;;) {
+                    std::vector<char> c((size_t)8 << 20);
+                    const int n = gzread(gzf, c.data(), (unsigned)c.size());
+                    std::unique_lock<std::mutex> l(m);
+                    if (n <= 0) { if (n < 0) err = "gzread failed (corrupt .gz input?)"; gz_done = true; cv_data.notify_all(); return; }
+                    c.resize((size_t)n);
+                    cv_room.wait(l, [this] { return queued < ((size_t)512 << 20) || gz_stop; });
+                    if (gz_stop) return;
+                    queued += c.size(); chunks.push_back(std::move(c));
+                    cv_data.notify_all();
+                }
+            });
+            return true;
+        }
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        if (fstat(fd, &sb)) return false;
+        size = (size_t)sb.st_size;
+        off = std::min(lo, size); end = std::min(hi, size);
+        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
         return true;
     }
-};
-
-struct Batch {
-    long seq = 0;                                // position in the input (output order)
-    long n = 0;                                  // records
-    bool end = false;                            // no more input after this batch
-    Pinned text1, text2;                         // the FASTQ text windows, as read from the files
-    Lines l1, l2;
-    RecIdx r1, r2;
-    int maxL = 0, k = 0, max_ops = 8;            // longest read of the batch, its threshold, CIGAR pool slots per read (bmbs_max_cigar_ops)
-    bool uniform = true;                         // every read of the batch has the same length
-    Pinned res, pool;
-    std::vector<std::vector<char>> text;         // SAM text per formatter slice (capacity kept from batch to batch)
-    std::vector<size_t> text_len;
-    std::vector<std::vector<char>> bam_rec, bam_z;   // --bam: records and BGZF blocks of a slice
-};
-
-inline char rc_char(char c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }   // rc_table, Process_Reads.cpp:1603
-
-// eight characters at a time: reverse complement (A<->T = ^0x15, C<->G = ^0x04, everything else unchanged) and upper-casing
-inline uint64_t zero_bytes(uint64_t x) { const uint64_t K7F = 0x7f7f7f7f7f7f7f7full; return ~(((x & K7F) + K7F) | x | K7F); }   // 0x80 where a byte is 0
-inline uint64_t comp8(uint64_t w)
-{
-    const uint64_t at = zero_bytes(w ^ 0x4141414141414141ull) | zero_bytes(w ^ 0x5454545454545454ull);
-    const uint64_t cg = zero_bytes(w ^ 0x4343434343434343ull) | zero_bytes(w ^ 0x4747474747474747ull);
-    return w ^ ((at >> 7) * 0x15) ^ ((cg >> 7) * 0x04);
-}
-// dst[i] = complement(src[L-1-i])
-inline void revcomp_copy(char* dst, const char* src, int L)
-{
-    int i = 0;
-    for (; i + 8 <= L; i += 8) { uint64_t w; memcpy(&w, src + L - 8 - i, 8); w = comp8(__builtin_bswap64(w)); memcpy(dst + i, &w, 8); }
-    for (; i < L; i++) dst[i] = rc_char(src[L - 1 - i]);
-}
-inline void reverse_copy(char* dst, const char* src, int L)
-{
-    int i = 0;
-    for (; i + 8 <= L; i += 8) { uint64_t w; memcpy(&w, src + L - 8 - i, 8); w = __builtin_bswap64(w); memcpy(dst + i, &w, 8); }
-    for (; i < L; i++) dst[i] = src[L - 1 - i];
-}
-// toupper over a buffer: a character with bit 0x20 set is rare in FASTQ sequence lines, so test 8 at a time
-inline void upper_inplace(char* d, int L)
-{
-    int i = 0;
-    for (; i + 8 <= L; i += 8) {
-        uint64_t w; memcpy(&w, d + i, 8);
-        if (w & 0x2020202020202020ull) for (int j = 0; j < 8; j++) { const char c = d[i + j]; if (c >= 'a' && c <= 'z') d[i + j] = (char)(c - 32); }
+    // up to `cap` bytes of text starting at the current record boundary into dst (which has 64 spare bytes behind cap); `last` when
+    // they reach the end of the range; counts[i] = newlines of dst[i * SUB_BLOCK ...).  false: I/O error (err says which)
+    bool window(Pool& pool, char* dst, size_t cap, size_t& len_out, bool& last, std::vector<uint32_t>& counts)
+    {
+        size_t len = 0;
+        if (!gz) {
+            len = std::min(cap, end - off);
+            const size_t nsb = (len + SUB_BLOCK - 1) / SUB_BLOCK;
+            counts.assign(nsb, 0);
+            const int T = pool.size() * 2;
+            const size_t per = ((nsb + (size_t)T - 1) / (size_t)T) * SUB_BLOCK;
+            std::atomic<int> bad(0);
+            pool.run(T, [&](int t) {
+                size_t a = std::min(len, per * (size_t)t);
+                const size_t e = std::min(len, a + per);
+                while (a < e) {
+                    const size_t stop = std::min(e, a + SUB_BLOCK);            // read one block, count it while it is in cache
+                    size_t at = a;
+                    while (at < stop) {
+                        const ssize_t g = pread(fd, dst + at, stop - at, (off_t)(off + at));
+                        if (g <= 0) { bad = g < 0 ? errno : EIO; return; }
+                        at += (size_t)g;
+                    }
+                    counts[a / SUB_BLOCK] = (uint32_t)count_nl(dst + a, stop - a);
+                    a = stop;
+                }
+            });
+            if (bad) { err = std::string("read error on the FASTQ input: ") + strerror(bad); return false; }
+            last = off + len == end;
+        } else {
+            size_t have = std::min(carry.size(), cap);
+            if (carry.size() > cap) { err = "internal: carried text larger than the window"; return false; }
+            if (have) memcpy(dst, carry.data(), have);
+            carry.clear();
+            bool done = false;
+            while (have < cap) {
+                std::unique_lock<std::mutex> l(m);
+                cv_data.wait(l, [this] { return !chunks.empty() || gz_done; });
+                if (chunks.empty()) { done = true; if (!err.empty()) return false; break; }
+                std::vector<char>& f = chunks.front();
+                const size_t take = std::min(cap - have, f.size() - front_used);
+                l.unlock();                                                     // only this thread consumes: the front chunk stays put
+                memcpy(dst + have, f.data() + front_used, take);
+                have += take; front_used += take;
+                l.lock();
+                if (front_used == f.size()) { queued -= f.size(); chunks.pop_front(); front_used = 0; cv_room.notify_all(); }
+            }
+            len = have;
+            last = done;
+            const size_t nsb = (len + SUB_BLOCK - 1) / SUB_BLOCK;
+            counts.assign(nsb, 0);
+            pool.run((int)std::min<size_t>(nsb, (size_t)pool.size() * 4), [&](int t) {
+                const size_t T = std::min<size_t>(nsb, (size_t)pool.size() * 4);
+                for (size_t i = (size_t)t; i < nsb; i += T) counts[i] = (uint32_t)count_nl(dst + i * SUB_BLOCK, std::min(SUB_BLOCK, len - i * SUB_BLOCK));
+            });
+        }
+        // an unterminated last line counts as a line: the device wants every line closed
+        if (last && len && dst[len - 1] != '\n') { dst[len] = '\n'; len++; if ((len - 1) / SUB_BLOCK >= counts.size()) counts.push_back(0); counts[(len - 1) / SUB_BLOCK]++; }
+        len_out = len;
+        return true;
     }
-    for (; i < L; i++) { const char c = d[i]; if (c >= 'a' && c <= 'z') d[i] = (char)(c - 32); }
+    void consumed(const char* p, size_t len, size_t used)
+    {
+        if (!gz) { off += std::min(used, end - off); return; }
+        carry.assign(p + used, p + len);
+    }
+    void close()
+    {
+        if (inflater.joinable()) {
+            { std::lock_guard<std::mutex> l(m); gz_stop = true; }
+            cv_room.notify_all();
+            inflater.join();
+        }
+        if (gzf) gzclose(gzf);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+// offset just behind the k-th newline of a window whose blocks have been counted
+size_t after_kth_nl_blocks(const char* p, size_t len, const std::vector<uint32_t>& counts, size_t k)
+{
+    size_t acc = 0;
+    for (size_t i = 0; i < counts.size(); i++) {
+        if (acc + counts[i] >= k) { const size_t a = i * SUB_BLOCK; return a + after_kth_nl(p + a, std::min(SUB_BLOCK, len - a), k - acc); }
+        acc += counts[i];
+    }
+    return len;
+}
+
+// ---- where the parts begin: record boundaries of plain FASTQ files ----------------------------------------------------------------
+// first record start at or after `guess`: a line that begins with '@' whose second successor begins with '+' (a quality line may
+// begin with '@', but then the line two further on is a sequence line, which cannot begin with '+')
+size_t record_start_at(int fd, size_t size, size_t guess)
+{
+    if (guess == 0) return 0;
+    if (guess >= size) return size;
+    for (size_t span = (size_t)1 << 20; ; span *= 4) {
+        const size_t a = guess - 1, n = std::min(span, size - a);           // from the byte before: a newline there makes `guess` a line start
+        std::vector<char> buf(n);
+        size_t got = 0;
+        while (got < n) { const ssize_t g = pread(fd, buf.data() + got, n - got, (off_t)(a + got)); if (g <= 0) break; got += (size_t)g; }
+        std::vector<size_t> ls;                                                // line starts inside the buffer
+        for (size_t i = 0; i + 1 < got; i++) if (buf[i] == '\n') ls.push_back(i + 1);
+        for (size_t i = 0; i + 2 < ls.size(); i++)
+            if (buf[ls[i]] == '@' && buf[ls[i + 2]] == '+' && (i + 4 >= ls.size() || buf[ls[i + 4]] == '@')) return a + ls[i];
+        if (a + n >= size) return size;
+    }
+}
+// name of the record at `at`, cut like the paired-end reader does (first ' ' or '/')
+std::string cut_name_at(int fd, size_t size, size_t at)
+{
+    char b[4096];
+    const size_t n = std::min(sizeof b, size - at);
+    const ssize_t g = pread(fd, b, n, (off_t)at);
+    std::string s;
+    for (ssize_t i = 0; i < g && b[i] != '\n' && b[i] != ' ' && b[i] != '/'; i++) s += b[i];
+    return s;
+}
+size_t next_record(int fd, size_t size, size_t at)       // start of the record after the one at `at`
+{
+    size_t pos = at; int lines = 0;
+    char b[1 << 16];
+    while (pos < size && lines < 4) {
+        const ssize_t g = pread(fd, b, sizeof b, (off_t)pos);
+        if (g <= 0) break;
+        for (ssize_t i = 0; i < g; i++) if (b[i] == '\n' && ++lines == 4) return pos + (size_t)i + 1;
+        pos += (size_t)g;
+    }
+    return size;
+}
+size_t count_lines(Pool& pool, int fd, size_t a, size_t b)                 // newlines of file bytes [a, b)
+{
+    const size_t blk = (size_t)16 << 20, nb = (b - a + blk - 1) / blk;
+    std::vector<size_t> c(nb, 0);
+    const int T = (int)std::min<size_t>(nb, (size_t)pool.size() * 2);
+    pool.run(T, [&](int t) {
+        std::vector<char> buf(blk);
+        for (size_t i = (size_t)t; i < nb; i += (size_t)T) {
+            const size_t lo = a + i * blk, n = std::min(blk, b - lo);
+            size_t got = 0;
+            while (got < n) { const ssize_t g = pread(fd, buf.data() + got, n - got, (off_t)(lo + got)); if (g <= 0) break; got += (size_t)g; }
+            c[i] = count_nl(buf.data(), got);
+        }
+    });
+    size_t s = 0;
+    for (size_t x : c) s += x;
+    return s;
+}
+size_t offset_of_line(Pool& pool, int fd, size_t size, size_t line)          // offset of the first byte of line `line` (0-based)
+{
+    if (line == 0) return 0;
+    const size_t blk = (size_t)16 << 20, nb = (size + blk - 1) / blk;
+    std::vector<size_t> c(nb, 0);
+    const int T = (int)std::min<size_t>(nb, (size_t)pool.size() * 2);
+    pool.run(T, [&](int t) {
+        std::vector<char> buf(blk);
+        for (size_t i = (size_t)t; i < nb; i += (size_t)T) {
+            const size_t lo = i * blk, n = std::min(blk, size - lo);
+            size_t got = 0;
+            while (got < n) { const ssize_t g = pread(fd, buf.data() + got, n - got, (off_t)(lo + got)); if (g <= 0) break; got += (size_t)g; }
+            c[i] = count_nl(buf.data(), got);
+        }
+    });
+    size_t acc = 0;
+    for (size_t i = 0; i < nb; i++) {
+        if (acc + c[i] >= line) {
+            const size_t lo = i * blk, n = std::min(blk, size - lo);
+            std::vector<char> buf(n);
+            size_t got = 0;
+            while (got < n) { const ssize_t g = pread(fd, buf.data() + got, n - got, (off_t)(lo + got)); if (g <= 0) break; got += (size_t)g; }
+            return lo + after_kth_nl(buf.data(), got, line - acc);
+        }
+        acc += c[i];
+    }
+    return size;
+}
+// the record of file 2 that pairs with the record starting at b1 of file 1: looked for by name around the proportional offset
+// (two consecutive names have to agree and the match has to be the only one in the window); counted when the names do not tell
+size_t mate_boundary(Pool& pool, int fd1, size_t size1, size_t b1, int fd2, size_t size2)
+{
+    if (b1 == 0) return 0;
+    if (b1 >= size1) return size2;
+    const std::string n0 = cut_name_at(fd1, size1, b1);
+    const size_t b1n = next_record(fd1, size1, b1);
+    const std::string n1 = b1n < size1 ? cut_name_at(fd1, size1, b1n) : std::string();
+    const size_t g2 = (size_t)((double)size2 * ((double)b1 / (double)size1));
+    for (size_t W = (size_t)2 << 20; W <= ((size_t)64 << 20) && !n0.empty(); W *= 4) {
+        size_t lo = g2 > W ? record_start_at(fd2, size2, g2 - W) : 0;
+        const size_t hi = std::min(size2, g2 + W);
+        size_t found = size2 + 1; int hits = 0;
+        for (size_t at = lo; at < hi && at < size2; at = next_record(fd2, size2, at)) {
+            if (cut_name_at(fd2, size2, at) != n0) continue;
+            const size_t nx = next_record(fd2, size2, at);
+            if (!n1.empty() && (nx >= size2 || cut_name_at(fd2, size2, nx) != n1)) continue;
+            hits++; found = at;
+        }
+        if (hits == 1) return found;
+        if (hits > 1) break;                                                  // names repeat: they do not identify a record
+    }
+    const size_t lines = count_lines(pool, fd1, 0, b1);                       // b1 is a record start: lines % 4 == 0
+    return offset_of_line(pool, fd2, size2, lines);
 }
 
 inline void put_uint(std::string& s, unsigned long long v)
@@ -329,48 +443,6 @@ inline void put_uint(std::string& s, unsigned long long v)
     do { b[--i] = (char)('0' + v % 10); v /= 10; } while (v);
     s.append(b + i, (size_t)(24 - i));
 }
-
-// raw cursor into a pre-sized slice buffer (the formatter computes an upper bound first)
-struct Out {
-    char* p;
-    void ch(char c) { *p++ = c; }
-    void mem(const char* s, size_t n) { memcpy(p, s, n); p += n; }
-    void str(const std::string& s) { mem(s.data(), s.size()); }
-    template <size_t N> void lit(const char (&s)[N]) { memcpy(p, s, N - 1); p += N - 1; }
-    void num(unsigned long long v)
-    {
-        char b[24]; int i = 24;
-        do { b[--i] = (char)('0' + v % 10); v /= 10; } while (v);
-        mem(b + i, (size_t)(24 - i));
-    }
-    void cigar(const bmbs_result& r, const uint32_t* pool, int L)
-    {
-        if (r.n_cigar == 0) { num((unsigned)L); ch('M'); return; }
-        if (r.n_cigar == 255) {               // "more operations than pool slots": bmbs_max_cigar_ops rules it out; never print garbage
-            fprintf(stderr, "bmbs_search: internal error: an alignment overflowed its CIGAR slots\n");
-            std::_Exit(3);
-        }
-        for (int i = 0; i < r.n_cigar; i++) { const uint32_t o = pool[r.cigar_off + i]; num(o >> 4); ch("MDISH"[o & 15]); }
-    }
-    // SEQ \t QUAL from the FASTQ text: bases upper-cased (Process_Reads.cpp:836), a quality line shorter than the sequence
-    // padded with ' ' (qual.resize); as read, or reverse-complemented with reversed qualities
-    void seq(const char* sq, const char* ql, int L, int qlen, bool rc)
-    {
-        char* qd = p + L + 1;
-        if (!rc) {
-            memcpy(p, sq, (size_t)L); upper_inplace(p, L);
-            memcpy(qd, ql, (size_t)qlen);
-            for (int i = qlen; i < L; i++) qd[i] = ' ';
-        } else {
-            memcpy(qd, sq, (size_t)L); upper_inplace(qd, L);            // the quality area as scratch
-            revcomp_copy(p, qd, L);
-            if (qlen == L) reverse_copy(qd, ql, L);
-            else for (int i = 0; i < L; i++) { const int jj = L - 1 - i; qd[i] = jj < qlen ? ql[jj] : ' '; }
-        }
-        p[L] = '\t';
-        p += 2 * (size_t)L + 1;
-    }
-};
 
 // ---- --bam (Process_CommandLines.cpp:94; the reference hands each SAM line to htslib's sam_parse1 and bam_write1,
 // bam_prase.cpp:201-221): the same conversion here, line by line, then BGZF blocks compressed by the I/O threads ----------
@@ -501,15 +573,40 @@ bool is_dir(const std::string& p) { struct stat sb; return stat(p.c_str(), &sb) 
 
 double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
+struct Part;
+struct Batch {
+    Part* part = nullptr;
+    long seq = 0;                                // position within the part (output order)
+    long n = 0;                                  // records (pairs)
+    bool end = false;                            // the part's input ends with this batch
+    Pinned text1, text2, sam;                    // FASTQ windows in, SAM text out
+    size_t used1 = 0, used2 = 0;
+    uint64_t sam_bytes = 0;
+    std::vector<std::vector<char>> bam_rec, bam_z;   // --bam: records and BGZF blocks per slice
+    std::vector<uint32_t> counts1, counts2;
+};
+
+struct Part {                                    // one contiguous record range of the input -> one output file
+    int id = 0;
+    Source s1, s2;
+    int ofd = -1;
+    size_t out_off = 0;
+    OrderedChan<Batch*> out_q;
+    long next_seq = 0;
+    std::thread reader, writer;
+    double t_read = 0, t_write = 0, t_format = 0, t_wait_r = 0, t_wait_w = 0;
+    long records = 0;
+};
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
     bmbs_params P; bmbs_default_params(&P);
     std::string index, seq, seq1, seq2, out = "output", mapstats, build_fasta, index_folder;
-    int device = 0, io_threads = 0, contexts = 2;
+    int device = 0, io_threads = 0, contexts = 3, parts = 1;
     std::vector<int> devices;
-    long batch = 500000;                         // 20 M SE reads to a file: 27.3 M reads/s with 250-500 k, 23.3-24.2 with 1 M (pipeline fill)
+    long batch = 500000;
     bool verbose = false, unmapped_out = false, pbat = false, bam = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -545,6 +642,7 @@ int main(int argc, char** argv)
         }
         else if (a == "--contexts") contexts = atoi(val());
         else if (a == "--batch") batch = atol(val());
+        else if (a == "--out-parts") parts = atoi(val());
         else if (a == "--verbose") verbose = true;
         else if (a == "--unmapped_out") unmapped_out = true;          // Process_CommandLines.cpp:104-105
         else if (a == "--ambiguous_out") P.ambiguous_out = 1;
@@ -569,26 +667,37 @@ int main(int argc, char** argv)
         return 0;
     }
     if (index.empty() || (seq.empty() && (seq1.empty() || seq2.empty()))) {
-        fprintf(stderr, "usage: bmbs_search --index <genome.fa> [--index_folder dir] [-t threads]\n       bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--pbat] [--unmapped_out] [--ambiguous_out] [--bam] [--mapstats f] [-t io_threads]\n");
+        fprintf(stderr, "usage: bmbs_search --index <genome.fa> [--index_folder dir] [-t threads]\n       bmbs_search --search <index> (--seq r.fq | --seq1 a.fq --seq2 b.fq) [-o out.sam] [-e f] [--min n] [--max n] [--sensitive] [--pbat] [--unmapped_out] [--ambiguous_out] [--bam] [--mapstats f] [-t io_threads] [--out-parts n]\n");
         return 2;
     }
     if (batch < 1) batch = 1;
     if (io_threads <= 0) { io_threads = (int)std::thread::hardware_concurrency(); if (io_threads > 32) io_threads = 32; }
     if (io_threads < 1) io_threads = 1;
+    if (parts < 1) parts = 1;
+    if (parts > 64) parts = 64;
     const double t_start = now();
     if (devices.empty()) devices.push_back(device);
     if (contexts < 1) contexts = 1;
     const bool pe = seq.empty();
-    const int n_batches = 4 + (int)devices.size() * contexts;
+    // --pbat: single-end reads are mapped as their reverse complement with mirrored qualities (inputReads_single_directly_pbat,
+    // Process_Reads.cpp:986-1075; Schema.cpp:15102 need_reverse_quality = 1); paired-end input files swap roles
+    // (exchange_two_reads, Process_Reads.cpp:1628, called from Bitmapper_main.cpp:169)
+    if (pbat && pe) std::swap(seq1, seq2);
+    const std::string& in1 = pe ? seq1 : seq;
+    const bool gz_in = Source::is_gz(in1.c_str()) || (pe && Source::is_gz(seq2.c_str()));
+    // a .gz stream cannot be entered in the middle: everything goes through part 0, the other part files stay empty
+    const int live_parts = gz_in ? 1 : parts;
+    // the drivers' contexts run one batch at a time each: one lane per context is enough (BMBS_LANES is only read by bmbs_create)
+    setenv("BMBS_LANES", "1", 0);
+    const int n_ctx = (int)devices.size() * contexts;
+    const int n_batches = live_parts + n_ctx + 2;
     std::vector<Batch> batches((size_t)n_batches);
-    // page-locking memory costs ~0.2 ms per MB: the staging of every circulating batch is allocated once, here, by a few threads
-    // at a time, sized from the first records of the (plain-text) input -- a batch that needs more grows its own, which for 250-base
-    // reads and the former fixed 400 bytes per record re-allocated every window once: 1.2 s of a 1.6 s run
+    // bytes per record of the input, from its first records (plain text): sizes the page-locked windows, which cost ~0.2 ms per MB
+    // to pin and are therefore allocated once, by several threads, while the index loads
     size_t est0 = 400;
     {
-        const std::string& f0 = pe ? seq1 : seq;
         char head[1 << 16];
-        FILE* fp = fopen(f0.c_str(), "rb");
+        FILE* fp = fopen(in1.c_str(), "rb");
         const size_t got = fp ? fread(head, 1, sizeof head, fp) : 0;
         if (fp) fclose(fp);
         if (got > 2 && !((unsigned char)head[0] == 0x1f && (unsigned char)head[1] == 0x8b)) {
@@ -597,26 +706,31 @@ int main(int argc, char** argv)
             if (lines >= 4) est0 = std::max<size_t>(est0, last / (lines / 4) + 32);
         }
     }
-    std::thread prealloc([&] {
-        const size_t want = std::min<size_t>((size_t)batch * est0 + (1u << 16), (size_t)4000 << 20) + 64;
-        const int ops250 = std::max(8, (int)bmbs_max_cigar_ops(&P, 250));
-        std::vector<std::thread> th;
-        for (auto& b : batches)
-            th.emplace_back([&, want, ops250] {
-                Batch* bb = &b;
-                bb->text1.need(want); if (pe) bb->text2.need(want);
-                bb->r1.need((size_t)batch); if (pe) bb->r2.need((size_t)batch);
-                bb->res.need((size_t)batch * sizeof(bmbs_result) * (pe ? 2 : 1) + 64);
-                bb->pool.need((size_t)batch * (size_t)ops250 * (pe ? 2 : 1) * 4 + 64);
-                bb->l1.nl.reserve((size_t)batch * 4 + 16); if (pe) bb->l2.nl.reserve((size_t)batch * 4 + 16);
-            });
-        for (auto& t : th) t.join();
-    });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } prealloc_guard{prealloc};     // error returns below must not leave it running
     if (is_dir(index)) index += "/genome";           // Index.cpp:1048-1069
     bmbs_index_file* ixf = bmbs_index_file_load(index.c_str());
     if (!ixf) { fprintf(stderr, "Cannot open index %s.index*\n", index.c_str()); return 1; }
     bmbs_index_view view; bmbs_index_file_view(ixf, &view);
+    std::vector<std::string> chrom_names;
+    size_t max_chrom = 0;
+    for (int i = 0; i < view.n_chrom; i++) { chrom_names.push_back(bmbs_index_file_chrom_name(ixf, i)); max_chrom = std::max(max_chrom, chrom_names.back().size()); }
+    // SAM bytes a batch can need: QNAME + SEQ + QUAL come out of the text, the other columns are bounded per line
+    const int L_est = (int)std::min<size_t>(1000, (est0 / 2) + (est0 / 4));
+    auto sam_bound = [&](size_t text_bytes, size_t lines, int L) {
+        return text_bytes + lines * (max_chrom + 5 * (size_t)std::max(8, (int)bmbs_max_cigar_ops(&P, std::max(1, std::min(1000, L)))) + 96) + 4096;
+    };
+    auto window_bytes = [&](size_t est) { return std::min<size_t>((size_t)batch * est + (1u << 16), (size_t)4000 << 20); };
+    std::thread prealloc([&] {
+        const size_t want = window_bytes(est0) + 64;
+        std::vector<std::thread> th;
+        for (auto& b : batches)
+            th.emplace_back([&, want] {
+                Batch* bb = &b;
+                bb->text1.need(want); if (pe) bb->text2.need(want);
+                bb->sam.need(sam_bound(want * (pe ? 2 : 1), (size_t)batch * (pe ? 2 : 1), L_est));
+            });
+        for (auto& t : th) t.join();
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } prealloc_guard{prealloc};     // error returns below must not leave it running
     // one owner context per listed device (attached in parallel: each uploads and re-packs its own index copy), plus
     // contexts-1 further contexts per device on the owner's index (bmbs_index_share)
     std::vector<bmbs_ctx*> ctxs;                  // owners first
@@ -639,396 +753,238 @@ int main(int argc, char** argv)
             if (!c || bmbs_index_share(c, ctxs[i])) { fprintf(stderr, "bmbs_search: cannot create a shared context on device %d\n", devices[i]); return 1; }
             ctxs.push_back(c);
         }
-    const double t_loaded = now();
-    std::vector<std::string> chrom_names;
-    for (int i = 0; i < view.n_chrom; i++) chrom_names.push_back(bmbs_index_file_chrom_name(ixf, i));
-    const int ofd = ::open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (ofd < 0) { fprintf(stderr, "Cannot open %s\n", out.c_str()); return 1; }
-    size_t out_off = 0;
     {
-        // OutPutSAM_Nounheader (Process_sam_out.cpp:1137-1153)
-        std::string h = "@HD\tVN:1.4\tSO:unsorted\n";
-        for (int i = 0; i < view.n_chrom; i++) { h += "@SQ\tSN:" + chrom_names[(size_t)i] + "\tLN:"; put_uint(h, view.chrom_len[i]); h += '\n'; }
-        h += "@PG\tID:BitMapperBS\tVN:1.0.2.3\tCL:";
-        for (int i = 0; i < argc; i++) { h += argv[i]; h += ' '; }
-        h += '\n';
-        if (bam) {
-            // BAM header: magic, the same text, the reference dictionary; one BGZF block series
-            std::vector<char> hb = {'B', 'A', 'M', 1}, z;
-            put_le32(hb, (uint32_t)h.size()); hb.insert(hb.end(), h.begin(), h.end());
-            put_le32(hb, (uint32_t)view.n_chrom);
-            for (int i = 0; i < view.n_chrom; i++) {
-                const std::string& nm = chrom_names[(size_t)i];
-                put_le32(hb, (uint32_t)nm.size() + 1); hb.insert(hb.end(), nm.begin(), nm.end()); hb.push_back(0);
-                put_le32(hb, (uint32_t)view.chrom_len[i]);
-            }
-            bgzf_append(hb.data(), hb.size(), z);
-            h.assign(z.begin(), z.end());
-        }
-        if (pwrite(ofd, h.data(), h.size(), 0) != (ssize_t)h.size()) { fprintf(stderr, "write error on %s\n", out.c_str()); return 1; }
-        out_off = h.size();
+        std::vector<const char*> nm;
+        for (const auto& s : chrom_names) nm.push_back(s.c_str());
+        for (bmbs_ctx* c : ctxs) if (bmbs_sam_refs(c, nm.data(), (int32_t)nm.size())) { fprintf(stderr, "%s\n", bmbs_last_error(c)); return 1; }
     }
+    // ---- the parts: record ranges of the input, one output file each
+    std::vector<std::unique_ptr<Part>> P_(static_cast<size_t>(parts));
+    for (int p = 0; p < parts; p++) { P_[(size_t)p].reset(new Part()); P_[(size_t)p]->id = p; }
+    {
+        std::vector<size_t> cut1((size_t)live_parts + 1, 0), cut2((size_t)live_parts + 1, 0);
+        if (!gz_in) {
+            Pool pool(std::max(1, io_threads / 2) - 1);
+            const int fd1 = ::open(in1.c_str(), O_RDONLY), fd2 = pe ? ::open(seq2.c_str(), O_RDONLY) : -1;
+            struct stat sb1, sb2;
+            if (fd1 < 0 || fstat(fd1, &sb1) || (pe && (fd2 < 0 || fstat(fd2, &sb2)))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
+            const size_t size1 = (size_t)sb1.st_size, size2 = pe ? (size_t)sb2.st_size : 0;
+            cut1[(size_t)live_parts] = size1; cut2[(size_t)live_parts] = size2;
+            for (int p = 1; p < live_parts; p++) {
+                cut1[(size_t)p] = std::max(cut1[(size_t)p - 1], record_start_at(fd1, size1, (size_t)((double)size1 * p / live_parts)));
+                if (pe) cut2[(size_t)p] = std::max(cut2[(size_t)p - 1], mate_boundary(pool, fd1, size1, cut1[(size_t)p], fd2, size2));
+            }
+            ::close(fd1); if (fd2 >= 0) ::close(fd2);
+        } else { cut1[1] = cut2[1] = ~(size_t)0; }
+        for (int p = 0; p < live_parts; p++) {
+            Part& pt = *P_[(size_t)p];
+            if (!pt.s1.open(in1.c_str(), cut1[(size_t)p], cut1[(size_t)p + 1]) || (pe && !pt.s2.open(seq2.c_str(), cut2[(size_t)p], cut2[(size_t)p + 1]))) {
+                fprintf(stderr, "Cannot open the read file(s)\n"); return 1;
+            }
+        }
+    }
+    const double t_loaded = now();
     BamNames bam_refs; bam_refs.names = chrom_names;
+    for (int p = 0; p < parts; p++) {
+        Part& pt = *P_[(size_t)p];
+        std::string path = out;
+        if (parts > 1) { char suf[32]; snprintf(suf, sizeof suf, ".part%03d", p); path += suf; }
+        pt.ofd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (pt.ofd < 0) { fprintf(stderr, "Cannot open %s\n", path.c_str()); return 1; }
+        if (p == 0) {
+            // OutPutSAM_Nounheader (Process_sam_out.cpp:1137-1153)
+            std::string h = "@HD\tVN:1.4\tSO:unsorted\n";
+            for (int i = 0; i < view.n_chrom; i++) { h += "@SQ\tSN:" + chrom_names[(size_t)i] + "\tLN:"; put_uint(h, view.chrom_len[i]); h += '\n'; }
+            h += "@PG\tID:BitMapperBS\tVN:1.0.2.3\tCL:";
+            for (int i = 0; i < argc; i++) { h += argv[i]; h += ' '; }
+            h += '\n';
+            if (bam) {
+                // BAM header: magic, the same text, the reference dictionary; one BGZF block series
+                std::vector<char> hb = {'B', 'A', 'M', 1}, z;
+                put_le32(hb, (uint32_t)h.size()); hb.insert(hb.end(), h.begin(), h.end());
+                put_le32(hb, (uint32_t)view.n_chrom);
+                for (int i = 0; i < view.n_chrom; i++) {
+                    const std::string& nm = chrom_names[(size_t)i];
+                    put_le32(hb, (uint32_t)nm.size() + 1); hb.insert(hb.end(), nm.begin(), nm.end()); hb.push_back(0);
+                    put_le32(hb, (uint32_t)view.chrom_len[i]);
+                }
+                bgzf_append(hb.data(), hb.size(), z);
+                h.assign(z.begin(), z.end());
+            }
+            if (pwrite(pt.ofd, h.data(), h.size(), 0) != (ssize_t)h.size()) { fprintf(stderr, "write error on %s\n", path.c_str()); return 1; }
+            pt.out_off = h.size();
+        }
+    }
     prealloc.join();
-    const bool ambiguous_out = P.ambiguous_out != 0;
-    // --pbat: single-end reads are mapped as their reverse complement with mirrored qualities (inputReads_single_directly_pbat,
-    // Process_Reads.cpp:986-1075; Schema.cpp:15102 need_reverse_quality = 1); paired-end input files swap roles
-    // (exchange_two_reads, Process_Reads.cpp:1628, called from Bitmapper_main.cpp:169)
-    if (pbat && pe) std::swap(seq1, seq2);
-    const bool pbat_se = pbat && !pe;
-    Source src1, src2;
-    if (!src1.open(pe ? seq1.c_str() : seq.c_str()) || (pe && !src2.open(seq2.c_str()))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
+    const int32_t flags = (pbat && !pe ? BMBS_TEXT_PBAT : 0) | (unmapped_out ? BMBS_TEXT_UNMAPPED : 0);
 
-    Chan<Batch*> free_q, gpu_q, wr_q;
-    OrderedChan<Batch*> out_q;                    // the G workers finish in any order; formatting and writing follow the input order
-    long next_seq = 0;
+    Chan<Batch*> free_q, gpu_q;
     for (auto& b : batches) free_q.put(&b);
     std::atomic<bool> failed(false);
-    double t_read = 0, t_gpu = 0, t_write = 0, t_index = 0, t_format = 0, t_window = 0, t_wait_r = 0, t_wait_f = 0, t_wait_w = 0, t_wait_g = 0;
-    struct Ev { char stage; long n; double a, b; };
-    std::vector<Ev> ev_r, ev_g, ev_f, ev_w;
+    std::mutex err_mu;
+    auto fail = [&](const std::string& why) { std::lock_guard<std::mutex> l(err_mu); if (!failed.exchange(true)) fprintf(stderr, "bmbs_search: %s\n", why.c_str()); };
+    const int r_threads = std::max(1, io_threads / (2 * live_parts));
+    const int w_threads = std::max(1, (io_threads - r_threads * live_parts) / live_parts);
 
-    // ---------------- stage R: text window -> line index -> per-record line starts and lengths ---------------------
-    std::thread reader([&] {
-        Pool pool(std::max(1, io_threads / 4) - 1);
-        size_t est = est0;                                              // bytes per record, refined from the data
-        std::vector<std::vector<size_t>> part;                          // scratch reused by every batch
+    // ---------------- stage R (one per part): text window + newline count -> how many whole records ----------------------------
+    auto reader_fn = [&](Part* pt) {
+        Pool pool(r_threads - 1);
+        size_t est = est0;
         for (;;) {
             const double tw0 = now();
             Batch* b = free_q.get();
             const double t0 = now();
-            t_wait_r += t0 - tw0;
-            b->seq = next_seq++;
-            b->n = 0; b->end = false; b->maxL = 0; b->k = 0; b->uniform = true;
-            auto bail = [&](const char* why) {
-                if (why) fprintf(stderr, "bmbs_search: %s\n", why);
-                failed = true; b->end = true; b->n = 0; gpu_q.put(b);
-            };
-            // a window is handed to the library with 32-bit offsets: keep it below 4 GiB
-            const size_t want = std::min<size_t>((size_t)batch * est + (1u << 16), (size_t)4000 << 20);
+            pt->t_wait_r += t0 - tw0;
+            b->part = pt; b->seq = pt->next_seq++; b->n = 0; b->end = false; b->used1 = b->used2 = 0; b->sam_bytes = 0;
+            auto bail = [&](const std::string& why) { fail(why); b->end = true; b->n = 0; gpu_q.put(b); };
+            if (failed) { b->end = true; gpu_q.put(b); return; }
+            // (.gz: what the previous window left over is copied in first and must fit whatever the new estimate says)
+            const size_t want = std::max(window_bytes(est), std::max(pt->s1.carry.size(), pt->s2.carry.size()) + (1u << 16));
             if (!b->text1.need(want + 64) || (pe && !b->text2.need(want + 64))) { bail("cannot allocate page-locked staging memory"); return; }
             bool last1 = true, last2 = true;
-            const size_t n1 = src1.window(pool, b->text1.p, want, last1);
-            t_window += now() - t0;
-            index_lines(pool, b->text1.p, n1, last1, b->l1, part);
-            t_index += now() - t0;
-            long avail1 = (long)(b->l1.nl.size() / 4), avail2 = 0;
-            long nrec = avail1;
-            size_t n2 = 0;
-            if (pe) {
-                n2 = src2.window(pool, b->text2.p, want, last2);
-                index_lines(pool, b->text2.p, n2, last2, b->l2, part);
-                avail2 = (long)(b->l2.nl.size() / 4);
-                nrec = std::min(nrec, avail2);
-            }
+            size_t n1 = 0, n2 = 0;
+            if (!pt->s1.window(pool, b->text1.p, want, n1, last1, b->counts1)) { bail(pt->s1.err); return; }
+            if (pe && !pt->s2.window(pool, b->text2.p, want, n2, last2, b->counts2)) { bail(pt->s2.err); return; }
+            size_t l1 = 0, l2 = 0;
+            for (uint32_t c : b->counts1) l1 += c;
+            for (uint32_t c : b->counts2) l2 += c;
+            const long avail1 = (long)(l1 / 4), avail2 = pe ? (long)(l2 / 4) : 0;
+            long nrec = pe ? std::min(avail1, avail2) : avail1;
             if (nrec > batch) nrec = batch;
-            // the input ends with this batch when a file has no complete record left after it (PE: the shorter file decides)
+            // the part's input ends with this batch when a file has no complete record left after it (PE: the shorter file decides)
             b->end = (last1 && avail1 == nrec) || (pe && last2 && avail2 == nrec);
             if (nrec == 0) {
-                if (!b->end) { fprintf(stderr, "bmbs_search: FASTQ record larger than the %zu-byte window\n", want); failed = true; b->end = true; }
+                if (!b->end) { bail("FASTQ record larger than the " + std::to_string(want) + "-byte window"); return; }
                 gpu_q.put(b);
                 return;
             }
-            const size_t used1 = std::min(n1, b->l1.nl[(size_t)nrec * 4 - 1] + 1);
-            src1.consumed(b->text1.p, n1, used1);
-            b->l1.used = used1;
-            if (pe) { b->l2.used = std::min(n2, b->l2.nl[(size_t)nrec * 4 - 1] + 1); src2.consumed(b->text2.p, n2, b->l2.used); }
-            est = std::max<size_t>(64, used1 / (size_t)nrec + 16);
+            b->used1 = after_kth_nl_blocks(b->text1.p, n1, b->counts1, (size_t)nrec * 4);
+            pt->s1.consumed(b->text1.p, n1, b->used1);
+            if (pe) { b->used2 = after_kth_nl_blocks(b->text2.p, n2, b->counts2, (size_t)nrec * 4); pt->s2.consumed(b->text2.p, n2, b->used2); }
+            est = std::max<size_t>(64, std::max(b->used1, b->used2) / (size_t)nrec + 16);
             b->n = nrec;
-            if (!b->r1.need((size_t)nrec) || (pe && !b->r2.need((size_t)nrec))) { bail("cannot allocate page-locked staging memory"); return; }
-            // ---- one batch = one library call: every record keeps its own length, rows in input order
-            const int T = pool.size();
-            const long per = (nrec + T - 1) / T;
-            std::vector<int> mx((size_t)T, 0), mn((size_t)T, 1 << 30);
-            std::vector<long> bad((size_t)T, -1);
-            pool.run(T, [&](int t) {
-                const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
-                int m = 0, lo = 1 << 30;
-                auto one = [&](const Lines& ln, RecIdx& ri, long r) -> bool {
-                    const size_t s0 = ln.start((size_t)r * 4 + 1), e0 = ln.end((size_t)r * 4 + 1);
-                    const size_t q0 = ln.start((size_t)r * 4 + 3), q1 = ln.end((size_t)r * 4 + 3);
-                    const size_t L = e0 - s0;
-                    if (L < 1 || L > 1000) return false;
-                    ri.seq_off[r] = (uint32_t)s0; ri.qual_off[r] = (uint32_t)q0;
-                    ri.seq_len[r] = (uint16_t)L; ri.qual_len[r] = (uint16_t)std::min(L, q1 - q0);
-                    m = std::max(m, (int)L); lo = std::min(lo, (int)L);
-                    return true;
-                };
-                for (long r = a; r < e; r++)
-                    if (!one(b->l1, b->r1, r) || (pe && !one(b->l2, b->r2, r))) { if (bad[(size_t)t] < 0) bad[(size_t)t] = r; break; }
-                mx[(size_t)t] = m; mn[(size_t)t] = lo;
-            });
-            int maxL = 0, minL = 1 << 30;
-            for (int t = 0; t < T; t++) {
-                maxL = std::max(maxL, mx[(size_t)t]); minL = std::min(minL, mn[(size_t)t]);
-                if (bad[(size_t)t] >= 0) {
-                    // the reference's reader has no such limit on paper, its kernels do (SEQ_MAX_LENGTH 1000, Schema.h); a silently
-                    // dropped record would change the mapstats totals, so stop instead
-                    fprintf(stderr, "bmbs_search: record %ld of this batch has an empty or longer-than-1000-character sequence line: not supported\n", bad[(size_t)t]);
-                    bail(nullptr); return;
-                }
-            }
-            b->maxL = maxL; b->uniform = minL == maxL;
-            int k = (int)(uint64_t)(P.e_f * maxL); if (k > 31) k = 31;
-            b->k = k;
-            b->max_ops = std::max(8, (int)bmbs_max_cigar_ops(&P, maxL));
-            const size_t pool_ops = (size_t)nrec * (size_t)b->max_ops * (pe ? 2 : 1);
-            if (!b->res.need((size_t)nrec * sizeof(bmbs_result) * (pe ? 2 : 1) + 64) || !b->pool.need(pool_ops * 4 + 64)) { bail("cannot allocate page-locked staging memory"); return; }
-            t_read += now() - t0;
-            ev_r.push_back({'R', nrec, t0, now()});
+            const int Lg = (int)std::min<size_t>(1000, est / 2);
+            if (!b->sam.need(sam_bound(b->used1 + b->used2, (size_t)nrec * (pe ? 2 : 1), Lg))) { bail("cannot allocate page-locked staging memory"); return; }
+            pt->t_read += now() - t0;
+            pt->records += nrec;
             const bool end = b->end;
             gpu_q.put(b);
             if (end) return;
         }
-    });
+    };
 
-    // ---------------- stage F: SAM text, formatted by the I/O threads into per-slice buffers ---------------------
-    std::thread formatter([&] {
-        Pool pool(std::max(1, io_threads - io_threads / 4 - 2) - 1);
-        size_t max_chrom = 0;
-        for (const auto& c : chrom_names) max_chrom = std::max(max_chrom, c.size());
+    // ---------------- stage W (one per part): the SAM text (or its BAM form) goes into the part's file, in order -----------------
+    auto writer_fn = [&](Part* pt) {
+        Pool pool(bam ? w_threads - 1 : 0);
         for (;;) {
             const double tw0 = now();
-            Batch* b = out_q.get();
+            Batch* b = pt->out_q.get();
             const double t0 = now();
-            t_wait_f += t0 - tw0;
-            const long nrec = b->n;
+            pt->t_wait_w += t0 - tw0;
             const bool end = b->end;
-            const int T = pool.size() * 2;
-            b->text.resize((size_t)T); b->text_len.assign((size_t)T, 0);
-            if (bam) { b->bam_rec.resize((size_t)T); b->bam_z.resize((size_t)T); }
-            if (nrec && !failed) {
-                const long per = (nrec + T - 1) / T;
-                const bmbs_result* res = (const bmbs_result*)b->res.p;
-                const uint32_t* cpool = (const uint32_t*)b->pool.p;
-                pool.run(T, [&](int t) {
-                    const long a = std::min<long>(nrec, per * t), e = std::min<long>(nrec, a + per);
-                    // upper bound of this slice's text: name + fixed columns + CIGAR + SEQ + QUAL per line
-                    size_t bound = 64;
-                    for (long r = a; r < e; r++) {
-                        const size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
-                        bound += ((size_t)(pe ? 2 : 1)) * (nl + max_chrom + 2 * (size_t)b->maxL + 6 * (size_t)b->max_ops + 128);
+            if (b->n && !failed && b->sam_bytes) {
+                const char* text = b->sam.p;
+                const size_t len = (size_t)b->sam_bytes;
+                if (!bam) {
+                    size_t done = 0;
+                    while (done < len) {
+                        const ssize_t w = pwrite(pt->ofd, text + done, len - done, (off_t)(pt->out_off + done));
+                        if (w <= 0) { fail(std::string("write error: ") + strerror(errno)); break; }
+                        done += (size_t)w;
                     }
-                    std::vector<char>& buf = b->text[(size_t)t];
-                    if (buf.size() < bound) buf.resize(bound + bound / 8);
-                    Out o{buf.data()};
-                    const char* t1 = b->l1.p;
-                    const char* t2 = b->l2.p;
-                    for (long r = a; r < e; r++) {
-                        const int L = (int)b->r1.seq_len[r], L2 = pe ? (int)b->r2.seq_len[r] : 0;
-                        const char* s1 = t1 + b->r1.seq_off[r];
-                        const char* q1 = t1 + b->r1.qual_off[r];
-                        const int ql1 = (int)b->r1.qual_len[r];
-                        const char* nm = t1 + b->l1.start((size_t)r * 4);
-                        size_t nl = b->l1.end((size_t)r * 4) - b->l1.start((size_t)r * 4);
-                        if (!pe) {
-                            const bmbs_result& x = res[r];
-                            const bool mapped = x.status == BMBS_ST_UNIQUE || (x.status == BMBS_ST_AMBIG && ambiguous_out);
-                            if (!mapped && !(unmapped_out && x.status != BMBS_ST_AMBIG)) continue;
-                            size_t c = 0;                               // cut at the first ' ' or '/' (Process_Reads.cpp:843-850)
-                            while (c < nl && nm[c] != ' ' && nm[c] != '/') c++;
-                            nl = c;
-                            if (nl && nm[0] == '@') { nm++; nl--; }
-                            o.mem(nm, nl); o.ch('\t');
-                            if (!mapped) {
-                                // output_sam_unmapped (Schema.cpp:23955-23975); pbat prints the record as it was read (25538-25543)
-                                o.lit("4\t*\t0\t0\t*\t*\t0\t0\t");
-                                o.seq(s1, q1, L, ql1, false);
-                                o.ch('\n');
-                                continue;
-                            }
-                            o.num(x.flag); o.ch('\t'); o.str(chrom_names[(size_t)x.chrom]); o.ch('\t'); o.num(x.pos); o.ch('\t');
-                            o.num(x.mapq); o.ch('\t'); o.cigar(x, cpool, L); o.lit("\t*\t0\t0\t");
-                            // a --pbat read was mapped as the reverse complement of the text: flag 16 prints the text as it is
-                            o.seq(s1, q1, L, ql1, ((x.flag & 16) != 0) != pbat_se);
-                            o.lit("\tNM:i:"); o.num(x.nm); o.ch('\n');
-                        } else {
-                            const bmbs_result &x1 = res[2 * r], &x2 = res[2 * r + 1];
-                            const bool mapped = x1.status == BMBS_ST_UNIQUE || (x1.status == BMBS_ST_AMBIG && ambiguous_out);
-                            if (!mapped && !(unmapped_out && x1.status != BMBS_ST_AMBIG)) continue;
-                            const char* s2 = t2 + b->r2.seq_off[r];
-                            const char* q2 = t2 + b->r2.qual_off[r];
-                            const int ql2 = (int)b->r2.qual_len[r];
-                            const char* nm2 = t2 + b->l2.start((size_t)r * 4);
-                            const size_t nl2 = b->l2.end((size_t)r * 4) - b->l2.start((size_t)r * 4);
-                            size_t c = 0;                               // first differing char, ' ' or '/' (Process_Reads.cpp:296-307)
-                            while (c < nl && c < nl2 && nm[c] == nm2[c] && nm[c] != ' ' && nm[c] != '/') c++;
-                            nl = c;
-                            if (nl && nm[0] == '@') { nm++; nl--; }
-                            if (!mapped) {
-                                // directly_output_unmapped_PE (Schema.cpp:10392-10430)
-                                o.mem(nm, nl); o.lit("\t77\t*\t0\t0\t*\t*\t0\t0\t");
-                                o.seq(s1, q1, L, ql1, false); o.ch('\n');
-                                o.mem(nm, nl); o.lit("\t141\t*\t0\t0\t*\t*\t0\t0\t");
-                                o.seq(s2, q2, L2, ql2, false); o.ch('\n');
-                                continue;
-                            }
-                            const unsigned tlen = x1.tlen;
-                            o.mem(nm, nl); o.ch('\t');
-                            o.num(x1.flag); o.ch('\t'); o.str(chrom_names[(size_t)x1.chrom]); o.ch('\t'); o.num(x1.pos); o.ch('\t');
-                            o.num(x1.mapq); o.ch('\t'); o.cigar(x1, cpool, L); o.lit("\t=\t"); o.num(x2.pos); o.ch('\t');
-                            if (x2.pos < x1.pos) o.ch('-');             // TLEN sign, Schema.cpp:10575-10600
-                            o.num(tlen); o.ch('\t');
-                            o.seq(s1, q1, L, ql1, !(x1.flag & 32));
-                            o.lit("\tNM:i:"); o.num(x1.nm); o.ch('\n');
-                            o.mem(nm, nl); o.ch('\t');
-                            o.num(x2.flag); o.ch('\t'); o.str(chrom_names[(size_t)x2.chrom]); o.ch('\t'); o.num(x2.pos); o.ch('\t');
-                            o.num(x2.mapq); o.ch('\t'); o.cigar(x2, cpool, L2); o.lit("\t=\t"); o.num(x1.pos); o.ch('\t');
-                            if (!(x1.pos > x2.pos)) o.ch('-');           // Schema.cpp:11530-11555
-                            o.num(tlen); o.ch('\t');
-                            o.seq(s2, q2, L2, ql2, (x2.flag & 16) != 0);
-                            o.lit("\tNM:i:"); o.num(x2.nm); o.ch('\n');
-                        }
+                    pt->out_off += len;
+                } else {
+                    // the batch's SAM lines -> BAM records -> BGZF blocks, by slices that begin at line starts (records may straddle
+                    // blocks, as in the reference's stream)
+                    const int T = pool.size() * 2;
+                    std::vector<size_t> cut((size_t)T + 1, len);
+                    cut[0] = 0;
+                    for (int t = 1; t < T; t++) {
+                        size_t at = len * (size_t)t / (size_t)T;
+                        const char* h = at < len ? (const char*)memchr(text + at, '\n', len - at) : nullptr;
+                        cut[(size_t)t] = std::max(cut[(size_t)t - 1], h ? (size_t)(h - text) + 1 : len);
                     }
-                    size_t tl = (size_t)(o.p - buf.data());
-                    if (bam && tl) {
-                        // the slice's SAM lines -> BAM records -> BGZF blocks (records may straddle blocks)
+                    b->bam_rec.resize((size_t)T); b->bam_z.resize((size_t)T);
+                    pool.run(T, [&](int t) {
                         std::vector<char>& rec = b->bam_rec[(size_t)t];
                         std::vector<char>& z = b->bam_z[(size_t)t];
                         rec.clear(); z.clear();
-                        const char* q = buf.data();
-                        const char* e2 = q + tl;
+                        const char* q = text + cut[(size_t)t];
+                        const char* e2 = text + cut[(size_t)t + 1];
                         while (q < e2) {
                             const char* nlp = (const char*)memchr(q, '\n', (size_t)(e2 - q));
                             const size_t ll = nlp ? (size_t)(nlp - q) : (size_t)(e2 - q);
                             sam_line_to_bam(q, ll, bam_refs, rec);
                             q += ll + 1;
                         }
-                        bgzf_append(rec.data(), rec.size(), z);
-                        if (buf.size() < z.size()) buf.resize(z.size());
-                        memcpy(buf.data(), z.data(), z.size());
-                        tl = z.size();
-                    }
-                    b->text_len[(size_t)t] = tl;
-                });
-            }
-            t_format += now() - t0;
-            ev_f.push_back({'F', nrec, t0, now()});
-            wr_q.put(b);
-            if (end) return;
-        }
-    });
-
-    // ---------------- stage W: the slices go into the output file at their prefix offsets -----------------------------
-    // write()/pwrite() to ONE file take its inode lock exclusively: N threads writing N slices run one after the other at the
-    // speed of one memcpy (tools/host_mem_probe on the MI355X box: 10.5 GB/s with 1, 8, 16 or 32 threads; tmpfs 5.4 GB/s) -- that,
-    // 30 M SAM records of 350 bytes per second, is the ceiling of a file-to-file run.  The alternative, a shared mapping of the
-    // file filled by several threads (BMBS_MMAP_OUT=1), measured WORSE on that box: 8.4 GB/s with one thread, 2.3 GB/s with 8-16
-    // (page-fault path of the overlay file system), so pwrite stays the default.
-    struct stat ost;
-    const bool out_mappable = fstat(ofd, &ost) == 0 && S_ISREG(ost.st_mode) && getenv("BMBS_MMAP_OUT");
-    std::thread writer([&] {
-        Pool pool(out_mappable ? std::max(1, io_threads / 4) - 1 : 1);     // pwrite()s to one file run one at a time anyway
-        for (;;) {
-            const double tw0 = now();
-            Batch* b = wr_q.get();
-            const double t0 = now();
-            t_wait_w += t0 - tw0;
-            const bool end = b->end;
-            const int T = (int)b->text.size();
-            if (b->n && !failed) {
-                std::vector<size_t> at((size_t)T + 1, out_off);
-                for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + b->text_len[(size_t)t];
-                const size_t total = at[(size_t)T] - out_off;
-                char* map = nullptr;
-                size_t map_lo = 0, map_len = 0;
-                if (out_mappable && total) {
-                    map_lo = out_off & ~(size_t)4095; map_len = at[(size_t)T] - map_lo;
-                    if (ftruncate(ofd, (off_t)at[(size_t)T]) == 0) {
-                        void* m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, ofd, (off_t)map_lo);
-                        if (m != MAP_FAILED) map = (char*)m;
-                    }
-                }
-                if (map) {
-                    // equal byte ranges, not slices: the copy is balanced whatever the slices' sizes are
-                    const int W = pool.size() * 2;
-                    const size_t per = (total + (size_t)W - 1) / (size_t)W;
-                    pool.run(W, [&](int w) {
-                        size_t lo = out_off + std::min(total, per * (size_t)w);
-                        const size_t hi = out_off + std::min(total, per * (size_t)(w + 1));
-                        int t = (int)(std::upper_bound(at.begin(), at.end(), lo) - at.begin()) - 1;
-                        while (lo < hi && t < T) {
-                            const size_t stop = std::min(hi, at[(size_t)t + 1]);
-                            if (stop > lo) memcpy(map + (lo - map_lo), b->text[(size_t)t].data() + (lo - at[(size_t)t]), stop - lo);
-                            lo = std::max(lo, stop);
-                            t++;
-                        }
+                        if (!rec.empty()) bgzf_append(rec.data(), rec.size(), z);
                     });
-                    munmap(map, map_len);
-                } else {
-                    pool.run(T, [&](int t) {
-                        const char* d = b->text[(size_t)t].data();
-                        const size_t len = b->text_len[(size_t)t];
+                    const double t1 = now();
+                    pt->t_format += t1 - t0;
+                    for (int t = 0; t < T; t++) {
+                        const std::vector<char>& z = b->bam_z[(size_t)t];
                         size_t done = 0;
-                        while (done < len) {
-                            const ssize_t w = pwrite(ofd, d + done, len - done, (off_t)(at[(size_t)t] + done));
-                            if (w <= 0) { failed = true; break; }
+                        while (done < z.size()) {
+                            const ssize_t w = pwrite(pt->ofd, z.data() + done, z.size() - done, (off_t)(pt->out_off + done));
+                            if (w <= 0) { fail(std::string("write error: ") + strerror(errno)); break; }
                             done += (size_t)w;
                         }
-                    });
+                        pt->out_off += z.size();
+                    }
+                    pt->t_write -= t1 - t0;
                 }
-                out_off = at[(size_t)T];
             }
-            t_write += now() - t0;
-            ev_w.push_back({'W', b->n, t0, now()});
+            pt->t_write += now() - t0;
             free_q.put(b);
             if (end) return;
         }
-    });
+    };
 
     // ---------------- stage G: one worker per context, one library call per batch ---------------------------------------
-    std::atomic<long> total_records_a(0);
+    double t_gpu = 0, t_wait_g = 0;
     std::mutex g_mu;
     auto g_worker = [&](bmbs_ctx* ctx) {
         for (;;) {
             const double tw0 = now();
             Batch* b = gpu_q.get();
-            if (!b) return;                                                // another worker has seen the last batch
+            if (!b) return;
             const double t0 = now();
-            { std::lock_guard<std::mutex> l(g_mu); t_wait_g += t0 - tw0; }
             if (!failed && b->n) {
-                int64_t used = 0;
-                int rc;
-                bmbs_fastq_view v1 = {b->text1.p, (uint64_t)b->l1.used, b->r1.seq_off, b->r1.qual_off, b->r1.seq_len, b->r1.qual_len};
-                const int64_t cap = (int64_t)b->n * b->max_ops * (pe ? 2 : 1);
-                if (!pe)
-                    rc = bmbs_map_se_fastq(ctx, &v1, b->n, b->maxL, b->uniform ? 1 : 0, pbat_se ? 1 : 0, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, cap, &used);
-                else {
-                    bmbs_fastq_view v2 = {b->text2.p, (uint64_t)b->l2.used, b->r2.seq_off, b->r2.qual_off, b->r2.seq_len, b->r2.qual_len};
-                    rc = bmbs_map_pe_fastq(ctx, &v1, &v2, b->n, b->maxL, b->uniform ? 1 : 0, (bmbs_result*)b->res.p, (uint32_t*)b->pool.p, cap, &used);
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    uint64_t bytes = 0; int64_t lines = 0;
+                    const int rc = pe ? bmbs_map_pe_text(ctx, b->text1.p, b->used1, b->text2.p, b->used2, b->n, flags, b->sam.p, b->sam.cap, &bytes, &lines)
+                                      : bmbs_map_se_text(ctx, b->text1.p, b->used1, b->n, flags, b->sam.p, b->sam.cap, &bytes, &lines);
+                    if (rc == BMBS_ENOMEM && bytes > b->sam.cap && attempt == 0 && b->sam.need((size_t)bytes + 64)) continue;   // reads longer than guessed
+                    if (rc) fail(bmbs_last_error(ctx));
+                    b->sam_bytes = rc ? 0 : bytes;
+                    break;
                 }
-                if (rc) { fprintf(stderr, "%s\n", bmbs_last_error(ctx)); failed = true; }
             }
-            total_records_a += b->n;
-            {
-                std::lock_guard<std::mutex> l(g_mu);
-                t_gpu += now() - t0;
-                ev_g.push_back({'G', b->n, t0, now()});
-            }
-            const bool end = b->end;
-            out_q.put(b->seq, b);
-            if (end) { for (size_t i = 1; i < ctxs.size(); i++) gpu_q.put(nullptr); return; }
+            { std::lock_guard<std::mutex> l(g_mu); t_wait_g += t0 - tw0; t_gpu += now() - t0; }
+            b->part->out_q.put(b->seq, b);
         }
     };
-    {
-        std::vector<std::thread> workers;
-        for (size_t i = 1; i < ctxs.size(); i++) workers.emplace_back(g_worker, ctxs[i]);
-        g_worker(ctxs[0]);
-        for (auto& t : workers) t.join();
+    std::vector<std::thread> workers;
+    for (bmbs_ctx* c : ctxs) workers.emplace_back(g_worker, c);
+    for (int p = 0; p < live_parts; p++) { Part* pt = P_[(size_t)p].get(); pt->writer = std::thread(writer_fn, pt); pt->reader = std::thread(reader_fn, pt); }
+    for (int p = 0; p < live_parts; p++) P_[(size_t)p]->reader.join();
+    for (int p = 0; p < live_parts; p++) P_[(size_t)p]->writer.join();           // every batch has passed its writer: the workers are idle
+    for (size_t i = 0; i < workers.size(); i++) gpu_q.put(nullptr);
+    for (auto& t : workers) t.join();
+    long total_records = 0;
+    double t_read = 0, t_write = 0, t_format = 0, t_wait_r = 0, t_wait_w = 0;
+    for (int p = 0; p < live_parts; p++) {
+        const Part& pt = *P_[(size_t)p];
+        total_records += pt.records; t_read += pt.t_read; t_write += pt.t_write; t_format += pt.t_format; t_wait_r += pt.t_wait_r; t_wait_w += pt.t_wait_w;
     }
-    const long total_records = total_records_a.load();
-    reader.join();
-    formatter.join();
-    writer.join();
     if (bam && !failed) {
         static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (pwrite(ofd, eof_block, 28, (off_t)out_off) != 28) failed = true;
-        out_off += 28;
+        Part& lastp = *P_[(size_t)parts - 1];
+        if (pwrite(lastp.ofd, eof_block, 28, (off_t)lastp.out_off) != 28) failed = true;
+        lastp.out_off += 28;
     }
     const double t_joined = now();
-    ::close(ofd);
-    src1.close();
-    if (pe) src2.close();
+    for (int p = 0; p < parts; p++) { Part& pt = *P_[(size_t)p]; ::close(pt.ofd); if (p < live_parts) { pt.s1.close(); if (pe) pt.s2.close(); } }
     if (failed) { fprintf(stderr, "bmbs_search: failed\n"); return 1; }
     int64_t st[5];
     bmbs_stats_allreduce(ctxs.data(), (int)ctxs.size(), st);      // get_mapping_informations: the counters of every worker summed
@@ -1036,17 +992,13 @@ int main(int argc, char** argv)
     if (!mapstats.empty()) { FILE* m = fopen(mapstats.c_str(), "w"); if (m) { print_stats(m, st); fclose(m); } }
     const double t_end = now();
     if (verbose)
-        fprintf(stderr, "[bmbs_search] records %ld  load+attach %.3fs  mapping wall %.3fs  (pipeline %.3fs; stage busy: read/pack %.3fs of which line index %.3fs, gpu %.3fs, format %.3fs, write %.3fs)  %d I/O threads, batch %ld, %zu device(s) x %d context(s)\n",
-                total_records, t_loaded - t_start, t_end - t_loaded, t_joined - t_loaded, t_read, t_index, t_gpu, t_format, t_write, io_threads, batch,
-                n_owner, contexts);
+        fprintf(stderr, "[bmbs_search] records %ld  load+attach %.3fs  mapping wall %.3fs  (pipeline %.3fs; stage busy, summed over %d part(s): read + newline count %.3fs, gpu calls %.3fs over %d context(s), host format %.3fs, write %.3fs)  %d I/O threads, batch %ld, %zu device(s) x %d context(s), %d output part(s)\n",
+                total_records, t_loaded - t_start, t_end - t_loaded, t_joined - t_loaded, live_parts, t_read, t_gpu, n_ctx, t_format, t_write, io_threads, batch,
+                n_owner, contexts, parts);
     if (verbose)
-        fprintf(stderr, "[bmbs_search] read stage: window %.3fs, line index %.3fs; stage idle (waiting for a batch): read %.3fs, gpu workers %.3fs (summed), format %.3fs, write %.3fs\n",
-                t_window, t_index - t_window, t_wait_r, t_wait_g, t_wait_f, t_wait_w);
-    if (verbose && getenv("BMBS_TRACE"))
-        for (const auto* v : {&ev_r, &ev_g, &ev_f, &ev_w})
-            for (const Ev& e : *v) fprintf(stderr, "[trace] %c n=%ld %.4f .. %.4f\n", e.stage, e.n, e.a - t_loaded, e.b - t_loaded);
+        fprintf(stderr, "[bmbs_search] stage idle (waiting for a batch, summed): readers %.3fs, gpu workers %.3fs, writers %.3fs\n", t_wait_r, t_wait_g, t_wait_w);
     const double t0 = now();
-    for (auto& b : batches) { b.text1.release(); b.text2.release(); b.r1.mem.release(); b.r2.mem.release(); b.res.release(); b.pool.release(); }
+    for (auto& b : batches) { b.text1.release(); b.text2.release(); b.sam.release(); }
     const double t1 = now();
     for (size_t i = ctxs.size(); i-- > 0;) bmbs_destroy(ctxs[i]);     // the sharing contexts go before their owners
     const double t2 = now();

@@ -160,6 +160,31 @@ class Mapper:
                                             capi.ptr(l2), L, stride, n, capi.ptr(res), capi.ptr(pool), cap, C.byref(used)))
         return res, pool[:used.value]
 
+    # ---- FASTQ text in, SAM text out (newline index and SAM formatting on the device) ---------------
+    TEXT_PBAT, TEXT_UNMAPPED = 1, 2
+
+    def _set_refs(self):
+        if getattr(self, "_refs_set", False):
+            return
+        names = (C.c_char_p * len(self.index.chrom_names))(*[n.encode() for n in self.index.chrom_names])
+        self._chk(self._lib.bmbs_sam_refs(self._ctx, names, len(self.index.chrom_names)))
+        self._refs_set = True
+
+    def map_text(self, text1: bytes, n: int, text2: bytes | None = None, flags: int = 0) -> bytes:
+        """FASTQ text of n records (pairs with text2) -> the SAM lines the reference prints for them, in input order"""
+        self._set_refs()
+        cap = len(text1) + (len(text2) if text2 else 0) + (2 if text2 else 1) * n * 640 + 4096
+        out = np.empty(cap, dtype=np.uint8)
+        used = C.c_uint64(0); lines = C.c_int64(0)
+        a1 = np.frombuffer(text1, dtype=np.uint8)
+        if text2 is None:
+            self._chk(self._lib.bmbs_map_se_text(self._ctx, capi.ptr(a1), a1.size, n, flags, capi.ptr(out), cap, C.byref(used), C.byref(lines)))
+        else:
+            a2 = np.frombuffer(text2, dtype=np.uint8)
+            self._chk(self._lib.bmbs_map_pe_text(self._ctx, capi.ptr(a1), a1.size, capi.ptr(a2), a2.size, n, flags, capi.ptr(out), cap,
+                                                 C.byref(used), C.byref(lines)))
+        return out[:used.value].tobytes()
+
     def sync(self):
         self._chk(self._lib.bmbs_sync(self._ctx))
 

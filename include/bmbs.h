@@ -236,6 +236,25 @@ int bmbs_map_se_fastq(bmbs_ctx*, const bmbs_fastq_view* reads, int64_t n_reads, 
 int bmbs_map_pe_fastq(bmbs_ctx*, const bmbs_fastq_view* mate1, const bmbs_fastq_view* mate2, int64_t n_pairs, int32_t L_max,
                       int32_t uniform, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used);
 
+/* ---- FASTQ text in, SAM text out: both ends of the file-to-file path on the device -------------------------------------------------
+ * The reference's reader and its SAM sink are one host thread each (Process_Reads.cpp:2057-2260, Process_sam_out.cpp:954-1006) and
+ * bound the whole program.  Here the host hands over the text window exactly as it came from the file(s) together with the number
+ * of complete records it holds (it only has to count newlines), and gets the finished SAM lines of those records back: the
+ * newline index, the read rows, the mapping and the formatting of output_sam_end_to_end / directly_output_read1 / _read2 /
+ * output_sam_unmapped / directly_output_unmapped_PE (Schema.cpp:11989-12039, 10537-10640, 11494-11590, 23955-23975, 10392-10430)
+ * all happen on the device; QNAME, SEQ and QUAL are taken from the FASTQ text that is resident there anyway.
+ * text = n_records * 4 lines (a window may hold more: the rest is ignored); paired end: record i of text1 and of text2 are a pair.
+ * sam receives the lines in input order, *sam_bytes their total size; BMBS_ENOMEM with *sam_bytes = the size needed when sam_cap is
+ * too small.  Page-locked buffers (bmbs_host_alloc) move at link speed.  bmbs_sam_refs sets the RNAME strings (the names of the
+ * index's sequences, in index order: bmbs_index_file_chrom_name) once per context.                                           */
+#define BMBS_TEXT_PBAT      1   /* single end --pbat: reads are mapped as their reverse complement (Process_Reads.cpp:986-1075)   */
+#define BMBS_TEXT_UNMAPPED  2   /* --unmapped_out: unmapped reads / pairs are printed with flag 4 / 77 + 141                      */
+int bmbs_sam_refs(bmbs_ctx*, const char* const* names, int32_t n_names);
+int bmbs_map_se_text(bmbs_ctx*, const char* text, uint64_t text_bytes, int64_t n_records, int32_t flags,
+                     char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
+int bmbs_map_pe_text(bmbs_ctx*, const char* text1, uint64_t bytes1, const char* text2, uint64_t bytes2, int64_t n_pairs, int32_t flags,
+                     char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
+
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
  * error bases} (Schema.cpp:25141-25146); bmbs_stats_allreduce sums them over the ctxs one process
  * drives (get_mapping_informations, Schema.cpp:451-476).  Multi-process jobs sum the five int64 with

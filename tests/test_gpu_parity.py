@@ -1050,3 +1050,157 @@ def test_device_entry_points_split_over_lanes(env, monkeypatch):
             a = ca[int(ra[i]["cigar_off"]):int(ra[i]["cigar_off"]) + int(ra[i]["n_cigar"])]
             b = cb[int(rb[i]["cigar_off"]):int(rb[i]["cigar_off"]) + int(rb[i]["n_cigar"])]
             assert (a == b).all(), i
+
+
+# ---- FASTQ text in, SAM text out: line index and SAM formatting on the device (bmbs_map_*_text) ---------------------------------------
+def _sam_body(text):
+    return "".join(l for l in text.splitlines(keepends=True) if not l.startswith("@"))
+
+
+@pytest.mark.parametrize("name", sorted(golden_args()))
+def test_device_sam_text_equals_reference_golden_se(name, tmp_path):
+    """the FASTQ file's bytes go to the device as they are; the SAM lines that come back are the reference's, byte for byte"""
+    from bitmapperbs_amd import mapper, distributed
+    fa = str(tmp_path / "genome.fa")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    mapper.Index.build(fa, fa, threads=4)
+    ix = mapper.Index(fa)
+    text = gzip.open(os.path.join(GOLD, "se_%s.fq.gz" % name), "rb").read()
+    n = text.count(b"\n") // 4
+    m = mapper.Mapper(ix, 0, e_f=e_of(golden_args()[name]))
+    # the whole file in one call, then the same records in three windows (a window may hold more text than the records asked for)
+    mine = m.map_text(text, n).decode()
+    assert mine == _sam_body(gzip.open(os.path.join(GOLD, "se_%s.ref.sam.gz" % name), "rt").read())
+    assert distributed.mapstats_text(m.stats()) == open(os.path.join(GOLD, "se_%s.ref.stats" % name)).read()
+    lines = text.split(b"\n")
+    cut = [0, n // 3, n // 3 + 1, n]
+    parts = []
+    for a, b in zip(cut[:-1], cut[1:]):
+        w = b"\n".join(lines[4 * a:]) if b == n else b"\n".join(lines[4 * a:4 * b + 2]) + b"\n"
+        parts.append(m.map_text(w, b - a).decode())
+    assert "".join(parts) == mine
+    m.close()
+
+
+@pytest.mark.parametrize("name", sorted(pe_golden_args()))
+def test_device_sam_text_equals_reference_golden_pe(name, tmp_path):
+    from bitmapperbs_amd import mapper, distributed
+    from test_oracle import pe_params
+    fa = str(tmp_path / "genome.fa")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    mapper.Index.build(fa, fa, threads=4)
+    ix = mapper.Index(fa)
+    t1 = gzip.open(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), "rb").read()
+    t2 = gzip.open(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), "rb").read()
+    n = t1.count(b"\n") // 4
+    m = mapper.Mapper(ix, 0, **pe_params(pe_golden_args()[name]))
+    mine = m.map_text(t1, n, t2).decode()
+    assert mine == _sam_body(gzip.open(os.path.join(GOLD, "pe_%s.ref.sam.gz" % name), "rt").read())
+    assert distributed.mapstats_text(m.stats()) == open(os.path.join(GOLD, "pe_%s.ref.stats" % name)).read()
+    m.close()
+
+
+def test_device_sam_text_odd_input(env):
+    """names with blanks and slashes, lower-case bases, a quality line shorter than its sequence, no newline at the end of the
+    window, mixed lengths, unmapped_out: the device text against the host-side formatter over the same records"""
+    from bitmapperbs_amd import synth, mapper
+    r = synth.make_reads_se(env["chroms"], n=3000, L=120, seed=41, sub=0.03, indel=0.002, qual="random", n_rate=0.002)
+    rng = np.random.default_rng(6)
+    recs = []
+    for i in range(3000):
+        Li = int(rng.integers(30, 121))
+        s = r["seq"][i, :Li].tobytes(); q = r["qual"][i, :Li].tobytes()
+        if i % 7 == 0: s = s.lower()
+        if i % 11 == 0: q = q[:max(1, Li - 5)]
+        nm = b"@read%d" % i + (b" extra/1" if i % 3 == 0 else b"/1" if i % 3 == 1 else b"")
+        recs.append(nm + b"\n" + s + b"\n+\n" + q)
+    text = b"\n".join(recs)                                  # no '\n' behind the last quality line
+    m = mapper.Mapper(env["ix"], 0)
+    got = m.map_text(text + b"\n", 3000, flags=mapper.Mapper.TEXT_UNMAPPED).decode().splitlines()
+    m.close()
+    # expected: the records through the row interface + the host formatter
+    m = mapper.Mapper(env["ix"], 0)
+    L = 120
+    seq = np.zeros((3000, L), dtype=np.uint8); qual = np.zeros((3000, L), dtype=np.uint8); lens = np.zeros(3000, dtype=np.uint16)
+    names = []
+    for i, rec in enumerate(recs):
+        nm, s, _, q = rec.split(b"\n")
+        s = s.upper(); q = q + b" " * (len(s) - len(q))
+        seq[i, :len(s)] = np.frombuffer(s, dtype=np.uint8); qual[i, :len(s)] = np.frombuffer(q, dtype=np.uint8); lens[i] = len(s)
+        names.append(nm[1:])
+    res, pool = m.map_se_var(seq, qual, lens)
+    m.close()
+    exp = []
+    for i in range(3000):
+        x = res[i]; Li = int(lens[i])
+        nm = names[i].decode().split(" ")[0].split("/")[0]
+        s = seq[i, :Li]; q = qual[i, :Li]
+        if int(x["status"]) == 1:
+            if int(x["flag"]) & 16:
+                s = mapper._COMP[s][::-1]; q = q[::-1]
+            exp.append("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d" % (nm, int(x["flag"]), env["ix"].chrom_names[int(x["chrom"])], int(x["pos"]),
+                       int(x["mapq"]), mapper.cigar_text(x, pool, Li), s.tobytes().decode(), q.tobytes().decode(), int(x["nm"])))
+        elif int(x["status"]) != 2:
+            exp.append("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s" % (nm, s.tobytes().decode(), q.tobytes().decode()))
+    assert got == exp
+
+
+@pytest.mark.parametrize("kind,name,nparts,mode", [
+    ("se", "b150", 3, "plain"), ("pe", "p100", 4, "plain"), ("pe", "s100", 2, "names_differ"), ("pe", "p150", 3, "no_names"),
+    ("se", "e75", 2, "gz"), ("pe", "p75", 3, "bam"),
+])
+def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, nparts, mode, tmp_path):
+    """--out-parts N: the input is cut into N record ranges (pairs: at the same record in both files, found by the read names, or by
+    counting lines when the names do not identify a record), every range is read, mapped and written by a pipeline of its own,
+    and `cat` of the parts in order is byte for byte what the one-file run writes (= the reference's output)"""
+    import shutil
+    import subprocess
+    from bitmapperbs_amd import mapper
+    fa = str(tmp_path / "genome.fa"); out = str(tmp_path / "o.sam")
+    gunzip_to(os.path.join(GOLD, "genome.fa.gz"), fa)
+    mapper.Index.build(fa, fa, threads=4)
+    if kind == "se":
+        fq = str(tmp_path / "r.fq")
+        gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % name), fq)
+        if mode == "gz":
+            shutil.copy(os.path.join(GOLD, "se_%s.fq.gz" % name), fq + ".gz"); fq += ".gz"
+        inp = ["--seq", fq]; args = golden_args()[name]
+    else:
+        f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq")
+        gunzip_to(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1)
+        gunzip_to(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), f2)
+        if mode == "names_differ":          # mate files whose names differ behind a blank, and records of different sizes in the two files
+            t = open(f2, "rb").read().split(b"\n")
+            for i in range(0, len(t) - 1, 4):
+                t[i] = t[i] + b" 2:N:0:" + b"X" * ((i // 4) % 17)
+            open(f2, "wb").write(b"\n".join(t))
+        if mode == "no_names":              # every record has the same name: the cut has to be found by counting lines
+            for f in (f1, f2):
+                t = open(f, "rb").read().split(b"\n")
+                for i in range(0, len(t) - 1, 4):
+                    t[i] = b"@same"
+                open(f, "wb").write(b"\n".join(t))
+        inp = ["--seq1", f1, "--seq2", f2]; args = pe_golden_args()[name]
+    if mode == "bam":
+        args = args + ["--bam"]
+    one = subprocess.run([_driver(), "--search", fa] + inp + ["-o", out, "--batch", "211"] + args, capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr
+    par = subprocess.run([_driver(), "--search", fa] + inp + ["-o", out + ".p", "--batch", "211", "--out-parts", str(nparts)] + args,
+                         capture_output=True, text=True)
+    assert par.returncode == 0, par.stderr
+    parts = [open(out + ".p.part%03d" % i, "rb").read() for i in range(nparts)]
+    if mode != "gz":
+        assert all(len(x) > 0 for x in parts[1:])         # every part got its share
+    if mode == "bam":
+        from common import bam_payload
+        cat = str(tmp_path / "cat.bam")
+        open(cat, "wb").write(b"".join(parts))
+        assert bam_payload(cat) == bam_payload(out)
+    else:
+        strip = lambda b: b"".join(l for l in b.splitlines(keepends=True) if not l.startswith(b"@PG"))
+        assert strip(b"".join(parts)) == strip(open(out, "rb").read())
+        if mode in ("plain", "gz"):
+            ref = gzip.open(os.path.join(GOLD, "%s_%s.ref.sam.gz" % (kind, name)), "rb").read()
+            assert strip(b"".join(parts)) == ref
+    st = lambda p: "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
+    assert st(one) == st(par)

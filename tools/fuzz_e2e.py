@@ -132,6 +132,10 @@ def run_trial(t, env, wd):
     outs = {}
     # the driver's own knobs vary too: batch size (records per library call), host threads, contexts per device
     drv_extra = ["-t", str(int(rng.choice([1, 3, 8, 16]))), "--batch", str(int(rng.choice([97, 333, 1777, 50000]))), "--contexts", str(int(rng.choice([1, 2, 3])))]
+    # ... and the number of output parts (every part a pipeline of its own over its record range; `cat` of the parts is compared)
+    n_parts = int(rng.choice([1, 1, 2, 3, 5]))
+    if n_parts > 1 and not USE_ORACLE:
+        drv_extra += ["--out-parts", str(n_parts)]
     for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", ORC if USE_ORACLE else DRV, [] if USE_ORACLE else drv_extra)):
         out = os.path.join(wd, who + ".sam"); ms = os.path.join(wd, who + ".ms")
         for f in (out, ms):
@@ -141,6 +145,10 @@ def run_trial(t, env, wd):
         p = subprocess.run(head + inp + t["opt"] + ["-o", out, "--mapstats", ms] + extra, capture_output=True, text=True, cwd=wd)
         if p.returncode:
             return ["%s exit code %d: %s" % (who, p.returncode, p.stderr[-300:])], 0
+        if who == "gpu" and "--out-parts" in extra:
+            with open(out, "wb") as o:
+                for k in range(n_parts):
+                    o.write(open(out + ".part%03d" % k, "rb").read())
         outs[who] = (bam_body(out) if "--bam" in t["opt"] else body(out), open(ms).read() if os.path.exists(ms) else "")
     a, b = outs["ref"], outs["gpu"]
     bad = []
