@@ -219,21 +219,46 @@ def cpu_baseline(args, cfg, fa, host_reads, L):
 
 
 # ---- roofline accounting --------------------------------------------------------------------------------------------------------
-def pmc_traffic(kernel, tag):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/<tag>_pmc_fetch_write.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units as rocprofv3
-    reports them).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (>= 16 B/lane) coalesced streams by 2x; the
-    mapping kernels issue 4-16 B per-lane gathers, for which the guide gives no calibration; tools/gather_bench (known byte
-    count, same access shape) reads 1.0x, so the raw (FETCH_SIZE + WRITE_SIZE) * 1024 is reported.  None when no profile of
-    this configuration has been committed."""
+# FETCH_SIZE correction per kernel (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports exactly half the bytes of a wide
+# coalesced streaming read, 16 B per lane; WRITE_SIZE is exact for 16-byte streaming stores).  "x2": the kernel's reads are such
+# streams -- whole rows / text fetched 16 bytes per lane by consecutive lanes; "raw": per-lane gathers of 4-16 bytes at unrelated
+# addresses (index walks, candidate lists), for which tools/gather_bench with a known byte count reads 1.0x.
+FETCH_RULE = {
+    "k_pe_prepare": "x2", "k_pe_prepare_p": "x2", "k_pack_rows": "x2", "k_fastq_rows": "x2", "k_seed_decide_p": "x2 on the staged rows, raw on the window gathers: reported raw (lower bound)",
+    "k_finalize_pe": "x2", "k_finalize": "x2", "k_fq_count": "x2", "k_fq_lines": "x2", "k_sam_write": "raw (byte gathers from the text)",
+}
+
+
+def fetch_rule(kernel):
+    r = FETCH_RULE.get(kernel.split("<")[0], "raw")
+    return r, (2.0 if r == "x2" else 1.0)
+
+
+def pmc_table(tag):
+    """{kernel: (fetch bytes corrected, write bytes, rule)} per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/<tag>_pmc_fetch_write.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units as rocprofv3 reports
+    them); {} when no profile of this configuration has been committed"""
     import csv
     path = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write.csv" % tag)
+    out = {}
     if not os.path.exists(path):
-        return None
+        return out
     for row in csv.DictReader(open(path)):
-        if row["kernel"].split("<")[0] == kernel and row["FETCH_SIZE_KB_last_launch"] and row["WRITE_SIZE_KB_last_launch"]:
-            return int((float(row["FETCH_SIZE_KB_last_launch"]) + float(row["WRITE_SIZE_KB_last_launch"])) * 1024)
-    return None
+        if not (row["FETCH_SIZE_KB_last_launch"] and row["WRITE_SIZE_KB_last_launch"]):
+            continue
+        name = row["kernel"].split("<")[0].split("(")[0]
+        rule, f = fetch_rule(name)
+        lanes = int(row.get("launches_per_call") or 1)
+        fe = float(row["FETCH_SIZE_KB_last_launch"]) * 1024 * f * lanes
+        wr = float(row["WRITE_SIZE_KB_last_launch"]) * 1024 * lanes
+        a, b, _ = out.get(name, (0.0, 0.0, rule))
+        out[name] = (a + fe, b + wr, rule)
+    return out
+
+
+def pmc_traffic(kernel, tag):
+    t = pmc_table(tag).get(kernel)
+    return int(t[0] + t[1]) if t else None
 
 
 def algorithmic_bytes(cnt, nr, L, k, pe):
@@ -267,6 +292,18 @@ def algorithmic_bytes(cnt, nr, L, k, pe):
     if pe:
         s8d["k_pe_prepare"] = 2 * L * nr; own["k_pe_prepare"] = 2 * L * nr       # both mates read, the working copy written
     return s8d, own
+
+
+def native_bytes(cnt, wide):
+    """the bytes THIS layout has to move for the same events (the reference's 40-byte Occ blocks and 10-byte hash entries are not
+    what is in HBM here): 8 B per lookup (one outcome-table entry answers the 16-mer lookup and the first 4-5 extensions), 32 B per
+    backward extension (two 16-byte Occ blocks), 4 / 8 B per suffix-array read (64-bit SA on texts >= 2^32), 16 B of packed row per
+    seed start, 16 B per seed record written"""
+    out = {}
+    for kn in ("k_seed_first", "k_seed_second", "k_seed_extra"):
+        c = cnt[kn]
+        out[kn] = (8 + 16 + 16) * c["n_hash"] + 32 * c["n_ext"] + (8 if wide else 4) * c["n_sa"]
+    return out
 
 
 def gather_roofline(kernel, cnt, kern_ms):
@@ -506,7 +543,7 @@ def file_to_file_rate(args, cfg, fa, L):
     # the cpu_baseline sample twice over: a run of a few tenths of a second is mostly pipeline fill and first-call allocations, while
     # four times over (16 GB of SAM on configs[2]) ran into the box's dirty-page throttling in some runs (20.7 M reads/s in one, 7.6 in
     # the next; the /dev/null run beside it 53-59 in both)
-    REP = 2
+    REP = 4
     big = [f[:-3] + "_x%d.fq" % REP for f in files]
     for src, dst in zip(files, big):
         with open(dst, "wb") as o:
@@ -520,7 +557,7 @@ def file_to_file_rate(args, cfg, fa, L):
     inp = [big[files.index(x)] if x in files else x for x in inp]
     n = os.path.getsize(big[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     out = {}
-    parts = 4
+    parts = 8
     for label, dst, extra in (("file", os.path.join(args.workdir, "f2f.sam"), []),
                               ("file_%d_parts" % parts, os.path.join(args.workdir, "f2f.sam"), ["--out-parts", str(parts)]),
                               ("null_sink", "/dev/null", [])):
@@ -617,7 +654,10 @@ def main():
         mapping = {kn: v for kn, v in kern_ms.items() if kn.startswith("k_")}
         dom = max(mapping, key=mapping.get) if mapping else "k_seed_first"
         s8d, own = algorithmic_bytes(cnt, nr, L, k, pe)
-        tag = "r02_c%d" % args.config
+        nat = native_bytes(cnt, 2 * cfg["genome"] + 1 >= (1 << 32))
+        tag = "r03_c%d" % args.config
+        if not os.path.exists(os.path.join(ROOT, "profiles", tag + "_pmc_fetch_write.csv")):
+            tag = "r02_c%d" % args.config
         def rl(model):
             b = model.get(dom, 0)
             a = b / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0
@@ -645,6 +685,12 @@ def main():
                          "model": "SURVEY 8(d) terms: 10 B/16-mer lookup, 80 B/extension, 4 B/SA read, window bytes, read characters consumed, 32 B/record",
                          # the builder's own model (adds the seed / carry records this design writes) next to it
                          "builder_model": {"algorithmic_bytes_per_launch": int(bo), "achieved": round(ao, 3), "frac": round(ao / HBM_PEAK_GBS, 6)},
+                         # ... and what THIS layout has to move for the same events (16-byte Occ blocks, 8-byte outcome-table entries)
+                         "design_native_model": ({"algorithmic_bytes_per_launch": int(nat[dom]), "achieved": round(nat[dom] / (kern_ms[dom] * 1e-3) / 1e9, 3),
+                                                  "frac": round(nat[dom] / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                                  "model": "8 B/lookup (outcome-table entry) + 16 B packed row + 16 B seed record per seed start, 32 B/extension, 4|8 B/SA read"}
+                                                 if dom in nat and kern_ms.get(dom, 0) > 0 else None),
+                         "traffic_rule": fetch_rule(dom)[0], "traffic_profile": tag,
                          "traffic_over_algorithmic": round(traffic / b8, 3) if traffic and b8 else None,
                          # the same kernel against the bound that applies to an index walk: divergent gather requests/s
                          "gather": gather_roofline(dom, cnt, kern_ms),
@@ -652,6 +698,11 @@ def main():
                                       "frac": round(traffic / (kern_ms[dom] * 1e-3) / 1e9 / SECTOR_CEILING_GBS, 4)} if traffic else None)},
             "kernels_ms_per_launch": {a: round(b, 4) for a, b in kern_ms.items()},
             "kernels_algorithmic_GBps": {kn: round(s8d[kn] / (kern_ms[kn] * 1e-3) / 1e9, 2) for kn in s8d if kern_ms.get(kn, 0) > 0},
+            # PMC traffic per launch of every mapping kernel (committed profile of this command), FETCH_SIZE corrected by the rule named,
+            # next to the kernel's 8(d) algorithmic bytes
+            "kernels_traffic": {kn: {"fetch_plus_write_bytes": int(t[0] + t[1]), "rule": t[2],
+                                     "over_algorithmic": (round((t[0] + t[1]) / s8d[kn], 2) if s8d.get(kn) else None)}
+                                for kn, t in sorted(pmc_table(tag).items()) if kn.startswith("k_")},
             "counters_last_launch": cnt,
             "mapstats": {"reads_or_pairs": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                          "unmapped": int(stats[0] - stats[1] - stats[2]), "mapped_bases": int(stats[3]), "error_bases": int(stats[4])},

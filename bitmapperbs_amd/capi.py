@@ -22,7 +22,7 @@ SYMBOLS = [
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
-    "bmbs_max_cigar_ops", "bmbs_retries", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset",
+    "bmbs_max_cigar_ops", "bmbs_host_prefault", "bmbs_reserve", "bmbs_host_alloc_kind", "bmbs_retries", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset",
 ]
 
 
@@ -145,6 +145,12 @@ def lib() -> C.CDLL:
     L.bmbs_map_pe_text.restype = C.c_int
     L.bmbs_retries.argtypes = [vp]
     L.bmbs_retries.restype = i64
+    L.bmbs_host_prefault.argtypes = [vp, vp, u64, i32]
+    L.bmbs_host_prefault.restype = C.c_int
+    L.bmbs_reserve.argtypes = [vp, u64]
+    L.bmbs_reserve.restype = C.c_int
+    L.bmbs_host_alloc_kind.argtypes = [u64, i32]
+    L.bmbs_host_alloc_kind.restype = vp
     L.bmbs_host_alloc.argtypes = [u64]
     L.bmbs_host_alloc.restype = vp
     L.bmbs_host_free.argtypes = [vp]

@@ -10,7 +10,10 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,7 +21,33 @@ namespace {
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
+    bool arena = false;                 // carved out of the lane's arena: never freed on its own
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Work buffers of a lane come out of a few large slabs: hipMalloc / hipFree wait for the whole device, and a lane's first call
+// used to make ~70 of them -- with three contexts on one GPU every such call stalled the other two (bmbs_search, first batches:
+// 50-140 ms instead of 2).  Buffers only ever grow; a grown buffer leaves its old region behind until the lane is destroyed.
+struct Arena {
+    struct Slab { char* p; size_t cap, used; };
+    std::vector<Slab> slabs;
+    size_t total = 0;
+    void* alloc(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (size_t i = slabs.size(); i-- > 0;)
+            if (slabs[i].used + bytes <= slabs[i].cap) { void* r = slabs[i].p + slabs[i].used; slabs[i].used += bytes; return r; }
+        size_t cap = std::max<size_t>(bytes, std::max<size_t>((size_t)1 << 30, total / 2));
+        void* p = nullptr;
+        if (hipMalloc(&p, cap) != hipSuccess) {
+            cap = bytes;
+            if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+        }
+        slabs.push_back({(char*)p, cap, bytes});
+        total += cap;
+        return p;
+    }
+    void free_all() { for (auto& s : slabs) (void)hipFree(s.p); slabs.clear(); total = 0; }
 };
 
 struct Prof { const char* name; hipEvent_t a, b; bool used; };
@@ -35,6 +64,9 @@ struct Knobs {
     int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
+    bool copy_streams = true;   // BMBS_COPY_STREAMS=0: the text calls' copies go on the lane's kernel stream
+    bool copy_lock = true;      // BMBS_COPY_LOCK=0: the text calls of different contexts copy at the same time
+    bool arena = true;          // BMBS_ARENA=0: every work buffer a hipMalloc of its own (round 2)
     double cap_scale = 1.0;     // BMBS_CAP_SCALE: scales the learned capacities (tests: a small value forces the repeat-with-exact-sizes path)
     void read()
     {
@@ -56,6 +88,9 @@ struct Knobs {
         if ((e = getenv("BMBS_SPLIT_MIN"))) split_min = atol(e);
         if (split_min < 1) split_min = 1;
         if ((e = getenv("BMBS_CAP_SCALE"))) cap_scale = atof(e);
+        arena = !is(getenv("BMBS_ARENA"), "0");
+        copy_lock = !is(getenv("BMBS_COPY_LOCK"), "0");
+        copy_streams = !is(getenv("BMBS_COPY_STREAMS"), "0");
     }
 };
 
@@ -80,9 +115,14 @@ struct Pending {
 struct Lane {
     int dev = 0;
     hipStream_t stream = nullptr;
+    // copies to and from host buffers go on streams that never carry a kernel: a hipMemcpyAsync on a stream that also runs kernels
+    // moved 26-30 GB/s on the MI355X boxes (ROCm 7.2), on a stream of its own 56 (tools/e2e_trace.sh)
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    hipEvent_t ev_up = nullptr, ev_k = nullptr;
     bmbs_params prm;
     ScoreParams sp;
     Knobs kn;
+    Arena arena;
     std::string err;
     bool attached = false;
     DevIndex ix;
@@ -161,18 +201,28 @@ namespace {
         }                                                                                                 \
     } while (0)
 
-int ensure(Lane* c, DevBuf& b, size_t bytes)
+// zero: the buffer is cleared when it is (re)allocated (packed rows: the mask words behind a row's last piece are never written)
+int ensure(Lane* c, DevBuf& b, size_t bytes, bool zero = false)
 {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return BMBS_OK;
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); b.p = nullptr; return BMBS_ENOMEM; }
-    b.cap = want;
+    if (c->kn.arena && want <= ((size_t)1 << 31)) {
+        void* p = c->arena.alloc(want);
+        if (!p) { c->err = "out of device memory (lane arena)"; return BMBS_ENOMEM; }
+        if (b.p && !b.arena) (void)hipFree(b.p);
+        b.p = p; b.cap = want; b.arena = true;
+    } else {
+        if (b.p && !b.arena) (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0; b.arena = false;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); b.p = nullptr; return BMBS_ENOMEM; }
+        b.cap = want;
+    }
+    if (zero && hipMemsetAsync(b.p, 0, want, c->stream) != hipSuccess) { c->err = "hipMemsetAsync failed"; return BMBS_ESTATE; }
     return BMBS_OK;
 }
-void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+void release(DevBuf& b) { if (b.p && !b.arena) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; b.arena = false; }
 
 #define ENS(c, buf, bytes) do { int rc_ = ensure((c), (buf), (bytes)); if (rc_) return rc_; } while (0)
 
@@ -534,7 +584,7 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
     if (packed_rows) {
         const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
         if (!prepacked) {
-            ENS(c, c->prow, n * (u64)pwords * 8 + 64); ENS(c, c->prow_dirty, n + 64);
+            { int rz_ = ensure(c, c->prow, n * (u64)pwords * 8 + 64, true); if (rz_) return rz_; } ENS(c, c->prow_dirty, n + 64);
             HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n + 64, c->stream));
             prof_begin(c, "k_pack_rows");
             hipLaunchKernelGGL(k_pack_rows, dim3(nblk(n * (u64)(stride / 16), 256)), dim3(256), 0, c->stream, d_seq, gm, stride, (long)n,
@@ -696,16 +746,17 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
 }
 
 // host rows (stride bytes apart) -> device rows padded to a multiple of 16 bytes
-int upload_rows(Lane* c, DevBuf& dst, const char* src, int L, int stride, u64 n, int* dstride)
+int upload_rows(Lane* c, DevBuf& dst, const char* src, int L, int stride, u64 n, int* dstride, hipStream_t st = nullptr)
 {
+    if (!st) st = c->stream;
     const int ds = (L + 15) / 16 * 16;
     *dstride = ds;
     ENS(c, dst, n * (u64)ds + 64);
     // rows that are already `ds` bytes apart go over as ONE block (the bytes past L are ignored by every kernel); a 2-D copy of
     // 150-byte rows out of a 160-byte pitch ran at half the link rate
-    if (n && stride == ds) { HIPCHK(c, hipMemcpyAsync(dst.p, src, n * (u64)ds, hipMemcpyHostToDevice, c->stream)); return BMBS_OK; }
-    HIPCHK(c, hipMemsetAsync(dst.p, 0, n * (u64)ds + 64, c->stream));
-    if (n) HIPCHK(c, hipMemcpy2DAsync(dst.p, ds, src, stride, L, n, hipMemcpyHostToDevice, c->stream));
+    if (n && stride == ds) { HIPCHK(c, hipMemcpyAsync(dst.p, src, n * (u64)ds, hipMemcpyHostToDevice, st)); return BMBS_OK; }
+    HIPCHK(c, hipMemsetAsync(dst.p, 0, n * (u64)ds + 64, st));
+    if (n) HIPCHK(c, hipMemcpy2DAsync(dst.p, ds, src, stride, L, n, hipMemcpyHostToDevice, st));
     return BMBS_OK;
 }
 
@@ -730,6 +781,10 @@ Lane* lane_create(int device_id, const bmbs_params& prm, const Knobs& kn, bool f
     c->sp.gap_open = c->prm.gap_open; c->sp.gap_ext = c->prm.gap_ext; c->sp.q_base = c->prm.q_base;
     c->sp.seed_len = c->prm.seed_len;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
+    (void)hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming);
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
     const size_t shard_bytes = BMBS_SHARDS * BMBS_SHARD_WORDS * 8;
@@ -787,10 +842,15 @@ void lane_destroy(Lane* c)
                      &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx, &c->prow, &c->prow_dirty, &c->pe_mid_flag, &c->pe_mid_list};
     for (DevBuf* b : all) release(*b);
     for (auto& set : c->profset) for (auto& p : set) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    c->arena.free_all();
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->h_info) (void)hipHostFree(c->h_info);
     { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off};
       for (DevBuf* b : tx) release(*b); }
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+    if (c->ev_k) (void)hipEventDestroy(c->ev_k);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1069,11 +1129,12 @@ int map_se_dev(Lane* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int
 }
 
 // host lengths -> device (u16 per read)
-int upload_lens(Lane* c, const uint16_t* len, u64 n, u64 at, u64 total, int L)
+int upload_lens(Lane* c, const uint16_t* len, u64 n, u64 at, u64 total, int L, hipStream_t st = nullptr)
 {
+    if (!st) st = c->stream;
     for (u64 i = 0; i < n; i++) if (len[i] == 0 || len[i] > L) { c->err = "read length 0 or longer than L_max"; return BMBS_EINVAL; }
     ENS(c, c->in_len, total * 2 + 16);           // sized for the whole batch up front: growing would drop the first part
-    HIPCHK(c, hipMemcpyAsync(c->in_len.as<u16>() + at, len, n * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_len.as<u16>() + at, len, n * 2, hipMemcpyHostToDevice, st));
     return BMBS_OK;
 }
 
@@ -1121,7 +1182,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
         u64* prow = nullptr; u32* pdirty = nullptr;
         const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
         if (use_packed_rows(c)) {
-            ENS(c, c->prow, n2 * (u64)pwords * 8 + 64); ENS(c, c->prow_dirty, n2 + 64);
+            { int rz_ = ensure(c, c->prow, n2 * (u64)pwords * 8 + 64, true); if (rz_) return rz_; } ENS(c, c->prow_dirty, n2 + 64);
             HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n2 + 64, c->stream));
             prow = c->prow.as<u64>(); pdirty = c->prow_dirty.as<u32>(); prepacked = true;
         }
@@ -1497,16 +1558,18 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
         const u64 retries0 = c->n_retries;
         int rc = lane_settle(c);
         if (rc) return rc;
+        const bool cs = c->kn.copy_streams && c->up_stream && c->down_stream && c->ev_up && c->ev_k;
+        hipStream_t dsn = cs ? c->down_stream : c->stream;
         if (c->n_retries != retries0)               // the chunk was issued again with exact sizes: the records copied behind the first attempt are stale
-            HIPCHK(c, hipMemcpyAsync(results + o.off * rpu, c->out_res.p, (u64)o.m * rpu * 32, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(results + o.off * rpu, c->out_res.p, (u64)o.m * rpu * 32, hipMemcpyDeviceToHost, dsn));
         const u64 used = c->last_n_jobs * (u64)max_ops;
         const u64 base = ch == n ? 0 : (u64)o.off * rpu * (u64)max_ops;
         if (base + used > (u64)cigar_cap) { c->err = "host cigar pool too small"; return BMBS_ENOMEM; }
         if (used) {
-            HIPCHK(c, hipMemcpyAsync(cigar_pool + base, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(cigar_pool + base, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, dsn));
             extent = std::max<int64_t>(extent, (int64_t)(base + used));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(dsn));
         return BMBS_OK;
     };
     int li = 0, used_lanes = 0, rc = BMBS_OK;
@@ -1524,16 +1587,19 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             ENS(c, c->cig_pool, pool * 4);
             int ds = 0;
             const size_t ro = (size_t)off * (size_t)stride;
-            int r1 = upload_rows(c, c->in_seq, in.seq1 + ro, L, stride, um, &ds); if (r1) return r1;
-            r1 = upload_rows(c, c->in_qual, in.qual1 + ro, L, stride, um, &ds); if (r1) return r1;
+            const bool cs = c->kn.copy_streams && c->up_stream && c->down_stream && c->ev_up && c->ev_k;
+            hipStream_t us = cs ? c->up_stream : c->stream, dsn = cs ? c->down_stream : c->stream;
+            int r1 = upload_rows(c, c->in_seq, in.seq1 + ro, L, stride, um, &ds, us); if (r1) return r1;
+            r1 = upload_rows(c, c->in_qual, in.qual1 + ro, L, stride, um, &ds, us); if (r1) return r1;
             if (pe) {
-                r1 = upload_rows(c, c->in_seq2, in.seq2 + ro, L, stride, um, &ds); if (r1) return r1;
-                r1 = upload_rows(c, c->in_qual2, in.qual2 + ro, L, stride, um, &ds); if (r1) return r1;
+                r1 = upload_rows(c, c->in_seq2, in.seq2 + ro, L, stride, um, &ds, us); if (r1) return r1;
+                r1 = upload_rows(c, c->in_qual2, in.qual2 + ro, L, stride, um, &ds, us); if (r1) return r1;
             }
             if (in.len1) {
-                r1 = upload_lens(c, in.len1 + off, um, 0, um * rpu, L); if (r1) return r1;
-                if (pe) { r1 = upload_lens(c, in.len2 + off, um, um, um * rpu, L); if (r1) return r1; }
+                r1 = upload_lens(c, in.len1 + off, um, 0, um * rpu, L, us); if (r1) return r1;
+                if (pe) { r1 = upload_lens(c, in.len2 + off, um, um, um * rpu, L, us); if (r1) return r1; }
             }
+            if (cs) { HIPCHK(c, hipEventRecord(c->ev_up, us)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_up, 0)); }
             Pending P;
             P.pe = pe; P.L = L; P.stride = ds; P.n = m;
             P.a[0] = (uint64_t)c->in_seq.p; P.a[1] = (uint64_t)c->in_qual.p; P.a[2] = pe ? (uint64_t)c->in_seq2.p : 0; P.a[3] = pe ? (uint64_t)c->in_qual2.p : 0;
@@ -1542,7 +1608,8 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             P.cigar_base = ch == n ? 0u : (u32)((u64)off * rpu * (u64)max_ops);
             r1 = lane_enqueue(c, P, true);
             if (r1) return r1;
-            HIPCHK(c, hipMemcpyAsync(results + off * rpu, c->out_res.p, um * rpu * 32, hipMemcpyDeviceToHost, c->stream));
+            if (cs) { HIPCHK(c, hipEventRecord(c->ev_k, c->stream)); HIPCHK(c, hipStreamWaitEvent(dsn, c->ev_k, 0)); }
+            HIPCHK(c, hipMemcpyAsync(results + off * rpu, c->out_res.p, um * rpu * 32, hipMemcpyDeviceToHost, dsn));
             return BMBS_OK;
         }();
         if (rc) { X->err = c->err; break; }
@@ -1554,7 +1621,7 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
         const int r2 = finish(i);
         if (r2 && !rc) { rc = r2; X->err = X->lanes[(size_t)i]->err; }
     }
-    if (rc) { for (Lane* c : X->lanes) { (void)hipStreamSynchronize(c->stream); c->inflight.clear(); } return rc; }
+    if (rc) { for (Lane* c : X->lanes) { (void)hipStreamSynchronize(c->stream); if (c->down_stream) (void)hipStreamSynchronize(c->down_stream); c->inflight.clear(); } return rc; }
     X->used_lanes = used_lanes ? used_lanes : 1;
     if (n_cigar_used) *n_cigar_used = extent;
     return BMBS_OK;
@@ -1739,18 +1806,15 @@ static int lane_map_pe_fastq(Lane* c, const bmbs_fastq_view* mate1, const bmbs_f
 // ------------------------------------------------------------------------------------------------
 // FASTQ text in, SAM text out (bmbs_text.hip): the host reads and writes files, everything between is on the device
 namespace {
-// newline index of one text window -> per-record fields; the totals slot gets the number of lines found
-int text_index(Lane* c, DevBuf& dtext, const char* text, u64 bytes, u64 n, int f, FqRec& rec)
+// newline index of one text window (already on the device) -> per-record fields; the totals slot gets the number of lines found
+int text_index(Lane* c, DevBuf& dtext, u64 bytes, u64 n, int f, FqRec& rec)
 {
-    ENS(c, dtext, bytes + 64);
-    HIPCHK(c, hipMemcpyAsync(dtext.p, text, bytes, hipMemcpyHostToDevice, c->stream));
     const u64 tiles = (bytes + FQ_TILE_BYTES - 1) / FQ_TILE_BYTES;
     ENS(c, c->tx_tilecnt, tiles * 4 + 64); ENS(c, c->tx_tileoff, (tiles + 1) * 8 + 64);
-    ENS(c, c->tx_nl[f], (4 * n + 8) * 4); ENS(c, c->tx_rec[f], n * 18 + 256);
-    char* b = c->tx_rec[f].as<char>();
+    ENS(c, c->tx_nl[f], (4 * n + 8) * 4);
     const u64 n4 = (n * 4 + 63) & ~63ull, n2 = (n * 2 + 63) & ~63ull;
     ENS(c, c->tx_rec[f], 3 * n4 + 3 * n2 + 64);
-    b = c->tx_rec[f].as<char>();
+    char* b = c->tx_rec[f].as<char>();
     rec.seq_off = reinterpret_cast<u32*>(b); rec.qual_off = reinterpret_cast<u32*>(b + n4); rec.name_off = reinterpret_cast<u32*>(b + 2 * n4);
     rec.seq_len = reinterpret_cast<u16*>(b + 3 * n4); rec.qual_len = reinterpret_cast<u16*>(b + 3 * n4 + n2); rec.name_len = reinterpret_cast<u16*>(b + 3 * n4 + 2 * n2);
     hipLaunchKernelGGL(k_fq_count, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tilecnt.as<u32>());
@@ -1759,11 +1823,15 @@ int text_index(Lane* c, DevBuf& dtext, const char* text, u64 bytes, u64 n, int f
     hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tileoff.as<u64>(), 4 * n, c->tx_nl[f].as<u32>());
     return BMBS_OK;
 }
+// One upload and one download at a time per device, whatever the number of contexts: concurrent copies in one direction share the
+// link badly (tools/pcie_probe: 48 GB/s each way with one stream per direction, 33 with three), and a context's copies are long
+// enough (hundreds of MB) to fill the link on their own.  Held from the first copy of a phase until the wait that ends it.
+std::mutex g_h2d_mu[16], g_d2h_mu[16];
 // D2H in pieces: one 2 GiB device-to-host copy ran at a quarter of the link rate on the MI355X boxes (tools/pcie_probe)
-int d2h_chunked(Lane* c, char* dst, const char* src, u64 bytes)
+int d2h_chunked(Lane* c, char* dst, const char* src, u64 bytes, hipStream_t st)
 {
     const u64 piece = 128ull << 20;
-    for (u64 o = 0; o < bytes; o += piece) HIPCHK(c, hipMemcpyAsync(dst + o, src + o, std::min(piece, bytes - o), hipMemcpyDeviceToHost, c->stream));
+    for (u64 o = 0; o < bytes; o += piece) HIPCHK(c, hipMemcpyAsync(dst + o, src + o, std::min(piece, bytes - o), hipMemcpyDeviceToHost, st));
     return BMBS_OK;
 }
 
@@ -1783,13 +1851,42 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
     const u64 n = (u64)n_records, n2 = pe ? 2 * n : n;
     static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;       // diagnostic: host-side phase times of every text call
     auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
-    double tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_uplock = 0, t_dnlock = 0, t_dnstart = 0;
     tp[0] = wall();
     FqRec rec[2] = {};
     HIPCHK(c, hipMemsetAsync(c->tx_info.p, 0, 64, c->stream));
-    int rc = text_index(c, c->fq_text1, text1, bytes1, n, 0, rec[0]);
+    int rc;
+    ENS(c, c->fq_text1, bytes1 + 64);
+    if (pe) ENS(c, c->fq_text2, bytes2 + 64);
+    {
+        // the link is claimed for the copies alone: the kernels behind them may have to queue behind other contexts' kernels
+        std::unique_lock<std::mutex> up(g_h2d_mu[c->dev & 15], std::defer_lock);
+        if (c->kn.copy_lock) up.lock();
+        t_uplock = wall();
+        // on a stream of their own that never carries a kernel (the lane has nothing in flight here: the previous call ended with a wait)
+        hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
+        HIPCHK(c, hipMemcpyAsync(c->fq_text1.p, text1, bytes1, hipMemcpyHostToDevice, us));
+        if (pe) HIPCHK(c, hipMemcpyAsync(c->fq_text2.p, text2, bytes2, hipMemcpyHostToDevice, us));
+        if (c->kn.copy_lock || us != c->stream) HIPCHK(c, hipStreamSynchronize(us));
+    }
+    if (trace) tp[7] = wall();
+    // diagnostic (tools/e2e_trace.sh): BMBS_TEXT_COPY_ONLY=1 moves the bytes of a batch over the link and runs nothing in between
+    static const bool copy_only = getenv("BMBS_TEXT_COPY_ONLY") != nullptr;
+    if (copy_only) {
+        const u64 total = std::min<u64>(sam_cap, (bytes1 + bytes2) * 115 / 100);
+        ENS(c, c->sam_out, total + 64);
+        std::unique_lock<std::mutex> down(g_d2h_mu[c->dev & 15], std::defer_lock);
+        if (c->kn.copy_lock) down.lock();
+        rc = d2h_chunked(c, sam, c->sam_out.as<char>(), total, c->stream);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (sam_bytes) *sam_bytes = 0;
+        if (trace) fprintf(stderr, "[text] copy only: upload %.2f (wait %.2f) download %.2f ms\n", (tp[7] - tp[0]) * 1e3, (t_uplock - tp[0]) * 1e3, (wall() - tp[7]) * 1e3);
+        return BMBS_OK;
+    }
+    rc = text_index(c, c->fq_text1, bytes1, n, 0, rec[0]);
     if (rc) return rc;
-    if (pe) { rc = text_index(c, c->fq_text2, text2, bytes2, n, 1, rec[1]); if (rc) return rc; }
+    if (pe) { rc = text_index(c, c->fq_text2, bytes2, n, 1, rec[1]); if (rc) return rc; }
     // records can only be cut out once the host knows that every one of them is complete: the line counts first
     HIPCHK(c, hipMemcpyAsync(c->h_info + 16, c->totals.as<u64>() + 16, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1871,13 +1968,21 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
     hipLaunchKernelGGL(k_sam_write, dim3(nblk(n2, (unsigned)lpw)), dim3(64), (size_t)lpw * hb, c->stream, in, (long)n2, c->sam_off.as<u64>(), lpw, hb, c->sam_out.as<char>());
     prof_end(c);
     if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); tp[5] = wall(); }
-    rc = d2h_chunked(c, sam, c->sam_out.as<char>(), total);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
+        if (c->kn.copy_lock || ds != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));       // the text is complete before the link is claimed
+        std::unique_lock<std::mutex> down(g_d2h_mu[c->dev & 15], std::defer_lock);
+        t_dnstart = wall();
+        if (c->kn.copy_lock) down.lock();
+        t_dnlock = wall();
+        rc = d2h_chunked(c, sam, c->sam_out.as<char>(), total, ds);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(ds));
+    }
     tp[6] = wall();
     if (trace)
-        fprintf(stderr, "[text] n=%ld in=%.1fMB out=%.1fMB  upload+lines %.2f  records %.2f  rows+map %.2f  len+scan %.2f  write %.2f  download %.2f  total %.2f ms\n",
-                (long)n2, (double)(bytes1 + bytes2) / 1e6, (double)total / 1e6, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3,
+        fprintf(stderr, "[text] n=%ld in=%.1fMB out=%.1fMB  (waits for the link: up %.2f, down %.2f)  upload %.2f lines %.2f  records %.2f  rows+map %.2f  len+scan %.2f  write %.2f  download %.2f  total %.2f ms\n",
+                (long)n2, (double)(bytes1 + bytes2) / 1e6, (double)total / 1e6, (t_uplock - tp[0]) * 1e3, (t_dnlock - t_dnstart) * 1e3, (tp[7] - tp[0]) * 1e3, (tp[1] - tp[7]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3,
                 (tp[4] - tp[3]) * 1e3, (tp[5] - tp[4]) * 1e3, (tp[6] - tp[5]) * 1e3, (tp[6] - tp[0]) * 1e3);
     return BMBS_OK;
 }
@@ -2185,6 +2290,50 @@ extern "C" int bmbs_counters_all(bmbs_ctx* X, uint64_t out[32])
     return BMBS_OK;
 }
 
+// room for the work buffers of later calls, taken now (a lane's buffers are carved out of large slabs; the first slab costs a
+// device-wide hipMalloc): a driver calls this while it loads, so that its first batches do not pay for it
+extern "C" int bmbs_reserve(bmbs_ctx* X, uint64_t bytes_per_lane)
+{
+    if (!X) return BMBS_EINVAL;
+    for (Lane* c : X->lanes) {
+        if (!c->kn.arena) continue;
+        HIPCHK(c, hipSetDevice(c->dev));
+        size_t have = 0;
+        for (const auto& sl : c->arena.slabs) have += sl.cap - sl.used;
+        if (have >= bytes_per_lane) continue;
+        const size_t cap = (size_t)bytes_per_lane;
+        void* p = nullptr;
+        if (hipMalloc(&p, cap) != hipSuccess) { X->err = "bmbs_reserve: out of device memory"; return BMBS_ENOMEM; }
+        c->arena.slabs.push_back({(char*)p, cap, 0});
+        c->arena.total += cap;
+    }
+    return BMBS_OK;
+}
+
+// first use of a page-locked buffer by the device is slow (the first 361 MB download into a fresh buffer took 44 ms instead of 7 on
+// the MI355X boxes): a driver lets every staging buffer be touched once in each direction while it loads
+extern "C" int bmbs_host_prefault(bmbs_ctx* X, void* p, uint64_t bytes, int32_t kind)
+{
+    Lane* c = lane0(X);
+    if (!c || !p) return BMBS_EINVAL;
+    HIPCHK(c, hipSetDevice(c->dev));
+    const u64 piece = 64ull << 20;
+    DevBuf tmp;
+    void* d = nullptr;
+    if (hipMalloc(&d, piece) != hipSuccess) return BMBS_ENOMEM;
+    hipStream_t st = c->down_stream ? c->down_stream : c->stream;
+    hipError_t e = hipSuccess;
+    for (u64 o = 0; o < bytes && e == hipSuccess; o += piece) {
+        const u64 m = std::min(piece, bytes - o);
+        if (kind != 2) e = hipMemcpyAsync(d, (char*)p + o, m, hipMemcpyHostToDevice, st);
+        if (kind != 1 && e == hipSuccess) e = hipMemcpyAsync((char*)p + o, d, m, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    (void)tmp;
+    return e == hipSuccess ? BMBS_OK : BMBS_ESTATE;
+}
+
 // diagnostic: calls that were issued again with exact sizes because a stage count did not fit the capacity learned so far
 extern "C" int64_t bmbs_retries(bmbs_ctx* X)
 {
@@ -2237,10 +2386,49 @@ extern "C" int bmbs_map_pe_fastq(bmbs_ctx* X, const bmbs_fastq_view* mate1, cons
 #endif
 extern "C" const char* bmbs_build_id(void) { return BMBS_BUILD_ID; }
 
-extern "C" void* bmbs_host_alloc(uint64_t bytes)
+// BMBS_HOST_INTERLEAVE=1: the pages of page-locked buffers are spread over all NUMA nodes of the host (set_mempolicy around the
+// allocation): a file-to-file run moves ~1.3 KB per read through host memory, and one node of a 4-nodes-per-socket host has a
+// quarter of the socket's bandwidth
+static long set_policy_interleave(bool on)
 {
+#ifdef SYS_set_mempolicy
+    unsigned long mask[16];
+    memset(mask, 0, sizeof mask);
+    int nodes = 0;
+    if (FILE* f = fopen("/sys/devices/system/node/online", "r")) {
+        int a = 0, b = 0;
+        const int k = fscanf(f, "%d-%d", &a, &b);
+        fclose(f);
+        nodes = k == 2 ? b + 1 : 1;
+    }
+    if (nodes < 2) return -1;
+    for (int i = 0; i < nodes && i < 1024; i++) mask[i / (8 * sizeof(long))] |= 1ul << (i % (8 * sizeof(long)));
+    return syscall(SYS_set_mempolicy, on ? 3 /* MPOL_INTERLEAVE */ : 0 /* MPOL_DEFAULT */, on ? mask : nullptr, on ? (unsigned long)(nodes + 1) : 0ul);
+#else
+    (void)on; return -1;
+#endif
+}
+static void* host_alloc_flags(uint64_t bytes, unsigned extra);
+extern "C" void* bmbs_host_alloc(uint64_t bytes) { return host_alloc_flags(bytes, 0); }
+// kind 1: written by the host, read by the device (FASTQ windows); kind 2: written by the device, read by the host (SAM text).
+// The HIP flags of either kind can be set from the environment for experiments (BMBS_PIN_IN_FLAGS / BMBS_PIN_OUT_FLAGS, numeric:
+// 0x40000000 hipHostMallocNonCoherent, 0x4 hipHostMallocWriteCombined)
+extern "C" void* bmbs_host_alloc_kind(uint64_t bytes, int32_t kind)
+{
+    static const unsigned in_flags = [] { const char* e = getenv("BMBS_PIN_IN_FLAGS"); return e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();
+    static const unsigned out_flags = [] { const char* e = getenv("BMBS_PIN_OUT_FLAGS"); return e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();
+    return host_alloc_flags(bytes, kind == 1 ? in_flags : kind == 2 ? out_flags : 0u);
+}
+static void* host_alloc_flags(uint64_t bytes, unsigned extra)
+{
+    static const bool interleave = [] { const char* e = getenv("BMBS_HOST_INTERLEAVE"); return e && !strcmp(e, "1"); }();
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) return nullptr;      // portable: contexts on several devices copy from it
+    unsigned flags = hipHostMallocPortable | extra;                           // portable: contexts on several devices copy from it
+    bool pol = false;
+    if (interleave && set_policy_interleave(true) == 0) { pol = true; flags |= hipHostMallocNumaUser; }
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, flags);
+    if (pol) (void)set_policy_interleave(false);
+    if (e != hipSuccess) return nullptr;
     return p;
 }
 extern "C" void bmbs_host_free(void* p) { if (p) (void)hipHostFree(p); }

@@ -9,7 +9,7 @@
 //   output variants (Process_CommandLines.cpp:93-105): --pbat, --unmapped_out, --ambiguous_out, --bam (BGZF-compressed BAM)
 //   extra: --device N | --devices a,b,... (one index copy per listed device, batches dealt to whichever context is free, output
 //          order kept), --contexts S (contexts per device sharing its index: S batches in flight per GPU so that the copies of
-//          one overlap the kernels of another; default 3), --batch N (records per GPU batch, default 500 k), -t N (host I/O
+//          one overlap the kernels of another; default 4), --batch N (records per GPU batch, default 500 k), -t N (host I/O
 //          threads), --out-parts N (the input is cut into N contiguous record ranges, each written to its own file
 //          <out>.part000 ... concurrently; `cat` of the parts in order == the one-file output), --verbose
 //
@@ -162,14 +162,14 @@ inline size_t after_kth_nl(const char* p, size_t n, size_t k)
     return k ? n : (size_t)(q - p);
 }
 
-struct Pinned {                                  // page-locked staging (bmbs_host_alloc)
-    char* p = nullptr; size_t cap = 0;
+struct Pinned {                                  // page-locked staging (bmbs_host_alloc_kind)
+    char* p = nullptr; size_t cap = 0; int kind = 0;
     bool need(size_t bytes)
     {
         if (bytes <= cap) return true;
         if (p) bmbs_host_free(p);
         cap = bytes + bytes / 4 + 4096;
-        p = (char*)bmbs_host_alloc(cap);
+        p = (char*)bmbs_host_alloc_kind(cap, kind);
         if (!p) { cap = 0; return false; }
         return true;
     }
@@ -604,7 +604,7 @@ int main(int argc, char** argv)
 {
     bmbs_params P; bmbs_default_params(&P);
     std::string index, seq, seq1, seq2, out = "output", mapstats, build_fasta, index_folder;
-    int device = 0, io_threads = 0, contexts = 3, parts = 1;
+    int device = 0, io_threads = 0, contexts = 4, parts = 1, reader_threads = 0;
     std::vector<int> devices;
     long batch = 500000;
     bool verbose = false, unmapped_out = false, pbat = false, bam = false;
@@ -643,6 +643,7 @@ int main(int argc, char** argv)
         else if (a == "--contexts") contexts = atoi(val());
         else if (a == "--batch") batch = atol(val());
         else if (a == "--out-parts") parts = atoi(val());
+        else if (a == "--reader-threads") reader_threads = atoi(val());     // pread threads per part (default: -t / (2 x parts))
         else if (a == "--verbose") verbose = true;
         else if (a == "--unmapped_out") unmapped_out = true;          // Process_CommandLines.cpp:104-105
         else if (a == "--ambiguous_out") P.ambiguous_out = 1;
@@ -692,6 +693,7 @@ int main(int argc, char** argv)
     const int n_ctx = (int)devices.size() * contexts;
     const int n_batches = live_parts + n_ctx + 2;
     std::vector<Batch> batches((size_t)n_batches);
+    for (auto& b : batches) { b.text1.kind = 1; b.text2.kind = 1; b.sam.kind = 2; }
     // bytes per record of the input, from its first records (plain text): sizes the page-locked windows, which cost ~0.2 ms per MB
     // to pin and are therefore allocated once, by several threads, while the index loads
     size_t est0 = 400;
@@ -758,6 +760,8 @@ int main(int argc, char** argv)
         for (const auto& s : chrom_names) nm.push_back(s.c_str());
         for (bmbs_ctx* c : ctxs) if (bmbs_sam_refs(c, nm.data(), (int32_t)nm.size())) { fprintf(stderr, "%s\n", bmbs_last_error(c)); return 1; }
     }
+    // device memory for the work buffers of a batch, taken while the index loads instead of inside the first calls
+    for (bmbs_ctx* c : ctxs) (void)bmbs_reserve(c, (uint64_t)batch * (pe ? 2 : 1) * (2200 + 6 * (uint64_t)std::max<size_t>(est0 / 2, 100)));
     // ---- the parts: record ranges of the input, one output file each
     std::vector<std::unique_ptr<Part>> P_(static_cast<size_t>(parts));
     for (int p = 0; p < parts; p++) { P_[(size_t)p].reset(new Part()); P_[(size_t)p]->id = p; }
@@ -783,7 +787,6 @@ int main(int argc, char** argv)
             }
         }
     }
-    const double t_loaded = now();
     BamNames bam_refs; bam_refs.names = chrom_names;
     for (int p = 0; p < parts; p++) {
         Part& pt = *P_[(size_t)p];
@@ -816,15 +819,30 @@ int main(int argc, char** argv)
         }
     }
     prealloc.join();
+    // the device touches every staging buffer once now (BMBS_NO_PREFAULT=1 skips it)
+    if (!getenv("BMBS_NO_PREFAULT")) {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < batches.size(); i++)
+            th.emplace_back([&, i] {
+                Batch& b = batches[i];
+                bmbs_ctx* c = ctxs[i % ctxs.size()];
+                if (b.text1.p) (void)bmbs_host_prefault(c, b.text1.p, b.text1.cap, 1);
+                if (b.text2.p) (void)bmbs_host_prefault(c, b.text2.p, b.text2.cap, 1);
+                if (b.sam.p) (void)bmbs_host_prefault(c, b.sam.p, b.sam.cap, 2);
+            });
+        for (auto& t : th) t.join();
+    }
     const int32_t flags = (pbat && !pe ? BMBS_TEXT_PBAT : 0) | (unmapped_out ? BMBS_TEXT_UNMAPPED : 0);
+    const double t_loaded = now();
 
     Chan<Batch*> free_q, gpu_q;
     for (auto& b : batches) free_q.put(&b);
     std::atomic<bool> failed(false);
     std::mutex err_mu;
     auto fail = [&](const std::string& why) { std::lock_guard<std::mutex> l(err_mu); if (!failed.exchange(true)) fprintf(stderr, "bmbs_search: %s\n", why.c_str()); };
-    const int r_threads = std::max(1, io_threads / (2 * live_parts));
-    const int w_threads = std::max(1, (io_threads - r_threads * live_parts) / live_parts);
+    // SAM: the writers only pwrite, every I/O thread reads; --bam: half of them convert and compress
+    const int r_threads = reader_threads > 0 ? reader_threads : std::max(1, io_threads / ((bam ? 2 : 1) * live_parts));
+    const int w_threads = std::max(1, io_threads / (2 * live_parts));
 
     // ---------------- stage R (one per part): text window + newline count -> how many whole records ----------------------------
     auto reader_fn = [&](Part* pt) {

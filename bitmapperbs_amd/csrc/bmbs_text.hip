@@ -274,75 +274,91 @@ k_sam_len(SamIn in, long n_lines, u32* __restrict__ len_out)
     len_out[line] = len;
 }
 
-// One wave per `lpw` consecutive output lines.  Phase A: lane i renders the numeric columns of line i into LDS (every lane busy).
-// Phase B: the wave walks its lines; for each one the 64 lanes produce the line's bytes four at a time into destination-aligned
-// dwords (QNAME, SEQ and QUAL come from the FASTQ text that is still resident, upper-cased / complemented / reversed / padded on
-// the way; the columns in between from LDS); the ragged first and last dword of a line are written byte-wise, because its
-// neighbours -- possibly on another wave -- own the other bytes.
+// One wave per `lpw` consecutive output lines, i.e. per contiguous piece of the output.
+// Phase A: lane i describes line i -- where its QNAME / SEQ / QUAL sit in the FASTQ text, strand, lengths -- and renders its
+// numeric columns into LDS (every lane busy with a line of its own).
+// Phase B: every group of 16 lanes takes a line at a time and produces its bytes four at a time into destination-aligned dwords:
+// QNAME, SEQ and QUAL bytes come from the FASTQ text that is still resident (upper-cased / complemented / reversed / padded on
+// the way), the columns in between from LDS; the ragged first and last dword of a line are written byte-wise, because the
+// neighbouring lines -- possibly on another wave -- own the other bytes.
+struct SamDesc {                 // per line, in LDS
+    const char* name; const char* seq; const char* qual;
+    u32 start;                   // offset of the line inside the piece
+    u32 total;                   // bytes (0: the line is not printed)
+    u16 nlen, hl, tl, L, qn, rc;
+};
 __global__ void __launch_bounds__(64)
 k_sam_write(SamIn in, long n_lines, const u64* __restrict__ off, int lpw, int hb, char* __restrict__ out)
 {
     extern __shared__ char lds_sam[];                  // [lpw][hb]: head, then tail
-    __shared__ int s_hl[64], s_tl[64];
+    __shared__ SamDesc s_d[64];
+    __shared__ u32 s_start[65];
     const long line0 = (long)blockIdx.x * lpw;
     const int lane = threadIdx.x;
-    SamLine mine; mine.kind = 0; mine.mate = 0; mine.rec = 0; mine.name_skip = 0; mine.name_len = 0; mine.rc = false; mine.x = nullptr; mine.mate_x = nullptr;
-    if (lane < lpw && line0 + lane < n_lines) {
-        mine = sam_line(in, line0 + lane);
-        if (mine.kind) {
+    const int nl = (int)((n_lines - line0) < (long)lpw ? (n_lines - line0) : (long)lpw);      // lines of this wave
+    const u64 o0 = off[line0];
+    if (lane < nl) {
+        const long line = line0 + lane;
+        const SamLine sl = sam_line(in, line);
+        SamDesc d;
+        d.name = d.seq = d.qual = nullptr; d.start = (u32)(off[line] - o0); d.total = 0; d.nlen = d.hl = d.tl = d.L = d.qn = d.rc = 0;
+        if (sl.kind) {
             char* h = lds_sam + (size_t)lane * hb;
-            const int hl = sam_head(in, mine, h);
-            s_hl[lane] = hl; s_tl[lane] = sam_tail(mine, h + hl);
+            const int hl = sam_head(in, sl, h);
+            const int tl = sam_tail(sl, h + hl);
+            const FqRec& R = in.rec[sl.mate];
+            const char* text = in.text[sl.mate];
+            // the pair's QNAME comes from mate 1's name line whichever mate is printed
+            d.name = ((in.flags & BMBS_TEXT_PE) ? in.text[0] + in.rec[0].name_off[sl.rec] : text + R.name_off[sl.rec]) + sl.name_skip;
+            d.seq = text + R.seq_off[sl.rec]; d.qual = text + R.qual_off[sl.rec];
+            d.nlen = (u16)sl.name_len; d.hl = (u16)hl; d.tl = (u16)tl; d.L = R.seq_len[sl.rec]; d.qn = R.qual_len[sl.rec]; d.rc = sl.rc ? 1 : 0;
+            d.total = (u32)(sl.name_len + hl + 2 * (int)d.L + 1 + tl);
         }
+        s_d[lane] = d;
+        s_start[lane] = d.start;
     }
+    if (lane == 0) s_start[nl] = (u32)(off[line0 + nl] - o0);
     __syncthreads();
-    for (int j = 0; j < lpw; j++) {
-        const long line = line0 + j;
-        if (line >= n_lines) break;
-        // line j's description, from lane j to everybody
-        const int kind = __shfl(mine.kind, j, 64);
-        if (!kind) continue;
-        const int mate = __shfl(mine.mate, j, 64);
-        const long rec = ((long)__shfl((int)(mine.rec >> 32), j, 64) << 32) | (u32)__shfl((int)mine.rec, j, 64);
-        const int nskip = __shfl(mine.name_skip, j, 64), nlen = __shfl(mine.name_len, j, 64);
-        const bool rc = __shfl((int)mine.rc, j, 64) != 0;
-        const int hl = s_hl[j], tl = s_tl[j];
-        const char* text = in.text[mate];
-        const FqRec& R = in.rec[mate];
-        const char* nm = text + R.name_off[rec] + nskip;
-        // the pair's QNAME comes from mate 1's name line whichever mate is printed
-        const char* nm_p = (in.flags & BMBS_TEXT_PE) ? in.text[0] + in.rec[0].name_off[rec] + nskip : nm;
-        const char* sq = text + R.seq_off[rec];
-        const char* ql = text + R.qual_off[rec];
-        const int L = R.seq_len[rec], qn = R.qual_len[rec];
+    if (!s_start[nl]) return;
+    // Phase B: four lines at a time, 16 lanes each (the loads of four lines are in flight together; with all 64 lanes on one
+    // line the kernel waited out one load latency per line: 2.7 ms per 2 M lines; with one binary search per dword over the
+    // piece's line offsets instead, 3.7 ms)
+    const int grp = lane >> 4, gl = lane & 15;
+    for (int j = grp; j < nl; j += 4) {
+        const SamDesc d = s_d[j];
+        if (!d.total) continue;
         const char* hd = lds_sam + (size_t)j * hb;
-        const u64 o = off[line];
-        const int total = nlen + hl + 2 * L + 1 + tl;
-        const int b1 = nlen, b2 = b1 + hl, b3 = b2 + L, b4 = b3 + 1, b5 = b4 + L;
+        const int L = d.L, qn = d.qn;
+        const bool rc = d.rc != 0;
+        const int b1 = d.nlen, b2 = b1 + d.hl, b3 = b2 + L, b4 = b3 + 1, b5 = b4 + L;
+        const int total = (int)d.total;
+        const u64 o = o0 + d.start;
+        const u64 d0 = o & ~3ull;                      // first destination dword that holds a byte of this line
+        const int lead = (int)(o - d0);
+        const int ndw = (lead + total + 3) >> 2;
         auto byte_at = [&](int t) -> u32 {
-            if (t < b1) return (unsigned char)nm_p[t];
+            if (t < b1) return (unsigned char)d.name[t];
             if (t < b2) return (unsigned char)hd[t - b1];
             if (t < b3) {
                 const int i = t - b2;
-                unsigned char c = (unsigned char)sq[rc ? L - 1 - i : i];
+                unsigned char c = (unsigned char)d.seq[rc ? L - 1 - i : i];
                 if (c >= 'a' && c <= 'z') c -= 32;                                                                     // toupper, Process_Reads.cpp:836
                 if (rc) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;                    // rc_table, Process_Reads.cpp:1603
                 return c;
             }
             if (t < b4) return (u32)'\t';
-            if (t < b5) { const int i = t - b4, jj = rc ? L - 1 - i : i; return jj < qn ? (unsigned char)ql[jj] : (u32)' '; }   // qual.resize(seq.size(), ' ')
-            return (unsigned char)hd[hl + (t - b5)];
+            if (t < b5) { const int i = t - b4, jj = rc ? L - 1 - i : i; return jj < qn ? (unsigned char)d.qual[jj] : (u32)' '; }   // qual.resize(seq.size(), ' ')
+            return (unsigned char)hd[d.hl + (t - b5)];
         };
-        const u64 d0 = o & ~3ull;                      // first destination dword that holds a byte of this line
-        const int lead = (int)(o - d0);
-        const int ndw = (lead + total + 3) >> 2;
-        for (int w = lane; w < ndw; w += 64) {
+        for (int w = gl; w < ndw; w += 16) {
             const int t0 = 4 * w - lead;               // line-relative index of the dword's first byte
+            char* dst = out + d0 + 4 * (u64)w;
             if (t0 >= 0 && t0 + 4 <= total) {
                 const u32 v = byte_at(t0) | (byte_at(t0 + 1) << 8) | (byte_at(t0 + 2) << 16) | (byte_at(t0 + 3) << 24);
-                *reinterpret_cast<u32*>(out + d0 + 4 * (u64)w) = v;
+                *reinterpret_cast<u32*>(dst) = v;
             } else {
-                for (int b = 0; b < 4; b++) { const int t = t0 + b; if (t >= 0 && t < total) out[d0 + 4 * (u64)w + b] = (char)byte_at(t); }
+                // the ragged first and last dword of a line: its neighbours own the other bytes
+                for (int b = 0; b < 4; b++) { const int t = t0 + b; if (t >= 0 && t < total) dst[b] = (char)byte_at(t); }
             }
         }
     }

@@ -349,7 +349,9 @@ struct Dev {
 inline unsigned nb(u64 n, unsigned bs) { const u64 b = (n + bs - 1) / bs; return (unsigned)(b < (1u << 22) ? (b ? b : 1) : (1u << 22)); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-#define IB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "bmbs_index_build_device: %s: %s\n", #call, hipGetErrorString(e_)); return BMBS_ENODEV; } } while (0)
+// out of device memory is BMBS_ENOMEM (a smaller GPU needs ~60 B per base), any other runtime failure BMBS_ESTATE; BMBS_ENODEV is kept
+// for "there is no such device"
+#define IB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "bmbs_index_build_device: %s: %s\n", #call, hipGetErrorString(e_)); return e_ == hipErrorOutOfMemory ? BMBS_ENOMEM : BMBS_ESTATE; } } while (0)
 #define IB_PTR(p) do { if (!(p)) { fprintf(stderr, "bmbs_index_build_device: %s\n", D.err.c_str()); return BMBS_ENOMEM; } } while (0)
 
 struct MaxOp { __device__ __host__ u64 operator()(const u64& a, const u64& b) const { return a > b ? a : b; } };
@@ -405,6 +407,8 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
         fprintf(stderr, "bmbs_index_build_device: no HIP device %d (the host builder is bmbs_index_build)\n", device_id);
         return BMBS_ENODEV;
     }
+    // the caller's current device is put back on every way out
+    struct DeviceGuard { int prev = -1; DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; } ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); } } device_guard;
     IB_HIP(hipSetDevice(device_id));
     double t_last = now_s();
     auto lap = [&](const char* what) {
@@ -437,6 +441,7 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
     IB_HIP(hipMemcpy(d_pac, B.pac.data(), B.pac.size(), hipMemcpyHostToDevice));
     IB_HIP(hipMemset(d_tx, 0, (n_words + 3) * 8));
     hipLaunchKernelGGL(k_ib_text, dim3(nb(n_words, 256)), dim3(256), 0, 0, d_pac, G, n_words, d_tx);
+    IB_HIP(hipGetLastError());
     IB_HIP(hipDeviceSynchronize());
     D.drop(d_pac);
     IbText T = {d_tx, n};
@@ -446,6 +451,7 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
     unsigned long long* d_hist = D.get<unsigned long long>(17); IB_PTR(d_hist);
     IB_HIP(hipMemset(d_hist, 0, 17 * 8));
     hipLaunchKernelGGL(k_ib_hist, dim3(nb(n_words, 256)), dim3(256), 0, 0, T, n_words, d_hist);
+    IB_HIP(hipGetLastError());
     unsigned long long hist[16];
     IB_HIP(hipMemcpy(hist, d_hist, 16 * 8, hipMemcpyDeviceToHost));
     u64 max_bucket = 1;

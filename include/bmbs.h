@@ -116,6 +116,9 @@ void      bmbs_destroy(bmbs_ctx*);
 const char* bmbs_last_error(const bmbs_ctx*);
 /* replaces the in-memory result of Load_Index + load_index: uploads once, re-packs for HBM        */
 int bmbs_index_attach(bmbs_ctx*, const bmbs_index_view*);
+/* takes device memory for the work buffers of later calls now (bytes per lane; about 2.5 KB per read of the largest batch for the
+ * text calls): optional, saves the first calls the device-wide allocation                                           */
+int bmbs_reserve(bmbs_ctx*, uint64_t bytes_per_lane);
 /* a further context on the index `owner` has attached (same device): shares the index in HBM, owns its stream and work buffers.
  * For keeping two batches in flight from two host threads; `owner` has to outlive it.                                  */
 int bmbs_index_share(bmbs_ctx*, const bmbs_ctx* owner);
@@ -305,7 +308,13 @@ const char* bmbs_build_id(void);
  * full link speed).  The reference's per-thread scratch is plain malloc (Schema.cpp:24344-24362); a caller that
  * keeps malloc'ed buffers still works, only slower.  NULL on failure.                                     */
 void* bmbs_host_alloc(uint64_t bytes);
+/* the same with the buffer's role stated: 1 = the host writes it and the device reads it (FASTQ windows), 2 = the device writes it
+ * and the host reads it (SAM text), 0 = either                                                             */
+void* bmbs_host_alloc_kind(uint64_t bytes, int32_t kind);
 void  bmbs_host_free(void* p);
+/* lets the device touch a page-locked buffer once (kind 1: reads it, 2: writes it, 0: both): the first copy to or from a fresh
+ * buffer is several times slower than the later ones; a driver does this while it loads                                  */
+int   bmbs_host_prefault(bmbs_ctx*, void* p, uint64_t bytes, int32_t kind);
 
 #ifdef __cplusplus
 }

@@ -1204,3 +1204,61 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
             assert strip(b"".join(parts)) == ref
     st = lambda p: "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
     assert st(one) == st(par)
+
+
+# ---- a text of more than 2^32 symbols, for real (the wide device forms without any override) ---------------------------------------------
+@pytest.fixture(scope="module")
+def wide_env(tmp_path_factory):
+    """2.2 Gb uniform-random genome (4.4 G doubled symbols > 2^32: 64-bit suffix array, three Occ super-blocks at 2^31, the 3^21 outcome
+    table when the device has the room), index built on the device; the oracle loads the very same files"""
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from bitmapperbs_amd import synth, mapper
+    wd = tmp_path_factory.mktemp("wide")
+    names, chroms = synth.make_genome(2_200_000_000, 12, seed=4242)
+    fa = str(wd / "w.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=min(64, os.cpu_count() or 8), device=0)
+    ix = mapper.Index(fa)
+    assert 2 * ix.ref_len + 1 > (1 << 32)
+    env = dict(fa=fa, chroms=chroms, ix=ix, oix=orc.OrcIndex(fa))
+    yield env
+    env["oix"].close(); ix.close()
+    for f in os.listdir(str(wd)):
+        os.unlink(os.path.join(str(wd), f))
+
+
+def test_true_size_wide_index_matches_oracle(wide_env, monkeypatch):
+    """reads over the whole 2.2 Gb genome -- half of the suffix-array rows they touch lie beyond 2^32 -- single end, pairs in fast
+    mode and --sensitive, every record and the statistics against the oracle; SA[row] for rows on both sides of 2^32 and of the
+    super-block borders.  Nothing is forced: this is the code path a GRCh38 index takes (bwt.h:1059-1070, bwt.cpp:2563-2643)"""
+    from bitmapperbs_amd import synth, mapper
+    for v in ("BMBS_WIDE", "BMBS_SUPER_SHIFT", "BMBS_TDEPTH", "BMBS_T20"):
+        monkeypatch.delenv(v, raising=False)
+    env = wide_env
+    G = env["ix"].ref_len
+    oix = env["oix"]
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
+    rng = np.random.default_rng(12)
+    edges = [0, 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 2 * G - 1, 2 * G]
+    rows = np.concatenate([rng.integers(0, 2 * G + 1, 6000), rng.integers(1 << 32, 2 * G + 1, 6000), edges]).astype(np.uint64)
+    got = m.locate(rows)
+    exp = np.array([oix.L.orc_sa_at(oix.h, int(r)) for r in rows], dtype=np.uint64)
+    assert (got == exp).all()
+    assert (got >= (1 << 32)).sum() > 100                       # text positions beyond 32 bits really occur (2.4 % of a 4.4 G text)
+    r = synth.make_reads_se(env["chroms"], n=20000, L=150, seed=51, sub=0.02, indel=0.002, qual="random", n_rate=0.001)
+    res, pool = m.map_se(r["seq"], r["qual"], 150)
+    recs, ost, _ = oix.map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 150)
+    assert (recs["status"] == 1).sum() > 18000
+    assert not compare_records(res, pool, recs, 150)
+    assert (m.stats() == ost).all()
+    m.close()
+    for sensitive in (0, 1):
+        m1, m2 = synth.make_reads_pe(env["chroms"], n=10000, L=150, seed=52 + sensitive, sub=0.04 if sensitive else 0.02, indel=0.002, qual="random")
+        m = mapper.Mapper(env["ix"], 0, sensitive=sensitive)
+        res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+        recs, ost, _ = oix.map_pe(orc.params(sensitive=sensitive), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+        assert (recs["status"] == 1).sum() > 8000
+        assert not compare_pe(res, pool, recs, 150)
+        assert (m.stats() == ost).all()
+        m.close()

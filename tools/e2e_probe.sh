@@ -4,7 +4,7 @@
 O=${1:-gpurun_out/e2e}; N=${2:-10000000}
 W=${BMBS_BENCH_DIR:-/tmp/bmbs_bench}
 mkdir -p $O
-read FA F1 F2 NP < <(python3 tools/e2e_setup.py $((N / 2)) 2 | tail -1)
+read FA F1 F2 NP < <(python3 tools/e2e_setup.py $((N / 4)) 4 | tail -1)
 echo "inputs: $FA $F1 $F2 pairs=$NP"
 run() { # label, args...
   local label=$1; shift
