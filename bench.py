@@ -321,7 +321,7 @@ def gather_roofline(kernel, cnt, kern_ms):
 class Job:
     """reads of one configuration resident in HBM + the launch closure"""
 
-    def __init__(self, m, cfg, chroms, rank, sub, indel, qual, genome_d=None):
+    def __init__(self, m, cfg, chroms, rank, sub, indel, qual, genome_d=None, trimmed=False):
         import torch
         from bitmapperbs_amd import gpusynth
         self.m, self.cfg = m, cfg
@@ -346,6 +346,16 @@ class Job:
             del g, lens, genome_d
             torch.cuda.empty_cache()
         nrec = self.n * (2 if cfg["pe"] else 1)
+        # a trimmed library: 70 % of the reads cut to a uniform-random length in [30, L] at their 3' end (tests/common.py:trim_fastq);
+        # the rows keep their stride, the lengths travel beside them (u16: first mates, then second mates)
+        self.lens = None
+        if trimmed:
+            g = torch.Generator(device="cuda"); g.manual_seed(4242 + rank)
+            self.lens = []
+            for _ in self.batches:
+                ln = torch.randint(30, L + 1, (nrec,), generator=g, device="cuda")
+                keep = torch.rand(nrec, generator=g, device="cuda") >= 0.7
+                self.lens.append(torch.where(keep, torch.full_like(ln, L), ln).to(torch.int16))
         self.reads_per_launch = nrec
         self.cig_cap = nrec * self.max_ops
         self.res_d = torch.empty((nrec, 32), dtype=torch.uint8, device="cuda")
@@ -354,7 +364,17 @@ class Job:
 
     def launch(self, b):
         t = self.batches[b]
-        if self.cfg["pe"]:
+        if self.lens is not None:
+            from bitmapperbs_amd import capi
+            lib = capi.lib()
+            if self.cfg["pe"]:
+                rc = lib.bmbs_map_pe_var_device(self.m._ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), self.lens[b].data_ptr(),
+                                                self.L, self.stride, self.n, self.res_d.data_ptr(), self.cig_d.data_ptr(), self.cig_cap)
+            else:
+                rc = lib.bmbs_map_se_var_device(self.m._ctx, t[0].data_ptr(), t[1].data_ptr(), self.lens[b].data_ptr(), self.L, self.stride, self.n,
+                                                self.res_d.data_ptr(), self.cig_d.data_ptr(), self.cig_cap)
+            self.m._chk(rc)
+        elif self.cfg["pe"]:
             self.m.map_pe_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), self.L, self.stride, self.n,
                                  self.res_d.data_ptr(), self.cig_d.data_ptr(), self.cig_cap)
         else:
@@ -459,7 +479,7 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
             "ms_per_launch": round(dt / total * 1e3, 3)}
 
 
-def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3):
+def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3, trimmed=False):
     """a short secondary measurement on its own index / mapper: -> dict(value, ms_per_launch, ...)"""
     import torch
     from bitmapperbs_amd import mapper
@@ -470,7 +490,7 @@ def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", r
         fa, names, chroms, built = ensure_index(args, cfg, rank, local, 1, None, repeats=repeats)
         ix = mapper.Index(fa)
         m = mapper.Mapper(ix, device=local, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0)
-        job = Job(m, cfg, chroms, rank, args.sub if sub is None else sub, args.indel, qual)
+        job = Job(m, cfg, chroms, rank, args.sub if sub is None else sub, args.indel, qual, trimmed=trimmed)
         dt, passes, kern_ms = timed(job, steps, 1, 0.5, 1, None, torch)
         nreads = job.reads_per_step() * steps * passes
         top = sorted(((v, k_) for k_, v in kern_ms.items() if k_.startswith("k_")), reverse=True)[:3]
@@ -522,9 +542,15 @@ def host_buffer_rate(m, job, torch):
     dt = time.perf_counter() - t
     for p_ in pin + [res, pool]:
         lib.bmbs_host_free(p_)
-    return {"what": "bmbs_map_%s on page-locked HOST buffers (%d %s per call, H2D + kernels + D2H serialised on one context)" % (
+    up = nbytes * len(pin) * reps
+    down = nrec * 32 * reps + int(used.value) * 4 * reps
+    LINK = 56.0           # GB/s one direction, page-locked, measured on these boxes (tools/pcie_probe; PCIe Gen5 x16 spec 63)
+    return {"what": "bmbs_map_%s on page-locked HOST buffers, %d %s per call: the call is cut into chunks of 500 k units dealt to the context's lanes, "
+                    "uploads, kernels and downloads of different chunks overlap (copies on streams that carry no kernel); PCIe-inclusive, never `value`" % (
                 "pe" if job.cfg["pe"] else "se", n, "pairs" if job.cfg["pe"] else "reads"),
-            "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s"}
+            "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s",
+            "bytes_up_per_read": round(up / (nrec * reps), 1), "bytes_down_per_read": round(down / (nrec * reps), 1),
+            "upload_GBps": round(up / dt / 1e9, 1), "link_GBps_one_direction": LINK, "frac_of_link": round(up / dt / 1e9 / LINK, 3)}
 
 
 def file_to_file_rate(args, cfg, fa, L):
@@ -540,9 +566,8 @@ def file_to_file_rate(args, cfg, fa, L):
     if not os.path.exists(drv) or not all(os.path.exists(f) for f in files):
         return None
     rec_bytes = 2 * L + 15                      # write_fastq_sample: '@s%08d\n' + L + '\n+\n' + L + '\n'
-    # the cpu_baseline sample twice over: a run of a few tenths of a second is mostly pipeline fill and first-call allocations, while
-    # four times over (16 GB of SAM on configs[2]) ran into the box's dirty-page throttling in some runs (20.7 M reads/s in one, 7.6 in
-    # the next; the /dev/null run beside it 53-59 in both)
+    # the cpu_baseline sample four times over (20 M pairs on configs[2]: 12.6 GB of FASTQ, 14.4 GB of SAM): the pipeline needs ~0.1 s to
+    # fill (first batch read, first calls of every context), which a run of 0.15 s mostly measures
     REP = 4
     big = [f[:-3] + "_x%d.fq" % REP for f in files]
     for src, dst in zip(files, big):
@@ -558,9 +583,10 @@ def file_to_file_rate(args, cfg, fa, L):
     n = os.path.getsize(big[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     out = {}
     parts = 8
-    for label, dst, extra in (("file", os.path.join(args.workdir, "f2f.sam"), []),
-                              ("file_%d_parts" % parts, os.path.join(args.workdir, "f2f.sam"), ["--out-parts", str(parts)]),
-                              ("null_sink", "/dev/null", [])):
+    # (the run that writes most files goes first: 14 GB of dirty pages from an earlier run made the box throttle the next writer)
+    for label, dst, extra in (("file_%d_parts" % parts, os.path.join(args.workdir, "f2f.sam"), ["--out-parts", str(parts)]),
+                              ("null_sink", "/dev/null", []),
+                              ("file", os.path.join(args.workdir, "f2f.sam"), [])):
         p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "32", "--verbose"] + extra, capture_output=True, text=True)
         if p.returncode:
             return {"error": p.stderr[-300:]}
@@ -733,7 +759,7 @@ def main():
                 out["sample_sam_lines_compared"] = len(theirs)
             if not args.no_secondary:
                 try:
-                    out["e2e"] = {"host_buffers": host_buffer_rate(m, job, torch)}
+                    out["e2e"] = {"host_buffers_overlapped": host_buffer_rate(m, job, torch)}
                 except Exception as ex:
                     out["e2e"] = {"error": repr(ex)}
                 try:
@@ -762,6 +788,7 @@ def main():
                     sec["configs1_se_chr21"] = secondary(args, CONFIGS[1]["label"], c1, rank, local)
                 one = dict(cfg, launches=1)
                 sec["random_qualities"] = secondary(args, "main configuration, Phred 2..40 uniform-random qualities", one, rank, local, qual="random")
+                sec["trimmed_library"] = secondary(args, "main configuration, 70 % of the reads trimmed to a uniform-random length in [30, L] (mates independently)", one, rank, local, trimmed=True)
                 sec["sub_5pct"] = secondary(args, "main configuration, 5 % substitutions", one, rank, local, sub=0.05)
                 sec["no_20mer_table"] = secondary(args, "main configuration, BMBS_T20=0 (16-mer table + Occ walk only)", one, rank, local, env={"BMBS_T20": "0"})
                 sec["repeats_50000"] = secondary(args, "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)

@@ -37,7 +37,7 @@ struct Arena {
         bytes = (bytes + 255) & ~(size_t)255;
         for (size_t i = slabs.size(); i-- > 0;)
             if (slabs[i].used + bytes <= slabs[i].cap) { void* r = slabs[i].p + slabs[i].used; slabs[i].used += bytes; return r; }
-        size_t cap = std::max<size_t>(bytes, std::max<size_t>((size_t)1 << 30, total / 2));
+        size_t cap = std::max<size_t>(bytes, std::min<size_t>((size_t)2 << 30, std::max<size_t>((size_t)512 << 20, total / 2)));
         void* p = nullptr;
         if (hipMalloc(&p, cap) != hipSuccess) {
             cap = bytes;
@@ -207,7 +207,7 @@ int ensure(Lane* c, DevBuf& b, size_t bytes, bool zero = false)
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return BMBS_OK;
     size_t want = bytes + bytes / 8 + 256;
-    if (c->kn.arena && want <= ((size_t)1 << 31)) {
+    if (c->kn.arena && want <= ((size_t)256 << 20)) {              // larger ones keep a hipMalloc of their own (freed when they grow)
         void* p = c->arena.alloc(want);
         if (!p) { c->err = "out of device memory (lane arena)"; return BMBS_ENOMEM; }
         if (b.p && !b.arena) (void)hipFree(b.p);
@@ -691,7 +691,7 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
     rc = cand_total(c, st, n, exact, &tot);
     if (rc) return rc;
     *total_cand = tot;
-    const u64 t1 = tot ? tot : 1;
+    const u64 t1 = exact ? std::max<u64>(tot, cap_from((double)tot / (double)n, n, n)) : tot;     // buffers as the next call (which does not wait) will want them
     ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(bmbs_vote)); ENS(c, c->slot_read, t1 * 4);
     ENS(c, c->ferr, t1 * 4); ENS(c, c->fend, t1 * 4);
     // locate + sort + votes; BMBS_VOTE=split runs the two-kernel form (k_locate, k_vote) for A/B measurements
@@ -1052,7 +1052,7 @@ int map_se_dev(Lane* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int
     c->last_total_cand = tot;
     ENS(c, c->vote_off, (n + 1) * 8);
     {
-        const u64 t1 = tot ? tot : 1;
+        const u64 t1 = exact ? std::max<u64>(tot, cap_from((double)tot / (double)n, n, n)) : (tot ? tot : 1);
         ENS(c, c->votes_dense, t1 * sizeof(bmbs_vote)); ENS(c, c->dense_read, t1 * 4);
     }
     prof_begin(c, "vote_compact");
@@ -1225,7 +1225,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     rc = cand_total(c, st, n2, exact, &tot);
     if (rc) return rc;
     c->last_total_cand = tot;
-    const u64 t1 = tot ? tot : 1;
+    const u64 t1 = exact ? std::max<u64>(tot, cap_from((double)tot / (double)n2, n2, n2)) : (tot ? tot : 1);
     ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(PeCand)); ENS(c, c->pe_B, t1 * sizeof(PeCand)); ENS(c, c->slot_read, t1 * 4);
     ENS(c, c->dense_read, t1 * 4); ENS(c, c->ferr, t1 * 4);
     PeCand* A = c->votes.as<PeCand>();
@@ -1331,7 +1331,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
         }
         c->last_reseeded = rt[0]; c->last_reseed_cand = rt[1];
         if (rt[0]) {
-            const u64 rtot = rt[1] ? rt[1] : 1;
+            const u64 rtot = exact ? std::max<u64>(rt[1], cap_from((double)rt[1] / (double)n2, n2, 65536)) : (rt[1] ? rt[1] : 1);
             ENS(c, c->pe_R, rtot * sizeof(PeCand)); ENS(c, c->pe_rcand, rtot * 8);
             ENS(c, c->dense_read, rtot * 4); ENS(c, c->ferr, rtot * 4);
             ps.R = c->pe_R.as<PeCand>();

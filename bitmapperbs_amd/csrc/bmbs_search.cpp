@@ -761,7 +761,7 @@ int main(int argc, char** argv)
         for (bmbs_ctx* c : ctxs) if (bmbs_sam_refs(c, nm.data(), (int32_t)nm.size())) { fprintf(stderr, "%s\n", bmbs_last_error(c)); return 1; }
     }
     // device memory for the work buffers of a batch, taken while the index loads instead of inside the first calls
-    for (bmbs_ctx* c : ctxs) (void)bmbs_reserve(c, (uint64_t)batch * (pe ? 2 : 1) * (2200 + 6 * (uint64_t)std::max<size_t>(est0 / 2, 100)));
+    for (bmbs_ctx* c : ctxs) (void)bmbs_reserve(c, (uint64_t)batch * (pe ? 2 : 1) * (1200 + 3 * (uint64_t)std::max<size_t>(est0 / 2, 100)));
     // ---- the parts: record ranges of the input, one output file each
     std::vector<std::unique_ptr<Part>> P_(static_cast<size_t>(parts));
     for (int p = 0; p < parts; p++) { P_[(size_t)p].reset(new Part()); P_[(size_t)p]->id = p; }
