@@ -106,9 +106,88 @@ def launch_children(args) -> int:
 
 
 # ---- workload ------------------------------------------------------------------------------------------------------------------
-def make_genome(cfg, repeats=0):
+# repeat content of the GRCh38-like stress genome: (name, element length, copies per Gb, divergence range, what)
+REPEAT_FAMILIES = [
+    ("SINE/Alu-like", 300, 350_000, (0.05, 0.18), "interspersed"),
+    ("SINE/MIR-like", 260, 180_000, (0.15, 0.30), "interspersed"),
+    ("LINE/L1-like 5'-truncated", 900, 170_000, (0.04, 0.20), "interspersed"),
+    ("LINE/L1-like full length", 6000, 1_600, (0.02, 0.10), "interspersed"),
+    ("LTR-like", 450, 140_000, (0.08, 0.22), "interspersed"),
+    ("DNA-transposon-like", 280, 110_000, (0.12, 0.28), "interspersed"),
+    ("segmental duplication", 40_000, 700, (0.005, 0.03), "interspersed"),
+    ("alpha-satellite-like arrays (171 bp monomer)", 171, 160_000, (0.01, 0.06), "tandem"),
+    ("microsatellite tracts (2-6 bp unit)", 120, 90_000, (0.0, 0.03), "simple"),
+]
+
+
+def plant_repeat_families(chroms, seed=99, device="cuda"):
+    """GRCh38-like repeat structure planted into the uniform-random chromosomes, on the GPU: about 45 % of the bases come from
+    nine families of 10^3-10^6 copies each with per-copy divergence drawn from the family's range (half of the copies reverse
+    complemented), satellite monomers in head-to-tail arrays of 300-3000 units, microsatellites as short unit repeats.
+    -> fraction of the genome covered (overlaps counted once is not attempted: copies may land on one another, as in a real genome)"""
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    comp = torch.arange(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    planted = 0
+    total = sum(c.size for c in chroms)
+    for ci, ch in enumerate(chroms):
+        t = torch.from_numpy(ch).to(device)
+        n = t.numel()
+        for fi, (name, elen, per_gb, (d_lo, d_hi), kind) in enumerate(REPEAT_FAMILIES):
+            fg = torch.Generator(device=device); fg.manual_seed(seed * 1000 + fi)        # the family's consensus is the same on every chromosome
+            copies = max(1, int(per_gb * n / 1e9))
+            if kind == "simple":
+                unit_len = torch.randint(2, 7, (copies,), generator=g, device=device)
+                units = acgt[torch.randint(0, 4, (copies, 6), generator=g, device=device)]
+                j = torch.arange(elen, device=device)[None, :]
+                vals = torch.gather(units, 1, j % unit_len[:, None])
+            else:
+                cons = acgt[torch.randint(0, 4, (elen,), generator=fg, device=device)]
+                vals = None
+            if kind == "tandem":
+                arrays = max(1, copies // 1500)
+                for _ in range(arrays):
+                    units_n = int(torch.randint(300, 3000, (1,), generator=g, device=device).item())
+                    L_arr = units_n * elen
+                    if L_arr >= n - 1:
+                        continue
+                    p = int(torch.randint(0, n - L_arr, (1,), generator=g, device=device).item())
+                    arr = cons.repeat(units_n)
+                    div = d_lo + (d_hi - d_lo) * float(torch.rand(1, generator=g, device=device).item())
+                    m = torch.rand(L_arr, generator=g, device=device) < div
+                    arr = torch.where(m, acgt[torch.randint(0, 4, (L_arr,), generator=g, device=device)], arr)
+                    t[p:p + L_arr] = arr
+                    planted += L_arr
+                continue
+            step = max(1, (1 << 26) // elen)
+            for a in range(0, copies, step):
+                b = min(copies, a + step)
+                k = b - a
+                v = vals[a:b] if vals is not None else cons[None, :].expand(k, elen).clone()
+                div = d_lo + (d_hi - d_lo) * torch.rand((k, 1), generator=g, device=device)
+                m = torch.rand((k, elen), generator=g, device=device) < div
+                v = torch.where(m, acgt[torch.randint(0, 4, (k, elen), generator=g, device=device)], v)
+                rc = torch.rand(k, generator=g, device=device) < 0.5
+                v = torch.where(rc[:, None], comp[v.flip(1).long()], v)
+                p = torch.randint(0, n - elen, (k,), generator=g, device=device)
+                idx = p[:, None] + torch.arange(elen, device=device)[None, :]
+                t[idx.reshape(-1)] = v.reshape(-1)
+                planted += k * elen
+        ch[:] = t.cpu().numpy()
+        del t
+    torch.cuda.empty_cache()
+    return planted / total
+
+
+def make_genome(cfg, repeats=0, grch38_like=False):
     from bitmapperbs_amd import synth
     names, chroms = synth.make_genome(cfg["genome"], cfg["n_chrom"], seed=20240229)
+    if grch38_like:
+        frac = plant_repeat_families(chroms)
+        sys.stderr.write("[bench] GRCh38-like repeat families planted: %.1f %% of the bases\n" % (100 * frac))
     if repeats:
         # interspersed-repeat stress (Alu-like): seeds inside a copy hit hundreds of places, candidate lists get long
         rng = np.random.default_rng(77)
@@ -124,12 +203,12 @@ def make_genome(cfg, repeats=0):
     return names, chroms
 
 
-def ensure_index(args, cfg, rank, local, world, dist, repeats=0):
+def ensure_index(args, cfg, rank, local, world, dist, repeats=0, grch38_like=False):
     """-> (fasta/prefix path, names, chroms, seconds spent building or 0 when cached)"""
     from bitmapperbs_amd import synth, mapper
-    wd = os.path.join(args.workdir, "g%d_c%d%s" % (cfg["genome"], cfg["n_chrom"], "_r%d" % repeats if repeats else ""))
+    wd = os.path.join(args.workdir, "g%d_c%d%s%s" % (cfg["genome"], cfg["n_chrom"], "_r%d" % repeats if repeats else "", "_hg" if grch38_like else ""))
     fa = os.path.join(wd, "g.fa")
-    names, chroms = make_genome(cfg, repeats)
+    names, chroms = make_genome(cfg, repeats, grch38_like)
     built = 0.0
     if rank == 0:
         os.makedirs(wd, exist_ok=True)
@@ -479,7 +558,7 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
             "ms_per_launch": round(dt / total * 1e3, 3)}
 
 
-def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3, trimmed=False):
+def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3, trimmed=False, grch38_like=False):
     """a short secondary measurement on its own index / mapper: -> dict(value, ms_per_launch, ...)"""
     import torch
     from bitmapperbs_amd import mapper
@@ -487,16 +566,18 @@ def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", r
     for k_, v_ in (env or {}).items():
         old[k_] = os.environ.get(k_); os.environ[k_] = v_
     try:
-        fa, names, chroms, built = ensure_index(args, cfg, rank, local, 1, None, repeats=repeats)
+        fa, names, chroms, built = ensure_index(args, cfg, rank, local, 1, None, repeats=repeats, grch38_like=grch38_like)
         ix = mapper.Index(fa)
         m = mapper.Mapper(ix, device=local, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0)
         job = Job(m, cfg, chroms, rank, args.sub if sub is None else sub, args.indel, qual, trimmed=trimmed)
         dt, passes, kern_ms = timed(job, steps, 1, 0.5, 1, None, torch)
         nreads = job.reads_per_step() * steps * passes
         top = sorted(((v, k_) for k_, v in kern_ms.items() if k_.startswith("k_")), reverse=True)[:3]
+        st = m.stats()
         out = {"what": label, "value": round(nreads / dt / 1e6, 2), "unit": "Mreads/s", "timed_s": round(dt, 3),
                "ms_per_launch": round(dt / (steps * passes * len(job.batches)) * 1e3, 3),
-               "top_kernels_ms": {k_: round(v, 3) for v, k_ in top}}
+               "top_kernels_ms": {k_: round(v, 3) for v, k_ in top},
+               "mapstats": {"unique_pct": round(100.0 * float(st[1]) / max(1.0, float(st[0])), 2), "ambiguous_pct": round(100.0 * float(st[2]) / max(1.0, float(st[0])), 2)}}
         m.close(); ix.close()
         del job
         torch.cuda.empty_cache()
@@ -553,6 +634,55 @@ def host_buffer_rate(m, job, torch):
             "upload_GBps": round(up / dt / 1e9, 1), "link_GBps_one_direction": LINK, "frac_of_link": round(up / dt / 1e9 / LINK, 3)}
 
 
+def write_bgzf(path, data, level=1, threads=16):
+    """bgzip's format (SAM spec 4.1): independent gzip members of <= 64 KiB of input, compressed size in a 'BC' extra field"""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    block = 65280
+
+    def one(a):
+        chunk = data[a:a + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        z = co.compress(chunk) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(z) + 25) + z +
+                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    with open(path, "wb") as f, ThreadPoolExecutor(threads) as ex:
+        for blk in ex.map(one, range(0, len(data), block)):
+            f.write(blk)
+        f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
+
+
+def gz_input_rate(args, drv, fa, cfg, files, inp, rec_bytes):
+    out = {}
+    n_plain = 2_500_000                                # records of the one-member gzip files (compressed by one gzip process each)
+    for label in ("bgzf", "plain_gzip"):
+        gzf = []
+        procs = []
+        for src in files:
+            dst = src + (".bgzf.gz" if label == "bgzf" else ".plain.gz")
+            if label == "bgzf":
+                with open(src, "rb") as f:
+                    write_bgzf(dst, f.read())
+            else:
+                procs.append(subprocess.Popen("head -c %d %s | gzip -1 -c > %s" % (n_plain * rec_bytes, src, dst), shell=True))
+            gzf.append(dst)
+        for pr in procs:
+            pr.wait()
+        n = (os.path.getsize(files[0]) // rec_bytes if label == "bgzf" else n_plain) * (2 if cfg["pe"] else 1)
+        a = [gzf[files.index(x)] if x in files else x for x in inp]
+        p = subprocess.run([drv, "--search", fa] + a + ["-e", str(cfg["e"]), "-o", "/dev/null", "-t", "32", "--verbose"], capture_output=True, text=True)
+        for f in gzf:
+            os.unlink(f)
+        if p.returncode:
+            out[label] = {"error": p.stderr[-300:]}
+            continue
+        line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
+        wall = float(line.split("mapping wall")[1].split("s")[0])
+        out[label] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n)}
+    return out
+
+
 def file_to_file_rate(args, cfg, fa, L):
     """FASTQ file(s) -> SAM file through bitmapperbs_amd/bmbs_search (the drop-in driver) on the cpu_baseline sample files; the
     SAM goes to --workdir's file system and, second run, to /dev/null (one buffered file takes ~10.5 GB/s on these boxes)"""
@@ -579,6 +709,8 @@ def file_to_file_rate(args, cfg, fa, L):
                         if not blk:
                             break
                         o.write(blk)
+    os.sync()           # the inputs just written are dirty pages: left there, they count against the writers of the runs below
+    inp0 = list(inp)
     inp = [big[files.index(x)] if x in files else x for x in inp]
     n = os.path.getsize(big[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     out = {}
@@ -598,6 +730,12 @@ def file_to_file_rate(args, cfg, fa, L):
             f = os.path.join(args.workdir, "f2f.sam.part%03d" % k)
             if os.path.exists(f):
                 os.unlink(f)
+    # gzipped input: bgzip-style files (independent 64 KiB blocks: inflated by several threads per file) and ordinary one-member
+    # gzip files (one inflate thread per file, both mates side by side); -o /dev/null
+    try:
+        out["gz_input"] = gz_input_rate(args, drv, fa, cfg, files, inp0, rec_bytes)
+    except Exception as ex:
+        out["gz_input"] = {"error": repr(ex)}
     for f in [os.path.join(args.workdir, "f2f.sam")] + big:
         if os.path.exists(f):
             os.unlink(f)
@@ -791,6 +929,10 @@ def main():
                 sec["trimmed_library"] = secondary(args, "main configuration, 70 % of the reads trimmed to a uniform-random length in [30, L] (mates independently)", one, rank, local, trimmed=True)
                 sec["sub_5pct"] = secondary(args, "main configuration, 5 % substitutions", one, rank, local, sub=0.05)
                 sec["no_20mer_table"] = secondary(args, "main configuration, BMBS_T20=0 (16-mer table + Occ walk only)", one, rank, local, env={"BMBS_T20": "0"})
+                if cfg["genome"] >= 1_000_000_000:
+                    sec["grch38_like"] = secondary(args, "main configuration on a genome of the same size with GRCh38-like repeat content: ~45 % of the bases from nine "
+                                                   "families (Alu / MIR / L1 / LTR / DNA-transposon-like interspersed copies at 1-30 % divergence, segmental "
+                                                   "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True)
                 sec["repeats_50000"] = secondary(args, "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)
             except Exception as ex:      # a secondary key must never lose the headline line
                 sec["error"] = repr(ex)

@@ -902,7 +902,7 @@ static int lane_index_attach(Lane* c, const bmbs_index_view* v)
     const u64 G = v->ref_len, n = 2 * G, rows = n + 1;
     if (v->sa_length != rows) { c->err = "index view: sa_length != 2*ref_len + 1"; return BMBS_EINVAL; }
     if (rows >= (1ull << 36)) { c->err = "genome too large: rows must fit the 36-bit fields of the 16-mer table"; return BMBS_EINVAL; }
-    if (v->n_chrom < 1 || v->n_chrom > 32767) { c->err = "index view: n_chrom must be 1..32767 (bmbs_result.chrom is a 16-bit field)"; return BMBS_EINVAL; }
+    if (v->n_chrom < 1) { c->err = "index view: n_chrom must be at least 1"; return BMBS_EINVAL; }
     // texts of 2^32 symbols and more (GRCh38) take the wide forms: 64-bit suffix array, Occ counts relative to super-blocks of 2^31
     // symbols whose sums travel in the DevIndex; BMBS_WIDE=1 forces them on a small index and BMBS_SUPER_SHIFT=s (>= 16) makes the
     // super-blocks small enough for such an index to have several (tests)

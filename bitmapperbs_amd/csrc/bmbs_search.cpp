@@ -185,14 +185,20 @@ struct Source {
     int fd = -1;
     size_t size = 0, off = 0, end = 0;           // plain: the part's byte range [off, end)
     std::string err;
-    // .gz
+    // .gz: inflated text arrives as numbered chunks; `ready` hands them to window() in order
     gzFile gzf = nullptr;
-    std::thread inflater;
+    std::vector<std::thread> inflaters;
     std::mutex m; std::condition_variable cv_data, cv_room;
-    std::deque<std::vector<char>> chunks;        // inflated text, in order
+    std::map<long, std::vector<char>> ready;     // chunk number -> text
+    long next_chunk = 0;                         // the chunk window() takes next
     size_t queued = 0, front_used = 0;
     bool gz_done = false, gz_stop = false;
+    int live_inflaters = 0;
     std::vector<char> carry;
+    // BGZF (bgzip): independent deflate blocks of <= 64 KiB with their compressed size in the header -- inflated by several threads
+    bool bgzf = false;
+    const unsigned char* zmap = nullptr; size_t zsize = 0, znext = 0;     // the compressed file, mapped; next unassigned block
+    long zjob = 0;                                                        // number of the next job
 
     static bool is_gz(const char* path)
     {
@@ -203,25 +209,99 @@ struct Source {
         fclose(f);
         return got == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
     }
-    bool open(const char* path, size_t lo, size_t hi)
+    // compressed size of the BGZF block at p (0: not a BGZF block header)
+    static size_t bgzf_block(const unsigned char* p, size_t avail)
+    {
+        if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4) || p[10] != 6 || p[11] != 0 || p[12] != 'B' || p[13] != 'C' || p[14] != 2 || p[15] != 0) return 0;
+        const size_t bs = (size_t)(p[16] | (p[17] << 8)) + 1;
+        return bs >= 26 && bs <= avail ? bs : 0;
+    }
+    void push_chunk(long id, std::vector<char>&& c)
+    {
+        std::unique_lock<std::mutex> l(m);
+        // the chunk window() is waiting for always gets in; the others wait for room (text inflated ahead of its turn is bounded)
+        cv_room.wait(l, [&] { return id == next_chunk || queued < ((size_t)768 << 20) || gz_stop; });
+        if (gz_stop) return;
+        queued += c.size();
+        ready[id] = std::move(c);
+        cv_data.notify_all();
+    }
+    void inflater_exit()
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (--live_inflaters == 0) { gz_done = true; cv_data.notify_all(); }
+    }
+    bool open(const char* path, size_t lo, size_t hi, int gz_threads = 1)
     {
         gz = is_gz(path);
         if (gz) {
+            const int zfd = ::open(path, O_RDONLY);
+            struct stat zsb;
+            if (zfd >= 0 && fstat(zfd, &zsb) == 0 && zsb.st_size > 28) {
+                void* mp = mmap(nullptr, (size_t)zsb.st_size, PROT_READ, MAP_PRIVATE, zfd, 0);
+                if (mp != MAP_FAILED) {
+                    if (bgzf_block((const unsigned char*)mp, (size_t)zsb.st_size)) { bgzf = true; zmap = (const unsigned char*)mp; zsize = (size_t)zsb.st_size; }
+                    else munmap(mp, (size_t)zsb.st_size);
+                }
+            }
+            if (zfd >= 0) ::close(zfd);
+            if (bgzf) {
+                live_inflaters = std::max(1, gz_threads);
+                for (int t = 0; t < live_inflaters; t++)
+                    inflaters.emplace_back([this] {
+                        z_stream zs; memset(&zs, 0, sizeof zs);
+                        inflateInit2(&zs, -15);
+                        for (;;) {
+                            // a job = the blocks of the next ~2 MiB of the compressed file
+                            size_t a, e; long id;
+                            {
+                                std::lock_guard<std::mutex> l(m);
+                                if (gz_stop || znext >= zsize) break;
+                                a = znext; id = zjob++;
+                                size_t q = a;
+                                while (q < zsize && q - a < ((size_t)2 << 20)) { const size_t bs = bgzf_block(zmap + q, zsize - q); if (!bs) break; q += bs; }
+                                if (q == a) { err = "corrupt BGZF block header in the .gz input"; znext = zsize; break; }
+                                e = q; znext = q;
+                            }
+                            std::vector<char> out;
+                            size_t total = 0;
+                            for (size_t q = a; q < e;) { const size_t bs = bgzf_block(zmap + q, zsize - q); total += (size_t)zmap[q + bs - 4] | ((size_t)zmap[q + bs - 3] << 8) | ((size_t)zmap[q + bs - 2] << 16) | ((size_t)zmap[q + bs - 1] << 24); q += bs; }
+                            out.resize(total);
+                            size_t at = 0; bool bad = false;
+                            for (size_t q = a; q < e && !bad;) {
+                                const size_t bs = bgzf_block(zmap + q, zsize - q);
+                                const size_t isz = (size_t)zmap[q + bs - 4] | ((size_t)zmap[q + bs - 3] << 8) | ((size_t)zmap[q + bs - 2] << 16) | ((size_t)zmap[q + bs - 1] << 24);
+                                if (isz) {
+                                    inflateReset(&zs);
+                                    zs.next_in = (Bytef*)(zmap + q + 18); zs.avail_in = (uInt)(bs - 26);
+                                    zs.next_out = (Bytef*)(out.data() + at); zs.avail_out = (uInt)isz;
+                                    const int rc = inflate(&zs, Z_FINISH);
+                                    if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+                                }
+                                at += isz; q += bs;
+                            }
+                            if (bad) { std::lock_guard<std::mutex> l(m); err = "corrupt BGZF block in the .gz input"; znext = zsize; break; }
+                            push_chunk(id, std::move(out));
+                        }
+                        inflateEnd(&zs);
+                        inflater_exit();
+                    });
+                return true;
+            }
             gzf = gzopen(path, "rb");
             if (!gzf) return false;
             gzbuffer(gzf, 1 << 20);
-            inflater = std::thread([this] {
-                for (;;) {
+            live_inflaters = 1;
+            inflaters.emplace_back([this] {
+                for (long id = 0;; id++) {
                     std::vector<char> c((size_t)8 << 20);
                     const int n = gzread(gzf, c.data(), (unsigned)c.size());
-                    std::unique_lock<std::mutex> l(m);
-                    if (n <= 0) { if (n < 0) err = "gzread failed (corrupt .gz input?)"; gz_done = true; cv_data.notify_all(); return; }
+                    if (n <= 0) { if (n < 0) { std::lock_guard<std::mutex> l(m); err = "gzread failed (corrupt .gz input?)"; } break; }
                     c.resize((size_t)n);
-                    cv_room.wait(l, [this] { return queued < ((size_t)512 << 20) || gz_stop; });
-                    if (gz_stop) return;
-                    queued += c.size(); chunks.push_back(std::move(c));
-                    cv_data.notify_all();
+                    push_chunk(id, std::move(c));
+                    { std::lock_guard<std::mutex> l(m); if (gz_stop) break; }
                 }
+                inflater_exit();
             });
             return true;
         }
@@ -271,23 +351,24 @@ struct Source {
             bool done = false;
             while (have < cap) {
                 std::unique_lock<std::mutex> l(m);
-                cv_data.wait(l, [this] { return !chunks.empty() || gz_done; });
-                if (chunks.empty()) { done = true; if (!err.empty()) return false; break; }
-                std::vector<char>& f = chunks.front();
+                cv_data.wait(l, [this] { return ready.count(next_chunk) != 0 || gz_done; });
+                auto it = ready.find(next_chunk);
+                if (it == ready.end()) { done = true; if (!err.empty()) return false; break; }
+                std::vector<char>& f = it->second;
                 const size_t take = std::min(cap - have, f.size() - front_used);
-                l.unlock();                                                     // only this thread consumes: the front chunk stays put
+                l.unlock();                                                     // only this thread consumes: the chunk stays put
                 memcpy(dst + have, f.data() + front_used, take);
                 have += take; front_used += take;
                 l.lock();
-                if (front_used == f.size()) { queued -= f.size(); chunks.pop_front(); front_used = 0; cv_room.notify_all(); }
+                if (front_used == f.size()) { queued -= f.size(); ready.erase(it); next_chunk++; front_used = 0; cv_room.notify_all(); }
             }
             len = have;
             last = done;
             const size_t nsb = (len + SUB_BLOCK - 1) / SUB_BLOCK;
             counts.assign(nsb, 0);
-            pool.run((int)std::min<size_t>(nsb, (size_t)pool.size() * 4), [&](int t) {
-                const size_t T = std::min<size_t>(nsb, (size_t)pool.size() * 4);
-                for (size_t i = (size_t)t; i < nsb; i += T) counts[i] = (uint32_t)count_nl(dst + i * SUB_BLOCK, std::min(SUB_BLOCK, len - i * SUB_BLOCK));
+            const int T = (int)std::min<size_t>(nsb, (size_t)pool.size() * 4);
+            pool.run(T, [&](int t) {
+                for (size_t i = (size_t)t; i < nsb; i += (size_t)T) counts[i] = (uint32_t)count_nl(dst + i * SUB_BLOCK, std::min(SUB_BLOCK, len - i * SUB_BLOCK));
             });
         }
         // an unterminated last line counts as a line: the device wants every line closed
@@ -302,12 +383,14 @@ struct Source {
     }
     void close()
     {
-        if (inflater.joinable()) {
+        if (!inflaters.empty()) {
             { std::lock_guard<std::mutex> l(m); gz_stop = true; }
             cv_room.notify_all();
-            inflater.join();
+            for (auto& t : inflaters) t.join();
+            inflaters.clear();
         }
         if (gzf) gzclose(gzf);
+        if (zmap) munmap((void*)zmap, zsize);
         if (fd >= 0) ::close(fd);
     }
 };
@@ -782,7 +865,8 @@ int main(int argc, char** argv)
         } else { cut1[1] = cut2[1] = ~(size_t)0; }
         for (int p = 0; p < live_parts; p++) {
             Part& pt = *P_[(size_t)p];
-            if (!pt.s1.open(in1.c_str(), cut1[(size_t)p], cut1[(size_t)p + 1]) || (pe && !pt.s2.open(seq2.c_str(), cut2[(size_t)p], cut2[(size_t)p + 1]))) {
+            const int zt = std::max(1, io_threads / (pe ? 4 : 2));          // BGZF input: inflate threads per file
+            if (!pt.s1.open(in1.c_str(), cut1[(size_t)p], cut1[(size_t)p + 1], zt) || (pe && !pt.s2.open(seq2.c_str(), cut2[(size_t)p], cut2[(size_t)p + 1], zt))) {
                 fprintf(stderr, "Cannot open the read file(s)\n"); return 1;
             }
         }

@@ -119,3 +119,19 @@ def bam_payload(path):
         ln = struct.unpack("<i", d[q:q + 4])[0]
         q += 8 + ln
     return d[p:q], d[q:]
+
+
+def write_bgzf(path, data: bytes, block: int = 60000, level: int = 6):
+    """what `bgzip` writes: independent gzip members of at most 64 KiB of input with their compressed size in a 'BC' extra field
+    (SAM specification section 4.1), closed by the empty end-of-file block"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for a in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if a is None else data[a:a + block]
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            z = co.compress(chunk) + co.flush()
+            bsize = len(z) + 25
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize))
+            f.write(z)
+            f.write(struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))

@@ -868,15 +868,19 @@ def test_shared_index_contexts_map_concurrently(env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_contigs", [500, 1500])
+@pytest.mark.parametrize("n_contigs", [500, 1500, 40000])
 def test_many_contigs_match_oracle(tmp_path, n_contigs):
-    """an assembly of 500 / 1500 short sequences: placement by binary search over the contig starts (SE and PE); the finalize
-    kernels keep the table in LDS up to 1024 sequences and read it from global memory beyond"""
+    """an assembly of 500 / 1500 / 40 000 short sequences (a scaffold-level assembly: bmbs_result.chrom is 32 bits since round 3):
+    placement by binary search over the contig starts (SE and PE); the finalize kernels keep the table in LDS up to 1024 sequences
+    and read it from global memory beyond"""
     from bitmapperbs_amd import synth, mapper
     names, chroms = synth.make_genome(1_200_000 * n_contigs // 500, n_contigs, seed=611)
     fa = str(tmp_path / "contigs.fa")
     synth.write_fasta(fa, names, chroms)
-    mapper.Index.build(fa, fa, threads=8)
+    if n_contigs > 5000:
+        mapper.Index.build(fa, fa, threads=8, device=0)
+    else:
+        mapper.Index.build(fa, fa, threads=8)
     ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
     r = synth.make_reads_se(chroms, n=30000, L=100, seed=612, sub=0.02, indel=0.002, qual="random", n_rate=0.002)
     m = mapper.Mapper(ix, 0, e_f=0.08)
@@ -884,7 +888,9 @@ def test_many_contigs_match_oracle(tmp_path, n_contigs):
     recs, ost, cnt = oix.map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 100)
     assert not compare_records(res, pool, recs, 100)
     assert (m.stats() == ost).all()
-    assert len(set(int(x) for x in res["chrom"][res["status"] == 1])) > 0.6 * n_contigs          # the reads really land on many contigs
+    assert len(set(int(x) for x in res["chrom"][res["status"] == 1])) > 0.4 * min(n_contigs, 30000)          # the reads really land on many contigs
+    if n_contigs > 32767:
+        assert int(res["chrom"][res["status"] == 1].max()) > 32767
     m.close()
     m1, m2 = synth.make_reads_pe(chroms, n=10000, L=100, seed=613, sub=0.02, indel=0.002, qual="random")
     m = mapper.Mapper(ix, 0)
@@ -1147,7 +1153,7 @@ def test_device_sam_text_odd_input(env):
 
 @pytest.mark.parametrize("kind,name,nparts,mode", [
     ("se", "b150", 3, "plain"), ("pe", "p100", 4, "plain"), ("pe", "s100", 2, "names_differ"), ("pe", "p150", 3, "no_names"),
-    ("se", "e75", 2, "gz"), ("pe", "p75", 3, "bam"),
+    ("se", "e75", 2, "gz"), ("pe", "p75", 3, "bam"), ("pe", "p100", 2, "bgzf"), ("se", "b150", 3, "bgzf"),
 ])
 def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, nparts, mode, tmp_path):
     """--out-parts N: the input is cut into N record ranges (pairs: at the same record in both files, found by the read names, or by
@@ -1164,6 +1170,9 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
         gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % name), fq)
         if mode == "gz":
             shutil.copy(os.path.join(GOLD, "se_%s.fq.gz" % name), fq + ".gz"); fq += ".gz"
+        if mode == "bgzf":              # bgzip-style input: independent blocks, inflated by several threads
+            from common import write_bgzf
+            write_bgzf(fq + ".gz", open(fq, "rb").read(), block=7000); fq += ".gz"
         inp = ["--seq", fq]; args = golden_args()[name]
     else:
         f1 = str(tmp_path / "1.fq"); f2 = str(tmp_path / "2.fq")
@@ -1180,6 +1189,10 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
                 for i in range(0, len(t) - 1, 4):
                     t[i] = b"@same"
                 open(f, "wb").write(b"\n".join(t))
+        if mode == "bgzf":
+            from common import write_bgzf
+            write_bgzf(f1 + ".gz", open(f1, "rb").read(), block=9000); write_bgzf(f2 + ".gz", open(f2, "rb").read(), block=65000)
+            f1 += ".gz"; f2 += ".gz"
         inp = ["--seq1", f1, "--seq2", f2]; args = pe_golden_args()[name]
     if mode == "bam":
         args = args + ["--bam"]
@@ -1189,7 +1202,7 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
                          capture_output=True, text=True)
     assert par.returncode == 0, par.stderr
     parts = [open(out + ".p.part%03d" % i, "rb").read() for i in range(nparts)]
-    if mode != "gz":
+    if mode not in ("gz", "bgzf"):
         assert all(len(x) > 0 for x in parts[1:])         # every part got its share
     if mode == "bam":
         from common import bam_payload
@@ -1199,7 +1212,7 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
     else:
         strip = lambda b: b"".join(l for l in b.splitlines(keepends=True) if not l.startswith(b"@PG"))
         assert strip(b"".join(parts)) == strip(open(out, "rb").read())
-        if mode in ("plain", "gz"):
+        if mode in ("plain", "gz", "bgzf"):
             ref = gzip.open(os.path.join(GOLD, "%s_%s.ref.sam.gz" % (kind, name)), "rb").read()
             assert strip(b"".join(parts)) == ref
     st = lambda p: "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
