@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=None, help="reads / pairs timed on the host CPU baseline (rank 0, N=1)")
     ap.add_argument("--cpu-threads", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-single-lane", action="store_true", help="skip the extra single-lane pass that times the kernels alone")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1] SE line, stress keys)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S)
     ap.add_argument("--host-index", action="store_true", help="build the index with the host builder (bmbs_index_build)")
@@ -801,6 +802,27 @@ def main():
 
     dt, passes, kern_ms = timed(job, args.steps, args.warmup, args.min_seconds, world, dist, torch, cdev)
     stats = torch.from_numpy(m.stats()).to(cdev)
+    # The same launches once more on ONE lane (a context of its own on the same index, BMBS_LANES=1, outside the timed region): with
+    # two lanes the kernels of two chunks share the chip, so a kernel's own duration -- the roofline's denominator -- is longer than
+    # it is alone although the job is faster; this gives the duration alone beside it.  Rank 0, N = 1 only.
+    single = None
+    if world == 1 and not args.no_single_lane and os.environ.get("BMBS_LANES", "2") != "1":
+        old_l = os.environ.get("BMBS_LANES")
+        os.environ["BMBS_LANES"] = "1"
+        try:
+            m1 = mapper.Mapper(ix, device=local, share=m, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0)
+        finally:
+            if old_l is None:
+                os.environ.pop("BMBS_LANES", None)
+            else:
+                os.environ["BMBS_LANES"] = old_l
+        keep = job.m
+        job.m = m1
+        dt1, p1, k1 = timed(job, 2, 1, 0.0, 1, None, torch, cdev)
+        job.m = keep
+        single = {"ms_per_launch": round(dt1 / (2 * p1 * len(job.batches)) * 1e3, 3), "value": round(job.reads_per_step() * 2 * p1 / dt1 / 1e6, 2), "kernels_ms": k1,
+                  "counters": m1.counters()}
+        m1.close()
     tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -855,6 +877,12 @@ def main():
                                                   "model": "8 B/lookup (outcome-table entry) + 16 B packed row + 16 B seed record per seed start, 32 B/extension, 4|8 B/SA read"}
                                                  if dom in nat and kern_ms.get(dom, 0) > 0 else None),
                          "traffic_rule": fetch_rule(dom)[0], "traffic_profile": tag,
+                         # the same kernel timed ALONE (one lane, same launches, outside the timed region): what round 2's figure was
+                         "single_lane": ({"avg_launch_ms": round(single["kernels_ms"].get(dom, 0.0), 4),
+                                          "achieved": round(s8d.get(dom, 0) / (single["kernels_ms"][dom] * 1e-3) / 1e9, 3),
+                                          "frac": round(s8d.get(dom, 0) / (single["kernels_ms"][dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                          "value_M_reads_s": single["value"], "ms_per_launch": single["ms_per_launch"]}
+                                         if single and single["kernels_ms"].get(dom, 0) > 0 else None),
                          "traffic_over_algorithmic": round(traffic / b8, 3) if traffic and b8 else None,
                          # the same kernel against the bound that applies to an index walk: divergent gather requests/s
                          "gather": gather_roofline(dom, cnt, kern_ms),

@@ -64,6 +64,7 @@ struct Knobs {
     int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
+    bool pef_long = true;       // BMBS_PEF_LONG=0: k_pe_filter_pairs walks every pair's lists with one lane (round 2)
     bool copy_streams = true;   // BMBS_COPY_STREAMS=0: the text calls' copies go on the lane's kernel stream
     bool copy_lock = true;      // BMBS_COPY_LOCK=0: the text calls of different contexts copy at the same time
     bool arena = true;          // BMBS_ARENA=0: every work buffer a hipMalloc of its own (round 2)
@@ -91,6 +92,7 @@ struct Knobs {
         arena = !is(getenv("BMBS_ARENA"), "0");
         copy_lock = !is(getenv("BMBS_COPY_LOCK"), "0");
         copy_streams = !is(getenv("BMBS_COPY_STREAMS"), "0");
+        pef_long = !is(getenv("BMBS_PEF_LONG"), "0");
     }
 };
 
@@ -1280,7 +1282,16 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     };
     if (!sensitive) {
         prof_begin(c, "k_pe_filter_pairs");
-        hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B);
+        // pairs with long candidate lists (repeats) are left to a second kernel, one wave per pair (BMBS_PEF_LONG=0: all in the first)
+        u32* pef_flag = c->kn.pef_long ? c->long_flag.as<u32>() : nullptr;
+        if (pef_flag) HIPCHK(c, hipMemsetAsync(pef_flag, 0, n * 4, c->stream));
+        hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B, pef_flag);
+        if (pef_flag) {
+            rc = scan_u32(c, pef_flag, n, c->long_off.as<u64>(), 12, c->long_list.as<u32>());
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_pe_filter_pairs_long, dim3((unsigned)std::min<u64>(n, 65536)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, c->totals.as<u64>() + 12,
+                               c->long_list.as<u32>(), A, B);
+        }
         prof_end(c);
         rc = verify_round(1, tot, "k_filter_pe_r1", "k_pe_compact_r1");
         if (rc) return rc;

@@ -246,8 +246,9 @@ struct Source {
             }
             if (zfd >= 0) ::close(zfd);
             if (bgzf) {
-                live_inflaters = std::max(1, gz_threads);
-                for (int t = 0; t < live_inflaters; t++)
+                const int n_inflaters = std::max(1, gz_threads);
+                live_inflaters = n_inflaters;                   // (the threads count it down as they finish: not the loop bound)
+                for (int t = 0; t < n_inflaters; t++)
                     inflaters.emplace_back([this] {
                         z_stream zs; memset(&zs, 0, sizeof zs);
                         inflateInit2(&zs, -15);
@@ -683,6 +684,36 @@ struct Part {                                    // one contiguous record range 
 
 }  // namespace
 
+#ifdef BMBS_SOURCE_TEST
+// reader self-test (no GPU): bmbs_reader_test <file> <window bytes> <threads> -- the text the driver's reader hands on, window by
+// window, to stdout; what is left of a window behind its last complete record is carried into the next one as in the real pipeline
+int main(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    Source s;
+    const size_t cap = (size_t)atol(argv[2]);
+    if (!s.open(argv[1], 0, ~(size_t)0, atoi(argv[3]))) { fprintf(stderr, "cannot open\n"); return 1; }
+    Pool pool(3);
+    std::vector<char> buf(cap + 64 + ((size_t)64 << 20));
+    std::vector<uint32_t> counts;
+    for (;;) {
+        size_t n = 0; bool last = false;
+        const size_t want = std::max(cap, s.carry.size() + 1024);
+        if (!s.window(pool, buf.data(), want, n, last, counts)) { fprintf(stderr, "%s\n", s.err.c_str()); return 1; }
+        size_t lines = 0;
+        for (uint32_t c : counts) lines += c;
+        const size_t nrec = lines / 4;
+        if (nrec == 0 && !last) { fprintf(stderr, "record larger than the window\n"); return 1; }
+        const size_t used = nrec ? after_kth_nl_blocks(buf.data(), n, counts, nrec * 4) : 0;
+        fwrite(buf.data(), 1, used, stdout);
+        s.consumed(buf.data(), n, used);
+        if (last && used == n) break;
+        if (last && nrec == 0) break;
+    }
+    s.close();
+    return 0;
+}
+#else
 int main(int argc, char** argv)
 {
     bmbs_params P; bmbs_default_params(&P);
@@ -690,7 +721,7 @@ int main(int argc, char** argv)
     int device = 0, io_threads = 0, contexts = 4, parts = 1, reader_threads = 0;
     std::vector<int> devices;
     long batch = 500000;
-    bool verbose = false, unmapped_out = false, pbat = false, bam = false;
+    bool verbose = false, unmapped_out = false, pbat = false, bam = false, print_parts = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -726,6 +757,7 @@ int main(int argc, char** argv)
         else if (a == "--contexts") contexts = atoi(val());
         else if (a == "--batch") batch = atol(val());
         else if (a == "--out-parts") parts = atoi(val());
+        else if (a == "--print-parts") print_parts = true;                   // the record ranges --out-parts would use, then exit (no GPU needed: tests)
         else if (a == "--reader-threads") reader_threads = atoi(val());     // pread threads per part (default: -t / (2 x parts))
         else if (a == "--verbose") verbose = true;
         else if (a == "--unmapped_out") unmapped_out = true;          // Process_CommandLines.cpp:104-105
@@ -771,6 +803,30 @@ int main(int argc, char** argv)
     const bool gz_in = Source::is_gz(in1.c_str()) || (pe && Source::is_gz(seq2.c_str()));
     // a .gz stream cannot be entered in the middle: everything goes through part 0, the other part files stay empty
     const int live_parts = gz_in ? 1 : parts;
+    // where the parts begin: byte offsets of record starts, the same record in both files of a pair (plain files; a .gz stream cannot
+    // be entered in the middle)
+    auto compute_cuts = [&](std::vector<size_t>& cut1, std::vector<size_t>& cut2) -> bool {
+        cut1.assign((size_t)live_parts + 1, 0); cut2.assign((size_t)live_parts + 1, 0);
+        if (gz_in) { cut1[1] = cut2[1] = ~(size_t)0; return true; }
+        Pool pool(std::max(1, io_threads / 2) - 1);
+        const int fd1 = ::open(in1.c_str(), O_RDONLY), fd2 = pe ? ::open(seq2.c_str(), O_RDONLY) : -1;
+        struct stat sb1, sb2;
+        if (fd1 < 0 || fstat(fd1, &sb1) || (pe && (fd2 < 0 || fstat(fd2, &sb2)))) return false;
+        const size_t size1 = (size_t)sb1.st_size, size2 = pe ? (size_t)sb2.st_size : 0;
+        cut1[(size_t)live_parts] = size1; cut2[(size_t)live_parts] = size2;
+        for (int p = 1; p < live_parts; p++) {
+            cut1[(size_t)p] = std::max(cut1[(size_t)p - 1], record_start_at(fd1, size1, (size_t)((double)size1 * p / live_parts)));
+            if (pe) cut2[(size_t)p] = std::max(cut2[(size_t)p - 1], mate_boundary(pool, fd1, size1, cut1[(size_t)p], fd2, size2));
+        }
+        ::close(fd1); if (fd2 >= 0) ::close(fd2);
+        return true;
+    };
+    if (print_parts) {
+        std::vector<size_t> cut1, cut2;
+        if (!compute_cuts(cut1, cut2)) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
+        for (int p = 0; p <= live_parts; p++) printf("%d\t%zu\t%zu\n", p, cut1[(size_t)p], cut2[(size_t)p]);
+        return 0;
+    }
     // the drivers' contexts run one batch at a time each: one lane per context is enough (BMBS_LANES is only read by bmbs_create)
     setenv("BMBS_LANES", "1", 0);
     const int n_ctx = (int)devices.size() * contexts;
@@ -849,20 +905,8 @@ int main(int argc, char** argv)
     std::vector<std::unique_ptr<Part>> P_(static_cast<size_t>(parts));
     for (int p = 0; p < parts; p++) { P_[(size_t)p].reset(new Part()); P_[(size_t)p]->id = p; }
     {
-        std::vector<size_t> cut1((size_t)live_parts + 1, 0), cut2((size_t)live_parts + 1, 0);
-        if (!gz_in) {
-            Pool pool(std::max(1, io_threads / 2) - 1);
-            const int fd1 = ::open(in1.c_str(), O_RDONLY), fd2 = pe ? ::open(seq2.c_str(), O_RDONLY) : -1;
-            struct stat sb1, sb2;
-            if (fd1 < 0 || fstat(fd1, &sb1) || (pe && (fd2 < 0 || fstat(fd2, &sb2)))) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
-            const size_t size1 = (size_t)sb1.st_size, size2 = pe ? (size_t)sb2.st_size : 0;
-            cut1[(size_t)live_parts] = size1; cut2[(size_t)live_parts] = size2;
-            for (int p = 1; p < live_parts; p++) {
-                cut1[(size_t)p] = std::max(cut1[(size_t)p - 1], record_start_at(fd1, size1, (size_t)((double)size1 * p / live_parts)));
-                if (pe) cut2[(size_t)p] = std::max(cut2[(size_t)p - 1], mate_boundary(pool, fd1, size1, cut1[(size_t)p], fd2, size2));
-            }
-            ::close(fd1); if (fd2 >= 0) ::close(fd2);
-        } else { cut1[1] = cut2[1] = ~(size_t)0; }
+        std::vector<size_t> cut1, cut2;
+        if (!compute_cuts(cut1, cut2)) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
         for (int p = 0; p < live_parts; p++) {
             Part& pt = *P_[(size_t)p];
             const int zt = std::max(1, io_threads / (pe ? 4 : 2));          // BGZF input: inflate threads per file
@@ -1108,3 +1152,4 @@ int main(int argc, char** argv)
     if (verbose) fprintf(stderr, "[bmbs_search] teardown: unpin %.3fs, destroy ctx %.3fs, free index %.3fs\n", t1 - t0, t2 - t1, now() - t2);
     return 0;
 }
+#endif

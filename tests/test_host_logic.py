@@ -169,3 +169,83 @@ def test_bench_configs_match_baseline_json():
     assert "150bp PE" in base["metric"] and "50 M synthetic 150 bp PE reads vs GRCh38" in base["configs"][2]
     a1 = b.parse(["--config", "1"])
     assert not a1.cfg["pe"] and a1.cfg["units"] == 10_000_000 and abs(a1.cfg["e"] - 0.04) < 1e-12
+
+
+def _fastq(path, names, lens, rng, at_quals=False):
+    with open(path, "wb") as f:
+        for nm, L in zip(names, lens):
+            seq = bytes(rng.choice(list(b"ACGT"), L).tolist())
+            q = bytearray(rng.integers(35, 74, L).astype("u1").tobytes())
+            if at_quals and L > 1:
+                q[0] = ord("@") if rng.random() < 0.5 else ord("+")       # quality lines that begin like a header / separator line
+            f.write(b"@" + nm + b"\n" + seq + b"\n+\n" + bytes(q) + b"\n")
+
+
+@pytest.mark.parametrize("mode", ["names", "repeated_names", "se"])
+def test_out_parts_cut_points_are_the_same_record_in_both_files(tmp_path, mode):
+    """bmbs_search --out-parts: the input is cut at record starts, pairs at the SAME record in both files -- found by the read names,
+    by counting lines when names repeat; quality lines that begin with '@' or '+' must not be mistaken for headers (host logic: the
+    driver prints the cut points and exits before it would need a GPU)"""
+    import subprocess
+    drv = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
+    if not os.path.exists(drv):
+        pytest.skip("bmbs_search not built")
+    rng = np.random.default_rng(17)
+    n = 60000
+    l1 = rng.integers(30, 151, n); l2 = rng.integers(30, 151, n)
+    if mode == "repeated_names":
+        names = [b"same" for _ in range(n)]
+    else:
+        names = [b"r%d:%d" % (i, int(rng.integers(0, 1 << 30))) for i in range(n)]
+    f1 = str(tmp_path / "a_1.fq"); f2 = str(tmp_path / "a_2.fq")
+    _fastq(f1, [x + b" 1:N:0" for x in names], l1, rng, at_quals=True)
+    _fastq(f2, [x + b" 2:N:0:" + b"X" * (i % 13) for i, x in enumerate(names)], l2, rng, at_quals=True)
+    parts = 7
+    inp = ["--seq", f1] if mode == "se" else ["--seq1", f1, "--seq2", f2]
+    p = subprocess.run([drv, "--search", "unused", "--print-parts", "--out-parts", str(parts), "-t", "4"] + inp, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    rows = [tuple(int(x) for x in l.split()) for l in p.stdout.splitlines()]
+    assert len(rows) == parts + 1 and rows[0][1:] == (0, 0)
+    t1 = open(f1, "rb").read(); t2 = open(f2, "rb").read()
+    assert rows[-1][1] == len(t1)
+    starts1 = np.concatenate([[0], np.cumsum(1 + np.array([len(x) for x in names]) + len(b" 1:N:0") + 1 + l1 + 3 + l1 + 1)])
+    prev = -1
+    for k, c1, c2 in rows[1:-1]:
+        rec = int(np.searchsorted(starts1, c1))
+        assert starts1[rec] == c1, "cut %d of file 1 is not a record start" % k
+        assert rec > prev and 0.5 * n * k / parts < rec < 1.5 * n * k / parts + 10          # roughly even, strictly increasing
+        prev = rec
+        if mode != "se":
+            # the same record index in file 2
+            assert t2[:c2].count(b"\n") == 4 * rec, "cut %d: file 2 is not at the record file 1 is at" % k
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf_small_blocks", "bgzf_big_blocks"])
+def test_driver_reader_hands_on_every_record_once(tmp_path, kind):
+    """the FASTQ reader of bmbs_search on its own (bmbs_reader_test: no GPU): whatever the window size, the input format (plain
+    text, one-member gzip inflated by one thread, bgzip-style blocks inflated by several threads in parallel) and the number of
+    threads, the windows' whole records concatenate to the input text; an unterminated last line gets its newline"""
+    import gzip
+    import subprocess
+    from common import write_bgzf
+    exe = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_reader_test")
+    if not os.path.exists(exe):
+        pytest.skip("bmbs_reader_test not built")
+    rng = np.random.default_rng(5)
+    n = 20000
+    f = str(tmp_path / "r.fq")
+    _fastq(f, [b"r%d extra" % i for i in range(n)], rng.integers(20, 200, n), rng, at_quals=True)
+    raw = open(f, "rb").read()
+    for trunc in (False, True):
+        text = raw[:-1] if trunc else raw                       # without the final newline
+        src = str(tmp_path / ("t%d" % trunc))
+        if kind == "plain":
+            open(src, "wb").write(text)
+        elif kind == "gzip":
+            open(src, "wb").write(gzip.compress(text, 1))
+        else:
+            write_bgzf(src, text, block=3000 if kind == "bgzf_small_blocks" else 65000)
+        for window, threads in ((5000, 1), (70000, 3), (1 << 20, 8), (1 << 26, 16)):
+            p = subprocess.run([exe, src, str(window), str(threads)], capture_output=True, timeout=120)
+            assert p.returncode == 0, p.stderr
+            assert p.stdout == raw, (kind, trunc, window, threads, len(p.stdout), len(raw))

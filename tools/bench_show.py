@@ -7,6 +7,7 @@ r = d["roofline"]
 print("value %.1f M reads/s  ms/step %.1f  wall %.0f s" % (d["value"], d["ms_per_step"], d.get("wall_s", 0)))
 print("roofline %s frac %.3f (native %s) traffic %s x%s rule=%s" % (r["kernel"], r["frac"], (r.get("design_native_model") or {}).get("frac"), r.get("traffic"),
                                                                     r.get("traffic_over_algorithmic"), r.get("traffic_rule")))
+print("single_lane", r.get("single_lane"))
 print("cpu_baseline", (d.get("cpu_baseline") or {}).get("value"), "sam identical", d.get("sample_sam_identical_to_reference"))
 e = d.get("e2e", {})
 print("host_buffers_overlapped", json.dumps(e.get("host_buffers_overlapped")))

@@ -11,7 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --config $CFG > $O/bench.json 2> $O/bench.err
 Q="--config $CFG --no-cpu --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $Q > $O/bench_under_rocprof.json 2>/dev/null
-P="$Q --steps 1 --warmup 1 --min-seconds 0"
+# the counter passes run the call on ONE lane (BMBS_LANES=1): a kernel's last dispatch is then the whole launch, as the algorithmic bytes of
+# the bench line are; the counters of a kernel do not depend on what runs beside it
+export BMBS_LANES=1
+P="$Q --steps 1 --warmup 1 --min-seconds 0 --no-single-lane --launches 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $P > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py $P > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py $P > /dev/null 2>&1
