@@ -64,7 +64,7 @@ struct Knobs {
     int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
-    bool pef_long = true;       // BMBS_PEF_LONG=0: k_pe_filter_pairs walks every pair's lists with one lane (round 2)
+    int pef_long = 1;           // BMBS_PEF_LONG: 0 k_pe_filter_pairs walks every pair's lists with one lane (round 2), 1 long lists get a wave when the input is repeat-rich, 2 always
     bool copy_streams = true;   // BMBS_COPY_STREAMS=0: the text calls' copies go on the lane's kernel stream
     bool copy_lock = true;      // BMBS_COPY_LOCK=0: the text calls of different contexts copy at the same time
     bool arena = true;          // BMBS_ARENA=0: every work buffer a hipMalloc of its own (round 2)
@@ -92,7 +92,7 @@ struct Knobs {
         arena = !is(getenv("BMBS_ARENA"), "0");
         copy_lock = !is(getenv("BMBS_COPY_LOCK"), "0");
         copy_streams = !is(getenv("BMBS_COPY_STREAMS"), "0");
-        pef_long = !is(getenv("BMBS_PEF_LONG"), "0");
+        if ((e = getenv("BMBS_PEF_LONG"))) pef_long = atoi(e);
     }
 };
 
@@ -172,7 +172,7 @@ struct Lane {
     u64 h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // ---- launches without host round trips: what the stages of earlier calls needed, per read (0: nothing known yet -> the
     // first call of a lane waits for its counts); the pinned words the device leaves its counts and guard flags in; the call in flight
-    double lr_cand = 0, lr_sw = 0, lr_rcand = 0;
+    double lr_cand = 0, lr_sw = 0, lr_rcand = 0, lr_long = 0;
     u64* h_tot = nullptr;                      // page-locked: per call in flight, totals[16] followed by the flag words (call_end)
     std::deque<Pending> inflight;
     int next_slot = 0;
@@ -719,7 +719,9 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         }
         // long reads (up to 25 seeds): lists of 17..32 candidates are the rule, not the repeat case -- they get a kernel of their
         // own (k_vote_mid); its flag and list live in the seeding work-list buffers, free by now
-        const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !c->kn.vote_nomid;
+        // ... and on a repeat-rich genome also for short reads (seeds with many hits): taken when the last call left more than 0.5 % of
+        // its reads to the long-list kernels (a wave per read)
+        const bool use_mid = (gm.L / 10 - 1 > VOTE_REG || c->lr_long > 0.005) && !c->kn.vote_nomid;
         u32* mid_flag = use_mid ? c->sd_flag_c.as<u32>() : nullptr;
         if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n * 4, c->stream));
         hipLaunchKernelGGL(k_vote_fused, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, st, c->cand.as<u64>(),
@@ -1235,7 +1237,8 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     ENS(c, c->long_flag, n2 * 4); ENS(c, c->long_off, (n2 + 1) * 8); ENS(c, c->long_list, n2 * 4);
     // reads of 180 bases and more place up to 25 seeds: lists of 17..32 candidates are the rule there and get a kernel of their own
     // (k_vote_pe_mid; buffers of its own: --sensitive still reads the seeding flags afterwards)
-    const bool use_mid = gm.L / 10 - 1 > VOTE_REG && !c->kn.vote_nomid;
+    // (on a repeat-rich genome also for short reads: when the last call left more than 0.5 % of its reads to the long-list kernels)
+    const bool use_mid = (gm.L / 10 - 1 > VOTE_REG || c->lr_long > 0.005) && !c->kn.vote_nomid;
     if (use_mid) { ENS(c, c->pe_mid_flag, n2 * 4); ENS(c, c->pe_mid_list, n2 * 4); }
     u32* mid_flag = use_mid ? c->pe_mid_flag.as<u32>() : nullptr;
     if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n2 * 4, c->stream));
@@ -1282,8 +1285,10 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     };
     if (!sensitive) {
         prof_begin(c, "k_pe_filter_pairs");
-        // pairs with long candidate lists (repeats) are left to a second kernel, one wave per pair (BMBS_PEF_LONG=0: all in the first)
-        u32* pef_flag = c->kn.pef_long ? c->long_flag.as<u32>() : nullptr;
+        // pairs with long candidate lists (repeats) are left to a second kernel, one wave per pair -- on repeat-rich input only (the last
+        // call left more than 0.5 % of its reads to the long-list vote kernels): flag array, scan and the extra launch cost 0.3 ms per
+        // 10 M pairs, 4 % of a launch on a repeat-poor genome.  BMBS_PEF_LONG=0: never, =2: always
+        u32* pef_flag = (c->kn.pef_long == 2 || (c->kn.pef_long == 1 && c->lr_long > 0.005)) ? c->long_flag.as<u32>() : nullptr;
         if (pef_flag) HIPCHK(c, hipMemsetAsync(pef_flag, 0, n * 4, c->stream));
         hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B, pef_flag);
         if (pef_flag) {
@@ -1432,6 +1437,7 @@ int lane_settle(Lane* c)
                     c->lr_cand = std::max(c->lr_cand, std::max(1e-9, (double)t[0] / nr));
                     c->lr_sw = std::max(c->lr_sw, (double)t[2] / nr);
                     c->lr_rcand = std::max(c->lr_rcand, (double)t[8] / nr);
+                    c->lr_long = ((double)t[9] + (double)t[11]) / nr;             // reads whose candidate lists went to the mid / long kernels
                 }
                 c->last_total_cand = t[0]; c->last_n_jobs = t[1];
                 prof_collect(c, P.slot);
@@ -1468,9 +1474,9 @@ int lane_enqueue(Lane* c, Pending P, bool staged)
 // what earlier calls needed per read is shared by the lanes of a context
 void share_needs(bmbs_ctx* X)
 {
-    double a = 0, b = 0, d = 0;
-    for (Lane* c : X->lanes) { a = std::max(a, c->lr_cand); b = std::max(b, c->lr_sw); d = std::max(d, c->lr_rcand); }
-    for (Lane* c : X->lanes) { c->lr_cand = a; c->lr_sw = b; c->lr_rcand = d; }
+    double a = 0, b = 0, d = 0, g = 0;
+    for (Lane* c : X->lanes) { a = std::max(a, c->lr_cand); b = std::max(b, c->lr_sw); d = std::max(d, c->lr_rcand); g = std::max(g, c->lr_long); }
+    for (Lane* c : X->lanes) { c->lr_cand = a; c->lr_sw = b; c->lr_rcand = d; c->lr_long = g; }
 }
 
 int settle_all(bmbs_ctx* X)

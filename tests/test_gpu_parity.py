@@ -1275,3 +1275,20 @@ def test_true_size_wide_index_matches_oracle(wide_env, monkeypatch):
         assert not compare_pe(res, pool, recs, 150)
         assert (m.stats() == ost).all()
         m.close()
+
+
+@pytest.mark.parametrize("sensitive", [0, 1])
+def test_long_list_kernels_forced_on_pairs(env, monkeypatch, sensitive):
+    """k_pe_filter_pairs_long (a wave per pair whose candidate lists are long) forced for every pair above the threshold
+    (BMBS_PEF_LONG=2), with a minimum insert that makes the hit rule order-dependent (lane 0 keeps the reference's loop) and
+    without; on the second call the mid-list vote kernel is on as well (the first call told the context that the input is repeat-rich)"""
+    from bitmapperbs_amd import synth, mapper
+    monkeypatch.setenv("BMBS_PEF_LONG", "2")
+    for prm in (dict(), dict(min_ins=260, max_ins=700)):
+        m1, m2 = synth.make_reads_pe(env["chroms"], n=12000, L=100, seed=991 + sensitive, sub=0.03, indel=0.002, qual="random", ins_hi=680)
+        m = mapper.Mapper(env["ix"], 0, sensitive=sensitive, **prm)
+        for rep in range(2):
+            res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+            recs, ost, _ = env["oix"].map_pe(orc.params(sensitive=sensitive, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+            assert not compare_pe(res, pool, recs, 100), (prm, rep)
+        m.close()
