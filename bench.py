@@ -309,6 +309,10 @@ FETCH_RULE = {
 }
 
 
+# kernel name in the rocprofv3 CSV -> the label its launches carry in the HIP-event profile (and in the algorithmic-byte tables)
+PROF_NAME = {"k_pe_prepare_p": "k_pe_prepare", "k_seed_decide_p": "k_seed_decide", "k_align_sw2": "k_align_sw", "k_align_ungapped_p": "k_align_ungapped"}
+
+
 def fetch_rule(kernel):
     r = FETCH_RULE.get(kernel.split("<")[0], "raw")
     return r, (2.0 if r == "x2" else 1.0)
@@ -893,7 +897,7 @@ def main():
             # PMC traffic per launch of every mapping kernel (committed profile of this command), FETCH_SIZE corrected by the rule named,
             # next to the kernel's 8(d) algorithmic bytes
             "kernels_traffic": {kn: {"fetch_plus_write_bytes": int(t[0] + t[1]), "rule": t[2],
-                                     "over_algorithmic": (round((t[0] + t[1]) / s8d[kn], 2) if s8d.get(kn) else None)}
+                                     "over_algorithmic": (round((t[0] + t[1]) / s8d[PROF_NAME.get(kn, kn)], 2) if s8d.get(PROF_NAME.get(kn, kn)) else None)}
                                 for kn, t in sorted(pmc_table(tag).items()) if kn.startswith("k_")},
             "counters_last_launch": cnt,
             "mapstats": {"reads_or_pairs": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),

@@ -146,6 +146,7 @@ struct Lane {
     // host-variant staging
     DevBuf in_seq, in_qual, out_res, cig_pool, in_a, in_b, in_c, in_d, in_len;
     DevBuf pe_mid_flag, pe_mid_list;                    // k_vote_pe_mid work list
+    DevBuf big_list;                                    // reads whose lists exceed the wave form of k_vote_[pe_]long
     DevBuf wavelog_buf, wavelog_count; std::string wavelog_path;    // BMBS_WAVELOG diagnostic
     DevBuf prow, prow_dirty;                            // packed copy of the read rows (k_pack_rows), one dirty byte per read
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
@@ -280,52 +281,42 @@ inline u64 cap_from(double need_per_read, u64 n_reads, u64 floor_, double scale 
     return c > floor_ ? c : floor_;
 }
 
-// MismatchPenaltyByQuality (ksw.h:148-161), evaluated here in IEEE double exactly as the reference
+// MismatchPenaltyByQuality (ksw.h:148-161): mp_min + (int)(min(Q - q_base, 40) / 40 * (mp_max - mp_min)), every step in IEEE double
+// as the reference evaluates it (the product is tabulated once per context: pen_lut)
 int mismatch_penalty(const bmbs_params& P, int Q)
 {
-    double Phred = Q - P.q_base;
-    if (Phred > 40) Phred = 40;
-    Phred = Phred / 40;
-    int r = Phred * (P.mp_max - P.mp_min);
-    return r + P.mp_min;
+    const double phred = std::min<double>(Q - P.q_base, 40.0) / 40;
+    return (int)(phred * (P.mp_max - P.mp_min)) + P.mp_min;
 }
 
-// MAP_Calculation (Schema.cpp:168-405) in the reference's double arithmetic; tabulated per k
+// MAP_Calculation (Schema.cpp:168-405) as data.  The reference's ladder of `if`s compares two ratios -- the runner-up's distance in
+// edits over the threshold (rank_error) and the winner's score above the worst admissible score over that range (rank) -- with
+// fixed cut points; the tables below are those cut points and the MAPQ each cell returns.  The ratios are formed and compared in
+// double exactly as there; the result is tabulated per threshold on the host (prepare_luts) and only looked up on the device.
 int map_calculation(const bmbs_params& P, unsigned second_best_diff, unsigned error_threshold, int best_score)
 {
-    int scoreMax = P.gap_open + P.gap_ext;
-    if (scoreMax < P.mp_max) scoreMax = P.mp_max;
-    scoreMax = -scoreMax * error_threshold;
-    int scoreMaxRange = -scoreMax;
-    int score_diff = best_score - scoreMax;
-    if (score_diff < 0) score_diff = 0;
-    int error_diff = second_best_diff;
-    if (second_best_diff > error_threshold) error_diff = error_threshold + 1;
-    double rank, rank_error;
-    if ((unsigned)error_diff > error_threshold) {
-        rank = (double)score_diff / (double)scoreMaxRange;
-        if (rank >= 0.8) return 42;
-        if (rank >= 0.7) return 40;
-        if (rank >= 0.6) return 24;
-        if (rank >= 0.5) return 23;
-        if (rank >= 0.4) return 8;
-        if (rank >= 0.3) return 3;
+    const int unit = std::max(P.gap_open + P.gap_ext, P.mp_max);
+    const int worst = -unit * (int)error_threshold;                 // scoreMax of the reference
+    const double rank = (double)std::max(best_score - worst, 0) / (double)(-worst);
+    const unsigned ediff = second_best_diff > error_threshold ? error_threshold + 1 : second_best_diff;
+    if (ediff > error_threshold) {
+        // no runner-up within the threshold: the score alone decides
+        static const struct { double at; int q; } alone[] = {{0.8, 42}, {0.7, 40}, {0.6, 24}, {0.5, 23}, {0.4, 8}, {0.3, 3}};
+        for (const auto& r : alone) if (rank >= r.at) return r.q;
         return 0;
     }
-    rank_error = (double)error_diff / (double)error_threshold;
-    rank = (double)score_diff / (double)scoreMaxRange;
-    const bool z = best_score == 0;
-    if (rank_error >= 0.9) return z ? 39 : 33;
-    if (rank_error >= 0.8) return z ? 38 : 27;
-    if (rank_error >= 0.7) return z ? 37 : 26;
-    if (rank_error >= 0.6) return z ? 36 : 22;
-    if (rank_error >= 0.5) return z ? 35 : rank >= 0.84 ? 25 : rank >= 0.68 ? 16 : 5;
-    if (rank_error >= 0.4) return z ? 34 : rank >= 0.84 ? 21 : rank >= 0.68 ? 14 : 4;
-    if (rank_error >= 0.3) return z ? 32 : rank >= 0.88 ? 18 : rank >= 0.67 ? 15 : 3;
-    if (rank_error >= 0.2) return z ? 31 : rank >= 0.88 ? 17 : rank >= 0.67 ? 11 : 0;
-    if (rank_error >= 0.1) return z ? 30 : rank >= 0.88 ? 12 : rank >= 0.67 ? 7 : 0;
-    if (error_diff == 0) return rank >= 0.67 ? 1 : 0;
-    return rank >= 0.67 ? 6 : 2;
+    const double rerr = (double)(int)ediff / (double)error_threshold;
+    const bool perfect = best_score == 0;
+    // rows: rank_error >= at; `zero` for a perfect winner, otherwise the first column whose rank cut is reached (hi, mid), else lo
+    static const struct { double at; int zero; double hi_cut; int hi; double mid_cut; int mid; int lo; } rows[] = {
+        {0.9, 39, 0.0, 33, 0.0, 33, 33}, {0.8, 38, 0.0, 27, 0.0, 27, 27}, {0.7, 37, 0.0, 26, 0.0, 26, 26}, {0.6, 36, 0.0, 22, 0.0, 22, 22},
+        {0.5, 35, 0.84, 25, 0.68, 16, 5}, {0.4, 34, 0.84, 21, 0.68, 14, 4},
+        {0.3, 32, 0.88, 18, 0.67, 15, 3}, {0.2, 31, 0.88, 17, 0.67, 11, 0}, {0.1, 30, 0.88, 12, 0.67, 7, 0},
+    };
+    for (const auto& r : rows)
+        if (rerr >= r.at) return perfect ? r.zero : rank >= r.hi_cut ? r.hi : rank >= r.mid_cut ? r.mid : r.lo;
+    // runner-up (almost) as good as the winner
+    return ediff == 0 ? (rank >= 0.67 ? 1 : 0) : (rank >= 0.67 ? 6 : 2);
 }
 
 int threshold_k(const bmbs_params& P, int L)
@@ -740,10 +731,14 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         prof_begin(c, "k_vote_long");
         int rl = scan_u32(c, c->long_flag.as<u32>(), n, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
         if (rl) return rl;
+        // the wave form (lists of up to 256 candidates) walks the list and hands the longer ones to a list of their own (slot 13)
+        ENS(c, c->big_list, n * 4 + 64);
+        unsigned long long* big_count = c->totals.as<unsigned long long>() + 13;
+        HIPCHK(c, hipMemsetAsync(big_count, 0, 8, c->stream));
         hipLaunchKernelGGL((k_vote_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
-                           c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
-        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
-                           c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
+                           c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->big_list.as<u32>(), big_count);
+        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
         prof_end(c);
     }
     return BMBS_OK;
@@ -849,7 +844,7 @@ void lane_destroy(Lane* c)
     c->arena.free_all();
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->h_info) (void)hipHostFree(c->h_info);
-    { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off};
+    { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list};
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
@@ -1256,10 +1251,13 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     prof_begin(c, "k_vote_pe_long");
     rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
     if (rc) return rc;
+    ENS(c, c->big_list, n2 * 4 + 64);
+    unsigned long long* big_count = c->totals.as<unsigned long long>() + 13;
+    HIPCHK(c, hipMemsetAsync(big_count, 0, 8, c->stream));
     hipLaunchKernelGGL((k_vote_pe_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A);
+                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A, c->big_list.as<u32>(), big_count);
     hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A);
+                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {

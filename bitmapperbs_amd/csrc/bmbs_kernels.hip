@@ -2026,6 +2026,60 @@ DEVI int vl_prefix(bool flag, int* sh_w, int& total)
     total = tot;
     return add + __popcll(m & ((1ull << lane) - 1));
 }
+// keys[0, nc) ascending, by the whole block, in place: stable 2-bit LSD passes.  Every thread owns E = ceil(nc / threads) consecutive
+// keys in registers; a pass counts its keys per digit (four 16-bit counters in one u64), one block-wide exclusive scan of that word
+// gives every key its destination.  nc <= 16 * blockDim.x.
+DEVI void vl_radix_sort(u64* keys, int nc)
+{
+    __shared__ u64 sh_scan[18];
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+    const int E = (nc + T - 1) / T;                     // <= 16
+    u64 mine[16];
+    // the bits that vary: OR of key ^ keys[0]
+    u64 diff = 0;
+    const u64 k0 = keys[0];
+    for (int i = tid; i < nc; i += T) diff |= keys[i] ^ k0;
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    if (lane == 0) sh_scan[w] = diff;
+    __syncthreads();
+    diff = 0;
+    for (int i = 0; i < nw; i++) diff |= sh_scan[i];
+    __syncthreads();
+    const int nbits = diff ? 64 - __builtin_clzll(diff) : 0;
+    for (int b = 0; b < nbits; b += 2) {
+        u64 cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int idx = tid * E + e;
+            if (e < E && idx < nc) { mine[e] = keys[idx]; cnt += 1ull << (16 * (int)((mine[e] >> b) & 3)); }
+        }
+        // block-wide exclusive scan of cnt (four packed counters: a digit's total is at most 4096 < 2^16)
+        u64 incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const u64 v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) sh_scan[w] = incl;
+        __syncthreads();
+        u64 wbase = 0, total = 0;
+        for (int i = 0; i < nw; i++) { const u64 x = sh_scan[i]; if (i < w) wbase += x; total += x; }
+        const u64 excl = wbase + incl - cnt;
+        // first slot of every digit: totals of the smaller digits
+        const u32 t0 = (u32)(total & 0xffff), t1 = (u32)((total >> 16) & 0xffff), t2 = (u32)((total >> 32) & 0xffff);
+        // (slot of the next key of digit d = totals of the smaller digits + this thread's share of the scan; kept in four scalars:
+        // an array indexed by the digit would live in scratch memory)
+        u32 r0 = (u32)(excl & 0xffff), r1 = t0 + (u32)((excl >> 16) & 0xffff), r2 = t0 + t1 + (u32)((excl >> 32) & 0xffff),
+            r3 = t0 + t1 + t2 + (u32)((excl >> 48) & 0xffff);
+        __syncthreads();                                // every key is in registers: the array may be overwritten
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int idx = tid * E + e;
+            if (e < E && idx < nc) {
+                const int d = (int)((mine[e] >> b) & 3);
+                const u32 r = d == 0 ? r0++ : d == 1 ? r1++ : d == 2 ? r2++ : r3++;
+                keys[r] = mine[e];
+            }
+        }
+        __syncthreads();
+    }
+}
 // locate the nc <= VL_CAP candidates of a read into keys[0, np2) (padded with ~0) and sort them ascending; returns np2
 DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u64* keys, u32* sh_pref)
 {
@@ -2044,6 +2098,10 @@ DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u
         keys[j] = key;
     }
     __syncthreads();
+    // long lists (a read inside a repeat family: up to 25 seeds x 1000 rows): LSD radix sort, two bits a pass over the bits that
+    // vary -- 17 passes of one block scan each for a 6.2 G text, where the bitonic network takes 78 stages of 8 sweeps over 4096
+    // keys.  On a GRCh38-like genome these lists were most of k_vote_pe_long's 11-13 ms per 10 M pairs.
+    if (np2 > 512 && blockDim.x >= 128) { vl_radix_sort(keys, nc); return np2; }
     for (int size = 2; size <= np2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
@@ -2231,7 +2289,8 @@ DEVI bool vl_sort_votes(bmbs_vk* items, int nv, void* scratch, int* sh_w, int* c
 template <int CAP, int BLOCK, int LO>
 __global__ void __launch_bounds__(BLOCK)
 k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
-            u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read)
+            u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read, u32* __restrict__ big_list,
+            unsigned long long* __restrict__ big_count)
 {
     __shared__ u64 keys[CAP];
     __shared__ u16 endpos[CAP];
@@ -2243,6 +2302,8 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
     for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
         const long r = list[item];
         const long nc = (long)st.n_cand[r];
+        // the wave form sees every listed read and passes the ones beyond its capacity on to a list of their own (see k_vote_pe_long)
+        if (big_list && CAP != VL_CAP && nc > CAP) { if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1ull)] = (u32)r; continue; }
         if (nc <= LO || (CAP != VL_CAP && nc > CAP)) continue;          // another instance's size class
         const int k = gm.rk(gm.rl(r));
         const u64 off = st.cand_off[r];
@@ -4118,7 +4179,7 @@ k_vote_pe_mid(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __r
 template <int CAP, int BLOCK, int LO>
 __global__ void __launch_bounds__(BLOCK)
 k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
-               PeCand* __restrict__ A)
+               PeCand* __restrict__ A, u32* __restrict__ big_list, unsigned long long* __restrict__ big_count)
 {
     __shared__ u64 keys[CAP];
     __shared__ u16 endpos[CAP];
@@ -4128,6 +4189,9 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
     for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
         const long r = list[item];
         const long nc = (long)st.n_cand[r];
+        // the wave form sees every listed read and passes the ones beyond its capacity on (a list of their own: the block form used
+        // to walk the whole list -- millions of reads on a repeat-rich genome, two dependent loads each -- to find its few)
+        if (big_list && nc > CAP) { if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1ull)] = (u32)r; continue; }
         if (nc <= LO || nc > CAP) continue;                          // another instance's size class
         const int L = gm.rl(r), k = gm.rk(L);
         const int v = st.verdict[r];

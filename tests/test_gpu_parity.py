@@ -1292,3 +1292,42 @@ def test_long_list_kernels_forced_on_pairs(env, monkeypatch, sensitive):
             recs, ost, _ = env["oix"].map_pe(orc.params(sensitive=sensitive, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
             assert not compare_pe(res, pool, recs, 100), (prm, rep)
         m.close()
+
+
+def test_very_long_candidate_lists_match_oracle(tmp_path):
+    """reads inside a family of 900 identical copies (and one of 600 copies at 2 % divergence): seeds that hit hundreds of rows each
+    give candidate lists of thousands -- the block form of the long-list kernels with its radix sort (lists beyond 512), the
+    wave-per-pair filter, lists beyond the 4096-candidate capacity on the single-lane fall-back; SE and pairs, first call and second
+    (which has the mid-list kernels on)"""
+    from bitmapperbs_amd import synth, mapper
+    names, chroms = synth.make_genome(2_000_000, 2, seed=1234)
+    rng = np.random.default_rng(4321)
+    for elen, copies, div in ((120, 900, 0.0), (200, 600, 0.02)):
+        el = synth._ACGT[rng.integers(0, 4, elen)]
+        for _ in range(copies):
+            ch = chroms[int(rng.integers(0, 2))]
+            p = int(rng.integers(0, ch.size - elen))
+            e = el.copy()
+            m_ = rng.random(elen) < div
+            e[m_] = synth._ACGT[rng.integers(0, 4, int(m_.sum()))]
+            ch[p:p + elen] = synth.revcomp(e) if rng.random() < 0.5 else e
+    fa = str(tmp_path / "rep.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=8)
+    ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
+    r = synth.make_reads_se(chroms, n=12000, L=150, seed=77, sub=0.01, indel=0.001, qual="random")
+    m = mapper.Mapper(ix, 0, e_f=0.08, ambiguous_out=1)
+    recs, ost, cnt = oix.map_se(orc.params(e_f=0.08, ambiguous_out=1), r["seq"], r["qual"], 150)
+    assert int(recs["n_cand"].max()) > 1000                     # the lists really get long
+    for rep in range(2):
+        res, pool = m.map_se(r["seq"], r["qual"], 150)
+        assert not compare_records(res, pool, recs, 150, amb=True), rep
+    m.close()
+    m1, m2 = synth.make_reads_pe(chroms, n=8000, L=150, seed=78, sub=0.01, indel=0.001, qual="random")
+    for sensitive in (0, 1):
+        m = mapper.Mapper(ix, 0, sensitive=sensitive)
+        recs, ost, _ = oix.map_pe(orc.params(sensitive=sensitive), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+        for rep in range(2):
+            res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+            assert not compare_pe(res, pool, recs, 150), (sensitive, rep)
+        m.close()
