@@ -893,6 +893,8 @@ def main():
                          "sectors": ({"traffic_GBps": round(traffic / (kern_ms[dom] * 1e-3) / 1e9, 1), "random_sector_ceiling_GBps": SECTOR_CEILING_GBS,
                                       "frac": round(traffic / (kern_ms[dom] * 1e-3) / 1e9 / SECTOR_CEILING_GBS, 4)} if traffic else None)},
             "kernels_ms_per_launch": {a: round(b, 4) for a, b in kern_ms.items()},
+            # the same table from the single-lane pass: each kernel alone on the chip (what a kernel change should be read against)
+            "kernels_ms_per_launch_single_lane": ({a: round(b, 4) for a, b in single["kernels_ms"].items()} if single else None),
             "kernels_algorithmic_GBps": {kn: round(s8d[kn] / (kern_ms[kn] * 1e-3) / 1e9, 2) for kn in s8d if kern_ms.get(kn, 0) > 0},
             # PMC traffic per launch of every mapping kernel (committed profile of this command), FETCH_SIZE corrected by the rule named,
             # next to the kernel's 8(d) algorithmic bytes

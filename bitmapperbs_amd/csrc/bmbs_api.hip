@@ -265,12 +265,11 @@ void prof_collect(Lane* c, int slot)
 int scan_u32(Lane* c, const u32* in, u64 n, u64* out, int slot, u32* list = nullptr, int nz = 0, const u64* n_dev = nullptr)
 {
     const u64 per = (u64)SCAN_BLOCK * SCAN_ITEMS;
-    const u64 nb = (n + per - 1) / per;
+    const u64 nb = n ? (n + per - 1) / per : 1;
     ENS(c, c->scan_tmp, (nb + 1) * 8);
     u64* bs = c->scan_tmp.as<u64>();
     hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, nz, n_dev);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, bs, nb, c->totals.as<u64>() + slot);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list, nz, n_dev);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list, nz, n_dev, c->totals.as<u64>() + slot);
     return BMBS_OK;
 }
 

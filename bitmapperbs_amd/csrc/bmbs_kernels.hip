@@ -477,9 +477,10 @@ DEVI int count_mism_p(const DevIndex& ix, const u64* row, int W, bool dirty, int
 // Fast path (every byte one of A C G T, the piece inside the read): a dozen 32-bit ops per four characters.
 DEVI void pack_piece(const uint4& v, int valid, u32& bases, u32& mask)
 {
+    // branch-free: the last piece of every row is ragged (L = 150: six characters), so every wave would take a per-character
+    // path beside the whole-piece one; the mask of the bad bytes is formed by SWAR instead and applied to all sixteen at once
     const u32 w[4] = {v.x, v.y, v.z, v.w};
-    u32 out = 0, anybad = 0;
-    u32 badw[4];
+    u32 out = 0, bad16 = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const u32 x = w[q];
@@ -488,28 +489,19 @@ DEVI void pack_piece(const uint4& v, int valid, u32& bases, u32& mask)
         c ^= (c >> 1) & 0x01010101u;
         // a byte that is not one of A C G T: rebuild the letter its bits 1-2 stand for and compare (as swar_code3)
         const u32 isT = (x >> 2) & ~(x >> 1) & 0x01010101u;
-        badw[q] = x ^ (0x41414141u | (x & 0x06060606u)) ^ (isT * 0x11u);
-        anybad |= badw[q];
+        const u32 b = x ^ (0x41414141u | (x & 0x06060606u)) ^ (isT * 0x11u);
+        u32 y = ((((b & 0x7f7f7f7fu) + 0x7f7f7f7fu) | b) & 0x80808080u) >> 7;      // 1 in bit 0 of every byte that differs
+        y = (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xfu;                         // the four bits side by side
+        bad16 |= y << (4 * q);
         u32 t = (c | (c >> 6)) & 0x000f000fu;
         t = (t | (t >> 12)) & 0xffu;
         out |= t << (8 * q);
     }
-    bases = out; mask = 0;
-    if (anybad == 0 && valid >= 16) return;
-    // slow path: per-character mask, characters beyond the read's end dropped
-    u32 m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int pos = 4 * q + j;
-            const bool in = pos < valid;
-            const bool bad = ((badw[q] >> (8 * j)) & 0xffu) != 0;
-            if (in && bad) m |= 1u << pos;
-            if (!in || bad) out &= ~(3u << (2 * pos));
-        }
-    }
-    bases = out; mask = m;
+    const u32 in16 = valid >= 16 ? 0xffffu : valid > 0 ? (1u << valid) - 1u : 0u;  // characters beyond the read's end are dropped
+    mask = bad16 & in16;
+    u32 k = in16 & ~bad16;                                                         // real bases -> both bits of their pair
+    k = (k | (k << 8)) & 0x00ff00ffu; k = (k | (k << 4)) & 0x0f0f0f0fu; k = (k | (k << 2)) & 0x33333333u; k = (k | (k << 1)) & 0x55555555u;
+    bases = out & (k | (k << 1));
 }
 
 // one thread per 16-byte piece of an ASCII row
@@ -685,7 +677,7 @@ __global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out, u64*
 }
 
 // ================================================================================================
-// scan (exclusive, u32 -> u64), three launches; not a hot kernel
+// scan (exclusive, u32 -> u64), two launches: tile sums, then every tile adds up the sums before it (L2 hits) and writes its part
 // ================================================================================================
 #define SCAN_BLOCK 256
 #define SCAN_ITEMS 8            // per thread
@@ -734,23 +726,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partial(const u32* in, u64 
     (void)block_scan_incl(s, sh, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
-// one block of 1024 threads: thread t owns a contiguous run of block sums, scanned serially, runs combined by one block scan
-__global__ void __launch_bounds__(1024) k_scan_blocks(u64* block_sums, u64 nb, u64* total)
-{
-    __shared__ u64 sh[16];
-    const u64 per = (nb + blockDim.x - 1) / blockDim.x;
-    const u64 a = (u64)threadIdx.x * per, b = a + per < nb ? a + per : nb;
-    u64 s = 0;
-    for (u64 i = a; i < b; i++) s += block_sums[i];
-    u64 tot;
-    const u64 incl = block_scan_incl(s, sh, tot);
-    u64 run = incl - s;
-    for (u64 i = a; i < b; i++) { const u64 v = block_sums[i]; block_sums[i] = run; run += v; }
-    if (threadIdx.x == 0) *total = tot;
-}
 // list != nullptr: `in` holds 0/1 flags and the positions of the ones are written, in order, to list[]; the offsets
 // themselves are not stored (the work lists of the seeding stages need nothing else)
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* block_sums, u64* out, u32* list, int nz, const u64* __restrict__ n_dev)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n, const u64* __restrict__ block_sums, u64* out, u32* list, int nz, const u64* __restrict__ n_dev, u64* total)
 {
     __shared__ u64 sh[SCAN_BLOCK / 64];
     if (n_dev) { const u64 nd = *n_dev; if (nd < n) n = nd; }
@@ -764,9 +742,15 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* in, u64 n,
     u64 s = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) s += x[j];
+    // what the tiles before this one hold: 256 threads over blockIdx.x sums
+    u64 before = 0;
+    for (u32 i = threadIdx.x; i < blockIdx.x; i += SCAN_BLOCK) before += block_sums[i];
+    u64 prefix;
+    (void)block_scan_incl(before, sh, prefix);
     u64 tot;
     const u64 incl = block_scan_incl(s, sh, tot);
-    u64 run = incl - s + block_sums[blockIdx.x];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = prefix + tot;
+    u64 run = incl - s + prefix;
     if (list) {
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n && x[j]) { list[run] = (u32)(base + j); run += x[j]; }

@@ -20,3 +20,6 @@ print("two_contexts", (d.get("two_contexts") or {}).get("value"), "three", (d.ge
 for k, v in (d.get("secondary") or {}).items():
     print("sec", k, v if isinstance(v, str) else (v.get("value"), v.get("top_kernels_ms")))
 print({k: round(v, 3) for k, v in d["kernels_ms_per_launch"].items()})
+if d.get("kernels_ms_per_launch_single_lane"):
+    k1 = d["kernels_ms_per_launch_single_lane"]
+    print("single lane:", {k: round(v, 3) for k, v in sorted(k1.items(), key=lambda x: -x[1])}, "sum %.2f" % sum(k1.values()))
