@@ -631,7 +631,7 @@ def host_buffer_rate(m, job, torch):
     up = nbytes * len(pin) * reps
     down = nrec * 32 * reps + int(used.value) * 4 * reps
     LINK = 56.0           # GB/s one direction, page-locked, measured on these boxes (tools/pcie_probe; PCIe Gen5 x16 spec 63)
-    return {"what": "bmbs_map_%s on page-locked HOST buffers, %d %s per call: the call is cut into chunks of 500 k units dealt to the context's lanes, "
+    return {"what": "bmbs_map_%s on page-locked HOST buffers, %d %s per call: the call is cut into chunks of n/8 (250 k .. 500 k) units dealt to the context's lanes, "
                     "uploads, kernels and downloads of different chunks overlap (copies on streams that carry no kernel); PCIe-inclusive, never `value`" % (
                 "pe" if job.cfg["pe"] else "se", n, "pairs" if job.cfg["pe"] else "reads"),
             "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s",

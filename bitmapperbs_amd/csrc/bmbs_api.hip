@@ -1485,12 +1485,14 @@ int settle_all(bmbs_ctx* X)
 
 // units per chunk of a call: the whole call on lane 0 when it is small (or the caller's CIGAR pool has no room for every chunk's
 // worst case), otherwise n / lanes (BMBS_CHUNK overrides) so that every lane gets one chunk per call
-// host_copies: the chunks carry their own H2D / D2H copies; smaller ones (500 k units) leave a shorter tail behind the last upload
+// host_copies: the chunks carry their own H2D / D2H copies; smaller ones (n / 8, within 250 k .. 500 k units) leave a shorter tail behind the last upload
 int64_t chunk_units(const bmbs_ctx* X, int64_t n, int64_t cigar_cap, int rpu, int max_ops, bool host_copies = false)
 {
     if (X->lanes.size() < 2 || n < 2 * X->kn.split_min || cigar_cap < n * rpu * (int64_t)max_ops) return n;
     int64_t ch = X->kn.chunk > 0 ? X->kn.chunk : (n + (int64_t)X->lanes.size() - 1) / (int64_t)X->lanes.size();
-    if (host_copies && X->kn.chunk <= 0 && ch > 500000) ch = 500000;
+    // (a call of 2 M pairs: 126 M reads/s in chunks of 500 k, 133-138 in chunks of 250 k -- the first upload and the last chunk's
+    // kernels and download are not hidden behind anything; tools/hostbuf_ab.py)
+    if (host_copies && X->kn.chunk <= 0) ch = std::min<int64_t>(ch, std::min<int64_t>(500000, std::max<int64_t>(250000, n / 8)));
     if (ch < X->kn.split_min) ch = X->kn.split_min;
     return ch < n ? ch : n;
 }
