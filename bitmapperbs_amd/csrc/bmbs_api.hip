@@ -59,6 +59,7 @@ struct Knobs {
     bool rows_ascii = false;    // BMBS_ROWS=ascii
     int seed_waves = 65536;     // BMBS_SEED_WAVES
     int decide = 0;             // BMBS_DECIDE: 0 default, 1 plain, 2 lds, 3 vec8
+    bool extra_plds = true;
     bool extra_nolds = false, extra_lds = false, vote_split = false, vote_nomid = false, pe_ascii_full = false;
     bool exact = false;         // BMBS_EXACT=1: every call waits for its stage counts (the round-2 launch sequence)
     int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
@@ -78,6 +79,7 @@ struct Knobs {
         if ((e = getenv("BMBS_SEED_WAVES"))) seed_waves = atoi(e);
         e = getenv("BMBS_DECIDE");
         decide = is(e, "plain") ? 1 : is(e, "lds") ? 2 : is(e, "vec8") ? 3 : 0;
+        if (const char* e = getenv("BMBS_EXTRA_PLDS")) extra_plds = atoi(e) != 0;
         extra_nolds = getenv("BMBS_EXTRA_NOLDS") != nullptr; extra_lds = getenv("BMBS_EXTRA_LDS") != nullptr;
         vote_split = is(getenv("BMBS_VOTE"), "split"); vote_nomid = getenv("BMBS_VOTE_NOMID") != nullptr;
         pe_ascii_full = is(getenv("BMBS_PE_ASCII"), "full");
@@ -635,7 +637,12 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
         // save: 4.20 ms with LDS rows, 3.93 ms without on the configs[2] batch (BMBS_EXTRA_LDS=1 / BMBS_EXTRA_NOLDS=1 force either)
         const bool wide_ix = c->ix.sa64 != nullptr;
         const int rows_in_lds = lds <= 48 * 1024 && !c->kn.extra_nolds && (!wide_ix || c->kn.extra_lds);
-        if (packed_rows)
+        // packed rows: the lane's row in its LDS slot (4.6 KB per wave at 150 bases: no occupancy lost); BMBS_EXTRA_PLDS=0: from global memory
+        const size_t plds = (size_t)64 * (pr.pwords + 1) * 8;
+        if (packed_rows && c->kn.extra_plds && plds <= 16 * 1024)
+            hipLaunchKernelGGL((k_seed_extra<false, true, true>), dim3(chunks_min), dim3(64), plds, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
+                               target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
+        else if (packed_rows)
             hipLaunchKernelGGL((k_seed_extra<false, true>), dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
         else if (rows_in_lds)

@@ -1618,7 +1618,10 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
 
 // ---- the remaining seeds (Schema.cpp:24809-24889) -------------------------------------------------
 // ROWS_LDS: ASCII rows staged in LDS (small indexes); PACKED: packed rows read from global memory (64 bytes per read)
-template <bool ROWS_LDS, bool PACKED = false>
+// PLDS (with PACKED): the packed row of a lane's read (pwords x 8 bytes) is copied into the lane's LDS slot when the lane takes the
+// read -- coalesced 16-byte loads along the rows -- and every seed start and cursor refill reads LDS: one request to the memory
+// pipeline per seed start less (of about five), at 64 x (pwords + 1) x 8 = 4.6 KB of LDS per wave for 150-base reads
+template <bool ROWS_LDS, bool PACKED = false, bool PLDS = false>
 __global__ void __launch_bounds__(64)
 k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
              int seed_len, int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
@@ -1645,7 +1648,8 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
     __shared__ u8 take_lane[64];
     const int lstride = stride + 16;                  // 16-byte aligned rows, shifted against bank conflicts
     const char* rd = ROWS_LDS ? lds_rows + (size_t)(threadIdx.x & 63) * lstride : seq;
-    const u64* prow = nullptr;
+    const int plw = pr.pwords + 1;                    // PLDS: LDS row stride in words, odd against bank conflicts
+    const u64* prow = PLDS ? reinterpret_cast<const u64*>(lds_rows) + (size_t)(threadIdx.x & 63) * plw : nullptr;
     bool dirty = false;
     typename std::conditional<PACKED, SearchP, Search>::type S; SeedHit h = {0, 0, 0};
     SeedRec* my = nullptr;
@@ -1687,15 +1691,26 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
             const long avail = chunk_end - next;
             const int n_take = (long)__popcll(want) < avail ? __popcll(want) : (int)(avail > 0 ? avail : 0);
             next += __popcll(want);
-            if (ROWS_LDS && n_take > 0) {
+            if ((ROWS_LDS || PLDS) && n_take > 0) {
                 // (source row, destination lane) of every taker, then the copy: lane t moves piece t % per_row of taker t / per_row
                 if (pending && !have && it < chunk_end) { take_row[rank] = sc.list_d[it]; take_lane[rank] = (u8)(threadIdx.x & 63); }
                 __syncthreads();
-                const int per_row = stride / 16, pieces = n_take * per_row;
-                for (int t = threadIdx.x & 63; t < pieces; t += 64) {
-                    const int w = t / per_row, cc = t - w * per_row;
-                    const uint4 v = *reinterpret_cast<const uint4*>(seq + (size_t)take_row[w] * stride + (size_t)cc * 16);
-                    *reinterpret_cast<uint4*>(lds_rows + (size_t)take_lane[w] * lstride + cc * 16) = v;
+                if constexpr (PLDS) {
+                    const int per_row = pr.pwords / 2, pieces = n_take * per_row;         // rows are 16-byte aligned, pwords is even
+                    u64* lr = reinterpret_cast<u64*>(lds_rows);
+                    for (int t = threadIdx.x & 63; t < pieces; t += 64) {
+                        const int w = t / per_row, cc = t - w * per_row;
+                        u64 a, b; load2(pr.base + (size_t)take_row[w] * pr.pwords + 2 * cc, a, b);
+                        u64* d = lr + (size_t)take_lane[w] * plw + 2 * cc;
+                        d[0] = a; d[1] = b;
+                    }
+                } else {
+                    const int per_row = stride / 16, pieces = n_take * per_row;
+                    for (int t = threadIdx.x & 63; t < pieces; t += 64) {
+                        const int w = t / per_row, cc = t - w * per_row;
+                        const uint4 v = *reinterpret_cast<const uint4*>(seq + (size_t)take_row[w] * stride + (size_t)cc * 16);
+                        *reinterpret_cast<uint4*>(lds_rows + (size_t)take_lane[w] * lstride + cc * 16) = v;
+                    }
                 }
                 __syncthreads();
             }
@@ -1703,7 +1718,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
                 if (it < chunk_end) {
                     r = sc.list_d[it]; L = gm.rl(r);
                     if (!ROWS_LDS) rd = seq + (size_t)r * stride;
-                    if (PACKED) { prow = pr.base + (size_t)r * pr.pwords; dirty = pr.dirty[r] != 0; }
+                    if constexpr (PACKED) { if constexpr (!PLDS) prow = pr.base + (size_t)r * pr.pwords; dirty = pr.dirty[r] != 0; }
                     my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
                     ns = st.n_seeds[r]; ncand = st.n_cand[r]; clen = sc.clen[r]; tm = sc.tm[r]; seed_id = sc.seed_id[r];
                     max_seed = L / 10 == 0 ? 25 : (L / 10 - 1 > 25 ? 25 : L / 10 - 1);
