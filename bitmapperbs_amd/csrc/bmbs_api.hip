@@ -60,6 +60,7 @@ struct Knobs {
     int seed_waves = 65536;     // BMBS_SEED_WAVES
     int decide = 0;             // BMBS_DECIDE: 0 default, 1 plain, 2 lds, 3 vec8
     bool extra_plds = true;
+    int vote_class3 = 128;     // BMBS_VOTE_CLASS3: 0 = one block form for all handed-over lists, 128 / 256 = threads of the <= 1024-key form (measured: 2.77 / 2.22 / 2.84 ms)
     bool extra_nolds = false, extra_lds = false, vote_split = false, vote_nomid = false, pe_ascii_full = false;
     bool exact = false;         // BMBS_EXACT=1: every call waits for its stage counts (the round-2 launch sequence)
     int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
@@ -80,6 +81,7 @@ struct Knobs {
         e = getenv("BMBS_DECIDE");
         decide = is(e, "plain") ? 1 : is(e, "lds") ? 2 : is(e, "vec8") ? 3 : 0;
         if (const char* e = getenv("BMBS_EXTRA_PLDS")) extra_plds = atoi(e) != 0;
+        if (const char* e = getenv("BMBS_VOTE_CLASS3")) vote_class3 = atoi(e);
         extra_nolds = getenv("BMBS_EXTRA_NOLDS") != nullptr; extra_lds = getenv("BMBS_EXTRA_LDS") != nullptr;
         vote_split = is(getenv("BMBS_VOTE"), "split"); vote_nomid = getenv("BMBS_VOTE_NOMID") != nullptr;
         pe_ascii_full = is(getenv("BMBS_PE_ASCII"), "full");
@@ -1262,8 +1264,23 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     HIPCHK(c, hipMemsetAsync(big_count, 0, 8, c->stream));
     hipLaunchKernelGGL((k_vote_pe_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 9, c->long_list.as<u32>(), A, c->big_list.as<u32>(), big_count);
-    hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+    prof_end(c);
+    prof_begin(c, "k_vote_pe_big");
+    // the handed-over lists in two size classes: up to 1024 candidates (10 KB of LDS per block: twice the blocks per CU of the
+    // 4096-key form; on the GRCh38-like genome 88 % of the handed-over lists), and the rest
+    if (c->kn.vote_class3 == 128) {
+        hipLaunchKernelGGL((k_vote_pe_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, ps,
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+    } else if (c->kn.vote_class3) {
+        hipLaunchKernelGGL((k_vote_pe_long<1024, 256, VM_CAP>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+    }
+    if (c->kn.vote_class3)
+        hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+    else
+        hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {

@@ -2028,12 +2028,13 @@ DEVI int vl_prefix(bool flag, int* sh_w, int& total)
 // keys[0, nc) ascending, by the whole block, in place: stable 2-bit LSD passes.  Every thread owns E = ceil(nc / threads) consecutive
 // keys in registers; a pass counts its keys per digit (four 16-bit counters in one u64), one block-wide exclusive scan of that word
 // gives every key its destination.  nc <= 16 * blockDim.x.
+template <int EMAX>
 DEVI void vl_radix_sort(u64* keys, int nc)
 {
     __shared__ u64 sh_scan[18];
     const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
-    const int E = (nc + T - 1) / T;                     // <= 16
-    u64 mine[16];
+    const int E = (nc + T - 1) / T;                     // <= EMAX = capacity / threads of the instance
+    u64 mine[EMAX];
     // the bits that vary: OR of key ^ keys[0]
     u64 diff = 0;
     const u64 k0 = keys[0];
@@ -2048,7 +2049,7 @@ DEVI void vl_radix_sort(u64* keys, int nc)
     for (int b = 0; b < nbits; b += 2) {
         u64 cnt = 0;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
+        for (int e = 0; e < EMAX; e++) {
             const int idx = tid * E + e;
             if (e < E && idx < nc) { mine[e] = keys[idx]; cnt += 1ull << (16 * (int)((mine[e] >> b) & 3)); }
         }
@@ -2068,7 +2069,7 @@ DEVI void vl_radix_sort(u64* keys, int nc)
             r3 = t0 + t1 + t2 + (u32)((excl >> 48) & 0xffff);
         __syncthreads();                                // every key is in registers: the array may be overwritten
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
+        for (int e = 0; e < EMAX; e++) {
             const int idx = tid * E + e;
             if (e < E && idx < nc) {
                 const int d = (int)((mine[e] >> b) & 3);
@@ -2080,6 +2081,7 @@ DEVI void vl_radix_sort(u64* keys, int nc)
     }
 }
 // locate the nc <= VL_CAP candidates of a read into keys[0, np2) (padded with ~0) and sort them ascending; returns np2
+template <int EMAX>
 DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u64* keys, u32* sh_pref)
 {
     if (threadIdx.x == 0) { u32 a = 0; for (int s2 = 0; s2 < ns; s2++) { sh_pref[s2] = a; a += my[s2].hits; } sh_pref[ns] = a; }
@@ -2100,7 +2102,7 @@ DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u
     // long lists (a read inside a repeat family: up to 25 seeds x 1000 rows): LSD radix sort, two bits a pass over the bits that
     // vary -- 17 passes of one block scan each for a 6.2 G text, where the bitonic network takes 78 stages of 8 sweeps over 4096
     // keys.  On a GRCh38-like genome these lists were most of k_vote_pe_long's 11-13 ms per 10 M pairs.
-    if (np2 > 512 && blockDim.x >= 128) { vl_radix_sort(keys, nc); return np2; }
+    if (np2 > 512 && blockDim.x >= 128) { vl_radix_sort<EMAX>(keys, nc); return np2; }
     for (int size = 2; size <= np2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
@@ -2335,7 +2337,7 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
             __syncthreads();
             continue;
         }
-        vl_locate_sort(ix, my, ns, (int)nc, keys, sh_pref);
+        vl_locate_sort<(CAP + BLOCK - 1) / BLOCK>(ix, my, ns, (int)nc, keys, sh_pref);
         const int nv = vl_run_ends(keys, (int)nc, endpos, sh_w);
         // (vote, entry) items in site order; a site collects at most one vote per seed, so the vote fits 8 bits
         for (int e = threadIdx.x; e < nv; e += BLOCK) {
@@ -4195,7 +4197,7 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
         const int L = gm.rl(r), k = gm.rk(L);
         const int v = st.verdict[r];
         PeCand* o = A + st.cand_off[r];
-        vl_locate_sort(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], (int)nc, keys, sh_pref);
+        vl_locate_sort<(CAP + BLOCK - 1) / BLOCK>(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], (int)nc, keys, sh_pref);
         if (v == 4) {
             for (long i = threadIdx.x; i < nc; i += BLOCK) { PeCand e; e.site = keys[i]; e.err = 0; e.end = L - 1; o[i] = e; }
             if (threadIdx.x == 0) { ps.occ[r] = (int)nc; ps.len[r] = (u32)nc; }
@@ -4381,59 +4383,130 @@ k_filter_pe(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom g
 }
 
 // the PE compaction (Schema.cpp:7480-7690): keep err <= k whose site+end differs from the previous candidate's
+// A lane walks its read's list; a list of more than 64 entries (a read inside a repeat family: hundreds to thousands) is walked by
+// the whole wave afterwards, 64 entries a step -- one such lane used to hold its wave for the length of its list.
 __global__ void __launch_bounds__(64)
 k_pe_compact(long n, long n2, ReadGeom gm, int round, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n2) return;
-    const int k = gm.rk(gm.rl(r));
-    if (ps.vround[r] != round) return;
-    const long p = r < n ? r : r - n;
-    if (ps.dead[p]) return;
-    PeCand* l = pe_list(ps, st, A, B, r);
-    const long m = ps.len[r];
-    u64 pre = ~0ull;
-    int occ = 0;
-    for (long i = 0; i < m; i++) {
-        const PeCand c = l[i];
-        const u64 t = c.site + (u64)(long long)c.end;
-        if (c.err <= (u32)k && pre != t) { l[occ] = c; occ++; }
-        pre = t;
+    const int lane = threadIdx.x & 63;
+    bool act = r < n2 && ps.vround[r] == round;
+    if (act) { const long p = r < n ? r : r - n; if (ps.dead[p]) act = false; }
+    const long m = act ? (long)ps.len[r] : 0;
+    const bool coop = m > 64;
+    if (act && !coop) {
+        const int k = gm.rk(gm.rl(r));
+        PeCand* l = pe_list(ps, st, A, B, r);
+        u64 pre = ~0ull;
+        int occ = 0;
+        for (long i = 0; i < m; i++) {
+            const PeCand c = l[i];
+            const u64 t = c.site + (u64)(long long)c.end;
+            if (c.err <= (u32)k && pre != t) { l[occ] = c; occ++; }
+            pre = t;
+        }
+        ps.occ[r] = occ;
     }
-    ps.occ[r] = occ;
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long rr = (long)__shfl((long long)r, src, 64);
+        const long mm = (long)ps.len[rr];
+        const int k = gm.rk(gm.rl(rr));
+        PeCand* l = pe_list(ps, st, A, B, rr);
+        u64 carry = ~0ull;                              // site + end of the entry before the step's first
+        int occ = 0;
+        for (long base = 0; base < mm; base += 64) {
+            const long i = base + lane;
+            PeCand c; c.site = 0; c.err = 0; c.end = 0;
+            u64 t = 0;
+            if (i < mm) { c = l[i]; t = c.site + (u64)(long long)c.end; }
+            u64 pre = (u64)__shfl_up((long long)t, 1, 64);
+            if (lane == 0) pre = carry;
+            const bool keep = i < mm && c.err <= (u32)k && pre != t;
+            const unsigned long long kb = __ballot(keep);       // every entry of the step is in registers before the first is stored
+            if (keep) l[occ + __popcll(kb & ((1ull << lane) - 1))] = c;
+            occ += __popcll(kb);
+            carry = (u64)__shfl((long long)t, 63, 64);
+        }
+        if (lane == src) ps.occ[rr] = occ;
+    }
 }
 
 // after round 1 of a both-unverified pair: filter_pairs_single_side (Schema.cpp:16186-16270)
+// The reference's merge loop, one lane per pair -- and, for a pair whose two lists hold more than 64 entries, by the whole wave:
+// with a lower bound of the distance <= 0 (the default insert range) the loop keeps b[j] exactly when some a[i] lies within maxd of
+// it (it drops b[j] only when the current a[i] is more than maxd above it, and then so is every later one; it leaves the scan of
+// a[i] only at a b[j] more than maxd above a[i], and then so is every later one), so every b[j] is decided by one binary search in a.
 __global__ void __launch_bounds__(64)
 k_pe_prune(long n, ReadGeom gm, PeIns pi, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    long long maxd, mind; int large_k;
-    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
-    if (ps.dead[p] || !ps.both[p]) return;
-    const long rs = ps.vround[p] == 1 ? p : p + n;       // verified side
-    const long ro = ps.vround[p] == 1 ? p + n : p;       // side still to verify
-    const int occ_s = ps.occ[rs];
-    if (occ_s == 0) { ps.dead[p] = 1; return; }
-    const PeCand* a = pe_list(ps, st, A, B, rs);
-    PeCand* b = pe_list(ps, st, A, B, ro);
-    const long nb = ps.len[ro];
-    long len2 = 0, first = 0;
-    for (long i = 0; i < occ_s; i++) {
-        for (long j = first; j < nb; j++) {
-            if (a[i].site > b[j].site) {
-                const long long d = (long long)(a[i].site - b[j].site);
-                if (d > maxd) first = j + 1;
-                else if (d >= mind) { b[len2] = b[j]; len2++; first = j + 1; }
-            } else {
-                const long long d = (long long)(b[j].site - a[i].site);
-                if (d > maxd) break;
-                if (d >= mind) { b[len2] = b[j]; len2++; first = j + 1; }
+    const int lane = threadIdx.x & 63;
+    bool act = p < n && !ps.dead[p] && ps.both[p];
+    long long maxd = 0, mind = 0; int large_k;
+    long rs = 0, ro = 0;
+    int occ_s = 0;
+    if (act) {
+        pe_bounds(gm, pi, p, n, maxd, mind, large_k);
+        rs = ps.vround[p] == 1 ? p : p + n;       // verified side
+        ro = ps.vround[p] == 1 ? p + n : p;       // side still to verify
+        occ_s = ps.occ[rs];
+        if (occ_s == 0) { ps.dead[p] = 1; act = false; }
+    }
+    const long nb = act ? (long)ps.len[ro] : 0;
+    auto serial = [&](const PeCand* a, long na, PeCand* b, long nbb, long long mxd, long long mnd) -> long {
+        long len2 = 0, first = 0;
+        for (long i = 0; i < na; i++) {
+            for (long j = first; j < nbb; j++) {
+                if (a[i].site > b[j].site) {
+                    const long long d = (long long)(a[i].site - b[j].site);
+                    if (d > mxd) first = j + 1;
+                    else if (d >= mnd) { b[len2] = b[j]; len2++; first = j + 1; }
+                } else {
+                    const long long d = (long long)(b[j].site - a[i].site);
+                    if (d > mxd) break;
+                    if (d >= mnd) { b[len2] = b[j]; len2++; first = j + 1; }
+                }
             }
         }
+        return len2;
+    };
+    const bool coop = act && nb + occ_s > 64 && mind <= 0 && maxd >= 0;
+    if (act && !coop) ps.len[ro] = (u32)serial(pe_list(ps, st, A, B, rs), occ_s, pe_list(ps, st, A, B, ro), nb, maxd, mind);
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long pp = (long)__shfl((long long)p, src, 64);
+        long long mxd, mnd; int lk;
+        pe_bounds(gm, pi, pp, n, mxd, mnd, lk);
+        const long rs2 = ps.vround[pp] == 1 ? pp : pp + n, ro2 = ps.vround[pp] == 1 ? pp + n : pp;
+        const long na = ps.occ[rs2], nbb = (long)ps.len[ro2];
+        const PeCand* a = pe_list(ps, st, A, B, rs2);
+        PeCand* b = pe_list(ps, st, A, B, ro2);
+        // sites that wrapped below zero (the last ones of an ascending list) make the distances negative: the loop itself decides
+        if ((a[na - 1].site >> 63) || (nbb && (b[nbb - 1].site >> 63))) {
+            if (lane == src) ps.len[ro2] = (u32)serial(a, na, b, nbb, mxd, mnd);
+            continue;
+        }
+        long len2 = 0;
+        for (long base = 0; base < nbb; base += 64) {
+            const long j = base + lane;
+            PeCand e; e.site = 0; e.err = 0; e.end = 0;
+            bool keep = false;
+            if (j < nbb) {
+                e = b[j];
+                const long i = pe_lower_bound(a, na, e.site > (u64)mxd ? e.site - (u64)mxd : 0);      // the first a not more than maxd below b[j]
+                keep = i < na && (a[i].site <= e.site || a[i].site - e.site <= (u64)mxd);             // ... and not more than maxd above
+            }
+            const unsigned long long kb = __ballot(keep);
+            if (keep) b[len2 + __popcll(kb & ((1ull << lane) - 1))] = e;
+            len2 += __popcll(kb);
+        }
+        if (lane == src) ps.len[ro2] = (u32)len2;
     }
-    ps.len[ro] = (u32)len2;
 }
 
 // ================================================================================================

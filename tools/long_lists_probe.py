@@ -26,6 +26,22 @@ def main():
         job.launch(0); m.sync()
         prof, calls = m.profile_total()
         print("call %d: " % rep + ", ".join("%s=%.2f" % (k, v) for k, v in sorted(prof.items(), key=lambda kv: -kv[1])[:10]))
+    # A/B of a knob the context reads when it is created: PROBE_AB="BMBS_VOTE_CLASS3=0,128,256"
+    ab = os.environ.get("PROBE_AB")
+    if ab:
+        key, vals = ab.split("=")
+        for v in vals.split(","):
+            os.environ[key] = v
+            m2 = mapper.Mapper(ix, device=0, share=m, e_f=cfg["e"])
+            job.m = m2
+            for rep in range(3):
+                m2.profile_reset()
+                job.launch(0); m2.sync()
+                prof, calls = m2.profile_total()
+            print("%s=%s: " % (key, v) + ", ".join("%s=%.2f" % (k, x) for k, x in sorted(prof.items(), key=lambda kv: -kv[1])[:8]))
+            m2.close()
+        job.m = m
+        os.environ.pop(key, None)
     res = job.res_d.cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1)
     nc = res["n_cand"].astype(np.int64)
     edges = [0, 1, 2, 17, 33, 65, 257, 513, 1025, 4097, 65535, 1 << 30]
