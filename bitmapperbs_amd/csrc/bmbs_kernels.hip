@@ -4720,52 +4720,131 @@ k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ c
 }
 
 // new_faster_verify_pairs (Schema.cpp:15773-15900) + hand-over of the winning candidates to K11-K13
+// What the reference's loop leaves behind, as a summary of an ORDERED run of (i, j) hits that can be merged left to right:
+// the lowest error sum m, where it first occurs, how often it occurs (c), and the lowest sum among the hits before that first
+// occurrence (pm) -- the loop's `second` is the running best at the moment the final best was first met (not the true runner-up),
+// or the best itself when it was met again afterwards.
+struct PairSum { int m, c, pm; long i, j; };
+DEVI PairSum pair_comb(const PairSum& L, const PairSum& R)
+{
+    if (R.c == 0) return L;
+    if (L.c == 0) return R;
+    PairSum o;
+    if (L.m < R.m) o = L;
+    else if (L.m > R.m) { o = R; o.pm = L.m < R.pm ? L.m : R.pm; }
+    else { o = L; o.c = L.c + R.c; }
+    return o;
+}
 __global__ void __launch_bounds__(64)
 k_pe_pair(DevIndex ix, long n, ReadGeom gm, PeIns pi, int ambiguous_out, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    long long maxd, mind; int large_k;
-    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
+    const int lane = threadIdx.x & 63;
+    bool act = p < n;
+    long long maxd = 0, mind = 0; int large_k = 0;
     const long r1 = p, r2 = p + n;
-    st.job_flag[r1] = 0; st.job_flag[r2] = 0;
-    st.red_status[r1] = 0; st.red_status[r2] = 0;
-    if (ps.dead[p]) return;
-    const int n1 = ps.occ[r1], n2 = ps.occ[r2];
-    const PeCand* a = pe_list(ps, st, A, B, r1);
-    const PeCand* b = pe_list(ps, st, A, B, r2);
+    if (act) {
+        pe_bounds(gm, pi, p, n, maxd, mind, large_k);
+        st.job_flag[r1] = 0; st.job_flag[r2] = 0;
+        st.red_status[r1] = 0; st.red_status[r2] = 0;
+        if (ps.dead[p]) act = false;
+    }
+    const int n1 = act ? ps.occ[r1] : 0, n2 = act ? ps.occ[r2] : 0;
+    const PeCand* a = act ? pe_list(ps, st, A, B, r1) : nullptr;
+    const PeCand* b = act ? pe_list(ps, st, A, B, r2) : nullptr;
     int mapping_pair = 0;
-    int best_sum = 4 * large_k + 2;
-    long long second = (long long)best_sum * 2, bi = 0, bj = 0;
+    long long bi = 0, bj = 0;
     u32 sbd = 0;
-    bool early = false;
-    if (n1 > 0 && n2 > 0) {
+    // the reference's loop itself, one lane
+    auto serial = [&](const PeCand* a_, long n1_, const PeCand* b_, long n2_, long long mxd, long long mnd, int lk, int& mp_out, u32& sbd_out,
+                      long long& bi_out, long long& bj_out) {
+        int mp = 0;
+        int best_sum = 4 * lk + 2;
+        long long second = (long long)best_sum * 2, bi_ = 0, bj_ = 0;
+        bool early = false;
         long first = 0;
-        for (long i = 0; i < n1 && !early; i++) {
-            for (long j = first; j < n2; j++) {
+        for (long i = 0; i < n1_ && !early; i++) {
+            for (long j = first; j < n2_; j++) {
                 bool hit = false;
-                if (a[i].site > b[j].site) {
-                    const long long d = (long long)(a[i].site - b[j].site);
-                    if (d > maxd) first = j + 1;
-                    else if (d >= mind) hit = true;
+                if (a_[i].site > b_[j].site) {
+                    const long long d = (long long)(a_[i].site - b_[j].site);
+                    if (d > mxd) first = j + 1;
+                    else if (d >= mnd) hit = true;
                 } else {
-                    const long long d = (long long)(b[j].site - a[i].site);
-                    if (d > maxd) break;
-                    if (d >= mind) hit = true;
+                    const long long d = (long long)(b_[j].site - a_[i].site);
+                    if (d > mxd) break;
+                    if (d >= mnd) hit = true;
                 }
                 if (hit) {
-                    const long long cur = (long long)a[i].err + (long long)b[j].err;
-                    if (cur < best_sum) { second = best_sum; best_sum = (int)cur; bi = i; bj = j; mapping_pair = 1; }
+                    const long long cur = (long long)a_[i].err + (long long)b_[j].err;
+                    if (cur < best_sum) { second = best_sum; best_sum = (int)cur; bi_ = i; bj_ = j; mp = 1; }
                     else if (cur == best_sum) {
-                        second = best_sum; mapping_pair++;
+                        second = best_sum; mp++;
                         if (best_sum == 0) { early = true; break; }
                     }
                 }
             }
         }
+        mp_out = mp; bi_out = bi_; bj_out = bj_;
+        sbd_out = early ? 0u : (mp != 0 ? (u32)(second - best_sum) : 0u);
+    };
+    // two long lists (both mates inside a repeat family: hundreds of verified copies each) go to the whole wave: with a lower bound of
+    // the distance <= 0 the hits of a[i] are exactly the b[j] within maxd of it, in order -- a lane takes an a[i], finds its window in b
+    // by binary search and sums it up, and the lanes' summaries merge in order (pair_comb)
+    const bool coop = act && n1 > 0 && n2 > 0 && (long)n1 + n2 > 64 && mind <= 0 && maxd >= 0;
+    if (act && !coop && n1 > 0 && n2 > 0) serial(a, n1, b, n2, maxd, mind, large_k, mapping_pair, sbd, bi, bj);
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long pp = (long)__shfl((long long)p, src, 64);
+        long long mxd, mnd; int lk;
+        pe_bounds(gm, pi, pp, n, mxd, mnd, lk);
+        const long m1 = ps.occ[pp], m2 = ps.occ[pp + n];
+        const PeCand* a2 = pe_list(ps, st, A, B, pp);
+        const PeCand* b2 = pe_list(ps, st, A, B, pp + n);
+        if ((a2[m1 - 1].site >> 63) || (b2[m2 - 1].site >> 63)) {     // sites that wrapped below zero: the loop itself decides
+            if (lane == src) serial(a2, m1, b2, m2, mxd, mnd, lk, mapping_pair, sbd, bi, bj);
+            continue;
+        }
+        PairSum tot; tot.m = 0; tot.c = 0; tot.pm = 0x7fffffff; tot.i = 0; tot.j = 0;
+        for (long base = 0; base < m1; base += 64) {
+            const long i = base + lane;
+            PairSum me; me.m = 0; me.c = 0; me.pm = 0x7fffffff; me.i = i; me.j = 0;
+            if (i < m1) {
+                const PeCand e = a2[i];
+                const u64 hi = e.site + (u64)mxd;
+                for (long j = pe_lower_bound(b2, m2, e.site > (u64)mxd ? e.site - (u64)mxd : 0); j < m2; j++) {
+                    const PeCand f = b2[j];
+                    if (f.site > hi) break;
+                    const int cur = (int)(e.err + f.err);
+                    if (me.c == 0 || cur < me.m) { if (me.c) me.pm = me.m < me.pm ? me.m : me.pm; me.m = cur; me.c = 1; me.j = j; }
+                    else if (cur == me.m) me.c++;
+                }
+            }
+            // ordered reduction over the lanes: lane l collects lanes l .. l + 2 off - 1
+            for (int off = 1; off < 64; off <<= 1) {
+                PairSum o;
+                o.m = __shfl_down(me.m, off, 64); o.c = __shfl_down(me.c, off, 64); o.pm = __shfl_down(me.pm, off, 64);
+                o.i = (long)__shfl_down((long long)me.i, off, 64); o.j = (long)__shfl_down((long long)me.j, off, 64);
+                if ((lane & (2 * off - 1)) == 0 && lane + off < 64) me = pair_comb(me, o);
+            }
+            PairSum ch;
+            ch.m = __shfl(me.m, 0, 64); ch.c = __shfl(me.c, 0, 64); ch.pm = __shfl(me.pm, 0, 64);
+            ch.i = (long)__shfl((long long)me.i, 0, 64); ch.j = (long)__shfl((long long)me.j, 0, 64);
+            tot = pair_comb(tot, ch);
+        }
+        if (lane == src) {
+            const int init = 4 * lk + 2;
+            if (tot.c == 0) { mapping_pair = 0; sbd = 0; }
+            else {
+                bi = tot.i; bj = tot.j;
+                if (tot.c >= 2) { mapping_pair = tot.m == 0 ? 2 : tot.c; sbd = 0; }     // met again: second = best (sum 0: the loop stops at the second)
+                else { mapping_pair = 1; sbd = (u32)((tot.pm < init ? tot.pm : init) - tot.m); }
+            }
+        }
     }
-    if (early) sbd = 0;
-    else if (mapping_pair != 0) sbd = (u32)(second - best_sum);
+    if (!act) return;
     ps.npair[p] = mapping_pair; ps.sbd[p] = sbd;
     if (mapping_pair == 1 || (ambiguous_out && mapping_pair > 1)) {          // Schema.cpp:19342-19347
         st.best_site[r1] = a[bi].site; st.best_end[r1] = a[bi].end; st.best_err[r1] = a[bi].err;
