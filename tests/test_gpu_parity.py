@@ -1294,6 +1294,62 @@ def test_long_list_kernels_forced_on_pairs(env, monkeypatch, sensitive):
         m.close()
 
 
+@pytest.fixture(scope="module")
+def both_mates_repeat_env(tmp_path_factory):
+    """1 Mb genome, 40 % of it copies of a 600-base element at 1.5 % divergence and identical copies of a 450-base one: a pair that
+    falls inside a copy has hundreds of candidates on BOTH mates and as many admissible pairs"""
+    from bitmapperbs_amd import synth, mapper
+    d = tmp_path_factory.mktemp("bothrep")
+    names, chroms = synth.make_genome(1_000_000, 2, seed=4242)
+    rng = np.random.default_rng(2424)
+    for elen, copies, div in ((600, 700, 0.015), (450, 300, 0.0)):
+        el = synth._ACGT[rng.integers(0, 4, elen)]
+        for _ in range(copies):
+            ch = chroms[int(rng.integers(0, 2))]
+            p_ = int(rng.integers(0, ch.size - elen))
+            e = el.copy()
+            m_ = rng.random(elen) < div
+            e[m_] = synth._ACGT[rng.integers(0, 4, int(m_.sum()))]
+            ch[p_:p_ + elen] = synth.revcomp(e) if rng.random() < 0.5 else e
+    fa = str(d / "both.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=8)
+    ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
+    m1, m2 = synth.make_reads_pe(chroms, n=5000, L=100, seed=515, sub=0.01, indel=0.001, qual="random")
+    yield dict(ix=ix, oix=oix, m1=m1, m2=m2)
+    ix.close(); oix.close()
+
+
+@pytest.mark.parametrize("variant", ["default", "min_insert", "ambiguous_out", "sensitive", "one_block_form", "block_256"])
+def test_long_lists_on_both_mates_match_oracle(both_mates_repeat_env, monkeypatch, variant):
+    """the wave-cooperative parts of k_pe_compact / k_pe_prune / k_pe_pair (lists of more than 64 entries on both mates: compaction by
+    ballot, prune by binary search, pairing by ordered summaries) against the oracle's loops -- ties of the best error sum, the
+    early exit at a second pair without errors, `second_best_diff`; with a minimum insert the reference's loop is order-dependent
+    and one lane runs it; the size classes of the block form of the vote kernel (BMBS_VOTE_CLASS3)"""
+    from bitmapperbs_amd import mapper
+    e = both_mates_repeat_env
+    prm, sensitive = {}, 0
+    if variant == "min_insert":
+        prm = dict(min_ins=150, max_ins=600)
+    elif variant == "ambiguous_out":
+        prm = dict(ambiguous_out=1)
+    elif variant == "sensitive":
+        sensitive = 1
+    elif variant == "one_block_form":
+        monkeypatch.setenv("BMBS_VOTE_CLASS3", "0")
+    elif variant == "block_256":
+        monkeypatch.setenv("BMBS_VOTE_CLASS3", "256")
+    m1, m2 = e["m1"], e["m2"]
+    recs, ost, _ = e["oix"].map_pe(orc.params(sensitive=sensitive, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+    m = mapper.Mapper(e["ix"], 0, sensitive=sensitive, **prm)
+    for rep in range(2):
+        res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+        nc = res["n_cand"].astype(np.int64).reshape(-1, 2)
+        assert int((nc.min(axis=1) > 64).sum()) > 100         # pairs with long lists on both mates
+        assert not compare_pe(res, pool, recs, 100), (variant, rep)
+    m.close()
+
+
 def test_very_long_candidate_lists_match_oracle(tmp_path):
     """reads inside a family of 900 identical copies (and one of 600 copies at 2 % divergence): seeds that hit hundreds of rows each
     give candidate lists of thousands -- the block form of the long-list kernels with its radix sort (lists beyond 512), the
