@@ -745,8 +745,23 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         HIPCHK(c, hipMemsetAsync(big_count, 0, 8, c->stream));
         hipLaunchKernelGGL((k_vote_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
                            c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->big_list.as<u32>(), big_count);
-        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        prof_end(c);
+        prof_begin(c, "k_vote_big");
+        // the handed-over lists in two size classes (as k_vote_pe_long): the <= 1024-key form needs 14 KB of LDS instead of 57 KB, so five
+        // times as many reads are in flight -- the vote order (std::sort's permutation, one partition pass after the other) is a
+        // chain of barriers, not work
+        if (c->kn.vote_class3 == 128)
+            hipLaunchKernelGGL((k_vote_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        else if (c->kn.vote_class3)
+            hipLaunchKernelGGL((k_vote_long<1024, 256, VM_CAP>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        if (c->kn.vote_class3)
+            hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
         prof_end(c);
     }
     return BMBS_OK;

@@ -2217,9 +2217,58 @@ DEVI void vl_intro_small(bmbs_vk* v, int first0, int last0, int depth0)
         }
     }
 }
+// items[0, nv) stably by vote (the top byte), descending: 2-bit LSD passes over the vote bits that vary (a site collects at most one
+// vote per seed: votes stay below 32, two or three passes), thread t owning items [t E, (t + 1) E) as vl_radix_sort does
+template <int EMAX>
+DEVI void vl_stable_by_vote_desc(bmbs_vk* items, int nv)
+{
+    __shared__ u64 sh_vscan[18];
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (T + 63) >> 6;
+    const int E = (nv + T - 1) / T;                     // <= EMAX
+    u32 mine[EMAX];
+    u32 diff = 0;
+    const u32 v0 = items[0].x >> 24;
+    for (int i = tid; i < nv; i += T) diff |= (items[i].x >> 24) ^ v0;
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    if (lane == 0) sh_vscan[w] = diff;
+    __syncthreads();
+    diff = 0;
+    for (int i = 0; i < nw; i++) diff |= (u32)sh_vscan[i];
+    __syncthreads();
+    const int nbits = diff ? 32 - __builtin_clz(diff) : 0;
+    for (int b = 0; b < nbits; b += 2) {
+        u64 cnt = 0;
+#pragma unroll
+        for (int e = 0; e < EMAX; e++) {
+            const int idx = tid * E + e;
+            if (e < E && idx < nv) { mine[e] = items[idx].x; cnt += 1ull << (16 * (3 - (int)((mine[e] >> (24 + b)) & 3))); }
+        }
+        u64 incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const u64 v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) sh_vscan[w] = incl;
+        __syncthreads();
+        u64 wbase = 0, total = 0;
+        for (int i = 0; i < nw; i++) { const u64 x = sh_vscan[i]; if (i < w) wbase += x; total += x; }
+        const u64 excl = wbase + incl - cnt;
+        const u32 t0 = (u32)(total & 0xffff), t1 = (u32)((total >> 16) & 0xffff), t2 = (u32)((total >> 32) & 0xffff);
+        u32 r0 = (u32)(excl & 0xffff), r1 = t0 + (u32)((excl >> 16) & 0xffff), r2 = t0 + t1 + (u32)((excl >> 32) & 0xffff),
+            r3 = t0 + t1 + t2 + (u32)((excl >> 48) & 0xffff);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EMAX; e++) {
+            const int idx = tid * E + e;
+            if (e < E && idx < nv) {
+                const int d = 3 - (int)((mine[e] >> (24 + b)) & 3);
+                const u32 r = d == 0 ? r0++ : d == 1 ? r1++ : d == 2 ? r2++ : r3++;
+                items[r].x = mine[e];
+            }
+        }
+        __syncthreads();
+    }
+}
 // items[0, nv) -> std::sort(.., vote descending)'s permutation.  scratch: 4*CAP + 512 + CAP/2 bytes.  Returns false when a
 // large range ran out of depth budget (heapsort fallback): the caller then takes the serial path.
-template <int CAP, int SMALL>
+template <int CAP, int SMALL, int EMAX>
 DEVI bool vl_sort_votes(bmbs_vk* items, int nv, void* scratch, int* sh_w, int* ctl)
 {
     u16* Lpos = (u16*)scratch;
@@ -2264,24 +2313,9 @@ DEVI bool vl_sort_votes(bmbs_vk* items, int nv, void* scratch, int* sh_w, int* c
         for (int s2 = threadIdx.x; s2 < n_small; s2 += (int)blockDim.x) vl_intro_small(items, small[s2].f, small[s2].l, small[s2].d);
         __syncthreads();
     }
-    // the final insertion sort = stable sort by vote descending of the current arrangement
-    int np2 = 32;
-    while (np2 < nv) np2 <<= 1;
-    for (int j = threadIdx.x; j < np2; j += (int)blockDim.x)
-        items[j].x = j < nv ? ((255u - (items[j].x >> 24)) << 24) | ((u32)j << 12) | (items[j].x & 0xfffu) : 0xffffffffu;
-    __syncthreads();
-    for (int size = 2; size <= np2; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < np2 / 2; t += (int)blockDim.x) {
-                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
-                const bool asc = (i & size) == 0;
-                const u32 a = items[i].x, b = items[j].x;
-                if ((a > b) == asc) { items[i].x = b; items[j].x = a; }
-            }
-            __syncthreads();
-        }
-    for (int j = threadIdx.x; j < nv; j += (int)blockDim.x) { const u32 x = items[j].x; items[j].x = ((255u - (x >> 24)) << 24) | (x & 0xfffu); }
-    __syncthreads();
+    // the final insertion sort = stable sort by vote descending of the current arrangement (a bitonic network on (vote, position)
+    // keys did this before: 55 stages with a barrier each for 1024 items, most of the time of a long list)
+    vl_stable_by_vote_desc<EMAX>(items, nv);
     return true;
 }
 
@@ -2349,7 +2383,7 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
         for (int e = threadIdx.x; e < nv; e += BLOCK) c[e] = keys[endpos[e]];
         __syncthreads();
         // std::sort(votes, compare_seed_votes), Schema.cpp:24986
-        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32)>(items, nv, keys, sh_w, sh_ctl)) {
+        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32), (CAP + BLOCK - 1) / BLOCK>(items, nv, keys, sh_w, sh_ctl)) {
             for (int e = threadIdx.x; e < nv; e += BLOCK) {
                 const u32 vote = (u32)endpos[e] - (e ? (u32)endpos[e - 1] : 0xffffffffu);
                 items[e].x = (vote << 24) | (u32)e;
@@ -2386,7 +2420,7 @@ k_vote_order(const uint8_t* __restrict__ vote, const long* __restrict__ seg_off,
         if (nv <= 0 || nv > CAP) continue;
         for (int e = threadIdx.x; e < nv; e += BLOCK) items[e].x = ((u32)vote[a + e] << 24) | (u32)e;
         __syncthreads();
-        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32)>(items, nv, scratch, sh_w, sh_ctl)) {
+        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32), (CAP + BLOCK - 1) / BLOCK>(items, nv, scratch, sh_w, sh_ctl)) {
             for (int e = threadIdx.x; e < nv; e += BLOCK) items[e].x = ((u32)vote[a + e] << 24) | (u32)e;
             __syncthreads();
             if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);
@@ -2658,31 +2692,82 @@ k_filter_pairs(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int strid
 // ================================================================================================
 // K9: ordered reduction over a read's votes (Schema.cpp:7847-8172 / 8335-8750)
 // ================================================================================================
+// What the loop below leaves behind, as a summary of an ORDERED run of votes that merges left to right (as pair_comb): the lowest
+// error m, where it first occurs (i0, with its site + end t0), whether a later vote reaches m at another place (amb), and the
+// lowest error before i0 (pm: second_best_diff is the drop at the moment the final best was first met).
+struct RedSum { u32 m, pm; int i0; int amb; u64 t0; };          // i0 < 0: empty
+DEVI RedSum red_comb(const RedSum& L, const RedSum& R)
+{
+    if (R.i0 < 0) return L;
+    if (L.i0 < 0) return R;
+    RedSum o;
+    if (L.m < R.m) o = L;
+    else if (L.m > R.m) { o = R; o.pm = L.m < R.pm ? L.m : R.pm; }
+    else { o = L; o.amb = L.amb | R.amb | (R.t0 != L.t0 ? 1 : 0); }
+    return o;
+}
 __global__ void __launch_bounds__(256)
 k_reduce(long n, int ambiguous_out, ReadState st, const u64* __restrict__ vote_off, const bmbs_vote* __restrict__ votes,
          const u32* __restrict__ ferr, const int* __restrict__ fend, const u64* __restrict__ count_ptr, const u32* __restrict__ list)
 {
     // list != nullptr: the compacted list of reads with candidates (k_vote_fused's); job_flag / red_status of the others were zeroed
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     long r = it;
-    if (list) { if (it >= (long)*count_ptr) return; r = list[it]; }
+    bool act = true;
+    if (list) { if (it >= (long)*count_ptr) act = false; else r = list[it]; }
     else {
-        if (r >= n) return;
-        st.job_flag[r] = 0;
-        st.red_status[r] = 0;
+        if (r >= n) act = false;
+        else { st.job_flag[r] = 0; st.red_status[r] = 0; }
     }
-    if (st.verdict[r] != 3) return;
-    const u64 off = vote_off[r];
-    const long nv = (long)st.n_votes[r];
+    if (act && st.verdict[r] != 3) act = false;
+    const u64 off = act ? vote_off[r] : 0;
+    const long nv = act ? (long)st.n_votes[r] : 0;
     u32 min_err = 0xfffffffeu, sbd = 0;
     long min_idx = -1;
-    u64 min_site = ~0ull;
-    for (long i = 0; i < nv; i++) {
-        const u32 e = ferr[off + i];
-        const u64 tmp_site = votes[off + i].site + (u64)(long long)fend[off + i];
-        if (e == min_err && min_site != tmp_site && min_idx >= 0) { sbd = 0; min_idx = -2 - min_idx; }
-        else if (e < min_err) { sbd = min_err - e; min_err = e; min_idx = i; min_site = tmp_site; }
+    const bool coop = nv > 64;                  // a read inside a repeat family: hundreds of verified votes -- the whole wave walks them
+    if (act && !coop) {
+        u64 min_site = ~0ull;
+        for (long i = 0; i < nv; i++) {
+            const u32 e = ferr[off + i];
+            const u64 tmp_site = votes[off + i].site + (u64)(long long)fend[off + i];
+            if (e == min_err && min_site != tmp_site && min_idx >= 0) { sbd = 0; min_idx = -2 - min_idx; }
+            else if (e < min_err) { sbd = min_err - e; min_err = e; min_idx = i; min_site = tmp_site; }
+        }
     }
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long rr = (long)__shfl((long long)r, src, 64);
+        const u64 o2 = vote_off[rr];
+        const long nv2 = (long)st.n_votes[rr];
+        RedSum tot; tot.m = 0; tot.pm = 0xfffffffeu; tot.i0 = -1; tot.amb = 0; tot.t0 = 0;
+        for (long base = 0; base < nv2; base += 64) {
+            const long i = base + lane;
+            RedSum me; me.m = 0; me.pm = 0xfffffffeu; me.i0 = -1; me.amb = 0; me.t0 = 0;
+            if (i < nv2) {
+                const u32 e = ferr[o2 + i];
+                if (e < 0xfffffffeu) { me.m = e; me.i0 = (int)i; me.t0 = votes[o2 + i].site + (u64)(long long)fend[o2 + i]; }
+            }
+            for (int d = 1; d < 64; d <<= 1) {
+                RedSum o;
+                o.m = __shfl_down(me.m, d, 64); o.pm = __shfl_down(me.pm, d, 64); o.i0 = __shfl_down(me.i0, d, 64);
+                o.amb = __shfl_down(me.amb, d, 64); o.t0 = (u64)__shfl_down((long long)me.t0, d, 64);
+                if ((lane & (2 * d - 1)) == 0) me = red_comb(me, o);
+            }
+            RedSum ch;
+            ch.m = __shfl(me.m, 0, 64); ch.pm = __shfl(me.pm, 0, 64); ch.i0 = __shfl(me.i0, 0, 64); ch.amb = __shfl(me.amb, 0, 64);
+            ch.t0 = (u64)__shfl((long long)me.t0, 0, 64);
+            tot = red_comb(tot, ch);
+        }
+        if (lane == src && tot.i0 >= 0) {
+            min_err = tot.m;
+            if (tot.amb) { sbd = 0; min_idx = -2 - (long)tot.i0; }
+            else { sbd = tot.pm - tot.m; min_idx = tot.i0; }
+        }
+    }
+    if (!act) return;
     if (min_idx >= 0) {
         st.best_site[r] = votes[off + min_idx].site;
         st.best_end[r] = fend[off + min_idx];

@@ -1316,8 +1316,28 @@ def both_mates_repeat_env(tmp_path_factory):
     mapper.Index.build(fa, fa, threads=8)
     ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
     m1, m2 = synth.make_reads_pe(chroms, n=5000, L=100, seed=515, sub=0.01, indel=0.001, qual="random")
-    yield dict(ix=ix, oix=oix, m1=m1, m2=m2)
+    se = synth.make_reads_se(chroms, n=8000, L=120, seed=516, sub=0.01, indel=0.001, qual="random")
+    yield dict(ix=ix, oix=oix, m1=m1, m2=m2, se=se)
     ix.close(); oix.close()
+
+
+@pytest.mark.parametrize("class3", ["128", "0", "256"])
+def test_long_lists_single_end_size_classes_match_oracle(both_mates_repeat_env, monkeypatch, class3):
+    """single-end reads on the same genome: lists of hundreds of candidates through the three forms of k_vote_long (a wave; a block
+    of 128 or 256 threads over up to 1024 keys; 256 threads over up to 4096) -- sites, votes and std::sort's visiting order must
+    be the same whichever form a list takes (BMBS_VOTE_CLASS3), with and without --ambiguous_out"""
+    from bitmapperbs_amd import mapper
+    e = both_mates_repeat_env
+    monkeypatch.setenv("BMBS_VOTE_CLASS3", class3)
+    r = e["se"]
+    for amb in (0, 1):
+        recs, ost, cnt = e["oix"].map_se(orc.params(ambiguous_out=amb), r["seq"], r["qual"], 120)
+        m = mapper.Mapper(e["ix"], 0, ambiguous_out=amb)
+        for rep in range(2):
+            res, pool = m.map_se(r["seq"], r["qual"], 120)
+            assert int((res["n_cand"] > 256).sum()) > 100           # lists beyond the wave form
+            assert not compare_records(res, pool, recs, 120, amb=bool(amb)), (class3, amb, rep)
+        m.close()
 
 
 @pytest.mark.parametrize("variant", ["default", "min_insert", "ambiguous_out", "sensitive", "one_block_form", "block_256"])

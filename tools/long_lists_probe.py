@@ -15,7 +15,8 @@ def main():
     import torch
     from bitmapperbs_amd import mapper, capi
     pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-    args = bench.parse(["--config", "2", "--units", str(pairs), "--launches", "1"])
+    se = os.environ.get("PROBE_SE") == "1"           # single-end reads on the same genome (the SE vote / reduce kernels)
+    args = bench.parse(["--config", "2", "--units", str(pairs), "--launches", "1"] + (["--se"] if se else []))
     cfg = args.cfg
     fa, names, chroms, built = bench.ensure_index(args, cfg, 0, 0, 1, None, grch38_like=True)
     ix = mapper.Index(fa)
