@@ -967,6 +967,8 @@ def main():
                     sec["grch38_like"] = secondary(args, "main configuration on a genome of the same size with GRCh38-like repeat content: ~45 % of the bases from nine "
                                                    "families (Alu / MIR / L1 / LTR / DNA-transposon-like interspersed copies at 1-30 % divergence, segmental "
                                                    "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True)
+                    sec["grch38_like_se"] = secondary(args, "the same GRCh38-like genome, mate 1 alone as 150 bp single-end reads, -e 0.08 (every candidate of a "
+                                                      "single-end read is verified -- no mate prunes the list first)", dict(one, pe=False), rank, local, grch38_like=True)
                 sec["repeats_50000"] = secondary(args, "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)
             except Exception as ex:      # a secondary key must never lose the headline line
                 sec["error"] = repr(ex)

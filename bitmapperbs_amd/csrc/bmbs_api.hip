@@ -60,6 +60,7 @@ struct Knobs {
     int seed_waves = 65536;     // BMBS_SEED_WAVES
     int decide = 0;             // BMBS_DECIDE: 0 default, 1 plain, 2 lds, 3 vec8
     bool extra_plds = true;
+    bool pesv_long = true;     // BMBS_PESV_LONG=0: every re-seeded mate's candidates sorted by one lane (the round-2 form)
     int vote_class3 = 128;     // BMBS_VOTE_CLASS3: 0 = one block form for all handed-over lists, 128 / 256 = threads of the <= 1024-key form (measured: 2.77 / 2.22 / 2.84 ms)
     bool extra_nolds = false, extra_lds = false, vote_split = false, vote_nomid = false, pe_ascii_full = false;
     bool exact = false;         // BMBS_EXACT=1: every call waits for its stage counts (the round-2 launch sequence)
@@ -81,6 +82,7 @@ struct Knobs {
         e = getenv("BMBS_DECIDE");
         decide = is(e, "plain") ? 1 : is(e, "lds") ? 2 : is(e, "vec8") ? 3 : 0;
         if (const char* e = getenv("BMBS_EXTRA_PLDS")) extra_plds = atoi(e) != 0;
+        if (const char* e = getenv("BMBS_PESV_LONG")) pesv_long = atoi(e) != 0;
         if (const char* e = getenv("BMBS_VOTE_CLASS3")) vote_class3 = atoi(e);
         extra_nolds = getenv("BMBS_EXTRA_NOLDS") != nullptr; extra_lds = getenv("BMBS_EXTRA_LDS") != nullptr;
         vote_split = is(getenv("BMBS_VOTE"), "split"); vote_nomid = getenv("BMBS_VOTE_NOMID") != nullptr;
@@ -1388,8 +1390,18 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
             ENS(c, c->dense_read, rtot * 4); ENS(c, c->ferr, rtot * 4);
             ps.R = c->pe_R.as<PeCand>();
             prof_begin(c, "k_pes_vote");
+            // mates with more than PESV_LONG candidates are flagged, listed (slot 14) and sorted by a block each (BMBS_PESV_LONG=0: all by one lane)
+            u32* pv_flag = c->kn.pesv_long ? c->long_flag.as<u32>() : nullptr;     // n2 words: free again after the vote stage
             hipLaunchKernelGGL(k_pes_vote, dim3(nblk(rt[0], 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, pi, n_reseed, rlist,
-                               c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
+                               c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B, pv_flag);
+            if (pv_flag) {
+                rc = scan_u32(c, pv_flag, rt[0], c->long_off.as<u64>(), 14, c->long_list.as<u32>(), 0, n_reseed);
+                if (rc) return rc;
+                hipLaunchKernelGGL((k_pes_vote_long<1024, 128, PESV_LONG>), dim3(8192), dim3(128), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
+                                   c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
+                hipLaunchKernelGGL((k_pes_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
+                                   c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
+            }
             prof_end(c);
             rc = verify_round(3, rt[1], "k_filter_pe_r3", "k_pe_compact_r3");
             if (rc) return rc;

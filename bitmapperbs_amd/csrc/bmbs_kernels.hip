@@ -2080,21 +2080,23 @@ DEVI void vl_radix_sort(u64* keys, int nc)
         __syncthreads();
     }
 }
-// locate the nc <= VL_CAP candidates of a read into keys[0, np2) (padded with ~0) and sort them ascending; returns np2
+// locate candidates j0 .. j0 + cnt - 1 of a read (cnt <= the LDS capacity) into keys[0, np2) (padded with ~0) and sort them ascending;
+// returns np2.  build_pref: sh_pref (the running sum of the seeds' hit counts) is filled first -- once per read.
 template <int EMAX>
-DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u64* keys, u32* sh_pref)
+DEVI int vl_locate_sort_range(const DevIndex& ix, const SeedRec* my, int ns, long j0, int cnt, u64* keys, u32* sh_pref, bool build_pref)
 {
-    if (threadIdx.x == 0) { u32 a = 0; for (int s2 = 0; s2 < ns; s2++) { sh_pref[s2] = a; a += my[s2].hits; } sh_pref[ns] = a; }
+    if (build_pref && threadIdx.x == 0) { u32 a = 0; for (int s2 = 0; s2 < ns; s2++) { sh_pref[s2] = a; a += my[s2].hits; } sh_pref[ns] = a; }
     __syncthreads();
     int np2 = 32;
-    while (np2 < nc) np2 <<= 1;
+    while (np2 < cnt) np2 <<= 1;
     for (int j = threadIdx.x; j < np2; j += blockDim.x) {
         u64 key = ~0ull;
-        if (j < nc) {
+        if (j < cnt) {
+            const u32 g = (u32)(j0 + j);
             int s2 = 0;
-            while (s2 + 1 < ns && sh_pref[s2 + 1] <= (u32)j) s2++;
+            while (s2 + 1 < ns && sh_pref[s2 + 1] <= g) s2++;
             const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
-            key = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + ((u32)j - sh_pref[s2]))) - adj;
+            key = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + (g - sh_pref[s2]))) - adj;
         }
         keys[j] = key;
     }
@@ -2102,7 +2104,7 @@ DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u
     // long lists (a read inside a repeat family: up to 25 seeds x 1000 rows): LSD radix sort, two bits a pass over the bits that
     // vary -- 17 passes of one block scan each for a 6.2 G text, where the bitonic network takes 78 stages of 8 sweeps over 4096
     // keys.  On a GRCh38-like genome these lists were most of k_vote_pe_long's 11-13 ms per 10 M pairs.
-    if (np2 > 512 && blockDim.x >= 128) { vl_radix_sort<EMAX>(keys, nc); return np2; }
+    if (np2 > 512 && blockDim.x >= 128) { vl_radix_sort<EMAX>(keys, cnt); return np2; }
     for (int size = 2; size <= np2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
@@ -2114,6 +2116,11 @@ DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u
             __syncthreads();
         }
     return np2;
+}
+template <int EMAX>
+DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u64* keys, u32* sh_pref)
+{
+    return vl_locate_sort_range<EMAX>(ix, my, ns, 0, nc, keys, sh_pref, true);
 }
 // positions of the run ends of the sorted keys[0, nc), in order, into endpos; returns their number (block-uniform)
 DEVI int vl_run_ends(const u64* keys, int nc, u16* endpos, int* sh_w)
@@ -4764,12 +4771,15 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
 }
 
 // locate + sort + filtered votes of one re-seeded mate; the list goes to the R buffer (cur = 2)
+#define PESV_LONG 32        // re-seeded mates with more candidates than this go to k_pes_vote_long (a block per mate)
 __global__ void __launch_bounds__(64)
 k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ count_ptr, const u32* __restrict__ plist,
-           const u64* __restrict__ roff, ReadState st, PeState ps, u64* __restrict__ rcand, PeCand* __restrict__ A, PeCand* __restrict__ B)
+           const u64* __restrict__ roff, ReadState st, PeState ps, u64* __restrict__ rcand, PeCand* __restrict__ A, PeCand* __restrict__ B,
+           u32* __restrict__ long_flag)
 {
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= (long)*count_ptr) return;
+    if (long_flag) long_flag[it] = 0;
     const long p = plist[it];
     const int f = ps.first[p];
     const long rF = p + (long)f * n, r = p + (long)(1 - f) * n;
@@ -4780,6 +4790,7 @@ k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ c
     ps.roff[r] = o0;
     const long nc = (long)(o1 - o0);
     if (nc == 0) { ps.len[r] = 0; ps.vround[r] = 0; return; }       // no candidate: best_mapp_occ stays 0
+    if (long_flag && nc > PESV_LONG) { long_flag[it] = 1; return; }   // a mate inside a repeat family: hundreds of candidates, sorted by a block
     const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
     const int ns = st.n_seeds[r];
     u64* c = rcand + o0;
@@ -4802,6 +4813,164 @@ k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ c
         if (i < nc) pre = c[i];
     }
     ps.cur[r] = 2; ps.len[r] = (u32)nv; ps.vround[r] = 3;
+}
+
+// pes_suit without its running lower bound: it returns whether ANY verified hit of the mate lies mind <= |distance| <= maxd from
+// the site (the bound only skips hits more than maxd below the site, which a larger site cannot use either; the scan ends at the
+// first hit more than maxd above it) -- two binary searches in the ascending list.  Sites below 2^63 only (the caller checks).
+DEVI bool pes_suit_any(const PeCand* a, int na, u64 s, long long maxd, long long mind)
+{
+    if (na == 0 || maxd < 0) return false;
+    const u64 mn = mind > 0 ? (u64)mind : 0;
+    if (mn > (u64)maxd) return false;
+    long j = pe_lower_bound(a, na, s + mn);                                        // hits above the site: [s + mn, s + maxd]
+    if (j < na && a[j].site - s <= (u64)maxd) return true;
+    if (s < mn) return false;
+    j = pe_lower_bound(a, na, s > (u64)maxd ? s - (u64)maxd : 0);                  // hits below (or on) it: [s - maxd, s - mn]
+    return j < na && a[j].site <= s - mn;
+}
+// k_pes_vote for the mates it flagged: a block per mate -- candidates located into LDS and sorted (vl_locate_sort), distinct sites
+// (vl_run_ends), the window test per site, kept sites compacted in order.  Lists beyond the LDS capacity and lists with sites that
+// wrapped below zero take k_pes_vote's loop on one lane.
+template <int CAP, int BLOCK, int LO>
+__global__ void __launch_bounds__(BLOCK)
+k_pes_vote_long(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ count_ptr, const u32* __restrict__ items,
+                const u32* __restrict__ plist, const u64* __restrict__ roff, ReadState st, PeState ps, u64* __restrict__ rcand,
+                PeCand* __restrict__ A, PeCand* __restrict__ B)
+{
+    __shared__ u64 keys[CAP];
+    __shared__ u16 endpos[CAP];
+    __shared__ u32 sh_pref[BMBS_MAX_SEEDS + 1];
+    __shared__ int sh_w[2 * (BLOCK / 64) + 1];
+    const long total = (long)*count_ptr;
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long it = items[item];
+        const u64 o0 = roff[it], o1 = roff[it + 1];
+        const long nc = (long)(o1 - o0);
+        if (nc <= LO || (CAP != VL_CAP && nc > CAP)) continue;          // another instance's size class
+        const long p = plist[it];
+        const int f = ps.first[p];
+        const long rF = p + (long)f * n, r = p + (long)(1 - f) * n;
+        const int k = gm.rk(gm.rl(r));
+        long long maxd, mind; int large_k;
+        pe_bounds(gm, pi, p, n, maxd, mind, large_k);
+        const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
+        const int ns = st.n_seeds[r];
+        const PeCand* a = pe_list(ps, st, A, B, rF);
+        const int occF = ps.occ[rF];
+        PeCand* out = ps.R + o0;
+        if (nc > CAP) {
+            // beyond the LDS capacity (a re-seeded mate may collect 25 seeds x 1000 rows; one lane sorting ten thousand sites in global
+            // memory took 50 ms): tiles of CAP candidates are located and sorted in LDS and parked in the output segment (16 bytes
+            // per candidate: room for the 8-byte sites), every site then finds its place by a binary search in each of the other tiles
+            // (ties in tile order), and the merged list -- in the candidate segment -- is made distinct and filtered 256 sites a step
+            u64* tmp = reinterpret_cast<u64*>(out);
+            u64* c = rcand + o0;
+            const int T = (int)((nc + CAP - 1) / CAP);
+            for (int t = 0; t < T; t++) {
+                const long j0 = (long)t * CAP;
+                const int cnt = (int)(nc - j0 < CAP ? nc - j0 : CAP);
+                vl_locate_sort_range<(CAP + BLOCK - 1) / BLOCK>(ix, my, ns, j0, cnt, keys, sh_pref, t == 0);
+                for (int j = threadIdx.x; j < cnt; j += BLOCK) tmp[j0 + j] = keys[j];
+                __syncthreads();
+            }
+            for (long g = threadIdx.x; g < nc; g += BLOCK) {
+                const int t = (int)(g / CAP);
+                const u64 x = tmp[g];
+                long rank = g - (long)t * CAP;
+                for (int u = 0; u < T; u++) {
+                    if (u == t) continue;
+                    const u64* tu = tmp + (long)u * CAP;
+                    const long len = nc - (long)u * CAP < CAP ? nc - (long)u * CAP : CAP;
+                    long lo = 0, hi = len;
+                    while (lo < hi) { const long mid = (lo + hi) >> 1; const u64 y = tu[mid]; if (u < t ? y <= x : y < x) lo = mid + 1; else hi = mid; }
+                    rank += lo;
+                }
+                c[rank] = x;
+            }
+            __syncthreads();
+            if ((occF > 0 && (a[occF - 1].site >> 63)) || (c[nc - 1] >> 63)) {
+                // sites that wrapped below zero: the reference's loop over the sorted list, one lane
+                if (threadIdx.x == 0) {
+                    long nv = 0;
+                    int next_start = 0;
+                    u64 pre = c[0];
+                    for (long i = 1; i <= nc; i++) {
+                        if (i < nc && c[i] == pre) continue;
+                        const u64 site = pre < (u64)k ? 0 : pre - (u64)k;
+                        if (pes_suit(a, occF, next_start, site, maxd, mind)) { out[nv].site = site; out[nv].err = 0; out[nv].end = 0; nv++; }
+                        if (i < nc) pre = c[i];
+                    }
+                    ps.cur[r] = 2; ps.len[r] = (u32)nv; ps.vround[r] = 3;
+                }
+                __syncthreads();
+                continue;
+            }
+            int running = 0;
+            for (long base = 0; base < nc; base += BLOCK) {
+                const long i = base + (long)threadIdx.x;
+                bool keep = false;
+                u64 site = 0;
+                if (i < nc) {
+                    const u64 key = c[i];
+                    if (i == nc - 1 || c[i + 1] != key) { site = key < (u64)k ? 0 : key - (u64)k; keep = pes_suit_any(a, occF, site, maxd, mind); }
+                }
+                int tot;
+                const int pre = vl_prefix(keep, sh_w, tot);
+                if (keep) { PeCand c2; c2.site = site; c2.err = 0; c2.end = 0; out[running + pre] = c2; }
+                running += tot;
+            }
+            if (threadIdx.x == 0) { ps.cur[r] = 2; ps.len[r] = (u32)running; ps.vround[r] = 3; }
+            __syncthreads();
+            continue;
+        }
+        bool serial = occF > 0 && (a[occF - 1].site >> 63);
+        if (!serial) {
+            vl_locate_sort<(CAP + BLOCK - 1) / BLOCK>(ix, my, ns, (int)nc, keys, sh_pref);
+            serial = (keys[nc - 1] >> 63) != 0;
+        }
+        if (serial) {
+            if (threadIdx.x == 0) {
+                u64* c = rcand + o0;
+                long o = 0;
+                for (int s2 = 0; s2 < ns; s2++) {
+                    const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
+                    for (u32 j = 0; j < my[s2].hits; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;
+                }
+                sort_u64_asc(c, nc);
+                long nv = 0;
+                int next_start = 0;
+                u64 pre = c[0];
+                for (long i = 1; i <= nc; i++) {
+                    if (i < nc && c[i] == pre) continue;
+                    const u64 site = pre < (u64)k ? 0 : pre - (u64)k;
+                    if (pes_suit(a, occF, next_start, site, maxd, mind)) { out[nv].site = site; out[nv].err = 0; out[nv].end = 0; nv++; }
+                    if (i < nc) pre = c[i];
+                }
+                ps.cur[r] = 2; ps.len[r] = (u32)nv; ps.vround[r] = 3;
+            }
+            __syncthreads();
+            continue;
+        }
+        const int nd = vl_run_ends(keys, (int)nc, endpos, sh_w);
+        int running = 0;
+        for (int base = 0; base < nd; base += BLOCK) {
+            const int e = base + (int)threadIdx.x;
+            bool keep = false;
+            u64 site = 0;
+            if (e < nd) {
+                const u64 key = keys[endpos[e]];
+                site = key < (u64)k ? 0 : key - (u64)k;
+                keep = pes_suit_any(a, occF, site, maxd, mind);
+            }
+            int tot;
+            const int pre = vl_prefix(keep, sh_w, tot);
+            if (keep) { PeCand c2; c2.site = site; c2.err = 0; c2.end = 0; out[running + pre] = c2; }
+            running += tot;
+        }
+        if (threadIdx.x == 0) { ps.cur[r] = 2; ps.len[r] = (u32)running; ps.vround[r] = 3; }
+        __syncthreads();
+    }
 }
 
 // new_faster_verify_pairs (Schema.cpp:15773-15900) + hand-over of the winning candidates to K11-K13

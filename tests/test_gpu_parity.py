@@ -1317,8 +1317,28 @@ def both_mates_repeat_env(tmp_path_factory):
     ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
     m1, m2 = synth.make_reads_pe(chroms, n=5000, L=100, seed=515, sub=0.01, indel=0.001, qual="random")
     se = synth.make_reads_se(chroms, n=8000, L=120, seed=516, sub=0.01, indel=0.001, qual="random")
-    yield dict(ix=ix, oix=oix, m1=m1, m2=m2, se=se)
+    yield dict(ix=ix, oix=oix, m1=m1, m2=m2, se=se, chroms=chroms)
     ix.close(); oix.close()
+
+
+@pytest.mark.parametrize("form", ["block", "lane"])
+def test_sensitive_reseeded_mates_with_long_lists_match_oracle(both_mates_repeat_env, monkeypatch, form):
+    """--sensitive on diverged pairs inside the repeat families: a mate left without a hit is re-seeded and its candidates (hundreds)
+    are located, sorted, made distinct and tested against the verified mate's hits -- by a block per mate (k_pes_vote_long: binary
+    searches instead of the reference's running lower bound) or, BMBS_PESV_LONG=0, by one lane running the reference's loop;
+    with the default insert range and with a minimum insert (the lower bound of the distance above zero)"""
+    from bitmapperbs_amd import synth, mapper
+    e = both_mates_repeat_env
+    if form == "lane":
+        monkeypatch.setenv("BMBS_PESV_LONG", "0")
+    m1, m2 = synth.make_reads_pe(e["chroms"], n=5000, L=100, seed=616, sub=0.05, indel=0.002, qual="random")
+    for prm in (dict(), dict(min_ins=150, max_ins=600)):
+        recs, ost, _ = e["oix"].map_pe(orc.params(sensitive=1, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+        m = mapper.Mapper(e["ix"], 0, sensitive=1, **prm)
+        for rep in range(2):
+            res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
+            assert not compare_pe(res, pool, recs, 100), (form, prm, rep)
+        m.close()
 
 
 @pytest.mark.parametrize("class3", ["128", "0", "256"])

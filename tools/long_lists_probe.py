@@ -20,7 +20,7 @@ def main():
     cfg = args.cfg
     fa, names, chroms, built = bench.ensure_index(args, cfg, 0, 0, 1, None, grch38_like=True)
     ix = mapper.Index(fa)
-    m = mapper.Mapper(ix, device=0, e_f=cfg["e"])
+    m = mapper.Mapper(ix, device=0, e_f=cfg["e"], sensitive=1 if os.environ.get("PROBE_SENSITIVE") == "1" else 0)
     job = bench.Job(m, cfg, chroms, 0, args.sub, args.indel, args.qual)
     for rep in range(3):
         m.profile_reset()
