@@ -4658,31 +4658,91 @@ k_pes_order(long n, ReadState st, SeedCarry sc, PeState ps)
     else if (vF == 3) ps.vround[rF] = 1;
 }
 
+// pes_suit without its running lower bound: it returns whether ANY verified hit of the mate lies mind <= |distance| <= maxd from
+// the site (the bound only skips hits more than maxd below the site, which a larger site cannot use either; the scan ends at the
+// first hit more than maxd above it) -- two binary searches in the ascending list.  Sites below 2^63 only (the caller checks).
+DEVI bool pes_suit_any(const PeCand* a, int na, u64 s, long long maxd, long long mind)
+{
+    if (na == 0 || maxd < 0) return false;
+    const u64 mn = mind > 0 ? (u64)mind : 0;
+    if (mn > (u64)maxd) return false;
+    long j = pe_lower_bound(a, na, s + mn);                                        // hits above the site: [s + mn, s + maxd]
+    if (j < na && a[j].site - s <= (u64)maxd) return true;
+    if (s < mn) return false;
+    j = pe_lower_bound(a, na, s > (u64)maxd ? s - (u64)maxd : 0);                  // hits below (or on) it: [s - maxd, s - mn]
+    return j < na && a[j].site <= s - mn;
+}
 // after round 1: filter the second mate's votes by the first mate's verified hits (generate_candidate_votes_shift_filter)
+// One lane per pair; a pair whose two lists hold more than 64 entries is done by the whole wave afterwards (pes_suit_any per entry,
+// kept entries compacted by ballot) unless a site of its lists wrapped below zero.
 __global__ void __launch_bounds__(64)
 k_pes_second(long n, ReadGeom gm, PeIns pi, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    long long maxd, mind; int large_k;
-    pe_bounds(gm, pi, p, n, maxd, mind, large_k);
-    if (ps.dead[p]) return;
-    const int f = ps.first[p];
-    const long rF = p + (long)f * n, rS = p + (long)(1 - f) * n;
-    const int occF = ps.occ[rF];
-    if (occF == 0) { ps.dead[p] = 1; return; }
-    if (st.verdict[rS] != 3) return;             // direct hits / 1-mismatch exit / nothing: no verification
-    const PeCand* a = pe_list(ps, st, A, B, rF);
-    PeCand* b = pe_list(ps, st, A, B, rS);
-    const long nb = ps.len[rS];
-    long kept = 0;
-    int next_start = 0;
-    for (long j = 0; j < nb; j++) {
-        const PeCand cj = b[j];
-        if (pes_suit(a, occF, next_start, cj.site, maxd, mind)) b[kept++] = cj;
+    const int lane = threadIdx.x & 63;
+    bool act = p < n && !ps.dead[p];
+    long long maxd = 0, mind = 0; int large_k;
+    long rF = 0, rS = 0;
+    int occF = 0;
+    if (act) {
+        pe_bounds(gm, pi, p, n, maxd, mind, large_k);
+        const int f = ps.first[p];
+        rF = p + (long)f * n; rS = p + (long)(1 - f) * n;
+        occF = ps.occ[rF];
+        if (occF == 0) { ps.dead[p] = 1; act = false; }
+        else if (st.verdict[rS] != 3) act = false;             // direct hits / 1-mismatch exit / nothing: no verification
     }
-    ps.len[rS] = (u32)kept;
-    ps.vround[rS] = 2;
+    const long nb = act ? (long)ps.len[rS] : 0;
+    const bool coop = act && nb + occF > 64;
+    if (act && !coop) {
+        const PeCand* a = pe_list(ps, st, A, B, rF);
+        PeCand* b = pe_list(ps, st, A, B, rS);
+        long kept = 0;
+        int next_start = 0;
+        for (long j = 0; j < nb; j++) {
+            const PeCand cj = b[j];
+            if (pes_suit(a, occF, next_start, cj.site, maxd, mind)) b[kept++] = cj;
+        }
+        ps.len[rS] = (u32)kept;
+        ps.vround[rS] = 2;
+    }
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long pp = (long)__shfl((long long)p, src, 64);
+        long long mxd, mnd; int lk;
+        pe_bounds(gm, pi, pp, n, mxd, mnd, lk);
+        const int f = ps.first[pp];
+        const long rF2 = pp + (long)f * n, rS2 = pp + (long)(1 - f) * n;
+        const int na = ps.occ[rF2];
+        const long nb2 = (long)ps.len[rS2];
+        const PeCand* a = pe_list(ps, st, A, B, rF2);
+        PeCand* b = pe_list(ps, st, A, B, rS2);
+        if ((a[na - 1].site >> 63) || (nb2 && (b[nb2 - 1].site >> 63))) {
+            if (lane == src) {
+                long kept = 0;
+                int next_start = 0;
+                for (long j = 0; j < nb2; j++) {
+                    const PeCand cj = b[j];
+                    if (pes_suit(a, na, next_start, cj.site, mxd, mnd)) b[kept++] = cj;
+                }
+                ps.len[rS2] = (u32)kept; ps.vround[rS2] = 2;
+            }
+            continue;
+        }
+        long kept = 0;
+        for (long base = 0; base < nb2; base += 64) {
+            const long j = base + lane;
+            PeCand cj; cj.site = 0; cj.err = 0; cj.end = 0;
+            bool keep = false;
+            if (j < nb2) { cj = b[j]; keep = pes_suit_any(a, na, cj.site, mxd, mnd); }
+            const unsigned long long kb = __ballot(keep);      // every entry of the step is in registers before the first is stored
+            if (keep) b[kept + __popcll(kb & ((1ull << lane) - 1))] = cj;
+            kept += __popcll(kb);
+        }
+        if (lane == src) { ps.len[rS2] = (u32)kept; ps.vround[rS2] = 2; }
+    }
 }
 
 // pairs whose second mate has no hit are re-seeded
@@ -4815,20 +4875,6 @@ k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ c
     ps.cur[r] = 2; ps.len[r] = (u32)nv; ps.vround[r] = 3;
 }
 
-// pes_suit without its running lower bound: it returns whether ANY verified hit of the mate lies mind <= |distance| <= maxd from
-// the site (the bound only skips hits more than maxd below the site, which a larger site cannot use either; the scan ends at the
-// first hit more than maxd above it) -- two binary searches in the ascending list.  Sites below 2^63 only (the caller checks).
-DEVI bool pes_suit_any(const PeCand* a, int na, u64 s, long long maxd, long long mind)
-{
-    if (na == 0 || maxd < 0) return false;
-    const u64 mn = mind > 0 ? (u64)mind : 0;
-    if (mn > (u64)maxd) return false;
-    long j = pe_lower_bound(a, na, s + mn);                                        // hits above the site: [s + mn, s + maxd]
-    if (j < na && a[j].site - s <= (u64)maxd) return true;
-    if (s < mn) return false;
-    j = pe_lower_bound(a, na, s > (u64)maxd ? s - (u64)maxd : 0);                  // hits below (or on) it: [s - maxd, s - mn]
-    return j < na && a[j].site <= s - mn;
-}
 // k_pes_vote for the mates it flagged: a block per mate -- candidates located into LDS and sorted (vl_locate_sort), distinct sites
 // (vl_run_ends), the window test per site, kept sites compacted in order.  Lists beyond the LDS capacity and lists with sites that
 // wrapped below zero take k_pes_vote's loop on one lane.
