@@ -969,6 +969,8 @@ def main():
                                                    "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True)
                     sec["grch38_like_se"] = secondary(args, "the same GRCh38-like genome, mate 1 alone as 150 bp single-end reads, -e 0.08 (every candidate of a "
                                                       "single-end read is verified -- no mate prunes the list first)", dict(one, pe=False), rank, local, grch38_like=True)
+                    sec["grch38_like_sensitive"] = secondary(args, "the same GRCh38-like genome, pairs in --sensitive mode (configs[3]'s launch size: 5 M pairs)",
+                                                             dict(one, sensitive=True, units=min(cfg["units"], 5_000_000)), rank, local, grch38_like=True)
                 sec["repeats_50000"] = secondary(args, "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)
             except Exception as ex:      # a secondary key must never lose the headline line
                 sec["error"] = repr(ex)

@@ -1280,24 +1280,24 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     unsigned long long* big_count = c->totals.as<unsigned long long>() + 13;
     HIPCHK(c, hipMemsetAsync(big_count, 0, 8, c->stream));
     hipLaunchKernelGGL((k_vote_pe_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A, c->big_list.as<u32>(), big_count);
+                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A, c->big_list.as<u32>(), big_count, c->cand.as<u64>());
     prof_end(c);
     prof_begin(c, "k_vote_pe_big");
     // the handed-over lists in two size classes: up to 1024 candidates (10 KB of LDS per block: twice the blocks per CU of the
     // 4096-key form; on the GRCh38-like genome 88 % of the handed-over lists), and the rest
     if (c->kn.vote_class3 == 128) {
         hipLaunchKernelGGL((k_vote_pe_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
     } else if (c->kn.vote_class3) {
         hipLaunchKernelGGL((k_vote_pe_long<1024, 256, VM_CAP>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
     }
     if (c->kn.vote_class3)
         hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
     else
         hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr);
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {

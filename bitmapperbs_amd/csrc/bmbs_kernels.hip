@@ -2122,6 +2122,37 @@ DEVI int vl_locate_sort(const DevIndex& ix, const SeedRec* my, int ns, int nc, u
 {
     return vl_locate_sort_range<EMAX>(ix, my, ns, 0, nc, keys, sh_pref, true);
 }
+// a list beyond the LDS capacity (a read may collect 25 seeds x 1000 rows; one lane sorting ten thousand sites in global memory took
+// 50 ms and held its whole launch): tiles of CAP candidates are located and sorted in LDS and parked in tmp[0, nc), every site then
+// finds its place by a binary search in each of the other tiles (ties in tile order) and goes to c[rank].  Whole block; c and tmp
+// are global arrays of nc sites each.
+template <int CAP, int BLOCK>
+DEVI void vl_sort_huge(const DevIndex& ix, const SeedRec* my, int ns, long nc, u64* keys, u32* sh_pref, u64* tmp, u64* c)
+{
+    const int T = (int)((nc + CAP - 1) / CAP);
+    for (int t = 0; t < T; t++) {
+        const long j0 = (long)t * CAP;
+        const int cnt = (int)(nc - j0 < CAP ? nc - j0 : CAP);
+        vl_locate_sort_range<(CAP + BLOCK - 1) / BLOCK>(ix, my, ns, j0, cnt, keys, sh_pref, t == 0);
+        for (int j = threadIdx.x; j < cnt; j += BLOCK) tmp[j0 + j] = keys[j];
+        __syncthreads();
+    }
+    for (long g = threadIdx.x; g < nc; g += BLOCK) {
+        const int t = (int)(g / CAP);
+        const u64 x = tmp[g];
+        long rank = g - (long)t * CAP;
+        for (int u = 0; u < T; u++) {
+            if (u == t) continue;
+            const u64* tu = tmp + (long)u * CAP;
+            const long len = nc - (long)u * CAP < CAP ? nc - (long)u * CAP : CAP;
+            long lo = 0, hi = len;
+            while (lo < hi) { const long mid = (lo + hi) >> 1; const u64 y = tu[mid]; if (u < t ? y <= x : y < x) lo = mid + 1; else hi = mid; }
+            rank += lo;
+        }
+        c[rank] = x;
+    }
+    __syncthreads();
+}
 // positions of the run ends of the sorted keys[0, nc), in order, into endpos; returns their number (block-uniform)
 DEVI int vl_run_ends(const u64* keys, int nc, u16* endpos, int* sh_w)
 {
@@ -2353,28 +2384,63 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
         const int ns = st.n_seeds[r];
         bmbs_vote* v = votes + off;
         if (nc > CAP) {
-            // beyond the LDS capacity: the single-lane form
-            if (threadIdx.x == 0) {
-                u64* c = cand + off;
-                u64 o = 0;
-                for (int s2 = 0; s2 < ns && o < (u64)nc; s2++) {
-                    const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
-                    const u32 hh = my[s2].hits;
-                    for (u32 j = 0; j < hh && o < (u64)nc; j++) c[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;
-                }
-                sort_u64_asc(c, nc);
-                long nv = 0;
-                u64 pre = c[0];
-                u32 vote = 1;
-                for (long i = 1; i < nc; i++) {
-                    if (c[i] == pre) vote++;
-                    else { v[nv].site = pre < (u64)k ? 0 : pre - (u64)k; v[nv].vote = vote; v[nv].pad = 0; nv++; vote = 1; pre = c[i]; }
-                }
-                v[nv].site = pre >= (u64)k ? pre - (u64)k : 0; v[nv].vote = vote; v[nv].pad = 0; nv++;
-                intro_sort_desc(v, nv);
-                st.n_votes[r] = (u32)nv;
-                for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
+            // beyond the LDS capacity: the sites are sorted in tiles (vl_sort_huge; the vote segment, 16 bytes per candidate, parks the
+            // tiles), the run ends are listed in the slot map (one word per candidate), and when the distinct sites fit the LDS the vote
+            // order is made as for any other list; otherwise one lane runs std::sort's loop on the votes
+            u64* c = cand + off;
+            u64* tmp = reinterpret_cast<u64*>(v);
+            u32* endidx = slot_read + off;
+            vl_sort_huge<CAP, BLOCK>(ix, my, ns, nc, keys, sh_pref, tmp, c);
+            int nvh = 0;
+            for (long base = 0; base < nc; base += BLOCK) {
+                const long i = base + (long)threadIdx.x;
+                const bool flag = i < nc && (i == nc - 1 || c[i + 1] != c[i]);
+                int tot;
+                const int pre = vl_prefix(flag, sh_w, tot);
+                if (flag) endidx[nvh + pre] = (u32)i;
+                nvh += tot;
             }
+            __syncthreads();
+            for (long e = threadIdx.x; e < nvh; e += BLOCK) tmp[e] = c[endidx[e]];        // distinct sites, in order
+            __syncthreads();
+            if (nvh <= CAP) {
+                for (int e = threadIdx.x; e < nvh; e += BLOCK) {
+                    const u32 vote = endidx[e] - (e ? endidx[e - 1] : 0xffffffffu);
+                    items[e].x = (vote << 24) | (u32)e;
+                    c[e] = tmp[e];
+                }
+                __syncthreads();
+                if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32), (CAP + BLOCK - 1) / BLOCK>(items, nvh, keys, sh_w, sh_ctl)) {
+                    for (int e = threadIdx.x; e < nvh; e += BLOCK) {
+                        const u32 vote = endidx[e] - (e ? endidx[e - 1] : 0xffffffffu);
+                        items[e].x = (vote << 24) | (u32)e;
+                    }
+                    __syncthreads();
+                    if (threadIdx.x == 0) intro_sort_desc(items, (long)nvh);
+                    __syncthreads();
+                }
+                for (int j = threadIdx.x; j < nvh; j += BLOCK) {
+                    const u32 it = items[j].x;
+                    const u64 site = c[it & 0xffffffu];
+                    bmbs_vote o; o.site = site < (u64)k ? 0 : site - (u64)k; o.vote = it >> 24; o.pad = 0;
+                    v[j] = o;
+                }
+            } else {
+                // more distinct sites than the LDS holds: the votes in site order (written back to front: v[e] covers tmp[2e], tmp[2e + 1],
+                // which only entries at or beyond e still need), then std::sort's loop on one lane
+                if (threadIdx.x == 0) {
+                    for (long e = nvh - 1; e >= 0; e--) {
+                        const u64 site = tmp[e];
+                        const u32 vote = endidx[e] - (e ? endidx[e - 1] : 0xffffffffu);
+                        bmbs_vote o; o.site = site < (u64)k ? 0 : site - (u64)k; o.vote = vote; o.pad = 0;
+                        v[e] = o;
+                    }
+                    intro_sort_desc(v, (long)nvh);
+                }
+            }
+            __syncthreads();
+            for (long i = threadIdx.x; i < nc; i += BLOCK) slot_read[off + i] = i < nvh ? (u32)r : 0xffffffffu;
+            if (threadIdx.x == 0) st.n_votes[r] = (u32)nvh;
             __syncthreads();
             continue;
         }
@@ -4182,28 +4248,7 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
         return;
     }
     if (mid_flag && nc <= VOTE_MID) { mid_flag[r] = 1; return; }      // 17..32 candidates, the rule for reads of 180 bases and more: k_vote_pe_mid
-    if (nc <= VL_CAP) { long_flag[r] = 1; return; }          // repeats: k_vote_pe_long sorts the list out of LDS
-    u64* c = cand + off;
-    {
-        u64 w = 0;
-        for (int s2 = 0; s2 < ns && w < (u64)nc; s2++) {
-            const u64 sp = my[s2].sp, adj = (u64)my[s2].len + (u64)my[s2].off;
-            const u32 hh = my[s2].hits;
-            for (u32 j = 0; j < hh && w < (u64)nc; j++) c[w++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;
-        }
-    }
-    sort_u64_asc(c, nc);
-    if (v == 4) {
-        for (long i = 0; i < nc; i++) { o[i].site = c[i]; o[i].err = 0; o[i].end = L - 1; }
-        ps.occ[r] = (int)nc; ps.len[r] = (u32)nc;
-    } else {
-        long nv = 0;
-        u64 pre = c[0];
-        for (long i = 1; i < nc; i++)
-            if (c[i] != pre) { o[nv].site = pre < (u64)k ? 0 : pre - (u64)k; o[nv].err = 0; o[nv].end = 0; nv++; pre = c[i]; }
-        o[nv].site = pre >= (u64)k ? pre - (u64)k : 0; o[nv].err = 0; o[nv].end = 0; nv++;
-        ps.occ[r] = -1; ps.len[r] = (u32)nv;
-    }
+    long_flag[r] = 1;                                         // repeats: k_vote_pe_long sorts the list out of LDS (beyond its capacity: in tiles)
 }
 
 // lists of 17..32 candidates (reads of 180 bases and more place up to 25 seeds): one lane per read over the compacted list,
@@ -4272,7 +4317,7 @@ k_vote_pe_mid(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __r
 template <int CAP, int BLOCK, int LO>
 __global__ void __launch_bounds__(BLOCK)
 k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
-               PeCand* __restrict__ A, u32* __restrict__ big_list, unsigned long long* __restrict__ big_count)
+               PeCand* __restrict__ A, u32* __restrict__ big_list, unsigned long long* __restrict__ big_count, u64* __restrict__ cand)
 {
     __shared__ u64 keys[CAP];
     __shared__ u16 endpos[CAP];
@@ -4285,10 +4330,34 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
         // the wave form sees every listed read and passes the ones beyond its capacity on (a list of their own: the block form used
         // to walk the whole list -- millions of reads on a repeat-rich genome, two dependent loads each -- to find its few)
         if (big_list && nc > CAP) { if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1ull)] = (u32)r; continue; }
-        if (nc <= LO || nc > CAP) continue;                          // another instance's size class
+        if (nc <= LO || (CAP != VL_CAP && nc > CAP)) continue;       // another instance's size class (the largest also takes what is beyond it)
         const int L = gm.rl(r), k = gm.rk(L);
         const int v = st.verdict[r];
         PeCand* o = A + st.cand_off[r];
+        if (nc > CAP) {
+            // beyond the LDS capacity: sorted in tiles (vl_sort_huge; the output segment parks the tiles), then the same entries in order
+            u64* c = cand + st.cand_off[r];
+            vl_sort_huge<CAP, BLOCK>(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], nc, keys, sh_pref, reinterpret_cast<u64*>(o), c);
+            if (v == 4) {
+                for (long i = threadIdx.x; i < nc; i += BLOCK) { PeCand e; e.site = c[i]; e.err = 0; e.end = L - 1; o[i] = e; }
+                if (threadIdx.x == 0) { ps.occ[r] = (int)nc; ps.len[r] = (u32)nc; }
+            } else {
+                int running = 0;
+                for (long base = 0; base < nc; base += BLOCK) {
+                    const long i = base + (long)threadIdx.x;
+                    bool keep = false;
+                    u64 key = 0;
+                    if (i < nc) { key = c[i]; keep = i == nc - 1 || c[i + 1] != key; }
+                    int tot;
+                    const int pre = vl_prefix(keep, sh_w, tot);
+                    if (keep) { PeCand e; e.site = key < (u64)k ? 0 : key - (u64)k; e.err = 0; e.end = 0; o[running + pre] = e; }
+                    running += tot;
+                }
+                if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)running; }
+            }
+            __syncthreads();
+            continue;
+        }
         vl_locate_sort<(CAP + BLOCK - 1) / BLOCK>(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], (int)nc, keys, sh_pref);
         if (v == 4) {
             for (long i = threadIdx.x; i < nc; i += BLOCK) { PeCand e; e.site = keys[i]; e.err = 0; e.end = L - 1; o[i] = e; }
@@ -4906,35 +4975,10 @@ k_pes_vote_long(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restric
         const int occF = ps.occ[rF];
         PeCand* out = ps.R + o0;
         if (nc > CAP) {
-            // beyond the LDS capacity (a re-seeded mate may collect 25 seeds x 1000 rows; one lane sorting ten thousand sites in global
-            // memory took 50 ms): tiles of CAP candidates are located and sorted in LDS and parked in the output segment (16 bytes
-            // per candidate: room for the 8-byte sites), every site then finds its place by a binary search in each of the other tiles
-            // (ties in tile order), and the merged list -- in the candidate segment -- is made distinct and filtered 256 sites a step
-            u64* tmp = reinterpret_cast<u64*>(out);
+            // beyond the LDS capacity: vl_sort_huge, the tiles parked in the output segment (16 bytes per candidate: room for the 8-byte
+            // sites); the merged list -- in the candidate segment -- is made distinct and filtered 256 sites a step
             u64* c = rcand + o0;
-            const int T = (int)((nc + CAP - 1) / CAP);
-            for (int t = 0; t < T; t++) {
-                const long j0 = (long)t * CAP;
-                const int cnt = (int)(nc - j0 < CAP ? nc - j0 : CAP);
-                vl_locate_sort_range<(CAP + BLOCK - 1) / BLOCK>(ix, my, ns, j0, cnt, keys, sh_pref, t == 0);
-                for (int j = threadIdx.x; j < cnt; j += BLOCK) tmp[j0 + j] = keys[j];
-                __syncthreads();
-            }
-            for (long g = threadIdx.x; g < nc; g += BLOCK) {
-                const int t = (int)(g / CAP);
-                const u64 x = tmp[g];
-                long rank = g - (long)t * CAP;
-                for (int u = 0; u < T; u++) {
-                    if (u == t) continue;
-                    const u64* tu = tmp + (long)u * CAP;
-                    const long len = nc - (long)u * CAP < CAP ? nc - (long)u * CAP : CAP;
-                    long lo = 0, hi = len;
-                    while (lo < hi) { const long mid = (lo + hi) >> 1; const u64 y = tu[mid]; if (u < t ? y <= x : y < x) lo = mid + 1; else hi = mid; }
-                    rank += lo;
-                }
-                c[rank] = x;
-            }
-            __syncthreads();
+            vl_sort_huge<CAP, BLOCK>(ix, my, ns, nc, keys, sh_pref, reinterpret_cast<u64*>(out), c);
             if ((occF > 0 && (a[occF - 1].site >> 63)) || (c[nc - 1] >> 63)) {
                 // sites that wrapped below zero: the reference's loop over the sorted list, one lane
                 if (threadIdx.x == 0) {

@@ -1390,11 +1390,64 @@ def test_long_lists_on_both_mates_match_oracle(both_mates_repeat_env, monkeypatc
     m.close()
 
 
+@pytest.fixture(scope="module")
+def huge_lists_env(tmp_path_factory):
+    """1.4 Mb genome with 990 identical, non-overlapping copies of a 500-base element: a 250-base read inside a copy places up to
+    eight seeds of 990 rows each -- lists of 4 000 to 7 000 candidates, beyond the LDS capacity of the long-list kernels"""
+    from bitmapperbs_amd import synth, mapper
+    d = tmp_path_factory.mktemp("huge")
+    names, chroms = synth.make_genome(1_400_000, 2, seed=777)
+    rng = np.random.default_rng(888)
+    el = synth._ACGT[rng.integers(0, 4, 500)]
+    k_ = 0
+    for ch in chroms:
+        for p_ in range(100, ch.size - 600, 1400):
+            if k_ >= 990:
+                break
+            ch[p_:p_ + 500] = synth.revcomp(el) if rng.random() < 0.5 else el
+            k_ += 1
+    fa = str(d / "huge.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=8)
+    ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
+    yield dict(ix=ix, oix=oix, chroms=chroms)
+    ix.close(); oix.close()
+
+
+@pytest.mark.parametrize("mode", ["se", "se_ambiguous_out", "pe", "pe_sensitive"])
+def test_lists_beyond_the_lds_capacity_match_oracle(huge_lists_env, mode):
+    """candidate lists of more than 4096 sites: sorted in tiles by a block and merged by rank (vl_sort_huge) in k_vote_long (votes and
+    std::sort's visiting order after it), k_vote_pe_long and k_pes_vote_long -- one lane sorting such a list in global memory
+    used to hold its whole launch for tens of milliseconds"""
+    from bitmapperbs_amd import synth, mapper
+    e = huge_lists_env
+    L = 250
+    if mode.startswith("se"):
+        amb = 1 if mode == "se_ambiguous_out" else 0
+        r = synth.make_reads_se(e["chroms"], n=4000, L=L, seed=79, sub=0.04, indel=0.001, qual="random")
+        recs, ost, cnt = e["oix"].map_se(orc.params(ambiguous_out=amb), r["seq"], r["qual"], L)
+        assert int((recs["n_cand"] > 4096).sum()) > 50
+        m = mapper.Mapper(e["ix"], 0, ambiguous_out=amb)
+        for rep in range(2):
+            res, pool = m.map_se(r["seq"], r["qual"], L)
+            assert not compare_records(res, pool, recs, L, amb=bool(amb)), (mode, rep)
+        m.close()
+    else:
+        sens = 1 if mode == "pe_sensitive" else 0
+        m1, m2 = synth.make_reads_pe(e["chroms"], n=3000, L=L, seed=80, sub=0.05, indel=0.001, qual="random", ins_hi=480)
+        recs, ost, _ = e["oix"].map_pe(orc.params(sensitive=sens), m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+        m = mapper.Mapper(e["ix"], 0, sensitive=sens)
+        for rep in range(2):
+            res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+            assert int((res["n_cand"].astype(np.int64) > 4096).sum()) > 20
+            assert not compare_pe(res, pool, recs, L), (mode, rep)
+        m.close()
+
+
 def test_very_long_candidate_lists_match_oracle(tmp_path):
     """reads inside a family of 900 identical copies (and one of 600 copies at 2 % divergence): seeds that hit hundreds of rows each
-    give candidate lists of thousands -- the block form of the long-list kernels with its radix sort (lists beyond 512), the
-    wave-per-pair filter, lists beyond the 4096-candidate capacity on the single-lane fall-back; SE and pairs, first call and second
-    (which has the mid-list kernels on)"""
+    give candidate lists of up to 2 400 -- the block form of the long-list kernels with its radix sort (lists beyond 512), the
+    wave-per-pair filter; SE and pairs, first call and second (which has the mid-list kernels on)"""
     from bitmapperbs_amd import synth, mapper
     names, chroms = synth.make_genome(2_000_000, 2, seed=1234)
     rng = np.random.default_rng(4321)
