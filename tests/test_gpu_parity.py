@@ -1406,12 +1406,52 @@ def huge_lists_env(tmp_path_factory):
                 break
             ch[p_:p_ + 500] = synth.revcomp(el) if rng.random() < 0.5 else el
             k_ += 1
+    # eight 31-base elements, one copy of each in the free part of every slot, and ONE place where they stand side by side: a read
+    # from there (with a substitution at each junction) has seeds of 991 rows in six or more of them that agree on nothing --
+    # about 6 000 candidates and as many distinct sites
+    mosaic = [synth._ACGT[rng.integers(0, 4, 31)] for _ in range(8)]
+    k_ = 0
+    for ch in chroms:
+        for p_ in range(100, ch.size - 600, 1400):
+            if k_ >= 990:
+                break
+            for i, el8 in enumerate(mosaic):
+                ch[p_ + 560 + 43 * i:p_ + 560 + 43 * i + 31] = el8
+            k_ += 1
+    chroms[0][1150:1150 + 248] = np.concatenate(mosaic)
     fa = str(d / "huge.fa")
     synth.write_fasta(fa, names, chroms)
     mapper.Index.build(fa, fa, threads=8)
     ix, oix = mapper.Index(fa), orc.OrcIndex(fa)
-    yield dict(ix=ix, oix=oix, chroms=chroms)
+    yield dict(ix=ix, oix=oix, chroms=chroms, mosaic=np.concatenate(mosaic))
     ix.close(); oix.close()
+
+
+@pytest.mark.parametrize("amb", [0, 1])
+def test_more_distinct_sites_than_the_lds_holds_match_oracle(huge_lists_env, amb):
+    """single-end reads whose seeds hit 991 rows each in six different families and agree on nothing: more than 4096 DISTINCT sites
+    -- the votes of such a list cannot be ordered in LDS; the sites are still sorted by the block (vl_sort_huge), std::sort's
+    loop on the votes runs on one lane"""
+    from bitmapperbs_amd import mapper
+    e = huge_lists_env
+    rng = np.random.default_rng(99)
+    n, L = 200, 248
+    seq = np.tile(e["mosaic"], (n, 1)).copy()
+    other = {65: 67, 67: 71, 71: 84, 84: 65}
+    for i in range(n):
+        for el8 in range(1, 8):                            # one substitution at the end of each of the first seven elements
+            seq[i, el8 * 31 - 1] = other[int(seq[i, el8 * 31 - 1])]
+        if i % 3 == 0:                                     # ... and one more somewhere
+            j = int(rng.integers(5, L - 5))
+            seq[i, j] = other[int(seq[i, j])]
+    qual = rng.integers(35, 74, (n, L)).astype(np.uint8)
+    recs, ost, cnt = e["oix"].map_se(orc.params(ambiguous_out=amb), seq, qual, L)
+    assert int((recs["n_cand"] > 4096).sum()) > n // 2
+    m = mapper.Mapper(e["ix"], 0, ambiguous_out=amb)
+    for rep in range(2):
+        res, pool = m.map_se(seq, qual, L)
+        assert not compare_records(res, pool, recs, L, amb=bool(amb)), (amb, rep)
+    m.close()
 
 
 @pytest.mark.parametrize("mode", ["se", "se_ambiguous_out", "pe", "pe_sensitive"])
