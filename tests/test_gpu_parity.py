@@ -711,7 +711,7 @@ def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knob", ["BMBS_DECIDE=plain", "BMBS_DECIDE=lds", "BMBS_DECIDE=vec8", "BMBS_VOTE=split", "BMBS_VOTE_NOMID=1", "BMBS_SEED_WAVES=4096",
-                                  "BMBS_TDEPTH=21", "BMBS_SW=wave", "BMBS_SW=reg", "BMBS_ROWS=ascii"])
+                                  "BMBS_TDEPTH=21", "BMBS_SW=wave", "BMBS_SW=reg", "BMBS_ROWS=ascii", "BMBS_EXTRA_PLDS=0"])
 def test_ab_switches_give_identical_records(knob, env, monkeypatch):
     """the alternative kernel forms kept for A/B measurements map exactly like the default ones"""
     from bitmapperbs_amd import synth, mapper
