@@ -60,6 +60,7 @@ struct Knobs {
     int seed_waves = 65536;     // BMBS_SEED_WAVES
     int decide = 0;             // BMBS_DECIDE: 0 default, 1 plain, 2 lds, 3 vec8
     bool extra_plds = true;
+    bool vote_class4 = true;   // BMBS_VOTE_CLASS4=0: no 2048-key form between the 1024- and the 4096-key one (single-end k_vote_big 6.3 -> 5.1 ms with it)
     bool pesv_long = true;     // BMBS_PESV_LONG=0: every re-seeded mate's candidates sorted by one lane (the round-2 form)
     int vote_class3 = 128;     // BMBS_VOTE_CLASS3: 0 = one block form for all handed-over lists, 128 / 256 = threads of the <= 1024-key form (measured: 2.77 / 2.22 / 2.84 ms)
     bool extra_nolds = false, extra_lds = false, vote_split = false, vote_nomid = false, pe_ascii_full = false;
@@ -82,6 +83,7 @@ struct Knobs {
         e = getenv("BMBS_DECIDE");
         decide = is(e, "plain") ? 1 : is(e, "lds") ? 2 : is(e, "vec8") ? 3 : 0;
         if (const char* e = getenv("BMBS_EXTRA_PLDS")) extra_plds = atoi(e) != 0;
+        if (const char* e = getenv("BMBS_VOTE_CLASS4")) vote_class4 = atoi(e) != 0;
         if (const char* e = getenv("BMBS_PESV_LONG")) pesv_long = atoi(e) != 0;
         if (const char* e = getenv("BMBS_VOTE_CLASS3")) vote_class3 = atoi(e);
         extra_nolds = getenv("BMBS_EXTRA_NOLDS") != nullptr; extra_lds = getenv("BMBS_EXTRA_LDS") != nullptr;
@@ -758,7 +760,12 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         else if (c->kn.vote_class3)
             hipLaunchKernelGGL((k_vote_long<1024, 256, VM_CAP>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
                                c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
-        if (c->kn.vote_class3)
+        if (c->kn.vote_class3 && c->kn.vote_class4) {
+            hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        } else if (c->kn.vote_class3)
             hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
                                c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
         else
@@ -1292,7 +1299,12 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
         hipLaunchKernelGGL((k_vote_pe_long<1024, 256, VM_CAP>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
                            c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
     }
-    if (c->kn.vote_class3)
+    if (c->kn.vote_class3 && c->kn.vote_class4) {
+        hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+        hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
+                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+    } else if (c->kn.vote_class3)
         hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
                            c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
     else

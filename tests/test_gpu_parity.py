@@ -1341,14 +1341,16 @@ def test_sensitive_reseeded_mates_with_long_lists_match_oracle(both_mates_repeat
         m.close()
 
 
-@pytest.mark.parametrize("class3", ["128", "0", "256"])
+@pytest.mark.parametrize("class3", ["128", "0", "256", "128-no2048"])
 def test_long_lists_single_end_size_classes_match_oracle(both_mates_repeat_env, monkeypatch, class3):
     """single-end reads on the same genome: lists of hundreds of candidates through the three forms of k_vote_long (a wave; a block
     of 128 or 256 threads over up to 1024 keys; 256 threads over up to 4096) -- sites, votes and std::sort's visiting order must
     be the same whichever form a list takes (BMBS_VOTE_CLASS3), with and without --ambiguous_out"""
     from bitmapperbs_amd import mapper
     e = both_mates_repeat_env
-    monkeypatch.setenv("BMBS_VOTE_CLASS3", class3)
+    monkeypatch.setenv("BMBS_VOTE_CLASS3", class3.split("-")[0])
+    if class3.endswith("no2048"):
+        monkeypatch.setenv("BMBS_VOTE_CLASS4", "0")
     r = e["se"]
     for amb in (0, 1):
         recs, ost, cnt = e["oix"].map_se(orc.params(ambiguous_out=amb), r["seq"], r["qual"], 120)
@@ -1360,7 +1362,7 @@ def test_long_lists_single_end_size_classes_match_oracle(both_mates_repeat_env, 
         m.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "min_insert", "ambiguous_out", "sensitive", "one_block_form", "block_256"])
+@pytest.mark.parametrize("variant", ["default", "min_insert", "ambiguous_out", "sensitive", "one_block_form", "block_256", "no_2048_class"])
 def test_long_lists_on_both_mates_match_oracle(both_mates_repeat_env, monkeypatch, variant):
     """the wave-cooperative parts of k_pe_compact / k_pe_prune / k_pe_pair (lists of more than 64 entries on both mates: compaction by
     ballot, prune by binary search, pairing by ordered summaries) against the oracle's loops -- ties of the best error sum, the
@@ -1379,6 +1381,8 @@ def test_long_lists_on_both_mates_match_oracle(both_mates_repeat_env, monkeypatc
         monkeypatch.setenv("BMBS_VOTE_CLASS3", "0")
     elif variant == "block_256":
         monkeypatch.setenv("BMBS_VOTE_CLASS3", "256")
+    elif variant == "no_2048_class":
+        monkeypatch.setenv("BMBS_VOTE_CLASS4", "0")
     m1, m2 = e["m1"], e["m2"]
     recs, ost, _ = e["oix"].map_pe(orc.params(sensitive=sensitive, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
     m = mapper.Mapper(e["ix"], 0, sensitive=sensitive, **prm)
