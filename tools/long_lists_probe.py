@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """tools/long_lists_probe.py [pairs] -- on the GRCh38-like stress genome of bench.py: how long the candidate lists are (histogram of
-bmbs_result.n_cand over the reads of one launch) and what the vote / pair-filter kernels cost on them."""
+bmbs_result.n_cand over the reads of one launch) and what the vote / pair-filter kernels cost on them.
+Environment: PROBE_SE=1 single-end reads, PROBE_SENSITIVE=1 pairs in --sensitive mode, PROBE_AB="KNOB=v1,v2,..." the same launch
+under each value of a knob the context reads when it is created.  tools/trace_probe.sh runs it under rocprofv3 --kernel-trace (a
+kernel's own duration: the HIP-event sums printed here include what the other lane ran beside it)."""
 import os
 import sys
 
