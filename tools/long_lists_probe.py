@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/long_lists_probe.py [pairs] -- on the GRCh38-like stress genome of bench.py: how long the candidate lists are (histogram of
 bmbs_result.n_cand over the reads of one launch) and what the vote / pair-filter kernels cost on them.
-Environment: PROBE_SE=1 single-end reads, PROBE_SENSITIVE=1 pairs in --sensitive mode, PROBE_AB="KNOB=v1,v2,..." the same launch
+Environment: PROBE_CONFIG=4 the 250-base pairs of configs[4] (default 2), PROBE_SE=1 single-end reads, PROBE_SENSITIVE=1 pairs in --sensitive mode, PROBE_AB="KNOB=v1,v2,..." the same launch
 under each value of a knob the context reads when it is created.  tools/trace_probe.sh runs it under rocprofv3 --kernel-trace (a
 kernel's own duration: the HIP-event sums printed here include what the other lane ran beside it)."""
 import os
@@ -19,7 +19,7 @@ def main():
     from bitmapperbs_amd import mapper, capi
     pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
     se = os.environ.get("PROBE_SE") == "1"           # single-end reads on the same genome (the SE vote / reduce kernels)
-    args = bench.parse(["--config", "2", "--units", str(pairs), "--launches", "1"] + (["--se"] if se else []))
+    args = bench.parse(["--config", os.environ.get("PROBE_CONFIG", "2"), "--units", str(pairs), "--launches", "1"] + (["--se"] if se else []))
     cfg = args.cfg
     fa, names, chroms, built = bench.ensure_index(args, cfg, 0, 0, 1, None, grch38_like=True)
     ix = mapper.Index(fa)
