@@ -27,6 +27,7 @@
 // record range of the input; for pairs the ranges are cut at the same record in both files (found by the read names, by counting
 // lines when the names do not tell).
 #include "../../include/bmbs.h"
+#include "pgz.h"
 #include <zlib.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -186,7 +187,6 @@ struct Source {
     size_t size = 0, off = 0, end = 0;           // plain: the part's byte range [off, end)
     std::string err;
     // .gz: inflated text arrives as numbered chunks; `ready` hands them to window() in order
-    gzFile gzf = nullptr;
     std::vector<std::thread> inflaters;
     std::mutex m; std::condition_variable cv_data, cv_room;
     std::map<long, std::vector<char>> ready;     // chunk number -> text
@@ -199,6 +199,10 @@ struct Source {
     bool bgzf = false;
     const unsigned char* zmap = nullptr; size_t zsize = 0, znext = 0;     // the compressed file, mapped; next unassigned block
     long zjob = 0;                                                        // number of the next job
+    // ordinary gzip (one deflate stream per member): block-parallel inflate, pgz.h
+    std::unique_ptr<pgz::Engine> pgz_eng;
+    std::thread pgz_watch;
+    int gz_threads_ = 1;
 
     static bool is_gz(const char* path)
     {
@@ -215,6 +219,22 @@ struct Source {
         if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4) || p[10] != 6 || p[11] != 0 || p[12] != 'B' || p[13] != 'C' || p[14] != 2 || p[15] != 0) return 0;
         const size_t bs = (size_t)(p[16] | (p[17] << 8)) + 1;
         return bs >= 26 && bs <= avail ? bs : 0;
+    }
+    static size_t bgzf_isize(const unsigned char* p, size_t bs) { return (size_t)p[bs - 4] | ((size_t)p[bs - 3] << 8) | ((size_t)p[bs - 2] << 16) | ((size_t)p[bs - 1] << 24); }
+    // the gzip members from byte `at` of the mapped file on, chunk numbers from `first_id` (called with `m` held)
+    void start_pgz(size_t at, long first_id)
+    {
+        if (gz_stop || pgz_eng) return;
+        pgz::Options o; o.threads = gz_threads_; o.span = (size_t)1 << 20;
+        if (const char* sp = getenv("BMBS_GZ_SPAN")) { const long v = atol(sp); if (v >= 1024) o.span = (size_t)v; }      // tests: many spans in a small file
+        pgz_eng.reset(new pgz::Engine(zmap, zsize, at, first_id, o, [this](long id, std::vector<char>&& c) { push_chunk(id, std::move(c)); }));
+        live_inflaters++;
+        pgz_eng->start();
+        pgz_watch = std::thread([this] {
+            const std::string e = pgz_eng->wait();
+            if (!e.empty()) { std::lock_guard<std::mutex> l(m); if (err.empty()) err = e; }
+            inflater_exit();
+        });
     }
     void push_chunk(long id, std::vector<char>&& c)
     {
@@ -237,16 +257,20 @@ struct Source {
         if (gz) {
             const int zfd = ::open(path, O_RDONLY);
             struct stat zsb;
-            if (zfd >= 0 && fstat(zfd, &zsb) == 0 && zsb.st_size > 28) {
+            bool zmap_keep = false;
+            if (zfd >= 0 && fstat(zfd, &zsb) == 0 && zsb.st_size >= 18) {
                 void* mp = mmap(nullptr, (size_t)zsb.st_size, PROT_READ, MAP_PRIVATE, zfd, 0);
                 if (mp != MAP_FAILED) {
-                    if (bgzf_block((const unsigned char*)mp, (size_t)zsb.st_size)) { bgzf = true; zmap = (const unsigned char*)mp; zsize = (size_t)zsb.st_size; }
-                    else munmap(mp, (size_t)zsb.st_size);
+                    zmap = (const unsigned char*)mp; zsize = (size_t)zsb.st_size; zmap_keep = true;
+                    (void)madvise(mp, zsize, MADV_SEQUENTIAL);
+                    bgzf = bgzf_block(zmap, zsize) != 0;
                 }
             }
             if (zfd >= 0) ::close(zfd);
+            if (!zmap_keep) return false;
+            gz_threads_ = std::max(1, gz_threads);
             if (bgzf) {
-                const int n_inflaters = std::max(1, gz_threads);
+                const int n_inflaters = gz_threads_;
                 live_inflaters = n_inflaters;                   // (the threads count it down as they finish: not the loop bound)
                 for (int t = 0; t < n_inflaters; t++)
                     inflaters.emplace_back([this] {
@@ -258,29 +282,38 @@ struct Source {
                             {
                                 std::lock_guard<std::mutex> l(m);
                                 if (gz_stop || znext >= zsize) break;
-                                a = znext; id = zjob++;
+                                a = znext; id = zjob;
                                 size_t q = a;
                                 while (q < zsize && q - a < ((size_t)2 << 20)) { const size_t bs = bgzf_block(zmap + q, zsize - q); if (!bs) break; q += bs; }
-                                if (q == a) { err = "corrupt BGZF block header in the .gz input"; znext = zsize; break; }
-                                e = q; znext = q;
-                            }
-                            std::vector<char> out;
-                            size_t total = 0;
-                            for (size_t q = a; q < e;) { const size_t bs = bgzf_block(zmap + q, zsize - q); total += (size_t)zmap[q + bs - 4] | ((size_t)zmap[q + bs - 3] << 8) | ((size_t)zmap[q + bs - 2] << 16) | ((size_t)zmap[q + bs - 1] << 24); q += bs; }
-                            out.resize(total);
-                            size_t at = 0; bool bad = false;
-                            for (size_t q = a; q < e && !bad;) {
-                                const size_t bs = bgzf_block(zmap + q, zsize - q);
-                                const size_t isz = (size_t)zmap[q + bs - 4] | ((size_t)zmap[q + bs - 3] << 8) | ((size_t)zmap[q + bs - 2] << 16) | ((size_t)zmap[q + bs - 1] << 24);
-                                if (isz) {
-                                    inflateReset(&zs);
-                                    zs.next_in = (Bytef*)(zmap + q + 18); zs.avail_in = (uInt)(bs - 26);
-                                    zs.next_out = (Bytef*)(out.data() + at); zs.avail_out = (uInt)isz;
-                                    const int rc = inflate(&zs, Z_FINISH);
-                                    if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+                                if (q == a) {
+                                    // not a BGZF block: a file whose later members are ordinary gzip goes on through the stream inflater
+                                    znext = zsize;
+                                    if (pgz::gzip_header(zmap, zsize, a)) start_pgz(a, id);
+                                    else err = "corrupt BGZF block header in the .gz input";
+                                    break;
                                 }
-                                at += isz; q += bs;
+                                zjob++; e = q; znext = q;
                             }
+                            bool bad = false;
+                            std::vector<char> out;
+                            try {
+                                size_t total = 0;
+                                for (size_t q = a; q < e;) { const size_t bs = bgzf_block(zmap + q, zsize - q); const size_t isz = bgzf_isize(zmap + q, bs); if (isz > 65536) bad = true; total += isz; q += bs; }
+                                if (!bad) out.resize(total);
+                                size_t at = 0;
+                                for (size_t q = a; q < e && !bad;) {
+                                    const size_t bs = bgzf_block(zmap + q, zsize - q);
+                                    const size_t isz = bgzf_isize(zmap + q, bs);
+                                    if (isz) {
+                                        inflateReset(&zs);
+                                        zs.next_in = (Bytef*)(zmap + q + 18); zs.avail_in = (uInt)(bs - 26);
+                                        zs.next_out = (Bytef*)(out.data() + at); zs.avail_out = (uInt)isz;
+                                        const int rc = inflate(&zs, Z_FINISH);
+                                        if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+                                    }
+                                    at += isz; q += bs;
+                                }
+                            } catch (const std::exception&) { bad = true; }
                             if (bad) { std::lock_guard<std::mutex> l(m); err = "corrupt BGZF block in the .gz input"; znext = zsize; break; }
                             push_chunk(id, std::move(out));
                         }
@@ -289,21 +322,10 @@ struct Source {
                     });
                 return true;
             }
-            gzf = gzopen(path, "rb");
-            if (!gzf) return false;
-            gzbuffer(gzf, 1 << 20);
-            live_inflaters = 1;
-            inflaters.emplace_back([this] {
-                for (long id = 0;; id++) {
-                    std::vector<char> c((size_t)8 << 20);
-                    const int n = gzread(gzf, c.data(), (unsigned)c.size());
-                    if (n <= 0) { if (n < 0) { std::lock_guard<std::mutex> l(m); err = "gzread failed (corrupt .gz input?)"; } break; }
-                    c.resize((size_t)n);
-                    push_chunk(id, std::move(c));
-                    { std::lock_guard<std::mutex> l(m); if (gz_stop) break; }
-                }
-                inflater_exit();
-            });
+            {
+                std::lock_guard<std::mutex> l(m);
+                start_pgz(0, 0);
+            }
             return true;
         }
         fd = ::open(path, O_RDONLY);
@@ -384,16 +406,21 @@ struct Source {
     }
     void close()
     {
-        if (!inflaters.empty()) {
+        if (gz) {
             { std::lock_guard<std::mutex> l(m); gz_stop = true; }
             cv_room.notify_all();
+            if (pgz_eng) pgz_eng->stop();
             for (auto& t : inflaters) t.join();
             inflaters.clear();
+            if (pgz_watch.joinable()) pgz_watch.join();
+            pgz_eng.reset();
         }
-        if (gzf) gzclose(gzf);
         if (zmap) munmap((void*)zmap, zsize);
+        zmap = nullptr;
         if (fd >= 0) ::close(fd);
+        fd = -1; gz = false;
     }
+    ~Source() { close(); }
 };
 
 // offset just behind the k-th newline of a window whose blocks have been counted

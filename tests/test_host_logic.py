@@ -249,3 +249,76 @@ def test_driver_reader_hands_on_every_record_once(tmp_path, kind):
             p = subprocess.run([exe, src, str(window), str(threads)], capture_output=True, timeout=120)
             assert p.returncode == 0, p.stderr
             assert p.stdout == raw, (kind, trunc, window, threads, len(p.stdout), len(raw))
+
+
+@pytest.mark.parametrize("span", [4096, 100_000, 1 << 20])
+def test_parallel_gzip_reader_equals_zlib(tmp_path, span):
+    """ordinary gzip input is inflated block-parallel (csrc/pgz.h: speculative block starts, 16-bit window markers, in-order
+    resolution): whatever the compression level / strategy, the number of members, flush points, stored and fixed blocks,
+    trailing garbage, the span between cuts and the number of threads, the reader hands on exactly the text zlib inflates;
+    truncated or corrupted files end with an error, never with different text"""
+    import gzip
+    import subprocess
+    import zlib
+    from common import write_bgzf
+    exe = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_reader_test")
+    if not os.path.exists(exe):
+        pytest.skip("bmbs_reader_test not built")
+    rng = np.random.default_rng(11)
+    n = 12000
+    f = str(tmp_path / "r.fq")
+    _fastq(f, [b"read%d/1" % i for i in range(n)], rng.integers(100, 151, n), rng, at_quals=True)
+    raw = open(f, "rb").read()
+    half = raw.index(b"\n@read%d/1" % (n // 2)) + 1
+
+    def strat(st, level=6):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31, 8, st)
+        return c.compress(raw) + c.flush()
+
+    def flushes():
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        out = []
+        for k, i in enumerate(range(0, len(raw), 300_000)):
+            out.append(c.compress(raw[i:i + 300_000]))
+            out.append(c.flush(zlib.Z_FULL_FLUSH if k % 2 else zlib.Z_SYNC_FLUSH))
+        return b"".join(out) + c.flush()
+
+    bg = str(tmp_path / "b.gz")
+    write_bgzf(bg, raw[:half], block=40000)
+    files = {
+        "l1": gzip.compress(raw, 1), "l6": gzip.compress(raw, 6), "l9": gzip.compress(raw, 9), "l0_stored": gzip.compress(raw, 0),
+        "members": b"".join(gzip.compress(raw[i:i + 700_001], 4) for i in range(0, len(raw), 700_001)),
+        "fixed": strat(zlib.Z_FIXED), "huffman_only": strat(zlib.Z_HUFFMAN_ONLY), "rle": strat(zlib.Z_RLE), "flushes": flushes(),
+        "garbage_behind": gzip.compress(raw, 6) + b"\0" * 50 + b"junk",
+        "bgzf_then_plain": open(bg, "rb").read() + gzip.compress(raw[half:], 5),
+        "named": gzip.compress(raw, 6)[:3] + b"\x08" + gzip.compress(raw, 6)[4:10] + b"reads.fq\0" + gzip.compress(raw, 6)[10:],
+    }
+    env = dict(os.environ, BMBS_GZ_SPAN=str(span))
+    for name, z in files.items():
+        assert zlib.decompressobj(31).decompress(z)[:64] == raw[:64], name
+        src = str(tmp_path / (name + ".gz"))
+        open(src, "wb").write(z)
+        for threads in (1, 5):
+            p = subprocess.run([exe, src, str(1 << 22), str(threads)], capture_output=True, timeout=120, env=env)
+            assert p.returncode == 0, (name, threads, p.stderr)
+            assert p.stdout == raw, (name, span, threads, len(p.stdout), len(raw))
+    z = files["l6"]
+    bad = {"truncated": z[:len(z) // 2], "no_trailer": z[:-8]}
+    for k in range(3):
+        b = bytearray(z)
+        b[len(z) // 4 * (k + 1) + 7 * k] ^= 0x20 << k
+        bad["flipped%d" % k] = bytes(b)
+    for name, zb in bad.items():
+        src = str(tmp_path / (name + ".gz"))
+        open(src, "wb").write(zb)
+        p = subprocess.run([exe, src, str(1 << 22), "4"], capture_output=True, timeout=120, env=env)
+        ok = True
+        try:
+            want = zlib.decompressobj(31).decompress(zb)
+            ok = zb is z
+        except zlib.error:
+            ok = False
+        if not ok:
+            assert p.returncode != 0 and p.stderr, name
+        else:
+            assert p.stdout == want
