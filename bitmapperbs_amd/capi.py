@@ -165,7 +165,7 @@ def lib() -> C.CDLL:
     return L
 
 
-LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_text.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
+LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_text.hip", "bmbs_bam.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
             "../../include/bmbs.h")
 
 

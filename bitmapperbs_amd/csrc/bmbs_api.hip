@@ -5,6 +5,7 @@
 #include "../../include/bmbs.h"
 #include "bmbs_kernels.hip"
 #include "bmbs_text.hip"
+#include "bmbs_bam.hip"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -160,6 +161,7 @@ struct Lane {
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // bmbs_map_*_text: newline index built on the device, SAM text written on the device
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
+    DevBuf bam_raw, bam_tok, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
     u32* h_info = nullptr;                              // page-locked: 8 info words + 4 totals of the text path
     int n_refs = 0, max_ref_len = 0;
     // paired-end workspace
@@ -828,6 +830,15 @@ Lane* lane_create(int device_id, const bmbs_params& prm, const Knobs& kn, bool f
     (void)hipMemset(c->stats.p, 0, shard_bytes);
     (void)hipMemset(c->call_stats.p, 0, shard_bytes);
     (void)hipMemset(c->counters.p, 0, shard_bytes);
+    {
+        // x^(2^n) mod P of CRC-32 for the BGZF blocks' CRCs (bmbs_bam.hip: crc_x8n); the symbol lives per device
+        u32 x2n[32];
+        auto mult = [](u32 a, u32 b) { u32 m = 1u << 31, p = 0; for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1; } return p; };
+        u32 p = 1u << 30;
+        x2n[0] = p;
+        for (int n = 1; n < 32; n++) { p = mult(p, p); x2n[n] = p; }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(c_x2n), x2n, sizeof x2n);
+    }
     (void)hipMemset(c->totals.p, 0, 32 * 8);
     (void)hipMemset(c->flags.p, 0, BMBS_FLAG_WORDS * 4);
     // diagnostic: per-wave timeline of the kernels that call wavelog_begin/_end (one context at a time; tools/wavelog.py)
@@ -876,7 +887,8 @@ void lane_destroy(Lane* c)
     c->arena.free_all();
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->h_info) (void)hipHostFree(c->h_info);
-    { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list};
+    { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list,
+                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap};
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
@@ -2011,6 +2023,16 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
     }
     P.d_len = uniform ? nullptr : c->in_len.as<u16>();
     P.d_results = (uint64_t)c->out_res.p; P.d_cigar_pool = (uint64_t)c->cig_pool.p; P.cigar_cap = (int64_t)pool;
+    // a caller whose output buffer turns out too small repeats the call (BMBS_ENOMEM below): the batch must not be counted twice
+    const size_t stats_bytes = BMBS_SHARDS * BMBS_SHARD_WORDS * 8;
+    ENS(c, c->stats_snap, stats_bytes);
+    HIPCHK(c, hipMemcpyAsync(c->stats_snap.p, c->stats.p, stats_bytes, hipMemcpyDeviceToDevice, c->stream));
+    auto too_small = [&](const char* what) -> int {
+        (void)hipMemcpyAsync(c->stats.p, c->stats_snap.p, stats_bytes, hipMemcpyDeviceToDevice, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        c->err = what;
+        return BMBS_ENOMEM;
+    };
     rc = lane_enqueue(c, P, true);
     if (rc) return rc;
     rc = lane_settle(c);
@@ -2025,6 +2047,66 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
     in.n = (long)n;
     in.flags = (flags_in & (BMBS_TEXT_PBAT | BMBS_TEXT_UNMAPPED)) | (c->prm.ambiguous_out ? BMBS_TEXT_AMBIG : 0) | (pe ? BMBS_TEXT_PE : 0);
     ENS(c, c->sam_len, n2 * 4 + 64); ENS(c, c->sam_off, (n2 + 1) * 8 + 64);
+    if (flags_in & BMBS_TEXT_BAM) {
+        // ---- records -> BAM records -> BGZF blocks, all on the device (bmbs_bam.hip)
+        prof_begin(c, "k_bam_len");
+        hipLaunchKernelGGL(k_bam_len, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, in, (long)n2, c->sam_len.as<u32>(), c->tx_info.as<u32>());
+        rc = scan_u32(c, c->sam_len.as<u32>(), n2, c->sam_off.as<u64>(), 19);
+        if (rc) return rc;
+        prof_end(c);
+        HIPCHK(c, hipMemcpyAsync(c->h_info + 24, c->totals.as<u64>() + 19, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_info, c->tx_info.p, 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        tp[4] = wall();
+        const u64 raw_total = *reinterpret_cast<const u64*>(c->h_info + 24);
+        if (n_lines_out) *n_lines_out = (int64_t)n2;
+        if (c->h_info[3]) { c->err = "output line " + std::to_string(c->h_info[3] - 1) + " of this batch has a read name of more than 254 characters: BAM cannot hold it"; return BMBS_EINVAL; }
+        if (!raw_total) return BMBS_OK;
+        const u64 nb = (raw_total + BGZF_IN - 1) / BGZF_IN;
+        ENS(c, c->bam_raw, raw_total + 256);
+        const int hb = (36 + 4 * std::max(max_ops, 1) + 8 + 15) & ~15;
+        int lpw = (int)((48 * 1024) / hb);
+        if (lpw > 64) lpw = 64;
+        prof_begin(c, "k_bam_write");
+        hipLaunchKernelGGL(k_bam_write, dim3(nblk(n2, (unsigned)lpw)), dim3(64), (size_t)lpw * hb, c->stream, in, (long)n2, c->sam_off.as<u64>(), lpw, hb, c->bam_raw.as<char>());
+        prof_end(c);
+        ENS(c, c->bam_tok, nb * (u64)(BGZF_SEG * BGZF_THREADS) * 2); ENS(c, c->bam_slots, nb * (u64)BGZF_SLOT);
+        ENS(c, c->bam_slot_len, nb * 4 + 64); ENS(c, c->bam_off, (nb + 1) * 8 + 64);
+        const size_t lds = BGZF_IN + 512;
+        static std::once_flag lds_once[16];
+        std::call_once(lds_once[c->dev & 15], [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_block), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        prof_begin(c, "k_bgzf_block");
+        hipLaunchKernelGGL(k_bgzf_block, dim3((unsigned)nb), dim3(BGZF_THREADS), lds, c->stream, c->bam_raw.as<char>(), c->totals.as<u64>() + 19, c->bam_tok.as<u16>(),
+                           c->bam_slots.as<char>(), c->bam_slot_len.as<u32>());
+        prof_end(c);
+        rc = scan_u32(c, c->bam_slot_len.as<u32>(), nb, c->bam_off.as<u64>(), 20);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_info + 26, c->totals.as<u64>() + 20, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const u64 ztotal = *reinterpret_cast<const u64*>(c->h_info + 26);
+        if (sam_bytes) *sam_bytes = ztotal;
+        if (ztotal > sam_cap) return too_small("text call: the BAM buffer is too small (sam_bytes tells what this batch needs)");
+        ENS(c, c->sam_out, ztotal + 64);
+        prof_begin(c, "k_bgzf_gather");
+        hipLaunchKernelGGL(k_bgzf_gather, dim3((unsigned)nb), dim3(256), 0, c->stream, c->bam_slots.as<char>(), c->bam_slot_len.as<u32>(), c->bam_off.as<u64>(), c->sam_out.as<char>());
+        prof_end(c);
+        if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); tp[5] = wall(); }
+        {
+            hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
+            if (c->kn.copy_lock || ds != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::unique_lock<std::mutex> down(g_d2h_mu[c->dev & 15], std::defer_lock);
+            if (c->kn.copy_lock) down.lock();
+            rc = d2h_chunked(c, sam, c->sam_out.as<char>(), ztotal, ds);
+            if (rc) return rc;
+            HIPCHK(c, hipStreamSynchronize(ds));
+        }
+        tp[6] = wall();
+        if (trace)
+            fprintf(stderr, "[text/bam] n=%ld in=%.1fMB records=%.1fMB out=%.1fMB  upload %.2f lines+records %.2f rows+map %.2f  len+scan %.2f  write+deflate %.2f  download %.2f  total %.2f ms\n",
+                    (long)n2, (double)(bytes1 + bytes2) / 1e6, (double)raw_total / 1e6, (double)ztotal / 1e6, (tp[7] - tp[0]) * 1e3, (tp[2] - tp[7]) * 1e3, (tp[3] - tp[2]) * 1e3, (tp[4] - tp[3]) * 1e3,
+                    (tp[5] - tp[4]) * 1e3, (tp[6] - tp[5]) * 1e3, (tp[6] - tp[0]) * 1e3);
+        return BMBS_OK;
+    }
     prof_begin(c, "k_sam_len");
     hipLaunchKernelGGL(k_sam_len, dim3(nblk(n2, 256)), dim3(256), 0, c->stream, in, (long)n2, c->sam_len.as<u32>());
     rc = scan_u32(c, c->sam_len.as<u32>(), n2, c->sam_off.as<u64>(), 18);
@@ -2036,7 +2118,7 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
     const u64 total = *reinterpret_cast<const u64*>(c->h_info + 24);
     if (sam_bytes) *sam_bytes = total;
     if (n_lines_out) *n_lines_out = (int64_t)n2;
-    if (total > sam_cap) { c->err = "text call: the SAM buffer is too small (sam_bytes tells what this batch needs)"; return BMBS_ENOMEM; }
+    if (total > sam_cap) return too_small("text call: the SAM buffer is too small (sam_bytes tells what this batch needs)");
     if (!total) return BMBS_OK;
     ENS(c, c->sam_out, total + 64);
     const int hb = (c->max_ref_len + 5 * std::max(max_ops, 1) + 96 + 15) & ~15;

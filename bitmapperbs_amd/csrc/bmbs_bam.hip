@@ -1,0 +1,542 @@
+// bitmapperbs_amd/csrc/bmbs_bam.hip -- `--bam` on the device: records -> BAM records -> BGZF blocks (round 4).
+//
+// The reference hands every SAM line to htslib (sam_parse1 + bam_write1 over a BGZF stream, bam_prase.cpp:201-221) on its output
+// thread; round 3 of this tree re-parsed the device-made SAM text on the host's I/O threads and deflated it with zlib.  Here the
+// host never sees a record: the BAM record of every output line is built from bmbs_result + the resident FASTQ text
+// (k_bam_len / k_bam_write, the same line logic as the SAM text: sam_line), the record stream of the batch is cut into BGZF
+// blocks of 0xff00 input bytes, and every block is deflated by one workgroup (k_bgzf_block): run-length matches, a dynamic
+// Huffman code built from the block's own symbol counts (what compresses BAM: 4-bit base pairs and a small quality alphabet),
+// CRC-32 by segments combined with x^(8n) mod P.  The blocks of a batch come back as one contiguous piece of a BGZF file.
+// Parity surface: the INFLATED record stream equals the reference's (tests/common.bam_payload); block boundaries and compressed
+// bytes are this design's own.
+#ifndef BMBS_BAM_HIP
+#define BMBS_BAM_HIP
+
+#define BMBS_TEXT_BAM 16          // bmbs_map_*_text: `sam` receives BGZF-compressed BAM records instead of SAM text
+
+// htslib's seq_nt16_table ("=ACMGRSVTWYHKDBN"; digits 0-3 count as ACGT), two entries per byte
+__constant__ u8 c_nt16[256] = {
+    15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+    15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 1,2,4,8,15,15,15,15,15,15,15,15,15,0,15,15,
+    15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
+    15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
+    15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+    15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+    15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+    15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15};
+
+// hts_reg2bin(beg, end, 14, 5) as sam_parse1 calls it (end exclusive)
+DEVI int bam_reg2bin(long long beg, long long end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+DEVI void st32(char* p, u32 v) { p[0] = (char)v; p[1] = (char)(v >> 8); p[2] = (char)(v >> 16); p[3] = (char)(v >> 24); }
+DEVI void st16(char* p, u32 v) { p[0] = (char)v; p[1] = (char)(v >> 8); }
+
+// bytes of the NM tag of a mapped record: "NM" + the smallest unsigned type that holds the value (sam_parse1's choice)
+DEVI int bam_tag_len(const SamLine& s) { return s.kind == 1 ? (s.x->nm <= 0xff ? 4 : 5) : 0; }
+DEVI int bam_ncigar(const SamLine& s) { return s.kind == 1 ? (s.x->n_cigar ? (int)s.x->n_cigar : 1) : 0; }
+
+// the fixed 36 bytes (block_size + the 32-byte core), the CIGAR words and the tag of line s into p; returns their total length
+DEVI int bam_head(const SamIn& in, const SamLine& s, int L, int total, char* p)
+{
+    const bool pe = (in.flags & BMBS_TEXT_PE) != 0;
+    const int ncig = bam_ncigar(s);
+    st32(p, (u32)(total - 4));
+    if (s.kind == 2) {
+        const int flag = !pe ? 4 : s.mate == 0 ? 77 : 141;
+        st32(p + 4, 0xffffffffu); st32(p + 8, 0xffffffffu);
+        p[12] = (char)(s.name_len + 1); p[13] = 0; st16(p + 14, (u32)bam_reg2bin(-1, 0));
+        st16(p + 16, 0); st16(p + 18, (u32)flag); st32(p + 20, (u32)L);
+        st32(p + 24, 0xffffffffu); st32(p + 28, 0xffffffffu); st32(p + 32, 0);
+        return 36;
+    }
+    const bmbs_result_dev& x = *s.x;
+    const long long pos0 = (long long)x.pos - 1;
+    long long reflen = 0;
+    char* c = p + 36;
+    if (x.n_cigar == 0) { st32(c, (u32)L << 4); reflen = L; c += 4; }
+    else
+        for (int i = 0; i < x.n_cigar; i++) {
+            const u32 o = in.cigar[x.cigar_off + i];
+            const u32 k = o & 7u;                                             // ours: 0 M, 1 D, 2 I, 3 S, 4 H  ->  BAM: M 0, I 1, D 2, S 4, H 5
+            const u32 bop = k == 0 ? 0u : k == 1 ? 2u : k == 2 ? 1u : k == 3 ? 4u : 5u;
+            if (k <= 1) reflen += (long long)(o >> 4);
+            st32(c, (o & ~15u) | bop); c += 4;
+        }
+    st32(p + 4, (u32)x.chrom); st32(p + 8, (u32)pos0);
+    p[12] = (char)(s.name_len + 1); p[13] = (char)x.mapq; st16(p + 14, (u32)bam_reg2bin(pos0, pos0 + (reflen == 0 ? 1 : reflen)));
+    st16(p + 16, (u32)ncig); st16(p + 18, (u32)x.flag); st32(p + 20, (u32)L);
+    if (!pe) { st32(p + 24, 0xffffffffu); st32(p + 28, 0xffffffffu); st32(p + 32, 0); }
+    else {
+        const bmbs_result_dev& y = *s.mate_x;
+        const bool neg = s.mate == 0 ? (y.pos < x.pos) : !(y.pos > x.pos);      // TLEN sign as in sam_head
+        const u32 tl = s.mate == 0 ? x.tlen : y.tlen;
+        st32(p + 24, (u32)x.chrom); st32(p + 28, (u32)((long long)y.pos - 1)); st32(p + 32, neg ? (u32)(-(int)tl) : tl);
+    }
+    c[0] = 'N'; c[1] = 'M';
+    if (x.nm <= 0xff) { c[2] = 'C'; c[3] = (char)x.nm; c += 4; }
+    else { c[2] = 'S'; st16(c + 3, x.nm); c += 5; }
+    return (int)(c - p);
+}
+
+// bytes of the BAM record of output line `line` (0: nothing is printed for it); info[3] = 1 + a line whose QNAME is too long
+__global__ void __launch_bounds__(256)
+k_bam_len(SamIn in, long n_lines, u32* __restrict__ len_out, u32* __restrict__ info)
+{
+    const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= n_lines) return;
+    const SamLine s = sam_line(in, line);
+    u32 len = 0;
+    if (s.kind) {
+        const int L = in.rec[s.mate].seq_len[s.rec];
+        len = (u32)(36 + s.name_len + 1 + 4 * bam_ncigar(s) + (L + 1) / 2 + L + bam_tag_len(s));
+        if (s.name_len > 254) atomicMax(&info[3], (u32)line + 1u);         // l_read_name is one byte (htslib refuses such a line)
+    }
+    len_out[line] = len;
+}
+
+// the same shape as k_sam_write: lane i describes line i and renders its fixed part into LDS, then 16 lanes per line assemble the
+// record four bytes at a time into destination-aligned dwords
+__global__ void __launch_bounds__(64)
+k_bam_write(SamIn in, long n_lines, const u64* __restrict__ off, int lpw, int hb, char* __restrict__ out)
+{
+    extern __shared__ char lds_sam[];                  // [lpw][hb]: core + cigar + tag
+    __shared__ SamDesc s_d[64];
+    __shared__ u32 s_start[65];
+    const long line0 = (long)blockIdx.x * lpw;
+    const int lane = threadIdx.x;
+    const int nl = (int)((n_lines - line0) < (long)lpw ? (n_lines - line0) : (long)lpw);
+    const u64 o0 = off[line0];
+    if (lane < nl) {
+        const long line = line0 + lane;
+        const SamLine sl = sam_line(in, line);
+        SamDesc d;
+        d.name = d.seq = d.qual = nullptr; d.start = (u32)(off[line] - o0); d.total = 0; d.nlen = d.hl = d.tl = d.L = d.qn = d.rc = 0;
+        if (sl.kind) {
+            const FqRec& R = in.rec[sl.mate];
+            const char* text = in.text[sl.mate];
+            const int L = R.seq_len[sl.rec];
+            const int total = 36 + sl.name_len + 1 + 4 * bam_ncigar(sl) + (L + 1) / 2 + L + bam_tag_len(sl);
+            char* h = lds_sam + (size_t)lane * hb;
+            const int hl = bam_head(in, sl, L, total, h);
+            d.name = ((in.flags & BMBS_TEXT_PE) ? in.text[0] + in.rec[0].name_off[sl.rec] : text + R.name_off[sl.rec]) + sl.name_skip;
+            d.seq = text + R.seq_off[sl.rec]; d.qual = text + R.qual_off[sl.rec];
+            d.nlen = (u16)sl.name_len; d.hl = (u16)hl; d.tl = (u16)bam_tag_len(sl); d.L = (u16)L; d.qn = R.qual_len[sl.rec]; d.rc = sl.rc ? 1 : 0;
+            d.total = (u32)total;
+        }
+        s_d[lane] = d;
+        s_start[lane] = d.start;
+    }
+    if (lane == 0) s_start[nl] = (u32)(off[line0 + nl] - o0);
+    __syncthreads();
+    if (!s_start[nl]) return;
+    const int grp = lane >> 4, gl = lane & 15;
+    for (int j = grp; j < nl; j += 4) {
+        const SamDesc d = s_d[j];
+        if (!d.total) continue;
+        const char* hd = lds_sam + (size_t)j * hb;
+        const int L = d.L, qn = d.qn;
+        const bool rc = d.rc != 0;
+        const int cig = (int)d.hl - 36 - (int)d.tl;                   // bytes of CIGAR words
+        const int b1 = 36, b2 = b1 + d.nlen + 1, b3 = b2 + cig, b4 = b3 + (L + 1) / 2, b5 = b4 + L;
+        const int total = (int)d.total;
+        const u64 o = o0 + d.start;
+        const u64 d0 = o & ~3ull;
+        const int lead = (int)(o - d0);
+        const int ndw = (lead + total + 3) >> 2;
+        auto base_at = [&](int i) -> u32 {                            // the printed SEQ character i (as in k_sam_write)
+            unsigned char c = (unsigned char)d.seq[rc ? L - 1 - i : i];
+            if (c >= 'a' && c <= 'z') c -= 32;
+            if (rc) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+            return c;
+        };
+        auto byte_at = [&](int t) -> u32 {
+            if (t < b1) return (unsigned char)hd[t];
+            if (t < b2) return t - b1 < (int)d.nlen ? (u32)(unsigned char)d.name[t - b1] : 0u;
+            if (t < b3) return (unsigned char)hd[36 + (t - b2)];
+            if (t < b4) {
+                const int i = 2 * (t - b3);
+                const u32 hi = c_nt16[base_at(i)], lo = i + 1 < L ? (u32)c_nt16[base_at(i + 1)] : 0u;
+                return (hi << 4) | lo;
+            }
+            if (t < b5) { const int i = t - b4, jj = rc ? L - 1 - i : i; return ((jj < qn ? (u32)(unsigned char)d.qual[jj] : (u32)' ') - 33u) & 0xffu; }
+            return (unsigned char)hd[36 + cig + (t - b5)];
+        };
+        for (int w = gl; w < ndw; w += 16) {
+            const int t0 = 4 * w - lead;
+            char* dst = out + d0 + 4 * (u64)w;
+            if (t0 >= 0 && t0 + 4 <= total) {
+                const u32 v = byte_at(t0) | (byte_at(t0 + 1) << 8) | (byte_at(t0 + 2) << 16) | (byte_at(t0 + 3) << 24);
+                *reinterpret_cast<u32*>(dst) = v;
+            } else {
+                for (int b = 0; b < 4; b++) { const int t = t0 + b; if (t >= 0 && t < total) dst[b] = (char)byte_at(t); }
+            }
+        }
+    }
+}
+
+// ---- BGZF: one workgroup deflates one block of <= 0xff00 input bytes --------------------------------------------------------------
+#define BGZF_IN       0xff00                // input bytes per block (bgzf.h BGZF_BLOCK_SIZE)
+#define BGZF_SLOT     65536                 // bytes of a block's slot in the scratch output (a stored block fits: 0xff00 + 5 + 26)
+#define BGZF_THREADS  256
+#define BGZF_SEG      256                   // input bytes parsed by one thread
+#define DEF_LL        286                   // literal/length symbols
+#define DEF_D         30
+#define DEF_SYMS      320                   // ll at 0, distance codes at 288
+#define DEF_DOFF      288
+
+__constant__ u32 c_x2n[32];                 // x^(2^n) mod P of CRC-32 (reflected), n = 0..31: set by bgzf_init_constants
+__constant__ u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+#define CRC_POLY 0xedb88320u
+DEVI u32 crc_multmodp(u32 a, u32 b)
+{
+    u32 m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+// x^(8 n) mod P
+DEVI u32 crc_x8n(u32 n)
+{
+    u32 p = 1u << 31; int k = 3;
+    while (n) { if (n & 1) p = crc_multmodp(c_x2n[k & 31], p); n >>= 1; k++; }
+    return p;
+}
+
+DEVI void len_code(int len, int& code, int& extra, int& xval)
+{
+    const int v = len - 3;
+    if (v < 8) { code = v; extra = 0; xval = 0; return; }
+    if (len == 258) { code = 28; extra = 0; xval = 0; return; }
+    const int m = 31 - __clz(v);
+    code = 4 * (m - 1) + ((v >> (m - 2)) & 3); extra = m - 2; xval = v & ((1 << (m - 2)) - 1);
+}
+DEVI void dist_code(int dist, int& code, int& extra, int& xval)
+{
+    const int d = dist - 1;
+    if (d < 4) { code = d; extra = 0; xval = 0; return; }
+    const int m = 31 - __clz(d);
+    code = 2 * m + ((d >> (m - 1)) & 1); extra = m - 1; xval = d & ((1 << (m - 1)) - 1);
+}
+
+// Huffman code lengths of n symbols limited to `maxbits`, by ONE lane over LDS arrays (the trees of a block are a few hundred
+// sequential steps; the 255 other lanes wait at the barrier behind it).  zlib's construction in outline (build_tree / gen_bitlen,
+// trees.c): at least two codes, overflowing leaves moved up, lengths handed out again in frequency order -- so that every decoder
+// that reads zlib's streams reads these.  Work arrays: key[2n] (weights), par[2n], ord[n] (symbols by ascending frequency).
+struct HuffWork { u32* key; u16* par; u16* ord; u8* dep; };
+// ord[0, m) = the used symbols by ascending (frequency, symbol); m < 0: sort here (small alphabets)
+DEVI void huff_lengths(const u32* freq, int n, int maxbits, u8* len, const HuffWork& w, int m)
+{
+    for (int i = 0; i < n; i++) len[i] = 0;
+    if (m < 0) {
+        m = 0;
+        for (int s = 0; s < n; s++) {
+            const u32 f = freq[s];
+            if (!f) continue;
+            int j = m++;
+            while (j > 0 && freq[w.ord[j - 1]] > f) { w.ord[j] = w.ord[j - 1]; j--; }
+            w.ord[j] = (u16)s;
+        }
+    }
+    if (m == 0) { len[0] = 1; len[1] = 1; return; }                               // no symbol at all: two dummies (pkzip wants two codes)
+    if (m == 1) { const int s = w.ord[0]; len[s] = 1; len[s == 0 ? 1 : 0] = 1; return; }
+    // two-queue merge: leaves 0..m-1 in order, internal nodes m..2m-2 come out in ascending weight
+    for (int i = 0; i < m; i++) w.key[i] = freq[w.ord[i]];
+    int a = 0, b = m, e = m;                                                      // next leaf, next internal, end of internals
+    for (int k = 0; k < m - 1; k++) {
+        int c[2];
+        for (int q = 0; q < 2; q++) {
+            if (a < m && (b >= e || w.key[a] <= w.key[b])) c[q] = a++; else c[q] = b++;
+        }
+        w.key[e] = w.key[c[0]] + w.key[c[1]];
+        w.par[c[0]] = (u16)e; w.par[c[1]] = (u16)e;
+        e++;
+    }
+    // depths from the root down
+    const int root = e - 1;
+    w.dep[root] = 0;
+    for (int i = root - 1; i >= 0; i--) w.dep[i] = (u8)(w.dep[w.par[i]] + 1 > 255 ? 255 : w.dep[w.par[i]] + 1);
+    // bl_count with the overflow moved up (gen_bitlen)
+    int cnt[17]; for (int i = 0; i <= 16; i++) cnt[i] = 0;
+    int overflow = 0;
+    for (int i = 0; i < m; i++) { int d = w.dep[i]; if (d > maxbits) { d = maxbits; overflow++; } cnt[d]++; }
+    while (overflow > 0) {
+        int bits = maxbits - 1;
+        while (cnt[bits] == 0) bits--;
+        cnt[bits]--; cnt[bits + 1] += 2; cnt[maxbits]--;
+        overflow -= 2;
+    }
+    // the rarest symbols get the longest codes
+    int i = 0;
+    for (int bits = maxbits; bits >= 1; bits--) for (int c2 = cnt[bits]; c2 > 0; c2--) len[w.ord[i++]] = (u8)bits;
+}
+// canonical codes, bit-reversed for an LSB-first stream: code[s] = len << 16 | reversed code
+DEVI void huff_codes(const u8* len, int n, u32* code)
+{
+    int cnt[16]; for (int i = 0; i < 16; i++) cnt[i] = 0;
+    for (int s = 0; s < n; s++) cnt[len[s]]++;
+    cnt[0] = 0;
+    u32 next[16]; u32 c = 0;
+    for (int b = 1; b <= 15; b++) { c = (c + (u32)cnt[b - 1]) << 1; next[b] = c; }
+    for (int s = 0; s < n; s++) {
+        const int l = len[s];
+        if (!l) { code[s] = 0; continue; }
+        const u32 v = next[l]++;
+        code[s] = ((u32)l << 16) | (__brev(v) >> (32 - l));
+    }
+}
+
+struct BitOut { u32* w; u32 pos; };       // LSB-first bits OR-ed into zeroed 32-bit words (one writer)
+DEVI void put_bits(BitOut& o, u32 v, int n)
+{
+    if (!n) return;
+    const u32 wi = o.pos >> 5, sh = o.pos & 31;
+    o.w[wi] |= v << sh;
+    if (sh + n > 32) o.w[wi + 1] |= v >> (32 - sh);
+    o.pos += (u32)n;
+}
+
+// raw: the BAM record stream of the batch (total bytes); block b = raw[b * BGZF_IN ...).  slot b of `slots` receives the finished
+// BGZF block (header, deflate data, CRC-32, ISIZE), slot_len[b] its length.  tok: BGZF_SEG * BGZF_THREADS u16 per block of scratch
+// (a literal byte, or 0x8000 | run length - 3: the matches are runs, distance 1).
+__global__ void __launch_bounds__(BGZF_THREADS)
+k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, u16* __restrict__ tok_all, char* __restrict__ slots, u32* __restrict__ slot_len)
+{
+    // the block's bytes, later the staging area of the deflate stream (the tokens hold everything the encoder needs)
+    extern __shared__ __align__(16) u32 s_data[];     // (BGZF_IN + 512) / 4 words
+    __shared__ u32 s_freq[DEF_SYMS];
+    __shared__ u32 s_code[DEF_SYMS];
+    __shared__ u8 s_len[DEF_SYMS + 8];
+    __shared__ u32 s_crc_tab[256];
+    __shared__ u32 s_key[2 * DEF_LL]; __shared__ u16 s_par[2 * DEF_LL]; __shared__ u16 s_ord[DEF_LL]; __shared__ u16 s_ord_d[DEF_D + 2]; __shared__ u16 s_ord_c[20]; __shared__ u8 s_dep[2 * DEF_LL];
+    __shared__ u32 s_hdr[176];                        // header bits of the dynamic block
+    __shared__ u32 s_cl_freq[19]; __shared__ u32 s_cl_code[19]; __shared__ u8 s_cl_len[19];
+    __shared__ u8 s_rle_sym[DEF_SYMS]; __shared__ u8 s_rle_x[DEF_SYMS];
+    __shared__ u32 s_wave[BGZF_THREADS / 64];
+    __shared__ u32 s_misc[8];                         // 0 xbits, 1 crc, 2 hdr bits, 3 mode (0 stored, 1 dynamic), 4 body bits, 6 / 7 used ll / distance symbols
+
+    const u64 total = *total_ptr;
+    const u64 base = (u64)blockIdx.x * BGZF_IN;
+    if (base >= total) return;
+    const int blen = (int)((total - base) < (u64)BGZF_IN ? (total - base) : (u64)BGZF_IN);
+    const int tid = threadIdx.x;
+    u8* data = reinterpret_cast<u8*>(s_data);
+    u16* tok = tok_all + (size_t)blockIdx.x * (BGZF_SEG * BGZF_THREADS);
+    // ---- load (raw + base is 16-byte aligned: BGZF_IN is a multiple of 16), tables
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(raw + base);
+        const int n16 = (blen + 15) >> 4;
+        uint4* dst = reinterpret_cast<uint4*>(s_data);
+        for (int i = tid; i < n16; i += BGZF_THREADS) dst[i] = src[i];           // (the raw buffer is padded past `total`)
+        for (int i = tid; i < DEF_SYMS; i += BGZF_THREADS) s_freq[i] = 0;
+        u32 c = (u32)tid;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        s_crc_tab[tid] = c;
+        if (tid < 8) s_misc[tid] = 0;
+    }
+    __syncthreads();
+    // ---- parse: greedy, literals and runs (distance 1); CRC of the segment on the way
+    const int s0 = tid * BGZF_SEG, s1 = s0 + BGZF_SEG < blen ? s0 + BGZF_SEG : blen;
+    int ntok = 0;
+    u32 xbits = 0, crc = 0;
+    if (s0 < blen) {
+        u32 c = 0xffffffffu;
+        for (int p = s0; p < s1; p++) c = s_crc_tab[(c ^ data[p]) & 0xffu] ^ (c >> 8);
+        c = ~c;
+        crc = crc_multmodp(crc_x8n((u32)(blen - s1)), c);                       // this segment's share of the block's CRC
+        int p = s0;
+        while (p < s1) {
+            int run = 0;
+            if (p > 0) {
+                const u8 b = data[p - 1];
+                const int lim = s1 - p < 258 ? s1 - p : 258;
+                while (run < lim && data[p + run] == b) run++;
+            }
+            if (run >= 3) {
+                int lc, le, lx; len_code(run, lc, le, lx);
+                tok[s0 + ntok++] = (u16)(0x8000u | (u32)(run - 3));
+                atomicAdd(&s_freq[257 + lc], 1u); atomicAdd(&s_freq[DEF_DOFF + 0], 1u);
+                xbits += (u32)le;
+                p += run;
+            } else {
+                const u8 b = data[p++];
+                tok[s0 + ntok++] = (u16)b;
+                atomicAdd(&s_freq[b], 1u);
+            }
+        }
+    }
+    if (tid == 0) atomicAdd(&s_freq[256], 1u);
+    // block sums of xbits and the CRC shares (xor)
+    for (int o = 32; o > 0; o >>= 1) { xbits += __shfl_down(xbits, o, 64); crc ^= __shfl_down(crc, o, 64); }
+    if ((tid & 63) == 0) { atomicAdd(&s_misc[0], xbits); atomicXor(&s_misc[1], crc); }
+    __syncthreads();
+    // ---- the used symbols by ascending (frequency, symbol): every thread ranks its symbols against all the others (an insertion
+    // sort by one lane is ~20 000 dependent LDS steps for a block that uses all 256 byte values)
+    for (int sy = tid; sy < DEF_LL + DEF_D; sy += BGZF_THREADS) {
+        const bool dsym = sy >= DEF_LL;
+        const u32* fr = dsym ? s_freq + DEF_DOFF : s_freq;
+        const int me = dsym ? sy - DEF_LL : sy, n = dsym ? DEF_D : DEF_LL;
+        const u32 f = fr[me];
+        if (f) {
+            int r = 0;
+            for (int t = 0; t < n; t++) { const u32 g = fr[t]; r += (g && (g < f || (g == f && t < me))) ? 1 : 0; }
+            (dsym ? s_ord_d : s_ord)[r] = (u16)me;
+            atomicAdd(&s_misc[dsym ? 7 : 6], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- trees and header: lane 0 (the other lanes of the block wait)
+    if (tid == 0) {
+        HuffWork hw; hw.key = s_key; hw.par = s_par; hw.ord = s_ord; hw.dep = s_dep;
+        huff_lengths(s_freq, DEF_LL, 15, s_len, hw, (int)s_misc[6]);
+        hw.ord = s_ord_d;
+        huff_lengths(s_freq + DEF_DOFF, DEF_D, 15, s_len + DEF_DOFF, hw, (int)s_misc[7]);
+        hw.ord = s_ord_c;
+        huff_codes(s_len, DEF_LL, s_code);
+        huff_codes(s_len + DEF_DOFF, DEF_D, s_code + DEF_DOFF);
+        int hlit = DEF_LL; while (hlit > 257 && !s_len[hlit - 1]) hlit--;
+        int hdist = DEF_D; while (hdist > 1 && !s_len[DEF_DOFF + hdist - 1]) hdist--;
+        // the hlit + hdist lengths as one sequence, run-length coded with 16 / 17 / 18 (send_tree)
+        for (int i = 0; i < 19; i++) s_cl_freq[i] = 0;
+        int nr = 0;
+        const int nseq = hlit + hdist;
+        auto at = [&](int i) -> int { return i < hlit ? s_len[i] : s_len[DEF_DOFF + (i - hlit)]; };
+        for (int i = 0; i < nseq;) {
+            const int v = at(i);
+            int run = 1;
+            while (i + run < nseq && at(i + run) == v) run++;
+            int left = run;
+            if (v == 0) {
+                while (left >= 11) { const int r = left < 138 ? left : 138; s_rle_sym[nr] = 18; s_rle_x[nr++] = (u8)(r - 11); s_cl_freq[18]++; left -= r; }
+                if (left >= 3) { s_rle_sym[nr] = 17; s_rle_x[nr++] = (u8)(left - 3); s_cl_freq[17]++; left = 0; }
+                while (left-- > 0) { s_rle_sym[nr] = 0; s_rle_x[nr++] = 0; s_cl_freq[0]++; }
+            } else {
+                s_rle_sym[nr] = (u8)v; s_rle_x[nr++] = 0; s_cl_freq[v]++; left--;
+                while (left >= 3) { const int r = left < 6 ? left : 6; s_rle_sym[nr] = 16; s_rle_x[nr++] = (u8)(r - 3); s_cl_freq[16]++; left -= r; }
+                while (left-- > 0) { s_rle_sym[nr] = (u8)v; s_rle_x[nr++] = 0; s_cl_freq[v]++; }
+            }
+            i += run;
+        }
+        huff_lengths(s_cl_freq, 19, 7, s_cl_len, hw, -1);
+        huff_codes(s_cl_len, 19, s_cl_code);
+        int hclen = 19; while (hclen > 4 && !s_cl_len[c_cl_order[hclen - 1]]) hclen--;
+        for (int i = 0; i < 176; i++) s_hdr[i] = 0;
+        BitOut bo; bo.w = s_hdr; bo.pos = 0;
+        put_bits(bo, 1, 1); put_bits(bo, 2, 2);                                   // BFINAL, BTYPE = dynamic
+        put_bits(bo, (u32)(hlit - 257), 5); put_bits(bo, (u32)(hdist - 1), 5); put_bits(bo, (u32)(hclen - 4), 4);
+        for (int i = 0; i < hclen; i++) put_bits(bo, s_cl_len[c_cl_order[i]], 3);
+        for (int i = 0; i < nr; i++) {
+            const int s = s_rle_sym[i];
+            put_bits(bo, s_cl_code[s] & 0xffffu, (int)(s_cl_code[s] >> 16));
+            if (s == 16) put_bits(bo, s_rle_x[i], 2); else if (s == 17) put_bits(bo, s_rle_x[i], 3); else if (s == 18) put_bits(bo, s_rle_x[i], 7);
+        }
+        u32 body = s_misc[0];
+        for (int s = 0; s < DEF_LL; s++) body += s_freq[s] * s_len[s];
+        for (int s = 0; s < DEF_D; s++) body += s_freq[DEF_DOFF + s] * s_len[DEF_DOFF + s];
+        s_misc[2] = bo.pos; s_misc[4] = body;
+        const u32 dyn_bytes = (bo.pos + body + 7) >> 3;
+        s_misc[3] = dyn_bytes < (u32)blen + 5u ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool dynamic = s_misc[3] != 0;
+    const u32 hdr_bits = s_misc[2], body_bits = s_misc[4];
+    const u32 crc_all = s_misc[1];
+    char* slot = slots + (size_t)blockIdx.x * BGZF_SLOT;
+    u32 clen;                                                                      // bytes of deflate data
+    if (!dynamic) {
+        // stored: 1 byte of type bits, LEN, NLEN, the bytes
+        clen = 5u + (u32)blen;
+        if (tid == 0) { slot[18] = 1; slot[19] = (char)blen; slot[20] = (char)(blen >> 8); slot[21] = (char)~blen; slot[22] = (char)(~blen >> 8); }
+        for (int i = tid; i < blen; i += BGZF_THREADS) slot[23 + i] = (char)data[i];
+    } else {
+        clen = (hdr_bits + body_bits + 7) >> 3;
+        // bits of this thread's tokens, exclusive prefix over the block
+        u32 mybits = 0;
+        for (int j = 0; j < ntok; j++) {
+            const u32 t = tok[s0 + j];
+            if (t & 0x8000u) {
+                int lc, le, lx; len_code((int)(t & 0xffu) + 3, lc, le, lx);
+                int dc, de, dx; dist_code(1, dc, de, dx);
+                mybits += (s_code[257 + lc] >> 16) + (u32)le + (s_code[DEF_DOFF + dc] >> 16) + (u32)de;
+            } else mybits += s_code[t] >> 16;
+        }
+        u32 incl = mybits;
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();                                                            // (everybody has read its tokens' source: s_data may go)
+        u32 wbase = 0;
+        for (int i = 0; i < (tid >> 6); i++) wbase += s_wave[i];
+        u32 pos = hdr_bits + wbase + (incl - mybits);
+        const int nwords = (int)((clen + 3) >> 2) + 1;
+        for (int i = tid; i < nwords; i += BGZF_THREADS) s_data[i] = i < 176 ? s_hdr[i] : 0u;      // header bits + zeros
+        __syncthreads();
+        // emit: a 64-bit accumulator flushed word-wise with atomicOr (the first and last word of a thread's run are shared)
+        unsigned long long acc = 0; int have = 0; u32 wi = pos >> 5;
+        { const int sh = (int)(pos & 31); have = sh; }                              // bits of word wi below `have` belong to the neighbour
+        auto emit = [&](u32 v, int n) {
+            acc |= (unsigned long long)v << have; have += n;
+            if (have >= 32) { atomicOr(&s_data[wi], (u32)acc); wi++; acc >>= 32; have -= 32; }
+        };
+        for (int j = 0; j < ntok; j++) {
+            const u32 t = tok[s0 + j];
+            if (t & 0x8000u) {
+                int lc, le, lx; len_code((int)(t & 0xffu) + 3, lc, le, lx);
+                int dc, de, dx; dist_code(1, dc, de, dx);
+                emit(s_code[257 + lc] & 0xffffu, (int)(s_code[257 + lc] >> 16));
+                if (le) emit((u32)lx, le);
+                emit(s_code[DEF_DOFF + dc] & 0xffffu, (int)(s_code[DEF_DOFF + dc] >> 16));
+                if (de) emit((u32)dx, de);
+            } else emit(s_code[t] & 0xffffu, (int)(s_code[t] >> 16));
+        }
+        // the thread that holds the end of the input also writes the end-of-block code (exactly one: s0 < blen, s1 == blen)
+        if (s0 < blen && s1 == blen) emit(s_code[256] & 0xffffu, (int)(s_code[256] >> 16));
+        if (have > 0) atomicOr(&s_data[wi], (u32)acc);
+        __syncthreads();
+        const u8* z = reinterpret_cast<const u8*>(s_data);
+        for (u32 i = tid; i < clen; i += BGZF_THREADS) slot[18 + i] = (char)z[i];
+    }
+    if (tid == 0) {
+        const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        for (int i = 0; i < 16; i++) slot[i] = (char)hdr[i];
+        const u32 bsize = clen + 25u;                                               // total block size - 1
+        slot[16] = (char)bsize; slot[17] = (char)(bsize >> 8);
+        char* t = slot + 18 + clen;
+        st32(t, crc_all); st32(t + 4, (u32)blen);
+        slot_len[blockIdx.x] = clen + 26u;
+    }
+}
+
+// slots -> one contiguous piece: block b goes to out[off[b] ...); destination-aligned dwords, the ragged ends byte-wise
+__global__ void __launch_bounds__(256)
+k_bgzf_gather(const char* __restrict__ slots, const u32* __restrict__ slot_len, const u64* __restrict__ off, char* __restrict__ out)
+{
+    const u32 b = blockIdx.x;
+    const u32 len = slot_len[b];
+    const u64 o = off[b];
+    const char* src = slots + (size_t)b * BGZF_SLOT;
+    const u64 d0 = o & ~3ull;
+    const int lead = (int)(o - d0);
+    const int ndw = (int)((lead + len + 3) >> 2);
+    for (int w = threadIdx.x; w < ndw; w += blockDim.x) {
+        const int t0 = 4 * w - lead;
+        char* dst = out + d0 + 4 * (u64)w;
+        if (t0 >= 0 && t0 + 4 <= (int)len) {
+            const u32 v = (u32)(unsigned char)src[t0] | ((u32)(unsigned char)src[t0 + 1] << 8) | ((u32)(unsigned char)src[t0 + 2] << 16) | ((u32)(unsigned char)src[t0 + 3] << 24);
+            *reinterpret_cast<u32*>(dst) = v;
+        } else {
+            for (int k = 0; k < 4; k++) { const int t = t0 + k; if (t >= 0 && t < (int)len) dst[k] = src[t]; }
+        }
+    }
+}
+#endif

@@ -556,91 +556,9 @@ inline void put_uint(std::string& s, unsigned long long v)
 }
 
 // ---- --bam (Process_CommandLines.cpp:94; the reference hands each SAM line to htslib's sam_parse1 and bam_write1,
-// bam_prase.cpp:201-221): the same conversion here, line by line, then BGZF blocks compressed by the I/O threads ----------
-int reg2bin(long long beg, long long end)
-{
-    --end;
-    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
-    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
-    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
-    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
-    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
-    return 0;
-}
+// bam_prase.cpp:201-221): the records are built and deflated into BGZF blocks ON THE DEVICE (BMBS_TEXT_BAM, bmbs_bam.hip); the host
+// writes the BAM header (below) and the end-of-file block, and moves the device's bytes into the file ----------
 inline void put_le32(std::vector<char>& o, uint32_t v) { char b[4] = {(char)v, (char)(v >> 8), (char)(v >> 16), (char)(v >> 24)}; o.insert(o.end(), b, b + 4); }
-inline void put_le16(std::vector<char>& o, uint16_t v) { o.push_back((char)v); o.push_back((char)(v >> 8)); }
-
-struct BamNames { std::vector<std::string> names; int id(const char* s, size_t n) const { for (size_t i = 0; i < names.size(); i++) if (names[i].size() == n && !memcmp(names[i].data(), s, n)) return (int)i; return -1; } };
-
-// one SAM line of ours (11 mandatory columns + optional NM:i) -> one BAM record appended to o
-void sam_line_to_bam(const char* l, size_t n, const BamNames& refs, std::vector<char>& o)
-{
-    const char* f[13]; size_t fl[13]; int nf = 0;
-    const char* s = l; const char* e = l + n;
-    while (nf < 13) {
-        const char* t = (const char*)memchr(s, '\t', (size_t)(e - s));
-        f[nf] = s; fl[nf] = t ? (size_t)(t - s) : (size_t)(e - s); nf++;
-        if (!t) break;
-        s = t + 1;
-    }
-    auto num = [&](int i) -> long long { long long v = 0; bool neg = false; size_t j = 0; if (fl[i] && f[i][0] == '-') { neg = true; j = 1; } for (; j < fl[i]; j++) v = v * 10 + (f[i][j] - '0'); return neg ? -v : v; };
-    const int flag = (int)num(1);
-    const int refid = (fl[2] == 1 && f[2][0] == '*') ? -1 : refs.id(f[2], fl[2]);
-    const long long pos = num(3) - 1;
-    const int mapq = (int)num(4);
-    // CIGAR
-    std::vector<uint32_t> cig;
-    long long reflen = 0;
-    if (!(fl[5] == 1 && f[5][0] == '*')) {
-        uint32_t len = 0;
-        for (size_t j = 0; j < fl[5]; j++) {
-            const char c = f[5][j];
-            if (c >= '0' && c <= '9') { len = len * 10 + (uint32_t)(c - '0'); continue; }
-            const int op = c == 'M' ? 0 : c == 'I' ? 1 : c == 'D' ? 2 : c == 'N' ? 3 : c == 'S' ? 4 : c == 'H' ? 5 : c == 'P' ? 6 : c == '=' ? 7 : 8;
-            cig.push_back((len << 4) | (uint32_t)op);
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += len;
-            len = 0;
-        }
-    }
-    const int next_ref = (fl[6] == 1 && f[6][0] == '=') ? refid : (fl[6] == 1 && f[6][0] == '*') ? -1 : refs.id(f[6], fl[6]);
-    const long long next_pos = num(7) - 1;
-    const long long tlen = num(8);
-    const size_t lseq = (fl[9] == 1 && f[9][0] == '*') ? 0 : fl[9];
-    const size_t at = o.size();
-    put_le32(o, 0);                                                  // block_size, patched below
-    put_le32(o, (uint32_t)refid); put_le32(o, (uint32_t)pos);
-    o.push_back((char)(fl[0] + 1)); o.push_back((char)mapq);
-    put_le16(o, (uint16_t)reg2bin(pos, pos + (cig.empty() || reflen == 0 ? 1 : reflen)));
-    put_le16(o, (uint16_t)cig.size()); put_le16(o, (uint16_t)flag);
-    put_le32(o, (uint32_t)lseq); put_le32(o, (uint32_t)next_ref); put_le32(o, (uint32_t)next_pos); put_le32(o, (uint32_t)tlen);
-    o.insert(o.end(), f[0], f[0] + fl[0]); o.push_back(0);
-    for (uint32_t c : cig) put_le32(o, c);
-    static const unsigned char nt16[256] = {
-        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
-        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 1,2,4,8,15,15,15,15,15,15,15,15,15,0,15,15,
-        15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
-        15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
-        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
-        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
-        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
-        15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15};
-    for (size_t j = 0; j < lseq; j += 2) {
-        const unsigned char hi = nt16[(unsigned char)f[9][j]], lo = j + 1 < lseq ? nt16[(unsigned char)f[9][j + 1]] : 0;
-        o.push_back((char)((hi << 4) | lo));
-    }
-    if (fl[10] == 1 && f[10][0] == '*') o.insert(o.end(), lseq, (char)0xff);
-    else for (size_t j = 0; j < lseq; j++) o.push_back((char)(f[10][j] - 33));
-    if (nf > 11 && fl[11] > 5 && !memcmp(f[11], "NM:i:", 5)) {
-        long long v = 0;
-        for (size_t j = 5; j < fl[11]; j++) v = v * 10 + (f[11][j] - '0');
-        o.push_back('N'); o.push_back('M');
-        if (v <= 0xff) { o.push_back('C'); o.push_back((char)v); }
-        else if (v <= 0xffff) { o.push_back('S'); put_le16(o, (uint16_t)v); }
-        else { o.push_back('I'); put_le32(o, (uint32_t)v); }
-    }
-    const uint32_t bs = (uint32_t)(o.size() - at - 4);
-    o[at] = (char)bs; o[at + 1] = (char)(bs >> 8); o[at + 2] = (char)(bs >> 16); o[at + 3] = (char)(bs >> 24);
-}
 
 // BGZF: independent gzip members of at most 0xff00 input bytes with the BC extra field (SAM spec 4.1)
 void bgzf_append(const char* in, size_t n, std::vector<char>& out)
@@ -693,7 +611,6 @@ struct Batch {
     Pinned text1, text2, sam;                    // FASTQ windows in, SAM text out
     size_t used1 = 0, used2 = 0;
     uint64_t sam_bytes = 0;
-    std::vector<std::vector<char>> bam_rec, bam_z;   // --bam: records and BGZF blocks per slice
     std::vector<uint32_t> counts1, counts2;
 };
 
@@ -942,7 +859,6 @@ int main(int argc, char** argv)
             }
         }
     }
-    BamNames bam_refs; bam_refs.names = chrom_names;
     for (int p = 0; p < parts; p++) {
         Part& pt = *P_[(size_t)p];
         std::string path = out;
@@ -987,7 +903,7 @@ int main(int argc, char** argv)
             });
         for (auto& t : th) t.join();
     }
-    const int32_t flags = (pbat && !pe ? BMBS_TEXT_PBAT : 0) | (unmapped_out ? BMBS_TEXT_UNMAPPED : 0);
+    const int32_t flags = (pbat && !pe ? BMBS_TEXT_PBAT : 0) | (unmapped_out ? BMBS_TEXT_UNMAPPED : 0) | (bam ? BMBS_TEXT_BAM : 0);
     const double t_loaded = now();
 
     Chan<Batch*> free_q, gpu_q;
@@ -995,9 +911,8 @@ int main(int argc, char** argv)
     std::atomic<bool> failed(false);
     std::mutex err_mu;
     auto fail = [&](const std::string& why) { std::lock_guard<std::mutex> l(err_mu); if (!failed.exchange(true)) fprintf(stderr, "bmbs_search: %s\n", why.c_str()); };
-    // SAM: the writers only pwrite, every I/O thread reads; --bam: half of them convert and compress
-    const int r_threads = reader_threads > 0 ? reader_threads : std::max(1, io_threads / ((bam ? 2 : 1) * live_parts));
-    const int w_threads = std::max(1, io_threads / (2 * live_parts));
+    // the writers only pwrite (SAM text or finished BGZF blocks), every I/O thread reads
+    const int r_threads = reader_threads > 0 ? reader_threads : std::max(1, io_threads / live_parts);
 
     // ---------------- stage R (one per part): text window + newline count -> how many whole records ----------------------------
     auto reader_fn = [&](Part* pt) {
@@ -1048,7 +963,6 @@ int main(int argc, char** argv)
 
     // ---------------- stage W (one per part): the SAM text (or its BAM form) goes into the part's file, in order -----------------
     auto writer_fn = [&](Part* pt) {
-        Pool pool(bam ? w_threads - 1 : 0);
         for (;;) {
             const double tw0 = now();
             Batch* b = pt->out_q.get();
@@ -1058,54 +972,13 @@ int main(int argc, char** argv)
             if (b->n && !failed && b->sam_bytes) {
                 const char* text = b->sam.p;
                 const size_t len = (size_t)b->sam_bytes;
-                if (!bam) {
-                    size_t done = 0;
-                    while (done < len) {
-                        const ssize_t w = pwrite(pt->ofd, text + done, len - done, (off_t)(pt->out_off + done));
-                        if (w <= 0) { fail(std::string("write error: ") + strerror(errno)); break; }
-                        done += (size_t)w;
-                    }
-                    pt->out_off += len;
-                } else {
-                    // the batch's SAM lines -> BAM records -> BGZF blocks, by slices that begin at line starts (records may straddle
-                    // blocks, as in the reference's stream)
-                    const int T = pool.size() * 2;
-                    std::vector<size_t> cut((size_t)T + 1, len);
-                    cut[0] = 0;
-                    for (int t = 1; t < T; t++) {
-                        size_t at = len * (size_t)t / (size_t)T;
-                        const char* h = at < len ? (const char*)memchr(text + at, '\n', len - at) : nullptr;
-                        cut[(size_t)t] = std::max(cut[(size_t)t - 1], h ? (size_t)(h - text) + 1 : len);
-                    }
-                    b->bam_rec.resize((size_t)T); b->bam_z.resize((size_t)T);
-                    pool.run(T, [&](int t) {
-                        std::vector<char>& rec = b->bam_rec[(size_t)t];
-                        std::vector<char>& z = b->bam_z[(size_t)t];
-                        rec.clear(); z.clear();
-                        const char* q = text + cut[(size_t)t];
-                        const char* e2 = text + cut[(size_t)t + 1];
-                        while (q < e2) {
-                            const char* nlp = (const char*)memchr(q, '\n', (size_t)(e2 - q));
-                            const size_t ll = nlp ? (size_t)(nlp - q) : (size_t)(e2 - q);
-                            sam_line_to_bam(q, ll, bam_refs, rec);
-                            q += ll + 1;
-                        }
-                        if (!rec.empty()) bgzf_append(rec.data(), rec.size(), z);
-                    });
-                    const double t1 = now();
-                    pt->t_format += t1 - t0;
-                    for (int t = 0; t < T; t++) {
-                        const std::vector<char>& z = b->bam_z[(size_t)t];
-                        size_t done = 0;
-                        while (done < z.size()) {
-                            const ssize_t w = pwrite(pt->ofd, z.data() + done, z.size() - done, (off_t)(pt->out_off + done));
-                            if (w <= 0) { fail(std::string("write error: ") + strerror(errno)); break; }
-                            done += (size_t)w;
-                        }
-                        pt->out_off += z.size();
-                    }
-                    pt->t_write -= t1 - t0;
+                size_t done = 0;
+                while (done < len) {
+                    const ssize_t w = pwrite(pt->ofd, text + done, len - done, (off_t)(pt->out_off + done));
+                    if (w <= 0) { fail(std::string("write error: ") + strerror(errno)); break; }
+                    done += (size_t)w;
                 }
+                pt->out_off += len;
             }
             pt->t_write += now() - t0;
             free_q.put(b);

@@ -252,6 +252,10 @@ int bmbs_map_pe_fastq(bmbs_ctx*, const bmbs_fastq_view* mate1, const bmbs_fastq_
  * index's sequences, in index order: bmbs_index_file_chrom_name) once per context.                                           */
 #define BMBS_TEXT_PBAT      1   /* single end --pbat: reads are mapped as their reverse complement (Process_Reads.cpp:986-1075)   */
 #define BMBS_TEXT_UNMAPPED  2   /* --unmapped_out: unmapped reads / pairs are printed with flag 4 / 77 + 141                      */
+#define BMBS_TEXT_BAM      16   /* --bam: `sam` receives the batch's records as BAM inside complete BGZF blocks (a piece of a .bam file
+                                 * behind its header) instead of SAM text: what the reference gets from htslib's sam_parse1 + bam_write1
+                                 * per line (bam_prase.cpp:201-221), built and deflated on the device; the INFLATED bytes are the
+                                 * reference's, block boundaries and compressed bytes are not.  *sam_bytes = compressed bytes        */
 int bmbs_sam_refs(bmbs_ctx*, const char* const* names, int32_t n_names);
 int bmbs_map_se_text(bmbs_ctx*, const char* text, uint64_t text_bytes, int64_t n_records, int32_t flags,
                      char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
