@@ -191,6 +191,7 @@ struct Source {
     std::mutex m; std::condition_variable cv_data, cv_room;
     std::map<long, std::vector<char>> ready;     // chunk number -> text
     long next_chunk = 0;                         // the chunk window() takes next
+    long want_chunk = 0;                         // the chunk window() is waiting for (always admitted by push_chunk)
     size_t queued = 0, front_used = 0;
     bool gz_done = false, gz_stop = false;
     int live_inflaters = 0;
@@ -240,7 +241,7 @@ struct Source {
     {
         std::unique_lock<std::mutex> l(m);
         // the chunk window() is waiting for always gets in; the others wait for room (text inflated ahead of its turn is bounded)
-        cv_room.wait(l, [&] { return id == next_chunk || queued < ((size_t)768 << 20) || gz_stop; });
+        cv_room.wait(l, [&] { return id == want_chunk || queued < ((size_t)768 << 20) || gz_stop; });
         if (gz_stop) return;
         queued += c.size();
         ready[id] = std::move(c);
@@ -369,30 +370,52 @@ struct Source {
         } else {
             size_t have = std::min(carry.size(), cap);
             if (carry.size() > cap) { err = "internal: carried text larger than the window"; return false; }
-            if (have) memcpy(dst, carry.data(), have);
-            carry.clear();
+            // which pieces of which chunks make up the window (waiting for the inflaters as needed) ...
+            struct Piece { const char* src; size_t len, dst; };
+            std::vector<Piece> pieces;
+            if (have) pieces.push_back(Piece{carry.data(), have, 0});
             bool done = false;
+            long chunk = next_chunk; size_t used = front_used;
+            std::vector<long> finished;
             while (have < cap) {
                 std::unique_lock<std::mutex> l(m);
-                cv_data.wait(l, [this] { return ready.count(next_chunk) != 0 || gz_done; });
-                auto it = ready.find(next_chunk);
+                if (want_chunk != chunk) { want_chunk = chunk; cv_room.notify_all(); }
+                cv_data.wait(l, [&] { return ready.count(chunk) != 0 || gz_done; });
+                auto it = ready.find(chunk);
                 if (it == ready.end()) { done = true; if (!err.empty()) return false; break; }
-                std::vector<char>& f = it->second;
-                const size_t take = std::min(cap - have, f.size() - front_used);
-                l.unlock();                                                     // only this thread consumes: the chunk stays put
-                memcpy(dst + have, f.data() + front_used, take);
-                have += take; front_used += take;
-                l.lock();
-                if (front_used == f.size()) { queued -= f.size(); ready.erase(it); next_chunk++; front_used = 0; cv_room.notify_all(); }
+                std::vector<char>& f = it->second;                                  // (only this thread erases: the chunk stays put)
+                l.unlock();
+                const size_t take = std::min(cap - have, f.size() - used);
+                pieces.push_back(Piece{f.data() + used, take, have});
+                have += take; used += take;
+                if (used == f.size()) { finished.push_back(chunk); chunk++; used = 0; }
             }
             len = have;
             last = done;
+            // ... then every thread copies its share of the window and counts the newlines of what it has just written (one thread
+            // copying 300 MB windows of two files was the whole run time of gzipped input once the inflate ran on many threads)
             const size_t nsb = (len + SUB_BLOCK - 1) / SUB_BLOCK;
             counts.assign(nsb, 0);
-            const int T = (int)std::min<size_t>(nsb, (size_t)pool.size() * 4);
+            const int T = (int)std::min<size_t>(std::max<size_t>(nsb, 1), (size_t)pool.size() * 2);
+            const size_t per = ((nsb + (size_t)T - 1) / (size_t)T) * SUB_BLOCK;
             pool.run(T, [&](int t) {
-                for (size_t i = (size_t)t; i < nsb; i += (size_t)T) counts[i] = (uint32_t)count_nl(dst + i * SUB_BLOCK, std::min(SUB_BLOCK, len - i * SUB_BLOCK));
+                const size_t a = std::min(len, per * (size_t)t), e = std::min(len, a + per);
+                if (a >= e) return;
+                size_t lo = 0, hi = pieces.size();                                  // first piece that reaches beyond a
+                while (lo < hi) { const size_t mid = (lo + hi) / 2; if (pieces[mid].dst + pieces[mid].len <= a) lo = mid + 1; else hi = mid; }
+                for (size_t i = lo; i < pieces.size() && pieces[i].dst < e; i++) {
+                    const size_t x = std::max(a, pieces[i].dst), y = std::min(e, pieces[i].dst + pieces[i].len);
+                    if (x < y) memcpy(dst + x, pieces[i].src + (x - pieces[i].dst), y - x);
+                }
+                for (size_t q = a; q < e; q += SUB_BLOCK) counts[q / SUB_BLOCK] = (uint32_t)count_nl(dst + q, std::min(SUB_BLOCK, e - q));
             });
+            carry.clear();
+            {
+                std::lock_guard<std::mutex> l(m);
+                for (long id : finished) { auto it = ready.find(id); if (it != ready.end()) { queued -= it->second.size(); ready.erase(it); } }
+                next_chunk = chunk; want_chunk = chunk; front_used = used;
+                cv_room.notify_all();
+            }
         }
         // an unterminated last line counts as a line: the device wants every line closed
         if (last && len && dst[len - 1] != '\n') { dst[len] = '\n'; len++; if ((len - 1) / SUB_BLOCK >= counts.size()) counts.push_back(0); counts[(len - 1) / SUB_BLOCK]++; }
@@ -731,7 +754,12 @@ int main(int argc, char** argv)
         return 2;
     }
     if (batch < 1) batch = 1;
-    if (io_threads <= 0) { io_threads = (int)std::thread::hardware_concurrency(); if (io_threads > 32) io_threads = 32; }
+    if (io_threads <= 0) {
+        // plain text needs few threads to read at memory speed; compressed input is inflated by them (csrc/pgz.h): more pay off
+        const bool zin = Source::is_gz(seq.empty() ? seq1.c_str() : seq.c_str());
+        const int hw = (int)std::thread::hardware_concurrency();
+        io_threads = zin ? std::min(std::max(1, hw / 2), 64) : std::min(hw, 32);
+    }
     if (io_threads < 1) io_threads = 1;
     if (parts < 1) parts = 1;
     if (parts > 64) parts = 64;
@@ -853,7 +881,7 @@ int main(int argc, char** argv)
         if (!compute_cuts(cut1, cut2)) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
         for (int p = 0; p < live_parts; p++) {
             Part& pt = *P_[(size_t)p];
-            const int zt = std::max(1, io_threads / (pe ? 4 : 2));          // BGZF input: inflate threads per file
+            const int zt = std::max(1, io_threads / (pe ? 2 : 1));          // compressed input: inflate threads per file
             if (!pt.s1.open(in1.c_str(), cut1[(size_t)p], cut1[(size_t)p + 1], zt) || (pe && !pt.s2.open(seq2.c_str(), cut2[(size_t)p], cut2[(size_t)p + 1], zt))) {
                 fprintf(stderr, "Cannot open the read file(s)\n"); return 1;
             }
@@ -917,6 +945,7 @@ int main(int argc, char** argv)
     // ---------------- stage R (one per part): text window + newline count -> how many whole records ----------------------------
     auto reader_fn = [&](Part* pt) {
         Pool pool(r_threads - 1);
+        Pool pool2(pe && pt->s2.gz ? std::max(1, r_threads / 2) - 1 : 0);          // second mate's window of compressed input
         size_t est = est0;
         for (;;) {
             const double tw0 = now();
@@ -931,8 +960,18 @@ int main(int argc, char** argv)
             if (!b->text1.need(want + 64) || (pe && !b->text2.need(want + 64))) { bail("cannot allocate page-locked staging memory"); return; }
             bool last1 = true, last2 = true;
             size_t n1 = 0, n2 = 0;
-            if (!pt->s1.window(pool, b->text1.p, want, n1, last1, b->counts1)) { bail(pt->s1.err); return; }
-            if (pe && !pt->s2.window(pool, b->text2.p, want, n2, last2, b->counts2)) { bail(pt->s2.err); return; }
+            if (pe && pt->s2.gz) {
+                // compressed input: the two windows are assembled side by side (each waits for its own inflaters)
+                bool ok2 = true;
+                std::thread w2([&] { ok2 = pt->s2.window(pool2, b->text2.p, want, n2, last2, b->counts2); });
+                const bool ok1 = pt->s1.window(pool, b->text1.p, want, n1, last1, b->counts1);
+                w2.join();
+                if (!ok1) { bail(pt->s1.err); return; }
+                if (!ok2) { bail(pt->s2.err); return; }
+            } else {
+                if (!pt->s1.window(pool, b->text1.p, want, n1, last1, b->counts1)) { bail(pt->s1.err); return; }
+                if (pe && !pt->s2.window(pool, b->text2.p, want, n2, last2, b->counts2)) { bail(pt->s2.err); return; }
+            }
             size_t l1 = 0, l2 = 0;
             for (uint32_t c : b->counts1) l1 += c;
             for (uint32_t c : b->counts2) l2 += c;

@@ -400,7 +400,7 @@ public:
     void stop()
     {
         { std::lock_guard<std::mutex> l(m_); stop_ = true; }
-        cv_.notify_all();
+        cv_.notify_all(); cv_done_.notify_all();
         for (auto& t : th_) if (t.joinable()) t.join();
         th_.clear();
     }
@@ -408,7 +408,7 @@ public:
     std::string wait()
     {
         std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [this] { return finished_ || stop_; });
+        cv_done_.wait(l, [this] { return finished_ || stop_; });
         return err_;
     }
     bool finished() { std::lock_guard<std::mutex> l(m_); return finished_; }
@@ -621,7 +621,10 @@ private:
                     if (!failed_ && !stream_ended_) fail("the deflate stream ends before its last block (truncated .gz input?)");
                     finished_ = true;
                 }
-                cv_.notify_all();
+                // (a thread that changes the state goes round the loop itself and takes what has become possible: the others are woken
+                // one at a time, for the second piece of work an event may have made -- notify_all here woke every thread for every
+                // step of every task, and 64 threads queueing for this mutex were slower than 8)
+                if (finished_) { cv_.notify_all(); cv_done_.notify_all(); } else cv_.notify_one();
                 continue;
             }
             // B: the next task in order whose A has finished
@@ -635,7 +638,7 @@ private:
                 if (k.st == ST_ERROR && !k.skip && !failed_) fail(std::string("corrupt .gz input: ") + (k.why && *k.why ? k.why : "invalid deflate data"));
                 redone_ = redone_count_;
                 k.state = 3; next_b_++; sequencing_ = false;
-                cv_.notify_all();
+                cv_.notify_one();
                 continue;
             }
             // C: any task whose window is known
@@ -649,7 +652,6 @@ private:
                     if (!failed_) run_c(k); else { sym_put(k.sym); k.redo.reset(); }
                     l.lock();
                     k.state = 5;
-                    cv_.notify_all();
                     continue;
                 }
             }
@@ -662,7 +664,6 @@ private:
                 run_a(t, k);
                 l.lock();
                 k.state = 2;
-                cv_.notify_all();
                 continue;
             }
             if (failed_ && next_a_ < n_tasks_) {
@@ -679,7 +680,7 @@ private:
     const u8* d_; size_t n_; Options opt_; Sink sink_; long id0_;
     size_t body_ = 0; u64 body_bit_ = 0; long n_tasks_ = 0;
     std::vector<Task> tasks_;
-    std::mutex m_; std::condition_variable cv_;
+    std::mutex m_; std::condition_variable cv_, cv_done_;
     std::mutex pool_m_; std::vector<std::unique_ptr<OutBuf<u16>>> pool_;
     std::vector<std::thread> th_;
     long next_a_ = 0, next_b_ = 0, next_d_ = 0, emitted_ = 0, redone_ = 0, redone_count_ = 0;

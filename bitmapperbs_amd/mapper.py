@@ -161,7 +161,7 @@ class Mapper:
         return res, pool[:used.value]
 
     # ---- FASTQ text in, SAM text out (newline index and SAM formatting on the device) ---------------
-    TEXT_PBAT, TEXT_UNMAPPED = 1, 2
+    TEXT_PBAT, TEXT_UNMAPPED, TEXT_BAM = 1, 2, 16
 
     def _set_refs(self):
         if getattr(self, "_refs_set", False):
@@ -170,10 +170,12 @@ class Mapper:
         self._chk(self._lib.bmbs_sam_refs(self._ctx, names, len(self.index.chrom_names)))
         self._refs_set = True
 
-    def map_text(self, text1: bytes, n: int, text2: bytes | None = None, flags: int = 0) -> bytes:
-        """FASTQ text of n records (pairs with text2) -> the SAM lines the reference prints for them, in input order"""
+    def map_text(self, text1: bytes, n: int, text2: bytes | None = None, flags: int = 0, cap: int | None = None) -> bytes:
+        """FASTQ text of n records (pairs with text2) -> the SAM lines the reference prints for them, in input order (flags & TEXT_BAM:
+        their BAM records as complete BGZF blocks).  cap: bytes of the output buffer handed to the library (default: ample)"""
         self._set_refs()
-        cap = len(text1) + (len(text2) if text2 else 0) + (2 if text2 else 1) * n * 640 + 4096
+        if cap is None:
+            cap = len(text1) + (len(text2) if text2 else 0) + (2 if text2 else 1) * n * 640 + 4096
         out = np.empty(cap, dtype=np.uint8)
         used = C.c_uint64(0); lines = C.c_int64(0)
         a1 = np.frombuffer(text1, dtype=np.uint8)

@@ -135,3 +135,71 @@ def write_bgzf(path, data: bytes, block: int = 60000, level: int = 6):
             f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize))
             f.write(z)
             f.write(struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+
+
+_NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    for sh, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> sh == end >> sh:
+            return off + (beg >> sh)
+    return 0
+
+
+def sam_to_bam_records(sam: bytes, ref_names) -> bytes:
+    """the BAM record stream htslib's sam_parse1 + bam_write1 give for SAM lines of the shape this path prints (11 columns + NM:i):
+    the checker of the device-side BAM encoder (test infrastructure; SAM specification section 4.2)"""
+    import struct
+    ids = {n: i for i, n in enumerate(ref_names)}
+    out = []
+    for line in sam.split(b"\n"):
+        if not line or line.startswith(b"@"):
+            continue
+        f = line.decode("latin-1").split("\t")
+        flag = int(f[1]); refid = -1 if f[2] == "*" else ids[f[2]]; pos = int(f[3]) - 1; mapq = int(f[4])
+        cig = []; reflen = 0
+        if f[5] != "*":
+            num = ""
+            for ch in f[5]:
+                if ch.isdigit():
+                    num += ch
+                else:
+                    op = "MIDNSHP=X".index(ch); ln = int(num); num = ""
+                    cig.append(ln << 4 | op)
+                    if op in (0, 2, 3, 7, 8):
+                        reflen += ln
+        nref = refid if f[6] == "=" else (-1 if f[6] == "*" else ids[f[6]])
+        npos = int(f[7]) - 1; tlen = int(f[8])
+        seq = "" if f[9] == "*" else f[9]
+        name = f[0].encode("latin-1") + b"\0"
+        body = struct.pack("<iiBBHHHIiii", refid, pos, len(name), mapq, _reg2bin(pos, pos + (reflen if cig and reflen else 1)), len(cig), flag,
+                           len(seq), nref, npos, tlen) + name + b"".join(struct.pack("<I", c) for c in cig)
+        nib = [_NT16.get(c.upper(), 15) if not c.isdigit() else (1, 2, 4, 8, 15, 15, 15, 15, 15, 15)[int(c)] for c in seq]
+        if len(nib) & 1:
+            nib.append(0)
+        body += bytes((nib[i] << 4) | nib[i + 1] for i in range(0, len(nib), 2))
+        body += bytes(0xff for _ in seq) if f[10] == "*" else bytes((ord(c) - 33) & 0xff for c in f[10])
+        if len(f) > 11 and f[11].startswith("NM:i:"):
+            v = int(f[11][5:])
+            body += b"NM" + (b"C" + struct.pack("<B", v) if v <= 0xff else b"S" + struct.pack("<H", v) if v <= 0xffff else b"I" + struct.pack("<I", v))
+        out.append(struct.pack("<i", len(body)) + body)
+    return b"".join(out)
+
+
+def bgzf_blocks(data: bytes):
+    """the members of a BGZF byte string as (compressed size, inflated bytes); checks the BC field, CRC-32 and ISIZE of each"""
+    import struct
+    import zlib
+    at = 0
+    out = []
+    while at < len(data):
+        assert data[at:at + 4] == b"\x1f\x8b\x08\x04" and data[at + 10:at + 16] == b"\x06\x00BC\x02\x00", at
+        bsize = struct.unpack("<H", data[at + 16:at + 18])[0] + 1
+        raw = zlib.decompressobj(-15).decompress(data[at + 18:at + bsize - 8])
+        crc, isize = struct.unpack("<II", data[at + bsize - 8:at + bsize])
+        assert isize == len(raw) and crc == (zlib.crc32(raw) & 0xffffffff) and len(raw) <= 0xff00, at
+        out.append((bsize, raw))
+        at += bsize
+    return out

@@ -1151,6 +1151,93 @@ def test_device_sam_text_odd_input(env):
     assert got == exp
 
 
+def _odd_fastq(env, n=6000, L=120, seed=41):
+    from bitmapperbs_amd import synth
+    r = synth.make_reads_se(env["chroms"], n=n, L=L, seed=seed, sub=0.03, indel=0.002, qual="random", n_rate=0.002)
+    rng = np.random.default_rng(6)
+    recs = []
+    for i in range(n):
+        Li = int(rng.integers(30, L + 1))
+        s = r["seq"][i, :Li].tobytes(); q = r["qual"][i, :Li].tobytes()
+        if i % 7 == 0: s = s.lower()
+        if i % 11 == 0: q = q[:max(1, Li - 5)]
+        nm = b"@read%d" % i + (b" extra/1" if i % 3 == 0 else b"/1" if i % 3 == 1 else b"")
+        recs.append(nm + b"\n" + s + b"\n+\n" + q)
+    return b"\n".join(recs) + b"\n"
+
+
+@pytest.mark.parametrize("case", ["se_odd_unmapped", "se_pbat", "pe_p100", "pe_s150_unmapped", "se_constant_quality"])
+def test_device_bam_blocks_inflate_to_the_records_of_the_sam_text(env, case):
+    """--bam on the device (bmbs_bam.hip): the BGZF blocks a text call returns with BMBS_TEXT_BAM are well-formed (BC field, CRC-32,
+    ISIZE, <= 0xff00 bytes each) and inflate to exactly the BAM records htslib makes of the SAM lines the same call prints without the
+    flag (those lines are pinned to the reference's by the golden tests): names, flags, bins, CIGAR words, 4-bit bases, qualities - 33
+    (a padded quality is 0xff), NM tag types, mates' positions and signed TLEN; several blocks per call, records straddling blocks"""
+    from bitmapperbs_amd import mapper
+    from common import sam_to_bam_records, bgzf_blocks
+    M = mapper.Mapper
+    if case.startswith("se"):
+        if case == "se_constant_quality":
+            from bitmapperbs_amd import synth
+            r = synth.make_reads_se(env["chroms"], n=5000, L=150, seed=77, sub=0.01, indel=0.001, qual="const")
+            text = b"".join(b"@q%d\n" % i + r["seq"][i].tobytes() + b"\n+\n" + r["qual"][i].tobytes() + b"\n" for i in range(5000))
+            n, flags = 5000, 0
+        else:
+            text = _odd_fastq(env); n = 6000
+            flags = M.TEXT_UNMAPPED if case == "se_odd_unmapped" else M.TEXT_PBAT
+        m = M(env["ix"], 0)
+        sam = m.map_text(text, n, flags=flags)
+        z = m.map_text(text, n, flags=flags | M.TEXT_BAM)
+        names = env["ix"].chrom_names
+    else:
+        from bitmapperbs_amd import synth
+        sens = case.startswith("pe_s")
+        L = 150 if sens else 100
+        m1, m2 = synth.make_reads_pe(env["chroms"], n=4000, L=L, seed=5, sub=0.03, indel=0.003, qual="random")
+
+        def fq(mm):
+            return b"".join(b"@" + mm["names"][i] + b"\n" + mm["seq"][i].tobytes() + b"\n+\n" + mm["qual"][i].tobytes() + b"\n" for i in range(4000))
+        t1, t2 = fq(m1), fq(m2)
+        n = 4000
+        m = M(env["ix"], 0, sensitive=1 if sens else 0)
+        flags = M.TEXT_UNMAPPED if case.endswith("unmapped") else 0
+        sam = m.map_text(t1, n, t2, flags=flags)
+        z = m.map_text(t1, n, t2, flags=flags | M.TEXT_BAM)
+        names = env["ix"].chrom_names
+    m.close()
+    blocks = bgzf_blocks(z)
+    assert len(blocks) >= 2
+    assert all(len(raw) == 0xff00 for _, raw in blocks[:-1])
+    got = b"".join(raw for _, raw in blocks)
+    want = sam_to_bam_records(sam, names)
+    assert len(got) == len(want)
+    assert got == want
+    if case == "se_constant_quality":
+        assert len(z) < len(got) // 2             # runs + Huffman: constant qualities and 4-bit bases compress
+
+
+def test_text_call_with_a_small_buffer_can_be_repeated_and_counts_once(env):
+    """BMBS_ENOMEM of bmbs_map_*_text (output buffer too small) is retriable (*sam_bytes = the size needed): the batch it mapped is
+    NOT added to the context's mapstats, so that the repeat counts it once (SAM text and BAM)"""
+    import ctypes as C
+    from bitmapperbs_amd import mapper, capi
+    text = _odd_fastq(env, n=3000)
+    a1 = np.frombuffer(text, dtype=np.uint8)
+    for flags in (mapper.Mapper.TEXT_UNMAPPED, mapper.Mapper.TEXT_UNMAPPED | mapper.Mapper.TEXT_BAM):
+        m = mapper.Mapper(env["ix"], 0)
+        m._set_refs()
+        ref = m.map_text(text, 3000, flags=flags)
+        st1 = m.stats().copy()
+        small = np.empty(1000, dtype=np.uint8)
+        used = C.c_uint64(0); lines = C.c_int64(0)
+        rc = m._lib.bmbs_map_se_text(m._ctx, capi.ptr(a1), a1.size, 3000, flags, capi.ptr(small), small.size, C.byref(used), C.byref(lines))
+        assert rc == -12 and used.value == len(ref)
+        assert (m.stats() == st1).all()
+        again = m.map_text(text, 3000, flags=flags, cap=int(used.value))
+        assert again == ref
+        assert (m.stats() == 2 * st1).all()
+        m.close()
+
+
 @pytest.mark.parametrize("kind,name,nparts,mode", [
     ("se", "b150", 3, "plain"), ("pe", "p100", 4, "plain"), ("pe", "s100", 2, "names_differ"), ("pe", "p150", 3, "no_names"),
     ("se", "e75", 2, "gz"), ("pe", "p75", 3, "bam"), ("pe", "p100", 2, "bgzf"), ("se", "b150", 3, "bgzf"),

@@ -13,6 +13,7 @@ GZN=$((N * 2))
 ( head -c $((GZN * REC)) $F2 | gzip -1 -c > $W/g_2.fq.gz ) &
 wait
 ls -la $W/g_1.fq.gz $W/g_2.fq.gz
+tools/pgz_probe.sh $W/g_1.fq.gz $W/g_2.fq.gz
 run() { # label, reads, args...
   local label=$1; shift; local reads=$1; shift
   ./bitmapperbs_amd/bmbs_search --search $FA -e 0.08 --verbose "$@" 2> $O/$label.err > /dev/null
@@ -21,7 +22,7 @@ run() { # label, reads, args...
 }
 ALL=$((NP * 2)); GZR=$((GZN * 2))
 run text_null $ALL --seq1 $F1 --seq2 $F2 -o /dev/null -t 32
-for t in 32 64 128 192; do run gz_t$t $GZR --seq1 $W/g_1.fq.gz --seq2 $W/g_2.fq.gz -o /dev/null -t $t; done
+for t in 16 32 64 128; do run gz_t$t $GZR --seq1 $W/g_1.fq.gz --seq2 $W/g_2.fq.gz -o /dev/null -t $t; done
 run bam_null $ALL --seq1 $F1 --seq2 $F2 -o /dev/null -t 32 --bam
 run bam_file $ALL --seq1 $F1 --seq2 $F2 -o $W/o.bam -t 32 --bam
 ls -la $W/o.bam; python3 - <<PY
