@@ -73,6 +73,7 @@ struct Knobs {
     bool copy_streams = true;   // BMBS_COPY_STREAMS=0: the text calls' copies go on the lane's kernel stream
     bool copy_lock = true;      // BMBS_COPY_LOCK=0: the text calls of different contexts copy at the same time
     bool arena = true;          // BMBS_ARENA=0: every work buffer a hipMalloc of its own (round 2)
+    int exp = 0;                // BMBS_EXP: timing experiments (results are WRONG with it): 1 = k_seed_extra stores no seed records
     double cap_scale = 1.0;     // BMBS_CAP_SCALE: scales the learned capacities (tests: a small value forces the repeat-with-exact-sizes path)
     void read()
     {
@@ -94,6 +95,7 @@ struct Knobs {
         if ((e = getenv("BMBS_LANES"))) lanes = atoi(e);
         if (lanes < 1) lanes = 1;
         if (lanes > 8) lanes = 8;
+        if ((e = getenv("BMBS_EXP"))) exp = atoi(e);
         if ((e = getenv("BMBS_CHUNK"))) chunk = atol(e);
         if ((e = getenv("BMBS_SPLIT_MIN"))) split_min = atol(e);
         if (split_min < 1) split_min = 1;
@@ -649,7 +651,7 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
         const size_t plds = (size_t)64 * (pr.pwords + 1) * 8;
         if (packed_rows && c->kn.extra_plds && plds <= 16 * 1024)
             hipLaunchKernelGGL((k_seed_extra<false, true, true>), dim3(chunks_min), dim3(64), plds, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
-                               target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
+                               target_waves, c->prm.seed_len, pe_mode | (c->kn.exp << 8), st, sc, cnt);
         else if (packed_rows)
             hipLaunchKernelGGL((k_seed_extra<false, true>), dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);

@@ -1624,8 +1624,10 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
 template <bool ROWS_LDS, bool PACKED = false, bool PLDS = false>
 __global__ void __launch_bounds__(64)
 k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
-             int seed_len, int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
+             int seed_len, int pe_mode_x, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
 {
+    const int pe_mode = pe_mode_x & 0xff;
+    const bool exp_nostore = (pe_mode_x >> 8) & 1;    // BMBS_EXP=1 (timing experiment)
     int L = gm.L;                                     // length of the lane's current read
     const long total = (long)*count_ptr;
     const long chunk = seed_chunk(total, target_waves);
@@ -1660,8 +1662,9 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
     auto after_seed = [&]() -> bool {
         const int cur_len = L - tm;
         const u64 ml = h.ml;
-        if (h.hits == 1) { seed_record(my, ns, ncand, h.sp, 1, ml, (u64)tm); clen += 1; }
-        else if (ml >= (u64)seed_len && h.hits <= max_hits) { if (h.hits != 0) { seed_record(my, ns, ncand, h.sp, h.hits, ml, (u64)tm); clen += h.hits; } }
+        auto rec = [&](u64 hits) { if (exp_nostore) { ns++; ncand += hits; } else seed_record(my, ns, ncand, h.sp, hits, ml, (u64)tm); };
+        if (h.hits == 1) { rec(1); clen += 1; }
+        else if (ml >= (u64)seed_len && h.hits <= max_hits) { if (h.hits != 0) { rec(h.hits); clen += h.hits; } }
         else if ((u64)cur_len == ml) return false;
         if (ml == 0) {
             // only a read with a character outside ACGT can hold the 'N' determine_seed_offset_unmatch looks for

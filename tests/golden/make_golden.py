@@ -37,6 +37,12 @@ SETS = {
     "c150": dict(reads=dict(n=1200, L=150, seed=3, sub=0.03, indel=0.003, qual="random", conv=0.9), args=[]),
     "d250": dict(reads=dict(n=600, L=250, seed=4, sub=0.03, indel=0.001, qual="random"), args=[]),
     "e75": dict(reads=dict(n=1500, L=75, seed=5, sub=0.04, indel=0.004, qual="random", n_rate=0.01), args=[]),
+    # reads of 401 .. 998 bases: the threshold is capped at 31 (Schema.cpp:24546-24550), 25 seeds.  998 is the longest read the
+    # reference itself handles: at 999 and 1000 (Auxiliary.h:15 SEQ_MAX_LENGTH 1000) it prints 222 of 300 records of the same
+    # reads, one of them with bytes outside ASCII -- its fixed 1000-byte buffers have no room for the terminators -- so there is
+    # nothing to pin there
+    "f600": dict(reads=dict(n=400, L=600, seed=6, sub=0.02, indel=0.002, qual="random"), args=[]),
+    "g998": dict(reads=dict(n=300, L=998, seed=7, sub=0.015, indel=0.0015, qual="random", n_rate=0.001), args=[]),
 }
 
 PE_SETS = {
@@ -46,6 +52,8 @@ PE_SETS = {
     # --sensitive (Map_Pair_Seq_end_to_end rescue + reseed_filter): high-error pairs so that the rescue paths run
     "s100": dict(reads=dict(n=1200, L=100, seed=14, sub=0.06, indel=0.003, qual="random"), args=["--sensitive"]),
     "s150": dict(reads=dict(n=800, L=150, seed=15, sub=0.07, indel=0.004, qual="random", ins_hi=450), args=["--sensitive", "-e", "0.1", "--max", "450"]),
+    "p998": dict(reads=dict(n=250, L=998, seed=16, sub=0.015, indel=0.001, qual="random", ins_lo=1020, ins_hi=1500), args=["--max", "1600"]),
+    "s600": dict(reads=dict(n=300, L=600, seed=17, sub=0.05, indel=0.002, qual="random", ins_lo=620, ins_hi=1100), args=["--sensitive", "--max", "1200"]),
 }
 
 # output variants (Process_CommandLines.cpp:93-105) run on the read sets above; only the reference's SAM + mapstats are stored.

@@ -61,6 +61,11 @@ CASES = [
     dict(n=20000, L=75, seed=5, sub=0.04, indel=0.004, qual="random", n_rate=0.01, e=0.08),
     dict(n=10000, L=36, seed=6, sub=0.02, indel=0.0, qual="random", e=0.1),
     dict(n=2000, L=400, seed=7, sub=0.03, indel=0.001, qual="random", e=0.08),        # k = 31 cap... (32 -> 31)
+    # 401 .. 998 bases (the reference itself breaks at 999 and 1000, tests/golden/make_golden.py): k stays 31, 25 seeds, rows beyond the LDS slots of the short-read forms
+    dict(n=1500, L=600, seed=21, sub=0.02, indel=0.002, qual="random", e=0.08),
+    dict(n=1000, L=998, seed=22, sub=0.015, indel=0.0015, qual="random", n_rate=0.001, e=0.08),
+    dict(n=1000, L=998, seed=23, sub=0.004, indel=0.0005, qual="const", e=0.02),     # k = 19 on 998 bases
+    dict(n=1000, L=777, seed=24, sub=0.03, indel=0.003, qual="random", e=0.08, amb=1),
     dict(n=5000, L=150, seed=8, sub=0.0, indel=0.0, qual="const", conv=0.0, e=0.0),   # k = 0
     # --ambiguous_out: one hit of each ambiguous read is aligned and returned (exact-ambiguous and tie-in-the-filter forms)
     dict(n=30000, L=100, seed=9, sub=0.01, indel=0.001, qual="random", e=0.08, amb=1),
@@ -146,7 +151,8 @@ def test_filter_stage_matches_oracle_incl_invalid_sites(env):
                                       ("reg2", 150, 0.04), ("wave", 150, 0.04), ("reg", 150, 0.04),          # k = 6: 16 lanes
                                       ("reg2", 250, 0.08), ("wave", 250, 0.08), ("reg", 250, 0.08),          # k = 20: a whole wave
                                       ("reg2", 100, 0.31), ("wave", 100, 0.31), ("reg2", 61, 0.05), ("wave", 61, 0.05),   # k = 31 (band 63), k = 3
-                                      ("reg2", 400, 0.08), ("reg2", 36, 0.1)])
+                                      ("reg2", 400, 0.08), ("reg2", 36, 0.1),
+                                      ("reg2", 600, 0.08), ("reg", 600, 0.08), ("wave", 600, 0.08), ("reg2", 998, 0.08), ("reg", 998, 0.08), ("wave", 998, 0.02)])
 def test_align_stage_matches_oracle(env, monkeypatch, form, L, e):
     """K11-K13 through bmbs_align_batch: jobs = every accepted candidate of the filter stage with err > 0.
     The three forms of the DP kernel: `reg2` = two alignments per lane in packed 16-bit arithmetic (k_align_sw2, the default),
@@ -181,12 +187,12 @@ def test_align_stage_matches_oracle(env, monkeypatch, form, L, e):
     m.close()
 
 
-@pytest.mark.parametrize("L,e,sub", [(100, 0.08, 0.01), (150, 0.08, 0.04), (250, 0.08, 0.03)])
+@pytest.mark.parametrize("L,e,sub", [(100, 0.08, 0.01), (150, 0.08, 0.04), (250, 0.08, 0.03), (600, 0.08, 0.02), (998, 0.08, 0.015)])
 def test_seed_stage_verdicts_and_vote_sites(env, L, e, sub):
     """K1-K6 + a8-a10 through bmbs_seed_batch: verdicts, and for every general-path read the vote list itself -- sites AND
     counts, in the reference's visiting order (std::sort by vote, unstable) -- against the oracle's"""
     from bitmapperbs_amd import synth, mapper
-    r = synth.make_reads_se(env["chroms"], n=20000, L=L, seed=41, sub=sub, indel=0.001, qual="const", n_rate=0.002)
+    r = synth.make_reads_se(env["chroms"], n=20000 if L <= 250 else 4000, L=L, seed=41, sub=sub, indel=0.001, qual="const", n_rate=0.002)
     m = mapper.Mapper(env["ix"], 0, e_f=e)
     s = m.seed(r["seq"], L, vote_cap=4096 * 1024)
     recs, ovs, ovc, ovo = env["oix"].map_se_votes(orc.params(e_f=e), r["seq"], r["qual"], L)
@@ -206,7 +212,7 @@ def test_seed_stage_verdicts_and_vote_sites(env, L, e, sub):
         assert (s["vote_site"][a:a + nv] == ovs[oa:ob]).all(), i
         assert (s["vote_cnt"][a:a + nv] == ovc[oa:ob]).all(), i
         n_lists += 1; n_long += nv > 16
-    assert n_lists > 500 and (L < 150 or n_long > 0)
+    assert n_lists > (500 if L <= 250 else 100) and (L < 150 or n_long > 0)
     m.close()
 
 
@@ -357,6 +363,11 @@ PE_CASES = [
     # --ambiguous_out for pairs (Schema.cpp:19345 / 21251)
     dict(n=20000, L=75, seed=11, sub=0.01, indel=0.001, qual="random", ins_lo=60, ins_hi=300, prm=dict(ambiguous_out=1, min_ins=100, max_ins=250)),
     dict(n=15000, L=100, seed=12, sub=0.05, indel=0.002, qual="random", prm=dict(sensitive=1, ambiguous_out=1)),
+    # mates of 600 / 998 bases
+    dict(n=1200, L=600, seed=13, sub=0.02, indel=0.002, qual="random", ins_lo=620, ins_hi=1100, prm=dict(max_ins=1200)),
+    dict(n=800, L=998, seed=14, sub=0.015, indel=0.001, qual="random", ins_lo=1020, ins_hi=1500, prm=dict(max_ins=1600)),
+    dict(n=1000, L=600, seed=15, sub=0.05, indel=0.002, qual="random", ins_lo=620, ins_hi=1100, prm=dict(sensitive=1, max_ins=1200)),
+    dict(n=600, L=998, seed=16, sub=0.04, indel=0.002, qual="random", ins_lo=1020, ins_hi=1500, prm=dict(sensitive=1, max_ins=1600)),
 ]
 
 
