@@ -246,7 +246,7 @@ def write_fastq_sample(path, seq, qual, L):
     rec.tofile(path)
 
 
-def cpu_baseline(args, cfg, fa, host_reads, L):
+def cpu_baseline(args, cfg, fa, host_reads, L, tag="cpu_sample"):
     """Time the reference's own CPU path (oracle/_ref/bitmapperBS, kind 'reference') -- or, when it has not been built, the
     scalar restatement (oracle/liboracle.so, kind 'port') -- on a bounded sample of the step's first launch.
     host_reads = (seq, qual) or (seq1, qual1, seq2, qual2) numpy arrays."""
@@ -258,17 +258,17 @@ def cpu_baseline(args, cfg, fa, host_reads, L):
         n, unit, L, "PE" if pe else "SE", cfg["e"], ", --sensitive" if cfg["sensitive"] else "")
     if os.path.exists(ref):
         cores = args.cpu_threads or min(32, os.cpu_count() or 1)
-        out = os.path.join(args.workdir, "cpu_sample.sam")
+        out = os.path.join(args.workdir, tag + ".sam")
         cmd = [ref, "--search", fa]
         if pe:
-            f1 = os.path.join(args.workdir, "cpu_sample_1.fq"); f2 = os.path.join(args.workdir, "cpu_sample_2.fq")
+            f1 = os.path.join(args.workdir, tag + "_1.fq"); f2 = os.path.join(args.workdir, tag + "_2.fq")
             write_fastq_sample(f1, host_reads[0], host_reads[1], L)
             write_fastq_sample(f2, host_reads[2], host_reads[3], L)
             cmd += ["--seq1", f1, "--seq2", f2]
             if cfg["sensitive"]:
                 cmd += ["--sensitive"]
         else:
-            fq = os.path.join(args.workdir, "cpu_sample.fq")
+            fq = os.path.join(args.workdir, tag + ".fq")
             write_fastq_sample(fq, host_reads[0], host_reads[1], L)
             cmd += ["--seq", fq]
         cmd += ["-e", str(cfg["e"]), "-t", str(cores), "-o", out]
@@ -296,6 +296,24 @@ def cpu_baseline(args, cfg, fa, host_reads, L):
     dt = time.time() - t
     return {"value": round(m / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
             "sample": "first %d reads of the step's first launch, scalar CPU restatement (oracle/)" % m}, None
+
+
+def sam_identity(ix, m, job, host, L, pe, ref_sam, nchk):
+    """the GPU records of the first nchk reads / pairs of the job's first launch print the same SAM lines as the reference wrote for
+    them (ref_sam: the reference's output for a sample that starts with those reads) -> (identical, lines compared)"""
+    from bitmapperbs_amd import mapper, capi
+    job.launch(0); m.sync()
+    nrec = nchk * (2 if pe else 1)
+    res_h = job.res_d[:nrec].cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1)
+    cig_h = job.cig_d.cpu().numpy().view(np.uint32)
+    names_s = [b"s%08d" % i for i in range(nchk)]
+    if pe:
+        mine = set(mapper.sam_lines_pe(ix, names_s, names_s, host[0][:nchk], host[1][:nchk], host[2][:nchk], host[3][:nchk], L, res_h, cig_h))
+    else:
+        mine = set(mapper.sam_lines_se(ix, names_s, host[0][:nchk], host[1][:nchk], L, res_h, cig_h))
+    with open(ref_sam) as f:
+        theirs = set(x for x in f if not x.startswith("@") and int(x[1:x.index("\t")]) < nchk)
+    return mine == theirs, len(theirs)
 
 
 # ---- roofline accounting --------------------------------------------------------------------------------------------------------
@@ -563,7 +581,7 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
             "ms_per_launch": round(dt / total * 1e3, 3)}
 
 
-def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3, trimmed=False, grch38_like=False):
+def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3, trimmed=False, grch38_like=False, ref_check=0):
     """a short secondary measurement on its own index / mapper: -> dict(value, ms_per_launch, ...)"""
     import torch
     from bitmapperbs_amd import mapper
@@ -583,6 +601,22 @@ def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", r
                "ms_per_launch": round(dt / (steps * passes * len(job.batches)) * 1e3, 3),
                "top_kernels_ms": {k_: round(v, 3) for v, k_ in top},
                "mapstats": {"unique_pct": round(100.0 * float(st[1]) / max(1.0, float(st[0])), 2), "ambiguous_pct": round(100.0 * float(st[2]) / max(1.0, float(st[0])), 2)}}
+        if ref_check and not args.no_cpu:
+            # the reference binary on the first ref_check reads / pairs of this key's first launch: the same SAM lines?
+            try:
+                L = cfg["read_len"]
+                host = [x[:ref_check].cpu().numpy() for x in job.batches[0]]
+                cb, ref_sam = cpu_baseline(args, cfg, fa, host, L, tag="chk_sample")
+                if ref_sam:
+                    same, nl = sam_identity(ix, m, job, host, L, cfg["pe"], ref_sam, ref_check)
+                    out["sample_sam_identical_to_reference"] = same
+                    out["sample_sam_lines_compared"] = nl
+                    out["reference_on_the_sample"] = cb
+                for f_ in ("chk_sample.sam", "chk_sample_1.fq", "chk_sample_2.fq", "chk_sample.fq"):
+                    if os.path.exists(os.path.join(args.workdir, f_)):
+                        os.unlink(os.path.join(args.workdir, f_))
+            except Exception as ex:
+                out["sample_sam_identical_to_reference"] = "error: %r" % (ex,)
         m.close(); ix.close()
         del job
         torch.cuda.empty_cache()
@@ -595,7 +629,7 @@ def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", r
                 os.environ[k_] = v_
 
 
-def host_buffer_rate(m, job, torch):
+def host_buffer_rate(m, job, torch, jobs_per_read=0.0):
     """PCIe-inclusive rate through the host-pointer entry point (bmbs_map_se / bmbs_map_pe): page-locked host buffers in, records
     and CIGAR pool back out, copy-in -> kernels -> copy-out serialised on one context (never `value`)."""
     import ctypes as C
@@ -629,14 +663,18 @@ def host_buffer_rate(m, job, torch):
     for p_ in pin + [res, pool]:
         lib.bmbs_host_free(p_)
     up = nbytes * len(pin) * reps
-    down = nrec * 32 * reps + int(used.value) * 4 * reps
+    # what the library copies back: a 32-byte record per read and the CIGAR slots of the DP jobs a chunk produced (max_ops x 4 bytes
+    # per job; `used` is the EXTENT of the host pool that was written to, not the bytes moved)
+    down = nrec * 32 * reps + int(jobs_per_read * nrec) * job.max_ops * 4 * reps
     LINK = 56.0           # GB/s one direction, page-locked, measured on these boxes (tools/pcie_probe; PCIe Gen5 x16 spec 63)
     return {"what": "bmbs_map_%s on page-locked HOST buffers, %d %s per call: the call is cut into chunks of n/8 (250 k .. 500 k) units dealt to the context's lanes, "
                     "uploads, kernels and downloads of different chunks overlap (copies on streams that carry no kernel); PCIe-inclusive, never `value`" % (
                 "pe" if job.cfg["pe"] else "se", n, "pairs" if job.cfg["pe"] else "reads"),
             "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s",
             "bytes_up_per_read": round(up / (nrec * reps), 1), "bytes_down_per_read": round(down / (nrec * reps), 1),
-            "upload_GBps": round(up / dt / 1e9, 1), "link_GBps_one_direction": LINK, "frac_of_link": round(up / dt / 1e9 / LINK, 3)}
+            "host_cigar_pool_extent_per_read": round(int(used.value) * 4 / nrec, 1),
+            "upload_GBps": round(up / dt / 1e9, 1), "download_GBps": round(down / dt / 1e9, 1), "link_GBps_one_direction": LINK,
+            "frac_of_link": round(up / dt / 1e9 / LINK, 3)}
 
 
 def write_bgzf(path, data, level=1, threads=16):
@@ -916,22 +954,17 @@ def main():
             if ref_sam:
                 # the GPU records of the same sample print the same SAM lines as the reference
                 nchk = min(ns, 100_000 if pe else 200_000)
-                job.launch(0); m.sync()
-                nrec = nchk * (2 if pe else 1)
-                res_h = job.res_d[:nrec].cpu().numpy().view(capi.RESULT_DTYPE).reshape(-1)
-                cig_h = job.cig_d.cpu().numpy().view(np.uint32)
-                names_s = [b"s%08d" % i for i in range(nchk)]
-                if pe:
-                    mine = set(mapper.sam_lines_pe(ix, names_s, names_s, host[0][:nchk], host[1][:nchk], host[2][:nchk], host[3][:nchk], L, res_h, cig_h))
-                else:
-                    mine = set(mapper.sam_lines_se(ix, names_s, host[0][:nchk], host[1][:nchk], L, res_h, cig_h))
-                with open(ref_sam) as f:
-                    theirs = set(x for x in f if not x.startswith("@") and int(x[1:x.index("\t")]) < nchk)
-                out["sample_sam_identical_to_reference"] = (mine == theirs)
-                out["sample_sam_lines_compared"] = len(theirs)
+                same, nl = sam_identity(ix, m, job, host, L, pe, ref_sam, nchk)
+                out["sample_sam_identical_to_reference"] = same
+                out["sample_sam_lines_compared"] = nl
             if not args.no_secondary:
                 try:
-                    out["e2e"] = {"host_buffers_overlapped": host_buffer_rate(m, job, torch)}
+                    hb = host_buffer_rate(m, job, torch, jobs_per_read=float(cnt.get("n_jobs", 0)) / max(1, nr))
+                    out["e2e"] = {"host_buffers_overlapped": hb}
+                    # SURVEY 8(d) defines the metric "incl. H2D/D2H": the same mapping with inputs and results in HOST memory
+                    out["value_incl_pcie"] = {"value": hb["value"], "unit": "Mreads/s", "frac_of_link": hb["frac_of_link"],
+                                              "bytes_up_per_read": hb["bytes_up_per_read"], "bytes_down_per_read": hb["bytes_down_per_read"],
+                                              "what": "bmbs_map_pe / bmbs_map_se on page-locked host buffers (e2e.host_buffers_overlapped); `value` is the device-resident rate the roofline describes"}
                 except Exception as ex:
                     out["e2e"] = {"error": repr(ex)}
                 try:
@@ -966,7 +999,7 @@ def main():
                 if cfg["genome"] >= 1_000_000_000:
                     sec["grch38_like"] = secondary(args, "main configuration on a genome of the same size with GRCh38-like repeat content: ~45 % of the bases from nine "
                                                    "families (Alu / MIR / L1 / LTR / DNA-transposon-like interspersed copies at 1-30 % divergence, segmental "
-                                                   "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True)
+                                                   "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True, ref_check=100_000)
                     sec["grch38_like_se"] = secondary(args, "the same GRCh38-like genome, mate 1 alone as 150 bp single-end reads, -e 0.08 (every candidate of a "
                                                       "single-end read is verified -- no mate prunes the list first)", dict(one, pe=False), rank, local, grch38_like=True)
                     sec["grch38_like_sensitive"] = secondary(args, "the same GRCh38-like genome, pairs in --sensitive mode (configs[3]'s launch size: 5 M pairs)",

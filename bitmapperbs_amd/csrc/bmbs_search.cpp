@@ -275,8 +275,11 @@ struct Source {
                 live_inflaters = n_inflaters;                   // (the threads count it down as they finish: not the loop bound)
                 for (int t = 0; t < n_inflaters; t++)
                     inflaters.emplace_back([this] {
-                        z_stream zs; memset(&zs, 0, sizeof zs);
-                        inflateInit2(&zs, -15);
+                        // every block is a gzip member of its own: the driver's own inflater (pgz.h) on known bytes -- no window in
+                        // front of a block, no markers -- and the member's CRC-32 checked by carry-less multiplication
+                        pgz::OutBuf<pgz::u8> ob;
+                        std::unique_ptr<pgz::Tables> dyn(new pgz::Tables);
+                        std::vector<pgz::MemberEnd> ends;
                         for (;;) {
                             // a job = the blocks of the next ~2 MiB of the compressed file
                             size_t a, e; long id;
@@ -306,11 +309,12 @@ struct Source {
                                     const size_t bs = bgzf_block(zmap + q, zsize - q);
                                     const size_t isz = bgzf_isize(zmap + q, bs);
                                     if (isz) {
-                                        inflateReset(&zs);
-                                        zs.next_in = (Bytef*)(zmap + q + 18); zs.avail_in = (uInt)(bs - 26);
-                                        zs.next_out = (Bytef*)(out.data() + at); zs.avail_out = (uInt)isz;
-                                        const int rc = inflate(&zs, Z_FINISH);
-                                        if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+                                        if (!ob.mem) { if (!ob.reserve(70000)) throw std::bad_alloc(); memset(ob.mem, 0, pgz::WIN); }
+                                        ob.n = 0; ends.clear();
+                                        const pgz::DecodeResult r = pgz::decode_blocks<pgz::u8>(zmap, q + bs, (pgz::u64)(q + 18) * 8, ~(pgz::u64)0, ob, ends, *dyn);
+                                        if (r.st != pgz::ST_END || ob.n != isz || ends.size() != 1 || ends[0].isize != (pgz::u32)isz ||
+                                            ends[0].crc != pgz::crc32_fast(0, ob.out(), isz)) bad = true;
+                                        else memcpy(out.data() + at, ob.out(), isz);
                                     }
                                     at += isz; q += bs;
                                 }
@@ -318,7 +322,6 @@ struct Source {
                             if (bad) { std::lock_guard<std::mutex> l(m); err = "corrupt BGZF block in the .gz input"; znext = zsize; break; }
                             push_chunk(id, std::move(out));
                         }
-                        inflateEnd(&zs);
                         inflater_exit();
                     });
                 return true;
