@@ -141,7 +141,7 @@ struct Lane {
     DevIndex ix;
     u64 rows = 0;
     // index buffers
-    DevBuf occ, hash, sa, gen2, chrom_start, t20;
+    DevBuf occ, hash, sa, gen2, chrom_start, t20, occ3, c3;
     // LUTs
     DevBuf pen_lut, mapq_lut;
     bool luts_ready = false;
@@ -873,7 +873,7 @@ void lane_destroy(Lane* c)
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wavelog), &d, sizeof(d));
         release(c->wavelog_buf); release(c->wavelog_count);
     }
-    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
+    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->occ3, &c->c3, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
@@ -1036,6 +1036,39 @@ static int lane_index_attach(Lane* c, const bmbs_index_view* v)
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { c->err = std::string("index re-pack: ") + hipGetErrorString(e); return BMBS_ENODEV; }
+    // trigram rank table: three backward extensions per gather pair (bmbs_dev.h: occ3).  4.5 bytes per row; built from the full SA and
+    // the 2-bit text, checked against three single steps on a million rows before it is used.  BMBS_KGRAM=0: off
+    ix.occ3 = nullptr; ix.c3 = nullptr; ix.nb3 = 0;
+    {
+        const char* kg_env = getenv("BMBS_KGRAM");
+        const u64 nb = rows / 96 + 2;
+        const u64 need = 27 * nb * 16;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        if (!(kg_env && !strcmp(kg_env, "0")) && free_b > need + (40ull << 30) && ensure(c, c->occ3, need) == BMBS_OK && ensure(c, c->c3, 64 * 8) == BMBS_OK) {
+            DevBuf sums;
+            const u64 n_chunks = (nb + OCC3_CHUNK - 1) / OCC3_CHUNK;
+            if (ensure(c, sums, 27 * n_chunks * 8 + 64) == BMBS_OK) {
+                u32* flag = c->c3.as<u32>() + 2 * 60;                              // two spare words behind the 27 entries: overflow, mismatches
+                (void)hipMemsetAsync(c->c3.p, 0, 64 * 8, c->stream);
+                hipLaunchKernelGGL(k_occ3_planes, dim3(8192), dim3(256), 0, c->stream, ix, rows, nb, c->occ3.as<uint4>());
+                hipLaunchKernelGGL(k_occ3_chunk_sums, dim3(nblk(27 * n_chunks, 256)), dim3(256), 0, c->stream, c->occ3.as<uint4>(), nb, n_chunks, sums.as<u64>());
+                hipLaunchKernelGGL(k_occ3_chunk_scan, dim3(1), dim3(64), 0, c->stream, sums.as<u64>(), n_chunks, flag);
+                hipLaunchKernelGGL(k_occ3_apply, dim3(nblk(27 * n_chunks, 256)), dim3(256), 0, c->stream, c->occ3.as<uint4>(), nb, n_chunks, sums.as<u64>());
+                hipLaunchKernelGGL(k_occ3_c3, dim3(1), dim3(64), 0, c->stream, ix, c->c3.as<u64>());
+                DevIndex probe = ix;
+                probe.occ3 = c->occ3.as<uint4>(); probe.c3 = c->c3.as<u64>(); probe.nb3 = nb;
+                const u64 n_check = 1u << 20;
+                hipLaunchKernelGGL(k_occ3_check, dim3(nblk(n_check, 256)), dim3(256), 0, c->stream, probe, rows, n_check, flag + 1);
+                u32 h[2] = {1, 1};
+                if (hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess && h[0] == 0 && h[1] == 0) {
+                    ix.occ3 = probe.occ3; ix.c3 = probe.c3; ix.nb3 = nb;
+                } else if (h[1] != 0 && getenv("BMBS_VERBOSE")) fprintf(stderr, "[bmbs] trigram table failed its check (%u differences): not used\n", h[1]);
+                release(sums);
+            }
+            if (!ix.occ3) { release(c->occ3); }
+        }
+    }
     c->ix = ix; c->rows = rows; c->attached = true;
     return BMBS_OK;
 }

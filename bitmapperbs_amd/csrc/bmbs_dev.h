@@ -39,6 +39,13 @@ struct DevIndex {
     const u64*   gen2;
     const u64*   t20;           // optional: outcome of the first t_e extensions of every (16 + t_e)-mer (k_build_t20), else nullptr
     int          t_e;           // letters the table looks ahead: 4 (3^20 entries, 27.9 GB) or 5 (3^21 entries, 83.7 GB; GRCh38-size texts)
+    // three backward extensions in one step (round 4): occ3[g * nb3 + row / 96] = { rows before the block whose three preceding text
+    // letters are the trigram g, one bit per row of the block for "this row's are" }, g = d1 + 3 d2 + 9 d3 in extension order;
+    // c3[g] = first row of the suffixes that begin with the trigram.  LF_d3(LF_d2(LF_d1(row))) = c3[g] + rank_g(row): one 16-byte
+    // gather per interval end for three letters.  27 x 16 B per 96 rows = 4.5 B per row (27.9 GB at GRCh38 size); nullptr: off
+    const uint4* occ3;
+    const u64*   c3;
+    u64          nb3;
     const u64*   chrom_start;   // n_chrom+1 cumulative starts (single strand)
     u64 G;                      // one-strand length
     u64 total;                  // 2G = total_SA_length

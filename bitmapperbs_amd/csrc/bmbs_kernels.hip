@@ -108,6 +108,34 @@ DEVI void lf_pair(const DevIndex& ix, u64& top, u64& bot, int c)
     top = ix.C[c] + ct; bot = ix.C[c] + cb;
 }
 
+// ---- three letters per step (DevIndex::occ3) ------------------------------------------------------------------------------------
+DEVI u32 occ3_in_block(const uint4& h, u32 r)        // rows 0 .. r-1 of the block that carry the trigram
+{
+    const u32 m0 = r >= 32 ? ~0u : ((1u << r) - 1u);
+    const u32 m1 = r >= 64 ? ~0u : (r > 32 ? ((1u << (r - 32)) - 1u) : 0u);
+    const u32 m2 = r > 64 ? ((1u << (r - 64)) - 1u) : 0u;
+    return h.x + __popc(h.y & m0) + __popc(h.z & m1) + __popc(h.w & m2);
+}
+// both ends of an interval through the trigram g: c3g + rank_g(row) (c3g = c3[g], from the block's LDS copy)
+DEVI void lf3_pair(const DevIndex& ix, int g, u64 c3g, u64& top, u64& bot)
+{
+    const u64 bt = top / 96, bb = bot / 96;
+    const uint4* base = ix.occ3 + (u64)g * ix.nb3;
+    const uint4 ht = base[bt];
+    uint4 hb = ht;
+    if (bb != bt) hb = base[bb];
+    top = c3g + occ3_in_block(ht, (u32)(top - bt * 96));
+    bot = c3g + occ3_in_block(hb, (u32)(bot - bb * 96));
+}
+// the block's copy of c3 (27 words of LDS): a per-lane load from global memory would be one more request per step
+DEVI const u64* kgram_c3(const DevIndex& ix, u64* lds)
+{
+    if (!ix.occ3) return nullptr;
+    if (threadIdx.x < 27) lds[threadIdx.x] = ix.c3[threadIdx.x];
+    __syncthreads();
+    return lds;
+}
+
 // BWT symbol of a row (access_bwt_delta, bwt.h:2413-2447); only used while expanding the SA
 DEVI int bwt_sym(const DevIndex& ix, u64 row)
 {
@@ -676,6 +704,97 @@ __global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out, u64*
   }
 }
 
+// ---- the trigram rank table (DevIndex::occ3) ---------------------------------------------------------------------------------------------
+// trigram of a row = the three text letters in front of its suffix in extension order (index alphabet G0 T1 A2, C folded into T);
+// 27 = none (the suffix starts less than three letters into the text)
+DEVI int row_trigram(const DevIndex& ix, u64 row)
+{
+    const u64 p = sa_at(ix, row);
+    if (p < 3) return 27;
+    const u64 q = p - 3;
+    const int sh = 2 * (int)(q & 31);
+    u64 w = ix.gen2[q >> 5] >> sh;
+    if (sh > 58) w |= ix.gen2[(q >> 5) + 1] << (64 - sh);
+    const int b3 = (int)(w & 3), b2 = (int)((w >> 2) & 3), b1 = (int)((w >> 4) & 3);            // text[p-3], [p-2], [p-1]
+    return ((0x46 >> (2 * b1)) & 3) + 3 * ((0x46 >> (2 * b2)) & 3) + 9 * ((0x46 >> (2 * b3)) & 3);
+}
+// one wave per block of 96 rows: the 27 bit planes by ballots, lane g keeps and stores trigram g's; .x = rows of the block that carry it
+__global__ void __launch_bounds__(256)
+k_occ3_planes(DevIndex ix, u64 rows, u64 nb, uint4* __restrict__ out)
+{
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (u64 blk = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; blk < nb; blk += n_waves) {
+        int gA = 27, gB = 27;
+        u64 r = blk * 96 + (u64)lane;
+        if (r < rows) gA = row_trigram(ix, r);
+        r += 64;
+        if (lane < 32 && r < rows) gB = row_trigram(ix, r);
+        u32 w0 = 0, w1 = 0, w2 = 0;
+        for (int g = 0; g < 27; g++) {
+            const unsigned long long mA = __ballot(gA == g), mB = __ballot(gB == g);
+            if (lane == g) { w0 = (u32)mA; w1 = (u32)(mA >> 32); w2 = (u32)mB; }
+        }
+        if (lane < 27) out[(u64)lane * nb + blk] = make_uint4((u32)(__popc(w0) + __popc(w1) + __popc(w2)), w0, w1, w2);
+    }
+}
+// .x of every block -> rows before the block: sums of chunks of OCC3_CHUNK blocks, a scan of the chunk sums by one thread per
+// trigram, then the running count inside every chunk.  A trigram whose total does not fit 32 bits raises *overflow (the table is
+// then not used: counts are 32-bit)
+#define OCC3_CHUNK 512
+__global__ void __launch_bounds__(256)
+k_occ3_chunk_sums(const uint4* __restrict__ t, u64 nb, u64 n_chunks, u64* __restrict__ sums)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 27 * n_chunks) return;
+    const u64 g = i / n_chunks, c = i - g * n_chunks;
+    const u64 a = c * OCC3_CHUNK, e = a + OCC3_CHUNK < nb ? a + OCC3_CHUNK : nb;
+    u64 s = 0;
+    for (u64 b = a; b < e; b++) s += t[g * nb + b].x;
+    sums[i] = s;
+}
+__global__ void k_occ3_chunk_scan(u64* __restrict__ sums, u64 n_chunks, u32* __restrict__ overflow)
+{
+    const int g = threadIdx.x;
+    if (g >= 27) return;
+    u64 run = 0;
+    for (u64 c = 0; c < n_chunks; c++) { const u64 v = sums[(u64)g * n_chunks + c]; sums[(u64)g * n_chunks + c] = run; run += v; }
+    if (run >= (1ull << 32)) *overflow = 1;
+}
+__global__ void __launch_bounds__(256)
+k_occ3_apply(uint4* __restrict__ t, u64 nb, u64 n_chunks, const u64* __restrict__ sums)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 27 * n_chunks) return;
+    const u64 g = i / n_chunks, c = i - g * n_chunks;
+    const u64 a = c * OCC3_CHUNK, e = a + OCC3_CHUNK < nb ? a + OCC3_CHUNK : nb;
+    u64 run = sums[i];
+    for (u64 b = a; b < e; b++) { const u32 v = t[g * nb + b].x; t[g * nb + b].x = (u32)run; run += v; }
+}
+// c3[g] = LF_d3(LF_d2(LF_d1(0))): the first row of the suffixes that begin with the trigram (letters in text order d3 d2 d1)
+__global__ void k_occ3_c3(DevIndex ix, u64* __restrict__ c3)
+{
+    const int g = threadIdx.x;
+    if (g >= 27) return;
+    const int d1 = g % 3, d2 = (g / 3) % 3, d3 = g / 9;
+    c3[g] = lf_step(ix, lf_step(ix, lf_step(ix, 0, d1), d2), d3);
+}
+// the table against three single steps on pseudo-random rows: *bad counts the differences (attach refuses the table if any)
+__global__ void __launch_bounds__(256)
+k_occ3_check(DevIndex ix, u64 rows, u64 n, u32* __restrict__ bad)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 row = i < 200 ? (i < 100 ? i : rows - (i - 100)) : (i * 0x9E3779B97F4A7C15ull >> 11) % (rows + 1);
+    const int g = (int)(i % 27);
+    const int d1 = g % 3, d2 = (g / 3) % 3, d3 = g / 9;
+    const u64 want = lf_step(ix, lf_step(ix, lf_step(ix, row, d1), d2), d3);
+    u64 t = row, b = row;
+    lf3_pair(ix, g, ix.c3[g], t, b);
+    if (t != want) atomicAdd(bad, 1u);
+}
+
+
 // ================================================================================================
 // scan (exclusive, u32 -> u64), two launches: tile sums, then every tile adds up the sums before it (L2 hits) and writes its part
 // ================================================================================================
@@ -912,7 +1031,7 @@ DEVI bool search_step(const DevIndex& ix, const char* rd, int L, Search& S, Seed
 }
 
 // ---- the same two functions over a packed row (PackedRows) ----------------------------------------------------------------
-struct SearchP { u64 top, bot, ptop, pbot; int s, steps, tm; PCur cur; };
+struct SearchP { u64 top, bot, ptop, pbot; int s, steps, tm, kg; PCur cur; };      // kg: steps in a row that kept most of the interval (< 0: three-letter steps are off for this seed)
 
 // four 2-bit digits (d0 in bits 0-1) -> d0 + 3 d1 + 9 d2 + 27 d3
 DEVI u32 base3_of4x2(u32 v8)
@@ -938,7 +1057,7 @@ DEVI bool search_begin_p(const DevIndex& ix, const u64* row, int W, bool dirty, 
     const u32 d32 = (u32)D;
     const u64 key = base3_of4x2(d32 & 0xffu) + 81u * base3_of4x2((d32 >> 8) & 0xffu) + 6561u * base3_of4x2((d32 >> 16) & 0xffu) +
                     531441u * base3_of4x2(d32 >> 24);
-    S.steps = len - 16; S.tm = tm;
+    S.steps = len - 16; S.tm = tm; S.kg = 0;
     S.cur.row = row; S.cur.W = W; S.cur.dirty = dirty;
     const int E = ix.t_e;
     if ((!FIXED || LOCATED) && ix.t20 && len >= 16 + E) {
@@ -978,32 +1097,54 @@ DEVI bool search_begin_p(const DevIndex& ix, const u64* row, int W, bool dirty, 
     return true;
 }
 
+// Three letters at once (lf3_pair) while the interval shrinks slowly -- a read inside a repeat family walks the index for most of
+// its length with hundreds of rows, one dependent gather pair per letter.  Exact by construction: a jump is TAKEN only when the
+// interval behind it still has two rows or more, so none of the reference's stop conditions (one row left, letter absent, letter
+// outside the alphabet -- bwt.h:2081-2209, 1848-1952) fell inside it; otherwise it is dropped, the three letters are stepped one by
+// one as before, and the seed makes no further attempt.  Counted as three extensions (the reference's events).
 template <bool FIXED>
-DEVI bool search_step_p(const DevIndex& ix, int L, SearchP& S, SeedHit& out, u32& n_ext)
+DEVI bool search_step_p(const DevIndex& ix, int L, SearchP& S, SeedHit& out, u32& n_ext, const u64* c3 = nullptr, u32* n_jump = nullptr)
 {
     const int len = L - S.tm;
     if (!FIXED) {
         S.ptop = S.top; S.pbot = S.bot;
         if (S.bot - S.top == 1) { out.ml = 16 + S.s; out.sp = S.top; out.hits = 1; return true; }
-        const int d = S.cur.next3();
+    } else out.ml = (u64)len;
+    const u64 before = S.bot - S.top;
+    if (c3 && S.kg >= (before >= 8 ? 1 : 2) && S.steps - S.s >= 3 && S.cur.have >= 3 && before >= 2) {
+        const u32 b6 = (u32)S.cur.buf & 63u;
+        bool clean = true;                                 // none of the three letters outside ACGT (their mask bits inside one word)
+        if (S.cur.dirty) { const int o = S.cur.pos & 63; clean = o <= 61 && ((S.cur.row[S.cur.W + (S.cur.pos >> 6)] >> o) & 7ull) == 0; }
+        if (clean) {
+            const int g = ((0x46 >> (2 * (b6 & 3u))) & 3) + 3 * ((0x46 >> (2 * ((b6 >> 2) & 3u))) & 3) + 9 * ((0x46 >> (2 * (b6 >> 4))) & 3);
+            u64 t2 = S.top, b2 = S.bot;
+            lf3_pair(ix, g, c3[g], t2, b2);
+            if (b2 > t2 && b2 - t2 >= 2) {
+                S.top = t2; S.bot = b2; S.s += 3; n_ext += 3;
+                if (n_jump) (*n_jump)++;
+                S.cur.buf >>= 6; S.cur.have -= 3; S.cur.pos += 3;
+                if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
+                return false;
+            }
+            S.kg = -(1 << 20);
+        }
+    }
+    const int d = S.cur.next3();
+    if (!FIXED) {
         if (d > 2) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
         lf_pair(ix, S.top, S.bot, d);
         n_ext++;
         if (S.bot <= S.top) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
-        S.s++;
-        if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
-        return false;
     } else {
-        out.ml = (u64)len;
-        const int d = S.cur.next3();
         if (d > 2) { out.hits = 0; out.sp = 0; return true; }
         lf_pair(ix, S.top, S.bot, d);
         n_ext++;
-        if (S.bot <= S.top) { out.hits = 0; out.sp = S.top; return true; }
-        S.s++;
-        if (S.s == S.steps) { out.sp = S.top; out.hits = S.bot - S.top; return true; }
-        return false;
+        if (S.bot <= S.top) { out.hits = 0; out.sp = S.top; return true; }      // the remaining iterations only break
     }
+    S.kg = 2 * (S.bot - S.top) > before ? S.kg + 1 : (S.kg < 0 ? S.kg : 0);
+    S.s++;
+    if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
+    return false;
 }
 
 // does read[q0 .. L) equal the text at doubled coordinate site0 + (q - tm) in the index alphabet?  (k_seed_second's single-row
@@ -1088,15 +1229,16 @@ DEVI long seed_chunk(long total, int target_waves)
     return c < SEED_CHUNK_MIN ? SEED_CHUNK_MIN : (c > SEED_CHUNK ? SEED_CHUNK : c);
 }
 
-struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung; };
+struct LaneCounters { u32 n_hash, n_ext, n_sa, n_ung, n_jump; };      // n_jump: three-letter steps taken (each also counts three in n_ext)
 // totals in counters[0,1,2,5]; per-kernel copies in counters[16 + 4*kid ..] (kid 0 first, 1 second, 2 extra)
 DEVI void flush_counters(unsigned long long* counters, const LaneCounters& c, int kid)
 {
     // 64-thread blocks: one wave; reduce with shuffles, one atomic per wave and counter
-    u32 a = c.n_hash, b = c.n_ext, d = c.n_sa, e = c.n_ung;
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); e += __shfl_down(e, o); }
+    u32 a = c.n_hash, b = c.n_ext, d = c.n_sa, e = c.n_ung, j = c.n_jump;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); e += __shfl_down(e, o); j += __shfl_down(j, o); }
     if ((threadIdx.x & 63) == 0 && counters) {
         counters = SHARD(counters);
+        if (j) atomicAdd(&counters[8], (unsigned long long)j);
         unsigned long long* k = counters + 16 + 4 * kid;
         if (a) { atomicAdd(&counters[0], (unsigned long long)a); atomicAdd(&k[0], (unsigned long long)a); }
         if (b) { atomicAdd(&counters[1], (unsigned long long)b); atomicAdd(&k[1], (unsigned long long)b); }
@@ -1125,12 +1267,14 @@ __global__ void __launch_bounds__(64)
 k_seed_first(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, SeedCarry sc,
              unsigned long long* __restrict__ counters)
 {
+    __shared__ u64 s_c3[27];
+    const u64* c3 = kgram_c3(ix, s_c3);
     const WaveLogT wl_t = wavelog_begin();
     int L = gm.L;                                     // length of the lane's current read
     const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
     const long chunk_end = chunk_begin + SEED_CHUNK < n ? chunk_begin + SEED_CHUNK : n;
     long next = chunk_begin;
-    LaneCounters lc = {0, 0, 0, 0};
+    LaneCounters lc = {0, 0, 0, 0, 0};
     bool active = false;
     long r = 0;
     const char* rd = seq;
@@ -1165,7 +1309,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
 #endif
         if (active) {
             bool fin;
-            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
+            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
             if (fin) { active = false; pending = true; }
         }
     }
@@ -1480,10 +1624,12 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
+    __shared__ u64 s_c3[27];
+    const u64* c3 = kgram_c3(ix, s_c3);
     const WaveLogT wl_t = wavelog_begin();
     const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
-    LaneCounters lc = {0, 0, 0, 0};
+    LaneCounters lc = {0, 0, 0, 0, 0};
     bool active = false;
     long r = 0;
     const char* rd = seq;
@@ -1607,7 +1753,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
 #endif
         if (active) {
             bool fin;
-            if constexpr (PACKED) fin = search_step_p<true>(ix, L, S, h, lc.n_ext); else fin = search_step<true>(ix, rd, L, S, h, lc.n_ext);
+            if constexpr (PACKED) fin = search_step_p<true>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<true>(ix, rd, L, S, h, lc.n_ext);
             if (fin) { active = false; pending = true; }
             else if (S.bot - S.top == 1) { verify = true; active = false; pending = true; }
         }
@@ -1633,10 +1779,12 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
+    __shared__ u64 s_c3[27];
+    const u64* c3 = kgram_c3(ix, s_c3);
     const WaveLogT wl_t = wavelog_begin();
     const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
-    LaneCounters lc = {0, 0, 0, 0};
+    LaneCounters lc = {0, 0, 0, 0, 0};
     bool active = false, have = false;
     long r = 0;
     // A lane keeps its read for all the remaining seeds (about eight), and every seed start reads the row at a new offset.
@@ -1744,7 +1892,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
 #endif
         if (active) {
             bool fin;
-            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
+            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
             if (fin) { active = false; pending = true; seed_done = true; }
         }
     }
@@ -4834,8 +4982,10 @@ __global__ void __launch_bounds__(64)
 k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, const u64* __restrict__ count_ptr,
              const u32* __restrict__ plist, ReadState st, PeState ps, u32* __restrict__ rcnt, unsigned long long* __restrict__ counters)
 {
+    __shared__ u64 s_c3[27];
+    const u64* c3 = kgram_c3(ix, s_c3);
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    LaneCounters lc = {0, 0, 0, 0};
+    LaneCounters lc = {0, 0, 0, 0, 0};
     if (it < (long)*count_ptr) {
         const long p = plist[it];
         const long r = p + (long)(1 - ps.first[p]) * n;
@@ -4871,7 +5021,7 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
             const int tm = rs[seed_id], ml = rl[seed_id];
             if constexpr (PACKED) {
                 if (search_begin_p<true>(ix, prow, pr.W, dirty, tm + ml, tm, S, h, lc.n_hash))
-                    while (!search_step_p<true>(ix, tm + ml, S, h, lc.n_ext)) {}
+                    while (!search_step_p<true>(ix, tm + ml, S, h, lc.n_ext, c3, &lc.n_jump)) {}
             } else {
                 if (search_begin<true>(ix, rd, tm + ml, tm, S, h, lc.n_hash))
                     while (!search_step<true>(ix, rd, tm + ml, S, h, lc.n_ext)) {}
@@ -4885,7 +5035,7 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
         while (seed_id < max_seed && tm < L) {
             if constexpr (PACKED) {
                 if (search_begin_p<false>(ix, prow, pr.W, dirty, L, tm, S, h, lc.n_hash))
-                    while (!search_step_p<false>(ix, L, S, h, lc.n_ext)) {}
+                    while (!search_step_p<false>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump)) {}
             } else {
                 if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash))
                     while (!search_step<false>(ix, rd, L, S, h, lc.n_ext)) {}

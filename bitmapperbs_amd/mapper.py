@@ -297,6 +297,7 @@ class Mapper:
         self._chk(self._lib.bmbs_counters_all(self._ctx, capi.ptr(c)))
         keys = ("n_hash", "n_ext", "n_sa", "n_filter", "n_sw", "n_ungapped", "n_cand_slots", "n_jobs")
         d = {k: int(v) for k, v in zip(keys, c[:8])}
+        d["n_jump"] = int(c[8])          # three-letter index steps taken (each counts three in n_ext)
         for kid, nm in enumerate(("k_seed_first", "k_seed_second", "k_seed_extra")):
             d[nm] = {"n_hash": int(c[16 + 4 * kid]), "n_ext": int(c[17 + 4 * kid]), "n_sa": int(c[18 + 4 * kid])}
         return d

@@ -739,6 +739,57 @@ def test_ab_switches_give_identical_records(knob, env, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["se", "pe", "pe_sensitive"])
+def test_three_letter_index_steps_change_nothing_but_the_gathers(tmp_path, monkeypatch, mode):
+    """the trigram rank table (DevIndex::occ3: three backward extensions per gather pair while an interval shrinks slowly) on a
+    genome whose reads walk the index for most of their length -- families of 40 .. 400 near-identical copies: records and
+    statistics equal the oracle's, the event counters (16-mer lookups, extensions -- the reference's events) equal those of
+    BMBS_KGRAM=0, and the steps were really taken"""
+    from bitmapperbs_amd import synth, mapper
+    names, chroms = synth.make_genome(1_200_000, 2, seed=91)
+    rng = np.random.default_rng(92)
+    for (elen, copies, div) in [(900, 400, 0.01), (2500, 60, 0.004), (400, 150, 0.03), (3000, 40, 0.0)]:
+        el = synth._ACGT[rng.integers(0, 4, elen)]
+        for _ in range(copies):
+            ch = chroms[rng.integers(0, len(chroms))]
+            p = int(rng.integers(0, ch.size - elen))
+            e = el.copy(); mm = rng.random(elen) < div
+            e[mm] = synth._ACGT[rng.integers(0, 4, int(mm.sum()))]
+            if rng.random() < 0.5: e = synth.revcomp(e)
+            ch[p:p + elen] = e
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, chroms)
+    mapper.Index.build(fa, fa, threads=8)
+    ix = mapper.Index(fa); oix = orc.OrcIndex(fa)
+    out = {}
+    for kg in ("1", "0"):
+        monkeypatch.setenv("BMBS_KGRAM", kg)
+        sens = 1 if mode == "pe_sensitive" else 0
+        m = mapper.Mapper(ix, 0, sensitive=sens)
+        if mode == "se":
+            r = synth.make_reads_se(chroms, n=20000, L=150, seed=5, sub=0.01, indel=0.001, qual="random", n_rate=0.001)
+            res, pool = m.map_se(r["seq"], r["qual"], 150)
+            if kg == "1":
+                recs, ost, _ = oix.map_se(orc.params(), r["seq"], r["qual"], 150)
+                assert not compare_records(res, pool, recs, 150)
+        else:
+            m1, m2 = synth.make_reads_pe(chroms, n=12000, L=150, seed=6, sub=0.04 if sens else 0.01, indel=0.001, qual="random")
+            res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+            if kg == "1":
+                recs, ost, _ = oix.map_pe(orc.params(sensitive=sens), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 150)
+                assert not compare_pe(res, pool, recs, 150)
+        if kg == "1":
+            assert (m.stats() == ost).all()
+        out[kg] = (res.tobytes(), pool.tobytes(), m.stats().tolist(), m.counters())
+        m.close()
+    a, b = out["1"], out["0"]
+    assert a[:3] == b[:3]
+    assert (a[3]["n_hash"], a[3]["n_ext"], a[3]["n_sa"]) == (b[3]["n_hash"], b[3]["n_ext"], b[3]["n_sa"])
+    assert b[3]["n_jump"] == 0 and a[3]["n_jump"] > 1000, a[3]
+    assert 3 * a[3]["n_jump"] < a[3]["n_ext"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sensitive,rows", [(0, "packed"), (1, "packed"), (0, "ascii"), (1, "ascii")])
 def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive, rows):
     """the 21-mer form of the outcome table (3^21 entries, 84 GB: what a GRCh38-size index gets) forced on the test genome: the
