@@ -807,9 +807,13 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         st = torch.tensor([rank + 1, 1, 0, 0, 0], dtype=torch.int64)
         dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+        every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, tt)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"metric": "dry-run", "n_gpus": dist.get_world_size(), "mapstats_sum": st.tolist()}), flush=True)
+            print(json.dumps({"metric": "dry-run", "n_gpus": dist.get_world_size(), "mapstats_sum": st.tolist(),
+                              "per_rank_s": [float(x.item()) for x in every]}), flush=True)
         dist.destroy_process_group()
         return
     if args.same_device:
@@ -866,9 +870,14 @@ def main():
                   "counters": m1.counters()}
         m1.close()
     tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    per_rank_s = [dt]
     if world > 1:
+        # every rank's own timed seconds (for the per-GPU table of BASELINE.md section 4), then the job's: the slowest rank's
+        every = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_s = [float(x.item()) for x in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)        # the only collective: 5 x int64 mapstats
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)        # the only collective on the data path's results: 5 x int64 mapstats
     dt = float(tt.item())
     stats = stats.cpu().numpy()
     cnt = m.counters()                                       # event counters of the LAST launch
@@ -940,6 +949,8 @@ def main():
                                      "over_algorithmic": (round((t[0] + t[1]) / s8d[PROF_NAME.get(kn, kn)], 2) if s8d.get(PROF_NAME.get(kn, kn)) else None)}
                                 for kn, t in sorted(pmc_table(tag).items()) if kn.startswith("k_")},
             "counters_last_launch": cnt,
+            # one entry per rank: what each GPU mapped per second over its own timed region (value = all reads / the slowest rank's time)
+            "per_rank_Mreads_s": [round(reads_per_step * args.steps / t_ / 1e6, 2) for t_ in per_rank_s],
             "mapstats": {"reads_or_pairs": int(stats[0]), "unique": int(stats[1]), "ambiguous": int(stats[2]),
                          "unmapped": int(stats[0] - stats[1] - stats[2]), "mapped_bases": int(stats[3]), "error_bases": int(stats[4])},
             "library": {"build_id": capi.build_id(), "sources_id": capi.sources_id(), "built_from_these_sources": capi.build_id() == capi.sources_id()},

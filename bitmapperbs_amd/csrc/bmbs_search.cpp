@@ -645,6 +645,8 @@ struct Part {                                    // one contiguous record range 
     Source s1, s2;
     int ofd = -1;
     size_t out_off = 0;
+    size_t alloc_end = 0;                        // the file's blocks are reserved up to here (fallocate ahead of the writers)
+    bool can_alloc = true;
     OrderedChan<Batch*> out_q;
     long next_seq = 0;
     std::thread reader, writer;
@@ -691,7 +693,7 @@ int main(int argc, char** argv)
     int device = 0, io_threads = 0, contexts = 4, parts = 1, reader_threads = 0;
     std::vector<int> devices;
     long batch = 500000;
-    bool verbose = false, unmapped_out = false, pbat = false, bam = false, print_parts = false;
+    bool verbose = false, unmapped_out = false, pbat = false, bam = false, print_parts = false, print_plan = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -727,6 +729,7 @@ int main(int argc, char** argv)
         else if (a == "--contexts") contexts = atoi(val());
         else if (a == "--batch") batch = atol(val());
         else if (a == "--out-parts") parts = atoi(val());
+        else if (a == "--print-plan") print_parts = print_plan = true;           // ... and how the parts are worked off: devices, contexts, workers (no GPU needed: tests)
         else if (a == "--print-parts") print_parts = true;                   // the record ranges --out-parts would use, then exit (no GPU needed: tests)
         else if (a == "--reader-threads") reader_threads = atoi(val());     // pread threads per part (default: -t / (2 x parts))
         else if (a == "--verbose") verbose = true;
@@ -800,6 +803,15 @@ int main(int argc, char** argv)
         std::vector<size_t> cut1, cut2;
         if (!compute_cuts(cut1, cut2)) { fprintf(stderr, "Cannot open the read file(s)\n"); return 1; }
         for (int p = 0; p <= live_parts; p++) printf("%d\t%zu\t%zu\n", p, cut1[(size_t)p], cut2[(size_t)p]);
+        if (print_plan) {
+            // record ranges of the input -> GPUs, index replicated, no exchange step, output concatenated in range order.
+            // Here a range is a part; its batches go to whichever context is free (one worker thread per context, `contexts` contexts
+            // on every listed device sharing that device's index copy) and come back in order through the part's own queue.
+            printf("plan\tdevices\t%zu\tcontexts_per_device\t%d\tworkers\t%zu\tparts\t%d\tbatches_in_flight\t%zu\tbatch\t%ld\n",
+                   devices.size(), contexts, devices.size() * (size_t)contexts, live_parts, (size_t)live_parts + devices.size() * (size_t)contexts + 2, batch);
+            for (size_t d = 0; d < devices.size(); d++) printf("device\t%d\tindex_copy\t1\tcontexts\t%d\n", devices[d], contexts);
+            printf("stats\tsum over %zu contexts (bmbs_stats_allreduce)\n", devices.size() * (size_t)contexts);
+        }
         return 0;
     }
     // the drivers' contexts run one batch at a time each: one lane per context is enough (BMBS_LANES is only read by bmbs_create)
@@ -1005,6 +1017,7 @@ int main(int argc, char** argv)
 
     // ---------------- stage W (one per part): the SAM text (or its BAM form) goes into the part's file, in order -----------------
     auto writer_fn = [&](Part* pt) {
+        Pool wpool(std::max(1, std::min(8, io_threads / (2 * live_parts))) - 1);       // slices of a batch written side by side
         for (;;) {
             const double tw0 = now();
             Batch* b = pt->out_q.get();
@@ -1014,12 +1027,25 @@ int main(int argc, char** argv)
             if (b->n && !failed && b->sam_bytes) {
                 const char* text = b->sam.p;
                 const size_t len = (size_t)b->sam_bytes;
-                size_t done = 0;
-                while (done < len) {
-                    const ssize_t w = pwrite(pt->ofd, text + done, len - done, (off_t)(pt->out_off + done));
-                    if (w <= 0) { fail(std::string("write error: ") + strerror(errno)); break; }
-                    done += (size_t)w;
+                // One buffered pwrite per batch extends the file under its inode lock at the speed of one memcpy (10 GB/s = 28 M SAM
+                // records/s on the MI355X boxes).  With the blocks reserved ahead (fallocate in 4 GiB steps, cut back to the true size
+                // at the end) several slices of a batch go into the page cache side by side: 17 GB/s (profiles/r02_write_probe.txt)
+                if (pt->can_alloc && pt->out_off + len > pt->alloc_end) {
+                    const size_t step = std::max<size_t>((size_t)4 << 30, 2 * len);
+                    if (fallocate(pt->ofd, 0, (off_t)pt->alloc_end, (off_t)(pt->out_off + len + step - pt->alloc_end)) == 0) pt->alloc_end = pt->out_off + len + step;
+                    else pt->can_alloc = false;                                     // not a regular file (/dev/null, a pipe), or a file system without it
                 }
+                const int T = pt->can_alloc ? wpool.size() : 1;
+                const size_t per = ((len + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+                wpool.run(T, [&](int t) {
+                    size_t done = std::min(len, per * (size_t)t);
+                    const size_t stop = std::min(len, done + per);
+                    while (done < stop) {
+                        const ssize_t w = pwrite(pt->ofd, text + done, stop - done, (off_t)(pt->out_off + done));
+                        if (w <= 0) { fail(std::string("write error: ") + strerror(errno)); break; }
+                        done += (size_t)w;
+                    }
+                });
                 pt->out_off += len;
             }
             pt->t_write += now() - t0;
@@ -1072,7 +1098,7 @@ int main(int argc, char** argv)
         lastp.out_off += 28;
     }
     const double t_joined = now();
-    for (int p = 0; p < parts; p++) { Part& pt = *P_[(size_t)p]; ::close(pt.ofd); if (p < live_parts) { pt.s1.close(); if (pe) pt.s2.close(); } }
+    for (int p = 0; p < parts; p++) { Part& pt = *P_[(size_t)p]; if (pt.alloc_end > pt.out_off && ftruncate(pt.ofd, (off_t)pt.out_off) != 0) failed = true; ::close(pt.ofd); if (p < live_parts) { pt.s1.close(); if (pe) pt.s2.close(); } }
     if (failed) { fprintf(stderr, "bmbs_search: failed\n"); return 1; }
     int64_t st[5];
     bmbs_stats_allreduce(ctxs.data(), (int)ctxs.size(), st);      // get_mapping_informations: the counters of every worker summed

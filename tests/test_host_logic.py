@@ -153,6 +153,7 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2
     assert d["mapstats_sum"][:2] == [3, 2]          # ranks contributed (rank + 1, 1): one all-reduce over both
+    assert d["per_rank_s"] == [1.0, 2.0]             # every rank's own timed seconds, gathered in rank order
 
 
 def test_bench_configs_match_baseline_json():
@@ -322,3 +323,34 @@ def test_parallel_gzip_reader_equals_zlib(tmp_path, span):
             assert p.returncode != 0 and p.stderr, name
         else:
             assert p.stdout == want
+
+
+def test_driver_plan_for_an_eight_gpu_node(tmp_path):
+    """bmbs_search --devices 0,..,7 --out-parts 8 --print-plan (no GPU touched): the input is cut into eight record ranges at record
+    starts (pairs: at the same record in both files), every device gets an index copy and `--contexts` contexts, one worker per
+    context takes batches of any range, and the statistics are the sum over all of them -- SURVEY section 8e's partition"""
+    import subprocess
+    from common import ROOT
+    drv = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
+    if not os.path.exists(drv):
+        pytest.skip("bmbs_search not built")
+    rng = np.random.default_rng(8)
+    n = 16000
+    names = [b"p%d" % i for i in range(n)]
+    f1 = str(tmp_path / "a_1.fq"); f2 = str(tmp_path / "a_2.fq")
+    l1 = rng.integers(50, 151, n); l2 = rng.integers(50, 151, n)
+    _fastq(f1, [x + b"/1" for x in names], l1, rng); _fastq(f2, [x + b"/2" for x in names], l2, rng)
+    p = subprocess.run([drv, "--search", "unused", "--print-plan", "--devices", "0,1,2,3,4,5,6,7", "--contexts", "3", "--out-parts", "8", "-t", "8",
+                        "--seq1", f1, "--seq2", f2], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    rows = [l.split("\t") for l in p.stdout.splitlines()]
+    cuts = [tuple(int(x) for x in r) for r in rows if r[0].isdigit()]
+    assert len(cuts) == 9 and cuts[0][1:] == (0, 0) and cuts[-1][1:] == (os.path.getsize(f1), os.path.getsize(f2))
+    t1 = open(f1, "rb").read(); t2 = open(f2, "rb").read()
+    recs = [t1[:c1].count(b"\n") // 4 for _, c1, _ in cuts]
+    assert recs == sorted(recs) and all(t2[:c2].count(b"\n") == 4 * r for (_, _, c2), r in zip(cuts, recs))
+    assert all(abs((b - a) - n / 8) < n / 16 for a, b in zip(recs, recs[1:]))                   # even ranges
+    plan = [r for r in rows if r[0] == "plan"][0]
+    kv = dict(zip(plan[1::2], plan[2::2]))
+    assert (kv["devices"], kv["contexts_per_device"], kv["workers"], kv["parts"]) == ("8", "3", "24", "8")
+    assert [r[1] for r in rows if r[0] == "device"] == [str(i) for i in range(8)]
