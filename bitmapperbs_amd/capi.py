@@ -22,7 +22,7 @@ SYMBOLS = [
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
-    "bmbs_max_cigar_ops", "bmbs_host_prefault", "bmbs_reserve", "bmbs_host_alloc_kind", "bmbs_retries", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset",
+    "bmbs_max_cigar_ops", "bmbs_host_prefault", "bmbs_reserve", "bmbs_host_alloc_kind", "bmbs_retries", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset", "bmbs_inflate_bgzf",
 ]
 
 
@@ -165,7 +165,7 @@ def lib() -> C.CDLL:
     return L
 
 
-LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_text.hip", "bmbs_bam.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
+LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_text.hip", "bmbs_bam.hip", "bmbs_inflate.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
             "../../include/bmbs.h")
 
 

@@ -1,0 +1,358 @@
+// bitmapperbs_amd/csrc/bmbs_inflate.hip -- bgzip'ed FASTQ inflated on the device (round 4).
+//
+// The reference reads .fastq.gz through zlib's gzread on its one reader thread (Process_Reads.cpp:1455-1514).  A BGZF file is a
+// series of independent gzip members of at most 64 KiB of text with their compressed size in the header: nothing in one block
+// depends on another, so a window of them is inflated here by one WAVE per block -- the host of an MI355X box (16 cores' worth of
+// CPU for the whole driver) inflates ~7 GB/s of text at best, a third of what the mapping path takes.
+//   lane 0 walks the Huffman codes (tables in LDS: 11-bit root for literals / lengths with two literals per entry where both codes
+//   fit, 10-bit root for distances; longer codes -- rare by construction -- by a canonical search), literals are staged in LDS and
+//   stored 64 lanes wide, matches are copied by the whole wave; the block's CRC-32 and ISIZE are checked against its trailer
+//   (segments combined with x^(8n) mod P as in bmbs_bam.hip).
+// Everything zlib's inflate refuses is refused (err[block] != 0): over-subscribed / incomplete codes, missing end-of-block code,
+// reserved block type, distance too far back, stored-length check, output longer than the trailer says, CRC mismatch.
+#ifndef BMBS_INFLATE_HIP
+#define BMBS_INFLATE_HIP
+
+#define INF_LIT_ROOT 11
+#define INF_DIST_ROOT 10
+#define INF_STAGE 256
+
+// entry = value << 16 | extra bits (or literal count) << 8 | kind << 5 | code bits
+#define IK_BAD 0
+#define IK_LIT 1
+#define IK_BASE 2
+#define IK_EOB 3
+#define IK_LONG 4            // a code longer than the root: canonical search
+
+__constant__ u16 c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ u8 c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ u16 c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ u8 c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+struct InfCode {             // canonical description of one Huffman code, in LDS
+    u16 count[16];           // codes per length
+    u16 first[16];           // first (MSB-first) code of each length
+    u16 offs[16];            // index of that code's symbol in `sorted`
+    u16* sorted;             // symbols by (length, symbol)
+};
+
+DEVI u32 inf_mk(u32 value, u32 extra, u32 kind, u32 bits) { return value << 16 | extra << 8 | kind << 5 | bits; }
+
+// lens[0, n) -> count / first / offs / sorted (all lanes; returns false on a set zlib refuses).  n <= 288.
+DEVI bool inf_canonical(const u8* lens, int n, InfCode& c, int lane)
+{
+    if (lane < 16) c.count[lane] = 0;
+    __syncthreads();
+    for (int s = lane; s < n; s += 64) if (lens[s]) atomicAdd(reinterpret_cast<u32*>(&c.count[lens[s] & ~1]), lens[s] & 1 ? 0x10000u : 1u);
+    __syncthreads();
+    // Kraft sum, first codes, offsets: 15 steps, every lane the same (LDS broadcast reads)
+    int left = 1, maxl = 0; u32 code = 0, off = 0;
+    bool over = false;
+    u32 firsts[16], offsv[16];
+    firsts[0] = 0; offsv[0] = 0;
+    for (int l = 1; l <= 15; l++) {
+        const int cn = c.count[l];
+        left = left * 2 - cn; if (left < 0) over = true;
+        if (cn) maxl = l;
+        code = (code + (l > 1 ? (u32)c.count[l - 1] : 0u)) << 1;
+        firsts[l] = code; offsv[l] = off; off += (u32)cn;
+    }
+    if (over) return false;
+    if (left > 0 && maxl > 1) return false;                      // incomplete: only "one code of one bit" / "no code" pass
+    if (lane < 16) { c.first[lane] = (u16)firsts[lane]; c.offs[lane] = (u16)offsv[lane]; }
+    // sorted: position of symbol s = offs[len] + symbols t < s of the same length
+    for (int s = lane; s < n; s += 64) {
+        const int l = lens[s];
+        if (!l) continue;
+        int r = 0;
+        for (int t = 0; t < s; t++) r += lens[t] == l;
+        c.sorted[offsv[l] + (u32)r] = (u16)s;
+    }
+    __syncthreads();
+    return true;
+}
+// the symbol whose code (of up to `maxbits` bits) starts the LSB-first bit string v: -> (symbol, length), length 0 = none
+DEVI int inf_search(const InfCode& c, u32 v, int from, int maxbits, int& len_out)
+{
+    u32 code = 0;
+    for (int l = 1; l <= maxbits; l++) {
+        code = (code << 1) | ((v >> (l - 1)) & 1u);
+        if (l < from) continue;
+        const u32 d = code - (u32)c.first[l];
+        if (code >= (u32)c.first[l] && d < (u32)c.count[l]) { len_out = l; return (int)c.sorted[(u32)c.offs[l] + d]; }
+    }
+    len_out = 0;
+    return -1;
+}
+// root table of a code: every lane fills its share of the indexes by a canonical search over the index's own bits
+DEVI void inf_root(const InfCode& c, bool dist, u32* tab, int root, int lane)
+{
+    const int n = 1 << root;
+    for (int i = lane; i < n; i += 64) {
+        int l; const int s = inf_search(c, (u32)i, 1, root, l);
+        u32 e;
+        if (s < 0) e = inf_mk(0, 0, IK_LONG, 0);                                  // (also covers "no code at all": the search fails again)
+        else if (dist) e = s < 30 ? inf_mk(c_dist_base[s], c_dist_extra[s], IK_BASE, (u32)l) : inf_mk(0, 0, IK_BAD, (u32)l);
+        else if (s < 256) e = inf_mk((u32)s, 1, IK_LIT, (u32)l);
+        else if (s == 256) e = inf_mk(0, 0, IK_EOB, (u32)l);
+        else e = s < 286 ? inf_mk(c_len_base[s - 257], c_len_extra[s - 257], IK_BASE, (u32)l) : inf_mk(0, 0, IK_BAD, (u32)l);
+        tab[i] = e;
+    }
+    __syncthreads();
+    if (!dist) {
+        // two literals per entry where both codes fit into the root index (read from the finished single-literal table, written to a
+        // register first: an entry's partner may be any other entry)
+        u32 mine[(1 << INF_LIT_ROOT) / 64];
+        for (int q = 0; q < n / 64; q++) {
+            const int i = lane + 64 * q;
+            u32 e1 = tab[i];
+            if (((e1 >> 5) & 7u) == IK_LIT && (int)(e1 & 31u) < root) {
+                const u32 e2 = tab[(u32)i >> (e1 & 31u)];
+                if (((e2 >> 5) & 7u) == IK_LIT && ((e2 >> 8) & 31u) == 1 && (e1 & 31u) + (e2 & 31u) <= (u32)root)
+                    e1 = inf_mk((e1 >> 16) | ((e2 >> 16) << 8), 2, IK_LIT, (e1 & 31u) + (e2 & 31u));
+            }
+            mine[q] = e1;
+        }
+        __syncthreads();
+        for (int q = 0; q < n / 64; q++) tab[lane + 64 * q] = mine[q];
+        __syncthreads();
+    }
+}
+
+struct InfBits {             // lane 0's bit reader over global memory: aligned 4-byte loads, 33 bits or more held after refill()
+    const u8* p; const u8* end; u64 buf; int cnt;
+    DEVI void init(const u8* b, const u8* e)
+    {
+        p = b; end = e; buf = 0; cnt = 0;
+        while (((size_t)p & 3) && cnt < 24) { buf |= (u64)*p++ << cnt; cnt += 8; }      // (bytes behind `end` belong to the buffer too: comp has slack)
+    }
+    DEVI void refill()
+    {
+        if (cnt <= 32) { buf |= (u64)*reinterpret_cast<const u32*>(p) << cnt; p += 4; cnt += 32; }
+    }
+    DEVI u32 peek(int n) const { return (u32)(buf & ((1ull << n) - 1)); }
+    DEVI void drop(int n) { buf >>= n; cnt -= n; }
+    DEVI u32 take(int n) { const u32 v = peek(n); drop(n); return v; }
+    DEVI const u8* at() const { return p - (cnt >> 3); }                       // the first byte that has not been consumed (cnt % 8 == 0)
+    DEVI bool over() const { return p - ((cnt + 7) >> 3) > end; }
+};
+
+// comp: the compressed bytes of n BGZF blocks, block b at comp + blk_off[b] (blk_off[n] = end); its text goes to text + out_off[b]
+// (out_off[b + 1] - out_off[b] = the ISIZE its trailer states).  err[b] = 0 when the block was well-formed and its CRC matched.
+__global__ void __launch_bounds__(64)
+k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, const u64* __restrict__ out_off, long n, char* __restrict__ text, u32* __restrict__ err)
+{
+    __shared__ u32 s_lit[1 << INF_LIT_ROOT];
+    __shared__ u32 s_dist[1 << INF_DIST_ROOT];
+    __shared__ u8 s_lens[320];
+    __shared__ u16 s_sorted_l[288]; __shared__ u16 s_sorted_d[32]; __shared__ u16 s_sorted_c[20];
+    __shared__ InfCode s_cl, s_cd, s_cc;
+    __shared__ u8 s_stage[INF_STAGE + 8];
+    __shared__ u32 s_crc_tab[256];
+    __shared__ u32 s_ev[8];                              // lane 0 -> wave: event, staged literals, match length, distance
+    const long b = blockIdx.x;
+    if (b >= n) return;
+    const int lane = threadIdx.x;
+    const u8* z = comp + blk_off[b];
+    const u64 zlen = blk_off[b + 1] - blk_off[b];
+    char* out = text + out_off[b];
+    const u32 isize = (u32)(out_off[b + 1] - out_off[b]);
+    u32 status = 0;                                       // 0 ok so far
+    // ---- gzip member header (BGZF: FEXTRA with the BC subfield; any other well-formed header is read too)
+    u32 body = 0;
+    if (zlen < 18 + 8 || z[0] != 0x1f || z[1] != 0x8b || z[2] != 8 || (z[3] & 0xe0)) status = 1;
+    else {
+        const int flg = z[3];
+        u64 q = 10;
+        if (flg & 4) { const u64 xl = (u64)z[q] | ((u64)z[q + 1] << 8); q += 2 + xl; }
+        if ((flg & 8) && q < zlen) { while (q < zlen && z[q]) q++; q++; }
+        if ((flg & 16) && q < zlen) { while (q < zlen && z[q]) q++; q++; }
+        if (flg & 2) q += 2;
+        if (q + 8 > zlen) status = 1;
+        body = (u32)q;
+    }
+    {
+        u32 c = (u32)lane;                                 // CRC table: four entries per lane
+        for (int t = 0; t < 4; t++) { u32 v = (u32)(lane + 64 * t); for (int k = 0; k < 8; k++) v = (v & 1) ? (v >> 1) ^ 0xedb88320u : v >> 1; s_crc_tab[lane + 64 * t] = v; }
+        (void)c;
+    }
+    s_cl.sorted = s_sorted_l; s_cd.sorted = s_sorted_d; s_cc.sorted = s_sorted_c;
+    __syncthreads();
+    InfBits in; in.init(z + body, z + zlen - 8);
+    u32 n_out = 0;                                        // bytes of text written so far (wave-uniform)
+    bool last = false;
+    while (!status && !last) {
+        // ---- block header (lane 0 reads, the wave follows)
+        u32 btype = 0;
+        if (lane == 0) { in.refill(); last = in.take(1) != 0; btype = in.take(2); }
+        last = __shfl((int)last, 0) != 0; btype = (u32)__shfl((int)btype, 0);
+        if (btype == 3) { status = 2; break; }
+        if (btype == 0) {
+            // stored: LEN, NLEN, bytes
+            u32 len = 0, bad = 0; u64 at = 0;
+            if (lane == 0) {
+                in.drop(in.cnt & 7); in.refill();
+                len = in.take(16); in.refill(); const u32 nlen = in.take(16);
+                bad = (len ^ 0xffffu) != nlen;
+                at = (u64)(in.at() - z);                              // byte position of the data
+            }
+            len = (u32)__shfl((int)len, 0); bad = (u32)__shfl((int)bad, 0);
+            at = ((u64)(u32)__shfl((int)(at >> 32), 0) << 32) | (u32)__shfl((int)at, 0);
+            if (bad || at + len > zlen - 8 || n_out + len > isize) { status = 3; break; }
+            for (u32 i = lane; i < len; i += 64) out[n_out + i] = (char)z[at + i];
+            n_out += len;
+            if (lane == 0) in.init(z + at + len, z + zlen - 8);
+            continue;
+        }
+        // ---- the two codes
+        bool ok = true;
+        if (btype == 1) {
+            for (int s = lane; s < 288; s += 64) s_lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 32) s_lens[288 + lane] = 5;
+            __syncthreads();
+            ok = inf_canonical(s_lens, 288, s_cl, lane) && inf_canonical(s_lens + 288, 32, s_cd, lane);
+        } else {
+            // dynamic: HLIT, HDIST, HCLEN, the code-length code, then the lengths (lane 0 walks them)
+            int hlit = 0, hdist = 0, hclen = 0;
+            if (lane < 19) s_lens[lane] = 0;
+            __syncthreads();
+            if (lane == 0) {
+                in.refill();
+                hlit = (int)in.take(5) + 257; hdist = (int)in.take(5) + 1; hclen = (int)in.take(4) + 4;
+                const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                for (int i = 0; i < hclen; i++) { in.refill(); s_lens[order[i]] = (u8)in.take(3); }
+            }
+            hlit = __shfl(hlit, 0); hdist = __shfl(hdist, 0);
+            __syncthreads();
+            if (hlit > 286 || hdist > 30) { status = 4; break; }
+            ok = inf_canonical(s_lens, 19, s_cc, lane);
+            {
+                // zlib: the code-length code has to be complete
+                int left = 1; for (int l = 1; l <= 7; l++) left = left * 2 - (int)s_cc.count[l];
+                if (left != 0) ok = false;
+            }
+            if (!ok) { status = 4; break; }
+            u32 bad = 0;
+            if (lane == 0) {
+                // (the 19 lengths were consumed: s_lens is rewritten with the literal/length + distance lengths behind a copy of nothing
+                // -- the code-length code now lives in s_cc alone)
+                int have = 0; const int total = hlit + hdist;
+                u8 prev = 0;
+                while (have < total && !bad) {
+                    in.refill();
+                    int l; const int s = inf_search(s_cc, in.peek(7), 1, 7, l);
+                    if (s < 0) { bad = 1; break; }
+                    in.drop(l);
+                    if (s < 16) { prev = (u8)s; s_lens[have < hlit ? have : 288 + (have - hlit)] = prev; have++; continue; }
+                    int rep; u8 v = 0;
+                    if (s == 16) { if (!have) { bad = 1; break; } v = prev; rep = 3 + (int)in.take(2); }
+                    else if (s == 17) rep = 3 + (int)in.take(3);
+                    else rep = 11 + (int)in.take(7);
+                    if (have + rep > total) { bad = 1; break; }
+                    if (s != 16) prev = 0;
+                    while (rep--) { s_lens[have < hlit ? have : 288 + (have - hlit)] = v; have++; }
+                }
+                for (int i = hlit; i < 288; i++) s_lens[i] = 0;
+                for (int i = hdist; i < 32; i++) s_lens[288 + i] = 0;
+                if (!bad && !s_lens[256]) bad = 1;                       // zlib: missing end-of-block code
+                if (in.over()) bad = 1;
+            }
+            bad = (u32)__shfl((int)bad, 0);
+            __syncthreads();
+            if (bad) { status = 4; break; }
+            ok = inf_canonical(s_lens, 288, s_cl, lane) && inf_canonical(s_lens + 288, 32, s_cd, lane);
+        }
+        if (!ok) { status = 4; break; }
+        inf_root(s_cl, false, s_lit, INF_LIT_ROOT, lane);
+        inf_root(s_cd, true, s_dist, INF_DIST_ROOT, lane);
+        // ---- symbols: lane 0 decodes until something needs the wave (staging full, a match, the end of the block, an error)
+        for (;;) {
+            if (lane == 0) {
+                u32 ev = 0, ns = 0, mlen = 0, mdist = 0;
+                for (;;) {
+                    in.refill();
+                    u32 e = s_lit[in.buf & ((1u << INF_LIT_ROOT) - 1)];
+                    u32 kind = (e >> 5) & 7u;
+                    if (kind == IK_LONG) {
+                        int l; const int s = inf_search(s_cl, in.peek(15), INF_LIT_ROOT + 1, 15, l);
+                        if (s < 0) { ev = 9; break; }
+                        e = s < 256 ? inf_mk((u32)s, 1, IK_LIT, (u32)l) : s == 256 ? inf_mk(0, 0, IK_EOB, (u32)l)
+                            : s < 286 ? inf_mk(c_len_base[s - 257], c_len_extra[s - 257], IK_BASE, (u32)l) : inf_mk(0, 0, IK_BAD, (u32)l);
+                        kind = (e >> 5) & 7u;
+                    }
+                    in.drop((int)(e & 31u));
+                    if (kind == IK_LIT) {
+                        s_stage[ns] = (u8)(e >> 16); s_stage[ns + 1] = (u8)(e >> 24); ns += (e >> 8) & 31u;
+                        // further literals from the same refill (56 bits held; 15 + 3 x 11 used at most)
+                        for (int more = 0; more < 3 && ns < INF_STAGE - 2; more++) {
+                            in.refill();
+                            e = s_lit[in.buf & ((1u << INF_LIT_ROOT) - 1)];
+                            if (((e >> 5) & 7u) != IK_LIT) break;
+                            in.drop((int)(e & 31u));
+                            s_stage[ns] = (u8)(e >> 16); s_stage[ns + 1] = (u8)(e >> 24); ns += (e >> 8) & 31u;
+                        }
+                        if (ns >= INF_STAGE - 2) { ev = 1; break; }
+                        continue;
+                    }
+                    if (kind == IK_BASE) {
+                        mlen = (e >> 16) + in.take((int)((e >> 8) & 31u));
+                        in.refill();
+                        u32 d = s_dist[in.buf & ((1u << INF_DIST_ROOT) - 1)];
+                        if (((d >> 5) & 7u) == IK_LONG) {
+                            int l; const int s = inf_search(s_cd, in.peek(15), INF_DIST_ROOT + 1, 15, l);
+                            if (s < 0 || s >= 30) { ev = 9; break; }
+                            d = inf_mk(c_dist_base[s], c_dist_extra[s], IK_BASE, (u32)l);
+                        }
+                        if (((d >> 5) & 7u) != IK_BASE) { ev = 9; break; }
+                        in.drop((int)(d & 31u));
+                        in.refill();
+                        mdist = (d >> 16) + in.take((int)((d >> 8) & 31u));
+                        ev = 2; break;
+                    }
+                    if (kind == IK_EOB) { ev = 3; break; }
+                    ev = 9; break;
+                }
+                if (in.over()) ev = 9;
+                s_ev[0] = ev; s_ev[1] = ns; s_ev[2] = mlen; s_ev[3] = mdist;
+            }
+            __syncthreads();
+            const u32 ev = s_ev[0], ns = s_ev[1], mlen = s_ev[2], mdist = s_ev[3];
+            __syncthreads();
+            if (ns) {
+                if (n_out + ns > isize) { status = 5; break; }
+                for (u32 i = lane; i < ns; i += 64) out[n_out + i] = (char)s_stage[i];
+                n_out += ns;
+            }
+            if (ev == 2) {
+                if (mdist > n_out || n_out + mlen > isize) { status = 6; break; }
+                __threadfence_block();                                  // the bytes other lanes have just stored are read below
+                // source bytes repeat with period `mdist` when the match overlaps itself
+                for (u32 i = lane; i < mlen; i += 64) out[n_out + i] = out[n_out - mdist + (mdist >= mlen ? i : i % mdist)];
+                n_out += mlen;
+                __threadfence_block();
+            } else if (ev == 3) break;
+            else if (ev == 9) { status = 7; break; }
+        }
+    }
+    // ---- trailer: ISIZE and CRC-32 (every lane one segment, combined by x^(8 * bytes behind it))
+    if (!status) {
+        const u8* t = z + zlen - 8;
+        const u32 want_crc = (u32)t[0] | (u32)t[1] << 8 | (u32)t[2] << 16 | (u32)t[3] << 24;
+        const u32 want_len = (u32)t[4] | (u32)t[5] << 8 | (u32)t[6] << 16 | (u32)t[7] << 24;
+        if (n_out != isize || want_len != isize) status = 8;
+        else {
+            __threadfence_block();
+            const u32 seg = (isize + 63) / 64;
+            const u32 a = (u32)lane * seg < isize ? (u32)lane * seg : isize, e2 = a + seg < isize ? a + seg : isize;
+            u32 c = 0xffffffffu;
+            for (u32 i = a; i < e2; i++) c = s_crc_tab[(c ^ (u8)out[i]) & 0xffu] ^ (c >> 8);
+            c = ~c;
+            u32 x = a < e2 ? crc_multmodp(crc_x8n(isize - e2), c) : 0u;
+            for (int o = 32; o > 0; o >>= 1) x ^= __shfl_down(x, o, 64);
+            x = (u32)__shfl((int)x, 0);
+            if (x != want_crc) status = 9;
+        }
+    }
+    if (lane == 0) err[b] = status;
+}
+#endif

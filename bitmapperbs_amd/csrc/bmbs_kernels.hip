@@ -705,17 +705,19 @@ __global__ void k_expand_sa(DevIndex ix, RefIndexDev R, u64 rows, u32* out, u64*
 }
 
 // ---- the trigram rank table (DevIndex::occ3) ---------------------------------------------------------------------------------------------
-// trigram of a row = the three text letters in front of its suffix in extension order (index alphabet G0 T1 A2, C folded into T);
-// 27 = none (the suffix starts less than three letters into the text)
+// trigram of a row = the three letters in front of its suffix in extension order (index alphabet G0 T1 A2, C folded into T);
+// 27 = none (the suffix starts less than three letters into the indexed text)
 DEVI int row_trigram(const DevIndex& ix, u64 row)
 {
+    // the index is built over the REVERSED doubled text (a backward extension of the pattern is a step forward along the genome:
+    // site = 2G - pos - ..., Schema.cpp:4657), so the letters in front of suffix p are the doubled-genome bases at 2G - p, + 1, + 2
     const u64 p = sa_at(ix, row);
     if (p < 3) return 27;
-    const u64 q = p - 3;
+    const u64 q = ix.total - p;
     const int sh = 2 * (int)(q & 31);
     u64 w = ix.gen2[q >> 5] >> sh;
     if (sh > 58) w |= ix.gen2[(q >> 5) + 1] << (64 - sh);
-    const int b3 = (int)(w & 3), b2 = (int)((w >> 2) & 3), b1 = (int)((w >> 4) & 3);            // text[p-3], [p-2], [p-1]
+    const int b1 = (int)(w & 3), b2 = (int)((w >> 2) & 3), b3 = (int)((w >> 4) & 3);            // first, second, third extension letter
     return ((0x46 >> (2 * b1)) & 3) + 3 * ((0x46 >> (2 * b2)) & 3) + 9 * ((0x46 >> (2 * b3)) & 3);
 }
 // one wave per block of 96 rows: the 27 bit planes by ballots, lane g keeps and stores trigram g's; .x = rows of the block that carry it

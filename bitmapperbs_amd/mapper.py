@@ -187,6 +187,22 @@ class Mapper:
                                                  C.byref(used), C.byref(lines)))
         return out[:used.value].tobytes()
 
+    def inflate_bgzf(self, data: bytes) -> bytes:
+        """the text of a BGZF byte string (bgzip's format), inflated on the device (bmbs_inflate_bgzf); raises on a malformed block"""
+        import struct
+        blk = [0]; out = [0]
+        at = 0
+        while at < len(data):
+            bs = struct.unpack("<H", data[at + 16:at + 18])[0] + 1
+            isz = struct.unpack("<I", data[at + bs - 4:at + bs])[0]
+            at += bs; blk.append(at); out.append(out[-1] + isz)
+        n = len(blk) - 1
+        a = np.frombuffer(data, dtype=np.uint8)
+        b = np.array(blk, dtype=np.uint64); o = np.array(out, dtype=np.uint64)
+        text = np.empty(max(1, out[-1]), dtype=np.uint8)
+        self._chk(self._lib.bmbs_inflate_bgzf(self._ctx, capi.ptr(a), a.size, capi.ptr(b), capi.ptr(o), n, capi.ptr(text), out[-1]))
+        return text[:out[-1]].tobytes()
+
     def sync(self):
         self._chk(self._lib.bmbs_sync(self._ctx))
 

@@ -262,6 +262,16 @@ int bmbs_map_se_text(bmbs_ctx*, const char* text, uint64_t text_bytes, int64_t n
 int bmbs_map_pe_text(bmbs_ctx*, const char* text1, uint64_t bytes1, const char* text2, uint64_t bytes2, int64_t n_pairs, int32_t flags,
                      char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
 
+/* ---- bgzip'ed FASTQ inflated on the device -------------------------------------------------------------------------------------------
+ * The reference reads .gz input through zlib's gzread on its reader thread (Process_Reads.cpp:1455-1514).  A BGZF file (bgzip) is a
+ * series of independent gzip members of at most 64 KiB of text whose compressed size stands in the header: a window of them is
+ * inflated here by one wave per block, CRC-32 and ISIZE of every block checked.  comp = the bytes of n_blocks consecutive blocks
+ * (block i at comp + blk_off[i], blk_off[n_blocks] = their end), text receives block i's bytes at text + out_off[i]
+ * (out_off[i + 1] - out_off[i] = the ISIZE in block i's trailer).  Needs no index.  BMBS_EINVAL (bmbs_last_error says which
+ * block) for anything zlib's inflate would refuse or a CRC that does not match.  Page-locked `text` moves at link speed.         */
+int bmbs_inflate_bgzf(bmbs_ctx*, const void* comp, uint64_t comp_bytes, const uint64_t* blk_off, const uint64_t* out_off, int64_t n_blocks,
+                      char* text, uint64_t text_bytes);
+
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
  * error bases} (Schema.cpp:25141-25146); bmbs_stats_allreduce sums them over the ctxs one process
  * drives (get_mapping_informations, Schema.cpp:451-476).  Multi-process jobs sum the five int64 with
