@@ -76,6 +76,9 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective check without a GPU: gloo, no mapping (tests)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the N > 1 run (gloo: tests)")
     ap.add_argument("--same-device", action="store_true", help="every rank on GPU 0 (a functional test of the N > 1 path on a 1-GPU box; use with --dist-backend gloo)")
+    ap.add_argument("--fasta", default=os.environ.get("BMBS_BENCH_FASTA"),
+                    help="a real assembly (e.g. GRCh38) instead of the synthetic genome of the main configuration: indexed by the GPU builder, "
+                         "reads drawn from its N-free parts (SURVEY.md 8d); also BMBS_BENCH_FASTA")
     ap.add_argument("--workdir", default=os.environ.get("BMBS_BENCH_DIR", "/tmp/bmbs_bench"))
     a = ap.parse_args(argv)
     cfg = dict(CONFIGS[a.config])
@@ -204,9 +207,50 @@ def make_genome(cfg, repeats=0, grch38_like=False):
     return names, chroms
 
 
+def load_fasta(path):
+    """-> (names, chroms): the sequences of a FASTA file as upper-case uint8 arrays with everything outside ACGT REMOVED (reads are
+    drawn from these; the index is built from the file itself, where the builder puts a fixed pseudo-random base for such letters)"""
+    data = np.fromfile(path, dtype=np.uint8)
+    nl = np.flatnonzero(data == 10)
+    starts = np.concatenate([[0], nl[:-1] + 1]) if nl.size else np.array([0])
+    heads = starts[data[starts] == ord(">")]
+    names, chroms = [], []
+    for i, h in enumerate(heads):
+        e = int(nl[np.searchsorted(nl, h)])
+        stop = int(heads[i + 1]) if i + 1 < heads.size else data.size
+        names.append(bytes(data[h + 1:e]).split()[0].decode())
+        seg = data[e + 1:stop] & 0xDF                       # upper case (newline 10 -> 10 & 0xDF = 10: dropped below with the rest)
+        keep = (seg == 65) | (seg == 67) | (seg == 71) | (seg == 84)
+        chroms.append(np.ascontiguousarray(seg[keep]))
+    return names, chroms
+
+
 def ensure_index(args, cfg, rank, local, world, dist, repeats=0, grch38_like=False):
     """-> (fasta/prefix path, names, chroms, seconds spent building or 0 when cached)"""
     from bitmapperbs_amd import synth, mapper
+    if getattr(args, "fasta", None) and not repeats and not grch38_like and cfg["genome"] >= 1_000_000_000:
+        # a real assembly supplied at run time (SURVEY.md 8d) takes the place of the synthetic genome of the GRCh38-size configurations
+        src = os.path.abspath(args.fasta)
+        wd = os.path.join(args.workdir, "fa_%s_%d" % (os.path.basename(src).replace(".", "_"), os.path.getsize(src)))
+        fa = os.path.join(wd, "g.fa")
+        built = 0.0
+        if rank == 0:
+            os.makedirs(wd, exist_ok=True)
+            if not os.path.exists(fa):
+                os.symlink(src, fa)
+            if not os.path.exists(fa + ".index.bs.index.sa.ok"):
+                t = time.time()
+                mapper.Index.build(fa, fa, threads=min(64, os.cpu_count() or 1), device=local)
+                open(fa + ".index.bs.index.sa.ok", "w").write("ok\n")
+                built = time.time() - t
+                sys.stderr.write("[bench] index of %s built in %.1f s (GPU builder)\n" % (src, built))
+        if world > 1:
+            dist.barrier()
+        names, chroms = load_fasta(fa)
+        cfg["genome"] = int(sum(c.size for c in chroms)); cfg["n_chrom"] = len(chroms)
+        cfg["label"] += " [real assembly: %s, %d sequences, %d ACGT bases]" % (os.path.basename(src), len(chroms), cfg["genome"])
+        cfg["real_fasta"] = True
+        return fa, names, chroms, built
     wd = os.path.join(args.workdir, "g%d_c%d%s%s" % (cfg["genome"], cfg["n_chrom"], "_r%d" % repeats if repeats else "", "_hg" if grch38_like else ""))
     fa = os.path.join(wd, "g.fa")
     names, chroms = make_genome(cfg, repeats, grch38_like)
@@ -714,7 +758,10 @@ def gz_input_rate(args, drv, fa, cfg, files, inp, rec_bytes):
             pr.wait()
         n = (os.path.getsize(files[0]) // rec_bytes if label == "bgzf" else n_plain) * (2 if cfg["pe"] else 1)
         a = [gzf[files.index(x)] if x in files else x for x in inp]
-        p = subprocess.run([drv, "--search", fa] + a + ["-e", str(cfg["e"]), "-o", "/dev/null", "-t", "32", "--verbose"], capture_output=True, text=True)
+        # bgzip-style blocks are inflated on the device; one-member gzip by the host's block-parallel inflater on the driver's default
+        # thread count for compressed input
+        p = subprocess.run([drv, "--search", fa] + a + ["-e", str(cfg["e"]), "-o", "/dev/null", "--verbose"] + (["-t", "32"] if label == "bgzf" else []),
+                           capture_output=True, text=True)
         for f in gzf:
             os.unlink(f)
         if p.returncode:
@@ -761,7 +808,10 @@ def file_to_file_rate(args, cfg, fa, L):
     # (the run that writes most files goes first: 14 GB of dirty pages from an earlier run made the box throttle the next writer)
     for label, dst, extra in (("file_%d_parts" % parts, os.path.join(args.workdir, "f2f.sam"), ["--out-parts", str(parts)]),
                               ("null_sink", "/dev/null", []),
-                              ("file", os.path.join(args.workdir, "f2f.sam"), [])):
+                              ("file", os.path.join(args.workdir, "f2f.sam"), []),
+                              # --bam (the reference's documented invocation, README.md:44): records and BGZF blocks made on the device
+                              ("bam", os.path.join(args.workdir, "f2f.sam"), ["--bam"]),
+                              ("bam_null_sink", "/dev/null", ["--bam"])):
         p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "32", "--verbose"] + extra, capture_output=True, text=True)
         if p.returncode:
             return {"error": p.stderr[-300:]}
@@ -784,7 +834,9 @@ def file_to_file_rate(args, cfg, fa, L):
             os.unlink(f)
     out["what"] = ("bmbs_search, FASTQ -> SAM, 1 GPU, 32 host I/O threads, the cpu_baseline sample %d times over, index load + attach excluded "
                    "(as the reference's own 'mapping time'); newline index and SAM text on the device, the host only reads and writes; "
-                   "`file` = one output file, `file_%d_parts` = --out-parts %d (as many inodes written at once), `null_sink` = -o /dev/null" % (REP, parts, parts))
+                   "`file` = one output file, `file_%d_parts` = --out-parts %d (as many inodes written at once), `null_sink` = -o /dev/null, "
+                   "`bam` / `bam_null_sink` = --bam (BAM records and BGZF blocks made on the device); gz_input: `bgzf` inflated on the device, "
+                   "`plain_gzip` (one deflate stream per file) by the host's block-parallel inflater" % (REP, parts, parts))
     return out
 
 
@@ -906,9 +958,10 @@ def main():
             "metric": "M %dbp %s reads aligned/s" % (L, "PE" if pe else "SE"), "value": round(value, 4), "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s; one step = %d launch(es) x %d %s%s per GPU; %d bp %d-chromosome uniform-random N-free synthetic genome "
-                                   "(repeat-poor: NOT representative of GRCh38's repeat structure), -e %.2f (k=%d), %s, substitutions %.3f, "
-                                   "indels %.4f/bp, qualities %s; inputs and results resident in HBM" % (
+            "config": {"workload": ("%s; one step = %d launch(es) x %d %s%s per GPU; %d bp %d-chromosome " + ("REAL assembly (--fasta)" if cfg.get("real_fasta") else
+                                    "uniform-random N-free synthetic genome (repeat-poor: NOT representative of GRCh38's repeat structure -- secondary.grch38_like is "
+                                    "the same launch on a repeat-rich genome)") + ", -e %.2f (k=%d), %s, substitutions %.3f, "
+                                    "indels %.4f/bp, qualities %s; inputs and results resident in HBM") % (
                                        cfg["label"], len(job.batches), job.n, "pairs" if pe else "reads",
                                        " x %d passes (timed region stretched to >= %.1f s)" % (passes, args.min_seconds) if passes > 1 else "",
                                        cfg["genome"], cfg["n_chrom"], cfg["e"], k,

@@ -13,7 +13,6 @@ GZN=$((N * 2))
 ( head -c $((GZN * REC)) $F2 | gzip -1 -c > $W/g_2.fq.gz ) &
 wait
 ls -la $W/g_1.fq.gz $W/g_2.fq.gz
-tools/pgz_probe.sh $W/g_1.fq.gz $W/g_2.fq.gz
 run() { # label, reads, args...
   local label=$1; shift; local reads=$1; shift
   ./bitmapperbs_amd/bmbs_search --search $FA -e 0.08 --verbose "$@" 2> $O/$label.err > /dev/null
@@ -21,8 +20,21 @@ run() { # label, reads, args...
   echo "$label: wall $wall s -> $(python3 -c "print(round($reads/$wall/1e6,1))") M reads/s | $(grep 'stage busy' $O/$label.err | sed 's/.*(pipeline/(pipeline/' | cut -c1-260)"
 }
 ALL=$((NP * 2)); GZR=$((GZN * 2))
+python3 - <<PY
+import sys; sys.path.insert(0, ".")
+import bench
+for k in (1, 2):
+    with open("$W/e2e_%d.fq" % k, "rb") as f: data = f.read($GZN * $REC)
+    bench.write_bgzf("$W/b_%d.fq.gz" % k, data, level=1, threads=16)
+PY
+ls -la $W/b_1.fq.gz
 run text_null $ALL --seq1 $F1 --seq2 $F2 -o /dev/null -t 32
-for t in 16 32 64 128; do run gz_t$t $GZR --seq1 $W/g_1.fq.gz --seq2 $W/g_2.fq.gz -o /dev/null -t $t; done
+for t in 16 32; do run gz_t$t $GZR --seq1 $W/g_1.fq.gz --seq2 $W/g_2.fq.gz -o /dev/null -t $t; done
+run bgzf_device_t32 $GZR --seq1 $W/b_1.fq.gz --seq2 $W/b_2.fq.gz -o /dev/null -t 32
+BMBS_GZ_DEVICE=0 run bgzf_host_t32 $GZR --seq1 $W/b_1.fq.gz --seq2 $W/b_2.fq.gz -o /dev/null -t 32
+run bgzf_device_bam $GZR --seq1 $W/b_1.fq.gz --seq2 $W/b_2.fq.gz -o /dev/null -t 32 --bam
+run file_single $ALL --seq1 $F1 --seq2 $F2 -o $W/o.sam -t 32
+rm -f $W/o.sam
 run bam_null $ALL --seq1 $F1 --seq2 $F2 -o /dev/null -t 32 --bam
 run bam_file $ALL --seq1 $F1 --seq2 $F2 -o $W/o.bam -t 32 --bam
 ls -la $W/o.bam; python3 - <<PY
@@ -39,4 +51,4 @@ PY
 rm -f $W/o.bam
 run gz_bam_t64 $GZR --seq1 $W/g_1.fq.gz --seq2 $W/g_2.fq.gz -o /dev/null -t 64 --bam
 BMBS_TEXT_TRACE=1 ./bitmapperbs_amd/bmbs_search --search $FA -e 0.08 --seq1 $F1 --seq2 $F2 -o /dev/null -t 32 --bam --contexts 1 2>&1 | grep "text/bam" | head -5
-rm -f $W/g_1.fq.gz $W/g_2.fq.gz
+rm -f $W/g_1.fq.gz $W/g_2.fq.gz $W/b_1.fq.gz $W/b_2.fq.gz
