@@ -74,6 +74,7 @@ struct Knobs {
     bool copy_streams = true;   // BMBS_COPY_STREAMS=0: the text calls' copies go on the lane's kernel stream
     bool copy_lock = true;      // BMBS_COPY_LOCK=0: the text calls of different contexts copy at the same time
     bool arena = true;          // BMBS_ARENA=0: every work buffer a hipMalloc of its own (round 2)
+    int kgram = 1;              // BMBS_KGRAM: 0 no trigram table, 1 (default) its kernels are used once a context has seen reads that walk the index in long chains, 2 always
     int exp = 0;                // BMBS_EXP: timing experiments (results are WRONG with it): 1 = k_seed_extra stores no seed records
     double cap_scale = 1.0;     // BMBS_CAP_SCALE: scales the learned capacities (tests: a small value forces the repeat-with-exact-sizes path)
     void read()
@@ -96,6 +97,7 @@ struct Knobs {
         if ((e = getenv("BMBS_LANES"))) lanes = atoi(e);
         if (lanes < 1) lanes = 1;
         if (lanes > 8) lanes = 8;
+        if ((e = getenv("BMBS_KGRAM"))) kgram = atoi(e);
         if ((e = getenv("BMBS_EXP"))) exp = atoi(e);
         if ((e = getenv("BMBS_CHUNK"))) chunk = atol(e);
         if ((e = getenv("BMBS_SPLIT_MIN"))) split_min = atol(e);
@@ -184,6 +186,7 @@ struct Lane {
     u64 acc_calls = 0;
     u64 last_total_cand = 0, last_n_jobs = 0;
     int last_max_ops = 0;
+    double lr_chain = 0;                       // extensions per 16-mer lookup of the last settled call (three-letter steps from 3 on)
     u64 h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // ---- launches without host round trips: what the stages of earlier calls needed, per read (0: nothing known yet -> the
     // first call of a lane waits for its counts); the pinned words the device leaves its counts and guard flags in; the call in flight
@@ -600,7 +603,11 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
         pr.base = c->prow.as<u64>(); pr.dirty = c->prow_dirty.as<u8>(); pr.pwords = pwords; pr.W = W;
     }
     prof_begin(c, "k_seed_first");
-    if (packed_rows) hipLaunchKernelGGL(k_seed_first<true>, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
+    // three-letter index steps (DevIndex::occ3): their kernels hold more registers (one or two waves per SIMD fewer), which costs a
+    // few per cent where chains are short -- so they are used once the context has seen long ones (BMBS_KGRAM=2: always, 0: never)
+    const bool kg = c->ix.occ3 && packed_rows && (c->kn.kgram >= 2 || (c->kn.kgram == 1 && c->lr_chain >= 3.0));
+    if (packed_rows && kg) hipLaunchKernelGGL((k_seed_first<true, true>), dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
+    else if (packed_rows) hipLaunchKernelGGL(k_seed_first<true>, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
     else hipLaunchKernelGGL(k_seed_first<false>, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_decide");
@@ -633,7 +640,8 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
     if (rc) return rc;
     prof_end(c);
     prof_begin(c, "k_seed_second");
-    if (packed_rows) hipLaunchKernelGGL(k_seed_second<true>, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode, st, sc, cnt);
+    if (packed_rows && kg) hipLaunchKernelGGL((k_seed_second<true, true>), dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode, st, sc, cnt);
+    else if (packed_rows) hipLaunchKernelGGL(k_seed_second<true>, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode, st, sc, cnt);
     else hipLaunchKernelGGL(k_seed_second<false>, dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 3, target_waves, pe_mode, st, sc, cnt);
     prof_end(c);
     prof_begin(c, "list_extra");
@@ -651,7 +659,10 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
         const int rows_in_lds = lds <= 48 * 1024 && !c->kn.extra_nolds && (!wide_ix || c->kn.extra_lds);
         // packed rows: the lane's row in its LDS slot (4.6 KB per wave at 150 bases: no occupancy lost); BMBS_EXTRA_PLDS=0: from global memory
         const size_t plds = (size_t)64 * (pr.pwords + 1) * 8;
-        if (packed_rows && c->kn.extra_plds && plds <= 16 * 1024)
+        if (packed_rows && c->kn.extra_plds && plds <= 16 * 1024 && kg)
+            hipLaunchKernelGGL((k_seed_extra<false, true, true, true>), dim3(chunks_min), dim3(64), plds, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
+                               target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
+        else if (packed_rows && c->kn.extra_plds && plds <= 16 * 1024)
             hipLaunchKernelGGL((k_seed_extra<false, true, true>), dim3(chunks_min), dim3(64), plds, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode | (c->kn.exp << 8), st, sc, cnt);
         else if (packed_rows)
@@ -1096,6 +1107,7 @@ int call_end(Lane* c, int slot)
     const int words = BMBS_SHARDS * BMBS_SHARD_WORDS;
     hipLaunchKernelGGL(k_stats_commit, dim3(nblk(words, 256)), dim3(256), 0, c->stream, c->flags.as<u32>(), c->call_stats.as<unsigned long long>(),
                        c->stats.as<unsigned long long>(), words);
+    hipLaunchKernelGGL(k_call_chain_counts, dim3(1), dim3(64), 0, c->stream, c->counters.as<unsigned long long>(), c->totals.as<u64>());
     HIPCHK(c, hipMemcpyAsync(h, c->totals.p, 16 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h + 16, c->flags.p, BMBS_FLAG_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     return BMBS_OK;
@@ -1428,7 +1440,8 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
         {
             PackedRows prs = {nullptr, nullptr, 0, 0};
             if (use_packed_rows(c)) { prs.base = c->prow.as<u64>(); prs.dirty = c->prow_dirty.as<u8>(); prs.pwords = pack_words(gm.L); prs.W = pack_base_words(gm.L); }
-            hipLaunchKernelGGL((prs.base ? k_pes_reseed<true> : k_pes_reseed<false>), dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, prs, gm, stride,
+            const bool kg = c->ix.occ3 && prs.base && (c->kn.kgram >= 2 || (c->kn.kgram == 1 && c->lr_chain >= 3.0));
+            hipLaunchKernelGGL((kg ? k_pes_reseed<true, true> : prs.base ? k_pes_reseed<true> : k_pes_reseed<false>), dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, seq_all, prs, gm, stride,
                                (long)n, n_reseed, rlist, st, ps, rcnt, cnt);
         }
         rc = scan_u32(c, rcnt, n, c->pe_ritem_off.as<u64>(), 8);
@@ -1547,6 +1560,7 @@ int lane_settle(Lane* c)
                     c->lr_sw = std::max(c->lr_sw, (double)t[2] / nr);
                     c->lr_rcand = std::max(c->lr_rcand, (double)t[8] / nr);
                     c->lr_long = ((double)t[9] + (double)t[11]) / nr;             // reads whose candidate lists went to the mid / long kernels
+                    if (t[14]) c->lr_chain = (double)t[15] / (double)t[14];
                 }
                 c->last_total_cand = t[0]; c->last_n_jobs = t[1];
                 prof_collect(c, P.slot);
@@ -1584,8 +1598,9 @@ int lane_enqueue(Lane* c, Pending P, bool staged)
 void share_needs(bmbs_ctx* X)
 {
     double a = 0, b = 0, d = 0, g = 0;
-    for (Lane* c : X->lanes) { a = std::max(a, c->lr_cand); b = std::max(b, c->lr_sw); d = std::max(d, c->lr_rcand); g = std::max(g, c->lr_long); }
-    for (Lane* c : X->lanes) { c->lr_cand = a; c->lr_sw = b; c->lr_rcand = d; c->lr_long = g; }
+    double ch = 0;
+    for (Lane* c : X->lanes) { a = std::max(a, c->lr_cand); b = std::max(b, c->lr_sw); d = std::max(d, c->lr_rcand); g = std::max(g, c->lr_long); ch = std::max(ch, c->lr_chain); }
+    for (Lane* c : X->lanes) { c->lr_cand = a; c->lr_sw = b; c->lr_rcand = d; c->lr_long = g; c->lr_chain = ch; }
 }
 
 int settle_all(bmbs_ctx* X)

@@ -1033,7 +1033,7 @@ DEVI bool search_step(const DevIndex& ix, const char* rd, int L, Search& S, Seed
 }
 
 // ---- the same two functions over a packed row (PackedRows) ----------------------------------------------------------------
-struct SearchP { u64 top, bot, ptop, pbot; int s, steps, tm, kg; PCur cur; };      // kg: steps in a row that kept most of the interval (< 0: three-letter steps are off for this seed)
+struct SearchP { u64 top, bot; int s, steps, tm, kg; PCur cur; };      // kg: steps in a row that kept most of the interval (< 0: three-letter steps are off for this seed)
 
 // four 2-bit digits (d0 in bits 0-1) -> d0 + 3 d1 + 9 d2 + 27 d3
 DEVI u32 base3_of4x2(u32 v8)
@@ -1076,7 +1076,7 @@ DEVI bool search_begin_p(const DevIndex& ix, const u64* row, int W, bool dirty, 
                 if (FIXED) {
                     if (tag > E && tag <= 2 * E) return false;
                     if (tag != 0) {
-                        S.top = rowv | (1ull << 63); S.bot = S.top + 1; S.ptop = ~0ull; S.pbot = ~0ull; S.s = tag == 2 * E + 1 ? E : tag - 1;
+                        S.top = rowv | (1ull << 63); S.bot = S.top + 1; S.s = tag == 2 * E + 1 ? E : tag - 1;
                         return true;
                     }
                 } else {
@@ -1084,7 +1084,7 @@ DEVI bool search_begin_p(const DevIndex& ix, const u64* row, int W, bool dirty, 
                     if (tag == 2 * E + 1) { out.ml = (u64)(16 + E); out.sp = rowv | (1ull << 63); out.hits = 1; return false; }
                     if (tag > E) { out.ml = (u64)(15 - E + tag); out.sp = rowv; out.hits = hits; return false; }
                 }
-                S.top = rowv; S.bot = rowv + hits; S.ptop = ~0ull; S.pbot = ~0ull; S.s = E;
+                S.top = rowv; S.bot = rowv + hits; S.s = E;
                 if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = hits; return false; }
                 S.cur.pos = tm + 16 + E; S.cur.buf = x >> (2 * (16 + E)); S.cur.have = 16 - E;
                 return true;
@@ -1094,7 +1094,7 @@ DEVI bool search_begin_p(const DevIndex& ix, const u64* row, int W, bool dirty, 
     hash_lookup(ix, key, S.top, S.bot);
     n_hash++;
     if (S.bot <= S.top) return false;
-    S.ptop = ~0ull; S.pbot = ~0ull; S.s = 0;
+    S.s = 0;
     S.cur.pos = tm + 16; S.cur.buf = x >> 32; S.cur.have = 16;
     return true;
 }
@@ -1104,46 +1104,67 @@ DEVI bool search_begin_p(const DevIndex& ix, const u64* row, int W, bool dirty, 
 // interval behind it still has two rows or more, so none of the reference's stop conditions (one row left, letter absent, letter
 // outside the alphabet -- bwt.h:2081-2209, 1848-1952) fell inside it; otherwise it is dropped, the three letters are stepped one by
 // one as before, and the seed makes no further attempt.  Counted as three extensions (the reference's events).
-template <bool FIXED>
+template <bool FIXED, bool KG = false>
 DEVI bool search_step_p(const DevIndex& ix, int L, SearchP& S, SeedHit& out, u32& n_ext, const u64* c3 = nullptr, u32* n_jump = nullptr)
 {
     const int len = L - S.tm;
+    const u64 ptop = S.top, pbot = S.bot;
     if (!FIXED) {
-        S.ptop = S.top; S.pbot = S.bot;
-        if (S.bot - S.top == 1) { out.ml = 16 + S.s; out.sp = S.top; out.hits = 1; return true; }
+        if (pbot - ptop == 1) { out.ml = 16 + S.s; out.sp = ptop; out.hits = 1; return true; }
     } else out.ml = (u64)len;
-    const u64 before = S.bot - S.top;
-    if (c3 && S.kg >= (before >= 8 ? 1 : 2) && S.steps - S.s >= 3 && S.cur.have >= 3 && before >= 2) {
+    const u64 before = pbot - ptop;
+    // which kind of step this lane takes: three letters (trigram g) or one (digit d).  Both kinds then share ONE gather pair -- a
+    // jump tried in a branch of its own made every wave with a jumping lane wait out two memory round trips per iteration
+    bool jump = false; int g = 0, d = 0;
+    if (KG && S.kg >= (before >= 8 ? 1 : 2) && S.steps - S.s >= 3 && S.cur.have >= 3 && before >= 2) {
+        jump = true;                                       // none of the three letters outside ACGT (their mask bits inside one word)
+        if (S.cur.dirty) { const int o = S.cur.pos & 63; jump = o <= 61 && ((S.cur.row[S.cur.W + (S.cur.pos >> 6)] >> o) & 7ull) == 0; }
         const u32 b6 = (u32)S.cur.buf & 63u;
-        bool clean = true;                                 // none of the three letters outside ACGT (their mask bits inside one word)
-        if (S.cur.dirty) { const int o = S.cur.pos & 63; clean = o <= 61 && ((S.cur.row[S.cur.W + (S.cur.pos >> 6)] >> o) & 7ull) == 0; }
-        if (clean) {
-            const int g = ((0x46 >> (2 * (b6 & 3u))) & 3) + 3 * ((0x46 >> (2 * ((b6 >> 2) & 3u))) & 3) + 9 * ((0x46 >> (2 * (b6 >> 4))) & 3);
-            u64 t2 = S.top, b2 = S.bot;
-            lf3_pair(ix, g, c3[g], t2, b2);
-            if (b2 > t2 && b2 - t2 >= 2) {
-                S.top = t2; S.bot = b2; S.s += 3; n_ext += 3;
-                if (n_jump) (*n_jump)++;
-                S.cur.buf >>= 6; S.cur.have -= 3; S.cur.pos += 3;
-                if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
-                return false;
-            }
-            S.kg = -(1 << 20);
+        g = ((0x46 >> (2 * (b6 & 3u))) & 3) + 3 * ((0x46 >> (2 * ((b6 >> 2) & 3u))) & 3) + 9 * ((0x46 >> (2 * (b6 >> 4))) & 3);
+    }
+    if (!jump) {
+        d = S.cur.next3();
+        if (d > 2) {
+            if (!FIXED) { out.ml = 16 + S.s; out.sp = ptop; out.hits = pbot - ptop; } else { out.hits = 0; out.sp = 0; }
+            return true;
         }
     }
-    const int d = S.cur.next3();
-    if (!FIXED) {
-        if (d > 2) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
-        lf_pair(ix, S.top, S.bot, d);
-        n_ext++;
-        if (S.bot <= S.top) { out.ml = 16 + S.s; out.sp = S.ptop; out.hits = S.pbot - S.ptop; return true; }
-    } else {
-        if (d > 2) { out.hits = 0; out.sp = 0; return true; }
-        lf_pair(ix, S.top, S.bot, d);
-        n_ext++;
-        if (S.bot <= S.top) { out.hits = 0; out.sp = S.top; return true; }      // the remaining iterations only break
+    const u64 lt = ptop - (ptop > ix.shapline ? 1 : 0), lb = pbot - (pbot > ix.shapline ? 1 : 0);       // (single steps: '$' row removed)
+    // rows fit 36 bits (checked at attach), so row >> 5 fits 32: the division by 96 is a 32-bit one by 3
+    const u32 it = jump ? (u32)(ptop >> 5) / 3u : (u32)(lt >> 5), ib = jump ? (u32)(pbot >> 5) / 3u : (u32)(lb >> 5);
+    const u32 rt = jump ? (u32)(ptop - (u64)it * 96) : (u32)lt & 31u, rb = jump ? (u32)(pbot - (u64)ib * 96) : (u32)lb & 31u;
+    const uint4* base = jump ? ix.occ3 + (u64)g * ix.nb3 : ix.occ;
+    const uint4 ht = base[it];
+    uint4 hb = ht;
+    if (ib != it) hb = base[ib];
+    if (jump) {
+        const u64 c3g = c3[g];
+        const u64 t2 = c3g + occ3_in_block(ht, rt), b2 = c3g + occ3_in_block(hb, rb);
+        if (b2 > t2 && b2 - t2 >= 2) {
+            S.top = t2; S.bot = b2; S.s += 3; n_ext += 3;
+            if (n_jump) (*n_jump)++;
+            S.cur.buf >>= 6; S.cur.have -= 3; S.cur.pos += 3;
+            if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
+            return false;
+        }
+        S.kg = -(1 << 20);                                 // dropped: nothing was consumed, the next calls step letter by letter
+        return false;
     }
-    S.kg = 2 * (S.bot - S.top) > before ? S.kg + 1 : (S.kg < 0 ? S.kg : 0);
+    {
+        const u32 mt = rt ? (~0u << (32 - rt)) : 0u, mb = rb ? (~0u << (32 - rb)) : 0u;
+        u64 tT = (u64)ht.x + __popc(ht.z & mt), tA = (u64)ht.y + __popc(ht.w & mt);
+        u64 bT = (u64)hb.x + __popc(hb.z & mb), bA = (u64)hb.y + __popc(hb.w & mb);
+        if (ix.sup_shift) { super_add(ix, lt, tT, tA); super_add(ix, lb, bT, bA); }
+        const u64 ct = d == 1 ? tT : (d == 2 ? tA : lt - tT - tA);
+        const u64 cb = d == 1 ? bT : (d == 2 ? bA : lb - bT - bA);
+        S.top = ix.C[d] + ct; S.bot = ix.C[d] + cb;
+    }
+    n_ext++;
+    if (S.bot <= S.top) {
+        if (!FIXED) { out.ml = 16 + S.s; out.sp = ptop; out.hits = pbot - ptop; } else { out.hits = 0; out.sp = S.top; }      // (FIXED: the remaining iterations only break)
+        return true;
+    }
+    if (KG) S.kg = 2 * (S.bot - S.top) > before ? S.kg + 1 : (S.kg < 0 ? S.kg : 0);
     S.s++;
     if (S.s == S.steps) { out.ml = (u64)len; out.sp = S.top; out.hits = S.bot - S.top; return true; }
     return false;
@@ -1264,13 +1285,13 @@ DEVI void wave_stats_add(unsigned long long* sh, u32 v0, u32 v1, u32 v2, u32 v3,
 }
 
 // ---- first seed of every read ------------------------------------------------------------------
-template <bool PACKED>
+template <bool PACKED, bool KG = false>
 __global__ void __launch_bounds__(64)
 k_seed_first(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, SeedCarry sc,
              unsigned long long* __restrict__ counters)
 {
-    __shared__ u64 s_c3[27];
-    const u64* c3 = kgram_c3(ix, s_c3);
+    __shared__ u64 s_c3[KG ? 27 : 1];
+    const u64* c3 = KG ? kgram_c3(ix, s_c3) : nullptr;
     const WaveLogT wl_t = wavelog_begin();
     int L = gm.L;                                     // length of the lane's current read
     const long chunk_begin = (long)blockIdx.x * SEED_CHUNK;
@@ -1311,7 +1332,7 @@ k_seed_first(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
 #endif
         if (active) {
             bool fin;
-            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
+            if constexpr (PACKED) fin = search_step_p<false, KG>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
             if (fin) { active = false; pending = true; }
         }
     }
@@ -1616,7 +1637,7 @@ k_seed_decide_p(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGe
 }
 
 // ---- second seed of the 1-mismatch reads + fast exit C (Schema.cpp:24734-24801, 24894-24898) -----
-template <bool PACKED>
+template <bool PACKED, bool KG = false>
 __global__ void __launch_bounds__(64)
 k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
               int pe_mode, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
@@ -1626,8 +1647,8 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
-    __shared__ u64 s_c3[27];
-    const u64* c3 = kgram_c3(ix, s_c3);
+    __shared__ u64 s_c3[KG ? 27 : 1];
+    const u64* c3 = KG ? kgram_c3(ix, s_c3) : nullptr;
     const WaveLogT wl_t = wavelog_begin();
     const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
@@ -1755,7 +1776,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
 #endif
         if (active) {
             bool fin;
-            if constexpr (PACKED) fin = search_step_p<true>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<true>(ix, rd, L, S, h, lc.n_ext);
+            if constexpr (PACKED) fin = search_step_p<true, KG>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<true>(ix, rd, L, S, h, lc.n_ext);
             if (fin) { active = false; pending = true; }
             else if (S.bot - S.top == 1) { verify = true; active = false; pending = true; }
         }
@@ -1769,7 +1790,7 @@ k_seed_second(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom
 // PLDS (with PACKED): the packed row of a lane's read (pwords x 8 bytes) is copied into the lane's LDS slot when the lane takes the
 // read -- coalesced 16-byte loads along the rows -- and every seed start and cursor refill reads LDS: one request to the memory
 // pipeline per seed start less (of about five), at 64 x (pwords + 1) x 8 = 4.6 KB of LDS per wave for 150-base reads
-template <bool ROWS_LDS, bool PACKED = false, bool PLDS = false>
+template <bool ROWS_LDS, bool PACKED = false, bool PLDS = false, bool KG = false>
 __global__ void __launch_bounds__(64)
 k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, const u64* __restrict__ count_ptr, int target_waves,
              int seed_len, int pe_mode_x, ReadState st, SeedCarry sc, unsigned long long* __restrict__ counters)
@@ -1781,8 +1802,8 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
     const long chunk = seed_chunk(total, target_waves);
     const long chunk_begin = (long)blockIdx.x * chunk;
     if (chunk_begin >= total) return;
-    __shared__ u64 s_c3[27];
-    const u64* c3 = kgram_c3(ix, s_c3);
+    __shared__ u64 s_c3[KG ? 27 : 1];
+    const u64* c3 = KG ? kgram_c3(ix, s_c3) : nullptr;
     const WaveLogT wl_t = wavelog_begin();
     const long chunk_end = chunk_begin + chunk < total ? chunk_begin + chunk : total;
     long next = chunk_begin;
@@ -1894,7 +1915,7 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
 #endif
         if (active) {
             bool fin;
-            if constexpr (PACKED) fin = search_step_p<false>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
+            if constexpr (PACKED) fin = search_step_p<false, KG>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump); else fin = search_step<false>(ix, rd, L, S, h, lc.n_ext);
             if (fin) { active = false; pending = true; seed_done = true; }
         }
     }
@@ -3067,6 +3088,17 @@ k_stats_commit(const u32* __restrict__ flags, unsigned long long* __restrict__ c
     const unsigned long long v = call_stats[i];
     call_stats[i] = 0;
     if (!again && v) stats[i] += v;
+}
+
+// 16-mer lookups and extensions of this call (summed over the counter shards) -> totals[14], [15]: the host learns from them
+// whether the reads of this input walk the index in long chains (three-letter steps pay off) or not
+__global__ void k_call_chain_counts(const unsigned long long* __restrict__ counters, u64* __restrict__ totals)
+{
+    const int j = threadIdx.x;                  // 0: lookups, 1: extensions
+    if (j >= 2) return;
+    u64 t = 0;
+    for (int sdx = 0; sdx < BMBS_SHARDS; sdx++) t += counters[sdx * BMBS_SHARD_WORDS + j];
+    totals[14 + j] = t;
 }
 
 // job arrays shared by the fused path and bmbs_align_batch
@@ -4979,13 +5011,13 @@ k_pes_reseed_flag(long n, PeState ps, u32* __restrict__ flag)
 
 // reseed_filter's seeding (Schema.cpp:16678-16900) with select_best_seeds (16630): up to three fixed segments
 // (count_hash_table) and then count_backward_as_much_1_terminate seeds sliding by 8.  One re-seeded mate per lane.
-template <bool PACKED>
+template <bool PACKED, bool KG = false>
 __global__ void __launch_bounds__(64)
 k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, long n, const u64* __restrict__ count_ptr,
              const u32* __restrict__ plist, ReadState st, PeState ps, u32* __restrict__ rcnt, unsigned long long* __restrict__ counters)
 {
-    __shared__ u64 s_c3[27];
-    const u64* c3 = kgram_c3(ix, s_c3);
+    __shared__ u64 s_c3[KG ? 27 : 1];
+    const u64* c3 = KG ? kgram_c3(ix, s_c3) : nullptr;
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
     LaneCounters lc = {0, 0, 0, 0, 0};
     if (it < (long)*count_ptr) {
@@ -5023,7 +5055,7 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
             const int tm = rs[seed_id], ml = rl[seed_id];
             if constexpr (PACKED) {
                 if (search_begin_p<true>(ix, prow, pr.W, dirty, tm + ml, tm, S, h, lc.n_hash))
-                    while (!search_step_p<true>(ix, tm + ml, S, h, lc.n_ext, c3, &lc.n_jump)) {}
+                    while (!search_step_p<true, KG>(ix, tm + ml, S, h, lc.n_ext, c3, &lc.n_jump)) {}
             } else {
                 if (search_begin<true>(ix, rd, tm + ml, tm, S, h, lc.n_hash))
                     while (!search_step<true>(ix, rd, tm + ml, S, h, lc.n_ext)) {}
@@ -5037,7 +5069,7 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
         while (seed_id < max_seed && tm < L) {
             if constexpr (PACKED) {
                 if (search_begin_p<false>(ix, prow, pr.W, dirty, L, tm, S, h, lc.n_hash))
-                    while (!search_step_p<false>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump)) {}
+                    while (!search_step_p<false, KG>(ix, L, S, h, lc.n_ext, c3, &lc.n_jump)) {}
             } else {
                 if (search_begin<false>(ix, rd, L, tm, S, h, lc.n_hash))
                     while (!search_step<false>(ix, rd, L, S, h, lc.n_ext)) {}

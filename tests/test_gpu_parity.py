@@ -763,7 +763,7 @@ def test_three_letter_index_steps_change_nothing_but_the_gathers(tmp_path, monke
     ix = mapper.Index(fa); oix = orc.OrcIndex(fa)
     out = {}
     for kg in ("1", "0"):
-        monkeypatch.setenv("BMBS_KGRAM", kg)
+        monkeypatch.setenv("BMBS_KGRAM", "2" if kg == "1" else "0")       # 2: the trigram kernels from the first call on (1 = once long chains were seen)
         sens = 1 if mode == "pe_sensitive" else 0
         m = mapper.Mapper(ix, 0, sensitive=sens)
         if mode == "se":
