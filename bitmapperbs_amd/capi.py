@@ -140,7 +140,7 @@ def lib() -> C.CDLL:
     L.bmbs_sam_refs.argtypes = [vp, C.POINTER(C.c_char_p), i32]
     L.bmbs_sam_refs.restype = C.c_int
     L.bmbs_map_se_text.argtypes = [vp, vp, u64, i64, i32, vp, u64, C.POINTER(u64), C.POINTER(i64)]
-    L.bmbs_inflate_bgzf.argtypes = [vp, vp, u64, vp, vp, i64, vp, u64]
+    L.bmbs_inflate_bgzf.argtypes = [vp, vp, u64, vp, vp, i64, vp, u64, vp, u64]
     L.bmbs_inflate_bgzf.restype = C.c_int
     L.bmbs_map_se_text.restype = C.c_int
     L.bmbs_map_pe_text.argtypes = [vp, vp, u64, vp, u64, i64, i32, vp, u64, C.POINTER(u64), C.POINTER(i64)]

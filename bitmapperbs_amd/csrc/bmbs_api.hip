@@ -167,7 +167,7 @@ struct Lane {
     // bmbs_map_*_text: newline index built on the device, SAM text written on the device
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
     DevBuf bam_raw, bam_tok, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
-    DevBuf z_comp, z_off, z_text, z_err;                                         // bmbs_inflate_bgzf
+    DevBuf z_comp, z_off, z_text, z_err, z_nl;                                   // bmbs_inflate_bgzf
     u32* h_info = nullptr;                              // page-locked: 8 info words + 4 totals of the text path
     int n_refs = 0, max_ref_len = 0;
     // paired-end workspace
@@ -903,7 +903,7 @@ void lane_destroy(Lane* c)
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->h_info) (void)hipHostFree(c->h_info);
     { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list,
-                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err};
+                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl};
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
@@ -2549,7 +2549,7 @@ extern "C" int bmbs_host_prefault(bmbs_ctx* X, void* p, uint64_t bytes, int32_t 
 
 // bgzip'ed input inflated on the device (bmbs_inflate.hip): needs no index
 extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_bytes, const uint64_t* blk_off, const uint64_t* out_off, int64_t n_blocks,
-                                 char* text, uint64_t text_bytes)
+                                 char* text, uint64_t text_bytes, uint32_t* nl_per_64k, uint64_t window_shift)
 {
     Lane* c = lane0(X);
     if (!c) return BMBS_EINVAL;
@@ -2569,9 +2569,15 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
     HIPCHK(c, hipStreamSynchronize(us));
     hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)n), dim3(64), 0, c->stream, c->z_comp.as<u8>(), c->z_off.as<u64>(), c->z_off.as<u64>() + (n + 1), (long)n,
                        c->z_text.as<char>(), c->z_err.as<u32>());
+    const u64 n_cnt = nl_per_64k ? (window_shift + out_off[n] + 65535) >> 16 : 0;
+    if (n_cnt) {
+        ENS(c, c->z_nl, n_cnt * 4 + 64);
+        hipLaunchKernelGGL(k_nl_count64k, dim3((unsigned)n_cnt), dim3(256), 0, c->stream, c->z_text.as<char>(), out_off[n], window_shift, c->z_nl.as<u32>());
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<u32> err(n);
     HIPCHK(c, hipMemcpyAsync(err.data(), c->z_err.p, n * 4, hipMemcpyDeviceToHost, ds));
+    if (n_cnt) HIPCHK(c, hipMemcpyAsync(nl_per_64k, c->z_nl.p, n_cnt * 4, hipMemcpyDeviceToHost, ds));
     int rc = d2h_chunked(c, text, c->z_text.as<char>(), out_off[n], ds);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(ds));

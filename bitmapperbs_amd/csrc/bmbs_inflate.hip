@@ -355,4 +355,33 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     }
     if (lane == 0) err[b] = status;
 }
+
+// newlines of the inflated text per 64 KiB of the caller's window: text byte i sits at window offset shift + i; counts[j] = newlines
+// among the bytes whose window offset lies in [j * 65536, (j + 1) * 65536) (the driver's reader needs nothing else from the text)
+__global__ void __launch_bounds__(256)
+k_nl_count64k(const char* __restrict__ text, u64 total, u64 shift, u32* __restrict__ counts)
+{
+    __shared__ u32 sh[4];
+    const u64 j = blockIdx.x;
+    const u64 w0 = j << 16, w1 = w0 + 65536;
+    const u64 a = w0 > shift ? w0 - shift : 0, e = w1 > shift ? (w1 - shift < total ? w1 - shift : total) : 0;
+    u32 c = 0;
+    // 16 bytes per thread and step where the range allows (the text buffer is 16-byte aligned, `a` is not in general)
+    u64 i = a + threadIdx.x;
+    const u64 a16 = (a + 15) & ~15ull, e16 = e & ~15ull;
+    if (a16 < e16) {
+        for (u64 q = a + threadIdx.x; q < a16; q += 256) c += text[q] == '\n';
+        const uint4* p = reinterpret_cast<const uint4*>(text + a16);
+        const u64 n16 = (e16 - a16) >> 4;
+        for (u64 q = threadIdx.x; q < n16; q += 256) {
+            const uint4 v = p[q];
+            c += (u32)__popc(nl_mask4(v.x)) + (u32)__popc(nl_mask4(v.y)) + (u32)__popc(nl_mask4(v.z)) + (u32)__popc(nl_mask4(v.w));
+        }
+        for (u64 q = e16 + threadIdx.x; q < e; q += 256) c += text[q] == '\n';
+    } else for (; i < e; i += 256) c += text[i] == '\n';
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[j] = sh[0] + sh[1] + sh[2] + sh[3];
+}
 #endif

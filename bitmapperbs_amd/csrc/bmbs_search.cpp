@@ -189,14 +189,14 @@ struct Source {
     // .gz: inflated text arrives as numbered chunks; `ready` hands them to window() in order
     std::vector<std::thread> inflaters;
     std::mutex m; std::condition_variable cv_data, cv_room;
-    struct Chunk {                               // a piece of inflated text: a vector (host inflaters) or a page-locked buffer (device)
-        std::vector<char> v; char* pin = nullptr; size_t n = 0, cap = 0;
-        const char* data() const { return pin ? pin : v.data(); }
-        size_t size() const { return pin ? n : v.size(); }
-    };
-    std::map<long, Chunk> ready;                 // chunk number -> text
-    std::vector<std::pair<char*, size_t>> pin_free;      // page-locked buffers of finished chunks, for the next ones
+    std::map<long, std::vector<char>> ready;     // chunk number -> text
     int zdev = -1;                               // >= 0: BGZF blocks are inflated on this HIP device (bmbs_inflate_bgzf)
+    // ... a window at a time, straight into the batch's page-locked window: no inflater threads, no chunk queue, and the newline counts
+    // come back with the text -- the host moves the compressed bytes into a staging buffer and nothing else
+    bool zdirect = false;
+    bmbs_ctx* zc = nullptr;
+    Pinned zstage;
+    std::vector<uint64_t> zblk, zout;
     long next_chunk = 0;                         // the chunk window() takes next
     long want_chunk = 0;                         // the chunk window() is waiting for (always admitted by push_chunk)
     size_t queued = 0, front_used = 0;
@@ -244,75 +244,12 @@ struct Source {
             inflater_exit();
         });
     }
-    // BGZF blocks inflated on the device, ~16 MiB of the compressed file per call, into page-locked buffers (the host of an MI355X
-    // box inflates ~7 GB/s with every core it is given; the device takes the compressed bytes -- a sixth of the text -- and returns
-    // the text at link speed).  false: no context on the device (the caller falls back to the host inflater)
-    bool device_inflater()
-    {
-        bmbs_params P; bmbs_default_params(&P);
-        bmbs_ctx* zc = bmbs_create(zdev, &P);
-        if (!zc) return false;
-        std::vector<uint64_t> blk, out;
-        for (;;) {
-            size_t a, e; long id;
-            blk.clear(); out.clear();
-            bool handover = false;
-            {
-                std::lock_guard<std::mutex> l(m);
-                if (gz_stop || znext >= zsize) break;
-                a = znext; id = zjob;
-                size_t q = a; uint64_t text = 0;
-                blk.push_back(0); out.push_back(0);
-                while (q < zsize && q - a < ((size_t)16 << 20)) {
-                    const size_t bs = bgzf_block(zmap + q, zsize - q);
-                    if (!bs) break;
-                    const size_t isz = bgzf_isize(zmap + q, bs);
-                    if (isz > 65536) { err = "corrupt BGZF block in the .gz input"; znext = zsize; q = a; break; }
-                    q += bs; text += isz;
-                    blk.push_back(q - a); out.push_back(text);
-                }
-                if (q == a) {
-                    if (err.empty()) {
-                        znext = zsize;
-                        if (pgz::gzip_header(zmap, zsize, a)) start_pgz(a, id);
-                        else err = "corrupt BGZF block header in the .gz input";
-                    }
-                    handover = true;
-                } else { zjob++; e = q; znext = q; }
-            }
-            if (handover) break;
-            Chunk c;
-            c.n = (size_t)out.back();
-            {
-                std::lock_guard<std::mutex> l(m);
-                for (size_t i = 0; i < pin_free.size(); i++)
-                    if (pin_free[i].second >= c.n) { c.pin = pin_free[i].first; c.cap = pin_free[i].second; pin_free.erase(pin_free.begin() + (long)i); break; }
-            }
-            if (!c.pin) {
-                c.cap = std::max<size_t>(c.n + c.n / 8 + 4096, (size_t)64 << 20);
-                c.pin = (char*)bmbs_host_alloc_kind(c.cap, 2);
-                if (!c.pin) { std::lock_guard<std::mutex> l(m); err = "cannot allocate page-locked memory for the inflated text"; znext = zsize; break; }
-            }
-            const int rc = bmbs_inflate_bgzf(zc, zmap + a, e - a, blk.data(), out.data(), (int64_t)blk.size() - 1, c.pin, c.n);
-            if (rc) {
-                std::lock_guard<std::mutex> l(m);
-                if (err.empty()) err = std::string(bmbs_last_error(zc));
-                pin_free.push_back(std::make_pair(c.pin, c.cap));
-                znext = zsize;
-                break;
-            }
-            push_chunk(id, std::move(c));
-        }
-        bmbs_destroy(zc);
-        return true;
-    }
-    void push_chunk(long id, std::vector<char>&& c) { Chunk k; k.v = std::move(c); push_chunk(id, std::move(k)); }
-    void push_chunk(long id, Chunk&& c)
+    void push_chunk(long id, std::vector<char>&& c)
     {
         std::unique_lock<std::mutex> l(m);
         // the chunk window() is waiting for always gets in; the others wait for room (text inflated ahead of its turn is bounded)
         cv_room.wait(l, [&] { return id == want_chunk || queued < ((size_t)768 << 20) || gz_stop; });
-        if (gz_stop) { if (c.pin) pin_free.push_back(std::make_pair(c.pin, c.cap)); return; }
+        if (gz_stop) return;
         queued += c.size();
         ready[id] = std::move(c);
         cv_data.notify_all();
@@ -344,11 +281,16 @@ struct Source {
             if (bgzf) {
                 const char* zd = getenv("BMBS_GZ_DEVICE");
                 if (zd && !strcmp(zd, "0")) zdev = -1;
-                const int n_inflaters = zdev >= 0 ? std::min(gz_threads_, 3) : gz_threads_;
+                if (zdev >= 0) {
+                    bmbs_params P0; bmbs_default_params(&P0);
+                    zc = bmbs_create(zdev, &P0);
+                    if (zc) { zdirect = true; zstage.kind = 1; return true; }
+                    zdev = -1;                                  // no context on the device: the host inflaters
+                }
+                const int n_inflaters = gz_threads_;
                 live_inflaters = n_inflaters;                   // (the threads count it down as they finish: not the loop bound)
                 for (int t = 0; t < n_inflaters; t++)
                     inflaters.emplace_back([this] {
-                        if (zdev >= 0 && device_inflater()) { inflater_exit(); return; }        // (no device, no context: the host loop below)
                         // every block is a gzip member of its own: the driver's own inflater (pgz.h) on known bytes -- no window in
                         // front of a block, no markers -- and the member's CRC-32 checked by carry-less multiplication
                         pgz::OutBuf<pgz::u8> ob;
@@ -444,6 +386,50 @@ struct Source {
             });
             if (bad) { err = std::string("read error on the FASTQ input: ") + strerror(bad); return false; }
             last = off + len == end;
+        } else if (zdirect) {
+            size_t have = carry.size();
+            if (have > cap) { err = "internal: carried text larger than the window"; return false; }
+            if (have) memcpy(dst, carry.data(), have);
+            carry.clear();
+            // the BGZF blocks whose text fits behind the carried bytes
+            const size_t a = znext;
+            size_t q = a; uint64_t text = 0;
+            zblk.clear(); zout.clear(); zblk.push_back(0); zout.push_back(0);
+            bool foreign = false;
+            while (q < zsize) {
+                const size_t bs = bgzf_block(zmap + q, zsize - q);
+                if (!bs) { foreign = true; break; }
+                const size_t isz = bgzf_isize(zmap + q, bs);
+                if (isz > 65536) { err = "corrupt BGZF block in the .gz input"; return false; }
+                if (have + text + isz > cap) break;
+                q += bs; text += isz;
+                zblk.push_back(q - a); zout.push_back(text);
+            }
+            if (foreign && q == a) {
+                // a member that is not a BGZF block: the rest of the file goes through the host's stream inflater (chunks)
+                if (!pgz::gzip_header(zmap, zsize, a)) { err = "corrupt BGZF block header in the .gz input"; return false; }
+                zdirect = false;
+                { std::lock_guard<std::mutex> l(m); znext = zsize; start_pgz(a, 0); }
+                carry.assign(dst, dst + have);
+                return window(pool, dst, cap, len_out, last, counts);
+            }
+            if (q == a && q < zsize) { err = "a BGZF block larger than the window"; return false; }
+            znext = q;
+            len = have + (size_t)text;
+            last = znext >= zsize;
+            const size_t nsb = (len + SUB_BLOCK - 1) / SUB_BLOCK;
+            counts.assign(nsb + 1, 0);
+            if (q > a) {
+                const size_t zbytes = q - a;
+                if (!zstage.need(zbytes + 64)) { err = "cannot allocate page-locked staging memory"; return false; }
+                const int T = pool.size() * 2;
+                const size_t per = ((zbytes + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+                pool.run(T, [&](int t) { const size_t x = std::min(zbytes, per * (size_t)t), y = std::min(zbytes, x + per); if (x < y) memcpy(zstage.p + x, zmap + a + x, y - x); });
+                const int rc = bmbs_inflate_bgzf(zc, zstage.p, zbytes, zblk.data(), zout.data(), (int64_t)zblk.size() - 1, dst + have, (uint64_t)text, counts.data(), (uint64_t)have);
+                if (rc) { err = bmbs_last_error(zc); return false; }
+            }
+            counts.resize(nsb);
+            for (size_t i = 0; i * SUB_BLOCK < have; i++) counts[i] += (uint32_t)count_nl(dst + i * SUB_BLOCK, std::min(SUB_BLOCK, have - i * SUB_BLOCK));
         } else {
             size_t have = std::min(carry.size(), cap);
             if (carry.size() > cap) { err = "internal: carried text larger than the window"; return false; }
@@ -460,7 +446,7 @@ struct Source {
                 cv_data.wait(l, [&] { return ready.count(chunk) != 0 || gz_done; });
                 auto it = ready.find(chunk);
                 if (it == ready.end()) { done = true; if (!err.empty()) return false; break; }
-                Chunk& f = it->second;                                              // (only this thread erases: the chunk stays put)
+                std::vector<char>& f = it->second;                                  // (only this thread erases: the chunk stays put)
                 l.unlock();
                 const size_t take = std::min(cap - have, f.size() - used);
                 pieces.push_back(Piece{f.data() + used, take, have});
@@ -489,7 +475,7 @@ struct Source {
             carry.clear();
             {
                 std::lock_guard<std::mutex> l(m);
-                for (long id : finished) { auto it = ready.find(id); if (it != ready.end()) { queued -= it->second.size(); if (it->second.pin) pin_free.push_back(std::make_pair(it->second.pin, it->second.cap)); ready.erase(it); } }
+                for (long id : finished) { auto it = ready.find(id); if (it != ready.end()) { queued -= it->second.size(); ready.erase(it); } }
                 next_chunk = chunk; want_chunk = chunk; front_used = used;
                 cv_room.notify_all();
             }
@@ -515,16 +501,20 @@ struct Source {
             if (pgz_watch.joinable()) pgz_watch.join();
             pgz_eng.reset();
         }
-        for (auto& kv : ready) if (kv.second.pin) bmbs_host_free(kv.second.pin);
         ready.clear();
-        for (auto& pf : pin_free) bmbs_host_free(pf.first);
-        pin_free.clear();
         if (zmap) munmap((void*)zmap, zsize);
         zmap = nullptr;
         if (fd >= 0) ::close(fd);
         fd = -1; gz = false;
     }
-    ~Source() { close(); }
+    // the device side of a compressed source (context, staging): released apart from close(), outside a driver's timed region
+    void release_device()
+    {
+        if (zc) bmbs_destroy(zc);
+        zc = nullptr;
+        zstage.release();
+    }
+    ~Source() { close(); release_device(); }
 };
 
 // offset just behind the k-th newline of a window whose blocks have been counted
@@ -1112,7 +1102,7 @@ int main(int argc, char** argv)
                 if (pt->can_alloc && pt->out_off + len > pt->alloc_end) {
                     const size_t step = std::max<size_t>((size_t)4 << 30, 2 * len);
                     if (fallocate(pt->ofd, 0, (off_t)pt->alloc_end, (off_t)(pt->out_off + len + step - pt->alloc_end)) == 0) pt->alloc_end = pt->out_off + len + step;
-                    else pt->can_alloc = false;                                     // not a regular file (/dev/null, a pipe), or a file system without it
+                    else { pt->can_alloc = false; if (verbose && pt->alloc_end == 0) fprintf(stderr, "[bmbs_search] part %d: fallocate not available on the output (%s): one writer per batch\n", pt->id, strerror(errno)); }      // not a regular file (/dev/null, a pipe), or a file system without it
                 }
                 const int T = pt->can_alloc ? wpool.size() : 1;
                 const size_t per = ((len + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
@@ -1184,6 +1174,7 @@ int main(int argc, char** argv)
     print_stats(stderr, st);
     if (!mapstats.empty()) { FILE* m = fopen(mapstats.c_str(), "w"); if (m) { print_stats(m, st); fclose(m); } }
     const double t_end = now();
+    for (int p = 0; p < live_parts; p++) { P_[(size_t)p]->s1.release_device(); P_[(size_t)p]->s2.release_device(); }
     if (verbose)
         fprintf(stderr, "[bmbs_search] records %ld  load+attach %.3fs  mapping wall %.3fs  (pipeline %.3fs; stage busy, summed over %d part(s): read + newline count %.3fs, gpu calls %.3fs over %d context(s), host format %.3fs, write %.3fs)  %d I/O threads, batch %ld, %zu device(s) x %d context(s), %d output part(s)\n",
                 total_records, t_loaded - t_start, t_end - t_loaded, t_joined - t_loaded, live_parts, t_read, t_gpu, n_ctx, t_format, t_write, io_threads, batch,

@@ -187,7 +187,7 @@ class Mapper:
                                                  C.byref(used), C.byref(lines)))
         return out[:used.value].tobytes()
 
-    def inflate_bgzf(self, data: bytes) -> bytes:
+    def inflate_bgzf(self, data: bytes, shift: int | None = None):
         """the text of a BGZF byte string (bgzip's format), inflated on the device (bmbs_inflate_bgzf); raises on a malformed block"""
         import struct
         blk = [0]; out = [0]
@@ -200,8 +200,12 @@ class Mapper:
         a = np.frombuffer(data, dtype=np.uint8)
         b = np.array(blk, dtype=np.uint64); o = np.array(out, dtype=np.uint64)
         text = np.empty(max(1, out[-1]), dtype=np.uint8)
-        self._chk(self._lib.bmbs_inflate_bgzf(self._ctx, capi.ptr(a), a.size, capi.ptr(b), capi.ptr(o), n, capi.ptr(text), out[-1]))
-        return text[:out[-1]].tobytes()
+        if shift is None:
+            self._chk(self._lib.bmbs_inflate_bgzf(self._ctx, capi.ptr(a), a.size, capi.ptr(b), capi.ptr(o), n, capi.ptr(text), out[-1], None, 0))
+            return text[:out[-1]].tobytes()
+        cnt = np.zeros(max(1, (shift + out[-1] + 65535) >> 16), dtype=np.uint32)
+        self._chk(self._lib.bmbs_inflate_bgzf(self._ctx, capi.ptr(a), a.size, capi.ptr(b), capi.ptr(o), n, capi.ptr(text), out[-1], capi.ptr(cnt), shift))
+        return text[:out[-1]].tobytes(), cnt
 
     def sync(self):
         self._chk(self._lib.bmbs_sync(self._ctx))

@@ -268,9 +268,12 @@ int bmbs_map_pe_text(bmbs_ctx*, const char* text1, uint64_t bytes1, const char* 
  * inflated here by one wave per block, CRC-32 and ISIZE of every block checked.  comp = the bytes of n_blocks consecutive blocks
  * (block i at comp + blk_off[i], blk_off[n_blocks] = their end), text receives block i's bytes at text + out_off[i]
  * (out_off[i + 1] - out_off[i] = the ISIZE in block i's trailer).  Needs no index.  BMBS_EINVAL (bmbs_last_error says which
- * block) for anything zlib's inflate would refuse or a CRC that does not match.  Page-locked `text` moves at link speed.         */
+ * block) for anything zlib's inflate would refuse or a CRC that does not match.  Page-locked `text` moves at link speed.
+ * nl_per_64k (optional): what the driver's reader would otherwise count on the host -- the newlines of the inflated text per 64 KiB
+ * of the caller's WINDOW, in which text byte i sits at offset window_shift + i: nl_per_64k[j] = newlines among the bytes at window
+ * offsets [j * 65536, (j + 1) * 65536); (window_shift + text length + 65535) / 65536 entries.                                  */
 int bmbs_inflate_bgzf(bmbs_ctx*, const void* comp, uint64_t comp_bytes, const uint64_t* blk_off, const uint64_t* out_off, int64_t n_blocks,
-                      char* text, uint64_t text_bytes);
+                      char* text, uint64_t text_bytes, uint32_t* nl_per_64k, uint64_t window_shift);
 
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
  * error bases} (Schema.cpp:25141-25146); bmbs_stats_allreduce sums them over the ctxs one process

@@ -1319,6 +1319,12 @@ def test_device_bgzf_inflate_equals_zlib(env):
             o = zlib.decompressobj(31); ref += o.decompress(d); d = o.unused_data
         got = m.inflate_bgzf(z)
         assert got == ref, (name, len(got), len(ref))
+        # ... and the newline counts per 64 KiB of a window in which the text starts `shift` bytes in
+        for shift in (0, 1, 40000, 65536, 70001):
+            got2, cnt = m.inflate_bgzf(z, shift=shift)
+            arr = np.frombuffer(b"\0" * shift + ref, dtype=np.uint8) == 10
+            want = [int(arr[i:i + 65536].sum()) for i in range(0, max(1, arr.size), 65536)]
+            assert got2 == ref and cnt.tolist()[:len(want)] == want, (name, shift)
     good = cases["l6"]
     first = struct.unpack("<H", good[16:18])[0] + 1
     for name, pos, xor in (("flipped_bit", 30, 0x10), ("crc", first - 8, 0x01), ("isize_vs_data", 40, 0x80)):
