@@ -50,10 +50,21 @@ def bam_body(path):
     return head + recs
 
 
-def write_fq(path, reads, lens, rng, lower):
+def write_fq(path, reads, lens, rng, lower, bgzf=False):
     import gzip
     seq, qual = reads["seq"], reads["qual"]
-    with (gzip.open(path, "wb", compresslevel=1) if path.endswith(".gz") else open(path, "wb")) as f:
+    if bgzf:
+        # bgzip's block format (blocks of a drawn size; the driver inflates them on the device)
+        from common import write_bgzf
+        text = []
+        for i in range(seq.shape[0]):
+            s = seq[i, :lens[i]].tobytes()
+            if lower and rng.random() < 0.3:
+                s = s.lower()
+            text.append(b"@r%d some comment\n" % i + s + b"\n+\n" + qual[i, :lens[i]].tobytes() + b"\n")
+        write_bgzf(path, b"".join(text), block=int(rng.choice([700, 5000, 40000, 65280])), level=int(rng.choice([1, 6])))
+        return
+    with (gzip.open(path, "wb", compresslevel=int(rng.choice([1, 6, 9]))) if path.endswith(".gz") else open(path, "wb")) as f:
         for i in range(seq.shape[0]):
             s = seq[i, :lens[i]].tobytes()
             if lower and rng.random() < 0.3:
@@ -64,6 +75,9 @@ def write_fq(path, reads, lens, rng, lower):
 def draw(rng):
     mode = ["se", "se_pbat", "pe", "pes"][int(rng.integers(0, 4))]
     L = int(rng.choice([int(rng.integers(30, 70)), int(rng.integers(70, 160)), int(rng.integers(160, 251))]))
+    long_reads = bool(rng.integers(0, 10) == 0)
+    if long_reads:
+        L = int(rng.integers(251, 999))            # one trial in ten: up to 998 bases, the longest read the reference itself handles
     mp_max = int(rng.integers(2, 9))
     goe_open = int(rng.integers(2, 9))
     opt = ["-e", str(float(rng.choice([0.02, 0.04, 0.08, 0.1, 0.12])))]
@@ -75,7 +89,7 @@ def draw(rng):
         opt += ["--unmapped_out"]
     if rng.random() < 0.4:
         opt += ["--ambiguous_out"]
-    t = dict(mode=mode, L=L, n=int(rng.integers(1500, 5000)), seed=int(rng.integers(1, 1 << 30)), sub=float(rng.choice([0.0, 0.01, 0.04, 0.07])),
+    t = dict(mode=mode, L=L, n=int(rng.integers(1500, 5000)) if not long_reads else int(rng.integers(200, 800)), seed=int(rng.integers(1, 1 << 30)), sub=float(rng.choice([0.0, 0.01, 0.04, 0.07])),
              indel=float(rng.choice([0.0, 0.001, 0.003])), n_rate=float(rng.choice([0.0, 0.002, 0.02])), mixed=bool(rng.integers(0, 2)),
              lower=bool(rng.integers(0, 4) == 0), opt=opt)
     if mode in ("pe", "pes"):
@@ -90,14 +104,15 @@ def draw(rng):
         while int(e * shortest) < 1:
             e = round(e + 0.02, 2)
         t["opt"][1] = str(e)
-        mx = int(rng.choice([400, 500, 700]))
+        mx = int(rng.choice([400, 500, 700])) if not long_reads else L + int(rng.choice([200, 500]))
         t["opt"] += ["--min", str(int(rng.choice([0, 0, 80]))), "--max", str(mx)]
         t["ins_hi"] = max(L + 40, mx + int(rng.integers(-50, 60)))
         if mode == "pes":
             t["opt"] += ["--sensitive"]
     if mode == "se_pbat":
         t["opt"] += ["--pbat"]
-    t["gz"] = bool(rng.integers(0, 5) == 0) and not USE_ORACLE            # gzipped FASTQ input
+    t["gz"] = bool(rng.integers(0, 4) == 0) and not USE_ORACLE            # gzipped FASTQ input ...
+    t["bgzf"] = bool(t["gz"] and rng.integers(0, 2) == 0)                 # ... half of it in bgzip's block format (inflated on the device)
     if rng.integers(0, 5) == 0 and not USE_ORACLE:
         t["opt"] += ["--bam"]
     return t
@@ -115,7 +130,7 @@ def run_trial(t, env, wd):
             comp = np.arange(256, dtype=np.uint8); comp[ord("A")] = ord("T"); comp[ord("T")] = ord("A"); comp[ord("C")] = ord("G"); comp[ord("G")] = ord("C")
             r = dict(seq=comp[r["seq"][:, ::-1]].copy(), qual=r["qual"][:, ::-1].copy())
         lens = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
-        fq = os.path.join(wd, "r.fq" + (".gz" if t.get("gz") else "")); write_fq(fq, r, lens, rng, t["lower"])
+        fq = os.path.join(wd, "r.fq" + (".gz" if t.get("gz") else "")); write_fq(fq, r, lens, rng, t["lower"], t.get("bgzf", False))
         inp = ["--seq", fq]
     else:
         m1, m2 = synth.make_reads_pe(env["chroms"], n=n, L=L, seed=t["seed"], sub=t["sub"], indel=t["indel"], qual="random", ins_hi=t["ins_hi"])
@@ -127,7 +142,7 @@ def run_trial(t, env, wd):
         l1 = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
         l2 = rng.integers(max(20, L // 3), L + 1, n) if t["mixed"] else np.full(n, L)
         f1 = os.path.join(wd, "r_1.fq" + (".gz" if t.get("gz") else "")); f2 = os.path.join(wd, "r_2.fq" + (".gz" if t.get("gz") else ""))
-        write_fq(f1, m1, l1, rng, t["lower"]); write_fq(f2, m2f, l2, rng, t["lower"])
+        write_fq(f1, m1, l1, rng, t["lower"], t.get("bgzf", False)); write_fq(f2, m2f, l2, rng, t["lower"], t.get("bgzf", False))
         inp = ["--seq1", f1, "--seq2", f2]
     outs = {}
     # the driver's own knobs vary too: batch size (records per library call), host threads, contexts per device

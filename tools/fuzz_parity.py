@@ -20,15 +20,19 @@ def draw(rng):
     """one random trial description (plain dict, JSON-able)"""
     mode = ["se", "pe", "pes"][int(rng.integers(0, 3))]
     L = int(rng.choice([int(rng.integers(20, 60)), int(rng.integers(60, 160)), int(rng.integers(160, 301))]))
+    if rng.integers(0, 10) == 0:
+        L = int(rng.integers(301, 999))            # one trial in ten: up to 998 bases, the longest read the reference itself handles
     mp_max = int(rng.integers(2, 11))
     prm = dict(e_f=float(rng.choice([0.0, 0.02, 0.04, 0.06, 0.08, 0.1, 0.12, 0.15])), mp_max=mp_max, mp_min=int(rng.integers(0, mp_max + 1)),
                np=int(rng.integers(0, 4)), gap_open=int(rng.integers(1, 9)), gap_ext=int(rng.integers(1, 6)), ambiguous_out=int(rng.integers(0, 2)))
-    t = dict(mode=mode, L=L, prm=prm, n=int(rng.integers(2000, 9000)), seed=int(rng.integers(1, 1 << 30)), sub=float(rng.choice([0.0, 0.005, 0.02, 0.05, 0.08])),
+    t = dict(mode=mode, L=L, prm=prm, n=int(rng.integers(2000, 9000)) if L <= 300 else int(rng.integers(300, 1200)), seed=int(rng.integers(1, 1 << 30)), sub=float(rng.choice([0.0, 0.005, 0.02, 0.05, 0.08])),
              indel=float(rng.choice([0.0, 0.0005, 0.003])), qual=str(rng.choice(["const", "random"])), conv=float(rng.choice([0.0, 0.5, 0.99])),
              n_rate=float(rng.choice([0.0, 0.0, 0.003, 0.02])), mixed=bool(rng.integers(0, 3) == 0))
     if mode != "se":
         prm["min_ins"] = int(rng.choice([0, 0, 50, 120])); prm["max_ins"] = int(rng.choice([300, 500, 500, 800]))
         prm["sensitive"] = 1 if mode == "pes" else 0
+        if L > 300:
+            prm["max_ins"] = L + int(rng.choice([200, 500]))
         t["ins_hi"] = int(max(L + 40, prm["max_ins"] + int(rng.integers(-60, 80))))
     return t
 
