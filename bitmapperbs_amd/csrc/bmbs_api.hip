@@ -54,58 +54,39 @@ struct Arena {
 
 struct Prof { const char* name; hipEvent_t a, b; bool used; };
 
-// A/B switches (environment), read ONCE when a context is created -- never on the launch path.  All forms give identical results
-// (the GPU tests run them); DESIGN.md section 3 lists what each one selects.
+// Switches (environment), read ONCE when a context is created -- never on the launch path.  Every form gives identical results and the
+// GPU suite runs each one in single-end and paired-end mode (test_ab_switches_give_identical_records); DESIGN.md section 3 lists them.
+//   forms:      BMBS_LEGACY=1 (the round-1 ASCII-row seeding engine and byte-wise mate preparation, as a whole), BMBS_SW=reg2|reg|wave,
+//               BMBS_KGRAM=0|1|2, BMBS_T20=0, BMBS_TDEPTH=20|21, BMBS_WIDE=1 (+ BMBS_SUPER_SHIFT), BMBS_LANES=n, BMBS_EXACT=1, BMBS_SEED_WAVES=n
+//   test aids:  BMBS_CAP_SCALE, BMBS_SPLIT_MIN, BMBS_CHUNK, BMBS_PEF_LONG=2 (make small inputs reach the paths large ones take)
 struct Knobs {
     int sw_form = 0;            // BMBS_SW: 0 default (reg2 from k = 5), 1 reg, 2 reg2, 3 wave
-    bool rows_ascii = false;    // BMBS_ROWS=ascii
+    bool rows_ascii = false;    // BMBS_LEGACY=1: seeding on the ASCII rows (no packed copy), mate 2 prepared byte-wise with its full ASCII text
     int seed_waves = 65536;     // BMBS_SEED_WAVES
-    int decide = 0;             // BMBS_DECIDE: 0 default, 1 plain, 2 lds, 3 vec8
-    bool extra_plds = true;
-    bool vote_class4 = true;   // BMBS_VOTE_CLASS4=0: no 2048-key form between the 1024- and the 4096-key one (single-end k_vote_big 6.3 -> 5.1 ms with it)
-    bool pesv_long = true;     // BMBS_PESV_LONG=0: every re-seeded mate's candidates sorted by one lane (the round-2 form)
-    int vote_class3 = 128;     // BMBS_VOTE_CLASS3: 0 = one block form for all handed-over lists, 128 / 256 = threads of the <= 1024-key form (measured: 2.77 / 2.22 / 2.84 ms)
-    bool extra_nolds = false, extra_lds = false, vote_split = false, vote_nomid = false, pe_ascii_full = false;
     bool exact = false;         // BMBS_EXACT=1: every call waits for its stage counts (the round-2 launch sequence)
     int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
-    int pef_long = 1;           // BMBS_PEF_LONG: 0 k_pe_filter_pairs walks every pair's lists with one lane (round 2), 1 long lists get a wave when the input is repeat-rich, 2 always
-    bool copy_streams = true;   // BMBS_COPY_STREAMS=0: the text calls' copies go on the lane's kernel stream
-    bool copy_lock = true;      // BMBS_COPY_LOCK=0: the text calls of different contexts copy at the same time
-    bool arena = true;          // BMBS_ARENA=0: every work buffer a hipMalloc of its own (round 2)
+    int pef_long = 1;           // BMBS_PEF_LONG: 1 long lists of k_pe_filter_pairs get a wave when the input is repeat-rich, 2 always (tests)
     int kgram = 1;              // BMBS_KGRAM: 0 no trigram table, 1 (default) its kernels are used once a context has seen reads that walk the index in long chains, 2 always
-    int exp = 0;                // BMBS_EXP: timing experiments (results are WRONG with it): 1 = k_seed_extra stores no seed records
     double cap_scale = 1.0;     // BMBS_CAP_SCALE: scales the learned capacities (tests: a small value forces the repeat-with-exact-sizes path)
+    static const bool copy_streams = true, copy_lock = true, arena = true;     // (measured in round 3; the alternatives are gone)
     void read()
     {
         auto is = [](const char* e, const char* v) { return e && !strcmp(e, v); };
         const char* e = getenv("BMBS_SW");
         sw_form = is(e, "reg") ? 1 : is(e, "reg2") ? 2 : is(e, "wave") ? 3 : 0;
-        rows_ascii = is(getenv("BMBS_ROWS"), "ascii");
+        rows_ascii = is(getenv("BMBS_LEGACY"), "1");
         if ((e = getenv("BMBS_SEED_WAVES"))) seed_waves = atoi(e);
-        e = getenv("BMBS_DECIDE");
-        decide = is(e, "plain") ? 1 : is(e, "lds") ? 2 : is(e, "vec8") ? 3 : 0;
-        if (const char* e = getenv("BMBS_EXTRA_PLDS")) extra_plds = atoi(e) != 0;
-        if (const char* e = getenv("BMBS_VOTE_CLASS4")) vote_class4 = atoi(e) != 0;
-        if (const char* e = getenv("BMBS_PESV_LONG")) pesv_long = atoi(e) != 0;
-        if (const char* e = getenv("BMBS_VOTE_CLASS3")) vote_class3 = atoi(e);
-        extra_nolds = getenv("BMBS_EXTRA_NOLDS") != nullptr; extra_lds = getenv("BMBS_EXTRA_LDS") != nullptr;
-        vote_split = is(getenv("BMBS_VOTE"), "split"); vote_nomid = getenv("BMBS_VOTE_NOMID") != nullptr;
-        pe_ascii_full = is(getenv("BMBS_PE_ASCII"), "full");
         exact = is(getenv("BMBS_EXACT"), "1");
         if ((e = getenv("BMBS_LANES"))) lanes = atoi(e);
         if (lanes < 1) lanes = 1;
         if (lanes > 8) lanes = 8;
         if ((e = getenv("BMBS_KGRAM"))) kgram = atoi(e);
-        if ((e = getenv("BMBS_EXP"))) exp = atoi(e);
         if ((e = getenv("BMBS_CHUNK"))) chunk = atol(e);
         if ((e = getenv("BMBS_SPLIT_MIN"))) split_min = atol(e);
         if (split_min < 1) split_min = 1;
         if ((e = getenv("BMBS_CAP_SCALE"))) cap_scale = atof(e);
-        arena = !is(getenv("BMBS_ARENA"), "0");
-        copy_lock = !is(getenv("BMBS_COPY_LOCK"), "0");
-        copy_streams = !is(getenv("BMBS_COPY_STREAMS"), "0");
         if ((e = getenv("BMBS_PEF_LONG"))) pef_long = atoi(e);
     }
 };
@@ -611,23 +592,13 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
     else hipLaunchKernelGGL(k_seed_first<false>, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
     prof_end(c);
     prof_begin(c, "k_seed_decide");
-    // rows staged through LDS (each read fetched from HBM exactly once, coalesced) + 8 characters per compare step;
-    // BMBS_DECIDE=plain|lds|vec8 select the other forms for A/B measurements.  (An 8-lanes-per-read form without
-    // staging was measured at 2.07 ms against 1.36 ms: the per-read bookkeeping, replicated eight times, costs more than it saves.)
-    const int dv = c->kn.decide;
+    // rows staged through LDS (each read fetched from HBM exactly once, coalesced) + 8 characters per compare step.  (An
+    // 8-lanes-per-read form without staging was measured at 2.07 ms against 1.36 ms; the un-staged and the one-character forms of
+    // round 1 were removed in round 4.)
     const bool lds_ok = (size_t)64 * (stride + 8) <= 48 * 1024;
-    if (packed_rows && !dv)
+    if (packed_rows)
         hipLaunchKernelGGL(k_seed_decide_p, dim3(nblk(n, 64)), dim3(64), (size_t)64 * (pr.pwords + 1) * 8, c->stream, c->ix, d_seq, pr, gm, stride,
                            (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
-    else if (dv == 1)
-        hipLaunchKernelGGL((k_seed_decide<false, false>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
-                           c->prm.seed_len, pe_mode, st, sc, cnt);
-    else if (dv == 3)
-        hipLaunchKernelGGL((k_seed_decide<false, true>), dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, d_seq, gm, stride, (long)n,
-                           c->prm.seed_len, pe_mode, st, sc, cnt);
-    else if (dv == 2 && lds_ok)
-        hipLaunchKernelGGL((k_seed_decide<true, false>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, gm,
-                           stride, (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
     else if (lds_ok)
         hipLaunchKernelGGL((k_seed_decide<true, true>), dim3(nblk(n, 64)), dim3(64), (size_t)64 * (stride + 8), c->stream, c->ix, d_seq, gm,
                            stride, (long)n, c->prm.seed_len, pe_mode, st, sc, cnt);
@@ -654,17 +625,17 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
         const size_t lds = 64 * (size_t)(stride + 16);
         // ... and, measured, only while the index gathers are short: on a GRCh38-size index (wide forms) every gather is an HBM
         // round trip and the 11 KB of LDS per wave cost more occupancy (3.5 instead of 8 waves per SIMD) than the coalesced rows
-        // save: 4.20 ms with LDS rows, 3.93 ms without on the configs[2] batch (BMBS_EXTRA_LDS=1 / BMBS_EXTRA_NOLDS=1 force either)
+        // save: 4.20 ms with LDS rows, 3.93 ms without on the configs[2] batch
         const bool wide_ix = c->ix.sa64 != nullptr;
-        const int rows_in_lds = lds <= 48 * 1024 && !c->kn.extra_nolds && (!wide_ix || c->kn.extra_lds);
-        // packed rows: the lane's row in its LDS slot (4.6 KB per wave at 150 bases: no occupancy lost); BMBS_EXTRA_PLDS=0: from global memory
+        const int rows_in_lds = lds <= 48 * 1024 && !wide_ix;
+        // packed rows: the lane's row in its LDS slot (4.6 KB per wave at 150 bases: no occupancy lost); rows too long for 16 KB: from global memory
         const size_t plds = (size_t)64 * (pr.pwords + 1) * 8;
-        if (packed_rows && c->kn.extra_plds && plds <= 16 * 1024 && kg)
+        if (packed_rows && plds <= 16 * 1024 && kg)
             hipLaunchKernelGGL((k_seed_extra<false, true, true, true>), dim3(chunks_min), dim3(64), plds, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
-        else if (packed_rows && c->kn.extra_plds && plds <= 16 * 1024)
+        else if (packed_rows && plds <= 16 * 1024)
             hipLaunchKernelGGL((k_seed_extra<false, true, true>), dim3(chunks_min), dim3(64), plds, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
-                               target_waves, c->prm.seed_len, pe_mode | (c->kn.exp << 8), st, sc, cnt);
+                               target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
         else if (packed_rows)
             hipLaunchKernelGGL((k_seed_extra<false, true>), dim3(chunks_min), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, c->totals.as<u64>() + 4,
                                target_waves, c->prm.seed_len, pe_mode, st, sc, cnt);
@@ -716,18 +687,8 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
     const u64 t1 = exact ? std::max<u64>(tot, cap_from((double)tot / (double)n, n, n)) : tot;     // buffers as the next call (which does not wait) will want them
     ENS(c, c->cand, t1 * 8); ENS(c, c->votes, t1 * sizeof(bmbs_vote)); ENS(c, c->slot_read, t1 * 4);
     ENS(c, c->ferr, t1 * 4); ENS(c, c->fend, t1 * 4);
-    // locate + sort + votes; BMBS_VOTE=split runs the two-kernel form (k_locate, k_vote) for A/B measurements
-    if (c->kn.vote_split) {
-        if (tot) {
-            prof_begin(c, "k_locate");
-            hipLaunchKernelGGL(k_locate, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->ix, (long)n, st, c->cand.as<u64>());
-            prof_end(c);
-        }
-        prof_begin(c, "k_vote");
-        hipLaunchKernelGGL(k_vote, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, st, c->cand.as<u64>(),
-                           c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
-        prof_end(c);
-    } else {
+    // locate + sort + votes in one kernel per list-size class (the two-kernel form of round 1, k_locate + k_vote, was removed in round 4)
+    {
         ENS(c, c->long_flag, n * 4); ENS(c, c->long_off, (n + 1) * 8); ENS(c, c->long_list, n * 4); ENS(c, c->vote_list, n * 4);
         prof_begin(c, "k_vote_fused");
         // the reads that have candidates, compacted (the scan's list mode on n_cand != 0), so that the vote kernel's waves are dense
@@ -741,7 +702,7 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         // own (k_vote_mid); its flag and list live in the seeding work-list buffers, free by now
         // ... and on a repeat-rich genome also for short reads (seeds with many hits): taken when the last call left more than 0.5 % of
         // its reads to the long-list kernels (a wave per read)
-        const bool use_mid = (gm.L / 10 - 1 > VOTE_REG || c->lr_long > 0.005) && !c->kn.vote_nomid;
+        const bool use_mid = gm.L / 10 - 1 > VOTE_REG || c->lr_long > 0.005;
         u32* mid_flag = use_mid ? c->sd_flag_c.as<u32>() : nullptr;
         if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n * 4, c->stream));
         hipLaunchKernelGGL(k_vote_fused, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, st, c->cand.as<u64>(),
@@ -771,23 +732,12 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         // the handed-over lists in two size classes (as k_vote_pe_long): the <= 1024-key form needs 14 KB of LDS instead of 57 KB, so five
         // times as many reads are in flight -- the vote order (std::sort's permutation, one partition pass after the other) is a
         // chain of barriers, not work
-        if (c->kn.vote_class3 == 128)
-            hipLaunchKernelGGL((k_vote_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
-        else if (c->kn.vote_class3)
-            hipLaunchKernelGGL((k_vote_long<1024, 256, VM_CAP>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
-        if (c->kn.vote_class3 && c->kn.vote_class4) {
-            hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
-            hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
-        } else if (c->kn.vote_class3)
-            hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
-        else
-            hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                               c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((k_vote_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
         prof_end(c);
     }
     return BMBS_OK;
@@ -1164,12 +1114,10 @@ int map_se_dev(Lane* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int
     }
     prof_begin(c, "k_reduce");
     {
-        // over the compacted list of reads with candidates when the vote stage built one (BMBS_VOTE=split does not)
-        const bool listed = !c->kn.vote_split;
-        if (listed) {
-            HIPCHK(c, hipMemsetAsync(st.job_flag, 0, n * 4, c->stream));
-            HIPCHK(c, hipMemsetAsync(st.red_status, 0, n, c->stream));
-        }
+        // over the compacted list of reads with candidates the vote stage built
+        const bool listed = true;
+        HIPCHK(c, hipMemsetAsync(st.job_flag, 0, n * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(st.red_status, 0, n, c->stream));
         hipLaunchKernelGGL(k_reduce, dim3(nblk(n, 256)), dim3(256), 0, c->stream, (long)n, c->prm.ambiguous_out, st, c->vote_off.as<u64>(),
                            c->votes_dense.as<bmbs_vote>(), c->ferr.as<u32>(), c->fend.as<int>(), c->totals.as<u64>() + 10,
                            listed ? c->vote_list.as<u32>() : (const u32*)nullptr);
@@ -1279,9 +1227,8 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
             prow = c->prow.as<u64>(); pdirty = c->prow_dirty.as<u32>(); prepacked = true;
         }
         // on packed rows nothing reads the ASCII rows except under a set bit of the mask plane, so only those pieces are written
-        // (BMBS_PE_ASCII=full keeps the complete copy)
-        // ... and BMBS_DECIDE selects an ASCII form of k_seed_decide, which reads whole rows: no sparse copy then
-        const int sparse = prow && !c->kn.pe_ascii_full && c->kn.decide == 0;
+        // (BMBS_LEGACY=1: no packed rows, the complete ASCII copy)
+        const int sparse = prow != nullptr;
         prof_begin(c, "k_pe_prepare");
         const int ppr = stride / 16;
         if (sparse && ppr <= 256) {
@@ -1326,7 +1273,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     // reads of 180 bases and more place up to 25 seeds: lists of 17..32 candidates are the rule there and get a kernel of their own
     // (k_vote_pe_mid; buffers of its own: --sensitive still reads the seeding flags afterwards)
     // (on a repeat-rich genome also for short reads: when the last call left more than 0.5 % of its reads to the long-list kernels)
-    const bool use_mid = (gm.L / 10 - 1 > VOTE_REG || c->lr_long > 0.005) && !c->kn.vote_nomid;
+    const bool use_mid = gm.L / 10 - 1 > VOTE_REG || c->lr_long > 0.005;
     if (use_mid) { ENS(c, c->pe_mid_flag, n2 * 4); ENS(c, c->pe_mid_list, n2 * 4); }
     u32* mid_flag = use_mid ? c->pe_mid_flag.as<u32>() : nullptr;
     if (use_mid) HIPCHK(c, hipMemsetAsync(mid_flag, 0, n2 * 4, c->stream));
@@ -1353,24 +1300,12 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     prof_begin(c, "k_vote_pe_big");
     // the handed-over lists in two size classes: up to 1024 candidates (10 KB of LDS per block: twice the blocks per CU of the
     // 4096-key form; on the GRCh38-like genome 88 % of the handed-over lists), and the rest
-    if (c->kn.vote_class3 == 128) {
-        hipLaunchKernelGGL((k_vote_pe_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
-    } else if (c->kn.vote_class3) {
-        hipLaunchKernelGGL((k_vote_pe_long<1024, 256, VM_CAP>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
-    }
-    if (c->kn.vote_class3 && c->kn.vote_class4) {
-        hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
-        hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
-    } else if (c->kn.vote_class3)
-        hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
-    else
-        hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, VM_CAP>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                           c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+    hipLaunchKernelGGL((k_vote_pe_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, ps,
+                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+    hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
+                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+    hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
+                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {
@@ -1464,8 +1399,8 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
             ENS(c, c->dense_read, rtot * 4); ENS(c, c->ferr, rtot * 4);
             ps.R = c->pe_R.as<PeCand>();
             prof_begin(c, "k_pes_vote");
-            // mates with more than PESV_LONG candidates are flagged, listed (slot 14) and sorted by a block each (BMBS_PESV_LONG=0: all by one lane)
-            u32* pv_flag = c->kn.pesv_long ? c->long_flag.as<u32>() : nullptr;     // n2 words: free again after the vote stage
+            // mates with more than PESV_LONG candidates are flagged, listed (slot 14) and sorted by a block each
+            u32* pv_flag = c->long_flag.as<u32>();                                  // n2 words: free again after the vote stage
             hipLaunchKernelGGL(k_pes_vote, dim3(nblk(rt[0], 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, pi, n_reseed, rlist,
                                c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B, pv_flag);
             if (pv_flag) {

@@ -1924,56 +1924,10 @@ k_seed_extra(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
 }
 
 // ================================================================================================
-// K5/K6 + a8: one candidate slot per lane
+// K5/K6 + a8-a10: locate, per-read candidate sort, run-length votes, reference vote order
 // ================================================================================================
-__global__ void __launch_bounds__(256)
-k_locate(DevIndex ix, long n, ReadState st, u64* __restrict__ cand)
-{
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (st.n_cand[r] == 0) return;
-    const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
-    const int ns = st.n_seeds[r];
-    u64 o = st.cand_off[r];
-    const u64 o_end = st.cand_off[r + 1];
-    for (int s = 0; s < ns && o < o_end; s++) {
-        const u64 sp = my[s].sp, adj = (u64)my[s].len + (u64)my[s].off;
-        const u32 h = my[s].hits;
-        for (u32 j = 0; j < h && o < o_end; j++)
-            cand[o++] = ix.total - ((sp >> 63) ? (sp & ~(1ull << 63)) : sa_at(ix, sp + j)) - adj;   // reverse_and_adjust_site, Schema.cpp:4669
-    }
-}
-
-// ================================================================================================
-// a9/a10: per-read candidate sort, run-length votes, reference vote order
-// ================================================================================================
-__global__ void __launch_bounds__(64)
-k_vote(long n, ReadGeom gm, ReadState st, u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read)
-{
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int k = gm.rk(gm.rl(r));
-    if (st.verdict[r] != 3) { st.n_votes[r] = 0; return; }
-    const u64 off = st.cand_off[r];
-    const long nc = (long)st.n_cand[r];
-    u64* c = cand + off;
-    sort_u64_asc(c, nc);
-    // generate_candidate_votes_shift (Schema.cpp:4687-4773)
-    bmbs_vote* v = votes + off;
-    long nv = 0;
-    u64 pre = c[0];
-    u32 vote = 1;
-    for (long i = 1; i < nc; i++) {
-        if (c[i] == pre) vote++;
-        else { v[nv].site = pre < (u64)k ? 0 : pre - (u64)k; v[nv].vote = vote; v[nv].pad = 0; nv++; vote = 1; pre = c[i]; }
-    }
-    v[nv].site = pre >= (u64)k ? pre - (u64)k : 0; v[nv].vote = vote; v[nv].pad = 0; nv++;
-    intro_sort_desc(v, nv);             // std::sort(votes, compare_seed_votes), Schema.cpp:24986
-    st.n_votes[r] = (u32)nv;
-    for (long i = 0; i < nc; i++) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
-}
-
-// k_locate + k_vote in one pass for the usual small candidate lists: up to VOTE_REG candidates are located straight into
+// (reverse_and_adjust_site, Schema.cpp:4669; generate_candidate_votes_shift, 4687-4773; std::sort(votes, compare_seed_votes), 24986)
+// locate and vote in one pass for the usual small candidate lists: up to VOTE_REG candidates are located straight into
 // registers, sorted by a fixed compare-exchange network and ranked (std::sort on <= 16 elements is libstdc++'s plain
 // insertion sort, i.e. stable: rank = votes larger + equal votes earlier), so the candidate array never goes through
 // memory and no per-lane sort runs on global memory.  Longer lists take the two-step path inside the same kernel.

@@ -685,15 +685,18 @@ def test_vote_order_kernels_give_std_sort_permutation(form, env, tmp_path):
 
 
 @pytest.mark.gpu
-def test_seed_extra_without_lds_rows_matches_oracle(env, monkeypatch):
-    """k_seed_extra<false>: the form for reads too long to stage 64 rows in LDS (forced here with BMBS_EXTRA_NOLDS=1)"""
+@pytest.mark.parametrize("legacy", [0, 1])
+def test_seed_extra_without_lds_rows_matches_oracle(env, monkeypatch, legacy):
+    """k_seed_extra without the rows in LDS: the form for reads too long to stage 64 rows there (packed rows: beyond 16 KB per
+    wave, i.e. reads of more than ~650 bases; ASCII rows under BMBS_LEGACY=1: beyond 48 KB)"""
     from bitmapperbs_amd import synth, mapper
-    monkeypatch.setenv("BMBS_EXTRA_NOLDS", "1")
-    r = synth.make_reads_se(env["chroms"], n=20000, L=150, seed=77, sub=0.04, indel=0.003, qual="random", n_rate=0.003)
+    if legacy:
+        monkeypatch.setenv("BMBS_LEGACY", "1")
+    r = synth.make_reads_se(env["chroms"], n=3000, L=800, seed=77, sub=0.04, indel=0.003, qual="random", n_rate=0.003)
     m = mapper.Mapper(env["ix"], 0, e_f=0.08)
-    res, pool = m.map_se(r["seq"], r["qual"], 150)
-    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 150)
-    assert not compare_records(res, pool, recs, 150)
+    res, pool = m.map_se(r["seq"], r["qual"], 800)
+    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], 800)
+    assert not compare_records(res, pool, recs, 800)
     assert (m.stats() == ost).all()
     m.close()
 
@@ -721,19 +724,37 @@ def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["BMBS_DECIDE=plain", "BMBS_DECIDE=lds", "BMBS_DECIDE=vec8", "BMBS_VOTE=split", "BMBS_VOTE_NOMID=1", "BMBS_SEED_WAVES=4096",
-                                  "BMBS_TDEPTH=21", "BMBS_SW=wave", "BMBS_SW=reg", "BMBS_ROWS=ascii", "BMBS_EXTRA_PLDS=0"])
-def test_ab_switches_give_identical_records(knob, env, monkeypatch):
-    """the alternative kernel forms kept for A/B measurements map exactly like the default ones"""
+@pytest.mark.parametrize("mode", ["se", "pe", "pe_sensitive"])
+@pytest.mark.parametrize("knob", ["BMBS_LEGACY=1", "BMBS_SW=wave", "BMBS_SW=reg", "BMBS_KGRAM=2", "BMBS_KGRAM=0", "BMBS_T20=0", "BMBS_TDEPTH=21", "BMBS_WIDE=1",
+                                  "BMBS_LANES=1", "BMBS_EXACT=1", "BMBS_SEED_WAVES=4096"])
+def test_ab_switches_give_identical_records(knob, mode, env, monkeypatch):
+    """every documented switch (bmbs_api.hip: struct Knobs) maps exactly like the default forms: single-end,
+    paired-end and --sensitive, reads with letters outside ACGT, lengths that are not a multiple of 16"""
     from bitmapperbs_amd import synth, mapper
     name, val = knob.split("=")
     monkeypatch.setenv(name, val)
-    L = 250 if name == "BMBS_VOTE_NOMID" else 150
-    r = synth.make_reads_se(env["chroms"], n=12000, L=L, seed=300 + len(knob), sub=0.03, indel=0.002, qual="random", n_rate=0.003)
-    m = mapper.Mapper(env["ix"], 0, e_f=0.08)
-    res, pool = m.map_se(r["seq"], r["qual"], L)
-    recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], L)
-    assert not compare_records(res, pool, recs, L)
+    if name == "BMBS_LANES":
+        monkeypatch.setenv("BMBS_SPLIT_MIN", "2000")
+    L = 251 if name == "BMBS_SW" else 150
+    sens = 1 if mode == "pe_sensitive" else 0
+    m = mapper.Mapper(env["ix"], 0, e_f=0.08, sensitive=sens)
+    if mode == "se":
+        r = synth.make_reads_se(env["chroms"], n=12000, L=L, seed=300 + len(knob), sub=0.03, indel=0.002, qual="random", n_rate=0.003)
+        res, pool = m.map_se(r["seq"], r["qual"], L)
+        recs, ost, cnt = env["oix"].map_se(orc.params(e_f=0.08), r["seq"], r["qual"], L)
+        assert not compare_records(res, pool, recs, L)
+    else:
+        m1, m2 = synth.make_reads_pe(env["chroms"], n=8000, L=L, seed=400 + len(knob), sub=0.05 if sens else 0.02, indel=0.002, qual="random", ins_hi=max(500, 2 * L + 50))
+        rng = np.random.default_rng(len(knob))
+        for mm in (m1, m2):
+            pos = rng.random(mm["seq"].shape) < 0.003
+            mm["seq"][pos] = np.frombuffer(b"NNNRY", dtype=np.uint8)[rng.integers(0, 5, int(pos.sum()))]
+        prm = dict(max_ins=max(500, 2 * L + 50))
+        m.close()
+        m = mapper.Mapper(env["ix"], 0, e_f=0.08, sensitive=sens, **prm)
+        res, pool = m.map_pe(m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+        recs, ost, _ = env["oix"].map_pe(orc.params(e_f=0.08, sensitive=sens, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], L)
+        assert not compare_pe(res, pool, recs, L)
     assert (m.stats() == ost).all()
     m.close()
 
@@ -790,14 +811,15 @@ def test_three_letter_index_steps_change_nothing_but_the_gathers(tmp_path, monke
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sensitive,rows", [(0, "packed"), (1, "packed"), (0, "ascii"), (1, "ascii")])
+@pytest.mark.parametrize("sensitive,rows", [(0, "packed"), (1, "packed"), (0, "ascii"), (1, "ascii")])     # ascii = BMBS_LEGACY=1
 def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive, rows):
     """the 21-mer form of the outcome table (3^21 entries, 84 GB: what a GRCh38-size index gets) forced on the test genome: the
     seeding engine reads five letters ahead instead of four; pairs in both modes against the oracle, with the seeding kernels on
     the packed rows k_pe_prepare writes (the paired-end default) and on the ASCII rows"""
     from bitmapperbs_amd import synth, mapper
     monkeypatch.setenv("BMBS_TDEPTH", "21")
-    monkeypatch.setenv("BMBS_ROWS", rows)
+    if rows == "ascii":
+        monkeypatch.setenv("BMBS_LEGACY", "1")
     m1, m2 = synth.make_reads_pe(env["chroms"], n=12000, L=150, seed=77 + sensitive, sub=0.03, indel=0.002, qual="random")
     # a few characters outside ACGT, 'N' and others, so that the not-ACGT plane of the packed rows is exercised by pairs too
     rng = np.random.default_rng(5)
@@ -818,12 +840,12 @@ def test_depth21_outcome_table_paired_end(env, monkeypatch, sensitive, rows):
 @pytest.mark.parametrize("L", [40, 101, 150, 251])
 def test_pe_prepare_forms_on_odd_lengths(env, monkeypatch, L, form, sensitive):
     """k_pe_prepare_p (the default: mate 2 reverse-complemented on the packed words, ASCII text kept only for the 16-byte pieces
-    that hold a character outside ACGT) against the byte-wise form (BMBS_PE_ASCII=full): fixed lengths that are and are not
+    that hold a character outside ACGT) against the byte-wise form (BMBS_LEGACY=1): fixed lengths that are and are not
     multiples of 16 / 32 / 64, then mates trimmed independently, with 'N' and other letters in both mates; fast mode and
     --sensitive (whose re-seeding, k_pes_reseed, searches the packed rows too)"""
     from bitmapperbs_amd import synth, mapper
     if form == "full":
-        monkeypatch.setenv("BMBS_PE_ASCII", "full")
+        monkeypatch.setenv("BMBS_LEGACY", "1")
     m1, m2 = synth.make_reads_pe(env["chroms"], n=6000, L=L, seed=900 + L, sub=0.05 if sensitive else 0.02, indel=0.002, qual="random",
                                  ins_hi=max(500, 2 * L + 50))
     rng = np.random.default_rng(L)
@@ -1527,16 +1549,14 @@ def both_mates_repeat_env(tmp_path_factory):
     ix.close(); oix.close()
 
 
-@pytest.mark.parametrize("form", ["block", "lane"])
+@pytest.mark.parametrize("form", ["block"])
 def test_sensitive_reseeded_mates_with_long_lists_match_oracle(both_mates_repeat_env, monkeypatch, form):
     """--sensitive on diverged pairs inside the repeat families: a mate left without a hit is re-seeded and its candidates (hundreds)
     are located, sorted, made distinct and tested against the verified mate's hits -- by a block per mate (k_pes_vote_long: binary
-    searches instead of the reference's running lower bound) or, BMBS_PESV_LONG=0, by one lane running the reference's loop;
+    searches instead of the reference's running lower bound; shorter lists by one lane running the reference's loop);
     with the default insert range and with a minimum insert (the lower bound of the distance above zero)"""
     from bitmapperbs_amd import synth, mapper
     e = both_mates_repeat_env
-    if form == "lane":
-        monkeypatch.setenv("BMBS_PESV_LONG", "0")
     m1, m2 = synth.make_reads_pe(e["chroms"], n=5000, L=100, seed=616, sub=0.05, indel=0.002, qual="random")
     for prm in (dict(), dict(min_ins=150, max_ins=600)):
         recs, ost, _ = e["oix"].map_pe(orc.params(sensitive=1, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
@@ -1547,16 +1567,13 @@ def test_sensitive_reseeded_mates_with_long_lists_match_oracle(both_mates_repeat
         m.close()
 
 
-@pytest.mark.parametrize("class3", ["128", "0", "256", "128-no2048"])
+@pytest.mark.parametrize("class3", ["128"])
 def test_long_lists_single_end_size_classes_match_oracle(both_mates_repeat_env, monkeypatch, class3):
     """single-end reads on the same genome: lists of hundreds of candidates through the three forms of k_vote_long (a wave; a block
     of 128 or 256 threads over up to 1024 keys; 256 threads over up to 4096) -- sites, votes and std::sort's visiting order must
-    be the same whichever form a list takes (BMBS_VOTE_CLASS3), with and without --ambiguous_out"""
+    be the same whichever form a list takes, with and without --ambiguous_out"""
     from bitmapperbs_amd import mapper
     e = both_mates_repeat_env
-    monkeypatch.setenv("BMBS_VOTE_CLASS3", class3.split("-")[0])
-    if class3.endswith("no2048"):
-        monkeypatch.setenv("BMBS_VOTE_CLASS4", "0")
     r = e["se"]
     for amb in (0, 1):
         recs, ost, cnt = e["oix"].map_se(orc.params(ambiguous_out=amb), r["seq"], r["qual"], 120)
@@ -1568,12 +1585,12 @@ def test_long_lists_single_end_size_classes_match_oracle(both_mates_repeat_env, 
         m.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "min_insert", "ambiguous_out", "sensitive", "one_block_form", "block_256", "no_2048_class"])
+@pytest.mark.parametrize("variant", ["default", "min_insert", "ambiguous_out", "sensitive"])
 def test_long_lists_on_both_mates_match_oracle(both_mates_repeat_env, monkeypatch, variant):
     """the wave-cooperative parts of k_pe_compact / k_pe_prune / k_pe_pair (lists of more than 64 entries on both mates: compaction by
     ballot, prune by binary search, pairing by ordered summaries) against the oracle's loops -- ties of the best error sum, the
     early exit at a second pair without errors, `second_best_diff`; with a minimum insert the reference's loop is order-dependent
-    and one lane runs it; the size classes of the block form of the vote kernel (BMBS_VOTE_CLASS3)"""
+    and one lane runs it"""
     from bitmapperbs_amd import mapper
     e = both_mates_repeat_env
     prm, sensitive = {}, 0
@@ -1583,12 +1600,6 @@ def test_long_lists_on_both_mates_match_oracle(both_mates_repeat_env, monkeypatc
         prm = dict(ambiguous_out=1)
     elif variant == "sensitive":
         sensitive = 1
-    elif variant == "one_block_form":
-        monkeypatch.setenv("BMBS_VOTE_CLASS3", "0")
-    elif variant == "block_256":
-        monkeypatch.setenv("BMBS_VOTE_CLASS3", "256")
-    elif variant == "no_2048_class":
-        monkeypatch.setenv("BMBS_VOTE_CLASS4", "0")
     m1, m2 = e["m1"], e["m2"]
     recs, ost, _ = e["oix"].map_pe(orc.params(sensitive=sensitive, **prm), m1["seq"], m1["qual"], m2["seq"], m2["qual"], 100)
     m = mapper.Mapper(e["ix"], 0, sensitive=sensitive, **prm)

@@ -30,7 +30,7 @@ def main():
         job.launch(0); m.sync()
         prof, calls = m.profile_total()
         print("call %d: " % rep + ", ".join("%s=%.2f" % (k, v) for k, v in sorted(prof.items(), key=lambda kv: -kv[1])[:10]))
-    # A/B of a knob the context reads when it is created: PROBE_AB="BMBS_VOTE_CLASS3=0,128,256"
+    # A/B of a knob the context reads when it is created: PROBE_AB="BMBS_SW=reg2,reg"
     ab = os.environ.get("PROBE_AB")
     if ab:
         key, vals = ab.split("=")
