@@ -2495,6 +2495,9 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
     for (u64 i = 0; i < n; i++)
         if (blk_off[i + 1] < blk_off[i] + 26 || out_off[i + 1] < out_off[i] || out_off[i + 1] - out_off[i] > 65536) { c->err = "inflate: malformed block table"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
+    static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;       // diagnostic: host-side phase times of every call
+    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double t0 = wall();
     ENS(c, c->z_comp, comp_bytes + 64); ENS(c, c->z_off, 2 * (n + 1) * 8 + 64); ENS(c, c->z_text, out_off[n] + 64); ENS(c, c->z_err, n * 4 + 64);
     hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
     hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
@@ -2502,6 +2505,7 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
     HIPCHK(c, hipMemcpyAsync(c->z_off.p, blk_off, (n + 1) * 8, hipMemcpyHostToDevice, us));
     HIPCHK(c, hipMemcpyAsync(c->z_off.as<u64>() + (n + 1), out_off, (n + 1) * 8, hipMemcpyHostToDevice, us));
     HIPCHK(c, hipStreamSynchronize(us));
+    const double t1 = wall();
     hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)n), dim3(64), 0, c->stream, c->z_comp.as<u8>(), c->z_off.as<u64>(), c->z_off.as<u64>() + (n + 1), (long)n,
                        c->z_text.as<char>(), c->z_err.as<u32>());
     const u64 n_cnt = nl_per_64k ? (window_shift + out_off[n] + 65535) >> 16 : 0;
@@ -2510,12 +2514,15 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
         hipLaunchKernelGGL(k_nl_count64k, dim3((unsigned)n_cnt), dim3(256), 0, c->stream, c->z_text.as<char>(), out_off[n], window_shift, c->z_nl.as<u32>());
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t2 = wall();
     std::vector<u32> err(n);
     HIPCHK(c, hipMemcpyAsync(err.data(), c->z_err.p, n * 4, hipMemcpyDeviceToHost, ds));
     if (n_cnt) HIPCHK(c, hipMemcpyAsync(nl_per_64k, c->z_nl.p, n_cnt * 4, hipMemcpyDeviceToHost, ds));
     int rc = d2h_chunked(c, text, c->z_text.as<char>(), out_off[n], ds);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(ds));
+    if (trace) fprintf(stderr, "[inflate] %lu blocks, %.1f MB -> %.1f MB: alloc+upload %.2f  kernel %.2f  download %.2f ms\n", (unsigned long)n, (double)comp_bytes / 1e6, (double)out_off[n] / 1e6,
+                       (t1 - t0) * 1e3, (t2 - t1) * 1e3, (wall() - t2) * 1e3);
     for (u64 i = 0; i < n; i++)
         if (err[i]) { c->err = "corrupt BGZF block in the .gz input (block " + std::to_string(i) + " of this window, code " + std::to_string(err[i]) + ")"; return BMBS_EINVAL; }
     return BMBS_OK;

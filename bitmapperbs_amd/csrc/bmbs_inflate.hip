@@ -180,6 +180,8 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     __syncthreads();
     InfBits in; in.init(z + body, z + zlen - 8);
     u32 n_out = 0;                                        // bytes of text written so far (wave-uniform)
+    u32 fenced = 0;                                       // every byte of the text below this offset is visible to every lane
+    char last_byte = 0;                                   // the byte at n_out - 1 (wave-uniform)
     bool last = false;
     while (!status && !last) {
         // ---- block header (lane 0 reads, the wave follows)
@@ -201,6 +203,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
             if (bad || at + len > zlen - 8 || n_out + len > isize) { status = 3; break; }
             for (u32 i = lane; i < len; i += 64) out[n_out + i] = (char)z[at + i];
             n_out += len;
+            if (len) last_byte = (char)z[at + len - 1];
             if (lane == 0) in.init(z + at + len, z + zlen - 8);
             continue;
         }
@@ -322,14 +325,25 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 if (n_out + ns > isize) { status = 5; break; }
                 for (u32 i = lane; i < ns; i += 64) out[n_out + i] = (char)s_stage[i];
                 n_out += ns;
+                last_byte = (char)s_stage[ns - 1];
             }
             if (ev == 2) {
                 if (mdist > n_out || n_out + mlen > isize) { status = 6; break; }
-                __threadfence_block();                                  // the bytes other lanes have just stored are read below
-                // source bytes repeat with period `mdist` when the match overlaps itself
-                for (u32 i = lane; i < mlen; i += 64) out[n_out + i] = out[n_out - mdist + (mdist >= mlen ? i : i % mdist)];
+                char myv = 0;
+                if (mdist == 1) {
+                    // a run of the byte before it (quality strings): no read at all
+                    myv = last_byte;
+                    for (u32 i = lane; i < mlen; i += 64) out[n_out + i] = myv;
+                } else {
+                    // bytes other lanes stored since the last fence are not visible to this lane yet: a fence only when the source
+                    // reaches into them (a fence waits for every store in flight: two per match were most of this kernel's time)
+                    const u32 src_end = mdist >= mlen ? n_out - mdist + mlen : n_out;
+                    if (src_end > fenced) { __threadfence_block(); fenced = n_out; }
+                    // source bytes repeat with period `mdist` when the match overlaps itself
+                    for (u32 i = lane; i < mlen; i += 64) { myv = out[n_out - mdist + (mdist >= mlen ? i : i % mdist)]; out[n_out + i] = myv; }
+                }
+                last_byte = (char)__shfl((int)myv, (int)((mlen - 1) & 63u));
                 n_out += mlen;
-                __threadfence_block();
             } else if (ev == 3) break;
             else if (ev == 9) { status = 7; break; }
         }

@@ -714,7 +714,7 @@ struct Part {                                    // one contiguous record range 
     int ofd = -1;
     size_t out_off = 0;
     size_t alloc_end = 0;                        // the file's blocks are reserved up to here (fallocate ahead of the writers)
-    bool can_alloc = true;
+    bool can_alloc = true, regular = false;
     OrderedChan<Batch*> out_q;
     long next_seq = 0;
     std::thread reader, writer;
@@ -977,6 +977,7 @@ int main(int argc, char** argv)
         if (parts > 1) { char suf[32]; snprintf(suf, sizeof suf, ".part%03d", p); path += suf; }
         pt.ofd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (pt.ofd < 0) { fprintf(stderr, "Cannot open %s\n", path.c_str()); return 1; }
+        { struct stat osb; pt.regular = fstat(pt.ofd, &osb) == 0 && S_ISREG(osb.st_mode); pt.can_alloc = pt.regular; }
         if (p == 0) {
             // OutPutSAM_Nounheader (Process_sam_out.cpp:1137-1153)
             std::string h = "@HD\tVN:1.4\tSO:unsorted\n";
@@ -1104,7 +1105,8 @@ int main(int argc, char** argv)
                     if (fallocate(pt->ofd, 0, (off_t)pt->alloc_end, (off_t)(pt->out_off + len + step - pt->alloc_end)) == 0) pt->alloc_end = pt->out_off + len + step;
                     else { pt->can_alloc = false; if (verbose && pt->alloc_end == 0) fprintf(stderr, "[bmbs_search] part %d: fallocate not available on the output (%s): one writer per batch\n", pt->id, strerror(errno)); }      // not a regular file (/dev/null, a pipe), or a file system without it
                 }
-                const int T = pt->can_alloc ? wpool.size() : 1;
+                // (no fallocate -- overlayfs says ENODEV: four slices still extend a regular file a little faster than one, 12.8 against 10 GB/s)
+                const int T = pt->can_alloc ? wpool.size() : (pt->regular ? std::min(4, wpool.size()) : 1);
                 const size_t per = ((len + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
                 wpool.run(T, [&](int t) {
                     size_t done = std::min(len, per * (size_t)t);
