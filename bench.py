@@ -944,9 +944,11 @@ def main():
         dom = max(mapping, key=mapping.get) if mapping else "k_seed_first"
         s8d, own = algorithmic_bytes(cnt, nr, L, k, pe)
         nat = native_bytes(cnt, 2 * cfg["genome"] + 1 >= (1 << 32))
-        tag = "r03_c%d" % args.config
-        if not os.path.exists(os.path.join(ROOT, "profiles", tag + "_pmc_fetch_write.csv")):
-            tag = "r02_c%d" % args.config
+        tag = "r02_c%d" % args.config
+        for rnd in ("r04", "r03"):                       # the newest committed PMC pass of this configuration
+            if os.path.exists(os.path.join(ROOT, "profiles", "%s_c%d_pmc_fetch_write.csv" % (rnd, args.config))):
+                tag = "%s_c%d" % (rnd, args.config)
+                break
         def rl(model):
             b = model.get(dom, 0)
             a = b / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0

@@ -4,10 +4,11 @@
 // series of independent gzip members of at most 64 KiB of text with their compressed size in the header: nothing in one block
 // depends on another, so a window of them is inflated here by one WAVE per block -- the host of an MI355X box (16 cores' worth of
 // CPU for the whole driver) inflates ~7 GB/s of text at best, a third of what the mapping path takes.
-//   lane 0 walks the Huffman codes (tables in LDS: 11-bit root for literals / lengths with two literals per entry where both codes
-//   fit, 10-bit root for distances; longer codes -- rare by construction -- by a canonical search), literals are staged in LDS and
-//   stored 64 lanes wide, matches are copied by the whole wave; the block's CRC-32 and ISIZE are checked against its trailer
-//   (segments combined with x^(8n) mod P as in bmbs_bam.hip).
+//   every lane decodes the token that would start at its own bit offset (tables in LDS: 11-bit root for literals / lengths with two
+//   literals per entry where both codes fit, 10-bit root for distances; longer codes -- rare by construction -- by a canonical search
+//   on lane 0), a walk from offset 0 picks the tokens that are really there (~12 per 64-bit window of FASTQ text), literals are stored
+//   by their lanes, matches copied by the whole wave; the block's CRC-32 and ISIZE are checked against its trailer (segments
+//   combined with x^(8n) mod P as in bmbs_bam.hip).
 // Everything zlib's inflate refuses is refused (err[block] != 0): over-subscribed / incomplete codes, missing end-of-block code,
 // reserved block type, distance too far back, stored-length check, output longer than the trailer says, CRC mismatch.
 #ifndef BMBS_INFLATE_HIP
@@ -15,7 +16,6 @@
 
 #define INF_LIT_ROOT 11
 #define INF_DIST_ROOT 10
-#define INF_STAGE 256
 
 // entry = value << 16 | extra bits (or literal count) << 8 | kind << 5 | code bits
 #define IK_BAD 0
@@ -147,7 +147,6 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     __shared__ u8 s_lens[320];
     __shared__ u16 s_sorted_l[288]; __shared__ u16 s_sorted_d[32]; __shared__ u16 s_sorted_c[20];
     __shared__ InfCode s_cl, s_cd, s_cc;
-    __shared__ u8 s_stage[INF_STAGE + 8];
     __shared__ u32 s_crc_tab[256];
     __shared__ u32 s_ev[8];                              // lane 0 -> wave: event, staged literals, match length, distance
     const long b = blockIdx.x;
@@ -268,85 +267,149 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         if (!ok) { status = 4; break; }
         inf_root(s_cl, false, s_lit, INF_LIT_ROOT, lane);
         inf_root(s_cd, true, s_dist, INF_DIST_ROOT, lane);
-        // ---- symbols: lane 0 decodes until something needs the wave (staging full, a match, the end of the block, an error)
-        for (;;) {
-            if (lane == 0) {
-                u32 ev = 0, ns = 0, mlen = 0, mdist = 0;
-                for (;;) {
-                    in.refill();
-                    u32 e = s_lit[in.buf & ((1u << INF_LIT_ROOT) - 1)];
-                    u32 kind = (e >> 5) & 7u;
-                    if (kind == IK_LONG) {
-                        int l; const int s = inf_search(s_cl, in.peek(15), INF_LIT_ROOT + 1, 15, l);
-                        if (s < 0) { ev = 9; break; }
-                        e = s < 256 ? inf_mk((u32)s, 1, IK_LIT, (u32)l) : s == 256 ? inf_mk(0, 0, IK_EOB, (u32)l)
-                            : s < 286 ? inf_mk(c_len_base[s - 257], c_len_extra[s - 257], IK_BASE, (u32)l) : inf_mk(0, 0, IK_BAD, (u32)l);
-                        kind = (e >> 5) & 7u;
-                    }
-                    in.drop((int)(e & 31u));
-                    if (kind == IK_LIT) {
-                        s_stage[ns] = (u8)(e >> 16); s_stage[ns + 1] = (u8)(e >> 24); ns += (e >> 8) & 31u;
-                        // further literals from the same refill (56 bits held; 15 + 3 x 11 used at most)
-                        for (int more = 0; more < 3 && ns < INF_STAGE - 2; more++) {
-                            in.refill();
-                            e = s_lit[in.buf & ((1u << INF_LIT_ROOT) - 1)];
-                            if (((e >> 5) & 7u) != IK_LIT) break;
-                            in.drop((int)(e & 31u));
-                            s_stage[ns] = (u8)(e >> 16); s_stage[ns + 1] = (u8)(e >> 24); ns += (e >> 8) & 31u;
-                        }
-                        if (ns >= INF_STAGE - 2) { ev = 1; break; }
-                        continue;
-                    }
-                    if (kind == IK_BASE) {
-                        mlen = (e >> 16) + in.take((int)((e >> 8) & 31u));
-                        in.refill();
-                        u32 d = s_dist[in.buf & ((1u << INF_DIST_ROOT) - 1)];
-                        if (((d >> 5) & 7u) == IK_LONG) {
-                            int l; const int s = inf_search(s_cd, in.peek(15), INF_DIST_ROOT + 1, 15, l);
-                            if (s < 0 || s >= 30) { ev = 9; break; }
-                            d = inf_mk(c_dist_base[s], c_dist_extra[s], IK_BASE, (u32)l);
-                        }
-                        if (((d >> 5) & 7u) != IK_BASE) { ev = 9; break; }
-                        in.drop((int)(d & 31u));
-                        in.refill();
-                        mdist = (d >> 16) + in.take((int)((d >> 8) & 31u));
-                        ev = 2; break;
-                    }
-                    if (kind == IK_EOB) { ev = 3; break; }
-                    ev = 9; break;
-                }
-                if (in.over()) ev = 9;
-                s_ev[0] = ev; s_ev[1] = ns; s_ev[2] = mlen; s_ev[3] = mdist;
+        // ---- symbols.  Every lane decodes the token that WOULD start at its own bit offset (bp + lane): one or two literals, a
+        // match with its length / distance codes and extra bits, or the end-of-block code -- two dependent LDS look-ups for all 64
+        // offsets at once.  The tokens that really are in the stream are the ones reached from offset 0 by following the token
+        // lengths: a walk over at most 64 lanes (one shuffle per token) that also hands every token its place in the text.  A
+        // 64-bit window holds ~12 tokens of FASTQ text; one lane decoding alone took ~0.5 us per token (200 MB in 9-16 ms).
+        u32 bp = 0;
+        if (lane == 0) bp = (u32)((in.p - z) * 8) - (u32)in.cnt;
+        bp = (u32)__shfl((int)bp, 0);
+        const u32 end_bits = (u32)(zlen - 8) * 8;
+        bool block_done = false;
+        while (!block_done && !status) {
+            if (bp > end_bits) { status = 7; break; }
+            // 160 bits from the aligned dword that holds bit bp (the same five words for every lane)
+            const size_t a = (size_t)z + (bp >> 3);
+            const u32* wp = reinterpret_cast<const u32*>(a & ~(size_t)3);
+            const u32 o = (u32)(a & 3) * 8 + (bp & 7u) + (u32)lane;                    // 0 .. 94
+            const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+            const u32 j = o >> 5, sh = o & 31u;
+            const u32 x0 = j == 0 ? d0 : j == 1 ? d1 : d2, x1 = j == 0 ? d1 : j == 1 ? d2 : d3, x2 = j == 0 ? d2 : j == 1 ? d3 : d4;
+            u64 v = (((u64)x1 << 32) | x0) >> sh;
+            if (sh) v |= (u64)x2 << (64 - sh);
+            // the token at this offset
+            const u32 e = s_lit[(u32)v & ((1u << INF_LIT_ROOT) - 1)];
+            const u32 kind = (e >> 5) & 7u;
+            u32 tb = e & 31u, ol = 0, flag = 0, mlen = 0, mdist = 0;                       // flag: 1 end of block, 2 long code (serial), 3 invalid
+            if (kind == IK_LIT) ol = (e >> 8) & 31u;
+            else if (kind == IK_BASE) {
+                const u32 ex = (e >> 8) & 31u;
+                mlen = (e >> 16) + ((u32)(v >> tb) & ((1u << ex) - 1u)); tb += ex;
+                const u32 d = s_dist[(u32)(v >> tb) & ((1u << INF_DIST_ROOT) - 1)];
+                const u32 dk = (d >> 5) & 7u;
+                if (dk == IK_BASE) {
+                    const u32 dx = (d >> 8) & 31u;
+                    tb += d & 31u;
+                    mdist = (d >> 16) + ((u32)(v >> tb) & ((1u << dx) - 1u)); tb += dx;
+                    ol = mlen;
+                } else flag = dk == IK_LONG ? 2u : 3u;
+            } else if (kind == IK_EOB) flag = 1;
+            else flag = kind == IK_LONG ? 2u : 3u;
+            // the chain from offset 0
+            const u32 packed = tb | (flag << 6) | (ol << 8);
+            u32 t = 0, run = n_out, stop = 0, stop_bits = 0, my_out = 0;
+            bool mine = false;
+            while (t < 64) {
+                const u32 p = (u32)__shfl((int)packed, (int)t);
+                if ((p >> 6) & 3u) { stop = (p >> 6) & 3u; stop_bits = p & 63u; break; }
+                if ((u32)lane == t) { mine = true; my_out = run; }
+                run += p >> 8; t += p & 63u;
             }
-            __syncthreads();
-            const u32 ev = s_ev[0], ns = s_ev[1], mlen = s_ev[2], mdist = s_ev[3];
-            __syncthreads();
-            if (ns) {
-                if (n_out + ns > isize) { status = 5; break; }
-                for (u32 i = lane; i < ns; i += 64) out[n_out + i] = (char)s_stage[i];
-                n_out += ns;
-                last_byte = (char)s_stage[ns - 1];
-            }
-            if (ev == 2) {
-                if (mdist > n_out || n_out + mlen > isize) { status = 6; break; }
+            if (run > isize) { status = 5; break; }
+            // literals first, then the matches in stream order (a match may read what the tokens before it have just stored)
+            const bool is_lit = mine && kind == IK_LIT, is_match = mine && kind == IK_BASE;
+            if (is_lit) { out[my_out] = (char)(e >> 16); if (ol == 2) out[my_out + 1] = (char)(e >> 24); }
+            const unsigned long long chain = __ballot(mine);
+            unsigned long long mm = __ballot(is_match);
+            char tail = last_byte;                                                       // the byte in front of the next token
+            while (mm) {
+                const int Lm = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const u32 mo = (u32)__shfl((int)my_out, Lm), ml = (u32)__shfl((int)mlen, Lm), md = (u32)__shfl((int)mdist, Lm);
+                if (md > mo) { status = 6; break; }
                 char myv = 0;
-                if (mdist == 1) {
-                    // a run of the byte before it (quality strings): no read at all
-                    myv = last_byte;
-                    for (u32 i = lane; i < mlen; i += 64) out[n_out + i] = myv;
+                // the byte in front of this match: the last literal of the token before it in this window, when that is a literal
+                const unsigned long long before = chain & ((1ull << Lm) - 1ull);
+                bool have_prev = false; char prev = 0;
+                if (before) {
+                    const int Lp = 63 - __builtin_clzll(before);
+                    const u32 pe = (u32)__shfl((int)e, Lp);
+                    if (((pe >> 5) & 7u) == IK_LIT) { have_prev = true; prev = (char)(((pe >> 8) & 31u) == 2 ? pe >> 24 : pe >> 16); }
+                } else { have_prev = mo == n_out; prev = tail; }
+                if (md == 1 && have_prev) {
+                    myv = prev;                                                          // a run of the byte before it (quality strings): no read at all
+                    for (u32 i = lane; i < ml; i += 64) out[mo + i] = myv;
                 } else {
-                    // bytes other lanes stored since the last fence are not visible to this lane yet: a fence only when the source
-                    // reaches into them (a fence waits for every store in flight: two per match were most of this kernel's time)
-                    const u32 src_end = mdist >= mlen ? n_out - mdist + mlen : n_out;
-                    if (src_end > fenced) { __threadfence_block(); fenced = n_out; }
-                    // source bytes repeat with period `mdist` when the match overlaps itself
-                    for (u32 i = lane; i < mlen; i += 64) { myv = out[n_out - mdist + (mdist >= mlen ? i : i % mdist)]; out[n_out + i] = myv; }
+                    // bytes stored since the last fence are not visible to the other lanes yet: a fence only when the source reaches into them
+                    const u32 src_end = md >= ml ? mo - md + ml : mo;
+                    if (src_end > fenced) { __threadfence_block(); fenced = mo; }
+                    for (u32 i = lane; i < ml; i += 64) { myv = out[mo - md + (md >= ml ? i : i % md)]; out[mo + i] = myv; }
                 }
-                last_byte = (char)__shfl((int)myv, (int)((mlen - 1) & 63u));
-                n_out += mlen;
-            } else if (ev == 3) break;
-            else if (ev == 9) { status = 7; break; }
+                // (kept for the next window: the last byte of the text so far when this match is the window's last token)
+                const char lastv = (char)__shfl((int)myv, (int)((ml - 1) & 63u));
+                if (mo + ml == run) tail = lastv;
+            }
+            if (status) break;
+            // the byte in front of the next window's first token
+            if (chain) {
+                const int Ll = 63 - __builtin_clzll(chain);
+                const u32 le = (u32)__shfl((int)e, Ll);
+                if (((le >> 5) & 7u) == IK_LIT) tail = (char)(((le >> 8) & 31u) == 2 ? le >> 24 : le >> 16);
+            }
+            last_byte = tail;
+            n_out = run; bp += t;
+            if (stop == 1) { bp += stop_bits; block_done = true; }
+            else if (stop == 3) status = 7;
+            else if (stop == 2) {
+                // a code longer than the root tables (rare by construction): this one token by lane 0, bit by bit
+                u32 ev = 0, lit = 0, sl = 0, sd = 0, used = 0;
+                if (lane == 0) {
+                    InfBits q; q.init(z + (bp >> 3), z + zlen - 8);
+                    q.refill(); q.drop((int)(bp & 7u));
+                    const u32 c0 = (u32)((q.p - z) * 8) - (u32)q.cnt;
+                    q.refill();
+                    int l; int sy = -1;                                                   // -1 invalid, -2 a length code from the root table
+                    const u32 e1 = s_lit[q.buf & ((1u << INF_LIT_ROOT) - 1)];
+                    if (((e1 >> 5) & 7u) == IK_LONG) { sy = inf_search(s_cl, q.peek(15), INF_LIT_ROOT + 1, 15, l); if (sy >= 0) q.drop(l); }
+                    else if (((e1 >> 5) & 7u) == IK_BASE) { sy = -2; q.drop((int)(e1 & 31u)); sl = (e1 >> 16) + q.take((int)((e1 >> 8) & 31u)); }
+                    if (sy >= 257 && sy < 286) sl = c_len_base[sy - 257] + q.take((int)c_len_extra[sy - 257]);
+                    if (sy == -1 || sy >= 286) ev = 9;
+                    else if (sy >= 0 && sy < 256) { ev = 1; lit = (u32)sy; }
+                    else if (sy == 256) ev = 3;
+                    else {
+                        q.refill();
+                        const u32 d = s_dist[q.buf & ((1u << INF_DIST_ROOT) - 1)];
+                        if (((d >> 5) & 7u) == IK_LONG) {
+                            const int ds = inf_search(s_cd, q.peek(15), INF_DIST_ROOT + 1, 15, l);
+                            if (ds >= 0 && ds < 30) { q.drop(l); q.refill(); sd = c_dist_base[ds] + q.take((int)c_dist_extra[ds]); ev = 2; } else ev = 9;
+                        } else if (((d >> 5) & 7u) == IK_BASE) { q.drop((int)(d & 31u)); q.refill(); sd = (d >> 16) + q.take((int)((d >> 8) & 31u)); ev = 2; }
+                        else ev = 9;
+                    }
+                    used = (u32)((q.p - z) * 8) - (u32)q.cnt - c0;
+                    s_ev[0] = ev; s_ev[1] = lit; s_ev[2] = sl; s_ev[3] = sd; s_ev[4] = used;
+                }
+                __syncthreads();
+                ev = s_ev[0]; lit = s_ev[1]; sl = s_ev[2]; sd = s_ev[3]; used = s_ev[4];
+                __syncthreads();
+                bp += used;
+                if (ev == 1) {
+                    if (n_out + 1 > isize) { status = 5; break; }
+                    if (lane == 0) out[n_out] = (char)lit;
+                    n_out++; last_byte = (char)lit;
+                } else if (ev == 2) {
+                    if (sd > n_out || n_out + sl > isize) { status = 6; break; }
+                    __threadfence_block(); fenced = n_out;
+                    char myv = 0;
+                    for (u32 i = lane; i < sl; i += 64) { myv = out[n_out - sd + (sd >= sl ? i : i % sd)]; out[n_out + i] = myv; }
+                    last_byte = (char)__shfl((int)myv, (int)((sl - 1) & 63u));
+                    n_out += sl;
+                } else if (ev == 3) block_done = true;
+                else status = 7;
+            }
         }
+        // the next block header is read by lane 0 from bp
+        if (lane == 0) { in.init(z + (bp >> 3), z + zlen - 8); in.refill(); in.drop((int)(bp & 7u)); }
     }
     // ---- trailer: ISIZE and CRC-32 (every lane one segment, combined by x^(8 * bytes behind it))
     if (!status) {

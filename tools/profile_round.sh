@@ -3,7 +3,7 @@
 # SAME command, then separate --pmc passes: FETCH_SIZE, WRITE_SIZE, SQ stall counters).  Output under gpurun_out/prof_<tag>/.
 set -u
 CFG=${1:-2}
-TAG=${2:-r03_c$CFG}
+TAG=${2:-r04_c$CFG}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
