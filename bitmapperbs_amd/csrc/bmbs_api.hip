@@ -148,7 +148,8 @@ struct Lane {
     // bmbs_map_*_text: newline index built on the device, SAM text written on the device
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
     DevBuf bam_raw, bam_tok, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
-    DevBuf z_comp, z_off, z_text, z_err, z_nl;                                   // bmbs_inflate_bgzf
+    DevBuf z_comp, z_off, z_text, z_err, z_nl, z_comp2, z_off2, z_err2;          // bmbs_inflate_bgzf; (…2: mate 2 of bmbs_text_open_bgzf)
+    struct OpenText { bool valid = false, pe = false; u64 bytes1 = 0, bytes2 = 0; int64_t n = 0; } open_text;      // between bmbs_text_open_bgzf and bmbs_text_map_open
     u32* h_info = nullptr;                              // page-locked: 8 info words + 4 totals of the text path
     int n_refs = 0, max_ref_len = 0;
     // paired-end workspace
@@ -853,7 +854,7 @@ void lane_destroy(Lane* c)
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->h_info) (void)hipHostFree(c->h_info);
     { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list,
-                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl};
+                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl, &c->z_comp2, &c->z_off2, &c->z_err2};
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
@@ -1884,21 +1885,27 @@ static int lane_map_pe_fastq(Lane* c, const bmbs_fastq_view* mate1, const bmbs_f
 // ------------------------------------------------------------------------------------------------
 // FASTQ text in, SAM text out (bmbs_text.hip): the host reads and writes files, everything between is on the device
 namespace {
-// newline index of one text window (already on the device) -> per-record fields; the totals slot gets the number of lines found
-int text_index(Lane* c, DevBuf& dtext, u64 bytes, u64 n, int f, FqRec& rec)
+// newline index of one text window (already on the device): positions of its first 4 * n_cap newlines; the totals slot 16 + f gets
+// the number of lines found
+int text_index(Lane* c, DevBuf& dtext, u64 bytes, u64 n_cap, int f)
 {
     const u64 tiles = (bytes + FQ_TILE_BYTES - 1) / FQ_TILE_BYTES;
     ENS(c, c->tx_tilecnt, tiles * 4 + 64); ENS(c, c->tx_tileoff, (tiles + 1) * 8 + 64);
-    ENS(c, c->tx_nl[f], (4 * n + 8) * 4);
+    ENS(c, c->tx_nl[f], (4 * n_cap + 8) * 4);
+    hipLaunchKernelGGL(k_fq_count, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tilecnt.as<u32>());
+    int rc = scan_u32(c, c->tx_tilecnt.as<u32>(), tiles, c->tx_tileoff.as<u64>(), 16 + f);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tileoff.as<u64>(), 4 * n_cap, c->tx_nl[f].as<u32>());
+    return BMBS_OK;
+}
+// the per-record field arrays of n records of file f
+int fq_rec_setup(Lane* c, u64 n, int f, FqRec& rec)
+{
     const u64 n4 = (n * 4 + 63) & ~63ull, n2 = (n * 2 + 63) & ~63ull;
     ENS(c, c->tx_rec[f], 3 * n4 + 3 * n2 + 64);
     char* b = c->tx_rec[f].as<char>();
     rec.seq_off = reinterpret_cast<u32*>(b); rec.qual_off = reinterpret_cast<u32*>(b + n4); rec.name_off = reinterpret_cast<u32*>(b + 2 * n4);
     rec.seq_len = reinterpret_cast<u16*>(b + 3 * n4); rec.qual_len = reinterpret_cast<u16*>(b + 3 * n4 + n2); rec.name_len = reinterpret_cast<u16*>(b + 3 * n4 + 2 * n2);
-    hipLaunchKernelGGL(k_fq_count, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tilecnt.as<u32>());
-    int rc = scan_u32(c, c->tx_tilecnt.as<u32>(), tiles, c->tx_tileoff.as<u64>(), 16 + f);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)tiles), dim3(FQ_TILE_THREADS), 0, c->stream, dtext.as<char>(), bytes, c->tx_tileoff.as<u64>(), 4 * n, c->tx_nl[f].as<u32>());
     return BMBS_OK;
 }
 // One upload and one download at a time per device, whatever the number of contexts: concurrent copies in one direction share the
@@ -1913,6 +1920,9 @@ int d2h_chunked(Lane* c, char* dst, const char* src, u64 bytes, hipStream_t st)
     return BMBS_OK;
 }
 
+int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records, int32_t flags_in, char* sam, u64 sam_cap, u64* sam_bytes,
+                     int64_t* n_lines_out, double t_start, double t_uploaded);
+
 int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* text2, u64 bytes2, int64_t n_records, int32_t flags_in, char* sam,
                   u64 sam_cap, u64* sam_bytes, int64_t* n_lines_out)
 {
@@ -1926,12 +1936,11 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
     if (bytes1 >= (1ull << 32) || bytes2 >= (1ull << 32)) { c->err = "a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
     { const int rs = lane_settle(c); if (rs) return rs; }
-    const u64 n = (u64)n_records, n2 = pe ? 2 * n : n;
+    c->open_text.valid = false;
+    const u64 n = (u64)n_records;
     static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;       // diagnostic: host-side phase times of every text call
     auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
-    double tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_uplock = 0, t_dnlock = 0, t_dnstart = 0;
-    tp[0] = wall();
-    FqRec rec[2] = {};
+    const double t_start = wall();
     HIPCHK(c, hipMemsetAsync(c->tx_info.p, 0, 64, c->stream));
     int rc;
     ENS(c, c->fq_text1, bytes1 + 64);
@@ -1940,14 +1949,13 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
         // the link is claimed for the copies alone: the kernels behind them may have to queue behind other contexts' kernels
         std::unique_lock<std::mutex> up(g_h2d_mu[c->dev & 15], std::defer_lock);
         if (c->kn.copy_lock) up.lock();
-        t_uplock = wall();
         // on a stream of their own that never carries a kernel (the lane has nothing in flight here: the previous call ended with a wait)
         hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
         HIPCHK(c, hipMemcpyAsync(c->fq_text1.p, text1, bytes1, hipMemcpyHostToDevice, us));
         if (pe) HIPCHK(c, hipMemcpyAsync(c->fq_text2.p, text2, bytes2, hipMemcpyHostToDevice, us));
         if (c->kn.copy_lock || us != c->stream) HIPCHK(c, hipStreamSynchronize(us));
     }
-    if (trace) tp[7] = wall();
+    const double t_uploaded = trace ? wall() : 0;
     // diagnostic (tools/e2e_trace.sh): BMBS_TEXT_COPY_ONLY=1 moves the bytes of a batch over the link and runs nothing in between
     static const bool copy_only = getenv("BMBS_TEXT_COPY_ONLY") != nullptr;
     if (copy_only) {
@@ -1959,12 +1967,28 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (sam_bytes) *sam_bytes = 0;
-        if (trace) fprintf(stderr, "[text] copy only: upload %.2f (wait %.2f) download %.2f ms\n", (tp[7] - tp[0]) * 1e3, (t_uplock - tp[0]) * 1e3, (wall() - tp[7]) * 1e3);
+        if (trace) fprintf(stderr, "[text] copy only: upload %.2f download %.2f ms\n", (t_uploaded - t_start) * 1e3, (wall() - t_uploaded) * 1e3);
         return BMBS_OK;
     }
-    rc = text_index(c, c->fq_text1, bytes1, n, 0, rec[0]);
+    rc = text_index(c, c->fq_text1, bytes1, n, 0);
     if (rc) return rc;
-    if (pe) { rc = text_index(c, c->fq_text2, bytes2, n, 1, rec[1]); if (rc) return rc; }
+    if (pe) { rc = text_index(c, c->fq_text2, bytes2, n, 1); if (rc) return rc; }
+    return lane_text_finish(c, pe, bytes1, bytes2, n_records, flags_in, sam, sam_cap, sam_bytes, n_lines_out, t_start, t_uploaded);
+}
+
+// the text window(s) are on the device (fq_text1 / fq_text2) and their newline positions are being indexed (text_index): record fields,
+// rows, mapping, SAM text or BAM blocks, download
+int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records, int32_t flags_in, char* sam, u64 sam_cap, u64* sam_bytes,
+                     int64_t* n_lines_out, double t_start, double t_uploaded)
+{
+    const u64 n = (u64)n_records, n2 = pe ? 2 * n : n;
+    static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;
+    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double tp[8] = {t_start, 0, 0, 0, 0, 0, 0, t_uploaded}, t_uplock = t_start, t_dnlock = 0, t_dnstart = 0;
+    FqRec rec[2] = {};
+    int rc = fq_rec_setup(c, n, 0, rec[0]);
+    if (rc) return rc;
+    if (pe) { rc = fq_rec_setup(c, n, 1, rec[1]); if (rc) return rc; }
     // records can only be cut out once the host knows that every one of them is complete: the line counts first
     HIPCHK(c, hipMemcpyAsync(c->h_info + 16, c->totals.as<u64>() + 16, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2133,6 +2157,123 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
                 (long)n2, (double)(bytes1 + bytes2) / 1e6, (double)total / 1e6, (t_uplock - tp[0]) * 1e3, (t_dnlock - t_dnstart) * 1e3, (tp[7] - tp[0]) * 1e3, (tp[1] - tp[7]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3,
                 (tp[4] - tp[3]) * 1e3, (tp[5] - tp[4]) * 1e3, (tp[6] - tp[5]) * 1e3, (tp[6] - tp[0]) * 1e3);
     return BMBS_OK;
+}
+
+// ---- compressed input that stays on the device: open (assemble + index a window from BGZF blocks) and map (everything after) -------
+struct ZTextArgs { const bmbs_ztext* z; DevBuf* text; DevBuf* comp; DevBuf* off; DevBuf* err; };
+
+int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int64_t max_records, int32_t last1, int32_t last2, int64_t* n_records,
+                        char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes, char* tail2, uint64_t* tail2_bytes)
+{
+    if (!c) return BMBS_EINVAL;
+    if (n_records) *n_records = 0;
+    if (tail1_bytes) *tail1_bytes = 0;
+    if (tail2_bytes) *tail2_bytes = 0;
+    c->open_text.valid = false;
+    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
+    if (!z1 || max_records <= 0 || !n_records || !tail1 || !tail1_bytes || (z2 && (!tail2 || !tail2_bytes))) { c->err = "text open: NULL argument"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    { const int rs = lane_settle(c); if (rs) return rs; }
+    const bool pe = z2 != nullptr;
+    ZTextArgs A[2] = {{z1, &c->fq_text1, &c->z_comp, &c->z_off, &c->z_err}, {z2, &c->fq_text2, &c->z_comp2, &c->z_off2, &c->z_err2}};
+    const int32_t last[2] = {last1, last2};
+    u64 bytes[2] = {0, 0};
+    HIPCHK(c, hipMemsetAsync(c->tx_info.p, 0, 64, c->stream));
+    hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
+    for (int f = 0; f < (pe ? 2 : 1); f++) {
+        const bmbs_ztext* z = A[f].z;
+        const u64 nb = (u64)std::max<int64_t>(0, z->n_blocks);
+        if ((z->prefix_bytes && !z->prefix) || (nb && (!z->comp || !z->blk_off || !z->out_off))) { c->err = "text open: NULL buffer"; return BMBS_EINVAL; }
+        const u64 text = nb ? z->out_off[nb] : 0;
+        if (nb && z->blk_off[nb] > z->comp_bytes) { c->err = "text open: block table outside the compressed bytes"; return BMBS_EINVAL; }
+        for (u64 i = 0; i < nb; i++)
+            if (z->blk_off[i + 1] < z->blk_off[i] + 26 || z->out_off[i + 1] < z->out_off[i] || z->out_off[i + 1] - z->out_off[i] > 65536) { c->err = "text open: malformed block table"; return BMBS_EINVAL; }
+        // the prefix is aligned up to 16 bytes in front of the inflated text?  No: the text has to be contiguous -- the inflate kernel takes
+        // any byte offset, and the line kernels read the window from its (16-byte aligned) start
+        bytes[f] = z->prefix_bytes + text;
+        if (bytes[f] + 1 >= (1ull << 32)) { c->err = "a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
+        ENS(c, *A[f].text, bytes[f] + 64 + 16);
+        if (z->prefix_bytes) HIPCHK(c, hipMemcpyAsync(A[f].text->p, z->prefix, z->prefix_bytes, hipMemcpyHostToDevice, us));
+        if (nb) {
+            ENS(c, *A[f].comp, z->comp_bytes + 64); ENS(c, *A[f].off, 2 * (nb + 1) * 8 + 64); ENS(c, *A[f].err, nb * 4 + 64);
+            HIPCHK(c, hipMemcpyAsync(A[f].comp->p, z->comp, z->comp_bytes, hipMemcpyHostToDevice, us));
+            HIPCHK(c, hipMemcpyAsync(A[f].off->p, z->blk_off, (nb + 1) * 8, hipMemcpyHostToDevice, us));
+            HIPCHK(c, hipMemcpyAsync(A[f].off->as<u64>() + (nb + 1), z->out_off, (nb + 1) * 8, hipMemcpyHostToDevice, us));
+        }
+    }
+    if (us != c->stream) HIPCHK(c, hipStreamSynchronize(us));
+    for (int f = 0; f < (pe ? 2 : 1); f++) {
+        const bmbs_ztext* z = A[f].z;
+        const u64 nb = (u64)std::max<int64_t>(0, z->n_blocks);
+        if (nb)
+            hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)nb), dim3(64), 0, c->stream, A[f].comp->as<u8>(), A[f].off->as<u64>(), A[f].off->as<u64>() + (nb + 1), (long)nb,
+                               A[f].text->as<char>() + z->prefix_bytes, A[f].err->as<u32>());
+        if (last[f] && bytes[f]) {
+            // an unterminated last line counts as a line (the reader's rule): the newline is added here, on the device
+            hipLaunchKernelGGL(k_close_last_line, dim3(1), dim3(1), 0, c->stream, A[f].text->as<char>(), bytes[f], c->totals.as<u64>() + 21 + f);
+        } else HIPCHK(c, hipMemsetAsync(c->totals.as<u64>() + 21 + f, 0, 8, c->stream));
+    }
+    // whether a newline was added has to be known before the lines are indexed
+    HIPCHK(c, hipMemcpyAsync(c->h_info + 28, c->totals.as<u64>() + 21, 16, hipMemcpyDeviceToHost, c->stream));
+    std::vector<u32> err[2];
+    for (int f = 0; f < (pe ? 2 : 1); f++) {
+        const u64 nb = (u64)std::max<int64_t>(0, A[f].z->n_blocks);
+        err[f].resize(nb);
+        if (nb) HIPCHK(c, hipMemcpyAsync(err[f].data(), A[f].err->p, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int f = 0; f < (pe ? 2 : 1); f++)
+        for (size_t i = 0; i < err[f].size(); i++)
+            if (err[f][i]) { c->err = "corrupt BGZF block in the .gz input (file " + std::to_string(f + 1) + ", block " + std::to_string(i) + " of this window, code " + std::to_string(err[f][i]) + ")"; return BMBS_EINVAL; }
+    const u64* added = reinterpret_cast<const u64*>(c->h_info + 28);
+    bytes[0] += added[0]; if (pe) bytes[1] += added[1];
+    const u64 n_cap = (u64)max_records;
+    int rc = text_index(c, c->fq_text1, bytes[0], n_cap, 0);
+    if (rc) return rc;
+    if (pe) { rc = text_index(c, c->fq_text2, bytes[1], n_cap, 1); if (rc) return rc; }
+    HIPCHK(c, hipMemcpyAsync(c->h_info + 16, c->totals.as<u64>() + 16, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u64* lines = reinterpret_cast<const u64*>(c->h_info + 16);
+    u64 n = lines[0] / 4;
+    if (pe) n = std::min(n, lines[1] / 4);
+    n = std::min(n, n_cap);
+    // the text behind the n records: handed back for the next window
+    u64 cut[2] = {0, 0};
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->h_info + 20, c->tx_nl[0].as<u32>() + (4 * n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        if (pe) HIPCHK(c, hipMemcpyAsync(c->h_info + 21, c->tx_nl[1].as<u32>() + (4 * n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        cut[0] = (u64)c->h_info[20] + 1; if (pe) cut[1] = (u64)c->h_info[21] + 1;
+    }
+    hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
+    char* tails[2] = {tail1, tail2}; uint64_t* tb[2] = {tail1_bytes, tail2_bytes};
+    for (int f = 0; f < (pe ? 2 : 1); f++) {
+        const u64 t = bytes[f] - cut[f];
+        if (t > tail_cap) { c->err = "text open: the tail buffer is too small (" + std::to_string(t) + " bytes behind the window's records)"; *tb[f] = t; return BMBS_ENOMEM; }
+        if (t) HIPCHK(c, hipMemcpyAsync(tails[f], A[f].text->as<char>() + cut[f], t, hipMemcpyDeviceToHost, ds));
+        *tb[f] = t;
+    }
+    HIPCHK(c, hipStreamSynchronize(ds));
+    *n_records = (int64_t)n;
+    c->open_text.valid = n > 0; c->open_text.pe = pe; c->open_text.bytes1 = cut[0]; c->open_text.bytes2 = cut[1]; c->open_text.n = (int64_t)n;
+    return BMBS_OK;
+}
+
+int lane_text_map_open(Lane* c, int32_t flags_in, char* sam, u64 sam_cap, u64* sam_bytes, int64_t* n_lines_out)
+{
+    if (!c) return BMBS_EINVAL;
+    if (sam_bytes) *sam_bytes = 0;
+    if (n_lines_out) *n_lines_out = 0;
+    if (!c->open_text.valid) { c->err = "text map: no open batch (bmbs_text_open_bgzf first)"; return BMBS_ESTATE; }
+    if (c->n_refs != c->ix.n_chrom) { c->err = "bmbs_sam_refs has not been given the index's reference names"; return BMBS_ESTATE; }
+    if (!sam) { c->err = "text call: NULL buffer"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double t0 = wall();
+    // (an output buffer that turns out too small leaves the batch open: the call can be repeated)
+    const int rc = lane_text_finish(c, c->open_text.pe, c->open_text.bytes1, c->open_text.bytes2, c->open_text.n, flags_in, sam, sam_cap, sam_bytes, n_lines_out, t0, t0);
+    if (rc != BMBS_ENOMEM) c->open_text.valid = false;
+    return rc;
 }
 
 // RNAME table of the SAM text: the names behind the index's sequences, in index order
@@ -2551,6 +2692,11 @@ extern "C" int bmbs_sam_refs(bmbs_ctx* X, const char* const* names, int32_t n_na
 extern "C" int bmbs_map_se_text(bmbs_ctx* X, const char* text, uint64_t text_bytes, int64_t n_records, int32_t flags, char* sam, uint64_t sam_cap,
                                 uint64_t* sam_bytes, int64_t* n_lines)
 { ON_LANE0(lane_map_text(c, false, text, text_bytes, nullptr, 0, n_records, flags, sam, sam_cap, sam_bytes, n_lines)); }
+extern "C" int bmbs_text_open_bgzf(bmbs_ctx* X, const bmbs_ztext* mate1, const bmbs_ztext* mate2, int64_t max_records, int32_t last1, int32_t last2,
+                                   int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes, char* tail2, uint64_t* tail2_bytes)
+{ ON_LANE0(lane_text_open_bgzf(c, mate1, mate2, max_records, last1, last2, n_records, tail1, tail_cap, tail1_bytes, tail2, tail2_bytes)); }
+extern "C" int bmbs_text_map_open(bmbs_ctx* X, int32_t flags, char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines)
+{ ON_LANE0(lane_text_map_open(c, flags, sam, sam_cap, sam_bytes, n_lines)); }
 extern "C" int bmbs_map_pe_text(bmbs_ctx* X, const char* text1, uint64_t bytes1, const char* text2, uint64_t bytes2, int64_t n_pairs, int32_t flags,
                                 char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines)
 { ON_LANE0(lane_map_text(c, true, text1, bytes1, text2, bytes2, n_pairs, flags, sam, sam_cap, sam_bytes, n_lines)); }

@@ -433,6 +433,12 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     if (lane == 0) err[b] = status;
 }
 
+// a window that ends the file: an unterminated last line gets its newline (the text buffer has the room); *added = 1 when it did
+__global__ void k_close_last_line(char* __restrict__ text, u64 bytes, u64* __restrict__ added)
+{
+    if (text[bytes - 1] != '\n') { text[bytes] = '\n'; *added = 1; } else *added = 0;
+}
+
 // newlines of the inflated text per 64 KiB of the caller's window: text byte i sits at window offset shift + i; counts[j] = newlines
 // among the bytes whose window offset lies in [j * 65536, (j + 1) * 65536) (the driver's reader needs nothing else from the text)
 __global__ void __launch_bounds__(256)

@@ -281,12 +281,7 @@ struct Source {
             if (bgzf) {
                 const char* zd = getenv("BMBS_GZ_DEVICE");
                 if (zd && !strcmp(zd, "0")) zdev = -1;
-                if (zdev >= 0) {
-                    bmbs_params P0; bmbs_default_params(&P0);
-                    zc = bmbs_create(zdev, &P0);
-                    if (zc) { zdirect = true; zstage.kind = 1; return true; }
-                    zdev = -1;                                  // no context on the device: the host inflaters
-                }
+                if (zdev >= 0) { zdirect = true; zstage.kind = 1; return true; }      // inflated on the device, a window at a time (no threads here)
                 const int n_inflaters = gz_threads_;
                 live_inflaters = n_inflaters;                   // (the threads count it down as they finish: not the loop bound)
                 for (int t = 0; t < n_inflaters; t++)
@@ -387,6 +382,12 @@ struct Source {
             if (bad) { err = std::string("read error on the FASTQ input: ") + strerror(bad); return false; }
             last = off + len == end;
         } else if (zdirect) {
+            if (!zc) {
+                // (only when the driver's two-phase path is not in use: a context of this source's own inflates into the host window)
+                bmbs_params P0; bmbs_default_params(&P0);
+                zc = bmbs_create(zdev, &P0);
+                if (!zc) { err = "cannot create a context on the device for the BGZF input (BMBS_GZ_DEVICE=0 inflates on the host)"; return false; }
+            }
             size_t have = carry.size();
             if (have > cap) { err = "internal: carried text larger than the window"; return false; }
             if (have) memcpy(dst, carry.data(), have);
@@ -506,6 +507,26 @@ struct Source {
         zmap = nullptr;
         if (fd >= 0) ::close(fd);
         fd = -1; gz = false;
+    }
+    // the next BGZF blocks whose text fits into `room` bytes (at least one): their bytes are zmap[a, q); tables relative to a.
+    // foreign: the file goes on with a member that is not a BGZF block.  false: corrupt header
+    bool next_blocks(size_t room, size_t& a, size_t& q, bool& foreign)
+    {
+        a = znext; q = a; foreign = false;
+        uint64_t text = 0;
+        zblk.clear(); zout.clear(); zblk.push_back(0); zout.push_back(0);
+        while (q < zsize) {
+            const size_t bs = bgzf_block(zmap + q, zsize - q);
+            if (!bs) { foreign = true; break; }
+            const size_t isz = bgzf_isize(zmap + q, bs);
+            if (isz > 65536) { err = "corrupt BGZF block in the .gz input"; return false; }
+            if (text + isz > room && q > a) break;
+            q += bs; text += isz;
+            zblk.push_back(q - a); zout.push_back(text);
+            if (text >= room) break;
+        }
+        if (foreign && q == a && !pgz::gzip_header(zmap, zsize, a)) { err = "corrupt BGZF block header in the .gz input"; return false; }
+        return true;
     }
     // the device side of a compressed source (context, staging): released apart from close(), outside a driver's timed region
     void release_device()
@@ -706,6 +727,7 @@ struct Batch {
     size_t used1 = 0, used2 = 0;
     uint64_t sam_bytes = 0;
     std::vector<uint32_t> counts1, counts2;
+    bmbs_ctx* open_ctx = nullptr;                // compressed input kept on the device: the context that holds this batch's open window
 };
 
 struct Part {                                    // one contiguous record range of the input -> one output file
@@ -1028,9 +1050,97 @@ int main(int argc, char** argv)
     const int r_threads = reader_threads > 0 ? reader_threads : std::max(1, io_threads / live_parts);
 
     // ---------------- stage R (one per part): text window + newline count -> how many whole records ----------------------------
+    // BGZF input that stays on the device (bmbs_text_open_bgzf / bmbs_text_map_open): the reader hands the compressed blocks of a window
+    // to a context, learns how many whole records they held and what is left over (the next window's prefix), and passes the context on
+    // to a worker for the mapping.  The inflated text never crosses the link -- the host moves compressed bytes and tails only.
+    Chan<bmbs_ctx*> ctx_pool;
+    auto z_mode = [&](Part* pt) { return pt->s1.zdirect && (!pe || pt->s2.zdirect); };
+    if (live_parts == 1 && z_mode(P_[0].get())) for (bmbs_ctx* c : ctxs) ctx_pool.put(c);
+    // true: the input is finished (or failed); false: go on with the host-window reader (a member that is not a BGZF block turned up)
+    auto reader_z = [&](Part* pt, Pool& pool, Pool& pool2) -> bool {
+        size_t est = est0;
+        Pinned tails[2]; tails[0].kind = 2; tails[1].kind = 2;
+        const size_t tail_cap = (size_t)64 << 20;
+        if (!tails[0].need(tail_cap) || (pe && !tails[1].need(tail_cap))) { fail("cannot allocate page-locked staging memory"); return true; }
+        Source* S[2] = {&pt->s1, &pt->s2};
+        const int nf = pe ? 2 : 1;
+        for (;;) {
+            const double tw0 = now();
+            Batch* b = free_q.get();
+            bmbs_ctx* ctx = ctx_pool.get();
+            const double t0 = now();
+            pt->t_wait_r += t0 - tw0;
+            b->part = pt; b->seq = pt->next_seq++; b->n = 0; b->end = false; b->used1 = b->used2 = 0; b->sam_bytes = 0; b->open_ctx = nullptr;
+            auto bail = [&](const std::string& why) { fail(why); b->end = true; b->n = 0; ctx_pool.put(ctx); gpu_q.put(b); };
+            if (failed) { b->end = true; ctx_pool.put(ctx); gpu_q.put(b); return true; }
+            const size_t target = std::min<size_t>((size_t)batch * est + (1u << 16), (size_t)3500 << 20);
+            bmbs_ztext z[2]; memset(z, 0, sizeof z);
+            size_t a[2] = {0, 0}, q[2] = {0, 0};
+            bool foreign_any = false;
+            for (int f = 0; f < nf; f++) {
+                Source& s = *S[f];
+                bool foreign = false;
+                const size_t room = target > s.carry.size() ? target - s.carry.size() : 0;
+                if (!s.next_blocks(room, a[f], q[f], foreign)) { bail(s.err); return true; }
+                if (foreign && q[f] == a[f]) foreign_any = true;
+            }
+            if (foreign_any) {
+                // the rest of such a file goes through the host's stream inflater; blocks already taken for this window are given back
+                for (int f = 0; f < nf; f++) {
+                    Source& s = *S[f];
+                    if (s.znext < s.zsize && !s.bgzf_block(s.zmap + s.znext, s.zsize - s.znext)) { std::lock_guard<std::mutex> l(s.m); s.zdirect = false; const size_t at = s.znext; s.znext = s.zsize; s.start_pgz(at, 0); }
+                }
+                pt->next_seq--;                                     // (the batch was not used)
+                free_q.put(b);
+                // every window opened so far has to be mapped before the workers go back to contexts of their own
+                for (size_t i = 1; i < ctxs.size(); i++) (void)ctx_pool.get();
+                return false;
+            }
+            size_t text_bytes = 0;
+            for (int f = 0; f < nf; f++) {
+                Source& s = *S[f];
+                const size_t zbytes = q[f] - a[f];
+                if (zbytes) {
+                    if (!s.zstage.need(zbytes + 64)) { bail("cannot allocate page-locked staging memory"); return true; }
+                    Pool& pl = f ? pool2 : pool;
+                    const int T = pl.size() * 2;
+                    const size_t per = ((zbytes + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+                    pl.run(T, [&](int t) { const size_t x = std::min(zbytes, per * (size_t)t), y = std::min(zbytes, x + per); if (x < y) memcpy(s.zstage.p + x, s.zmap + a[f] + x, y - x); });
+                }
+                s.znext = q[f];
+                z[f].prefix = s.carry.empty() ? nullptr : s.carry.data(); z[f].prefix_bytes = s.carry.size();
+                z[f].comp = s.zstage.p; z[f].comp_bytes = zbytes; z[f].blk_off = s.zblk.data(); z[f].out_off = s.zout.data(); z[f].n_blocks = (int64_t)s.zblk.size() - 1;
+                text_bytes += s.carry.size() + (size_t)s.zout.back();
+            }
+            const bool last1 = pt->s1.znext >= pt->s1.zsize, last2 = pe && pt->s2.znext >= pt->s2.zsize;
+            int64_t nrec = 0; uint64_t tb[2] = {0, 0};
+            const int rc = bmbs_text_open_bgzf(ctx, &z[0], pe ? &z[1] : nullptr, batch, last1 ? 1 : 0, last2 ? 1 : 0, &nrec, tails[0].p, tail_cap, &tb[0],
+                                               pe ? tails[1].p : nullptr, &tb[1]);
+            if (rc) { bail(bmbs_last_error(ctx)); return true; }
+            for (int f = 0; f < nf; f++) S[f]->carry.assign(tails[f].p, tails[f].p + tb[f]);
+            // the part's input ends with this batch when a file has nothing left behind it (PE: the shorter file decides)
+            b->end = (last1 && tb[0] == 0) || (pe && last2 && tb[1] == 0);
+            if (nrec == 0) {
+                if (!b->end && (last1 || (pe && last2))) b->end = true;            // a trailing fragment that is not a whole record
+                if (!b->end) { bail("FASTQ record larger than the " + std::to_string(target) + "-byte window"); return true; }
+                ctx_pool.put(ctx); gpu_q.put(b);
+                return true;
+            }
+            est = std::max<size_t>(64, text_bytes / (size_t)nf / (size_t)nrec + 16);
+            b->n = nrec; b->open_ctx = ctx;
+            const int Lg = (int)std::min<size_t>(1000, est / 2);
+            if (!b->sam.need(sam_bound(text_bytes, (size_t)nrec * (pe ? 2 : 1), Lg))) { bail("cannot allocate page-locked staging memory"); return true; }
+            pt->t_read += now() - t0;
+            pt->records += nrec;
+            const bool end = b->end;
+            gpu_q.put(b);
+            if (end) return true;
+        }
+    };
     auto reader_fn = [&](Part* pt) {
         Pool pool(r_threads - 1);
         Pool pool2(pe && pt->s2.gz ? std::max(1, r_threads / 2) - 1 : 0);          // second mate's window of compressed input
+        if (live_parts == 1 && z_mode(pt) && reader_z(pt, pool, pool2)) return;
         size_t est = est0;
         for (;;) {
             const double tw0 = now();
@@ -1128,16 +1238,21 @@ int main(int argc, char** argv)
     // ---------------- stage G: one worker per context, one library call per batch ---------------------------------------
     double t_gpu = 0, t_wait_g = 0;
     std::mutex g_mu;
-    auto g_worker = [&](bmbs_ctx* ctx) {
+    auto g_worker = [&](bmbs_ctx* own_ctx) {
         for (;;) {
+            bmbs_ctx* ctx = own_ctx;
             const double tw0 = now();
             Batch* b = gpu_q.get();
             if (!b) return;
             const double t0 = now();
+            bmbs_ctx* octx = b->open_ctx;                                        // compressed input on the device: the batch's window is open on this context
+            b->open_ctx = nullptr;
+            if (octx) ctx = octx;
             if (!failed && b->n) {
                 for (int attempt = 0; attempt < 2; attempt++) {
                     uint64_t bytes = 0; int64_t lines = 0;
-                    const int rc = pe ? bmbs_map_pe_text(ctx, b->text1.p, b->used1, b->text2.p, b->used2, b->n, flags, b->sam.p, b->sam.cap, &bytes, &lines)
+                    const int rc = octx ? bmbs_text_map_open(ctx, flags, b->sam.p, b->sam.cap, &bytes, &lines)
+                                 : pe ? bmbs_map_pe_text(ctx, b->text1.p, b->used1, b->text2.p, b->used2, b->n, flags, b->sam.p, b->sam.cap, &bytes, &lines)
                                       : bmbs_map_se_text(ctx, b->text1.p, b->used1, b->n, flags, b->sam.p, b->sam.cap, &bytes, &lines);
                     if (rc == BMBS_ENOMEM && bytes > b->sam.cap && attempt == 0 && b->sam.need((size_t)bytes + 64)) continue;   // reads longer than guessed
                     if (rc) fail(bmbs_last_error(ctx));
@@ -1146,6 +1261,7 @@ int main(int argc, char** argv)
                 }
             }
             { std::lock_guard<std::mutex> l(g_mu); t_wait_g += t0 - tw0; t_gpu += now() - t0; }
+            if (octx) ctx_pool.put(octx);
             b->part->out_q.put(b->seq, b);
         }
     };

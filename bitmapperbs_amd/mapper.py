@@ -207,6 +207,43 @@ class Mapper:
         self._chk(self._lib.bmbs_inflate_bgzf(self._ctx, capi.ptr(a), a.size, capi.ptr(b), capi.ptr(o), n, capi.ptr(text), out[-1], capi.ptr(cnt), shift))
         return text[:out[-1]].tobytes(), cnt
 
+    @staticmethod
+    def _ztext(prefix: bytes, blocks: bytes, keep):
+        """a capi.ZText over `prefix` + the BGZF blocks in `blocks` (objects that must stay alive are appended to `keep`)"""
+        import struct
+        blk = [0]; out = [0]
+        at = 0
+        while at < len(blocks):
+            bs = struct.unpack("<H", blocks[at + 16:at + 18])[0] + 1
+            isz = struct.unpack("<I", blocks[at + bs - 4:at + bs])[0]
+            at += bs; blk.append(at); out.append(out[-1] + isz)
+        a = np.frombuffer(blocks, dtype=np.uint8) if blocks else np.zeros(1, dtype=np.uint8)
+        pf = np.frombuffer(prefix, dtype=np.uint8) if prefix else np.zeros(1, dtype=np.uint8)
+        b = np.array(blk, dtype=np.uint64); o = np.array(out, dtype=np.uint64)
+        keep += [a, pf, b, o]
+        z = capi.ZText()
+        z.prefix = capi.ptr(pf) if prefix else None; z.prefix_bytes = len(prefix)
+        z.comp = capi.ptr(a); z.comp_bytes = len(blocks); z.blk_off = capi.ptr(b); z.out_off = capi.ptr(o); z.n_blocks = len(blk) - 1
+        return z
+
+    def text_open_bgzf(self, w1, w2=None, max_records=1 << 30, last=(False, False), tail_cap=1 << 24):
+        """w = (prefix bytes, BGZF blocks): the window(s) are assembled and indexed on the device -> (records, tail1, tail2)"""
+        self._set_refs()
+        keep = []
+        z1 = self._ztext(w1[0], w1[1], keep)
+        z2 = self._ztext(w2[0], w2[1], keep) if w2 is not None else None
+        t1 = np.empty(tail_cap, dtype=np.uint8); t2 = np.empty(tail_cap, dtype=np.uint8)
+        n = C.c_int64(0); b1 = C.c_uint64(0); b2 = C.c_uint64(0)
+        self._chk(self._lib.bmbs_text_open_bgzf(self._ctx, C.byref(z1), C.byref(z2) if z2 is not None else None, max_records, int(last[0]), int(last[1]),
+                                                C.byref(n), capi.ptr(t1), tail_cap, C.byref(b1), capi.ptr(t2), C.byref(b2)))
+        return int(n.value), t1[:b1.value].tobytes(), t2[:b2.value].tobytes()
+
+    def text_map_open(self, flags: int = 0, cap: int = 1 << 28) -> bytes:
+        out = np.empty(cap, dtype=np.uint8)
+        used = C.c_uint64(0); lines = C.c_int64(0)
+        self._chk(self._lib.bmbs_text_map_open(self._ctx, flags, capi.ptr(out), cap, C.byref(used), C.byref(lines)))
+        return out[:used.value].tobytes()
+
     def sync(self):
         self._chk(self._lib.bmbs_sync(self._ctx))
 

@@ -275,6 +275,29 @@ int bmbs_map_pe_text(bmbs_ctx*, const char* text1, uint64_t bytes1, const char* 
 int bmbs_inflate_bgzf(bmbs_ctx*, const void* comp, uint64_t comp_bytes, const uint64_t* blk_off, const uint64_t* out_off, int64_t n_blocks,
                       char* text, uint64_t text_bytes, uint32_t* nl_per_64k, uint64_t window_shift);
 
+/* ... and the same blocks as the INPUT of a text call, so that the inflated text never leaves the device.  Two phases, because a
+ * reader has to know what a window left over before it can cut the next one:
+ *   bmbs_text_open_bgzf   the window(s) are assembled on the device -- `prefix` (uncompressed bytes: what the previous window left
+ *                         over) followed by the text of the blocks --, their lines are indexed, *n_records = the complete records
+ *                         (pairs: of both mates) they hold, at most max_records; tail1 / tail2 receive the text BEHIND those records
+ *                         (the next window's prefix; BMBS_ENOMEM with *tail_bytes = the size needed when tail_cap is too small);
+ *                         last1 / last2: the window ends its file (an unterminated last line is closed, as the reader does)
+ *   bmbs_text_map_open    maps the open batch: records / SAM text / BAM blocks exactly as bmbs_map_*_text returns them
+ * The context holds one open batch at a time.                                                                                    */
+typedef struct bmbs_ztext {
+    const char*     prefix;        /* host; NULL when prefix_bytes == 0 */
+    uint64_t        prefix_bytes;
+    const void*     comp;          /* the bytes of n_blocks consecutive BGZF blocks (page-locked memory moves at link speed) */
+    uint64_t        comp_bytes;
+    const uint64_t* blk_off;       /* [n_blocks + 1] */
+    const uint64_t* out_off;       /* [n_blocks + 1]: ISIZE prefix sums */
+    int64_t         n_blocks;      /* may be 0 (a window made of the prefix alone) */
+} bmbs_ztext;
+int bmbs_text_open_bgzf(bmbs_ctx*, const bmbs_ztext* mate1, const bmbs_ztext* mate2 /* NULL: single end */, int64_t max_records,
+                        int32_t last1, int32_t last2, int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes,
+                        char* tail2, uint64_t* tail2_bytes);
+int bmbs_text_map_open(bmbs_ctx*, int32_t flags, char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
+
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
  * error bases} (Schema.cpp:25141-25146); bmbs_stats_allreduce sums them over the ctxs one process
  * drives (get_mapping_informations, Schema.cpp:451-476).  Multi-process jobs sum the five int64 with

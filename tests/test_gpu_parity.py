@@ -1356,6 +1356,68 @@ def test_device_bgzf_inflate_equals_zlib(env):
     m.close()
 
 
+@pytest.mark.parametrize("mode", ["se", "pe", "pe_bam"])
+def test_bgzf_windows_opened_on_the_device_map_like_the_text(env, mode):
+    """bmbs_text_open_bgzf + bmbs_text_map_open (compressed input that never leaves the device): a FASTQ file cut into windows of BGZF
+    blocks at block boundaries -- records straddle windows, so every window carries the previous one's tail as its prefix, the
+    mates' windows hold different numbers of records, the last line has no newline -- gives, window by window, exactly the lines
+    bmbs_map_*_text prints for the whole text"""
+    from bitmapperbs_amd import synth, mapper
+    from common import write_bgzf
+    M = mapper.Mapper
+    pe = mode != "se"
+    n = 5000
+    if pe:
+        m1, m2 = synth.make_reads_pe(env["chroms"], n=n, L=120, seed=61, sub=0.02, indel=0.002, qual="random")
+        rng = np.random.default_rng(7)
+        l1 = rng.integers(40, 121, n); l2 = rng.integers(40, 121, n)
+        texts = [b"".join(b"@" + mm["names"][i] + b"\n" + mm["seq"][i, :ll[i]].tobytes() + b"\n+\n" + mm["qual"][i, :ll[i]].tobytes() + b"\n" for i in range(n))[:-1]
+                 for mm, ll in ((m1, l1), (m2, l2))]
+    else:
+        texts = [_odd_fastq(env, n=n)[:-1]]
+    flags = M.TEXT_UNMAPPED | (M.TEXT_BAM if mode == "pe_bam" else 0)
+    m = M(env["ix"], 0)
+    want = m.map_text(texts[0] + b"\n", n, (texts[1] + b"\n") if pe else None, flags=flags)
+    # windows: different block sizes for the two files, a few blocks per window
+    import io, tempfile, os as _os
+    files = []
+    for k, t in enumerate(texts):
+        f = tempfile.mktemp(suffix=".gz")
+        write_bgzf(f, t, block=[9000, 13000][k], level=1)
+        z = open(f, "rb").read(); _os.unlink(f)
+        files.append(z[:-28])                                   # without the EOF marker block
+    def blocks(z):
+        import struct
+        out = []; at = 0
+        while at < len(z):
+            bs = struct.unpack("<H", z[at + 16:at + 18])[0] + 1
+            out.append(z[at:at + bs]); at += bs
+        return out
+    bl = [blocks(z) for z in files]
+    pos = [0, 0]; carry = [b"", b""]
+    got = []; total = 0
+    step = [7, 5]
+    while True:
+        w = []
+        for k in range(len(texts)):
+            take = bl[k][pos[k]:pos[k] + step[k]]; pos[k] += len(take)
+            w.append((carry[k], b"".join(take)))
+        last = tuple(pos[k] >= len(bl[k]) for k in range(len(texts))) + ((False,) if not pe else ())
+        nrec, t1, t2 = m.text_open_bgzf(w[0], w[1] if pe else None, max_records=700, last=(last[0], last[1] if pe else False))
+        carry = [t1, t2]
+        if nrec:
+            got.append(m.text_map_open(flags=flags)); total += nrec
+        if all(last[:len(texts)]) and (nrec == 0 or not t1 or (pe and not t2)):
+            break
+    assert total == n
+    if mode == "pe_bam":
+        from common import bgzf_blocks
+        assert b"".join(raw for _, raw in bgzf_blocks(b"".join(got))) == b"".join(raw for _, raw in bgzf_blocks(want))
+    else:
+        assert b"".join(got) == want
+    m.close()
+
+
 def test_text_call_with_a_small_buffer_can_be_repeated_and_counts_once(env):
     """BMBS_ENOMEM of bmbs_map_*_text (output buffer too small) is retriable (*sam_bytes = the size needed): the batch it mapped is
     NOT added to the context's mapstats, so that the repeat counts it once (SAM text and BAM)"""
