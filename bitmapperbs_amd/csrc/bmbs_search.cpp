@@ -854,7 +854,15 @@ int main(int argc, char** argv)
         // plain text needs few threads to read at memory speed; compressed input is inflated by them (csrc/pgz.h): more pay off
         const bool zin = Source::is_gz(seq.empty() ? seq1.c_str() : seq.c_str());
         const int hw = (int)std::thread::hardware_concurrency();
-        io_threads = zin ? std::min(std::max(1, hw / 2), 64) : std::min(hw, 32);
+        // what the process may actually use: a container's CPU quota (cgroup v2 cpu.max "quota period") is often far below the hardware
+        // threads it can see -- 16 cores' worth of 256 on the MI355X boxes -- and inflating on four times as many threads as that is slower
+        int eff = hw;
+        if (FILE* cf = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(cf, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) eff = (int)std::max<long long>(1, std::min<long long>(hw, (quota + period - 1) / period));
+            fclose(cf);
+        }
+        io_threads = zin ? std::min(std::max(1, eff), 64) : std::min(hw, 32);
     }
     if (io_threads < 1) io_threads = 1;
     if (parts < 1) parts = 1;
@@ -1060,7 +1068,9 @@ int main(int argc, char** argv)
     auto reader_z = [&](Part* pt, Pool& pool, Pool& pool2) -> bool {
         size_t est = est0;
         Pinned tails[2]; tails[0].kind = 2; tails[1].kind = 2;
-        const size_t tail_cap = (size_t)64 << 20;
+        // (what a window leaves over is a partial record, plus -- when the mates' records differ in size -- the surplus of one file, which the
+        // next window's smaller block count evens out: never more than a window)
+        const size_t tail_cap = std::min<size_t>((size_t)batch * est0 + ((size_t)8 << 20), (size_t)3600 << 20);
         if (!tails[0].need(tail_cap) || (pe && !tails[1].need(tail_cap))) { fail("cannot allocate page-locked staging memory"); return true; }
         Source* S[2] = {&pt->s1, &pt->s2};
         const int nf = pe ? 2 : 1;
@@ -1114,7 +1124,8 @@ int main(int argc, char** argv)
             }
             const bool last1 = pt->s1.znext >= pt->s1.zsize, last2 = pe && pt->s2.znext >= pt->s2.zsize;
             int64_t nrec = 0; uint64_t tb[2] = {0, 0};
-            const int rc = bmbs_text_open_bgzf(ctx, &z[0], pe ? &z[1] : nullptr, batch, last1 ? 1 : 0, last2 ? 1 : 0, &nrec, tails[0].p, tail_cap, &tb[0],
+            // every whole record of the window is taken (the window is what bounds a batch here: --batch records by the running estimate of a record's size)
+            const int rc = bmbs_text_open_bgzf(ctx, &z[0], pe ? &z[1] : nullptr, 4 * (int64_t)batch, last1 ? 1 : 0, last2 ? 1 : 0, &nrec, tails[0].p, tail_cap, &tb[0],
                                                pe ? tails[1].p : nullptr, &tb[1]);
             if (rc) { bail(bmbs_last_error(ctx)); return true; }
             for (int f = 0; f < nf; f++) S[f]->carry.assign(tails[f].p, tails[f].p + tb[f]);
