@@ -504,28 +504,32 @@ class Job:
                 self.lens.append(torch.where(keep, torch.full_like(ln, L), ln).to(torch.int16))
         self.reads_per_launch = nrec
         self.cig_cap = nrec * self.max_ops
-        self.res_d = torch.empty((nrec, 32), dtype=torch.uint8, device="cuda")
-        self.cig_d = torch.empty((self.cig_cap,), dtype=torch.int32, device="cuda")
+        # every launch of a step has result records and a CIGAR pool of its own: the launches of a step are in flight together (two
+        # lanes, up to eight calls each), and a shared pair of buffers would be written by all of them at once
+        self.res_all = [torch.empty((nrec, 32), dtype=torch.uint8, device="cuda") for _ in self.batches]
+        self.cig_all = [torch.empty((self.cig_cap,), dtype=torch.int32, device="cuda") for _ in self.batches]
+        self.res_d, self.cig_d = self.res_all[0], self.cig_all[0]            # (launch 0's: what the identity checks read)
         torch.cuda.synchronize()
 
     def launch(self, b):
         t = self.batches[b]
+        res_d, cig_d = self.res_all[b], self.cig_all[b]
         if self.lens is not None:
             from bitmapperbs_amd import capi
             lib = capi.lib()
             if self.cfg["pe"]:
                 rc = lib.bmbs_map_pe_var_device(self.m._ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), self.lens[b].data_ptr(),
-                                                self.L, self.stride, self.n, self.res_d.data_ptr(), self.cig_d.data_ptr(), self.cig_cap)
+                                                self.L, self.stride, self.n, res_d.data_ptr(), cig_d.data_ptr(), self.cig_cap)
             else:
                 rc = lib.bmbs_map_se_var_device(self.m._ctx, t[0].data_ptr(), t[1].data_ptr(), self.lens[b].data_ptr(), self.L, self.stride, self.n,
-                                                self.res_d.data_ptr(), self.cig_d.data_ptr(), self.cig_cap)
+                                                res_d.data_ptr(), cig_d.data_ptr(), self.cig_cap)
             self.m._chk(rc)
         elif self.cfg["pe"]:
             self.m.map_pe_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), self.L, self.stride, self.n,
-                                 self.res_d.data_ptr(), self.cig_d.data_ptr(), self.cig_cap)
+                                 res_d.data_ptr(), cig_d.data_ptr(), self.cig_cap)
         else:
-            self.m.map_se_device(t[0].data_ptr(), t[1].data_ptr(), self.L, self.stride, self.n, self.res_d.data_ptr(),
-                                 self.cig_d.data_ptr(), self.cig_cap)
+            self.m.map_se_device(t[0].data_ptr(), t[1].data_ptr(), self.L, self.stride, self.n, res_d.data_ptr(),
+                                 cig_d.data_ptr(), self.cig_cap)
 
     def step(self):
         # nothing waits inside a step: the calls go to the context's lanes one behind the other (per-kernel HIP-event times
@@ -620,7 +624,7 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
         x.close()
     del ctxs
     torch.cuda.empty_cache()
-    return {"what": "main configuration, launches dealt to %d contexts sharing one index (a stream, work buffers and a host thread each; bmbs_search runs 2 per device by default)" % n_ctx,
+    return {"what": "main configuration, launches dealt to %d contexts sharing one index (a stream, work buffers and a host thread each; bmbs_search runs --contexts 4 per device by default)" % n_ctx,
             "value": round(job.reads_per_launch * total / dt / 1e6, 2), "unit": "Mreads/s", "timed_s": round(dt, 3),
             "ms_per_launch": round(dt / total * 1e3, 3)}
 

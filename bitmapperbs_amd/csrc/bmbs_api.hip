@@ -210,6 +210,8 @@ int ensure(Lane* c, DevBuf& b, size_t bytes, bool zero = false)
     if (b.cap >= bytes) return BMBS_OK;
     size_t want = bytes + bytes / 8 + 256;
     if (c->kn.arena && want <= ((size_t)256 << 20)) {              // larger ones keep a hipMalloc of their own (freed when they grow)
+        // an arena buffer leaves its old region behind when it grows: growing by half bounds what a stream of slowly rising needs strands
+        if (b.cap) want = std::min<size_t>(std::max(want, b.cap + b.cap / 2), (size_t)256 << 20);
         void* p = c->arena.alloc(want);
         if (!p) { c->err = "out of device memory (lane arena)"; return BMBS_ENOMEM; }
         if (b.p && !b.arena) (void)hipFree(b.p);
