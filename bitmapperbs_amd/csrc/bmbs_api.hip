@@ -2180,8 +2180,14 @@ int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int
     ZTextArgs A[2] = {{z1, &c->fq_text1, &c->z_comp, &c->z_off, &c->z_err}, {z2, &c->fq_text2, &c->z_comp2, &c->z_off2, &c->z_err2}};
     const int32_t last[2] = {last1, last2};
     u64 bytes[2] = {0, 0};
+    static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;
+    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double tp[6] = {wall(), 0, 0, 0, 0, 0};
     HIPCHK(c, hipMemsetAsync(c->tx_info.p, 0, 64, c->stream));
-    hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // each file on a stream of its own: upload, inflate (one wave per block: a launch of one file's blocks leaves most of the chip's
+    // wave slots empty, so the two files' launches run side by side), last line
+    hipStream_t fs[2] = {c->stream, c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream};
     for (int f = 0; f < (pe ? 2 : 1); f++) {
         const bmbs_ztext* z = A[f].z;
         const u64 nb = (u64)std::max<int64_t>(0, z->n_blocks);
@@ -2190,31 +2196,30 @@ int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int
         if (nb && z->blk_off[nb] > z->comp_bytes) { c->err = "text open: block table outside the compressed bytes"; return BMBS_EINVAL; }
         for (u64 i = 0; i < nb; i++)
             if (z->blk_off[i + 1] < z->blk_off[i] + 26 || z->out_off[i + 1] < z->out_off[i] || z->out_off[i + 1] - z->out_off[i] > 65536) { c->err = "text open: malformed block table"; return BMBS_EINVAL; }
-        // the prefix is aligned up to 16 bytes in front of the inflated text?  No: the text has to be contiguous -- the inflate kernel takes
-        // any byte offset, and the line kernels read the window from its (16-byte aligned) start
+        // (the text has to be contiguous behind the prefix: the inflate kernel takes any byte offset, and the line kernels read the
+        // window from its 16-byte aligned start)
         bytes[f] = z->prefix_bytes + text;
         if (bytes[f] + 1 >= (1ull << 32)) { c->err = "a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
         ENS(c, *A[f].text, bytes[f] + 64 + 16);
-        if (z->prefix_bytes) HIPCHK(c, hipMemcpyAsync(A[f].text->p, z->prefix, z->prefix_bytes, hipMemcpyHostToDevice, us));
-        if (nb) {
-            ENS(c, *A[f].comp, z->comp_bytes + 64); ENS(c, *A[f].off, 2 * (nb + 1) * 8 + 64); ENS(c, *A[f].err, nb * 4 + 64);
-            HIPCHK(c, hipMemcpyAsync(A[f].comp->p, z->comp, z->comp_bytes, hipMemcpyHostToDevice, us));
-            HIPCHK(c, hipMemcpyAsync(A[f].off->p, z->blk_off, (nb + 1) * 8, hipMemcpyHostToDevice, us));
-            HIPCHK(c, hipMemcpyAsync(A[f].off->as<u64>() + (nb + 1), z->out_off, (nb + 1) * 8, hipMemcpyHostToDevice, us));
-        }
+        if (nb) { ENS(c, *A[f].comp, z->comp_bytes + 1024); ENS(c, *A[f].off, 2 * (nb + 1) * 8 + 64); ENS(c, *A[f].err, nb * 4 + 64); }
     }
-    if (us != c->stream) HIPCHK(c, hipStreamSynchronize(us));
     for (int f = 0; f < (pe ? 2 : 1); f++) {
         const bmbs_ztext* z = A[f].z;
         const u64 nb = (u64)std::max<int64_t>(0, z->n_blocks);
-        if (nb)
-            hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)nb), dim3(64), 0, c->stream, A[f].comp->as<u8>(), A[f].off->as<u64>(), A[f].off->as<u64>() + (nb + 1), (long)nb,
+        if (z->prefix_bytes) HIPCHK(c, hipMemcpyAsync(A[f].text->p, z->prefix, z->prefix_bytes, hipMemcpyHostToDevice, fs[f]));
+        if (nb) {
+            HIPCHK(c, hipMemcpyAsync(A[f].comp->p, z->comp, z->comp_bytes, hipMemcpyHostToDevice, fs[f]));
+            HIPCHK(c, hipMemcpyAsync(A[f].off->p, z->blk_off, (nb + 1) * 8, hipMemcpyHostToDevice, fs[f]));
+            HIPCHK(c, hipMemcpyAsync(A[f].off->as<u64>() + (nb + 1), z->out_off, (nb + 1) * 8, hipMemcpyHostToDevice, fs[f]));
+            hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)nb), dim3(64), 0, fs[f], A[f].comp->as<u8>(), A[f].off->as<u64>(), A[f].off->as<u64>() + (nb + 1), (long)nb,
                                A[f].text->as<char>() + z->prefix_bytes, A[f].err->as<u32>());
+        }
         if (last[f] && bytes[f]) {
             // an unterminated last line counts as a line (the reader's rule): the newline is added here, on the device
-            hipLaunchKernelGGL(k_close_last_line, dim3(1), dim3(1), 0, c->stream, A[f].text->as<char>(), bytes[f], c->totals.as<u64>() + 21 + f);
-        } else HIPCHK(c, hipMemsetAsync(c->totals.as<u64>() + 21 + f, 0, 8, c->stream));
+            hipLaunchKernelGGL(k_close_last_line, dim3(1), dim3(1), 0, fs[f], A[f].text->as<char>(), bytes[f], c->totals.as<u64>() + 21 + f);
+        } else HIPCHK(c, hipMemsetAsync(c->totals.as<u64>() + 21 + f, 0, 8, fs[f]));
     }
+    if (pe && fs[1] != c->stream) HIPCHK(c, hipStreamSynchronize(fs[1]));
     // whether a newline was added has to be known before the lines are indexed
     HIPCHK(c, hipMemcpyAsync(c->h_info + 28, c->totals.as<u64>() + 21, 16, hipMemcpyDeviceToHost, c->stream));
     std::vector<u32> err[2];
@@ -2227,6 +2232,7 @@ int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int
     for (int f = 0; f < (pe ? 2 : 1); f++)
         for (size_t i = 0; i < err[f].size(); i++)
             if (err[f][i]) { c->err = "corrupt BGZF block in the .gz input (file " + std::to_string(f + 1) + ", block " + std::to_string(i) + " of this window, code " + std::to_string(err[f][i]) + ")"; return BMBS_EINVAL; }
+    tp[1] = wall();
     const u64* added = reinterpret_cast<const u64*>(c->h_info + 28);
     bytes[0] += added[0]; if (pe) bytes[1] += added[1];
     const u64 n_cap = (u64)max_records;
@@ -2235,6 +2241,7 @@ int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int
     if (pe) { rc = text_index(c, c->fq_text2, bytes[1], n_cap, 1); if (rc) return rc; }
     HIPCHK(c, hipMemcpyAsync(c->h_info + 16, c->totals.as<u64>() + 16, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    tp[2] = wall();
     const u64* lines = reinterpret_cast<const u64*>(c->h_info + 16);
     u64 n = lines[0] / 4;
     if (pe) n = std::min(n, lines[1] / 4);
@@ -2256,6 +2263,11 @@ int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int
         *tb[f] = t;
     }
     HIPCHK(c, hipStreamSynchronize(ds));
+    tp[3] = wall();
+    if (trace)
+        fprintf(stderr, "[text open] n=%ld comp=%.1fMB text=%.1fMB  upload+inflate %.2f  lines %.2f  tails %.2f (%.2f MB)  total %.2f ms\n", (long)n,
+                (double)(z1->comp_bytes + (z2 ? z2->comp_bytes : 0)) / 1e6, (double)(bytes[0] + bytes[1]) / 1e6, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3,
+                (double)(*tb[0] + (pe ? *tb[1] : 0)) / 1e6, (tp[3] - tp[0]) * 1e3);
     *n_records = (int64_t)n;
     c->open_text.valid = n > 0; c->open_text.pe = pe; c->open_text.bytes1 = cut[0]; c->open_text.bytes2 = cut[1]; c->open_text.n = (int64_t)n;
     return BMBS_OK;
@@ -2641,7 +2653,7 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
     static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;       // diagnostic: host-side phase times of every call
     auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     const double t0 = wall();
-    ENS(c, c->z_comp, comp_bytes + 64); ENS(c, c->z_off, 2 * (n + 1) * 8 + 64); ENS(c, c->z_text, out_off[n] + 64); ENS(c, c->z_err, n * 4 + 64);
+    ENS(c, c->z_comp, comp_bytes + 1024); ENS(c, c->z_off, 2 * (n + 1) * 8 + 64); ENS(c, c->z_text, out_off[n] + 64); ENS(c, c->z_err, n * 4 + 64);
     hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
     hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
     HIPCHK(c, hipMemcpyAsync(c->z_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, us));
@@ -2670,6 +2682,16 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
         if (err[i]) { c->err = "corrupt BGZF block in the .gz input (block " + std::to_string(i) + " of this window, code " + std::to_string(err[i]) + ")"; return BMBS_EINVAL; }
     return BMBS_OK;
 }
+
+#ifdef INF_PROFILE
+// profiling build only (tools/inflate_prof.sh): the phase cycle sums of k_bgzf_inflate since the last call
+extern "C" int bmbs_debug_inflate_prof(uint64_t* out16)
+{
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_inf_prof), sizeof z) != hipSuccess) return BMBS_ENODEV;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_inf_prof), z, sizeof z) == hipSuccess ? BMBS_OK : BMBS_ENODEV;
+}
+#endif
 
 // diagnostic: calls that were issued again with exact sizes because a stage count did not fit the capacity learned so far
 extern "C" int64_t bmbs_retries(bmbs_ctx* X)

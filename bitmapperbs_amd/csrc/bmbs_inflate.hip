@@ -4,9 +4,9 @@
 // series of independent gzip members of at most 64 KiB of text with their compressed size in the header: nothing in one block
 // depends on another, so a window of them is inflated here by one WAVE per block -- the host of an MI355X box (16 cores' worth of
 // CPU for the whole driver) inflates ~7 GB/s of text at best, a third of what the mapping path takes.
-//   every lane decodes the token that would start at its own bit offset (tables in LDS: 11-bit root for literals / lengths with two
-//   literals per entry where both codes fit, 10-bit root for distances; longer codes -- rare by construction -- by a canonical search
-//   on lane 0), a walk from offset 0 picks the tokens that are really there (~12 per 64-bit window of FASTQ text), literals are stored
+//   every lane decodes the token that would start at its own bit offset (tables in LDS: 10-bit root for literals / lengths with two
+//   literals per entry where both codes fit, 9-bit root for distances; longer codes -- rare by construction -- by a canonical search
+//   in the lane that holds them), a walk from offset 0 picks the tokens that are really there (~12 per 64-bit window of FASTQ text), literals are stored
 //   by their lanes, matches copied by the whole wave; the block's CRC-32 and ISIZE are checked against its trailer (segments
 //   combined with x^(8n) mod P as in bmbs_bam.hip).
 // Everything zlib's inflate refuses is refused (err[block] != 0): over-subscribed / incomplete codes, missing end-of-block code,
@@ -14,8 +14,18 @@
 #ifndef BMBS_INFLATE_HIP
 #define BMBS_INFLATE_HIP
 
-#define INF_LIT_ROOT 11
-#define INF_DIST_ROOT 10
+#define INF_LIT_ROOT 10
+#define INF_DIST_ROOT 9
+
+// -DINF_PROFILE (tools/inflate_prof.sh builds a second library with it): cycles per phase of k_bgzf_inflate, summed over the blocks
+#ifdef INF_PROFILE
+__device__ unsigned long long g_inf_prof[16];
+#define INF_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); prof[k] += t_ - t_last; t_last = t_; } while (0)
+#define INF_N(k, v) prof[k] += (v)
+#else
+#define INF_T(k)
+#define INF_N(k, v)
+#endif
 
 // entry = value << 16 | extra bits (or literal count) << 8 | kind << 5 | code bits
 #define IK_BAD 0
@@ -139,7 +149,7 @@ struct InfBits {             // lane 0's bit reader over global memory: aligned 
 
 // comp: the compressed bytes of n BGZF blocks, block b at comp + blk_off[b] (blk_off[n] = end); its text goes to text + out_off[b]
 // (out_off[b + 1] - out_off[b] = the ISIZE its trailer states).  err[b] = 0 when the block was well-formed and its CRC matched.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 4)
 k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, const u64* __restrict__ out_off, long n, char* __restrict__ text, u32* __restrict__ err)
 {
     __shared__ u32 s_lit[1 << INF_LIT_ROOT];
@@ -148,7 +158,6 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     __shared__ u16 s_sorted_l[288]; __shared__ u16 s_sorted_d[32]; __shared__ u16 s_sorted_c[20];
     __shared__ InfCode s_cl, s_cd, s_cc;
     __shared__ u32 s_crc_tab[256];
-    __shared__ u32 s_ev[8];                              // lane 0 -> wave: event, staged literals, match length, distance
     const long b = blockIdx.x;
     if (b >= n) return;
     const int lane = threadIdx.x;
@@ -157,6 +166,11 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     char* out = text + out_off[b];
     const u32 isize = (u32)(out_off[b + 1] - out_off[b]);
     u32 status = 0;                                       // 0 ok so far
+#ifdef INF_PROFILE
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = clock64();
+    const unsigned long long t_begin = t_last;
+#endif
     // ---- gzip member header (BGZF: FEXTRA with the BC subfield; any other well-formed header is read too)
     u32 body = 0;
     if (zlen < 18 + 8 || z[0] != 0x1f || z[1] != 0x8b || z[2] != 8 || (z[3] & 0xe0)) status = 1;
@@ -178,6 +192,11 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     s_cl.sorted = s_sorted_l; s_cd.sorted = s_sorted_d; s_cc.sorted = s_sorted_c;
     __syncthreads();
     InfBits in; in.init(z + body, z + zlen - 8);
+    // the compressed bytes, 256 at a time: lane l holds dword l of chunk kc (`cur`) and of the chunk behind it (`nxt`, on its way
+    // while `cur` is decoded); the five dwords under a window are picked out of them with v_readlane
+    const u32* zw = reinterpret_cast<const u32*>((size_t)z & ~(size_t)3);
+    const u32 zsh = ((u32)(size_t)z & 3u) * 8;
+    u32 kc = 0xfffffff0u, cur = 0, nxt = 0;
     u32 n_out = 0;                                        // bytes of text written so far (wave-uniform)
     u32 fenced = 0;                                       // every byte of the text below this offset is visible to every lane
     char last_byte = 0;                                   // the byte at n_out - 1 (wave-uniform)
@@ -272,18 +291,35 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         // offsets at once.  The tokens that really are in the stream are the ones reached from offset 0 by following the token
         // lengths: a walk over at most 64 lanes (one shuffle per token) that also hands every token its place in the text.  A
         // 64-bit window holds ~12 tokens of FASTQ text; one lane decoding alone took ~0.5 us per token (200 MB in 9-16 ms).
+        INF_T(0);
         u32 bp = 0;
         if (lane == 0) bp = (u32)((in.p - z) * 8) - (u32)in.cnt;
         bp = (u32)__shfl((int)bp, 0);
         const u32 end_bits = (u32)(zlen - 8) * 8;
         bool block_done = false;
         while (!block_done && !status) {
+            // (bp, the chain position and the output offsets are the same in every lane: kept in scalar registers, so that the words of
+            // the window come through the scalar cache and a token's fields are read with v_readlane instead of a shuffle through LDS)
+            bp = (u32)__builtin_amdgcn_readfirstlane((int)bp);
+            n_out = (u32)__builtin_amdgcn_readfirstlane((int)n_out);
             if (bp > end_bits) { status = 7; break; }
             // 160 bits from the aligned dword that holds bit bp (the same five words for every lane)
-            const size_t a = (size_t)z + (bp >> 3);
-            const u32* wp = reinterpret_cast<const u32*>(a & ~(size_t)3);
-            const u32 o = (u32)(a & 3) * 8 + (bp & 7u) + (u32)lane;                    // 0 .. 94
-            const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+            const u32 gb = zsh + bp, wq = gb >> 5, kq = (u32)__builtin_amdgcn_readfirstlane((int)(wq >> 6));
+            if (kq != kc) {
+                cur = kq == kc + 1 ? nxt : zw[(size_t)kq * 64 + lane];
+                nxt = zw[((size_t)kq + 1) * 64 + lane];
+                kc = kq;
+            }
+            const u32 wl = wq & 63u;
+            u32 dw[5];
+#pragma unroll
+            for (u32 i = 0; i < 5; i++) {
+                const u32 a = (u32)__builtin_amdgcn_readlane((int)cur, (int)((wl + i) & 63u)), c2 = (u32)__builtin_amdgcn_readlane((int)nxt, (int)((wl + i) & 63u));
+                dw[i] = wl + i < 64 ? a : c2;
+            }
+            const u32 d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3], d4 = dw[4];
+            const u32 o = (gb & 31u) + (u32)lane;                                          // 0 .. 94
+            INF_T(1); INF_N(9, 1);
             const u32 j = o >> 5, sh = o & 31u;
             const u32 x0 = j == 0 ? d0 : j == 1 ? d1 : d2, x1 = j == 0 ? d1 : j == 1 ? d2 : d3, x2 = j == 0 ? d2 : j == 1 ? d3 : d4;
             u64 v = (((u64)x1 << 32) | x0) >> sh;
@@ -306,27 +342,54 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 } else flag = dk == IK_LONG ? 2u : 3u;
             } else if (kind == IK_EOB) flag = 1;
             else flag = kind == IK_LONG ? 2u : 3u;
+            INF_T(2);
             // the chain from offset 0
             const u32 packed = tb | (flag << 6) | (ol << 8);
             u32 t = 0, run = n_out, stop = 0, stop_bits = 0, my_out = 0;
             bool mine = false;
             while (t < 64) {
-                const u32 p = (u32)__shfl((int)packed, (int)t);
+                const u32 p = (u32)__builtin_amdgcn_readlane((int)packed, (int)t);
                 if ((p >> 6) & 3u) { stop = (p >> 6) & 3u; stop_bits = p & 63u; break; }
                 if ((u32)lane == t) { mine = true; my_out = run; }
-                run += p >> 8; t += p & 63u;
+                run += p >> 8; t = (u32)__builtin_amdgcn_readfirstlane((int)(t + (p & 63u)));
             }
+            INF_T(3);
             if (run > isize) { status = 5; break; }
-            // literals first, then the matches in stream order (a match may read what the tokens before it have just stored)
+            // literals and the short matches whose bytes were all there before this window: every lane its own token, side by side
+            // (one round trip to memory for all of them -- FASTQ text is mostly 3..8-byte matches far back into the sequence lines);
+            // then the others in stream order, by the whole wave (a match may read what the tokens before it have just stored)
             const bool is_lit = mine && kind == IK_LIT, is_match = mine && kind == IK_BASE;
+            if (__ballot(is_match && mdist > my_out)) { status = 6; break; }
+            const bool small = is_match && mlen <= 16 && mdist >= mlen && my_out - mdist + mlen <= n_out;
+            if (__ballot(small && my_out - mdist + mlen > fenced)) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
             if (is_lit) { out[my_out] = (char)(e >> 16); if (ol == 2) out[my_out + 1] = (char)(e >> 24); }
+            char my_last = 0;
+            if (small) {
+                const char* sp = out + (my_out - mdist); char* dp = out + my_out;
+                u64 v0 = 0, v1 = 0;
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) if (k < mlen) v0 |= (u64)(u8)sp[k] << (8 * k);
+                if (mlen > 8) {
+#pragma unroll
+                    for (u32 k = 0; k < 8; k++) if (8 + k < mlen) v1 |= (u64)(u8)sp[8 + k] << (8 * k);
+                }
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) if (k < mlen) dp[k] = (char)(v0 >> (8 * k));
+                if (mlen > 8) {
+#pragma unroll
+                    for (u32 k = 0; k < 8; k++) if (8 + k < mlen) dp[8 + k] = (char)(v1 >> (8 * k));
+                }
+                my_last = (char)((mlen > 8 ? v1 : v0) >> (8 * ((mlen - 1) & 7u)));
+            }
             const unsigned long long chain = __ballot(mine);
-            unsigned long long mm = __ballot(is_match);
+            const unsigned long long par = __ballot(small);
+            unsigned long long mm = __ballot(is_match && !small);
+            INF_T(4); INF_N(10, __popcll(chain)); INF_N(11, __popcll(mm)); INF_N(12, __popcll(par));
             char tail = last_byte;                                                       // the byte in front of the next token
             while (mm) {
                 const int Lm = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                const u32 mo = (u32)__shfl((int)my_out, Lm), ml = (u32)__shfl((int)mlen, Lm), md = (u32)__shfl((int)mdist, Lm);
+                const u32 mo = (u32)__builtin_amdgcn_readlane((int)my_out, Lm), ml = (u32)__builtin_amdgcn_readlane((int)mlen, Lm), md = (u32)__builtin_amdgcn_readlane((int)mdist, Lm);
                 if (md > mo) { status = 6; break; }
                 char myv = 0;
                 // the byte in front of this match: the last literal of the token before it in this window, when that is a literal
@@ -334,8 +397,9 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 bool have_prev = false; char prev = 0;
                 if (before) {
                     const int Lp = 63 - __builtin_clzll(before);
-                    const u32 pe = (u32)__shfl((int)e, Lp);
+                    const u32 pe = (u32)__builtin_amdgcn_readlane((int)e, Lp);
                     if (((pe >> 5) & 7u) == IK_LIT) { have_prev = true; prev = (char)(((pe >> 8) & 31u) == 2 ? pe >> 24 : pe >> 16); }
+                    else if ((par >> Lp) & 1ull) { have_prev = true; prev = (char)__builtin_amdgcn_readlane((int)my_last, Lp); }
                 } else { have_prev = mo == n_out; prev = tail; }
                 if (md == 1 && have_prev) {
                     myv = prev;                                                          // a run of the byte before it (quality strings): no read at all
@@ -343,55 +407,61 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 } else {
                     // bytes stored since the last fence are not visible to the other lanes yet: a fence only when the source reaches into them
                     const u32 src_end = md >= ml ? mo - md + ml : mo;
-                    if (src_end > fenced) { __threadfence_block(); fenced = mo; }
+                    if (src_end > fenced) { __threadfence_block(); fenced = mo; INF_N(13, 1); }
                     for (u32 i = lane; i < ml; i += 64) { myv = out[mo - md + (md >= ml ? i : i % md)]; out[mo + i] = myv; }
                 }
                 // (kept for the next window: the last byte of the text so far when this match is the window's last token)
-                const char lastv = (char)__shfl((int)myv, (int)((ml - 1) & 63u));
+                const char lastv = (char)__builtin_amdgcn_readlane((int)myv, (int)((ml - 1) & 63u));
                 if (mo + ml == run) tail = lastv;
             }
+            INF_T(5);
             if (status) break;
             // the byte in front of the next window's first token
             if (chain) {
                 const int Ll = 63 - __builtin_clzll(chain);
-                const u32 le = (u32)__shfl((int)e, Ll);
+                const u32 le = (u32)__builtin_amdgcn_readlane((int)e, Ll);
                 if (((le >> 5) & 7u) == IK_LIT) tail = (char)(((le >> 8) & 31u) == 2 ? le >> 24 : le >> 16);
+                else if ((par >> Ll) & 1ull) tail = (char)__builtin_amdgcn_readlane((int)my_last, Ll);
             }
             last_byte = tail;
             n_out = run; bp += t;
             if (stop == 1) { bp += stop_bits; block_done = true; }
             else if (stop == 3) status = 7;
             else if (stop == 2) {
-                // a code longer than the root tables (rare by construction): this one token by lane 0, bit by bit
+                INF_N(14, 1);
+                // a code longer than the root tables (rare by construction): the lane the walk stopped at holds 64 bits from that
+                // token's first bit -- more than any token has (15 + 5 + 15 + 13) -- and searches the canonical codes in LDS by itself
                 u32 ev = 0, lit = 0, sl = 0, sd = 0, used = 0;
-                if (lane == 0) {
-                    InfBits q; q.init(z + (bp >> 3), z + zlen - 8);
-                    q.refill(); q.drop((int)(bp & 7u));
-                    const u32 c0 = (u32)((q.p - z) * 8) - (u32)q.cnt;
-                    q.refill();
-                    int l; int sy = -1;                                                   // -1 invalid, -2 a length code from the root table
-                    const u32 e1 = s_lit[q.buf & ((1u << INF_LIT_ROOT) - 1)];
-                    if (((e1 >> 5) & 7u) == IK_LONG) { sy = inf_search(s_cl, q.peek(15), INF_LIT_ROOT + 1, 15, l); if (sy >= 0) q.drop(l); }
-                    else if (((e1 >> 5) & 7u) == IK_BASE) { sy = -2; q.drop((int)(e1 & 31u)); sl = (e1 >> 16) + q.take((int)((e1 >> 8) & 31u)); }
-                    if (sy >= 257 && sy < 286) sl = c_len_base[sy - 257] + q.take((int)c_len_extra[sy - 257]);
+                if ((u32)lane == t) {
+                    u64 q = v;
+                    int l = 0; int sy = -1;                                               // -1 invalid, -2 a length code from the root table
+                    if (kind == IK_LONG) { sy = inf_search(s_cl, (u32)q & 0x7fffu, INF_LIT_ROOT + 1, 15, l); if (sy >= 0) { q >>= l; used += (u32)l; } }
+                    else if (kind == IK_BASE) {
+                        const u32 ex = (e >> 8) & 31u;
+                        sy = -2; q >>= e & 31u; used += e & 31u;
+                        sl = (e >> 16) + ((u32)q & ((1u << ex) - 1u)); q >>= ex; used += ex;
+                    }
+                    if (sy >= 257 && sy < 286) { const u32 ex = c_len_extra[sy - 257]; sl = c_len_base[sy - 257] + ((u32)q & ((1u << ex) - 1u)); q >>= ex; used += ex; }
                     if (sy == -1 || sy >= 286) ev = 9;
                     else if (sy >= 0 && sy < 256) { ev = 1; lit = (u32)sy; }
                     else if (sy == 256) ev = 3;
                     else {
-                        q.refill();
-                        const u32 d = s_dist[q.buf & ((1u << INF_DIST_ROOT) - 1)];
-                        if (((d >> 5) & 7u) == IK_LONG) {
-                            const int ds = inf_search(s_cd, q.peek(15), INF_DIST_ROOT + 1, 15, l);
-                            if (ds >= 0 && ds < 30) { q.drop(l); q.refill(); sd = c_dist_base[ds] + q.take((int)c_dist_extra[ds]); ev = 2; } else ev = 9;
-                        } else if (((d >> 5) & 7u) == IK_BASE) { q.drop((int)(d & 31u)); q.refill(); sd = (d >> 16) + q.take((int)((d >> 8) & 31u)); ev = 2; }
-                        else ev = 9;
+                        const u32 d = s_dist[(u32)q & ((1u << INF_DIST_ROOT) - 1)];
+                        const u32 dk = (d >> 5) & 7u;
+                        if (dk == IK_LONG) {
+                            const int ds = inf_search(s_cd, (u32)q & 0x7fffu, INF_DIST_ROOT + 1, 15, l);
+                            if (ds >= 0 && ds < 30) { q >>= l; used += (u32)l; const u32 dx = c_dist_extra[ds]; sd = c_dist_base[ds] + ((u32)q & ((1u << dx) - 1u)); used += dx; ev = 2; }
+                            else ev = 9;
+                        } else if (dk == IK_BASE) {
+                            const u32 dx = (d >> 8) & 31u;
+                            q >>= d & 31u; used += d & 31u;
+                            sd = (d >> 16) + ((u32)q & ((1u << dx) - 1u)); used += dx; ev = 2;
+                        } else ev = 9;
                     }
-                    used = (u32)((q.p - z) * 8) - (u32)q.cnt - c0;
-                    s_ev[0] = ev; s_ev[1] = lit; s_ev[2] = sl; s_ev[3] = sd; s_ev[4] = used;
                 }
-                __syncthreads();
-                ev = s_ev[0]; lit = s_ev[1]; sl = s_ev[2]; sd = s_ev[3]; used = s_ev[4];
-                __syncthreads();
+                ev = (u32)__builtin_amdgcn_readlane((int)ev, (int)t); lit = (u32)__builtin_amdgcn_readlane((int)lit, (int)t);
+                sl = (u32)__builtin_amdgcn_readlane((int)sl, (int)t); sd = (u32)__builtin_amdgcn_readlane((int)sd, (int)t);
+                used = (u32)__builtin_amdgcn_readlane((int)used, (int)t);
                 bp += used;
                 if (ev == 1) {
                     if (n_out + 1 > isize) { status = 5; break; }
@@ -408,6 +478,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 else status = 7;
             }
         }
+        INF_T(7);
         // the next block header is read by lane 0 from bp
         if (lane == 0) { in.init(z + (bp >> 3), z + zlen - 8); in.refill(); in.drop((int)(bp & 7u)); }
     }
@@ -431,6 +502,11 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         }
     }
     if (lane == 0) err[b] = status;
+#ifdef INF_PROFILE
+    INF_T(8);
+    prof[15] = clock64() - t_begin;
+    if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_inf_prof[k], prof[k]);
+#endif
 }
 
 // a window that ends the file: an unterminated last line gets its newline (the text buffer has the room); *added = 1 when it did
