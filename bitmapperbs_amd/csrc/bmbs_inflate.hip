@@ -147,6 +147,31 @@ struct InfBits {             // lane 0's bit reader over global memory: aligned 
     DEVI bool over() const { return p - ((cnt + 7) >> 3) > end; }
 };
 
+// the token that starts an LSB-first bit string v (64 bits of it): table entry, match length / distance, and
+// packed = bits of the token | flag << 6 | bytes of text << 9
+// (flag: 1 end of block, 2 a code longer than the root, 3 invalid, 4 a match of more than 64 bytes -- copied by the whole wave).
+// No branches: both look-ups are made whatever the first one says.
+struct InfTok { u32 e, packed, mlen, mdist; };
+DEVI InfTok inf_token(u64 v, const u32* s_lit, const u32* s_dist)
+{
+    InfTok k;
+    k.e = s_lit[(u32)v & ((1u << INF_LIT_ROOT) - 1)];
+    const u32 kind = (k.e >> 5) & 7u, tb0 = k.e & 31u, ex = (k.e >> 8) & 31u;
+    const bool base = kind == IK_BASE;
+    const u32 tb1 = tb0 + (base ? ex : 0u);
+    const u32 d = s_dist[(u32)(v >> tb1) & ((1u << INF_DIST_ROOT) - 1)];
+    const u32 dk = (d >> 5) & 7u, dx = (d >> 8) & 31u, tb2 = tb1 + (d & 31u);
+    k.mlen = (k.e >> 16) + ((u32)(v >> tb0) & ((1u << ex) - 1u));
+    k.mdist = (d >> 16) + ((u32)(v >> tb2) & ((1u << dx) - 1u));
+    const bool okm = base && dk == IK_BASE;
+    const u32 tb = okm ? tb2 + dx : tb0;
+    u32 flag = kind == IK_LIT ? 0u : kind == IK_EOB ? 1u : kind == IK_LONG ? 2u : base ? (dk == IK_BASE ? 0u : dk == IK_LONG ? 2u : 3u) : 3u;
+    if (okm && k.mlen > 64) flag = 4;
+    const u32 ol = kind == IK_LIT ? ex : okm ? k.mlen : 0u;
+    k.packed = tb | flag << 6 | ol << 9;
+    return k;
+}
+
 // comp: the compressed bytes of n BGZF blocks, block b at comp + blk_off[b] (blk_off[n] = end); its text goes to text + out_off[b]
 // (out_off[b + 1] - out_off[b] = the ISIZE its trailer states).  err[b] = 0 when the block was well-formed and its CRC matched.
 __global__ void __launch_bounds__(64, 4)
@@ -158,6 +183,9 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     __shared__ u16 s_sorted_l[288]; __shared__ u16 s_sorted_d[32]; __shared__ u16 s_sorted_c[20];
     __shared__ InfCode s_cl, s_cd, s_cc;
     __shared__ u32 s_crc_tab[256];
+    __shared__ u32 s_ref32[64];                           // the window being put together: where each of its 256 bytes comes from ...
+    __shared__ u8 s_val[256 + 16];                        // ... and the bytes that are known (literals, text from before the window)
+    u8* s_ref = reinterpret_cast<u8*>(s_ref32);
     const long b = blockIdx.x;
     if (b >= n) return;
     const int lane = threadIdx.x;
@@ -286,11 +314,11 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         if (!ok) { status = 4; break; }
         inf_root(s_cl, false, s_lit, INF_LIT_ROOT, lane);
         inf_root(s_cd, true, s_dist, INF_DIST_ROOT, lane);
-        // ---- symbols.  Every lane decodes the token that WOULD start at its own bit offset (bp + lane): one or two literals, a
-        // match with its length / distance codes and extra bits, or the end-of-block code -- two dependent LDS look-ups for all 64
-        // offsets at once.  The tokens that really are in the stream are the ones reached from offset 0 by following the token
-        // lengths: a walk over at most 64 lanes (one shuffle per token) that also hands every token its place in the text.  A
-        // 64-bit window holds ~12 tokens of FASTQ text; one lane decoding alone took ~0.5 us per token (200 MB in 9-16 ms).
+        // ---- symbols.  Every lane decodes the tokens that WOULD start at its own two bit offsets (bp + lane, bp + 64 + lane): one or
+        // two literals, a match with its length / distance codes and extra bits, or the end-of-block code -- two dependent LDS
+        // look-ups for all 128 offsets at once.  The tokens that really are in the stream are the ones reached from offset 0 by
+        // following the token lengths: a walk in scalar registers (one v_readlane per token) that also hands every token its place
+        // in the text.  A 128-bit window holds ~12 tokens of FASTQ text; one lane decoding alone took ~0.5 us per token.
         INF_T(0);
         u32 bp = 0;
         if (lane == 0) bp = (u32)((in.p - z) * 8) - (u32)in.cnt;
@@ -298,12 +326,12 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         const u32 end_bits = (u32)(zlen - 8) * 8;
         bool block_done = false;
         while (!block_done && !status) {
-            // (bp, the chain position and the output offsets are the same in every lane: kept in scalar registers, so that the words of
-            // the window come through the scalar cache and a token's fields are read with v_readlane instead of a shuffle through LDS)
+            // (bp, the chain position and the output offsets are the same in every lane: kept in scalar registers, so that a token's
+            // fields are read with v_readlane instead of a shuffle through LDS)
             bp = (u32)__builtin_amdgcn_readfirstlane((int)bp);
             n_out = (u32)__builtin_amdgcn_readfirstlane((int)n_out);
             if (bp > end_bits) { status = 7; break; }
-            // 160 bits from the aligned dword that holds bit bp (the same five words for every lane)
+            // 224 bits from the aligned dword that holds bit bp (the same seven words for every lane)
             const u32 gb = zsh + bp, wq = gb >> 5, kq = (u32)__builtin_amdgcn_readfirstlane((int)(wq >> 6));
             if (kq != kc) {
                 cur = kq == kc + 1 ? nxt : zw[(size_t)kq * 64 + lane];
@@ -311,129 +339,135 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 kc = kq;
             }
             const u32 wl = wq & 63u;
-            u32 dw[5];
+            u32 dw[7];
+            if (wl + 7 <= 64) {
+                // (the usual case touches `cur` alone: no wait for the chunk that is still on its way)
 #pragma unroll
-            for (u32 i = 0; i < 5; i++) {
-                const u32 a = (u32)__builtin_amdgcn_readlane((int)cur, (int)((wl + i) & 63u)), c2 = (u32)__builtin_amdgcn_readlane((int)nxt, (int)((wl + i) & 63u));
-                dw[i] = wl + i < 64 ? a : c2;
+                for (u32 i = 0; i < 7; i++) dw[i] = (u32)__builtin_amdgcn_readlane((int)cur, (int)(wl + i));
+            } else {
+#pragma unroll
+                for (u32 i = 0; i < 7; i++) {
+                    const u32 a = (u32)__builtin_amdgcn_readlane((int)cur, (int)((wl + i) & 63u)), c2 = (u32)__builtin_amdgcn_readlane((int)nxt, (int)((wl + i) & 63u));
+                    dw[i] = wl + i < 64 ? a : c2;
+                }
             }
-            const u32 d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3], d4 = dw[4];
             const u32 o = (gb & 31u) + (u32)lane;                                          // 0 .. 94
             INF_T(1); INF_N(9, 1);
+            // the tokens at this lane's two offsets: A at bp + lane, B 64 bits further
             const u32 j = o >> 5, sh = o & 31u;
-            const u32 x0 = j == 0 ? d0 : j == 1 ? d1 : d2, x1 = j == 0 ? d1 : j == 1 ? d2 : d3, x2 = j == 0 ? d2 : j == 1 ? d3 : d4;
-            u64 v = (((u64)x1 << 32) | x0) >> sh;
-            if (sh) v |= (u64)x2 << (64 - sh);
-            // the token at this offset
-            const u32 e = s_lit[(u32)v & ((1u << INF_LIT_ROOT) - 1)];
-            const u32 kind = (e >> 5) & 7u;
-            u32 tb = e & 31u, ol = 0, flag = 0, mlen = 0, mdist = 0;                       // flag: 1 end of block, 2 long code (serial), 3 invalid
-            if (kind == IK_LIT) ol = (e >> 8) & 31u;
-            else if (kind == IK_BASE) {
-                const u32 ex = (e >> 8) & 31u;
-                mlen = (e >> 16) + ((u32)(v >> tb) & ((1u << ex) - 1u)); tb += ex;
-                const u32 d = s_dist[(u32)(v >> tb) & ((1u << INF_DIST_ROOT) - 1)];
-                const u32 dk = (d >> 5) & 7u;
-                if (dk == IK_BASE) {
-                    const u32 dx = (d >> 8) & 31u;
-                    tb += d & 31u;
-                    mdist = (d >> 16) + ((u32)(v >> tb) & ((1u << dx) - 1u)); tb += dx;
-                    ol = mlen;
-                } else flag = dk == IK_LONG ? 2u : 3u;
-            } else if (kind == IK_EOB) flag = 1;
-            else flag = kind == IK_LONG ? 2u : 3u;
+            const u32 x0 = j == 0 ? dw[0] : j == 1 ? dw[1] : dw[2], x1 = j == 0 ? dw[1] : j == 1 ? dw[2] : dw[3], x2 = j == 0 ? dw[2] : j == 1 ? dw[3] : dw[4];
+            const u32 x3 = j == 0 ? dw[3] : j == 1 ? dw[4] : dw[5], x4 = j == 0 ? dw[4] : j == 1 ? dw[5] : dw[6];
+            u64 vA = (((u64)x1 << 32) | x0) >> sh, vB = (((u64)x3 << 32) | x2) >> sh;
+            if (sh) { vA |= (u64)x2 << (64 - sh); vB |= (u64)x4 << (64 - sh); }
+            const InfTok A = inf_token(vA, s_lit, s_dist), B = inf_token(vB, s_lit, s_dist);
             INF_T(2);
-            // the chain from offset 0
-            const u32 packed = tb | (flag << 6) | (ol << 8);
-            u32 t = 0, run = n_out, stop = 0, stop_bits = 0, my_out = 0;
-            bool mine = false;
+            // the chain from offset 0: the tokens it visits (mA, mB: one bit per lane) and their places in the text.  It ends at the
+            // first token that is not a plain one, or when the window (256 bytes of text from `lo` on, see below) is full.
+            const u32 lo = (u32)(size_t)(out + n_out) & 3u;                                // the window starts at the 4-byte boundary at or below n_out
+            u32 t = 0, run = n_out, stop = 0;
+            unsigned long long mA = 0, mB = 0;
+            u32 outA = 0, outB = 0;
             while (t < 64) {
-                const u32 p = (u32)__builtin_amdgcn_readlane((int)packed, (int)t);
-                if ((p >> 6) & 3u) { stop = (p >> 6) & 3u; stop_bits = p & 63u; break; }
-                if ((u32)lane == t) { mine = true; my_out = run; }
-                run += p >> 8; t = (u32)__builtin_amdgcn_readfirstlane((int)(t + (p & 63u)));
+                const u32 p = (u32)__builtin_amdgcn_readlane((int)A.packed, (int)t);
+                const u32 f = (p >> 6) & 7u, ol = p >> 9;
+                if (f) { stop = f; break; }
+                if (run - n_out + lo + ol > 256) { stop = 5; break; }
+                mA |= 1ull << t;
+                outA = (u32)lane == t ? run : outA;
+                run += ol; t = (u32)__builtin_amdgcn_readfirstlane((int)(t + (p & 63u)));
+            }
+            if (!stop) while (t < 128) {
+                const u32 p = (u32)__builtin_amdgcn_readlane((int)B.packed, (int)(t - 64));
+                const u32 f = (p >> 6) & 7u, ol = p >> 9;
+                if (f) { stop = f; break; }
+                if (run - n_out + lo + ol > 256) { stop = 5; break; }
+                mB |= 1ull << (t - 64);
+                outB = (u32)lane == t - 64 ? run : outB;
+                run += ol; t = (u32)__builtin_amdgcn_readfirstlane((int)(t + (p & 63u)));
             }
             INF_T(3);
             if (run > isize) { status = 5; break; }
-            // literals and the short matches whose bytes were all there before this window: every lane its own token, side by side
-            // (one round trip to memory for all of them -- FASTQ text is mostly 3..8-byte matches far back into the sequence lines);
-            // then the others in stream order, by the whole wave (a match may read what the tokens before it have just stored)
-            const bool is_lit = mine && kind == IK_LIT, is_match = mine && kind == IK_BASE;
-            if (__ballot(is_match && mdist > my_out)) { status = 6; break; }
-            const bool small = is_match && mlen <= 16 && mdist >= mlen && my_out - mdist + mlen <= n_out;
-            if (__ballot(small && my_out - mdist + mlen > fenced)) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
-            if (is_lit) { out[my_out] = (char)(e >> 16); if (ol == 2) out[my_out + 1] = (char)(e >> 24); }
-            char my_last = 0;
-            if (small) {
-                const char* sp = out + (my_out - mdist); char* dp = out + my_out;
-                u64 v0 = 0, v1 = 0;
-#pragma unroll
-                for (u32 k = 0; k < 8; k++) if (k < mlen) v0 |= (u64)(u8)sp[k] << (8 * k);
-                if (mlen > 8) {
-#pragma unroll
-                    for (u32 k = 0; k < 8; k++) if (8 + k < mlen) v1 |= (u64)(u8)sp[8 + k] << (8 * k);
+            INF_N(10, __popcll(mA) + __popcll(mB));
+            if (run > n_out) {
+                // ---- the bytes of these tokens, put together in LDS.  Byte i of the window (text offset n_out - lo + i) is a literal,
+                // or a copy of text from before the window (read from memory: one round trip for all tokens at once), or a copy of an
+                // earlier byte of the window itself: s_ref[i] = that byte's index.  Following the references to their ends (pointer
+                // jumping, a few LDS rounds while the reads from memory are on their way) gives every byte, however the matches lean on
+                // each other -- bisulfite reads are three-letter text, zlib's matches there reach 20..40 bytes back -- and the
+                // window is stored with one aligned dword per lane.
+                const bool mineA = (mA >> lane) & 1ull, mineB = (mB >> lane) & 1ull;
+                const u32 kindA = (A.e >> 5) & 7u, kindB = (B.e >> 5) & 7u;
+                const bool litA = mineA && kindA == IK_LIT, litB = mineB && kindB == IK_LIT;
+                const bool matA = mineA && kindA == IK_BASE, matB = mineB && kindB == IK_BASE;
+                if (__ballot((matA && A.mdist > outA) || (matB && B.mdist > outB))) { status = 6; break; }
+                const u32 idxA = outA - n_out + lo, idxB = outB - n_out + lo;               // window index of the token's first byte
+                // bytes of a match that come from before the window: its first ext bytes
+                const u32 extA = matA && outA - A.mdist < n_out ? min(A.mlen, n_out - (outA - A.mdist)) : 0u;
+                const u32 extB = matB && outB - B.mdist < n_out ? min(B.mlen, n_out - (outB - B.mdist)) : 0u;
+                if (__ballot((extA && outA - A.mdist + extA > fenced) || (extB && outB - B.mdist + extB > fenced))) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
+                // (unaligned 8-byte loads: the bytes behind a match's source come along and are dropped -- the text buffer has the slack)
+                u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                if (extA) { const char* sp = out + (outA - A.mdist); __builtin_memcpy(&a0, sp, 8); if (extA > 8) __builtin_memcpy(&a1, sp + 8, 8); }
+                if (extB) { const char* sp = out + (outB - B.mdist); __builtin_memcpy(&b0, sp, 8); if (extB > 8) __builtin_memcpy(&b1, sp + 8, 8); }
+                s_ref32[lane] = (u32)lane * 0x04040404u + 0x03020100u;                      // every byte its own source
+                __syncthreads();
+                if (litA) { s_val[idxA] = (u8)(A.e >> 16); if (((A.e >> 8) & 31u) == 2) s_val[idxA + 1] = (u8)(A.e >> 24); }
+                if (litB) { s_val[idxB] = (u8)(B.e >> 16); if (((B.e >> 8) & 31u) == 2) s_val[idxB + 1] = (u8)(B.e >> 24); }
+                if (matA) for (u32 i = extA; i < A.mlen; i++) s_ref[idxA + i] = (u8)(idxA + i - A.mdist);
+                if (matB) for (u32 i = extB; i < B.mlen; i++) s_ref[idxB + i] = (u8)(idxB + i - B.mdist);
+                const bool inside = __ballot((matA && extA < A.mlen) || (matB && extB < B.mlen)) != 0;
+                __syncthreads();
+                if (inside) {
+                    for (int it = 0; it < 9; it++) {
+                        const u32 r4 = s_ref32[lane];
+                        const u32 n4 = (u32)s_ref[r4 & 255u] | (u32)s_ref[(r4 >> 8) & 255u] << 8 | (u32)s_ref[(r4 >> 16) & 255u] << 16 | (u32)s_ref[r4 >> 24] << 24;
+                        __syncthreads();
+                        s_ref32[lane] = n4;
+                        __syncthreads();
+                        if (!__ballot(n4 != r4)) break;
+                    }
                 }
+                INF_T(4);
+                // the text from before the window, as it arrives
+                for (u32 i = 0; i < (extA < 16u ? extA : 16u); i++) s_val[idxA + i] = (u8)((i < 8 ? a0 : a1) >> (8 * (i & 7u)));
+                for (u32 i = 0; i < (extB < 16u ? extB : 16u); i++) s_val[idxB + i] = (u8)((i < 8 ? b0 : b1) >> (8 * (i & 7u)));
+                for (u32 i = 16; i < extA; i++) s_val[idxA + i] = (u8)out[outA - A.mdist + i];
+                for (u32 i = 16; i < extB; i++) s_val[idxB + i] = (u8)out[outB - B.mdist + i];
+                __syncthreads();
+                const u32 r4 = s_ref32[lane];
+                const u32 w = (u32)s_val[r4 & 255u] | (u32)s_val[(r4 >> 8) & 255u] << 8 | (u32)s_val[(r4 >> 16) & 255u] << 16 | (u32)s_val[r4 >> 24] << 24;
+                const u32 hi = run - n_out + lo;                                            // window bytes [lo, hi) are text
+                char* wp = out + n_out - lo + 4 * (u32)lane;
+                const u32 r0 = 4 * (u32)lane;
+                if (r0 >= lo && r0 + 4 <= hi) *reinterpret_cast<u32*>(wp) = w;
+                else {
 #pragma unroll
-                for (u32 k = 0; k < 8; k++) if (k < mlen) dp[k] = (char)(v0 >> (8 * k));
-                if (mlen > 8) {
-#pragma unroll
-                    for (u32 k = 0; k < 8; k++) if (8 + k < mlen) dp[8 + k] = (char)(v1 >> (8 * k));
+                    for (u32 k = 0; k < 4; k++) if (r0 + k >= lo && r0 + k < hi) wp[k] = (char)(w >> (8 * k));
                 }
-                my_last = (char)((mlen > 8 ? v1 : v0) >> (8 * ((mlen - 1) & 7u)));
+                last_byte = (char)((u32)__builtin_amdgcn_readlane((int)w, (int)((hi - 1) >> 2)) >> (8 * ((hi - 1) & 3u)));
+                __syncthreads();
+                INF_T(5);
             }
-            const unsigned long long chain = __ballot(mine);
-            const unsigned long long par = __ballot(small);
-            unsigned long long mm = __ballot(is_match && !small);
-            INF_T(4); INF_N(10, __popcll(chain)); INF_N(11, __popcll(mm)); INF_N(12, __popcll(par));
-            char tail = last_byte;                                                       // the byte in front of the next token
-            while (mm) {
-                const int Lm = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const u32 mo = (u32)__builtin_amdgcn_readlane((int)my_out, Lm), ml = (u32)__builtin_amdgcn_readlane((int)mlen, Lm), md = (u32)__builtin_amdgcn_readlane((int)mdist, Lm);
-                if (md > mo) { status = 6; break; }
-                char myv = 0;
-                // the byte in front of this match: the last literal of the token before it in this window, when that is a literal
-                const unsigned long long before = chain & ((1ull << Lm) - 1ull);
-                bool have_prev = false; char prev = 0;
-                if (before) {
-                    const int Lp = 63 - __builtin_clzll(before);
-                    const u32 pe = (u32)__builtin_amdgcn_readlane((int)e, Lp);
-                    if (((pe >> 5) & 7u) == IK_LIT) { have_prev = true; prev = (char)(((pe >> 8) & 31u) == 2 ? pe >> 24 : pe >> 16); }
-                    else if ((par >> Lp) & 1ull) { have_prev = true; prev = (char)__builtin_amdgcn_readlane((int)my_last, Lp); }
-                } else { have_prev = mo == n_out; prev = tail; }
-                if (md == 1 && have_prev) {
-                    myv = prev;                                                          // a run of the byte before it (quality strings): no read at all
-                    for (u32 i = lane; i < ml; i += 64) out[mo + i] = myv;
-                } else {
-                    // bytes stored since the last fence are not visible to the other lanes yet: a fence only when the source reaches into them
-                    const u32 src_end = md >= ml ? mo - md + ml : mo;
-                    if (src_end > fenced) { __threadfence_block(); fenced = mo; INF_N(13, 1); }
-                    for (u32 i = lane; i < ml; i += 64) { myv = out[mo - md + (md >= ml ? i : i % md)]; out[mo + i] = myv; }
-                }
-                // (kept for the next window: the last byte of the text so far when this match is the window's last token)
-                const char lastv = (char)__builtin_amdgcn_readlane((int)myv, (int)((ml - 1) & 63u));
-                if (mo + ml == run) tail = lastv;
-            }
-            INF_T(5);
-            if (status) break;
-            // the byte in front of the next window's first token
-            if (chain) {
-                const int Ll = 63 - __builtin_clzll(chain);
-                const u32 le = (u32)__builtin_amdgcn_readlane((int)e, Ll);
-                if (((le >> 5) & 7u) == IK_LIT) tail = (char)(((le >> 8) & 31u) == 2 ? le >> 24 : le >> 16);
-                else if ((par >> Ll) & 1ull) tail = (char)__builtin_amdgcn_readlane((int)my_last, Ll);
-            }
-            last_byte = tail;
             n_out = run; bp += t;
-            if (stop == 1) { bp += stop_bits; block_done = true; }
+            const u32 tl = t & 63u;
+            // the token the chain stopped at
+            const u32 sp_ = t < 64 ? (u32)__builtin_amdgcn_readlane((int)A.packed, (int)tl) : (u32)__builtin_amdgcn_readlane((int)B.packed, (int)tl);
+            if (stop == 1) { bp += sp_ & 63u; block_done = true; }
             else if (stop == 3) status = 7;
-            else if (stop == 2) {
+            else if (stop == 2 || stop == 4) {
                 INF_N(14, 1);
+                u32 ev = 0, lit = 0, sl = 0, sd = 0, used = 0;
+                if (stop == 4) {
+                    // a long match (a quality string): by the whole wave
+                    ev = 2; used = sp_ & 63u;
+                    sl = t < 64 ? (u32)__builtin_amdgcn_readlane((int)A.mlen, (int)tl) : (u32)__builtin_amdgcn_readlane((int)B.mlen, (int)tl);
+                    sd = t < 64 ? (u32)__builtin_amdgcn_readlane((int)A.mdist, (int)tl) : (u32)__builtin_amdgcn_readlane((int)B.mdist, (int)tl);
+                } else {
                 // a code longer than the root tables (rare by construction): the lane the walk stopped at holds 64 bits from that
                 // token's first bit -- more than any token has (15 + 5 + 15 + 13) -- and searches the canonical codes in LDS by itself
-                u32 ev = 0, lit = 0, sl = 0, sd = 0, used = 0;
-                if ((u32)lane == t) {
-                    u64 q = v;
+                if ((u32)lane == tl) {
+                    u64 q = t < 64 ? vA : vB;
+                    const u32 e = t < 64 ? A.e : B.e, kind = (e >> 5) & 7u;
                     int l = 0; int sy = -1;                                               // -1 invalid, -2 a length code from the root table
                     if (kind == IK_LONG) { sy = inf_search(s_cl, (u32)q & 0x7fffu, INF_LIT_ROOT + 1, 15, l); if (sy >= 0) { q >>= l; used += (u32)l; } }
                     else if (kind == IK_BASE) {
@@ -459,9 +493,10 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                         } else ev = 9;
                     }
                 }
-                ev = (u32)__builtin_amdgcn_readlane((int)ev, (int)t); lit = (u32)__builtin_amdgcn_readlane((int)lit, (int)t);
-                sl = (u32)__builtin_amdgcn_readlane((int)sl, (int)t); sd = (u32)__builtin_amdgcn_readlane((int)sd, (int)t);
-                used = (u32)__builtin_amdgcn_readlane((int)used, (int)t);
+                ev = (u32)__builtin_amdgcn_readlane((int)ev, (int)tl); lit = (u32)__builtin_amdgcn_readlane((int)lit, (int)tl);
+                sl = (u32)__builtin_amdgcn_readlane((int)sl, (int)tl); sd = (u32)__builtin_amdgcn_readlane((int)sd, (int)tl);
+                used = (u32)__builtin_amdgcn_readlane((int)used, (int)tl);
+                }
                 bp += used;
                 if (ev == 1) {
                     if (n_out + 1 > isize) { status = 5; break; }
@@ -469,16 +504,22 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                     n_out++; last_byte = (char)lit;
                 } else if (ev == 2) {
                     if (sd > n_out || n_out + sl > isize) { status = 6; break; }
-                    __threadfence_block(); fenced = n_out;
-                    char myv = 0;
-                    for (u32 i = lane; i < sl; i += 64) { myv = out[n_out - sd + (sd >= sl ? i : i % sd)]; out[n_out + i] = myv; }
-                    last_byte = (char)__shfl((int)myv, (int)((sl - 1) & 63u));
+                    char myv = last_byte;
+                    if (sd == 1) {
+                        // a run of the byte in front of it (quality strings): no read at all
+                        for (u32 i = lane; i < sl; i += 64) out[n_out + i] = myv;
+                    } else {
+                        // bytes stored since the last fence are not visible to the other lanes yet: a fence when the source reaches into them
+                        if ((sd >= sl ? n_out - sd + sl : n_out) > fenced) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
+                        for (u32 i = lane; i < sl; i += 64) { myv = out[n_out - sd + (sd >= sl ? i : i % sd)]; out[n_out + i] = myv; }
+                    }
+                    last_byte = (char)__builtin_amdgcn_readlane((int)myv, (int)((sl - 1) & 63u));
                     n_out += sl;
                 } else if (ev == 3) block_done = true;
                 else status = 7;
             }
+            INF_T(7);
         }
-        INF_T(7);
         // the next block header is read by lane 0 from bp
         if (lane == 0) { in.init(z + (bp >> 3), z + zlen - 8); in.refill(); in.drop((int)(bp & 7u)); }
     }

@@ -1074,6 +1074,44 @@ int main(int argc, char** argv)
         if (!tails[0].need(tail_cap) || (pe && !tails[1].need(tail_cap))) { fail("cannot allocate page-locked staging memory"); return true; }
         Source* S[2] = {&pt->s1, &pt->s2};
         const int nf = pe ? 2 : 1;
+        // the compressed bytes of a window, staged: block tables and a page-locked copy per file.  Two of them: while a context opens
+        // one window (upload, inflate, index: the reader waits for the device), a helper thread stages the next
+        struct Staged {
+            Pinned buf[2]; std::vector<uint64_t> blk[2], out[2];
+            size_t a[2] = {0, 0}, q[2] = {0, 0};
+            bool foreign_any = false, ok = true; std::string err;
+        } st[2];
+        for (auto& x : st) { x.buf[0].kind = 1; x.buf[1].kind = 1; }
+        auto stage = [&](Staged& g, size_t room0, size_t room1) {
+            g.foreign_any = false; g.ok = true;
+            const size_t room[2] = {room0, room1};
+            for (int f = 0; f < nf && g.ok; f++) {
+                Source& s = *S[f];
+                bool foreign = false;
+                if (!s.next_blocks(room[f], g.a[f], g.q[f], foreign)) { g.ok = false; g.err = s.err; break; }
+                if (foreign && g.q[f] == g.a[f]) { g.foreign_any = true; continue; }
+                g.blk[f] = s.zblk; g.out[f] = s.zout;
+                const size_t zbytes = g.q[f] - g.a[f];
+                if (zbytes) {
+                    if (!g.buf[f].need(zbytes + 64)) { g.ok = false; g.err = "cannot allocate page-locked staging memory"; break; }
+                    Pool& pl = f ? pool2 : pool;
+                    const int T = pl.size() * 2;
+                    const size_t per = ((zbytes + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+                    char* dst = g.buf[f].p; const unsigned char* src = s.zmap + g.a[f];
+                    pl.run(T, [&](int t) { const size_t x = std::min(zbytes, per * (size_t)t), y = std::min(zbytes, x + per); if (x < y) memcpy(dst + x, src + x, y - x); });
+                }
+                s.znext = g.q[f];
+            }
+        };
+        auto room_for = [&](size_t est_now, int f) {
+            const size_t target = std::min<size_t>((size_t)batch * est_now + (1u << 16), (size_t)3500 << 20);
+            return target > S[f]->carry.size() ? target - S[f]->carry.size() : (size_t)0;
+        };
+        int cur = 0;
+        stage(st[0], room_for(est, 0), pe ? room_for(est, 1) : 0);
+        std::thread ahead;
+        auto join_ahead = [&] { if (ahead.joinable()) ahead.join(); };
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ahead};
         for (;;) {
             const double tw0 = now();
             Batch* b = free_q.get();
@@ -1081,23 +1119,18 @@ int main(int argc, char** argv)
             const double t0 = now();
             pt->t_wait_r += t0 - tw0;
             b->part = pt; b->seq = pt->next_seq++; b->n = 0; b->end = false; b->used1 = b->used2 = 0; b->sam_bytes = 0; b->open_ctx = nullptr;
-            auto bail = [&](const std::string& why) { fail(why); b->end = true; b->n = 0; ctx_pool.put(ctx); gpu_q.put(b); };
-            if (failed) { b->end = true; ctx_pool.put(ctx); gpu_q.put(b); return true; }
+            auto bail = [&](const std::string& why) { join_ahead(); fail(why); b->end = true; b->n = 0; ctx_pool.put(ctx); gpu_q.put(b); };
+            if (failed) { join_ahead(); b->end = true; ctx_pool.put(ctx); gpu_q.put(b); return true; }
+            join_ahead();
+            Staged& g = st[cur];
+            if (!g.ok) { bail(g.err); return true; }
             const size_t target = std::min<size_t>((size_t)batch * est + (1u << 16), (size_t)3500 << 20);
             bmbs_ztext z[2]; memset(z, 0, sizeof z);
-            size_t a[2] = {0, 0}, q[2] = {0, 0};
-            bool foreign_any = false;
-            for (int f = 0; f < nf; f++) {
-                Source& s = *S[f];
-                bool foreign = false;
-                const size_t room = target > s.carry.size() ? target - s.carry.size() : 0;
-                if (!s.next_blocks(room, a[f], q[f], foreign)) { bail(s.err); return true; }
-                if (foreign && q[f] == a[f]) foreign_any = true;
-            }
-            if (foreign_any) {
+            if (g.foreign_any) {
                 // the rest of such a file goes through the host's stream inflater; blocks already taken for this window are given back
                 for (int f = 0; f < nf; f++) {
                     Source& s = *S[f];
+                    s.znext = g.a[f];
                     if (s.znext < s.zsize && !s.bgzf_block(s.zmap + s.znext, s.zsize - s.znext)) { std::lock_guard<std::mutex> l(s.m); s.zdirect = false; const size_t at = s.znext; s.znext = s.zsize; s.start_pgz(at, 0); }
                 }
                 pt->next_seq--;                                     // (the batch was not used)
@@ -1109,20 +1142,19 @@ int main(int argc, char** argv)
             size_t text_bytes = 0;
             for (int f = 0; f < nf; f++) {
                 Source& s = *S[f];
-                const size_t zbytes = q[f] - a[f];
-                if (zbytes) {
-                    if (!s.zstage.need(zbytes + 64)) { bail("cannot allocate page-locked staging memory"); return true; }
-                    Pool& pl = f ? pool2 : pool;
-                    const int T = pl.size() * 2;
-                    const size_t per = ((zbytes + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
-                    pl.run(T, [&](int t) { const size_t x = std::min(zbytes, per * (size_t)t), y = std::min(zbytes, x + per); if (x < y) memcpy(s.zstage.p + x, s.zmap + a[f] + x, y - x); });
-                }
-                s.znext = q[f];
                 z[f].prefix = s.carry.empty() ? nullptr : s.carry.data(); z[f].prefix_bytes = s.carry.size();
-                z[f].comp = s.zstage.p; z[f].comp_bytes = zbytes; z[f].blk_off = s.zblk.data(); z[f].out_off = s.zout.data(); z[f].n_blocks = (int64_t)s.zblk.size() - 1;
-                text_bytes += s.carry.size() + (size_t)s.zout.back();
+                z[f].comp = g.buf[f].p; z[f].comp_bytes = g.q[f] - g.a[f]; z[f].blk_off = g.blk[f].data(); z[f].out_off = g.out[f].data(); z[f].n_blocks = (int64_t)g.blk[f].size() - 1;
+                text_bytes += s.carry.size() + (size_t)g.out[f].back();
             }
-            const bool last1 = pt->s1.znext >= pt->s1.zsize, last2 = pe && pt->s2.znext >= pt->s2.zsize;
+            const bool last1 = g.q[0] >= pt->s1.zsize, last2 = pe && g.q[1] >= pt->s2.zsize;
+            // the window behind this one is staged while the device works on this one (what this window will leave over is not known
+            // yet: the last window's leftover stands in for it when the room is measured)
+            {
+                const size_t r0 = room_for(est, 0), r1 = pe ? room_for(est, 1) : 0;
+                Staged* nx = &st[cur ^ 1];
+                ahead = std::thread([&stage, nx, r0, r1] { stage(*nx, r0, r1); });
+                cur ^= 1;
+            }
             int64_t nrec = 0; uint64_t tb[2] = {0, 0};
             // every whole record of the window is taken (the window is what bounds a batch here: --batch records by the running estimate of a record's size)
             const int rc = bmbs_text_open_bgzf(ctx, &z[0], pe ? &z[1] : nullptr, 4 * (int64_t)batch, last1 ? 1 : 0, last2 ? 1 : 0, &nrec, tails[0].p, tail_cap, &tb[0],

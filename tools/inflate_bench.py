@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/inflate_bench.py [MB=160] [lib] -- on the GPU box: k_bgzf_inflate alone on FASTQ-like text (bgzip level 1 blocks), kernel
+"""tools/inflate_bench.py [MB=160 | file.fq] [lib] -- on the GPU box: k_bgzf_inflate alone on FASTQ-like text (bgzip level 1 blocks), kernel
 time from the library's own trace (BMBS_TEXT_TRACE).  With a library built with -DINF_PROFILE (tools/inflate_prof.sh) as the second
 argument it also prints the cycles per phase."""
 import ctypes as C
@@ -43,8 +43,12 @@ def bgzf(data, level=1):
 
 
 def main():
-    mb = int(sys.argv[1]) if len(sys.argv) > 1 else 160
-    text = fastq_text(mb)
+    arg = sys.argv[1] if len(sys.argv) > 1 else "160"
+    if arg.isdigit():
+        text = fastq_text(int(arg))
+    else:                                        # the first 160 MB of a FASTQ file
+        with open(arg, "rb") as f:
+            text = f.read(160_000_000)
     comp = bgzf(text)
     print("text %.1f MB -> %.1f MB of BGZF" % (len(text) / 1e6, len(comp) / 1e6), flush=True)
     L = capi.lib()
@@ -72,13 +76,13 @@ def main():
         inflate()
         L.bmbs_debug_inflate_prof(out)
         v = list(out)
-        names = ["header+tables", "window load", "lookups", "chain walk", "literal stores", "matches", "fences", "block tail", "crc",
+        names = ["header+tables", "window words", "lookups", "chain walk", "fence+refs+jumps", "text+gather+store", "-", "stop tokens", "crc",
                  "windows", "tokens", "serial matches#", "lane matches#", "fences#", "long codes#", "total"]
         tot = v[15]
-        for k in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        for k in (0, 1, 2, 3, 4, 5, 7, 8):
             print("  %-16s %6.1f%%" % (names[k], 100.0 * v[k] / tot))
-        print("  windows %d  tokens %d  matches by the wave %d, by their lanes %d  fences %d  long codes %d  cycles/window %.0f" %
-              (v[9], v[10], v[11], v[12], v[13], v[14], tot / max(1, v[9])))
+        print("  windows %d  tokens in them %d  fences %d  tokens by the wave (long codes, long matches) %d  cycles/window %.0f" %
+              (v[9], v[10], v[13], v[14], tot / max(1, v[9])))
 
 
 main()
