@@ -149,7 +149,7 @@ struct InfBits {             // lane 0's bit reader over global memory: aligned 
 
 // the token that starts an LSB-first bit string v (64 bits of it): table entry, match length / distance, and
 // packed = bits of the token | flag << 6 | bytes of text << 9
-// (flag: 1 end of block, 2 a code longer than the root, 3 invalid, 4 a match of more than 64 bytes -- copied by the whole wave).
+// (flag: 1 end of block, 2 a code longer than the root, 3 invalid, 4 a match that would not fit into a window -- copied by the whole wave).
 // No branches: both look-ups are made whatever the first one says.
 struct InfTok { u32 e, packed, mlen, mdist; };
 DEVI InfTok inf_token(u64 v, const u32* s_lit, const u32* s_dist)
@@ -166,7 +166,7 @@ DEVI InfTok inf_token(u64 v, const u32* s_lit, const u32* s_dist)
     const bool okm = base && dk == IK_BASE;
     const u32 tb = okm ? tb2 + dx : tb0;
     u32 flag = kind == IK_LIT ? 0u : kind == IK_EOB ? 1u : kind == IK_LONG ? 2u : base ? (dk == IK_BASE ? 0u : dk == IK_LONG ? 2u : 3u) : 3u;
-    if (okm && k.mlen > 64) flag = 4;
+    if (okm && k.mlen > 250) flag = 4;
     const u32 ol = kind == IK_LIT ? ex : okm ? k.mlen : 0u;
     k.packed = tb | flag << 6 | ol << 9;
     return k;
@@ -404,36 +404,53 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 // bytes of a match that come from before the window: its first ext bytes
                 const u32 extA = matA && outA - A.mdist < n_out ? min(A.mlen, n_out - (outA - A.mdist)) : 0u;
                 const u32 extB = matB && outB - B.mdist < n_out ? min(B.mlen, n_out - (outB - B.mdist)) : 0u;
+                const bool shortA = matA && A.mlen <= 16, shortB = matB && B.mlen <= 16;   // by their own lanes; longer ones by the wave
                 if (__ballot((extA && outA - A.mdist + extA > fenced) || (extB && outB - B.mdist + extB > fenced))) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
                 // (unaligned 8-byte loads: the bytes behind a match's source come along and are dropped -- the text buffer has the slack)
                 u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-                if (extA) { const char* sp = out + (outA - A.mdist); __builtin_memcpy(&a0, sp, 8); if (extA > 8) __builtin_memcpy(&a1, sp + 8, 8); }
-                if (extB) { const char* sp = out + (outB - B.mdist); __builtin_memcpy(&b0, sp, 8); if (extB > 8) __builtin_memcpy(&b1, sp + 8, 8); }
+                if (extA && shortA) { const char* sp = out + (outA - A.mdist); __builtin_memcpy(&a0, sp, 8); if (extA > 8) __builtin_memcpy(&a1, sp + 8, 8); }
+                if (extB && shortB) { const char* sp = out + (outB - B.mdist); __builtin_memcpy(&b0, sp, 8); if (extB > 8) __builtin_memcpy(&b1, sp + 8, 8); }
+                // (one wave, and a wave's LDS operations complete in the order they were issued: no s_barrier between the steps below)
                 s_ref32[lane] = (u32)lane * 0x04040404u + 0x03020100u;                      // every byte its own source
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
                 if (litA) { s_val[idxA] = (u8)(A.e >> 16); if (((A.e >> 8) & 31u) == 2) s_val[idxA + 1] = (u8)(A.e >> 24); }
                 if (litB) { s_val[idxB] = (u8)(B.e >> 16); if (((B.e >> 8) & 31u) == 2) s_val[idxB + 1] = (u8)(B.e >> 24); }
-                if (matA) for (u32 i = extA; i < A.mlen; i++) s_ref[idxA + i] = (u8)(idxA + i - A.mdist);
-                if (matB) for (u32 i = extB; i < B.mlen; i++) s_ref[idxB + i] = (u8)(idxB + i - B.mdist);
+                if (shortA) for (u32 i = extA; i < A.mlen; i++) s_ref[idxA + i] = (u8)(idxA + i - A.mdist);
+                if (shortB) for (u32 i = extB; i < B.mlen; i++) s_ref[idxB + i] = (u8)(idxB + i - B.mdist);
+                // the long ones (a quality string repeating its first byte, a name): all lanes on one match
+                for (int half = 0; half < 2; half++) {
+                    unsigned long long lm = __ballot(half ? matB && !shortB : matA && !shortA);
+                    while (lm) {
+                        const int L = __builtin_ctzll(lm);
+                        lm &= lm - 1;
+                        const u32 ia = (u32)__builtin_amdgcn_readlane((int)idxA, L), ib = (u32)__builtin_amdgcn_readlane((int)idxB, L);
+                        const u32 la = (u32)__builtin_amdgcn_readlane((int)A.mlen, L), lb = (u32)__builtin_amdgcn_readlane((int)B.mlen, L);
+                        const u32 da = (u32)__builtin_amdgcn_readlane((int)A.mdist, L), db = (u32)__builtin_amdgcn_readlane((int)B.mdist, L);
+                        const u32 xa = (u32)__builtin_amdgcn_readlane((int)extA, L), xb = (u32)__builtin_amdgcn_readlane((int)extB, L);
+                        const u32 ix = half ? ib : ia, ml = half ? lb : la, md = half ? db : da, ex = half ? xb : xa;
+                        for (u32 i = lane; i < ml; i += 64) {
+                            if (i < ex) s_val[ix + i] = (u8)out[n_out - lo + ix + i - md];
+                            else s_ref[ix + i] = (u8)(ix + i - md);
+                        }
+                    }
+                }
                 const bool inside = __ballot((matA && extA < A.mlen) || (matB && extB < B.mlen)) != 0;
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
                 if (inside) {
                     for (int it = 0; it < 9; it++) {
                         const u32 r4 = s_ref32[lane];
                         const u32 n4 = (u32)s_ref[r4 & 255u] | (u32)s_ref[(r4 >> 8) & 255u] << 8 | (u32)s_ref[(r4 >> 16) & 255u] << 16 | (u32)s_ref[r4 >> 24] << 24;
-                        __syncthreads();
+                        __builtin_amdgcn_wave_barrier();
                         s_ref32[lane] = n4;
-                        __syncthreads();
+                        __builtin_amdgcn_wave_barrier();
                         if (!__ballot(n4 != r4)) break;
                     }
                 }
                 INF_T(4);
                 // the text from before the window, as it arrives
-                for (u32 i = 0; i < (extA < 16u ? extA : 16u); i++) s_val[idxA + i] = (u8)((i < 8 ? a0 : a1) >> (8 * (i & 7u)));
-                for (u32 i = 0; i < (extB < 16u ? extB : 16u); i++) s_val[idxB + i] = (u8)((i < 8 ? b0 : b1) >> (8 * (i & 7u)));
-                for (u32 i = 16; i < extA; i++) s_val[idxA + i] = (u8)out[outA - A.mdist + i];
-                for (u32 i = 16; i < extB; i++) s_val[idxB + i] = (u8)out[outB - B.mdist + i];
-                __syncthreads();
+                if (shortA) for (u32 i = 0; i < extA; i++) s_val[idxA + i] = (u8)((i < 8 ? a0 : a1) >> (8 * (i & 7u)));
+                if (shortB) for (u32 i = 0; i < extB; i++) s_val[idxB + i] = (u8)((i < 8 ? b0 : b1) >> (8 * (i & 7u)));
+                __builtin_amdgcn_wave_barrier();
                 const u32 r4 = s_ref32[lane];
                 const u32 w = (u32)s_val[r4 & 255u] | (u32)s_val[(r4 >> 8) & 255u] << 8 | (u32)s_val[(r4 >> 16) & 255u] << 16 | (u32)s_val[r4 >> 24] << 24;
                 const u32 hi = run - n_out + lo;                                            // window bytes [lo, hi) are text
@@ -445,7 +462,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                     for (u32 k = 0; k < 4; k++) if (r0 + k >= lo && r0 + k < hi) wp[k] = (char)(w >> (8 * k));
                 }
                 last_byte = (char)((u32)__builtin_amdgcn_readlane((int)w, (int)((hi - 1) >> 2)) >> (8 * ((hi - 1) & 3u)));
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
                 INF_T(5);
             }
             n_out = run; bp += t;
@@ -523,7 +540,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         // the next block header is read by lane 0 from bp
         if (lane == 0) { in.init(z + (bp >> 3), z + zlen - 8); in.refill(); in.drop((int)(bp & 7u)); }
     }
-    // ---- trailer: ISIZE and CRC-32 (every lane one segment, combined by x^(8 * bytes behind it))
+    // ---- trailer: ISIZE and CRC-32 (every lane one segment, the segments combined by x^(8 * bytes behind them))
     if (!status) {
         const u8* t = z + zlen - 8;
         const u32 want_crc = (u32)t[0] | (u32)t[1] << 8 | (u32)t[2] << 16 | (u32)t[3] << 24;
@@ -531,12 +548,41 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         if (n_out != isize || want_len != isize) status = 8;
         else {
             __threadfence_block();
-            const u32 seg = (isize + 63) / 64;
-            const u32 a = (u32)lane * seg < isize ? (u32)lane * seg : isize, e2 = a + seg < isize ? a + seg : isize;
-            u32 c = 0xffffffffu;
-            for (u32 i = a; i < e2; i++) c = s_crc_tab[(c ^ (u8)out[i]) & 0xffu] ^ (c >> 8);
-            c = ~c;
-            u32 x = a < e2 ? crc_multmodp(crc_x8n(isize - e2), c) : 0u;
+            // every lane one segment, in four quarters side by side (a table look-up waits ~100 cycles for LDS: four chains in flight
+            // instead of one); the quarters are joined with x^(8 * quarter) -- the same factor in every lane but the last
+            const u32 seg = (((isize + 63) / 64) + 3) & ~3u, q = seg / 4;
+            const u32 xq = crc_x8n(q);
+            u32 cc[4], ea[4], ee[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 a = (u32)lane * seg + (u32)k * q;
+                ea[k] = a < isize ? a : isize; ee[k] = a + q < isize ? a + q : isize;
+                cc[k] = 0xffffffffu;
+            }
+            // four bytes of every quarter per step (one unaligned load each, issued before the sixteen look-ups that use them)
+            for (u32 i = 0; i + 4 <= q; i += 4) {
+                u32 w[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { w[k] = 0; if (ea[k] + i + 4 <= ee[k]) __builtin_memcpy(&w[k], out + ea[k] + i, 4); }
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (ea[k] + i + 4 <= ee[k]) cc[k] = s_crc_tab[(cc[k] ^ (w[k] >> (8 * bb))) & 0xffu] ^ (cc[k] >> 8);
+                }
+            }
+            // (what is left of a quarter: up to three bytes, or the whole of a quarter that the text ends in)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 len = ee[k] - ea[k];
+                for (u32 i = len & ~3u; i < len; i++) cc[k] = s_crc_tab[(cc[k] ^ (u8)out[ea[k] + i]) & 0xffu] ^ (cc[k] >> 8);
+            }
+            u32 c = ~cc[0];
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                const u32 lk = ee[k] - ea[k];
+                if (lk) c = crc_multmodp(lk == q ? xq : crc_x8n(lk), c) ^ ~cc[k];
+            }
+            u32 x = ea[0] < ee[3] ? crc_multmodp(crc_x8n(isize - ee[3]), c) : 0u;
             for (int o = 32; o > 0; o >>= 1) x ^= __shfl_down(x, o, 64);
             x = (u32)__shfl((int)x, 0);
             if (x != want_crc) status = 9;

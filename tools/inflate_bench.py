@@ -70,7 +70,7 @@ def main():
     for _ in range(4):
         inflate()
     assert got.tobytes() == text
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and hasattr(L, "bmbs_debug_inflate_prof"):
         out = (C.c_uint64 * 16)()
         L.bmbs_debug_inflate_prof(out)          # (the four calls above)
         inflate()
