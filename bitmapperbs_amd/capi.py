@@ -176,7 +176,7 @@ def lib() -> C.CDLL:
     return L
 
 
-LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "bmbs_text.hip", "bmbs_bam.hip", "bmbs_inflate.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
+LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "k_index.hip", "k_rows.hip", "k_attach.hip", "k_scan.hip", "k_seed.hip", "k_vote.hip", "k_filter.hip", "k_reduce.hip", "k_align.hip", "k_finalize.hip", "k_pe_fast.hip", "k_pe_sensitive.hip", "bmbs_text.hip", "bmbs_bam.hip", "bmbs_inflate.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
             "../../include/bmbs.h")
 
 
