@@ -744,13 +744,16 @@ def write_bgzf(path, data, level=1, threads=16):
         f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
 
 
-def gz_input_rate(args, drv, fa, cfg, files, inp, rec_bytes):
+def gz_input_rate(args, drv, fa, cfg, files, inp, rec_bytes, big=None, inp_big=None):
+    """bgzf: the same files as the other keys (the sample REP times over) as bgzip-style blocks; plain_gzip: the first 2.5 M records of
+    the sample as one gzip member per file (what one `gzip -1` process per file writes in the time the bench can spare)"""
     out = {}
     n_plain = 2_500_000                                # records of the one-member gzip files (compressed by one gzip process each)
     for label in ("bgzf", "plain_gzip"):
         gzf = []
         procs = []
-        for src in files:
+        srcs = big if label == "bgzf" and big else files
+        for src in srcs:
             dst = src + (".bgzf.gz" if label == "bgzf" else ".plain.gz")
             if label == "bgzf":
                 with open(src, "rb") as f:
@@ -760,8 +763,8 @@ def gz_input_rate(args, drv, fa, cfg, files, inp, rec_bytes):
             gzf.append(dst)
         for pr in procs:
             pr.wait()
-        n = (os.path.getsize(files[0]) // rec_bytes if label == "bgzf" else n_plain) * (2 if cfg["pe"] else 1)
-        a = [gzf[files.index(x)] if x in files else x for x in inp]
+        n = (os.path.getsize(srcs[0]) // rec_bytes if label == "bgzf" else n_plain) * (2 if cfg["pe"] else 1)
+        a = [gzf[srcs.index(x)] if x in srcs else x for x in (inp_big if srcs is big else inp)]
         # bgzip-style blocks are inflated on the device; one-member gzip by the host's block-parallel inflater on the driver's default
         # thread count for compressed input
         p = subprocess.run([drv, "--search", fa] + a + ["-e", str(cfg["e"]), "-o", "/dev/null", "--verbose"] + (["-t", "32"] if label == "bgzf" else []),
@@ -830,7 +833,7 @@ def file_to_file_rate(args, cfg, fa, L):
     # gzipped input: bgzip-style files (independent 64 KiB blocks: inflated by several threads per file) and ordinary one-member
     # gzip files (one inflate thread per file, both mates side by side); -o /dev/null
     try:
-        out["gz_input"] = gz_input_rate(args, drv, fa, cfg, files, inp0, rec_bytes)
+        out["gz_input"] = gz_input_rate(args, drv, fa, cfg, files, inp0, rec_bytes, big, inp)
     except Exception as ex:
         out["gz_input"] = {"error": repr(ex)}
     for f in [os.path.join(args.workdir, "f2f.sam")] + big:
@@ -1058,25 +1061,27 @@ def main():
                 out["e2e"]["file_to_file"] = {"error": repr(ex)}
             c1 = dict(CONFIGS[1])
             small = dict(cfg, genome=46_000_000, n_chrom=4, launches=1, units=min(cfg["units"], 5_000_000))
-            try:
-                if args.config != 1:
-                    sec["configs1_se_chr21"] = secondary(args, CONFIGS[1]["label"], c1, rank, local)
-                one = dict(cfg, launches=1)
-                sec["random_qualities"] = secondary(args, "main configuration, Phred 2..40 uniform-random qualities", one, rank, local, qual="random")
-                sec["trimmed_library"] = secondary(args, "main configuration, 70 % of the reads trimmed to a uniform-random length in [30, L] (mates independently)", one, rank, local, trimmed=True)
-                sec["sub_5pct"] = secondary(args, "main configuration, 5 % substitutions", one, rank, local, sub=0.05)
-                sec["no_20mer_table"] = secondary(args, "main configuration, BMBS_T20=0 (16-mer table + Occ walk only)", one, rank, local, env={"BMBS_T20": "0"})
-                if cfg["genome"] >= 1_000_000_000:
-                    sec["grch38_like"] = secondary(args, "main configuration on a genome of the same size with GRCh38-like repeat content: ~45 % of the bases from nine "
-                                                   "families (Alu / MIR / L1 / LTR / DNA-transposon-like interspersed copies at 1-30 % divergence, segmental "
-                                                   "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True, ref_check=100_000)
-                    sec["grch38_like_se"] = secondary(args, "the same GRCh38-like genome, mate 1 alone as 150 bp single-end reads, -e 0.08 (every candidate of a "
-                                                      "single-end read is verified -- no mate prunes the list first)", dict(one, pe=False), rank, local, grch38_like=True)
-                    sec["grch38_like_sensitive"] = secondary(args, "the same GRCh38-like genome, pairs in --sensitive mode (configs[3]'s launch size: 5 M pairs)",
-                                                             dict(one, sensitive=True, units=min(cfg["units"], 5_000_000)), rank, local, grch38_like=True)
-                sec["repeats_50000"] = secondary(args, "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)
-            except Exception as ex:      # a secondary key must never lose the headline line
-                sec["error"] = repr(ex)
+            def one_key(name, *a, **kw):      # a secondary key must never lose the headline line, nor the keys behind it
+                try:
+                    sec[name] = secondary(args, *a, **kw)
+                except Exception as ex:
+                    sec[name] = {"error": repr(ex)}
+            if args.config != 1:
+                one_key("configs1_se_chr21", CONFIGS[1]["label"], c1, rank, local)
+            one = dict(cfg, launches=1)
+            one_key("random_qualities", "main configuration, Phred 2..40 uniform-random qualities", one, rank, local, qual="random")
+            one_key("trimmed_library", "main configuration, 70 % of the reads trimmed to a uniform-random length in [30, L] (mates independently)", one, rank, local, trimmed=True)
+            one_key("sub_5pct", "main configuration, 5 % substitutions", one, rank, local, sub=0.05)
+            one_key("no_20mer_table", "main configuration, BMBS_T20=0 (16-mer table + Occ walk only)", one, rank, local, env={"BMBS_T20": "0"})
+            if cfg["genome"] >= 1_000_000_000:
+                one_key("grch38_like", "main configuration on a genome of the same size with GRCh38-like repeat content: ~45 % of the bases from nine "
+                                               "families (Alu / MIR / L1 / LTR / DNA-transposon-like interspersed copies at 1-30 % divergence, segmental "
+                                               "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True, ref_check=100_000)
+                one_key("grch38_like_se", "the same GRCh38-like genome, mate 1 alone as 150 bp single-end reads, -e 0.08 (every candidate of a "
+                                                  "single-end read is verified -- no mate prunes the list first)", dict(one, pe=False), rank, local, grch38_like=True)
+                one_key("grch38_like_sensitive", "the same GRCh38-like genome, pairs in --sensitive mode (configs[3]'s launch size: 5 M pairs)",
+                                                         dict(one, sensitive=True, units=min(cfg["units"], 5_000_000)), rank, local, grch38_like=True)
+            one_key("repeats_50000", "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)
             out["secondary"] = sec
         out["wall_s"] = round(time.time() - t_all, 1)
         print(json.dumps(out), flush=True)

@@ -2256,12 +2256,11 @@ int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int
     }
     hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
     char* tails[2] = {tail1, tail2}; uint64_t* tb[2] = {tail1_bytes, tail2_bytes};
-    for (int f = 0; f < (pe ? 2 : 1); f++) {
-        const u64 t = bytes[f] - cut[f];
-        if (t > tail_cap) { c->err = "text open: the tail buffer is too small (" + std::to_string(t) + " bytes behind the window's records)"; *tb[f] = t; return BMBS_ENOMEM; }
-        if (t) HIPCHK(c, hipMemcpyAsync(tails[f], A[f].text->as<char>() + cut[f], t, hipMemcpyDeviceToHost, ds));
-        *tb[f] = t;
-    }
+    for (int f = 0; f < (pe ? 2 : 1); f++) *tb[f] = bytes[f] - cut[f];                   // (both sizes are known to a caller that has to come back with room)
+    for (int f = 0; f < (pe ? 2 : 1); f++)
+        if (*tb[f] > tail_cap) { c->err = "text open: the tail buffer is too small (" + std::to_string(*tb[f]) + " bytes behind the window's records)"; return BMBS_ENOMEM; }
+    for (int f = 0; f < (pe ? 2 : 1); f++)
+        if (*tb[f]) HIPCHK(c, hipMemcpyAsync(tails[f], A[f].text->as<char>() + cut[f], *tb[f], hipMemcpyDeviceToHost, ds));
     HIPCHK(c, hipStreamSynchronize(ds));
     tp[3] = wall();
     if (trace)

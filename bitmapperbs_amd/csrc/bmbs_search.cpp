@@ -945,9 +945,25 @@ int main(int argc, char** argv)
         return text_bytes + lines * (max_chrom + 5 * (size_t)std::max(8, (int)bmbs_max_cigar_ops(&P, std::max(1, std::min(1000, L)))) + 96) + 4096;
     };
     auto window_bytes = [&](size_t est) { return std::min<size_t>((size_t)batch * est + (1u << 16), (size_t)4000 << 20); };
+    // BGZF input that is inflated on the device: the compressed bytes of a window, staged (block tables and a page-locked copy per
+    // file).  Two of them: while a context opens one window, a helper thread stages the next
+    struct Staged {
+        Pinned buf[2]; std::vector<uint64_t> blk[2], out[2];
+        size_t a[2] = {0, 0}, q[2] = {0, 0};
+        bool foreign_any = false, ok = true; std::string err;
+    } zst[2];
+    for (auto& x : zst) { x.buf[0].kind = 1; x.buf[1].kind = 1; }
     std::thread prealloc([&] {
         const size_t want = window_bytes(est0) + 64;
         std::vector<std::thread> th;
+        if (gz_in)
+            for (auto& x : zst)
+                for (int f = 0; f < (pe ? 2 : 1); f++) {
+                    struct stat sb;
+                    const size_t fsize = stat((f ? seq2 : in1).c_str(), &sb) == 0 ? (size_t)sb.st_size : 0;
+                    Pinned* pb = &x.buf[f];
+                    th.emplace_back([pb, fsize, want] { pb->need(std::min(fsize + 64, want / 2)); });
+                }
         for (auto& b : batches)
             th.emplace_back([&, want] {
                 Batch* bb = &b;
@@ -1070,18 +1086,15 @@ int main(int argc, char** argv)
         Pinned tails[2]; tails[0].kind = 2; tails[1].kind = 2;
         // (what a window leaves over is a partial record, plus -- when the mates' records differ in size -- the surplus of one file, which the
         // next window's smaller block count evens out: never more than a window)
-        const size_t tail_cap = std::min<size_t>((size_t)batch * est0 + ((size_t)8 << 20), (size_t)3600 << 20);
+        // in practice a fraction of a record; the buffers grow when a call says so (page-locked memory is slow to get: ~0.1 ms per MB)
+        size_t tail_cap = (size_t)4 << 20;
+        if (const char* tv = getenv("BMBS_Z_TAIL")) { const long v = atol(tv); if (v >= 1) tail_cap = (size_t)v; }      // tests: the growth path
         if (!tails[0].need(tail_cap) || (pe && !tails[1].need(tail_cap))) { fail("cannot allocate page-locked staging memory"); return true; }
         Source* S[2] = {&pt->s1, &pt->s2};
         const int nf = pe ? 2 : 1;
-        // the compressed bytes of a window, staged: block tables and a page-locked copy per file.  Two of them: while a context opens
-        // one window (upload, inflate, index: the reader waits for the device), a helper thread stages the next
-        struct Staged {
-            Pinned buf[2]; std::vector<uint64_t> blk[2], out[2];
-            size_t a[2] = {0, 0}, q[2] = {0, 0};
-            bool foreign_any = false, ok = true; std::string err;
-        } st[2];
-        for (auto& x : st) { x.buf[0].kind = 1; x.buf[1].kind = 1; }
+        // (zst: the two staged windows -- while a context opens one (upload, inflate, index: the reader waits for the device), a helper
+        // thread stages the next)
+        Staged* st = zst;
         auto stage = [&](Staged& g, size_t room0, size_t room1) {
             g.foreign_any = false; g.ok = true;
             const size_t room[2] = {room0, room1};
@@ -1157,8 +1170,15 @@ int main(int argc, char** argv)
             }
             int64_t nrec = 0; uint64_t tb[2] = {0, 0};
             // every whole record of the window is taken (the window is what bounds a batch here: --batch records by the running estimate of a record's size)
-            const int rc = bmbs_text_open_bgzf(ctx, &z[0], pe ? &z[1] : nullptr, 4 * (int64_t)batch, last1 ? 1 : 0, last2 ? 1 : 0, &nrec, tails[0].p, tail_cap, &tb[0],
-                                               pe ? tails[1].p : nullptr, &tb[1]);
+            int rc = bmbs_text_open_bgzf(ctx, &z[0], pe ? &z[1] : nullptr, 4 * (int64_t)batch, last1 ? 1 : 0, last2 ? 1 : 0, &nrec, tails[0].p, tail_cap, &tb[0],
+                                         pe ? tails[1].p : nullptr, &tb[1]);
+            if (rc == BMBS_ENOMEM && std::max(tb[0], tb[1]) > tail_cap) {
+                // more text behind the window's records than the tail buffers hold (the mates' records differ in size): once more with room
+                tail_cap = (size_t)std::max(tb[0], tb[1]) + ((size_t)4 << 20);
+                if (!tails[0].need(tail_cap) || (pe && !tails[1].need(tail_cap))) { bail("cannot allocate page-locked staging memory"); return true; }
+                rc = bmbs_text_open_bgzf(ctx, &z[0], pe ? &z[1] : nullptr, 4 * (int64_t)batch, last1 ? 1 : 0, last2 ? 1 : 0, &nrec, tails[0].p, tail_cap, &tb[0],
+                                         pe ? tails[1].p : nullptr, &tb[1]);
+            }
             if (rc) { bail(bmbs_last_error(ctx)); return true; }
             for (int f = 0; f < nf; f++) S[f]->carry.assign(tails[f].p, tails[f].p + tb[f]);
             // the part's input ends with this batch when a file has nothing left behind it (PE: the shorter file decides)

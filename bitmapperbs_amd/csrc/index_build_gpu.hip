@@ -410,6 +410,9 @@ extern "C" int bmbs_index_build_device(int device_id, const char* fasta, const c
     // the caller's current device is put back on every way out
     struct DeviceGuard { int prev = -1; DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; } ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); } } device_guard;
     IB_HIP(hipSetDevice(device_id));
+    // (an error another library in this process has already handled -- an allocator that frees its cache and tries again after
+    // "out of memory" -- stays the thread's last error until it is read: not to be mistaken for one of this build's launches)
+    (void)hipGetLastError();
     double t_last = now_s();
     auto lap = [&](const char* what) {
         if (!verbose) return;
