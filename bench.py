@@ -590,7 +590,13 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
     import threading
     from bitmapperbs_amd import mapper
     extra = [mapper.Mapper(ix, device=local, share=m, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0) for _ in range(n_ctx - 1)]
-    ctxs = [(m, job.res_d, job.cig_d)] + [(x, torch.empty_like(job.res_d), torch.empty_like(job.cig_d)) for x in extra]
+    # (every further context brings work buffers of its own for a 10 M-pair call; the result buffers are the job's per-launch ones, and
+    # those beyond three are given back first: index 170 GB + trigram table 28 GB + inputs 32 GB leave no room for both)
+    del job.res_all[3:], job.cig_all[3:]
+    torch.cuda.empty_cache()
+    while len(job.res_all) < n_ctx:
+        job.res_all.append(torch.empty_like(job.res_d)); job.cig_all.append(torch.empty_like(job.cig_d))
+    ctxs = [(m, job.res_d, job.cig_d)] + [(x, job.res_all[1 + i], job.cig_all[1 + i]) for i, x in enumerate(extra)]
 
     def launch(c, b):
         mm, res, cig = c

@@ -32,6 +32,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
@@ -1023,7 +1024,14 @@ int main(int argc, char** argv)
         if (parts > 1) { char suf[32]; snprintf(suf, sizeof suf, ".part%03d", p); path += suf; }
         pt.ofd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (pt.ofd < 0) { fprintf(stderr, "Cannot open %s\n", path.c_str()); return 1; }
-        { struct stat osb; pt.regular = fstat(pt.ofd, &osb) == 0 && S_ISREG(osb.st_mode); pt.can_alloc = pt.regular; }
+        {
+            struct stat osb; pt.regular = fstat(pt.ofd, &osb) == 0 && S_ISREG(osb.st_mode);
+            // blocks are reserved ahead only where that is a table entry (extent file systems): tmpfs answers fallocate by taking and
+            // clearing the pages (4 GiB ahead of eight parts: slower than the writes, then ENOSPC), overlayfs refuses it
+            struct statfs fsb;
+            pt.can_alloc = pt.regular && fstatfs(pt.ofd, &fsb) == 0 &&
+                           ((unsigned long)fsb.f_type == 0xEF53ul || (unsigned long)fsb.f_type == 0x58465342ul || (unsigned long)fsb.f_type == 0x9123683Eul);
+        }
         if (p == 0) {
             // OutPutSAM_Nounheader (Process_sam_out.cpp:1137-1153)
             std::string h = "@HD\tVN:1.4\tSO:unsorted\n";
