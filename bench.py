@@ -591,8 +591,8 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
     from bitmapperbs_amd import mapper
     extra = [mapper.Mapper(ix, device=local, share=m, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0) for _ in range(n_ctx - 1)]
     # (every further context brings work buffers of its own for a 10 M-pair call; the result buffers are the job's per-launch ones, and
-    # those beyond three are given back first: index 170 GB + trigram table 28 GB + inputs 32 GB leave no room for both)
-    del job.res_all[3:], job.cig_all[3:]
+    # those -- and the input launches -- beyond three are given back first: index 170 GB + trigram table 28 GB + inputs 32 GB leave no room for both)
+    del job.res_all[3:], job.cig_all[3:], job.batches[3:]
     torch.cuda.empty_cache()
     while len(job.res_all) < n_ctx:
         job.res_all.append(torch.empty_like(job.res_d)); job.cig_all.append(torch.empty_like(job.cig_d))

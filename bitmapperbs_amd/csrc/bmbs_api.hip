@@ -149,6 +149,7 @@ struct Lane {
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
     DevBuf bam_raw, bam_tok, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
     DevBuf z_comp, z_off, z_text, z_err, z_nl, z_comp2, z_off2, z_err2;          // bmbs_inflate_bgzf; (…2: mate 2 of bmbs_text_open_bgzf)
+    DevBuf gz_start, gz_sym, gz_res, gz_wall, gz_off, gz_info;                  // bmbs_inflate_gzip: span starts, 16-bit symbols, results, windows, text offsets
     struct OpenText { bool valid = false, pe = false; u64 bytes1 = 0, bytes2 = 0; int64_t n = 0; } open_text;      // between bmbs_text_open_bgzf and bmbs_text_map_open
     u32* h_info = nullptr;                              // page-locked: 8 info words + 4 totals of the text path
     int n_refs = 0, max_ref_len = 0;
@@ -856,7 +857,8 @@ void lane_destroy(Lane* c)
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->h_info) (void)hipHostFree(c->h_info);
     { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list,
-                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl, &c->z_comp2, &c->z_off2, &c->z_err2};
+                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl, &c->z_comp2, &c->z_off2, &c->z_err2,
+                     &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info};
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
@@ -2679,6 +2681,71 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
                        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (wall() - t2) * 1e3);
     for (u64 i = 0; i < n; i++)
         if (err[i]) { c->err = "corrupt BGZF block in the .gz input (block " + std::to_string(i) + " of this window, code " + std::to_string(err[i]) + ")"; return BMBS_EINVAL; }
+    return BMBS_OK;
+}
+
+// ---- a window of ONE deflate stream (an ordinary .gz member), inflated by a wave per span -------------------------------------------
+// comp[0, comp_bytes): compressed bytes of the stream from the byte that holds bit start_bit (a block boundary the caller knows: the
+// stream's first block, or where the last call stopped); win_in: the win_len (<= 32768) bytes of text in front of that point.  Blocks are
+// entered up to limit_bytes (the caller keeps a margin of one block before the end of what it has, or passes comp_bytes at the end of
+// the file).  -> text of every span the chain reached, the bit it stopped at (*end_bit, a block boundary again), *final = the stream's
+// last block was decoded (the 8-byte trailer follows at the next byte boundary), win_out = the 32 KiB (or fewer) behind it.
+// *text_bytes == 0 with BMBS_OK: no span could be confirmed (a stream of stored blocks, a block longer than a span's symbol slot):
+// the caller's host inflater takes over.
+extern "C" int bmbs_inflate_gzip(bmbs_ctx* X, const void* comp, uint64_t comp_bytes, uint32_t start_bit, uint64_t limit_bytes, const void* win_in, uint32_t win_len,
+                                 char* text, uint64_t text_cap, uint64_t* text_bytes, uint64_t* end_bit, int32_t* final_block, void* win_out, uint32_t* win_out_len)
+{
+    Lane* c = lane0(X);
+    if (!c) return BMBS_EINVAL;
+    if (text_bytes) *text_bytes = 0;
+    if (!comp || !text_bytes || !end_bit || !final_block || !win_out || !win_out_len || (win_len && !win_in) || win_len > 32768 || (text_cap && !text)) { c->err = "inflate: NULL argument"; return BMBS_EINVAL; }
+    if (comp_bytes < 8 || comp_bytes + 1 >= (1ull << 29) || start_bit >= comp_bytes * 8) { c->err = "inflate: a window of a gzip stream has to be smaller than 512 MiB (32-bit bit offsets)"; return BMBS_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->dev));
+    static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;
+    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double t0 = wall();
+    u32 span = 65536;
+    if (const char* sv = getenv("BMBS_GZ_DEV_SPAN")) { const long v = atol(sv); if (v >= 256) span = (u32)v; }          // tests: many spans in a small file
+    const u64 lim = std::min<u64>(limit_bytes, comp_bytes);
+    const u32 n_spans = (u32)std::max<u64>(1, (lim + span - 1) / span);
+    const u32 cap = span * 12;                                                      // symbols a span may produce
+    ENS(c, c->z_comp, comp_bytes + 2048); ENS(c, c->gz_start, (u64)n_spans * 4 + 64); ENS(c, c->gz_sym, (u64)n_spans * cap * 2 + 64);
+    ENS(c, c->gz_res, (u64)n_spans * sizeof(GzSpan) + 64); ENS(c, c->gz_wall, ((u64)n_spans + 1) * 32768); ENS(c, c->gz_off, ((u64)n_spans + 1) * 8 + 64);
+    ENS(c, c->gz_info, 64);
+    hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
+    hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->z_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, us));
+    HIPCHK(c, hipMemsetAsync(c->z_comp.as<u8>() + comp_bytes, 0, 2048, us));
+    HIPCHK(c, hipMemsetAsync(c->gz_wall.p, 0, 32768, us));
+    if (win_len) HIPCHK(c, hipMemcpyAsync(c->gz_wall.as<u8>() + (32768 - win_len), win_in, win_len, hipMemcpyHostToDevice, us));
+    HIPCHK(c, hipStreamSynchronize(us));
+    const double t1 = wall();
+    hipLaunchKernelGGL(k_gz_starts, dim3(n_spans), dim3(64), 0, c->stream, c->z_comp.as<u8>(), comp_bytes, n_spans, span, start_bit, c->gz_start.as<u32>());
+    hipLaunchKernelGGL(k_gz_spans, dim3(n_spans), dim3(64), 0, c->stream, c->z_comp.as<u8>(), comp_bytes, n_spans, span, (u32)(lim * 8), c->gz_start.as<u32>(),
+                       c->gz_sym.as<u16>(), cap, c->gz_res.as<GzSpan>());
+    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(1024), 0, c->stream, c->gz_sym.as<u16>(), cap, c->gz_res.as<GzSpan>(), c->gz_start.as<u32>(), n_spans, start_bit,
+                       win_len, c->gz_wall.as<u8>(), c->gz_off.as<u64>(), c->gz_info.as<u64>());
+    u64 info[5];
+    HIPCHK(c, hipMemcpyAsync(info, c->gz_info.p, sizeof info, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t2 = wall();
+    const u32 good = (u32)info[0];
+    if (info[4]) { c->err = "corrupt deflate data in the .gz input (a match reaches in front of the stream)"; return BMBS_EINVAL; }
+    if (!good) { *end_bit = start_bit; *final_block = 0; *win_out_len = 0; return BMBS_OK; }
+    u64 total = 0;
+    HIPCHK(c, hipMemcpy(&total, c->gz_off.as<u64>() + good, 8, hipMemcpyDeviceToHost));
+    *text_bytes = total; *end_bit = info[2]; *final_block = (int32_t)info[1]; *win_out_len = (u32)info[3];
+    if (total > text_cap) { c->err = "inflate: the text buffer is too small"; return BMBS_ENOMEM; }
+    ENS(c, c->z_text, total + 64);
+    if (total) hipLaunchKernelGGL(k_gz_resolve, dim3(32, good), dim3(256), 0, c->stream, c->gz_sym.as<u16>(), cap, c->gz_res.as<GzSpan>(), c->gz_off.as<u64>(), c->gz_info.as<u64>(),
+                                  c->gz_wall.as<u8>(), c->z_text.as<char>());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t3 = wall();
+    HIPCHK(c, hipMemcpyAsync(win_out, c->gz_wall.as<u8>() + (size_t)good * 32768 + (32768 - info[3]), info[3], hipMemcpyDeviceToHost, ds));
+    if (total) { const int rc = d2h_chunked(c, text, c->z_text.as<char>(), total, ds); if (rc) return rc; }
+    HIPCHK(c, hipStreamSynchronize(ds));
+    if (trace) fprintf(stderr, "[inflate gzip] %u spans of %u bytes, %u reached, %.1f MB -> %.1f MB: alloc+upload %.2f  starts+spans+windows %.2f  resolve %.2f  download %.2f ms\n", n_spans, span, good,
+                       (double)comp_bytes / 1e6, (double)total / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (wall() - t3) * 1e3);
     return BMBS_OK;
 }
 

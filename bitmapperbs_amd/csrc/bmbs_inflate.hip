@@ -172,54 +172,40 @@ DEVI InfTok inf_token(u64 v, const u32* s_lit, const u32* s_dist)
     return k;
 }
 
-// comp: the compressed bytes of n BGZF blocks, block b at comp + blk_off[b] (blk_off[n] = end); its text goes to text + out_off[b]
-// (out_off[b + 1] - out_off[b] = the ISIZE its trailer states).  err[b] = 0 when the block was well-formed and its CRC matched.
-__global__ void __launch_bounds__(64, 4)
-k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, const u64* __restrict__ out_off, long n, char* __restrict__ text, u32* __restrict__ err)
+// ---- one wave inflates one deflate stream (or a stretch of one) -------------------------------------------------------------------
+// MODE 0: a whole gzip member's deflate data from start_bit (BGZF block), bytes out.  MODE 1: a SPAN of a longer stream, from a block
+// start at start_bit to the first block boundary at or behind stop_bit (or the end of the final block); what lies before the span is
+// not known: symbols are 16 bits, a byte or 0x8000 | w = "byte w of the 32 KiB in front of the span" (w = 32767: the byte just before
+// it) -- the scheme of pugz / rapidgzip, as in csrc/pgz.h.  MODE 2: the header of the block at start_bit is read and judged, nothing
+// else (status 0: a dynamic-Huffman header zlib would accept).
+template <int MODE> struct InfSym { typedef u8 T; };
+template <> struct InfSym<1> { typedef u16 T; };
+DEVI u32 inf_marker(int q) { return 0x8000u | (u32)(32768 + q); }                         // q in [-32768, -1]: position relative to the span's start
+template <int N> DEVI u64 inf_pick(const u64 (&r)[N], u32 k) { u64 v = r[0]; for (int j = 1; j < N; j++) v = k == (u32)j ? r[j] : v; return v; }
+
+template <int MODE>
+DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typename InfSym<MODE>::T* out, u32 isize, int lane,
+                   u32& status_r, u32& n_out_r, u32& end_bit_r, bool& final_r)
 {
+    typedef typename InfSym<MODE>::T S;
+    constexpr u32 BACK = MODE == 1 ? 32768u : 0u;          // how far before its own output a match of this stream may reach
     __shared__ u32 s_lit[1 << INF_LIT_ROOT];
     __shared__ u32 s_dist[1 << INF_DIST_ROOT];
     __shared__ u8 s_lens[320];
     __shared__ u16 s_sorted_l[288]; __shared__ u16 s_sorted_d[32]; __shared__ u16 s_sorted_c[20];
     __shared__ InfCode s_cl, s_cd, s_cc;
-    __shared__ u32 s_crc_tab[256];
-    __shared__ u32 s_ref32[64];                           // the window being put together: where each of its 256 bytes comes from ...
-    __shared__ u8 s_val[256 + 16];                        // ... and the bytes that are known (literals, text from before the window)
+    __shared__ u32 s_ref32[64];                           // the window being put together: where each of its 256 symbols comes from ...
+    __shared__ S s_val[256 + 16];                         // ... and the symbols that are known (literals, text from before the window)
     u8* s_ref = reinterpret_cast<u8*>(s_ref32);
-    const long b = blockIdx.x;
-    if (b >= n) return;
-    const int lane = threadIdx.x;
-    const u8* z = comp + blk_off[b];
-    const u64 zlen = blk_off[b + 1] - blk_off[b];
-    char* out = text + out_off[b];
-    const u32 isize = (u32)(out_off[b + 1] - out_off[b]);
     u32 status = 0;                                       // 0 ok so far
 #ifdef INF_PROFILE
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = clock64();
     const unsigned long long t_begin = t_last;
 #endif
-    // ---- gzip member header (BGZF: FEXTRA with the BC subfield; any other well-formed header is read too)
-    u32 body = 0;
-    if (zlen < 18 + 8 || z[0] != 0x1f || z[1] != 0x8b || z[2] != 8 || (z[3] & 0xe0)) status = 1;
-    else {
-        const int flg = z[3];
-        u64 q = 10;
-        if (flg & 4) { const u64 xl = (u64)z[q] | ((u64)z[q + 1] << 8); q += 2 + xl; }
-        if ((flg & 8) && q < zlen) { while (q < zlen && z[q]) q++; q++; }
-        if ((flg & 16) && q < zlen) { while (q < zlen && z[q]) q++; q++; }
-        if (flg & 2) q += 2;
-        if (q + 8 > zlen) status = 1;
-        body = (u32)q;
-    }
-    {
-        u32 c = (u32)lane;                                 // CRC table: four entries per lane
-        for (int t = 0; t < 4; t++) { u32 v = (u32)(lane + 64 * t); for (int k = 0; k < 8; k++) v = (v & 1) ? (v >> 1) ^ 0xedb88320u : v >> 1; s_crc_tab[lane + 64 * t] = v; }
-        (void)c;
-    }
     s_cl.sorted = s_sorted_l; s_cd.sorted = s_sorted_d; s_cc.sorted = s_sorted_c;
     __syncthreads();
-    InfBits in; in.init(z + body, z + zlen - 8);
+    InfBits in; in.init(z + (start_bit >> 3), zend); in.refill(); in.drop((int)(start_bit & 7u));
     // the compressed bytes, 256 at a time: lane l holds dword l of chunk kc (`cur`) and of the chunk behind it (`nxt`, on its way
     // while `cur` is decoded); the five dwords under a window are picked out of them with v_readlane
     const u32* zw = reinterpret_cast<const u32*>((size_t)z & ~(size_t)3);
@@ -227,9 +213,16 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     u32 kc = 0xfffffff0u, cur = 0, nxt = 0;
     u32 n_out = 0;                                        // bytes of text written so far (wave-uniform)
     u32 fenced = 0;                                       // every byte of the text below this offset is visible to every lane
-    char last_byte = 0;                                   // the byte at n_out - 1 (wave-uniform)
+    S last_byte = MODE == 1 ? (S)inf_marker(-1) : (S)0;      // the symbol at n_out - 1 (wave-uniform)
     bool last = false;
     while (!status && !last) {
+        if (MODE == 1) {
+            // a span ends at the first block boundary at or behind the next cut
+            u32 bs = 0;
+            if (lane == 0) bs = (u32)((in.p - z) * 8) - (u32)in.cnt;
+            bs = (u32)__shfl((int)bs, 0);
+            if (bs >= stop_bit) break;
+        }
         // ---- block header (lane 0 reads, the wave follows)
         u32 btype = 0;
         if (lane == 0) { in.refill(); last = in.take(1) != 0; btype = in.take(2); }
@@ -246,11 +239,11 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
             }
             len = (u32)__shfl((int)len, 0); bad = (u32)__shfl((int)bad, 0);
             at = ((u64)(u32)__shfl((int)(at >> 32), 0) << 32) | (u32)__shfl((int)at, 0);
-            if (bad || at + len > zlen - 8 || n_out + len > isize) { status = 3; break; }
-            for (u32 i = lane; i < len; i += 64) out[n_out + i] = (char)z[at + i];
+            if (bad || at + len > (u64)(zend - z) || n_out + len > isize) { status = 3; break; }
+            for (u32 i = lane; i < len; i += 64) out[n_out + i] = (S)z[at + i];
             n_out += len;
-            if (len) last_byte = (char)z[at + len - 1];
-            if (lane == 0) in.init(z + at + len, z + zlen - 8);
+            if (len) last_byte = (S)z[at + len - 1];
+            if (lane == 0) in.init(z + at + len, zend);
             continue;
         }
         // ---- the two codes
@@ -312,6 +305,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
             ok = inf_canonical(s_lens, 288, s_cl, lane) && inf_canonical(s_lens + 288, 32, s_cd, lane);
         }
         if (!ok) { status = 4; break; }
+        if (MODE == 2) break;                                     // (the header stands: all a search for block starts asks)
         inf_root(s_cl, false, s_lit, INF_LIT_ROOT, lane);
         inf_root(s_cd, true, s_dist, INF_DIST_ROOT, lane);
         // ---- symbols.  Every lane decodes the tokens that WOULD start at its own two bit offsets (bp + lane, bp + 64 + lane): one or
@@ -323,7 +317,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         u32 bp = 0;
         if (lane == 0) bp = (u32)((in.p - z) * 8) - (u32)in.cnt;
         bp = (u32)__shfl((int)bp, 0);
-        const u32 end_bits = (u32)(zlen - 8) * 8;
+        const u32 end_bits = (u32)(zend - z) * 8;
         bool block_done = false;
         while (!block_done && !status) {
             // (bp, the chain position and the output offsets are the same in every lane: kept in scalar registers, so that a token's
@@ -363,7 +357,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
             INF_T(2);
             // the chain from offset 0: the tokens it visits (mA, mB: one bit per lane) and their places in the text.  It ends at the
             // first token that is not a plain one, or when the window (256 bytes of text from `lo` on, see below) is full.
-            const u32 lo = (u32)(size_t)(out + n_out) & 3u;                                // the window starts at the 4-byte boundary at or below n_out
+            const u32 lo = (u32)((size_t)(out + n_out) / sizeof(S)) & 3u;                  // the window starts at the 4-symbol boundary at or below n_out
             u32 t = 0, run = n_out, stop = 0;
             unsigned long long mA = 0, mB = 0;
             u32 outA = 0, outB = 0;
@@ -399,22 +393,34 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 const u32 kindA = (A.e >> 5) & 7u, kindB = (B.e >> 5) & 7u;
                 const bool litA = mineA && kindA == IK_LIT, litB = mineB && kindB == IK_LIT;
                 const bool matA = mineA && kindA == IK_BASE, matB = mineB && kindB == IK_BASE;
-                if (__ballot((matA && A.mdist > outA) || (matB && B.mdist > outB))) { status = 6; break; }
+                if (__ballot((matA && A.mdist > outA + BACK) || (matB && B.mdist > outB + BACK))) { status = 6; break; }
                 const u32 idxA = outA - n_out + lo, idxB = outB - n_out + lo;               // window index of the token's first byte
                 // bytes of a match that come from before the window: its first ext bytes
-                const u32 extA = matA && outA - A.mdist < n_out ? min(A.mlen, n_out - (outA - A.mdist)) : 0u;
-                const u32 extB = matB && outB - B.mdist < n_out ? min(B.mlen, n_out - (outB - B.mdist)) : 0u;
+                const int srcA = (int)outA - (int)A.mdist, srcB = (int)outB - (int)B.mdist;   // (negative in a span: before its start, a marker)
+                const u32 extA = matA && srcA < (int)n_out ? min(A.mlen, (u32)((int)n_out - srcA)) : 0u;
+                const u32 extB = matB && srcB < (int)n_out ? min(B.mlen, (u32)((int)n_out - srcB)) : 0u;
                 const bool shortA = matA && A.mlen <= 16, shortB = matB && B.mlen <= 16;   // by their own lanes; longer ones by the wave
-                if (__ballot((extA && outA - A.mdist + extA > fenced) || (extB && outB - B.mdist + extB > fenced))) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
+                if (__ballot((extA && srcA + (int)extA > (int)fenced) || (extB && srcB + (int)extB > (int)fenced))) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
                 // (unaligned 8-byte loads: the bytes behind a match's source come along and are dropped -- the text buffer has the slack)
-                u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-                if (extA && shortA) { const char* sp = out + (outA - A.mdist); __builtin_memcpy(&a0, sp, 8); if (extA > 8) __builtin_memcpy(&a1, sp + 8, 8); }
-                if (extB && shortB) { const char* sp = out + (outB - B.mdist); __builtin_memcpy(&b0, sp, 8); if (extB > 8) __builtin_memcpy(&b1, sp + 8, 8); }
+                u64 ra[MODE == 1 ? 4 : 2], rb[MODE == 1 ? 4 : 2];
+                constexpr u32 PER = 8 / sizeof(S);                                          // symbols per 8-byte load
+#pragma unroll
+                for (u32 k = 0; k < 16 / PER; k++) { ra[k] = 0; rb[k] = 0; }
+                if (extA && shortA && srcA >= 0) {
+                    const S* sp = out + srcA;
+#pragma unroll
+                    for (u32 k = 0; k < 16 / PER; k++) if (extA > k * PER) __builtin_memcpy(&ra[k], sp + k * PER, 8);
+                }
+                if (extB && shortB && srcB >= 0) {
+                    const S* sp = out + srcB;
+#pragma unroll
+                    for (u32 k = 0; k < 16 / PER; k++) if (extB > k * PER) __builtin_memcpy(&rb[k], sp + k * PER, 8);
+                }
                 // (one wave, and a wave's LDS operations complete in the order they were issued: no s_barrier between the steps below)
                 s_ref32[lane] = (u32)lane * 0x04040404u + 0x03020100u;                      // every byte its own source
                 __builtin_amdgcn_wave_barrier();
-                if (litA) { s_val[idxA] = (u8)(A.e >> 16); if (((A.e >> 8) & 31u) == 2) s_val[idxA + 1] = (u8)(A.e >> 24); }
-                if (litB) { s_val[idxB] = (u8)(B.e >> 16); if (((B.e >> 8) & 31u) == 2) s_val[idxB + 1] = (u8)(B.e >> 24); }
+                if (litA) { s_val[idxA] = (S)(u8)(A.e >> 16); if (((A.e >> 8) & 31u) == 2) s_val[idxA + 1] = (S)(u8)(A.e >> 24); }
+                if (litB) { s_val[idxB] = (S)(u8)(B.e >> 16); if (((B.e >> 8) & 31u) == 2) s_val[idxB + 1] = (S)(u8)(B.e >> 24); }
                 if (shortA) for (u32 i = extA; i < A.mlen; i++) s_ref[idxA + i] = (u8)(idxA + i - A.mdist);
                 if (shortB) for (u32 i = extB; i < B.mlen; i++) s_ref[idxB + i] = (u8)(idxB + i - B.mdist);
                 // the long ones (a quality string repeating its first byte, a name): all lanes on one match
@@ -429,7 +435,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                         const u32 xa = (u32)__builtin_amdgcn_readlane((int)extA, L), xb = (u32)__builtin_amdgcn_readlane((int)extB, L);
                         const u32 ix = half ? ib : ia, ml = half ? lb : la, md = half ? db : da, ex = half ? xb : xa;
                         for (u32 i = lane; i < ml; i += 64) {
-                            if (i < ex) s_val[ix + i] = (u8)out[n_out - lo + ix + i - md];
+                            if (i < ex) { const int q = (int)(n_out - lo + ix + i) - (int)md; s_val[ix + i] = MODE == 1 && q < 0 ? (S)inf_marker(q) : out[q]; }
                             else s_ref[ix + i] = (u8)(ix + i - md);
                         }
                     }
@@ -448,20 +454,30 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 }
                 INF_T(4);
                 // the text from before the window, as it arrives
-                if (shortA) for (u32 i = 0; i < extA; i++) s_val[idxA + i] = (u8)((i < 8 ? a0 : a1) >> (8 * (i & 7u)));
-                if (shortB) for (u32 i = 0; i < extB; i++) s_val[idxB + i] = (u8)((i < 8 ? b0 : b1) >> (8 * (i & 7u)));
+                if (shortA) for (u32 i = 0; i < extA; i++) {
+                    const int q = srcA + (int)i;
+                    s_val[idxA + i] = MODE == 1 && q < 0 ? (S)inf_marker(q) : MODE == 1 && srcA < 0 ? out[q] : (S)(inf_pick(ra, i / PER) >> (8 * sizeof(S) * (i % PER)));
+                }
+                if (shortB) for (u32 i = 0; i < extB; i++) {
+                    const int q = srcB + (int)i;
+                    s_val[idxB + i] = MODE == 1 && q < 0 ? (S)inf_marker(q) : MODE == 1 && srcB < 0 ? out[q] : (S)(inf_pick(rb, i / PER) >> (8 * sizeof(S) * (i % PER)));
+                }
                 __builtin_amdgcn_wave_barrier();
                 const u32 r4 = s_ref32[lane];
-                const u32 w = (u32)s_val[r4 & 255u] | (u32)s_val[(r4 >> 8) & 255u] << 8 | (u32)s_val[(r4 >> 16) & 255u] << 16 | (u32)s_val[r4 >> 24] << 24;
-                const u32 hi = run - n_out + lo;                                            // window bytes [lo, hi) are text
-                char* wp = out + n_out - lo + 4 * (u32)lane;
+                constexpr u32 SB = 8 * sizeof(S);                                           // bits per symbol
+                const u64 w = (u64)s_val[r4 & 255u] | (u64)s_val[(r4 >> 8) & 255u] << SB | (u64)s_val[(r4 >> 16) & 255u] << (2 * SB) | (u64)s_val[r4 >> 24] << (3 * SB);
+                const u32 hi = run - n_out + lo;                                            // window symbols [lo, hi) are text
+                S* wp = out + n_out - lo + 4 * (u32)lane;
                 const u32 r0 = 4 * (u32)lane;
-                if (r0 >= lo && r0 + 4 <= hi) *reinterpret_cast<u32*>(wp) = w;
+                if (r0 >= lo && r0 + 4 <= hi) { if (MODE == 1) *reinterpret_cast<u64*>(wp) = w; else *reinterpret_cast<u32*>(wp) = (u32)w; }
                 else {
 #pragma unroll
-                    for (u32 k = 0; k < 4; k++) if (r0 + k >= lo && r0 + k < hi) wp[k] = (char)(w >> (8 * k));
+                    for (u32 k = 0; k < 4; k++) if (r0 + k >= lo && r0 + k < hi) wp[k] = (S)(w >> (SB * k));
                 }
-                last_byte = (char)((u32)__builtin_amdgcn_readlane((int)w, (int)((hi - 1) >> 2)) >> (8 * ((hi - 1) & 3u)));
+                {
+                    const u32 wl_ = (u32)__builtin_amdgcn_readlane((int)(u32)w, (int)((hi - 1) >> 2)), wh_ = (u32)__builtin_amdgcn_readlane((int)(u32)(w >> 32), (int)((hi - 1) >> 2));
+                    last_byte = (S)((((u64)wh_ << 32) | wl_) >> (SB * ((hi - 1) & 3u)));
+                }
                 __builtin_amdgcn_wave_barrier();
                 INF_T(5);
             }
@@ -517,20 +533,20 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
                 bp += used;
                 if (ev == 1) {
                     if (n_out + 1 > isize) { status = 5; break; }
-                    if (lane == 0) out[n_out] = (char)lit;
-                    n_out++; last_byte = (char)lit;
+                    if (lane == 0) out[n_out] = (S)lit;
+                    n_out++; last_byte = (S)lit;
                 } else if (ev == 2) {
-                    if (sd > n_out || n_out + sl > isize) { status = 6; break; }
-                    char myv = last_byte;
+                    if (sd > n_out + BACK || n_out + sl > isize) { status = 6; break; }
+                    S myv = last_byte;
                     if (sd == 1) {
                         // a run of the byte in front of it (quality strings): no read at all
                         for (u32 i = lane; i < sl; i += 64) out[n_out + i] = myv;
                     } else {
                         // bytes stored since the last fence are not visible to the other lanes yet: a fence when the source reaches into them
-                        if ((sd >= sl ? n_out - sd + sl : n_out) > fenced) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
-                        for (u32 i = lane; i < sl; i += 64) { myv = out[n_out - sd + (sd >= sl ? i : i % sd)]; out[n_out + i] = myv; }
+                        if ((int)(sd >= sl ? n_out + sl : n_out + sd) - (int)sd > (int)fenced) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
+                        for (u32 i = lane; i < sl; i += 64) { const int q = (int)n_out - (int)sd + (int)(sd >= sl ? i : i % sd); myv = MODE == 1 && q < 0 ? (S)inf_marker(q) : out[q]; out[n_out + i] = myv; }
                     }
-                    last_byte = (char)__builtin_amdgcn_readlane((int)myv, (int)((sl - 1) & 63u));
+                    last_byte = (S)__builtin_amdgcn_readlane((int)myv, (int)((sl - 1) & 63u));
                     n_out += sl;
                 } else if (ev == 3) block_done = true;
                 else status = 7;
@@ -538,7 +554,56 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
             INF_T(7);
         }
         // the next block header is read by lane 0 from bp
-        if (lane == 0) { in.init(z + (bp >> 3), z + zlen - 8); in.refill(); in.drop((int)(bp & 7u)); }
+        if (lane == 0) { in.init(z + (bp >> 3), zend); in.refill(); in.drop((int)(bp & 7u)); }
+    }
+    // where the stream stands: behind the last block that was read (lane 0 re-opened its reader there), or at the block not entered
+    u32 eb = 0;
+    if (lane == 0) eb = (u32)((in.p - z) * 8) - (u32)in.cnt;
+    end_bit_r = (u32)__shfl((int)eb, 0);
+    status_r = status; n_out_r = n_out; final_r = last;
+#ifdef INF_PROFILE
+    prof[15] = clock64() - t_begin;
+    if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_inf_prof[k], prof[k]);
+#endif
+}
+
+// comp: the compressed bytes of n BGZF blocks, block b at comp + blk_off[b] (blk_off[n] = end); its text goes to text + out_off[b]
+// (out_off[b + 1] - out_off[b] = the ISIZE its trailer states).  err[b] = 0 when the block was well-formed and its CRC matched.
+__global__ void __launch_bounds__(64, 4)
+k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, const u64* __restrict__ out_off, long n, char* __restrict__ text, u32* __restrict__ err)
+{
+    __shared__ u32 s_crc_tab[256];
+    const long b = blockIdx.x;
+    if (b >= n) return;
+    const int lane = threadIdx.x;
+    const u8* z = comp + blk_off[b];
+    const u64 zlen = blk_off[b + 1] - blk_off[b];
+    char* out = text + out_off[b];
+    const u32 isize = (u32)(out_off[b + 1] - out_off[b]);
+    u32 status = 0;                                       // 0 ok so far
+    // ---- gzip member header (BGZF: FEXTRA with the BC subfield; any other well-formed header is read too)
+    u32 body = 0;
+    if (zlen < 18 + 8 || z[0] != 0x1f || z[1] != 0x8b || z[2] != 8 || (z[3] & 0xe0)) status = 1;
+    else {
+        const int flg = z[3];
+        u64 q = 10;
+        if (flg & 4) { const u64 xl = (u64)z[q] | ((u64)z[q + 1] << 8); q += 2 + xl; }
+        if ((flg & 8) && q < zlen) { while (q < zlen && z[q]) q++; q++; }
+        if ((flg & 16) && q < zlen) { while (q < zlen && z[q]) q++; q++; }
+        if (flg & 2) q += 2;
+        if (q + 8 > zlen) status = 1;
+        body = (u32)q;
+    }
+    {
+        u32 c = (u32)lane;                                 // CRC table: four entries per lane
+        for (int t = 0; t < 4; t++) { u32 v = (u32)(lane + 64 * t); for (int k = 0; k < 8; k++) v = (v & 1) ? (v >> 1) ^ 0xedb88320u : v >> 1; s_crc_tab[lane + 64 * t] = v; }
+        (void)c;
+    }
+    __syncthreads();
+    u32 n_out = 0;
+    if (!status) {
+        u32 end_bit = 0; bool fin = false;
+        inf_wave<0>(z, z + zlen - 8, body * 8, 0xffffffffu, reinterpret_cast<u8*>(out), isize, lane, status, n_out, end_bit, fin);
     }
     // ---- trailer: ISIZE and CRC-32 (every lane one segment, the segments combined by x^(8 * bytes behind them))
     if (!status) {
@@ -589,11 +654,6 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         }
     }
     if (lane == 0) err[b] = status;
-#ifdef INF_PROFILE
-    INF_T(8);
-    prof[15] = clock64() - t_begin;
-    if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_inf_prof[k], prof[k]);
-#endif
 }
 
 // a window that ends the file: an unterminated last line gets its newline (the text buffer has the room); *added = 1 when it did
@@ -629,5 +689,128 @@ k_nl_count64k(const char* __restrict__ text, u64 total, u64 shift, u32* __restri
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) counts[j] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- one-member gzip: a window of ONE deflate stream, inflated by many waves (round 4) ----------------------------------------------
+// The stream is cut every `span` bytes.  (1) k_gz_starts: the wave of a cut looks for the first bit offset behind it at which a
+// dynamic-Huffman block header parses -- a lane per offset for the cheap test (block type, HLIT / HDIST, complete code-length code, as
+// pgz::header_plausible), the whole header (inf_wave<2>) for the survivors.  (2) k_gz_spans: a wave per span decodes from its start to
+// the first block boundary at or behind the next cut, into 16-bit symbols (inf_wave<1>).  (3) k_gz_windows: one workgroup walks the spans
+// in order -- a span counts when it starts where its predecessor stopped -- and pushes the 32 KiB window through each.  (4) k_gz_resolve:
+// symbols -> bytes at the span's place in the text.  What the chain does not reach (a start that was not one, a block longer than a span,
+// a stream of stored blocks) is left to the caller: the next call begins at the boundary the chain did reach.
+#define GZ_NONE 0xffffffffu
+struct GzSpan { u32 status, n_sym, end_bit, final; };
+
+DEVI bool gz_plausible(const u8* z, u32 bit)
+{
+    u64 v; __builtin_memcpy(&v, z + (bit >> 3), 8);
+    v >>= (bit & 7u);
+    if ((v & 7u) != 4u) return false;                                           // BFINAL 0, BTYPE 2
+    if (((v >> 3) & 31u) > 29u || ((v >> 8) & 31u) > 29u) return false;
+    const int hclen = (int)((v >> 13) & 15u) + 4;
+    const u32 b2 = bit + 17;                                                    // the 3-bit lengths of the code-length code
+    u64 w; __builtin_memcpy(&w, z + (b2 >> 3), 8);
+    w >>= (b2 & 7u);                                                            // >= 57 bits = 19 lengths
+    int left = 1 << 7;                                                          // Kraft sum in units of 2^-7
+    for (int i = 0; i < hclen; i++) { const int l = (int)(w & 7u); w >>= 3; if (l) left -= 128 >> l; }
+    return left == 0;
+}
+
+__global__ void __launch_bounds__(64)
+k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_bytes, u32 first_bit, u32* __restrict__ start_bit)
+{
+    const u32 s = blockIdx.x;
+    if (s >= n_spans) return;
+    const int lane = threadIdx.x;
+    if (s == 0) { if (lane == 0) start_bit[0] = first_bit; return; }
+    const u64 last_bit = total_bytes > 64 ? (total_bytes - 64) * 8 : 0;        // a header needs room behind it
+    const u64 from = (u64)s * span_bytes * 8, to = min((u64)(s + 1) * span_bytes * 8, last_bit);
+    u32 found = GZ_NONE;
+    for (u64 base = from; base < to && found == GZ_NONE; base += 64) {
+        const u32 bit = (u32)base + (u32)lane;
+        unsigned long long m = __ballot(bit < to && gz_plausible(comp, bit));
+        while (m) {
+            const u32 c = (u32)base + (u32)__builtin_ctzll(m);
+            m &= m - 1;
+            u32 st = 0, n = 0, eb = 0; bool fin = false;
+            inf_wave<2>(comp, comp + total_bytes, c, 0xffffffffu, nullptr, 0, lane, st, n, eb, fin);
+            if (!st) { found = c; break; }
+        }
+    }
+    if (lane == 0) start_bit[s] = found;
+}
+
+__global__ void __launch_bounds__(64, 3)
+k_gz_spans(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_bytes, u32 limit_bit, const u32* __restrict__ start_bit,
+           u16* __restrict__ sym, u32 cap, GzSpan* __restrict__ res)
+{
+    const u32 s = blockIdx.x;
+    if (s >= n_spans) return;
+    const int lane = threadIdx.x;
+    const u32 from = start_bit[s];
+    GzSpan r; r.status = 100; r.n_sym = 0; r.end_bit = 0; r.final = 0;
+    if (from != GZ_NONE) {
+        const u64 next_cut = (u64)(s + 1) * span_bytes * 8;
+        const u32 stop = s + 1 < n_spans ? (u32)min(next_cut, (u64)limit_bit) : limit_bit;
+        bool fin = false;
+        inf_wave<1>(comp, comp + total_bytes, from, stop, sym + (size_t)s * cap, cap, lane, r.status, r.n_sym, r.end_bit, fin);
+        r.final = fin ? 1u : 0u;
+    }
+    if (lane == 0) res[s] = r;
+}
+
+// windows: wall[0] = the 32 KiB in front of the window's first span (right-aligned: wall[0][32767] = the byte just before it; the first
+// 32768 - win_len bytes do not exist), wall[s + 1] = the 32 KiB behind span s.  off[s] = where span s's text begins.  info[0] = spans the
+// chain reached, info[1] = the stream's final block was among them, info[2] = bit position reached, info[3] = bytes of the last window
+// that exist, info[4] = a marker pointed in front of the stream (corrupt input)
+__global__ void __launch_bounds__(1024)
+k_gz_windows(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ res, const u32* __restrict__ start_bit, u32 n_spans, u32 first_bit,
+             u32 win_len, u8* __restrict__ wall, u64* __restrict__ off, u64* __restrict__ info)
+{
+    __shared__ u8 w0[32768];
+    __shared__ u8 w1[32768];
+    __shared__ u32 s_bad;
+    const u32 t = threadIdx.x;
+    for (u32 i = t; i < 32768; i += 1024) w0[i] = wall[i];
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    u8* wp = w0; u8* wn = w1;
+    u32 reached = first_bit, have = win_len, good = 0, fin = 0;
+    u64 at = 0;
+    for (u32 s = 0; s < n_spans; s++) {
+        const GzSpan r = res[s];
+        if (r.status != 0 || start_bit[s] != reached) break;
+        if (t == 0) off[s] = at;
+        const u16* sy = sym + (size_t)s * cap;
+        const u32 n = r.n_sym;
+        const u32 lowest = 32768 - have;                                        // window positions below this do not exist
+        for (u32 i = t; i < 32768; i += 1024) {
+            const long q = (long)n - 32768 + (long)i;                           // position in the span's output (negative: the old window, shifted)
+            u8 v;
+            if (q >= 0) { const u32 x = sy[q]; if (x < 0x8000u) v = (u8)x; else { const u32 w = x & 0x7fffu; if (w < lowest) s_bad = 1; v = wp[w]; } }
+            else v = wp[32768 + q];
+            wn[i] = v;
+            wall[(size_t)(s + 1) * 32768 + i] = v;
+        }
+        __syncthreads();
+        u8* x = wp; wp = wn; wn = x;
+        at += n; reached = r.end_bit; have = min(32768u, have + n); good = s + 1;
+        if (r.final) { fin = 1; break; }
+    }
+    if (t == 0) { off[good] = at; info[0] = good; info[1] = fin; info[2] = reached; info[3] = have; info[4] = s_bad; }
+}
+
+__global__ void __launch_bounds__(256)
+k_gz_resolve(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ res, const u64* __restrict__ off, const u64* __restrict__ info,
+             const u8* __restrict__ wall, char* __restrict__ text)
+{
+    const u32 s = blockIdx.y;
+    if (s >= (u32)info[0]) return;
+    const u32 n = res[s].n_sym;
+    const u16* sy = sym + (size_t)s * cap;
+    const u8* w = wall + (size_t)s * 32768;                                     // the window in front of span s
+    char* o = text + off[s];
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const u32 x = sy[i]; o[i] = (char)(x < 0x8000u ? x : w[x & 0x7fffu]); }
 }
 #endif

@@ -262,6 +262,20 @@ int bmbs_map_se_text(bmbs_ctx*, const char* text, uint64_t text_bytes, int64_t n
 int bmbs_map_pe_text(bmbs_ctx*, const char* text1, uint64_t bytes1, const char* text2, uint64_t bytes2, int64_t n_pairs, int32_t flags,
                      char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
 
+/* ---- an ordinary .gz member (ONE deflate stream) inflated on the device, a window at a time ------------------------------------------
+ * comp[0, comp_bytes): compressed bytes of the stream from the byte that holds bit start_bit -- a block boundary the caller knows (the
+ * stream's first block, or where the previous call stopped); win_in: the win_len (<= 32768) bytes of text in front of that point.
+ * The window is cut every 64 KiB; a wave per cut finds the next block start and decodes its span with the 32 KiB in front of it
+ * unknown (16-bit symbols, markers), the spans are chained in order and resolved (bmbs_inflate.hip).  Blocks are entered up to
+ * limit_bytes: keep a margin of one block (256 KiB is plenty) before the end of what comp holds, or pass comp_bytes at the end of
+ * the file.  -> text of every span the chain reached, *end_bit = where it stopped (a block boundary, relative to comp), *final_block
+ * = the stream's last block was decoded (its 8-byte trailer follows at the next byte boundary: CRC-32 and ISIZE are the caller's to
+ * check), win_out / *win_out_len = the text behind that point for the next call.  *text_bytes == 0 with BMBS_OK: nothing could be
+ * confirmed (stored blocks only, a block longer than a span's slot): the caller's host inflater takes over.  BMBS_ENOMEM with
+ * *text_bytes set when text_cap is too small.  Needs no index.                                                                       */
+int bmbs_inflate_gzip(bmbs_ctx*, const void* comp, uint64_t comp_bytes, uint32_t start_bit, uint64_t limit_bytes, const void* win_in, uint32_t win_len,
+                      char* text, uint64_t text_cap, uint64_t* text_bytes, uint64_t* end_bit, int32_t* final_block, void* win_out, uint32_t* win_out_len);
+
 /* ---- bgzip'ed FASTQ inflated on the device -------------------------------------------------------------------------------------------
  * The reference reads .gz input through zlib's gzread on its reader thread (Process_Reads.cpp:1455-1514).  A BGZF file (bgzip) is a
  * series of independent gzip members of at most 64 KiB of text whose compressed size stands in the header: a window of them is

@@ -1299,6 +1299,36 @@ def test_device_bam_blocks_inflate_to_the_records_of_the_sam_text(env, case):
         assert len(z) < len(got) // 2             # runs + Huffman: constant qualities and 4-bit bases compress
 
 
+@pytest.mark.parametrize("level,span,window", [(1, 65536, 1 << 22), (6, 65536, 1 << 22), (9, 4096, 300000), (1, 2048, 100000), (6, 65536, 700000)])
+def test_device_gzip_inflate_equals_zlib(env, level, span, window, monkeypatch):
+    """an ordinary one-member .gz file (one deflate stream): spans cut every `span` bytes, block starts found by the search over bit
+    offsets, 16-bit symbols with window markers, chained and resolved on the device -- the text, and the trailer's CRC-32 / ISIZE, are
+    zlib's; several calls per file (the caller's loop carries the bit position and the 32 KiB window)"""
+    import zlib
+    from bitmapperbs_amd import mapper
+    monkeypatch.setenv("BMBS_GZ_DEV_SPAN", str(span))
+    rng = np.random.default_rng(7 + level)
+    n = 30000
+    seq = np.frombuffer(b"AGTC", dtype=np.uint8)[rng.choice(4, size=(n, 150), p=[0.3, 0.3, 0.39, 0.01])]
+    q = np.frombuffer(b"FFFFFFFF:,#", dtype=np.uint8)[rng.integers(0, 11, size=(n, 150))]
+    out = bytearray()
+    for i in range(n):
+        out += b"@read%d/1\n" % i; out += seq[i].tobytes(); out += b"\n+\n"; out += q[i].tobytes(); out += b"\n"
+    text = bytes(out)
+    m = mapper.Mapper(env["ix"], 0)
+    noise = bytes(rng.integers(0, 256, 200000, dtype=np.uint8))
+    for data in (gzip.compress(text, level), gzip.compress(text[:1000], level), gzip.compress(noise + text[:300000], level),
+                 gzip.compress(b"A" * 3000000 + text[:50000], level)):
+        try:
+            got, calls = m.inflate_gzip(data, window=window)
+        except RuntimeError as ex:
+            # (the device path may decline -- stored blocks, a block longer than a span's slot -- but never return wrong text)
+            assert "no progress" in str(ex), ex
+            continue
+        assert got == zlib.decompress(data, 31), (len(got), calls)
+    m.close()
+
+
 def test_device_bgzf_inflate_equals_zlib(env):
     """bmbs_inflate_bgzf (one wave per BGZF block, bmbs_inflate.hip) against zlib: FASTQ text at every compression level and
     strategy (dynamic, fixed and stored blocks, codes longer than the root tables, runs that overlap themselves, several deflate
