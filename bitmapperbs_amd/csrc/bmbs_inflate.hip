@@ -567,6 +567,55 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
 #endif
 }
 
+// CRC-32 of out[0, isize) by one wave (the table in LDS): every lane one segment, in four quarters side by side (a table look-up waits
+// ~100 cycles for LDS: four chains in flight instead of one); the quarters are joined with x^(8 * quarter) -- the same factor in every
+// lane but the last --, the lanes' segments with x^(8 * bytes behind them)
+DEVI void inf_crc_table(u32* s_crc_tab, int lane)
+{
+    for (int t = 0; t < 4; t++) { u32 v = (u32)(lane + 64 * t); for (int k = 0; k < 8; k++) v = (v & 1) ? (v >> 1) ^ 0xedb88320u : v >> 1; s_crc_tab[lane + 64 * t] = v; }
+}
+DEVI u32 inf_crc32_wave(const u8* out, u32 isize, const u32* s_crc_tab, int lane)
+{
+    // every lane one segment, in four quarters side by side (a table look-up waits ~100 cycles for LDS: four chains in flight
+    // instead of one); the quarters are joined with x^(8 * quarter) -- the same factor in every lane but the last
+    const u32 seg = (((isize + 63) / 64) + 3) & ~3u, q = seg / 4;
+    const u32 xq = crc_x8n(q);
+    u32 cc[4], ea[4], ee[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 a = (u32)lane * seg + (u32)k * q;
+        ea[k] = a < isize ? a : isize; ee[k] = a + q < isize ? a + q : isize;
+        cc[k] = 0xffffffffu;
+    }
+    // four bytes of every quarter per step (one unaligned load each, issued before the sixteen look-ups that use them)
+    for (u32 i = 0; i + 4 <= q; i += 4) {
+        u32 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { w[k] = 0; if (ea[k] + i + 4 <= ee[k]) __builtin_memcpy(&w[k], out + ea[k] + i, 4); }
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (ea[k] + i + 4 <= ee[k]) cc[k] = s_crc_tab[(cc[k] ^ (w[k] >> (8 * bb))) & 0xffu] ^ (cc[k] >> 8);
+        }
+    }
+    // (what is left of a quarter: up to three bytes, or the whole of a quarter that the text ends in)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 len = ee[k] - ea[k];
+        for (u32 i = len & ~3u; i < len; i++) cc[k] = s_crc_tab[(cc[k] ^ out[ea[k] + i]) & 0xffu] ^ (cc[k] >> 8);
+    }
+    u32 c = ~cc[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        const u32 lk = ee[k] - ea[k];
+        if (lk) c = crc_multmodp(lk == q ? xq : crc_x8n(lk), c) ^ ~cc[k];
+    }
+    u32 x = ea[0] < ee[3] ? crc_multmodp(crc_x8n(isize - ee[3]), c) : 0u;
+    for (int o = 32; o > 0; o >>= 1) x ^= __shfl_down(x, o, 64);
+    x = (u32)__shfl((int)x, 0);
+    return x;
+}
+
 // comp: the compressed bytes of n BGZF blocks, block b at comp + blk_off[b] (blk_off[n] = end); its text goes to text + out_off[b]
 // (out_off[b + 1] - out_off[b] = the ISIZE its trailer states).  err[b] = 0 when the block was well-formed and its CRC matched.
 __global__ void __launch_bounds__(64, 4)
@@ -594,11 +643,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         if (q + 8 > zlen) status = 1;
         body = (u32)q;
     }
-    {
-        u32 c = (u32)lane;                                 // CRC table: four entries per lane
-        for (int t = 0; t < 4; t++) { u32 v = (u32)(lane + 64 * t); for (int k = 0; k < 8; k++) v = (v & 1) ? (v >> 1) ^ 0xedb88320u : v >> 1; s_crc_tab[lane + 64 * t] = v; }
-        (void)c;
-    }
+    inf_crc_table(s_crc_tab, lane);
     __syncthreads();
     u32 n_out = 0;
     if (!status) {
@@ -613,43 +658,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
         if (n_out != isize || want_len != isize) status = 8;
         else {
             __threadfence_block();
-            // every lane one segment, in four quarters side by side (a table look-up waits ~100 cycles for LDS: four chains in flight
-            // instead of one); the quarters are joined with x^(8 * quarter) -- the same factor in every lane but the last
-            const u32 seg = (((isize + 63) / 64) + 3) & ~3u, q = seg / 4;
-            const u32 xq = crc_x8n(q);
-            u32 cc[4], ea[4], ee[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u32 a = (u32)lane * seg + (u32)k * q;
-                ea[k] = a < isize ? a : isize; ee[k] = a + q < isize ? a + q : isize;
-                cc[k] = 0xffffffffu;
-            }
-            // four bytes of every quarter per step (one unaligned load each, issued before the sixteen look-ups that use them)
-            for (u32 i = 0; i + 4 <= q; i += 4) {
-                u32 w[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) { w[k] = 0; if (ea[k] + i + 4 <= ee[k]) __builtin_memcpy(&w[k], out + ea[k] + i, 4); }
-#pragma unroll
-                for (int bb = 0; bb < 4; bb++) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) if (ea[k] + i + 4 <= ee[k]) cc[k] = s_crc_tab[(cc[k] ^ (w[k] >> (8 * bb))) & 0xffu] ^ (cc[k] >> 8);
-                }
-            }
-            // (what is left of a quarter: up to three bytes, or the whole of a quarter that the text ends in)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u32 len = ee[k] - ea[k];
-                for (u32 i = len & ~3u; i < len; i++) cc[k] = s_crc_tab[(cc[k] ^ (u8)out[ea[k] + i]) & 0xffu] ^ (cc[k] >> 8);
-            }
-            u32 c = ~cc[0];
-#pragma unroll
-            for (int k = 1; k < 4; k++) {
-                const u32 lk = ee[k] - ea[k];
-                if (lk) c = crc_multmodp(lk == q ? xq : crc_x8n(lk), c) ^ ~cc[k];
-            }
-            u32 x = ea[0] < ee[3] ? crc_multmodp(crc_x8n(isize - ee[3]), c) : 0u;
-            for (int o = 32; o > 0; o >>= 1) x ^= __shfl_down(x, o, 64);
-            x = (u32)__shfl((int)x, 0);
+            const u32 x = inf_crc32_wave(reinterpret_cast<const u8*>(out), isize, s_crc_tab, lane);
             if (x != want_crc) status = 9;
         }
     }
@@ -702,41 +711,124 @@ k_nl_count64k(const char* __restrict__ text, u64 total, u64 shift, u32* __restri
 #define GZ_NONE 0xffffffffu
 struct GzSpan { u32 status, n_sym, end_bit, final; };
 
-DEVI bool gz_plausible(const u8* z, u32 bit)
+// the cheap test on the 128 bits w (LSB first) that begin at the candidate's bit: block type, HLIT / HDIST, complete code-length code
+DEVI bool gz_plausible(u64 lo, u64 hi)
 {
-    u64 v; __builtin_memcpy(&v, z + (bit >> 3), 8);
-    v >>= (bit & 7u);
-    if ((v & 7u) != 4u) return false;                                           // BFINAL 0, BTYPE 2
-    if (((v >> 3) & 31u) > 29u || ((v >> 8) & 31u) > 29u) return false;
-    const int hclen = (int)((v >> 13) & 15u) + 4;
-    const u32 b2 = bit + 17;                                                    // the 3-bit lengths of the code-length code
-    u64 w; __builtin_memcpy(&w, z + (b2 >> 3), 8);
-    w >>= (b2 & 7u);                                                            // >= 57 bits = 19 lengths
+    if ((lo & 7u) != 4u) return false;                                          // BFINAL 0, BTYPE 2
+    if (((lo >> 3) & 31u) > 29u || ((lo >> 8) & 31u) > 29u) return false;
+    const int hclen = (int)((lo >> 13) & 15u) + 4;
+    u64 w = (lo >> 17) | (hi << 47);                                            // the 3-bit lengths of the code-length code: 57 bits = 19 lengths
     int left = 1 << 7;                                                          // Kraft sum in units of 2^-7
     for (int i = 0; i < hclen; i++) { const int l = (int)(w & 7u); w >>= 3; if (l) left -= 128 >> l; }
     return left == 0;
 }
 
+// the whole dynamic-Huffman header at `bit`, judged by ONE lane (64 candidates side by side): HLIT / HDIST, the code-length code as a
+// 128-entry table in the lane's LDS slot, the ~300 code lengths walked with their repeat codes, and what zlib's inflate_table asks of
+// the two codes they describe -- complete (Kraft sum exactly one), an end-of-block code; a distance code may be a single code or none
+DEVI u64 gz_bits(const u8* z, u32 p) { u64 v; __builtin_memcpy(&v, z + (p >> 3), 8); return v >> (p & 7u); }      // >= 57 bits from bit p
+DEVI bool gz_header_ok(const u8* z, u32 bit, u32 end_bit, u8* tab /* [128] of this lane */)
+{
+    u32 p = bit + 3;
+    u64 v = gz_bits(z, p);
+    const u32 hlit = (u32)(v & 31u) + 257, hdist = (u32)((v >> 5) & 31u) + 1, hclen = (u32)((v >> 10) & 15u) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    p += 14;
+    v = gz_bits(z, p);
+    p += 3 * hclen;
+    // lengths of the code-length code in symbol order, 3 bits each
+    u64 cl = 0;
+    u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const u64 order = 0x0f0e0d0c0b0a0908ull;                                          // (not used: the order is spelled out below)
+        (void)order;
+        const u8 ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+#pragma unroll
+        for (u32 i = 0; i < 19; i++) {
+            const u32 l = i < hclen ? (u32)((v >> (3 * i)) & 7u) : 0u;
+            cl |= (u64)l << (3 * ord[i]);
+#pragma unroll
+            for (u32 k = 1; k < 8; k++) cnt[k] += l == k;
+        }
+    }
+    // canonical codes -> table indexed by the next 7 bits (LSB first): entry = symbol << 3 | length, 0 = no code
+    for (u32 i = 0; i < 128; i++) tab[i] = 0;
+    {
+        u32 next[8]; u32 code = 0;
+#pragma unroll
+        for (u32 k = 1; k < 8; k++) { code = (code + cnt[k - 1]) << 1; next[k] = code; }
+#pragma unroll
+        for (u32 sym = 0; sym < 19; sym++) {
+            const u32 l = (u32)((cl >> (3 * sym)) & 7u);
+            if (!l) continue;
+            u32 c = 0;
+#pragma unroll
+            for (u32 k = 1; k < 8; k++) if (l == k) { c = next[k]; next[k] = c + 1; }
+            const u32 r = __brev(c) >> (32 - l);                                          // the code as it arrives, LSB first
+            for (u32 i = r; i < 128; i += 1u << l) tab[i] = (u8)(sym << 3 | l);
+        }
+    }
+    const u32 total = hlit + hdist;
+    u32 have = 0, prev = 0, litK = 0, distK = 0, dist_codes = 0;
+    bool eob = false;
+    while (have < total) {
+        if (p + 64 > end_bit) return false;
+        v = gz_bits(z, p);
+        const u32 e = tab[v & 127u], l = e & 7u, sym = e >> 3;
+        if (!l) return false;
+        p += l; v >>= l;
+        u32 len = 0, rep = 1;
+        if (sym < 16) { len = sym; prev = sym; }
+        else if (sym == 16) { if (!have) return false; len = prev; rep = 3 + (u32)(v & 3u); p += 2; }
+        else if (sym == 17) { rep = 3 + (u32)(v & 7u); p += 3; prev = 0; }
+        else { rep = 11 + (u32)(v & 127u); p += 7; prev = 0; }
+        if (have + rep > total) return false;
+        const u32 n_lit = have < hlit ? min(rep, hlit - have) : 0u, n_dist = rep - n_lit;
+        if (len) {
+            litK += n_lit << (15 - len); distK += n_dist << (15 - len); dist_codes += n_dist;
+            if (litK > 32768u || (distK > 32768u)) return false;                // over-subscribed: what random bits run into within a few lengths
+            if (have <= 256 && 256 < have + n_lit) eob = true;
+        }
+        have += rep;
+    }
+    if (!eob || litK != 32768u) return false;
+    return distK == 32768u || dist_codes <= 1;
+}
+
 __global__ void __launch_bounds__(64)
 k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_bytes, u32 first_bit, u32* __restrict__ start_bit)
 {
+    __shared__ u8 s_tab[64][128];
     const u32 s = blockIdx.x;
     if (s >= n_spans) return;
     const int lane = threadIdx.x;
     if (s == 0) { if (lane == 0) start_bit[0] = first_bit; return; }
     const u64 last_bit = total_bytes > 64 ? (total_bytes - 64) * 8 : 0;        // a header needs room behind it
-    const u64 from = (u64)s * span_bytes * 8, to = min((u64)(s + 1) * span_bytes * 8, last_bit);
+    // (the search goes on behind the span's own bytes: a span whose first block start lies in a later span decodes nothing and hands the
+    // chain on -- blocks may be longer than a span)
+    const u64 from = (u64)s * span_bytes * 8, to = min(from + ((u64)1 << 23), last_bit);
     u32 found = GZ_NONE;
-    for (u64 base = from; base < to && found == GZ_NONE; base += 64) {
-        const u32 bit = (u32)base + (u32)lane;
-        unsigned long long m = __ballot(bit < to && gz_plausible(comp, bit));
-        while (m) {
-            const u32 c = (u32)base + (u32)__builtin_ctzll(m);
-            m &= m - 1;
-            u32 st = 0, n = 0, eb = 0; bool fin = false;
-            inf_wave<2>(comp, comp + total_bytes, c, 0xffffffffu, nullptr, 0, lane, st, n, eb, fin);
-            if (!st) { found = c; break; }
+    // 512 bit offsets per step: a lane takes the eight offsets of one byte and reads the 16 bytes they need once; the offsets that pass
+    // the cheap test are judged in full by their own lanes, the lowest that stands is the start
+    for (u64 base = from; base < to && found == GZ_NONE; base += 512) {
+        const u32 byte0 = (u32)(base >> 3) + (u32)lane;
+        u64 lo, hi; __builtin_memcpy(&lo, comp + byte0, 8); __builtin_memcpy(&hi, comp + byte0 + 8, 8);
+        u32 m8 = 0;
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+            const u64 l2 = j ? (lo >> j) | (hi << (64 - j)) : lo, h2 = hi >> j;
+            if ((u64)byte0 * 8 + j < to && gz_plausible(l2, h2)) m8 |= 1u << j;
         }
+        u32 best = GZ_NONE;
+        while (m8) {
+            const u32 j = (u32)__builtin_ctz(m8);
+            m8 &= m8 - 1;
+            const u32 c = byte0 * 8 + j;
+            if (gz_header_ok(comp, c, (u32)(total_bytes * 8), s_tab[lane])) { best = c; break; }
+        }
+        // the lowest offset over the lanes
+        for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }
+        found = best;
     }
     if (lane == 0) start_bit[s] = found;
 }
@@ -763,42 +855,86 @@ k_gz_spans(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_b
 // windows: wall[0] = the 32 KiB in front of the window's first span (right-aligned: wall[0][32767] = the byte just before it; the first
 // 32768 - win_len bytes do not exist), wall[s + 1] = the 32 KiB behind span s.  off[s] = where span s's text begins.  info[0] = spans the
 // chain reached, info[1] = the stream's final block was among them, info[2] = bit position reached, info[3] = bytes of the last window
-// that exist, info[4] = a marker pointed in front of the stream (corrupt input)
+// that exist, info[4] = a marker pointed in front of the stream (corrupt input), info[5] = bytes of text of the spans reached
+#define GZ_MAX_SPANS 8192
+DEVI void gz_load32(const u16* sy, long q0, u32 (&x)[16])
+{
+    if (q0 >= 0) {
+        // (16 bytes at a time at whatever alignment the span's length leaves)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { uint4 v; __builtin_memcpy(&v, sy + q0 + 8 * k, 16); x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const long qa = q0 + 2 * k, qb = qa + 1;
+            const u32 a = qa >= 0 ? (u32)sy[qa] : 0x8000u | (u32)(32768 + qa), b2 = qb >= 0 ? (u32)sy[qb] : 0x8000u | (u32)(32768 + qb);
+            x[k] = a | b2 << 16;
+        }
+    }
+}
 __global__ void __launch_bounds__(1024)
 k_gz_windows(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ res, const u32* __restrict__ start_bit, u32 n_spans, u32 first_bit,
              u32 win_len, u8* __restrict__ wall, u64* __restrict__ off, u64* __restrict__ info)
 {
-    __shared__ u8 w0[32768];
-    __shared__ u8 w1[32768];
-    __shared__ u32 s_bad;
+    __shared__ __attribute__((aligned(16))) u8 w0[32768];
+    __shared__ __attribute__((aligned(16))) u8 w1[32768];
+    __shared__ u32 s_n[GZ_MAX_SPANS];
+    __shared__ u32 s_bad, s_good, s_fin;
     const u32 t = threadIdx.x;
     for (u32 i = t; i < 32768; i += 1024) w0[i] = wall[i];
-    if (t == 0) s_bad = 0;
+    if (t == 0) { s_bad = 0; s_good = n_spans; s_fin = 0xffffffffu; }
     __syncthreads();
-    u8* wp = w0; u8* wn = w1;
-    u32 reached = first_bit, have = win_len, good = 0, fin = 0;
-    u64 at = 0;
-    for (u32 s = 0; s < n_spans; s++) {
+    // how far the chain goes: span s counts when it decoded and starts where span s - 1 stopped -- every link is judged on its own, the
+    // first broken one ends the chain; it also ends behind the stream's final block
+    for (u32 s = t; s < n_spans; s += 1024) {
         const GzSpan r = res[s];
-        if (r.status != 0 || start_bit[s] != reached) break;
-        if (t == 0) off[s] = at;
-        const u16* sy = sym + (size_t)s * cap;
-        const u32 n = r.n_sym;
-        const u32 lowest = 32768 - have;                                        // window positions below this do not exist
-        for (u32 i = t; i < 32768; i += 1024) {
-            const long q = (long)n - 32768 + (long)i;                           // position in the span's output (negative: the old window, shifted)
-            u8 v;
-            if (q >= 0) { const u32 x = sy[q]; if (x < 0x8000u) v = (u8)x; else { const u32 w = x & 0x7fffu; if (w < lowest) s_bad = 1; v = wp[w]; } }
-            else v = wp[32768 + q];
-            wn[i] = v;
-            wall[(size_t)(s + 1) * 32768 + i] = v;
-        }
-        __syncthreads();
-        u8* x = wp; wp = wn; wn = x;
-        at += n; reached = r.end_bit; have = min(32768u, have + n); good = s + 1;
-        if (r.final) { fin = 1; break; }
+        const u32 prev_end = s ? res[s - 1].end_bit : first_bit;
+        s_n[s] = r.n_sym;
+        if (r.status != 0 || start_bit[s] != prev_end) atomicMin(&s_good, s);
+        if (r.status == 0 && r.final) atomicMin(&s_fin, s);
     }
-    if (t == 0) { off[good] = at; info[0] = good; info[1] = fin; info[2] = reached; info[3] = have; info[4] = s_bad; }
+    __syncthreads();
+    u32 good = s_good, fin = 0;
+    if (s_fin < good) { good = s_fin + 1; fin = 1; }
+    u8* wp = w0; u8* wn = w1;
+    u32 have = win_len;
+    u64 at = 0;
+    u32 x[16], xn[16];
+    if (good) gz_load32(sym, (long)s_n[0] - 32768 + (long)t * 32, x);
+    for (u32 s = 0; s < good; s++) {
+        if (t == 0) off[s] = at;
+        const u32 n = s_n[s];
+        const u32 lowest = 32768 - have;                                        // window positions below this do not exist
+        // a thread takes 32 consecutive positions of the new window: position i = symbol n - 32768 + i of the span, or -- in front of
+        // the span's first symbol -- the old window shifted.  (The next span's symbols are on their way while this one is resolved.)
+        const long q0 = (long)n - 32768 + (long)t * 32;
+        if (s + 1 < good) gz_load32(sym + (size_t)(s + 1) * cap, (long)s_n[s + 1] - 32768 + (long)t * 32, xn);
+        u32 o[8];
+        u32 bad = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 a = x[k] & 0xffffu, b2 = x[k] >> 16;
+            // (no branches: the window is read for every symbol, a byte keeps itself.  A marker of the span itself must point at text
+            // that exists; the shifted part of the old window carries its gaps along)
+            const u32 wa = a & 0x7fffu, wb = b2 & 0x7fffu;
+            const u32 la = wp[wa], lb = wp[wb];
+            bad |= (a >= 0x8000u && q0 + 2 * k >= 0 && wa < lowest) || (b2 >= 0x8000u && q0 + 2 * k + 1 >= 0 && wb < lowest);
+            const u32 va = a >= 0x8000u ? la : a, vb = b2 >= 0x8000u ? lb : b2;
+            const u32 two = (va & 0xffu) | (vb & 0xffu) << 8;
+            if (k & 1) o[k >> 1] |= two << 16; else o[k >> 1] = two;
+        }
+        if (bad) s_bad = 1;
+        uint4* dn = reinterpret_cast<uint4*>(wn + t * 32);
+        uint4* dg = reinterpret_cast<uint4*>(wall + (size_t)(s + 1) * 32768 + t * 32);
+        const uint4 v0 = make_uint4(o[0], o[1], o[2], o[3]), v1 = make_uint4(o[4], o[5], o[6], o[7]);
+        dn[0] = v0; dn[1] = v1; dg[0] = v0; dg[1] = v1;
+        __syncthreads();
+        u8* xw = wp; wp = wn; wn = xw;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = xn[k];
+        at += n; have = min(32768u, have + n);
+    }
+    if (t == 0) { off[good] = at; info[0] = good; info[1] = fin; info[2] = good ? res[good - 1].end_bit : first_bit; info[3] = have; info[4] = s_bad; info[5] = at; }
 }
 
 __global__ void __launch_bounds__(256)
@@ -812,5 +948,20 @@ k_gz_resolve(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ re
     const u8* w = wall + (size_t)s * 32768;                                     // the window in front of span s
     char* o = text + off[s];
     for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const u32 x = sy[i]; o[i] = (char)(x < 0x8000u ? x : w[x & 0x7fffu]); }
+}
+
+// CRC-32 of every 64 KiB piece of a text (the caller joins them: crc32 of a concatenation = crc1 * x^(8 len2) + crc2)
+__global__ void __launch_bounds__(64)
+k_crc_segs(const u8* __restrict__ text, u64 total, u32* __restrict__ crc)
+{
+    __shared__ u32 s_crc_tab[256];
+    const int lane = threadIdx.x;
+    inf_crc_table(s_crc_tab, lane);
+    __syncthreads();
+    const u64 a = (u64)blockIdx.x << 16;
+    if (a >= total) return;
+    const u32 len = (u32)min((u64)65536, total - a);
+    const u32 x = inf_crc32_wave(text + a, len, s_crc_tab, lane);
+    if (lane == 0) crc[blockIdx.x] = x;
 }
 #endif

@@ -287,6 +287,33 @@ class Mapper:
                                                 C.byref(n), capi.ptr(t1), tail_cap, C.byref(b1), capi.ptr(t2), C.byref(b2)))
         return int(n.value), t1[:b1.value].tobytes(), t2[:b2.value].tobytes()
 
+    def text_open_gzip(self, g1, g2=None, max_records=1 << 30, last=(False, False), tail_cap=1 << 24):
+        """g = dict(prefix, comp, start_bit, limit, win): a window of ONE deflate stream per file, inflated and indexed on the device ->
+        (records, tail1, tail2, out1, out2) with out = dict(end_bit, final, crc32, text_bytes, win)"""
+        self._set_refs()
+        keep = []
+
+        def mk(g):
+            z = capi.GzText()
+            for name, val in (("prefix", g["prefix"]), ("comp", g["comp"]), ("win", g["win"])):
+                a = np.frombuffer(val, dtype=np.uint8) if val else np.zeros(1, dtype=np.uint8)
+                keep.append(a)
+                setattr(z, name, a.ctypes.data)
+            z.prefix_bytes = len(g["prefix"]); z.comp_bytes = len(g["comp"]); z.win_len = len(g["win"])
+            z.start_bit = g["start_bit"]; z.limit_bytes = g["limit"]
+            wo = np.empty(32768, dtype=np.uint8); keep.append(wo)
+            z.win_out = wo.ctypes.data
+            return z, wo
+        z1, w1 = mk(g1)
+        z2, w2 = mk(g2) if g2 is not None else (None, None)
+        t1 = np.empty(tail_cap, dtype=np.uint8); t2 = np.empty(tail_cap, dtype=np.uint8)
+        n = C.c_int64(0); b1 = C.c_uint64(0); b2 = C.c_uint64(0)
+        self._chk(self._lib.bmbs_text_open_gzip(self._ctx, C.byref(z1), C.byref(z2) if z2 is not None else None, max_records, int(last[0]), int(last[1]),
+                                                C.byref(n), capi.ptr(t1), tail_cap, C.byref(b1), capi.ptr(t2), C.byref(b2)))
+        outs = [dict(end_bit=int(z.end_bit), final=bool(z.final_block), crc32=int(z.crc32), text_bytes=int(z.text_bytes), win=w[:z.win_out_len].tobytes()) if z is not None else None
+                for z, w in ((z1, w1), (z2, w2))]
+        return int(n.value), t1[:b1.value].tobytes(), t2[:b2.value].tobytes(), outs[0], outs[1]
+
     def text_map_open(self, flags: int = 0, cap: int = 1 << 28) -> bytes:
         out = np.empty(cap, dtype=np.uint8)
         used = C.c_uint64(0); lines = C.c_int64(0)

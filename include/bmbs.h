@@ -310,6 +310,31 @@ typedef struct bmbs_ztext {
 int bmbs_text_open_bgzf(bmbs_ctx*, const bmbs_ztext* mate1, const bmbs_ztext* mate2 /* NULL: single end */, int64_t max_records,
                         int32_t last1, int32_t last2, int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes,
                         char* tail2, uint64_t* tail2_bytes);
+/* the same for an ordinary .gz member (ONE deflate stream; bmbs_inflate_gzip describes the scheme and the caller's loop): the window's
+ * compressed bytes from the block boundary the previous call reached, the text in front of it, and back come -- per file -- where the
+ * chain of spans stopped, whether the stream's final block was decoded, the window's CRC-32 and length (the caller joins them over a
+ * member and checks the trailer) and the 32 KiB for the next call.  last*: this file ends with the member's final block (its last line
+ * gets a newline when it has none) -- applied only when that block was reached.  text_bytes == 0 in a file whose call was given
+ * compressed bytes: nothing could be confirmed there, the caller's host inflater takes that file over.                               */
+typedef struct bmbs_gztext {
+    const char*     prefix;        /* host; NULL when prefix_bytes == 0: what the previous window left over */
+    uint64_t        prefix_bytes;
+    const void*     comp;          /* compressed bytes from the byte that holds bit start_bit (page-locked memory moves at link speed) */
+    uint64_t        comp_bytes;    /* may be 0 (a window made of the prefix alone) */
+    uint32_t        start_bit;     /* a block boundary */
+    uint64_t        limit_bytes;   /* blocks are entered up to here: a block's margin before comp_bytes, or comp_bytes at the end of the file */
+    const void*     win;           /* the win_len (<= 32768) bytes of text in front of start_bit */
+    uint32_t        win_len;
+    /* out */
+    uint64_t        end_bit;       /* where the chain stopped: a block boundary, relative to comp */
+    int32_t         final_block;
+    uint32_t        crc32;         /* of the text_bytes of text this window's blocks inflated to */
+    uint64_t        text_bytes;
+    void*           win_out;       /* [32768]: receives the win_out_len bytes of text behind end_bit */
+    uint32_t        win_out_len;
+} bmbs_gztext;
+int bmbs_text_open_gzip(bmbs_ctx*, bmbs_gztext* mate1, bmbs_gztext* mate2 /* NULL: single end */, int64_t max_records, int32_t last1, int32_t last2,
+                        int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes, char* tail2, uint64_t* tail2_bytes);
 int bmbs_text_map_open(bmbs_ctx*, int32_t flags, char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
 
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
