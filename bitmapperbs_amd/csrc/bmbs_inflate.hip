@@ -752,7 +752,7 @@ DEVI bool gz_header_ok(const u8* z, u32 bit, u32 end_bit, u8* tab /* [128] of th
         }
     }
     // canonical codes -> table indexed by the next 7 bits (LSB first): entry = symbol << 3 | length, 0 = no code
-    for (u32 i = 0; i < 128; i++) tab[i] = 0;
+    // (the code-length code is complete -- the cheap test's Kraft sum --: the codes below fill every one of the 128 entries)
     {
         u32 next[8]; u32 code = 0;
 #pragma unroll
@@ -813,18 +813,21 @@ k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_
     for (u64 base = from; base < to && found == GZ_NONE; base += 512) {
         const u32 byte0 = (u32)(base >> 3) + (u32)lane;
         u64 lo, hi; __builtin_memcpy(&lo, comp + byte0, 8); __builtin_memcpy(&hi, comp + byte0 + 8, 8);
+        // (block type and HLIT / HDIST of the eight offsets first -- one offset in ten passes --, the code-length code's Kraft sum and
+        // the whole header only for those)
         u32 m8 = 0;
 #pragma unroll
         for (u32 j = 0; j < 8; j++) {
-            const u64 l2 = j ? (lo >> j) | (hi << (64 - j)) : lo, h2 = hi >> j;
-            if ((u64)byte0 * 8 + j < to && gz_plausible(l2, h2)) m8 |= 1u << j;
+            const u32 v = (u32)(lo >> j);                                       // 13 bits: within the low word for j < 8
+            if ((v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u && (u64)byte0 * 8 + j < to) m8 |= 1u << j;
         }
         u32 best = GZ_NONE;
         while (m8) {
             const u32 j = (u32)__builtin_ctz(m8);
             m8 &= m8 - 1;
             const u32 c = byte0 * 8 + j;
-            if (gz_header_ok(comp, c, (u32)(total_bytes * 8), s_tab[lane])) { best = c; break; }
+            const u64 l2 = j ? (lo >> j) | (hi << (64 - j)) : lo, h2 = hi >> j;
+            if (gz_plausible(l2, h2) && gz_header_ok(comp, c, (u32)(total_bytes * 8), s_tab[lane])) { best = c; break; }
         }
         // the lowest offset over the lanes
         for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }

@@ -1543,6 +1543,7 @@ def test_text_call_with_a_small_buffer_can_be_repeated_and_counts_once(env):
 @pytest.mark.parametrize("kind,name,nparts,mode", [
     ("se", "b150", 3, "plain"), ("pe", "p100", 4, "plain"), ("pe", "s100", 2, "names_differ"), ("pe", "p150", 3, "no_names"),
     ("se", "e75", 2, "gz"), ("pe", "p75", 3, "bam"), ("pe", "p100", 2, "bgzf"), ("se", "b150", 3, "bgzf"), ("pe", "p150", 2, "bgzf_tails_grow"),
+    ("se", "b150", 2, "gz_device"), ("pe", "p100", 2, "gz_device"), ("pe", "p150", 2, "gz_device_small_windows"),
 ])
 def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, nparts, mode, tmp_path):
     """--out-parts N: the input is cut into N record ranges (pairs: at the same record in both files, found by the read names, or by
@@ -1557,7 +1558,7 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
     if kind == "se":
         fq = str(tmp_path / "r.fq")
         gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % name), fq)
-        if mode == "gz":
+        if mode in ("gz", "gz_device"):
             shutil.copy(os.path.join(GOLD, "se_%s.fq.gz" % name), fq + ".gz"); fq += ".gz"
         if mode == "bgzf":              # bgzip-style input: independent blocks, inflated by several threads
             from common import write_bgzf
@@ -1578,6 +1579,9 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
                 for i in range(0, len(t) - 1, 4):
                     t[i] = b"@same"
                 open(f, "wb").write(b"\n".join(t))
+        if mode.startswith("gz_device"):          # ordinary one-member .gz files, inflated on the device (BMBS_GZ_DEVICE=2)
+            shutil.copy(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1 + ".gz"); shutil.copy(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), f2 + ".gz")
+            f1 += ".gz"; f2 += ".gz"
         if mode in ("bgzf", "bgzf_tails_grow"):
             from common import write_bgzf
             write_bgzf(f1 + ".gz", open(f1, "rb").read(), block=9000); write_bgzf(f2 + ".gz", open(f2, "rb").read(), block=65000)
@@ -1588,13 +1592,17 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
     # (bgzf_tails_grow: the device-side reader starts with 8-byte buffers for what a window leaves behind its last whole record and has to
     # come back with room, bmbs_text_open_bgzf's BMBS_ENOMEM protocol)
     env = dict(os.environ, BMBS_Z_TAIL="8") if mode == "bgzf_tails_grow" else None
+    if mode == "gz_device":
+        env = dict(os.environ, BMBS_GZ_DEVICE="2", BMBS_GZ_DEV_SPAN="2048")
+    if mode == "gz_device_small_windows":     # a few kilobytes of compressed input per call: most calls end inside a block, the host inflates it
+        env = dict(os.environ, BMBS_GZ_DEVICE="2", BMBS_GZ_DEV_SPAN="1024", BMBS_GZ_DEV_WINDOW="9000", BMBS_Z_TAIL="64")
     one = subprocess.run([_driver(), "--search", fa] + inp + ["-o", out, "--batch", "211"] + args, capture_output=True, text=True, env=env)
     assert one.returncode == 0, one.stderr
     par = subprocess.run([_driver(), "--search", fa] + inp + ["-o", out + ".p", "--batch", "211", "--out-parts", str(nparts)] + args,
                          capture_output=True, text=True)
     assert par.returncode == 0, par.stderr
     parts = [open(out + ".p.part%03d" % i, "rb").read() for i in range(nparts)]
-    if mode not in ("gz", "bgzf", "bgzf_tails_grow"):
+    if mode not in ("gz", "bgzf", "bgzf_tails_grow") and not mode.startswith("gz_device"):
         assert all(len(x) > 0 for x in parts[1:])         # every part got its share
     if mode == "bam":
         from common import bam_payload
@@ -1604,7 +1612,7 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
     else:
         strip = lambda b: b"".join(l for l in b.splitlines(keepends=True) if not l.startswith(b"@PG"))
         assert strip(b"".join(parts)) == strip(open(out, "rb").read())
-        if mode in ("plain", "gz", "bgzf", "bgzf_tails_grow"):
+        if mode in ("plain", "gz", "bgzf", "bgzf_tails_grow") or mode.startswith("gz_device"):
             ref = gzip.open(os.path.join(GOLD, "%s_%s.ref.sam.gz" % (kind, name)), "rb").read()
             assert strip(b"".join(parts)) == ref
     st = lambda p: "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
