@@ -808,6 +808,9 @@ k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_
     // chain on -- blocks may be longer than a span)
     const u64 from = (u64)s * span_bytes * 8, to = min(from + ((u64)1 << 23), last_bit);
     u32 found = GZ_NONE;
+#ifdef INF_PROFILE
+    unsigned long long p_steps = 0, p_cheap = 0, p_kraft = 0, p_cyc_val = 0; const unsigned long long p_t0 = clock64();
+#endif
     // 512 bit offsets per step: a lane takes the eight offsets of one byte and reads the 16 bytes they need once; the offsets that pass
     // the cheap test are judged in full by their own lanes, the lowest that stands is the start
     for (u64 base = from; base < to && found == GZ_NONE; base += 512) {
@@ -822,18 +825,35 @@ k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_
             if ((v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u && (u64)byte0 * 8 + j < to) m8 |= 1u << j;
         }
         u32 best = GZ_NONE;
+#ifdef INF_PROFILE
+        p_steps++; p_cheap += __popcll(__ballot(m8 != 0)); const unsigned long long p_t1 = clock64();
+#endif
         while (m8) {
             const u32 j = (u32)__builtin_ctz(m8);
             m8 &= m8 - 1;
             const u32 c = byte0 * 8 + j;
             const u64 l2 = j ? (lo >> j) | (hi << (64 - j)) : lo, h2 = hi >> j;
-            if (gz_plausible(l2, h2) && gz_header_ok(comp, c, (u32)(total_bytes * 8), s_tab[lane])) { best = c; break; }
+            if (!gz_plausible(l2, h2)) continue;
+#ifdef INF_PROFILE
+            p_kraft++;
+#endif
+            if (gz_header_ok(comp, c, (u32)(total_bytes * 8), s_tab[lane])) { best = c; break; }
         }
+#ifdef INF_PROFILE
+        p_cyc_val += clock64() - p_t1;
+#endif
         // the lowest offset over the lanes
         for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }
         found = best;
     }
     if (lane == 0) start_bit[s] = found;
+#ifdef INF_PROFILE
+    {
+        unsigned long long k = p_kraft;
+        for (int o = 32; o > 0; o >>= 1) k += __shfl_xor((long long)k, o, 64);
+        if (lane == 0) { atomicAdd(&g_inf_prof[0], p_steps); atomicAdd(&g_inf_prof[1], p_cheap); atomicAdd(&g_inf_prof[2], k); atomicAdd(&g_inf_prof[3], clock64() - p_t0); atomicAdd(&g_inf_prof[4], p_cyc_val); atomicAdd(&g_inf_prof[5], 1ull); }
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(64, 3)

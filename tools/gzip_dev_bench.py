@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/gzip_dev_bench.py [file.fq | MB=160] [window MB=64] -- on the GPU box: an ordinary one-member gzip stream (zlib level 1 of FASTQ
+"""tools/gzip_dev_bench.py [file.fq | MB=160] [window MB=64] [lib] -- on the GPU box: an ordinary one-member gzip stream (zlib level 1 of FASTQ
 text) through bmbs_inflate_gzip, window by window as a reader would call it; phase times from the library's trace (BMBS_TEXT_TRACE)."""
 import ctypes as C
 import os
@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["BMBS_TEXT_TRACE"] = "1"
 from bitmapperbs_amd import capi  # noqa: E402
+if len(sys.argv) > 3:                       # another build of the library (tools/inflate_prof.sh: cycle counters)
+    capi.LIB_PATH = os.path.abspath(sys.argv[3])
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
@@ -56,6 +58,13 @@ def main():
         dt = time.time() - t0
         got = b"".join(out)
         print("pass %d: %d calls, %.1f MB in %.3f s (host loop included), identical: %s" % (rep, calls, len(got) / 1e6, dt, got == text), flush=True)
+        if hasattr(L, "bmbs_debug_inflate_prof"):
+            out = (C.c_uint64 * 16)()
+            L.bmbs_debug_inflate_prof(out)
+            v = list(out)
+            if v[5]:
+                print("  starts: %d span-waves, %.0f steps each, lanes with a candidate per step %.2f, full header checks per step %.2f, cycles per wave %.0f (%.0f in the checks)" %
+                      (v[5], v[0] / v[5], v[1] / max(1, v[0]), v[2] / max(1, v[0]), v[3] / v[5], v[4] / v[5]))
 
 
 main()
