@@ -149,6 +149,7 @@ struct Lane {
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
     DevBuf bam_raw, bam_tok, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
     DevBuf z_comp, z_off, z_text, z_err, z_nl, z_comp2, z_off2, z_err2;          // bmbs_inflate_bgzf; (…2: mate 2 of bmbs_text_open_bgzf)
+    DevBuf gz_map, gz_wgrp, gz_have, gz_map2, gz_wgrp2, gz_have2;               // (window chain: span maps, group windows, bytes of each window that exist)
     DevBuf gz_start, gz_sym, gz_res, gz_wall, gz_off, gz_info, gz_crc;          // bmbs_inflate_gzip: span starts, 16-bit symbols, results, windows, text offsets, CRCs per 64 KiB
     DevBuf gz_start2, gz_sym2, gz_res2, gz_wall2, gz_off2, gz_info2, gz_crc2;   // (mate 2 of bmbs_text_open_gzip)
     struct OpenText { bool valid = false, pe = false; u64 bytes1 = 0, bytes2 = 0; int64_t n = 0; } open_text;      // between bmbs_text_open_bgzf and bmbs_text_map_open
@@ -860,7 +861,8 @@ void lane_destroy(Lane* c)
     { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list,
                      &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl, &c->z_comp2, &c->z_off2, &c->z_err2,
                      &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info, &c->gz_crc,
-                     &c->gz_start2, &c->gz_sym2, &c->gz_res2, &c->gz_wall2, &c->gz_off2, &c->gz_info2, &c->gz_crc2};
+                     &c->gz_start2, &c->gz_sym2, &c->gz_res2, &c->gz_wall2, &c->gz_off2, &c->gz_info2, &c->gz_crc2,
+                     &c->gz_map, &c->gz_wgrp, &c->gz_have, &c->gz_map2, &c->gz_wgrp2, &c->gz_have2};
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
@@ -2296,7 +2298,7 @@ static u32 host_crc_x8n(u64 n)            // x^(8 n) mod P
     while (n) { if (n & 1) p = host_crc_mult(x2n[k & 31], p); n >>= 1; k++; }
     return p;
 }
-struct GzBufs { DevBuf *comp, *start, *sym, *res, *wall, *off, *info, *crc; };
+struct GzBufs { DevBuf *comp, *start, *sym, *res, *wall, *off, *info, *crc, *map, *wgrp, *have; };
 struct GzPlan { u32 span, n_spans, cap; u64 lim; };
 static GzPlan gz_plan(u64 comp_bytes, u64 limit_bytes)
 {
@@ -2314,6 +2316,7 @@ static int gz_reserve(Lane* c, const GzBufs& B, const GzPlan& g, u64 comp_bytes)
     ENS(c, *B.comp, comp_bytes + 2048); ENS(c, *B.start, (u64)g.n_spans * 4 + 64); ENS(c, *B.sym, (u64)g.n_spans * g.cap * 2 + 64);
     ENS(c, *B.res, (u64)g.n_spans * sizeof(GzSpan) + 64); ENS(c, *B.wall, ((u64)g.n_spans + 1) * 32768); ENS(c, *B.off, ((u64)g.n_spans + 1) * 8 + 64);
     ENS(c, *B.info, 64);
+    ENS(c, *B.map, (u64)g.n_spans * 65536 + 64); ENS(c, *B.wgrp, ((u64)g.n_spans / GZ_GROUP + 2) * 32768); ENS(c, *B.have, ((u64)g.n_spans + 2) * 4 + 64);
     return BMBS_OK;
 }
 // upload, starts, spans, windows on stream st; info_host (8 u64, page-locked) is filled when st has drained
@@ -2321,13 +2324,16 @@ static int gz_launch(Lane* c, const GzBufs& B, const GzPlan& g, const void* comp
 {
     HIPCHK(c, hipMemcpyAsync(B.comp->p, comp, comp_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(B.comp->as<u8>() + comp_bytes, 0, 2048, st));
-    HIPCHK(c, hipMemsetAsync(B.wall->p, 0, 32768, st));
-    if (win_len) HIPCHK(c, hipMemcpyAsync(B.wall->as<u8>() + (32768 - win_len), win_in, win_len, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(B.wgrp->p, 0, 32768, st));
+    if (win_len) HIPCHK(c, hipMemcpyAsync(B.wgrp->as<u8>() + (32768 - win_len), win_in, win_len, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(B.wall->p, B.wgrp->p, 32768, hipMemcpyDeviceToDevice, st));                 // wall[0] = the caller's window too
     hipLaunchKernelGGL(k_gz_starts, dim3(g.n_spans), dim3(64), 0, st, B.comp->as<u8>(), comp_bytes, g.n_spans, g.span, start_bit, B.start->as<u32>());
     hipLaunchKernelGGL(k_gz_spans, dim3(g.n_spans), dim3(64), 0, st, B.comp->as<u8>(), comp_bytes, g.n_spans, g.span, (u32)(g.lim * 8), B.start->as<u32>(),
                        B.sym->as<u16>(), g.cap, B.res->as<GzSpan>());
-    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(1024), 0, st, B.sym->as<u16>(), g.cap, B.res->as<GzSpan>(), B.start->as<u32>(), g.n_spans, start_bit,
-                       win_len, B.wall->as<u8>(), B.off->as<u64>(), B.info->as<u64>());
+    hipLaunchKernelGGL(k_gz_link, dim3(1), dim3(1024), 0, st, B.res->as<GzSpan>(), B.start->as<u32>(), g.n_spans, start_bit, win_len, B.off->as<u64>(), B.have->as<u32>(), B.info->as<u64>());
+    hipLaunchKernelGGL(k_gz_chain_local, dim3((g.n_spans + GZ_GROUP - 1) / GZ_GROUP), dim3(1024), 0, st, B.sym->as<u16>(), g.cap, B.res->as<GzSpan>(), B.info->as<u64>(), B.map->as<u16>());
+    hipLaunchKernelGGL(k_gz_chain_groups, dim3(1), dim3(1024), 0, st, B.map->as<u16>(), B.info->as<u64>(), B.wgrp->as<u8>());
+    hipLaunchKernelGGL(k_gz_apply, dim3(g.n_spans), dim3(256), 0, st, B.map->as<u16>(), B.wgrp->as<u8>(), B.have->as<u32>(), B.info->as<u64>(), B.wall->as<u8>());
     HIPCHK(c, hipMemcpyAsync(info_host, B.info->p, 48, hipMemcpyDeviceToHost, st));
     return BMBS_OK;
 }
@@ -2348,8 +2354,8 @@ int lane_text_open_gzip(Lane* c, bmbs_gztext* g1, bmbs_gztext* g2, int64_t max_r
     const int nf = pe ? 2 : 1;
     bmbs_gztext* G[2] = {g1, g2};
     DevBuf* texts[2] = {&c->fq_text1, &c->fq_text2};
-    const GzBufs B[2] = {{&c->z_comp, &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info, &c->gz_crc},
-                         {&c->z_comp2, &c->gz_start2, &c->gz_sym2, &c->gz_res2, &c->gz_wall2, &c->gz_off2, &c->gz_info2, &c->gz_crc2}};
+    const GzBufs B[2] = {{&c->z_comp, &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info, &c->gz_crc, &c->gz_map, &c->gz_wgrp, &c->gz_have},
+                         {&c->z_comp2, &c->gz_start2, &c->gz_sym2, &c->gz_res2, &c->gz_wall2, &c->gz_off2, &c->gz_info2, &c->gz_crc2, &c->gz_map2, &c->gz_wgrp2, &c->gz_have2}};
     const int32_t last[2] = {last1, last2};
     static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;
     auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
@@ -2860,51 +2866,31 @@ static int lane_inflate_gzip(Lane* c, const void* comp, uint64_t comp_bytes, uin
     static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;
     auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     const double t0 = wall();
-    u32 span = 16384;                                                               // about one block of zlib's at its fast levels
-    if (const char* sv = getenv("BMBS_GZ_DEV_SPAN")) { const long v = atol(sv); if (v >= 256) span = (u32)v; }          // tests: many spans in a small file
-    const u64 lim = std::min<u64>(limit_bytes, comp_bytes);
-    const u32 n_spans = (u32)std::min<u64>(GZ_MAX_SPANS, std::max<u64>(1, (lim + span - 1) / span));      // (a window of more spans ends early: the caller comes back)
-    const u32 cap = std::max<u32>(span * 12, 1u << 19);                             // symbols a span may produce (it ends at the first boundary behind the next cut: a whole block at least)
-    ENS(c, c->z_comp, comp_bytes + 2048); ENS(c, c->gz_start, (u64)n_spans * 4 + 64); ENS(c, c->gz_sym, (u64)n_spans * cap * 2 + 64);
-    ENS(c, c->gz_res, (u64)n_spans * sizeof(GzSpan) + 64); ENS(c, c->gz_wall, ((u64)n_spans + 1) * 32768); ENS(c, c->gz_off, ((u64)n_spans + 1) * 8 + 64);
-    ENS(c, c->gz_info, 64);
-    hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
+    const GzPlan g = gz_plan(comp_bytes, limit_bytes);
+    const GzBufs B = {&c->z_comp, &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info, &c->gz_crc, &c->gz_map, &c->gz_wgrp, &c->gz_have};
+    { const int rc = gz_reserve(c, B, g, comp_bytes); if (rc) return rc; }
     hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->z_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, us));
-    HIPCHK(c, hipMemsetAsync(c->z_comp.as<u8>() + comp_bytes, 0, 2048, us));
-    HIPCHK(c, hipMemsetAsync(c->gz_wall.p, 0, 32768, us));
-    if (win_len) HIPCHK(c, hipMemcpyAsync(c->gz_wall.as<u8>() + (32768 - win_len), win_in, win_len, hipMemcpyHostToDevice, us));
-    HIPCHK(c, hipStreamSynchronize(us));
-    const double t1 = wall();
-    hipLaunchKernelGGL(k_gz_starts, dim3(n_spans), dim3(64), 0, c->stream, c->z_comp.as<u8>(), comp_bytes, n_spans, span, start_bit, c->gz_start.as<u32>());
-    double t1a = 0, t1b = 0;
-    if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); t1a = wall(); }
-    hipLaunchKernelGGL(k_gz_spans, dim3(n_spans), dim3(64), 0, c->stream, c->z_comp.as<u8>(), comp_bytes, n_spans, span, (u32)(std::min<u64>(lim, (u64)n_spans * span) * 8), c->gz_start.as<u32>(),
-                       c->gz_sym.as<u16>(), cap, c->gz_res.as<GzSpan>());
-    if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); t1b = wall(); }
-    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(1024), 0, c->stream, c->gz_sym.as<u16>(), cap, c->gz_res.as<GzSpan>(), c->gz_start.as<u32>(), n_spans, start_bit,
-                       win_len, c->gz_wall.as<u8>(), c->gz_off.as<u64>(), c->gz_info.as<u64>());
-    u64 info[5];
-    HIPCHK(c, hipMemcpyAsync(info, c->gz_info.p, sizeof info, hipMemcpyDeviceToHost, c->stream));
+    u64* info = reinterpret_cast<u64*>(c->h_tot);
+    { const int rc = gz_launch(c, B, g, comp, comp_bytes, start_bit, win_in, win_len, c->stream, info); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const double t2 = wall();
     const u32 good = (u32)info[0];
     if (info[4]) { c->err = "corrupt deflate data in the .gz input (a match reaches in front of the stream)"; return BMBS_EINVAL; }
     if (!good) { *end_bit = start_bit; *final_block = 0; *win_out_len = 0; return BMBS_OK; }
-    u64 total = 0;
-    HIPCHK(c, hipMemcpy(&total, c->gz_off.as<u64>() + good, 8, hipMemcpyDeviceToHost));
+    const u64 total = info[5];
     *text_bytes = total; *end_bit = info[2]; *final_block = (int32_t)info[1]; *win_out_len = (u32)info[3];
     if (total > text_cap) { c->err = "inflate: the text buffer is too small"; return BMBS_ENOMEM; }
     ENS(c, c->z_text, total + 64);
-    if (total) hipLaunchKernelGGL(k_gz_resolve, dim3(32, good), dim3(256), 0, c->stream, c->gz_sym.as<u16>(), cap, c->gz_res.as<GzSpan>(), c->gz_off.as<u64>(), c->gz_info.as<u64>(),
+    if (total) hipLaunchKernelGGL(k_gz_resolve, dim3(32, good), dim3(256), 0, c->stream, c->gz_sym.as<u16>(), g.cap, c->gz_res.as<GzSpan>(), c->gz_off.as<u64>(), c->gz_info.as<u64>(),
                                   c->gz_wall.as<u8>(), c->z_text.as<char>());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const double t3 = wall();
-    HIPCHK(c, hipMemcpyAsync(win_out, c->gz_wall.as<u8>() + (size_t)good * 32768 + (32768 - info[3]), info[3], hipMemcpyDeviceToHost, ds));
+    const u32 wl = (u32)info[3];
+    if (wl) HIPCHK(c, hipMemcpyAsync(win_out, c->gz_wall.as<u8>() + (size_t)good * 32768 + (32768 - wl), wl, hipMemcpyDeviceToHost, ds));
     if (total) { const int rc = d2h_chunked(c, text, c->z_text.as<char>(), total, ds); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(ds));
-    if (trace) fprintf(stderr, "[inflate gzip] %u spans of %u bytes, %u reached, %.1f MB -> %.1f MB: alloc+upload %.2f  starts %.2f  spans %.2f  windows %.2f  resolve %.2f  download %.2f ms\n", n_spans, span, good,
-                       (double)comp_bytes / 1e6, (double)total / 1e6, (t1 - t0) * 1e3, (t1a - t1) * 1e3, (t1b - t1a) * 1e3, (t2 - t1b) * 1e3, (t3 - t2) * 1e3, (wall() - t3) * 1e3);
+    if (trace) fprintf(stderr, "[inflate gzip] %u spans of %u bytes, %u reached, %.1f MB -> %.1f MB: upload + starts + spans + window chain %.2f  resolve %.2f  download %.2f ms\n", g.n_spans, g.span, good,
+                       (double)comp_bytes / 1e6, (double)total / 1e6, (t2 - t0) * 1e3, (t3 - t2) * 1e3, (wall() - t3) * 1e3);
     return BMBS_OK;
 }
 
@@ -2922,6 +2908,8 @@ extern "C" int bmbs_debug_inflate_prof(uint64_t* out16)
 {
     unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_inf_prof), sizeof z) != hipSuccess) return BMBS_ENODEV;
+    if (hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(g_gz_prof), 64) != hipSuccess) return BMBS_ENODEV;       // (the caller's array has 24 words)
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gz_prof), z, 64);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_inf_prof), z, sizeof z) == hipSuccess ? BMBS_OK : BMBS_ENODEV;
 }
 #endif

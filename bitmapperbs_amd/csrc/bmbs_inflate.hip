@@ -20,6 +20,7 @@
 // -DINF_PROFILE (tools/inflate_prof.sh builds a second library with it): cycles per phase of k_bgzf_inflate, summed over the blocks
 #ifdef INF_PROFILE
 __device__ unsigned long long g_inf_prof[16];
+__device__ unsigned long long g_gz_prof[8];         // k_gz_starts: steps, lanes with a candidate, full header checks, cycles, cycles in the checks, waves
 #define INF_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); prof[k] += t_ - t_last; t_last = t_; } while (0)
 #define INF_N(k, v) prof[k] += (v)
 #else
@@ -711,16 +712,18 @@ k_nl_count64k(const char* __restrict__ text, u64 total, u64 shift, u32* __restri
 #define GZ_NONE 0xffffffffu
 struct GzSpan { u32 status, n_sym, end_bit, final; };
 
-// the cheap test on the 128 bits w (LSB first) that begin at the candidate's bit: block type, HLIT / HDIST, complete code-length code
-DEVI bool gz_plausible(u64 lo, u64 hi)
+// the second cheap test on the 128 bits (LSB first) that begin at the candidate's bit, whose block type and HLIT / HDIST passed: the
+// code-length code complete.  kraft9[x] = sum of 2^(7 - l) over the three 3-bit lengths in x (l = 0: no code): seven look-ups for the
+// 19 lengths instead of a loop over them
+DEVI bool gz_plausible(u64 lo, u64 hi, const u8* kraft9)
 {
-    if ((lo & 7u) != 4u) return false;                                          // BFINAL 0, BTYPE 2
-    if (((lo >> 3) & 31u) > 29u || ((lo >> 8) & 31u) > 29u) return false;
-    const int hclen = (int)((lo >> 13) & 15u) + 4;
+    const u32 hclen = (u32)((lo >> 13) & 15u) + 4;
     u64 w = (lo >> 17) | (hi << 47);                                            // the 3-bit lengths of the code-length code: 57 bits = 19 lengths
-    int left = 1 << 7;                                                          // Kraft sum in units of 2^-7
-    for (int i = 0; i < hclen; i++) { const int l = (int)(w & 7u); w >>= 3; if (l) left -= 128 >> l; }
-    return left == 0;
+    w &= (1ull << (3 * hclen)) - 1;
+    u32 sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < 7; k++) sum += kraft9[(u32)(w >> (9 * k)) & 511u];
+    return sum == 128u;
 }
 
 // the whole dynamic-Huffman header at `bit`, judged by ONE lane (64 candidates side by side): HLIT / HDIST, the code-length code as a
@@ -799,10 +802,17 @@ __global__ void __launch_bounds__(64)
 k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_bytes, u32 first_bit, u32* __restrict__ start_bit)
 {
     __shared__ u8 s_tab[64][128];
+    __shared__ u8 s_kraft9[512];
     const u32 s = blockIdx.x;
     if (s >= n_spans) return;
     const int lane = threadIdx.x;
     if (s == 0) { if (lane == 0) start_bit[0] = first_bit; return; }
+    for (u32 x = lane; x < 512; x += 64) {
+        u32 k = 0;
+        for (u32 f = 0; f < 3; f++) { const u32 l = (x >> (3 * f)) & 7u; if (l) k += 128u >> l; }
+        s_kraft9[x] = (u8)k;                                                   // (three lengths of 1 make 192: fits)
+    }
+    __syncthreads();
     const u64 last_bit = total_bytes > 64 ? (total_bytes - 64) * 8 : 0;        // a header needs room behind it
     // (the search goes on behind the span's own bytes: a span whose first block start lies in a later span decodes nothing and hands the
     // chain on -- blocks may be longer than a span)
@@ -833,7 +843,7 @@ k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_
             m8 &= m8 - 1;
             const u32 c = byte0 * 8 + j;
             const u64 l2 = j ? (lo >> j) | (hi << (64 - j)) : lo, h2 = hi >> j;
-            if (!gz_plausible(l2, h2)) continue;
+            if (!gz_plausible(l2, h2, s_kraft9)) continue;
 #ifdef INF_PROFILE
             p_kraft++;
 #endif
@@ -851,7 +861,7 @@ k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_
     {
         unsigned long long k = p_kraft;
         for (int o = 32; o > 0; o >>= 1) k += __shfl_xor((long long)k, o, 64);
-        if (lane == 0) { atomicAdd(&g_inf_prof[0], p_steps); atomicAdd(&g_inf_prof[1], p_cheap); atomicAdd(&g_inf_prof[2], k); atomicAdd(&g_inf_prof[3], clock64() - p_t0); atomicAdd(&g_inf_prof[4], p_cyc_val); atomicAdd(&g_inf_prof[5], 1ull); }
+        if (lane == 0) { atomicAdd(&g_gz_prof[0], p_steps); atomicAdd(&g_gz_prof[1], p_cheap); atomicAdd(&g_gz_prof[2], k); atomicAdd(&g_gz_prof[3], clock64() - p_t0); atomicAdd(&g_gz_prof[4], p_cyc_val); atomicAdd(&g_gz_prof[5], 1ull); }
     }
 #endif
 }
@@ -876,10 +886,14 @@ k_gz_spans(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_b
 }
 
 // windows: wall[0] = the 32 KiB in front of the window's first span (right-aligned: wall[0][32767] = the byte just before it; the first
-// 32768 - win_len bytes do not exist), wall[s + 1] = the 32 KiB behind span s.  off[s] = where span s's text begins.  info[0] = spans the
-// chain reached, info[1] = the stream's final block was among them, info[2] = bit position reached, info[3] = bytes of the last window
-// that exist, info[4] = a marker pointed in front of the stream (corrupt input), info[5] = bytes of text of the spans reached
+// 32768 - win_len bytes do not exist), wall[s + 1] = the 32 KiB behind span s.  off[s] = where span s's text begins.  Pushing the window
+// through 1 700 spans one after the other is 8 ms on one CU; it is a scan (a span's effect on the window is a map "byte, or position of
+// the window before", maps compose): groups of 32 spans chained side by side with their input open, the groups' maps chained by one
+// workgroup, every span's map applied to its group's window.
 #define GZ_MAX_SPANS 8192
+#define GZ_GROUP 32                          // spans whose windows one workgroup chains (the chain over a window's spans is a scan in three phases)
+// 32 consecutive positions of span's tail map: position i of the 32 KiB behind the span = symbol n - 32768 + i of the span, or -- in front
+// of the span's first symbol -- a reference to the window before it, shifted (the same marker a symbol would be)
 DEVI void gz_load32(const u16* sy, long q0, u32 (&x)[16])
 {
     if (q0 >= 0) {
@@ -895,20 +909,21 @@ DEVI void gz_load32(const u16* sy, long q0, u32 (&x)[16])
         }
     }
 }
+
+// (1) which spans count, where their text goes.  info[0] = spans the chain reached, [1] = the stream's final block was among them,
+// [2] = bit position reached, [3] = bytes of the last window that exist, [4] = a marker pointed in front of the stream (set later),
+// [5] = bytes of text; have[s] = bytes of the window BEFORE span s that exist
 __global__ void __launch_bounds__(1024)
-k_gz_windows(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ res, const u32* __restrict__ start_bit, u32 n_spans, u32 first_bit,
-             u32 win_len, u8* __restrict__ wall, u64* __restrict__ off, u64* __restrict__ info)
+k_gz_link(const GzSpan* __restrict__ res, const u32* __restrict__ start_bit, u32 n_spans, u32 first_bit, u32 win_len, u64* __restrict__ off,
+          u32* __restrict__ have, u64* __restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) u8 w0[32768];
-    __shared__ __attribute__((aligned(16))) u8 w1[32768];
     __shared__ u32 s_n[GZ_MAX_SPANS];
-    __shared__ u32 s_bad, s_good, s_fin;
+    __shared__ u32 s_good, s_fin;
     const u32 t = threadIdx.x;
-    for (u32 i = t; i < 32768; i += 1024) w0[i] = wall[i];
-    if (t == 0) { s_bad = 0; s_good = n_spans; s_fin = 0xffffffffu; }
+    if (t == 0) { s_good = n_spans; s_fin = 0xffffffffu; }
     __syncthreads();
-    // how far the chain goes: span s counts when it decoded and starts where span s - 1 stopped -- every link is judged on its own, the
-    // first broken one ends the chain; it also ends behind the stream's final block
+    // span s counts when it decoded and starts where span s - 1 stopped -- every link is judged on its own, the first broken one ends
+    // the chain; it also ends behind the stream's final block
     for (u32 s = t; s < n_spans; s += 1024) {
         const GzSpan r = res[s];
         const u32 prev_end = s ? res[s - 1].end_bit : first_bit;
@@ -917,47 +932,123 @@ k_gz_windows(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ re
         if (r.status == 0 && r.final) atomicMin(&s_fin, s);
     }
     __syncthreads();
-    u32 good = s_good, fin = 0;
-    if (s_fin < good) { good = s_fin + 1; fin = 1; }
-    u8* wp = w0; u8* wn = w1;
-    u32 have = win_len;
-    u64 at = 0;
+    if (t == 0) {
+        u32 good = s_good, fin = 0;
+        if (s_fin < good) { good = s_fin + 1; fin = 1; }
+        u64 at = 0; u32 h = win_len;
+        for (u32 s = 0; s < good; s++) { off[s] = at; have[s] = h; at += s_n[s]; h = min(32768u, h + s_n[s]); }
+        off[good] = at; have[good] = h;
+        info[0] = good; info[1] = fin; info[2] = good ? res[good - 1].end_bit : first_bit; info[3] = h; info[4] = 0; info[5] = at;
+    }
+}
+
+// (2) a workgroup chains the spans of its group with the window in front of the group left open: map[s][i] = what position i of the
+// window behind span s is -- a byte, or 0x8000 | a position of the window in front of the GROUP
+__global__ void __launch_bounds__(1024)
+k_gz_chain_local(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ res, const u64* __restrict__ info, u16* __restrict__ map)
+{
+    __shared__ __attribute__((aligned(16))) u16 p0[32768];
+    __shared__ __attribute__((aligned(16))) u16 p1[32768];
+    const u32 good = (u32)info[0];
+    const u32 s0 = blockIdx.x * GZ_GROUP;
+    if (s0 >= good) return;
+    const u32 s1 = min(good, s0 + GZ_GROUP);
+    const u32 t = threadIdx.x;
+    for (u32 i = t; i < 32768; i += 1024) p0[i] = (u16)(0x8000u | i);
+    __syncthreads();
+    u16* pp = p0; u16* pn = p1;
     u32 x[16], xn[16];
-    if (good) gz_load32(sym, (long)s_n[0] - 32768 + (long)t * 32, x);
-    for (u32 s = 0; s < good; s++) {
-        if (t == 0) off[s] = at;
-        const u32 n = s_n[s];
-        const u32 lowest = 32768 - have;                                        // window positions below this do not exist
-        // a thread takes 32 consecutive positions of the new window: position i = symbol n - 32768 + i of the span, or -- in front of
-        // the span's first symbol -- the old window shifted.  (The next span's symbols are on their way while this one is resolved.)
-        const long q0 = (long)n - 32768 + (long)t * 32;
-        if (s + 1 < good) gz_load32(sym + (size_t)(s + 1) * cap, (long)s_n[s + 1] - 32768 + (long)t * 32, xn);
-        u32 o[8];
-        u32 bad = 0;
+    gz_load32(sym + (size_t)s0 * cap, (long)res[s0].n_sym - 32768 + (long)t * 32, x);
+    for (u32 s = s0; s < s1; s++) {
+        if (s + 1 < s1) gz_load32(sym + (size_t)(s + 1) * cap, (long)res[s + 1].n_sym - 32768 + (long)t * 32, xn);
+        u32 o[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const u32 a = x[k] & 0xffffu, b2 = x[k] >> 16;
-            // (no branches: the window is read for every symbol, a byte keeps itself.  A marker of the span itself must point at text
-            // that exists; the shifted part of the old window carries its gaps along)
-            const u32 wa = a & 0x7fffu, wb = b2 & 0x7fffu;
-            const u32 la = wp[wa], lb = wp[wb];
-            bad |= (a >= 0x8000u && q0 + 2 * k >= 0 && wa < lowest) || (b2 >= 0x8000u && q0 + 2 * k + 1 >= 0 && wb < lowest);
-            const u32 va = a >= 0x8000u ? la : a, vb = b2 >= 0x8000u ? lb : b2;
-            const u32 two = (va & 0xffu) | (vb & 0xffu) << 8;
+            const u32 la = pp[a & 0x7fffu], lb = pp[b2 & 0x7fffu];               // (no branches: looked up whatever the symbol is)
+            o[k] = (a >= 0x8000u ? la : a) | (b2 >= 0x8000u ? lb : b2) << 16;
+        }
+        uint4* dn = reinterpret_cast<uint4*>(pn + t * 32);
+        uint4* dg = reinterpret_cast<uint4*>(map + (size_t)s * 32768 + t * 32);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint4 v = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]); dn[k] = v; dg[k] = v; }
+        __syncthreads();
+        u16* xw = pp; pp = pn; pn = xw;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = xn[k];
+    }
+}
+
+// (3) one workgroup walks the GROUPS: wgrp[g] = the window in front of group g (wgrp[0] = the caller's, right-aligned)
+__global__ void __launch_bounds__(1024)
+k_gz_chain_groups(const u16* __restrict__ map, const u64* __restrict__ info, u8* __restrict__ wgrp)
+{
+    __shared__ __attribute__((aligned(16))) u8 w0[32768];
+    __shared__ __attribute__((aligned(16))) u8 w1[32768];
+    const u32 good = (u32)info[0];
+    const u32 groups = (good + GZ_GROUP - 1) / GZ_GROUP;
+    const u32 t = threadIdx.x;
+    for (u32 i = t; i < 32768; i += 1024) w0[i] = wgrp[i];
+    __syncthreads();
+    u8* wp = w0; u8* wn = w1;
+    for (u32 g = 0; g + 1 < groups; g++) {
+        const u32 last = (g + 1) * GZ_GROUP - 1;                                // the group's last span: its map is the group's
+        const uint4* m4 = reinterpret_cast<const uint4*>(map + (size_t)last * 32768 + t * 32);
+        u32 x[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint4 v = m4[k]; x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w; }
+        u32 o[8];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 a = x[k] & 0xffffu, b2 = x[k] >> 16;
+            const u32 la = wp[a & 0x7fffu], lb = wp[b2 & 0x7fffu];
+            const u32 two = ((a >= 0x8000u ? la : a) & 0xffu) | ((b2 >= 0x8000u ? lb : b2) & 0xffu) << 8;
             if (k & 1) o[k >> 1] |= two << 16; else o[k >> 1] = two;
         }
-        if (bad) s_bad = 1;
         uint4* dn = reinterpret_cast<uint4*>(wn + t * 32);
-        uint4* dg = reinterpret_cast<uint4*>(wall + (size_t)(s + 1) * 32768 + t * 32);
+        uint4* dg = reinterpret_cast<uint4*>(wgrp + (size_t)(g + 1) * 32768 + t * 32);
         const uint4 v0 = make_uint4(o[0], o[1], o[2], o[3]), v1 = make_uint4(o[4], o[5], o[6], o[7]);
         dn[0] = v0; dn[1] = v1; dg[0] = v0; dg[1] = v1;
         __syncthreads();
         u8* xw = wp; wp = wn; wn = xw;
-#pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = xn[k];
-        at += n; have = min(32768u, have + n);
     }
-    if (t == 0) { off[good] = at; info[0] = good; info[1] = fin; info[2] = good ? res[good - 1].end_bit : first_bit; info[3] = have; info[4] = s_bad; info[5] = at; }
+}
+
+// (4) every span's window: its map applied to the window in front of its group.  wall[0] = the caller's window, wall[s + 1] = the
+// window behind span s.  A position that exists and refers to one that does not (in front of the stream) marks the input corrupt
+__global__ void __launch_bounds__(256)
+k_gz_apply(const u16* __restrict__ map, const u8* __restrict__ wgrp, const u32* __restrict__ have, u64* __restrict__ info, u8* __restrict__ wall)
+{
+    __shared__ __attribute__((aligned(16))) u8 w[32768];
+    const u32 s = blockIdx.x;
+    if (s >= (u32)info[0]) return;
+    const u32 g = s / GZ_GROUP;
+    const u32 t = threadIdx.x;
+    const uint4* src = reinterpret_cast<const uint4*>(wgrp + (size_t)g * 32768);
+    for (u32 i = t; i < 2048; i += 256) reinterpret_cast<uint4*>(w)[i] = src[i];
+    __syncthreads();
+    const u32 low_base = 32768 - have[g * GZ_GROUP], low_here = 32768 - have[s + 1];
+    u32 bad = 0;
+    for (u32 c = t; c < 1024; c += 256) {                                        // chunks of 32 positions
+        const uint4* m4 = reinterpret_cast<const uint4*>(map + (size_t)s * 32768 + c * 32);
+        u32 x[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint4 v = m4[k]; x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w; }
+        u32 o[8];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 a = x[k] & 0xffffu, b2 = x[k] >> 16;
+            const u32 wa = a & 0x7fffu, wb = b2 & 0x7fffu;
+            const u32 la = w[wa], lb = w[wb];
+            const u32 i0 = c * 32 + 2 * k;
+            bad |= (a >= 0x8000u && i0 >= low_here && wa < low_base) || (b2 >= 0x8000u && i0 + 1 >= low_here && wb < low_base);
+            const u32 two = ((a >= 0x8000u ? la : a) & 0xffu) | ((b2 >= 0x8000u ? lb : b2) & 0xffu) << 8;
+            if (k & 1) o[k >> 1] |= two << 16; else o[k >> 1] = two;
+        }
+        uint4* dg = reinterpret_cast<uint4*>(wall + (size_t)(s + 1) * 32768 + c * 32);
+        dg[0] = make_uint4(o[0], o[1], o[2], o[3]); dg[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    if (bad) info[4] = 1;
 }
 
 __global__ void __launch_bounds__(256)

@@ -59,9 +59,9 @@ def main():
         got = b"".join(out)
         print("pass %d: %d calls, %.1f MB in %.3f s (host loop included), identical: %s" % (rep, calls, len(got) / 1e6, dt, got == text), flush=True)
         if hasattr(L, "bmbs_debug_inflate_prof"):
-            out = (C.c_uint64 * 16)()
+            out = (C.c_uint64 * 24)()
             L.bmbs_debug_inflate_prof(out)
-            v = list(out)
+            v = list(out)[16:]
             if v[5]:
                 print("  starts: %d span-waves, %.0f steps each, lanes with a candidate per step %.2f, full header checks per step %.2f, cycles per wave %.0f (%.0f in the checks)" %
                       (v[5], v[0] / v[5], v[1] / max(1, v[0]), v[2] / max(1, v[0]), v[3] / v[5], v[4] / v[5]))

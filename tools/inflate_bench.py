@@ -71,7 +71,7 @@ def main():
         inflate()
     assert got.tobytes() == text
     if len(sys.argv) > 2 and hasattr(L, "bmbs_debug_inflate_prof"):
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 24)()
         L.bmbs_debug_inflate_prof(out)          # (the four calls above)
         inflate()
         L.bmbs_debug_inflate_prof(out)
