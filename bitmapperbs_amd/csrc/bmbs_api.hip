@@ -177,6 +177,7 @@ struct Lane {
     // first call of a lane waits for its counts); the pinned words the device leaves its counts and guard flags in; the call in flight
     double lr_cand = 0, lr_sw = 0, lr_rcand = 0, lr_long = 0;
     u64* h_tot = nullptr;                      // page-locked: per call in flight, totals[16] followed by the flag words (call_end)
+    u8* h_gz = nullptr;                        // page-locked, 192 KiB: what bmbs_text_open_gzip brings back (two windows, CRCs per 64 KiB)
     std::deque<Pending> inflight;
     int next_slot = 0;
     u64 n_retries = 0;
@@ -857,6 +858,7 @@ void lane_destroy(Lane* c)
     for (auto& set : c->profset) for (auto& p : set) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->arena.free_all();
     if (c->h_tot) (void)hipHostFree(c->h_tot);
+    if (c->h_gz) (void)hipHostFree(c->h_gz);
     if (c->h_info) (void)hipHostFree(c->h_info);
     { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list,
                      &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl, &c->z_comp2, &c->z_off2, &c->z_err2,
@@ -2376,6 +2378,7 @@ int lane_text_open_gzip(Lane* c, bmbs_gztext* g1, bmbs_gztext* g2, int64_t max_r
     }
     HIPCHK(c, hipMemsetAsync(c->tx_info.p, 0, 64, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t_res = wall();
     // each file on a stream of its own: the two files' spans decode side by side
     hipStream_t fs[2] = {c->stream, c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream};
     u64* info_host = reinterpret_cast<u64*>(c->h_tot);                             // (page-locked words of the lane that nothing else uses during a text call)
@@ -2385,8 +2388,13 @@ int lane_text_open_gzip(Lane* c, bmbs_gztext* g1, bmbs_gztext* g2, int64_t max_r
         if (plan[f].n_spans) { const int rc = gz_launch(c, B[f], plan[f], g->comp, g->comp_bytes, g->start_bit, g->win, g->win_len, fs[f], info_host + 8 * f); if (rc) return rc; }
     }
     for (int f = 0; f < nf; f++) HIPCHK(c, hipStreamSynchronize(fs[f]));
+    const double t_dec = wall();
     u64 bytes[2] = {0, 0};
-    std::vector<u32> segcrc[2];
+    // (what comes back -- the windows behind the chains, the CRCs per 64 KiB -- lands in page-locked words of the lane: a copy into
+    // pageable memory costs milliseconds whatever its size)
+    if (!c->h_gz && hipHostMalloc((void**)&c->h_gz, 192 << 10, hipHostMallocPortable) != hipSuccess) { c->h_gz = nullptr; c->err = "cannot allocate page-locked memory"; return BMBS_ENOMEM; }
+    u32* segcrc[2] = {reinterpret_cast<u32*>(c->h_gz + (64 << 10)), reinterpret_cast<u32*>(c->h_gz + (128 << 10))};
+    u64 nseg[2] = {0, 0};
     for (int f = 0; f < nf; f++) {
         bmbs_gztext* g = G[f];
         bytes[f] = g->prefix_bytes;
@@ -2401,13 +2409,13 @@ int lane_text_open_gzip(Lane* c, bmbs_gztext* g1, bmbs_gztext* g2, int64_t max_r
         if (total) {
             hipLaunchKernelGGL(k_gz_resolve, dim3(32, good), dim3(256), 0, fs[f], B[f].sym->as<u16>(), plan[f].cap, B[f].res->as<GzSpan>(), B[f].off->as<u64>(), B[f].info->as<u64>(),
                                B[f].wall->as<u8>(), dst);
-            const u64 nseg = (total + 65535) >> 16;
-            ENS(c, *B[f].crc, nseg * 4 + 64);
-            hipLaunchKernelGGL(k_crc_segs, dim3((unsigned)nseg), dim3(64), 0, fs[f], reinterpret_cast<const u8*>(dst), total, B[f].crc->as<u32>());
-            segcrc[f].resize(nseg);
-            HIPCHK(c, hipMemcpyAsync(segcrc[f].data(), B[f].crc->p, nseg * 4, hipMemcpyDeviceToHost, fs[f]));
+            nseg[f] = (total + 65535) >> 16;
+            if (nseg[f] > (64 << 10) / 4) { c->err = "text open: a window of a gzip stream inflates to more than 1 GiB"; return BMBS_EINVAL; }
+            ENS(c, *B[f].crc, nseg[f] * 4 + 64);
+            hipLaunchKernelGGL(k_crc_segs, dim3((unsigned)nseg[f]), dim3(64), 0, fs[f], reinterpret_cast<const u8*>(dst), total, B[f].crc->as<u32>());
+            HIPCHK(c, hipMemcpyAsync(segcrc[f], B[f].crc->p, nseg[f] * 4, hipMemcpyDeviceToHost, fs[f]));
         }
-        if (info[3]) HIPCHK(c, hipMemcpyAsync(g->win_out, B[f].wall->as<u8>() + (size_t)good * 32768 + (32768 - info[3]), info[3], hipMemcpyDeviceToHost, fs[f]));
+        if (info[3]) HIPCHK(c, hipMemcpyAsync(c->h_gz + f * 32768, B[f].wall->as<u8>() + (size_t)good * 32768 + (32768 - info[3]), info[3], hipMemcpyDeviceToHost, fs[f]));
         bytes[f] += total;
         if (last[f] && g->final_block && bytes[f]) hipLaunchKernelGGL(k_close_last_line, dim3(1), dim3(1), 0, fs[f], texts[f]->as<char>(), bytes[f], c->totals.as<u64>() + 21 + f);
         else HIPCHK(c, hipMemsetAsync(c->totals.as<u64>() + 21 + f, 0, 8, fs[f]));
@@ -2419,13 +2427,15 @@ int lane_text_open_gzip(Lane* c, bmbs_gztext* g1, bmbs_gztext* g2, int64_t max_r
         // CRC-32 of the window's text: the pieces joined (crc of a concatenation = crc1 * x^(8 len2) + crc2)
         u32 crc = 0; const u64 total = G[f]->text_bytes;
         const u32 x64k = host_crc_x8n(65536);
-        for (size_t i = 0; i < segcrc[f].size(); i++) {
+        if (G[f]->win_out_len) memcpy(G[f]->win_out, c->h_gz + f * 32768, G[f]->win_out_len);
+        for (size_t i = 0; i < nseg[f]; i++) {
             const u64 len = std::min<u64>(65536, total - ((u64)i << 16));
             crc = host_crc_mult(len == 65536 ? x64k : host_crc_x8n(len), crc) ^ segcrc[f][i];
         }
         G[f]->crc32 = crc;
     }
     tp[1] = wall();
+    if (trace) fprintf(stderr, "[text open gzip] buffers %.2f  upload + starts + spans + chain %.2f  resolve + crc + windows back %.2f ms\n", (t_res - tp[0]) * 1e3, (t_dec - t_res) * 1e3, (tp[1] - t_dec) * 1e3);
     const u64* added = reinterpret_cast<const u64*>(c->h_info + 28);
     bytes[0] += added[0]; if (pe) bytes[1] += added[1];
     return lane_text_open_finish(c, pe, texts, bytes, max_records, n_records, tail1, tail_cap, tail1_bytes, tail2, tail2_bytes, tp, trace ? "gzip" : nullptr,

@@ -402,7 +402,8 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                 const u32 extB = matB && srcB < (int)n_out ? min(B.mlen, (u32)((int)n_out - srcB)) : 0u;
                 const bool shortA = matA && A.mlen <= 16, shortB = matB && B.mlen <= 16;   // by their own lanes; longer ones by the wave
                 if (__ballot((extA && srcA + (int)extA > (int)fenced) || (extB && srcB + (int)extB > (int)fenced))) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
-                // (unaligned 8-byte loads: the bytes behind a match's source come along and are dropped -- the text buffer has the slack)
+                // (unaligned 16-byte loads -- a vector memory instruction costs the CU's address unit a cycle per lane whatever its width --:
+                // the bytes behind a match's source come along and are dropped, the buffers have the slack)
                 u64 ra[MODE == 1 ? 4 : 2], rb[MODE == 1 ? 4 : 2];
                 constexpr u32 PER = 8 / sizeof(S);                                          // symbols per 8-byte load
 #pragma unroll
@@ -410,12 +411,12 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                 if (extA && shortA && srcA >= 0) {
                     const S* sp = out + srcA;
 #pragma unroll
-                    for (u32 k = 0; k < 16 / PER; k++) if (extA > k * PER) __builtin_memcpy(&ra[k], sp + k * PER, 8);
+                    for (u32 k = 0; k < 16 / PER; k += 2) if (extA > k * PER) __builtin_memcpy(&ra[k], sp + k * PER, 16);
                 }
                 if (extB && shortB && srcB >= 0) {
                     const S* sp = out + srcB;
 #pragma unroll
-                    for (u32 k = 0; k < 16 / PER; k++) if (extB > k * PER) __builtin_memcpy(&rb[k], sp + k * PER, 8);
+                    for (u32 k = 0; k < 16 / PER; k += 2) if (extB > k * PER) __builtin_memcpy(&rb[k], sp + k * PER, 16);
                 }
                 // (one wave, and a wave's LDS operations complete in the order they were issued: no s_barrier between the steps below)
                 s_ref32[lane] = (u32)lane * 0x04040404u + 0x03020100u;                      // every byte its own source
@@ -705,10 +706,11 @@ k_nl_count64k(const char* __restrict__ text, u64 total, u64 shift, u32* __restri
 // The stream is cut every `span` bytes.  (1) k_gz_starts: the wave of a cut looks for the first bit offset behind it at which a
 // dynamic-Huffman block header parses -- a lane per offset for the cheap test (block type, HLIT / HDIST, complete code-length code, as
 // pgz::header_plausible), the whole header (inf_wave<2>) for the survivors.  (2) k_gz_spans: a wave per span decodes from its start to
-// the first block boundary at or behind the next cut, into 16-bit symbols (inf_wave<1>).  (3) k_gz_windows: one workgroup walks the spans
-// in order -- a span counts when it starts where its predecessor stopped -- and pushes the 32 KiB window through each.  (4) k_gz_resolve:
-// symbols -> bytes at the span's place in the text.  What the chain does not reach (a start that was not one, a block longer than a span,
-// a stream of stored blocks) is left to the caller: the next call begins at the boundary the chain did reach.
+// the first block boundary at or behind the next cut, into 16-bit symbols (inf_wave<1>).  (3) k_gz_link / k_gz_chain_local /
+// k_gz_chain_groups / k_gz_apply: which spans count -- a span counts when it starts where its predecessor stopped -- and the 32 KiB
+// window behind every one of them (a scan over the spans' maps).  (4) k_gz_resolve: symbols -> bytes at the span's place in the text.
+// What the chain does not reach (a start that was not one, a block longer than a span's slot, a stream of stored blocks) is left to the
+// caller: the next call begins at the boundary the chain did reach.
 #define GZ_NONE 0xffffffffu
 struct GzSpan { u32 status, n_sym, end_bit, final; };
 
@@ -866,7 +868,7 @@ k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_
 #endif
 }
 
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, 4)
 k_gz_spans(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_bytes, u32 limit_bit, const u32* __restrict__ start_bit,
            u16* __restrict__ sym, u32 cap, GzSpan* __restrict__ res)
 {

@@ -61,6 +61,11 @@ def main():
         if hasattr(L, "bmbs_debug_inflate_prof"):
             out = (C.c_uint64 * 24)()
             L.bmbs_debug_inflate_prof(out)
+            w = list(out)[:16]
+            names = ["header+tables", "window words", "lookups", "chain walk", "fence+refs+jumps", "text+gather+store", "-", "stop tokens"]
+            if w[15]:
+                print("  span decode: " + "  ".join("%s %.1f%%" % (names[k], 100.0 * w[k] / w[15]) for k in (0, 1, 2, 3, 4, 5, 7)) +
+                      "  | windows %d  tokens %d  cycles/window %.0f" % (w[9], w[10], w[15] / max(1, w[9])))
             v = list(out)[16:]
             if v[5]:
                 print("  starts: %d span-waves, %.0f steps each, lanes with a candidate per step %.2f, full header checks per step %.2f, cycles per wave %.0f (%.0f in the checks)" %
