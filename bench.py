@@ -594,6 +594,11 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
     # those -- and the input launches -- beyond three are given back first: index 170 GB + trigram table 28 GB + inputs 32 GB leave no room for both)
     del job.res_all[3:], job.cig_all[3:], job.batches[3:]
     torch.cuda.empty_cache()
+    free_b, _total_b = torch.cuda.mem_get_info()
+    need_b = 40e9 * (n_ctx - 1)                      # work buffers of a further context for a 10 M-pair call (two lanes)
+    if free_b < need_b:
+        return {"skipped": "%.0f GB of HBM free, a further context's work buffers for calls of this size need 30-40 GB each (index + outcome table + "
+                           "trigram table hold ~200 GB at this genome size); bmbs_search runs its contexts on 0.5 M-pair batches" % (free_b / 1e9)}
     while len(job.res_all) < n_ctx:
         job.res_all.append(torch.empty_like(job.res_d)); job.cig_all.append(torch.empty_like(job.cig_d))
     ctxs = [(m, job.res_d, job.cig_d)] + [(x, job.res_all[1 + i], job.cig_all[1 + i]) for i, x in enumerate(extra)]
