@@ -778,16 +778,20 @@ def gz_input_rate(args, drv, fa, cfg, files, inp, rec_bytes, big=None, inp_big=N
         a = [gzf[srcs.index(x)] if x in srcs else x for x in (inp_big if srcs is big else inp)]
         # bgzip-style blocks are inflated on the device; one-member gzip by the host's block-parallel inflater on the driver's default
         # thread count for compressed input
-        p = subprocess.run([drv, "--search", fa] + a + ["-e", str(cfg["e"]), "-o", "/dev/null", "--verbose"] + (["-t", "32"] if label == "bgzf" else []),
-                           capture_output=True, text=True)
+        runs = [(label, None)]
+        if label == "plain_gzip":               # the same files through the device's span decoder (exact, not the default: DESIGN.md section 7)
+            runs.append(("plain_gzip_device", dict(os.environ, BMBS_GZ_DEVICE="2")))
+        for key, env in runs:
+            p = subprocess.run([drv, "--search", fa] + a + ["-e", str(cfg["e"]), "-o", "/dev/null", "--verbose"] + (["-t", "32"] if key != "plain_gzip" else []),
+                               capture_output=True, text=True, env=env)
+            if p.returncode:
+                out[key] = {"error": p.stderr[-300:]}
+                continue
+            line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
+            wall = float(line.split("mapping wall")[1].split("s")[0])
+            out[key] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n)}
         for f in gzf:
             os.unlink(f)
-        if p.returncode:
-            out[label] = {"error": p.stderr[-300:]}
-            continue
-        line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
-        wall = float(line.split("mapping wall")[1].split("s")[0])
-        out[label] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n)}
     return out
 
 
@@ -854,7 +858,7 @@ def file_to_file_rate(args, cfg, fa, L):
                    "(as the reference's own 'mapping time'); newline index and SAM text on the device, the host only reads and writes; "
                    "`file` = one output file, `file_%d_parts` = --out-parts %d (as many inodes written at once), `null_sink` = -o /dev/null, "
                    "`bam` / `bam_null_sink` = --bam (BAM records and BGZF blocks made on the device); gz_input: `bgzf` inflated on the device, "
-                   "`plain_gzip` (one deflate stream per file) by the host's block-parallel inflater" % (REP, parts, parts))
+                   "`plain_gzip` (one deflate stream per file) by the host's block-parallel inflater, `plain_gzip_device` by the device's span decoder (BMBS_GZ_DEVICE=2)" % (REP, parts, parts))
     return out
 
 
