@@ -2924,6 +2924,23 @@ extern "C" int bmbs_debug_inflate_prof(uint64_t* out16)
 }
 #endif
 
+// diagnostic: the Huffman code lengths the device's BGZF deflater gives a table of symbol frequencies (n <= 320, maxbits <= 15)
+extern "C" int bmbs_debug_huff_lengths(bmbs_ctx* X, const uint32_t* freq, int32_t n, int32_t maxbits, uint8_t* len_out)
+{
+    Lane* c = lane0(X);
+    if (!c) return BMBS_EINVAL;
+    if (!freq || !len_out || n < 2 || n > 320 || maxbits < 2 || maxbits > 15) { c->err = "huff lengths: bad argument"; return fin(X, c, BMBS_EINVAL); }
+    if (hipSetDevice(c->dev) != hipSuccess) return BMBS_ENODEV;
+    u32* df = nullptr; u8* dl = nullptr;
+    if (hipMalloc((void**)&df, 320 * 4) != hipSuccess || hipMalloc((void**)&dl, 320) != hipSuccess) { if (df) (void)hipFree(df); return BMBS_ENOMEM; }
+    int rc = BMBS_OK;
+    if (hipMemcpy(df, freq, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) rc = BMBS_ENODEV;
+    if (!rc) { hipLaunchKernelGGL(k_debug_huff, dim3(1), dim3(64), 0, c->stream, df, n, maxbits, dl); if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BMBS_ENODEV; }
+    if (!rc && hipMemcpy(len_out, dl, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = BMBS_ENODEV;
+    (void)hipFree(df); (void)hipFree(dl);
+    return rc;
+}
+
 // diagnostic: calls that were issued again with exact sizes because a stage count did not fit the capacity learned so far
 extern "C" int64_t bmbs_retries(bmbs_ctx* X)
 {

@@ -267,15 +267,20 @@ DEVI void huff_lengths(const u32* freq, int n, int maxbits, u8* len, const HuffW
     const int root = e - 1;
     w.dep[root] = 0;
     for (int i = root - 1; i >= 0; i--) w.dep[i] = (u8)(w.dep[w.par[i]] + 1 > 255 ? 255 : w.dep[w.par[i]] + 1);
-    // bl_count with the overflow moved up (gen_bitlen)
+    // bl_count with the overflow moved up (gen_bitlen).  Leaves deeper than maxbits are set to maxbits; what that adds to the Kraft sum
+    // -- counted in units of 2^-maxbits: zlib counts it as half the nodes, leaves AND internal ones, whose parent sits at maxbits, which
+    // the number of deep LEAVES alone is not once the tree is three levels deeper than maxbits -- is taken off one unit per step: a leaf
+    // one level up moves down beside a leaf that comes up from maxbits
     int cnt[17]; for (int i = 0; i <= 16; i++) cnt[i] = 0;
-    int overflow = 0;
-    for (int i = 0; i < m; i++) { int d = w.dep[i]; if (d > maxbits) { d = maxbits; overflow++; } cnt[d]++; }
-    while (overflow > 0) {
+    for (int i = 0; i < m; i++) { int d = w.dep[i]; if (d > maxbits) d = maxbits; cnt[d]++; }
+    long kraft = 0;
+    for (int d = 1; d <= maxbits; d++) kraft += (long)cnt[d] << (maxbits - d);
+    long over = kraft - (1l << maxbits);
+    while (over > 0) {
         int bits = maxbits - 1;
         while (cnt[bits] == 0) bits--;
         cnt[bits]--; cnt[bits + 1] += 2; cnt[maxbits]--;
-        overflow -= 2;
+        over--;
     }
     // the rarest symbols get the longest codes
     int i = 0;
@@ -537,6 +542,18 @@ k_bgzf_gather(const char* __restrict__ slots, const u32* __restrict__ slot_len, 
         } else {
             for (int k = 0; k < 4; k++) { const int t = t0 + k; if (t >= 0 && t < (int)len) dst[k] = src[t]; }
         }
+    }
+}
+
+// diagnostic (bmbs_debug_huff_lengths): the code lengths huff_lengths gives a frequency table, as k_bgzf_block calls it (m < 0: sorted here)
+__global__ void k_debug_huff(const u32* __restrict__ freq, int n, int maxbits, u8* __restrict__ len_out)
+{
+    __shared__ u32 s_f[320]; __shared__ u32 s_key[640]; __shared__ u16 s_par[640]; __shared__ u16 s_ord[320]; __shared__ u8 s_dep[640]; __shared__ u8 s_len[320];
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < n; i++) s_f[i] = freq[i];
+        HuffWork hw; hw.key = s_key; hw.par = s_par; hw.ord = s_ord; hw.dep = s_dep;
+        huff_lengths(s_f, n, maxbits, s_len, hw, -1);
+        for (int i = 0; i < n; i++) len_out[i] = s_len[i];
     }
 }
 #endif

@@ -364,6 +364,9 @@ int bmbs_counters_all(bmbs_ctx*, uint64_t c[32]);
 /* calls that were issued a second time with exact buffer sizes because a stage count (candidate slots, DP jobs, re-seeded
  * candidates) exceeded the capacity learned from earlier calls (see "launch sequence" below); diagnostic                      */
 int64_t bmbs_retries(bmbs_ctx*);
+/* diagnostic: the Huffman code lengths the device's BGZF deflater (--bam) gives a table of symbol frequencies -- n <= 320 symbols,
+ * maxbits <= 15; every used symbol gets a length, the lengths form a complete prefix code (tests/test_gpu_parity.py)              */
+int bmbs_debug_huff_lengths(bmbs_ctx*, const uint32_t* freq, int32_t n, int32_t maxbits, uint8_t* len_out);
 
 /* ---- index files (next-row (f)2: reader/writer of the reference's on-disk formats) ------------- */
 typedef struct bmbs_index_file bmbs_index_file;

@@ -1299,6 +1299,39 @@ def test_device_bam_blocks_inflate_to_the_records_of_the_sam_text(env, case):
         assert len(z) < len(got) // 2             # runs + Huffman: constant qualities and 4-bit bases compress
 
 
+def test_device_huffman_lengths_form_a_complete_code(env):
+    """the length-limited Huffman codes of the device's BGZF deflater (bmbs_bam.hip: huff_lengths): whatever the symbol frequencies --
+    Fibonacci counts whose tree is 8 levels deeper than the 15-bit limit, the same under a bush of other symbols (the shape of the BAM
+    block a fuzz trial of round 4 found over-subscribed by one code: zlib refused it), the 19-symbol code-length code at 7 bits, random
+    tables -- every used symbol gets a length within the limit, rarer symbols never get shorter codes, and the Kraft sum is exactly one"""
+    import ctypes as C
+    from fractions import Fraction
+    from bitmapperbs_amd import mapper, capi
+    m = mapper.Mapper(env["ix"], 0)
+    L = capi.lib()
+    rng = np.random.default_rng(11)
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    tables = [(fib, 15), (fib[:21] + [int(x) for x in rng.integers(50, 3000, 60)], 15), (fib[:19], 7), ([1] * 19, 7), ([5, 0, 0, 9], 15)]
+    for _ in range(150):
+        n = int(rng.integers(2, 321))
+        f = (rng.integers(0, 4, n) == 0) * rng.integers(1, 1 << int(rng.integers(1, 20)), n)
+        f = f * (rng.random(n) < rng.random())
+        tables.append(([int(x) for x in f], int(rng.choice([7, 9, 15])) if n <= 19 else 15))
+    for freq, maxbits in tables:
+        if sum(1 for x in freq if x) < 2:
+            continue
+        a = np.array(freq, dtype=np.uint32); out = np.zeros(len(freq), dtype=np.uint8)
+        assert L.bmbs_debug_huff_lengths(m._ctx, capi.ptr(a), len(freq), maxbits, capi.ptr(out)) == 0
+        used = [(int(x), int(l)) for x, l in zip(freq, out) if x]
+        assert all(1 <= l <= maxbits for _, l in used), (freq, out)
+        assert all(int(l) == 0 for x, l in zip(freq, out) if not x)
+        assert sum(Fraction(1, 1 << l) for _, l in used) == 1, (freq, list(out))
+        assert all(l1 >= l2 for (x1, l1) in used for (x2, l2) in used if x1 < x2), (freq, list(out))
+    m.close()
+
+
 @pytest.mark.parametrize("level,span,window", [(1, 65536, 1 << 22), (6, 65536, 1 << 22), (9, 4096, 300000), (1, 2048, 100000), (6, 65536, 700000)])
 def test_device_gzip_inflate_equals_zlib(env, level, span, window, monkeypatch):
     """an ordinary one-member .gz file (one deflate stream): spans cut every `span` bytes, block starts found by the search over bit

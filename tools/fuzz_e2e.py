@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--oracle", action="store_true", help="compare the ORACLE's command line (CPU) with the reference instead of bmbs_search")
     ap.add_argument("--big", action="store_true", help="the repeat-rich 5 Mb genome of the BIG golden family instead of the 1.5 Mb one")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_e2e.json"))
+    ap.add_argument("--only", type=int, default=-1, help="run this one trial of the sequence (the draws before it are made and dropped)")
+    ap.add_argument("--keep", default="", help="directory that receives the output files of a trial that fails or raises")
     a = ap.parse_args()
     global USE_ORACLE
     USE_ORACLE = a.oracle
@@ -220,7 +222,18 @@ def main():
         env = make_env(wd, a.big)
         for i in range(a.trials):
             t = draw(rng)
-            bad, lines = run_trial(t, env, wd)
+            if a.only >= 0 and i != a.only:
+                continue
+            try:
+                bad, lines = run_trial(t, env, wd)
+            except Exception as ex:           # (an output file that cannot even be read: kept for the post-mortem)
+                bad, lines = ["exception: %r" % (ex,)], 0
+            if bad and a.keep:
+                import shutil
+                os.makedirs(a.keep, exist_ok=True)
+                for f in os.listdir(wd):
+                    if f.startswith("gpu.") or f.startswith("ref.sam"):
+                        shutil.copy(os.path.join(wd, f), os.path.join(a.keep, "t%d_%s" % (i, f)))
             print("trial %3d %-7s L=%3d n=%4d mixed=%d records=%5d %s  %s" % (i, t["mode"], t["L"], t["n"], t["mixed"], lines, "SAME" if not bad else "DIFF", " ".join(t["opt"])), flush=True)
             if bad:
                 print("\n".join(bad)[:1500], flush=True)
