@@ -1986,6 +1986,28 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
     return lane_text_finish(c, pe, bytes1, bytes2, n_records, flags_in, sam, sam_cap, sam_bytes, n_lines_out, t_start, t_uploaded);
 }
 
+// k_line_write's launch shape: lines per workgroup and the LDS it gets for the image of its piece of the output and for the staged
+// FASTQ text, from the window's bytes per record.  `hb` bounds the computed columns of one line (the plain path keeps them in a
+// quarter of the image buffer).  BMBS_TXW_TINY=1 (test aid): staging buffers too small for anything -- every workgroup takes the plain path.
+struct TxwPlan { int lpb; u32 out_cap, src_cap; size_t lds; };
+static TxwPlan txw_plan(bool pe, u64 text_bytes, u64 n_lines, int hb)
+{
+    static const bool tiny = getenv("BMBS_TXW_TINY") != nullptr;
+    TxwPlan t = {0, 0, 0, 0};
+    if (4 * (u64)hb > 30 * 1024) return t;
+    const u64 rec = text_bytes / std::max<u64>(n_lines, 1) + 8, line = rec + 96;
+    const u64 out_max = 30 * 1024, src_max = pe ? 15 * 1024 : 30 * 1024;
+    int lpb = 32;
+    auto need_out = [&](int l) { return ((u64)l * line * 5 / 4 + 64 + 15) & ~15ull; };
+    auto need_src = [&](int l) { return ((u64)(pe ? l / 2 : l) * rec * 5 / 4 + 64 + 15) & ~15ull; };
+    while (lpb > 2 && (need_out(lpb) > out_max || need_src(lpb) > src_max)) lpb /= 2;
+    t.lpb = lpb;
+    t.out_cap = (u32)std::min<u64>(std::max<u64>(need_out(lpb), (4 * (u64)hb + 15) & ~15ull), out_max);
+    t.src_cap = tiny ? 16u : (u32)std::min<u64>(need_src(lpb), src_max);
+    t.lds = (size_t)t.out_cap + 16 + (pe ? 2 : 1) * ((size_t)t.src_cap + 16);
+    return t;
+}
+
 // the text window(s) are on the device (fq_text1 / fq_text2) and their newline positions are being indexed (text_index): record fields,
 // rows, mapping, SAM text or BAM blocks, download
 int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records, int32_t flags_in, char* sam, u64 sam_cap, u64* sam_bytes,
@@ -2085,11 +2107,11 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
         if (!raw_total) return BMBS_OK;
         const u64 nb = (raw_total + BGZF_IN - 1) / BGZF_IN;
         ENS(c, c->bam_raw, raw_total + 256);
-        const int hb = (36 + 4 * std::max(max_ops, 1) + 8 + 15) & ~15;
-        int lpw = (int)((48 * 1024) / hb);
-        if (lpw > 64) lpw = 64;
+        const TxwPlan tw = txw_plan(pe, bytes1 + bytes2, n2, (36 + 4 * std::max(max_ops, 1) + 8 + 15) & ~15);
+        if (!tw.lpb) { c->err = "text call: CIGARs too long"; return BMBS_EINVAL; }
         prof_begin(c, "k_bam_write");
-        hipLaunchKernelGGL(k_bam_write, dim3(nblk(n2, (unsigned)lpw)), dim3(64), (size_t)lpw * hb, c->stream, in, (long)n2, c->sam_off.as<u64>(), lpw, hb, c->bam_raw.as<char>());
+        hipLaunchKernelGGL(k_line_write<true>, dim3(nblk(n2, (unsigned)tw.lpb)), dim3(TXW_THREADS), tw.lds, c->stream, in, (long)n2, c->sam_off.as<u64>(), tw.lpb, tw.out_cap, tw.src_cap,
+                           c->bam_raw.as<char>());
         prof_end(c);
         ENS(c, c->bam_tok, nb * (u64)(BGZF_SEG * BGZF_THREADS) * 2); ENS(c, c->bam_slots, nb * (u64)BGZF_SLOT);
         ENS(c, c->bam_slot_len, nb * 4 + 64); ENS(c, c->bam_off, (nb + 1) * 8 + 64);
@@ -2142,12 +2164,11 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
     if (total > sam_cap) return too_small("text call: the SAM buffer is too small (sam_bytes tells what this batch needs)");
     if (!total) return BMBS_OK;
     ENS(c, c->sam_out, total + 64);
-    const int hb = (c->max_ref_len + 5 * std::max(max_ops, 1) + 96 + 15) & ~15;
-    int lpw = (int)((48 * 1024) / hb);
-    if (lpw > 64) lpw = 64;
-    if (lpw < 1) { c->err = "text call: reference names too long"; return BMBS_EINVAL; }
+    const TxwPlan tw = txw_plan(pe, bytes1 + bytes2, n2, (c->max_ref_len + 5 * std::max(max_ops, 1) + 96 + 15) & ~15);
+    if (!tw.lpb) { c->err = "text call: reference names too long"; return BMBS_EINVAL; }
     prof_begin(c, "k_sam_write");
-    hipLaunchKernelGGL(k_sam_write, dim3(nblk(n2, (unsigned)lpw)), dim3(64), (size_t)lpw * hb, c->stream, in, (long)n2, c->sam_off.as<u64>(), lpw, hb, c->sam_out.as<char>());
+    hipLaunchKernelGGL(k_line_write<false>, dim3(nblk(n2, (unsigned)tw.lpb)), dim3(TXW_THREADS), tw.lds, c->stream, in, (long)n2, c->sam_off.as<u64>(), tw.lpb, tw.out_cap, tw.src_cap,
+                       c->sam_out.as<char>());
     prof_end(c);
     if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); tp[5] = wall(); }
     {

@@ -43,8 +43,9 @@ DEVI void st16(char* p, u32 v) { p[0] = (char)v; p[1] = (char)(v >> 8); }
 DEVI int bam_tag_len(const SamLine& s) { return s.kind == 1 ? (s.x->nm <= 0xff ? 4 : 5) : 0; }
 DEVI int bam_ncigar(const SamLine& s) { return s.kind == 1 ? (s.x->n_cigar ? (int)s.x->n_cigar : 1) : 0; }
 
-// the fixed 36 bytes (block_size + the 32-byte core), the CIGAR words and the tag of line s into p; returns their total length
-DEVI int bam_head(const SamIn& in, const SamLine& s, int L, int total, char* p)
+// the fixed 36 bytes (block_size + the 32-byte core) of line s into p, its CIGAR words into c and its tag behind the qualities
+// into g (the three sit apart in the record: core, QNAME, CIGAR, SEQ, QUAL, tag)
+DEVI void bam_head(const SamIn& in, const SamLine& s, int L, int total, char* p, char* c, char* g)
 {
     const bool pe = (in.flags & BMBS_TEXT_PE) != 0;
     const int ncig = bam_ncigar(s);
@@ -55,12 +56,11 @@ DEVI int bam_head(const SamIn& in, const SamLine& s, int L, int total, char* p)
         p[12] = (char)(s.name_len + 1); p[13] = 0; st16(p + 14, (u32)bam_reg2bin(-1, 0));
         st16(p + 16, 0); st16(p + 18, (u32)flag); st32(p + 20, (u32)L);
         st32(p + 24, 0xffffffffu); st32(p + 28, 0xffffffffu); st32(p + 32, 0);
-        return 36;
+        return;
     }
     const bmbs_result_dev& x = *s.x;
     const long long pos0 = (long long)x.pos - 1;
     long long reflen = 0;
-    char* c = p + 36;
     if (x.n_cigar == 0) { st32(c, (u32)L << 4); reflen = L; c += 4; }
     else
         for (int i = 0; i < x.n_cigar; i++) {
@@ -80,10 +80,9 @@ DEVI int bam_head(const SamIn& in, const SamLine& s, int L, int total, char* p)
         const u32 tl = s.mate == 0 ? x.tlen : y.tlen;
         st32(p + 24, (u32)x.chrom); st32(p + 28, (u32)((long long)y.pos - 1)); st32(p + 32, neg ? (u32)(-(int)tl) : tl);
     }
-    c[0] = 'N'; c[1] = 'M';
-    if (x.nm <= 0xff) { c[2] = 'C'; c[3] = (char)x.nm; c += 4; }
-    else { c[2] = 'S'; st16(c + 3, x.nm); c += 5; }
-    return (int)(c - p);
+    g[0] = 'N'; g[1] = 'M';
+    if (x.nm <= 0xff) { g[2] = 'C'; g[3] = (char)x.nm; }
+    else { g[2] = 'S'; st16(g + 3, x.nm); }
 }
 
 // bytes of the BAM record of output line `line` (0: nothing is printed for it); info[3] = 1 + a line whose QNAME is too long
@@ -102,83 +101,216 @@ k_bam_len(SamIn in, long n_lines, u32* __restrict__ len_out, u32* __restrict__ i
     len_out[line] = len;
 }
 
-// the same shape as k_sam_write: lane i describes line i and renders its fixed part into LDS, then 16 lanes per line assemble the
-// record four bytes at a time into destination-aligned dwords
-__global__ void __launch_bounds__(64)
-k_bam_write(SamIn in, long n_lines, const u64* __restrict__ off, int lpw, int hb, char* __restrict__ out)
+// ---- records -> SAM text or BAM records: one workgroup per piece of the output (round 5) ------------------------------------------------
+// A workgroup of 256 threads owns `lpb` consecutive output lines = one contiguous piece of the output, and their sources are
+// contiguous too: the records of consecutive lines follow each other in the resident FASTQ text (pairs: in either mate's text).
+//   1. the source range(s) come into LDS with 16-byte loads, the records' fields into registers (lane i: line i);
+//   2. lane i finds its QNAME in the staged text and renders its numeric columns (SAM) / core, CIGAR words and tag (BAM)
+//      straight into the line's place in the LDS image of the piece;
+//   3. 16 lanes per line move QNAME / SEQ / QUAL from the staged text into the image: upper case, complement, reversal, padding
+//      (Process_Reads.cpp:836, 1603), 4-bit bases and qualities - 33 for BAM;
+//   4. the image goes out with 16-byte stores (its first and last 16-byte unit byte-wise: the neighbouring pieces own the rest).
+// The round-3/4 form built every output dword from four single-byte global loads, one wave per workgroup: 4.5 ms per 1.05 M lines
+// (160 GB/s); this one moves the same bytes at the rate of its loads and stores.
+// A piece or a source range that does not fit its LDS buffer (names of kilobytes, a length estimate that was off) takes the plain
+// path: a wave per line, bytes straight from and to memory.
+#define TXW_THREADS 256
+struct TxwDesc {                 // per line, in LDS
+    u32 start;                   // offset of the line inside the piece
+    u32 total;                   // bytes (0: the line is not printed)
+    u16 name_rel, seq_rel, qual_rel;   // where QNAME / SEQ / QUAL start in the staged text (QNAME: file 0; SEQ / QUAL: the line's own file)
+    u16 nlen, hl, tl, L, qn;
+    u8 rc, mate;
+};
+
+// printed SEQ character: upper case (Process_Reads.cpp:836), complemented when the line prints the other strand (rc_table, :1603)
+DEVI u32 txw_base(u32 c, bool rc)
 {
-    extern __shared__ char lds_sam[];                  // [lpw][hb]: core + cigar + tag
-    __shared__ SamDesc s_d[64];
-    __shared__ u32 s_start[65];
-    const long line0 = (long)blockIdx.x * lpw;
-    const int lane = threadIdx.x;
-    const int nl = (int)((n_lines - line0) < (long)lpw ? (n_lines - line0) : (long)lpw);
-    const u64 o0 = off[line0];
-    if (lane < nl) {
-        const long line = line0 + lane;
-        const SamLine sl = sam_line(in, line);
-        SamDesc d;
-        d.name = d.seq = d.qual = nullptr; d.start = (u32)(off[line] - o0); d.total = 0; d.nlen = d.hl = d.tl = d.L = d.qn = d.rc = 0;
-        if (sl.kind) {
-            const FqRec& R = in.rec[sl.mate];
-            const char* text = in.text[sl.mate];
-            const int L = R.seq_len[sl.rec];
-            const int total = 36 + sl.name_len + 1 + 4 * bam_ncigar(sl) + (L + 1) / 2 + L + bam_tag_len(sl);
-            char* h = lds_sam + (size_t)lane * hb;
-            const int hl = bam_head(in, sl, L, total, h);
-            d.name = ((in.flags & BMBS_TEXT_PE) ? in.text[0] + in.rec[0].name_off[sl.rec] : text + R.name_off[sl.rec]) + sl.name_skip;
-            d.seq = text + R.seq_off[sl.rec]; d.qual = text + R.qual_off[sl.rec];
-            d.nlen = (u16)sl.name_len; d.hl = (u16)hl; d.tl = (u16)bam_tag_len(sl); d.L = (u16)L; d.qn = R.qual_len[sl.rec]; d.rc = sl.rc ? 1 : 0;
-            d.total = (u32)total;
-        }
-        s_d[lane] = d;
-        s_start[lane] = d.start;
+    if (c >= 'a' && c <= 'z') c -= 32;
+    if (rc) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+    return c;
+}
+
+template <bool BAM>
+DEVI int txw_line_bytes(const SamLine& s, int L, int hl, int tl) { return BAM ? 36 + s.name_len + 1 + hl + (L + 1) / 2 + L + tl : s.name_len + hl + 2 * L + 1 + tl; }
+
+template <bool BAM>
+__global__ void __launch_bounds__(TXW_THREADS)
+k_line_write(SamIn in, long n_lines, const u64* __restrict__ off, int lpb, u32 out_cap, u32 src_cap, char* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_txw[];        // [out_cap + 16] image of the piece, [src_cap + 16] x files: staged text
+    __shared__ TxwDesc s_d[64];
+    char* const img = lds_txw;
+    char* const src0 = lds_txw + out_cap + 16;
+    char* const src1 = src0 + src_cap + 16;
+    const bool pe = (in.flags & BMBS_TEXT_PE) != 0;
+    const long line0 = (long)blockIdx.x * lpb;
+    const int tid = threadIdx.x;
+    const int nl = (int)((n_lines - line0) < (long)lpb ? (n_lines - line0) : (long)lpb);      // lines of this workgroup
+    const u64 o0 = off[line0], o1 = off[line0 + nl];
+    const u32 piece = (u32)(o1 - o0);
+    if (!piece) return;
+    // source ranges: records r0 .. r1 of every file, from the name line of r0 to the last quality character of r1
+    const long r0 = pe ? line0 >> 1 : line0, r1 = pe ? (line0 + nl - 1) >> 1 : line0 + nl - 1;
+    const int nf = pe ? 2 : 1;
+    u32 a0[2] = {0, 0}, span[2] = {0, 0};
+    bool fits = piece <= out_cap;
+    for (int f = 0; f < nf; f++) {
+        const u32 s = in.rec[f].name_off[r0], e = in.rec[f].qual_off[r1] + in.rec[f].qual_len[r1];
+        const u32 lead = (u32)((uintptr_t)(in.text[f] + s) & 15u);
+        a0[f] = s - lead; span[f] = e - a0[f];
+        fits = fits && span[f] <= src_cap;
     }
-    if (lane == 0) s_start[nl] = (u32)(off[line0 + nl] - o0);
-    __syncthreads();
-    if (!s_start[nl]) return;
-    const int grp = lane >> 4, gl = lane & 15;
-    for (int j = grp; j < nl; j += 4) {
-        const SamDesc d = s_d[j];
-        if (!d.total) continue;
-        const char* hd = lds_sam + (size_t)j * hb;
-        const int L = d.L, qn = d.qn;
-        const bool rc = d.rc != 0;
-        const int cig = (int)d.hl - 36 - (int)d.tl;                   // bytes of CIGAR words
-        const int b1 = 36, b2 = b1 + d.nlen + 1, b3 = b2 + cig, b4 = b3 + (L + 1) / 2, b5 = b4 + L;
-        const int total = (int)d.total;
-        const u64 o = o0 + d.start;
-        const u64 d0 = o & ~3ull;
-        const int lead = (int)(o - d0);
-        const int ndw = (lead + total + 3) >> 2;
-        auto base_at = [&](int i) -> u32 {                            // the printed SEQ character i (as in k_sam_write)
-            unsigned char c = (unsigned char)d.seq[rc ? L - 1 - i : i];
-            if (c >= 'a' && c <= 'z') c -= 32;
-            if (rc) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
-            return c;
-        };
-        auto byte_at = [&](int t) -> u32 {
-            if (t < b1) return (unsigned char)hd[t];
-            if (t < b2) return t - b1 < (int)d.nlen ? (u32)(unsigned char)d.name[t - b1] : 0u;
-            if (t < b3) return (unsigned char)hd[36 + (t - b2)];
-            if (t < b4) {
-                const int i = 2 * (t - b3);
-                const u32 hi = c_nt16[base_at(i)], lo = i + 1 < L ? (u32)c_nt16[base_at(i + 1)] : 0u;
-                return (hi << 4) | lo;
-            }
-            if (t < b5) { const int i = t - b4, jj = rc ? L - 1 - i : i; return ((jj < qn ? (u32)(unsigned char)d.qual[jj] : (u32)' ') - 33u) & 0xffu; }
-            return (unsigned char)hd[36 + cig + (t - b5)];
-        };
-        for (int w = gl; w < ndw; w += 16) {
-            const int t0 = 4 * w - lead;
-            char* dst = out + d0 + 4 * (u64)w;
-            if (t0 >= 0 && t0 + 4 <= total) {
-                const u32 v = byte_at(t0) | (byte_at(t0 + 1) << 8) | (byte_at(t0 + 2) << 16) | (byte_at(t0 + 3) << 24);
-                *reinterpret_cast<u32*>(dst) = v;
-            } else {
-                for (int b = 0; b < 4; b++) { const int t = t0 + b; if (t >= 0 && t < total) dst[b] = (char)byte_at(t); }
+    const u32 lead = (u32)((uintptr_t)(out + o0) & 15u);
+    char* const gout = out + o0 - lead;                        // 16-byte aligned; byte `lead` of the image is the piece's first
+    if (fits) {
+        // ---- 1. stage the text, fetch the records
+        for (int f = 0; f < nf; f++) {
+            const uint4* g = reinterpret_cast<const uint4*>(in.text[f] + a0[f]);
+            uint4* d = reinterpret_cast<uint4*>(f ? src1 : src0);
+            const int n16 = (int)((span[f] + 15u) >> 4);
+#pragma unroll 2
+            for (int i = tid; i < n16; i += TXW_THREADS) d[i] = g[i];
+        }
+        SamLine sl; sl.kind = 0;
+        u32 start = 0;
+        int L = 0, qn = 0;
+        u32 nm0 = 0, nm1 = 0, so = 0, qo = 0; int nl0 = 0, nl1 = 0;
+        if (tid < nl) {
+            const long line = line0 + tid;
+            sl = sam_line_core(in, line);
+            start = (u32)(off[line] - o0);
+            if (sl.kind) {
+                const FqRec& R = in.rec[sl.mate];
+                L = R.seq_len[sl.rec]; qn = R.qual_len[sl.rec];
+                so = R.seq_off[sl.rec] - a0[sl.mate]; qo = R.qual_off[sl.rec] - a0[sl.mate];
+                nm0 = in.rec[0].name_off[sl.rec] - a0[0]; nl0 = in.rec[0].name_len[sl.rec];
+                if (pe) { nm1 = in.rec[1].name_off[sl.rec] - a0[1]; nl1 = in.rec[1].name_len[sl.rec]; }
             }
         }
+        __syncthreads();
+        // ---- 2. QNAME from the staged text; the columns that are computed, into the image
+        if (tid < nl) {
+            TxwDesc d;
+            d.start = start; d.total = 0; d.name_rel = d.seq_rel = d.qual_rel = 0; d.nlen = d.hl = d.tl = d.L = d.qn = 0; d.rc = d.mate = 0;
+            if (sl.kind) {
+                if (!pe) qname_se(src0 + nm0, nl0, sl.name_skip, sl.name_len);
+                else qname_pe(src0 + nm0, nl0, src1 + nm1, nl1, sl.name_skip, sl.name_len);
+                char* const p = img + lead + start;
+                int hl, tl;
+                if (BAM) {
+                    hl = 4 * bam_ncigar(sl); tl = bam_tag_len(sl);
+                    const int total = txw_line_bytes<true>(sl, L, hl, tl);
+                    bam_head(in, sl, L, total, p, p + 36 + sl.name_len + 1, p + total - tl);
+                    d.total = (u32)total;
+                } else {
+                    hl = sam_head(in, sl, p + sl.name_len);
+                    tl = sam_tail(sl, p + sl.name_len + hl + 2 * L + 1);
+                    d.total = (u32)txw_line_bytes<false>(sl, L, hl, tl);
+                }
+                d.name_rel = (u16)(nm0 + sl.name_skip); d.seq_rel = (u16)so; d.qual_rel = (u16)qo;
+                d.nlen = (u16)sl.name_len; d.hl = (u16)hl; d.tl = (u16)tl; d.L = (u16)L; d.qn = (u16)qn; d.rc = sl.rc ? 1 : 0; d.mate = (u8)sl.mate;
+            }
+            s_d[tid] = d;
+        }
+        __syncthreads();
+        // ---- 3. QNAME / SEQ / QUAL: 16 lanes per line
+        const int grp = tid >> 4, gl = tid & 15;
+        for (int j = grp; j < nl; j += TXW_THREADS / 16) {
+            const TxwDesc d = s_d[j];
+            if (!d.total) continue;
+            const int L = d.L, qn = d.qn, nlen = d.nlen;
+            const bool rc = d.rc != 0;
+            const char* const nm = src0 + d.name_rel;
+            const char* const sq = (d.mate ? src1 : src0) + d.seq_rel;
+            const char* const ql = (d.mate ? src1 : src0) + d.qual_rel;
+            char* const p = img + lead + d.start;
+            if (BAM) {
+                char* const q = p + 36;
+                for (int t = gl; t <= nlen; t += 16) q[t] = t < nlen ? nm[t] : (char)0;
+                char* const s4 = q + nlen + 1 + d.hl;
+                for (int t = gl; t < (L + 1) / 2; t += 16) {
+                    const int i = 2 * t;
+                    const u32 hi = c_nt16[txw_base((unsigned char)sq[rc ? L - 1 - i : i], rc)];
+                    const u32 lo = i + 1 < L ? (u32)c_nt16[txw_base((unsigned char)sq[rc ? L - 2 - i : i + 1], rc)] : 0u;
+                    s4[t] = (char)((hi << 4) | lo);
+                }
+                char* const qq = s4 + (L + 1) / 2;
+                for (int i = gl; i < L; i += 16) { const int jj = rc ? L - 1 - i : i; qq[i] = (char)((jj < qn ? (u32)(unsigned char)ql[jj] : (u32)' ') - 33u); }
+            } else {
+                for (int t = gl; t < nlen; t += 16) p[t] = nm[t];
+                char* const s1 = p + nlen + d.hl;
+                for (int i = gl; i < L; i += 16) s1[i] = (char)txw_base((unsigned char)sq[rc ? L - 1 - i : i], rc);
+                if (gl == 0) s1[L] = '\t';
+                char* const qq = s1 + L + 1;
+                for (int i = gl; i < L; i += 16) { const int jj = rc ? L - 1 - i : i; qq[i] = jj < qn ? ql[jj] : ' '; }       // qual.resize(seq.size(), ' ')
+            }
+        }
+        __syncthreads();
+        // ---- 4. the image goes out
+        const u32 end = lead + piece;
+        const int n16 = (int)((end + 15u) >> 4);
+        for (int c = tid; c < n16; c += TXW_THREADS) {
+            const u32 b = (u32)c << 4;
+            if (b >= lead && b + 16u <= end) *reinterpret_cast<uint4*>(gout + b) = *reinterpret_cast<const uint4*>(img + b);
+            else for (u32 i = b; i < b + 16u; i++) if (i >= lead && i < end) gout[i] = img[i];
+        }
+        return;
+    }
+    // ---- the plain path: a wave per line, its computed columns in the wave's quarter of the LDS buffer, bytes from and to memory
+    const int wave = tid >> 6, lane = tid & 63;
+    char* const hd = lds_txw + (size_t)wave * ((out_cap + 16) / 4);
+    for (int j = wave; j < nl; j += TXW_THREADS / 64) {
+        const long line = line0 + j;
+        SamLine sl = sam_line(in, line);
+        if (!sl.kind) continue;
+        const FqRec& R = in.rec[sl.mate];
+        const char* const text = in.text[sl.mate];
+        const int L = R.seq_len[sl.rec], qn = R.qual_len[sl.rec];
+        const char* const nm = in.text[0] + in.rec[0].name_off[sl.rec] + sl.name_skip;
+        const char* const sq = text + R.seq_off[sl.rec];
+        const char* const ql = text + R.qual_off[sl.rec];
+        const bool rc = sl.rc;
+        int hl, tl, total;
+        if (BAM) { hl = 4 * bam_ncigar(sl); tl = bam_tag_len(sl); total = txw_line_bytes<true>(sl, L, hl, tl); }
+        else { hl = sam_head(in, sl, nullptr); tl = sam_tail(sl, nullptr); total = txw_line_bytes<false>(sl, L, hl, tl); }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            if (BAM) bam_head(in, sl, L, total, hd, hd + 36, hd + 36 + hl);
+            else { sam_head(in, sl, hd); sam_tail(sl, hd + hl); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        char* const dst = out + off[line];
+        const int nlen = sl.name_len;
+        for (int t = lane; t < total; t += 64) {
+            u32 v;
+            if (BAM) {
+                const int b1 = 36, b2 = b1 + nlen + 1, b3 = b2 + hl, b4 = b3 + (L + 1) / 2, b5 = b4 + L;
+                if (t < b1) v = (unsigned char)hd[t];
+                else if (t < b2) v = t - b1 < nlen ? (u32)(unsigned char)nm[t - b1] : 0u;
+                else if (t < b3) v = (unsigned char)hd[36 + (t - b2)];
+                else if (t < b4) {
+                    const int i = 2 * (t - b3);
+                    const u32 hi = c_nt16[txw_base((unsigned char)sq[rc ? L - 1 - i : i], rc)];
+                    const u32 lo = i + 1 < L ? (u32)c_nt16[txw_base((unsigned char)sq[rc ? L - 2 - i : i + 1], rc)] : 0u;
+                    v = (hi << 4) | lo;
+                }
+                else if (t < b5) { const int i = t - b4, jj = rc ? L - 1 - i : i; v = ((jj < qn ? (u32)(unsigned char)ql[jj] : (u32)' ') - 33u) & 0xffu; }
+                else v = (unsigned char)hd[36 + hl + (t - b5)];
+            } else {
+                const int b1 = nlen, b2 = b1 + hl, b3 = b2 + L, b4 = b3 + 1, b5 = b4 + L;
+                if (t < b1) v = (unsigned char)nm[t];
+                else if (t < b2) v = (unsigned char)hd[t - b1];
+                else if (t < b3) { const int i = t - b2; v = txw_base((unsigned char)sq[rc ? L - 1 - i : i], rc); }
+                else if (t < b4) v = (u32)'\t';
+                else if (t < b5) { const int i = t - b4, jj = rc ? L - 1 - i : i; v = jj < qn ? (u32)(unsigned char)ql[jj] : (u32)' '; }
+                else v = (unsigned char)hd[hl + (t - b5)];
+            }
+            dst[t] = (char)v;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

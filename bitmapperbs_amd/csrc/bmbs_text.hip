@@ -177,7 +177,8 @@ DEVI void qname_pe(const char* a, int la, const char* b, int lb, int& skip, int&
     if (len && a[0] == '@') { skip = 1; len--; }
 }
 
-DEVI SamLine sam_line(const SamIn& in, long line)
+// everything of a line but its QNAME (name_skip / name_len): global loads of the records only
+DEVI SamLine sam_line_core(const SamIn& in, long line)
 {
     SamLine s; s.kind = 0; s.mate = 0; s.rec = 0; s.name_skip = 0; s.name_len = 0; s.rc = false; s.x = nullptr; s.mate_x = nullptr;
     const bool pe = (in.flags & BMBS_TEXT_PE) != 0, amb_out = (in.flags & BMBS_TEXT_AMBIG) != 0, unm_out = (in.flags & BMBS_TEXT_UNMAPPED) != 0;
@@ -188,7 +189,6 @@ DEVI SamLine sam_line(const SamIn& in, long line)
         const bool mapped = st == 1 || (st == 2 && amb_out);
         if (!mapped && !(unm_out && st != 2)) return s;
         s.kind = mapped ? 1 : 2; s.rec = r; s.x = x;
-        qname_se(in.text[0] + in.rec[0].name_off[r], in.rec[0].name_len[r], s.name_skip, s.name_len);
         // a --pbat read was mapped as the reverse complement of the text: flag 16 prints the text as it is (Schema.cpp:25538-25543)
         s.rc = mapped && (((x->flag & 16) != 0) != ((in.flags & BMBS_TEXT_PBAT) != 0));
         return s;
@@ -201,9 +201,16 @@ DEVI SamLine sam_line(const SamIn& in, long line)
     const bool mapped = st == 1 || (st == 2 && amb_out);
     if (!mapped && !(unm_out && st != 2)) return s;
     s.kind = mapped ? 1 : 2; s.mate = m; s.rec = p; s.x = m ? x2 : x1; s.mate_x = m ? x1 : x2;
-    qname_pe(in.text[0] + in.rec[0].name_off[p], in.rec[0].name_len[p], in.text[1] + in.rec[1].name_off[p], in.rec[1].name_len[p], s.name_skip, s.name_len);
     // mate 1 prints as read unless it mapped to the reverse strand (flag 83: no 0x20); mate 2's text is in FASTQ orientation
     if (mapped) s.rc = m == 0 ? !(x1->flag & 32) : (x2->flag & 16) != 0;
+    return s;
+}
+DEVI SamLine sam_line(const SamIn& in, long line)
+{
+    SamLine s = sam_line_core(in, line);
+    if (!s.kind) return s;
+    if (!(in.flags & BMBS_TEXT_PE)) qname_se(in.text[0] + in.rec[0].name_off[s.rec], in.rec[0].name_len[s.rec], s.name_skip, s.name_len);
+    else qname_pe(in.text[0] + in.rec[0].name_off[s.rec], in.rec[0].name_len[s.rec], in.text[1] + in.rec[1].name_off[s.rec], in.rec[1].name_len[s.rec], s.name_skip, s.name_len);
     return s;
 }
 
@@ -274,93 +281,4 @@ k_sam_len(SamIn in, long n_lines, u32* __restrict__ len_out)
     len_out[line] = len;
 }
 
-// One wave per `lpw` consecutive output lines, i.e. per contiguous piece of the output.
-// Phase A: lane i describes line i -- where its QNAME / SEQ / QUAL sit in the FASTQ text, strand, lengths -- and renders its
-// numeric columns into LDS (every lane busy with a line of its own).
-// Phase B: every group of 16 lanes takes a line at a time and produces its bytes four at a time into destination-aligned dwords:
-// QNAME, SEQ and QUAL bytes come from the FASTQ text that is still resident (upper-cased / complemented / reversed / padded on
-// the way), the columns in between from LDS; the ragged first and last dword of a line are written byte-wise, because the
-// neighbouring lines -- possibly on another wave -- own the other bytes.
-struct SamDesc {                 // per line, in LDS
-    const char* name; const char* seq; const char* qual;
-    u32 start;                   // offset of the line inside the piece
-    u32 total;                   // bytes (0: the line is not printed)
-    u16 nlen, hl, tl, L, qn, rc;
-};
-__global__ void __launch_bounds__(64)
-k_sam_write(SamIn in, long n_lines, const u64* __restrict__ off, int lpw, int hb, char* __restrict__ out)
-{
-    extern __shared__ char lds_sam[];                  // [lpw][hb]: head, then tail
-    __shared__ SamDesc s_d[64];
-    __shared__ u32 s_start[65];
-    const long line0 = (long)blockIdx.x * lpw;
-    const int lane = threadIdx.x;
-    const int nl = (int)((n_lines - line0) < (long)lpw ? (n_lines - line0) : (long)lpw);      // lines of this wave
-    const u64 o0 = off[line0];
-    if (lane < nl) {
-        const long line = line0 + lane;
-        const SamLine sl = sam_line(in, line);
-        SamDesc d;
-        d.name = d.seq = d.qual = nullptr; d.start = (u32)(off[line] - o0); d.total = 0; d.nlen = d.hl = d.tl = d.L = d.qn = d.rc = 0;
-        if (sl.kind) {
-            char* h = lds_sam + (size_t)lane * hb;
-            const int hl = sam_head(in, sl, h);
-            const int tl = sam_tail(sl, h + hl);
-            const FqRec& R = in.rec[sl.mate];
-            const char* text = in.text[sl.mate];
-            // the pair's QNAME comes from mate 1's name line whichever mate is printed
-            d.name = ((in.flags & BMBS_TEXT_PE) ? in.text[0] + in.rec[0].name_off[sl.rec] : text + R.name_off[sl.rec]) + sl.name_skip;
-            d.seq = text + R.seq_off[sl.rec]; d.qual = text + R.qual_off[sl.rec];
-            d.nlen = (u16)sl.name_len; d.hl = (u16)hl; d.tl = (u16)tl; d.L = R.seq_len[sl.rec]; d.qn = R.qual_len[sl.rec]; d.rc = sl.rc ? 1 : 0;
-            d.total = (u32)(sl.name_len + hl + 2 * (int)d.L + 1 + tl);
-        }
-        s_d[lane] = d;
-        s_start[lane] = d.start;
-    }
-    if (lane == 0) s_start[nl] = (u32)(off[line0 + nl] - o0);
-    __syncthreads();
-    if (!s_start[nl]) return;
-    // Phase B: four lines at a time, 16 lanes each (the loads of four lines are in flight together; with all 64 lanes on one
-    // line the kernel waited out one load latency per line: 2.7 ms per 2 M lines; with one binary search per dword over the
-    // piece's line offsets instead, 3.7 ms)
-    const int grp = lane >> 4, gl = lane & 15;
-    for (int j = grp; j < nl; j += 4) {
-        const SamDesc d = s_d[j];
-        if (!d.total) continue;
-        const char* hd = lds_sam + (size_t)j * hb;
-        const int L = d.L, qn = d.qn;
-        const bool rc = d.rc != 0;
-        const int b1 = d.nlen, b2 = b1 + d.hl, b3 = b2 + L, b4 = b3 + 1, b5 = b4 + L;
-        const int total = (int)d.total;
-        const u64 o = o0 + d.start;
-        const u64 d0 = o & ~3ull;                      // first destination dword that holds a byte of this line
-        const int lead = (int)(o - d0);
-        const int ndw = (lead + total + 3) >> 2;
-        auto byte_at = [&](int t) -> u32 {
-            if (t < b1) return (unsigned char)d.name[t];
-            if (t < b2) return (unsigned char)hd[t - b1];
-            if (t < b3) {
-                const int i = t - b2;
-                unsigned char c = (unsigned char)d.seq[rc ? L - 1 - i : i];
-                if (c >= 'a' && c <= 'z') c -= 32;                                                                     // toupper, Process_Reads.cpp:836
-                if (rc) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;                    // rc_table, Process_Reads.cpp:1603
-                return c;
-            }
-            if (t < b4) return (u32)'\t';
-            if (t < b5) { const int i = t - b4, jj = rc ? L - 1 - i : i; return jj < qn ? (unsigned char)d.qual[jj] : (u32)' '; }   // qual.resize(seq.size(), ' ')
-            return (unsigned char)hd[d.hl + (t - b5)];
-        };
-        for (int w = gl; w < ndw; w += 16) {
-            const int t0 = 4 * w - lead;               // line-relative index of the dword's first byte
-            char* dst = out + d0 + 4 * (u64)w;
-            if (t0 >= 0 && t0 + 4 <= total) {
-                const u32 v = byte_at(t0) | (byte_at(t0 + 1) << 8) | (byte_at(t0 + 2) << 16) | (byte_at(t0 + 3) << 24);
-                *reinterpret_cast<u32*>(dst) = v;
-            } else {
-                // the ragged first and last dword of a line: its neighbours own the other bytes
-                for (int b = 0; b < 4; b++) { const int t = t0 + b; if (t >= 0 && t < total) dst[b] = (char)byte_at(t); }
-            }
-        }
-    }
-}
 #endif
