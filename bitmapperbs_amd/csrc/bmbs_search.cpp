@@ -182,7 +182,6 @@ struct Pinned {                                  // page-locked staging (bmbs_ho
 // the newlines counted per 64 KiB block by the thread that has just read it.  .gz: a thread of its own inflates into a queue of
 // chunks (so that the two files of a paired-end run inflate side by side) and the window is assembled from them. ---------------
 #define SUB_BLOCK ((size_t)1 << 16)
-#define GZ_WINDOW_MAX ((size_t)120 << 20)         // compressed bytes of one device call on a gzip stream (8192 spans of 16 KiB)
 struct Source {
     bool gz = false;
     int fd = -1;
@@ -196,13 +195,6 @@ struct Source {
     // ... a window at a time, straight into the batch's page-locked window: no inflater threads, no chunk queue, and the newline counts
     // come back with the text -- the host moves the compressed bytes into a staging buffer and nothing else
     bool zdirect = false;
-    // an ordinary .gz member on the device (bmbs_text_open_gzip): where the stream stands -- bit position of the next block in the file, the
-    // 32 KiB of text in front of it, CRC-32 and length of the member so far.  gcand: the file qualifies; the driver decides (both mates)
-    bool gcand = false, gdirect = false, gdone = false;
-    uint64_t gbit = 0, glen = 0;
-    uint32_t gcrc = 0;
-    std::vector<unsigned char> gwin;
-    Pinned gstage;
     bmbs_ctx* zc = nullptr;
     Pinned zstage;
     std::vector<uint64_t> zblk, zout;
@@ -269,7 +261,7 @@ struct Source {
         if (--live_inflaters == 0) { gz_done = true; cv_data.notify_all(); }
     }
     // a one-member .gz file that is not taken by the device path after all: the host's block-parallel inflater from its first byte
-    void host_stream() { std::lock_guard<std::mutex> l(m); gcand = false; gdirect = false; start_pgz(0, 0); }
+    void host_stream() { std::lock_guard<std::mutex> l(m); start_pgz(0, 0); }
     bool open(const char* path, size_t lo, size_t hi, int gz_threads = 1, int device = -1)
     {
         zdev = device;
@@ -332,8 +324,11 @@ struct Source {
                                     const size_t isz = bgzf_isize(zmap + q, bs);
                                     if (isz) {
                                         if (!ob.mem) { if (!ob.reserve(70000)) throw std::bad_alloc(); memset(ob.mem, 0, pgz::WIN); }
-                                        ob.n = 0; ends.clear();
-                                        const pgz::DecodeResult r = pgz::decode_blocks<pgz::u8>(zmap, q + bs, (pgz::u64)(q + 18) * 8, ~(pgz::u64)0, ob, ends, *dyn);
+                                        ob.n = 0; ob.mstart = 0; ob.reach = 0; ends.clear();      // (a member of its own: nothing in front of it)
+                                        // (the deflate data starts behind the WHOLE member header: a block may carry a name, a comment or a header CRC too)
+                                        const size_t body = pgz::gzip_header(zmap, q + bs, q);
+                                        pgz::DecodeResult r; r.st = pgz::ST_ERROR; r.end_bit = 0; r.why = "";
+                                        if (body) r = pgz::decode_blocks<pgz::u8>(zmap, q + bs, (pgz::u64)body * 8, ~(pgz::u64)0, ob, ends, *dyn);
                                         if (r.st != pgz::ST_END || ob.n != isz || ends.size() != 1 || ends[0].isize != (pgz::u32)isz ||
                                             ends[0].crc != pgz::crc32_fast(0, ob.out(), isz)) bad = true;
                                         else memcpy(out.data() + at, ob.out(), isz);
@@ -347,13 +342,6 @@ struct Source {
                         inflater_exit();
                     });
                 return true;
-            }
-            {
-                const char* zd = getenv("BMBS_GZ_DEVICE");
-                const size_t body = pgz::gzip_header(zmap, zsize, 0);
-                // (BMBS_GZ_DEVICE=2: the device's span decoder for ordinary gzip members too -- correct, and measured slower than the host's
-                // block-parallel inflater so far: not the default)
-                if (zdev >= 0 && zd && !strcmp(zd, "2") && body) { gcand = true; gbit = (uint64_t)body * 8; gstage.kind = 1; return true; }
             }
             host_stream();
             return true;
@@ -548,7 +536,7 @@ struct Source {
     {
         if (zc) bmbs_destroy(zc);
         zc = nullptr;
-        zstage.release(); gstage.release();
+        zstage.release();
     }
     ~Source() { close(); release_device(); }
 };
@@ -1030,11 +1018,6 @@ int main(int argc, char** argv)
                 (pe && !pt.s2.open(seq2.c_str(), cut2[(size_t)p], cut2[(size_t)p + 1], zt, devices[(size_t)p % devices.size()]))) {
                 fprintf(stderr, "Cannot open the read file(s)\n"); return 1;
             }
-            // ordinary .gz members go to the device when every input file of the run qualifies (one reader hands both mates' windows to a
-            // context); else the host's block-parallel inflater takes them
-            const bool g = live_parts == 1 && pt.s1.gcand && (!pe || pt.s2.gcand);
-            if (g) { pt.s1.gdirect = true; if (pe) pt.s2.gdirect = true; }
-            else { if (pt.s1.gcand) pt.s1.host_stream(); if (pe && pt.s2.gcand) pt.s2.host_stream(); }
         }
     }
     for (int p = 0; p < parts; p++) {
@@ -1106,8 +1089,7 @@ int main(int argc, char** argv)
     // to a worker for the mapping.  The inflated text never crosses the link -- the host moves compressed bytes and tails only.
     Chan<bmbs_ctx*> ctx_pool;
     auto z_mode = [&](Part* pt) { return pt->s1.zdirect && (!pe || pt->s2.zdirect); };
-    auto g_mode = [&](Part* pt) { return pt->s1.gdirect && (!pe || pt->s2.gdirect); };
-    if (live_parts == 1 && (z_mode(P_[0].get()) || g_mode(P_[0].get()))) for (bmbs_ctx* c : ctxs) ctx_pool.put(c);
+    if (live_parts == 1 && z_mode(P_[0].get())) for (bmbs_ctx* c : ctxs) ctx_pool.put(c);
     // true: the input is finished (or failed); false: go on with the host-window reader (a member that is not a BGZF block turned up)
     auto reader_z = [&](Part* pt, Pool& pool, Pool& pool2) -> bool {
         size_t est = est0;
@@ -1228,157 +1210,9 @@ int main(int argc, char** argv)
             if (end) return true;
         }
     };
-    // ordinary .gz members (ONE deflate stream per file) on the device: a window = the compressed bytes from the block boundary the
-    // last call reached; the call says where its chain of spans stopped and hands back the 32 KiB behind that point.  A stretch the
-    // device declines (a block that inflates to more than a span's slot holds, stored blocks) is inflated here, block by block, and
-    // travels as part of the next window's prefix.  Member trailers (CRC-32, ISIZE) are checked here from the windows' CRCs.
-    auto reader_g = [&](Part* pt, Pool& pool, Pool& pool2) {
-        size_t est = est0;
-        Pinned tails[2]; tails[0].kind = 2; tails[1].kind = 2;
-        size_t tail_cap = (size_t)4 << 20;
-        if (const char* tv = getenv("BMBS_Z_TAIL")) { const long v = atol(tv); if (v >= 1) tail_cap = (size_t)v; }      // tests: the growth path
-        if (!tails[0].need(tail_cap) || (pe && !tails[1].need(tail_cap))) { fail("cannot allocate page-locked staging memory"); return; }
-        Source* S[2] = {&pt->s1, &pt->s2};
-        const int nf = pe ? 2 : 1;
-        double cr[2] = {0.3, 0.3};                                   // compressed bytes per byte of text, learned window by window
-        unsigned char wout[2][32768];
-        const size_t margin = (size_t)256 << 10;                     // a block's worth of bytes kept behind the last block a call may enter
-        size_t win_mb = 0;
-        if (const char* wv = getenv("BMBS_GZ_DEV_WINDOW")) win_mb = (size_t)atol(wv);      // tests: compressed bytes per call
-        // the next member of a file (or its end): trailer checked, the stream state reset
-        auto member_end = [&](Source& s) -> bool {
-            const size_t tr = (size_t)((s.gbit + 7) >> 3);
-            if (tr + 8 > s.zsize) { s.err = "gzip trailer missing in the .gz input"; return false; }
-            const unsigned char* t = s.zmap + tr;
-            const uint32_t crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
-            const uint32_t isz = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
-            if (crc != s.gcrc || isz != (uint32_t)s.glen) { s.err = "CRC or length error in the .gz input"; return false; }
-            const size_t nxt = pgz::gzip_header(s.zmap, s.zsize, tr + 8);          // no further member: the rest is ignored, as gzread does
-            if (!nxt) { s.gdone = true; return true; }
-            s.gbit = (uint64_t)nxt * 8; s.gwin.clear(); s.gcrc = 0; s.glen = 0;
-            return true;
-        };
-        for (;;) {
-            const double tw0 = now();
-            Batch* b = free_q.get();
-            bmbs_ctx* ctx = ctx_pool.get();
-            const double t0 = now();
-            pt->t_wait_r += t0 - tw0;
-            b->part = pt; b->seq = pt->next_seq++; b->n = 0; b->end = false; b->used1 = b->used2 = 0; b->sam_bytes = 0; b->open_ctx = nullptr;
-            auto bail = [&](const std::string& why) { fail(why); b->end = true; b->n = 0; ctx_pool.put(ctx); gpu_q.put(b); };
-            if (failed) { b->end = true; ctx_pool.put(ctx); gpu_q.put(b); return; }
-            const size_t target = std::min<size_t>((size_t)batch * est + (1u << 16), (size_t)3500 << 20);
-            bmbs_gztext g[2]; memset(g, 0, sizeof g);
-            size_t a[2] = {0, 0}, took[2] = {0, 0};
-            size_t text_bytes = 0;
-            for (int f = 0; f < nf; f++) {
-                Source& s = *S[f];
-                g[f].prefix = s.carry.empty() ? nullptr : s.carry.data(); g[f].prefix_bytes = s.carry.size();
-                g[f].win_out = wout[f];
-                text_bytes += s.carry.size();
-                if (s.gdone) continue;
-                a[f] = (size_t)(s.gbit >> 3);
-                const size_t room = target > s.carry.size() ? target - s.carry.size() : 0;
-                size_t want = win_mb ? win_mb : (size_t)((double)room * cr[f]) + margin;
-                if (!room) want = 0;
-                want = std::min(want, (size_t)GZ_WINDOW_MAX);
-                const size_t have = s.zsize - a[f];
-                const bool to_end = want >= have;
-                took[f] = to_end ? have : want;
-                if (!took[f]) continue;
-                if (!s.gstage.need(took[f] + 64)) { bail("cannot allocate page-locked staging memory"); return; }
-                Pool& pl = f ? pool2 : pool;
-                const int T = std::max(1, pl.size() * 2);
-                const size_t zb = took[f], per = ((zb + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
-                char* dst = s.gstage.p; const unsigned char* src = s.zmap + a[f];
-                pl.run(T, [&](int t) { const size_t x = std::min(zb, per * (size_t)t), y = std::min(zb, x + per); if (x < y) memcpy(dst + x, src + x, y - x); });
-                g[f].comp = s.gstage.p; g[f].comp_bytes = took[f]; g[f].start_bit = (uint32_t)(s.gbit & 7);
-                g[f].limit_bytes = to_end ? took[f] : (took[f] > margin ? took[f] - margin : took[f]);
-                g[f].win = s.gwin.empty() ? nullptr : s.gwin.data(); g[f].win_len = (uint32_t)s.gwin.size();
-            }
-            int64_t nrec = 0; uint64_t tb[2] = {0, 0};
-            int rc = bmbs_text_open_gzip(ctx, &g[0], pe ? &g[1] : nullptr, 4 * (int64_t)batch, 0, 0, &nrec, tails[0].p, tail_cap, &tb[0], pe ? tails[1].p : nullptr, &tb[1]);
-            if (rc == BMBS_ENOMEM && std::max(tb[0], tb[1]) > tail_cap) {
-                tail_cap = (size_t)std::max(tb[0], tb[1]) + ((size_t)4 << 20);
-                if (!tails[0].need(tail_cap) || (pe && !tails[1].need(tail_cap))) { bail("cannot allocate page-locked staging memory"); return; }
-                rc = bmbs_text_open_gzip(ctx, &g[0], pe ? &g[1] : nullptr, 4 * (int64_t)batch, 0, 0, &nrec, tails[0].p, tail_cap, &tb[0], pe ? tails[1].p : nullptr, &tb[1]);
-            }
-            if (rc) { bail(bmbs_last_error(ctx)); return; }
-            bool all_done = true, closed_a_line = false;
-            for (int f = 0; f < nf; f++) {
-                Source& s = *S[f];
-                s.carry.assign(tails[f].p, tails[f].p + tb[f]);
-                if (!s.gdone && took[f]) {
-                    text_bytes += (size_t)g[f].text_bytes;
-                    if (g[f].text_bytes || g[f].final_block) {
-                        s.gcrc = (uint32_t)crc32_combine(s.gcrc, g[f].crc32, (z_off_t)g[f].text_bytes); s.glen += g[f].text_bytes;
-                        const uint64_t used_bits = g[f].end_bit - (s.gbit & 7);
-                        if (g[f].text_bytes) cr[f] = std::min(1.5, std::max(0.01, (double)(used_bits / 8) / (double)g[f].text_bytes));
-                        s.gbit = (uint64_t)a[f] * 8 + g[f].end_bit;
-                        s.gwin.assign(wout[f], wout[f] + g[f].win_out_len);
-                        if (g[f].final_block && !member_end(s)) { bail(s.err); return; }
-                    } else {
-                        // the device could not confirm a single span here: a few blocks on the host, from the same boundary with the same window
-                        std::unique_ptr<pgz::Tables> dyn(new pgz::Tables);
-                        for (int blk = 0; blk < 4 && !s.gdone; blk++) {
-                            pgz::OutBuf<pgz::u8> ob;
-                            if (!ob.reserve((size_t)1 << 20)) { bail("out of memory"); return; }
-                            memset(ob.mem, 0, pgz::WIN);
-                            if (!s.gwin.empty()) memcpy(ob.mem + (pgz::WIN - s.gwin.size()), s.gwin.data(), s.gwin.size());
-                            std::vector<pgz::MemberEnd> ends;
-                            pgz::DecodeResult r; r.st = pgz::ST_ERROR; r.end_bit = s.gbit; r.why = "";
-                            try { r = pgz::decode_blocks<pgz::u8>(s.zmap, s.zsize, s.gbit, ~(pgz::u64)0, ob, ends, *dyn, 1); } catch (const std::exception&) { r.st = pgz::ST_ERROR; r.why = "out of memory"; }
-                            if (r.st == pgz::ST_ERROR || (r.st == pgz::ST_BOUNDARY && r.end_bit == s.gbit && ends.empty())) {
-                                bail(std::string("corrupt deflate data in the .gz input") + (r.why && *r.why ? std::string(": ") + r.why : "")); return;
-                            }
-                            const size_t n = ob.n;
-                            s.carry.insert(s.carry.end(), (const char*)ob.out(), (const char*)ob.out() + n);
-                            s.gcrc = (uint32_t)crc32(s.gcrc, (const Bytef*)ob.out(), (uInt)n); s.glen += n;
-                            const size_t keep = std::min<size_t>(pgz::WIN, s.gwin.size() + n);
-                            std::vector<unsigned char> w(ob.mem + pgz::WIN + n - keep, ob.mem + pgz::WIN + n);
-                            s.gwin.swap(w);
-                            if (!ends.empty()) {
-                                // the member's final block: its trailer was read by the decoder
-                                if (ends[0].crc != s.gcrc || ends[0].isize != (uint32_t)s.glen) { bail("CRC or length error in the .gz input"); return; }
-                                if (r.st == pgz::ST_END) s.gdone = true;
-                                else { s.gbit = r.end_bit; s.gwin.clear(); s.gcrc = 0; s.glen = 0; }
-                                break;
-                            }
-                            s.gbit = r.end_bit;
-                        }
-                    }
-                }
-                // a file that has ended with a line that is not closed: the reader's rule -- it counts as a line
-                if (s.gdone && !s.carry.empty() && s.carry.back() != '\n') { s.carry.push_back('\n'); closed_a_line = true; }
-                if (!s.gdone || !s.carry.empty()) all_done = false;
-            }
-            // the part's input ends with this batch when a file has nothing left behind it (PE: the shorter file decides)
-            bool any_end = false;
-            for (int f = 0; f < nf; f++) if (S[f]->gdone && S[f]->carry.empty()) any_end = true;
-            b->end = any_end;
-            if (nrec == 0) {
-                // nothing new was given and nothing came out: a trailing fragment that is not a whole record
-                const bool stuck = !took[0] && !took[1] && !closed_a_line;
-                if (all_done || b->end) { b->end = true; ctx_pool.put(ctx); gpu_q.put(b); return; }
-                if (stuck) { b->end = true; ctx_pool.put(ctx); gpu_q.put(b); return; }
-                pt->next_seq--; ctx_pool.put(ctx); free_q.put(b);
-                continue;
-            }
-            est = std::max<size_t>(64, text_bytes / (size_t)nf / (size_t)nrec + 16);
-            b->n = nrec; b->open_ctx = ctx;
-            const int Lg = (int)std::min<size_t>(1000, est / 2);
-            if (!b->sam.need(sam_bound(text_bytes, (size_t)nrec * (pe ? 2 : 1), Lg))) { bail("cannot allocate page-locked staging memory"); return; }
-            pt->t_read += now() - t0;
-            pt->records += nrec;
-            const bool end = b->end;
-            gpu_q.put(b);
-            if (end) return;
-        }
-    };
     auto reader_fn = [&](Part* pt) {
         Pool pool(r_threads - 1);
         Pool pool2(pe && pt->s2.gz ? std::max(1, r_threads / 2) - 1 : 0);          // second mate's window of compressed input
-        if (live_parts == 1 && g_mode(pt)) { reader_g(pt, pool, pool2); return; }
         if (live_parts == 1 && z_mode(pt) && reader_z(pt, pool, pool2)) return;
         size_t est = est0;
         for (;;) {

@@ -18,7 +18,10 @@
 //
 // Everything zlib's inflate refuses is refused here (over-subscribed or incomplete codes, missing end-of-block code, distance too
 // far back, reserved block type, stored-block length check, trailer mismatch), multi-member files and trailing garbage are handled
-// as gzread does.  The scheme is the published one of pugz / rapidgzip (two-pass decoding with window markers); no code of either.
+// as gzread does.  One case is caught later than zlib catches it: a match of a LATER member of a multi-member file that reaches back
+// past its member's start is refused at once when the member began inside the stretch being decoded (OutBuf::mstart), and by the
+// member's CRC-32 / length check when it began in an earlier stretch (the 32 KiB window handed from stretch to stretch does not
+// carry where the member began).  The scheme is the published one of pugz / rapidgzip (two-pass decoding with window markers); no code of either.
 #ifndef BMBS_PGZ_H
 #define BMBS_PGZ_H
 #include <stdint.h>
@@ -316,6 +319,9 @@ static bool read_dynamic(BitIn& in, Tables& T)
 // ---- output of a decoding task: symbols of type S behind a 32 Ki prefix (the window in front of the task) ------------------------
 template <class S> struct OutBuf {
     S* mem = nullptr; size_t cap = 0, n = 0;          // mem[0, WIN) = the window, mem[WIN + i] = output symbol i
+    // how far back a match may reach: to output symbol `mstart` (where the member being decoded began, if it began in this buffer),
+    // and `reach` symbols into the window in front of the buffer while no member has begun in it (zlib: "invalid distance too far back")
+    size_t mstart = 0, reach = WIN;
     ~OutBuf() { free(mem); }
     OutBuf() {}
     OutBuf(const OutBuf&) = delete; OutBuf& operator=(const OutBuf&) = delete;
@@ -415,7 +421,7 @@ static DecodeResult decode_blocks(const u8* data, size_t size, u64 start_bit, u6
                     if (e_kind(d) != K_BASE) { r.why = "invalid distance code"; return r; }
                     in.drop((int)e_bits(d));
                     const u32 dist = e_val(d) + in.take((int)e_extra(d));
-                    if ((u64)dist > n + WIN) { r.why = "distance too far back"; return r; }
+                    if ((u64)dist > n - ob.mstart + ob.reach) { r.why = "distance too far back"; return r; }
                     S* dst = o + n; const S* src = dst - dist;
                     const u32 step = 16 / sizeof(S);                         // elements per 16-byte move
                     if (dist >= step) {
@@ -446,6 +452,7 @@ static DecodeResult decode_blocks(const u8* data, size_t size, u64 start_bit, u6
             const size_t nxt = gzip_header(data, size, (size_t)byte + 8);        // no further member: the rest is ignored, as gzread does
             if (!nxt) { r.st = ST_END; r.end_bit = (byte + 8) * 8; return r; }
             in.init(data, size, (u64)nxt * 8);
+            ob.mstart = ob.n; ob.reach = 0;                                      // the next member's matches stay inside the member
         }
     }
 }
