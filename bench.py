@@ -325,7 +325,7 @@ def cpu_baseline(args, cfg, fa, host_reads, L, tag="cpu_sample"):
                 load = float(line.split()[1]); secs = float(line.split()[2])   # "Total: <load s> <map s>" (Bitmapper_main.cpp:262)
         if p.returncode == 0 and secs and secs > 0:
             nr = n * (2 if pe else 1)
-            return {"value": round(nr / secs / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "reference",
+            return {"value": round(nr / secs / 1e6, 4), "unit": "Mreads/s", "cores": cores, "cpu_quota_cores": cpu_quota_cores(), "kind": "reference",
                     "sample": sample + ", bitmapperBS -t %d, mapping seconds as printed by main (%.1f s; index load %.1f s; wall %.1f s)" % (
                         cores, secs, load, wall)}, out
         sys.stderr.write("[bench] reference run failed (rc %d): %s\n" % (p.returncode, p.stderr[-400:]))
@@ -755,49 +755,103 @@ def write_bgzf(path, data, level=1, threads=16):
         f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
 
 
-def gz_input_rate(args, drv, fa, cfg, files, inp, rec_bytes, big=None, inp_big=None):
-    """bgzf: the same files as the other keys (the sample REP times over) as bgzip-style blocks; plain_gzip: the first 2.5 M records of
-    the sample as one gzip member per file (what one `gzip -1` process per file writes in the time the bench can spare)"""
+def write_gzip_one_member(path, src, level=1, threads=16, piece=8 << 20):
+    """ONE gzip member (one deflate stream) holding the bytes of file `src`, written the way pigz does it: pieces deflated side by side,
+    each ended by a sync flush (an empty stored block: the piece ends on a byte boundary), the last one by the final block; CRC-32
+    over the whole text in the trailer.  A single `gzip -1` process would take minutes for the bench's 6 GB files."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    size = os.path.getsize(src)
+    offs = list(range(0, size, piece)) or [0]
+
+    def one(a):
+        with open(src, "rb") as f:
+            f.seek(a)
+            chunk = f.read(piece)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        z = co.compress(chunk) + (co.flush(zlib.Z_FINISH) if a + piece >= size else co.flush(zlib.Z_SYNC_FLUSH))
+        return z, chunk
+    crc = 0
+    with open(path, "wb") as o, ThreadPoolExecutor(threads) as ex:
+        o.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\xff")
+        for z, chunk in ex.map(one, offs):
+            o.write(z)
+            crc = zlib.crc32(chunk, crc)
+        o.write(struct.pack("<II", crc & 0xffffffff, size & 0xffffffff))
+
+
+def driver_run(drv, fa, inp, cfg, extra, env=None):
+    """one bmbs_search run -> (mapping wall seconds, the driver's own busy fractions, its stage lines) from --verbose"""
+    p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "--verbose"] + extra, capture_output=True, text=True, env=env)
+    if p.returncode:
+        raise RuntimeError(p.stderr[-300:])
+    lines = [x[len("[bmbs_search] "):] for x in p.stderr.splitlines() if x.startswith("[bmbs_search]")]
+    wall = float([x for x in lines if x.startswith("records") and "mapping wall" in x][-1].split("mapping wall")[1].split("s")[0])
+    busy = {}
+    for x in lines:
+        if x.startswith("busy fractions"):
+            t = x.split(":", 1)[1]
+            for key, tag in (("link_up", "link up "), ("link_down", "link down "), ("gpu_workers", "gpu workers "), ("readers", "readers "), ("writers", "writers ")):
+                busy[key] = float(t.split(tag)[1].split(",")[0].split(" ")[0])
+    return wall, busy, " | ".join(lines)[:1100]
+
+
+def e2e_key(n_reads, wall, busy, stages, loops=1):
+    d = {"value": round(n_reads / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n_reads), "input_passes": loops, "busy": busy}
+    if busy:
+        d["bound"] = max(busy, key=busy.get)
+    if stages:
+        d["stages"] = stages
+    return d
+
+
+def gz_input_rate(args, drv, fa, cfg, big, inp_big, rec_bytes, loops):
+    """compressed input, the SAME records for every key (the sample REP times over): `bgzf` = bgzip-style blocks, inflated on the device
+    (read `loops` times over: --loop-input), `plain_gzip` = one gzip member per file, inflated by the host's block-parallel inflater"""
     out = {}
-    n_plain = 2_500_000                                # records of the one-member gzip files (compressed by one gzip process each)
+    n = os.path.getsize(big[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     for label in ("bgzf", "plain_gzip"):
         gzf = []
-        procs = []
-        srcs = big if label == "bgzf" and big else files
-        for src in srcs:
+        for src in big:
             dst = src + (".bgzf.gz" if label == "bgzf" else ".plain.gz")
             if label == "bgzf":
                 with open(src, "rb") as f:
                     write_bgzf(dst, f.read())
             else:
-                procs.append(subprocess.Popen("head -c %d %s | gzip -1 -c > %s" % (n_plain * rec_bytes, src, dst), shell=True))
+                write_gzip_one_member(dst, src)
             gzf.append(dst)
-        for pr in procs:
-            pr.wait()
-        n = (os.path.getsize(srcs[0]) // rec_bytes if label == "bgzf" else n_plain) * (2 if cfg["pe"] else 1)
-        a = [gzf[srcs.index(x)] if x in srcs else x for x in (inp_big if srcs is big else inp)]
-        # bgzip-style blocks are inflated on the device; one-member gzip by the host's block-parallel inflater on the driver's default
-        # thread count for compressed input
-        runs = [(label, None)]
-        if label == "plain_gzip":               # the same files through the device's span decoder (exact, not the default: DESIGN.md section 7)
-            runs.append(("plain_gzip_device", dict(os.environ, BMBS_GZ_DEVICE="2")))
-        for key, env in runs:
-            p = subprocess.run([drv, "--search", fa] + a + ["-e", str(cfg["e"]), "-o", "/dev/null", "--verbose"] + (["-t", "32"] if key != "plain_gzip" else []),
-                               capture_output=True, text=True, env=env)
-            if p.returncode:
-                out[key] = {"error": p.stderr[-300:]}
-                continue
-            line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
-            wall = float(line.split("mapping wall")[1].split("s")[0])
-            out[key] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n)}
+        a = [gzf[big.index(x)] if x in big else x for x in inp_big]
+        k = loops if label == "bgzf" else 1
+        try:
+            wall, busy, stages = driver_run(drv, fa, a, cfg, ["-o", "/dev/null"] + (["-t", "32", "--loop-input", str(k)] if label == "bgzf" else []))
+            out[label] = e2e_key(n * k, wall, busy, None, k)
+        except RuntimeError as ex:
+            out[label] = {"error": str(ex)}
         for f in gzf:
             os.unlink(f)
     return out
 
 
+def cpu_quota_cores():
+    """cores' worth of CPU time the container grants a process group (cgroup v2 cpu.max, v1 cfs quota), None when unlimited / unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except Exception:
+        return None
+
+
 def file_to_file_rate(args, cfg, fa, L):
-    """FASTQ file(s) -> SAM file through bitmapperbs_amd/bmbs_search (the drop-in driver) on the cpu_baseline sample files; the
-    SAM goes to --workdir's file system and, second run, to /dev/null (one buffered file takes ~10.5 GB/s on these boxes)"""
+    """FASTQ file(s) -> SAM / BAM file through bitmapperbs_amd/bmbs_search (the drop-in driver).  Input: the cpu_baseline sample REP times
+    over (20 M pairs on configs[2]), which the driver reads `input_passes` times (--loop-input, a measurement aid) so that every key
+    maps for seconds, not for the half second in which the pipeline's fill and the contexts' first calls are a fifth of the wall; the
+    keys that write a real file take fewer passes (the box's disk) and report the median of three runs."""
     drv = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
     if cfg["pe"]:
         files = [os.path.join(args.workdir, "cpu_sample_1.fq"), os.path.join(args.workdir, "cpu_sample_2.fq")]
@@ -808,8 +862,6 @@ def file_to_file_rate(args, cfg, fa, L):
     if not os.path.exists(drv) or not all(os.path.exists(f) for f in files):
         return None
     rec_bytes = 2 * L + 15                      # write_fastq_sample: '@s%08d\n' + L + '\n+\n' + L + '\n'
-    # the cpu_baseline sample four times over (20 M pairs on configs[2]: 12.6 GB of FASTQ, 14.4 GB of SAM): the pipeline needs ~0.1 s to
-    # fill (first batch read, first calls of every context), which a run of 0.15 s mostly measures
     REP = 4
     big = [f[:-3] + "_x%d.fq" % REP for f in files]
     for src, dst in zip(files, big):
@@ -822,43 +874,46 @@ def file_to_file_rate(args, cfg, fa, L):
                             break
                         o.write(blk)
     os.sync()           # the inputs just written are dirty pages: left there, they count against the writers of the runs below
-    inp0 = list(inp)
     inp = [big[files.index(x)] if x in files else x for x in inp]
     n = os.path.getsize(big[0]) // rec_bytes * (2 if cfg["pe"] else 1)
     out = {}
     parts = 8
+    sam = os.path.join(args.workdir, "f2f.sam")
     # (the run that writes most files goes first: 14 GB of dirty pages from an earlier run made the box throttle the next writer)
-    for label, dst, extra in (("file_%d_parts" % parts, os.path.join(args.workdir, "f2f.sam"), ["--out-parts", str(parts)]),
-                              ("null_sink", "/dev/null", []),
-                              ("file", os.path.join(args.workdir, "f2f.sam"), []),
-                              # --bam (the reference's documented invocation, README.md:44): records and BGZF blocks made on the device
-                              ("bam", os.path.join(args.workdir, "f2f.sam"), ["--bam"]),
-                              ("bam_null_sink", "/dev/null", ["--bam"])):
-        p = subprocess.run([drv, "--search", fa] + inp + ["-e", str(cfg["e"]), "-o", dst, "-t", "32", "--verbose"] + extra, capture_output=True, text=True)
-        if p.returncode:
-            return {"error": p.stderr[-300:]}
-        line = [x for x in p.stderr.splitlines() if x.startswith("[bmbs_search]") and "mapping wall" in x][-1]
-        wall = float(line.split("mapping wall")[1].split("s")[0])
-        out[label] = {"value": round(n / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n),
-                      "stages": " | ".join(x[len("[bmbs_search] "):] for x in p.stderr.splitlines() if x.startswith("[bmbs_search]"))[:900]}
-        for k in range(parts):
-            f = os.path.join(args.workdir, "f2f.sam.part%03d" % k)
-            if os.path.exists(f):
-                os.unlink(f)
-    # gzipped input: bgzip-style files (independent 64 KiB blocks: inflated by several threads per file) and ordinary one-member
-    # gzip files (one inflate thread per file, both mates side by side); -o /dev/null
+    for label, dst, extra, loops, runs in (("file_%d_parts" % parts, sam, ["--out-parts", str(parts)], 1, 3),
+                                          ("null_sink", "/dev/null", [], 8, 1),
+                                          ("file", sam, [], 1, 3),
+                                          # --bam (the reference's documented invocation, README.md:44): records and BGZF blocks made on the device
+                                          ("bam", sam, ["--bam"], 3, 1),
+                                          ("bam_null_sink", "/dev/null", ["--bam"], 8, 1)):
+        got = []
+        try:
+            for _ in range(runs):
+                got.append(driver_run(drv, fa, inp, cfg, ["-o", dst, "-t", "32", "--loop-input", str(loops)] + extra))
+                for f in [sam] + [os.path.join(args.workdir, "f2f.sam.part%03d" % k) for k in range(parts)]:
+                    if os.path.exists(f):
+                        os.unlink(f)            # (the boxes' scratch disk holds one such output beside the inputs, not two)
+        except RuntimeError as ex:
+            return {"error": str(ex)}
+        got.sort(key=lambda g: g[0])
+        wall, busy, stages = got[len(got) // 2]
+        out[label] = e2e_key(n * loops, wall, busy, stages, loops)
+        if runs > 1:
+            out[label]["runs_Mreads_s"] = [round(n * loops / g[0] / 1e6, 2) for g in got]
     try:
-        out["gz_input"] = gz_input_rate(args, drv, fa, cfg, files, inp0, rec_bytes, big, inp)
+        out["gz_input"] = gz_input_rate(args, drv, fa, cfg, big, inp, rec_bytes, 6)
     except Exception as ex:
         out["gz_input"] = {"error": repr(ex)}
-    for f in [os.path.join(args.workdir, "f2f.sam")] + big:
+    for f in [sam] + big:
         if os.path.exists(f):
             os.unlink(f)
-    out["what"] = ("bmbs_search, FASTQ -> SAM, 1 GPU, 32 host I/O threads, the cpu_baseline sample %d times over, index load + attach excluded "
-                   "(as the reference's own 'mapping time'); newline index and SAM text on the device, the host only reads and writes; "
-                   "`file` = one output file, `file_%d_parts` = --out-parts %d (as many inodes written at once), `null_sink` = -o /dev/null, "
-                   "`bam` / `bam_null_sink` = --bam (BAM records and BGZF blocks made on the device); gz_input: `bgzf` inflated on the device, "
-                   "`plain_gzip` (one deflate stream per file) by the host's block-parallel inflater, `plain_gzip_device` by the device's span decoder (BMBS_GZ_DEVICE=2)" % (REP, parts, parts))
+    out["what"] = ("bmbs_search, FASTQ -> SAM / BAM, 1 GPU, 32 host I/O threads, the cpu_baseline sample %d times over read `input_passes` times (--loop-input), "
+                   "index load + attach excluded (as the reference's own 'mapping time'); newline index and SAM text / BAM blocks on the device, the host only "
+                   "reads and writes; `file` = one output file, `file_%d_parts` = --out-parts %d, `null_sink` = -o /dev/null, `bam` / `bam_null_sink` = --bam; "
+                   "gz_input (same records, /dev/null): `bgzf` inflated on the device, `plain_gzip` (one deflate stream per file, written pigz-style) by the "
+                   "host's block-parallel inflater; `busy` = fraction of the mapping wall the link was held per direction (copies of the text calls), the "
+                   "GPU worker threads were inside calls, the readers / writers were at work; `bound` = the largest of them; keys with "
+                   "`runs_Mreads_s` are the median of three runs" % (REP, parts, parts))
     return out
 
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
-    "bmbs_max_cigar_ops", "bmbs_host_prefault", "bmbs_reserve", "bmbs_host_alloc_kind", "bmbs_retries", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset", "bmbs_inflate_bgzf", "bmbs_inflate_gzip", "bmbs_debug_huff_lengths", "bmbs_text_open_bgzf", "bmbs_text_open_gzip", "bmbs_text_map_open",
+    "bmbs_max_cigar_ops", "bmbs_host_prefault", "bmbs_reserve", "bmbs_host_alloc_kind", "bmbs_retries", "bmbs_text_times", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset", "bmbs_inflate_bgzf", "bmbs_debug_huff_lengths", "bmbs_text_open_bgzf", "bmbs_text_map_open",
 ]
 
 
@@ -41,13 +41,6 @@ class FastqView(C.Structure):
 class ZText(C.Structure):
     _fields_ = [("prefix", C.c_void_p), ("prefix_bytes", C.c_uint64), ("comp", C.c_void_p), ("comp_bytes", C.c_uint64),
                 ("blk_off", C.c_void_p), ("out_off", C.c_void_p), ("n_blocks", C.c_int64)]
-
-
-class GzText(C.Structure):
-    _fields_ = [("prefix", C.c_void_p), ("prefix_bytes", C.c_uint64), ("comp", C.c_void_p), ("comp_bytes", C.c_uint64),
-                ("start_bit", C.c_uint32), ("limit_bytes", C.c_uint64), ("win", C.c_void_p), ("win_len", C.c_uint32),
-                ("end_bit", C.c_uint64), ("final_block", C.c_int32), ("crc32", C.c_uint32), ("text_bytes", C.c_uint64),
-                ("win_out", C.c_void_p), ("win_out_len", C.c_uint32)]
 
 
 class IndexView(C.Structure):
@@ -154,12 +147,8 @@ def lib() -> C.CDLL:
     L.bmbs_map_se_text.argtypes = [vp, vp, u64, i64, i32, vp, u64, C.POINTER(u64), C.POINTER(i64)]
     L.bmbs_inflate_bgzf.argtypes = [vp, vp, u64, vp, vp, i64, vp, u64, vp, u64]
     L.bmbs_inflate_bgzf.restype = C.c_int
-    L.bmbs_text_open_gzip.argtypes = [vp, vp, vp, i64, C.c_int32, C.c_int32, vp, vp, u64, vp, vp, vp]
-    L.bmbs_text_open_gzip.restype = C.c_int
     L.bmbs_debug_huff_lengths.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     L.bmbs_debug_huff_lengths.restype = C.c_int
-    L.bmbs_inflate_gzip.argtypes = [vp, vp, u64, C.c_uint32, u64, vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp]
-    L.bmbs_inflate_gzip.restype = C.c_int
     L.bmbs_text_open_bgzf.argtypes = [vp, C.POINTER(ZText), C.POINTER(ZText), i64, i32, i32, C.POINTER(i64), vp, u64, C.POINTER(u64), vp, C.POINTER(u64)]
     L.bmbs_text_open_bgzf.restype = C.c_int
     L.bmbs_text_map_open.argtypes = [vp, i32, vp, u64, C.POINTER(u64), C.POINTER(i64)]

@@ -144,14 +144,12 @@ struct Lane {
     DevBuf big_list;                                    // reads whose lists exceed the wave form of k_vote_[pe_]long
     DevBuf wavelog_buf, wavelog_count; std::string wavelog_path;    // BMBS_WAVELOG diagnostic
     DevBuf prow, prow_dirty;                            // packed copy of the read rows (k_pack_rows), one dirty byte per read
+    double link_up_s = 0, link_down_s = 0, text_call_s = 0; u64 text_calls = 0;       // bmbs_text_times: wall seconds the text calls' copies held the link
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // bmbs_map_*_text: newline index built on the device, SAM text written on the device
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
     DevBuf bam_raw, bam_tok, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
     DevBuf z_comp, z_off, z_text, z_err, z_nl, z_comp2, z_off2, z_err2;          // bmbs_inflate_bgzf; (…2: mate 2 of bmbs_text_open_bgzf)
-    DevBuf gz_map, gz_wgrp, gz_have, gz_map2, gz_wgrp2, gz_have2;               // (window chain: span maps, group windows, bytes of each window that exist)
-    DevBuf gz_start, gz_sym, gz_res, gz_wall, gz_off, gz_info, gz_crc;          // bmbs_inflate_gzip: span starts, 16-bit symbols, results, windows, text offsets, CRCs per 64 KiB
-    DevBuf gz_start2, gz_sym2, gz_res2, gz_wall2, gz_off2, gz_info2, gz_crc2;   // (mate 2 of bmbs_text_open_gzip)
     struct OpenText { bool valid = false, pe = false; u64 bytes1 = 0, bytes2 = 0; int64_t n = 0; } open_text;      // between bmbs_text_open_bgzf and bmbs_text_map_open
     u32* h_info = nullptr;                              // page-locked: 8 info words + 4 totals of the text path
     int n_refs = 0, max_ref_len = 0;
@@ -177,7 +175,6 @@ struct Lane {
     // first call of a lane waits for its counts); the pinned words the device leaves its counts and guard flags in; the call in flight
     double lr_cand = 0, lr_sw = 0, lr_rcand = 0, lr_long = 0;
     u64* h_tot = nullptr;                      // page-locked: per call in flight, totals[16] followed by the flag words (call_end)
-    u8* h_gz = nullptr;                        // page-locked, 192 KiB: what bmbs_text_open_gzip brings back (two windows, CRCs per 64 KiB)
     std::deque<Pending> inflight;
     int next_slot = 0;
     u64 n_retries = 0;
@@ -858,13 +855,9 @@ void lane_destroy(Lane* c)
     for (auto& set : c->profset) for (auto& p : set) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->arena.free_all();
     if (c->h_tot) (void)hipHostFree(c->h_tot);
-    if (c->h_gz) (void)hipHostFree(c->h_gz);
     if (c->h_info) (void)hipHostFree(c->h_info);
     { DevBuf* tx[] = {&c->tx_tilecnt, &c->tx_tileoff, &c->tx_nl[0], &c->tx_nl[1], &c->tx_rec[0], &c->tx_rec[1], &c->tx_info, &c->sam_len, &c->sam_off, &c->sam_out, &c->chrom_chars, &c->chrom_off, &c->big_list,
-                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl, &c->z_comp2, &c->z_off2, &c->z_err2,
-                     &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info, &c->gz_crc,
-                     &c->gz_start2, &c->gz_sym2, &c->gz_res2, &c->gz_wall2, &c->gz_off2, &c->gz_info2, &c->gz_crc2,
-                     &c->gz_map, &c->gz_wgrp, &c->gz_have, &c->gz_map2, &c->gz_wgrp2, &c->gz_have2};
+                     &c->bam_raw, &c->bam_tok, &c->bam_slots, &c->bam_slot_len, &c->bam_off, &c->stats_snap, &c->z_comp, &c->z_off, &c->z_text, &c->z_err, &c->z_nl, &c->z_comp2, &c->z_off2, &c->z_err2};
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
@@ -1959,11 +1952,12 @@ int lane_map_text(Lane* c, bool pe, const char* text1, u64 bytes1, const char* t
         // the link is claimed for the copies alone: the kernels behind them may have to queue behind other contexts' kernels
         std::unique_lock<std::mutex> up(g_h2d_mu[c->dev & 15], std::defer_lock);
         if (c->kn.copy_lock) up.lock();
+        const double t_up0 = wall();
         // on a stream of their own that never carries a kernel (the lane has nothing in flight here: the previous call ended with a wait)
         hipStream_t us = c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream;
         HIPCHK(c, hipMemcpyAsync(c->fq_text1.p, text1, bytes1, hipMemcpyHostToDevice, us));
         if (pe) HIPCHK(c, hipMemcpyAsync(c->fq_text2.p, text2, bytes2, hipMemcpyHostToDevice, us));
-        if (c->kn.copy_lock || us != c->stream) HIPCHK(c, hipStreamSynchronize(us));
+        if (c->kn.copy_lock || us != c->stream) { HIPCHK(c, hipStreamSynchronize(us)); c->link_up_s += wall() - t_up0; }
     }
     const double t_uploaded = trace ? wall() : 0;
     // diagnostic (tools/e2e_trace.sh): BMBS_TEXT_COPY_ONLY=1 moves the bytes of a batch over the link and runs nothing in between
@@ -2139,11 +2133,14 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
             if (c->kn.copy_lock || ds != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
             std::unique_lock<std::mutex> down(g_d2h_mu[c->dev & 15], std::defer_lock);
             if (c->kn.copy_lock) down.lock();
+            const double t_dn0 = wall();
             rc = d2h_chunked(c, sam, c->sam_out.as<char>(), ztotal, ds);
             if (rc) return rc;
             HIPCHK(c, hipStreamSynchronize(ds));
+            c->link_down_s += wall() - t_dn0;
         }
         tp[6] = wall();
+        c->text_call_s += tp[6] - tp[0]; c->text_calls++;
         if (trace)
             fprintf(stderr, "[text/bam] n=%ld in=%.1fMB records=%.1fMB out=%.1fMB  upload %.2f lines+records %.2f rows+map %.2f  len+scan %.2f  write+deflate %.2f  download %.2f  total %.2f ms\n",
                     (long)n2, (double)(bytes1 + bytes2) / 1e6, (double)raw_total / 1e6, (double)ztotal / 1e6, (tp[7] - tp[0]) * 1e3, (tp[2] - tp[7]) * 1e3, (tp[3] - tp[2]) * 1e3, (tp[4] - tp[3]) * 1e3,
@@ -2181,8 +2178,10 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
         rc = d2h_chunked(c, sam, c->sam_out.as<char>(), total, ds);
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(ds));
+        c->link_down_s += wall() - t_dnlock;
     }
     tp[6] = wall();
+    c->text_call_s += tp[6] - tp[0]; c->text_calls++;
     if (trace)
         fprintf(stderr, "[text] n=%ld in=%.1fMB out=%.1fMB  (waits for the link: up %.2f, down %.2f)  upload %.2f lines %.2f  records %.2f  rows+map %.2f  len+scan %.2f  write %.2f  download %.2f  total %.2f ms\n",
                 (long)n2, (double)(bytes1 + bytes2) / 1e6, (double)total / 1e6, (t_uplock - tp[0]) * 1e3, (t_dnlock - t_dnstart) * 1e3, (tp[7] - tp[0]) * 1e3, (tp[1] - tp[7]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3,
@@ -2309,158 +2308,6 @@ int lane_text_open_bgzf(Lane* c, const bmbs_ztext* z1, const bmbs_ztext* z2, int
     DevBuf* texts[2] = {&c->fq_text1, &c->fq_text2};
     return lane_text_open_finish(c, pe, texts, bytes, max_records, n_records, tail1, tail_cap, tail1_bytes, tail2, tail2_bytes, tp, trace ? "bgzf" : nullptr,
                                  (double)(z1->comp_bytes + (z2 ? z2->comp_bytes : 0)) / 1e6);
-}
-
-// ---- one-member gzip kept on the device: the pipeline of bmbs_inflate.hip on one stream ------------------------------------------------
-static u32 host_crc_mult(u32 a, u32 b) { u32 m = 1u << 31, p = 0; for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1; } return p; }
-static u32 host_crc_x8n(u64 n)            // x^(8 n) mod P
-{
-    static u32 x2n[32]; static bool have = false;
-    if (!have) { u32 p = 1u << 30; x2n[0] = p; for (int i = 1; i < 32; i++) { p = host_crc_mult(p, p); x2n[i] = p; } have = true; }
-    u32 p = 1u << 31; int k = 3;
-    while (n) { if (n & 1) p = host_crc_mult(x2n[k & 31], p); n >>= 1; k++; }
-    return p;
-}
-struct GzBufs { DevBuf *comp, *start, *sym, *res, *wall, *off, *info, *crc, *map, *wgrp, *have; };
-struct GzPlan { u32 span, n_spans, cap; u64 lim; };
-static GzPlan gz_plan(u64 comp_bytes, u64 limit_bytes)
-{
-    GzPlan g;
-    g.span = 16384;                                                                 // about one block of zlib's at its fast levels
-    if (const char* sv = getenv("BMBS_GZ_DEV_SPAN")) { const long v = atol(sv); if (v >= 256) g.span = (u32)v; }          // tests: many spans in a small file
-    const u64 lim = std::min<u64>(limit_bytes, comp_bytes);
-    g.n_spans = (u32)std::min<u64>(GZ_MAX_SPANS, std::max<u64>(1, (lim + g.span - 1) / g.span));      // (a window of more spans ends early: the caller comes back)
-    g.cap = std::max<u32>(g.span * 12, 1u << 19);                                   // symbols a span may produce (it ends at the first boundary behind the next cut: a whole block at least)
-    g.lim = std::min<u64>(lim, (u64)g.n_spans * g.span);
-    return g;
-}
-static int gz_reserve(Lane* c, const GzBufs& B, const GzPlan& g, u64 comp_bytes)
-{
-    ENS(c, *B.comp, comp_bytes + 2048); ENS(c, *B.start, (u64)g.n_spans * 4 + 64); ENS(c, *B.sym, (u64)g.n_spans * g.cap * 2 + 64);
-    ENS(c, *B.res, (u64)g.n_spans * sizeof(GzSpan) + 64); ENS(c, *B.wall, ((u64)g.n_spans + 1) * 32768); ENS(c, *B.off, ((u64)g.n_spans + 1) * 8 + 64);
-    ENS(c, *B.info, 64);
-    ENS(c, *B.map, (u64)g.n_spans * 65536 + 64); ENS(c, *B.wgrp, ((u64)g.n_spans / GZ_GROUP + 2) * 32768); ENS(c, *B.have, ((u64)g.n_spans + 2) * 4 + 64);
-    return BMBS_OK;
-}
-// upload, starts, spans, windows on stream st; info_host (8 u64, page-locked) is filled when st has drained
-static int gz_launch(Lane* c, const GzBufs& B, const GzPlan& g, const void* comp, u64 comp_bytes, u32 start_bit, const void* win_in, u32 win_len, hipStream_t st, u64* info_host)
-{
-    HIPCHK(c, hipMemcpyAsync(B.comp->p, comp, comp_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(B.comp->as<u8>() + comp_bytes, 0, 2048, st));
-    HIPCHK(c, hipMemsetAsync(B.wgrp->p, 0, 32768, st));
-    if (win_len) HIPCHK(c, hipMemcpyAsync(B.wgrp->as<u8>() + (32768 - win_len), win_in, win_len, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(B.wall->p, B.wgrp->p, 32768, hipMemcpyDeviceToDevice, st));                 // wall[0] = the caller's window too
-    hipLaunchKernelGGL(k_gz_starts, dim3(g.n_spans), dim3(64), 0, st, B.comp->as<u8>(), comp_bytes, g.n_spans, g.span, start_bit, B.start->as<u32>());
-    hipLaunchKernelGGL(k_gz_spans, dim3(g.n_spans), dim3(64), 0, st, B.comp->as<u8>(), comp_bytes, g.n_spans, g.span, (u32)(g.lim * 8), B.start->as<u32>(),
-                       B.sym->as<u16>(), g.cap, B.res->as<GzSpan>());
-    hipLaunchKernelGGL(k_gz_link, dim3(1), dim3(1024), 0, st, B.res->as<GzSpan>(), B.start->as<u32>(), g.n_spans, start_bit, win_len, B.off->as<u64>(), B.have->as<u32>(), B.info->as<u64>());
-    hipLaunchKernelGGL(k_gz_chain_local, dim3((g.n_spans + GZ_GROUP - 1) / GZ_GROUP), dim3(1024), 0, st, B.sym->as<u16>(), g.cap, B.res->as<GzSpan>(), B.info->as<u64>(), B.map->as<u16>());
-    hipLaunchKernelGGL(k_gz_chain_groups, dim3(1), dim3(1024), 0, st, B.map->as<u16>(), B.info->as<u64>(), B.wgrp->as<u8>());
-    hipLaunchKernelGGL(k_gz_apply, dim3(g.n_spans), dim3(256), 0, st, B.map->as<u16>(), B.wgrp->as<u8>(), B.have->as<u32>(), B.info->as<u64>(), B.wall->as<u8>());
-    HIPCHK(c, hipMemcpyAsync(info_host, B.info->p, 48, hipMemcpyDeviceToHost, st));
-    return BMBS_OK;
-}
-
-int lane_text_open_gzip(Lane* c, bmbs_gztext* g1, bmbs_gztext* g2, int64_t max_records, int32_t last1, int32_t last2, int64_t* n_records,
-                        char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes, char* tail2, uint64_t* tail2_bytes)
-{
-    if (!c) return BMBS_EINVAL;
-    if (n_records) *n_records = 0;
-    if (tail1_bytes) *tail1_bytes = 0;
-    if (tail2_bytes) *tail2_bytes = 0;
-    c->open_text.valid = false;
-    if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
-    if (!g1 || max_records <= 0 || !n_records || !tail1 || !tail1_bytes || (g2 && (!tail2 || !tail2_bytes))) { c->err = "text open: NULL argument"; return BMBS_EINVAL; }
-    HIPCHK(c, hipSetDevice(c->dev));
-    { const int rs = lane_settle(c); if (rs) return rs; }
-    const bool pe = g2 != nullptr;
-    const int nf = pe ? 2 : 1;
-    bmbs_gztext* G[2] = {g1, g2};
-    DevBuf* texts[2] = {&c->fq_text1, &c->fq_text2};
-    const GzBufs B[2] = {{&c->z_comp, &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info, &c->gz_crc, &c->gz_map, &c->gz_wgrp, &c->gz_have},
-                         {&c->z_comp2, &c->gz_start2, &c->gz_sym2, &c->gz_res2, &c->gz_wall2, &c->gz_off2, &c->gz_info2, &c->gz_crc2, &c->gz_map2, &c->gz_wgrp2, &c->gz_have2}};
-    const int32_t last[2] = {last1, last2};
-    static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;
-    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
-    double tp[6] = {wall(), 0, 0, 0, 0, 0};
-    GzPlan plan[2]; u64 text_cap[2] = {0, 0};
-    for (int f = 0; f < nf; f++) {
-        bmbs_gztext* g = G[f];
-        g->end_bit = g->start_bit; g->final_block = 0; g->crc32 = 0; g->text_bytes = 0; g->win_out_len = 0;
-        if ((g->prefix_bytes && !g->prefix) || (g->comp_bytes && !g->comp) || (g->win_len && !g->win) || g->win_len > 32768 || !g->win_out) { c->err = "text open: NULL buffer"; return BMBS_EINVAL; }
-        if (g->comp_bytes + 1 >= (1ull << 29)) { c->err = "text open: a window of a gzip stream has to be smaller than 512 MiB (32-bit bit offsets)"; return BMBS_EINVAL; }
-        if (g->comp_bytes >= 8 && g->start_bit < g->comp_bytes * 8) {
-            plan[f] = gz_plan(g->comp_bytes, g->limit_bytes);
-            const int rc = gz_reserve(c, B[f], plan[f], g->comp_bytes); if (rc) return rc;
-            text_cap[f] = std::max<u64>(g->comp_bytes * 16, (u64)64 << 20);
-        } else plan[f].n_spans = 0;
-        if (g->prefix_bytes + text_cap[f] + 1 >= (1ull << 32)) { c->err = "a text window has to be smaller than 4 GiB (32-bit offsets)"; return BMBS_EINVAL; }
-        ENS(c, *texts[f], g->prefix_bytes + text_cap[f] + 64 + 16);
-    }
-    HIPCHK(c, hipMemsetAsync(c->tx_info.p, 0, 64, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const double t_res = wall();
-    // each file on a stream of its own: the two files' spans decode side by side
-    hipStream_t fs[2] = {c->stream, c->kn.copy_streams && c->up_stream ? c->up_stream : c->stream};
-    u64* info_host = reinterpret_cast<u64*>(c->h_tot);                             // (page-locked words of the lane that nothing else uses during a text call)
-    for (int f = 0; f < nf; f++) {
-        bmbs_gztext* g = G[f];
-        if (g->prefix_bytes) HIPCHK(c, hipMemcpyAsync(texts[f]->p, g->prefix, g->prefix_bytes, hipMemcpyHostToDevice, fs[f]));
-        if (plan[f].n_spans) { const int rc = gz_launch(c, B[f], plan[f], g->comp, g->comp_bytes, g->start_bit, g->win, g->win_len, fs[f], info_host + 8 * f); if (rc) return rc; }
-    }
-    for (int f = 0; f < nf; f++) HIPCHK(c, hipStreamSynchronize(fs[f]));
-    const double t_dec = wall();
-    u64 bytes[2] = {0, 0};
-    // (what comes back -- the windows behind the chains, the CRCs per 64 KiB -- lands in page-locked words of the lane: a copy into
-    // pageable memory costs milliseconds whatever its size)
-    if (!c->h_gz && hipHostMalloc((void**)&c->h_gz, 192 << 10, hipHostMallocPortable) != hipSuccess) { c->h_gz = nullptr; c->err = "cannot allocate page-locked memory"; return BMBS_ENOMEM; }
-    u32* segcrc[2] = {reinterpret_cast<u32*>(c->h_gz + (64 << 10)), reinterpret_cast<u32*>(c->h_gz + (128 << 10))};
-    u64 nseg[2] = {0, 0};
-    for (int f = 0; f < nf; f++) {
-        bmbs_gztext* g = G[f];
-        bytes[f] = g->prefix_bytes;
-        if (!plan[f].n_spans) { HIPCHK(c, hipMemsetAsync(c->totals.as<u64>() + 21 + f, 0, 8, fs[f])); continue; }
-        const u64* info = info_host + 8 * f;
-        if (info[4]) { c->err = "corrupt deflate data in the .gz input (a match reaches in front of the stream; file " + std::to_string(f + 1) + ")"; return BMBS_EINVAL; }
-        const u32 good = (u32)info[0];
-        const u64 total = info[5];
-        if (total > text_cap[f]) { c->err = "text open: the window inflates to more than its buffer holds"; return BMBS_ENOMEM; }
-        g->end_bit = info[2]; g->final_block = (int32_t)info[1]; g->text_bytes = total; g->win_out_len = (u32)info[3];
-        char* dst = texts[f]->as<char>() + g->prefix_bytes;
-        if (total) {
-            hipLaunchKernelGGL(k_gz_resolve, dim3(32, good), dim3(256), 0, fs[f], B[f].sym->as<u16>(), plan[f].cap, B[f].res->as<GzSpan>(), B[f].off->as<u64>(), B[f].info->as<u64>(),
-                               B[f].wall->as<u8>(), dst);
-            nseg[f] = (total + 65535) >> 16;
-            if (nseg[f] > (64 << 10) / 4) { c->err = "text open: a window of a gzip stream inflates to more than 1 GiB"; return BMBS_EINVAL; }
-            ENS(c, *B[f].crc, nseg[f] * 4 + 64);
-            hipLaunchKernelGGL(k_crc_segs, dim3((unsigned)nseg[f]), dim3(64), 0, fs[f], reinterpret_cast<const u8*>(dst), total, B[f].crc->as<u32>());
-            HIPCHK(c, hipMemcpyAsync(segcrc[f], B[f].crc->p, nseg[f] * 4, hipMemcpyDeviceToHost, fs[f]));
-        }
-        if (info[3]) HIPCHK(c, hipMemcpyAsync(c->h_gz + f * 32768, B[f].wall->as<u8>() + (size_t)good * 32768 + (32768 - info[3]), info[3], hipMemcpyDeviceToHost, fs[f]));
-        bytes[f] += total;
-        if (last[f] && g->final_block && bytes[f]) hipLaunchKernelGGL(k_close_last_line, dim3(1), dim3(1), 0, fs[f], texts[f]->as<char>(), bytes[f], c->totals.as<u64>() + 21 + f);
-        else HIPCHK(c, hipMemsetAsync(c->totals.as<u64>() + 21 + f, 0, 8, fs[f]));
-    }
-    for (int f = 0; f < nf; f++) HIPCHK(c, hipStreamSynchronize(fs[f]));
-    HIPCHK(c, hipMemcpyAsync(c->h_info + 28, c->totals.as<u64>() + 21, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int f = 0; f < nf; f++) {
-        // CRC-32 of the window's text: the pieces joined (crc of a concatenation = crc1 * x^(8 len2) + crc2)
-        u32 crc = 0; const u64 total = G[f]->text_bytes;
-        const u32 x64k = host_crc_x8n(65536);
-        if (G[f]->win_out_len) memcpy(G[f]->win_out, c->h_gz + f * 32768, G[f]->win_out_len);
-        for (size_t i = 0; i < nseg[f]; i++) {
-            const u64 len = std::min<u64>(65536, total - ((u64)i << 16));
-            crc = host_crc_mult(len == 65536 ? x64k : host_crc_x8n(len), crc) ^ segcrc[f][i];
-        }
-        G[f]->crc32 = crc;
-    }
-    tp[1] = wall();
-    if (trace) fprintf(stderr, "[text open gzip] buffers %.2f  upload + starts + spans + chain %.2f  resolve + crc + windows back %.2f ms\n", (t_res - tp[0]) * 1e3, (t_dec - t_res) * 1e3, (tp[1] - t_dec) * 1e3);
-    const u64* added = reinterpret_cast<const u64*>(c->h_info + 28);
-    bytes[0] += added[0]; if (pe) bytes[1] += added[1];
-    return lane_text_open_finish(c, pe, texts, bytes, max_records, n_records, tail1, tail_cap, tail1_bytes, tail2, tail2_bytes, tp, trace ? "gzip" : nullptr,
-                                 (double)(g1->comp_bytes + (g2 ? g2->comp_bytes : 0)) / 1e6);
 }
 
 int lane_text_map_open(Lane* c, int32_t flags_in, char* sam, u64 sam_cap, u64* sam_bytes, int64_t* n_lines_out)
@@ -2879,68 +2726,12 @@ extern "C" int bmbs_inflate_bgzf(bmbs_ctx* X, const void* comp, uint64_t comp_by
     return fin(X, c, lane_inflate_bgzf(c, comp, comp_bytes, blk_off, out_off, n_blocks, text, text_bytes, nl_per_64k, window_shift));
 }
 
-// ---- a window of ONE deflate stream (an ordinary .gz member), inflated by a wave per span -------------------------------------------
-// comp[0, comp_bytes): compressed bytes of the stream from the byte that holds bit start_bit (a block boundary the caller knows: the
-// stream's first block, or where the last call stopped); win_in: the win_len (<= 32768) bytes of text in front of that point.  Blocks are
-// entered up to limit_bytes (the caller keeps a margin of one block before the end of what it has, or passes comp_bytes at the end of
-// the file).  -> text of every span the chain reached, the bit it stopped at (*end_bit, a block boundary again), *final = the stream's
-// last block was decoded (the 8-byte trailer follows at the next byte boundary), win_out = the 32 KiB (or fewer) behind it.
-// *text_bytes == 0 with BMBS_OK: no span could be confirmed (a stream of stored blocks, a block longer than a span's symbol slot):
-// the caller's host inflater takes over.
-static int lane_inflate_gzip(Lane* c, const void* comp, uint64_t comp_bytes, uint32_t start_bit, uint64_t limit_bytes, const void* win_in, uint32_t win_len,
-                             char* text, uint64_t text_cap, uint64_t* text_bytes, uint64_t* end_bit, int32_t* final_block, void* win_out, uint32_t* win_out_len)
-{
-    if (text_bytes) *text_bytes = 0;
-    if (!comp || !text_bytes || !end_bit || !final_block || !win_out || !win_out_len || (win_len && !win_in) || win_len > 32768 || (text_cap && !text)) { c->err = "inflate: NULL argument"; return BMBS_EINVAL; }
-    if (comp_bytes < 8 || comp_bytes + 1 >= (1ull << 29) || start_bit >= comp_bytes * 8) { c->err = "inflate: a window of a gzip stream has to be smaller than 512 MiB (32-bit bit offsets)"; return BMBS_EINVAL; }
-    HIPCHK(c, hipSetDevice(c->dev));
-    static const bool trace = getenv("BMBS_TEXT_TRACE") != nullptr;
-    auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
-    const double t0 = wall();
-    const GzPlan g = gz_plan(comp_bytes, limit_bytes);
-    const GzBufs B = {&c->z_comp, &c->gz_start, &c->gz_sym, &c->gz_res, &c->gz_wall, &c->gz_off, &c->gz_info, &c->gz_crc, &c->gz_map, &c->gz_wgrp, &c->gz_have};
-    { const int rc = gz_reserve(c, B, g, comp_bytes); if (rc) return rc; }
-    hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
-    u64* info = reinterpret_cast<u64*>(c->h_tot);
-    { const int rc = gz_launch(c, B, g, comp, comp_bytes, start_bit, win_in, win_len, c->stream, info); if (rc) return rc; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const double t2 = wall();
-    const u32 good = (u32)info[0];
-    if (info[4]) { c->err = "corrupt deflate data in the .gz input (a match reaches in front of the stream)"; return BMBS_EINVAL; }
-    if (!good) { *end_bit = start_bit; *final_block = 0; *win_out_len = 0; return BMBS_OK; }
-    const u64 total = info[5];
-    *text_bytes = total; *end_bit = info[2]; *final_block = (int32_t)info[1]; *win_out_len = (u32)info[3];
-    if (total > text_cap) { c->err = "inflate: the text buffer is too small"; return BMBS_ENOMEM; }
-    ENS(c, c->z_text, total + 64);
-    if (total) hipLaunchKernelGGL(k_gz_resolve, dim3(32, good), dim3(256), 0, c->stream, c->gz_sym.as<u16>(), g.cap, c->gz_res.as<GzSpan>(), c->gz_off.as<u64>(), c->gz_info.as<u64>(),
-                                  c->gz_wall.as<u8>(), c->z_text.as<char>());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const double t3 = wall();
-    const u32 wl = (u32)info[3];
-    if (wl) HIPCHK(c, hipMemcpyAsync(win_out, c->gz_wall.as<u8>() + (size_t)good * 32768 + (32768 - wl), wl, hipMemcpyDeviceToHost, ds));
-    if (total) { const int rc = d2h_chunked(c, text, c->z_text.as<char>(), total, ds); if (rc) return rc; }
-    HIPCHK(c, hipStreamSynchronize(ds));
-    if (trace) fprintf(stderr, "[inflate gzip] %u spans of %u bytes, %u reached, %.1f MB -> %.1f MB: upload + starts + spans + window chain %.2f  resolve %.2f  download %.2f ms\n", g.n_spans, g.span, good,
-                       (double)comp_bytes / 1e6, (double)total / 1e6, (t2 - t0) * 1e3, (t3 - t2) * 1e3, (wall() - t3) * 1e3);
-    return BMBS_OK;
-}
-
-extern "C" int bmbs_inflate_gzip(bmbs_ctx* X, const void* comp, uint64_t comp_bytes, uint32_t start_bit, uint64_t limit_bytes, const void* win_in, uint32_t win_len,
-                                 char* text, uint64_t text_cap, uint64_t* text_bytes, uint64_t* end_bit, int32_t* final_block, void* win_out, uint32_t* win_out_len)
-{
-    Lane* c = lane0(X);
-    if (!c) return BMBS_EINVAL;
-    return fin(X, c, lane_inflate_gzip(c, comp, comp_bytes, start_bit, limit_bytes, win_in, win_len, text, text_cap, text_bytes, end_bit, final_block, win_out, win_out_len));
-}
-
 #ifdef INF_PROFILE
 // profiling build only (tools/inflate_prof.sh): the phase cycle sums of k_bgzf_inflate since the last call
 extern "C" int bmbs_debug_inflate_prof(uint64_t* out16)
 {
     unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_inf_prof), sizeof z) != hipSuccess) return BMBS_ENODEV;
-    if (hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(g_gz_prof), 64) != hipSuccess) return BMBS_ENODEV;       // (the caller's array has 24 words)
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gz_prof), z, 64);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_inf_prof), z, sizeof z) == hipSuccess ? BMBS_OK : BMBS_ENODEV;
 }
 #endif
@@ -2960,6 +2751,16 @@ extern "C" int bmbs_debug_huff_lengths(bmbs_ctx* X, const uint32_t* freq, int32_
     if (!rc && hipMemcpy(len_out, dl, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = BMBS_ENODEV;
     (void)hipFree(df); (void)hipFree(dl);
     return rc;
+}
+
+// diagnostic: seconds the context's text calls held the link (uploads, downloads: copy + wait for its end, the wait for the link's lock
+// excluded), seconds inside those calls, and their number
+extern "C" int bmbs_text_times(bmbs_ctx* X, double out[4])
+{
+    if (!X || !out) return BMBS_EINVAL;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (Lane* c : X->lanes) { out[0] += c->link_up_s; out[1] += c->link_down_s; out[2] += c->text_call_s; out[3] += (double)c->text_calls; }
+    return BMBS_OK;
 }
 
 // diagnostic: calls that were issued again with exact sizes because a stage count did not fit the capacity learned so far
@@ -2988,9 +2789,6 @@ extern "C" int bmbs_map_se_text(bmbs_ctx* X, const char* text, uint64_t text_byt
 extern "C" int bmbs_text_open_bgzf(bmbs_ctx* X, const bmbs_ztext* mate1, const bmbs_ztext* mate2, int64_t max_records, int32_t last1, int32_t last2,
                                    int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes, char* tail2, uint64_t* tail2_bytes)
 { ON_LANE0(lane_text_open_bgzf(c, mate1, mate2, max_records, last1, last2, n_records, tail1, tail_cap, tail1_bytes, tail2, tail2_bytes)); }
-extern "C" int bmbs_text_open_gzip(bmbs_ctx* X, bmbs_gztext* mate1, bmbs_gztext* mate2, int64_t max_records, int32_t last1, int32_t last2,
-                                   int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes, char* tail2, uint64_t* tail2_bytes)
-{ ON_LANE0(lane_text_open_gzip(c, mate1, mate2, max_records, last1, last2, n_records, tail1, tail_cap, tail1_bytes, tail2, tail2_bytes)); }
 extern "C" int bmbs_text_map_open(bmbs_ctx* X, int32_t flags, char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines)
 { ON_LANE0(lane_text_map_open(c, flags, sam, sam_cap, sam_bytes, n_lines)); }
 extern "C" int bmbs_map_pe_text(bmbs_ctx* X, const char* text1, uint64_t bytes1, const char* text2, uint64_t bytes2, int64_t n_pairs, int32_t flags,

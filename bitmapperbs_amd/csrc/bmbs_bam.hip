@@ -324,27 +324,7 @@ k_line_write(SamIn in, long n_lines, const u64* __restrict__ off, int lpb, u32 o
 #define DEF_SYMS      320                   // ll at 0, distance codes at 288
 #define DEF_DOFF      288
 
-__constant__ u32 c_x2n[32];                 // x^(2^n) mod P of CRC-32 (reflected), n = 0..31: set by bgzf_init_constants
 __constant__ u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-#define CRC_POLY 0xedb88320u
-DEVI u32 crc_multmodp(u32 a, u32 b)
-{
-    u32 m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
-        m >>= 1;
-        b = (b & 1) ? (b >> 1) ^ CRC_POLY : b >> 1;
-    }
-    return p;
-}
-// x^(8 n) mod P
-DEVI u32 crc_x8n(u32 n)
-{
-    u32 p = 1u << 31; int k = 3;
-    while (n) { if (n & 1) p = crc_multmodp(c_x2n[k & 31], p); n >>= 1; k++; }
-    return p;
-}
 
 DEVI void len_code(int len, int& code, int& extra, int& xval)
 {

@@ -13,6 +13,7 @@
 // reserved block type, distance too far back, stored-length check, output longer than the trailer says, CRC mismatch.
 #ifndef BMBS_INFLATE_HIP
 #define BMBS_INFLATE_HIP
+#include "bmbs_bytes.h"
 
 #define INF_LIT_ROOT 10
 #define INF_DIST_ROOT 9
@@ -20,7 +21,6 @@
 // -DINF_PROFILE (tools/inflate_prof.sh builds a second library with it): cycles per phase of k_bgzf_inflate, summed over the blocks
 #ifdef INF_PROFILE
 __device__ unsigned long long g_inf_prof[16];
-__device__ unsigned long long g_gz_prof[8];         // k_gz_starts: steps, lanes with a candidate, full header checks, cycles, cycles in the checks, waves
 #define INF_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); prof[k] += t_ - t_last; t_last = t_; } while (0)
 #define INF_N(k, v) prof[k] += (v)
 #else
@@ -174,22 +174,15 @@ DEVI InfTok inf_token(u64 v, const u32* s_lit, const u32* s_dist)
 }
 
 // ---- one wave inflates one deflate stream (or a stretch of one) -------------------------------------------------------------------
-// MODE 0: a whole gzip member's deflate data from start_bit (BGZF block), bytes out.  MODE 1: a SPAN of a longer stream, from a block
-// start at start_bit to the first block boundary at or behind stop_bit (or the end of the final block); what lies before the span is
-// not known: symbols are 16 bits, a byte or 0x8000 | w = "byte w of the 32 KiB in front of the span" (w = 32767: the byte just before
-// it) -- the scheme of pugz / rapidgzip, as in csrc/pgz.h.  MODE 2: the header of the block at start_bit is read and judged, nothing
-// else (status 0: a dynamic-Huffman header zlib would accept).
-template <int MODE> struct InfSym { typedef u8 T; };
-template <> struct InfSym<1> { typedef u16 T; };
-DEVI u32 inf_marker(int q) { return 0x8000u | (u32)(32768 + q); }                         // q in [-32768, -1]: position relative to the span's start
-template <int N> DEVI u64 inf_pick(const u64 (&r)[N], u32 k) { u64 v = r[0]; for (int j = 1; j < N; j++) v = k == (u32)j ? r[j] : v; return v; }
-
-template <int MODE>
-DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typename InfSym<MODE>::T* out, u32 isize, int lane,
-                   u32& status_r, u32& n_out_r, u32& end_bit_r, bool& final_r)
+// A whole gzip member's deflate data from start_bit (a BGZF block), bytes out.  (Round 4 also ran this loop over spans of ONE long
+// deflate stream with 16-bit symbols -- the device form of csrc/pgz.h; exact, and slower than the host's: removed in round 5.
+// Round 5 also tried keeping the last 2 KiB of the text in an LDS ring, so that what a match copies from before the window being
+// assembled needs neither the round trip to memory nor the fence that three windows in four took: the same 4.7 ms per window
+// (tools/inflate_kbench.hip) -- the round trip was already hidden behind the pointer jumping; a wave's own chain of dependent
+// instructions bounds the kernel, and two windows side by side take 3.5 ms each.)
+DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u8* out, u32 isize, int lane, u32& status_r, u32& n_out_r)
 {
-    typedef typename InfSym<MODE>::T S;
-    constexpr u32 BACK = MODE == 1 ? 32768u : 0u;          // how far before its own output a match of this stream may reach
+    typedef u8 S;
     __shared__ u32 s_lit[1 << INF_LIT_ROOT];
     __shared__ u32 s_dist[1 << INF_DIST_ROOT];
     __shared__ u8 s_lens[320];
@@ -214,16 +207,9 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
     u32 kc = 0xfffffff0u, cur = 0, nxt = 0;
     u32 n_out = 0;                                        // bytes of text written so far (wave-uniform)
     u32 fenced = 0;                                       // every byte of the text below this offset is visible to every lane
-    S last_byte = MODE == 1 ? (S)inf_marker(-1) : (S)0;      // the symbol at n_out - 1 (wave-uniform)
+    S last_byte = (S)0;                                   // the symbol at n_out - 1 (wave-uniform)
     bool last = false;
     while (!status && !last) {
-        if (MODE == 1) {
-            // a span ends at the first block boundary at or behind the next cut
-            u32 bs = 0;
-            if (lane == 0) bs = (u32)((in.p - z) * 8) - (u32)in.cnt;
-            bs = (u32)__shfl((int)bs, 0);
-            if (bs >= stop_bit) break;
-        }
         // ---- block header (lane 0 reads, the wave follows)
         u32 btype = 0;
         if (lane == 0) { in.refill(); last = in.take(1) != 0; btype = in.take(2); }
@@ -306,7 +292,6 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
             ok = inf_canonical(s_lens, 288, s_cl, lane) && inf_canonical(s_lens + 288, 32, s_cd, lane);
         }
         if (!ok) { status = 4; break; }
-        if (MODE == 2) break;                                     // (the header stands: all a search for block starts asks)
         inf_root(s_cl, false, s_lit, INF_LIT_ROOT, lane);
         inf_root(s_cd, true, s_dist, INF_DIST_ROOT, lane);
         // ---- symbols.  Every lane decodes the tokens that WOULD start at its own two bit offsets (bp + lane, bp + 64 + lane): one or
@@ -394,7 +379,7 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                 const u32 kindA = (A.e >> 5) & 7u, kindB = (B.e >> 5) & 7u;
                 const bool litA = mineA && kindA == IK_LIT, litB = mineB && kindB == IK_LIT;
                 const bool matA = mineA && kindA == IK_BASE, matB = mineB && kindB == IK_BASE;
-                if (__ballot((matA && A.mdist > outA + BACK) || (matB && B.mdist > outB + BACK))) { status = 6; break; }
+                if (__ballot((matA && A.mdist > outA) || (matB && B.mdist > outB))) { status = 6; break; }
                 const u32 idxA = outA - n_out + lo, idxB = outB - n_out + lo;               // window index of the token's first byte
                 // bytes of a match that come from before the window: its first ext bytes
                 const int srcA = (int)outA - (int)A.mdist, srcB = (int)outB - (int)B.mdist;   // (negative in a span: before its start, a marker)
@@ -404,7 +389,7 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                 if (__ballot((extA && srcA + (int)extA > (int)fenced) || (extB && srcB + (int)extB > (int)fenced))) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
                 // (unaligned 16-byte loads -- a vector memory instruction costs the CU's address unit a cycle per lane whatever its width --:
                 // the bytes behind a match's source come along and are dropped, the buffers have the slack)
-                u64 ra[MODE == 1 ? 4 : 2], rb[MODE == 1 ? 4 : 2];
+                u64 ra[2], rb[2];
                 constexpr u32 PER = 8 / sizeof(S);                                          // symbols per 8-byte load
 #pragma unroll
                 for (u32 k = 0; k < 16 / PER; k++) { ra[k] = 0; rb[k] = 0; }
@@ -437,7 +422,7 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                         const u32 xa = (u32)__builtin_amdgcn_readlane((int)extA, L), xb = (u32)__builtin_amdgcn_readlane((int)extB, L);
                         const u32 ix = half ? ib : ia, ml = half ? lb : la, md = half ? db : da, ex = half ? xb : xa;
                         for (u32 i = lane; i < ml; i += 64) {
-                            if (i < ex) { const int q = (int)(n_out - lo + ix + i) - (int)md; s_val[ix + i] = MODE == 1 && q < 0 ? (S)inf_marker(q) : out[q]; }
+                            if (i < ex) { const int q = (int)(n_out - lo + ix + i) - (int)md; s_val[ix + i] = out[q]; }
                             else s_ref[ix + i] = (u8)(ix + i - md);
                         }
                     }
@@ -458,11 +443,11 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                 // the text from before the window, as it arrives
                 if (shortA) for (u32 i = 0; i < extA; i++) {
                     const int q = srcA + (int)i;
-                    s_val[idxA + i] = MODE == 1 && q < 0 ? (S)inf_marker(q) : MODE == 1 && srcA < 0 ? out[q] : (S)(inf_pick(ra, i / PER) >> (8 * sizeof(S) * (i % PER)));
+                    s_val[idxA + i] = (S)((i < 8 ? ra[0] : ra[1]) >> (8 * (i & 7u)));
                 }
                 if (shortB) for (u32 i = 0; i < extB; i++) {
                     const int q = srcB + (int)i;
-                    s_val[idxB + i] = MODE == 1 && q < 0 ? (S)inf_marker(q) : MODE == 1 && srcB < 0 ? out[q] : (S)(inf_pick(rb, i / PER) >> (8 * sizeof(S) * (i % PER)));
+                    s_val[idxB + i] = (S)((i < 8 ? rb[0] : rb[1]) >> (8 * (i & 7u)));
                 }
                 __builtin_amdgcn_wave_barrier();
                 const u32 r4 = s_ref32[lane];
@@ -471,7 +456,7 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                 const u32 hi = run - n_out + lo;                                            // window symbols [lo, hi) are text
                 S* wp = out + n_out - lo + 4 * (u32)lane;
                 const u32 r0 = 4 * (u32)lane;
-                if (r0 >= lo && r0 + 4 <= hi) { if (MODE == 1) *reinterpret_cast<u64*>(wp) = w; else *reinterpret_cast<u32*>(wp) = (u32)w; }
+                if (r0 >= lo && r0 + 4 <= hi) { *reinterpret_cast<u32*>(wp) = (u32)w; }
                 else {
 #pragma unroll
                     for (u32 k = 0; k < 4; k++) if (r0 + k >= lo && r0 + k < hi) wp[k] = (S)(w >> (SB * k));
@@ -538,7 +523,7 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                     if (lane == 0) out[n_out] = (S)lit;
                     n_out++; last_byte = (S)lit;
                 } else if (ev == 2) {
-                    if (sd > n_out + BACK || n_out + sl > isize) { status = 6; break; }
+                    if (sd > n_out || n_out + sl > isize) { status = 6; break; }
                     S myv = last_byte;
                     if (sd == 1) {
                         // a run of the byte in front of it (quality strings): no read at all
@@ -546,7 +531,7 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
                     } else {
                         // bytes stored since the last fence are not visible to the other lanes yet: a fence when the source reaches into them
                         if ((int)(sd >= sl ? n_out + sl : n_out + sd) - (int)sd > (int)fenced) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
-                        for (u32 i = lane; i < sl; i += 64) { const int q = (int)n_out - (int)sd + (int)(sd >= sl ? i : i % sd); myv = MODE == 1 && q < 0 ? (S)inf_marker(q) : out[q]; out[n_out + i] = myv; }
+                        for (u32 i = lane; i < sl; i += 64) { const u32 q = n_out - sd + (sd >= sl ? i : i % sd); myv = out[q]; out[n_out + i] = myv; }
                     }
                     last_byte = (S)__builtin_amdgcn_readlane((int)myv, (int)((sl - 1) & 63u));
                     n_out += sl;
@@ -558,11 +543,7 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u32 stop_bit, typ
         // the next block header is read by lane 0 from bp
         if (lane == 0) { in.init(z + (bp >> 3), zend); in.refill(); in.drop((int)(bp & 7u)); }
     }
-    // where the stream stands: behind the last block that was read (lane 0 re-opened its reader there), or at the block not entered
-    u32 eb = 0;
-    if (lane == 0) eb = (u32)((in.p - z) * 8) - (u32)in.cnt;
-    end_bit_r = (u32)__shfl((int)eb, 0);
-    status_r = status; n_out_r = n_out; final_r = last;
+    status_r = status; n_out_r = n_out;
 #ifdef INF_PROFILE
     prof[15] = clock64() - t_begin;
     if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_inf_prof[k], prof[k]);
@@ -649,8 +630,7 @@ k_bgzf_inflate(const u8* __restrict__ comp, const u64* __restrict__ blk_off, con
     __syncthreads();
     u32 n_out = 0;
     if (!status) {
-        u32 end_bit = 0; bool fin = false;
-        inf_wave<0>(z, z + zlen - 8, body * 8, 0xffffffffu, reinterpret_cast<u8*>(out), isize, lane, status, n_out, end_bit, fin);
+        inf_wave(z, z + zlen - 8, body * 8, reinterpret_cast<u8*>(out), isize, lane, status, n_out);
     }
     // ---- trailer: ISIZE and CRC-32 (every lane one segment, the segments combined by x^(8 * bytes behind them))
     if (!status) {
@@ -702,382 +682,4 @@ k_nl_count64k(const char* __restrict__ text, u64 total, u64 shift, u32* __restri
     if (threadIdx.x == 0) counts[j] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// ---- one-member gzip: a window of ONE deflate stream, inflated by many waves (round 4) ----------------------------------------------
-// The stream is cut every `span` bytes.  (1) k_gz_starts: the wave of a cut looks for the first bit offset behind it at which a
-// dynamic-Huffman block header parses -- a lane per offset for the cheap test (block type, HLIT / HDIST, complete code-length code, as
-// pgz::header_plausible), the whole header (inf_wave<2>) for the survivors.  (2) k_gz_spans: a wave per span decodes from its start to
-// the first block boundary at or behind the next cut, into 16-bit symbols (inf_wave<1>).  (3) k_gz_link / k_gz_chain_local /
-// k_gz_chain_groups / k_gz_apply: which spans count -- a span counts when it starts where its predecessor stopped -- and the 32 KiB
-// window behind every one of them (a scan over the spans' maps).  (4) k_gz_resolve: symbols -> bytes at the span's place in the text.
-// What the chain does not reach (a start that was not one, a block longer than a span's slot, a stream of stored blocks) is left to the
-// caller: the next call begins at the boundary the chain did reach.
-#define GZ_NONE 0xffffffffu
-struct GzSpan { u32 status, n_sym, end_bit, final; };
-
-// the second cheap test on the 128 bits (LSB first) that begin at the candidate's bit, whose block type and HLIT / HDIST passed: the
-// code-length code complete.  kraft9[x] = sum of 2^(7 - l) over the three 3-bit lengths in x (l = 0: no code): seven look-ups for the
-// 19 lengths instead of a loop over them
-DEVI bool gz_plausible(u64 lo, u64 hi, const u8* kraft9)
-{
-    const u32 hclen = (u32)((lo >> 13) & 15u) + 4;
-    u64 w = (lo >> 17) | (hi << 47);                                            // the 3-bit lengths of the code-length code: 57 bits = 19 lengths
-    w &= (1ull << (3 * hclen)) - 1;
-    u32 sum = 0;
-#pragma unroll
-    for (u32 k = 0; k < 7; k++) sum += kraft9[(u32)(w >> (9 * k)) & 511u];
-    return sum == 128u;
-}
-
-// the whole dynamic-Huffman header at `bit`, judged by ONE lane (64 candidates side by side): HLIT / HDIST, the code-length code as a
-// 128-entry table in the lane's LDS slot, the ~300 code lengths walked with their repeat codes, and what zlib's inflate_table asks of
-// the two codes they describe -- complete (Kraft sum exactly one), an end-of-block code; a distance code may be a single code or none
-DEVI u64 gz_bits(const u8* z, u32 p) { u64 v; __builtin_memcpy(&v, z + (p >> 3), 8); return v >> (p & 7u); }      // >= 57 bits from bit p
-DEVI bool gz_header_ok(const u8* z, u32 bit, u32 end_bit, u8* tab /* [128] of this lane */)
-{
-    u32 p = bit + 3;
-    u64 v = gz_bits(z, p);
-    const u32 hlit = (u32)(v & 31u) + 257, hdist = (u32)((v >> 5) & 31u) + 1, hclen = (u32)((v >> 10) & 15u) + 4;
-    if (hlit > 286 || hdist > 30) return false;
-    p += 14;
-    v = gz_bits(z, p);
-    p += 3 * hclen;
-    // lengths of the code-length code in symbol order, 3 bits each
-    u64 cl = 0;
-    u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    {
-        const u64 order = 0x0f0e0d0c0b0a0908ull;                                          // (not used: the order is spelled out below)
-        (void)order;
-        const u8 ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-#pragma unroll
-        for (u32 i = 0; i < 19; i++) {
-            const u32 l = i < hclen ? (u32)((v >> (3 * i)) & 7u) : 0u;
-            cl |= (u64)l << (3 * ord[i]);
-#pragma unroll
-            for (u32 k = 1; k < 8; k++) cnt[k] += l == k;
-        }
-    }
-    // canonical codes -> table indexed by the next 7 bits (LSB first): entry = symbol << 3 | length, 0 = no code
-    // (the code-length code is complete -- the cheap test's Kraft sum --: the codes below fill every one of the 128 entries)
-    {
-        u32 next[8]; u32 code = 0;
-#pragma unroll
-        for (u32 k = 1; k < 8; k++) { code = (code + cnt[k - 1]) << 1; next[k] = code; }
-#pragma unroll
-        for (u32 sym = 0; sym < 19; sym++) {
-            const u32 l = (u32)((cl >> (3 * sym)) & 7u);
-            if (!l) continue;
-            u32 c = 0;
-#pragma unroll
-            for (u32 k = 1; k < 8; k++) if (l == k) { c = next[k]; next[k] = c + 1; }
-            const u32 r = __brev(c) >> (32 - l);                                          // the code as it arrives, LSB first
-            for (u32 i = r; i < 128; i += 1u << l) tab[i] = (u8)(sym << 3 | l);
-        }
-    }
-    const u32 total = hlit + hdist;
-    u32 have = 0, prev = 0, litK = 0, distK = 0, dist_codes = 0;
-    bool eob = false;
-    while (have < total) {
-        if (p + 64 > end_bit) return false;
-        v = gz_bits(z, p);
-        const u32 e = tab[v & 127u], l = e & 7u, sym = e >> 3;
-        if (!l) return false;
-        p += l; v >>= l;
-        u32 len = 0, rep = 1;
-        if (sym < 16) { len = sym; prev = sym; }
-        else if (sym == 16) { if (!have) return false; len = prev; rep = 3 + (u32)(v & 3u); p += 2; }
-        else if (sym == 17) { rep = 3 + (u32)(v & 7u); p += 3; prev = 0; }
-        else { rep = 11 + (u32)(v & 127u); p += 7; prev = 0; }
-        if (have + rep > total) return false;
-        const u32 n_lit = have < hlit ? min(rep, hlit - have) : 0u, n_dist = rep - n_lit;
-        if (len) {
-            litK += n_lit << (15 - len); distK += n_dist << (15 - len); dist_codes += n_dist;
-            if (litK > 32768u || (distK > 32768u)) return false;                // over-subscribed: what random bits run into within a few lengths
-            if (have <= 256 && 256 < have + n_lit) eob = true;
-        }
-        have += rep;
-    }
-    if (!eob || litK != 32768u) return false;
-    return distK == 32768u || dist_codes <= 1;
-}
-
-__global__ void __launch_bounds__(64)
-k_gz_starts(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_bytes, u32 first_bit, u32* __restrict__ start_bit)
-{
-    __shared__ u8 s_tab[64][128];
-    __shared__ u8 s_kraft9[512];
-    const u32 s = blockIdx.x;
-    if (s >= n_spans) return;
-    const int lane = threadIdx.x;
-    if (s == 0) { if (lane == 0) start_bit[0] = first_bit; return; }
-    for (u32 x = lane; x < 512; x += 64) {
-        u32 k = 0;
-        for (u32 f = 0; f < 3; f++) { const u32 l = (x >> (3 * f)) & 7u; if (l) k += 128u >> l; }
-        s_kraft9[x] = (u8)k;                                                   // (three lengths of 1 make 192: fits)
-    }
-    __syncthreads();
-    const u64 last_bit = total_bytes > 64 ? (total_bytes - 64) * 8 : 0;        // a header needs room behind it
-    // (the search goes on behind the span's own bytes: a span whose first block start lies in a later span decodes nothing and hands the
-    // chain on -- blocks may be longer than a span)
-    const u64 from = (u64)s * span_bytes * 8, to = min(from + ((u64)1 << 23), last_bit);
-    u32 found = GZ_NONE;
-#ifdef INF_PROFILE
-    unsigned long long p_steps = 0, p_cheap = 0, p_kraft = 0, p_cyc_val = 0; const unsigned long long p_t0 = clock64();
-#endif
-    // 512 bit offsets per step: a lane takes the eight offsets of one byte and reads the 16 bytes they need once; the offsets that pass
-    // the cheap test are judged in full by their own lanes, the lowest that stands is the start
-    for (u64 base = from; base < to && found == GZ_NONE; base += 512) {
-        const u32 byte0 = (u32)(base >> 3) + (u32)lane;
-        u64 lo, hi; __builtin_memcpy(&lo, comp + byte0, 8); __builtin_memcpy(&hi, comp + byte0 + 8, 8);
-        // (block type and HLIT / HDIST of the eight offsets first -- one offset in ten passes --, the code-length code's Kraft sum and
-        // the whole header only for those)
-        u32 m8 = 0;
-#pragma unroll
-        for (u32 j = 0; j < 8; j++) {
-            const u32 v = (u32)(lo >> j);                                       // 13 bits: within the low word for j < 8
-            if ((v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u && (u64)byte0 * 8 + j < to) m8 |= 1u << j;
-        }
-        u32 best = GZ_NONE;
-#ifdef INF_PROFILE
-        p_steps++; p_cheap += __popcll(__ballot(m8 != 0)); const unsigned long long p_t1 = clock64();
-#endif
-        while (m8) {
-            const u32 j = (u32)__builtin_ctz(m8);
-            m8 &= m8 - 1;
-            const u32 c = byte0 * 8 + j;
-            const u64 l2 = j ? (lo >> j) | (hi << (64 - j)) : lo, h2 = hi >> j;
-            if (!gz_plausible(l2, h2, s_kraft9)) continue;
-#ifdef INF_PROFILE
-            p_kraft++;
-#endif
-            if (gz_header_ok(comp, c, (u32)(total_bytes * 8), s_tab[lane])) { best = c; break; }
-        }
-#ifdef INF_PROFILE
-        p_cyc_val += clock64() - p_t1;
-#endif
-        // the lowest offset over the lanes
-        for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }
-        found = best;
-    }
-    if (lane == 0) start_bit[s] = found;
-#ifdef INF_PROFILE
-    {
-        unsigned long long k = p_kraft;
-        for (int o = 32; o > 0; o >>= 1) k += __shfl_xor((long long)k, o, 64);
-        if (lane == 0) { atomicAdd(&g_gz_prof[0], p_steps); atomicAdd(&g_gz_prof[1], p_cheap); atomicAdd(&g_gz_prof[2], k); atomicAdd(&g_gz_prof[3], clock64() - p_t0); atomicAdd(&g_gz_prof[4], p_cyc_val); atomicAdd(&g_gz_prof[5], 1ull); }
-    }
-#endif
-}
-
-__global__ void __launch_bounds__(64, 4)
-k_gz_spans(const u8* __restrict__ comp, u64 total_bytes, u32 n_spans, u32 span_bytes, u32 limit_bit, const u32* __restrict__ start_bit,
-           u16* __restrict__ sym, u32 cap, GzSpan* __restrict__ res)
-{
-    const u32 s = blockIdx.x;
-    if (s >= n_spans) return;
-    const int lane = threadIdx.x;
-    const u32 from = start_bit[s];
-    GzSpan r; r.status = 100; r.n_sym = 0; r.end_bit = 0; r.final = 0;
-    if (from != GZ_NONE) {
-        const u64 next_cut = (u64)(s + 1) * span_bytes * 8;
-        const u32 stop = s + 1 < n_spans ? (u32)min(next_cut, (u64)limit_bit) : limit_bit;
-        bool fin = false;
-        inf_wave<1>(comp, comp + total_bytes, from, stop, sym + (size_t)s * cap, cap, lane, r.status, r.n_sym, r.end_bit, fin);
-        r.final = fin ? 1u : 0u;
-    }
-    if (lane == 0) res[s] = r;
-}
-
-// windows: wall[0] = the 32 KiB in front of the window's first span (right-aligned: wall[0][32767] = the byte just before it; the first
-// 32768 - win_len bytes do not exist), wall[s + 1] = the 32 KiB behind span s.  off[s] = where span s's text begins.  Pushing the window
-// through 1 700 spans one after the other is 8 ms on one CU; it is a scan (a span's effect on the window is a map "byte, or position of
-// the window before", maps compose): groups of 32 spans chained side by side with their input open, the groups' maps chained by one
-// workgroup, every span's map applied to its group's window.
-#define GZ_MAX_SPANS 8192
-#define GZ_GROUP 32                          // spans whose windows one workgroup chains (the chain over a window's spans is a scan in three phases)
-// 32 consecutive positions of span's tail map: position i of the 32 KiB behind the span = symbol n - 32768 + i of the span, or -- in front
-// of the span's first symbol -- a reference to the window before it, shifted (the same marker a symbol would be)
-DEVI void gz_load32(const u16* sy, long q0, u32 (&x)[16])
-{
-    if (q0 >= 0) {
-        // (16 bytes at a time at whatever alignment the span's length leaves)
-#pragma unroll
-        for (int k = 0; k < 4; k++) { uint4 v; __builtin_memcpy(&v, sy + q0 + 8 * k, 16); x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w; }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const long qa = q0 + 2 * k, qb = qa + 1;
-            const u32 a = qa >= 0 ? (u32)sy[qa] : 0x8000u | (u32)(32768 + qa), b2 = qb >= 0 ? (u32)sy[qb] : 0x8000u | (u32)(32768 + qb);
-            x[k] = a | b2 << 16;
-        }
-    }
-}
-
-// (1) which spans count, where their text goes.  info[0] = spans the chain reached, [1] = the stream's final block was among them,
-// [2] = bit position reached, [3] = bytes of the last window that exist, [4] = a marker pointed in front of the stream (set later),
-// [5] = bytes of text; have[s] = bytes of the window BEFORE span s that exist
-__global__ void __launch_bounds__(1024)
-k_gz_link(const GzSpan* __restrict__ res, const u32* __restrict__ start_bit, u32 n_spans, u32 first_bit, u32 win_len, u64* __restrict__ off,
-          u32* __restrict__ have, u64* __restrict__ info)
-{
-    __shared__ u32 s_n[GZ_MAX_SPANS];
-    __shared__ u32 s_good, s_fin;
-    const u32 t = threadIdx.x;
-    if (t == 0) { s_good = n_spans; s_fin = 0xffffffffu; }
-    __syncthreads();
-    // span s counts when it decoded and starts where span s - 1 stopped -- every link is judged on its own, the first broken one ends
-    // the chain; it also ends behind the stream's final block
-    for (u32 s = t; s < n_spans; s += 1024) {
-        const GzSpan r = res[s];
-        const u32 prev_end = s ? res[s - 1].end_bit : first_bit;
-        s_n[s] = r.n_sym;
-        if (r.status != 0 || start_bit[s] != prev_end) atomicMin(&s_good, s);
-        if (r.status == 0 && r.final) atomicMin(&s_fin, s);
-    }
-    __syncthreads();
-    if (t == 0) {
-        u32 good = s_good, fin = 0;
-        if (s_fin < good) { good = s_fin + 1; fin = 1; }
-        u64 at = 0; u32 h = win_len;
-        for (u32 s = 0; s < good; s++) { off[s] = at; have[s] = h; at += s_n[s]; h = min(32768u, h + s_n[s]); }
-        off[good] = at; have[good] = h;
-        info[0] = good; info[1] = fin; info[2] = good ? res[good - 1].end_bit : first_bit; info[3] = h; info[4] = 0; info[5] = at;
-    }
-}
-
-// (2) a workgroup chains the spans of its group with the window in front of the group left open: map[s][i] = what position i of the
-// window behind span s is -- a byte, or 0x8000 | a position of the window in front of the GROUP
-__global__ void __launch_bounds__(1024)
-k_gz_chain_local(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ res, const u64* __restrict__ info, u16* __restrict__ map)
-{
-    __shared__ __attribute__((aligned(16))) u16 p0[32768];
-    __shared__ __attribute__((aligned(16))) u16 p1[32768];
-    const u32 good = (u32)info[0];
-    const u32 s0 = blockIdx.x * GZ_GROUP;
-    if (s0 >= good) return;
-    const u32 s1 = min(good, s0 + GZ_GROUP);
-    const u32 t = threadIdx.x;
-    for (u32 i = t; i < 32768; i += 1024) p0[i] = (u16)(0x8000u | i);
-    __syncthreads();
-    u16* pp = p0; u16* pn = p1;
-    u32 x[16], xn[16];
-    gz_load32(sym + (size_t)s0 * cap, (long)res[s0].n_sym - 32768 + (long)t * 32, x);
-    for (u32 s = s0; s < s1; s++) {
-        if (s + 1 < s1) gz_load32(sym + (size_t)(s + 1) * cap, (long)res[s + 1].n_sym - 32768 + (long)t * 32, xn);
-        u32 o[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u32 a = x[k] & 0xffffu, b2 = x[k] >> 16;
-            const u32 la = pp[a & 0x7fffu], lb = pp[b2 & 0x7fffu];               // (no branches: looked up whatever the symbol is)
-            o[k] = (a >= 0x8000u ? la : a) | (b2 >= 0x8000u ? lb : b2) << 16;
-        }
-        uint4* dn = reinterpret_cast<uint4*>(pn + t * 32);
-        uint4* dg = reinterpret_cast<uint4*>(map + (size_t)s * 32768 + t * 32);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint4 v = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]); dn[k] = v; dg[k] = v; }
-        __syncthreads();
-        u16* xw = pp; pp = pn; pn = xw;
-#pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = xn[k];
-    }
-}
-
-// (3) one workgroup walks the GROUPS: wgrp[g] = the window in front of group g (wgrp[0] = the caller's, right-aligned)
-__global__ void __launch_bounds__(1024)
-k_gz_chain_groups(const u16* __restrict__ map, const u64* __restrict__ info, u8* __restrict__ wgrp)
-{
-    __shared__ __attribute__((aligned(16))) u8 w0[32768];
-    __shared__ __attribute__((aligned(16))) u8 w1[32768];
-    const u32 good = (u32)info[0];
-    const u32 groups = (good + GZ_GROUP - 1) / GZ_GROUP;
-    const u32 t = threadIdx.x;
-    for (u32 i = t; i < 32768; i += 1024) w0[i] = wgrp[i];
-    __syncthreads();
-    u8* wp = w0; u8* wn = w1;
-    for (u32 g = 0; g + 1 < groups; g++) {
-        const u32 last = (g + 1) * GZ_GROUP - 1;                                // the group's last span: its map is the group's
-        const uint4* m4 = reinterpret_cast<const uint4*>(map + (size_t)last * 32768 + t * 32);
-        u32 x[16];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint4 v = m4[k]; x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w; }
-        u32 o[8];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u32 a = x[k] & 0xffffu, b2 = x[k] >> 16;
-            const u32 la = wp[a & 0x7fffu], lb = wp[b2 & 0x7fffu];
-            const u32 two = ((a >= 0x8000u ? la : a) & 0xffu) | ((b2 >= 0x8000u ? lb : b2) & 0xffu) << 8;
-            if (k & 1) o[k >> 1] |= two << 16; else o[k >> 1] = two;
-        }
-        uint4* dn = reinterpret_cast<uint4*>(wn + t * 32);
-        uint4* dg = reinterpret_cast<uint4*>(wgrp + (size_t)(g + 1) * 32768 + t * 32);
-        const uint4 v0 = make_uint4(o[0], o[1], o[2], o[3]), v1 = make_uint4(o[4], o[5], o[6], o[7]);
-        dn[0] = v0; dn[1] = v1; dg[0] = v0; dg[1] = v1;
-        __syncthreads();
-        u8* xw = wp; wp = wn; wn = xw;
-    }
-}
-
-// (4) every span's window: its map applied to the window in front of its group.  wall[0] = the caller's window, wall[s + 1] = the
-// window behind span s.  A position that exists and refers to one that does not (in front of the stream) marks the input corrupt
-__global__ void __launch_bounds__(256)
-k_gz_apply(const u16* __restrict__ map, const u8* __restrict__ wgrp, const u32* __restrict__ have, u64* __restrict__ info, u8* __restrict__ wall)
-{
-    __shared__ __attribute__((aligned(16))) u8 w[32768];
-    const u32 s = blockIdx.x;
-    if (s >= (u32)info[0]) return;
-    const u32 g = s / GZ_GROUP;
-    const u32 t = threadIdx.x;
-    const uint4* src = reinterpret_cast<const uint4*>(wgrp + (size_t)g * 32768);
-    for (u32 i = t; i < 2048; i += 256) reinterpret_cast<uint4*>(w)[i] = src[i];
-    __syncthreads();
-    const u32 low_base = 32768 - have[g * GZ_GROUP], low_here = 32768 - have[s + 1];
-    u32 bad = 0;
-    for (u32 c = t; c < 1024; c += 256) {                                        // chunks of 32 positions
-        const uint4* m4 = reinterpret_cast<const uint4*>(map + (size_t)s * 32768 + c * 32);
-        u32 x[16];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint4 v = m4[k]; x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w; }
-        u32 o[8];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u32 a = x[k] & 0xffffu, b2 = x[k] >> 16;
-            const u32 wa = a & 0x7fffu, wb = b2 & 0x7fffu;
-            const u32 la = w[wa], lb = w[wb];
-            const u32 i0 = c * 32 + 2 * k;
-            bad |= (a >= 0x8000u && i0 >= low_here && wa < low_base) || (b2 >= 0x8000u && i0 + 1 >= low_here && wb < low_base);
-            const u32 two = ((a >= 0x8000u ? la : a) & 0xffu) | ((b2 >= 0x8000u ? lb : b2) & 0xffu) << 8;
-            if (k & 1) o[k >> 1] |= two << 16; else o[k >> 1] = two;
-        }
-        uint4* dg = reinterpret_cast<uint4*>(wall + (size_t)(s + 1) * 32768 + c * 32);
-        dg[0] = make_uint4(o[0], o[1], o[2], o[3]); dg[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    }
-    if (bad) info[4] = 1;
-}
-
-__global__ void __launch_bounds__(256)
-k_gz_resolve(const u16* __restrict__ sym, u32 cap, const GzSpan* __restrict__ res, const u64* __restrict__ off, const u64* __restrict__ info,
-             const u8* __restrict__ wall, char* __restrict__ text)
-{
-    const u32 s = blockIdx.y;
-    if (s >= (u32)info[0]) return;
-    const u32 n = res[s].n_sym;
-    const u16* sy = sym + (size_t)s * cap;
-    const u8* w = wall + (size_t)s * 32768;                                     // the window in front of span s
-    char* o = text + off[s];
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const u32 x = sy[i]; o[i] = (char)(x < 0x8000u ? x : w[x & 0x7fffu]); }
-}
-
-// CRC-32 of every 64 KiB piece of a text (the caller joins them: crc32 of a concatenation = crc1 * x^(8 len2) + crc2)
-__global__ void __launch_bounds__(64)
-k_crc_segs(const u8* __restrict__ text, u64 total, u32* __restrict__ crc)
-{
-    __shared__ u32 s_crc_tab[256];
-    const int lane = threadIdx.x;
-    inf_crc_table(s_crc_tab, lane);
-    __syncthreads();
-    const u64 a = (u64)blockIdx.x << 16;
-    if (a >= total) return;
-    const u32 len = (u32)min((u64)65536, total - a);
-    const u32 x = inf_crc32_wave(text + a, len, s_crc_tab, lane);
-    if (lane == 0) crc[blockIdx.x] = x;
-}
 #endif

@@ -182,8 +182,12 @@ struct Pinned {                                  // page-locked staging (bmbs_ho
 // the newlines counted per 64 KiB block by the thread that has just read it.  .gz: a thread of its own inflates into a queue of
 // chunks (so that the two files of a paired-end run inflate side by side) and the window is assembled from them. ---------------
 #define SUB_BLOCK ((size_t)1 << 16)
+// --loop-input N (measurement aid; plain FASTQ, and BGZF input that is inflated on the device): a part's byte range is read N times over, so that a run lasts seconds on an input
+// that fits the page cache (the pipeline's fill and the contexts' first calls then weigh what they weigh in a real run)
+static int g_loop_input = 1;
 struct Source {
     bool gz = false;
+    size_t lo0 = 0; int loops_left = 0;
     int fd = -1;
     size_t size = 0, off = 0, end = 0;           // plain: the part's byte range [off, end)
     std::string err;
@@ -284,7 +288,7 @@ struct Source {
             if (bgzf) {
                 const char* zd = getenv("BMBS_GZ_DEVICE");
                 if (zd && !strcmp(zd, "0")) zdev = -1;
-                if (zdev >= 0) { zdirect = true; zstage.kind = 1; return true; }      // inflated on the device, a window at a time (no threads here)
+                if (zdev >= 0) { zdirect = true; zstage.kind = 1; loops_left = g_loop_input - 1; return true; }      // inflated on the device, a window at a time (no threads here)
                 const int n_inflaters = gz_threads_;
                 live_inflaters = n_inflaters;                   // (the threads count it down as they finish: not the loop bound)
                 for (int t = 0; t < n_inflaters; t++)
@@ -352,6 +356,7 @@ struct Source {
         if (fstat(fd, &sb)) return false;
         size = (size_t)sb.st_size;
         off = std::min(lo, size); end = std::min(hi, size);
+        lo0 = off; loops_left = g_loop_input - 1;
         (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
         return true;
     }
@@ -361,6 +366,7 @@ struct Source {
     {
         size_t len = 0;
         if (!gz) {
+            if (off == end && loops_left > 0) { off = lo0; loops_left--; }
             len = std::min(cap, end - off);
             const size_t nsb = (len + SUB_BLOCK - 1) / SUB_BLOCK;
             counts.assign(nsb, 0);
@@ -383,7 +389,7 @@ struct Source {
                 }
             });
             if (bad) { err = std::string("read error on the FASTQ input: ") + strerror(bad); return false; }
-            last = off + len == end;
+            last = off + len == end && loops_left == 0;
         } else if (zdirect) {
             if (!zc) {
                 // (only when the driver's two-phase path is not in use: a context of this source's own inflates into the host window)
@@ -821,6 +827,7 @@ int main(int argc, char** argv)
         }
         else if (a == "--contexts") contexts = atoi(val());
         else if (a == "--batch") batch = atol(val());
+        else if (a == "--loop-input") g_loop_input = std::max(1, atoi(val()));
         else if (a == "--out-parts") parts = atoi(val());
         else if (a == "--print-plan") print_parts = print_plan = true;           // ... and how the parts are worked off: devices, contexts, workers (no GPU needed: tests)
         else if (a == "--print-parts") print_parts = true;                   // the record ranges --out-parts would use, then exit (no GPU needed: tests)
@@ -954,6 +961,7 @@ int main(int argc, char** argv)
         Pinned buf[2]; std::vector<uint64_t> blk[2], out[2];
         size_t a[2] = {0, 0}, q[2] = {0, 0};
         bool foreign_any = false, ok = true; std::string err;
+        bool last[2] = {false, false};               // the window ends its file (--loop-input: for the last time)
     } zst[2];
     for (auto& x : zst) { x.buf[0].kind = 1; x.buf[1].kind = 1; }
     std::thread prealloc([&] {
@@ -1124,6 +1132,8 @@ int main(int argc, char** argv)
                     pl.run(T, [&](int t) { const size_t x = std::min(zbytes, per * (size_t)t), y = std::min(zbytes, x + per); if (x < y) memcpy(dst + x, src + x, y - x); });
                 }
                 s.znext = g.q[f];
+                g.last[f] = g.q[f] >= s.zsize && s.loops_left == 0;
+                if (g.q[f] >= s.zsize && s.loops_left > 0) { s.znext = 0; s.loops_left--; }      // --loop-input: the file once more
             }
         };
         auto room_for = [&](size_t est_now, int f) {
@@ -1169,7 +1179,7 @@ int main(int argc, char** argv)
                 z[f].comp = g.buf[f].p; z[f].comp_bytes = g.q[f] - g.a[f]; z[f].blk_off = g.blk[f].data(); z[f].out_off = g.out[f].data(); z[f].n_blocks = (int64_t)g.blk[f].size() - 1;
                 text_bytes += s.carry.size() + (size_t)g.out[f].back();
             }
-            const bool last1 = g.q[0] >= pt->s1.zsize, last2 = pe && g.q[1] >= pt->s2.zsize;
+            const bool last1 = g.last[0], last2 = pe && g.last[1];
             // the window behind this one is staged while the device works on this one (what this window will leave over is not known
             // yet: the last window's leftover stands in for it when the room is measured)
             {
@@ -1372,6 +1382,15 @@ int main(int argc, char** argv)
                 n_owner, contexts, parts);
     if (verbose)
         fprintf(stderr, "[bmbs_search] stage idle (waiting for a batch, summed): readers %.3fs, gpu workers %.3fs, writers %.3fs\n", t_wait_r, t_wait_g, t_wait_w);
+    if (verbose) {
+        // what bounds the run: the link's busy time per direction (copies of the text calls, summed over the contexts: one copy per direction
+        // and device at a time) and the workers' busy time against the mapping wall
+        double up = 0, down = 0, in_calls = 0, calls = 0;
+        for (bmbs_ctx* c : ctxs) { double t4[4]; if (bmbs_text_times(c, t4) == 0) { up += t4[0]; down += t4[1]; in_calls += t4[2]; calls += t4[3]; } }
+        const double wall_s = t_end - t_loaded, nd = (double)std::max<size_t>(1, n_owner);
+        fprintf(stderr, "[bmbs_search] busy fractions of the mapping wall: link up %.3f, link down %.3f (per device), gpu workers %.3f, readers %.3f, writers %.3f  (text calls %.0f, %.3fs inside them)\n",
+                up / nd / wall_s, down / nd / wall_s, t_gpu / std::max(1, n_ctx) / wall_s, t_read / std::max(1, live_parts) / wall_s, t_write / std::max(1, live_parts) / wall_s, calls, in_calls);
+    }
     const double t0 = now();
     for (auto& b : batches) { b.text1.release(); b.text2.release(); b.sam.release(); }
     const double t1 = now();

@@ -12,18 +12,13 @@
 // by the link behind them, not by arithmetic.
 #ifndef BMBS_TEXT_HIP
 #define BMBS_TEXT_HIP
+#include "bmbs_bytes.h"
 
 // ---- FASTQ text -> newline positions -----------------------------------------------------------------------------------------------
 #define FQ_TILE_THREADS 256
 #define FQ_BYTES_PER_THREAD 64
 #define FQ_TILE_BYTES (FQ_TILE_THREADS * FQ_BYTES_PER_THREAD)
 
-// bit 8j+7 set where byte j of w is '\n'
-DEVI u32 nl_mask4(u32 w)
-{
-    const u32 x = w ^ 0x0a0a0a0au;
-    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
-}
 // the 64 bytes of thread `t` of a tile as a 64-bit mask of newline positions (bit j = byte j); bytes at and beyond `n` do not count
 DEVI u64 nl_mask64(const char* __restrict__ text, u64 base, u64 n)
 {

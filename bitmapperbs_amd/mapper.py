@@ -207,55 +207,6 @@ class Mapper:
         self._chk(self._lib.bmbs_inflate_bgzf(self._ctx, capi.ptr(a), a.size, capi.ptr(b), capi.ptr(o), n, capi.ptr(text), out[-1], capi.ptr(cnt), shift))
         return text[:out[-1]].tobytes(), cnt
 
-    def inflate_gzip(self, data: bytes, window: int = 1 << 22, margin: int = 1 << 18):
-        """the text of ONE gzip member (an ordinary .gz file), inflated on the device window by window (bmbs_inflate_gzip): the
-        caller's loop -- compressed bytes from the last block boundary on, the 32 KiB of text in front of it, a margin of one block
-        before the end of what a call is given.  -> (text, calls); raises when a call makes no progress"""
-        import struct
-        import zlib
-        assert data[:3] == b"\x1f\x8b\x08"
-        flg = data[3]; at = 10
-        if flg & 4:
-            at += 2 + struct.unpack("<H", data[at:at + 2])[0]
-        if flg & 8:
-            at = data.index(b"\0", at) + 1
-        if flg & 16:
-            at = data.index(b"\0", at) + 1
-        if flg & 2:
-            at += 2
-        bit = at * 8                                        # absolute bit position of the next block
-        win = b""
-        out = []
-        calls = 0
-        a = np.frombuffer(data, dtype=np.uint8)
-        while True:
-            b0 = bit >> 3
-            nbytes = min(len(data) - b0, window)
-            eof = b0 + nbytes >= len(data)
-            limit = nbytes if eof else max(1, nbytes - margin)
-            cap = max(1 << 20, nbytes * 40)
-            text = np.empty(cap, dtype=np.uint8)
-            wout = np.empty(32768, dtype=np.uint8)
-            tb = C.c_uint64(0); eb = C.c_uint64(0); fin = C.c_int32(0); wl = C.c_uint32(0)
-            w = np.frombuffer(win, dtype=np.uint8) if win else np.zeros(1, dtype=np.uint8)
-            chunk = np.ascontiguousarray(a[b0:b0 + nbytes])
-            self._chk(self._lib.bmbs_inflate_gzip(self._ctx, capi.ptr(chunk), nbytes, bit & 7, limit, capi.ptr(w), len(win), capi.ptr(text), cap,
-                                                  C.byref(tb), C.byref(eb), C.byref(fin), capi.ptr(wout), C.byref(wl)))
-            calls += 1
-            if tb.value == 0 and not fin.value:
-                raise RuntimeError("bmbs_inflate_gzip made no progress at bit %d" % bit)
-            out.append(text[:tb.value].tobytes())
-            win = wout[:wl.value].tobytes()
-            bit = b0 * 8 + eb.value
-            if fin.value:
-                break
-        text = b"".join(out)
-        tr = ((bit + 7) >> 3)
-        crc, isize = struct.unpack("<II", data[tr:tr + 8])
-        if zlib.crc32(text) != crc or (len(text) & 0xffffffff) != isize:
-            raise RuntimeError("gzip trailer does not match the inflated text")
-        return text, calls
-
     @staticmethod
     def _ztext(prefix: bytes, blocks: bytes, keep):
         """a capi.ZText over `prefix` + the BGZF blocks in `blocks` (objects that must stay alive are appended to `keep`)"""
@@ -286,33 +237,6 @@ class Mapper:
         self._chk(self._lib.bmbs_text_open_bgzf(self._ctx, C.byref(z1), C.byref(z2) if z2 is not None else None, max_records, int(last[0]), int(last[1]),
                                                 C.byref(n), capi.ptr(t1), tail_cap, C.byref(b1), capi.ptr(t2), C.byref(b2)))
         return int(n.value), t1[:b1.value].tobytes(), t2[:b2.value].tobytes()
-
-    def text_open_gzip(self, g1, g2=None, max_records=1 << 30, last=(False, False), tail_cap=1 << 24):
-        """g = dict(prefix, comp, start_bit, limit, win): a window of ONE deflate stream per file, inflated and indexed on the device ->
-        (records, tail1, tail2, out1, out2) with out = dict(end_bit, final, crc32, text_bytes, win)"""
-        self._set_refs()
-        keep = []
-
-        def mk(g):
-            z = capi.GzText()
-            for name, val in (("prefix", g["prefix"]), ("comp", g["comp"]), ("win", g["win"])):
-                a = np.frombuffer(val, dtype=np.uint8) if val else np.zeros(1, dtype=np.uint8)
-                keep.append(a)
-                setattr(z, name, a.ctypes.data)
-            z.prefix_bytes = len(g["prefix"]); z.comp_bytes = len(g["comp"]); z.win_len = len(g["win"])
-            z.start_bit = g["start_bit"]; z.limit_bytes = g["limit"]
-            wo = np.empty(32768, dtype=np.uint8); keep.append(wo)
-            z.win_out = wo.ctypes.data
-            return z, wo
-        z1, w1 = mk(g1)
-        z2, w2 = mk(g2) if g2 is not None else (None, None)
-        t1 = np.empty(tail_cap, dtype=np.uint8); t2 = np.empty(tail_cap, dtype=np.uint8)
-        n = C.c_int64(0); b1 = C.c_uint64(0); b2 = C.c_uint64(0)
-        self._chk(self._lib.bmbs_text_open_gzip(self._ctx, C.byref(z1), C.byref(z2) if z2 is not None else None, max_records, int(last[0]), int(last[1]),
-                                                C.byref(n), capi.ptr(t1), tail_cap, C.byref(b1), capi.ptr(t2), C.byref(b2)))
-        outs = [dict(end_bit=int(z.end_bit), final=bool(z.final_block), crc32=int(z.crc32), text_bytes=int(z.text_bytes), win=w[:z.win_out_len].tobytes()) if z is not None else None
-                for z, w in ((z1, w1), (z2, w2))]
-        return int(n.value), t1[:b1.value].tobytes(), t2[:b2.value].tobytes(), outs[0], outs[1]
 
     def text_map_open(self, flags: int = 0, cap: int = 1 << 28) -> bytes:
         out = np.empty(cap, dtype=np.uint8)

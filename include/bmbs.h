@@ -262,20 +262,6 @@ int bmbs_map_se_text(bmbs_ctx*, const char* text, uint64_t text_bytes, int64_t n
 int bmbs_map_pe_text(bmbs_ctx*, const char* text1, uint64_t bytes1, const char* text2, uint64_t bytes2, int64_t n_pairs, int32_t flags,
                      char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
 
-/* ---- an ordinary .gz member (ONE deflate stream) inflated on the device, a window at a time ------------------------------------------
- * comp[0, comp_bytes): compressed bytes of the stream from the byte that holds bit start_bit -- a block boundary the caller knows (the
- * stream's first block, or where the previous call stopped); win_in: the win_len (<= 32768) bytes of text in front of that point.
- * The window is cut every 64 KiB; a wave per cut finds the next block start and decodes its span with the 32 KiB in front of it
- * unknown (16-bit symbols, markers), the spans are chained in order and resolved (bmbs_inflate.hip).  Blocks are entered up to
- * limit_bytes: keep a margin of one block (256 KiB is plenty) before the end of what comp holds, or pass comp_bytes at the end of
- * the file.  -> text of every span the chain reached, *end_bit = where it stopped (a block boundary, relative to comp), *final_block
- * = the stream's last block was decoded (its 8-byte trailer follows at the next byte boundary: CRC-32 and ISIZE are the caller's to
- * check), win_out / *win_out_len = the text behind that point for the next call.  *text_bytes == 0 with BMBS_OK: nothing could be
- * confirmed (stored blocks only, a block longer than a span's slot): the caller's host inflater takes over.  BMBS_ENOMEM with
- * *text_bytes set when text_cap is too small.  Needs no index.                                                                       */
-int bmbs_inflate_gzip(bmbs_ctx*, const void* comp, uint64_t comp_bytes, uint32_t start_bit, uint64_t limit_bytes, const void* win_in, uint32_t win_len,
-                      char* text, uint64_t text_cap, uint64_t* text_bytes, uint64_t* end_bit, int32_t* final_block, void* win_out, uint32_t* win_out_len);
-
 /* ---- bgzip'ed FASTQ inflated on the device -------------------------------------------------------------------------------------------
  * The reference reads .gz input through zlib's gzread on its reader thread (Process_Reads.cpp:1455-1514).  A BGZF file (bgzip) is a
  * series of independent gzip members of at most 64 KiB of text whose compressed size stands in the header: a window of them is
@@ -310,31 +296,8 @@ typedef struct bmbs_ztext {
 int bmbs_text_open_bgzf(bmbs_ctx*, const bmbs_ztext* mate1, const bmbs_ztext* mate2 /* NULL: single end */, int64_t max_records,
                         int32_t last1, int32_t last2, int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes,
                         char* tail2, uint64_t* tail2_bytes);
-/* the same for an ordinary .gz member (ONE deflate stream; bmbs_inflate_gzip describes the scheme and the caller's loop): the window's
- * compressed bytes from the block boundary the previous call reached, the text in front of it, and back come -- per file -- where the
- * chain of spans stopped, whether the stream's final block was decoded, the window's CRC-32 and length (the caller joins them over a
- * member and checks the trailer) and the 32 KiB for the next call.  last*: this file ends with the member's final block (its last line
- * gets a newline when it has none) -- applied only when that block was reached.  text_bytes == 0 in a file whose call was given
- * compressed bytes: nothing could be confirmed there, the caller's host inflater takes that file over.                               */
-typedef struct bmbs_gztext {
-    const char*     prefix;        /* host; NULL when prefix_bytes == 0: what the previous window left over */
-    uint64_t        prefix_bytes;
-    const void*     comp;          /* compressed bytes from the byte that holds bit start_bit (page-locked memory moves at link speed) */
-    uint64_t        comp_bytes;    /* may be 0 (a window made of the prefix alone) */
-    uint32_t        start_bit;     /* a block boundary */
-    uint64_t        limit_bytes;   /* blocks are entered up to here: a block's margin before comp_bytes, or comp_bytes at the end of the file */
-    const void*     win;           /* the win_len (<= 32768) bytes of text in front of start_bit */
-    uint32_t        win_len;
-    /* out */
-    uint64_t        end_bit;       /* where the chain stopped: a block boundary, relative to comp */
-    int32_t         final_block;
-    uint32_t        crc32;         /* of the text_bytes of text this window's blocks inflated to */
-    uint64_t        text_bytes;
-    void*           win_out;       /* [32768]: receives the win_out_len bytes of text behind end_bit */
-    uint32_t        win_out_len;
-} bmbs_gztext;
-int bmbs_text_open_gzip(bmbs_ctx*, bmbs_gztext* mate1, bmbs_gztext* mate2 /* NULL: single end */, int64_t max_records, int32_t last1, int32_t last2,
-                        int64_t* n_records, char* tail1, uint64_t tail_cap, uint64_t* tail1_bytes, char* tail2, uint64_t* tail2_bytes);
+/* (An ordinary .gz file -- ONE deflate stream per member -- is inflated by the driver's block-parallel host inflater, csrc/pgz.h.  Round 4
+ * also carried a device form of that scheme, bmbs_inflate_gzip / bmbs_text_open_gzip: exact, and slower than the host's; removed in round 5.) */
 int bmbs_text_map_open(bmbs_ctx*, int32_t flags, char* sam, uint64_t sam_cap, uint64_t* sam_bytes, int64_t* n_lines);
 
 /* a21: per-ctx counters of the batches mapped so far = {reads, unique, ambiguous, mapped bases,
@@ -364,6 +327,10 @@ int bmbs_counters_all(bmbs_ctx*, uint64_t c[32]);
 /* calls that were issued a second time with exact buffer sizes because a stage count (candidate slots, DP jobs, re-seeded
  * candidates) exceeded the capacity learned from earlier calls (see "launch sequence" below); diagnostic                      */
 int64_t bmbs_retries(bmbs_ctx*);
+/* diagnostic (bmbs_search --verbose, bench.py's e2e keys): out = { seconds the context's bmbs_map_*_text / bmbs_text_map_open calls kept
+ * the link busy with uploads, with downloads (a copy and the wait for its end; waiting for another context's copy excluded), seconds
+ * spent inside those calls, number of calls }                                                                                     */
+int bmbs_text_times(bmbs_ctx*, double out[4]);
 /* diagnostic: the Huffman code lengths the device's BGZF deflater (--bam) gives a table of symbol frequencies -- n <= 320 symbols,
  * maxbits <= 15; every used symbol gets a length, the lengths form a complete prefix code (tests/test_gpu_parity.py)              */
 int bmbs_debug_huff_lengths(bmbs_ctx*, const uint32_t* freq, int32_t n, int32_t maxbits, uint8_t* len_out);

@@ -1332,36 +1332,6 @@ def test_device_huffman_lengths_form_a_complete_code(env):
     m.close()
 
 
-@pytest.mark.parametrize("level,span,window", [(1, 65536, 1 << 22), (6, 65536, 1 << 22), (9, 4096, 300000), (1, 2048, 100000), (6, 65536, 700000)])
-def test_device_gzip_inflate_equals_zlib(env, level, span, window, monkeypatch):
-    """an ordinary one-member .gz file (one deflate stream): spans cut every `span` bytes, block starts found by the search over bit
-    offsets, 16-bit symbols with window markers, chained and resolved on the device -- the text, and the trailer's CRC-32 / ISIZE, are
-    zlib's; several calls per file (the caller's loop carries the bit position and the 32 KiB window)"""
-    import zlib
-    from bitmapperbs_amd import mapper
-    monkeypatch.setenv("BMBS_GZ_DEV_SPAN", str(span))
-    rng = np.random.default_rng(7 + level)
-    n = 30000
-    seq = np.frombuffer(b"AGTC", dtype=np.uint8)[rng.choice(4, size=(n, 150), p=[0.3, 0.3, 0.39, 0.01])]
-    q = np.frombuffer(b"FFFFFFFF:,#", dtype=np.uint8)[rng.integers(0, 11, size=(n, 150))]
-    out = bytearray()
-    for i in range(n):
-        out += b"@read%d/1\n" % i; out += seq[i].tobytes(); out += b"\n+\n"; out += q[i].tobytes(); out += b"\n"
-    text = bytes(out)
-    m = mapper.Mapper(env["ix"], 0)
-    noise = bytes(rng.integers(0, 256, 200000, dtype=np.uint8))
-    for k, data in enumerate((gzip.compress(text, level), gzip.compress(text[:1000], level), gzip.compress(noise + text[:300000], level),
-                              gzip.compress(b"A" * 3000000 + text[:50000], level))):
-        try:
-            got, calls = m.inflate_gzip(data, window=window)
-        except RuntimeError as ex:
-            # (the device path may decline -- a block that inflates to more than a span's slot holds -- but never return wrong text)
-            assert "no progress" in str(ex) and k == 3, ex
-            continue
-        assert got == zlib.decompress(data, 31), (len(got), calls)
-    m.close()
-
-
 def test_device_bgzf_inflate_equals_zlib(env):
     """bmbs_inflate_bgzf (one wave per BGZF block, bmbs_inflate.hip) against zlib: FASTQ text at every compression level and
     strategy (dynamic, fixed and stored blocks, codes longer than the root tables, runs that overlap themselves, several deflate
@@ -1481,75 +1451,6 @@ def test_bgzf_windows_opened_on_the_device_map_like_the_text(env, mode):
     m.close()
 
 
-@pytest.mark.parametrize("mode", ["se", "pe", "pe_bam"])
-def test_gzip_windows_opened_on_the_device_map_like_the_text(env, mode, monkeypatch):
-    """bmbs_text_open_gzip + bmbs_text_map_open: ordinary one-member .gz files (one deflate stream each) taken a window of compressed
-    bytes at a time -- the call says where its chain of spans stopped and hands back the 32 KiB behind that point, the records that
-    straddle windows travel as prefixes, the windows' CRCs joined give the trailer's -- gives, window by window, exactly the lines
-    bmbs_map_*_text prints for the whole text"""
-    import struct
-    import zlib
-    from bitmapperbs_amd import synth, mapper
-    M = mapper.Mapper
-    monkeypatch.setenv("BMBS_GZ_DEV_SPAN", "3000")
-    pe = mode != "se"
-    n = 5000
-    if pe:
-        m1, m2 = synth.make_reads_pe(env["chroms"], n=n, L=120, seed=61, sub=0.02, indel=0.002, qual="random")
-        rng = np.random.default_rng(7)
-        l1 = rng.integers(40, 121, n); l2 = rng.integers(40, 121, n)
-        texts = [b"".join(b"@" + mm["names"][i] + b"\n" + mm["seq"][i, :ll[i]].tobytes() + b"\n+\n" + mm["qual"][i, :ll[i]].tobytes() + b"\n" for i in range(n))[:-1]
-                 for mm, ll in ((m1, l1), (m2, l2))]
-    else:
-        texts = [_odd_fastq(env, n=n)[:-1]]
-    flags = M.TEXT_UNMAPPED | (M.TEXT_BAM if mode == "pe_bam" else 0)
-    m = M(env["ix"], 0)
-    want = m.map_text(texts[0] + b"\n", n, (texts[1] + b"\n") if pe else None, flags=flags)
-    files = [gzip.compress(t, [6, 1][k]) for k, t in enumerate(texts)]
-    nf = len(files)
-    bit = [80, 80]                                              # (gzip.compress writes the 10-byte header)
-    win = [b"", b""]; carry = [b"", b""]; crc = [0, 0]; length = [0, 0]; done = [False, False]
-    got = []; total = 0
-    step = [60000, 45000]                                       # compressed bytes a call is given
-    for _ in range(1000):
-        g = []
-        for k in range(nf):
-            b0 = bit[k] >> 3
-            nb = 0 if done[k] else min(len(files[k]) - 8 - b0, step[k])
-            eof = b0 + nb >= len(files[k]) - 8
-            g.append(dict(prefix=carry[k], comp=files[k][b0:b0 + nb], start_bit=bit[k] & 7, limit=nb if eof else max(1, nb - 9000), win=win[k]))
-        nrec, t1, t2, o1, o2 = m.text_open_gzip(g[0], g[1] if pe else None, max_records=700, last=(True, True))
-        carry = [t1, t2]
-        for k, o in enumerate((o1, o2)[:nf]):
-            if done[k] or not len(g[k]["comp"]):
-                continue
-            assert o["text_bytes"] or o["final"], "no progress"
-            crc[k] = _crc_join(crc[k], o["crc32"], o["text_bytes"]); length[k] += o["text_bytes"]
-            bit[k] = (bit[k] >> 3) * 8 + o["end_bit"]; win[k] = o["win"]
-            if o["final"]:
-                done[k] = True
-                tr = (bit[k] + 7) >> 3
-                assert struct.unpack("<II", files[k][tr:tr + 8]) == (crc[k], length[k] & 0xffffffff)
-        if nrec:
-            got.append(m.text_map_open(flags=flags)); total += nrec
-        if all(done[:nf]) and (nrec == 0 or not t1 or (pe and not t2)):
-            break
-    assert total == n
-    if mode == "pe_bam":
-        from common import bgzf_blocks
-        assert b"".join(raw for _, raw in bgzf_blocks(b"".join(got))) == b"".join(raw for _, raw in bgzf_blocks(want))
-    else:
-        assert b"".join(got) == want
-    m.close()
-
-
-def _crc_join(crc1, crc2, len2):
-    """zlib's crc32_combine: crc(A + B) = crc(A + 0^len2) ^ crc(0^len2) ^ crc(B)"""
-    import zlib
-    z = b"\0" * len2
-    return zlib.crc32(z, crc1) ^ zlib.crc32(z) ^ crc2
-
-
 def test_text_call_with_a_small_buffer_can_be_repeated_and_counts_once(env):
     """BMBS_ENOMEM of bmbs_map_*_text (output buffer too small) is retriable (*sam_bytes = the size needed): the batch it mapped is
     NOT added to the context's mapstats, so that the repeat counts it once (SAM text and BAM)"""
@@ -1576,7 +1477,7 @@ def test_text_call_with_a_small_buffer_can_be_repeated_and_counts_once(env):
 @pytest.mark.parametrize("kind,name,nparts,mode", [
     ("se", "b150", 3, "plain"), ("pe", "p100", 4, "plain"), ("pe", "s100", 2, "names_differ"), ("pe", "p150", 3, "no_names"),
     ("se", "e75", 2, "gz"), ("pe", "p75", 3, "bam"), ("pe", "p100", 2, "bgzf"), ("se", "b150", 3, "bgzf"), ("pe", "p150", 2, "bgzf_tails_grow"),
-    ("se", "b150", 2, "gz_device"), ("pe", "p100", 2, "gz_device"), ("pe", "p150", 2, "gz_device_small_windows"),
+    ("se", "b150", 2, "gz"), ("pe", "p100", 2, "gz"),
 ])
 def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, nparts, mode, tmp_path):
     """--out-parts N: the input is cut into N record ranges (pairs: at the same record in both files, found by the read names, or by
@@ -1591,7 +1492,7 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
     if kind == "se":
         fq = str(tmp_path / "r.fq")
         gunzip_to(os.path.join(GOLD, "se_%s.fq.gz" % name), fq)
-        if mode in ("gz", "gz_device"):
+        if mode == "gz":
             shutil.copy(os.path.join(GOLD, "se_%s.fq.gz" % name), fq + ".gz"); fq += ".gz"
         if mode == "bgzf":              # bgzip-style input: independent blocks, inflated by several threads
             from common import write_bgzf
@@ -1612,7 +1513,7 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
                 for i in range(0, len(t) - 1, 4):
                     t[i] = b"@same"
                 open(f, "wb").write(b"\n".join(t))
-        if mode.startswith("gz_device"):          # ordinary one-member .gz files, inflated on the device (BMBS_GZ_DEVICE=2)
+        if mode == "gz":                    # ordinary one-member .gz files: the driver's block-parallel host inflater (pgz.h)
             shutil.copy(os.path.join(GOLD, "pe_%s_1.fq.gz" % name), f1 + ".gz"); shutil.copy(os.path.join(GOLD, "pe_%s_2.fq.gz" % name), f2 + ".gz")
             f1 += ".gz"; f2 += ".gz"
         if mode in ("bgzf", "bgzf_tails_grow"):
@@ -1625,17 +1526,13 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
     # (bgzf_tails_grow: the device-side reader starts with 8-byte buffers for what a window leaves behind its last whole record and has to
     # come back with room, bmbs_text_open_bgzf's BMBS_ENOMEM protocol)
     env = dict(os.environ, BMBS_Z_TAIL="8") if mode == "bgzf_tails_grow" else None
-    if mode == "gz_device":
-        env = dict(os.environ, BMBS_GZ_DEVICE="2", BMBS_GZ_DEV_SPAN="2048")
-    if mode == "gz_device_small_windows":     # a few kilobytes of compressed input per call: most calls end inside a block, the host inflates it
-        env = dict(os.environ, BMBS_GZ_DEVICE="2", BMBS_GZ_DEV_SPAN="1024", BMBS_GZ_DEV_WINDOW="9000", BMBS_Z_TAIL="64")
     one = subprocess.run([_driver(), "--search", fa] + inp + ["-o", out, "--batch", "211"] + args, capture_output=True, text=True, env=env)
     assert one.returncode == 0, one.stderr
     par = subprocess.run([_driver(), "--search", fa] + inp + ["-o", out + ".p", "--batch", "211", "--out-parts", str(nparts)] + args,
                          capture_output=True, text=True)
     assert par.returncode == 0, par.stderr
     parts = [open(out + ".p.part%03d" % i, "rb").read() for i in range(nparts)]
-    if mode not in ("gz", "bgzf", "bgzf_tails_grow") and not mode.startswith("gz_device"):
+    if mode not in ("gz", "bgzf", "bgzf_tails_grow"):
         assert all(len(x) > 0 for x in parts[1:])         # every part got its share
     if mode == "bam":
         from common import bam_payload
@@ -1645,7 +1542,7 @@ def test_cpp_driver_out_parts_concatenate_to_the_one_file_output(kind, name, npa
     else:
         strip = lambda b: b"".join(l for l in b.splitlines(keepends=True) if not l.startswith(b"@PG"))
         assert strip(b"".join(parts)) == strip(open(out, "rb").read())
-        if mode in ("plain", "gz", "bgzf", "bgzf_tails_grow") or mode.startswith("gz_device"):
+        if mode in ("plain", "gz", "bgzf", "bgzf_tails_grow"):
             ref = gzip.open(os.path.join(GOLD, "%s_%s.ref.sam.gz" % (kind, name)), "rb").read()
             assert strip(b"".join(parts)) == ref
     st = lambda p: "".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("No. of") or l.startswith("Mismatch"))
