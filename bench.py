@@ -71,6 +71,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single-lane", action="store_true", help="skip the extra single-lane pass that times the kernels alone")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1] SE line, stress keys)")
+    ap.add_argument("--no-stress", action="store_true", help="keep the PCIe-inclusive and file-to-file keys, skip the stress keys behind them (other genomes / read sets)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S)
     ap.add_argument("--host-index", action="store_true", help="build the index with the host builder (bmbs_index_build)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective check without a GPU: gloo, no mapping (tests)")
@@ -688,52 +689,75 @@ def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", r
                 os.environ[k_] = v_
 
 
-def host_buffer_rate(m, job, torch, jobs_per_read=0.0):
-    """PCIe-inclusive rate through the host-pointer entry point (bmbs_map_se / bmbs_map_pe): page-locked host buffers in, records
-    and CIGAR pool back out, copy-in -> kernels -> copy-out serialised on one context (never `value`)."""
+def host_buffer_rate(m, job, torch, jobs_per_read=0.0, packed=False):
+    """PCIe-inclusive rate through the host-pointer entry points: page-locked host buffers in, records and CIGAR pool back out,
+    copy-in -> kernels -> copy-out of different chunks overlapped on one context (never `value`).  packed: bmbs_map_*_packed -- the
+    sequences as 2 bits per base + an 'N' plane (bmbs_pack_rows, timed apart), the qualities as bytes."""
     import ctypes as C
     from bitmapperbs_amd import capi
     lib = capi.lib()
     n = min(job.n, 2_000_000)
     host = [x[:n].cpu().numpy() for x in job.batches[0]]
     nbytes = host[0].nbytes
+    L, stride, pe = job.L, job.stride, job.cfg["pe"]
+    pwords = (L + 31) // 32 + (L + 63) // 64
     pin = []
-    for h in host:
-        p_ = lib.bmbs_host_alloc(nbytes)
-        C.memmove(p_, h.ctypes.data, nbytes)
+    pack_s = None
+    for i, h in enumerate(host):
+        if packed and i % 2 == 0:                  # sequence rows -> packed rows, straight into page-locked memory
+            p_ = lib.bmbs_host_alloc(n * pwords * 8)
+            t0 = time.perf_counter()
+            rc = lib.bmbs_pack_rows(h.ctypes.data, L, stride, n, None, p_, pwords, 16, None)
+            pack_s = (pack_s or 0.0) + time.perf_counter() - t0
+            if rc:
+                raise RuntimeError("bmbs_pack_rows: %d" % rc)
+        else:
+            p_ = lib.bmbs_host_alloc(nbytes)
+            C.memmove(p_, h.ctypes.data, nbytes)
         pin.append(p_)
-    nrec = n * (2 if job.cfg["pe"] else 1)
+    nrec = n * (2 if pe else 1)
     cap = nrec * job.max_ops
     res = lib.bmbs_host_alloc(nrec * 32); pool = lib.bmbs_host_alloc(cap * 4)
     used = C.c_int64(0)
     def call():
-        if job.cfg["pe"]:
-            rc = lib.bmbs_map_pe(m._ctx, pin[0], pin[1], pin[2], pin[3], job.L, job.stride, n, res, pool, cap, C.byref(used))
+        if packed and pe:
+            rc = lib.bmbs_map_pe_packed(m._ctx, pin[0], pin[2], pwords, pin[1], pin[3], None, None, L, stride, n, res, pool, cap, C.byref(used))
+        elif packed:
+            rc = lib.bmbs_map_se_packed(m._ctx, pin[0], pwords, pin[1], None, L, stride, n, res, pool, cap, C.byref(used))
+        elif pe:
+            rc = lib.bmbs_map_pe(m._ctx, pin[0], pin[1], pin[2], pin[3], L, stride, n, res, pool, cap, C.byref(used))
         else:
-            rc = lib.bmbs_map_se(m._ctx, pin[0], pin[1], job.L, job.stride, n, res, pool, cap, C.byref(used))
+            rc = lib.bmbs_map_se(m._ctx, pin[0], pin[1], L, stride, n, res, pool, cap, C.byref(used))
         if rc:
             raise RuntimeError(lib.bmbs_last_error(m._ctx).decode())
     call()
+    first = np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint8)), shape=(nrec * 32,)).copy()
     t = time.perf_counter()
     reps = 3
     for _ in range(reps):
         call()
     dt = time.perf_counter() - t
+    again = np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint8)), shape=(nrec * 32,))
+    same = bool((first == again).all())
     for p_ in pin + [res, pool]:
         lib.bmbs_host_free(p_)
-    up = nbytes * len(pin) * reps
+    up = ((n * pwords * 8 + nbytes) * (2 if pe else 1) if packed else nbytes * len(pin)) * reps
     # what the library copies back: a 32-byte record per read and the CIGAR slots of the DP jobs a chunk produced (max_ops x 4 bytes
     # per job; `used` is the EXTENT of the host pool that was written to, not the bytes moved)
     down = nrec * 32 * reps + int(jobs_per_read * nrec) * job.max_ops * 4 * reps
     LINK = 56.0           # GB/s one direction, page-locked, measured on these boxes (tools/pcie_probe; PCIe Gen5 x16 spec 63)
-    return {"what": "bmbs_map_%s on page-locked HOST buffers, %d %s per call: the call is cut into chunks of n/8 (250 k .. 500 k) units dealt to the context's lanes, "
-                    "uploads, kernels and downloads of different chunks overlap (copies on streams that carry no kernel); PCIe-inclusive, never `value`" % (
-                "pe" if job.cfg["pe"] else "se", n, "pairs" if job.cfg["pe"] else "reads"),
-            "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s",
-            "bytes_up_per_read": round(up / (nrec * reps), 1), "bytes_down_per_read": round(down / (nrec * reps), 1),
-            "host_cigar_pool_extent_per_read": round(int(used.value) * 4 / nrec, 1),
-            "upload_GBps": round(up / dt / 1e9, 1), "download_GBps": round(down / dt / 1e9, 1), "link_GBps_one_direction": LINK,
-            "frac_of_link": round(up / dt / 1e9 / LINK, 3)}
+    out = {"what": "bmbs_map_%s%s on page-locked HOST buffers, %d %s per call: the call is cut into chunks of n/8 (250 k .. 500 k) units dealt to the context's lanes, "
+                   "uploads, kernels and downloads of different chunks overlap (copies on streams that carry no kernel); PCIe-inclusive, never `value`" % (
+                "pe" if pe else "se", "_packed" if packed else "", n, "pairs" if pe else "reads"),
+           "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s",
+           "bytes_up_per_read": round(up / (nrec * reps), 1), "bytes_down_per_read": round(down / (nrec * reps), 1),
+           "host_cigar_pool_extent_per_read": round(int(used.value) * 4 / nrec, 1),
+           "upload_GBps": round(up / dt / 1e9, 1), "download_GBps": round(down / dt / 1e9, 1), "link_GBps_one_direction": LINK,
+           "frac_of_link": round(up / dt / 1e9 / LINK, 3), "repeat_calls_identical": same}
+    if packed:
+        out["pack_rows_host_GBps"] = round(nbytes * (2 if pe else 1) / pack_s / 1e9, 2)
+        out["pack_rows_threads"] = 16
+    return out, first
 
 
 def write_bgzf(path, data, level=1, threads=16):
@@ -1102,12 +1126,20 @@ def main():
                 out["sample_sam_lines_compared"] = nl
             if not args.no_secondary:
                 try:
-                    hb = host_buffer_rate(m, job, torch, jobs_per_read=float(cnt.get("n_jobs", 0)) / max(1, nr))
-                    out["e2e"] = {"host_buffers_overlapped": hb}
-                    # SURVEY 8(d) defines the metric "incl. H2D/D2H": the same mapping with inputs and results in HOST memory
-                    out["value_incl_pcie"] = {"value": hb["value"], "unit": "Mreads/s", "frac_of_link": hb["frac_of_link"],
-                                              "bytes_up_per_read": hb["bytes_up_per_read"], "bytes_down_per_read": hb["bytes_down_per_read"],
-                                              "what": "bmbs_map_pe / bmbs_map_se on page-locked host buffers (e2e.host_buffers_overlapped); `value` is the device-resident rate the roofline describes"}
+                    jpr = float(cnt.get("n_jobs", 0)) / max(1, nr)
+                    hb, rec_ascii = host_buffer_rate(m, job, torch, jobs_per_read=jpr)
+                    hp, rec_packed = host_buffer_rate(m, job, torch, jobs_per_read=jpr, packed=True)
+                    hp["records_identical_to_ascii_call"] = bool((rec_ascii == rec_packed).all())
+                    out["e2e"] = {"host_buffers_overlapped": hb, "host_buffers_packed": hp}
+                    # SURVEY 8(d) defines the metric "incl. H2D/D2H": the same mapping with inputs and results in HOST memory -- through the
+                    # packed entry point (2 bits per base over the link), and through the ASCII one beside it
+                    out["value_incl_pcie"] = {"value": hp["value"], "unit": "Mreads/s", "frac_of_link": hp["frac_of_link"],
+                                              "bytes_up_per_read": hp["bytes_up_per_read"], "bytes_down_per_read": hp["bytes_down_per_read"],
+                                              "entry": "bmbs_map_pe_packed" if pe else "bmbs_map_se_packed",
+                                              "ascii_rows": {"value": hb["value"], "frac_of_link": hb["frac_of_link"], "bytes_up_per_read": hb["bytes_up_per_read"],
+                                                             "entry": "bmbs_map_pe" if pe else "bmbs_map_se"},
+                                              "records_identical_to_ascii_call": hp["records_identical_to_ascii_call"],
+                                              "what": "page-locked host buffers in, records back out (e2e.host_buffers_packed / _overlapped); `value` is the device-resident rate the roofline describes"}
                 except Exception as ex:
                     out["e2e"] = {"error": repr(ex)}
                 try:
@@ -1129,6 +1161,10 @@ def main():
                     out["e2e"]["file_to_file"] = file_to_file_rate(args, cfg, fa, L)
             except Exception as ex:
                 out["e2e"]["file_to_file"] = {"error": repr(ex)}
+            if args.no_stress:
+                out["wall_s"] = round(time.time() - t_all, 1)
+                print(json.dumps(out), flush=True)
+                return
             c1 = dict(CONFIGS[1])
             small = dict(cfg, genome=46_000_000, n_chrom=4, launches=1, units=min(cfg["units"], 5_000_000))
             def one_key(name, *a, **kw):      # a secondary key must never lose the headline line, nor the keys behind it

@@ -22,7 +22,7 @@ SYMBOLS = [
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
     "bmbs_index_file_free", "bmbs_index_build", "bmbs_index_build_device", "bmbs_host_alloc", "bmbs_host_free", "bmbs_build_id",
-    "bmbs_max_cigar_ops", "bmbs_host_prefault", "bmbs_reserve", "bmbs_host_alloc_kind", "bmbs_retries", "bmbs_text_times", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset", "bmbs_inflate_bgzf", "bmbs_debug_huff_lengths", "bmbs_text_open_bgzf", "bmbs_text_map_open",
+    "bmbs_max_cigar_ops", "bmbs_host_prefault", "bmbs_reserve", "bmbs_host_alloc_kind", "bmbs_retries", "bmbs_text_times", "bmbs_pack_rows", "bmbs_map_se_packed", "bmbs_map_pe_packed", "bmbs_sam_refs", "bmbs_map_se_text", "bmbs_map_pe_text", "bmbs_profile_total", "bmbs_profile_reset", "bmbs_inflate_bgzf", "bmbs_debug_huff_lengths", "bmbs_text_open_bgzf", "bmbs_text_map_open",
 ]
 
 
@@ -115,6 +115,12 @@ def lib() -> C.CDLL:
     L.bmbs_map_se_var_device.argtypes = [vp, u64, u64, u64, i32, i32, i64, u64, u64, i64]
     L.bmbs_map_pe_var.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_map_pe_var_device.argtypes = [vp, u64, u64, u64, u64, u64, i32, i32, i64, u64, u64, i64]
+    L.bmbs_pack_rows.argtypes = [vp, i32, i32, i64, vp, vp, i32, i32, C.POINTER(i64)]
+    L.bmbs_pack_rows.restype = C.c_int
+    L.bmbs_map_se_packed.argtypes = [vp, vp, i32, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]
+    L.bmbs_map_se_packed.restype = C.c_int
+    L.bmbs_map_pe_packed.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]
+    L.bmbs_map_pe_packed.restype = C.c_int
     L.bmbs_map_se_fastq.argtypes = [vp, C.POINTER(FastqView), i64, i32, i32, i32, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_map_pe_fastq.argtypes = [vp, C.POINTER(FastqView), C.POINTER(FastqView), i64, i32, i32, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_sync.argtypes = [vp]

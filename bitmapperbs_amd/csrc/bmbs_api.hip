@@ -17,6 +17,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -103,6 +104,7 @@ struct Pending {
     int64_t cigar_cap = 0;
     u32 cigar_base = 0;
     bool prepared = false;                   // map_pe_dev: the lane's pe_seq already holds the rows (FASTQ-text entry point)
+    int packed_hw = 0;                       // > 0: a[0] (a[2]: mate 2) are the caller's PACKED rows, packed_hw words apart (bmbs_map_*_packed)
     bool staged = false;                     // the call reads lane-owned staging buffers, which the lane's next call overwrites
 };
 
@@ -145,6 +147,7 @@ struct Lane {
     DevBuf wavelog_buf, wavelog_count; std::string wavelog_path;    // BMBS_WAVELOG diagnostic
     DevBuf prow, prow_dirty;                            // packed copy of the read rows (k_pack_rows), one dirty byte per read
     double link_up_s = 0, link_down_s = 0, text_call_s = 0; u64 text_calls = 0;       // bmbs_text_times: wall seconds the text calls' copies held the link
+    DevBuf pk_in1, pk_in2, pk_ascii;                    // bmbs_map_*_packed: the caller's packed rows as uploaded; single end: the sparse ASCII rows
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // bmbs_map_*_text: newline index built on the device, SAM text written on the device
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
@@ -673,11 +676,11 @@ int cand_total(Lane* c, const ReadState& st, u64 n, bool exact, u64* tot_out)
 }
 
 // stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
-int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, u64* total_cand, int pe_mode = 0, bool exact = true)
+int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, u64* total_cand, int pe_mode = 0, bool exact = true, bool prepacked = false)
 {
     ReadState st = read_state(c);
     {
-        int rcs = launch_seeding(c, d_seq, gm, stride, n, pe_mode);
+        int rcs = launch_seeding(c, d_seq, gm, stride, n, pe_mode, prepacked);
         if (rcs) return rcs;
     }
     prof_begin(c, "scan_cand");
@@ -850,7 +853,7 @@ void lane_destroy(Lane* c)
                      &c->sd_sp0, &c->sd_hits0, &c->sd_ml0, &c->sd_tm, &c->sd_seed_id, &c->sd_clen, &c->sd_first_ml, &c->sd_flag_c, &c->sd_flag_d,
                      &c->sd_off_c, &c->sd_off_d, &c->sd_list_c, &c->sd_list_d, &c->pe_vround, &c->pe_dead, &c->pe_both, &c->pe_npair, &c->pe_sbd, &c->in_seq2, &c->in_qual2,
                      &c->pe_first, &c->pe_full, &c->pe_R, &c->pe_roff, &c->pe_rflag, &c->pe_rscan, &c->pe_rlist, &c->pe_rcnt, &c->pe_ritem_off, &c->pe_rcand, &c->long_flag, &c->long_off, &c->long_list, &c->vote_list,
-                     &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx, &c->prow, &c->prow_dirty, &c->pe_mid_flag, &c->pe_mid_list};
+                     &c->mapq_off, &c->klut, &c->in_len, &c->fq_text1, &c->fq_text2, &c->fq_idx, &c->pk_in1, &c->pk_in2, &c->pk_ascii, &c->prow, &c->prow_dirty, &c->pe_mid_flag, &c->pe_mid_list};
     for (DevBuf* b : all) release(*b);
     for (auto& set : c->profset) for (auto& p : set) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->arena.free_all();
@@ -899,7 +902,7 @@ extern "C" void bmbs_destroy(bmbs_ctx* X)
 
 extern "C" int32_t bmbs_max_cigar_ops(const bmbs_params* params, int32_t L)
 {
-    if (L <= 0 || L > 1000) return -1;
+    if (L <= 0 || L > BMBS_MAX_READ) return -1;
     bmbs_params P;
     if (params) P = *params; else bmbs_default_params(&P);
     return cigar_ops_bound(P, L, threshold_k(P, L));
@@ -1067,12 +1070,25 @@ int call_end(Lane* c, int slot)
     return BMBS_OK;
 }
 
+// the caller's packed rows (bmbs_map_*_packed) -> the lane's: prow / prow_dirty, and `ascii` (rows `stride` apart) gets the text of the
+// pieces that hold an 'N'.  rc: the rows are reverse-complemented on the way (mate 2).  row0: where these rows sit in the batch
+int rows_from_packed(Lane* c, const u64* src, int hw, const ReadGeom& gm, u64 row0, u64 n, bool rc, char* ascii, int stride)
+{
+    const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
+    if (hw < W + (gm.L + 63) / 64) { c->err = "packed rows: pwords is smaller than a row of this length takes"; return BMBS_EINVAL; }
+    const unsigned g = nblk(n * (u64)W, 256);
+    if (rc) hipLaunchKernelGGL(k_rows_from_packed<true>, dim3(g), dim3(256), 0, c->stream, src, hw, gm, (long)row0, (long)n, c->prow.as<u64>(), pwords, W, c->prow_dirty.as<u32>(), ascii, stride);
+    else hipLaunchKernelGGL(k_rows_from_packed<false>, dim3(g), dim3(256), 0, c->stream, src, hw, gm, (long)row0, (long)n, c->prow.as<u64>(), pwords, W, c->prow_dirty.as<u32>(), ascii, stride);
+    return BMBS_OK;
+}
+
+// packed_hw > 0: d_seq_ holds the caller's packed rows (packed_hw words apart) instead of ASCII rows
 int map_se_dev(Lane* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int32_t L, int32_t stride,
-               int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap, bool exact = true, u32 cigar_base = 0, int slot = 0)
+               int64_t n_reads, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap, bool exact = true, u32 cigar_base = 0, int slot = 0, int packed_hw = 0)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
-    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L <= 0 || L > BMBS_MAX_READ || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     if ((stride & 15) || (d_seq_ & 15) || (d_qual_ & 15)) { c->err = "device read buffers must be 16-byte aligned with a stride that is a multiple of 16"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
     const char* d_seq = reinterpret_cast<const char*>(d_seq_);
@@ -1090,10 +1106,22 @@ int map_se_dev(Lane* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int
     if (rc) return rc;
     rc = call_begin(c, slot);
     if (rc) return rc;
+    if (packed_hw) {
+        // the ASCII rows exist only where a piece holds an 'N' (written by k_rows_from_packed into the lane's own buffer)
+        if (!use_packed_rows(c)) { c->err = "packed reads need the packed-row kernels (BMBS_LEGACY is set)"; return BMBS_EINVAL; }
+        ENS(c, c->pk_ascii, n * (u64)stride + 64);
+        { int rz_ = ensure(c, c->prow, n * (u64)pack_words(gm.L) * 8 + 64, true); if (rz_) return rz_; } ENS(c, c->prow_dirty, n + 64);
+        HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n + 64, c->stream));
+        prof_begin(c, "k_rows_from_packed");
+        rc = rows_from_packed(c, reinterpret_cast<const u64*>(d_seq_), packed_hw, gm, 0, n, false, c->pk_ascii.as<char>(), stride);
+        if (rc) return rc;
+        prof_end(c);
+        d_seq = c->pk_ascii.as<char>();
+    }
     ReadState st = read_state(c);
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     u64 tot = 0;                     // candidate slots: the count itself (exact) or the capacity the buffers and grids are sized for
-    rc = run_seed_stages(c, d_seq, gm, stride, n, &tot, 0, exact);
+    rc = run_seed_stages(c, d_seq, gm, stride, n, &tot, 0, exact, packed_hw > 0);
     if (rc) return rc;
     c->last_total_cand = tot;
     ENS(c, c->vote_off, (n + 1) * 8);
@@ -1192,11 +1220,11 @@ namespace {
 // them there straight from the text and k_pe_prepare is not run
 int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint64_t d_qual2, const u16* d_len,
                int32_t L, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool, int64_t cigar_cap, bool prepared = false,
-               bool exact = true, u32 cigar_base = 0, int slot = 0)
+               bool exact = true, u32 cigar_base = 0, int slot = 0, int packed_hw = 0)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
-    if (L <= 0 || L > 1000 || stride < L || n_pairs < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L <= 0 || L > BMBS_MAX_READ || stride < L || n_pairs < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     if ((stride & 15) || ((d_seq1 | d_qual1 | d_seq2 | d_qual2) & 15)) { c->err = "device read buffers must be 16-byte aligned with a stride that is a multiple of 16"; return BMBS_EINVAL; }
     HIPCHK(c, hipSetDevice(c->dev));
     const u64 n = (u64)n_pairs, n2 = 2 * n;
@@ -1222,7 +1250,18 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     const char* qual_1 = reinterpret_cast<const char*>(d_qual1);
     const char* qual_2 = reinterpret_cast<const char*>(d_qual2);
     bool prepacked = false;
-    if (!prepared) {
+    if (packed_hw) {
+        // the caller's packed rows: mate 1 as it is, mate 2 reverse-complemented (bmbs_map_pe_packed); no ASCII rows to read at all
+        if (!use_packed_rows(c)) { c->err = "packed reads need the packed-row kernels (BMBS_LEGACY is set)"; return BMBS_EINVAL; }
+        { int rz_ = ensure(c, c->prow, n2 * (u64)pack_words(gm.L) * 8 + 64, true); if (rz_) return rz_; } ENS(c, c->prow_dirty, n2 + 64);
+        HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n2 + 64, c->stream));
+        prof_begin(c, "k_rows_from_packed");
+        rc = rows_from_packed(c, reinterpret_cast<const u64*>(d_seq1), packed_hw, gm, 0, n, false, seq_all, stride);
+        if (!rc) rc = rows_from_packed(c, reinterpret_cast<const u64*>(d_seq2), packed_hw, gm, n, n, true, seq_all, stride);
+        if (rc) return rc;
+        prof_end(c);
+        prepacked = true;
+    } else if (!prepared) {
         u64* prow = nullptr; u32* pdirty = nullptr;
         const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
         if (use_packed_rows(c)) {
@@ -1472,8 +1511,8 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
 int lane_issue(Lane* c, const Pending& P)
 {
     return P.pe ? map_pe_dev(c, P.a[0], P.a[1], P.a[2], P.a[3], P.d_len, P.L, P.stride, P.n, P.d_results, P.d_cigar_pool, P.cigar_cap, P.prepared, P.exact,
-                             P.cigar_base, P.slot)
-                : map_se_dev(c, P.a[0], P.a[1], P.d_len, P.L, P.stride, P.n, P.d_results, P.d_cigar_pool, P.cigar_cap, P.exact, P.cigar_base, P.slot);
+                             P.cigar_base, P.slot, P.packed_hw)
+                : map_se_dev(c, P.a[0], P.a[1], P.d_len, P.L, P.stride, P.n, P.d_results, P.d_cigar_pool, P.cigar_cap, P.exact, P.cigar_base, P.slot, P.packed_hw);
 }
 
 // Wait for the lane, then read what its calls left in their page-locked words: the stage counts (they size the next calls) and the
@@ -1569,7 +1608,7 @@ int dispatch_device(bmbs_ctx* X, bool pe, uint64_t a0, uint64_t a1, uint64_t a2,
 {
     if (!X || X->lanes.empty()) return BMBS_EINVAL;
     Lane* c0 = X->lanes[0];
-    if (L <= 0 || L > 1000 || stride < L || n < 0) { X->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L <= 0 || L > BMBS_MAX_READ || stride < L || n < 0) { X->err = "bad read geometry"; return BMBS_EINVAL; }
     if (n == 0) return BMBS_OK;
     const int rpu = pe ? 2 : 1;
     const int max_ops = cigar_ops_bound(X->prm, L, threshold_k(X->prm, L));
@@ -1615,7 +1654,7 @@ int dispatch_device(bmbs_ctx* X, bool pe, uint64_t a0, uint64_t a1, uint64_t a2,
 
 // host entry points: chunk i is uploaded, mapped and read back on lane i % lanes -- its copies run beside the kernels of the
 // chunks on the other lanes (one direction of the link each: 48 GB/s both ways at once on the MI355X boxes, tools/pcie_probe)
-struct HostIn { const char *seq1, *qual1, *seq2, *qual2; const uint16_t *len1, *len2; };
+struct HostIn { const char *seq1, *qual1, *seq2, *qual2; const uint16_t *len1, *len2; const uint64_t *rows1 = nullptr, *rows2 = nullptr; int hw = 0; };
 int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t stride, int64_t n, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap,
                   int64_t* n_cigar_used)
 {
@@ -1623,7 +1662,7 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
     if (!X || X->lanes.empty()) return BMBS_EINVAL;
     if (n_cigar_used) *n_cigar_used = 0;
     if (n <= 0) return BMBS_OK;
-    if (L <= 0 || L > 1000 || stride < L) { X->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L <= 0 || L > BMBS_MAX_READ || stride < L) { X->err = "bad read geometry"; return BMBS_EINVAL; }
     const int rpu = pe ? 2 : 1;
     const int max_ops = cigar_ops_bound(X->prm, L, threshold_k(X->prm, L));
     const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops, true);
@@ -1671,10 +1710,17 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             const size_t ro = (size_t)off * (size_t)stride;
             const bool cs = c->kn.copy_streams && c->up_stream && c->down_stream && c->ev_up && c->ev_k;
             hipStream_t us = cs ? c->up_stream : c->stream, dsn = cs ? c->down_stream : c->stream;
-            int r1 = upload_rows(c, c->in_seq, in.seq1 + ro, L, stride, um, &ds, us); if (r1) return r1;
+            int r1 = BMBS_OK;
+            if (in.hw) {
+                // packed rows: hw words per read go over as they are (one block per mate)
+                const u64 pb = um * (u64)in.hw * 8;
+                ENS(c, c->pk_in1, pb + 64);
+                HIPCHK(c, hipMemcpyAsync(c->pk_in1.p, in.rows1 + (size_t)off * (size_t)in.hw, pb, hipMemcpyHostToDevice, us));
+                if (pe) { ENS(c, c->pk_in2, pb + 64); HIPCHK(c, hipMemcpyAsync(c->pk_in2.p, in.rows2 + (size_t)off * (size_t)in.hw, pb, hipMemcpyHostToDevice, us)); }
+            } else { r1 = upload_rows(c, c->in_seq, in.seq1 + ro, L, stride, um, &ds, us); if (r1) return r1; }
             r1 = upload_rows(c, c->in_qual, in.qual1 + ro, L, stride, um, &ds, us); if (r1) return r1;
             if (pe) {
-                r1 = upload_rows(c, c->in_seq2, in.seq2 + ro, L, stride, um, &ds, us); if (r1) return r1;
+                if (!in.hw) { r1 = upload_rows(c, c->in_seq2, in.seq2 + ro, L, stride, um, &ds, us); if (r1) return r1; }
                 r1 = upload_rows(c, c->in_qual2, in.qual2 + ro, L, stride, um, &ds, us); if (r1) return r1;
             }
             if (in.len1) {
@@ -1685,6 +1731,7 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             Pending P;
             P.pe = pe; P.L = L; P.stride = ds; P.n = m;
             P.a[0] = (uint64_t)c->in_seq.p; P.a[1] = (uint64_t)c->in_qual.p; P.a[2] = pe ? (uint64_t)c->in_seq2.p : 0; P.a[3] = pe ? (uint64_t)c->in_qual2.p : 0;
+            if (in.hw) { P.packed_hw = in.hw; P.a[0] = (uint64_t)c->pk_in1.p; P.a[2] = pe ? (uint64_t)c->pk_in2.p : 0; }
             P.d_len = in.len1 ? c->in_len.as<u16>() : nullptr;
             P.d_results = (uint64_t)c->out_res.p; P.d_cigar_pool = (uint64_t)c->cig_pool.p; P.cigar_cap = (int64_t)pool;
             P.cigar_base = ch == n ? 0u : (u32)((u64)off * rpu * (u64)max_ops);
@@ -1770,6 +1817,57 @@ extern "C" int bmbs_map_pe_var(bmbs_ctx* X, const char* seq1, const char* qual1,
     return dispatch_host(X, true, in, L_max, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
 }
 
+// ---- packed reads (include/bmbs.h): 2 bits per base + an 'N' plane instead of a byte per base ---------------------------------------------
+extern "C" int bmbs_map_se_packed(bmbs_ctx* X, const uint64_t* rows, int32_t pwords, const char* qual, const uint16_t* len, int32_t L_max, int32_t stride,
+                                  int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (X && (!rows || !qual || pwords <= 0)) { X->err = "packed reads: NULL rows / qualities or pwords <= 0"; return BMBS_EINVAL; }
+    HostIn in = {nullptr, qual, nullptr, nullptr, len, nullptr};
+    in.rows1 = rows; in.hw = pwords;
+    return dispatch_host(X, false, in, L_max, stride, n_reads, results, cigar_pool, cigar_cap, n_cigar_used);
+}
+extern "C" int bmbs_map_pe_packed(bmbs_ctx* X, const uint64_t* rows1, const uint64_t* rows2, int32_t pwords, const char* qual1, const char* qual2,
+                                  const uint16_t* len1, const uint16_t* len2, int32_t L_max, int32_t stride, int64_t n_pairs, bmbs_result* results,
+                                  uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used)
+{
+    if (X && (!rows1 || !rows2 || !qual1 || !qual2 || pwords <= 0 || (len1 != nullptr) != (len2 != nullptr))) { X->err = "packed reads: NULL rows / qualities, pwords <= 0, or only one of len1 / len2"; return BMBS_EINVAL; }
+    HostIn in = {nullptr, qual1, nullptr, qual2, len1, len2};
+    in.rows1 = rows1; in.rows2 = rows2; in.hw = pwords;
+    return dispatch_host(X, true, in, L_max, stride, n_pairs, results, cigar_pool, cigar_cap, n_cigar_used);
+}
+// ASCII rows -> packed rows on the host's threads (what a caller's reader does once per batch).  -> BMBS_OK, or BMBS_EINVAL with *bad_row =
+// the first row that holds a character other than A C G T N
+extern "C" int bmbs_pack_rows(const char* seq, int32_t L_max, int32_t stride, int64_t n, const uint16_t* len, uint64_t* rows, int32_t pwords, int32_t threads,
+                              int64_t* bad_row)
+{
+    const int W = (L_max + 31) / 32, M = (L_max + 63) / 64;
+    if (bad_row) *bad_row = -1;
+    if (!seq || !rows || L_max <= 0 || L_max > BMBS_MAX_READ || stride < L_max || pwords < W + M || n < 0) return BMBS_EINVAL;
+    static unsigned char code[256]; static std::once_flag once;
+    std::call_once(once, [] { for (int i = 0; i < 256; i++) code[i] = 5; code[(int)'A'] = 0; code[(int)'C'] = 1; code[(int)'G'] = 2; code[(int)'T'] = 3; code[(int)'N'] = 4; });
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : 1, n / 4096 + 1));
+    std::vector<int64_t> bad((size_t)T, -1);
+    auto work = [&](int t) {
+        const int64_t a = n * t / T, e = n * (t + 1) / T;
+        for (int64_t r = a; r < e; r++) {
+            const unsigned char* s = reinterpret_cast<const unsigned char*>(seq) + (size_t)r * (size_t)stride;
+            uint64_t* o = rows + (size_t)r * (size_t)pwords;
+            const int Lr = len ? (int)len[r] : L_max;
+            for (int q = 0; q < pwords; q++) o[q] = 0;
+            for (int j = 0; j < Lr; j++) {
+                const unsigned c = code[s[j]];
+                if (c < 4) o[j >> 5] |= (uint64_t)c << (2 * (j & 31));
+                else if (c == 4) o[W + (j >> 6)] |= 1ull << (j & 63);
+                else if (bad[(size_t)t] < 0) bad[(size_t)t] = r;
+            }
+        }
+    };
+    if (T == 1) work(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    for (int t = 0; t < T; t++) if (bad[(size_t)t] >= 0) { if (bad_row) *bad_row = bad[(size_t)t]; return BMBS_EINVAL; }
+    return BMBS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // FASTQ text in (the host only finds the line starts; the rows are cut out of the text on the device)
 namespace {
@@ -1812,7 +1910,7 @@ static int lane_map_se_fastq(Lane* c, const bmbs_fastq_view* reads, int64_t n_re
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_cigar_used) *n_cigar_used = 0;
     if (n_reads <= 0) return BMBS_OK;
-    if (L_max <= 0 || L_max > 1000) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L_max <= 0 || L_max > BMBS_MAX_READ) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     { const int r0 = fastq_check(c, reads, n_reads, L_max); if (r0) return r0; }
     const u64 n = (u64)n_reads;
     const int ds = (L_max + 15) / 16 * 16;
@@ -1849,7 +1947,7 @@ static int lane_map_pe_fastq(Lane* c, const bmbs_fastq_view* mate1, const bmbs_f
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_cigar_used) *n_cigar_used = 0;
     if (n_pairs <= 0) return BMBS_OK;
-    if (L_max <= 0 || L_max > 1000) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L_max <= 0 || L_max > BMBS_MAX_READ) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     { int r0 = fastq_check(c, mate1, n_pairs, L_max); if (r0) return r0; r0 = fastq_check(c, mate2, n_pairs, L_max); if (r0) return r0; }
     const u64 n = (u64)n_pairs, n2 = 2 * n;
     const int ds = (L_max + 15) / 16 * 16;
@@ -1914,7 +2012,29 @@ int fq_rec_setup(Lane* c, u64 n, int f, FqRec& rec)
 // One upload and one download at a time per device, whatever the number of contexts: concurrent copies in one direction share the
 // link badly (tools/pcie_probe: 48 GB/s each way with one stream per direction, 33 with three), and a context's copies are long
 // enough (hundreds of MB) to fill the link on their own.  Held from the first copy of a phase until the wait that ends it.
-std::mutex g_h2d_mu[16], g_d2h_mu[16];
+std::mutex g_h2d_mu[16];
+std::mutex g_d2h_mu[16];
+// The results of a text call go down the lane's own copy stream under the device's download mutex: one copy per direction and device at
+// a time (two at once share the link and both finish late).  Round 5 tried ONE download stream per device shared by all contexts, the
+// copies queued back to back without the host in between: 320 M reads to /dev/null took 3.3-3.8 s instead of 2.9-3.05 s, whether the
+// copy waited on the stream for its kernel or was queued once the kernel had ended (tools/e2e_quick.sh, same box, alternating runs).
+// *copy_s = seconds the copy held the link.
+int d2h_chunked(Lane* c, char* dst, const char* src, u64 bytes, hipStream_t st);
+extern std::mutex g_d2h_mu[16];
+int download_locked(Lane* c, char* dst, const char* src, u64 bytes, hipStream_t after, double* copy_s)
+{
+    hipStream_t ds = c->down_stream ? c->down_stream : c->stream;
+    HIPCHK(c, hipStreamSynchronize(after));                  // the bytes are complete before the link is claimed
+    std::lock_guard<std::mutex> down(g_d2h_mu[c->dev & 15]);
+    timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int rc = d2h_chunked(c, dst, src, bytes, ds);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(ds));
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (copy_s) *copy_s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    return BMBS_OK;
+}
+
 // D2H in pieces: one 2 GiB device-to-host copy ran at a quarter of the link rate on the MI355X boxes (tools/pcie_probe)
 int d2h_chunked(Lane* c, char* dst, const char* src, u64 bytes, hipStream_t st)
 {
@@ -2029,7 +2149,7 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
     const u32* inf = c->h_info;
     for (int f = 0; f < (pe ? 2 : 1); f++)
         if (inf[4 * f + 2]) {
-            c->err = "record " + std::to_string(inf[4 * f + 2] - 1) + " of this batch has an empty or longer-than-1000-character sequence line: not supported";
+            c->err = "record " + std::to_string(inf[4 * f + 2] - 1) + " of this batch has an empty or longer-than-998-character sequence line: not supported (the reference's own buffers end there)";
             return BMBS_EINVAL;
         }
     int maxL = (int)inf[0], minL = (int)~inf[1];
@@ -2129,15 +2249,10 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
         prof_end(c);
         if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); tp[5] = wall(); }
         {
-            hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
-            if (c->kn.copy_lock || ds != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
-            std::unique_lock<std::mutex> down(g_d2h_mu[c->dev & 15], std::defer_lock);
-            if (c->kn.copy_lock) down.lock();
-            const double t_dn0 = wall();
-            rc = d2h_chunked(c, sam, c->sam_out.as<char>(), ztotal, ds);
+            double cs = 0;
+            rc = download_locked(c, sam, c->sam_out.as<char>(), ztotal, c->stream, &cs);
             if (rc) return rc;
-            HIPCHK(c, hipStreamSynchronize(ds));
-            c->link_down_s += wall() - t_dn0;
+            c->link_down_s += cs;
         }
         tp[6] = wall();
         c->text_call_s += tp[6] - tp[0]; c->text_calls++;
@@ -2169,16 +2284,12 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
     prof_end(c);
     if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); tp[5] = wall(); }
     {
-        hipStream_t ds = c->kn.copy_streams && c->down_stream ? c->down_stream : c->stream;
-        if (c->kn.copy_lock || ds != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));       // the text is complete before the link is claimed
-        std::unique_lock<std::mutex> down(g_d2h_mu[c->dev & 15], std::defer_lock);
+        double cs = 0;
         t_dnstart = wall();
-        if (c->kn.copy_lock) down.lock();
-        t_dnlock = wall();
-        rc = d2h_chunked(c, sam, c->sam_out.as<char>(), total, ds);
+        rc = download_locked(c, sam, c->sam_out.as<char>(), total, c->stream, &cs);
         if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(ds));
-        c->link_down_s += wall() - t_dnlock;
+        c->link_down_s += cs;
+        t_dnlock = wall() - cs;                       // (trace: what was not the copy was the wait behind other contexts' copies)
     }
     tp[6] = wall();
     c->text_call_s += tp[6] - tp[0]; c->text_calls++;
@@ -2429,7 +2540,7 @@ static int lane_filter_batch(Lane* c, const char* seq, int32_t L, int32_t stride
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_cand <= 0) return BMBS_OK;
-    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L <= 0 || L > BMBS_MAX_READ || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     if (!seq || !read_of || !site || !err || !end_site) { c->err = "filter batch: NULL buffer"; return BMBS_EINVAL; }
     for (int64_t i = 0; i < n_cand; i++) if ((int64_t)read_of[i] >= n_reads) { c->err = "filter batch: read_of out of range"; return BMBS_EINVAL; }
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_cand;
@@ -2455,7 +2566,7 @@ static int lane_align_batch(Lane* c, const char* seq, const char* qual, int32_t 
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
     HIPCHK(c, hipSetDevice(c->dev));
     if (n_jobs <= 0) return BMBS_OK;
-    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L <= 0 || L > BMBS_MAX_READ || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     if (max_ops < cigar_ops_bound(c->prm, L, threshold_k(c->prm, L))) { c->err = "align batch: max_ops must be at least bmbs_max_cigar_ops(L)"; return BMBS_EINVAL; }
     for (int64_t i = 0; i < n_jobs; i++) if ((int64_t)read_of[i] >= n_reads) { c->err = "align batch: read_of out of range"; return BMBS_EINVAL; }
     const u64 bytes = (u64)n_reads * stride, m = (u64)n_jobs;
@@ -2498,7 +2609,7 @@ static int lane_seed_batch(Lane* c, const char* seq, int32_t L, int32_t stride, 
     const u64 n = (u64)n_reads, bytes = n * (u64)stride;
     if (total_slots) *total_slots = 0;
     if (n == 0) return BMBS_OK;
-    if (L <= 0 || L > 1000 || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
+    if (L <= 0 || L > BMBS_MAX_READ || stride < L || n_reads < 0) { c->err = "bad read geometry"; return BMBS_EINVAL; }
     { const int r0 = prepare_luts(c); if (r0) return r0; }
     c->cur_slot = 0; c->prof_used[0] = 0;
     int rc = per_read_workspace(c, n);

@@ -441,14 +441,8 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u8* out, u32 isiz
                 }
                 INF_T(4);
                 // the text from before the window, as it arrives
-                if (shortA) for (u32 i = 0; i < extA; i++) {
-                    const int q = srcA + (int)i;
-                    s_val[idxA + i] = (S)((i < 8 ? ra[0] : ra[1]) >> (8 * (i & 7u)));
-                }
-                if (shortB) for (u32 i = 0; i < extB; i++) {
-                    const int q = srcB + (int)i;
-                    s_val[idxB + i] = (S)((i < 8 ? rb[0] : rb[1]) >> (8 * (i & 7u)));
-                }
+                if (shortA) for (u32 i = 0; i < extA; i++) s_val[idxA + i] = (S)((i < 8 ? ra[0] : ra[1]) >> (8 * (i & 7u)));
+                if (shortB) for (u32 i = 0; i < extB; i++) s_val[idxB + i] = (S)((i < 8 ? rb[0] : rb[1]) >> (8 * (i & 7u)));
                 __builtin_amdgcn_wave_barrier();
                 const u32 r4 = s_ref32[lane];
                 constexpr u32 SB = 8 * sizeof(S);                                           // bits per symbol

@@ -80,7 +80,7 @@ k_fq_lines(const char* __restrict__ text, u64 n, const u64* __restrict__ tile_of
 }
 
 // per-record fields from the newline positions (record r = lines 4r .. 4r+3) + the checks the host reader made:
-// a sequence line of 1..1000 characters.  info[0] = longest read, info[1] = ~shortest (atomicMax of the complement),
+// a sequence line of 1..998 characters (BMBS_MAX_READ).  info[0] = longest read, info[1] = ~shortest (atomicMax of the complement),
 // info[2] = 1 + index of a bad record (0: none)
 struct FqRec {
     u32* seq_off; u32* qual_off; u32* name_off; u16* seq_len; u16* qual_len; u16* name_len;
@@ -99,7 +99,7 @@ k_fq_records(const u32* __restrict__ nl, long n, FqRec o, u32* __restrict__ info
         const u32 nml = e0 - s0;
         o.name_off[r] = s0; o.name_len[r] = (u16)(nml > 0xffffu ? 0xffffu : nml);
         o.seq_off[r] = e0 + 1u; o.qual_off[r] = e2 + 1u;
-        if (sl < 1u || sl > 1000u) { bad = (u32)r + 1u; o.seq_len[r] = 1; o.qual_len[r] = 0; }
+        if (sl < 1u || sl > 998u) { bad = (u32)r + 1u; o.seq_len[r] = 1; o.qual_len[r] = 0; }
         else { o.seq_len[r] = (u16)sl; o.qual_len[r] = (u16)ql; L = sl; Lc = ~sl; }
     }
     for (int of = 32; of > 0; of >>= 1) {

@@ -180,3 +180,96 @@ k_pack_rows(const char* __restrict__ seq, ReadGeom gm, int stride, long n, u64* 
     reinterpret_cast<u16*>(row + W)[piece] = (u16)mask;
     if (mask) atomicOr(&dirty32[r >> 2], 1u << (8 * (int)(r & 3)));
 }
+
+// ---- packed rows handed over by the caller (bmbs_map_*_packed, round 5) ---------------------------------------------------------------
+// Host format of a row (include/bmbs.h): W = ceil(L_max / 32) words of bases (base j in bits 2 (j % 32) .. +1 of word j / 32, A0 C1 G2 T3),
+// then M = ceil(L_max / 64) words of marks (bit j % 64 of word j / 64: the character at j is 'N', its base bits are 0), rows `hw` words
+// apart: 64 bytes for 150 bases where the ASCII row takes 160.  This kernel makes the lane's own packed rows of them (pack_words(L_max)
+// words: the same two planes and the spare words the two-word loads read), sets the rows' dirty bytes, rebuilds the ASCII text of every
+// 16-character piece that holds an 'N' (the only pieces whose text a kernel ever asks for) -- and, RC, reverse-complements the row on
+// the way: mate 2 comes in FASTQ orientation and is mapped as its reverse complement (Process_Reads.cpp:262-267).  It replaces
+// k_pe_prepare / k_pack_rows for such callers: 2 x 64 bytes read per pair instead of 2 x 160.
+// One thread per 32-base word of an output row; bits at and beyond a read's length come out 0 whatever the caller left there.
+DEVI u64 pk_win_bases(const u64* w, int nw, int s)          // bases s .. s+31 of a row of nw words (0 outside it)
+{
+    if (s <= -32 || s >= 32 * nw) return 0;
+    if (s < 0) return w[0] << (2 * -s);
+    const int i = s >> 5, sh = 2 * (s & 31);
+    u64 v = w[i] >> sh;
+    if (sh && i + 1 < nw) v |= w[i + 1] << (64 - sh);
+    return v;
+}
+DEVI u32 pk_win_marks(const u64* m, int nm, int s)          // marks s .. s+31
+{
+    if (s <= -32 || s >= 64 * nm) return 0;
+    if (s < 0) return (u32)(m[0] << -s);
+    const int i = s >> 6, sh = s & 63;
+    u64 v = m[i] >> sh;
+    if (sh && i + 1 < nm) v |= m[i + 1] << (64 - sh);
+    return (u32)v;
+}
+template <bool RC>
+__global__ void __launch_bounds__(256)
+k_rows_from_packed(const u64* __restrict__ src, int hw, ReadGeom gm, long row0, long n, u64* __restrict__ prow, int pwords, int W,
+                   u32* __restrict__ dirty32, char* __restrict__ ascii, int stride)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long r = t / W;
+    const int k = (int)(t - r * W);
+    if (r >= n) return;
+    const long row_id = row0 + r;
+    const int L = gm.rl(row_id);
+    const int M = (gm.L + 63) / 64;
+    const u64* in = src + (size_t)r * hw;
+    u64* out = prow + (size_t)row_id * pwords;
+    const int j0 = 32 * k;                                   // first base of this thread's word
+    // the 32 bases and marks of output positions j0 .. j0+31
+    u64 b = 0; u32 mk = 0;
+    const u32 inr = j0 >= L ? 0u : L - j0 >= 32 ? 0xffffffffu : (1u << (L - j0)) - 1u;      // output positions inside the read
+    if (inr) {
+        if (!RC) { b = in[k]; mk = pk_win_marks(in + W, M, j0); }
+        else {
+            const int s = L - 32 - j0;                       // input positions s .. s+31, reversed, are output positions j0 .. j0+31
+            const u64 x = pk_win_bases(in, W, s);
+            u64 rv = __brevll(x);
+            rv = ((rv >> 1) & PK_EVEN) | ((rv & PK_EVEN) << 1);
+            b = rv;
+            mk = __brev(pk_win_marks(in + W, M, s));
+        }
+        mk &= inr;
+        const u64 v = spread32(inr & ~mk);                   // real bases -> both bits of their pair
+        const u64 vv = v | (v << 1);
+        b = RC ? (b ^ vv) & vv : b & vv;                     // complement: code -> 3 - code; everything else 0
+    }
+    out[k] = b;
+    // marks: this thread's 32 bits are one half of mask word k / 2
+    reinterpret_cast<u32*>(out + W)[k] = mk;
+    if ((W & 1) && k == W - 1) reinterpret_cast<u32*>(out + W)[W] = 0;                       // (the upper half of the last mask word when W is odd)
+    if (k == 0) for (int q = W + M; q < pwords; q++) out[q] = 0;                             // the spare words
+    if (mk) {
+        atomicOr(&dirty32[row_id >> 2], 1u << (8 * (int)(row_id & 3)));
+        // the text of the pieces that hold an 'N'
+        char* arow = ascii + (size_t)row_id * stride;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const u32 pm = (mk >> (16 * h)) & 0xffffu;
+            if (!pm || j0 + 16 * h >= stride) continue;
+            u32 wv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32 x = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int p = 16 * h + 4 * q + e;        // position inside this thread's 32
+                    const u32 code = (u32)(b >> (2 * p)) & 3u;
+                    u32 c = (0x54474341u >> (8 * code)) & 0xffu;                             // 'A' 'C' 'G' 'T'
+                    if ((mk >> p) & 1u) c = 'N';
+                    if (!((inr >> p) & 1u)) c = 0;
+                    x |= c << (8 * e);
+                }
+                wv[q] = x;
+            }
+            *reinterpret_cast<uint4*>(arow + j0 + 16 * h) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+    }
+}

@@ -160,6 +160,48 @@ class Mapper:
                                             capi.ptr(l2), L, stride, n, capi.ptr(res), capi.ptr(pool), cap, C.byref(used)))
         return res, pool[:used.value]
 
+    # ---- packed reads: 2 bits per base + an 'N' plane (bmbs_map_*_packed) -----------------------------
+    @staticmethod
+    def pack_rows(seq: np.ndarray, L: int, lens: np.ndarray | None = None, pwords: int | None = None, threads: int = 8) -> np.ndarray:
+        """ASCII rows [n][stride] -> packed rows [n][pwords] of u64 (bmbs_pack_rows); raises when a row holds something other than ACGTN"""
+        a = np.ascontiguousarray(seq, dtype=np.uint8)
+        n, stride = a.shape
+        if pwords is None:
+            pwords = (L + 31) // 32 + (L + 63) // 64
+        rows = np.empty((n, pwords), dtype=np.uint64)
+        bad = C.c_int64(-1)
+        ln = np.ascontiguousarray(lens, dtype=np.uint16) if lens is not None else None
+        rc = capi.lib().bmbs_pack_rows(capi.ptr(a), L, stride, n, capi.ptr(ln) if ln is not None else None, capi.ptr(rows), pwords, threads, C.byref(bad))
+        if rc:
+            raise ValueError("bmbs_pack_rows: row %d cannot be packed (rc %d)" % (bad.value, rc))
+        return rows
+
+    def map_se_packed(self, rows: np.ndarray, qual: np.ndarray, L: int, lens: np.ndarray | None = None):
+        q = np.ascontiguousarray(qual, dtype=np.uint8)
+        n, stride = q.shape
+        res = np.zeros(n, dtype=capi.RESULT_DTYPE)
+        cap = max(1, n * self.max_cigar_ops(L))
+        pool = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        ln = np.ascontiguousarray(lens, dtype=np.uint16) if lens is not None else None
+        self._chk(self._lib.bmbs_map_se_packed(self._ctx, capi.ptr(rows), rows.shape[1], capi.ptr(q), capi.ptr(ln) if ln is not None else None, L, stride, n,
+                                               capi.ptr(res), capi.ptr(pool), cap, C.byref(used)))
+        return res, pool[:used.value]
+
+    def map_pe_packed(self, rows1: np.ndarray, rows2: np.ndarray, qual1: np.ndarray, qual2: np.ndarray, L: int, lens1=None, lens2=None):
+        q1 = np.ascontiguousarray(qual1, dtype=np.uint8); q2 = np.ascontiguousarray(qual2, dtype=np.uint8)
+        n, stride = q1.shape
+        res = np.zeros(2 * n, dtype=capi.RESULT_DTYPE)
+        cap = max(1, 2 * n * self.max_cigar_ops(L))
+        pool = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        l1 = np.ascontiguousarray(lens1, dtype=np.uint16) if lens1 is not None else None
+        l2 = np.ascontiguousarray(lens2, dtype=np.uint16) if lens2 is not None else None
+        self._chk(self._lib.bmbs_map_pe_packed(self._ctx, capi.ptr(rows1), capi.ptr(rows2), rows1.shape[1], capi.ptr(q1), capi.ptr(q2),
+                                               capi.ptr(l1) if l1 is not None else None, capi.ptr(l2) if l2 is not None else None, L, stride, n,
+                                               capi.ptr(res), capi.ptr(pool), cap, C.byref(used)))
+        return res, pool[:used.value]
+
     # ---- FASTQ text in, SAM text out (newline index and SAM formatting on the device) ---------------
     TEXT_PBAT, TEXT_UNMAPPED, TEXT_BAM = 1, 2, 16
 

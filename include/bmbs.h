@@ -21,6 +21,11 @@ extern "C" {
 #endif
 
 #define BMBS_OK            0
+/* the longest read the path takes.  The reference sizes its per-read buffers for 1000 characters (Auxiliary.h:14) and has no room for
+ * their terminators at 999 and 1000: it prints 222 of 300 records at those lengths, one with bytes outside ASCII
+ * (tests/golden/make_golden.py) -- there is nothing to be identical to, so reads of 999 and 1000 bases are refused (BMBS_EINVAL)
+ * rather than mapped unpinned.  998 is pinned by goldens (se_g998, pe_p998).                                                    */
+#define BMBS_MAX_READ    998
 #define BMBS_EINVAL      (-22)
 #define BMBS_ENOMEM      (-12)
 #define BMBS_ENODEV      (-19)   /* no HIP device / runtime error: the product never falls back to CPU */
@@ -166,7 +171,7 @@ int bmbs_seed_batch(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int64
 
 /* Slots per read (per mate) the cigar pool of the mapping calls needs for reads of length L under these parameters (NULL: the
  * defaults): 2k + 8 with the default penalties, more when --gap_open / --gap_extension (Process_CommandLines.cpp:129-130) make
- * gaps cheaper than mismatches; -1 for L outside 1..1000.  A pool of n_reads * bmbs_max_cigar_ops(params, L_max) entries (twice
+ * gaps cheaper than mismatches; -1 for L outside 1..BMBS_MAX_READ.  A pool of n_reads * bmbs_max_cigar_ops(params, L_max) entries (twice
  * that for pairs) is always enough; parameter sets that allow more than 254 operations per alignment are refused by the mapping
  * calls (BMBS_EINVAL): n_cigar of a record is 8 bits. */
 int32_t bmbs_max_cigar_ops(const bmbs_params* params, int32_t L);
@@ -200,6 +205,26 @@ int bmbs_map_pe_var_device(bmbs_ctx*, uint64_t d_seq1, uint64_t d_qual1, uint64_
                            int32_t L_max, int32_t stride, int64_t n_pairs, uint64_t d_results, uint64_t d_cigar_pool,
                            int64_t cigar_cap);
 
+/* ---- packed reads (round 5): the same calls with 2 bits per base going over the link instead of a byte ---------------------------------
+ * What the reference's reader hands a mapping thread is the upper-cased sequence line (Process_Reads.cpp:810-890; mate 2 reverse-
+ * complemented, :262-267); the host-buffer entry points above move that as it is, 160 bytes of ASCII per 150-base read and mate, and are
+ * bound by the link (SURVEY 8d counts H2D / D2H).  Here the caller packs the sequence once per batch (bmbs_pack_rows, a few GB/s on the
+ * host's threads, or its own reader writes the format directly):
+ *   row = W = ceil(L_max / 32) u64 words of bases -- base j in bits 2 (j % 32), 2 (j % 32) + 1 of word j / 32: A 0, C 1, G 2, T 3 --
+ *         followed by M = ceil(L_max / 64) words of marks -- bit j % 64 of word j / 64 set: the character at j is 'N' (its base bits 0);
+ *         bits at and beyond a read's length are ignored; rows `pwords` (>= W + M) words apart.  150 bases: 8 words = 64 bytes.
+ * Characters other than A C G T N cannot be expressed (bmbs_pack_rows says BMBS_EINVAL and which row): such batches take the ASCII
+ * calls.  BOTH mates are given in FASTQ orientation (what bmbs_map_pe takes as seq2): the device reverse-complements mate 2 on the
+ * packed words.  Qualities stay bytes (`stride` apart, as above); len NULL: every read has length L_max.  Results, CIGAR pool, errors:
+ * exactly those of bmbs_map_se[_var] / bmbs_map_pe[_var] on the ASCII rows the packed ones stand for (tests/test_gpu_parity.py).     */
+int bmbs_pack_rows(const char* seq, int32_t L_max, int32_t stride, int64_t n, const uint16_t* len /* NULL: uniform */, uint64_t* rows, int32_t pwords,
+                   int32_t threads, int64_t* bad_row /* may be NULL */);
+int bmbs_map_se_packed(bmbs_ctx*, const uint64_t* rows, int32_t pwords, const char* qual, const uint16_t* len, int32_t L_max, int32_t stride,
+                       int64_t n_reads, bmbs_result* results, uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used);
+int bmbs_map_pe_packed(bmbs_ctx*, const uint64_t* rows1, const uint64_t* rows2, int32_t pwords, const char* qual1, const char* qual2,
+                       const uint16_t* len1, const uint16_t* len2, int32_t L_max, int32_t stride, int64_t n_pairs, bmbs_result* results,
+                       uint32_t* cigar_pool, int64_t cigar_cap, int64_t* n_cigar_used);
+
 /* ---- fused paired-end mapping, default (fast) mode: Map_Pair_Seq_end_to_end_fast (Schema.cpp:18570-19546)
  * = get_candidates x2 (18172), filter_pairs (16052), verify_candidate_locations (18130) on the smaller side,
  * filter_pairs_single_side (16186), new_faster_verify_pairs (15773), calculate_best_map_cigar_end_to_end_return
@@ -223,7 +248,7 @@ int bmbs_map_pe_device(bmbs_ctx*, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_
  * Process_Reads.cpp:810-890, 155-317: kseq line splitting, toupper, `qual.resize(seq.size(), ' ')`, the reverse complement of
  * mate 2 at :262-267 and of every --pbat read with mirrored qualities at :986-1075) is done by one kernel over the batch; the host
  * hands over the text window as it came from the file plus the line starts it found.  A window is smaller than 4 GiB.
- * Records keep their own lengths (1..L_max, L_max <= 1000); `uniform` != 0 promises that every read has length L_max (the
+ * Records keep their own lengths (1..L_max, L_max <= BMBS_MAX_READ); `uniform` != 0 promises that every read has length L_max (the
  * fixed-length kernels are used).  results / cigar_pool as for bmbs_map_se / bmbs_map_pe.  Page-locked text buffers
  * (bmbs_host_alloc) are copied at link speed.                                                                                  */
 typedef struct bmbs_fastq_view {

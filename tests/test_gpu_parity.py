@@ -580,6 +580,81 @@ def test_map_pe_mixed_lengths_match_oracle(prm, env):
     m.close()
 
 
+# ---- packed reads: 2 bits per base + an 'N' plane over the link (bmbs_map_*_packed) -----------------------------------------------------
+def _sprinkle_n(rng, seq, lens, rate=0.003):
+    out = seq.copy()
+    hit = rng.random(out.shape) < rate
+    hit &= np.arange(out.shape[1])[None, :] < (lens[:, None] if lens is not None else out.shape[1])
+    hit[::7] = False                                   # most reads stay clean: both kinds of piece in one batch
+    out[hit] = ord("N")
+    return out
+
+
+@pytest.mark.parametrize("case", ["se150", "se_mixed", "se998", "pe100_fast", "pe150_sensitive", "pe_mixed", "pe_chunks"])
+def test_packed_reads_match_oracle(case, env, monkeypatch):
+    """bmbs_map_se_packed / bmbs_map_pe_packed: the caller's 2-bit rows (bmbs_pack_rows) -- mate 2 in FASTQ orientation, reverse-
+    complemented on the device on the packed words; 'N' in a plane of its own, its text rebuilt only where a kernel asks for it --
+    give the oracle's records, CIGARs and mapstats, like the ASCII calls: uniform and mixed lengths, 998 bases (32 words per row),
+    fast and --sensitive pairs, and a call cut into chunks over three lanes"""
+    from bitmapperbs_amd import synth, mapper
+    M = mapper.Mapper
+    rng = np.random.default_rng(5)
+    if case.startswith("se"):
+        L = 998 if case == "se998" else 150
+        n = 1500 if case == "se998" else 20000
+        r = synth.make_reads_se(env["chroms"], n=n, L=L, seed=51, sub=0.02, indel=0.002, qual="random", n_rate=0.002)
+        lens = None
+        seq, qual = r["seq"], r["qual"]
+        if case == "se_mixed":
+            lens = rng.integers(20, L + 1, n).astype(np.uint16); lens[:500] = L
+            seq, qual = _trim(seq, lens), _trim(qual, lens)
+        m = M(env["ix"], 0, e_f=0.08)
+        rows = M.pack_rows(seq, L, lens)
+        assert rows.shape[1] == (L + 31) // 32 + (L + 63) // 64
+        res, pool = m.map_se_packed(rows, qual, L, lens)
+        if lens is None:
+            recs, ost, _ = env["oix"].map_se(orc.params(e_f=0.08), seq, qual, L)
+        else:
+            recs, ost, _ = env["oix"].map_se_var(orc.params(e_f=0.08), seq, qual, lens)
+        assert (recs["status"] == 1).sum() > n // 2
+        bad = compare_records(res, pool, recs, L if lens is None else lens)
+        assert not bad, bad[:5]
+        assert (m.stats() == ost).all(), (m.stats(), ost)
+        m.close()
+        return
+    prm = dict(sensitive=1) if case == "pe150_sensitive" else dict()
+    L = 150 if case in ("pe150_sensitive", "pe_chunks") else 100 if case == "pe100_fast" else 125
+    n = 12000
+    if case == "pe_chunks":
+        monkeypatch.setenv("BMBS_LANES", "3"); monkeypatch.setenv("BMBS_SPLIT_MIN", "1000")
+    m1, m2 = synth.make_reads_pe(env["chroms"], n=n, L=L, seed=52, sub=0.02, indel=0.002, qual="random", ins_hi=480)
+    l1 = l2 = None
+    s1, q1, s2, q2 = m1["seq"], m1["qual"], m2["seq"], m2["qual"]
+    if case == "pe_mixed":
+        l1 = rng.integers(30, L + 1, n).astype(np.uint16); l2 = rng.integers(30, L + 1, n).astype(np.uint16)
+        l1[:2000] = L; l2[:2000] = L
+        s1, q1, s2, q2 = _trim(s1, l1), _trim(q1, l1), _trim(s2, l2), _trim(q2, l2)
+    s1 = _sprinkle_n(rng, s1, l1); s2 = _sprinkle_n(rng, s2, l2)
+    m = M(env["ix"], 0, **prm)
+    r1 = M.pack_rows(s1, L, l1, pwords=12 if L <= 150 else None); r2 = M.pack_rows(s2, L, l2, pwords=12 if L <= 150 else None)      # (rows may be further apart than they need)
+    res, pool = m.map_pe_packed(r1, r2, q1, q2, L, l1, l2)
+    if l1 is None:
+        recs, ost, _ = env["oix"].map_pe(orc.params(**prm), s1, q1, s2, q2, L)
+        bad = compare_pe(res, pool, recs, L, L)
+    else:
+        recs, ost, _ = env["oix"].map_pe_var(orc.params(**prm), s1, q1, s2, q2, l1, l2)
+        bad = compare_pe(res, pool, recs, l1, l2)
+    assert (recs["status"] == 1).sum() > n // 2
+    assert not bad, bad[:5]
+    assert (m.stats() == ost).all(), (m.stats(), ost)
+    # ... and exactly what the ASCII call returns for the same rows
+    m.reset_stats()
+    res2, pool2 = (m.map_pe(s1, q1, s2, q2, L) if l1 is None else m.map_pe_var(s1, q1, s2, q2, l1, l2))
+    for f in ("status", "chrom", "pos", "flag", "mapq", "nm", "score", "n_cigar", "tlen"):
+        assert (res[f] == res2[f]).all(), f
+    m.close()
+
+
 @pytest.mark.parametrize("super_shift", [None, "20"])
 def test_wide_index_forms_match_oracle(env, monkeypatch, super_shift):
     """texts of 2^32 symbols and more (GRCh38): 64-bit suffix array + Occ counts relative to super-blocks whose sums travel in
@@ -1187,6 +1262,33 @@ def test_device_sam_text_equals_reference_golden_pe(name, tmp_path):
     mine = m.map_text(t1, n, t2).decode()
     assert mine == _sam_body(gzip.open(os.path.join(GOLD, "pe_%s.ref.sam.gz" % name), "rt").read())
     assert distributed.mapstats_text(m.stats()) == open(os.path.join(GOLD, "pe_%s.ref.stats" % name)).read()
+    m.close()
+
+
+@pytest.mark.gpu
+def test_reads_of_999_and_1000_bases_are_refused(env):
+    """the reference corrupts its own 1000-byte buffers at 999 and 1000 bases (tests/golden/make_golden.py): nothing to be identical
+    to, so every entry point says BMBS_EINVAL (include/bmbs.h, BMBS_MAX_READ = 998) instead of mapping them unpinned; 998 maps"""
+    import ctypes as C
+    from bitmapperbs_amd import mapper, capi, synth
+    lib = capi.lib()
+    m = mapper.Mapper(env["ix"], 0)
+    m._set_refs()
+    for L in (998, 999, 1000):
+        r = synth.make_reads_se(env["chroms"], n=8, L=L, seed=3, sub=0.01, indel=0.0, qual="const")
+        stride = 1008
+        seq = np.zeros((8, stride), dtype=np.uint8); qual = np.zeros((8, stride), dtype=np.uint8)
+        seq[:, :L] = r["seq"]; qual[:, :L] = r["qual"]
+        res = np.zeros(8 * 32, dtype=np.uint8); pool = np.zeros(8 * 300, dtype=np.uint32); used = C.c_int64(0)
+        rc = lib.bmbs_map_se(m._ctx, capi.ptr(seq), capi.ptr(qual), L, stride, 8, capi.ptr(res), capi.ptr(pool), pool.size, C.byref(used))
+        assert rc == (0 if L == 998 else -22), (L, rc)
+        assert (lib.bmbs_max_cigar_ops(C.byref(m.params), L) > 0) == (L == 998)
+        text = b"".join(b"@r%d\n" % i + r["seq"][i].tobytes() + b"\n+\n" + r["qual"][i].tobytes() + b"\n" for i in range(8))
+        if L == 998:
+            assert m.map_text(text, 8, flags=mapper.Mapper.TEXT_UNMAPPED).count(b"\n") == 8
+        else:
+            with pytest.raises(RuntimeError, match="998"):
+                m.map_text(text, 8)
     m.close()
 
 

@@ -354,3 +354,19 @@ def test_driver_plan_for_an_eight_gpu_node(tmp_path):
     kv = dict(zip(plan[1::2], plan[2::2]))
     assert (kv["devices"], kv["contexts_per_device"], kv["workers"], kv["parts"]) == ("8", "3", "24", "8")
     assert [r[1] for r in rows if r[0] == "device"] == [str(i) for i in range(8)]
+
+
+def test_pack_rows_refuses_what_the_format_cannot_hold():
+    """bmbs_pack_rows (host code: runs without a device): letters other than A C G T N have no place in two bits and a mark"""
+    from bitmapperbs_amd import mapper
+    seq = np.frombuffer(b"ACGTNACGTNACGTNA" * 4, dtype=np.uint8).reshape(2, 32).copy()
+    rows = mapper.Mapper.pack_rows(seq, 30)
+    assert rows.shape == (2, 2)
+    want = 0
+    for j, ch in enumerate(b"ACGTNACGTNACGTNAACGTNACGTNACGTN"[:30]):
+        want |= {65: 0, 67: 1, 71: 2, 84: 3, 78: 0}[ch] << (2 * j)
+    assert int(rows[0, 0]) == want
+    assert int(rows[0, 1]) == sum(1 << j for j, ch in enumerate(b"ACGTNACGTNACGTNAACGTNACGTNACGTN"[:30]) if ch == 78)
+    seq[1, 7] = ord("R")
+    with pytest.raises(ValueError, match="row 1"):
+        mapper.Mapper.pack_rows(seq, 30)

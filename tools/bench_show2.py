@@ -2,7 +2,7 @@
 """tools/bench_show2.py <bench json> -- the headline, PCIe-inclusive and e2e keys of a bench line, one per row"""
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print("value", d["value"], "ms/step", d["ms_per_step"], "roofline", d["roofline"]["frac"], d["roofline"]["kernel"], "single_lane", d["roofline"].get("single_lane", {}).get("frac"))
+print("value", d["value"], "ms/step", d["ms_per_step"], "roofline", d["roofline"]["frac"], d["roofline"]["kernel"], "single_lane", (d["roofline"].get("single_lane") or {}).get("frac"))
 print("incl_pcie", {k: v for k, v in d.get("value_incl_pcie", {}).items() if k != "what"})
 e = d.get("e2e", {}).get("file_to_file", {}) or {}
 for k, v in e.items():
