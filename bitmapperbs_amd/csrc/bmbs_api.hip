@@ -66,6 +66,9 @@ struct Knobs {
     int seed_waves = 65536;     // BMBS_SEED_WAVES
     bool exact = false;         // BMBS_EXACT=1: every call waits for its stage counts (the round-2 launch sequence)
     int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
+    int host_lanes = 4;         // BMBS_HOST_LANES: lanes the host-buffer entry points deal their chunks to (>= lanes): upload, kernels and download of
+                                // a chunk follow each other on a lane, so what overlaps is what different lanes do -- 2 M pairs through
+                                // bmbs_map_pe_packed: 164 M reads/s on two lanes, 180 on four (tools/hostbuf_probe.py)
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
     int pef_long = 1;           // BMBS_PEF_LONG: 1 long lists of k_pe_filter_pairs get a wave when the input is repeat-rich, 2 always (tests)
@@ -83,6 +86,9 @@ struct Knobs {
         if ((e = getenv("BMBS_LANES"))) lanes = atoi(e);
         if (lanes < 1) lanes = 1;
         if (lanes > 8) lanes = 8;
+        if ((e = getenv("BMBS_HOST_LANES"))) host_lanes = atoi(e);
+        if (host_lanes < lanes) host_lanes = lanes;
+        if (host_lanes > 8) host_lanes = 8;
         if ((e = getenv("BMBS_KGRAM"))) kgram = atoi(e);
         if ((e = getenv("BMBS_CHUNK"))) chunk = atol(e);
         if ((e = getenv("BMBS_SPLIT_MIN"))) split_min = atol(e);
@@ -884,7 +890,7 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
     X->dev = device_id;
     if (params) X->prm = *params; else bmbs_default_params(&X->prm);
     X->kn.read();                                  // the A/B environment is read here, once; the launch path never calls getenv
-    for (int i = 0; i < X->kn.lanes; i++) {
+    for (int i = 0; i < X->kn.host_lanes; i++) {          // (the first kn.lanes of them take the chunks of the *_device calls)
         Lane* c = lane_create(device_id, X->prm, X->kn, i == 0);
         if (!c) { bmbs_destroy(X); return nullptr; }
         X->lanes.push_back(c);
@@ -1593,8 +1599,9 @@ int settle_all(bmbs_ctx* X)
 // host_copies: the chunks carry their own H2D / D2H copies; smaller ones (n / 8, within 250 k .. 500 k units) leave a shorter tail behind the last upload
 int64_t chunk_units(const bmbs_ctx* X, int64_t n, int64_t cigar_cap, int rpu, int max_ops, bool host_copies = false)
 {
-    if (X->lanes.size() < 2 || n < 2 * X->kn.split_min || cigar_cap < n * rpu * (int64_t)max_ops) return n;
-    int64_t ch = X->kn.chunk > 0 ? X->kn.chunk : (n + (int64_t)X->lanes.size() - 1) / (int64_t)X->lanes.size();
+    const int64_t nl = host_copies ? (int64_t)X->lanes.size() : std::min<int64_t>((int64_t)X->lanes.size(), X->kn.lanes);
+    if (nl < 2 || n < 2 * X->kn.split_min || cigar_cap < n * rpu * (int64_t)max_ops) return n;
+    int64_t ch = X->kn.chunk > 0 ? X->kn.chunk : (n + nl - 1) / nl;
     // (a call of 2 M pairs: 126 M reads/s in chunks of 500 k, 133-138 in chunks of 250 k -- the first upload and the last chunk's
     // kernels and download are not hidden behind anything; tools/hostbuf_ab.py)
     if (host_copies && X->kn.chunk <= 0) ch = std::min<int64_t>(ch, std::min<int64_t>(500000, std::max<int64_t>(250000, n / 8)));
@@ -1646,7 +1653,7 @@ int dispatch_device(bmbs_ctx* X, bool pe, uint64_t a0, uint64_t a1, uint64_t a2,
         const int rc = lane_enqueue(c, P, staged);
         if (rc) { X->err = c->err; return rc; }
         used = std::max(used, (ch == n ? 0 : li) + 1);
-        li = (li + 1) % (int)X->lanes.size();
+        li = (li + 1) % std::min((int)X->lanes.size(), X->kn.lanes);
     }
     X->used_lanes = used;
     return BMBS_OK;
