@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--sub", type=float, default=0.005, help="substitution rate of the synthetic reads (SURVEY.md 8d: 0.5 %%)")
     ap.add_argument("--indel", type=float, default=0.0002, help="indel rate per base (SURVEY.md 8d: 0.02 %%; at most one per read)")
     ap.add_argument("--qual", default="const", choices=["const", "random"])
+    ap.add_argument("--grch38-like", action="store_true", help="the main workload on the repeat-rich genome of secondary.grch38_like (profiles of the representative case)")
     ap.add_argument("--repeats", type=int, default=0, help="stress: plant this many diverged copies of 300-bp elements into the genome")
     ap.add_argument("--cpu-sample", type=int, default=None, help="reads / pairs timed on the host CPU baseline (rank 0, N=1)")
     ap.add_argument("--cpu-threads", type=int, default=None)
@@ -984,7 +985,9 @@ def main():
     from bitmapperbs_amd import mapper, capi
 
     t_all = time.time()
-    fa, names, chroms, built_s = ensure_index(args, cfg, rank, local, world, dist, repeats=args.repeats)
+    fa, names, chroms, built_s = ensure_index(args, cfg, rank, local, world, dist, repeats=args.repeats, grch38_like=args.grch38_like)
+    if args.grch38_like:
+        cfg["label"] = cfg["label"] + " on the GRCh38-like repeat-rich genome"
     L = cfg["read_len"]
     t = time.time()
     ix = mapper.Index(fa)
@@ -1046,7 +1049,7 @@ def main():
         s8d, own = algorithmic_bytes(cnt, nr, L, k, pe)
         nat = native_bytes(cnt, 2 * cfg["genome"] + 1 >= (1 << 32))
         tag = "r02_c%d" % args.config
-        for rnd in ("r04", "r03"):                       # the newest committed PMC pass of this configuration
+        for rnd in ("r05", "r04", "r03"):                       # the newest committed PMC pass of this configuration
             if os.path.exists(os.path.join(ROOT, "profiles", "%s_c%d_pmc_fetch_write.csv" % (rnd, args.config))):
                 tag = "%s_c%d" % (rnd, args.config)
                 break

@@ -1,15 +1,16 @@
 #!/bin/bash
-# tools/profile_round.sh [config] [tag] -- on the MI355X box: the bench line and the rocprofv3 evidence behind it (kernel stats of the
+# tools/profile_round.sh [config] [tag] [extra bench.py arguments, e.g. "--grch38-like --se"] -- on the MI355X box: the bench line and the rocprofv3 evidence behind it (kernel stats of the
 # SAME command, then separate --pmc passes: FETCH_SIZE, WRITE_SIZE, SQ stall counters).  Output under gpurun_out/prof_<tag>/.
 set -u
 CFG=${1:-2}
-TAG=${2:-r04_c$CFG}
+TAG=${2:-r05_c$CFG}
+X=${3:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --config $CFG > $O/bench.json 2> $O/bench.err
-Q="--config $CFG --no-cpu --no-secondary"
+python3 $R/bench.py --config $CFG $X ${BENCH_FIRST:---no-stress} > $O/bench.json 2> $O/bench.err
+Q="--config $CFG $X --no-cpu --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $Q > $O/bench_under_rocprof.json 2>/dev/null
 # the counter passes run the call on ONE lane (BMBS_LANES=1): a kernel's last dispatch is then the whole launch, as the algorithmic bytes of
 # the bench line are; the counters of a kernel do not depend on what runs beside it
