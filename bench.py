@@ -872,6 +872,31 @@ def cpu_quota_cores():
         return None
 
 
+def fs_write_ceiling(workdir, gb=6, threads=(4, 8), block=4 << 20):
+    """what ONE file takes on this box's scratch file system: `threads` writers pwrite()-ing 4 MiB blocks at disjoint, interleaved offsets
+    of a new file (buffered, the file growing as they go -- the overlay file system of the boxes refuses fallocate; O_DIRECT measured
+    slower, profiles/r02_write_probe.txt) -> best GB/s.  The `file` key cannot be faster than this whatever the mapper does."""
+    import threading
+    buf = bytes(block)
+    nblk = (gb << 30) // block
+    best = 0.0
+    for T in threads:
+        path = os.path.join(workdir, "fs_probe.bin")
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        def work(t):
+            for b in range(t, nblk, T):
+                os.pwrite(fd, buf, b * block)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        for x in th: x.start()
+        for x in th: x.join()
+        dt = time.perf_counter() - t0
+        os.close(fd)
+        os.unlink(path)
+        best = max(best, nblk * block / dt / 1e9)
+    return round(best, 2)
+
+
 def file_to_file_rate(args, cfg, fa, L):
     """FASTQ file(s) -> SAM / BAM file through bitmapperbs_amd/bmbs_search (the drop-in driver).  Input: the cpu_baseline sample REP times
     over (20 M pairs on configs[2]), which the driver reads `input_passes` times (--loop-input, a measurement aid) so that every key
@@ -914,17 +939,26 @@ def file_to_file_rate(args, cfg, fa, L):
         got = []
         try:
             for _ in range(runs):
-                got.append(driver_run(drv, fa, inp, cfg, ["-o", dst, "-t", "32", "--loop-input", str(loops)] + extra))
+                g_ = driver_run(drv, fa, inp, cfg, ["-o", dst, "-t", "32", "--loop-input", str(loops)] + extra)
+                written = sum(os.path.getsize(f) for f in [sam] + [os.path.join(args.workdir, "f2f.sam.part%03d" % k) for k in range(parts)] if os.path.exists(f))
+                got.append(g_ + (written,))
                 for f in [sam] + [os.path.join(args.workdir, "f2f.sam.part%03d" % k) for k in range(parts)]:
                     if os.path.exists(f):
                         os.unlink(f)            # (the boxes' scratch disk holds one such output beside the inputs, not two)
         except RuntimeError as ex:
             return {"error": str(ex)}
         got.sort(key=lambda g: g[0])
-        wall, busy, stages = got[len(got) // 2]
+        wall, busy, stages, written = got[len(got) // 2]
         out[label] = e2e_key(n * loops, wall, busy, stages, loops)
+        if written:
+            out[label]["written_GBps"] = round(written / wall / 1e9, 2)
         if runs > 1:
             out[label]["runs_Mreads_s"] = [round(n * loops / g[0] / 1e6, 2) for g in got]
+    try:
+        # the one-file sink against what one inode takes here
+        out["file"]["fs_ceiling_GBps"] = fs_write_ceiling(args.workdir)
+    except Exception as ex:
+        out["file"]["fs_ceiling_GBps"] = repr(ex)
     try:
         out["gz_input"] = gz_input_rate(args, drv, fa, cfg, big, inp, rec_bytes, 6)
     except Exception as ex:
