@@ -15,6 +15,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -114,6 +115,20 @@ struct Pending {
     bool staged = false;                     // the call reads lane-owned staging buffers, which the lane's next call overwrites
 };
 
+// The trigram rank table (DevIndex::occ3, 27.9 GB at GRCh38 size) is built when a context that uses the index has seen reads that walk
+// it in long chains (lr_chain >= 3 extensions per lookup: a repeat-rich genome) -- not at attach, where round 4 built it for every
+// index: on a repeat-poor genome it was never used and cost a third context its work buffers.  One object per attached index, shared
+// by the owner's lanes and by every context that shares the index; the table's memory belongs to it.
+struct Occ3Shared {
+    std::mutex mu;
+    bool tried = false;
+    int dev = 0;
+    DevIndex base;                      // the index without the table (what the builder reads)
+    u64 rows = 0;
+    void* occ3 = nullptr; void* c3 = nullptr; u64 nb3 = 0;
+    ~Occ3Shared() { if (occ3 || c3) { (void)hipSetDevice(dev); if (occ3) (void)hipFree(occ3); if (c3) (void)hipFree(c3); } }
+};
+
 // One lane = one stream with its own work buffers, counters and HIP-event profile: what a whole context was in round 2.  A context
 // owns BMBS_LANES of them on one attached index and deals the chunks of a call to them, so that the issue-bound kernels (DP, Myers,
 // row preparation) of one chunk run beside the memory-bound seeding kernels of another without a second context or host thread.
@@ -133,7 +148,8 @@ struct Lane {
     DevIndex ix;
     u64 rows = 0;
     // index buffers
-    DevBuf occ, hash, sa, gen2, chrom_start, t20, occ3, c3;
+    DevBuf occ, hash, sa, gen2, chrom_start, t20;
+    std::shared_ptr<Occ3Shared> o3;            // the index's trigram table, built on demand (occ3_want)
     // LUTs
     DevBuf pen_lut, mapq_lut;
     bool luts_ready = false;
@@ -569,6 +585,51 @@ SeedCarry seed_carry(Lane* c)
 // (k_pack_rows, 0.53 ms per 10 M reads) that the consumers win back (+1.8 %: 1463 -> 1489 M reads/s on configs[1]).
 bool use_packed_rows(const Lane* c) { return !c->kn.rows_ascii; }
 
+// trigram rank table: three backward extensions per gather pair (bmbs_dev.h: occ3).  4.5 bytes per row; built from the full SA and
+// the 2-bit text on a stream of its own, checked against three single steps on a million rows before it is used.
+void occ3_build(Occ3Shared& o)
+{
+    const u64 rows = o.rows, nb = rows / 96 + 2, need = 27 * nb * 16;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (free_b <= need + (40ull << 30)) return;
+    const u64 n_chunks = (nb + OCC3_CHUNK - 1) / OCC3_CHUNK;
+    void *t3 = nullptr, *c3 = nullptr, *sums = nullptr;
+    hipStream_t st = nullptr;
+    bool ok = hipMalloc(&t3, need) == hipSuccess && hipMalloc(&c3, 64 * 8) == hipSuccess && hipMalloc(&sums, 27 * n_chunks * 8 + 64) == hipSuccess &&
+              hipStreamCreate(&st) == hipSuccess;
+    if (ok) {
+        u32* flag = reinterpret_cast<u32*>(c3) + 2 * 60;                       // two spare words behind the 27 entries: overflow, mismatches
+        (void)hipMemsetAsync(c3, 0, 64 * 8, st);
+        hipLaunchKernelGGL(k_occ3_planes, dim3(8192), dim3(256), 0, st, o.base, rows, nb, reinterpret_cast<uint4*>(t3));
+        hipLaunchKernelGGL(k_occ3_chunk_sums, dim3(nblk(27 * n_chunks, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(t3), nb, n_chunks, reinterpret_cast<u64*>(sums));
+        hipLaunchKernelGGL(k_occ3_chunk_scan, dim3(1), dim3(64), 0, st, reinterpret_cast<u64*>(sums), n_chunks, flag);
+        hipLaunchKernelGGL(k_occ3_apply, dim3(nblk(27 * n_chunks, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(t3), nb, n_chunks, reinterpret_cast<u64*>(sums));
+        hipLaunchKernelGGL(k_occ3_c3, dim3(1), dim3(64), 0, st, o.base, reinterpret_cast<u64*>(c3));
+        DevIndex probe = o.base;
+        probe.occ3 = reinterpret_cast<const uint4*>(t3); probe.c3 = reinterpret_cast<const u64*>(c3); probe.nb3 = nb;
+        const u64 n_check = 1u << 20;
+        hipLaunchKernelGGL(k_occ3_check, dim3(nblk(n_check, 256)), dim3(256), 0, st, probe, rows, n_check, flag + 1);
+        u32 h[2] = {1, 1};
+        ok = hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && h[0] == 0 && h[1] == 0;
+        if (!ok && getenv("BMBS_VERBOSE")) fprintf(stderr, "[bmbs] trigram table not used: count overflow %u, differences from three single steps %u\n", h[0], h[1]);
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (sums) (void)hipFree(sums);
+    if (ok) { o.occ3 = t3; o.c3 = c3; o.nb3 = nb; }
+    else { if (t3) (void)hipFree(t3); if (c3) (void)hipFree(c3); }
+}
+// called where a lane decides which seeding kernels to launch, and when a settled call has told it how long its chains are: builds the
+// table once for all users of the index when this lane would use it, and adopts it when someone has built it
+void occ3_want(Lane* c)
+{
+    if (c->ix.occ3 || !c->o3 || c->kn.kgram < 1 || !use_packed_rows(c)) return;
+    const bool wants = c->kn.kgram >= 2 || c->lr_chain >= 3.0;
+    std::lock_guard<std::mutex> l(c->o3->mu);
+    if (!c->o3->occ3 && wants && !c->o3->tried) { c->o3->tried = true; (void)hipSetDevice(c->dev); occ3_build(*c->o3); }
+    if (c->o3->occ3) { c->ix.occ3 = reinterpret_cast<const uint4*>(c->o3->occ3); c->ix.c3 = reinterpret_cast<const u64*>(c->o3->c3); c->ix.nb3 = c->o3->nb3; }
+}
+
 int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, int pe_mode, bool prepacked = false)
 {
     ENS(c, c->sd_sp0, n * 8); ENS(c, c->sd_hits0, n * 4); ENS(c, c->sd_ml0, n * 2); ENS(c, c->sd_tm, n * 2); ENS(c, c->sd_seed_id, n);
@@ -599,6 +660,7 @@ int launch_seeding(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u
     prof_begin(c, "k_seed_first");
     // three-letter index steps (DevIndex::occ3): their kernels hold more registers (one or two waves per SIMD fewer), which costs a
     // few per cent where chains are short -- so they are used once the context has seen long ones (BMBS_KGRAM=2: always, 0: never)
+    occ3_want(c);
     const bool kg = c->ix.occ3 && packed_rows && (c->kn.kgram >= 2 || (c->kn.kgram == 1 && c->lr_chain >= 3.0));
     if (packed_rows && kg) hipLaunchKernelGGL((k_seed_first<true, true>), dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
     else if (packed_rows) hipLaunchKernelGGL(k_seed_first<true>, dim3(chunks), dim3(64), 0, c->stream, c->ix, d_seq, pr, gm, stride, (long)n, sc, cnt);
@@ -849,7 +911,7 @@ void lane_destroy(Lane* c)
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wavelog), &d, sizeof(d));
         release(c->wavelog_buf); release(c->wavelog_count);
     }
-    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->occ3, &c->c3, &c->pen_lut, &c->mapq_lut, &c->verdict,
+    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
@@ -1012,39 +1074,10 @@ static int lane_index_attach(Lane* c, const bmbs_index_view* v)
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { c->err = std::string("index re-pack: ") + hipGetErrorString(e); return BMBS_ENODEV; }
-    // trigram rank table: three backward extensions per gather pair (bmbs_dev.h: occ3).  4.5 bytes per row; built from the full SA and
-    // the 2-bit text, checked against three single steps on a million rows before it is used.  BMBS_KGRAM=0: off
+    // the trigram rank table is built when it is wanted (occ3_want): BMBS_KGRAM=2 at the first call, 1 (default) once long chains were seen
     ix.occ3 = nullptr; ix.c3 = nullptr; ix.nb3 = 0;
-    {
-        const char* kg_env = getenv("BMBS_KGRAM");
-        const u64 nb = rows / 96 + 2;
-        const u64 need = 27 * nb * 16;
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        if (!(kg_env && !strcmp(kg_env, "0")) && free_b > need + (40ull << 30) && ensure(c, c->occ3, need) == BMBS_OK && ensure(c, c->c3, 64 * 8) == BMBS_OK) {
-            DevBuf sums;
-            const u64 n_chunks = (nb + OCC3_CHUNK - 1) / OCC3_CHUNK;
-            if (ensure(c, sums, 27 * n_chunks * 8 + 64) == BMBS_OK) {
-                u32* flag = c->c3.as<u32>() + 2 * 60;                              // two spare words behind the 27 entries: overflow, mismatches
-                (void)hipMemsetAsync(c->c3.p, 0, 64 * 8, c->stream);
-                hipLaunchKernelGGL(k_occ3_planes, dim3(8192), dim3(256), 0, c->stream, ix, rows, nb, c->occ3.as<uint4>());
-                hipLaunchKernelGGL(k_occ3_chunk_sums, dim3(nblk(27 * n_chunks, 256)), dim3(256), 0, c->stream, c->occ3.as<uint4>(), nb, n_chunks, sums.as<u64>());
-                hipLaunchKernelGGL(k_occ3_chunk_scan, dim3(1), dim3(64), 0, c->stream, sums.as<u64>(), n_chunks, flag);
-                hipLaunchKernelGGL(k_occ3_apply, dim3(nblk(27 * n_chunks, 256)), dim3(256), 0, c->stream, c->occ3.as<uint4>(), nb, n_chunks, sums.as<u64>());
-                hipLaunchKernelGGL(k_occ3_c3, dim3(1), dim3(64), 0, c->stream, ix, c->c3.as<u64>());
-                DevIndex probe = ix;
-                probe.occ3 = c->occ3.as<uint4>(); probe.c3 = c->c3.as<u64>(); probe.nb3 = nb;
-                const u64 n_check = 1u << 20;
-                hipLaunchKernelGGL(k_occ3_check, dim3(nblk(n_check, 256)), dim3(256), 0, c->stream, probe, rows, n_check, flag + 1);
-                u32 h[2] = {1, 1};
-                if (hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess && h[0] == 0 && h[1] == 0) {
-                    ix.occ3 = probe.occ3; ix.c3 = probe.c3; ix.nb3 = nb;
-                } else if (getenv("BMBS_VERBOSE")) fprintf(stderr, "[bmbs] trigram table not used: count overflow %u, differences from three single steps %u\n", h[0], h[1]);
-                release(sums);
-            }
-            if (!ix.occ3) { release(c->occ3); }
-        }
-    }
+    c->o3 = std::make_shared<Occ3Shared>();
+    c->o3->dev = c->dev; c->o3->base = ix; c->o3->rows = rows;
     c->ix = ix; c->rows = rows; c->attached = true;
     return BMBS_OK;
 }
@@ -1544,7 +1577,7 @@ int lane_settle(Lane* c)
                     c->lr_sw = std::max(c->lr_sw, (double)t[2] / nr);
                     c->lr_rcand = std::max(c->lr_rcand, (double)t[8] / nr);
                     c->lr_long = ((double)t[9] + (double)t[11]) / nr;             // reads whose candidate lists went to the mid / long kernels
-                    if (t[14]) c->lr_chain = (double)t[15] / (double)t[14];
+                    if (t[14]) { c->lr_chain = (double)t[15] / (double)t[14]; occ3_want(c); }      // (the table is built here, behind the call that showed the chains)
                 }
                 c->last_total_cand = t[0]; c->last_n_jobs = t[1];
                 prof_collect(c, P.slot);
@@ -2494,7 +2527,7 @@ extern "C" int bmbs_index_share(bmbs_ctx* X, const bmbs_ctx* owner)
     if (!o->attached) { X->err = "index share: the owner has no index attached"; return BMBS_ESTATE; }
     if (X->dev != owner->dev) { X->err = "index share: contexts on different devices"; return BMBS_EINVAL; }
     if (X->lanes[0]->attached) { X->err = "index share: this context already has an index"; return BMBS_ESTATE; }
-    for (Lane* c : X->lanes) { c->ix = o->ix; c->rows = o->rows; c->attached = true; }
+    for (Lane* c : X->lanes) { c->ix = o->ix; c->rows = o->rows; c->o3 = o->o3; c->attached = true; }
     return BMBS_OK;
 }
 
@@ -2897,7 +2930,7 @@ extern "C" int bmbs_index_attach(bmbs_ctx* X, const bmbs_index_view* v)
     if (!c) return BMBS_EINVAL;
     const int rc = lane_index_attach(c, v);
     if (rc) return fin(X, c, rc);
-    for (size_t i = 1; i < X->lanes.size(); i++) { Lane* o = X->lanes[i]; o->ix = c->ix; o->rows = c->rows; o->attached = true; }
+    for (size_t i = 1; i < X->lanes.size(); i++) { Lane* o = X->lanes[i]; o->ix = c->ix; o->rows = c->rows; o->o3 = c->o3; o->attached = true; }
     return BMBS_OK;
 }
 extern "C" int bmbs_sam_refs(bmbs_ctx* X, const char* const* names, int32_t n_names) { ON_LANE0(lane_sam_refs(c, names, n_names)); }
