@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbmbs_hip.so")
+LIB_PATH = os.environ.get("BMBS_LIB") or os.path.join(_HERE, "libbmbs_hip.so")      # (BMBS_LIB: an experimental build, A/B runs of tools/)
 
 # every symbol include/bmbs.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -184,8 +184,9 @@ def lib() -> C.CDLL:
     return L
 
 
-LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "k_index.hip", "k_rows.hip", "k_attach.hip", "k_scan.hip", "k_seed.hip", "k_vote.hip", "k_filter.hip", "k_reduce.hip", "k_align.hip", "k_finalize.hip", "k_pe_fast.hip", "k_pe_sensitive.hip", "bmbs_text.hip", "bmbs_bam.hip", "bmbs_inflate.hip", "bmbs_dev.h", "bmbs_sort.h", "index_io.cpp", "index_io.h", "index_build_gpu.hip",
-            "../../include/bmbs.h")
+LIB_SRCS = ("bmbs_api.hip", "bmbs_kernels.hip", "k_index.hip", "k_rows.hip", "k_attach.hip", "k_scan.hip", "k_seed.hip", "k_vote.hip", "k_filter.hip", "k_reduce.hip", "k_align.hip", "k_finalize.hip", "k_pe_fast.hip", "k_pe_sensitive.hip",
+            "bmbs_textpath.hip", "bmbs_text.hip", "bmbs_bam.hip", "bmbs_inflate.hip", "bmbs_bytes.h", "bmbs_host.h", "bmbs_dev.h", "bmbs_sort.h", "../../include/bmbs.h",
+            "index_io.cpp", "index_io.h", "index_build_gpu.hip", "build_id.cpp")
 
 
 def sources_id() -> str:

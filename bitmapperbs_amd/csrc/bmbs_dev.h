@@ -92,4 +92,13 @@ struct ScoreParams {
     int mp_max, mp_min, np, gap_open, gap_ext, q_base;
     int seed_len;
 };
+struct bmbs_result_dev {   // == bmbs_result (include/bmbs.h), 32 bytes
+    u64 pos; u32 cigar_off; int32_t chrom; u16 flag; u16 nm; int16_t score; u8 status; u8 mapq; u8 n_cigar; u8 path; u16 n_cand; u32 tlen;
+};
+
+// Event / stats counters are sharded: 64 shards of 32 u64 (256 B apart), shard = blockIdx & 63, summed on the host.
+// One global word sustains only ~90 atomics/us on MI355X; with >100 k blocks per launch un-sharded counters
+// cost more than the kernels themselves (k_seed_decide: 4.0 ms -> 1.2 ms).
+#define BMBS_SHARDS 64
+#define BMBS_SHARD_WORDS 32
 #endif

@@ -20,11 +20,6 @@
 
 #define DEVI __device__ __forceinline__
 
-// Event / stats counters are sharded: 64 shards of 32 u64 (256 B apart), shard = blockIdx & 63, summed on the host.
-// One global word sustains only ~90 atomics/us on MI355X; with >100 k blocks per launch un-sharded counters
-// cost more than the kernels themselves (k_seed_decide: 4.0 ms -> 1.2 ms).
-#define BMBS_SHARDS 64
-#define BMBS_SHARD_WORDS 32
 #define SHARD(p) ((p) + (size_t)(blockIdx.x & (BMBS_SHARDS - 1)) * BMBS_SHARD_WORDS)
 
 // ---- per-wave timeline (diagnostic, BMBS_WAVELOG=<file>) ------------------------------------------------------------------------

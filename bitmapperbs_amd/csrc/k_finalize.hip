@@ -3,9 +3,6 @@
 // ================================================================================================
 // finalize: MAPQ, placement, stats
 // ================================================================================================
-struct bmbs_result_dev {   // == bmbs_result (include/bmbs.h), 32 bytes
-    u64 pos; u32 cigar_off; int32_t chrom; u16 flag; u16 nm; int16_t score; u8 status; u8 mapq; u8 n_cigar; u8 path; u16 n_cand; u32 tlen;
-};
 DEVI u16 sat16(u32 v) { return v > 0xffffu ? (u16)0xffffu : (u16)v; }
 
 // mapq_lut[(ed) * (range+1) + sd]: MAP_Calculation (Schema.cpp:168-405) tabulated on the host in

@@ -184,58 +184,6 @@ k_pe_prepare_p(const char* __restrict__ s1, const char* __restrict__ s2raw, Read
     }
 }
 
-// ---- FASTQ text -> read rows (bmbs_map_*_fastq) --------------------------------------------------------------------------------
-// What inputReads_single_directly / inputReads_paired_directly (Process_Reads.cpp:810-890, 155-317) do per record on the host --
-// cut the sequence and quality lines out of the text, upper-case the bases, pad short quality lines with ' ', reverse-complement
-// mate 2 (and every read of a --pbat library, with mirrored qualities) -- done here for a whole batch from the FASTQ text as it was
-// read from the file: the host only finds the line starts.  One thread per 16-byte piece of an output row.
-__global__ void __launch_bounds__(256)
-k_fastq_rows(const char* __restrict__ text, const u32* __restrict__ seq_off, const u32* __restrict__ qual_off,
-             const u16* __restrict__ seq_len, const u16* __restrict__ qual_len, long n, int stride, int rc_seq, int rev_qual,
-             char* __restrict__ seq_out, char* __restrict__ qual_out, u16* __restrict__ len_out)
-{
-    const long i16 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_row = stride / 16;
-    if (i16 >= n * per_row) return;
-    const long r = i16 / per_row;
-    const int j0 = (int)(i16 - r * per_row) * 16;
-    const int L = seq_len[r];
-    if (len_out && j0 == 0) len_out[r] = (u16)L;
-    const char* src = text + seq_off[r];
-    unsigned char o[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const int j = j0 + t;
-        unsigned char c = 0;
-        if (j < L) {
-            c = (unsigned char)src[rc_seq ? L - 1 - j : j];
-            if (c >= 'a' && c <= 'z') c -= 32;
-            if (rc_seq) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;      // rc_table, Process_Reads.cpp:1603
-        }
-        o[t] = c;
-    }
-    uint4 v;
-    v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
-    v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
-    v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
-    v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
-    reinterpret_cast<uint4*>(seq_out)[i16] = v;
-    if (!qual_out) return;
-    const int ql = qual_len[r];
-    const char* qs = text + qual_off[r];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const int j = j0 + t;
-        unsigned char c = 0;
-        if (j < L) { const int jj = rev_qual ? L - 1 - j : j; c = jj < ql ? (unsigned char)qs[jj] : (unsigned char)' '; }
-        o[t] = c;
-    }
-    v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
-    v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
-    v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
-    v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
-    reinterpret_cast<uint4*>(qual_out)[i16] = v;
-}
 
 // get_candidates' list construction (Schema.cpp:18510-18545): site-sorted votes (NOT re-sorted by vote)
 __global__ void __launch_bounds__(64)
