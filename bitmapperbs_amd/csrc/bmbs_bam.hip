@@ -314,6 +314,14 @@ k_line_write(SamIn in, long n_lines, const u64* __restrict__ off, int lpb, u32 o
     }
 }
 
+// -DBGZF_PROFILE (tools/bgzf_prof.sh): cycles per phase of k_bgzf_block as thread 0 sees them, summed over the blocks
+#ifdef BGZF_PROFILE
+__device__ unsigned long long g_bgzf_prof[8];
+#define BZ_T(k) do { if (tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_bgzf_prof[k], t_ - bz_t); bz_t = t_; } } while (0)
+#else
+#define BZ_T(k)
+#endif
+
 // ---- BGZF: one workgroup deflates one block of <= 0xff00 input bytes --------------------------------------------------------------
 #define BGZF_IN       0xff00                // input bytes per block (bgzf.h BGZF_BLOCK_SIZE)
 #define BGZF_SLOT     65536                 // bytes of a block's slot in the scratch output (a stored block fits: 0xff00 + 5 + 26)
@@ -425,13 +433,54 @@ DEVI void put_bits(BitOut& o, u32 v, int n)
 }
 
 // raw: the BAM record stream of the batch (total bytes); block b = raw[b * BGZF_IN ...).  slot b of `slots` receives the finished
-// BGZF block (header, deflate data, CRC-32, ISIZE), slot_len[b] its length.  tok: BGZF_SEG * BGZF_THREADS u16 per block of scratch
-// (a literal byte, or 0x8000 | run length - 3: the matches are runs, distance 1).
-__global__ void __launch_bounds__(BGZF_THREADS)
-k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, u16* __restrict__ tok_all, char* __restrict__ slots, u32* __restrict__ slot_len)
+// BGZF block (header, deflate data, CRC-32, ISIZE), slot_len[b] its length.
+// Round 5: a thread's 256-byte segment sits in LDS at a stride of 65 words, so that the 64 lanes of a wave reading "their" word j hit
+// 32 different banks (at 64 words apart every access of the byte loops was a 64-way bank conflict: 58 % of the kernel's time); the
+// tokens -- a literal byte, or a run of the byte before it (distance 1) -- are not stored anywhere: they follow from 256 "equals the
+// byte before it" bits a thread keeps in registers, and the three passes that need them (symbol counts, bit lengths, emit) walk the
+// segment again; the deflate stream goes straight into the block's slot in memory (whole words stored, shared edge words OR-ed in).  (Round 4 kept 16-bit tokens in memory: 590 MB of
+// scratch and 1.2 GB of 2-byte loads and stores per 300 MB of records.)
+#define BGZF_PSTRIDE  65                    // words between the segments of two threads in LDS
+// number of consecutive set bits of e (256 bits, LSB first) from position p on
+DEVI int bz_streak(const u64 (&e)[4], int p)
 {
-    // the block's bytes, later the staging area of the deflate stream (the tokens hold everything the encoder needs)
-    extern __shared__ __align__(16) u32 s_data[];     // (BGZF_IN + 512) / 4 words
+    int n = 0;
+    for (int w = p >> 6, sh = p & 63; w < 4; w++, sh = 0) {
+        const u64 x = ~(e[w] >> sh);
+        const int room = 64 - sh;
+        const int t = x ? __builtin_ctzll(x) : 64;
+        if (t < room) return n + t;
+        n += room;
+    }
+    return n;
+}
+// the tokens of a segment of n bytes (seg: its words in LDS), in order: lit(byte) / run(length >= 3)
+template <class FL, class FR>
+DEVI void bz_walk(const u32* seg, const u64 (&e)[4], int n, FL lit, FR run)
+{
+    int skip = 0;
+    for (int j = 0; 4 * j < n; j++) {
+        const u32 w = seg[j];
+        const u32 e4 = (u32)(e[j >> 4] >> (4 * (j & 15))) & 15u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int p = 4 * j + q;
+            if (p >= n) break;
+            if (skip > 0) { skip--; continue; }
+            if ((e4 >> q) & 1u) {
+                const int sl = bz_streak(e, p);
+                if (sl >= 3) { run(sl); skip = sl - 1; continue; }
+            }
+            lit((w >> (8 * q)) & 0xffu);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BGZF_THREADS)
+k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, char* __restrict__ slots, u32* __restrict__ slot_len)
+{
+    extern __shared__ __align__(16) u32 s_dyn[];      // [BGZF_THREADS * BGZF_PSTRIDE] the block's bytes
+    u32* const s_in = s_dyn;
     __shared__ u32 s_freq[DEF_SYMS];
     __shared__ u32 s_code[DEF_SYMS];
     __shared__ u8 s_len[DEF_SYMS + 8];
@@ -448,14 +497,18 @@ k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, u1
     if (base >= total) return;
     const int blen = (int)((total - base) < (u64)BGZF_IN ? (total - base) : (u64)BGZF_IN);
     const int tid = threadIdx.x;
-    u8* data = reinterpret_cast<u8*>(s_data);
-    u16* tok = tok_all + (size_t)blockIdx.x * (BGZF_SEG * BGZF_THREADS);
+#ifdef BGZF_PROFILE
+    unsigned long long bz_t = clock64();
+#endif
     // ---- load (raw + base is 16-byte aligned: BGZF_IN is a multiple of 16), tables
     {
         const uint4* src = reinterpret_cast<const uint4*>(raw + base);
         const int n16 = (blen + 15) >> 4;
-        uint4* dst = reinterpret_cast<uint4*>(s_data);
-        for (int i = tid; i < n16; i += BGZF_THREADS) dst[i] = src[i];           // (the raw buffer is padded past `total`)
+        for (int i = tid; i < n16; i += BGZF_THREADS) {                          // (the raw buffer is padded past `total`)
+            const uint4 v = src[i];
+            u32* d = s_in + (i >> 4) * BGZF_PSTRIDE + (i & 15) * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
         for (int i = tid; i < DEF_SYMS; i += BGZF_THREADS) s_freq[i] = 0;
         u32 c = (u32)tid;
         for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
@@ -463,41 +516,42 @@ k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, u1
         if (tid < 8) s_misc[tid] = 0;
     }
     __syncthreads();
+    BZ_T(0);
     // ---- parse: greedy, literals and runs (distance 1); CRC of the segment on the way
     const int s0 = tid * BGZF_SEG, s1 = s0 + BGZF_SEG < blen ? s0 + BGZF_SEG : blen;
-    int ntok = 0;
+    const int nseg = s1 > s0 ? s1 - s0 : 0;          // bytes of this thread's segment
+    const u32* seg = s_in + tid * BGZF_PSTRIDE;
+    u64 eq[4] = {0, 0, 0, 0};                         // bit p: byte p of the segment equals the byte before it
     u32 xbits = 0, crc = 0;
-    if (s0 < blen) {
+    if (nseg > 0) {
         u32 c = 0xffffffffu;
-        for (int p = s0; p < s1; p++) c = s_crc_tab[(c ^ data[p]) & 0xffu] ^ (c >> 8);
+        u32 prev = tid > 0 ? s_in[(tid - 1) * BGZF_PSTRIDE + 63] >> 24 : 0x100u;  // (0x100: nothing in front of the block's first byte)
+        for (int j = 0; 4 * j < nseg; j++) {
+            const u32 w = seg[j];
+            u32 m4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 bq = (w >> (8 * q)) & 0xffu;
+                if (4 * j + q < nseg) {
+                    c = s_crc_tab[(c ^ bq) & 0xffu] ^ (c >> 8);
+                    m4 |= (bq == prev ? 1u : 0u) << q;
+                    prev = bq;
+                }
+            }
+            eq[j >> 4] |= (u64)m4 << (4 * (j & 15));
+        }
         c = ~c;
         crc = crc_multmodp(crc_x8n((u32)(blen - s1)), c);                       // this segment's share of the block's CRC
-        int p = s0;
-        while (p < s1) {
-            int run = 0;
-            if (p > 0) {
-                const u8 b = data[p - 1];
-                const int lim = s1 - p < 258 ? s1 - p : 258;
-                while (run < lim && data[p + run] == b) run++;
-            }
-            if (run >= 3) {
-                int lc, le, lx; len_code(run, lc, le, lx);
-                tok[s0 + ntok++] = (u16)(0x8000u | (u32)(run - 3));
-                atomicAdd(&s_freq[257 + lc], 1u); atomicAdd(&s_freq[DEF_DOFF + 0], 1u);
-                xbits += (u32)le;
-                p += run;
-            } else {
-                const u8 b = data[p++];
-                tok[s0 + ntok++] = (u16)b;
-                atomicAdd(&s_freq[b], 1u);
-            }
-        }
+        bz_walk(seg, eq, nseg,
+                [&](u32 b) { atomicAdd(&s_freq[b], 1u); },
+                [&](int run) { int lc, le, lx; len_code(run, lc, le, lx); atomicAdd(&s_freq[257 + lc], 1u); atomicAdd(&s_freq[DEF_DOFF + 0], 1u); xbits += (u32)le; });
     }
     if (tid == 0) atomicAdd(&s_freq[256], 1u);
     // block sums of xbits and the CRC shares (xor)
     for (int o = 32; o > 0; o >>= 1) { xbits += __shfl_down(xbits, o, 64); crc ^= __shfl_down(crc, o, 64); }
     if ((tid & 63) == 0) { atomicAdd(&s_misc[0], xbits); atomicXor(&s_misc[1], crc); }
     __syncthreads();
+    BZ_T(1);
     // ---- the used symbols by ascending (frequency, symbol): every thread ranks its symbols against all the others (an insertion
     // sort by one lane is ~20 000 dependent LDS steps for a block that uses all 256 byte values)
     for (int sy = tid; sy < DEF_LL + DEF_D; sy += BGZF_THREADS) {
@@ -513,6 +567,7 @@ k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, u1
         }
     }
     __syncthreads();
+    BZ_T(2);
     // ---- trees and header: lane 0 (the other lanes of the block wait)
     if (tid == 0) {
         HuffWork hw; hw.key = s_key; hw.par = s_par; hw.ord = s_ord; hw.dep = s_dep;
@@ -566,6 +621,7 @@ k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, u1
         s_misc[3] = dyn_bytes < (u32)blen + 5u ? 1u : 0u;
     }
     __syncthreads();
+    BZ_T(3);
     const bool dynamic = s_misc[3] != 0;
     const u32 hdr_bits = s_misc[2], body_bits = s_misc[4];
     const u32 crc_all = s_misc[1];
@@ -574,64 +630,85 @@ k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, u1
     if (!dynamic) {
         // stored: 1 byte of type bits, LEN, NLEN, the bytes
         clen = 5u + (u32)blen;
-        if (tid == 0) { slot[18] = 1; slot[19] = (char)blen; slot[20] = (char)(blen >> 8); slot[21] = (char)~blen; slot[22] = (char)(~blen >> 8); }
-        for (int i = tid; i < blen; i += BGZF_THREADS) slot[23 + i] = (char)data[i];
+        // (bytes 18, 19 share slot word 4 with BSIZE: OR-ed in below like every shared word)
+        if (tid == 0) { atomicOr(reinterpret_cast<u32*>(slot) + 4, (1u << 16) | (((u32)blen & 0xffu) << 24)); slot[20] = (char)(blen >> 8); slot[21] = (char)~blen; slot[22] = (char)(~blen >> 8); }
+        for (int i = tid; i < blen; i += BGZF_THREADS) slot[23 + i] = (char)(s_in[(i >> 8) * BGZF_PSTRIDE + ((i & 255) >> 2)] >> (8 * (i & 3)));
     } else {
         clen = (hdr_bits + body_bits + 7) >> 3;
         // bits of this thread's tokens, exclusive prefix over the block
         u32 mybits = 0;
-        for (int j = 0; j < ntok; j++) {
-            const u32 t = tok[s0 + j];
-            if (t & 0x8000u) {
-                int lc, le, lx; len_code((int)(t & 0xffu) + 3, lc, le, lx);
-                int dc, de, dx; dist_code(1, dc, de, dx);
-                mybits += (s_code[257 + lc] >> 16) + (u32)le + (s_code[DEF_DOFF + dc] >> 16) + (u32)de;
-            } else mybits += s_code[t] >> 16;
-        }
+        const u32 dcode = s_code[DEF_DOFF + 0];                                    // distance 1: code 0, no extra bits
+        bz_walk(seg, eq, nseg,
+                [&](u32 b) { mybits += s_code[b] >> 16; },
+                [&](int run) { int lc, le, lx; len_code(run, lc, le, lx); mybits += (s_code[257 + lc] >> 16) + (u32)le + (dcode >> 16); });
         u32 incl = mybits;
         for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
         if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
-        __syncthreads();                                                            // (everybody has read its tokens' source: s_data may go)
+        __syncthreads();
+        BZ_T(4);
         u32 wbase = 0;
         for (int i = 0; i < (tid >> 6); i++) wbase += s_wave[i];
-        u32 pos = hdr_bits + wbase + (incl - mybits);
-        const int nwords = (int)((clen + 3) >> 2) + 1;
-        for (int i = tid; i < nwords; i += BGZF_THREADS) s_data[i] = i < 176 ? s_hdr[i] : 0u;      // header bits + zeros
-        __syncthreads();
-        // emit: a 64-bit accumulator flushed word-wise with atomicOr (the first and last word of a thread's run are shared)
-        unsigned long long acc = 0; int have = 0; u32 wi = pos >> 5;
-        { const int sh = (int)(pos & 31); have = sh; }                              // bits of word wi below `have` belong to the neighbour
+        // The stream goes straight into the block's slot in memory (zeroed by the host before the launch), as 32-bit words of the slot:
+        // bit g of the slot = bit g % 32 of word g / 32; the deflate data starts at byte 18 = slot bit 144.  A thread owns the words that
+        // lie wholly inside its bit range and stores them; the word at either end it shares with a neighbour (or with the gzip header /
+        // the dynamic-block header in front) and ORs its bits in.
+        u32* const gw = reinterpret_cast<u32*>(slot);
+        // ... the dynamic-block header first: words of s_hdr shifted by 144 % 32 = 16 bits
+        for (u32 i = tid; i * 32 < hdr_bits + 16; i += BGZF_THREADS) {
+            const u32 lo = i ? s_hdr[i - 1] >> 16 : 0u, hi = i < 176 ? s_hdr[i] << 16 : 0u;         // slot word 4 + i
+            const u32 v = lo | hi;
+            const bool whole = i > 0 && (i + 1) * 32 <= hdr_bits + 16;
+            if (whole) gw[4 + i] = v; else if (v) atomicOr(&gw[4 + i], v);
+        }
+        const u32 pos = 144u + hdr_bits + wbase + (incl - mybits);                  // slot bit of this thread's first token
+        const u32 endb = pos + mybits + ((s0 < blen && s1 == blen) ? (s_code[256] >> 16) : 0u);
+        unsigned long long acc = 0; int have = (int)(pos & 31); u32 wi = pos >> 5;  // bits of word wi below `have` belong to the neighbour
+        bool first = true;
+        auto flush = [&](u32 v) {
+            // the first word is shared unless the range starts on its boundary; a later word is whole (its 32 bits are this thread's)
+            if (first && (pos & 31)) atomicOr(&gw[wi], v); else gw[wi] = v;
+            first = false;
+        };
         auto emit = [&](u32 v, int n) {
             acc |= (unsigned long long)v << have; have += n;
-            if (have >= 32) { atomicOr(&s_data[wi], (u32)acc); wi++; acc >>= 32; have -= 32; }
+            if (have >= 32) { flush((u32)acc); wi++; acc >>= 32; have -= 32; }
         };
-        for (int j = 0; j < ntok; j++) {
-            const u32 t = tok[s0 + j];
-            if (t & 0x8000u) {
-                int lc, le, lx; len_code((int)(t & 0xffu) + 3, lc, le, lx);
-                int dc, de, dx; dist_code(1, dc, de, dx);
-                emit(s_code[257 + lc] & 0xffffu, (int)(s_code[257 + lc] >> 16));
-                if (le) emit((u32)lx, le);
-                emit(s_code[DEF_DOFF + dc] & 0xffffu, (int)(s_code[DEF_DOFF + dc] >> 16));
-                if (de) emit((u32)dx, de);
-            } else emit(s_code[t] & 0xffffu, (int)(s_code[t] >> 16));
-        }
+        bz_walk(seg, eq, nseg,
+                [&](u32 b) { const u32 cd = s_code[b]; emit(cd & 0xffffu, (int)(cd >> 16)); },
+                [&](int run) {
+                    int lc, le, lx; len_code(run, lc, le, lx);
+                    const u32 cd = s_code[257 + lc];
+                    emit(cd & 0xffffu, (int)(cd >> 16));
+                    if (le) emit((u32)lx, le);
+                    emit(dcode & 0xffffu, (int)(dcode >> 16));
+                });
         // the thread that holds the end of the input also writes the end-of-block code (exactly one: s0 < blen, s1 == blen)
         if (s0 < blen && s1 == blen) emit(s_code[256] & 0xffffu, (int)(s_code[256] >> 16));
-        if (have > 0) atomicOr(&s_data[wi], (u32)acc);
-        __syncthreads();
-        const u8* z = reinterpret_cast<const u8*>(s_data);
-        for (u32 i = tid; i < clen; i += BGZF_THREADS) slot[18 + i] = (char)z[i];
+        if (have > 0 && (u32)(wi << 5) < endb) atomicOr(&gw[wi], (u32)acc);         // the last, partial word
+        BZ_T(5);
     }
     if (tid == 0) {
+        // (bytes 16, 17 share a word with the first two bytes of the deflate data: OR-ed in like everything shared)
         const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
         for (int i = 0; i < 16; i++) slot[i] = (char)hdr[i];
         const u32 bsize = clen + 25u;                                               // total block size - 1
-        slot[16] = (char)bsize; slot[17] = (char)(bsize >> 8);
-        char* t = slot + 18 + clen;
-        st32(t, crc_all); st32(t + 4, (u32)blen);
+        atomicOr(reinterpret_cast<u32*>(slot) + 4, bsize & 0xffffu);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the trailer behind the stream's last byte (its bits are in memory: every thread has passed the barrier; the bytes are this
+        // thread's alone -- but they may share a word with the stream's last bits, so they are OR-ed in as well)
+        const u32 at = 18u + clen;
+        const u32 isz = (u32)blen;
+        unsigned long long t8 = (unsigned long long)crc_all | ((unsigned long long)isz << 32);
+        u32* w = reinterpret_cast<u32*>(slot) + (at >> 2);
+        const int sh = (int)(at & 3u) * 8;
+        atomicOr(&w[0], (u32)(t8 << sh));
+        atomicOr(&w[1], (u32)(sh ? t8 >> (32 - sh) : t8 >> 32));
+        if (sh) atomicOr(&w[2], (u32)(t8 >> (64 - sh)));
         slot_len[blockIdx.x] = clen + 26u;
     }
+    BZ_T(6);
 }
 
 // slots -> one contiguous piece: block b goes to out[off[b] ...); destination-aligned dwords, the ragged ends byte-wise

@@ -170,7 +170,7 @@ struct Lane {
     DevBuf fq_text1, fq_text2, fq_idx;                  // bmbs_map_*_fastq: FASTQ text windows and the per-record line index
     // bmbs_map_*_text: newline index built on the device, SAM text written on the device
     DevBuf tx_tilecnt, tx_tileoff, tx_nl[2], tx_rec[2], tx_info, sam_len, sam_off, sam_out, chrom_chars, chrom_off;
-    DevBuf bam_raw, bam_tok, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
+    DevBuf bam_raw, bam_slots, bam_slot_len, bam_off, stats_snap;      // --bam: record stream, deflate scratch, BGZF slots
     DevBuf z_comp, z_off, z_text, z_err, z_nl, z_comp2, z_off2, z_err2;          // bmbs_inflate_bgzf; (…2: mate 2 of bmbs_text_open_bgzf)
     struct OpenText { bool valid = false, pe = false; u64 bytes1 = 0, bytes2 = 0; int64_t n = 0; } open_text;      // between bmbs_text_open_bgzf and bmbs_text_map_open
     u32* h_info = nullptr;                              // page-locked: 8 info words + 4 totals of the text path

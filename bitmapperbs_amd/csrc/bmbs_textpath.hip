@@ -376,13 +376,14 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
         hipLaunchKernelGGL(k_line_write<true>, dim3(nblk(n2, (unsigned)tw.lpb)), dim3(TXW_THREADS), tw.lds, c->stream, in, (long)n2, c->sam_off.as<u64>(), tw.lpb, tw.out_cap, tw.src_cap,
                            c->bam_raw.as<char>());
         prof_end(c);
-        ENS(c, c->bam_tok, nb * (u64)(BGZF_SEG * BGZF_THREADS) * 2); ENS(c, c->bam_slots, nb * (u64)BGZF_SLOT);
+        ENS(c, c->bam_slots, nb * (u64)BGZF_SLOT);
         ENS(c, c->bam_slot_len, nb * 4 + 64); ENS(c, c->bam_off, (nb + 1) * 8 + 64);
-        const size_t lds = BGZF_IN + 512;
+        const size_t lds = (size_t)BGZF_THREADS * BGZF_PSTRIDE * 4;                      // the block's bytes (padded segments)
+        HIPCHK(c, hipMemsetAsync(c->bam_slots.p, 0, nb * (u64)BGZF_SLOT, c->stream));      // (k_bgzf_block ORs the shared words of its stream into the slots)
         static std::once_flag lds_once[16];
         std::call_once(lds_once[c->dev & 15], [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_block), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         prof_begin(c, "k_bgzf_block");
-        hipLaunchKernelGGL(k_bgzf_block, dim3((unsigned)nb), dim3(BGZF_THREADS), lds, c->stream, c->bam_raw.as<char>(), c->totals.as<u64>() + 19, c->bam_tok.as<u16>(),
+        hipLaunchKernelGGL(k_bgzf_block, dim3((unsigned)nb), dim3(BGZF_THREADS), lds, c->stream, c->bam_raw.as<char>(), c->totals.as<u64>() + 19,
                            c->bam_slots.as<char>(), c->bam_slot_len.as<u32>());
         prof_end(c);
         rc = scan_u32(c, c->bam_slot_len.as<u32>(), nb, c->bam_off.as<u64>(), 20);
@@ -668,6 +669,16 @@ extern "C" int bmbs_debug_inflate_prof(uint64_t* out16)
     unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_inf_prof), sizeof z) != hipSuccess) return BMBS_ENODEV;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_inf_prof), z, sizeof z) == hipSuccess ? BMBS_OK : BMBS_ENODEV;
+}
+#endif
+
+#ifdef BGZF_PROFILE
+// profiling build only (tools/bgzf_prof.sh): the phase cycle sums of k_bgzf_block since the last call
+extern "C" int bmbs_debug_bgzf_prof(uint64_t* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bgzf_prof), sizeof z) != hipSuccess) return BMBS_ENODEV;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bgzf_prof), z, sizeof z) == hipSuccess ? BMBS_OK : BMBS_ENODEV;
 }
 #endif
 

@@ -1,0 +1,7 @@
+#!/bin/bash
+# tools/bgzf_prof.sh -- here: builds bitmapperbs_amd/libbmbs_hip_bzprof.so (the text-path translation unit with -DBGZF_PROFILE: phase cycle
+# counters in k_bgzf_block).  On the GPU box: BMBS_LIB=$PWD/bitmapperbs_amd/libbmbs_hip_bzprof.so python3 tools/text_bench.py
+cd "$(dirname "$0")/../bitmapperbs_amd/csrc" || exit 1
+make -s ../libbmbs_hip.so || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -DBGZF_PROFILE -c -o build/bmbs_textpath_bzprof.o bmbs_textpath.hip && \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -o ../libbmbs_hip_bzprof.so build/bmbs_api.o build/bmbs_textpath_bzprof.o build/index_build_gpu.o build/index_io.o build/build_id.o -lpthread

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["BMBS_TEXT_TRACE"] = "1"
 import bench  # noqa: E402
-from bitmapperbs_amd import synth, mapper  # noqa: E402
+from bitmapperbs_amd import synth, mapper, capi  # noqa: E402
 
 
 def fastq_text(seq, qual, L):
@@ -41,10 +41,13 @@ def main():
     t1 = fastq_text(m1["seq"], m1["qual"], L); t2 = fastq_text(m2["seq"], m2["qual"], L)
     m = mapper.Mapper(ix, 0, e_f=0.08)
     first = {}
+    only = os.environ.get("TEXT_BENCH_ONLY")
     for tag, fn in (("pe_sam", lambda: m.map_text(t1, pairs, t2)),
                     ("pe_bam", lambda: m.map_text(t1, pairs, t2, flags=mapper.Mapper.TEXT_BAM)),
                     ("se_sam", lambda: m.map_text(t1, pairs)),
                     ("pe_sam_unmapped", lambda: m.map_text(t1, pairs, t2, flags=mapper.Mapper.TEXT_UNMAPPED))):
+        if only and tag not in only.split(","):
+            continue
         for rep in range(4):
             sys.stderr.write("== %s rep %d\n" % (tag, rep)); sys.stderr.flush()
             t0 = time.time()
@@ -54,9 +57,13 @@ def main():
                 first[tag] = out
             assert out == first[tag], tag
         print("%s: %d bytes, last call %.1f ms" % (tag, len(out), dt * 1e3), flush=True)
-        for name, ms in m.profile():
-            if name.startswith(("k_sam", "k_bam", "k_bgzf", "k_fq", "k_fastq")):
-                print("  %-18s %8.3f ms" % (name, ms), flush=True)
+        if tag == "pe_bam" and hasattr(capi.lib(), "bmbs_debug_bgzf_prof"):       # a -DBGZF_PROFILE build (tools/bgzf_prof.sh)
+            import ctypes as C
+            v = (C.c_uint64 * 8)()
+            capi.lib().bmbs_debug_bgzf_prof(v)
+            tot = float(sum(v)) or 1.0
+            names = ["load + tables", "parse + CRC + counts", "ranks", "trees + header (lane 0)", "token bits + prefix", "emit", "copy out"]
+            print("  k_bgzf_block phases (thread 0's cycles, %d calls): " % 4 + ", ".join("%s %.1f%%" % (n_, 100.0 * x / tot) for n_, x in zip(names, v)), flush=True)
     m.close()
 
 
