@@ -422,6 +422,102 @@ DEVI void huff_codes(const u8* len, int n, u32* code)
     }
 }
 
+// ---- the same two functions by a whole workgroup (round 5): in k_bgzf_block one lane built the literal/length tree while 255 waited, ~9 000
+// dependent LDS accesses = 0.3 ms per block.  Only the two-queue merge is a chain; the rest is data-parallel: depths by pointer jumping
+// over the parent links, the length counts by LDS atomics, a symbol's length from its rank, a symbol's code from the number of symbols
+// of its length in front of it.  Same lengths and codes as huff_lengths / huff_codes (tests: bmbs_debug_huff_lengths with form 1).
+// scratch: w.key is reused once the merge is over (ancestor links and depths of the 2m - 1 nodes, 16 bits each); cnt_s: 20 words
+DEVI void huff_lengths_block(const u32* freq, int n, int maxbits, u8* len, const HuffWork& w, int m, int tid, int nt, u32* cnt_s)
+{
+    for (int i = tid; i < n; i += nt) len[i] = 0;
+    if (m < 2) {                                                                    // (m is the same in every thread)
+        __syncthreads();
+        if (tid == 0) { if (m == 0) { len[0] = 1; len[1] = 1; } else { const int s = w.ord[0]; len[s] = 1; len[s == 0 ? 1 : 0] = 1; } }
+        __syncthreads();
+        return;
+    }
+    for (int i = tid; i < m; i += nt) w.key[i] = freq[w.ord[i]];
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0, b = m, e = m;
+        for (int k = 0; k < m - 1; k++) {
+            int c[2];
+            for (int q = 0; q < 2; q++) {
+                if (a < m && (b >= e || w.key[a] <= w.key[b])) c[q] = a++; else c[q] = b++;
+            }
+            w.key[e] = w.key[c[0]] + w.key[c[1]];
+            w.par[c[0]] = (u16)e; w.par[c[1]] = (u16)e;
+            e++;
+        }
+    }
+    __syncthreads();
+    const int nn = 2 * m - 1, root = nn - 1;
+    u16* anc = reinterpret_cast<u16*>(w.key);                                       // [nn]
+    u16* dp = anc + 2 * DEF_LL;                                                     // [nn] (w.key has 2 * DEF_LL words = 4 * DEF_LL halves)
+    for (int i = tid; i < nn; i += nt) { anc[i] = (u16)(i == root ? root : w.par[i]); dp[i] = (u16)(i == root ? 0 : 1); }
+    __syncthreads();
+    for (int span = 1; span < nn; span <<= 1) {
+        u16 na[3], nd[3];                                                           // nn <= 571 nodes, nt = 256 threads: at most three each
+        int q = 0;
+        for (int i = tid; i < nn; i += nt, q++) { const int a = anc[i]; na[q] = anc[a]; nd[q] = (u16)(dp[i] + dp[a]); }
+        __syncthreads();
+        q = 0;
+        for (int i = tid; i < nn; i += nt, q++) { anc[i] = na[q]; dp[i] = nd[q]; }
+        __syncthreads();
+    }
+    if (tid < 20) cnt_s[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < m; i += nt) { int d = dp[i]; if (d > maxbits) d = maxbits; atomicAdd(&cnt_s[d], 1u); }
+    __syncthreads();
+    if (tid == 0) {
+        // bl_count with the overflow moved up (gen_bitlen): see huff_lengths
+        int cnt[17];
+        for (int i = 0; i <= 16; i++) cnt[i] = i <= maxbits ? (int)cnt_s[i] : 0;
+        long kraft = 0;
+        for (int d = 1; d <= maxbits; d++) kraft += (long)cnt[d] << (maxbits - d);
+        long over = kraft - (1l << maxbits);
+        while (over > 0) {
+            int bits = maxbits - 1;
+            while (cnt[bits] == 0) bits--;
+            cnt[bits]--; cnt[bits + 1] += 2; cnt[maxbits]--;
+            over--;
+        }
+        for (int i = 0; i <= 16; i++) cnt_s[i] = (u32)cnt[i];
+    }
+    __syncthreads();
+    // the rarest symbols get the longest codes: rank i (ascending frequency) falls into the run of its length
+    for (int i = tid; i < m; i += nt) {
+        int acc = 0, bits = maxbits;
+        for (; bits >= 1; bits--) { acc += (int)cnt_s[bits]; if (i < acc) break; }
+        len[w.ord[i]] = (u8)bits;
+    }
+    __syncthreads();
+}
+// canonical codes of n symbols by the workgroup: next_s: 16 words of scratch
+DEVI void huff_codes_block(const u8* len, int n, u32* code, int tid, int nt, u32* next_s)
+{
+    if (tid < 16) next_s[tid] = 0;
+    __syncthreads();
+    for (int s = tid; s < n; s += nt) if (len[s]) atomicAdd(&next_s[len[s]], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        u32 cnt[16]; for (int b = 0; b < 16; b++) cnt[b] = next_s[b];
+        cnt[0] = 0;
+        u32 c = 0;
+        for (int b = 1; b <= 15; b++) { c = (c + cnt[b - 1]) << 1; next_s[b] = c; }
+    }
+    __syncthreads();
+    for (int s = tid; s < n; s += nt) {
+        const int l = len[s];
+        if (!l) { code[s] = 0; continue; }
+        u32 r = 0;
+        for (int t = 0; t < s; t++) r += len[t] == l ? 1u : 0u;                      // symbols of the same length in front of s
+        const u32 v = next_s[l] + r;
+        code[s] = ((u32)l << 16) | (__brev(v) >> (32 - l));
+    }
+    __syncthreads();
+}
+
 struct BitOut { u32* w; u32 pos; };       // LSB-first bits OR-ed into zeroed 32-bit words (one writer)
 DEVI void put_bits(BitOut& o, u32 v, int n)
 {
@@ -568,15 +664,24 @@ k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, ch
     }
     __syncthreads();
     BZ_T(2);
-    // ---- trees and header: lane 0 (the other lanes of the block wait)
-    if (tid == 0) {
+    // ---- trees: the literal/length tree by the whole workgroup, the distance tree (one used symbol at most: every match is a run at
+    // distance 1) by one lane
+    __shared__ u32 s_cnt[20];
+    {
         HuffWork hw; hw.key = s_key; hw.par = s_par; hw.ord = s_ord; hw.dep = s_dep;
-        huff_lengths(s_freq, DEF_LL, 15, s_len, hw, (int)s_misc[6]);
-        hw.ord = s_ord_d;
-        huff_lengths(s_freq + DEF_DOFF, DEF_D, 15, s_len + DEF_DOFF, hw, (int)s_misc[7]);
-        hw.ord = s_ord_c;
-        huff_codes(s_len, DEF_LL, s_code);
-        huff_codes(s_len + DEF_DOFF, DEF_D, s_code + DEF_DOFF);
+        huff_lengths_block(s_freq, DEF_LL, 15, s_len, hw, (int)s_misc[6], tid, BGZF_THREADS, s_cnt);
+        if (tid == 0) {
+            hw.ord = s_ord_d;
+            huff_lengths(s_freq + DEF_DOFF, DEF_D, 15, s_len + DEF_DOFF, hw, (int)s_misc[7]);
+            huff_codes(s_len + DEF_DOFF, DEF_D, s_code + DEF_DOFF);
+        }
+        huff_codes_block(s_len, DEF_LL, s_code, tid, BGZF_THREADS, s_cnt);
+    }
+    // ---- the header of the dynamic block: the run-length coding of the code lengths and its small tree by one lane (a chain of ~300
+    // steps), the header's bits by everybody
+    __shared__ u32 s_hn[4];                           // 0 nr, 1 hlit, 2 hdist, 3 hclen
+    if (tid == 0) {
+        HuffWork hw; hw.key = s_key; hw.par = s_par; hw.ord = s_ord_c; hw.dep = s_dep;
         int hlit = DEF_LL; while (hlit > 257 && !s_len[hlit - 1]) hlit--;
         int hdist = DEF_D; while (hdist > 1 && !s_len[DEF_DOFF + hdist - 1]) hdist--;
         // the hlit + hdist lengths as one sequence, run-length coded with 16 / 17 / 18 (send_tree)
@@ -603,22 +708,61 @@ k_bgzf_block(const char* __restrict__ raw, const u64* __restrict__ total_ptr, ch
         huff_lengths(s_cl_freq, 19, 7, s_cl_len, hw, -1);
         huff_codes(s_cl_len, 19, s_cl_code);
         int hclen = 19; while (hclen > 4 && !s_cl_len[c_cl_order[hclen - 1]]) hclen--;
-        for (int i = 0; i < 176; i++) s_hdr[i] = 0;
-        BitOut bo; bo.w = s_hdr; bo.pos = 0;
-        put_bits(bo, 1, 1); put_bits(bo, 2, 2);                                   // BFINAL, BTYPE = dynamic
-        put_bits(bo, (u32)(hlit - 257), 5); put_bits(bo, (u32)(hdist - 1), 5); put_bits(bo, (u32)(hclen - 4), 4);
-        for (int i = 0; i < hclen; i++) put_bits(bo, s_cl_len[c_cl_order[i]], 3);
-        for (int i = 0; i < nr; i++) {
-            const int s = s_rle_sym[i];
-            put_bits(bo, s_cl_code[s] & 0xffffu, (int)(s_cl_code[s] >> 16));
-            if (s == 16) put_bits(bo, s_rle_x[i], 2); else if (s == 17) put_bits(bo, s_rle_x[i], 3); else if (s == 18) put_bits(bo, s_rle_x[i], 7);
+        s_hn[0] = (u32)nr; s_hn[1] = (u32)hlit; s_hn[2] = (u32)hdist; s_hn[3] = (u32)hclen;
+    }
+    for (int i = tid; i < 176; i += BGZF_THREADS) s_hdr[i] = 0;
+    __syncthreads();
+    {
+        // the header's bits: 17 bits of counts + 3 bits per code-length-code length, then the nr items, each at the bit its predecessors
+        // end at (a prefix sum of the items' bit lengths over the workgroup: at most two items per thread)
+        const int nr = (int)s_hn[0], hclen = (int)s_hn[3];
+        const u32 fixed = 17u + 3u * (u32)hclen;
+        auto item_bits = [&](int i) -> u32 { const int sy = s_rle_sym[i]; return (s_cl_code[sy] >> 16) + (sy == 16 ? 2u : sy == 17 ? 3u : sy == 18 ? 7u : 0u); };
+        const int i0 = 2 * tid, i1 = i0 + 1;
+        const u32 b0 = i0 < nr ? item_bits(i0) : 0u, b1 = i1 < nr ? item_bits(i1) : 0u;
+        u32 incl = b0 + b1;
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        u32 wb = 0, all = 0;
+        for (int i = 0; i < BGZF_THREADS / 64; i++) { if (i < (tid >> 6)) wb += s_wave[i]; all += s_wave[i]; }
+        auto put = [&](u32 pos, u32 v, int nbits) {                                 // nbits <= 14
+            if (!nbits) return;
+            const u32 wi = pos >> 5, sh = pos & 31;
+            atomicOr(&s_hdr[wi], v << sh);
+            if (sh + (u32)nbits > 32) atomicOr(&s_hdr[wi + 1], v >> (32 - sh));
+        };
+        if (tid == 0) {
+            put(0, 1, 1); put(1, 2, 2);                                             // BFINAL, BTYPE = dynamic
+            put(3, s_hn[1] - 257u, 5); put(8, s_hn[2] - 1u, 5); put(13, (u32)hclen - 4u, 4);
         }
-        u32 body = s_misc[0];
-        for (int s = 0; s < DEF_LL; s++) body += s_freq[s] * s_len[s];
-        for (int s = 0; s < DEF_D; s++) body += s_freq[DEF_DOFF + s] * s_len[DEF_DOFF + s];
-        s_misc[2] = bo.pos; s_misc[4] = body;
-        const u32 dyn_bytes = (bo.pos + body + 7) >> 3;
-        s_misc[3] = dyn_bytes < (u32)blen + 5u ? 1u : 0u;
+        if (tid < hclen) put(17u + 3u * (u32)tid, s_cl_len[c_cl_order[tid]], 3);
+        u32 pos = fixed + wb + (incl - b0 - b1);
+        for (int q = 0; q < 2; q++) {
+            const int i = q ? i1 : i0;
+            if (i >= nr) break;
+            const int sy = s_rle_sym[i];
+            const u32 cl = s_cl_code[sy] >> 16;
+            put(pos, s_cl_code[sy] & 0xffffu, (int)cl);
+            const int xb = sy == 16 ? 2 : sy == 17 ? 3 : sy == 18 ? 7 : 0;
+            if (xb) put(pos + cl, s_rle_x[i], xb);
+            pos += cl + (u32)xb;
+        }
+        // the body's bits: extra bits of the run lengths + every symbol's count times its code length
+        u32 body = 0;
+        for (int sy = tid; sy < DEF_SYMS; sy += BGZF_THREADS) body += s_freq[sy] * (u32)s_len[sy];
+        for (int o = 32; o > 0; o >>= 1) body += __shfl_down(body, o, 64);
+        __syncthreads();                                                            // (s_wave was read by everybody)
+        if ((tid & 63) == 0) s_wave[tid >> 6] = body;
+        __syncthreads();
+        if (tid == 0) {
+            u32 bsum = s_misc[0];
+            for (int i = 0; i < BGZF_THREADS / 64; i++) bsum += s_wave[i];
+            const u32 hb = fixed + all;
+            s_misc[2] = hb; s_misc[4] = bsum;
+            const u32 dyn_bytes = (hb + bsum + 7) >> 3;
+            s_misc[3] = dyn_bytes < (u32)blen + 5u ? 1u : 0u;
+        }
     }
     __syncthreads();
     BZ_T(3);
@@ -735,14 +879,37 @@ k_bgzf_gather(const char* __restrict__ slots, const u32* __restrict__ slot_len, 
 }
 
 // diagnostic (bmbs_debug_huff_lengths): the code lengths huff_lengths gives a frequency table, as k_bgzf_block calls it (m < 0: sorted here)
-__global__ void k_debug_huff(const u32* __restrict__ freq, int n, int maxbits, u8* __restrict__ len_out)
+// -- and, for alphabets of up to DEF_LL symbols, the lengths AND codes of the workgroup forms (huff_lengths_block / huff_codes_block on
+// the ranks k_bgzf_block computes): *differ = 1 when they are not the serial forms' lengths and codes
+__global__ void __launch_bounds__(256)
+k_debug_huff(const u32* __restrict__ freq, int n, int maxbits, u8* __restrict__ len_out, u32* __restrict__ differ)
 {
     __shared__ u32 s_f[320]; __shared__ u32 s_key[640]; __shared__ u16 s_par[640]; __shared__ u16 s_ord[320]; __shared__ u8 s_dep[640]; __shared__ u8 s_len[320];
-    if (threadIdx.x == 0) {
+    __shared__ u8 s_len2[320]; __shared__ u32 s_code[320]; __shared__ u32 s_code2[320]; __shared__ u32 s_cnt[20]; __shared__ u32 s_m;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
         for (int i = 0; i < n; i++) s_f[i] = freq[i];
         HuffWork hw; hw.key = s_key; hw.par = s_par; hw.ord = s_ord; hw.dep = s_dep;
         huff_lengths(s_f, n, maxbits, s_len, hw, -1);
+        huff_codes(s_len, n, s_code);
         for (int i = 0; i < n; i++) len_out[i] = s_len[i];
+        s_m = 0;
     }
+    __syncthreads();
+    if (n > DEF_LL) return;
+    for (int sy = tid; sy < n; sy += 256) {
+        const u32 f = s_f[sy];
+        if (f) {
+            int r = 0;
+            for (int t = 0; t < n; t++) { const u32 g = s_f[t]; r += (g && (g < f || (g == f && t < sy))) ? 1 : 0; }
+            s_ord[r] = (u16)sy;
+            atomicAdd(&s_m, 1u);
+        }
+    }
+    __syncthreads();
+    HuffWork hw; hw.key = s_key; hw.par = s_par; hw.ord = s_ord; hw.dep = s_dep;
+    huff_lengths_block(s_f, n, maxbits, s_len2, hw, (int)s_m, tid, 256, s_cnt);
+    huff_codes_block(s_len2, n, s_code2, tid, 256, s_cnt);
+    for (int i = tid; i < n; i += 256) if (s_len2[i] != s_len[i] || s_code2[i] != s_code[i]) atomicOr(differ, 1u);
 }
 #endif

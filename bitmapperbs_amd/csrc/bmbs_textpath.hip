@@ -690,12 +690,14 @@ extern "C" int bmbs_debug_huff_lengths(bmbs_ctx* X, const uint32_t* freq, int32_
     if (!freq || !len_out || n < 2 || n > 320 || maxbits < 2 || maxbits > 15) { c->err = "huff lengths: bad argument"; return fin(X, c, BMBS_EINVAL); }
     if (hipSetDevice(c->dev) != hipSuccess) return BMBS_ENODEV;
     u32* df = nullptr; u8* dl = nullptr;
-    if (hipMalloc((void**)&df, 320 * 4) != hipSuccess || hipMalloc((void**)&dl, 320) != hipSuccess) { if (df) (void)hipFree(df); return BMBS_ENOMEM; }
+    if (hipMalloc((void**)&df, 321 * 4) != hipSuccess || hipMalloc((void**)&dl, 320) != hipSuccess) { if (df) (void)hipFree(df); return BMBS_ENOMEM; }
     int rc = BMBS_OK;
-    if (hipMemcpy(df, freq, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) rc = BMBS_ENODEV;
-    if (!rc) { hipLaunchKernelGGL(k_debug_huff, dim3(1), dim3(64), 0, c->stream, df, n, maxbits, dl); if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BMBS_ENODEV; }
-    if (!rc && hipMemcpy(len_out, dl, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = BMBS_ENODEV;
+    u32 differ = 0;
+    if (hipMemcpy(df, freq, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(df + 320, 0, 4) != hipSuccess) rc = BMBS_ENODEV;
+    if (!rc) { hipLaunchKernelGGL(k_debug_huff, dim3(1), dim3(256), 0, c->stream, df, n, maxbits, dl, df + 320); if (hipStreamSynchronize(c->stream) != hipSuccess) rc = BMBS_ENODEV; }
+    if (!rc && (hipMemcpy(len_out, dl, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&differ, df + 320, 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = BMBS_ENODEV;
     (void)hipFree(df); (void)hipFree(dl);
+    if (!rc && differ) { c->err = "huff lengths: the workgroup forms (huff_lengths_block / huff_codes_block) differ from the serial ones"; return fin(X, c, BMBS_ESTATE); }
     return rc;
 }
 
