@@ -1470,7 +1470,7 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
     share_needs(X);
     struct Open { bool on = false; int64_t off = 0, m = 0; };
     std::vector<Open> open((size_t)nl);
-    int64_t extent = 0;
+    std::atomic<int64_t> extent(0);
     auto finish = [&](int li) -> int {            // the chunk in flight on lane li: counts, then exactly the CIGAR operations it produced
         Open& o = open[(size_t)li];
         if (!o.on) return BMBS_OK;
@@ -1488,19 +1488,15 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
         if (base + used > (u64)cigar_cap) { c->err = "host cigar pool too small"; return BMBS_ENOMEM; }
         if (used) {
             HIPCHK(c, hipMemcpyAsync(cigar_pool + base, c->cig_pool.p, used * 4, hipMemcpyDeviceToHost, dsn));
-            extent = std::max<int64_t>(extent, (int64_t)(base + used));
+            int64_t seen = extent.load();
+            while ((int64_t)(base + used) > seen && !extent.compare_exchange_weak(seen, (int64_t)(base + used))) {}
         }
         HIPCHK(c, hipStreamSynchronize(dsn));
         return BMBS_OK;
     };
-    int li = 0, used_lanes = 0, rc = BMBS_OK;
-    for (int64_t off = 0; off < n && !rc; off += ch) {
-        const int64_t m = std::min(ch, n - off);
-        const int lane_i = ch == n ? 0 : li;
+    // upload, kernels and the records' download of chunk [off, off + m) on lane lane_i (its previous chunk has been finished)
+    auto issue = [&](int lane_i, int64_t off, int64_t m) -> int {
         Lane* c = X->lanes[(size_t)lane_i];
-        rc = finish(lane_i);
-        if (rc) { X->err = c->err; break; }
-        rc = [&]() -> int {
             HIPCHK(c, hipSetDevice(c->dev));
             const u64 um = (u64)m;
             ENS(c, c->out_res, um * rpu * 32);
@@ -1540,19 +1536,38 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             if (cs) { HIPCHK(c, hipEventRecord(c->ev_k, c->stream)); HIPCHK(c, hipStreamWaitEvent(dsn, c->ev_k, 0)); }
             HIPCHK(c, hipMemcpyAsync(results + off * rpu, c->out_res.p, um * rpu * 32, hipMemcpyDeviceToHost, dsn));
             return BMBS_OK;
-        }();
-        if (rc) { X->err = c->err; break; }
-        open[(size_t)lane_i].on = true; open[(size_t)lane_i].off = off; open[(size_t)lane_i].m = m;
-        used_lanes = std::max(used_lanes, lane_i + 1);
-        li = (li + 1) % nl;
-    }
-    for (int i = 0; i < nl; i++) {
-        const int r2 = finish(i);
-        if (r2 && !rc) { rc = r2; X->err = X->lanes[(size_t)i]->err; }
+    };
+    // One host thread per lane: a chunk is ~110 kernel launches and a handful of waits, and with all of them issued by one thread the
+    // call was bound by that thread on boxes with slower cores (2 M pairs through bmbs_map_pe_packed: 137 M reads/s where the link
+    // would give 200).  Chunk k goes to lane k % lanes whoever issues it: the results do not depend on the threads.
+    const int64_t n_chunks = (n + ch - 1) / ch;
+    const int used_lanes = ch == n ? 1 : (int)std::min<int64_t>(nl, n_chunks);
+    int rc = BMBS_OK;
+    std::mutex err_mu;
+    std::atomic<int> stop(0);
+    auto worker = [&](int lane_i) {
+        Lane* c = X->lanes[(size_t)lane_i];
+        (void)hipSetDevice(c->dev);
+        int r = BMBS_OK;
+        for (int64_t k = lane_i; k < n_chunks && !r && !stop.load(); k += used_lanes) {
+            const int64_t off = k * ch, m = std::min(ch, n - off);
+            r = finish(lane_i);
+            if (!r) r = issue(lane_i, off, m);
+            if (!r) { open[(size_t)lane_i].on = true; open[(size_t)lane_i].off = off; open[(size_t)lane_i].m = m; }
+        }
+        if (!r) r = finish(lane_i);
+        if (r) { stop.store(1); std::lock_guard<std::mutex> l(err_mu); if (!rc) { rc = r; X->err = c->err; } }
+    };
+    if (used_lanes == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < used_lanes; t++) th.emplace_back(worker, t);
+        worker(0);
+        for (auto& t : th) t.join();
     }
     if (rc) { for (Lane* c : X->lanes) { (void)hipStreamSynchronize(c->stream); if (c->down_stream) (void)hipStreamSynchronize(c->down_stream); c->inflight.clear(); } return rc; }
-    X->used_lanes = used_lanes ? used_lanes : 1;
-    if (n_cigar_used) *n_cigar_used = extent;
+    X->used_lanes = used_lanes;
+    if (n_cigar_used) *n_cigar_used = extent.load();
     return BMBS_OK;
 }
 

@@ -6,6 +6,7 @@
 #include "../../include/bmbs.h"
 #include "bmbs_dev.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
