@@ -363,12 +363,13 @@ bool use_packed_rows(const Lane* c) { return !c->kn.rows_ascii; }
 
 // trigram rank table: three backward extensions per gather pair (bmbs_dev.h: occ3).  4.5 bytes per row; built from the full SA and
 // the 2-bit text on a stream of its own, checked against three single steps on a million rows before it is used.
-void occ3_build(Occ3Shared& o)
+// margin: HBM that has to stay free behind the table (the work buffers of calls still to come)
+void occ3_build(Occ3Shared& o, u64 margin)
 {
     const u64 rows = o.rows, nb = rows / 96 + 2, need = 27 * nb * 16;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    if (free_b <= need + (40ull << 30)) return;
+    if (free_b <= need + margin) return;
     const u64 n_chunks = (nb + OCC3_CHUNK - 1) / OCC3_CHUNK;
     void *t3 = nullptr, *c3 = nullptr, *sums = nullptr;
     hipStream_t st = nullptr;
@@ -397,12 +398,14 @@ void occ3_build(Occ3Shared& o)
 }
 // called where a lane decides which seeding kernels to launch, and when a settled call has told it how long its chains are: builds the
 // table once for all users of the index when this lane would use it, and adopts it when someone has built it
-void occ3_want(Lane* c)
+void occ3_want(Lane* c, bool behind_a_call = false)
 {
     if (c->ix.occ3 || !c->o3 || c->kn.kgram < 1 || !use_packed_rows(c)) return;
     const bool wants = c->kn.kgram >= 2 || c->lr_chain >= 3.0;
     std::lock_guard<std::mutex> l(c->o3->mu);
-    if (!c->o3->occ3 && wants && !c->o3->tried) { c->o3->tried = true; (void)hipSetDevice(c->dev); occ3_build(*c->o3); }
+    // (behind a settled call the lane's work buffers exist already -- the table needs little room beside itself; in front of a context's
+    // first call, BMBS_KGRAM=2, room for them is left)
+    if (!c->o3->occ3 && wants && !c->o3->tried) { c->o3->tried = true; (void)hipSetDevice(c->dev); occ3_build(*c->o3, behind_a_call ? (8ull << 30) : (40ull << 30)); }
     if (c->o3->occ3) { c->ix.occ3 = reinterpret_cast<const uint4*>(c->o3->occ3); c->ix.c3 = reinterpret_cast<const u64*>(c->o3->c3); c->ix.nb3 = c->o3->nb3; }
 }
 
@@ -1337,7 +1340,7 @@ int lane_settle(Lane* c)
                     c->lr_sw = std::max(c->lr_sw, (double)t[2] / nr);
                     c->lr_rcand = std::max(c->lr_rcand, (double)t[8] / nr);
                     c->lr_long = ((double)t[9] + (double)t[11]) / nr;             // reads whose candidate lists went to the mid / long kernels
-                    if (t[14]) { c->lr_chain = (double)t[15] / (double)t[14]; occ3_want(c); }      // (the table is built here, behind the call that showed the chains)
+                    if (t[14]) { c->lr_chain = (double)t[15] / (double)t[14]; occ3_want(c, true); }      // (the table is built here, behind the call that showed the chains)
                 }
                 c->last_total_cand = t[0]; c->last_n_jobs = t[1];
                 prof_collect(c, P.slot);

@@ -84,6 +84,27 @@ def run_trial(t, env):
         if not bad and not (m.stats() == ost).all():
             bad = [("stats", m.stats().tolist(), np.asarray(ost).tolist())]
         mapped = int((recs["status"] == 1).sum())
+        if not bad:
+            # the same batch through the packed entry points (2 bits per base + an N plane), whenever its letters can be packed
+            try:
+                if t["mode"] == "se":
+                    a = (seq, qual, lens) if t["mixed"] else (r["seq"], r["qual"], None)
+                    res2, pool2 = m.map_se_packed(mapper.Mapper.pack_rows(a[0], L, a[2]), a[1], L, a[2])
+                else:
+                    a = (s1, q1, s2, q2, l1, l2) if t["mixed"] else (m1["seq"], m1["qual"], m2["seq"], m2["qual"], None, None)
+                    res2, pool2 = m.map_pe_packed(mapper.Mapper.pack_rows(a[0], L, a[4]), mapper.Mapper.pack_rows(a[2], L, a[5]), a[1], a[3], L, a[4], a[5])
+                for f in ("status", "chrom", "pos", "flag", "mapq", "nm", "score", "n_cigar", "tlen", "path"):
+                    if not (res[f] == res2[f]).all():
+                        bad = [("packed entry differs in", f, int(np.nonzero(res[f] != res2[f])[0][0]))]
+                        break
+                if not bad:
+                    for i in np.nonzero(res["n_cigar"] > 0)[0][:20000]:
+                        x, y = res[i], res2[i]
+                        if not (pool[int(x["cigar_off"]):int(x["cigar_off"]) + int(x["n_cigar"])] == pool2[int(y["cigar_off"]):int(y["cigar_off"]) + int(y["n_cigar"])]).all():
+                            bad = [("packed entry differs in the CIGAR of", int(i))]
+                            break
+            except ValueError:
+                pass                                   # letters other than A C G T N: the packed format cannot hold them
     finally:
         m.close()
     return bad, mapped
