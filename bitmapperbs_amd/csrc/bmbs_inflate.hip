@@ -188,8 +188,12 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u8* out, u32 isiz
     __shared__ u8 s_lens[320];
     __shared__ u16 s_sorted_l[288]; __shared__ u16 s_sorted_d[32]; __shared__ u16 s_sorted_c[20];
     __shared__ InfCode s_cl, s_cd, s_cc;
-    __shared__ u32 s_ref32[64];                           // the window being put together: where each of its 256 symbols comes from ...
-    __shared__ S s_val[256 + 16];                         // ... and the symbols that are known (literals, text from before the window)
+    __shared__ u32 s_ref32[64];                           // the window being put together: where each of its 256 bytes comes from ...
+    __shared__ u32 s_val32[64 + 4];                       // ... and the symbols that are known (literals, text from before the window)
+    S* s_val = reinterpret_cast<S*>(s_val32);
+    __shared__ u32 s_tid32[64];                           // per window byte: the id of the token that starts there (0: none)
+    __shared__ u32 s_rec[128];                            // per token id - 1: its record (see the window assembly)
+    u8* s_tid = reinterpret_cast<u8*>(s_tid32);
     u8* s_ref = reinterpret_cast<u8*>(s_ref32);
     u32 status = 0;                                       // 0 ok so far
 #ifdef INF_PROFILE
@@ -375,59 +379,70 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u8* out, u32 isiz
                 // jumping, a few LDS rounds while the reads from memory are on their way) gives every byte, however the matches lean on
                 // each other -- bisulfite reads are three-letter text, zlib's matches there reach 20..40 bytes back -- and the
                 // window is stored with one aligned dword per lane.
+                // ---- (round 5) every lane puts together the four bytes of ITS dword of the window.  A token leaves a 32-bit record under its
+                // id (= its bit offset in the step + 1: ids rise with the tokens' places in the text) and its id at the window byte it starts
+                // at; a prefix maximum over the window's bytes tells every byte which token it belongs to.  A literal's byte is in the
+                // record; a match's byte is a reference to an earlier byte of the window (s_ref), or text from before the window, read from
+                // memory a byte at a time (the few lanes that need it; the others do not wait).  The round-4 form walked every token's
+                // bytes in a loop of its own lane (up to 16 rounds per window, two token sets) and copied long matches with the whole wave,
+                // one after the other: ~800 of a step's 1 140 instructions.
                 const bool mineA = (mA >> lane) & 1ull, mineB = (mB >> lane) & 1ull;
                 const u32 kindA = (A.e >> 5) & 7u, kindB = (B.e >> 5) & 7u;
-                const bool litA = mineA && kindA == IK_LIT, litB = mineB && kindB == IK_LIT;
                 const bool matA = mineA && kindA == IK_BASE, matB = mineB && kindB == IK_BASE;
                 if (__ballot((matA && A.mdist > outA) || (matB && B.mdist > outB))) { status = 6; break; }
                 const u32 idxA = outA - n_out + lo, idxB = outB - n_out + lo;               // window index of the token's first byte
-                // bytes of a match that come from before the window: its first ext bytes
-                const int srcA = (int)outA - (int)A.mdist, srcB = (int)outB - (int)B.mdist;   // (negative in a span: before its start, a marker)
-                const u32 extA = matA && srcA < (int)n_out ? min(A.mlen, (u32)((int)n_out - srcA)) : 0u;
-                const u32 extB = matB && srcB < (int)n_out ? min(B.mlen, (u32)((int)n_out - srcB)) : 0u;
-                const bool shortA = matA && A.mlen <= 16, shortB = matB && B.mlen <= 16;   // by their own lanes; longer ones by the wave
-                if (__ballot((extA && srcA + (int)extA > (int)fenced) || (extB && srcB + (int)extB > (int)fenced))) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
-                // (unaligned 16-byte loads -- a vector memory instruction costs the CU's address unit a cycle per lane whatever its width --:
-                // the bytes behind a match's source come along and are dropped, the buffers have the slack)
-                u64 ra[2], rb[2];
-                constexpr u32 PER = 8 / sizeof(S);                                          // symbols per 8-byte load
-#pragma unroll
-                for (u32 k = 0; k < 16 / PER; k++) { ra[k] = 0; rb[k] = 0; }
-                if (extA && shortA && srcA >= 0) {
-                    const S* sp = out + srcA;
-#pragma unroll
-                    for (u32 k = 0; k < 16 / PER; k += 2) if (extA > k * PER) __builtin_memcpy(&ra[k], sp + k * PER, 16);
-                }
-                if (extB && shortB && srcB >= 0) {
-                    const S* sp = out + srcB;
-#pragma unroll
-                    for (u32 k = 0; k < 16 / PER; k += 2) if (extB > k * PER) __builtin_memcpy(&rb[k], sp + k * PER, 16);
-                }
-                // (one wave, and a wave's LDS operations complete in the order they were issued: no s_barrier between the steps below)
-                s_ref32[lane] = (u32)lane * 0x04040404u + 0x03020100u;                      // every byte its own source
+                const u32 hi = run - n_out + lo;                                            // window symbols [lo, hi) are text
+                s_tid32[lane] = 0;
                 __builtin_amdgcn_wave_barrier();
-                if (litA) { s_val[idxA] = (S)(u8)(A.e >> 16); if (((A.e >> 8) & 31u) == 2) s_val[idxA + 1] = (S)(u8)(A.e >> 24); }
-                if (litB) { s_val[idxB] = (S)(u8)(B.e >> 16); if (((B.e >> 8) & 31u) == 2) s_val[idxB + 1] = (S)(u8)(B.e >> 24); }
-                if (shortA) for (u32 i = extA; i < A.mlen; i++) s_ref[idxA + i] = (u8)(idxA + i - A.mdist);
-                if (shortB) for (u32 i = extB; i < B.mlen; i++) s_ref[idxB + i] = (u8)(idxB + i - B.mdist);
-                // the long ones (a quality string repeating its first byte, a name): all lanes on one match
-                for (int half = 0; half < 2; half++) {
-                    unsigned long long lm = __ballot(half ? matB && !shortB : matA && !shortA);
-                    while (lm) {
-                        const int L = __builtin_ctzll(lm);
-                        lm &= lm - 1;
-                        const u32 ia = (u32)__builtin_amdgcn_readlane((int)idxA, L), ib = (u32)__builtin_amdgcn_readlane((int)idxB, L);
-                        const u32 la = (u32)__builtin_amdgcn_readlane((int)A.mlen, L), lb = (u32)__builtin_amdgcn_readlane((int)B.mlen, L);
-                        const u32 da = (u32)__builtin_amdgcn_readlane((int)A.mdist, L), db = (u32)__builtin_amdgcn_readlane((int)B.mdist, L);
-                        const u32 xa = (u32)__builtin_amdgcn_readlane((int)extA, L), xb = (u32)__builtin_amdgcn_readlane((int)extB, L);
-                        const u32 ix = half ? ib : ia, ml = half ? lb : la, md = half ? db : da, ex = half ? xb : xa;
-                        for (u32 i = lane; i < ml; i += 64) {
-                            if (i < ex) { const int q = (int)(n_out - lo + ix + i) - (int)md; s_val[ix + i] = out[q]; }
-                            else s_ref[ix + i] = (u8)(ix + i - md);
-                        }
-                    }
+                // record: bit 31 match; bits 0..7 window index of the first byte; bits 8..23 the distance, or the (one or two) literal bytes
+                if (mineA) { s_rec[lane] = (matA ? 0x80000000u | (A.mdist << 8) : ((A.e >> 16) & 0xffffu) << 8) | idxA; s_tid[idxA] = (u8)(lane + 1); }
+                if (mineB) { s_rec[64 + lane] = (matB ? 0x80000000u | (B.mdist << 8) : ((B.e >> 16) & 0xffffu) << 8) | idxB; s_tid[idxB] = (u8)(65 + lane); }
+                __builtin_amdgcn_wave_barrier();
+                u32 idk[4];
+                {
+                    const u32 t4 = s_tid32[lane];
+                    idk[0] = t4 & 0xffu; idk[1] = max(idk[0], (t4 >> 8) & 0xffu); idk[2] = max(idk[1], (t4 >> 16) & 0xffu); idk[3] = max(idk[2], t4 >> 24);
+                    u32 inc = idk[3];
+                    for (int o = 1; o < 64; o <<= 1) { const u32 v = (u32)__shfl_up((int)inc, o, 64); if (lane >= o) inc = max(inc, v); }
+                    u32 pre = (u32)__shfl_up((int)inc, 1, 64);
+                    if (lane == 0) pre = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) idk[k] = max(idk[k], pre);
                 }
-                const bool inside = __ballot((matA && extA < A.mlen) || (matB && extB < B.mlen)) != 0;
+                // (selects, not branches: every per-lane `if` costs the wave three scalar instructions of exec-mask bookkeeping, and the
+                // scalar unit is what this kernel is bound by once two windows share the chip)
+                u32 refs = 0, vals = 0, extm = 0, extq[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 wi = 4u * (u32)lane + (u32)k;
+                    const bool in = wi >= lo && wi < hi;
+                    const u32 rec = s_rec[(idk[k] - 1u) & 127u];
+                    const u32 o = wi - (rec & 0xffu);
+                    const bool mat = (rec >> 31) != 0;
+                    const u32 d = (rec >> 8) & 0xffffu;
+                    const bool inwin = wi >= lo + d;                                         // the source is an earlier byte of this window
+                    const u32 ref = in && mat && inwin ? wi - d : wi;
+                    const u32 val = in && !mat ? (rec >> (8 + 8 * (o & 1u))) & 0xffu : 0u;
+                    extm |= (in && mat && !inwin ? 1u : 0u) << k;                            // ... or text from before it
+                    extq[k] = n_out - lo + wi - d;
+                    refs |= ref << (8 * k); vals |= val << (8 * k);
+                }
+                // bytes stored since the last fence are not visible to the other lanes yet: a fence when a source reaches into them
+                {
+                    u32 top = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) top = max(top, (extm >> k) & 1u ? extq[k] + 1 : 0u);
+                    if (__ballot(top > fenced)) { __threadfence_block(); fenced = n_out; INF_N(13, 1); }
+                }
+                u32 ev[4] = {0, 0, 0, 0};
+                if (extm) {
+                    // (a byte that needs nothing reads the lane's first needed address again: one branch for the four loads)
+                    const u32 q0 = extq[__builtin_ctz(extm)];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ev[k] = out[(extm >> k) & 1u ? extq[k] : q0];
+                }
+                s_ref32[lane] = refs;
+                const bool inside = __ballot(refs != (u32)lane * 0x04040404u + 0x03020100u) != 0;
                 __builtin_amdgcn_wave_barrier();
                 if (inside) {
                     for (int it = 0; it < 9; it++) {
@@ -440,25 +455,21 @@ DEVI void inf_wave(const u8* z, const u8* zend, u32 start_bit, u8* out, u32 isiz
                     }
                 }
                 INF_T(4);
-                // the text from before the window, as it arrives
-                if (shortA) for (u32 i = 0; i < extA; i++) s_val[idxA + i] = (S)((i < 8 ? ra[0] : ra[1]) >> (8 * (i & 7u)));
-                if (shortB) for (u32 i = 0; i < extB; i++) s_val[idxB + i] = (S)((i < 8 ? rb[0] : rb[1]) >> (8 * (i & 7u)));
+                // the literals, and the text from before the window as it arrives
+#pragma unroll
+                for (int k = 0; k < 4; k++) vals |= ((extm >> k) & 1u ? ev[k] & 0xffu : 0u) << (8 * k);
+                s_val32[lane] = vals;
                 __builtin_amdgcn_wave_barrier();
                 const u32 r4 = s_ref32[lane];
-                constexpr u32 SB = 8 * sizeof(S);                                           // bits per symbol
-                const u64 w = (u64)s_val[r4 & 255u] | (u64)s_val[(r4 >> 8) & 255u] << SB | (u64)s_val[(r4 >> 16) & 255u] << (2 * SB) | (u64)s_val[r4 >> 24] << (3 * SB);
-                const u32 hi = run - n_out + lo;                                            // window symbols [lo, hi) are text
+                const u32 w = (u32)s_val[r4 & 255u] | (u32)s_val[(r4 >> 8) & 255u] << 8 | (u32)s_val[(r4 >> 16) & 255u] << 16 | (u32)s_val[r4 >> 24] << 24;
                 S* wp = out + n_out - lo + 4 * (u32)lane;
                 const u32 r0 = 4 * (u32)lane;
-                if (r0 >= lo && r0 + 4 <= hi) { *reinterpret_cast<u32*>(wp) = (u32)w; }
+                if (r0 >= lo && r0 + 4 <= hi) { *reinterpret_cast<u32*>(wp) = w; }
                 else {
 #pragma unroll
-                    for (u32 k = 0; k < 4; k++) if (r0 + k >= lo && r0 + k < hi) wp[k] = (S)(w >> (SB * k));
+                    for (u32 k = 0; k < 4; k++) if (r0 + k >= lo && r0 + k < hi) wp[k] = (S)(w >> (8 * k));
                 }
-                {
-                    const u32 wl_ = (u32)__builtin_amdgcn_readlane((int)(u32)w, (int)((hi - 1) >> 2)), wh_ = (u32)__builtin_amdgcn_readlane((int)(u32)(w >> 32), (int)((hi - 1) >> 2));
-                    last_byte = (S)((((u64)wh_ << 32) | wl_) >> (SB * ((hi - 1) & 3u)));
-                }
+                last_byte = (S)((u32)__builtin_amdgcn_readlane((int)w, (int)((hi - 1) >> 2)) >> (8 * ((hi - 1) & 3u)));
                 __builtin_amdgcn_wave_barrier();
                 INF_T(5);
             }
