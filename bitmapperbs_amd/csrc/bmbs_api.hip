@@ -680,7 +680,7 @@ void lane_destroy(Lane* c)
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wavelog), &d, sizeof(d));
         release(c->wavelog_buf); release(c->wavelog_count);
     }
-    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
+    DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->gen2p, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
                      &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
@@ -801,13 +801,14 @@ static int lane_index_attach(Lane* c, const bmbs_index_view* v)
     std::vector<u64> cs(v->n_chrom + 1, 0);
     for (int i = 0; i < v->n_chrom; i++) cs[i + 1] = cs[i] + v->chrom_len[i];
     if (ensure(c, c->occ, n_blk * 16) || ensure(c, c->hash, v->hash_entries * 8) || ensure(c, c->sa, rows * (wide ? 8 : 4)) ||
-        ensure(c, c->gen2, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8)) return BMBS_ENOMEM;
+        ensure(c, c->gen2, gen_words * 8) || ensure(c, c->gen2p, gen_words * 8) || ensure(c, c->chrom_start, cs.size() * 8)) return BMBS_ENOMEM;
     HIPCHK(c, hipMemcpyAsync(c->chrom_start.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_repack_occ, dim3(nblk(n_blk, 256)), dim3(256), 0, c->stream, R, n, n_blk, sup, c->occ.as<uint4>());
     hipLaunchKernelGGL(k_repack_hash, dim3(nblk(v->hash_entries, 256)), dim3(256), 0, c->stream, R, v->hash_entries, c->hash.as<u64>());
     hipLaunchKernelGGL(k_build_gen2, dim3(nblk(gen_words, 256)), dim3(256), 0, c->stream, R, G, gen_words, c->gen2.as<u64>());
+    hipLaunchKernelGGL(k_build_gen2p, dim3(nblk(gen_words, 256)), dim3(256), 0, c->stream, c->gen2.as<u64>(), gen_words, c->gen2p.as<u64>());
     DevIndex ix;
-    ix.occ = c->occ.as<uint4>(); ix.hash = c->hash.as<u64>(); ix.gen2 = c->gen2.as<u64>();
+    ix.occ = c->occ.as<uint4>(); ix.hash = c->hash.as<u64>(); ix.gen2 = c->gen2.as<u64>(); ix.gen2p = c->gen2p.as<u64>();
     ix.sa = wide ? nullptr : c->sa.as<u32>(); ix.sa64 = wide ? c->sa.as<u64>() : nullptr;
     ix.sup_shift = sup.shift;
     for (int q = 0; q < 4; q++) { ix.supT[q] = sup.T[q]; ix.supA[q] = sup.A[q]; }

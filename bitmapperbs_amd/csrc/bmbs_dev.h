@@ -25,7 +25,10 @@ typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef uint8_
 //           because the next letter does not occur, or still going with the depth-20 interval.  One lookup replaces the 16-mer
 //           lookup plus up to four dependent Occ gathers of a seed; 288 GB of HBM is what makes the table affordable;
 //   gen2  : the doubled genome (forward ++ reverse complement) 2 bits/base, 32 bases per u64
-//           LSB-first (A0 C1 G2 T3), so both strands' windows are forward reads.
+//           LSB-first (A0 C1 G2 T3), so both strands' windows are forward reads;
+//   gen2p : the same bases as two bit planes -- word w = { low half: bit 0 of the letters of bases 32 w .. 32 w + 31, high half: their
+//           bit 1 } -- which is the form the Myers filter works on (k_filter.hip): same footprint, same sectors per window, and no
+//           de-interleaving per candidate (1.55 GB more at GRCh38 size).
 struct DevIndex {
     const uint4* occ;
     const u64*   hash;
@@ -37,6 +40,7 @@ struct DevIndex {
     int          sup_shift;
     u64          supT[4], supA[4];
     const u64*   gen2;
+    const u64*   gen2p;
     const u64*   t20;           // optional: outcome of the first t_e extensions of every (16 + t_e)-mer (k_build_t20), else nullptr
     int          t_e;           // letters the table looks ahead: 4 (3^20 entries, 27.9 GB) or 5 (3^21 entries, 83.7 GB; GRCh38-size texts)
     // three backward extensions in one step (round 4): occ3[g * nb3 + row / 96] = { rows before the block whose three preceding text

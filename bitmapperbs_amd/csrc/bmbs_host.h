@@ -146,7 +146,7 @@ struct Lane {
     DevIndex ix;
     u64 rows = 0;
     // index buffers
-    DevBuf occ, hash, sa, gen2, chrom_start, t20;
+    DevBuf occ, hash, sa, gen2, gen2p, chrom_start, t20;
     std::shared_ptr<Occ3Shared> o3;            // the index's trigram table, built on demand (occ3_want)
     // LUTs
     DevBuf pen_lut, mapq_lut;

@@ -125,6 +125,24 @@ __global__ void k_build_gen2(RefIndexDev R, u64 G, u64 n_words, u64* out)
     out[w] = v;
 }
 
+// the same words as two bit planes (DevIndex::gen2p)
+__global__ void k_build_gen2p(const u64* __restrict__ gen2, u64 n_words, u64* __restrict__ out)
+{
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const u64 v = gen2[w];
+    auto squeeze = [](u64 x) -> u64 {              // bits 0, 2, 4 .. 62 -> bits 0 .. 31
+        x &= 0x5555555555555555ull;
+        x = (x | (x >> 1)) & 0x3333333333333333ull;
+        x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+        x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+        x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+        x = (x | (x >> 16)) & 0x00000000ffffffffull;
+        return x;
+    };
+    out[w] = squeeze(v) | (squeeze(v >> 1) << 32);
+}
+
 // full SA from the sampled SA: LF-walk to a flagged row (bwt_get_sa_restrict_steps_more_than_3,
 // bwt.h:2449-2560), done once per attach so that the mapping kernels never walk.
 // (grid-stride: a launch may not exceed 2^32 threads, GRCh38 has 6.2 G rows)

@@ -9,28 +9,23 @@
 // W = u32 when the band (2k+1 bits) fits 32 bits (k <= 15, exactly the case in which the reference runs
 // its 8 x 32-bit AVX2 form), else u64.
 // k_filter is bound by VALU issue, not by memory (profiles/: ~85 % of its time was VALU issue with four sliding Peq vectors), so this
-// form spends fewer instructions per read character: the window is kept as two bit planes (bit 0 / bit 1 of the 2-bit letters;
-// 64 or 96 bases per register set, re-filled every 32 rows), the row's Peq is derived from them with the bisulfite rule folded in
+// form spends fewer instructions per read character: the window is kept as two bit planes (bit 0 / bit 1 of the 2-bit letters, read
+// from the index's planar copy of the genome, DevIndex::gen2p), the row's Peq is derived from them with the bisulfite rule folded in
 // (T: plane 0 alone = {C, T}), and the characters come 16 per load.
 DEVI void planes32(const DevIndex& ix, u64 d, u32& lo, u32& hi)      // the 32 bases starting at doubled coordinate d
 {
-    const int sh = (int)(d & 31) * 2;
-    u64 w = ix.gen2[d >> 5] >> sh;
-    if (sh) w |= ix.gen2[(d >> 5) + 1] << (64 - sh);
-    auto squeeze = [](u32 x) -> u32 {           // bits 0, 2, 4 .. 30 -> bits 0 .. 15
-        x &= 0x55555555u;
-        x = (x | (x >> 1)) & 0x33333333u;
-        x = (x | (x >> 2)) & 0x0f0f0f0fu;
-        x = (x | (x >> 4)) & 0x00ff00ffu;
-        x = (x | (x >> 8)) & 0x0000ffffu;
-        return x;
-    };
-    const u32 a = (u32)w, b = (u32)(w >> 32);
-    lo = squeeze(a) | (squeeze(b) << 16);
-    hi = squeeze(a >> 1) | (squeeze(b >> 1) << 16);
+    const u64 a = ix.gen2p[d >> 5], b = ix.gen2p[(d >> 5) + 1];             // (the array carries spare words at its end)
+    const u32 s = (u32)(d & 31);
+    lo = __builtin_amdgcn_alignbit((u32)b, (u32)a, s);
+    hi = __builtin_amdgcn_alignbit((u32)(b >> 32), (u32)(a >> 32), s);
 }
 // W = u32: band <= 31 bits (k <= 15), 64 bases of each plane in a register pair; W = u64: band <= 63 bits (k <= 31), 96 bases.
 // PACKED: the read comes from a packed row (prow, 32 bases per word; pW = its base words; dirty = it holds characters outside ACGT)
+// Two forms of the window: a wave of u32 candidates whose windows all fit 192 bases (reads up to ~165 bases) fetches each window
+// ONCE, up front (every 32-byte sector of the genome a candidate needs is then asked for exactly once: the kernel sits at the
+// chip's rate of divergent DRAM requests, and a window streamed 32 bases at a time finds its sectors evicted again between
+// visits); any other wave streams the window 32 bases per 32 rows.
+constexpr int BPM_HELD = 6;                             // plane words (32 bases each) of a window held in registers
 template <class W, bool PACKED = false>
 DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site, u32& out_err, int& out_end,
                      const u64* prow = nullptr, int pW = 0, bool dirty = false)
@@ -38,122 +33,152 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
     constexpr bool WIDE = sizeof(W) == 8;
     out_err = 0xffffffffu; out_end = -1;
     const int p_len = L + 2 * k;
-    if (!window_valid(ix, site, (u64)p_len, site < ix.G)) return;
+    const bool valid = window_valid(ix, site, (u64)p_len, site < ix.G);
     const int band = 2 * k + 1;
     const W bmask = ((W)1 << band) - 1;
-    u64 loS, hiS;                                       // bit j = plane bit of base site + i0 + j
-    u32 loT = 0, hiT = 0;                               // WIDE: bits 64..95
-    {
-        u32 l0, h0, l1, h1;
-        planes32(ix, site, l0, h0); planes32(ix, site + 32, l1, h1);
-        loS = ((u64)l1 << 32) | l0; hiS = ((u64)h1 << 32) | h0;
-        if (WIDE) planes32(ix, site + 64, loT, hiT);
-    }
     W VP = 0, VN = 0;
     int err = 0;
+    u32 acc = 0;
     const int last_high = 2 * k;
-    // one read character: CHECKED also tests the read's end and that the character is one of A, C, G, T
-    auto step = [&](u32 tc, int i, int i0, auto checked) {
-        const int sh = i - i0;
-        W lo, hi;
-        if (WIDE) {
-            lo = (W)(sh ? (loS >> sh) | ((u64)loT << (64 - sh)) : loS) & bmask;
-            hi = (W)(sh ? (hiS >> sh) | ((u64)hiT << (64 - sh)) : hiS) & bmask;
-        } else { lo = (W)(loS >> sh) & bmask; hi = (W)(hiS >> sh) & bmask; }
-        const W xl = (tc == 'A' || tc == 'G') ? (lo ^ bmask) : lo;
-        const W xh = tc == 'G' ? hi : ~hi;
-        W eq = tc == 'T' ? lo : (xl & xh);
-        if (decltype(checked)::value) {
-            const u32 idx = tc ^ 0x40u;                                         // 'A' 1, 'C' 3, 'G' 7, 'T' 20
-            const u32 okc = idx < 32u ? (0x0010008au >> idx) & 1u : 0u;
-            eq &= (W)0 - (W)okc;
+    // One read character (row i of the matrix) as its 2-bit code (A0 C1 G2 T3): c0 / c1 = the code's bits spread over the word;
+    // lo / hi = the two planes of the window bases i .. i + 2k.  A window base matches when both of its plane bits equal the
+    // code's; a read T also matches a window C (plane 0 alone).  The row is 16 VALU instructions for W = u32 (two funnel shifts,
+    // two bit-field extracts, 3-input boolean ops); the D0 bit that the error count needs is funnelled into `acc` and counted
+    // once per 16 rows.  CHECKED also tests the read's end and the character's not-ACGT mark.
+    auto row = [&](W lo, W hi, u32 c16, u32 m16, int c, int i, auto checked) {
+        if constexpr (!WIDE) {
+            // (the 3-input boolean instruction, truth tables with a = 0xF0, b = 0xCC, c = 0xAA)
+            constexpr u32 A = 0xF0u, B = 0xCCu, C = 0xAAu;
+            const u32 c0 = (u32)__builtin_amdgcn_sbfe((int)c16, 2 * c, 1), c1 = (u32)__builtin_amdgcn_sbfe((int)c16, 2 * c + 1, 1);
+            const u32 t = __builtin_amdgcn_bitop3_b32(hi, c1, c0, (~(A ^ B) | (B & C)) & 0xffu);
+            u32 eq = __builtin_amdgcn_bitop3_b32(lo, c0, t, (~(A ^ B) & C) & 0xffu);
+            if (decltype(checked)::value) eq &= ((m16 >> c) & 1u) - 1u;
+            u32 X = __builtin_amdgcn_bitop3_b32(eq, bmask, VN, ((A & B) | C) & 0xffu);
+            const u32 D0 = __builtin_amdgcn_bitop3_b32(VP + (X & VP), VP, X, ((A ^ B) | C) & 0xffu);
+            const u32 HN = VP & D0;
+            const u32 HP = __builtin_amdgcn_bitop3_b32(VN, VP, D0, (A | ~(B | C)) & 0xffu);
+            X = D0 >> 1;
+            const u32 VN2 = X & HP, VP2 = __builtin_amdgcn_bitop3_b32(HN, X, HP, (A | ~(B | C)) & 0xffu);
+            if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
+            else { VN = VN2; VP = VP2; acc = __builtin_amdgcn_alignbit(D0, acc, 1); }
+        } else {
+            const W c0 = (W)(long long)((int)(c16 << (31 - 2 * c)) >> 31), c1 = (W)(long long)((int)(c16 << (30 - 2 * c)) >> 31);
+            W eq = ~(lo ^ c0) & (~(hi ^ c1) | (c0 & c1));
+            if (decltype(checked)::value) eq &= (W)(long long)(int)(((m16 >> c) & 1u) - 1u);
+            W X = (eq & bmask) | VN;
+            const W D0 = ((VP + (X & VP)) ^ VP) | X;
+            const W HN = VP & D0;
+            const W HP = VN | ~(VP | D0);
+            X = D0 >> 1;
+            const W VN2 = X & HP, VP2 = HN | ~(X | HP);
+            if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
+            else { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); }
         }
-        W X = eq | VN;
-        const W D0 = ((VP + (X & VP)) ^ VP) | X;
-        const W HN = VP & D0;
-        const W HP = VN | ~(VP | D0);
-        X = D0 >> 1;
-        const W VN2 = X & HP, VP2 = HN | ~(X | HP);
-        if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
-        else { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); }
     };
-    for (int i0 = 0; i0 < L; i0 += 32) {
-        if (i0) {
-            u32 nl, nh;
-            planes32(ix, site + (u64)i0 + (WIDE ? 64 : 32), nl, nh);
-            if (WIDE) {
-                loS = (loS >> 32) | ((u64)loT << 32); hiS = (hiS >> 32) | ((u64)hiT << 32);
-                loT = nl; hiT = nh;
-            } else { loS = (loS >> 32) | ((u64)nl << 32); hiS = (hiS >> 32) | ((u64)nh << 32); }
-        }
+    // the 16 characters of rows ib .. ib + 15 as codes (c16) and not-ACGT marks (m16); i0 = ib & ~31
+    auto codes = [&](int i0, int half, u32& c16, u32& m16) {
         if constexpr (PACKED) {
-            // 32 bases per word; the per-character step sees the 2-bit code (A0 C1 G2 T3) and, for dirty rows, the not-ACGT bit
-            const u64 rb = prow[i0 >> 5];
-            const u32 mb = dirty ? (u32)((prow[pW + (i0 >> 6)] >> (i0 & 63)) & 0xffffffffull) : 0u;
-            auto step_p = [&](u32 c, u32 bad, int i, auto checked) {
-                const int sh = i - i0;
-                W lo, hi;
-                if (WIDE) {
-                    lo = (W)(sh ? (loS >> sh) | ((u64)loT << (64 - sh)) : loS) & bmask;
-                    hi = (W)(sh ? (hiS >> sh) | ((u64)hiT << (64 - sh)) : hiS) & bmask;
-                } else { lo = (W)(loS >> sh) & bmask; hi = (W)(hiS >> sh) & bmask; }
-                const W xl = (c & 1u) ? lo : (lo ^ bmask);
-                const W xh = (c & 2u) ? hi : ~hi;
-                W eq = c == 3u ? lo : (xl & xh);
-                if (decltype(checked)::value) eq &= (W)0 - (W)(bad ^ 1u);
-                W X = eq | VN;
-                const W D0 = ((VP + (X & VP)) ^ VP) | X;
-                const W HN = VP & D0;
-                const W HP = VN | ~(VP | D0);
-                X = D0 >> 1;
-                const W VN2 = X & HP, VP2 = HN | ~(X | HP);
-                if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
-                else { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); }
-            };
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int ib = i0 + 16 * half;
-                if (ib >= L) break;
-                const u32 c16 = (u32)(rb >> (32 * half));
-                const u32 m16 = (mb >> (16 * half)) & 0xffffu;
-                const bool plain = m16 == 0 && ib + 16 <= L;
-                if (__all(plain)) {
-#pragma unroll
-                    for (int c = 0; c < 16; c++) step_p((c16 >> (2 * c)) & 3u, 0u, ib + c, std::false_type());
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 16; c++) step_p((c16 >> (2 * c)) & 3u, (m16 >> c) & 1u, ib + c, std::true_type());
-                }
-                if (__all(err - last_high > k)) return;
-            }
-            continue;
-        }
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int ib = i0 + 16 * half;
-            if (ib >= L) break;
-            const uint4 v = *reinterpret_cast<const uint4*>(rd + ib);       // rows are 16-byte aligned and padded
+            // 32 bases per word; for dirty rows the not-ACGT bit of each
+            c16 = (u32)(prow[i0 >> 5] >> (32 * half));
+            m16 = dirty ? (u32)((prow[pW + (i0 >> 6)] >> ((i0 & 63) + 16 * half)) & 0xffffull) : 0u;
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4*>(rd + i0 + 16 * half);       // rows are 16-byte aligned and padded
             const u32 cw[4] = {v.x, v.y, v.z, v.w};
-            // a wave whose lanes all hold 16 characters of A/C/G/T inside their reads runs the unchecked steps.  The letter a
-            // byte would have to be, rebuilt from its bits 1-2 (A 00, C 01, G 11, T 10): 0x41 | bits 1-2, T: ^ 0x11
-            u32 bad = 0;
+            // the letter a byte would have to be, rebuilt from its bits 1-2 (A 00, C 01, G 11, T 10): 0x41 | bits 1-2, T: ^ 0x11;
+            // the code is those two bits with G and T exchanged, four characters gathered into a byte by one multiplication
+            c16 = 0; m16 = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const u32 x = cw[q];
                 const u32 isT = (x >> 2) & ~(x >> 1) & 0x01010101u;
-                bad |= x ^ ((0x41414141u | (x & 0x06060606u)) ^ (isT * 0x11u));
+                const u32 bad = x ^ ((0x41414141u | (x & 0x06060606u)) ^ (isT * 0x11u));
+                const u32 nz = ((bad | ((bad & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;
+                const u32 b = (x >> 1) & 0x03030303u;
+                const u32 cd = b ^ ((b >> 1) & 0x01010101u);
+                c16 |= ((cd * 0x01041040u) >> 24) << (8 * q);
+                m16 |= ((nz * 0x01020408u) >> 24) << (4 * q);
             }
-            const bool plain = bad == 0 && ib + 16 <= L;
-            if (__all(plain)) {
+        }
+    };
+    // 16 rows from row ib on; win(sh, lo, hi) = the planes at offset sh of the current 32 rows.  true: no lane of the wave can
+    // come back under k (Levenshtein_Cal.h:455: such a candidate ends with err = ~0 whether or not it goes on)
+    auto rows16 = [&](int ib, int half, u32 c16, u32 m16, auto&& win) -> bool {
+        // a wave whose lanes all hold 16 characters of A/C/G/T inside their reads runs the unchecked rows
+        const bool plain = m16 == 0 && ib + 16 <= L;
+        if (__all(plain)) {
 #pragma unroll
-                for (int c = 0; c < 16; c++) step((cw[c >> 2] >> (8 * (c & 3))) & 0xffu, ib + c, i0, std::false_type());
-            } else {
+            for (int c = 0; c < 16; c++) { W lo, hi; win(16 * half + c, lo, hi); row(lo, hi, c16, 0u, c, ib + c, std::false_type()); }
+            if (!WIDE) err += 16 - __popc(acc >> 16);
+        } else {
 #pragma unroll
-                for (int c = 0; c < 16; c++) step((cw[c >> 2] >> (8 * (c & 3))) & 0xffu, ib + c, i0, std::true_type());
+            for (int c = 0; c < 16; c++) { W lo, hi; win(16 * half + c, lo, hi); row(lo, hi, c16, m16, c, ib + c, std::true_type()); }
+        }
+        return __all(err - last_high > k);
+    };
+    bool held = false;
+    if constexpr (!WIDE) held = __all(!valid || p_len <= 32 * BPM_HELD) != 0;
+    if (held) {
+        if constexpr (!WIDE) {
+            if (!valid) return;
+            // the words that hold the window's bases, all requested before the first is used
+            const u64* gp = ix.gen2p + (site >> 5);
+            const int nw = (int)(((site & 31) + (u64)p_len + 31) >> 5);
+            u64 raw[BPM_HELD + 1];
+#pragma unroll
+            for (int j = 0; j <= BPM_HELD; j++) raw[j] = j < nw ? gp[j] : 0ull;
+            u32 pl[BPM_HELD + 1], ph[BPM_HELD + 1];       // the planes of the words as they lie
+#pragma unroll
+            for (int j = 0; j <= BPM_HELD; j++) { pl[j] = (u32)raw[j]; ph[j] = (u32)(raw[j] >> 32); }
+            const u32 s = (u32)(site & 31);
+            u32 lo[BPM_HELD], hi[BPM_HELD];               // bit j of word w = plane bit of base site + 32 w + j
+#pragma unroll
+            for (int j = 0; j < BPM_HELD; j++) { lo[j] = __builtin_amdgcn_alignbit(pl[j + 1], pl[j], s); hi[j] = __builtin_amdgcn_alignbit(ph[j + 1], ph[j], s); }
+            for (int i0 = 0; i0 < L; i0 += 32) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int ib = i0 + 16 * half;
+                    if (ib >= L) break;
+                    u32 c16, m16;
+                    codes(i0, half, c16, m16);
+                    if (rows16(ib, half, c16, m16, [&](int sh, u32& a, u32& b) { a = __builtin_amdgcn_alignbit(lo[1], lo[0], (u32)sh); b = __builtin_amdgcn_alignbit(hi[1], hi[0], (u32)sh); })) return;
+                }
+#pragma unroll
+                for (int j = 0; j + 1 < BPM_HELD; j++) { lo[j] = lo[j + 1]; hi[j] = hi[j + 1]; }
+                lo[BPM_HELD - 1] = 0; hi[BPM_HELD - 1] = 0;
             }
-            // a candidate that cannot come back under k (Levenshtein_Cal.h:455) ends with err = ~0 below whether or not it
-            // goes on; the wave stops once that is every lane
-            if (__all(err - last_high > k)) return;
+        }
+    } else {
+        if (!valid) return;
+        u64 loS, hiS;                                       // bit j = plane bit of base site + i0 + j
+        u32 loT = 0, hiT = 0;                               // WIDE: bits 64..95
+        {
+            u32 l0, h0, l1, h1;
+            planes32(ix, site, l0, h0); planes32(ix, site + 32, l1, h1);
+            loS = ((u64)l1 << 32) | l0; hiS = ((u64)h1 << 32) | h0;
+            if (WIDE) planes32(ix, site + 64, loT, hiT);
+        }
+        for (int i0 = 0; i0 < L; i0 += 32) {
+            if (i0) {
+                u32 nl, nh;
+                planes32(ix, site + (u64)i0 + (WIDE ? 64 : 32), nl, nh);
+                if (WIDE) {
+                    loS = (loS >> 32) | ((u64)loT << 32); hiS = (hiS >> 32) | ((u64)hiT << 32);
+                    loT = nl; hiT = nh;
+                } else { loS = (loS >> 32) | ((u64)nl << 32); hiS = (hiS >> 32) | ((u64)nh << 32); }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int ib = i0 + 16 * half;
+                if (ib >= L) break;
+                u32 c16, m16;
+                codes(i0, half, c16, m16);
+                if (rows16(ib, half, c16, m16, [&](int sh, W& a, W& b) {
+                        if (WIDE) {
+                            a = (W)(sh ? (loS >> sh) | ((u64)loT << (64 - sh)) : loS);
+                            b = (W)(sh ? (hiS >> sh) | ((u64)hiT << (64 - sh)) : hiS);
+                        } else { a = (W)(loS >> sh); b = (W)(hiS >> sh); }
+                    })) return;
+            }
         }
     }
     if (err - last_high > k) return;
