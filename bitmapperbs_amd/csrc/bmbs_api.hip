@@ -1079,7 +1079,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
         const int ppr = stride / 16;
         if (sparse && ppr <= 256) {
             const int rpb = 256 / ppr;
-            hipLaunchKernelGGL(k_pe_prepare_p, dim3(nblk(n, rpb)), dim3(256), (size_t)rpb * (ppr + 1) * 8, c->stream,
+            hipLaunchKernelGGL(k_pe_prepare_p, dim3(std::min<u64>(nblk(n, rpb), 2048)), dim3(256), (size_t)rpb * (ppr + 1) * 16, c->stream,
                                reinterpret_cast<const char*>(d_seq1), reinterpret_cast<const char*>(d_seq2), gm, stride, (long)n, seq_all, prow,
                                pwords, W, pdirty);
         } else

@@ -108,79 +108,94 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGe
 // window of the forward row, complemented under its valid-base mask and reversed by 2-bit groups.  The byte-wise complement
 // + byte swap of the ASCII form cost ~2.5x the instructions of everything else in the kernel, which was VALU-bound.
 // A block takes 256 / (stride / 16) whole pairs; only a piece that holds a character outside ACGT rebuilds its ASCII text.
+// The grid is what the chip holds at once and every block walks the pairs in strides: one thread per 16-byte piece per launch made
+// 1.6 M waves that lived 5 microseconds each, and the kernel ran at the rate waves can be started (two resident per SIMD,
+// 1.3 TB/s); the pieces of the block's next group of pairs are requested before the current group is worked on, and the two LDS
+// buffers alternate so that a group costs one barrier.
 __global__ void __launch_bounds__(256)
 k_pe_prepare_p(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all,
                u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32)
 {
     extern __shared__ u32 lds_pp[];
     const int ppr = stride / 16, rpb = 256 / ppr;
-    u32* lb = lds_pp;                                   // [rpb][ppr + 1] forward base words (+ one zero word)
-    u32* lm = lds_pp + rpb * (ppr + 1);                 // [rpb][ppr + 1] forward mask pieces (16 bits each, + one zero)
+    const int bufw = rpb * (ppr + 1);                   // words of one plane of one buffer
     const int tid = threadIdx.x, rl = tid / ppr, piece = tid - rl * ppr;
-    const long r = (long)blockIdx.x * rpb + rl;
-    const bool on = rl < rpb && r < n;
     const long total = n * stride;
-    int L2 = 0;
-    if (on) {
-        const size_t i16 = (size_t)r * ppr + piece;
-        const int L1 = gm.rl(r);
-        L2 = gm.rl(n + r);
-        const uint4 v1 = reinterpret_cast<const uint4*>(s1)[i16];
-        const uint4 v2 = reinterpret_cast<const uint4*>(s2raw)[i16];
-        u32 b1, m1, b2, m2;
-        pack_piece(v1, L1 - piece * 16, b1, m1);
-        pack_piece(v2, L2 - piece * 16, b2, m2);
-        lb[rl * (ppr + 1) + piece] = b2; lm[rl * (ppr + 1) + piece] = m2;
-        if (piece == 0) { lb[rl * (ppr + 1) + ppr] = 0; lm[rl * (ppr + 1) + ppr] = 0; }
-        if (piece * 16 < ((L1 + 63) & ~63)) {
-            u64* row = prow + (size_t)r * pwords;
-            if (piece * 16 < ((L1 + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = b1;
-            reinterpret_cast<u16*>(row + W)[piece] = (u16)m1;
-            if (m1) { atomicOr(&dirty32[r >> 2], 1u << (8 * (int)(r & 3))); reinterpret_cast<uint4*>(seq_all)[i16] = v1; }
+    const long step = (long)gridDim.x * rpb;
+    long r = (long)blockIdx.x * rpb + rl;
+    bool on = rl < rpb && r < n;
+    uint4 v1 = {0, 0, 0, 0}, v2 = {0, 0, 0, 0};
+    if (on) { const size_t i16 = (size_t)r * ppr + piece; v1 = reinterpret_cast<const uint4*>(s1)[i16]; v2 = reinterpret_cast<const uint4*>(s2raw)[i16]; }
+    int buf = 0;
+    for (long base = (long)blockIdx.x * rpb; base < n; base += step, buf ^= 1) {
+        const long rn = r + step;
+        const bool onn = rl < rpb && rn < n;
+        uint4 n1 = {0, 0, 0, 0}, n2 = {0, 0, 0, 0};
+        if (onn) { const size_t j16 = (size_t)rn * ppr + piece; n1 = reinterpret_cast<const uint4*>(s1)[j16]; n2 = reinterpret_cast<const uint4*>(s2raw)[j16]; }
+        u32* lb = lds_pp + (size_t)buf * 2 * bufw;      // [rpb][ppr + 1] forward base words (+ one zero word)
+        u32* lm = lb + bufw;                            // [rpb][ppr + 1] forward mask pieces (16 bits each, + one zero)
+        int L2 = 0;
+        if (on) {
+            const size_t i16 = (size_t)r * ppr + piece;
+            const int L1 = gm.rl(r);
+            L2 = gm.rl(n + r);
+            u32 b1, m1, b2, m2;
+            pack_piece(v1, L1 - piece * 16, b1, m1);
+            pack_piece(v2, L2 - piece * 16, b2, m2);
+            lb[rl * (ppr + 1) + piece] = b2; lm[rl * (ppr + 1) + piece] = m2;
+            if (piece == 0) { lb[rl * (ppr + 1) + ppr] = 0; lm[rl * (ppr + 1) + ppr] = 0; }
+            if (piece * 16 < ((L1 + 63) & ~63)) {
+                u64* row = prow + (size_t)r * pwords;
+                if (piece * 16 < ((L1 + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = b1;
+                reinterpret_cast<u16*>(row + W)[piece] = (u16)m1;
+                if (m1) { atomicOr(&dirty32[r >> 2], 1u << (8 * (int)(r & 3))); reinterpret_cast<uint4*>(seq_all)[i16] = v1; }
+            }
         }
-    }
-    __syncthreads();
-    if (!on || piece * 16 >= ((L2 + 63) & ~63)) return;
-    const int j0 = piece * 16, lo = L2 - 16 - j0;       // forward positions lo .. lo+15, reversed, are rc positions j0 .. j0+15
-    const u32* fb = lb + rl * (ppr + 1); const u32* fm = lm + rl * (ppr + 1);
-    u32 win, bad, inr;
-    if (lo >= 0) {
-        const int idx = lo >> 4, sh = lo & 15;
-        win = sh ? (fb[idx] >> (2 * sh)) | (fb[idx + 1] << (32 - 2 * sh)) : fb[idx];
-        bad = ((fm[idx] | (fm[idx + 1] << 16)) >> sh) & 0xffffu;
-        inr = 0xffffu;
-    } else if (lo > -16) {
-        win = fb[0] << (2 * -lo);
-        bad = (fm[0] << -lo) & 0xffffu;
-        inr = (0xffffu << -lo) & 0xffffu;
-    } else { win = 0; bad = 0; inr = 0; }
-    u32 x = inr & ~bad;                                 // real bases of the window -> both bits of their pair
-    x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
-    win ^= x | (x << 1);                                // complement: code -> 3 - code
-    u32 rv = __brev(win);
-    rv = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
-    const u32 om = __brev(bad & inr) >> 16;
-    const long row_id = n + r;
-    u64* row = prow + (size_t)row_id * pwords;
-    if (j0 < ((L2 + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = rv;
-    reinterpret_cast<u16*>(row + W)[piece] = (u16)om;
-    if (om) {
-        atomicOr(&dirty32[row_id >> 2], 1u << (8 * (int)(row_id & 3)));
-        const char* src = s2raw + r * stride;
-        unsigned char o[16];
+        __syncthreads();
+        if (on && piece * 16 < ((L2 + 63) & ~63)) {
+            const int j0 = piece * 16, lo = L2 - 16 - j0;       // forward positions lo .. lo+15, reversed, are rc positions j0 .. j0+15
+            const u32* fb = lb + rl * (ppr + 1); const u32* fm = lm + rl * (ppr + 1);
+            u32 win, bad, inr;
+            if (lo >= 0) {
+                const int idx = lo >> 4, sh = lo & 15;
+                win = sh ? (fb[idx] >> (2 * sh)) | (fb[idx + 1] << (32 - 2 * sh)) : fb[idx];
+                bad = ((fm[idx] | (fm[idx + 1] << 16)) >> sh) & 0xffffu;
+                inr = 0xffffu;
+            } else if (lo > -16) {
+                win = fb[0] << (2 * -lo);
+                bad = (fm[0] << -lo) & 0xffffu;
+                inr = (0xffffu << -lo) & 0xffffu;
+            } else { win = 0; bad = 0; inr = 0; }
+            u32 x = inr & ~bad;                                 // real bases of the window -> both bits of their pair
+            x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+            win ^= x | (x << 1);                                // complement: code -> 3 - code
+            u32 rv = __brev(win);
+            rv = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
+            const u32 om = __brev(bad & inr) >> 16;
+            const long row_id = n + r;
+            u64* row = prow + (size_t)row_id * pwords;
+            if (j0 < ((L2 + 31) & ~31)) reinterpret_cast<u32*>(row)[piece] = rv;
+            reinterpret_cast<u16*>(row + W)[piece] = (u16)om;
+            if (om) {
+                atomicOr(&dirty32[row_id >> 2], 1u << (8 * (int)(row_id & 3)));
+                const char* src = s2raw + r * stride;
+                unsigned char o[16];
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int j = j0 + t;
-            char c = 0;
-            if (j < L2) { const char a = src[L2 - 1 - j]; c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a; }
-            o[t] = (unsigned char)c;
+                for (int t = 0; t < 16; t++) {
+                    const int j = j0 + t;
+                    char c = 0;
+                    if (j < L2) { const char a = src[L2 - 1 - j]; c = a == 'A' ? 'T' : a == 'T' ? 'A' : a == 'C' ? 'G' : a == 'G' ? 'C' : a; }
+                    o[t] = (unsigned char)c;
+                }
+                uint4 v;
+                v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
+                v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
+                v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
+                v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
+                reinterpret_cast<uint4*>(seq_all + total)[(size_t)r * ppr + piece] = v;
+            }
         }
-        uint4 v;
-        v.x = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
-        v.y = o[4] | (o[5] << 8) | (o[6] << 16) | ((u32)o[7] << 24);
-        v.z = o[8] | (o[9] << 8) | (o[10] << 16) | ((u32)o[11] << 24);
-        v.w = o[12] | (o[13] << 8) | (o[14] << 16) | ((u32)o[15] << 24);
-        reinterpret_cast<uint4*>(seq_all + total)[(size_t)r * ppr + piece] = v;
+        r = rn; on = onn; v1 = n1; v2 = n2;
     }
 }
 
