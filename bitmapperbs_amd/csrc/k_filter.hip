@@ -62,17 +62,27 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
             if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
             else { VN = VN2; VP = VP2; acc = __builtin_amdgcn_alignbit(D0, acc, 1); }
         } else {
-            const W c0 = (W)(long long)((int)(c16 << (31 - 2 * c)) >> 31), c1 = (W)(long long)((int)(c16 << (30 - 2 * c)) >> 31);
-            W eq = ~(lo ^ c0) & (~(hi ^ c1) | (c0 & c1));
-            if (decltype(checked)::value) eq &= (W)(long long)(int)(((m16 >> c) & 1u) - 1u);
-            W X = (eq & bmask) | VN;
-            const W D0 = ((VP + (X & VP)) ^ VP) | X;
-            const W HN = VP & D0;
-            const W HP = VN | ~(VP | D0);
-            X = D0 >> 1;
-            const W VN2 = X & HP, VP2 = HN | ~(X | HP);
-            if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); } }
-            else { VN = VN2; VP = VP2; err += 1 - (int)(D0 & 1u); }
+            // the same row on the two halves of a 64-bit band: 31 instructions (the add carries from the low half into the high one)
+            constexpr u32 A = 0xF0u, B = 0xCCu, C = 0xAAu;
+            constexpr u32 T_HI = (~(A ^ B) | (B & C)) & 0xffu, T_EQ = (~(A ^ B) & C) & 0xffu, T_X = ((A & B) | C) & 0xffu,
+                          T_D0 = ((A ^ B) | C) & 0xffu, T_P = (A | ~(B | C)) & 0xffu;
+            const u32 c0 = (u32)__builtin_amdgcn_sbfe((int)c16, 2 * c, 1), c1 = (u32)__builtin_amdgcn_sbfe((int)c16, 2 * c + 1, 1);
+            const u32 lol = (u32)lo, loh = (u32)(lo >> 32), hil = (u32)hi, hih = (u32)(hi >> 32);
+            const u32 VPl = (u32)VP, VPh = (u32)(VP >> 32), VNl = (u32)VN, VNh = (u32)(VN >> 32);
+            u32 eql = __builtin_amdgcn_bitop3_b32(lol, c0, __builtin_amdgcn_bitop3_b32(hil, c1, c0, T_HI), T_EQ);
+            u32 eqh = __builtin_amdgcn_bitop3_b32(loh, c0, __builtin_amdgcn_bitop3_b32(hih, c1, c0, T_HI), T_EQ);
+            if (decltype(checked)::value) { const u32 ok = ((m16 >> c) & 1u) - 1u; eql &= ok; eqh &= ok; }
+            const u32 Xl = __builtin_amdgcn_bitop3_b32(eql, (u32)bmask, VNl, T_X), Xh = __builtin_amdgcn_bitop3_b32(eqh, (u32)(bmask >> 32), VNh, T_X);
+            const u64 sum = VP + (((u64)(Xh & VPh) << 32) | (u64)(Xl & VPl));
+            const u32 D0l = __builtin_amdgcn_bitop3_b32((u32)sum, VPl, Xl, T_D0), D0h = __builtin_amdgcn_bitop3_b32((u32)(sum >> 32), VPh, Xh, T_D0);
+            const u32 HNl = VPl & D0l, HNh = VPh & D0h;
+            const u32 HPl = __builtin_amdgcn_bitop3_b32(VNl, VPl, D0l, T_P), HPh = __builtin_amdgcn_bitop3_b32(VNh, VPh, D0h, T_P);
+            const u32 Sl = __builtin_amdgcn_alignbit(D0h, D0l, 1), Sh = D0h >> 1;
+            const u32 VN2l = Sl & HPl, VN2h = Sh & HPh;
+            const u32 VP2l = __builtin_amdgcn_bitop3_b32(HNl, Sl, HPl, T_P), VP2h = __builtin_amdgcn_bitop3_b32(HNh, Sh, HPh, T_P);
+            const W VN2 = ((W)VN2h << 32) | VN2l, VP2 = ((W)VP2h << 32) | VP2l;
+            if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0l & 1u); } }
+            else { VN = VN2; VP = VP2; acc = __builtin_amdgcn_alignbit(D0l, acc, 1); }
         }
     };
     // the 16 characters of rows ib .. ib + 15 as codes (c16) and not-ACGT marks (m16); i0 = ib & ~31
@@ -108,7 +118,7 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
         if (__all(plain)) {
 #pragma unroll
             for (int c = 0; c < 16; c++) { W lo, hi; win(16 * half + c, lo, hi); row(lo, hi, c16, 0u, c, ib + c, std::false_type()); }
-            if (!WIDE) err += 16 - __popc(acc >> 16);
+            err += 16 - __popc(acc >> 16);
         } else {
 #pragma unroll
             for (int c = 0; c < 16; c++) { W lo, hi; win(16 * half + c, lo, hi); row(lo, hi, c16, m16, c, ib + c, std::true_type()); }
@@ -173,9 +183,9 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
                 u32 c16, m16;
                 codes(i0, half, c16, m16);
                 if (rows16(ib, half, c16, m16, [&](int sh, W& a, W& b) {
-                        if (WIDE) {
-                            a = (W)(sh ? (loS >> sh) | ((u64)loT << (64 - sh)) : loS);
-                            b = (W)(sh ? (hiS >> sh) | ((u64)hiT << (64 - sh)) : hiS);
+                        if (WIDE) {         // (three 32-bit funnel shifts' worth: sh < 32)
+                            a = (W)(((u64)__builtin_amdgcn_alignbit(loT, (u32)(loS >> 32), (u32)sh) << 32) | __builtin_amdgcn_alignbit((u32)(loS >> 32), (u32)loS, (u32)sh));
+                            b = (W)(((u64)__builtin_amdgcn_alignbit(hiT, (u32)(hiS >> 32), (u32)sh) << 32) | __builtin_amdgcn_alignbit((u32)(hiS >> 32), (u32)hiS, (u32)sh));
                         } else { a = (W)(loS >> sh); b = (W)(hiS >> sh); }
                     })) return;
             }
