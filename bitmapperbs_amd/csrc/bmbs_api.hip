@@ -728,6 +728,15 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
 
 extern "C" void bmbs_destroy(bmbs_ctx* X)
 {
+#ifdef VOTE_PROF
+    {
+        unsigned long long h[4][8];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_vote_prof), sizeof h) == hipSuccess)
+            for (int q = 0; q < 4; q++)
+                fprintf(stderr, "[vote_prof] class %d: lists %llu candidates %llu sites %llu | Mcycles: locate+sort %.1f run-ends %.1f vote-order %.1f write %.1f | one-lane fallbacks %llu\n",
+                        q, h[q][0], h[q][1], h[q][2], h[q][3] / 1e6, h[q][4] / 1e6, h[q][5] / 1e6, h[q][6] / 1e6, h[q][7]);
+    }
+#endif
     if (!X) return;
     (void)hipSetDevice(X->dev);
     for (size_t i = X->lanes.size(); i-- > 0;) lane_destroy(X->lanes[i]);      // lane 0 (the index owner) last

@@ -564,6 +564,16 @@ DEVI bool vl_sort_votes(bmbs_vk* items, int nv, void* scratch, int* sh_w, int* c
 
 // CAP, BLOCK = (VM_CAP, VM_BLOCK): lists of up to 256 candidates, one wave each; (VL_CAP, VL_BLOCK): the longer ones, one
 // block each (the two instances walk the same list and take the reads of their size class: LO < nc <= CAP, the last one also beyond)
+// -DVOTE_PROF (tools/vote_prof.sh): cycles per phase of k_vote_long as thread 0 of a block sees them, summed per size class
+// [class][0 lists, 1 candidates, 2 distinct sites, 3 locate + site sort, 4 run ends + items, 5 vote order, 6 write-out, 7 vote order fell back to one lane]
+#ifdef VOTE_PROF
+__device__ unsigned long long g_vote_prof[4][8];
+#define VP_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define VP_ADD(cls, slot, val) do { if (threadIdx.x == 0) atomicAdd(&g_vote_prof[cls][slot], (unsigned long long)(val)); } while (0)
+#else
+#define VP_T(v)
+#define VP_ADD(cls, slot, val)
+#endif
 template <int CAP, int BLOCK, int LO>
 __global__ void __launch_bounds__(BLOCK)
 k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
@@ -649,7 +659,10 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
             __syncthreads();
             continue;
         }
+        constexpr int VP_CLS = CAP == VM_CAP ? 0 : CAP == 1024 ? 1 : CAP == 2048 ? 2 : 3;
+        VP_T(vp0);
         vl_locate_sort<(CAP + BLOCK - 1) / BLOCK>(ix, my, ns, (int)nc, keys, sh_pref);
+        VP_T(vp1);
         const int nv = vl_run_ends(keys, (int)nc, endpos, sh_w);
         // (vote, entry) items in site order; a site collects at most one vote per seed, so the vote fits 8 bits
         for (int e = threadIdx.x; e < nv; e += BLOCK) {
@@ -660,6 +673,7 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
         u64* c = cand + off;
         for (int e = threadIdx.x; e < nv; e += BLOCK) c[e] = keys[endpos[e]];
         __syncthreads();
+        VP_T(vp2);
         // std::sort(votes, compare_seed_votes), Schema.cpp:24986
         if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32), (CAP + BLOCK - 1) / BLOCK>(items, nv, keys, sh_w, sh_ctl)) {
             for (int e = threadIdx.x; e < nv; e += BLOCK) {
@@ -669,7 +683,9 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
             __syncthreads();
             if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);
             __syncthreads();
+            VP_ADD(VP_CLS, 7, 1);
         }
+        VP_T(vp3);
         for (int j = threadIdx.x; j < nv; j += BLOCK) {
             const u32 it = items[j].x;
             const u64 site = c[it & 0xffffffu];
@@ -680,6 +696,9 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
         for (long i = threadIdx.x; i < nc; i += BLOCK) slot_read[off + i] = i < nv ? (u32)r : 0xffffffffu;
         if (threadIdx.x == 0) st.n_votes[r] = (u32)nv;
         __syncthreads();
+        VP_T(vp4);
+        VP_ADD(VP_CLS, 0, 1); VP_ADD(VP_CLS, 1, nc); VP_ADD(VP_CLS, 2, nv);
+        VP_ADD(VP_CLS, 3, vp1 - vp0); VP_ADD(VP_CLS, 4, vp2 - vp1); VP_ADD(VP_CLS, 5, vp3 - vp2); VP_ADD(VP_CLS, 6, vp4 - vp3);
     }
 }
 
