@@ -109,9 +109,10 @@ k_pe_prepare(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGe
 // + byte swap of the ASCII form cost ~2.5x the instructions of everything else in the kernel, which was VALU-bound.
 // A block takes 256 / (stride / 16) whole pairs; only a piece that holds a character outside ACGT rebuilds its ASCII text.
 // The grid is what the chip holds at once and every block walks the pairs in strides: one thread per 16-byte piece per launch made
-// 1.6 M waves that lived 5 microseconds each, and the kernel ran at the rate waves can be started (two resident per SIMD,
-// 1.3 TB/s); the pieces of the block's next group of pairs are requested before the current group is worked on, and the two LDS
-// buffers alternate so that a group costs one barrier.
+// 1.6 M waves that lived 5 microseconds each -- alone on the chip that streams at 4 TB/s, but beside another lane's kernel those
+// waves queue behind its workgroups (event time with two lanes 1.9 -> 1.55 ms per 10 M pairs; alone 1.2 ms either way).  The pieces
+// of the block's next group of pairs are requested before the current group is worked on, and the two LDS buffers alternate so
+// that a group costs one barrier.
 __global__ void __launch_bounds__(256)
 k_pe_prepare_p(const char* __restrict__ s1, const char* __restrict__ s2raw, ReadGeom gm, int stride, long n, char* __restrict__ seq_all,
                u64* __restrict__ prow, int pwords, int W, u32* __restrict__ dirty32)
