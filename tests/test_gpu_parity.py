@@ -117,10 +117,12 @@ def test_gpu_sam_equals_reference_golden(name, tmp_path):
     m.close()
 
 
-def test_filter_stage_matches_oracle_incl_invalid_sites(env):
-    """K7+K8 through bmbs_filter_batch on arbitrary (read, site) pairs, incl. strand ends and wild sites"""
+@pytest.mark.parametrize("L,e", [(120, 0.08), (150, 0.08), (180, 0.08), (250, 0.08), (40, 0.15)])
+def test_filter_stage_matches_oracle_incl_invalid_sites(env, L, e):
+    """K7+K8 through bmbs_filter_batch on arbitrary (read, site) pairs, incl. strand ends and wild sites.  The lengths take the
+    kernel's three forms of the window: held in registers (L + 2k <= 192), streamed with a 32-bit band (180 bases, k = 14) and
+    streamed with a 64-bit band (250 bases, k = 20)"""
     from bitmapperbs_amd import synth, mapper
-    L, e = 120, 0.08
     r = synth.make_reads_se(env["chroms"], n=3000, L=L, seed=21, sub=0.03, indel=0.004, qual="const", n_rate=0.003)
     m = mapper.Mapper(env["ix"], 0, e_f=e)
     k = m.threshold(L)
