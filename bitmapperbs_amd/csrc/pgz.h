@@ -670,7 +670,23 @@ private:
         else {
             n = k.sym->n; k.text.resize(n);
             const u16* s = k.sym->out(); const u8* w = k.window.data(); u8* o = (u8*)k.text.data();
-            for (size_t i = 0; i < n; i++) { const u16 v = s[i]; o[i] = v < 256 ? (u8)v : w[v & 0x7fffu]; }
+            // A symbol is a byte or a marker 0x8000 | w; on FASTQ text about half of them stay markers to the end of a stretch (a
+            // quality run copies the run before it, which copied the one before ...), so "v < 256 ? v : window[v & 0x7fff]" was an
+            // unpredictable branch per symbol and 35-40 % of a thread's time.  One table serves both kinds -- the identity in its first
+            // 256 entries, the window at 0x8000 -- and a group of sixteen symbols without a marker is one pack instruction.
+            std::vector<u8> tab((size_t)65536);
+            for (u32 v = 0; v < 256; v++) tab[v] = (u8)v;
+            memcpy(tab.data() + 0x8000, w, WIN);
+            const u8* T = tab.data();
+            size_t i = 0;
+            const __m128i zero = _mm_setzero_si128();
+            for (; i + 16 <= n; i += 16) {
+                const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i)), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 8));
+                const __m128i hi = _mm_srli_epi16(_mm_or_si128(a, b), 8);
+                if (_mm_movemask_epi8(_mm_cmpeq_epi8(hi, zero)) == 0xffff) _mm_storeu_si128(reinterpret_cast<__m128i*>(o + i), _mm_packus_epi16(a, b));
+                else for (size_t j = i; j < i + 16; j++) o[j] = T[s[j]];
+            }
+            for (; i < n; i++) o[i] = T[s[i]];
             sym_put(k.sym);
         }
         k.window.clear(); k.window.shrink_to_fit();

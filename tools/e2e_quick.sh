@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/e2e_quick.sh [keys...] -- on the GPU box: the bench's file-to-file keys alone (null bam_null bgzf file bam), each over seconds of
+# tools/e2e_quick.sh [keys...] -- on the GPU box: the bench's file-to-file keys alone (null bam_null bgzf file bam pgz), each over seconds of
 # mapping (--loop-input), with the driver's own busy fractions.  Needs nothing but the tree: index and sample are made here.
 W=${BMBS_BENCH_DIR:-/tmp/bmbs_bench}
 read FA F1 F2 NP < <(python3 tools/e2e_setup.py 5000000 4 | tail -1)
@@ -20,5 +20,15 @@ for k in (1, 2):
     bench.write_bgzf("$W/b_%d.fq.gz" % k, data, level=1, threads=16)
 PY
       echo -n "bgzf (x6): "; $D --seq1 $W/b_1.fq.gz --seq2 $W/b_2.fq.gz -o /dev/null --loop-input 6 2>&1 | show ;;
+    pgz)
+      python3 - <<PY
+import sys; sys.path.insert(0, ".")
+import bench
+for k in (1, 2):
+    with open("$W/e2e_%d.fq" % k, "rb") as f: data = f.read()
+    with open("$W/e2e2_%d.fq" % k, "wb") as f: f.write(data); f.write(data)            # (twice the sample: the run takes about a second)
+    bench.write_gzip_one_member("$W/g_%d.fq.gz" % k, "$W/e2e2_%d.fq" % k)
+PY
+      echo -n "plain_gzip (one member per file, host inflater): "; $D --seq1 $W/g_1.fq.gz --seq2 $W/g_2.fq.gz -o /dev/null 2>&1 | show; rm -f $W/e2e2_?.fq $W/g_?.fq.gz ;;
   esac
 done
