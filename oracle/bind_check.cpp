@@ -229,11 +229,11 @@ static int bind_map_single(bool is_pbat)
                     (name, s, rs, q, site, (bitmapper_bs_iter)(span - 1), 0, r.nm, cigar, len, &out.cell, &out.sub, &among, 0, r.mapq);
                 if (among) bind_die(name, "the reference's emitter rejected a record the library called mapped");
             } else if (unmapped_out == 1 && r.status != BMBS_ST_AMBIG) {
-                // output_sam_unmapped (Schema.cpp:23955-23975; entirely inlined in the reference's object, so its text branch is
-                // restated here; --bam with --unmapped_out goes through the paired-end emitter's single-record form below)
-                if (bam_output) bind_die("--unmapped_out --bam", "single end: output_sam_unmapped has no linkable symbol");
-                FILE* fp = get_Ouput_Dec();
-                fprintf(fp, "%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n", name[0] == '@' ? name + 1 : name, is_pbat ? rs : s, q);
+                // output_sam_unmapped (Schema.cpp:23955-24070) is inlined away in the reference's object -- no symbol to link --, so its
+                // one line is restated: text to the SAM stream, or the same line (no newline) to the reference's htslib writer
+                std::string line = std::string(name[0] == '@' ? name + 1 : name) + "\t4\t*\t0\t0\t*\t*\t0\t0\t" + (is_pbat ? rs : s) + "\t" + q;
+                if (bam_output) write_alignment_directly(&line[0], (long long)line.size(), &out.cell);
+                else { line += "\n"; fputs(line.c_str(), get_Ouput_Dec()); }
             }
         }
         //[doc:end]
