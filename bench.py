@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GATHER_CEILING_GREQ = 54.0   # measured on this chip: dependent divergent gathers/s (tools/gather_bench.hip, profiles/r01_gather_bench.txt)
 SECTOR_CEILING_GBS = 3100.0  # the same measurement in bytes: 48.4 G gathers/s over a 34 GB table x one 64-byte sector each
 MIN_TIMED_S = 2.0            # the timed region is stretched to at least this (whole extra passes per step) whatever --steps says
+SECONDARY_MIN_S = 1.0        # ... and that of every secondary key to this
 
 CONFIGS = {
     1: dict(pe=False, sensitive=False, genome=46_000_000, n_chrom=4, read_len=150, e=0.04, units=10_000_000, launches=1,
@@ -382,20 +383,35 @@ def fetch_rule(kernel):
     return r, (2.0 if r == "x2" else 1.0)
 
 
+def event_label(csv_name):
+    """kernel name of a rocprofv3 CSV row -> the label its launches carry in the library's HIP-event profile (and in the byte tables):
+    the size-class instances of the list kernels share one C++ name and differ in their template arguments"""
+    base = csv_name.split("<")[0].split("(")[0]
+    targ = csv_name.split("<")[1] if "<" in csv_name else ""
+    if base in ("k_vote_long", "k_vote_pe_long"):
+        wave_form = targ.startswith("256;") or targ.startswith("256,")
+        return base if wave_form else base.replace("_long", "_big")
+    if base == "k_pes_vote_long":
+        return "k_pes_vote"
+    if base == "k_pe_filter_pairs_long":
+        return "k_pe_filter_pairs"
+    return PROF_NAME.get(base, base)
+
+
 def pmc_table(tag):
-    """{kernel: (fetch bytes corrected, write bytes, rule)} per launch from the committed rocprofv3 PMC passes of this same command
+    """{event label: (fetch bytes corrected, write bytes, rule)} per launch from the committed rocprofv3 PMC passes of this same command
     (profiles/<tag>_pmc_fetch_write.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units as rocprofv3 reports
     them); {} when no profile of this configuration has been committed"""
     import csv
     path = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write.csv" % tag)
     out = {}
-    if not os.path.exists(path):
+    if not tag or not os.path.exists(path):
         return out
     for row in csv.DictReader(open(path)):
         if not (row["FETCH_SIZE_KB_last_launch"] and row["WRITE_SIZE_KB_last_launch"]):
             continue
-        name = row["kernel"].split("<")[0].split("(")[0]
-        rule, f = fetch_rule(name)
+        rule, f = fetch_rule(row["kernel"].split("<")[0].split("(")[0])
+        name = event_label(row["kernel"])
         lanes = int(row.get("launches_per_call") or 1)
         fe = float(row["FETCH_SIZE_KB_last_launch"]) * 1024 * f * lanes
         wr = float(row["WRITE_SIZE_KB_last_launch"]) * 1024 * lanes
@@ -407,6 +423,28 @@ def pmc_table(tag):
 def pmc_traffic(kernel, tag):
     t = pmc_table(tag).get(kernel)
     return int(t[0] + t[1]) if t else None
+
+
+def workload_tag(config, cfg, grch38_like, base_cfg=None):
+    """name of the committed profile family of the workload that ACTUALLY runs: c<config> for a BASELINE configuration as it stands,
+    grch38_like_{pe,se,sensitive} for the repeat-rich genome; anything else (a configuration changed by flags) has no committed PMC pass"""
+    if grch38_like:
+        return "grch38_like_" + ("se" if not cfg["pe"] else "sensitive" if cfg["sensitive"] else "pe")
+    base = base_cfg or CONFIGS[config]
+    if cfg["pe"] != base["pe"] or cfg["sensitive"] != base["sensitive"] or cfg["read_len"] != base["read_len"] or cfg["genome"] != base["genome"]:
+        return None
+    return "c%d" % config
+
+
+def profile_tag(wtag):
+    """the newest committed PMC pass of that workload: profiles/r<NN>_<wtag>_pmc_fetch_write.csv -> 'r<NN>_<wtag>' or None"""
+    if not wtag:
+        return None
+    for rnd in range(9, 1, -1):
+        t = "r%02d_%s" % (rnd, wtag)
+        if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_fetch_write.csv" % t)):
+            return t
+    return None
 
 
 def algorithmic_bytes(cnt, nr, L, k, pe):
@@ -428,9 +466,21 @@ def algorithmic_bytes(cnt, nr, L, k, pe):
         own[kn] = s8d[kn] + 16 * c["n_hash"] + (14 * nr if kn == "k_seed_first" else 24 * c["n_hash"] if kn == "k_seed_second" else 0)
     s8d["k_seed_decide"] = L * nr + 4 * cnt["n_sa"] + ((L + 3) // 4 + 1) * cnt["n_ungapped"]
     own["k_seed_decide"] = s8d["k_seed_decide"] + (14 + 40) * nr
+    # candidates by the kernel class that located them (device counters, round 6): lists of <= 16 (the fused kernels), 17..32 (mid),
+    # 33..256 (the wave form: k_vote[_pe]_long), beyond (the block forms: k_vote[_pe]_big)
     cand = cnt["n_cand_slots"]
+    c_mid, c_long, c_big = cnt.get("n_cand_mid", 0), cnt.get("n_cand_long", 0), cnt.get("n_cand_big", 0)
+    c_fused = max(0, cand - c_mid - c_long - c_big)
     for kn in ("k_vote_fused", "k_vote_pe_fused"):
-        s8d[kn] = 4 * cand; own[kn] = (4 + 16 + 4) * cand
+        s8d[kn] = 4 * c_fused; own[kn] = (4 + 16 + 4) * c_fused
+    # the list kernels: 4 B per suffix-array read + the 16-byte candidate record (site, err, end / site, vote) per located candidate
+    for kn, c_ in (("k_vote_mid", c_mid), ("k_vote_pe_mid", c_mid), ("k_vote_long", c_long), ("k_vote_pe_long", c_long),
+                   ("k_vote_big", c_big), ("k_vote_pe_big", c_big), ("k_pes_vote", cnt.get("n_cand_reseed", 0))):
+        s8d[kn] = 20 * c_; own[kn] = 24 * c_
+    # filter_pairs: the 16-byte entries of both mates' lists read once (survivors written: at most as many again, not counted)
+    s8d["k_pe_filter_pairs"] = 16 * cnt.get("n_pef_entries", 0); own["k_pe_filter_pairs"] = 32 * cnt.get("n_pef_entries", 0)
+    # K9 / K10: the 16-byte vote record and the 8 bytes of (err, end) of every filtered candidate
+    s8d["k_reduce"] = 24 * cnt["n_filter"]; own["k_reduce"] = 24 * cnt["n_filter"] + 40 * nr
     for kn in ("k_filter", "k_filter_pe_r1"):
         s8d[kn] = (win + L) * cnt["n_filter"]; own[kn] = (win + L + 24) * cnt["n_filter"]
     s8d["k_align_ungapped"] = (win + 2 * L) * cnt["n_jobs"]; own["k_align_ungapped"] = (win + 2 * L + 16) * cnt["n_jobs"]
@@ -463,6 +513,59 @@ def gather_roofline(kernel, cnt, kern_ms):
     return {"index_requests_per_launch": int(req), "achieved_Greq_s": round(ach, 2), "ceiling_Greq_s": GATHER_CEILING_GREQ,
             "frac": round(ach / GATHER_CEILING_GREQ, 4),
             "note": "counts index gathers only; read-character loads and result stores are further requests of the same kind"}
+
+
+def roofline_block(kern_ms, cnt, nr, L, k, pe, genome, wtag, single=None):
+    """the `roofline` object of a bench line for the workload that ran: dominant kernel by HIP-event time, SURVEY 8(d) bytes of the
+    last launch over that time, PMC traffic from the committed profile of THIS workload (wtag: workload_tag) -> (dict, s8d, tag)"""
+    mapping = {kn: v for kn, v in kern_ms.items() if kn.startswith("k_")}
+    dom = max(mapping, key=mapping.get) if mapping else "k_seed_first"
+    s8d, own = algorithmic_bytes(cnt, nr, L, k, pe)
+    nat = native_bytes(cnt, 2 * genome + 1 >= (1 << 32))
+    tag = profile_tag(wtag)
+
+    def rl(model):
+        b = model.get(dom, 0)
+        a = b / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0
+        return b, a
+    b8, a8 = rl(s8d)
+    bo, ao = rl(own)
+    traffic = pmc_traffic(dom, tag) if tag else None
+    out = {"bound": "hbm", "kernel": dom, "achieved": round(a8, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(a8 / HBM_PEAK_GBS, 6), "traffic": traffic,
+           "algorithmic_bytes_per_launch": int(b8), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4),
+           "model": "SURVEY 8(d) terms: 10 B/16-mer lookup, 80 B/extension, 4 B/SA read, window bytes, read characters consumed, 32 B/record; "
+                    "list kernels: 4 B/SA read + the 16-byte candidate record per located candidate; filter_pairs: 16 B/list entry read",
+           # the builder's own model (adds the seed / carry records this design writes) next to it
+           "builder_model": {"algorithmic_bytes_per_launch": int(bo), "achieved": round(ao, 3), "frac": round(ao / HBM_PEAK_GBS, 6)},
+           # ... and what THIS layout has to move for the same events (16-byte Occ blocks, 8-byte outcome-table entries)
+           "design_native_model": ({"algorithmic_bytes_per_launch": int(nat[dom]), "achieved": round(nat[dom] / (kern_ms[dom] * 1e-3) / 1e9, 3),
+                                    "frac": round(nat[dom] / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                    "model": "8 B/lookup (outcome-table entry) + 16 B packed row + 16 B seed record per seed start, 32 B/extension, 4|8 B/SA read"}
+                                   if dom in nat and kern_ms.get(dom, 0) > 0 else None),
+           "traffic_rule": (pmc_table(tag).get(dom) or (0, 0, fetch_rule(dom)[0]))[2], "traffic_profile": tag,
+           # the same kernel timed ALONE (one lane, same launches, outside the timed region): what round 2's figure was
+           "single_lane": ({"avg_launch_ms": round(single["kernels_ms"].get(dom, 0.0), 4),
+                            "achieved": round(s8d.get(dom, 0) / (single["kernels_ms"][dom] * 1e-3) / 1e9, 3),
+                            "frac": round(s8d.get(dom, 0) / (single["kernels_ms"][dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                            "value_M_reads_s": single["value"], "ms_per_launch": single["ms_per_launch"]}
+                           if single and single["kernels_ms"].get(dom, 0) > 0 else None),
+           "traffic_over_algorithmic": round(traffic / b8, 3) if traffic and b8 else None,
+           # the same kernel against the bound that applies to an index walk: divergent gather requests/s (index gathers only: table
+           # lookups, Occ blocks, SA rows -- ONE definition, also in DESIGN.md section 3)
+           "gather": gather_roofline(dom, cnt, kern_ms),
+           "sectors": ({"traffic_GBps": round(traffic / (kern_ms[dom] * 1e-3) / 1e9, 1), "random_sector_ceiling_GBps": SECTOR_CEILING_GBS,
+                        "frac": round(traffic / (kern_ms[dom] * 1e-3) / 1e9 / SECTOR_CEILING_GBS, 4)} if traffic else None)}
+    return out, s8d, tag
+
+
+def kernels_traffic_table(tag, s8d):
+    """PMC traffic per launch of every mapping kernel from the committed profile of this workload next to its 8(d) bytes"""
+    if not tag:
+        return None
+    return {kn: {"fetch_plus_write_bytes": int(t[0] + t[1]), "rule": t[2],
+                 "over_algorithmic": (round((t[0] + t[1]) / s8d[kn], 2) if s8d.get(kn) else None)}
+            for kn, t in sorted(pmc_table(tag).items()) if kn.startswith("k_")}
 
 
 # ---- one measured configuration ---------------------------------------------------------------------------------------------------
@@ -548,7 +651,9 @@ def timed(job, steps, warmup, min_seconds, world, dist, torch, cdev="cuda"):
     """W warm-up steps, then K timed steps between barrier + synchronize; a step is repeated `passes` whole times when K steps
     would take less than min_seconds.  -> (seconds, passes, per-launch kernel ms averages)"""
     t_w = None
-    for _ in range(max(1, warmup)):
+    # (the FIRST step of a context allocates its work buffers and learns its capacities -- several times a settled step: the length of
+    # a step is read off a later one, so a lone warm-up step is followed by a second)
+    for _ in range(max(2, warmup)):
         torch.cuda.synchronize()
         t = time.perf_counter()
         job.step()
@@ -642,7 +747,8 @@ def two_context_rate(m, ix, job, cfg, local, torch, steps=6, n_ctx=2):
             "ms_per_launch": round(dt / total * 1e3, 3)}
 
 
-def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3, trimmed=False, grch38_like=False, ref_check=0):
+def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", repeats=0, steps=3, trimmed=False, grch38_like=False, ref_check=0,
+              roofline=False):
     """a short secondary measurement on its own index / mapper: -> dict(value, ms_per_launch, ...)"""
     import torch
     from bitmapperbs_amd import mapper
@@ -654,14 +760,26 @@ def secondary(args, label, cfg, rank, local, env=None, sub=None, qual="const", r
         ix = mapper.Index(fa)
         m = mapper.Mapper(ix, device=local, e_f=cfg["e"], sensitive=1 if cfg["sensitive"] else 0)
         job = Job(m, cfg, chroms, rank, args.sub if sub is None else sub, args.indel, qual, trimmed=trimmed)
-        dt, passes, kern_ms = timed(job, steps, 1, 0.5, 1, None, torch)
+        # every key over >= 1 s of mapping (passes from a settled step: timed())
+        dt, passes, kern_ms = timed(job, steps, 1, SECONDARY_MIN_S, 1, None, torch)
         nreads = job.reads_per_step() * steps * passes
         top = sorted(((v, k_) for k_, v in kern_ms.items() if k_.startswith("k_")), reverse=True)[:3]
         st = m.stats()
         out = {"what": label, "value": round(nreads / dt / 1e6, 2), "unit": "Mreads/s", "timed_s": round(dt, 3),
+               "launches_timed": steps * passes * len(job.batches),
                "ms_per_launch": round(dt / (steps * passes * len(job.batches)) * 1e3, 3),
                "top_kernels_ms": {k_: round(v, 3) for v, k_ in top},
                "mapstats": {"unique_pct": round(100.0 * float(st[1]) / max(1.0, float(st[0])), 2), "ambiguous_pct": round(100.0 * float(st[2]) / max(1.0, float(st[0])), 2)}}
+        if roofline:
+            # the key's own roofline: its dominant kernel, the event counters of its last launch, the committed PMC pass of THIS workload
+            cnt = m.counters()
+            L_ = cfg["read_len"]
+            roof, s8d, tag = roofline_block(kern_ms, cnt, job.reads_per_launch, L_, m.threshold(L_), cfg["pe"], cfg["genome"],
+                                            workload_tag(2, cfg, grch38_like, base_cfg=cfg) if grch38_like else None)
+            out["roofline"] = roof
+            out["kernels_ms_per_launch"] = {a: round(b, 4) for a, b in kern_ms.items() if a.startswith("k_")}
+            out["kernels_traffic"] = kernels_traffic_table(tag, s8d)
+            out["counters_last_launch"] = {a: b for a, b in cnt.items() if not isinstance(b, dict)}
         if ref_check and not args.no_cpu:
             # the reference binary on the first ref_check reads / pairs of this key's first launch: the same SAM lines?
             try:
@@ -812,17 +930,25 @@ def driver_run(drv, fa, inp, cfg, extra, env=None):
     if p.returncode:
         raise RuntimeError(p.stderr[-300:])
     lines = [x[len("[bmbs_search] "):] for x in p.stderr.splitlines() if x.startswith("[bmbs_search]")]
-    wall = float([x for x in lines if x.startswith("records") and "mapping wall" in x][-1].split("mapping wall")[1].split("s")[0])
+    rec_line = [x for x in lines if x.startswith("records") and "mapping wall" in x][-1]
+    wall = float(rec_line.split("mapping wall")[1].split("s")[0])
+    records = int(rec_line.split()[1])            # what the driver mapped (reads, or pairs): --loop-input is not taken by every source kind
     busy = {}
     for x in lines:
         if x.startswith("busy fractions"):
             t = x.split(":", 1)[1]
             for key, tag in (("link_up", "link up "), ("link_down", "link down "), ("gpu_workers", "gpu workers "), ("readers", "readers "), ("writers", "writers ")):
                 busy[key] = float(t.split(tag)[1].split(",")[0].split(" ")[0])
-    return wall, busy, " | ".join(lines)[:1100]
+    return wall, busy, " | ".join(lines)[:1100], records
 
 
-def e2e_key(n_reads, wall, busy, stages, loops=1):
+def e2e_key(n_reads, wall, busy, stages, loops=1, records=None, pe=False):
+    # the rate is over the records the DRIVER says it mapped (its --verbose line), not over what the key expected
+    if records is not None:
+        got = records * (2 if pe else 1)
+        if got != int(n_reads):
+            sys.stderr.write("[bench] the driver mapped %d reads where %d were expected (input passes %d): rate over the driver's count\n" % (got, n_reads, loops))
+        n_reads = got
     d = {"value": round(n_reads / wall / 1e6, 2), "unit": "Mreads/s", "mapping_wall_s": wall, "reads": int(n_reads), "input_passes": loops, "busy": busy}
     if busy:
         d["bound"] = max(busy, key=busy.get)
@@ -849,11 +975,11 @@ def gz_input_rate(args, drv, fa, cfg, big, inp_big, rec_bytes, loops):
         a = [gzf[big.index(x)] if x in big else x for x in inp_big]
         k = loops if label == "bgzf" else 1
         try:
-            wall, busy, stages = driver_run(drv, fa, a, cfg, ["-o", "/dev/null"] + (["-t", "32", "--loop-input", str(k)] if label == "bgzf" else []))
-            out[label] = e2e_key(n * k, wall, busy, None, k)
+            wall, busy, stages, recs = driver_run(drv, fa, a, cfg, ["-o", "/dev/null"] + (["-t", "32", "--loop-input", str(k)] if label == "bgzf" else []))
+            out[label] = e2e_key(n * k, wall, busy, None, k, recs, cfg["pe"])
             if label == "bgzf":         # the reference's documented invocation (README.md:44,81): .fastq.gz in, --bam out
-                wall, busy, stages = driver_run(drv, fa, a, cfg, ["-o", "/dev/null", "--bam", "-t", "32", "--loop-input", str(k)])
-                out["bgzf_in_bam_out"] = e2e_key(n * k, wall, busy, None, k)
+                wall, busy, stages, recs = driver_run(drv, fa, a, cfg, ["-o", "/dev/null", "--bam", "-t", "32", "--loop-input", str(k)])
+                out["bgzf_in_bam_out"] = e2e_key(n * k, wall, busy, None, k, recs, cfg["pe"])
         except RuntimeError as ex:
             out[label] = {"error": str(ex)}
         for f in gzf:
@@ -951,8 +1077,8 @@ def file_to_file_rate(args, cfg, fa, L):
         except RuntimeError as ex:
             return {"error": str(ex)}
         got.sort(key=lambda g: g[0])
-        wall, busy, stages, written = got[len(got) // 2]
-        out[label] = e2e_key(n * loops, wall, busy, stages, loops)
+        wall, busy, stages, recs, written = got[len(got) // 2]
+        out[label] = e2e_key(n * loops, wall, busy, stages, loops, recs, cfg["pe"])
         if written:
             out[label]["written_GBps"] = round(written / wall / 1e9, 2)
         if runs > 1:
@@ -1081,22 +1207,8 @@ def main():
         reads_per_step = job.reads_per_step() * passes
         total_reads = reads_per_step * world * args.steps
         value = total_reads / dt / 1e6
-        mapping = {kn: v for kn, v in kern_ms.items() if kn.startswith("k_")}
-        dom = max(mapping, key=mapping.get) if mapping else "k_seed_first"
-        s8d, own = algorithmic_bytes(cnt, nr, L, k, pe)
-        nat = native_bytes(cnt, 2 * cfg["genome"] + 1 >= (1 << 32))
-        tag = "r02_c%d" % args.config
-        for rnd in ("r05", "r04", "r03"):                       # the newest committed PMC pass of this configuration
-            if os.path.exists(os.path.join(ROOT, "profiles", "%s_c%d_pmc_fetch_write.csv" % (rnd, args.config))):
-                tag = "%s_c%d" % (rnd, args.config)
-                break
-        def rl(model):
-            b = model.get(dom, 0)
-            a = b / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms.get(dom, 0) > 0 else 0.0
-            return b, a
-        b8, a8 = rl(s8d)
-        bo, ao = rl(own)
-        traffic = pmc_traffic(dom, tag)
+        wtag = workload_tag(args.config, cfg, args.grch38_like) if not (args.repeats or cfg.get("real_fasta")) else None
+        roof, s8d, tag = roofline_block(kern_ms, cnt, nr, L, k, pe, cfg["genome"], wtag, single)
         out = {
             "metric": "M %dbp %s reads aligned/s" % (L, "PE" if pe else "SE"), "value": round(value, 4), "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -1112,38 +1224,14 @@ def main():
                        "reads_per_gpu_per_step": reads_per_step, "units_per_launch": job.n, "launches_per_step": len(job.batches) * passes,
                        "read_len": L, "genome_bp": cfg["genome"], "timed_s": round(dt, 3),
                        "parallelism": "pairs sharded by rank, index replicated, %s all-reduce of 5 mapstats counters" % ("RCCL" if args.dist_backend == "nccl" else "gloo")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(a8, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(a8 / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(b8), "avg_launch_ms": round(kern_ms.get(dom, 0.0), 4),
-                         "model": "SURVEY 8(d) terms: 10 B/16-mer lookup, 80 B/extension, 4 B/SA read, window bytes, read characters consumed, 32 B/record",
-                         # the builder's own model (adds the seed / carry records this design writes) next to it
-                         "builder_model": {"algorithmic_bytes_per_launch": int(bo), "achieved": round(ao, 3), "frac": round(ao / HBM_PEAK_GBS, 6)},
-                         # ... and what THIS layout has to move for the same events (16-byte Occ blocks, 8-byte outcome-table entries)
-                         "design_native_model": ({"algorithmic_bytes_per_launch": int(nat[dom]), "achieved": round(nat[dom] / (kern_ms[dom] * 1e-3) / 1e9, 3),
-                                                  "frac": round(nat[dom] / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                                  "model": "8 B/lookup (outcome-table entry) + 16 B packed row + 16 B seed record per seed start, 32 B/extension, 4|8 B/SA read"}
-                                                 if dom in nat and kern_ms.get(dom, 0) > 0 else None),
-                         "traffic_rule": fetch_rule(dom)[0], "traffic_profile": tag,
-                         # the same kernel timed ALONE (one lane, same launches, outside the timed region): what round 2's figure was
-                         "single_lane": ({"avg_launch_ms": round(single["kernels_ms"].get(dom, 0.0), 4),
-                                          "achieved": round(s8d.get(dom, 0) / (single["kernels_ms"][dom] * 1e-3) / 1e9, 3),
-                                          "frac": round(s8d.get(dom, 0) / (single["kernels_ms"][dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                          "value_M_reads_s": single["value"], "ms_per_launch": single["ms_per_launch"]}
-                                         if single and single["kernels_ms"].get(dom, 0) > 0 else None),
-                         "traffic_over_algorithmic": round(traffic / b8, 3) if traffic and b8 else None,
-                         # the same kernel against the bound that applies to an index walk: divergent gather requests/s
-                         "gather": gather_roofline(dom, cnt, kern_ms),
-                         "sectors": ({"traffic_GBps": round(traffic / (kern_ms[dom] * 1e-3) / 1e9, 1), "random_sector_ceiling_GBps": SECTOR_CEILING_GBS,
-                                      "frac": round(traffic / (kern_ms[dom] * 1e-3) / 1e9 / SECTOR_CEILING_GBS, 4)} if traffic else None)},
+            "roofline": roof,
             "kernels_ms_per_launch": {a: round(b, 4) for a, b in kern_ms.items()},
             # the same table from the single-lane pass: each kernel alone on the chip (what a kernel change should be read against)
             "kernels_ms_per_launch_single_lane": ({a: round(b, 4) for a, b in single["kernels_ms"].items()} if single else None),
             "kernels_algorithmic_GBps": {kn: round(s8d[kn] / (kern_ms[kn] * 1e-3) / 1e9, 2) for kn in s8d if kern_ms.get(kn, 0) > 0},
             # PMC traffic per launch of every mapping kernel (committed profile of this command), FETCH_SIZE corrected by the rule named,
             # next to the kernel's 8(d) algorithmic bytes
-            "kernels_traffic": {kn: {"fetch_plus_write_bytes": int(t[0] + t[1]), "rule": t[2],
-                                     "over_algorithmic": (round((t[0] + t[1]) / s8d[PROF_NAME.get(kn, kn)], 2) if s8d.get(PROF_NAME.get(kn, kn)) else None)}
-                                for kn, t in sorted(pmc_table(tag).items()) if kn.startswith("k_")},
+            "kernels_traffic": kernels_traffic_table(tag, s8d),
             "counters_last_launch": cnt,
             # one entry per rank: what each GPU mapped per second over its own timed region (value = all reads / the slowest rank's time)
             "per_rank_Mreads_s": [round(reads_per_step * args.steps / t_ / 1e6, 2) for t_ in per_rank_s],
@@ -1225,13 +1313,21 @@ def main():
             if cfg["genome"] >= 1_000_000_000:
                 one_key("grch38_like", "main configuration on a genome of the same size with GRCh38-like repeat content: ~45 % of the bases from nine "
                                                "families (Alu / MIR / L1 / LTR / DNA-transposon-like interspersed copies at 1-30 % divergence, segmental "
-                                               "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True, ref_check=100_000)
+                                               "duplications, alpha-satellite arrays, microsatellites)", one, rank, local, grch38_like=True, ref_check=100_000, roofline=True)
                 one_key("grch38_like_se", "the same GRCh38-like genome, mate 1 alone as 150 bp single-end reads, -e 0.08 (every candidate of a "
-                                                  "single-end read is verified -- no mate prunes the list first)", dict(one, pe=False), rank, local, grch38_like=True)
+                                                  "single-end read is verified -- no mate prunes the list first)", dict(one, pe=False), rank, local, grch38_like=True, roofline=True)
                 one_key("grch38_like_sensitive", "the same GRCh38-like genome, pairs in --sensitive mode (configs[3]'s launch size: 5 M pairs)",
-                                                         dict(one, sensitive=True, units=min(cfg["units"], 5_000_000)), rank, local, grch38_like=True)
+                                                         dict(one, sensitive=True, units=min(cfg["units"], 5_000_000)), rank, local, grch38_like=True, roofline=True)
             one_key("repeats_50000", "46 Mb genome with 50 000 planted diverged 300-bp repeat copies, same mode", small, rank, local, repeats=50000)
             out["secondary"] = sec
+            # the workload BASELINE configs[2]-[4] name is "vs GRCh38": the same launch on the repeat-rich genome, with its own roofline,
+            # at the top level beside `value` (the secondary keys hold the details)
+            for top_key, sec_key in (("value_grch38_like", "grch38_like"), ("value_grch38_like_se", "grch38_like_se"),
+                                     ("value_grch38_like_sensitive", "grch38_like_sensitive")):
+                g_ = sec.get(sec_key)
+                if isinstance(g_, dict) and "value" in g_:
+                    out[top_key] = {"value": g_["value"], "unit": g_["unit"], "timed_s": g_["timed_s"], "ms_per_launch": g_["ms_per_launch"],
+                                    "roofline": g_.get("roofline"), "what": g_["what"]}
         out["wall_s"] = round(time.time() - t_all, 1)
         print(json.dumps(out), flush=True)
     if world > 1:

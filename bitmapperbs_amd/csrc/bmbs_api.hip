@@ -568,7 +568,7 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
             int rm = scan_u32(c, mid_flag, n, c->long_off.as<u64>(), 11, c->sd_list_c.as<u32>());
             if (rm) return rm;
             hipLaunchKernelGGL(k_vote_mid, dim3(nblk(n, 64)), dim3(64), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 11, c->sd_list_c.as<u32>(),
-                               c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>());
+                               c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->counters.as<unsigned long long>());
             prof_end(c);
         }
         // reads with more than 16 candidates (repeats): one block per read
@@ -580,18 +580,18 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         unsigned long long* big_count = c->totals.as<unsigned long long>() + 13;
         HIPCHK(c, hipMemsetAsync(big_count, 0, 8, c->stream));
         hipLaunchKernelGGL((k_vote_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 9,
-                           c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->big_list.as<u32>(), big_count);
+                           c->long_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), c->big_list.as<u32>(), big_count, c->counters.as<unsigned long long>());
         prof_end(c);
         prof_begin(c, "k_vote_big");
         // the handed-over lists in two size classes (as k_vote_pe_long): the <= 1024-key form needs 14 KB of LDS instead of 57 KB, so five
         // times as many reads are in flight -- the vote order (std::sort's permutation, one partition pass after the other) is a
         // chain of barriers, not work
         hipLaunchKernelGGL((k_vote_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
         hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
         hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
-                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr);
+                           c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
         prof_end(c);
     }
     return BMBS_OK;
@@ -1140,27 +1140,30 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
         prof_begin(c, "k_vote_pe_mid");
         rc = scan_u32(c, mid_flag, n2, c->long_off.as<u64>(), 11, c->pe_mid_list.as<u32>());
         if (rc) return rc;
-        hipLaunchKernelGGL(k_vote_pe_mid, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, c->ix, gm, st, ps, c->totals.as<u64>() + 11, c->pe_mid_list.as<u32>(), A);
+        hipLaunchKernelGGL(k_vote_pe_mid, dim3(nblk(n2, 64)), dim3(64), 0, c->stream, c->ix, gm, st, ps, c->totals.as<u64>() + 11, c->pe_mid_list.as<u32>(), A, cnt);
         prof_end(c);
     }
     prof_begin(c, "k_vote_pe_long");
+    // fast mode: located sites without a partner on the mate's finished list are dropped before the sort (k_pe_fast.hip; --sensitive
+    // uses the lists differently, Schema.cpp:19953-21459).  BMBS_PREFILTER=0: off (A/B runs, tests)
+    const int prefilter = (!sensitive && c->kn.prefilter) ? 1 : 0;
     rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
     if (rc) return rc;
     ENS(c, c->big_list, n2 * 4 + 64);
     unsigned long long* big_count = c->totals.as<unsigned long long>() + 13;
     HIPCHK(c, hipMemsetAsync(big_count, 0, 8, c->stream));
     hipLaunchKernelGGL((k_vote_pe_long<VM_CAP, VM_BLOCK, VOTE_REG>), dim3(32768), dim3(VM_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A, c->big_list.as<u32>(), big_count, c->cand.as<u64>());
+                       c->totals.as<u64>() + 9, c->long_list.as<u32>(), A, c->big_list.as<u32>(), big_count, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
     prof_end(c);
     prof_begin(c, "k_vote_pe_big");
     // the handed-over lists in two size classes: up to 1024 candidates (10 KB of LDS per block: twice the blocks per CU of the
     // 4096-key form; on the GRCh38-like genome 88 % of the handed-over lists), and the rest
     hipLaunchKernelGGL((k_vote_pe_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
     hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
     hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
-                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>());
+                       c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {
@@ -1191,7 +1194,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
         // 10 M pairs, 4 % of a launch on a repeat-poor genome.  BMBS_PEF_LONG=0: never, =2: always
         u32* pef_flag = (c->kn.pef_long == 2 || (c->kn.pef_long == 1 && c->lr_long > 0.005)) ? c->long_flag.as<u32>() : nullptr;
         if (pef_flag) HIPCHK(c, hipMemsetAsync(pef_flag, 0, n * 4, c->stream));
-        hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B, pef_flag);
+        hipLaunchKernelGGL(k_pe_filter_pairs, dim3(nblk(n, 64)), dim3(64), 0, c->stream, (long)n, gm, pi, st, ps, A, B, pef_flag, cnt);
         if (pef_flag) {
             rc = scan_u32(c, pef_flag, n, c->long_off.as<u64>(), 12, c->long_list.as<u32>());
             if (rc) return rc;
@@ -1257,7 +1260,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
             // mates with more than PESV_LONG candidates are flagged, listed (slot 14) and sorted by a block each
             u32* pv_flag = c->long_flag.as<u32>();                                  // n2 words: free again after the vote stage
             hipLaunchKernelGGL(k_pes_vote, dim3(nblk(rt[0], 64)), dim3(64), 0, c->stream, c->ix, (long)n, gm, pi, n_reseed, rlist,
-                               c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B, pv_flag);
+                               c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B, pv_flag, cnt);
             if (pv_flag) {
                 rc = scan_u32(c, pv_flag, rt[0], c->long_off.as<u64>(), 14, c->long_list.as<u32>(), 0, n_reseed);
                 if (rc) return rc;

@@ -21,6 +21,22 @@
 #define DEVI __device__ __forceinline__
 
 #define SHARD(p) ((p) + (size_t)(blockIdx.x & (BMBS_SHARDS - 1)) * BMBS_SHARD_WORDS)
+// event counter words beyond the seeding ones (bmbs_counters_all): what the list kernels handled, for the per-kernel byte terms of the
+// bench line.  (-DBMBS_UTIL builds overload words 8..13 with lane-utilisation probes.)
+#define CNT_CAND_MID   9      // candidates located by k_vote_mid / k_vote_pe_mid (lists of 17..32)
+#define CNT_CAND_LONG 10      // ... by the wave form of k_vote_long / k_vote_pe_long (33..256)
+#define CNT_CAND_BIG  11      // ... by their block forms (beyond 256)
+#define CNT_LISTS_LONG 12     // lists the wave and block forms took
+#define CNT_PEF_ENTRIES 13    // list entries filter_pairs read (both mates of the pairs that ran it)
+#define CNT_CAND_RESEED 14    // candidates located by k_pes_vote[_long] (--sensitive re-seeding)
+#define CNT_PREFILTER_DROP 15 // located sites the paired-end vote kernels dropped before their sort (no partner on the mate's list)
+// sum of v over the 64 lanes of a wave (EVERY lane has to arrive), one atomic per wave
+DEVI void wave_count_add(unsigned long long* counters, int word, u32 v)
+{
+    if (!counters) return;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&SHARD(counters)[word], (unsigned long long)v);
+}
 
 // ---- per-wave timeline (diagnostic, BMBS_WAVELOG=<file>) ------------------------------------------------------------------------
 // A kernel that calls wavelog_begin / wavelog_end records for each of its working waves where it ran (XCC, SE, CU, SIMD), when

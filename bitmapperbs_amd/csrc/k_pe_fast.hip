@@ -306,14 +306,16 @@ k_vote_pe_fused(DevIndex ix, long n2, ReadGeom gm, ReadState st, PeState ps, u64
 // located into registers and sorted by a bitonic network -- the paired-end counterpart of k_vote_mid (no vote order here)
 __global__ void __launch_bounds__(64)
 k_vote_pe_mid(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
-              PeCand* __restrict__ A)
+              PeCand* __restrict__ A, unsigned long long* __restrict__ counters)
 {
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= (long)*count_ptr) return;
-    const long r = list[it];
+    const bool act = it < (long)*count_ptr;
+    const long r = act ? (long)list[it] : 0;
+    const long nc = act ? (long)st.n_cand[r] : 0;
+    wave_count_add(counters, CNT_CAND_MID, (u32)nc);
+    if (!act) return;
     const int L = gm.rl(r), k = gm.rk(L);
     const int v = st.verdict[r];
-    const long nc = (long)st.n_cand[r];
     const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
     const int ns = st.n_seeds[r];
     PeCand* o = A + st.cand_off[r];
@@ -363,66 +365,176 @@ k_vote_pe_mid(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __r
     }
 }
 
+// ---- filter_pairs in front of the sort (round 6) ---------------------------------------------------------------------------------------
+// A read inside a repeat family locates hundreds to thousands of sites; filter_pairs (Schema.cpp:16052-16164) then keeps the few that
+// have a partner on the mate's list within the insert window, and nothing else ever reads the unfiltered list (get_candidates hands it
+// straight to filter_pairs, Schema.cpp:19055-19110; fast mode does not order the list by votes).  So when the mate's list is FINAL
+// before this read's is sorted -- it came from a kernel that ran earlier (a smaller size class), or from this very block (both mates in
+// one class: the one with fewer candidates goes first) -- every located site is tested against it first (a binary search for an entry
+// within maxd of the entry the site becomes) and only the survivors are sorted and made distinct.  Exact under the conditions
+// k_pe_filter_pairs_long already relies on (lower distance bound <= 0, no site wrapped below zero): an entry survives filter_pairs
+// iff the other list holds a site within maxd of it, so dropping the others early changes neither list's filtered form; filter_pairs
+// itself still runs afterwards, on the short list.
+DEVI long pe_lower_bound_u64(const u64* v, long n, u64 key)
+{
+    long lo = 0, hi = n;
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (v[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+DEVI long pe_lower_bound(const PeCand* v, long n, u64 key);
+#define PREF_STAGE 256          // mate lists of up to this many entries are searched out of LDS
+// keys[0, cnt): located raw sites -> the ones with a partner on `mate` (ascending sites), compacted in place, in order; returns their
+// number, or -1 when the list holds a site that wrapped below zero (the reference's mixed comparisons decide there: no pre-filter)
+template <int EMAX>
+DEVI int pe_prefilter(u64* keys, int cnt, int k, const PeCand* mate, long nm, u64 maxd, u64* sh_mate, int* sh_w)
+{
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int E = (cnt + T - 1) / T;
+    const bool staged = nm <= PREF_STAGE;
+    if (staged) for (int i = tid; i < (int)nm; i += T) sh_mate[i] = mate[i].site;
+    __syncthreads();
+    u64 mine[EMAX];
+    u32 keep = 0;
+    bool wrapped = false;
+    int kept = 0;
+#pragma unroll
+    for (int e = 0; e < EMAX; e++) {
+        const int idx = tid * E + e;
+        if (e < E && idx < cnt) {
+            const u64 c = keys[idx];
+            mine[e] = c;
+            wrapped |= (c >> 63) != 0;
+            const u64 x = c < (u64)k ? 0 : c - (u64)k;
+            const u64 lo = x > maxd ? x - maxd : 0;
+            bool ok;
+            if (staged) { const long j = pe_lower_bound_u64(sh_mate, nm, lo); ok = j < nm && (sh_mate[j] <= x || sh_mate[j] - x <= maxd); }
+            else { const long j = pe_lower_bound(mate, nm, lo); ok = j < nm && (mate[j].site <= x || mate[j].site - x <= maxd); }
+            if (ok) { keep |= 1u << e; kept++; }
+        }
+    }
+    if (__syncthreads_or(wrapped ? 1 : 0)) return -1;           // (also: every key is in registers)
+    int incl = kept;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) sh_w[w] = incl;
+    __syncthreads();
+    int base = incl - kept, total = 0;
+    for (int q = 0; q < (T + 63) / 64; q++) { const int x = sh_w[q]; if (q < w) base += x; total += x; }
+#pragma unroll
+    for (int e = 0; e < EMAX; e++) if (keep & (1u << e)) keys[base++] = mine[e];
+    __syncthreads();
+    return total;
+}
+
 // the paired-end counterpart of k_vote_long: no vote order here, so everything is parallel (general reads: one entry per
 // distinct site; exact-ambiguous reads: every hit)
 template <int CAP, int BLOCK, int LO>
 __global__ void __launch_bounds__(BLOCK)
 k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
-               PeCand* __restrict__ A, u32* __restrict__ big_list, unsigned long long* __restrict__ big_count, u64* __restrict__ cand)
+               PeCand* __restrict__ A, u32* __restrict__ big_list, unsigned long long* __restrict__ big_count, u64* __restrict__ cand,
+               unsigned long long* __restrict__ counters, long n_pairs, PeIns pi, int prefilter, const u32* __restrict__ long_flag)
 {
     __shared__ u64 keys[CAP];
     __shared__ u16 endpos[CAP];
     __shared__ u32 sh_pref[BMBS_MAX_SEEDS + 1];
     __shared__ int sh_w[2 * (BLOCK / 64) + 1];
+    __shared__ u64 sh_mate[PREF_STAGE];
+    constexpr int EMAX = (CAP + BLOCK - 1) / BLOCK;
+    auto in_class = [](long nc) { return nc > LO && (CAP == VL_CAP || nc <= CAP); };
+    // is read x's list built by one of these size-class kernels at all (k_vote_pe_fused / _mid wrote the others before this launch)
+    auto listed = [&](long x) { return long_flag[x] != 0; };
     const long total_items = (long)*count_ptr;
     for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
-        const long r = list[item];
-        const long nc = (long)st.n_cand[r];
+        const long r0 = list[item];
+        const long nc0 = (long)st.n_cand[r0];
         // the wave form sees every listed read and passes the ones beyond its capacity on (a list of their own: the block form used
         // to walk the whole list -- millions of reads on a repeat-rich genome, two dependent loads each -- to find its few)
-        if (big_list && nc > CAP) { if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1ull)] = (u32)r; continue; }
-        if (nc <= LO || (CAP != VL_CAP && nc > CAP)) continue;       // another instance's size class (the largest also takes what is beyond it)
-        const int L = gm.rl(r), k = gm.rk(L);
-        const int v = st.verdict[r];
-        PeCand* o = A + st.cand_off[r];
-        if (nc > CAP) {
-            // beyond the LDS capacity: sorted in tiles (vl_sort_huge; the output segment parks the tiles), then the same entries in order
-            u64* c = cand + st.cand_off[r];
-            vl_sort_huge<CAP, BLOCK>(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], nc, keys, sh_pref, reinterpret_cast<u64*>(o), c);
-            if (v == 4) {
-                for (long i = threadIdx.x; i < nc; i += BLOCK) { PeCand e; e.site = c[i]; e.err = 0; e.end = L - 1; o[i] = e; }
-                if (threadIdx.x == 0) { ps.occ[r] = (int)nc; ps.len[r] = (u32)nc; }
-            } else {
-                int running = 0;
-                for (long base = 0; base < nc; base += BLOCK) {
-                    const long i = base + (long)threadIdx.x;
-                    bool keep = false;
-                    u64 key = 0;
-                    if (i < nc) { key = c[i]; keep = i == nc - 1 || c[i + 1] != key; }
-                    int tot;
-                    const int pre = vl_prefix(keep, sh_w, tot);
-                    if (keep) { PeCand e; e.site = key < (u64)k ? 0 : key - (u64)k; e.err = 0; e.end = 0; o[running + pre] = e; }
-                    running += tot;
+        if (big_list && nc0 > CAP) { if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1ull)] = (u32)r0; continue; }
+        if (!in_class(nc0)) continue;                               // another instance's size class (the largest also takes what is beyond it)
+        // both mates in this class: ONE block takes them, the one with fewer candidates first (ties: mate 1), so that the second is
+        // filtered against a finished list
+        const long m0 = r0 < n_pairs ? r0 + n_pairs : r0 - n_pairs;
+        const bool mate_here = prefilter && listed(m0) && in_class((long)st.n_cand[m0]);
+        if (mate_here) {
+            const long ncm = (long)st.n_cand[m0];
+            if (ncm < nc0 || (ncm == nc0 && m0 < r0)) continue;    // the mate's block does both
+        }
+        for (int turn = 0; turn < (mate_here ? 2 : 1); turn++) {
+            const long r = turn ? m0 : r0;
+            const long m = turn ? r0 : m0;
+            const long nc = (long)st.n_cand[r];
+            if (counters && threadIdx.x == 0) {
+                atomicAdd(&SHARD(counters)[CAP == VM_CAP ? CNT_CAND_LONG : CNT_CAND_BIG], (unsigned long long)nc);
+                atomicAdd(&SHARD(counters)[CNT_LISTS_LONG], 1ull);
+            }
+            const int L = gm.rl(r), k = gm.rk(L);
+            const int v = st.verdict[r];
+            PeCand* o = A + st.cand_off[r];
+            if (nc > CAP) {
+                // beyond the LDS capacity: sorted in tiles (vl_sort_huge; the output segment parks the tiles), then the same entries in order
+                u64* c = cand + st.cand_off[r];
+                vl_sort_huge<CAP, BLOCK>(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], nc, keys, sh_pref, reinterpret_cast<u64*>(o), c);
+                if (v == 4) {
+                    for (long i = threadIdx.x; i < nc; i += BLOCK) { PeCand e; e.site = c[i]; e.err = 0; e.end = L - 1; o[i] = e; }
+                    if (threadIdx.x == 0) { ps.occ[r] = (int)nc; ps.len[r] = (u32)nc; }
+                } else {
+                    int running = 0;
+                    for (long base = 0; base < nc; base += BLOCK) {
+                        const long i = base + (long)threadIdx.x;
+                        bool keep = false;
+                        u64 key = 0;
+                        if (i < nc) { key = c[i]; keep = i == nc - 1 || c[i + 1] != key; }
+                        int tot;
+                        const int pre = vl_prefix(keep, sh_w, tot);
+                        if (keep) { PeCand e; e.site = key < (u64)k ? 0 : key - (u64)k; e.err = 0; e.end = 0; o[running + pre] = e; }
+                        running += tot;
+                    }
+                    if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)running; }
                 }
-                if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)running; }
+                __threadfence();                               // (a second turn reads this list from memory)
+                __syncthreads();
+                continue;
             }
+            vl_locate_range(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], 0, (int)nc, keys, sh_pref, true);
+            int cnt = (int)nc;
+            // the mate's list is final when an earlier kernel wrote it (verdicts 1 / 2 / none, lists of a smaller class) or this block
+            // just did (turn 1)
+            if (prefilter && v == 3) {
+                const bool mate_final = turn == 1 || !listed(m) || (long)st.n_cand[m] <= LO;
+                long long maxd, mind; int large_k;
+                pe_bounds(gm, pi, r < n_pairs ? r : r - n_pairs, n_pairs, maxd, mind, large_k);
+                if (mate_final && mind <= 0 && maxd >= 0) {
+                    const int occm = ps.occ[m];
+                    const long nm = occm == 0 ? 0 : (long)ps.len[m];
+                    const PeCand* ml = A + st.cand_off[m];
+                    if (nm == 0) cnt = 0;                           // the pair is dead whatever this list holds (Schema.cpp:19084-19090)
+                    else if (!(ml[nm - 1].site >> 63)) {
+                        const int kept = pe_prefilter<EMAX>(keys, cnt, k, ml, nm, (u64)maxd, sh_mate, sh_w);
+                        if (kept >= 0) cnt = kept;
+                    }
+                    if (cnt < (int)nc && counters && threadIdx.x == 0) atomicAdd(&SHARD(counters)[CNT_PREFILTER_DROP], (unsigned long long)(nc - cnt));
+                }
+            }
+            if (cnt == 0) {
+                if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = 0; }
+                __syncthreads();
+                continue;
+            }
+            vl_sort_keys<EMAX>(keys, cnt);
+            if (v == 4) {
+                for (long i = threadIdx.x; i < cnt; i += BLOCK) { PeCand e; e.site = keys[i]; e.err = 0; e.end = L - 1; o[i] = e; }
+                if (threadIdx.x == 0) { ps.occ[r] = (int)cnt; ps.len[r] = (u32)cnt; }
+            } else {
+                const int nv = vl_run_ends(keys, cnt, endpos, sh_w);
+                for (int e2 = threadIdx.x; e2 < nv; e2 += BLOCK) {
+                    const u64 site = keys[endpos[e2]];
+                    PeCand e; e.site = site < (u64)k ? 0 : site - (u64)k; e.err = 0; e.end = 0;
+                    o[e2] = e;
+                }
+                if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)nv; }
+            }
+            __threadfence();
             __syncthreads();
-            continue;
         }
-        vl_locate_sort<(CAP + BLOCK - 1) / BLOCK>(ix, st.seeds + (size_t)r * BMBS_MAX_SEEDS, st.n_seeds[r], (int)nc, keys, sh_pref);
-        if (v == 4) {
-            for (long i = threadIdx.x; i < nc; i += BLOCK) { PeCand e; e.site = keys[i]; e.err = 0; e.end = L - 1; o[i] = e; }
-            if (threadIdx.x == 0) { ps.occ[r] = (int)nc; ps.len[r] = (u32)nc; }
-        } else {
-            const int nv = vl_run_ends(keys, (int)nc, endpos, sh_w);
-            for (int e2 = threadIdx.x; e2 < nv; e2 += BLOCK) {
-                const u64 site = keys[endpos[e2]];
-                PeCand e; e.site = site < (u64)k ? 0 : site - (u64)k; e.err = 0; e.end = 0;
-                o[e2] = e;
-            }
-            if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)nv; }
-        }
-        __syncthreads();
     }
 }
 
@@ -476,18 +588,24 @@ DEVI void pe_filter_serial(const PeCand* a, long na, const PeCand* b, long nb, l
 }
 #define PEF_LONG 24       // pairs whose two lists hold more candidates than this go to k_pe_filter_pairs_long (one wave per pair)
 __global__ void __launch_bounds__(64)
-k_pe_filter_pairs(long n, ReadGeom gm, PeIns pi, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B, u32* __restrict__ long_flag)
+k_pe_filter_pairs(long n, ReadGeom gm, PeIns pi, ReadState st, PeState ps, PeCand* __restrict__ A, PeCand* __restrict__ B, u32* __restrict__ long_flag,
+                  unsigned long long* __restrict__ counters)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long r1 = p, r2 = p + n;
+    int occ1 = 1, occ2 = 1;
+    if (p < n) {
+        occ1 = ps.occ[r1]; occ2 = ps.occ[r2];
+        ps.dead[p] = 0; ps.both[p] = 0; ps.npair[p] = 0; ps.sbd[p] = 0;
+    }
+    const bool runs = p < n && !(occ1 > 0 && occ2 > 0) && occ1 != 0 && occ2 != 0;       // filter_pairs is reached (Schema.cpp:19084-19110)
+    const long na = runs ? (long)ps.len[r1] : 0, nb = runs ? (long)ps.len[r2] : 0;
+    wave_count_add(counters, CNT_PEF_ENTRIES, (u32)(na + nb));
     if (p >= n) return;
     long long maxd, mind; int large_k;
     pe_bounds(gm, pi, p, n, maxd, mind, large_k);
-    const long r1 = p, r2 = p + n;
-    int occ1 = ps.occ[r1], occ2 = ps.occ[r2];
-    ps.dead[p] = 0; ps.both[p] = 0; ps.npair[p] = 0; ps.sbd[p] = 0;
     if (occ1 > 0 && occ2 > 0) return;
     if (occ1 == 0 || occ2 == 0) { ps.dead[p] = 1; return; }
-    const long na = ps.len[r1], nb = ps.len[r2];
     // in a repeat-rich genome one pair in a few has lists of dozens to thousands of candidates: a lane that walks them alone holds its
     // wave for as long (k_pe_filter_pairs: 0.46 ms per 10 M pairs on the uniform genome, 12.8 ms on the GRCh38-like one)
     if (long_flag && na + nb > PEF_LONG) { long_flag[p] = 1; return; }

@@ -236,10 +236,12 @@ k_pes_reseed(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom 
 __global__ void __launch_bounds__(64)
 k_pes_vote(DevIndex ix, long n, ReadGeom gm, PeIns pi, const u64* __restrict__ count_ptr, const u32* __restrict__ plist,
            const u64* __restrict__ roff, ReadState st, PeState ps, u64* __restrict__ rcand, PeCand* __restrict__ A, PeCand* __restrict__ B,
-           u32* __restrict__ long_flag)
+           u32* __restrict__ long_flag, unsigned long long* __restrict__ counters)
 {
     const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= (long)*count_ptr) return;
+    const bool act_ = it < (long)*count_ptr;
+    wave_count_add(counters, CNT_CAND_RESEED, act_ ? (u32)(roff[it + 1] - roff[it]) : 0u);
+    if (!act_) return;
     if (long_flag) long_flag[it] = 0;
     const long p = plist[it];
     const int f = ps.first[p];

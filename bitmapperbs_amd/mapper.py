@@ -397,6 +397,10 @@ class Mapper:
         keys = ("n_hash", "n_ext", "n_sa", "n_filter", "n_sw", "n_ungapped", "n_cand_slots", "n_jobs")
         d = {k: int(v) for k, v in zip(keys, c[:8])}
         d["n_jump"] = int(c[8])          # three-letter index steps taken (each counts three in n_ext)
+        # what the list kernels handled (round 6): candidates located by the mid / wave / block forms, their lists, the entries
+        # filter_pairs read, re-seeded candidates (--sensitive), sites dropped by the paired-end pre-filter
+        for j, nm in enumerate(("n_cand_mid", "n_cand_long", "n_cand_big", "n_lists_long", "n_pef_entries", "n_cand_reseed", "n_prefilter_drop")):
+            d[nm] = int(c[9 + j])
         for kid, nm in enumerate(("k_seed_first", "k_seed_second", "k_seed_extra")):
             d[nm] = {"n_hash": int(c[16 + 4 * kid]), "n_ext": int(c[17 + 4 * kid]), "n_sa": int(c[18 + 4 * kid])}
         return d

@@ -345,8 +345,10 @@ int bmbs_profile_reset(bmbs_ctx*);
  * c[0]=n_hash c[1]=n_ext(LF pairs) c[2]=n_sa c[3]=n_cand(windows filtered) c[4]=n_sw(jobs that ran the DP) c[5]=n_ungapped
  * c[6]=window bytes                                                                               */
 int bmbs_counters_last(bmbs_ctx*, uint64_t c[8]);
-/* all 32 words: c[0..7] as above, c[8] three-letter index steps taken (each counts three in c[1]), c[9..15] lane-utilisation probes
- * (diagnostic builds), c[16+4*kid+{0,1,2,3}] =
+/* all 32 words: c[0..7] as above, c[8] three-letter index steps taken (each counts three in c[1]); what the list kernels handled:
+ * c[9] / c[10] / c[11] candidates located by the kernels for lists of 17..32 / 33..256 / more entries, c[12] lists of more than 32,
+ * c[13] list entries filter_pairs read, c[14] candidates of re-seeded mates (--sensitive), c[15] located sites the paired-end vote
+ * kernels dropped before sorting (no partner on the mate's list); c[16+4*kid+{0,1,2,3}] =
  * n_hash, n_ext, n_sa, n_ungapped of seeding kernel kid (0 k_seed_first, 1 k_seed_second, 2 k_seed_extra)          */
 int bmbs_counters_all(bmbs_ctx*, uint64_t c[32]);
 /* calls that were issued a second time with exact buffer sizes because a stage count (candidate slots, DP jobs, re-seeded
