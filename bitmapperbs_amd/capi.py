@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("BMBS_LIB") or os.path.join(_HERE, "libbmbs_hip.so")  
 # every symbol include/bmbs.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "bmbs_default_params", "bmbs_create", "bmbs_destroy", "bmbs_last_error", "bmbs_index_attach", "bmbs_index_share",
-    "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se", "bmbs_map_se_device",
+    "bmbs_locate_batch", "bmbs_vote_order_batch", "bmbs_window_batch", "bmbs_filter_batch", "bmbs_filter_batch_packed", "bmbs_align_batch", "bmbs_seed_batch", "bmbs_map_se", "bmbs_map_se_device",
     "bmbs_map_se_fastq", "bmbs_map_pe_fastq", "bmbs_map_pe", "bmbs_map_pe_device", "bmbs_map_se_var", "bmbs_map_se_var_device", "bmbs_map_pe_var", "bmbs_map_pe_var_device",
     "bmbs_sync", "bmbs_stats_get", "bmbs_stats_reset", "bmbs_stats_allreduce", "bmbs_profile_last",
     "bmbs_counters_last", "bmbs_counters_all", "bmbs_index_file_load", "bmbs_index_file_view", "bmbs_index_file_chrom_name",
@@ -105,6 +105,9 @@ def lib() -> C.CDLL:
     L.bmbs_window_batch.argtypes = [vp, vp, i64, i32, vp]
     L.bmbs_vote_order_batch.argtypes = [vp, vp, vp, i64, i32, vp]
     L.bmbs_filter_batch.argtypes = [vp, vp, i32, i32, i64, vp, vp, i64, vp, vp]
+    if hasattr(L, "bmbs_filter_batch_packed"):          # (BMBS_LIB may name an older build in same-box comparisons: tools/ab_*.sh)
+        L.bmbs_filter_batch_packed.argtypes = [vp, vp, i32, i32, i64, vp, vp, i64, vp, vp]
+        L.bmbs_filter_batch_packed.restype = C.c_int
     L.bmbs_align_batch.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i32]
     L.bmbs_seed_batch.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.bmbs_map_se.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, i64, C.POINTER(i64)]

@@ -522,6 +522,21 @@ int cand_total(Lane* c, const ReadState& st, u64 n, bool exact, u64* tot_out)
     return BMBS_OK;
 }
 
+// what the lane's stream has done so far is visible to its two side streams (side_fork); what they did since is waited for by the
+// lane's stream (side_join).  BMBS_SIDE=0: everything on the lane's stream (the round-5 sequence)
+static inline hipStream_t side_fork(Lane* c, int q)
+{
+    if (!c->kn.side || !c->side_stream[q]) return c->stream;
+    if (q == 0) (void)hipEventRecord(c->ev_fork, c->stream);
+    (void)hipStreamWaitEvent(c->side_stream[q], c->ev_fork, 0);
+    return c->side_stream[q];
+}
+static inline void side_join(Lane* c)
+{
+    if (!c->kn.side) return;
+    for (int q = 0; q < 2; q++) if (c->side_stream[q]) { (void)hipEventRecord(c->ev_side[q], c->side_stream[q]); (void)hipStreamWaitEvent(c->stream, c->ev_side[q], 0); }
+}
+
 // stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
 int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, u64* total_cand, int pe_mode = 0, bool exact = true, bool prepacked = false)
 {
@@ -586,12 +601,15 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         // the handed-over lists in two size classes (as k_vote_pe_long): the <= 1024-key form needs 14 KB of LDS instead of 57 KB, so five
         // times as many reads are in flight -- the vote order (std::sort's permutation, one partition pass after the other) is a
         // chain of barriers, not work
+        const hipStream_t s_cls1 = side_fork(c, 0), s_cls2 = side_fork(c, 1);
         hipLaunchKernelGGL((k_vote_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
                            c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
-        hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+        // (the three classes side by side: the largest has a few dozen lists per launch, each a long chain of serial steps)
+        hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, s_cls1, c->ix, gm, st, c->totals.as<u64>() + 13,
                            c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
-        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
+        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, s_cls2, c->ix, gm, st, c->totals.as<u64>() + 13,
                            c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
+        side_join(c);
         prof_end(c);
     }
     return BMBS_OK;
@@ -635,6 +653,12 @@ Lane* lane_create(int device_id, const bmbs_params& prm, const Knobs& kn, bool f
     (void)hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming);
+    // (only when asked for: every stream of the process takes a place on one of the runtime's hardware queues, and two streams that
+    // share a queue run one behind the other -- with these streams present the two lanes of a context stopped overlapping, round 6)
+    if (c->kn.side) {
+        for (int q = 0; q < 2; q++) { (void)hipStreamCreateWithFlags(&c->side_stream[q], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&c->ev_side[q], hipEventDisableTiming); }
+        (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    }
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
     const size_t shard_bytes = BMBS_SHARDS * BMBS_SHARD_WORDS * 8;
@@ -701,6 +725,8 @@ void lane_destroy(Lane* c)
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int q = 0; q < 2; q++) { if (c->ev_side[q]) (void)hipEventDestroy(c->ev_side[q]); if (c->side_stream[q]) (void)hipStreamDestroy(c->side_stream[q]); }
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1146,7 +1172,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     prof_begin(c, "k_vote_pe_long");
     // fast mode: located sites without a partner on the mate's finished list are dropped before the sort (k_pe_fast.hip; --sensitive
     // uses the lists differently, Schema.cpp:19953-21459).  BMBS_PREFILTER=0: off (A/B runs, tests)
-    const int prefilter = (!sensitive && c->kn.prefilter) ? 1 : 0;
+    const int prefilter = (!sensitive && c->kn.prefilter) ? (c->kn.side ? 2 : 1) : 0;       // 2: the block classes run side by side (side_fork)
     rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
     if (rc) return rc;
     ENS(c, c->big_list, n2 * 4 + 64);
@@ -1158,12 +1184,14 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     prof_begin(c, "k_vote_pe_big");
     // the handed-over lists in two size classes: up to 1024 candidates (10 KB of LDS per block: twice the blocks per CU of the
     // 4096-key form; on the GRCh38-like genome 88 % of the handed-over lists), and the rest
+    const hipStream_t s_cls1 = side_fork(c, 0), s_cls2 = side_fork(c, 1);       // (the three classes side by side, as in run_seed_stages)
     hipLaunchKernelGGL((k_vote_pe_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
-    hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
+    hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, s_cls1, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
-    hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
+    hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, s_cls2, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
+    side_join(c);
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {
@@ -1264,10 +1292,12 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
             if (pv_flag) {
                 rc = scan_u32(c, pv_flag, rt[0], c->long_off.as<u64>(), 14, c->long_list.as<u32>(), 0, n_reseed);
                 if (rc) return rc;
+                const hipStream_t s_pv = side_fork(c, 0);
                 hipLaunchKernelGGL((k_pes_vote_long<1024, 128, PESV_LONG>), dim3(8192), dim3(128), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
                                    c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
-                hipLaunchKernelGGL((k_pes_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
+                hipLaunchKernelGGL((k_pes_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, s_pv, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
                                    c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
+                if (c->kn.side && c->side_stream[0]) { (void)hipEventRecord(c->ev_side[0], c->side_stream[0]); (void)hipStreamWaitEvent(c->stream, c->ev_side[0], 0); }
             }
             prof_end(c);
             rc = verify_round(3, rt[1], "k_filter_pe_r3", "k_pe_compact_r3");
@@ -1772,7 +1802,7 @@ static int lane_window_batch(Lane* c, const uint64_t* site, int64_t n_sites, int
 
 static int lane_filter_batch(Lane* c, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
                                  const uint32_t* read_of, const uint64_t* site, int64_t n_cand, uint32_t* err,
-                                 int32_t* end_site)
+                                 int32_t* end_site, bool packed)
 {
     if (!c) return BMBS_EINVAL;
     if (!c->attached) { c->err = "no index attached"; return BMBS_ESTATE; }
@@ -1787,7 +1817,20 @@ static int lane_filter_batch(Lane* c, const char* seq, int32_t L, int32_t stride
     { int ds = 0; int r1 = upload_rows(c, c->in_seq, seq, L, stride, (u64)n_reads, &ds); if (r1) return r1; stride = ds; (void)bytes; }
     HIPCHK(c, hipMemcpyAsync(c->in_a.p, read_of, m * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->in_b.p, site, m * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_filter_pairs, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_seq.as<char>(), geom(c, L, nullptr), stride, m,
+    PackedRows pr = {nullptr, nullptr, 0, 0};
+    const ReadGeom gm = geom(c, L, nullptr);
+    if (packed) {
+        // the rows packed on the device exactly as the mapping calls pack them (k_pack_rows: 2 bits per base + the not-ACGT plane and the
+        // per-row dirty byte), then the Myers form those calls run (bpm_planes<W, true>)
+        const u64 nrd = (u64)n_reads;
+        const int pwords = pack_words(gm.L), W = pack_base_words(gm.L);
+        { int rz_ = ensure(c, c->prow, nrd * (u64)pwords * 8 + 64, true); if (rz_) return rz_; } ENS(c, c->prow_dirty, nrd + 64);
+        HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, nrd + 64, c->stream));
+        hipLaunchKernelGGL(k_pack_rows, dim3(nblk(nrd * (u64)(stride / 16), 256)), dim3(256), 0, c->stream, c->in_seq.as<char>(), gm, stride, (long)nrd,
+                           c->prow.as<u64>(), pwords, W, c->prow_dirty.as<u32>());
+        pr.base = c->prow.as<u64>(); pr.dirty = c->prow_dirty.as<u8>(); pr.pwords = pwords; pr.W = W;
+    }
+    hipLaunchKernelGGL(k_filter_pairs, dim3(nblk(m, 256)), dim3(256), 0, c->stream, c->ix, c->in_seq.as<char>(), pr, gm, stride, m,
                        c->in_a.as<u32>(), c->in_b.as<u64>(), c->ferr.as<u32>(), c->fend.as<int>());
     HIPCHK(c, hipMemcpyAsync(err, c->ferr.p, m * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(end_site, c->fend.p, m * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2047,7 +2090,10 @@ extern "C" int bmbs_vote_order_batch(bmbs_ctx* X, const uint8_t* vote, const int
 extern "C" int bmbs_window_batch(bmbs_ctx* X, const uint64_t* site, int64_t n_sites, int32_t len, char* out) { ON_LANE0(lane_window_batch(c, site, n_sites, len, out)); }
 extern "C" int bmbs_filter_batch(bmbs_ctx* X, const char* seq, int32_t L, int32_t stride, int64_t n_reads, const uint32_t* read_of, const uint64_t* site,
                                  int64_t n_cand, uint32_t* err, int32_t* end_site)
-{ ON_LANE0(lane_filter_batch(c, seq, L, stride, n_reads, read_of, site, n_cand, err, end_site)); }
+{ ON_LANE0(lane_filter_batch(c, seq, L, stride, n_reads, read_of, site, n_cand, err, end_site, false)); }
+extern "C" int bmbs_filter_batch_packed(bmbs_ctx* X, const char* seq, int32_t L, int32_t stride, int64_t n_reads, const uint32_t* read_of, const uint64_t* site,
+                                        int64_t n_cand, uint32_t* err, int32_t* end_site)
+{ ON_LANE0(lane_filter_batch(c, seq, L, stride, n_reads, read_of, site, n_cand, err, end_site, true)); }
 extern "C" int bmbs_align_batch(bmbs_ctx* X, const char* seq, const char* qual, int32_t L, int32_t stride, int64_t n_reads, const uint32_t* read_of,
                                 const uint64_t* site, const int32_t* end_site_in, const uint32_t* err_in, int64_t n_jobs, int32_t* start_site,
                                 int32_t* end_site, uint32_t* nm, int32_t* score, uint32_t* cigar_ops, int32_t* n_ops, int32_t max_ops)

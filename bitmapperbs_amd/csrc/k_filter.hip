@@ -265,7 +265,7 @@ k_window(DevIndex ix, const u64* __restrict__ site, long n, int len, char* __res
 
 // standalone form for bmbs_filter_batch: explicit (read, site) pairs
 __global__ void __launch_bounds__(256)
-k_filter_pairs(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int stride, u64 n_cand,
+k_filter_pairs(DevIndex ix, const char* __restrict__ seq, PackedRows pr, ReadGeom gm, int stride, u64 n_cand,
                const u32* __restrict__ read_of, const u64* __restrict__ site,
                u32* __restrict__ ferr, int* __restrict__ fend)
 {
@@ -273,6 +273,7 @@ k_filter_pairs(DevIndex ix, const char* __restrict__ seq, ReadGeom gm, int strid
     if (g >= n_cand) return;
     u32 e; int es;
     const int L = gm.rl(read_of[g]), k = gm.rk(L);
-    bpm_one(ix, seq + (size_t)read_of[g] * stride, L, k, site[g], e, es);
+    // pr.base: the read comes from its packed row (bpm_planes<W, true>: what k_filter / k_filter_pe run inside the mapping calls)
+    bpm_read(ix, seq, stride, pr, (long)read_of[g], L, k, site[g], e, es);
     ferr[g] = e; fend[g] = es;
 }

@@ -381,17 +381,16 @@ DEVI long pe_lower_bound_u64(const u64* v, long n, u64 key)
     while (lo < hi) { const long mid = (lo + hi) >> 1; if (v[mid] < key) lo = mid + 1; else hi = mid; }
     return lo;
 }
-DEVI long pe_lower_bound(const PeCand* v, long n, u64 key);
-#define PREF_STAGE 256          // mate lists of up to this many entries are searched out of LDS
+#define PREF_STAGE 256          // sites are tested against mate lists of up to this many entries (an LDS copy); longer ones: no pre-filter
 // keys[0, cnt): located raw sites -> the ones with a partner on `mate` (ascending sites), compacted in place, in order; returns their
-// number, or -1 when the list holds a site that wrapped below zero (the reference's mixed comparisons decide there: no pre-filter)
+// number, or -1 when the list holds a site that wrapped below zero (the reference's mixed comparisons decide there: no pre-filter).
+// nm <= PREF_STAGE.
 template <int EMAX>
 DEVI int pe_prefilter(u64* keys, int cnt, int k, const PeCand* mate, long nm, u64 maxd, u64* sh_mate, int* sh_w)
 {
     const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int E = (cnt + T - 1) / T;
-    const bool staged = nm <= PREF_STAGE;
-    if (staged) for (int i = tid; i < (int)nm; i += T) sh_mate[i] = mate[i].site;
+    for (int i = tid; i < (int)nm; i += T) sh_mate[i] = mate[i].site;           // nm <= PREF_STAGE (the caller's condition)
     __syncthreads();
     u64 mine[EMAX];
     u32 keep = 0;
@@ -406,9 +405,8 @@ DEVI int pe_prefilter(u64* keys, int cnt, int k, const PeCand* mate, long nm, u6
             wrapped |= (c >> 63) != 0;
             const u64 x = c < (u64)k ? 0 : c - (u64)k;
             const u64 lo = x > maxd ? x - maxd : 0;
-            bool ok;
-            if (staged) { const long j = pe_lower_bound_u64(sh_mate, nm, lo); ok = j < nm && (sh_mate[j] <= x || sh_mate[j] - x <= maxd); }
-            else { const long j = pe_lower_bound(mate, nm, lo); ok = j < nm && (mate[j].site <= x || mate[j].site - x <= maxd); }
+            const long j = pe_lower_bound_u64(sh_mate, nm, lo);
+            const bool ok = j < nm && (sh_mate[j] <= x || sh_mate[j] - x <= maxd);
             if (ok) { keep |= 1u << e; kept++; }
         }
     }
@@ -490,7 +488,7 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
                     }
                     if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)running; }
                 }
-                __threadfence();                               // (a second turn reads this list from memory)
+                if (mate_here && turn == 0) __threadfence();   // (the second turn reads this list from memory)
                 __syncthreads();
                 continue;
             }
@@ -499,7 +497,13 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
             // the mate's list is final when an earlier kernel wrote it (verdicts 1 / 2 / none, lists of a smaller class) or this block
             // just did (turn 1)
             if (prefilter && v == 3) {
-                const bool mate_final = turn == 1 || !listed(m) || (long)st.n_cand[m] <= LO;
+                // (only against a mate list short enough for the LDS copy: a binary search per site through a list in memory -- both
+                // mates inside repeats -- costs more than the sort it saves; measured, round 6)
+                // (a listed mate of a smaller class: its kernel ran earlier in the stream -- the wave form always does; the block classes only
+                // when they are launched one behind the other: prefilter == 1.  prefilter == 2: they run side by side)
+                const long ncm_ = (long)st.n_cand[m];
+                const bool earlier = !listed(m) || ncm_ <= (prefilter == 2 ? (LO < VM_CAP ? LO : VM_CAP) : LO);
+                const bool mate_final = (turn == 1 || earlier) && ps.len[m] <= PREF_STAGE;
                 long long maxd, mind; int large_k;
                 pe_bounds(gm, pi, r < n_pairs ? r : r - n_pairs, n_pairs, maxd, mind, large_k);
                 if (mate_final && mind <= 0 && maxd >= 0) {
@@ -532,7 +536,7 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
                 }
                 if (threadIdx.x == 0) { ps.occ[r] = -1; ps.len[r] = (u32)nv; }
             }
-            __threadfence();
+            if (mate_here && turn == 0) __threadfence();       // (an agent-scope fence is microseconds: only where a second turn follows)
             __syncthreads();
         }
     }

@@ -287,79 +287,6 @@ DEVI void vl_radix_sort(u64* keys, int nc)
         __syncthreads();
     }
 }
-// the same sort with 4-bit digits (round 6): sixteen 16-bit counters in four u64 words, one block-wide scan of those four words per
-// pass -- 9 passes for the 33 varying bits of a GRCh38-size text where the 2-bit form takes 17 (each pass is a chain of three barriers
-// and a scan: the passes, not the keys, are what a list of a few hundred sites pays for)
-template <int EMAX>
-DEVI void vl_radix_sort4(u64* keys, int nc)
-{
-    __shared__ u64 sh_scan4[4 * 4 + 4];
-    const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (T + 63) >> 6;
-    const int E = (nc + T - 1) / T;                     // <= EMAX
-    u64 mine[EMAX];
-    u64 diff = 0;
-    const u64 k0 = keys[0];
-    for (int i = tid; i < nc; i += T) diff |= keys[i] ^ k0;
-    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
-    if (lane == 0) sh_scan4[w] = diff;
-    __syncthreads();
-    diff = 0;
-    for (int i = 0; i < nw; i++) diff |= sh_scan4[i];
-    __syncthreads();
-    const int nbits = diff ? 64 - __builtin_clzll(diff) : 0;
-    for (int b = 0; b < nbits; b += 4) {
-        u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (int e = 0; e < EMAX; e++) {
-            const int idx = tid * E + e;
-            if (e < E && idx < nc) {
-                mine[e] = keys[idx];
-                const int d = (int)((mine[e] >> b) & 15);
-                const u64 inc = 1ull << (16 * (d & 3));
-                const int q = d >> 2;
-                c0 += q == 0 ? inc : 0; c1 += q == 1 ? inc : 0; c2 += q == 2 ? inc : 0; c3 += q == 3 ? inc : 0;
-            }
-        }
-        u64 i0 = c0, i1 = c1, i2 = c2, i3 = c3;
-        for (int o = 1; o < 64; o <<= 1) {
-            const u64 v0 = __shfl_up(i0, o, 64), v1 = __shfl_up(i1, o, 64), v2 = __shfl_up(i2, o, 64), v3 = __shfl_up(i3, o, 64);
-            if (lane >= o) { i0 += v0; i1 += v1; i2 += v2; i3 += v3; }
-        }
-        if (lane == 63) { sh_scan4[4 * w] = i0; sh_scan4[4 * w + 1] = i1; sh_scan4[4 * w + 2] = i2; sh_scan4[4 * w + 3] = i3; }
-        __syncthreads();
-        u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        for (int i = 0; i < nw; i++) {
-            const u64 x0 = sh_scan4[4 * i], x1 = sh_scan4[4 * i + 1], x2 = sh_scan4[4 * i + 2], x3 = sh_scan4[4 * i + 3];
-            if (i < w) { b0 += x0; b1 += x1; b2 += x2; b3 += x3; }
-            t0 += x0; t1 += x1; t2 += x2; t3 += x3;
-        }
-        // first slot of every digit = the totals of the smaller digits, packed like the counters (a total is at most 4096 < 2^16)
-        auto starts = [](u64 t, u32& run) -> u64 {
-            u64 o = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { o |= (u64)run << (16 * j); run += (u32)((t >> (16 * j)) & 0xffff); }
-            return o;
-        };
-        u32 run = 0;
-        u64 r0 = starts(t0, run); u64 r1 = starts(t1, run); u64 r2 = starts(t2, run); u64 r3 = starts(t3, run);
-        r0 += b0 + i0 - c0; r1 += b1 + i1 - c1; r2 += b2 + i2 - c2; r3 += b3 + i3 - c3;       // + this thread's exclusive share
-        __syncthreads();                                // every key is in registers: the array may be overwritten
-#pragma unroll
-        for (int e = 0; e < EMAX; e++) {
-            const int idx = tid * E + e;
-            if (e < E && idx < nc) {
-                const int d = (int)((mine[e] >> b) & 15);
-                const int q = d >> 2, sh = 16 * (d & 3);
-                const u64 word = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;
-                const u32 r = (u32)((word >> sh) & 0xffff);
-                const u64 inc = 1ull << sh;
-                r0 += q == 0 ? inc : 0; r1 += q == 1 ? inc : 0; r2 += q == 2 ? inc : 0; r3 += q == 3 ? inc : 0;
-                keys[r] = mine[e];
-            }
-        }
-        __syncthreads();
-    }
-}
 // candidates j0 .. j0 + cnt - 1 of a read located into keys[0, cnt).  build_pref: sh_pref (the running sum of the seeds' hit counts)
 // is filled first -- once per read.
 DEVI void vl_locate_range(const DevIndex& ix, const SeedRec* my, int ns, long j0, int cnt, u64* keys, u32* sh_pref, bool build_pref)
@@ -383,10 +310,11 @@ DEVI int vl_sort_keys(u64* keys, int cnt)
     while (np2 < cnt) np2 <<= 1;
     for (int j = cnt + (int)threadIdx.x; j < np2; j += blockDim.x) keys[j] = ~0ull;
     __syncthreads();
-    // long lists (a read inside a repeat family: up to 25 seeds x 1000 rows): LSD radix sort over the bits that vary -- 9 four-bit
-    // passes of one block scan each for a 6.2 G text, where the bitonic network takes 78 stages of 8 sweeps over 4096 keys.  On a
-    // GRCh38-like genome these lists were most of k_vote_pe_long's 11-13 ms per 10 M pairs.
-    if (np2 > 512 && blockDim.x >= 128) { vl_radix_sort4<EMAX>(keys, cnt); return np2; }
+    // long lists (a read inside a repeat family: up to 25 seeds x 1000 rows): LSD radix sort, two bits a pass over the bits that
+    // vary -- 17 passes of one block scan each for a 6.2 G text, where the bitonic network takes 78 stages of 8 sweeps over 4096
+    // keys.  On a GRCh38-like genome these lists were most of k_vote_pe_long's 11-13 ms per 10 M pairs.  (Four bits a pass -- nine
+    // passes, sixteen counters in four words -- was measured in round 6: the same time at equal occupancy, more registers.)
+    if (np2 > 512 && blockDim.x >= 128) { vl_radix_sort<EMAX>(keys, cnt); return np2; }
     for (int size = 2; size <= np2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
@@ -464,9 +392,87 @@ DEVI int vl_run_ends(const u64* keys, int nc, u16* endpos, int* sh_w)
 // same: in one __unguarded_partition pass the left cursor stops exactly at the positions whose vote is <= the pivot's (in
 // ascending order: Lpos) and the right cursor at those >= it (descending: Rpos); the pass swaps Lpos[t] <-> Rpos[t] for
 // every t with Lpos[t] < Rpos[t] (a prefix, T of them, since one list ascends and the other descends) and returns
-// cut = min(Lpos[T], Rpos[T-1]) (Lpos[0] when T = 0).  The final insertion sort of std::sort is the stable sort of what the
-// loop left.  tests/test_sort_order.py checks this formulation -- one range at a time, and level by level as vl_sort_votes_lv
-// below runs it -- against std::sort on the CPU.
+// cut = min(Lpos[T], Rpos[T-1]) (Lpos[0] when T = 0).  Ranges above SMALL elements are partitioned by the whole block that
+// way; the disjoint ranges of 17..SMALL elements that remain are finished by one lane each with the serial loop; the final
+// insertion sort of std::sort is the stable sort of what the loop left, done with a bitonic network on (vote, position) keys.
+// tests/test_sort_order.py checks this formulation against std::sort on the CPU.
+struct VlRange { u16 f, l; int d; };
+DEVI void vl_prefix2(bool f0, bool f1, int* sh_w, int& p0, int& p1, int& t0, int& t1)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+    if (lane == 0) { sh_w[w] = __popcll(m0); sh_w[nw + w] = __popcll(m1); }
+    __syncthreads();
+    int a0 = 0, a1 = 0, s0 = 0, s1 = 0;
+    for (int i = 0; i < nw; i++) { const int x = sh_w[i], y = sh_w[nw + i]; if (i < w) { a0 += x; a1 += y; } s0 += x; s1 += y; }
+    __syncthreads();
+    t0 = s0; t1 = s1;
+    const unsigned long long below = (1ull << lane) - 1;
+    p0 = a0 + __popcll(m0 & below); p1 = a1 + __popcll(m1 & below);
+}
+// std::__unguarded_partition_pivot on items[first, last) by the whole block; returns the cut (block-uniform)
+DEVI int vl_partition(bmbs_vk* items, int first, int last, u16* Lpos, u16* Rpos, int* sh_w)
+{
+    if (threadIdx.x == 0) {
+        using namespace bmbs_sort_detail;
+        move_median_to_first(items, (long)first, (long)first + 1, (long)first + (last - first) / 2, (long)last - 1);
+    }
+    __syncthreads();
+    const u32 pv = items[first].x >> 24;
+    const int n = last - first - 1;
+    int nL = 0, nR = 0;
+    for (int base = 0; base < n; base += (int)blockDim.x) {
+        const int j = base + (int)threadIdx.x;
+        const int iL = first + 1 + j, iR = last - 1 - j;
+        const bool fl = j < n && (items[iL].x >> 24) <= pv;
+        const bool fr = j < n && (items[iR].x >> 24) >= pv;
+        int pl, pr, tl, tr;
+        vl_prefix2(fl, fr, sh_w, pl, pr, tl, tr);
+        if (fl) Lpos[nL + pl] = (u16)iL;
+        if (fr) Rpos[nR + pr] = (u16)iR;
+        nL += tl; nR += tr;
+    }
+    __syncthreads();
+    const int m = nL < nR ? nL : nR;
+    int T = 0;
+    for (int base = 0; base < m; base += (int)blockDim.x) {
+        const int t = base + (int)threadIdx.x;
+        const bool c = t < m && Lpos[t] < Rpos[t];
+        int tot;
+        vl_prefix(c, sh_w, tot);
+        T += tot;
+        const int span = m - base < (int)blockDim.x ? m - base : (int)blockDim.x;
+        if (tot < span) break;                      // the condition is monotone in t
+    }
+    for (int t = threadIdx.x; t < T; t += (int)blockDim.x) {
+        const int a = Lpos[t], b = Rpos[t];
+        const bmbs_vk x = items[a]; items[a] = items[b]; items[b] = x;
+    }
+    int cut;
+    if (T == 0) cut = Lpos[0];
+    else { const int lt = T < nL ? (int)Lpos[T] : 0x7fffffff, rt = Rpos[T - 1]; cut = lt < rt ? lt : rt; }
+    __syncthreads();
+    return cut;
+}
+// the serial introsort loop on a short range (<= 128 elements: the pending ranges are disjoint and each above 16)
+DEVI void vl_intro_small(bmbs_vk* v, int first0, int last0, int depth0)
+{
+    using namespace bmbs_sort_detail;
+    int sf[8], sl[8], sd[8];
+    int sp = 1;
+    sf[0] = first0; sl[0] = last0; sd[0] = depth0;
+    while (sp > 0) {
+        --sp;
+        int first = sf[sp], last = sl[sp], depth = sd[sp];
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort(v, (long)first, (long)last); break; }
+            --depth;
+            const int cut = (int)partition_pivot(v, (long)first, (long)last);
+            if (last - cut > 16) { sf[sp] = cut; sl[sp] = last; sd[sp] = depth; ++sp; }
+            last = cut;
+        }
+    }
+}
 // items[0, nv) stably by vote (the top byte), descending: 2-bit LSD passes over the vote bits that vary (a site collects at most one
 // vote per seed: votes stay below 32, two or three passes), thread t owning items [t E, (t + 1) E) as vl_radix_sort does
 template <int EMAX>
@@ -516,170 +522,57 @@ DEVI void vl_stable_by_vote_desc(bmbs_vk* items, int nv)
         __syncthreads();
     }
 }
-// ---- every pending range of a recursion level in ONE block pass (round 6) ------------------------------------------------------
-// Round 3-5 partitioned one range after the other (vl_partition / vl_sort_votes, removed) -- 660 all-equal votes: seven block-wide partitions (660 -> 330 -> 165),
-// each a chain of scans and barriers, then eight lanes running the serial loop on ~82 elements while 120 wait: 37-60 % of a long
-// list's time (profiles/HISTORY.md, round 5).  The ranges of a level are disjoint, tile [0, nv) and all carry the same depth budget
-// (both halves of a partition inherit depth - 1), so a level is one pass over the positions:
-//   A  the head of every range of more than 16 elements moves the median of three to its first position (its owner thread)
-//   B  every position reads its range's pivot: flags "left cursor stops here" (vote <= pivot) and "right cursor stops here"
-//      (vote >= pivot); one block-wide inclusive scan of the two counts, packed in one word, kept per position (Pin)
-//   C  a stop's rank within its range is a difference of two Pin entries: Lbuf[f + 1 + rank] = position (ascending),
-//      Rbuf[f + 1 + rank] = position (descending)
-//   D  slot s of a range swaps items[Lbuf[s]] <-> items[Rbuf[s]] while Lbuf[s] < Rbuf[s] (a prefix of the slots); the head finds the
-//      number of swaps T by a binary search and the cut = min(Lbuf[T], Rbuf[T - 1]) (vl_partition's rule)
-//   E  positions at and beyond the cut start a new range
-// Five barriers per level, ~log2(nv / 16) levels, nothing serial but the medians.  rs[i] = first position of i's range; a range's end
-// sits in Rbuf[first] and its cut in Lbuf[first] (slot `first` of a range holds no stop: the pivot is there).
-// scratch: 8 * CAP bytes (Pin u32[CAP], Lbuf u16[CAP], Rbuf u16[CAP]); rs: u16[CAP].  Returns false when a range of more than 16
-// elements is left at depth 0 (std::sort would heap-sort it): the caller restores the items and takes the serial path.
-template <int CAP, int EMAX>
-DEVI bool vl_sort_votes_lv(bmbs_vk* items, int nv, u16* rs, void* scratch, int* sh_w)
+// items[0, nv) -> std::sort(.., vote descending)'s permutation.  scratch: 4*CAP + 512 + CAP/2 bytes.  Returns false when a
+// large range ran out of depth budget (heapsort fallback): the caller then takes the serial path.
+template <int CAP, int SMALL, int EMAX>
+DEVI bool vl_sort_votes(bmbs_vk* items, int nv, void* scratch, int* sh_w, int* ctl)
 {
-    u32* Pin = (u32*)scratch;
-    u16* Lbuf = (u16*)(Pin + CAP);
-    u16* Rbuf = Lbuf + CAP;
-    const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (T + 63) >> 6;
-    const int E = (nv + T - 1) / T;                     // <= EMAX
-    const int i0 = tid * E;
+    u16* Lpos = (u16*)scratch;
+    u16* Rpos = Lpos + CAP;
+    VlRange* big = (VlRange*)(Rpos + CAP);
+    VlRange* small = big + 64;
     if (nv > 16) {
-        int depth = 0;
-        for (int t = nv; t > 1; t >>= 1) depth += 2;
-        for (int e = 0; e < E; e++) { const int i = i0 + e; if (i < nv) rs[i] = 0; }
-        if (tid == 0) Rbuf[0] = (u16)nv;
+        if (threadIdx.x == 0) {
+            int lg = 0;
+            for (int t = nv; t > 1; t >>= 1) lg++;
+            VlRange rg; rg.f = 0; rg.l = (u16)nv; rg.d = 2 * lg;
+            ctl[0] = 0; ctl[1] = 0; ctl[2] = 0;
+            if (nv > SMALL) { big[0] = rg; ctl[0] = 1; } else { small[0] = rg; ctl[1] = 1; }
+        }
         __syncthreads();
         while (true) {
-            // ---- A: medians (and: is any range of more than 16 elements left?)
-            bool any = false;
-            for (int e = 0; e < E; e++) {
-                const int f = i0 + e;
-                if (f < nv && rs[f] == f) {
-                    const int l = Rbuf[f];
-                    if (l - f > 16) {
-                        any = true;
-                        if (depth > 0) bmbs_sort_detail::move_median_to_first(items, (long)f, (long)f + 1, (long)f + (l - f) / 2, (long)l - 1);
-                    }
-                }
-            }
-            if (!__syncthreads_or(any ? 1 : 0)) break;
-            if (depth == 0) return false;
-            --depth;
-            // ---- B: stop flags, inclusive prefix of both counts per position
-            u32 loc[EMAX];
-            u32 sum = 0;
-#pragma unroll
-            for (int e = 0; e < EMAX; e++) {
-                const int i = i0 + e;
-                u32 fl = 0;
-                if (e < E && i < nv) {
-                    const int f = rs[i], l = Rbuf[f];
-                    if (l - f > 16 && i != f) {
-                        const u32 pv = items[f].x >> 24, v = items[i].x >> 24;
-                        fl = (v <= pv ? 1u : 0u) | (v >= pv ? 0x10000u : 0u);
-                    }
-                }
-                sum += fl;
-                loc[e] = sum;
-            }
-            u32 incl = sum;
-            for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-            if (lane == 63) sh_w[w] = (int)incl;
+            const int nb = ctl[0];
+            if (nb == 0 || ctl[2]) break;
+            const VlRange rg = big[nb - 1];
             __syncthreads();
-            u32 base = incl - sum;
-            for (int q = 0; q < w; q++) base += (u32)sh_w[q];
-#pragma unroll
-            for (int e = 0; e < EMAX; e++) { const int i = i0 + e; if (e < E && i < nv) Pin[i] = base + loc[e]; }
-            __syncthreads();
-            // ---- C: the two stop lists of every range
-#pragma unroll
-            for (int e = 0; e < EMAX; e++) {
-                const int i = i0 + e;
-                if (e < E && i < nv) {
-                    const u32 mine = Pin[i], prev = e ? base + loc[e - 1] : base;          // prev = Pin[i - 1] (0 in front of the list)
-                    const u32 fl = mine - prev;
-                    if (fl) {
-                        const int f = rs[i], l = Rbuf[f];
-                        const u32 pf = Pin[f], pl = Pin[l - 1];
-                        if (fl & 1u) Lbuf[f + 1 + (int)((mine & 0xffffu) - 1 - (pf & 0xffffu))] = (u16)i;
-                        if (fl >> 16) Rbuf[f + 1 + (int)((pl >> 16) - (mine >> 16))] = (u16)i;
-                    }
+            if (threadIdx.x == 0) ctl[0] = nb - 1;
+            int first = rg.f, last = rg.l, depth = rg.d;
+            while (last - first > SMALL) {
+                if (depth == 0) { if (threadIdx.x == 0) ctl[2] = 1; break; }
+                --depth;
+                const int cut = vl_partition(items, first, last, Lpos, Rpos, sh_w);
+                if (threadIdx.x == 0) {
+                    VlRange q; q.f = (u16)cut; q.l = (u16)last; q.d = depth;
+                    if (last - cut > SMALL) big[ctl[0]++] = q;
+                    else if (last - cut > 16) small[ctl[1]++] = q;
                 }
+                last = cut;
             }
-            __syncthreads();
-            // ---- D: swaps, and the cut of every range (into Lbuf[first])
-#pragma unroll
-            for (int e = 0; e < EMAX; e++) {
-                const int i = i0 + e;
-                if (e < E && i < nv) {
-                    const int f = rs[i], l = Rbuf[f];
-                    if (l - f > 16) {
-                        const u32 pf = Pin[f], pl = Pin[l - 1];
-                        const int nL = (int)((pl & 0xffffu) - (pf & 0xffffu)), nR = (int)((pl >> 16) - (pf >> 16));
-                        const int m = nL < nR ? nL : nR;
-                        if (i == f) {
-                            // T = slots of the prefix that swap (the condition is monotone: one list ascends, the other descends)
-                            int lo = 0, hi = m;
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (Lbuf[f + 1 + mid] < Rbuf[f + 1 + mid]) lo = mid + 1; else hi = mid; }
-                            const int Tn = lo;
-                            int cut;
-                            if (Tn == 0) cut = Lbuf[f + 1];
-                            else { const int lt = Tn < nL ? (int)Lbuf[f + 1 + Tn] : 0x7fffffff, rt = Rbuf[f + Tn]; cut = lt < rt ? lt : rt; }
-                            Lbuf[f] = (u16)cut;
-                        } else {
-                            const int t = i - f - 1;
-                            if (t < m) {
-                                const int a = Lbuf[i], b = Rbuf[i];
-                                if (a < b) { const bmbs_vk x = items[a]; items[a] = items[b]; items[b] = x; }
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- E: the positions at and beyond a cut start a new range; the head records both ends
-            int nf[EMAX];
-#pragma unroll
-            for (int e = 0; e < EMAX; e++) {
-                const int i = i0 + e;
-                nf[e] = -1;
-                if (e < E && i < nv) {
-                    const int f = rs[i], l = Rbuf[f];
-                    if (l - f > 16) {
-                        const int cut = Lbuf[f];
-                        nf[e] = i >= cut ? cut : f;
-                        if (i == f) nf[e] = -2 - cut;            // the head: writes the ends once every thread has read the old ones
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < EMAX; e++) {
-                const int i = i0 + e;
-                if (e < E && i < nv) {
-                    if (nf[e] >= 0) rs[i] = (u16)nf[e];
-                    else if (nf[e] <= -2) { const int cut = -2 - nf[e]; const int l = Rbuf[i]; Rbuf[cut] = (u16)l; Rbuf[i] = (u16)cut; }
-                }
+            if (threadIdx.x == 0 && last - first > 16 && last - first <= SMALL) {
+                VlRange q; q.f = (u16)first; q.l = (u16)last; q.d = depth;
+                small[ctl[1]++] = q;
             }
             __syncthreads();
         }
+        if (ctl[2]) return false;
+        const int n_small = ctl[1];
+        for (int s2 = threadIdx.x; s2 < n_small; s2 += (int)blockDim.x) vl_intro_small(items, small[s2].f, small[s2].l, small[s2].d);
+        __syncthreads();
     }
+    // the final insertion sort = stable sort by vote descending of the current arrangement (a bitonic network on (vote, position)
+    // keys did this before: 55 stages with a barrier each for 1024 items, most of the time of a long list)
     vl_stable_by_vote_desc<EMAX>(items, nv);
     return true;
-}
-
-// items[] back in entry order (every item carries its entry index in the low 24 bits): what the serial fallback starts from
-template <int EMAX>
-DEVI void vl_restore_items(bmbs_vk* items, int nv)
-{
-    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-    const int E = (nv + T - 1) / T;
-    u32 mine[EMAX];
-#pragma unroll
-    for (int e = 0; e < EMAX; e++) { const int i = tid * E + e; if (e < E && i < nv) mine[e] = items[i].x; }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < EMAX; e++) { const int i = tid * E + e; if (e < E && i < nv) items[mine[e] & 0xffffffu].x = mine[e]; }
-    __syncthreads();
 }
 
 // CAP, BLOCK = (VM_CAP, VM_BLOCK): lists of up to 256 candidates, one wave each; (VL_CAP, VL_BLOCK): the longer ones, one
@@ -694,8 +587,11 @@ __device__ unsigned long long g_vote_prof[4][8];
 #define VP_T(v)
 #define VP_ADD(cls, slot, val)
 #endif
+// (amdgpu_waves_per_eu(5): 96 registers instead of 114-128 -- one more wave per SIMD, which the 15 KB of LDS of the 1024-key class
+// allow: the kernel issues 0.2 instructions per cycle and SIMD at four waves, every wave waiting on its own chain of LDS round
+// trips and barriers; tools/vote_kbench.hip: 3.06 -> 2.66 ms per 60 000 lists of 660)
 template <int CAP, int BLOCK, int LO>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5)))
 k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
             u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read, u32* __restrict__ big_list,
             unsigned long long* __restrict__ big_count, unsigned long long* __restrict__ counters)
@@ -705,6 +601,7 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
     __shared__ bmbs_vk items[CAP];
     __shared__ u32 sh_pref[BMBS_MAX_SEEDS + 1];
     __shared__ int sh_w[2 * (BLOCK / 64) + 1];
+    __shared__ int sh_ctl[4];
     const long total_items = (long)*count_ptr;
     for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
         const long r = list[item];
@@ -721,7 +618,7 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
         const SeedRec* my = st.seeds + (size_t)r * BMBS_MAX_SEEDS;
         const int ns = st.n_seeds[r];
         bmbs_vote* v = votes + off;
-        if (nc > CAP) {
+        if constexpr (CAP == VL_CAP) if (nc > CAP) {      // (only the largest class takes what is beyond its capacity: the others do not carry this path's registers)
             // beyond the LDS capacity: the sites are sorted in tiles (vl_sort_huge; the vote segment, 16 bytes per candidate, parks the
             // tiles), the run ends are listed in the slot map (one word per candidate), and when the distinct sites fit the LDS the vote
             // order is made as for any other list; otherwise one lane runs std::sort's loop on the votes
@@ -748,8 +645,12 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
                     c[e] = tmp[e];
                 }
                 __syncthreads();
-                if (!vl_sort_votes_lv<CAP, (CAP + BLOCK - 1) / BLOCK>(items, nvh, endpos, keys, sh_w)) {
-                    vl_restore_items<(CAP + BLOCK - 1) / BLOCK>(items, nvh);
+                if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32), (CAP + BLOCK - 1) / BLOCK>(items, nvh, keys, sh_w, sh_ctl)) {
+                    for (int e = threadIdx.x; e < nvh; e += BLOCK) {
+                        const u32 vote = endidx[e] - (e ? endidx[e - 1] : 0xffffffffu);
+                        items[e].x = (vote << 24) | (u32)e;
+                    }
+                    __syncthreads();
                     if (threadIdx.x == 0) intro_sort_desc(items, (long)nvh);
                     __syncthreads();
                 }
@@ -794,9 +695,12 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
         __syncthreads();
         VP_T(vp2);
         // std::sort(votes, compare_seed_votes), Schema.cpp:24986
-        // (endpos is free from here on: it becomes the range map of the level-synchronous replay)
-        if (!vl_sort_votes_lv<CAP, (CAP + BLOCK - 1) / BLOCK>(items, nv, endpos, keys, sh_w)) {
-            vl_restore_items<(CAP + BLOCK - 1) / BLOCK>(items, nv);
+        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32), (CAP + BLOCK - 1) / BLOCK>(items, nv, keys, sh_w, sh_ctl)) {
+            for (int e = threadIdx.x; e < nv; e += BLOCK) {
+                const u32 vote = (u32)endpos[e] - (e ? (u32)endpos[e - 1] : 0xffffffffu);
+                items[e].x = (vote << 24) | (u32)e;
+            }
+            __syncthreads();
             if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);
             __syncthreads();
             VP_ADD(VP_CLS, 7, 1);
@@ -825,16 +729,17 @@ k_vote_order(const uint8_t* __restrict__ vote, const long* __restrict__ seg_off,
 {
     __shared__ u64 scratch[CAP];
     __shared__ bmbs_vk items[CAP];
-    __shared__ u16 rs[CAP];
     __shared__ int sh_w[2 * (BLOCK / 64) + 1];
+    __shared__ int sh_ctl[4];
     for (long sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
         const long a = seg_off[sg];
         const int nv = (int)(seg_off[sg + 1] - a);
         if (nv <= 0 || nv > CAP) continue;
         for (int e = threadIdx.x; e < nv; e += BLOCK) items[e].x = ((u32)vote[a + e] << 24) | (u32)e;
         __syncthreads();
-        if (!vl_sort_votes_lv<CAP, (CAP + BLOCK - 1) / BLOCK>(items, nv, rs, scratch, sh_w)) {
-            vl_restore_items<(CAP + BLOCK - 1) / BLOCK>(items, nv);
+        if (!vl_sort_votes<CAP, (CAP > 256 ? 128 : 32), (CAP + BLOCK - 1) / BLOCK>(items, nv, scratch, sh_w, sh_ctl)) {
+            for (int e = threadIdx.x; e < nv; e += BLOCK) items[e].x = ((u32)vote[a + e] << 24) | (u32)e;
+            __syncthreads();
             if (threadIdx.x == 0) intro_sort_desc(items, (long)nv);
             __syncthreads();
         }

@@ -312,14 +312,17 @@ class Mapper:
         self._chk(self._lib.bmbs_window_batch(self._ctx, capi.ptr(site), site.size, length, capi.ptr(out)))
         return out
 
-    def filter(self, seq: np.ndarray, L: int, read_of: np.ndarray, site: np.ndarray):
+    def filter(self, seq: np.ndarray, L: int, read_of: np.ndarray, site: np.ndarray, packed: bool = False):
+        """K7+K8 on (read, site) pairs.  packed: the rows are packed on the device first and the Myers rows read the packed words -- the
+        form the mapping calls run (bmbs_filter_batch_packed)"""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         read_of = np.ascontiguousarray(read_of, dtype=np.uint32)
         site = np.ascontiguousarray(site, dtype=np.uint64)
         m = read_of.size
         err = np.zeros(m, dtype=np.uint32)
         end = np.zeros(m, dtype=np.int32)
-        self._chk(self._lib.bmbs_filter_batch(self._ctx, capi.ptr(seq), L, seq.shape[1], seq.shape[0], capi.ptr(read_of),
+        fn = self._lib.bmbs_filter_batch_packed if packed else self._lib.bmbs_filter_batch
+        self._chk(fn(self._ctx, capi.ptr(seq), L, seq.shape[1], seq.shape[0], capi.ptr(read_of),
                                               capi.ptr(site), m, capi.ptr(err), capi.ptr(end)))
         return err, end
 

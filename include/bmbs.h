@@ -153,6 +153,13 @@ int bmbs_filter_batch(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int
                       const uint32_t* read_of, const uint64_t* site, int64_t n_cand,
                       uint32_t* err, int32_t* end_site);
 
+/* the same call on the form the mapping calls run: the rows are packed on the device first (2 bits per base + a not-ACGT bit plane, what
+ * k_filter / k_filter_pe read since round 4) and the Myers rows take their characters from the packed words.  Same results as
+ * bmbs_filter_batch for every input, characters outside ACGT included (tests/test_gpu_parity.py).                                  */
+int bmbs_filter_batch_packed(bmbs_ctx*, const char* seq, int32_t L, int32_t stride, int64_t n_reads,
+                             const uint32_t* read_of, const uint64_t* site, int64_t n_cand,
+                             uint32_t* err, int32_t* end_site);
+
 /* K11-K13: fast_recalculate_bs_Cigar (ksw.cpp:2578) for job i = (read_of[i], site[i], end_site[i],
  * err[i]); cigar ops: max_ops per job, SAM order.                                                  */
 int bmbs_align_batch(bmbs_ctx*, const char* seq, const char* qual, int32_t L, int32_t stride,

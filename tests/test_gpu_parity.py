@@ -117,13 +117,18 @@ def test_gpu_sam_equals_reference_golden(name, tmp_path):
     m.close()
 
 
-@pytest.mark.parametrize("L,e", [(120, 0.08), (150, 0.08), (180, 0.08), (250, 0.08), (40, 0.15)])
-def test_filter_stage_matches_oracle_incl_invalid_sites(env, L, e):
-    """K7+K8 through bmbs_filter_batch on arbitrary (read, site) pairs, incl. strand ends and wild sites.  The lengths take the
-    kernel's three forms of the window: held in registers (L + 2k <= 192), streamed with a 32-bit band (180 bases, k = 14) and
-    streamed with a 64-bit band (250 bases, k = 20)"""
+@pytest.mark.parametrize("packed", [False, True], ids=["ascii_rows", "packed_rows"])
+@pytest.mark.parametrize("L,e", [(120, 0.08), (150, 0.08), (180, 0.08), (250, 0.08), (40, 0.15), (333, 0.05)])
+def test_filter_stage_matches_oracle_incl_invalid_sites(env, L, e, packed):
+    """K7+K8 through bmbs_filter_batch / bmbs_filter_batch_packed on arbitrary (read, site) pairs, incl. strand ends and wild sites.
+    The lengths take the kernel's three forms of the window: held in registers (L + 2k <= 192), streamed with a 32-bit band (180
+    bases, k = 14) and streamed with a 64-bit band (250 bases, k = 20).  packed_rows = the form the mapping calls run (rows packed
+    on the device by k_pack_rows, bpm_planes<W, true>): clean rows, and dirty ones -- a third of the reads carry an N, three of them
+    nothing but N, some an N in their last character (the ragged end of the packed words)"""
     from bitmapperbs_amd import synth, mapper
     r = synth.make_reads_se(env["chroms"], n=3000, L=L, seed=21, sub=0.03, indel=0.004, qual="const", n_rate=0.003)
+    r["seq"][5, :] = ord("N"); r["seq"][6, :] = ord("N"); r["seq"][77, :] = ord("N")
+    r["seq"][100:160, L - 1] = ord("N"); r["seq"][200:230, 0] = ord("N")
     m = mapper.Mapper(env["ix"], 0, e_f=e)
     k = m.threshold(L)
     G = env["ix"].ref_len
@@ -140,7 +145,7 @@ def test_filter_stage_matches_oracle_incl_invalid_sites(env, L, e):
     for j, s in enumerate(edge):
         read_of.append(j); site.append(np.uint64(s))
     read_of = np.array(read_of, dtype=np.uint32); site = np.array(site, dtype=np.uint64)
-    err, end = m.filter(r["seq"], L, read_of, site)
+    err, end = m.filter(r["seq"], L, read_of, site, packed=packed)
     for j in range(read_of.size):
         w = env["oix"].window(int(site[j]), L + 2 * k)
         oe, oend = orc.bpm(w, r["seq"][read_of[j]], k)
