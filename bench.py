@@ -28,6 +28,12 @@ import time
 
 import numpy as np
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue run
+# one behind the other: with four, the kernel streams of a context's two lanes shared a queue in some processes (lanes not overlapping:
+# the same binary 1108 or 1248 M reads/s from one run to the next).  The library asks for eight when it is loaded; torch may touch the
+# GPU before that, so the bench says it here, before anything else.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

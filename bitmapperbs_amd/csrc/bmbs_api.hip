@@ -364,12 +364,13 @@ bool use_packed_rows(const Lane* c) { return !c->kn.rows_ascii; }
 // trigram rank table: three backward extensions per gather pair (bmbs_dev.h: occ3).  4.5 bytes per row; built from the full SA and
 // the 2-bit text on a stream of its own, checked against three single steps on a million rows before it is used.
 // margin: HBM that has to stay free behind the table (the work buffers of calls still to come)
-void occ3_build(Occ3Shared& o, u64 margin)
+// -> false: there was no room for it this time (the caller may ask again behind a later call, when other contexts have gone)
+bool occ3_build(Occ3Shared& o, u64 margin)
 {
     const u64 rows = o.rows, nb = rows / 96 + 2, need = 27 * nb * 16;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    if (free_b <= need + margin) return;
+    if (free_b <= need + margin) return false;
     const u64 n_chunks = (nb + OCC3_CHUNK - 1) / OCC3_CHUNK;
     void *t3 = nullptr, *c3 = nullptr, *sums = nullptr;
     hipStream_t st = nullptr;
@@ -395,6 +396,7 @@ void occ3_build(Occ3Shared& o, u64 margin)
     if (sums) (void)hipFree(sums);
     if (ok) { o.occ3 = t3; o.c3 = c3; o.nb3 = nb; }
     else { if (t3) (void)hipFree(t3); if (c3) (void)hipFree(c3); }
+    return true;
 }
 // called where a lane decides which seeding kernels to launch, and when a settled call has told it how long its chains are: builds the
 // table once for all users of the index when this lane would use it, and adopts it when someone has built it
@@ -405,7 +407,14 @@ void occ3_want(Lane* c, bool behind_a_call = false)
     std::lock_guard<std::mutex> l(c->o3->mu);
     // (behind a settled call the lane's work buffers exist already -- the table needs little room beside itself; in front of a context's
     // first call, BMBS_KGRAM=2, room for them is left)
-    if (!c->o3->occ3 && wants && !c->o3->tried) { c->o3->tried = true; (void)hipSetDevice(c->dev); occ3_build(*c->o3, behind_a_call ? (8ull << 30) : (40ull << 30)); }
+    // (`tried` stays clear when the build was skipped for lack of room -- at most eight such attempts, so a device that stays full is not
+    // asked for its free memory behind every call.  A lane that sizes its work buffers AFTER the table was built can still meet
+    // BMBS_ENOMEM on a device this full: bmbs_reserve() in front of the first call takes the buffers first.)
+    if (!c->o3->occ3 && wants && !c->o3->tried) {
+        (void)hipSetDevice(c->dev);
+        const bool attempted = occ3_build(*c->o3, behind_a_call ? (8ull << 30) : (40ull << 30));
+        if (attempted || ++c->o3->skipped >= 8) c->o3->tried = true;
+    }
     if (c->o3->occ3) { c->ix.occ3 = reinterpret_cast<const uint4*>(c->o3->occ3); c->ix.c3 = reinterpret_cast<const u64*>(c->o3->c3); c->ix.nb3 = c->o3->nb3; }
 }
 
@@ -522,21 +531,6 @@ int cand_total(Lane* c, const ReadState& st, u64 n, bool exact, u64* tot_out)
     return BMBS_OK;
 }
 
-// what the lane's stream has done so far is visible to its two side streams (side_fork); what they did since is waited for by the
-// lane's stream (side_join).  BMBS_SIDE=0: everything on the lane's stream (the round-5 sequence)
-static inline hipStream_t side_fork(Lane* c, int q)
-{
-    if (!c->kn.side || !c->side_stream[q]) return c->stream;
-    if (q == 0) (void)hipEventRecord(c->ev_fork, c->stream);
-    (void)hipStreamWaitEvent(c->side_stream[q], c->ev_fork, 0);
-    return c->side_stream[q];
-}
-static inline void side_join(Lane* c)
-{
-    if (!c->kn.side) return;
-    for (int q = 0; q < 2; q++) if (c->side_stream[q]) { (void)hipEventRecord(c->ev_side[q], c->side_stream[q]); (void)hipStreamWaitEvent(c->stream, c->ev_side[q], 0); }
-}
-
 // stages K1-K6 + votes; leaves the vote segments in c->votes / c->slot_read
 int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, u64 n, u64* total_cand, int pe_mode = 0, bool exact = true, bool prepacked = false)
 {
@@ -601,15 +595,12 @@ int run_seed_stages(Lane* c, const char* d_seq, const ReadGeom& gm, int stride, 
         // the handed-over lists in two size classes (as k_vote_pe_long): the <= 1024-key form needs 14 KB of LDS instead of 57 KB, so five
         // times as many reads are in flight -- the vote order (std::sort's permutation, one partition pass after the other) is a
         // chain of barriers, not work
-        const hipStream_t s_cls1 = side_fork(c, 0), s_cls2 = side_fork(c, 1);
         hipLaunchKernelGGL((k_vote_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
                            c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
-        // (the three classes side by side: the largest has a few dozen lists per launch, each a long chain of serial steps)
-        hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, s_cls1, c->ix, gm, st, c->totals.as<u64>() + 13,
+        hipLaunchKernelGGL((k_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
                            c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
-        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, s_cls2, c->ix, gm, st, c->totals.as<u64>() + 13,
+        hipLaunchKernelGGL((k_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, c->totals.as<u64>() + 13,
                            c->big_list.as<u32>(), c->cand.as<u64>(), c->votes.as<bmbs_vote>(), c->slot_read.as<u32>(), (u32*)nullptr, (unsigned long long*)nullptr, c->counters.as<unsigned long long>());
-        side_join(c);
         prof_end(c);
     }
     return BMBS_OK;
@@ -649,16 +640,9 @@ Lane* lane_create(int device_id, const bmbs_params& prm, const Knobs& kn, bool f
     c->sp.gap_open = c->prm.gap_open; c->sp.gap_ext = c->prm.gap_ext; c->sp.q_base = c->prm.q_base;
     c->sp.seed_len = c->prm.seed_len;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
-    (void)hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking);
+    // (the copy streams are created by lane_copy_streams once every lane of the context has its kernel stream: see there)
     (void)hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming);
-    // (only when asked for: every stream of the process takes a place on one of the runtime's hardware queues, and two streams that
-    // share a queue run one behind the other -- with these streams present the two lanes of a context stopped overlapping, round 6)
-    if (c->kn.side) {
-        for (int q = 0; q < 2; q++) { (void)hipStreamCreateWithFlags(&c->side_stream[q], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&c->ev_side[q], hipEventDisableTiming); }
-        (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    }
     int lut[256];
     for (int q = 0; q < 256; q++) lut[q] = mismatch_penalty(c->prm, q);
     const size_t shard_bytes = BMBS_SHARDS * BMBS_SHARD_WORDS * 8;
@@ -686,6 +670,21 @@ Lane* lane_create(int device_id, const bmbs_params& prm, const Knobs& kn, bool f
     }
     return c;
 }
+
+// The runtime multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise),
+// each new stream taking the queue with the fewest users, and two streams on one queue run one behind the other.  With a lane's three
+// streams created together, the kernel streams of a context's two lanes ended up on ONE queue in some processes and not in others --
+// the lanes did not overlap there (round 5 took it for slow hosts; round 6: the same binary 1108 or 1248 M reads/s from one process
+// to the next, 1255 every time with GPU_MAX_HW_QUEUES=8; profiles/HISTORY.md).  So: all kernel streams first, then the upload streams,
+// then the download streams (a lane's download follows its kernels anyway: sharing a queue with them costs nothing), and bmbs_env_init
+// asks for eight queues unless the process has set the variable itself.
+void lane_copy_streams(std::vector<Lane*>& lanes)
+{
+    for (Lane* c : lanes) (void)hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
+    for (Lane* c : lanes) (void)hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking);
+}
+// runs when the library is loaded: before the HIP runtime reads its environment, if nothing in the process has touched the GPU yet
+__attribute__((constructor)) static void bmbs_env_init() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 void lane_destroy(Lane* c)
 {
@@ -725,8 +724,6 @@ void lane_destroy(Lane* c)
       for (DevBuf* b : tx) release(*b); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->ev_k) (void)hipEventDestroy(c->ev_k);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (int q = 0; q < 2; q++) { if (c->ev_side[q]) (void)hipEventDestroy(c->ev_side[q]); if (c->side_stream[q]) (void)hipStreamDestroy(c->side_stream[q]); }
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -749,6 +746,7 @@ extern "C" bmbs_ctx* bmbs_create(int device_id, const bmbs_params* params)
         if (!c) { bmbs_destroy(X); return nullptr; }
         X->lanes.push_back(c);
     }
+    lane_copy_streams(X->lanes);
     return X;
 }
 
@@ -944,11 +942,12 @@ int map_se_dev(Lane* c, uint64_t d_seq_, uint64_t d_qual_, const u16* d_len, int
     if (max_ops > BMBS_MAX_RECORD_OPS) { c->err = "these gap / mismatch penalties allow alignments with more CIGAR operations than a record holds (254)"; return BMBS_EINVAL; }
     rc = per_read_workspace(c, n);
     if (rc) return rc;
+    if (packed_hw && !use_packed_rows(c)) { c->err = "packed reads need the packed-row kernels (BMBS_LEGACY is set)"; return BMBS_EINVAL; }
+    if (packed_hw && packed_hw < pack_base_words(gm.L) + (gm.L + 63) / 64) { c->err = "packed rows: pwords is smaller than a row of this length takes"; return BMBS_EINVAL; }
     rc = call_begin(c, slot);
     if (rc) return rc;
     if (packed_hw) {
         // the ASCII rows exist only where a piece holds an 'N' (written by k_rows_from_packed into the lane's own buffer)
-        if (!use_packed_rows(c)) { c->err = "packed reads need the packed-row kernels (BMBS_LEGACY is set)"; return BMBS_EINVAL; }
         ENS(c, c->pk_ascii, n * (u64)stride + 64);
         { int rz_ = ensure(c, c->prow, n * (u64)pack_words(gm.L) * 8 + 64, true); if (rz_) return rz_; } ENS(c, c->prow_dirty, n + 64);
         HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n + 64, c->stream));
@@ -1081,6 +1080,8 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     ENS(c, c->pe_seq, n2 * (u64)stride + 64);
     ENS(c, c->pe_occ, n2 * 4); ENS(c, c->pe_len, n2 * 4); ENS(c, c->pe_cur, n2); ENS(c, c->pe_vround, n2);
     ENS(c, c->pe_dead, n); ENS(c, c->pe_both, n); ENS(c, c->pe_npair, n * 4); ENS(c, c->pe_sbd, n * 4);
+    if (packed_hw && !use_packed_rows(c)) { c->err = "packed reads need the packed-row kernels (BMBS_LEGACY is set)"; return BMBS_EINVAL; }
+    if (packed_hw && packed_hw < pack_base_words(gm.L) + (gm.L + 63) / 64) { c->err = "packed rows: pwords is smaller than a row of this length takes"; return BMBS_EINVAL; }
     rc = call_begin(c, slot);
     if (rc) return rc;
     char* seq_all = c->pe_seq.as<char>();
@@ -1090,7 +1091,6 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     bool prepacked = false;
     if (packed_hw) {
         // the caller's packed rows: mate 1 as it is, mate 2 reverse-complemented (bmbs_map_pe_packed); no ASCII rows to read at all
-        if (!use_packed_rows(c)) { c->err = "packed reads need the packed-row kernels (BMBS_LEGACY is set)"; return BMBS_EINVAL; }
         { int rz_ = ensure(c, c->prow, n2 * (u64)pack_words(gm.L) * 8 + 64, true); if (rz_) return rz_; } ENS(c, c->prow_dirty, n2 + 64);
         HIPCHK(c, hipMemsetAsync(c->prow_dirty.p, 0, n2 + 64, c->stream));
         prof_begin(c, "k_rows_from_packed");
@@ -1172,7 +1172,7 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     prof_begin(c, "k_vote_pe_long");
     // fast mode: located sites without a partner on the mate's finished list are dropped before the sort (k_pe_fast.hip; --sensitive
     // uses the lists differently, Schema.cpp:19953-21459).  BMBS_PREFILTER=0: off (A/B runs, tests)
-    const int prefilter = (!sensitive && c->kn.prefilter) ? (c->kn.side ? 2 : 1) : 0;       // 2: the block classes run side by side (side_fork)
+    const int prefilter = (!sensitive && c->kn.prefilter) ? 1 : 0;
     rc = scan_u32(c, c->long_flag.as<u32>(), n2, c->long_off.as<u64>(), 9, c->long_list.as<u32>());
     if (rc) return rc;
     ENS(c, c->big_list, n2 * 4 + 64);
@@ -1184,14 +1184,12 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
     prof_begin(c, "k_vote_pe_big");
     // the handed-over lists in two size classes: up to 1024 candidates (10 KB of LDS per block: twice the blocks per CU of the
     // 4096-key form; on the GRCh38-like genome 88 % of the handed-over lists), and the rest
-    const hipStream_t s_cls1 = side_fork(c, 0), s_cls2 = side_fork(c, 1);       // (the three classes side by side, as in run_seed_stages)
     hipLaunchKernelGGL((k_vote_pe_long<1024, 128, VM_CAP>), dim3(8192), dim3(128), 0, c->stream, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
-    hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, s_cls1, c->ix, gm, st, ps,
+    hipLaunchKernelGGL((k_vote_pe_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
-    hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, s_cls2, c->ix, gm, st, ps,
+    hipLaunchKernelGGL((k_vote_pe_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, gm, st, ps,
                        c->totals.as<u64>() + 13, c->big_list.as<u32>(), A, (u32*)nullptr, (unsigned long long*)nullptr, c->cand.as<u64>(), cnt, (long)n, pi, prefilter, c->long_flag.as<u32>());
-    side_join(c);
     prof_end(c);
     // one verification round: dense (read, list index) work list of the mates scheduled in `round`, Myers, compaction
     auto verify_round = [&](int round, u64 cap, const char* name_f, const char* name_c) -> int {
@@ -1292,12 +1290,10 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
             if (pv_flag) {
                 rc = scan_u32(c, pv_flag, rt[0], c->long_off.as<u64>(), 14, c->long_list.as<u32>(), 0, n_reseed);
                 if (rc) return rc;
-                const hipStream_t s_pv = side_fork(c, 0);
                 hipLaunchKernelGGL((k_pes_vote_long<1024, 128, PESV_LONG>), dim3(8192), dim3(128), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
                                    c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
-                hipLaunchKernelGGL((k_pes_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, s_pv, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
+                hipLaunchKernelGGL((k_pes_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
                                    c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
-                if (c->kn.side && c->side_stream[0]) { (void)hipEventRecord(c->ev_side[0], c->side_stream[0]); (void)hipStreamWaitEvent(c->stream, c->ev_side[0], 0); }
             }
             prof_end(c);
             rc = verify_round(3, rt[1], "k_filter_pe_r3", "k_pe_compact_r3");
@@ -1714,6 +1710,8 @@ extern "C" int bmbs_pack_rows(const char* seq, int32_t L_max, int32_t stride, in
             uint64_t* o = rows + (size_t)r * (size_t)pwords;
             const int Lr = len ? (int)len[r] : L_max;
             for (int q = 0; q < pwords; q++) o[q] = 0;
+            // (the rule upload_lens applies later: a length of 0 or beyond L_max would read past the row and write past its words)
+            if (Lr <= 0 || Lr > L_max) { if (bad[(size_t)t] < 0) bad[(size_t)t] = r; continue; }
             for (int j = 0; j < Lr; j++) {
                 const unsigned c = code[s[j]];
                 if (c < 4) o[j >> 5] |= (uint64_t)c << (2 * (j & 31));

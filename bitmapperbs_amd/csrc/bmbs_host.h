@@ -70,7 +70,6 @@ struct Knobs {
                                 // bmbs_map_pe_packed: 164 M reads/s on two lanes, 180 on four (tools/hostbuf_probe.py)
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
-    int side = 1;               // BMBS_SIDE: 0 the size-class instances of the list kernels run one behind the other on the lane's stream
     int prefilter = 1;          // BMBS_PREFILTER: 0 the paired-end long-list kernels sort every located site (the round-5 form; A/B runs, tests)
     int pef_long = 1;           // BMBS_PEF_LONG: 1 long lists of k_pe_filter_pairs get a wave when the input is repeat-rich, 2 always (tests)
     int kgram = 1;              // BMBS_KGRAM: 0 no trigram table, 1 (default) its kernels are used once a context has seen reads that walk the index in long chains, 2 always
@@ -97,7 +96,6 @@ struct Knobs {
         if ((e = getenv("BMBS_CAP_SCALE"))) cap_scale = atof(e);
         if ((e = getenv("BMBS_PEF_LONG"))) pef_long = atoi(e);
         if ((e = getenv("BMBS_PREFILTER"))) prefilter = atoi(e);
-        if ((e = getenv("BMBS_SIDE"))) side = atoi(e);
     }
 };
 
@@ -124,6 +122,7 @@ struct Pending {
 struct Occ3Shared {
     std::mutex mu;
     bool tried = false;
+    int skipped = 0;                    // builds put off because the device had no room for the table beside its margin
     int dev = 0;
     DevIndex base;                      // the index without the table (what the builder reads)
     u64 rows = 0;
@@ -141,10 +140,6 @@ struct Lane {
     // moved 26-30 GB/s on the MI355X boxes (ROCm 7.2), on a stream of its own 56 (tools/e2e_trace.sh)
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     hipEvent_t ev_up = nullptr, ev_k = nullptr;
-    // the size-class instances of a list kernel work on disjoint lists: they run side by side on two further streams of the lane
-    // (side_fork / side_join), so that the few blocks of the largest class do not hold the lane's stream while the chip idles
-    hipStream_t side_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_side[2] = {nullptr, nullptr};
     bmbs_params prm;
     ScoreParams sp;
     Knobs kn;

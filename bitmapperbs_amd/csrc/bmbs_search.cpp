@@ -28,7 +28,9 @@
 // lines when the names do not tell).
 #include "../../include/bmbs.h"
 #include "pgz.h"
+#if defined(__x86_64__)
 #include <emmintrin.h>
+#endif
 #include <zlib.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -151,6 +153,7 @@ private:
 inline size_t count_nl(const char* p, size_t n)
 {
     size_t c = 0, i = 0;
+#if defined(__x86_64__)
     const __m128i nl = _mm_set1_epi8('\n');
     for (; i + 64 <= n; i += 64) {
         const uint64_t a = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i)), nl));
@@ -159,7 +162,8 @@ inline size_t count_nl(const char* p, size_t n)
         const uint64_t e = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i + 48)), nl));
         c += (size_t)__builtin_popcountll(a | (b << 16) | (d << 32) | (e << 48));
     }
-    for (; i < n; i++) c += p[i] == '\n';
+#endif
+    for (; i < n; i++) c += p[i] == '\n';                 // (the whole buffer on a host without SSE2)
     return c;
 }
 // offset just behind the k-th newline (k >= 1) of p[0, n), n when there are fewer

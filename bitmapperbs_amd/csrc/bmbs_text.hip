@@ -99,7 +99,7 @@ k_fq_records(const u32* __restrict__ nl, long n, FqRec o, u32* __restrict__ info
         const u32 nml = e0 - s0;
         o.name_off[r] = s0; o.name_len[r] = (u16)(nml > 0xffffu ? 0xffffu : nml);
         o.seq_off[r] = e0 + 1u; o.qual_off[r] = e2 + 1u;
-        if (sl < 1u || sl > 998u) { bad = (u32)r + 1u; o.seq_len[r] = 1; o.qual_len[r] = 0; }
+        if (sl < 1u || sl > (u32)BMBS_MAX_READ) { bad = (u32)r + 1u; o.seq_len[r] = 1; o.qual_len[r] = 0; }
         else { o.seq_len[r] = (u16)sl; o.qual_len[r] = (u16)ql; L = sl; Lc = ~sl; }
     }
     for (int of = 32; of > 0; of >>= 1) {

@@ -298,7 +298,7 @@ int lane_text_finish(Lane* c, bool pe, u64 bytes1, u64 bytes2, int64_t n_records
     const u32* inf = c->h_info;
     for (int f = 0; f < (pe ? 2 : 1); f++)
         if (inf[4 * f + 2]) {
-            c->err = "record " + std::to_string(inf[4 * f + 2] - 1) + " of this batch has an empty or longer-than-998-character sequence line: not supported (the reference's own buffers end there)";
+            c->err = "record " + std::to_string(inf[4 * f + 2] - 1) + " of this batch has an empty or longer-than-" + std::to_string(BMBS_MAX_READ) + "-character sequence line: not supported (the reference's own buffers end there)";
             return BMBS_EINVAL;
         }
     int maxL = (int)inf[0], minL = (int)~inf[1];

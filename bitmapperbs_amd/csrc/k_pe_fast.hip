@@ -499,10 +499,8 @@ k_vote_pe_long(DevIndex ix, ReadGeom gm, ReadState st, PeState ps, const u64* __
             if (prefilter && v == 3) {
                 // (only against a mate list short enough for the LDS copy: a binary search per site through a list in memory -- both
                 // mates inside repeats -- costs more than the sort it saves; measured, round 6)
-                // (a listed mate of a smaller class: its kernel ran earlier in the stream -- the wave form always does; the block classes only
-                // when they are launched one behind the other: prefilter == 1.  prefilter == 2: they run side by side)
-                const long ncm_ = (long)st.n_cand[m];
-                const bool earlier = !listed(m) || ncm_ <= (prefilter == 2 ? (LO < VM_CAP ? LO : VM_CAP) : LO);
+                // (a listed mate of a smaller class: its kernel ran earlier in the stream -- the instances are launched one behind the other)
+                const bool earlier = !listed(m) || (long)st.n_cand[m] <= LO;
                 const bool mate_final = (turn == 1 || earlier) && ps.len[m] <= PREF_STAGE;
                 long long maxd, mind; int large_k;
                 pe_bounds(gm, pi, r < n_pairs ? r : r - n_pairs, n_pairs, maxd, mind, large_k);

@@ -679,7 +679,7 @@ k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ coun
             __syncthreads();
             continue;
         }
-        constexpr int VP_CLS = CAP == VM_CAP ? 0 : CAP == 1024 ? 1 : CAP == 2048 ? 2 : 3;
+        [[maybe_unused]] constexpr int VP_CLS = CAP == VM_CAP ? 0 : CAP == 1024 ? 1 : CAP == 2048 ? 2 : 3;
         VP_T(vp0);
         vl_locate_sort<(CAP + BLOCK - 1) / BLOCK>(ix, my, ns, (int)nc, keys, sh_pref);
         VP_T(vp1);

@@ -679,6 +679,7 @@ private:
             memcpy(tab.data() + 0x8000, w, WIN);
             const u8* T = tab.data();
             size_t i = 0;
+#if defined(__x86_64__)
             const __m128i zero = _mm_setzero_si128();
             for (; i + 16 <= n; i += 16) {
                 const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i)), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 8));
@@ -686,6 +687,7 @@ private:
                 if (_mm_movemask_epi8(_mm_cmpeq_epi8(hi, zero)) == 0xffff) _mm_storeu_si128(reinterpret_cast<__m128i*>(o + i), _mm_packus_epi16(a, b));
                 else for (size_t j = i; j < i + 16; j++) o[j] = T[s[j]];
             }
+#endif
             for (; i < n; i++) o[i] = T[s[i]];
             sym_put(k.sym);
         }

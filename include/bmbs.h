@@ -220,8 +220,8 @@ int bmbs_map_pe_var_device(bmbs_ctx*, uint64_t d_seq1, uint64_t d_qual1, uint64_
  *   row = W = ceil(L_max / 32) u64 words of bases -- base j in bits 2 (j % 32), 2 (j % 32) + 1 of word j / 32: A 0, C 1, G 2, T 3 --
  *         followed by M = ceil(L_max / 64) words of marks -- bit j % 64 of word j / 64 set: the character at j is 'N' (its base bits 0);
  *         bits at and beyond a read's length are ignored; rows `pwords` (>= W + M) words apart.  150 bases: 8 words = 64 bytes.
- * Characters other than A C G T N cannot be expressed (bmbs_pack_rows says BMBS_EINVAL and which row): such batches take the ASCII
- * calls.  BOTH mates are given in FASTQ orientation (what bmbs_map_pe takes as seq2): the device reverse-complements mate 2 on the
+ * Characters other than A C G T N cannot be expressed (bmbs_pack_rows says BMBS_EINVAL and which row; the same for a length of 0 or
+ * beyond L_max): such batches take the ASCII calls.  BOTH mates are given in FASTQ orientation (what bmbs_map_pe takes as seq2): the device reverse-complements mate 2 on the
  * packed words.  Qualities stay bytes (`stride` apart, as above); len NULL: every read has length L_max.  Results, CIGAR pool, errors:
  * exactly those of bmbs_map_se[_var] / bmbs_map_pe[_var] on the ASCII rows the packed ones stand for (tests/test_gpu_parity.py).     */
 int bmbs_pack_rows(const char* seq, int32_t L_max, int32_t stride, int64_t n, const uint16_t* len /* NULL: uniform */, uint64_t* rows, int32_t pwords,

@@ -62,9 +62,4 @@ echo $SRCS | tr ' ' '\n' | xargs -P "$JOBS" -I{} bash -c 'ref_one {}'
 g++ -o "$OUT/bitmapperBS" $(for s in $SRCS; do echo "$OUT/obj/$s.o"; done) \
     "$OUT/libhts.a" -lm -lz -lpthread -Wl,--allow-multiple-definition
 
-# ---- function-level shim over the reference headers (BPM variants, ksw, window fetch) ---------
-if [ -f "$HERE/ref_shim.cpp" ]; then
-  g++ $CXXFLAGS -fPIC -shared -iquote "$REF" -I"$REF" -I"$REF/htslib" "$HERE/ref_shim.cpp" \
-      "$OUT/obj/ksw.o" -o "$OUT/libref_kernels.so" 2>&1 | tail -5 || echo "ref_shim build failed (non-fatal)" >&2
-fi
 echo "build_ref: OK -> $OUT/bitmapperBS"
