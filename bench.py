@@ -100,6 +100,10 @@ def parse(argv=None):
             cfg[key] = v
     if a.genome is not None and a.genome < 1_000_000_000:
         cfg["n_chrom"] = 4
+    if a.grch38_like and a.launches is None and cfg["launches"] > 2:
+        # the repeat-rich genome's candidate lists take 30-38 GB of work buffers per lane at this launch size: with five launches' inputs
+        # and results resident beside the index, the trigram table and the single-lane pass's context, 288 GB do not always hold them
+        cfg["launches"] = 2
     a.cfg = cfg
     return a
 

@@ -1509,6 +1509,7 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
     const int max_ops = cigar_ops_bound(X->prm, L, threshold_k(X->prm, L));
     const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops, true);
     const int nl = (int)X->lanes.size();
+    const int used_lanes_ = ch == n ? 1 : (int)std::min<int64_t>(nl, (n + ch - 1) / ch);
     share_needs(X);
     struct Open { bool on = false; int64_t off = 0, m = 0; };
     std::vector<Open> open((size_t)nl);
@@ -1549,6 +1550,12 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             const bool cs = c->kn.copy_streams && c->up_stream && c->down_stream && c->ev_up && c->ev_k;
             hipStream_t us = cs ? c->up_stream : c->stream, dsn = cs ? c->down_stream : c->stream;
             int r1 = BMBS_OK;
+            // One upload at a time per device (the text calls' rule, bmbs_textpath.hip): four lanes that upload side by side share the
+            // link, finish together, compute together and leave the link idle meanwhile -- in turn, each chunk goes up at the full
+            // rate and its kernels run beside the next lane's upload.  The lock is held until this chunk's copies have ended; the
+            // kernels are queued behind them meanwhile.  BMBS_UP_TURNS=0: the round-5 form
+            std::unique_lock<std::mutex> up_turn(g_h2d_mu[c->dev & 15], std::defer_lock);
+            if (cs && used_lanes_ > 1 && c->kn.up_turns) up_turn.lock();
             if (in.hw) {
                 // packed rows: hw words per read go over as they are (one block per mate)
                 const u64 pb = um * (u64)in.hw * 8;
@@ -1577,6 +1584,7 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             if (r1) return r1;
             if (cs) { HIPCHK(c, hipEventRecord(c->ev_k, c->stream)); HIPCHK(c, hipStreamWaitEvent(dsn, c->ev_k, 0)); }
             HIPCHK(c, hipMemcpyAsync(results + off * rpu, c->out_res.p, um * rpu * 32, hipMemcpyDeviceToHost, dsn));
+            if (up_turn.owns_lock()) HIPCHK(c, hipEventSynchronize(c->ev_up));          // this chunk is up: the next lane's turn
             return BMBS_OK;
     };
     // One host thread per lane: a chunk is ~110 kernel launches and a handful of waits, and with all of them issued by one thread the

@@ -70,6 +70,7 @@ struct Knobs {
                                 // bmbs_map_pe_packed: 164 M reads/s on two lanes, 180 on four (tools/hostbuf_probe.py)
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
+    int up_turns = 1;           // BMBS_UP_TURNS: 0 the lanes of a host-buffer call upload side by side (the round-5 form)
     int prefilter = 1;          // BMBS_PREFILTER: 0 the paired-end long-list kernels sort every located site (the round-5 form; A/B runs, tests)
     int pef_long = 1;           // BMBS_PEF_LONG: 1 long lists of k_pe_filter_pairs get a wave when the input is repeat-rich, 2 always (tests)
     int kgram = 1;              // BMBS_KGRAM: 0 no trigram table, 1 (default) its kernels are used once a context has seen reads that walk the index in long chains, 2 always
@@ -96,6 +97,7 @@ struct Knobs {
         if ((e = getenv("BMBS_CAP_SCALE"))) cap_scale = atof(e);
         if ((e = getenv("BMBS_PEF_LONG"))) pef_long = atoi(e);
         if ((e = getenv("BMBS_PREFILTER"))) prefilter = atoi(e);
+        if ((e = getenv("BMBS_UP_TURNS"))) up_turns = atoi(e);
     }
 };
 

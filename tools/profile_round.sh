@@ -3,7 +3,7 @@
 # SAME command, then separate --pmc passes: FETCH_SIZE, WRITE_SIZE, SQ stall counters).  Output under gpurun_out/prof_<tag>/.
 set -u
 CFG=${1:-2}
-TAG=${2:-r05_c$CFG}
+TAG=${2:-r06_c$CFG}
 X=${3:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
