@@ -1432,9 +1432,16 @@ int settle_all(bmbs_ctx* X)
 // units per chunk of a call: the whole call on lane 0 when it is small (or the caller's CIGAR pool has no room for every chunk's
 // worst case), otherwise n / lanes (BMBS_CHUNK overrides) so that every lane gets one chunk per call
 // host_copies: the chunks carry their own H2D / D2H copies; smaller ones (n / 8, within 250 k .. 500 k units) leave a shorter tail behind the last upload
-int64_t chunk_units(const bmbs_ctx* X, int64_t n, int64_t cigar_cap, int rpu, int max_ops, bool host_copies = false)
+// lanes a device call is dealt to.  Measured on one box, lanes overlapping (round 6; M reads/s at 2 / 3 / 4 lanes): uniform-random genome
+// 1249 / 1211-vs-1201 / 1179 -- the seeding kernels there sit at the gather ceiling and a fourth lane only adds contention --;
+// GRCh38-like pairs 622 / 640 / 646, single-end 412 / 419 / 421, --sensitive 428 / 440 / 450 -- the list kernels wait on their own
+// chains and fill with whatever else is resident.  Three it is.  (Four on repeat-rich input, chosen from what
+// settled calls had shown, was built and taken out again: a call's chunk boundaries -- and with them the records' cigar_off -- then
+// differed between the first and the second call of a context on the same input.)
+int device_lanes(const bmbs_ctx* X) { return std::min<int>((int)X->lanes.size(), X->kn.lanes); }
+int64_t chunk_units(const bmbs_ctx* X, int64_t n, int64_t cigar_cap, int rpu, int max_ops, bool host_copies = false, int n_lanes = 0)
 {
-    const int64_t nl = host_copies ? (int64_t)X->lanes.size() : std::min<int64_t>((int64_t)X->lanes.size(), X->kn.lanes);
+    const int64_t nl = host_copies ? (int64_t)X->lanes.size() : (int64_t)(n_lanes > 0 ? n_lanes : device_lanes(X));
     if (nl < 2 || n < 2 * X->kn.split_min || cigar_cap < n * rpu * (int64_t)max_ops) return n;
     int64_t ch = X->kn.chunk > 0 ? X->kn.chunk : (n + nl - 1) / nl;
     // (a call of 2 M pairs: 126 M reads/s in chunks of 500 k, 133-138 in chunks of 250 k -- the first upload and the last chunk's
@@ -1454,8 +1461,9 @@ int dispatch_device(bmbs_ctx* X, bool pe, uint64_t a0, uint64_t a1, uint64_t a2,
     if (n == 0) return BMBS_OK;
     const int rpu = pe ? 2 : 1;
     const int max_ops = cigar_ops_bound(X->prm, L, threshold_k(X->prm, L));
-    const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops);
     share_needs(X);
+    const int n_lanes = device_lanes(X);                  // (fixed for the call: a lane that settles meanwhile may learn a new lr_long)
+    const int64_t ch = chunk_units(X, n, cigar_cap, rpu, max_ops, false, n_lanes);
     int li = 0, used = 0;
     for (int64_t off = 0; off < n; off += ch) {
         const int64_t m = std::min(ch, n - off);
@@ -1488,7 +1496,7 @@ int dispatch_device(bmbs_ctx* X, bool pe, uint64_t a0, uint64_t a1, uint64_t a2,
         const int rc = lane_enqueue(c, P, staged);
         if (rc) { X->err = c->err; return rc; }
         used = std::max(used, (ch == n ? 0 : li) + 1);
-        li = (li + 1) % std::min((int)X->lanes.size(), X->kn.lanes);
+        li = (li + 1) % n_lanes;
     }
     X->used_lanes = used;
     return BMBS_OK;

@@ -64,7 +64,7 @@ struct Knobs {
     bool rows_ascii = false;    // BMBS_LEGACY=1: seeding on the ASCII rows (no packed copy), mate 2 prepared byte-wise with its full ASCII text
     int seed_waves = 65536;     // BMBS_SEED_WAVES
     bool exact = false;         // BMBS_EXACT=1: every call waits for its stage counts (the round-2 launch sequence)
-    int lanes = 2;              // BMBS_LANES: half-batches in flight per context (each on a stream of its own)
+    int lanes = 3;              // BMBS_LANES: chunks of a device call in flight per context (each on a lane = a stream of its own)
     int host_lanes = 4;         // BMBS_HOST_LANES: lanes the host-buffer entry points deal their chunks to (>= lanes): upload, kernels and download of
                                 // a chunk follow each other on a lane, so what overlaps is what different lanes do -- 2 M pairs through
                                 // bmbs_map_pe_packed: 164 M reads/s on two lanes, 180 on four (tools/hostbuf_probe.py)
@@ -133,7 +133,7 @@ struct Occ3Shared {
 };
 
 // One lane = one stream with its own work buffers, counters and HIP-event profile: what a whole context was in round 2.  A context
-// owns BMBS_LANES of them on one attached index and deals the chunks of a call to them, so that the issue-bound kernels (DP, Myers,
+// owns BMBS_LANES (default three, device_lanes) of them on one attached index and deals the chunks of a call to them, so that the issue-bound kernels (DP, Myers,
 // row preparation) of one chunk run beside the memory-bound seeding kernels of another without a second context or host thread.
 struct Lane {
     int dev = 0;

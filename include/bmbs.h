@@ -106,9 +106,9 @@ typedef struct bmbs_result {
  * order (ksw.cpp:2785-2857 prints them forward or reversed by strand) */
 
 /* ---- launch sequence ----------------------------------------------------------------------------
- * A context owns BMBS_LANES (environment, default 2) lanes: a stream, work buffers and counters each, on one attached index.  A
+ * A context owns BMBS_LANES (environment, default 3) lanes: a stream, work buffers and counters each, on one attached index.  A
  * mapping call of 500 000 units and more is cut into one chunk per lane, so that the issue-bound kernels of one chunk (DP, Myers,
- * row preparation) run beside the memory-bound seeding kernels of the other; the host-pointer calls also overlap the copies of one
+ * row preparation) and the list kernels, which wait on their own chains, run beside the memory-bound seeding kernels of another; the host-pointer calls also overlap the copies of one
  * chunk with the kernels of another.  After the first call of a context no call waits for its stage counts: buffers and grids
  * are sized from what earlier calls needed per read (+25 %), guard kernels compare the real counts on the device, and a call that
  * did not fit is issued again with exact sizes when the context is next synchronised -- results and statistics are the same either

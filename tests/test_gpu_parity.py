@@ -282,11 +282,11 @@ def test_full_size_properties_idempotent_and_split_invariant(env):
 
 
 @pytest.mark.parametrize("mode,L,n,e", [("fast", 150, 5_000_000, 0.08), ("sensitive", 150, 5_000_000, 0.08), ("fast", 250, 1_000_000, 0.08),
-                                       ("sensitive", 250, 1_000_000, 0.08)])
+                                       ("sensitive", 250, 1_000_000, 0.08), ("fast", 150, 10_000_000, 0.08)])
 def test_full_size_properties_paired_end(env, mode, L, n, e):
-    """BASELINE configs[2] / [3] launch sizes (5 M pairs of 150 bp, fast and --sensitive) and configs[4]'s shape (250 bp pairs,
-    -e 0.08: k = 20, 64-bit Myers words, band of 41): run-to-run identical bytes, split invariance (pairs are independent units),
-    stats add up, and an oracle slice"""
+    """BASELINE configs[2] / [3] launch sizes (5 M pairs of 150 bp, fast and --sensitive; and the 10 M pairs of ONE bench.py launch,
+    which the context cuts into a chunk per lane) and configs[4]'s shape (250 bp pairs, -e 0.08: k = 20, 64-bit Myers words, band of
+    41): run-to-run identical bytes, split invariance (pairs are independent units), stats add up, and an oracle slice"""
     import torch
     from bitmapperbs_amd import gpusynth, mapper, capi
     stride = (L + 15) // 16 * 16
