@@ -1292,7 +1292,11 @@ int map_pe_dev(Lane* c, uint64_t d_seq1, uint64_t d_qual1, uint64_t d_seq2, uint
                 if (rc) return rc;
                 hipLaunchKernelGGL((k_pes_vote_long<1024, 128, PESV_LONG>), dim3(8192), dim3(128), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
                                    c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
-                hipLaunchKernelGGL((k_pes_vote_long<VL_CAP, VL_BLOCK, 1024>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
+                // (three size classes, as the vote kernels: a re-seeded mate of 1 025 .. 2 048 candidates in the 4 096-key form held 41 KB of
+                // LDS -- three lists per CU; r6)
+                hipLaunchKernelGGL((k_pes_vote_long<2048, 256, 1024>), dim3(4096), dim3(256), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
+                                   c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
+                hipLaunchKernelGGL((k_pes_vote_long<VL_CAP, VL_BLOCK, 2048>), dim3(2048), dim3(VL_BLOCK), 0, c->stream, c->ix, (long)n, gm, pi, c->totals.as<u64>() + 14,
                                    c->long_list.as<u32>(), rlist, c->pe_ritem_off.as<u64>(), st, ps, c->pe_rcand.as<u64>(), A, B);
             }
             prof_end(c);
@@ -1561,7 +1565,9 @@ int dispatch_host(bmbs_ctx* X, bool pe, const HostIn& in, int32_t L, int32_t str
             // One upload at a time per device (the text calls' rule, bmbs_textpath.hip): four lanes that upload side by side share the
             // link, finish together, compute together and leave the link idle meanwhile -- in turn, each chunk goes up at the full
             // rate and its kernels run beside the next lane's upload.  The lock is held until this chunk's copies have ended; the
-            // kernels are queued behind them meanwhile.  BMBS_UP_TURNS=0: the round-5 form
+            // kernels are queued behind them meanwhile.  BMBS_UP_TURNS=0: the round-5 form.  (ONE upload stream shared by the lanes --
+            // copies back to back with no host in between -- measured no better than side-by-side uploads: 172 against 174 / 165 M
+            // reads/s, turns 186 / 192; 2 M pairs per call, profiles/HISTORY.md)
             std::unique_lock<std::mutex> up_turn(g_h2d_mu[c->dev & 15], std::defer_lock);
             if (cs && used_lanes_ > 1 && c->kn.up_turns) up_turn.lock();
             if (in.hw) {
