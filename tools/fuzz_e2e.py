@@ -19,9 +19,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS")
 DRV = os.path.join(ROOT, "bitmapperbs_amd", "bmbs_search")
 ORC = os.path.join(ROOT, "oracle", "bmbs_oracle")
+BOUND = os.path.join(ROOT, "oracle", "_ref", "bitmapperBS_hip")        # the reference program linked around libbmbs_hip.so (oracle/build_ref_hip.sh)
 # --oracle: the second program is the oracle's command line instead of bmbs_search (no GPU needed): the same random files and options
 # pin the ORACLE to the real reference; no --bam / gzipped input there (the oracle writes SAM from plain FASTQ)
 USE_ORACLE = False
+USE_BOUND = False
 
 
 def body(path):
@@ -149,15 +151,20 @@ def run_trial(t, env, wd):
     drv_extra = ["-t", str(int(rng.choice([1, 3, 8, 16]))), "--batch", str(int(rng.choice([97, 333, 1777, 50000]))), "--contexts", str(int(rng.choice([1, 2, 3])))]
     # ... and the number of output parts (every part a pipeline of its own over its record range; `cat` of the parts is compared)
     n_parts = int(rng.choice([1, 1, 2, 3, 5]))
-    if n_parts > 1 and not USE_ORACLE:
+    if n_parts > 1 and not USE_ORACLE and not USE_BOUND:
         drv_extra += ["--out-parts", str(n_parts)]
-    for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", ORC if USE_ORACLE else DRV, [] if USE_ORACLE else drv_extra)):
+    # --bound: the second program is the reference's own main / CLI / reader / writers with its mapping loops bound to the library
+    # (oracle/bind_check.cpp); its batch size varies like the driver's
+    bound_env = dict(os.environ, BMBS_BIND_BATCH=str(int(rng.choice([97, 333, 1777, 50000]))))
+    second = (ORC, []) if USE_ORACLE else (BOUND, ["-t", "1"]) if USE_BOUND else (DRV, drv_extra)
+    for who, exe, extra in (("ref", REF, ["-t", "1"]), ("gpu", second[0], second[1])):
         out = os.path.join(wd, who + ".sam"); ms = os.path.join(wd, who + ".ms")
         for f in (out, ms):
             if os.path.exists(f):
                 os.unlink(f)
         head = [exe, "search", env["fa"]] if exe == ORC else [exe, "--search", env["fa"]]
-        p = subprocess.run(head + inp + t["opt"] + ["-o", out, "--mapstats", ms] + extra, capture_output=True, text=True, cwd=wd)
+        p = subprocess.run(head + inp + t["opt"] + ["-o", out, "--mapstats", ms] + extra, capture_output=True, text=True, cwd=wd,
+                           env=bound_env if (who == "gpu" and USE_BOUND) else None)
         if p.returncode:
             return ["%s exit code %d: %s" % (who, p.returncode, p.stderr[-300:])], 0
         if who == "gpu" and "--out-parts" in extra:
@@ -207,13 +214,17 @@ def main():
     ap.add_argument("--trials", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--oracle", action="store_true", help="compare the ORACLE's command line (CPU) with the reference instead of bmbs_search")
+    ap.add_argument("--bound", action="store_true", help="compare oracle/_ref/bitmapperBS_hip (the reference program bound to the library: INTEGRATION.md) with the reference instead of bmbs_search")
     ap.add_argument("--big", action="store_true", help="the repeat-rich 5 Mb genome of the BIG golden family instead of the 1.5 Mb one")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_e2e.json"))
     ap.add_argument("--only", type=int, default=-1, help="run this one trial of the sequence (the draws before it are made and dropped)")
     ap.add_argument("--keep", default="", help="directory that receives the output files of a trial that fails or raises")
     a = ap.parse_args()
-    global USE_ORACLE
+    global USE_ORACLE, USE_BOUND
     USE_ORACLE = a.oracle
+    USE_BOUND = a.bound
+    if USE_BOUND and not os.path.exists(BOUND):
+        sys.exit("oracle/_ref/bitmapperBS_hip is not here (oracle/build_ref_hip.sh builds it where /root/reference exists)")
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/bitmapperBS is not here (oracle/build_ref.sh builds it where /root/reference exists)")
     rng = np.random.default_rng(a.seed)
