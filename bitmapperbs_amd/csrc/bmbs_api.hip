@@ -65,14 +65,29 @@ void prof_collect(Lane* c, int slot)
 }
 
 // exclusive scan u32[n] -> u64[n+1], total left in c->totals[slot]; n_dev: a device-side count that bounds n (see k_scan_partial)
+// Two launches (tile sums, offsets) by default; BMBS_SCAN_CHAIN=1: one (k_scan_chain).
 int scan_u32(Lane* c, const u32* in, u64 n, u64* out, int slot, u32* list, int nz, const u64* n_dev)
 {
     const u64 per = (u64)SCAN_BLOCK * SCAN_ITEMS;
     const u64 nb = n ? (n + per - 1) / per : 1;
-    ENS(c, c->scan_tmp, (nb + 1) * 8);
-    u64* bs = c->scan_tmp.as<u64>();
-    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, nz, n_dev);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list, nz, n_dev, c->totals.as<u64>() + slot);
+    if (!c->kn.scan_chain) {
+        ENS(c, c->scan_tmp, (nb + 1) * 8);
+        u64* bs = c->scan_tmp.as<u64>();
+        hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, nz, n_dev);
+        hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, n, bs, out, list, nz, n_dev, c->totals.as<u64>() + slot);
+        return BMBS_OK;
+    }
+    // status words: zeroed when the buffer is (re)allocated and when the epoch wraps, so no word of an earlier scan carries this scan's epoch
+    const u64 nt = (nb + SCAN_SUB - 1) / SCAN_SUB;                  // a ticket per SCAN_SUB tiles
+    { int rc = ensure(c, c->scan_tmp, (nb + 1) * 8, true); if (rc) return rc; }
+    { int rc = ensure(c, c->scan_ticket, 64, true); if (rc) return rc; }
+    if (++c->scan_epoch >= SCAN_EPOCH_MAX) {
+        if (hipMemsetAsync(c->scan_tmp.p, 0, c->scan_tmp.cap, c->stream) != hipSuccess) { c->err = "hipMemsetAsync failed"; return BMBS_ESTATE; }
+        c->scan_epoch = 1;
+    }
+    hipLaunchKernelGGL(k_scan_chain, dim3((unsigned)nt), dim3(SCAN_BLOCK), 0, c->stream, in, n, out, list, nz, n_dev, c->totals.as<u64>() + slot,
+                       c->scan_ticket.as<unsigned int>(), c->scan_ticket_base, c->scan_tmp.as<u64>(), c->scan_epoch);
+    c->scan_ticket_base += (u32)nt;
     return BMBS_OK;
 }
 
@@ -706,7 +721,7 @@ void lane_destroy(Lane* c)
     DevBuf* all[] = {&c->occ, &c->hash, &c->sa, &c->gen2, &c->gen2p, &c->chrom_start, &c->t20, &c->pen_lut, &c->mapq_lut, &c->verdict,
                      &c->n_seeds, &c->multi, &c->mm_site, &c->exit_site, &c->seeds, &c->n_cand, &c->cand_off,
                      &c->n_votes, &c->best_site, &c->best_end, &c->best_err, &c->sbd, &c->red_status, &c->job_flag,
-                     &c->job_off, &c->scan_tmp, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
+                     &c->job_off, &c->scan_tmp, &c->scan_ticket, &c->totals, &c->cand, &c->votes, &c->slot_read, &c->vote_off, &c->votes_dense, &c->dense_read, &c->ferr, &c->fend,
                      &c->job_read, &c->job_site, &c->job_end, &c->job_err, &c->need_sw, &c->sw_off, &c->sw_job, &c->trace, &c->a_start, &c->a_end, &c->a_nm, &c->a_score, &c->a_nops,
                      &c->in_seq, &c->in_qual, &c->out_res, &c->cig_pool, &c->in_a, &c->in_b, &c->in_c, &c->in_d,
                      &c->stats, &c->call_stats, &c->flags, &c->counters, &c->pe_seq, &c->pe_B, &c->pe_occ, &c->pe_len, &c->pe_cur,

@@ -71,6 +71,9 @@ struct Knobs {
     long chunk = 0;             // BMBS_CHUNK: units per chunk of a split call (0: n / lanes, at least BMBS_SPLIT_MIN)
     long split_min = 250000;    // BMBS_SPLIT_MIN: calls with fewer units than twice this run on one lane
     int up_turns = 1;           // BMBS_UP_TURNS: 0 the lanes of a host-buffer call upload side by side (the round-5 form)
+    int scan_chain = 0;         // BMBS_SCAN_CHAIN: 1 every scan is ONE launch (k_scan_chain, a chained scan with look-back) instead of two: eight launches fewer per
+                                // paired-end chunk, 0.5-1 % fewer reads/s (tools/scan_kbench.hip: 52 against 45 us at 10 M entries) -- the lanes are bound by
+                                // GPU time, not by launches, so the two-launch form stays the default
     int prefilter = 1;          // BMBS_PREFILTER: 0 the paired-end long-list kernels sort every located site (the round-5 form; A/B runs, tests)
     int pef_long = 1;           // BMBS_PEF_LONG: 1 long lists of k_pe_filter_pairs get a wave when the input is repeat-rich, 2 always (tests)
     int kgram = 1;              // BMBS_KGRAM: 0 no trigram table, 1 (default) its kernels are used once a context has seen reads that walk the index in long chains, 2 always
@@ -98,6 +101,7 @@ struct Knobs {
         if ((e = getenv("BMBS_PEF_LONG"))) pef_long = atoi(e);
         if ((e = getenv("BMBS_PREFILTER"))) prefilter = atoi(e);
         if ((e = getenv("BMBS_UP_TURNS"))) up_turns = atoi(e);
+        if ((e = getenv("BMBS_SCAN_CHAIN"))) scan_chain = atoi(e);
     }
 };
 
@@ -161,6 +165,10 @@ struct Lane {
     // per-read workspace
     DevBuf verdict, n_seeds, multi, mm_site, exit_site, seeds, n_cand, cand_off, n_votes, best_site,
         best_end, best_err, sbd, red_status, job_flag, job_off, scan_tmp, totals;
+    // chained scan (k_scan_chain): scan_tmp holds the tiles' status words, scan_ticket the tile ticket; the host counts the tickets
+    // the launches so far took and the scans so far (the epoch the status words carry)
+    DevBuf scan_ticket;
+    u32 scan_ticket_base = 0, scan_epoch = 0;
     // per-candidate / per-job workspace
     DevBuf vote_list;
     DevBuf cand, votes, slot_read, vote_off, votes_dense, dense_read, ferr, fend, job_read, job_site, job_end, job_err, need_sw, sw_off, sw_job, trace,

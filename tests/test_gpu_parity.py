@@ -808,7 +808,7 @@ def test_without_the_20mer_table_matches_oracle(env, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["se", "pe", "pe_sensitive"])
 @pytest.mark.parametrize("knob", ["BMBS_LEGACY=1", "BMBS_SW=wave", "BMBS_SW=reg", "BMBS_KGRAM=2", "BMBS_KGRAM=0", "BMBS_T20=0", "BMBS_TDEPTH=21", "BMBS_WIDE=1",
-                                  "BMBS_LANES=1", "BMBS_EXACT=1", "BMBS_SEED_WAVES=4096"])
+                                  "BMBS_LANES=1", "BMBS_EXACT=1", "BMBS_SEED_WAVES=4096", "BMBS_SCAN_CHAIN=1"])
 def test_ab_switches_give_identical_records(knob, mode, env, monkeypatch):
     """every documented switch (bmbs_api.hip: struct Knobs) maps exactly like the default forms: single-end,
     paired-end and --sensitive, reads with letters outside ACGT, lengths that are not a multiple of 16"""
