@@ -40,6 +40,13 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
     int err = 0;
     u32 acc = 0;
     const int last_high = 2 * k;
+    // every active lane of the wave reads the same packed row (one read's candidates fill the wave)
+    [[maybe_unused]] bool uniform = false;
+    if constexpr (PACKED && !WIDE) {
+        const u64 pa = (u64)prow;
+        const u32 p0 = __builtin_amdgcn_readfirstlane((u32)pa), p1 = __builtin_amdgcn_readfirstlane((u32)(pa >> 32));
+        uniform = __all((u32)pa == p0 && (u32)(pa >> 32) == p1) != 0;
+    }
     // One read character (row i of the matrix) as its 2-bit code (A0 C1 G2 T3): c0 / c1 = the code's bits spread over the word;
     // lo / hi = the two planes of the window bases i .. i + 2k.  A window base matches when both of its plane bits equal the
     // code's; a read T also matches a window C (plane 0 alone).  The row is 16 VALU instructions for W = u32 (two funnel shifts,
@@ -83,6 +90,23 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
             const W VN2 = ((W)VN2h << 32) | VN2l, VP2 = ((W)VP2h << 32) | VP2l;
             if (decltype(checked)::value) { if (i < L) { VN = VN2; VP = VP2; err += 1 - (int)(D0l & 1u); } }
             else { VN = VN2; VP = VP2; acc = __builtin_amdgcn_alignbit(D0l, acc, 1); }
+        }
+    };
+    // The same row when every lane of the wave verifies a candidate of ONE read (the dense list keeps a read's candidates together, and
+    // on a repeat-rich genome most candidates belong to reads with hundreds of them): the character is a scalar, the wave branches
+    // on it, and the row's match vector is ONE funnel shift of the window's match plane for that letter (made once per 32 rows from
+    // the held planes: A = ~lo & ~hi, C = lo & ~hi, G = ~lo & hi; a read T matches window C and T: plane 0 alone) -- 11
+    // instructions instead of 16, in a kernel that runs at the VALU's issue rate.
+    auto row_eq = [&](u32 eq) {
+        if constexpr (!WIDE) {
+            constexpr u32 A = 0xF0u, B = 0xCCu, C = 0xAAu;
+            u32 X = __builtin_amdgcn_bitop3_b32(eq, bmask, VN, ((A & B) | C) & 0xffu);
+            const u32 D0 = __builtin_amdgcn_bitop3_b32(VP + (X & VP), VP, X, ((A ^ B) | C) & 0xffu);
+            const u32 HN = VP & D0;
+            const u32 HP = __builtin_amdgcn_bitop3_b32(VN, VP, D0, (A | ~(B | C)) & 0xffu);
+            X = D0 >> 1;
+            VN = X & HP; VP = __builtin_amdgcn_bitop3_b32(HN, X, HP, (A | ~(B | C)) & 0xffu);
+            acc = __builtin_amdgcn_alignbit(D0, acc, 1);
         }
     };
     // the 16 characters of rows ib .. ib + 15 as codes (c16) and not-ACGT marks (m16); i0 = ib & ~31
@@ -144,12 +168,38 @@ DEVI void bpm_planes(const DevIndex& ix, const char* rd, int L, int k, u64 site,
 #pragma unroll
             for (int j = 0; j < BPM_HELD; j++) { lo[j] = __builtin_amdgcn_alignbit(pl[j + 1], pl[j], s); hi[j] = __builtin_amdgcn_alignbit(ph[j + 1], ph[j], s); }
             for (int i0 = 0; i0 < L; i0 += 32) {
+                [[maybe_unused]] u32 m0[4], m1[4];          // the match planes of the four letters over the held pair of words
+                if constexpr (PACKED) if (uniform) {
+                    constexpr u32 A = 0xF0u, B = 0xCCu;
+                    m0[0] = __builtin_amdgcn_bitop3_b32(lo[0], hi[0], 0u, (~A & ~B) & 0xffu); m1[0] = __builtin_amdgcn_bitop3_b32(lo[1], hi[1], 0u, (~A & ~B) & 0xffu);
+                    m0[1] = __builtin_amdgcn_bitop3_b32(lo[0], hi[0], 0u, (A & ~B) & 0xffu);  m1[1] = __builtin_amdgcn_bitop3_b32(lo[1], hi[1], 0u, (A & ~B) & 0xffu);
+                    m0[2] = __builtin_amdgcn_bitop3_b32(lo[0], hi[0], 0u, (~A & B) & 0xffu);  m1[2] = __builtin_amdgcn_bitop3_b32(lo[1], hi[1], 0u, (~A & B) & 0xffu);
+                    m0[3] = lo[0]; m1[3] = lo[1];
+                }
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     const int ib = i0 + 16 * half;
                     if (ib >= L) break;
                     u32 c16, m16;
                     codes(i0, half, c16, m16);
+                    if constexpr (PACKED) if (uniform && __all(m16 == 0 && ib + 16 <= L)) {
+                        const u32 cs = __builtin_amdgcn_readfirstlane(c16);
+#pragma unroll
+                        for (int c = 0; c < 16; c++) {
+                            const u32 sh = (u32)(16 * half + c);
+                            u32 eq;
+                            switch ((cs >> (2 * c)) & 3u) {                       // a scalar: the wave branches
+                                case 0: eq = __builtin_amdgcn_alignbit(m1[0], m0[0], sh); break;
+                                case 1: eq = __builtin_amdgcn_alignbit(m1[1], m0[1], sh); break;
+                                case 2: eq = __builtin_amdgcn_alignbit(m1[2], m0[2], sh); break;
+                                default: eq = __builtin_amdgcn_alignbit(m1[3], m0[3], sh); break;
+                            }
+                            row_eq(eq);
+                        }
+                        err += 16 - __popc(acc >> 16);
+                        if (__all(err - last_high > k)) return;
+                        continue;
+                    }
                     if (rows16(ib, half, c16, m16, [&](int sh, u32& a, u32& b) { a = __builtin_amdgcn_alignbit(lo[1], lo[0], (u32)sh); b = __builtin_amdgcn_alignbit(hi[1], hi[0], (u32)sh); })) return;
                 }
 #pragma unroll

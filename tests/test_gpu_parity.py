@@ -154,6 +154,44 @@ def test_filter_stage_matches_oracle_incl_invalid_sites(env, L, e, packed):
     m.close()
 
 
+@pytest.mark.parametrize("L,e", [(150, 0.08), (100, 0.08), (165, 0.08), (40, 0.15), (180, 0.08)])
+def test_filter_stage_runs_of_one_read_fill_whole_waves(env, L, e):
+    """The rows of bpm_planes<u32, true> when every lane of a wave verifies a candidate of the SAME read (the dense list of a
+    repeat-rich input: hundreds of candidates per read): the character is a scalar there and the row's match vector one funnel shift of
+    a per-letter match plane.  Runs of 1 ... 300 candidates per read laid end to end, so that waves lie wholly inside a run, across
+    two runs, and at the ragged end; reads with N (those waves take the checked rows), sites near, at and far from the truth,
+    180 bases: the streamed window, which has no such rows."""
+    from bitmapperbs_amd import synth, mapper
+    r = synth.make_reads_se(env["chroms"], n=400, L=L, seed=77, sub=0.03, indel=0.004, qual="const", n_rate=0.0)
+    r["seq"][3, L // 2] = ord("N"); r["seq"][4, :] = ord("N"); r["seq"][9, L - 1] = ord("N")
+    m = mapper.Mapper(env["ix"], 0, e_f=e)
+    k = m.threshold(L)
+    G = env["ix"].ref_len
+    c, p, minus = r["truth"]
+    offs = np.concatenate([[0], np.cumsum([ch.size for ch in env["chroms"]])])[:-1]
+    true_site = np.where(minus, 2 * G - (offs[c] + p + L + 8) + 8, offs[c] + p).astype(np.int64) - k
+    rng = np.random.default_rng(11)
+    read_of, site = [], []
+    for i in range(60):
+        run = [64, 128, 300, 63, 65, 1, 200, 130, 64, 257][i % 10]
+        other = true_site[rng.integers(0, 400, run)]                  # somebody else's site: a repeat copy that does not match
+        d = rng.integers(-k, k + 1, run)
+        near = rng.random(run) < 0.5
+        st = np.where(near, true_site[i] + d, other + d)
+        st[rng.random(run) < 0.02] = 2 * G + 7                        # a wild site inside the run
+        read_of += [i] * run; site += [np.uint64(max(0, int(x))) for x in st]
+    read_of = np.array(read_of, dtype=np.uint32); site = np.array(site, dtype=np.uint64)
+    err, end = m.filter(r["seq"], L, read_of, site, packed=True)
+    err_a, end_a = m.filter(r["seq"], L, read_of, site, packed=False)
+    assert (err == err_a).all() and (end == end_a).all()
+    for j in range(read_of.size):
+        w = env["oix"].window(int(site[j]), L + 2 * k)
+        oe, oend = orc.bpm(w, r["seq"][read_of[j]], k)
+        assert (int(err[j]), int(end[j])) == (oe, oend), (j, int(read_of[j]), int(site[j]))
+    assert (err != 0xFFFFFFFF).sum() > 1500
+    m.close()
+
+
 @pytest.mark.parametrize("form,L,e", [("reg2", 150, 0.08), ("reg", 150, 0.08), ("wave", 150, 0.08),          # k = 12: 32 lanes per alignment
                                       ("reg2", 150, 0.04), ("wave", 150, 0.04), ("reg", 150, 0.04),          # k = 6: 16 lanes
                                       ("reg2", 250, 0.08), ("wave", 250, 0.08), ("reg", 250, 0.08),          # k = 20: a whole wave
