@@ -589,9 +589,11 @@ __device__ unsigned long long g_vote_prof[4][8];
 #endif
 // (amdgpu_waves_per_eu(5): 96 registers instead of 114-128 -- one more wave per SIMD, which the 15 KB of LDS of the 1024-key class
 // allow: the kernel issues 0.2 instructions per cycle and SIMD at four waves, every wave waiting on its own chain of LDS round
-// trips and barriers; tools/vote_kbench.hip: 3.06 -> 2.66 ms per 60 000 lists of 660)
+// trips and barriers; tools/vote_kbench.hip: 3.06 -> 2.66 ms per 60 000 lists of 660.  The wave form (4 KB of LDS) takes seven: 72
+// registers; 400 000 lists of 60 / 120 on the library's 32 768 waves: 1.83 / 2.92 ms at five, 1.68 / 2.67 at six, 1.58 / 2.47 at
+// seven, 1.64 / 2.45 at eight)
 template <int CAP, int BLOCK, int LO>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5)))
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CAP == 256 ? 7 : 5)))
 k_vote_long(DevIndex ix, ReadGeom gm, ReadState st, const u64* __restrict__ count_ptr, const u32* __restrict__ list,
             u64* __restrict__ cand, bmbs_vote* __restrict__ votes, u32* __restrict__ slot_read, u32* __restrict__ big_list,
             unsigned long long* __restrict__ big_count, unsigned long long* __restrict__ counters)

@@ -3,7 +3,7 @@
 // random suffix array, the kernel timed with HIP events, the first lists checked against the same steps on the host (std::sort).
 // build (here):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/vote_kbench tools/vote_kbench.hip
 //                (-DKVOTE_FILE='"../tools/_ab/k_vote_r05.hip"' -DVB_OLD: the round-5 kernel, for same-box comparisons)
-// run (GPU box): ./tools/vote_kbench [lists=60000] [mean candidates=660] [log2 of the suffix-array rows=26]
+// run (GPU box): ./tools/vote_kbench [lists=60000] [mean candidates=660] [log2 of the suffix-array rows=26] [blocks=8192]
 //                (-DVB_CAP=2048 -DVB_LO=1024 -DVB_BLOCK=256: the next size class)
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -43,6 +43,7 @@ int main(int argc, char** argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 60000;
     const int mean = argc > 2 ? atoi(argv[2]) : 660;
+    const unsigned grid = argc > 4 ? (unsigned)atoi(argv[4]) : 8192u;          // the library launches 32768 waves of the wave form, 8192 / 4096 / 2048 blocks of the others
     CK(hipSetDevice(0));
     unsigned long long s = 0x9e3779b97f4a7c15ull;
     auto rnd = [&] { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
@@ -97,9 +98,9 @@ int main(int argc, char** argv)
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     auto launch = [&] {
 #ifdef VB_OLD
-        hipLaunchKernelGGL((k_vote_long<VB_CAP, VB_BLOCK, VB_LO>), dim3(8192), dim3(VB_BLOCK), 0, 0, ix, gm, st, d_count, d_list, d_cand, d_votes, d_slot, (u32*)nullptr, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((k_vote_long<VB_CAP, VB_BLOCK, VB_LO>), dim3(grid), dim3(VB_BLOCK), 0, 0, ix, gm, st, d_count, d_list, d_cand, d_votes, d_slot, (u32*)nullptr, (unsigned long long*)nullptr);
 #else
-        hipLaunchKernelGGL((k_vote_long<VB_CAP, VB_BLOCK, VB_LO>), dim3(8192), dim3(VB_BLOCK), 0, 0, ix, gm, st, d_count, d_list, d_cand, d_votes, d_slot, (u32*)nullptr, (unsigned long long*)nullptr, d_cnt);
+        hipLaunchKernelGGL((k_vote_long<VB_CAP, VB_BLOCK, VB_LO>), dim3(grid), dim3(VB_BLOCK), 0, 0, ix, gm, st, d_count, d_list, d_cand, d_votes, d_slot, (u32*)nullptr, (unsigned long long*)nullptr, d_cnt);
 #endif
     };
     launch(); CK(hipDeviceSynchronize());
