@@ -869,11 +869,13 @@ def host_buffer_rate(m, job, torch, jobs_per_read=0.0, packed=False):
             raise RuntimeError(lib.bmbs_last_error(m._ctx).decode())
     call()
     first = np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint8)), shape=(nrec * 32,)).copy()
-    t = time.perf_counter()
-    reps = 3
+    reps = 7                        # (r6: each call timed, the MEDIAN call reported with the spread beside it: a 45 ms call now and then
+    per_call = []                   # loses a fifth of its rate to a host thread scheduled late, and a mean of three moved by 10 % with it)
     for _ in range(reps):
+        t = time.perf_counter()
         call()
-    dt = time.perf_counter() - t
+        per_call.append(time.perf_counter() - t)
+    dt = float(np.median(per_call)) * reps
     again = np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint8)), shape=(nrec * 32,))
     same = bool((first == again).all())
     for p_ in pin + [res, pool]:
@@ -886,7 +888,8 @@ def host_buffer_rate(m, job, torch, jobs_per_read=0.0, packed=False):
     out = {"what": "bmbs_map_%s%s on page-locked HOST buffers, %d %s per call: the call is cut into chunks of n/8 (250 k .. 500 k) units dealt to the context's lanes, "
                    "uploads, kernels and downloads of different chunks overlap (copies on streams that carry no kernel); PCIe-inclusive, never `value`" % (
                 "pe" if pe else "se", "_packed" if packed else "", n, "pairs" if pe else "reads"),
-           "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s",
+           "value": round(nrec * reps / dt / 1e6, 2), "unit": "Mreads/s", "statistic": "median of %d calls" % reps,
+           "calls_Mreads_s": [round(nrec / x / 1e6, 1) for x in per_call],
            "bytes_up_per_read": round(up / (nrec * reps), 1), "bytes_down_per_read": round(down / (nrec * reps), 1),
            "host_cigar_pool_extent_per_read": round(int(used.value) * 4 / nrec, 1),
            "upload_GBps": round(up / dt / 1e9, 1), "download_GBps": round(down / dt / 1e9, 1), "link_GBps_one_direction": LINK,
@@ -1284,6 +1287,7 @@ def main():
                     # SURVEY 8(d) defines the metric "incl. H2D/D2H": the same mapping with inputs and results in HOST memory -- through the
                     # packed entry point (2 bits per base over the link), and through the ASCII one beside it
                     out["value_incl_pcie"] = {"value": hp["value"], "unit": "Mreads/s", "frac_of_link": hp["frac_of_link"],
+                                              "statistic": hp["statistic"], "calls_Mreads_s": hp["calls_Mreads_s"],
                                               "bytes_up_per_read": hp["bytes_up_per_read"], "bytes_down_per_read": hp["bytes_down_per_read"],
                                               "entry": "bmbs_map_pe_packed" if pe else "bmbs_map_se_packed",
                                               "ascii_rows": {"value": hb["value"], "frac_of_link": hb["frac_of_link"], "bytes_up_per_read": hb["bytes_up_per_read"],
