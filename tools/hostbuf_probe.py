@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/hostbuf_probe.py [pairs=2000000] [packed=1] [reps=4] -- on the GPU box: bmbs_map_pe / bmbs_map_pe_packed on page-locked host buffers
+"""tools/hostbuf_probe.py [pairs=2000000] [packed=1] [reps=4] (PROBE_GAP_MS=<ms of idle time between calls>) -- on the GPU box: bmbs_map_pe / bmbs_map_pe_packed on page-locked host buffers
 (20 Mb genome, 150 bp pairs), the rate per call; run it under `rocprofv3 --kernel-trace --memory-copy-trace` and tools/timeline_summary.py
 shows how uploads, kernels and downloads of a call's chunks overlapped."""
 import ctypes as C
@@ -55,7 +55,10 @@ def main():
             rc = lib.bmbs_map_pe(m._ctx, pin[0], pin[1], pin[2], pin[3], L, stride, n, res, pool, cap, C.byref(used))
         assert rc == 0, lib.bmbs_last_error(m._ctx)
     call()
+    gap = float(os.environ.get("PROBE_GAP_MS", "0")) / 1e3        # idle time between calls (is a call right behind another one slower?)
     for r in range(reps):
+        if gap:
+            time.sleep(gap)
         t = time.perf_counter(); call(); dt = time.perf_counter() - t
         up = (n * pw * 8 + n * stride) * 2 if packed else n * stride * 4
         print("%s: %d pairs in %.2f ms = %.1f M reads/s, upload %.1f GB/s" % ("packed" if packed else "ascii", n, dt * 1e3, 2 * n / dt / 1e6, up / dt / 1e9), flush=True)
